@@ -1,0 +1,199 @@
+/*
+ * oracle/orc_main.c -- CPU ORACLE command line (test infrastructure / cpu_baseline leg only).
+ *
+ *   orc_bwa index <ref.fa>
+ *   orc_bwa mem [-t INT] [-p] [-R STR] [-I mean[,std[,max[,min]]]] [-C] <ref.fa> <in1.fq> [in2.fq]
+ *   orc_bwa samblaster [--excludeDups] [--addMateTags] [--maxSplitCount N] [--minNonOverlap N]
+ *                      [--splitterFile F] [--discordantFile F]
+ *
+ * Restates the upstream `bwa` / `samblaster` command lines the reference issues at
+ * /root/reference/bin/speedseq:389,438-439 (main_mem in upstream fastmap.c: batches of
+ * chunk_size*n_threads bases with an even read count; FASTQ parsing with the semantics of
+ * /root/reference/src/samtools-1.3.1/htslib-1.3.1/htslib/kseq.h:189-229).
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <zlib.h>
+#include <sys/time.h>
+#include "orc.h"
+
+static double now(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+
+typedef struct { gzFile fp; char *buf; size_t cap; int have; } fq_t;
+static int fq_getline(fq_t *f)
+{	/* returns length or -1 at EOF; strips \n and \r */
+	size_t l = 0;
+	for (;;) {
+		if (f->cap < l + 4096) { f->cap = (l + 4096) * 2; f->buf = realloc(f->buf, f->cap); }
+		if (!gzgets(f->fp, f->buf + l, (int)(f->cap - l))) { if (l == 0) return -1; break; }
+		l += strlen(f->buf + l);
+		if (l && f->buf[l-1] == '\n') break;
+	}
+	while (l && (f->buf[l-1] == '\n' || f->buf[l-1] == '\r')) f->buf[--l] = 0;
+	return (int)l;
+}
+static uint8_t nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+
+static int fq_read1(fq_t *f, orc_read_t *r, int keep_comment)
+{	/* one 4-line FASTQ (or 2-line FASTA) record */
+	int l;
+	do { l = fq_getline(f); if (l < 0) return -1; } while (l == 0);
+	if (f->buf[0] != '@' && f->buf[0] != '>') return -2;
+	int is_fq = f->buf[0] == '@';
+	char *p = f->buf + 1, *e = p; while (*e && !isspace((unsigned char)*e)) ++e;
+	r->name = strndup(p, e - p);
+	while (*e && isspace((unsigned char)*e)) ++e;
+	r->comment = (keep_comment && *e) ? strdup(e) : 0;
+	{	/* upstream trim_readno: strip a trailing /1 or /2 */
+		size_t nl = strlen(r->name);
+		if (nl > 2 && r->name[nl-2] == '/' && isdigit((unsigned char)r->name[nl-1])) r->name[nl-2] = 0;
+	}
+	l = fq_getline(f); if (l < 0) return -2;
+	r->l_seq = l; r->seq = malloc(l + 1);
+	for (int i = 0; i < l; ++i) r->seq[i] = nt4(f->buf[i]);
+	r->qual = 0;
+	if (is_fq) {
+		l = fq_getline(f); if (l < 0 || f->buf[0] != '+') return -2;
+		l = fq_getline(f); if (l != r->l_seq) return -2;
+		r->qual = strdup(f->buf);
+	}
+	r->sam = 0;
+	return 0;
+}
+
+static char *unescape_rg(const char *s)
+{	/* upstream bwa_set_rg/bwa_escape: "\t" -> TAB */
+	char *o = malloc(strlen(s) + 1), *q = o;
+	for (const char *p = s; *p; ++p) {
+		if (*p == '\\' && p[1] == 't') { *q++ = '\t'; ++p; }
+		else if (*p == '\\' && p[1] == 'n') { *q++ = '\n'; ++p; }
+		else if (*p == '\\' && p[1] == '\\') { *q++ = '\\'; ++p; }
+		else *q++ = *p;
+	}
+	*q = 0;
+	return o;
+}
+
+static int main_index(int argc, char **argv)
+{
+	if (argc < 2) { fprintf(stderr, "usage: orc_bwa index <ref.fa>\n"); return 1; }
+	orc_idx_t *idx = orc_idx_build_fasta(argv[argc-1]);
+	if (!idx) { fprintf(stderr, "[orc_bwa] cannot read %s\n", argv[argc-1]); return 1; }
+	int rc = orc_idx_save(idx, argv[argc-1]);
+	orc_idx_destroy(idx);
+	return rc ? 1 : 0;
+}
+
+static int main_mem(int argc, char **argv)
+{
+	orc_opt_t opt; orc_opt_init(&opt);
+	int interleaved = 0, keep_comment = 0, i; char *rg = 0, rg_id[256] = ""; orc_pestat_t pes0[4], *pes = 0;
+	int ai = 1;
+	for (; ai < argc && argv[ai][0] == '-' && argv[ai][1]; ++ai) {
+		char *a = argv[ai];
+		if (!strcmp(a, "-p")) interleaved = 1;
+		else if (!strcmp(a, "-C")) keep_comment = 1;
+		else if (!strcmp(a, "-M")) ; /* not used by speedseq */
+		else if (!strcmp(a, "-t") && ai + 1 < argc) opt.n_threads = atoi(argv[++ai]);
+		else if (!strcmp(a, "-R") && ai + 1 < argc) rg = unescape_rg(argv[++ai]);
+		else if (!strcmp(a, "-I") && ai + 1 < argc) { /* upstream main_mem -I: FR only */
+			char *p; pes = pes0; memset(pes0, 0, sizeof(pes0));
+			pes0[0].failed = pes0[2].failed = pes0[3].failed = 1;
+			pes0[1].avg = strtod(argv[++ai], &p);
+			pes0[1].std = pes0[1].avg * .1;
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].std = strtod(p + 1, &p);
+			pes0[1].high = (int)(pes0[1].avg + 4. * pes0[1].std + .499);
+			pes0[1].low  = (int)(pes0[1].avg - 4. * pes0[1].std + .499);
+			if (pes0[1].low < 1) pes0[1].low = 1;
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].high = (int)(strtod(p + 1, &p) + .499);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].low  = (int)(strtod(p + 1, &p) + .499);
+		} else { fprintf(stderr, "[orc_bwa] unsupported option %s\n", a); return 1; }
+	}
+	if (argc - ai < 2) { fprintf(stderr, "usage: orc_bwa mem [opts] <ref> <fq1> [fq2]\n"); return 1; }
+	if (rg) {
+		if (strncmp(rg, "@RG", 3) != 0) { fprintf(stderr, "[E::bwa_set_rg] the read group line is not started with @RG\n"); return 1; }
+		char *p = strstr(rg, "\tID:");
+		if (!p) { fprintf(stderr, "[E::bwa_set_rg] no ID at the read group line\n"); return 1; }
+		p += 4; for (i = 0; p[i] && p[i] != '\t' && p[i] != '\n' && i < 255; ++i) rg_id[i] = p[i];
+		rg_id[i] = 0;
+	}
+	double t0 = now();
+	orc_idx_t *idx = orc_idx_load(argv[ai]);
+	if (!idx) { fprintf(stderr, "[orc_bwa] fail to load index %s\n", argv[ai]); return 1; }
+	fq_t f1 = { gzopen(argv[ai+1], "r"), 0, 0, 0 }, f2 = { 0, 0, 0, 0 };
+	if (!f1.fp) { fprintf(stderr, "[orc_bwa] fail to open %s\n", argv[ai+1]); return 1; }
+	if (argc - ai >= 3) { f2.fp = gzopen(argv[ai+2], "r"); if (!f2.fp) { fprintf(stderr, "[orc_bwa] fail to open %s\n", argv[ai+2]); return 1; } }
+	if (!interleaved && !f2.fp) { fprintf(stderr, "[orc_bwa] single-end input is outside the oracle's scope (speedseq align is paired-end)\n"); return 1; }
+	{
+		char cl[4096]; size_t l = 0; cl[0] = 0;
+		for (i = 0; i < argc && l < sizeof(cl) - 1; ++i) l += snprintf(cl + l, sizeof(cl) - l, "%s%s", i ? " " : "bwa ", argv[i]);
+		char *h = orc_sam_header(idx, rg, cl); fputs(h, stdout); free(h);
+	}
+	int64_t n_processed = 0, chunk = (int64_t)opt.chunk_size * opt.n_threads;
+	for (;;) {
+		orc_read_t *s = 0; int n = 0, m = 0; int64_t size = 0; int rc = 0;
+		while (1) { /* upstream bseq_read */
+			if (n + 2 > m) { m = m ? m << 1 : 1024; s = realloc(s, m * sizeof(orc_read_t)); }
+			rc = fq_read1(&f1, &s[n], keep_comment); if (rc < 0) break;
+			size += s[n++].l_seq;
+			if (f2.fp) { rc = fq_read1(&f2, &s[n], keep_comment); if (rc < 0) { rc = -2; break; } size += s[n++].l_seq; }
+			if (size >= chunk && (n & 1) == 0) break;
+		}
+		if (rc == -2) { fprintf(stderr, "[orc_bwa] truncated / malformed FASTQ\n"); return 1; }
+		if (n == 0) { free(s); break; }
+		if (n & 1) { fprintf(stderr, "[orc_bwa] odd number of reads in paired-end mode\n"); return 1; }
+		for (i = 0; i < n; i += 2)
+			if (strcmp(s[i].name, s[i+1].name) != 0) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", s[i].name, s[i+1].name); return 1; }
+		orc_pestat_t pes_out[4];
+		orc_mem_process_pairs(&opt, idx, n_processed, n, s, pes, rg_id, pes_out, opt.n_threads);
+		fprintf(stderr, "[orc_bwa] processed %d reads; FR insert: failed=%d low=%d high=%d avg=%.2f std=%.2f\n", n, pes_out[1].failed, pes_out[1].low, pes_out[1].high, pes_out[1].avg, pes_out[1].std);
+		for (i = 0; i < n; ++i) {
+			fputs(s[i].sam, stdout);
+			free(s[i].sam); free(s[i].name); free(s[i].comment); free(s[i].seq); free(s[i].qual);
+		}
+		n_processed += n;
+		free(s);
+		if (rc < 0) break;
+	}
+	fprintf(stderr, "[orc_bwa] %lld reads in %.3f s; cells=%llu extend=%llu lf=%llu sa=%llu\n", (long long)n_processed, now() - t0,
+	        (unsigned long long)orc_cnt_cells, (unsigned long long)orc_cnt_extend, (unsigned long long)orc_cnt_lf, (unsigned long long)orc_cnt_sa);
+	gzclose(f1.fp); if (f2.fp) gzclose(f2.fp);
+	orc_idx_destroy(idx);
+	return 0;
+}
+
+static int main_samblaster(int argc, char **argv)
+{
+	orc_sbl_opt_t o; orc_sbl_opt_init(&o);
+	const char *spl = 0, *disc = 0;
+	for (int i = 1; i < argc; ++i) {
+		if (!strcmp(argv[i], "--excludeDups")) o.exclude_dups = 1;
+		else if (!strcmp(argv[i], "--addMateTags")) o.add_mate_tags = 1;
+		else if (!strcmp(argv[i], "--maxSplitCount") && i + 1 < argc) o.max_split_count = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--minNonOverlap") && i + 1 < argc) o.min_non_overlap = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--splitterFile") && i + 1 < argc) spl = argv[++i];
+		else if (!strcmp(argv[i], "--discordantFile") && i + 1 < argc) disc = argv[++i];
+		else { fprintf(stderr, "[orc_samblaster] unsupported option %s\n", argv[i]); return 1; }
+	}
+	FILE *fs = spl ? fopen(spl, "w") : 0, *fd = disc ? fopen(disc, "w") : 0;
+	uint64_t st[4] = {0,0,0,0};
+	int rc = orc_samblaster(&o, stdin, stdout, fs, fd, st);
+	if (fs) fclose(fs);
+	if (fd) fclose(fd);
+	fprintf(stderr, "[orc_samblaster] pairs=%llu dups=%llu discordant_pairs=%llu splitter_lines=%llu\n",
+	        (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3]);
+	return rc;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) { fprintf(stderr, "usage: orc_bwa <index|mem|samblaster> ...\n"); return 1; }
+	if (!strcmp(argv[1], "index")) return main_index(argc - 1, argv + 1);
+	if (!strcmp(argv[1], "mem")) return main_mem(argc - 1, argv + 1);
+	if (!strcmp(argv[1], "samblaster")) return main_samblaster(argc - 1, argv + 1);
+	fprintf(stderr, "unknown command %s\n", argv[1]);
+	return 1;
+}
