@@ -1,0 +1,87 @@
+/*
+ * ssgpu.h -- C ABI of libssgpu.so, the MI355X-native `speedseq align` hot path
+ * (BWA-MEM seed-and-extend + SAMBLASTER duplicate/discordant/splitter marking).
+ *
+ * This is the drop-in boundary below the reference's process-level plugin surface
+ * (/root/reference/bin/speedseq.config:13-14 names the `bwa` and `samblaster` executables;
+ * /root/reference/bin/speedseq:438-439 is the command line they must honour).  The reference's
+ * src/bwa and src/samblaster are empty submodules, so each entry point cites the upstream
+ * library function whose role it takes (upstream bwamem.h / ksw.h / bwt.h, SURVEY.md 8b last row)
+ * and the SURVEY.md 8a row it implements.  Plain pointers and sizes only; the caller owns every
+ * buffer it passes; all functions return 0 on success or a negative SSG_E* code; no globals
+ * besides the HIP runtime's own state.  Host buffers are copied to HBM by the library; `*_dev`
+ * variants take device pointers.
+ */
+#ifndef SSGPU_H
+#define SSGPU_H
+#include <stdint.h>
+#include <stddef.h>
+#include "../speedseq_amd/csrc/ssg_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSG_OK         0
+#define SSG_ENODEV   (-19)  /* no MI355X / HIP device: the library never falls back to the CPU */
+#define SSG_ENOMEM   (-12)
+#define SSG_EINVAL   (-22)
+#define SSG_EIO      (-5)
+#define SSG_EOVERFLOW (-75) /* an on-device capacity was exceeded; nothing was silently dropped */
+#define SSG_EHIP     (-1000)
+
+const char *ssg_version(void);
+const char *ssg_backend(void);            /* "hip:gfx950" (or "emu" for the CPU test build) */
+int ssg_device_count(void);
+int ssg_set_device(int dev);
+const char *ssg_last_error(void);
+
+/* upstream mem_opt_init() (bwamem.c) -- SURVEY 8a defaults, Appendix B */
+void ssg_mem_opt_init(ssg_mem_opt_t *opt);
+
+/* ---- FM-index (upstream bwa_idx_load / bwa_idx_destroy, bwa.c; row a1) ---- */
+typedef struct ssg_index ssg_index_t;
+int ssg_index_load(const char *prefix, ssg_index_t **out);      /* reads prefix.{bwt,sa,pac,ann} into HBM */
+int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t primary, const uint64_t L2[5],
+                          const uint64_t *sa, uint64_t n_sa, int sa_intv,
+                          const uint8_t *pac, int64_t l_pac,
+                          int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out);
+void ssg_index_destroy(ssg_index_t *idx);
+int64_t ssg_index_l_pac(const ssg_index_t *idx);
+int ssg_index_n_ctg(const ssg_index_t *idx);
+
+/* ---- stage-level batched entry points (host buffers) ---- */
+
+/* upstream ksw_extend2() (ksw.c; row a7), one job per wavefront.  qbuf/tbuf hold nt4 codes. */
+int ssg_extend_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_ext_job_t *jobs,
+                     const uint8_t *qbuf, size_t qbytes, const uint8_t *tbuf, size_t tbytes,
+                     ssg_ext_res_t *res, uint64_t *cells);
+
+/* upstream ksw_align2() (ksw.c; row a10), one job per wavefront. */
+int ssg_align2_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *jobs,
+                     const uint8_t *qbuf, size_t qbytes, const uint8_t *tbuf, size_t tbytes, ssg_kswr_t *res);
+
+/* upstream ksw_global2() (ksw.c; row a12): score + CIGAR (ops packed len<<4|op, "MIDSH").
+ * cigar: n_jobs x cap entries. */
+int ssg_global_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_glb_job_t *jobs,
+                     const uint8_t *qbuf, size_t qbytes, const uint8_t *tbuf, size_t tbytes,
+                     int32_t *score, int32_t *n_cigar, uint32_t *cigar, int cap);
+
+/* upstream mem_collect_intv() (bwamem.c; rows a1-a2).  seq: concatenated nt4 codes, off[n_reads+1].
+ * out_intv: n_reads x cap; out_n[r] = number of intervals (reads that overflow cap are re-run
+ * internally with a larger capacity; SSG_EOVERFLOW if `cap` cannot hold a read's final list). */
+int ssg_smem_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
+                   int cap, ssg_intv_t *out_intv, int32_t *out_n);
+
+/* upstream mem_align1_core() (bwamem.c; rows a1-a8) for a batch of reads: SMEM -> SAL -> chain ->
+ * filter -> extend -> sort/dedup/patch.  reg_off[n_reads+1] and regs (malloc'd by the library,
+ * release with ssg_free) receive each read's mem_alnreg_t list in upstream order. */
+int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
+                     int64_t *reg_off, ssg_alnreg_t **regs, uint64_t stats[8]);
+
+void ssg_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

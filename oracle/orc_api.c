@@ -1,0 +1,79 @@
+/*
+ * oracle/orc_api.c -- CPU ORACLE (test infrastructure): flat, ctypes-friendly wrappers used by
+ * tests/ to compare the HIP path with the oracle stage by stage.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "orc.h"
+
+typedef struct {
+	int64_t rb, re;
+	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp;
+	float frac_rep;
+	uint64_t hash;
+} orc_flatreg_t;
+
+static void flatten(const orc_alnreg_t *a, orc_flatreg_t *f)
+{
+	f->rb = a->rb; f->re = a->re; f->qb = a->qb; f->qe = a->qe; f->rid = a->rid; f->score = a->score; f->truesc = a->truesc;
+	f->sub = a->sub; f->alt_sc = a->alt_sc; f->csub = a->csub; f->sub_n = a->sub_n; f->w = a->w; f->seedcov = a->seedcov;
+	f->secondary = a->secondary; f->secondary_all = a->secondary_all; f->seedlen0 = a->seedlen0; f->n_comp = a->n_comp;
+	f->frac_rep = a->frac_rep; f->hash = a->hash;
+}
+
+orc_opt_t *orc_api_opt_new(void) { orc_opt_t *o = malloc(sizeof(orc_opt_t)); orc_opt_init(o); return o; }
+void orc_api_free(void *p) { free(p); }
+
+/* mem_collect_intv for one read; returns the number of intervals (out may be smaller than needed) */
+int orc_api_collect_intv(const orc_opt_t *opt, const orc_idx_t *idx, int len, const uint8_t *seq, orc_intv_t *out, int cap)
+{
+	orc_intv_v mem = {0,0,0};
+	orc_collect_intv(opt, idx->bwt, len, seq, &mem);
+	int n = (int)mem.n;
+	memcpy(out, mem.a, sizeof(orc_intv_t) * (n < cap ? n : cap));
+	free(mem.a);
+	return n;
+}
+
+/* mem_align1_core for a batch of reads; regs are appended to out (cap entries); reg_off[n+1] */
+int64_t orc_api_align1_batch(const orc_opt_t *opt, const orc_idx_t *idx, int n_reads, const uint8_t *seq, const int64_t *off,
+                             int64_t *reg_off, orc_flatreg_t *out, int64_t cap)
+{
+	int64_t tot = 0;
+	for (int r = 0; r < n_reads; ++r) {
+		int len = (int)(off[r+1] - off[r]);
+		uint8_t *s = malloc(len + 1); memcpy(s, seq + off[r], len);
+		orc_alnreg_v v = orc_mem_align1_core(opt, idx, len, s);
+		reg_off[r] = tot;
+		for (size_t i = 0; i < v.n; ++i) { if (tot < cap) flatten(&v.a[i], &out[tot]); ++tot; }
+		free(v.a); free(s);
+	}
+	reg_off[n_reads] = tot;
+	return tot;
+}
+
+/* ksw_global2 with the CIGAR copied out */
+int orc_api_global2(const orc_opt_t *opt, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int w, int *n_cigar, uint32_t *cigar, int cap)
+{
+	uint32_t *cg = 0; int n = 0;
+	int sc = orc_ksw_global2(qlen, q, tlen, t, 5, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w, &n, &cg);
+	*n_cigar = n;
+	memcpy(cigar, cg, 4 * (n < cap ? n : cap));
+	free(cg);
+	return sc;
+}
+
+void orc_api_extend2(const orc_opt_t *opt, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int w, int end_bonus, int zdrop, int h0, int out[6])
+{
+	out[0] = orc_ksw_extend2(qlen, q, tlen, t, 5, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w, end_bonus, zdrop, h0,
+	                         &out[1], &out[2], &out[3], &out[4], &out[5]);
+}
+
+void orc_api_align2(const orc_opt_t *opt, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int xtra, int out[7])
+{
+	uint8_t *qc = malloc(qlen + 1), *tc = malloc(tlen + 1);
+	memcpy(qc, q, qlen); memcpy(tc, t, tlen);
+	orc_kswr_t r = orc_ksw_align2(qlen, qc, tlen, tc, 5, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, xtra);
+	out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.score2; out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
+	free(qc); free(tc);
+}

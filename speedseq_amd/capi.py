@@ -1,0 +1,134 @@
+"""ctypes binding of libssgpu.so's C ABI (include/ssgpu.h).
+
+The product library is the HIP build in this directory.  There is no CPU fallback: if the shared
+object is missing or no GPU is visible the calls raise.  Tests may load the host-emulation build of
+the same sources (tests/emu/libssgpu_emu.so) by passing its path explicitly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libssgpu.so")
+
+# numpy mirrors of speedseq_amd/csrc/ssg_types.h
+OPT_DT = np.dtype([
+    ("a", "i4"), ("b", "i4"), ("o_del", "i4"), ("e_del", "i4"), ("o_ins", "i4"), ("e_ins", "i4"),
+    ("pen_unpaired", "i4"), ("pen_clip5", "i4"), ("pen_clip3", "i4"), ("w", "i4"), ("zdrop", "i4"),
+    ("T", "i4"), ("min_seed_len", "i4"), ("min_chain_weight", "i4"), ("max_chain_extend", "i4"),
+    ("split_width", "i4"), ("max_occ", "i4"), ("max_chain_gap", "i4"), ("max_ins", "i4"), ("max_matesw", "i4"),
+    ("max_XA_hits", "i4"), ("max_XA_hits_alt", "i4"), ("mapQ_coef_fac", "i4"), ("chunk_size", "i4"), ("n_threads", "i4"),
+    ("_align", "i4"),
+    ("max_mem_intv", "u8"),
+    ("split_factor", "f4"), ("mask_level", "f4"), ("drop_ratio", "f4"), ("XA_drop_ratio", "f4"),
+    ("mask_level_redun", "f4"), ("mapQ_coef_len", "f4"),
+    ("mat", "i1", (25,)), ("_pad", "i1", (7,)),
+], align=False)
+INTV_DT = np.dtype([("x0", "u8"), ("x1", "u8"), ("x2", "u8"), ("info", "u8")])
+EXT_JOB_DT = np.dtype([("qoff", "i4"), ("qlen", "i4"), ("toff", "i4"), ("tlen", "i4"), ("w", "i4"), ("end_bonus", "i4"), ("zdrop", "i4"), ("h0", "i4")])
+EXT_RES_DT = np.dtype([("score", "i4"), ("qle", "i4"), ("tle", "i4"), ("gtle", "i4"), ("gscore", "i4"), ("max_off", "i4")])
+SW_JOB_DT = np.dtype([("qoff", "i4"), ("qlen", "i4"), ("toff", "i4"), ("tlen", "i4"), ("xtra", "i4"), ("_pad", "i4")])
+KSWR_DT = np.dtype([("score", "i4"), ("te", "i4"), ("qe", "i4"), ("score2", "i4"), ("te2", "i4"), ("tb", "i4"), ("qb", "i4")])
+GLB_JOB_DT = np.dtype([("qoff", "i4"), ("qlen", "i4"), ("toff", "i4"), ("tlen", "i4"), ("w", "i4"), ("_pad", "i4")])
+ALNREG_DT = np.dtype([
+    ("rb", "i8"), ("re", "i8"), ("qb", "i4"), ("qe", "i4"), ("rid", "i4"), ("score", "i4"), ("truesc", "i4"), ("sub", "i4"),
+    ("alt_sc", "i4"), ("csub", "i4"), ("sub_n", "i4"), ("w", "i4"), ("seedcov", "i4"), ("secondary", "i4"),
+    ("secondary_all", "i4"), ("seedlen0", "i4"), ("n_comp", "i4"), ("frac_rep", "f4"), ("hash", "u8"),
+])
+PESTAT_DT = np.dtype([("low", "i4"), ("high", "i4"), ("failed", "i4"), ("_pad", "i4"), ("avg", "f8"), ("std", "f8")])
+
+
+class SsgError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Lib:
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise SsgError("%s not found: build it with `make lib` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        self.l = C.CDLL(path)
+        self.l.ssg_version.restype = C.c_char_p
+        self.l.ssg_backend.restype = C.c_char_p
+        self.l.ssg_last_error.restype = C.c_char_p
+        self.l.ssg_index_l_pac.restype = C.c_int64
+        assert OPT_DT.itemsize == self.sizeof_opt(), (OPT_DT.itemsize, self.sizeof_opt())
+
+    def sizeof_opt(self):
+        # ssg_mem_opt_t: 25 int32 (+4 pad) + u64 + 6 floats + 32 bytes
+        return 25 * 4 + 4 + 8 + 6 * 4 + 32
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SsgError("libssgpu error %d: %s" % (rc, self.l.ssg_last_error().decode()))
+
+    def backend(self):
+        return self.l.ssg_backend().decode()
+
+    def device_count(self):
+        return self.l.ssg_device_count()
+
+    def opt_init(self):
+        o = np.zeros(1, dtype=OPT_DT)
+        self.l.ssg_mem_opt_init(_ptr(o))
+        return o
+
+    # ---- index ----
+    def index_load(self, prefix):
+        h = C.c_void_p()
+        self._chk(self.l.ssg_index_load(prefix.encode(), C.byref(h)))
+        return h
+
+    def index_destroy(self, h):
+        self.l.ssg_index_destroy(h)
+
+    # ---- stage-level ----
+    def extend_batch(self, opt, jobs, qbuf, tbuf):
+        jobs = np.ascontiguousarray(jobs, dtype=EXT_JOB_DT)
+        res = np.zeros(len(jobs), dtype=EXT_RES_DT)
+        cells = C.c_uint64(0)
+        self._chk(self.l.ssg_extend_batch(_ptr(opt), C.c_int(len(jobs)), _ptr(jobs), _ptr(qbuf), C.c_size_t(qbuf.size),
+                                          _ptr(tbuf), C.c_size_t(tbuf.size), _ptr(res), C.byref(cells)))
+        return res, cells.value
+
+    def align2_batch(self, opt, jobs, qbuf, tbuf):
+        jobs = np.ascontiguousarray(jobs, dtype=SW_JOB_DT)
+        res = np.zeros(len(jobs), dtype=KSWR_DT)
+        self._chk(self.l.ssg_align2_batch(_ptr(opt), C.c_int(len(jobs)), _ptr(jobs), _ptr(qbuf), C.c_size_t(qbuf.size),
+                                          _ptr(tbuf), C.c_size_t(tbuf.size), _ptr(res)))
+        return res
+
+    def global_batch(self, opt, jobs, qbuf, tbuf, cap=64):
+        jobs = np.ascontiguousarray(jobs, dtype=GLB_JOB_DT)
+        n = len(jobs)
+        score = np.zeros(n, dtype=np.int32)
+        ncig = np.zeros(n, dtype=np.int32)
+        cig = np.zeros((n, cap), dtype=np.uint32)
+        self._chk(self.l.ssg_global_batch(_ptr(opt), C.c_int(n), _ptr(jobs), _ptr(qbuf), C.c_size_t(qbuf.size),
+                                          _ptr(tbuf), C.c_size_t(tbuf.size), _ptr(score), _ptr(ncig), _ptr(cig), C.c_int(cap)))
+        return score, ncig, cig
+
+    def smem_batch(self, idx, opt, seq, off, cap=64):
+        n = len(off) - 1
+        intv = np.zeros((n, cap), dtype=INTV_DT)
+        cnt = np.zeros(n, dtype=np.int32)
+        self._chk(self.l.ssg_smem_batch(idx, _ptr(opt), C.c_int(n), _ptr(seq), _ptr(off), C.c_int(cap), _ptr(intv), _ptr(cnt)))
+        return intv, cnt
+
+    def align1_batch(self, idx, opt, seq, off):
+        n = len(off) - 1
+        reg_off = np.zeros(n + 1, dtype=np.int64)
+        regs_p = C.c_void_p()
+        stats = np.zeros(8, dtype=np.uint64)
+        self._chk(self.l.ssg_align1_batch(idx, _ptr(opt), C.c_int(n), _ptr(seq), _ptr(off), _ptr(reg_off), C.byref(regs_p), _ptr(stats)))
+        tot = int(reg_off[n])
+        buf = (C.c_char * (tot * ALNREG_DT.itemsize)).from_address(regs_p.value) if tot else b""
+        regs = np.frombuffer(buf, dtype=ALNREG_DT, count=tot).copy()
+        self.l.ssg_free(regs_p)
+        return reg_off, regs, stats

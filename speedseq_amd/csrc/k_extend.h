@@ -1,0 +1,298 @@
+/*
+ * k_extend.h -- gfx950 kernels for seed extension.
+ *
+ *   ssg_k_extend_jobs   one wavefront per ksw_extend2 job (stage-level entry point; also the
+ *                       kernel the SW micro-benchmark and rocprof roofline line are taken from).
+ *   ssg_k_chain2aln     one wavefront per read: upstream mem_chain2aln over the read's surviving
+ *                       chains (left/right banded extension of each seed with the w, 2w retry),
+ *                       then mem_sort_dedup_patch.  The per-read control flow is inherently
+ *                       sequential (every seed is tested against the regions produced so far), so
+ *                       it runs wave-uniform on all lanes while the DP rows run lane-parallel.
+ *
+ * The reference window of a chain is decoded from the 2-bit .pac into LDS once per chain
+ * (<= SSG_TWIN_LDS bases per wave; longer windows use a per-wave global slab).
+ */
+#ifndef SSG_K_EXTEND_H
+#define SSG_K_EXTEND_H
+#include "k_sw.h"
+
+#define SSG_TWIN_LDS 1024
+#define SSG_TWIN_GLB 32768
+#define SSG_WAVES_PER_WG 4
+
+__global__ void ssg_k_extend_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_ext_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,
+                                  ssg_ext_res_t *res, unsigned long long *cells)
+{
+	long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (wid >= n_jobs) return;
+	ssg_ext_job_t jb = jobs[wid];
+	ssg_seqv_t q = { qbuf + jb.qoff, 1 }, t = { tbuf + jb.toff, 1 };
+	unsigned long long nc = 0;
+	ssg_ext_res_t r = wv_extend2_any(opt, jb.qlen, q, jb.tlen, t, jb.w, jb.end_bonus, jb.zdrop, jb.h0, &nc);
+	if (wv_lane() == 0) { res[wid] = r; if (cells) atomicAdd(cells, nc); }
+}
+
+SSG_DEVFN int ssg_cal_max_gap(const ssg_mem_opt_t &opt, int qlen)
+{
+	int l_del = (int)((double)(qlen * opt.a - opt.o_del) / opt.e_del + 1.);
+	int l_ins = (int)((double)(qlen * opt.a - opt.o_ins) / opt.e_ins + 1.);
+	int l = l_del > l_ins ? l_del : l_ins;
+	l = l > 1 ? l : 1;
+	return l < opt.w << 1 ? l : opt.w << 1;
+}
+
+/* cooperative decode of reference [beg,end) (doubled coordinates) into dst */
+SSG_DEVFN void wv_fetch_ref(const ssg_index_view_t &ix, int64_t beg, int64_t end, uint8_t *dst)
+{
+	ssg_wave_memsync();
+	for (int64_t k = beg + wv_lane(); k < end; k += 64) dst[k - beg] = (uint8_t)ssg_ref_base(ix, k);
+	ssg_wave_memsync();
+}
+
+struct ssg_u64_lt { SSG_DEVMEM bool operator()(uint64_t a, uint64_t b) const { return a < b; } };
+struct ssg_reg_re_lt { SSG_DEVMEM bool operator()(const ssg_alnreg_t &a, const ssg_alnreg_t &b) const { return a.re < b.re; } };
+struct ssg_reg_sc_lt {
+	SSG_DEVMEM bool operator()(const ssg_alnreg_t &a, const ssg_alnreg_t &b) const
+	{ return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb))); }
+};
+
+#define SSG_PATCH_MAX_R_BW 0.05f
+#define SSG_PATCH_MIN_SC_RATIO 0.90f
+
+/* score of the banded global alignment of query[qb,qe) vs reference [rb,re) as upstream
+ * bwa_gen_cigar2 computes it with n_cigar == NULL (both reversed when on the reverse strand) */
+SSG_DEVFN int wv_gen_score(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, int w_, int l_query, const uint8_t *query,
+                           int64_t rb, int64_t re, uint8_t *tbuf, int *ok, unsigned long long *cells)
+{
+	*ok = 0;
+	if (l_query <= 0 || rb >= re || (rb < ix.l_pac && re > ix.l_pac)) return 0;
+	if (rb < 0 || re > ix.l_pac << 1) return 0;
+	int rlen = (int)(re - rb);
+	wv_fetch_ref(ix, rb, re, tbuf);
+	*ok = 1;
+	const bool rev = rb >= ix.l_pac;
+	ssg_seqv_t q = { rev ? query + l_query - 1 : query, rev ? -1 : 1 };
+	ssg_seqv_t t = { rev ? tbuf + rlen - 1 : tbuf, rev ? -1 : 1 };
+	if (l_query == rlen && w_ == 0) {
+		int sc = 0;
+		for (int i = wv_lane(); i < l_query; i += 64) sc += opt.mat[sq_at(t, i) * 5 + sq_at(q, i)];
+		return wv_sum(sc);
+	}
+	int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+	int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+	int max_gap = max_ins > max_del ? max_ins : max_del;
+	max_gap = max_gap > 1 ? max_gap : 1;
+	int w = (max_gap + iabs(rlen - l_query) + 1) >> 1;
+	w = w < w_ ? w : w_;
+	int min_w = iabs(rlen - l_query) + 3;
+	w = w > min_w ? w : min_w;
+	return wv_global2_any(opt, l_query, q, rlen, t, w, 0, cells);
+}
+
+SSG_DEVFN int wv_patch_reg(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const uint8_t *query, const ssg_alnreg_t &a, const ssg_alnreg_t &b,
+                           int *_w, uint8_t *tbuf, int tcap, int *err, unsigned long long *cells)
+{	/* upstream mem_patch_reg */
+	int w, score, q_s, r_s, ok; double r;
+	if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
+	if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+	w = (int)((a.re - b.rb) - (a.qe - b.qb));
+	w = w > 0 ? w : -w;
+	r = (double)(a.re - b.rb) / (b.re - a.rb) - (double)(a.qe - b.qb) / (b.qe - a.qb);
+	r = r > 0. ? r : -r;
+	if (a.re < b.rb || a.qe < b.qb) { if (w > opt.w << 1 || r >= SSG_PATCH_MAX_R_BW) return 0; }
+	else if (w > opt.w << 2 || r >= SSG_PATCH_MAX_R_BW * 2) return 0;
+	w += a.w + b.w;
+	w = w < opt.w << 2 ? w : opt.w << 2;
+	if (b.re - a.rb > tcap) { *err = 1; return 0; }
+	score = wv_gen_score(ix, opt, w, b.qe - a.qb, query + a.qb, a.rb, b.re, tbuf, &ok, cells);
+	if (!ok) score = 0; /* upstream leaves score unset when bwa_gen_cigar2 bails out; unreachable for same-strand regs */
+	q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
+	r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
+	if ((double)score / (q_s > r_s ? q_s : r_s) < SSG_PATCH_MIN_SC_RATIO) return 0;
+	*_w = w;
+	return score;
+}
+
+/* upstream mem_sort_dedup_patch (wave-uniform; `patch` enables mem_patch_reg as in mem_align1_core) */
+SSG_DEVFN int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const uint8_t *query, int patch, int n, ssg_alnreg_t *a,
+                                  uint8_t *tbuf, int tcap, int *err, unsigned long long *cells)
+{
+	int m, i, j;
+	if (n <= 1) return n;
+	SSG_LANE0(ssg_introsort(a, (long)n, ssg_reg_re_lt()); for (int t = 0; t < n; ++t) a[t].n_comp = 1);
+	for (i = 1; i < n; ++i) {
+		ssg_alnreg_t *p = &a[i];
+		if (p->rid != a[i-1].rid || p->rb >= a[i-1].re + opt.max_chain_gap) continue;
+		for (j = i - 1; j >= 0 && p->rid == a[j].rid && p->rb < a[j].re + opt.max_chain_gap; --j) {
+			ssg_alnreg_t *q = &a[j];
+			int64_t or_, oq, mr, mq; int score, w;
+			if (q->qe == q->qb) continue;
+			or_ = q->re - p->rb;
+			oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+			mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+			mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+			if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq) {
+				if (p->score < q->score) { SSG_LANE0(p->qe = p->qb); break; }
+				else SSG_LANE0(q->qe = q->qb);
+			} else if (patch && q->rb < p->rb && (score = wv_patch_reg(ix, opt, query, *q, *p, &w, tbuf, tcap, err, cells)) > 0) {
+				SSG_LANE0(
+				p->n_comp += q->n_comp + 1;
+				p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+				p->sub = p->sub > q->sub ? p->sub : q->sub;
+				p->csub = p->csub > q->csub ? p->csub : q->csub;
+				p->qb = q->qb; p->rb = q->rb;
+				p->truesc = p->score = score;
+				p->w = w;
+				q->qb = q->qe);
+			}
+		}
+	}
+	m = 0;
+	SSG_LANE0(
+		int mm = 0, t;
+		for (t = 0; t < n; ++t)
+			if (a[t].qe > a[t].qb) { if (mm != t) a[mm++] = a[t]; else ++mm; }
+		int nn = mm;
+		ssg_introsort(a, (long)nn, ssg_reg_sc_lt());
+		for (t = 1; t < nn; ++t)
+			if (a[t].score == a[t-1].score && a[t].rb == a[t-1].rb && a[t].qb == a[t-1].qb) a[t].qe = a[t].qb;
+		for (t = 1, mm = 1; t < nn; ++t)
+			if (a[t].qe > a[t].qb) { if (mm != t) a[mm++] = a[t]; else ++mm; }
+		m = nn < 1 ? nn : mm);
+	return wv_bcast(m, 0);
+}
+
+#define SSG_MAX_BAND_TRY 2
+
+/*
+ * One wavefront per read.  Per-read slices start at seed_off[r]: chains[], order[] (surviving chain
+ * ids), srt[] (u64 work array), regs[] (capacity = #seeds of the read).  n_reg[r] receives the
+ * number of regions left after mem_sort_dedup_patch; err[r] != 0 flags a window overflow.
+ */
+__global__ void ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
+                                const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
+                                const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
+                                uint8_t *tglb, int32_t *err, unsigned long long *cells)
+{
+	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
+	const int wslot = (int)(threadIdx.x >> 6);
+	const long wid = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
+	if (wid >= n_reads) return;
+	const long r = wid;
+	const uint8_t *query = seq + read_off[r];
+	const int l_query = (int)(read_off[r+1] - read_off[r]);
+	const long s0 = seed_off[r];
+	const ssg_chain_t *ch = chains + s0; const int32_t *ord = order + s0;
+	uint64_t *srt = srt_all + s0;
+	ssg_alnreg_t *av = regs + s0;
+	uint8_t *tg = tglb + wid * (long)SSG_TWIN_GLB;
+	const int64_t l_pac = ix.l_pac;
+	int av_n = 0, myerr = 0;
+	unsigned long long nc = 0;
+	const int nch = n_chain[r];
+	for (int ci = 0; ci < nch; ++ci) {
+		const ssg_chain_t c = ch[ord[ci]];
+		const int32_t *cs = chain_seeds + c.first_seed;
+		int i, k, max_off[2], aw[2];
+		int64_t rmax[2], tmp;
+		if (c.n == 0) continue;
+		rmax[0] = l_pac << 1; rmax[1] = 0;
+		for (i = 0; i < c.n; ++i) {
+			const ssg_seed_t t = seeds[cs[i]];
+			int64_t b = t.rbeg - (t.qbeg + ssg_cal_max_gap(opt, t.qbeg));
+			int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + ssg_cal_max_gap(opt, l_query - t.qbeg - t.len));
+			rmax[0] = rmax[0] < b ? rmax[0] : b;
+			rmax[1] = rmax[1] > e ? rmax[1] : e;
+		}
+		rmax[0] = rmax[0] > 0 ? rmax[0] : 0;
+		rmax[1] = rmax[1] < l_pac << 1 ? rmax[1] : l_pac << 1;
+		const int64_t rbeg0 = seeds[cs[0]].rbeg;
+		if (rmax[0] < l_pac && l_pac < rmax[1]) { if (rbeg0 < l_pac) rmax[1] = l_pac; else rmax[0] = l_pac; }
+		{	/* upstream bns_fetch_seq: clip to the contig holding the first seed */
+			int is_rev; int rid = ssg_pos2rid(ix, ssg_depos(ix, rbeg0, &is_rev));
+			int64_t far_beg = ix.ctg_off[rid], far_end = far_beg + ix.ctg_len[rid];
+			if (is_rev) { int64_t t2 = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t2; }
+			rmax[0] = rmax[0] > far_beg ? rmax[0] : far_beg;
+			rmax[1] = rmax[1] < far_end ? rmax[1] : far_end;
+		}
+		const int span = (int)(rmax[1] - rmax[0]);
+		uint8_t *rseq = span <= SSG_TWIN_LDS ? tlds[wslot] : tg;
+		if (span > SSG_TWIN_GLB) { myerr = 1; continue; }
+		wv_fetch_ref(ix, rmax[0], rmax[1], rseq);
+		SSG_LANE0(for (int t = 0; t < c.n; ++t) srt[t] = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
+		          ssg_introsort(srt, (long)c.n, ssg_u64_lt()));
+		for (k = c.n - 1; k >= 0; --k) {
+			const ssg_seed_t s = seeds[cs[(uint32_t)srt[k]]];
+			for (i = 0; i < av_n; ++i) {
+				const ssg_alnreg_t p = av[i];
+				int64_t rd; int qd, w, max_gap;
+				if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
+				if (s.len - p.seedlen0 > .1 * l_query) continue;
+				qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+				max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+				w = max_gap < p.w ? max_gap : p.w;
+				if (qd - rd < w && rd - qd < w) break;
+				qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+				max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+				w = max_gap < p.w ? max_gap : p.w;
+				if (qd - rd < w && rd - qd < w) break;
+			}
+			if (i < av_n) {
+				for (i = k + 1; i < c.n; ++i) {
+					if (srt[i] == 0) continue;
+					const ssg_seed_t t = seeds[cs[(uint32_t)srt[i]]];
+					if (t.len < s.len * .95) continue;
+					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+				}
+				if (i == c.n) { SSG_LANE0(srt[k] = 0); continue; }
+			}
+			ssg_alnreg_t a;
+			a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = a.seedcov = a.secondary = a.secondary_all = a.n_comp = 0; a.hash = 0;
+			a.w = aw[0] = aw[1] = opt.w;
+			a.score = a.truesc = -1;
+			a.rid = c.rid;
+			if (s.qbeg) { /* left extension: both sequences walked backwards */
+				ssg_ext_res_t x; x.score = -1;
+				tmp = s.rbeg - rmax[0];
+				ssg_seqv_t qs = { query + s.qbeg - 1, -1 }, rs = { rseq + tmp - 1, -1 };
+				for (i = 0; i < SSG_MAX_BAND_TRY; ++i) {
+					int prev = a.score;
+					aw[0] = opt.w << i;
+					x = wv_extend2_any(opt, s.qbeg, qs, (int)tmp, rs, aw[0], opt.pen_clip5, opt.zdrop, s.len * opt.a, &nc);
+					a.score = x.score; max_off[0] = x.max_off;
+					if (a.score == prev || max_off[0] < (aw[0] >> 1) + (aw[0] >> 2)) break;
+				}
+				if (x.gscore <= 0 || x.gscore <= a.score - opt.pen_clip5) { a.qb = s.qbeg - x.qle; a.rb = s.rbeg - x.tle; a.truesc = a.score; }
+				else { a.qb = 0; a.rb = s.rbeg - x.gtle; a.truesc = x.gscore; }
+			} else { a.score = a.truesc = s.len * opt.a; a.qb = 0; a.rb = s.rbeg; }
+			if (s.qbeg + s.len != l_query) { /* right extension */
+				ssg_ext_res_t x; x.score = -1;
+				int qe = s.qbeg + s.len, sc0 = a.score;
+				int re = (int)(s.rbeg + s.len - rmax[0]);
+				ssg_seqv_t qs = { query + qe, 1 }, rs = { rseq + re, 1 };
+				for (i = 0; i < SSG_MAX_BAND_TRY; ++i) {
+					int prev = a.score;
+					aw[1] = opt.w << i;
+					x = wv_extend2_any(opt, l_query - qe, qs, (int)(rmax[1] - rmax[0] - re), rs, aw[1], opt.pen_clip3, opt.zdrop, sc0, &nc);
+					a.score = x.score; max_off[1] = x.max_off;
+					if (a.score == prev || max_off[1] < (aw[1] >> 1) + (aw[1] >> 2)) break;
+				}
+				if (x.gscore <= 0 || x.gscore <= a.score - opt.pen_clip3) { a.qe = qe + x.qle; a.re = rmax[0] + re + x.tle; a.truesc += a.score - sc0; }
+				else { a.qe = l_query; a.re = rmax[0] + re + x.gtle; a.truesc += x.gscore - sc0; }
+			} else { a.qe = l_query; a.re = s.rbeg + s.len; }
+			for (i = 0, a.seedcov = 0; i < c.n; ++i) {
+				const ssg_seed_t t = seeds[cs[i]];
+				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) a.seedcov += t.len;
+			}
+			a.w = aw[0] > aw[1] ? aw[0] : aw[1];
+			a.seedlen0 = s.len;
+			a.frac_rep = c.frac_rep;
+			SSG_LANE0(av[av_n] = a);
+			++av_n;
+		}
+	}
+	av_n = wv_sort_dedup_patch(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
+	if (wv_lane() == 0) { n_reg[r] = av_n; err[r] = myerr; if (cells) atomicAdd(cells, nc); }
+}
+#endif

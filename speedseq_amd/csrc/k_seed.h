@@ -1,0 +1,210 @@
+/*
+ * k_seed.h -- gfx950 kernels for FM-index seeding.
+ *
+ *   ssg_k_smem      one lane per read: the three SMEM passes of upstream mem_collect_intv
+ *                   (bwt_smem1a x2 + bwt_seed_strategy1), intervals sorted by (start,end).
+ *                   Every bwt_extend is two rank queries = two 64-byte HBM lines; the kernel is
+ *                   HBM-latency bound and relies on >=16 resident waves per CU to hide it.
+ *   ssg_k_sal_count per interval: number of sampled occurrences (<= max_occ) -> prefix sum.
+ *   ssg_k_sal       one lane per (interval, occurrence): upstream bwt_sa LF-walk + sampled-SA
+ *                   gather, then bns_intv2rid; writes mem_seed_t in upstream visiting order.
+ */
+#ifndef SSG_K_SEED_H
+#define SSG_K_SEED_H
+#include "ssg_dev.h"
+
+struct ssg_ivec_t { ssg_intv_t *a; int n, cap; int ovf; };
+SSG_DEVFN void iv_push(ssg_ivec_t &v, const ssg_intv_t &x) { if (v.n < v.cap) v.a[v.n] = x; else v.ovf = 1; ++v.n; }
+SSG_DEVFN void iv_reverse(ssg_ivec_t &v)
+{
+	int n = v.n < v.cap ? v.n : v.cap;
+	for (int j = 0; j < n >> 1; ++j) { ssg_intv_t t = v.a[n-1-j]; v.a[n-1-j] = v.a[j]; v.a[j] = t; }
+}
+SSG_DEVFN void ssg_set_intv(const ssg_index_view_t &ix, int c, ssg_intv_t &ik)
+{
+	ik.x0 = ix.L2[c] + 1; ik.x2 = ix.L2[c+1] - ix.L2[c]; ik.x1 = ix.L2[3-c] + 1; ik.info = 0;
+}
+
+/* upstream bwt_smem1a (max_intv == 0 as in mem_collect_intv) */
+SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, int x, uint64_t min_intv,
+                        ssg_ivec_t &mem, ssg_ivec_t &va, ssg_ivec_t &vb)
+{
+	int i, j, c, ret;
+	ssg_intv_t ik, ok[4];
+	ssg_ivec_t *prev = &va, *curr = &vb, *swap;
+	mem.n = 0;
+	if (q[x] > 3) return x + 1;
+	if (min_intv < 1) min_intv = 1;
+	ssg_set_intv(ix, q[x], ik);
+	ik.info = (uint64_t)(x + 1);
+	for (i = x + 1, curr->n = 0; i < len; ++i) {
+		if (q[i] < 4) {
+			c = 3 - q[i];
+			ssg_bwt_extend(ix, ik, ok, 0);
+			if (ok[c].x2 != ik.x2) {
+				iv_push(*curr, ik);
+				if (ok[c].x2 < min_intv) break;
+			}
+			ik = ok[c]; ik.info = (uint64_t)(i + 1);
+		} else { iv_push(*curr, ik); break; }
+	}
+	if (i == len) iv_push(*curr, ik);
+	iv_reverse(*curr);
+	ret = (int)curr->a[0].info;
+	swap = curr; curr = prev; prev = swap;
+	for (i = x - 1; i >= -1; --i) {
+		c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
+		for (j = 0, curr->n = 0; j < prev->n; ++j) {
+			ssg_intv_t p = prev->a[j];
+			if (c >= 0) ssg_bwt_extend(ix, p, ok, 1);
+			if (c < 0 || ok[c].x2 < min_intv) {
+				if (curr->n == 0) {
+					if (mem.n == 0 || (uint64_t)(i + 1) < (mem.a[mem.n-1].info >> 32)) {
+						ik = p; ik.info |= (uint64_t)(i + 1) << 32;
+						iv_push(mem, ik);
+					}
+				}
+			} else if (curr->n == 0 || ok[c].x2 != curr->a[curr->n-1].x2) {
+				ok[c].info = p.info;
+				iv_push(*curr, ok[c]);
+			}
+		}
+		if (curr->n == 0) break;
+		swap = curr; curr = prev; prev = swap;
+	}
+	iv_reverse(mem);
+	return ret;
+}
+
+/* upstream bwt_seed_strategy1 */
+SSG_DEVFN int ssg_seed_strategy1(const ssg_index_view_t &ix, int len, const uint8_t *q, int x, int min_len, uint64_t max_intv, ssg_intv_t &mem)
+{
+	int i, c;
+	ssg_intv_t ik, ok[4];
+	mem.x0 = mem.x1 = mem.x2 = mem.info = 0;
+	if (q[x] > 3) return x + 1;
+	ssg_set_intv(ix, q[x], ik);
+	for (i = x + 1; i < len; ++i) {
+		if (q[i] < 4) {
+			c = 3 - q[i];
+			ssg_bwt_extend(ix, ik, ok, 0);
+			if (ok[c].x2 < max_intv && i - x >= min_len) {
+				mem = ok[c];
+				mem.info = (uint64_t)x << 32 | (uint64_t)(i + 1);
+				return i + 1;
+			}
+			ik = ok[c];
+		} else return i + 1;
+	}
+	return len;
+}
+
+struct ssg_intv_lt { SSG_DEVMEM bool operator()(const ssg_intv_t &a, const ssg_intv_t &b) const { return a.info < b.info; } };
+
+/*
+ * One lane per read.  seq: concatenated nt4 codes; off[r]..off[r+1] delimit read r.
+ * out_intv: [n_reads x cap] ; out_n: per-read interval count (count > cap => overflow, the host
+ * re-runs those reads with a larger cap).  scratch: per launched lane 3*scap intervals.
+ */
+__global__ void ssg_k_smem(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
+                           const uint8_t *seq, const int64_t *off,
+                           ssg_intv_t *out_intv, int32_t *out_n, int cap,
+                           ssg_intv_t *scratch, int scap)
+{
+	long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
+	ssg_intv_t *my = scratch + gt * 3 * scap;
+	for (long it = gt; it < n_reads; it += nt) {
+		int r = read_ids ? read_ids[it] : (int)it;
+		const uint8_t *q = seq + off[r];
+		int len = (int)(off[r+1] - off[r]);
+		ssg_ivec_t mem = { out_intv + (long)it * cap, 0, cap, 0 };
+		ssg_ivec_t mem1 = { my, 0, scap, 0 }, va = { my + scap, 0, scap, 0 }, vb = { my + 2 * scap, 0, scap, 0 };
+		int x = 0, i, k, old_n;
+		int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+		if (len >= opt.min_seed_len) {
+			while (x < len) { /* pass 1 */
+				if (q[x] < 4) {
+					x = ssg_smem1(ix, len, q, x, 1, mem1, va, vb);
+					for (i = 0; i < mem1.n; ++i) {
+						ssg_intv_t p = mem1.a[i];
+						int slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
+						if (slen >= opt.min_seed_len) iv_push(mem, p);
+					}
+				} else ++x;
+			}
+			old_n = mem.n < mem.cap ? mem.n : mem.cap; /* pass 2 */
+			for (k = 0; k < old_n; ++k) {
+				ssg_intv_t p = mem.a[k];
+				int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
+				if (end - start < split_len || p.x2 > (uint64_t)opt.split_width) continue;
+				ssg_smem1(ix, len, q, (start + end) >> 1, p.x2 + 1, mem1, va, vb);
+				for (i = 0; i < mem1.n; ++i) {
+					ssg_intv_t m = mem1.a[i];
+					if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= opt.min_seed_len) iv_push(mem, m);
+				}
+			}
+			if (opt.max_mem_intv > 0) { /* pass 3 */
+				x = 0;
+				while (x < len) {
+					if (q[x] < 4) {
+						ssg_intv_t m;
+						x = ssg_seed_strategy1(ix, len, q, x, opt.min_seed_len, opt.max_mem_intv, m);
+						if (m.x2 > 0) iv_push(mem, m);
+					} else ++x;
+				}
+			}
+			if (mem.n <= mem.cap && !mem1.ovf && !va.ovf && !vb.ovf) ssg_introsort(mem.a, (long)mem.n, ssg_intv_lt());
+		}
+		out_n[it] = (mem.ovf || mem1.ovf || va.ovf || vb.ovf) ? -1 : mem.n;
+	}
+}
+
+/* number of sampled occurrences of one interval (upstream mem_chain: step/count rule) */
+SSG_DEVFN int ssg_intv_nocc(const ssg_mem_opt_t &opt, uint64_t x2)
+{
+	uint64_t step = x2 > (uint64_t)opt.max_occ ? x2 / (uint64_t)opt.max_occ : 1;
+	uint64_t cnt = (x2 + step - 1) / step;
+	return (int)(cnt < (uint64_t)opt.max_occ ? cnt : (uint64_t)opt.max_occ);
+}
+
+/* per read: total #occurrences over its intervals (for the prefix sum that places seeds) */
+__global__ void ssg_k_sal_count(ssg_mem_opt_t opt, int n_reads, const ssg_intv_t *intv, const int32_t *n_intv, int cap, int32_t *n_seed)
+{
+	long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	int n = n_intv[r], tot = 0;
+	const ssg_intv_t *p = intv + r * cap;
+	for (int i = 0; i < n; ++i) tot += ssg_intv_nocc(opt, p[i].x2);
+	n_seed[r] = tot;
+}
+
+/*
+ * One lane per (read, interval): walks that interval's sampled occurrences.  Seeds are written
+ * at seed_off[r] + (occurrences of earlier intervals) + k, i.e. in upstream's visiting order.
+ * Invalid seeds (bns_intv2rid < 0) get len = -1 and are skipped by the chaining kernel.
+ */
+__global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
+                          const int64_t *seed_off, ssg_seed_t *seeds, int32_t *seed_rid)
+{
+	long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	long r = g / cap; int ii = (int)(g % cap);
+	if (r >= n_reads || ii >= n_intv[r]) return;
+	const ssg_intv_t *p = intv + r * cap;
+	long base = seed_off[r];
+	for (int i = 0; i < ii; ++i) base += ssg_intv_nocc(opt, p[i].x2);
+	ssg_intv_t v = p[ii];
+	int slen = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
+	uint64_t step = v.x2 > (uint64_t)opt.max_occ ? v.x2 / (uint64_t)opt.max_occ : 1;
+	int count = 0;
+	for (uint64_t k = 0; k < v.x2 && count < opt.max_occ; k += step, ++count) {
+		ssg_seed_t s;
+		s.rbeg = (int64_t)ssg_bwt_sa(ix, v.x0 + k);
+		s.qbeg = (int32_t)(v.info >> 32);
+		s.len = s.score = slen;
+		s.next = -1;
+		int rid = ssg_intv2rid(ix, s.rbeg, s.rbeg + s.len);
+		seeds[base + count] = s;
+		seed_rid[base + count] = rid;
+	}
+}
+#endif

@@ -1,0 +1,245 @@
+/*
+ * ssg_dev.h -- device-side helpers for the gfx950 kernels: 64-lane wavefront primitives
+ * (shuffles / ballots lower to DPP, ds_bpermute and s_ballot on CDNA4), FM-index rank on one
+ * 64-byte block, 2-bit reference fetch.  Written for wave64 only.
+ *
+ * When SSG_EMU is defined the same sources build against tests/emu/emu.h (host emulation used
+ * only by the CPU-side tests; see that header).
+ */
+#ifndef SSG_DEV_H
+#define SSG_DEV_H
+#include "ssg_types.h"
+
+#ifdef SSG_EMU
+#include "emu.h"
+#define SSG_DEVFN static inline
+#define SSG_DEVMEM inline
+SSG_DEVFN int wv_shfl(int v, int src) { return emu_shfl_i32(v, src); }
+SSG_DEVFN unsigned long long wv_ballot(int p) { return emu_ballot(p); }
+#define SSG_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define SSG_DEVFN static __device__ __forceinline__
+#define SSG_DEVMEM __device__ __forceinline__
+SSG_DEVFN int wv_shfl(int v, int src) { return __shfl(v, src, 64); }
+SSG_DEVFN unsigned long long wv_ballot(int p) { return __ballot(p); }
+#define SSG_UNROLL _Pragma("unroll")
+#endif
+
+#define SSG_WAVE 64
+/* make one lane's global stores visible to the other lanes of the same wave */
+#ifdef SSG_EMU
+SSG_DEVFN void ssg_wave_memsync() { (void)emu_ballot(0); } /* fibers are not lock-step: rendezvous */
+#else
+SSG_DEVFN void ssg_wave_memsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+#endif
+/* A scalar (wave-uniform) mutation of memory shared by the wave: executed by lane 0 only, fenced on
+ * both sides so every lane's earlier reads are done and every lane's later reads see it. */
+#define SSG_LANE0(...) do { ssg_wave_memsync(); if (wv_lane() == 0) { __VA_ARGS__; } ssg_wave_memsync(); } while (0)
+
+SSG_DEVFN int wv_lane() { return (int)(threadIdx.x & 63); }
+/* value of lane-1 (lane 0 receives `fill`) */
+SSG_DEVFN int wv_up1(int v, int fill) { int l = wv_lane(); int r = wv_shfl(v, l - 1); return l == 0 ? fill : r; }
+SSG_DEVFN int wv_bcast(int v, int src) { return wv_shfl(v, src); }
+SSG_DEVFN long long wv_bcast64(long long v, int src)
+{
+	int lo = wv_shfl((int)(unsigned)(unsigned long long)v, src), hi = wv_shfl((int)((unsigned long long)v >> 32), src);
+	return (long long)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
+}
+SSG_DEVFN int wv_max(int v)
+{
+	for (int d = 1; d < 64; d <<= 1) { int o = wv_shfl(v, wv_lane() ^ d); v = v > o ? v : o; }
+	return v;
+}
+SSG_DEVFN int wv_min(int v)
+{
+	for (int d = 1; d < 64; d <<= 1) { int o = wv_shfl(v, wv_lane() ^ d); v = v < o ? v : o; }
+	return v;
+}
+SSG_DEVFN int wv_sum(int v)
+{
+	for (int d = 1; d < 64; d <<= 1) v += wv_shfl(v, wv_lane() ^ d);
+	return v;
+}
+/* inclusive prefix max over lanes 0..lane */
+SSG_DEVFN int wv_scan_max(int v)
+{
+	int l = wv_lane();
+	for (int d = 1; d < 64; d <<= 1) { int o = wv_shfl(v, l - d); if (l >= d) v = v > o ? v : o; }
+	return v;
+}
+SSG_DEVFN int imax(int a, int b) { return a > b ? a : b; }
+SSG_DEVFN int imin(int a, int b) { return a < b ? a : b; }
+SSG_DEVFN int iabs(int a) { return a < 0 ? -a : a; }
+SSG_DEVFN long long lmax(long long a, long long b) { return a > b ? a : b; }
+SSG_DEVFN long long lmin(long long a, long long b) { return a < b ? a : b; }
+
+/* ---------------- FM-index rank: one 64-byte block per query ---------------- */
+SSG_DEVFN int ssg_cnt16(uint32_t w, int c, int nsym)
+{	/* # of 2-bit symbols == c among the first nsym (MSB-first) symbols of w */
+	uint32_t m = ~(w ^ ((uint32_t)c * 0x55555555u));
+	uint32_t t = m & (m >> 1) & 0x55555555u;
+	if (nsym < 16) t &= nsym ? ~((1u << ((16 - nsym) << 1)) - 1) : 0u;
+	return __popc(t);
+}
+/* occ of all four symbols in stored BWT [0..k] (k = with-$ row index, (uint64_t)-1 allowed) */
+SSG_DEVFN void ssg_occ4(const ssg_index_view_t &ix, uint64_t k, uint64_t cnt[4])
+{
+	if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
+	k -= (k >= ix.primary);
+	const uint32_t *p = ix.bwt + ((k >> 7) << 4);
+	const uint64_t *pc = (const uint64_t*)p;
+	uint32_t w[8];
+	SSG_UNROLL for (int i = 0; i < 8; ++i) w[i] = p[8 + i];
+	int r = (int)(k & 127) + 1;
+	SSG_UNROLL for (int c = 0; c < 4; ++c) {
+		int n = 0;
+		SSG_UNROLL for (int i = 0; i < 8; ++i) { int ns = r - i * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns; n += ssg_cnt16(w[i], c, ns); }
+		cnt[c] = pc[c] + (uint64_t)n;
+	}
+}
+SSG_DEVFN uint64_t ssg_occ1(const ssg_index_view_t &ix, uint64_t k, int c)
+{	/* upstream bwt_occ */
+	if (k == ix.seq_len) return ix.L2[c+1] - ix.L2[c];
+	if (k == (uint64_t)-1) return 0;
+	k -= (k >= ix.primary);
+	const uint32_t *p = ix.bwt + ((k >> 7) << 4);
+	uint64_t n = ((const uint64_t*)p)[c];
+	int r = (int)(k & 127) + 1;
+	SSG_UNROLL for (int i = 0; i < 8; ++i) { int ns = r - i * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns; if (ns) n += ssg_cnt16(p[8 + i], c, ns); }
+	return n;
+}
+SSG_DEVFN int ssg_bwt_sym(const ssg_index_view_t &ix, uint64_t k)
+{	/* symbol at stored index k */
+	const uint32_t *p = ix.bwt + ((k >> 7) << 4) + 8;
+	return p[(k & 127) >> 4] >> ((~k & 15) << 1) & 3;
+}
+/* upstream bwt_extend */
+SSG_DEVFN void ssg_bwt_extend(const ssg_index_view_t &ix, const ssg_intv_t &ik, ssg_intv_t ok[4], int is_back)
+{
+	uint64_t tk[4], tl[4];
+	uint64_t kx = is_back ? ik.x0 : ik.x1, ox = is_back ? ik.x1 : ik.x0;
+	ssg_occ4(ix, kx - 1, tk);
+	ssg_occ4(ix, kx - 1 + ik.x2, tl);
+	uint64_t nk[4], ns[4], no[4];
+	for (int i = 0; i < 4; ++i) { nk[i] = ix.L2[i] + 1 + tk[i]; ns[i] = tl[i] - tk[i]; }
+	no[3] = ox + (kx <= ix.primary && kx + ik.x2 - 1 >= ix.primary);
+	no[2] = no[3] + ns[3];
+	no[1] = no[2] + ns[2];
+	no[0] = no[1] + ns[1];
+	for (int i = 0; i < 4; ++i) {
+		ok[i].x2 = ns[i];
+		if (is_back) { ok[i].x0 = nk[i]; ok[i].x1 = no[i]; } else { ok[i].x1 = nk[i]; ok[i].x0 = no[i]; }
+	}
+}
+/* upstream bwt_sa: LF-walk to a sampled row */
+SSG_DEVFN uint64_t ssg_bwt_sa(const ssg_index_view_t &ix, uint64_t k)
+{
+	uint64_t sa = 0, mask = (uint64_t)ix.sa_intv - 1;
+	while (k & mask) {
+		++sa;
+		if (k == ix.primary) { k = 0; continue; }
+		uint64_t x = k - (k > ix.primary);
+		int c = ssg_bwt_sym(ix, x);
+		k = ix.L2[c] + ssg_occ1(ix, k, c);
+	}
+	return sa + ix.sa[k / (uint64_t)ix.sa_intv];
+}
+
+/* ---------------- reference access ---------------- */
+SSG_DEVFN int ssg_ref_base(const ssg_index_view_t &ix, int64_t p)
+{	/* base at doubled coordinate p in [0, 2*l_pac) */
+	int64_t q = p < ix.l_pac ? p : (ix.l_pac << 1) - 1 - p;
+	int b = ix.pac[q >> 2] >> ((~q & 3) << 1) & 3;
+	return p < ix.l_pac ? b : 3 - b;
+}
+SSG_DEVFN int ssg_pos2rid(const ssg_index_view_t &ix, int64_t pos_f)
+{	/* upstream bns_pos2rid */
+	if (pos_f >= ix.l_pac) return -1;
+	int left = 0, mid = 0, right = ix.n_ctg;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos_f >= ix.ctg_off[mid]) {
+			if (mid == ix.n_ctg - 1) break;
+			if (pos_f < ix.ctg_off[mid + 1]) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	return mid;
+}
+SSG_DEVFN int64_t ssg_depos(const ssg_index_view_t &ix, int64_t pos, int *is_rev)
+{
+	return (*is_rev = (pos >= ix.l_pac)) ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+SSG_DEVFN int ssg_intv2rid(const ssg_index_view_t &ix, int64_t rb, int64_t re)
+{	/* upstream bns_intv2rid */
+	int is_rev;
+	if (rb < ix.l_pac && re > ix.l_pac) return -2;
+	int rid_b = ssg_pos2rid(ix, ssg_depos(ix, rb, &is_rev));
+	int rid_e = rb < re ? ssg_pos2rid(ix, ssg_depos(ix, re - 1, &is_rev)) : rid_b;
+	return rid_b == rid_e ? rid_b : -1;
+}
+SSG_DEVFN int ssg_score(const ssg_mem_opt_t &o, int t, int q) { return o.mat[t * 5 + q]; }
+
+/* ---------------- klib-compatible introsort over an index permutation ----------------
+ * Same operation sequence as ks_introsort (htslib ksort.h:178-229), so ties land in the same
+ * order as the reference's unstable sort.  `LT(a,b)` compares two element *values*. */
+template <class T, class LT>
+SSG_DEVFN void ssg_insertsort(T *s, T *t, LT lt)
+{
+	for (T *i = s + 1; i < t; ++i)
+		for (T *j = i; j > s && lt(*j, *(j - 1)); --j) { T x = *j; *j = *(j - 1); *(j - 1) = x; }
+}
+template <class T, class LT>
+SSG_DEVFN void ssg_combsort(T *a, long n, LT lt)
+{
+	const double shrink = 1.2473309501039786540366528676643;
+	int do_swap; long gap = n;
+	do {
+		if (gap > 2) { gap = (long)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+		do_swap = 0;
+		for (T *i = a; i < a + n - gap; ++i) {
+			T *j = i + gap;
+			if (lt(*j, *i)) { T x = *i; *i = *j; *j = x; do_swap = 1; }
+		}
+	} while (do_swap || gap > 2);
+	if (gap != 1) ssg_insertsort(a, a + n, lt);
+}
+template <class T, class LT>
+SSG_DEVFN void ssg_introsort(T *a, long n, LT lt)
+{
+	struct { T *l, *r; int d; } stack[128]; int top = 0;
+	int d; T rp, *s, *t, *i, *j, *k;
+	if (n < 1) return;
+	if (n == 2) { if (lt(a[1], a[0])) { T x = a[0]; a[0] = a[1]; a[1] = x; } return; }
+	for (d = 2; (1l << d) < n; ++d);
+	s = a; t = a + (n - 1); d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { ssg_combsort(s, t - s + 1, lt); t = s; continue; }
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			if (lt(*k, *i)) { if (lt(*k, *j)) k = j; }
+			else k = lt(*j, *i) ? i : j;
+			rp = *k;
+			if (k != t) { T x = *k; *k = *t; *t = x; }
+			for (;;) {
+				do ++i; while (lt(*i, rp));
+				do --j; while (i <= j && lt(rp, *j));
+				if (j <= i) break;
+				T x = *i; *i = *j; *j = x;
+			}
+			{ T x = *i; *i = *t; *t = x; }
+			if (i - s > t - i) {
+				if (i - s > 16) { stack[top].l = s; stack[top].r = i - 1; stack[top].d = d; ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { stack[top].l = i + 1; stack[top].r = t; stack[top].d = d; ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) { ssg_insertsort(a, a + n, lt); return; }
+			--top; s = stack[top].l; t = stack[top].r; d = stack[top].d;
+		}
+	}
+}
+#endif

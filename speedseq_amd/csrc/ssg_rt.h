@@ -1,0 +1,61 @@
+/*
+ * ssg_rt.h -- thin runtime layer under the host orchestration: HIP (product) or the host wave
+ * emulator (tests/emu, CPU-side tests only).  Device memory, copies, launches.
+ */
+#ifndef SSG_RT_H
+#define SSG_RT_H
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <string>
+
+extern thread_local std::string ssg_err_msg;
+
+#ifdef SSG_EMU
+#include "emu.h"
+#define SSG_BACKEND "emu"
+static inline int rt_device_count() { return 1; }
+static inline int rt_set_device(int) { return 0; }
+static inline void *rt_malloc(size_t n) { return calloc(n ? n : 1, 1); }
+static inline void rt_free(void *p) { free(p); }
+static inline int rt_h2d(void *d, const void *h, size_t n) { if (n) memcpy(d, h, n); return 0; }
+static inline int rt_d2h(void *h, const void *d, size_t n) { if (n) memcpy(h, d, n); return 0; }
+static inline int rt_memset(void *d, int v, size_t n) { if (n) memset(d, v, n); return 0; }
+static inline int rt_sync() { return 0; }
+#define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) emu::launch((unsigned)(grid), (unsigned)(block), (lds), [&]() { kern(__VA_ARGS__); }); } while (0)
+#else
+#include <hip/hip_runtime.h>
+#define SSG_BACKEND "hip:gfx950"
+static inline int rt_check(hipError_t e, const char *what)
+{
+	if (e == hipSuccess) return 0;
+	ssg_err_msg = std::string(what) + ": " + hipGetErrorString(e);
+	return -1000;
+}
+static inline int rt_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+static inline int rt_set_device(int d) { return rt_check(hipSetDevice(d), "hipSetDevice"); }
+static inline void *rt_malloc(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 256) != hipSuccess) { (void)hipGetLastError(); return 0; } return p; }
+static inline void rt_free(void *p) { if (p) (void)hipFree(p); }
+static inline int rt_h2d(void *d, const void *h, size_t n) { return n ? rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D") : 0; }
+static inline int rt_d2h(void *h, const void *d, size_t n) { return n ? rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
+static inline int rt_memset(void *d, int v, size_t n) { return n ? rt_check(hipMemset(d, v, n), "hipMemset") : 0; }
+static inline int rt_sync() { return rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+#define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } while (0)
+#endif
+
+/* RAII device buffer */
+template <class T> struct dbuf {
+	T *p; size_t n;
+	dbuf() : p(0), n(0) {}
+	explicit dbuf(size_t n_) : p((T*)rt_malloc(n_ * sizeof(T))), n(n_) {}
+	~dbuf() { rt_free(p); }
+	dbuf(const dbuf&) = delete; dbuf &operator=(const dbuf&) = delete;
+	bool alloc(size_t n_) { rt_free(p); n = n_; p = (T*)rt_malloc(n_ * sizeof(T)); return p != 0; }
+	bool ok() const { return p != 0; }
+	int up(const T *h, size_t cnt) { return rt_h2d(p, h, cnt * sizeof(T)); }
+	int down(T *h, size_t cnt) const { return rt_d2h(h, p, cnt * sizeof(T)); }
+	int zero() { return rt_memset(p, 0, n * sizeof(T)); }
+};
+#endif

@@ -1,0 +1,83 @@
+/*
+ * ssg_types.h -- plain-old-data types shared by the HIP kernels, the host orchestration and the
+ * C-ABI of libssgpu (MI355X-native `speedseq align` hot path).
+ *
+ * Naming follows the reference's domain (upstream bwa: bwtintv_t, mem_seed_t, mem_chain_t,
+ * mem_alnreg_t, mem_pestat_t, mem_aln_t).
+ */
+#ifndef SSG_TYPES_H
+#define SSG_TYPES_H
+#include <stdint.h>
+
+#define SSG_MAX_INS_HIST 10001   /* insert-size histogram bins: 0..max_ins (mem_pestat, a9) */
+
+/* upstream mem_opt_t (bwamem.h) -- same field meaning, same defaults (ssg_mem_opt_init) */
+typedef struct {
+	int32_t a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, pen_clip5, pen_clip3, w, zdrop;
+	int32_t T, min_seed_len, min_chain_weight, max_chain_extend;
+	int32_t split_width, max_occ, max_chain_gap, max_ins, max_matesw, max_XA_hits, max_XA_hits_alt;
+	int32_t mapQ_coef_fac, chunk_size, n_threads;
+	uint64_t max_mem_intv;
+	float split_factor, mask_level, drop_ratio, XA_drop_ratio, mask_level_redun, mapQ_coef_len;
+	int8_t mat[25];
+	int8_t _pad[7];
+} ssg_mem_opt_t;
+
+/* FM-index resident in HBM (upstream bwt_t + bntseq_t + pac).  The .bwt body is kept in its
+ * on-disk interleaved form: one 64-byte block = 4 x u64 running counts + 8 x u32 (128 symbols),
+ * i.e. one rank query = one 64-byte HBM line. */
+typedef struct {
+	const uint32_t *bwt;     /* device */
+	const uint64_t *sa;      /* device; sa[0] = (uint64_t)-1 */
+	const uint8_t  *pac;     /* device; 2-bit forward strand */
+	const int64_t  *ctg_off; /* device; n_ctg contig offsets */
+	const int32_t  *ctg_len; /* device */
+	uint64_t primary, L2[5], seq_len;
+	int64_t l_pac;
+	int32_t n_ctg, sa_intv;
+} ssg_index_view_t;
+
+typedef struct { uint64_t x0, x1, x2, info; } ssg_intv_t;          /* upstream bwtintv_t */
+typedef struct { int64_t rbeg; int32_t qbeg, len; int32_t score; int32_t next; } ssg_seed_t; /* mem_seed_t + chain link */
+
+typedef struct {            /* upstream mem_chain_t (seeds as a linked list through ssg_seed_t.next) */
+	int64_t pos;
+	int32_t first_seed, last_seed, n, rid;
+	int32_t w, kept, first, sec;   /* sec: tie rank reproducing the B-tree order among equal pos */
+	int32_t left, right;           /* BST links while chaining */
+	float frac_rep;
+	int32_t _pad;
+} ssg_chain_t;
+
+typedef struct {            /* upstream mem_alnreg_t */
+	int64_t rb, re;
+	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp;
+	float frac_rep;
+	uint64_t hash;
+} ssg_alnreg_t;
+
+typedef struct { int32_t low, high, failed, _pad; double avg, std; } ssg_pestat_t; /* mem_pestat_t */
+
+/* result of ksw_extend2 (a7) */
+typedef struct { int32_t score, qle, tle, gtle, gscore, max_off; } ssg_ext_res_t;
+/* one ksw_extend2 job for the stage-level entry point */
+typedef struct { int32_t qoff, qlen, toff, tlen, w, end_bonus, zdrop, h0; } ssg_ext_job_t;
+
+/* result of ksw_align2 (a10) */
+typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } ssg_kswr_t;
+typedef struct { int32_t qoff, qlen, toff, tlen, xtra, _pad; } ssg_sw_job_t;
+
+/* one ksw_global2 / bwa_gen_cigar2 job (a12) */
+typedef struct { int32_t qoff, qlen, toff, tlen, w, _pad; } ssg_glb_job_t;
+
+/* final alignment record (upstream mem_aln_t + the SAM fields mem_aln2sam derives) */
+#define SSG_MAX_CIGAR 64
+#define SSG_MAX_MD    320
+typedef struct {
+	int64_t pos;          /* 0-based on contig; -1 unmapped */
+	int32_t rid, flag, mapq, NM, score, sub, n_cigar, is_rev, l_md, reg_idx, xa_cnt, _pad;
+	uint32_t cigar[SSG_MAX_CIGAR];
+	char md[SSG_MAX_MD];
+} ssg_aln_t;
+
+#endif

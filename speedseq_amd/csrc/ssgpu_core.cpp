@@ -1,0 +1,326 @@
+/*
+ * ssgpu_core.cpp -- host orchestration and C ABI of libssgpu (see include/ssgpu.h).
+ * Compiled by hipcc for gfx950 (product) or by g++ with -DSSG_EMU against tests/emu (CPU tests).
+ *
+ * Stage order for a batch of reads (all intermediates stay in HBM):
+ *   ssg_k_smem -> ssg_k_sal_count -> [prefix sum] -> ssg_k_sal -> ssg_k_chain -> ssg_k_chain2aln
+ * Per-read variable-length outputs are placed by prefix sums over per-read counts; fixed-capacity
+ * stages report overflow and the affected reads are re-run with a larger capacity -- nothing is
+ * dropped silently and nothing falls back to the CPU.
+ */
+#include <vector>
+#include <algorithm>
+#include <math.h>
+#include "ssg_rt.h"
+#include "k_seed.h"
+#include "k_chain.h"
+#include "k_extend.h"
+#include "k_swjobs.h"
+#include "../../include/ssgpu.h"
+
+thread_local std::string ssg_err_msg;
+
+struct ssg_index {
+	ssg_index_view_t v;
+	uint32_t *bwt; uint64_t *sa; uint8_t *pac; int64_t *ctg_off; int32_t *ctg_len;
+	std::vector<std::string> names;
+	std::vector<int64_t> h_off; std::vector<int32_t> h_len;
+};
+
+#define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+#define CHKA(b) do { if (!(b).ok()) { ssg_err_msg = "device allocation failed: " #b; return SSG_ENOMEM; } } while (0)
+
+static int need_device()
+{
+	if (rt_device_count() < 1) { ssg_err_msg = "no HIP device visible: libssgpu has no CPU path"; return SSG_ENODEV; }
+	return 0;
+}
+
+extern "C" {
+
+const char *ssg_version(void) { return "0.1.0"; }
+const char *ssg_backend(void) { return SSG_BACKEND; }
+int ssg_device_count(void) { return rt_device_count(); }
+int ssg_set_device(int dev) { return rt_set_device(dev); }
+const char *ssg_last_error(void) { return ssg_err_msg.c_str(); }
+void ssg_free(void *p) { free(p); }
+
+void ssg_mem_opt_init(ssg_mem_opt_t *o)
+{
+	memset(o, 0, sizeof(*o));
+	o->a = 1; o->b = 4; o->o_del = o->o_ins = 6; o->e_del = o->e_ins = 1;
+	o->w = 100; o->T = 30; o->zdrop = 100; o->pen_unpaired = 17; o->pen_clip5 = o->pen_clip3 = 5;
+	o->max_mem_intv = 20; o->min_seed_len = 19; o->split_width = 10; o->max_occ = 500;
+	o->max_chain_gap = 10000; o->max_ins = 10000; o->mask_level = 0.50f; o->drop_ratio = 0.50f;
+	o->XA_drop_ratio = 0.80f; o->split_factor = 1.5f; o->chunk_size = 10000000; o->n_threads = 1;
+	o->max_XA_hits = 5; o->max_XA_hits_alt = 200; o->max_matesw = 50; o->mask_level_redun = 0.95f;
+	o->min_chain_weight = 0; o->max_chain_extend = 1 << 30;
+	o->mapQ_coef_len = 50; o->mapQ_coef_fac = (int)log((double)o->mapQ_coef_len);
+	for (int i = 0, k = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) o->mat[k++] = i == j ? o->a : -o->b; o->mat[k++] = -1; }
+	for (int j = 0; j < 5; ++j) o->mat[20 + j] = -1;
+}
+
+/* ------------------------------- index ------------------------------- */
+int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t primary, const uint64_t L2[5],
+                          const uint64_t *sa, uint64_t n_sa, int sa_intv, const uint8_t *pac, int64_t l_pac,
+                          int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out)
+{
+	CHK(need_device());
+	ssg_index *ix = new ssg_index();
+	size_t pac_bytes = (size_t)(l_pac / 4 + 1);
+	ix->bwt = (uint32_t*)rt_malloc(bwt_words * 4 + 64); ix->sa = (uint64_t*)rt_malloc(n_sa * 8);
+	ix->pac = (uint8_t*)rt_malloc(pac_bytes); ix->ctg_off = (int64_t*)rt_malloc(n_ctg * 8); ix->ctg_len = (int32_t*)rt_malloc(n_ctg * 4);
+	if (!ix->bwt || !ix->sa || !ix->pac || !ix->ctg_off || !ix->ctg_len) { ssg_index_destroy(ix); ssg_err_msg = "index allocation failed"; return SSG_ENOMEM; }
+	int rc = 0;
+	rc |= rt_h2d(ix->bwt, bwt, bwt_words * 4); rc |= rt_h2d(ix->sa, sa, n_sa * 8); rc |= rt_h2d(ix->pac, pac, pac_bytes);
+	rc |= rt_h2d(ix->ctg_off, ctg_off, n_ctg * 8); rc |= rt_h2d(ix->ctg_len, ctg_len, n_ctg * 4);
+	if (rc) { ssg_index_destroy(ix); return SSG_EHIP; }
+	ix->v.bwt = ix->bwt; ix->v.sa = ix->sa; ix->v.pac = ix->pac; ix->v.ctg_off = ix->ctg_off; ix->v.ctg_len = ix->ctg_len;
+	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
+	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
+	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
+	*out = ix;
+	return 0;
+}
+
+int ssg_index_load(const char *prefix, ssg_index_t **out)
+{	/* on-disk layout: SURVEY.md Appendix A (verified against the bundled example index) */
+	CHK(need_device());
+	std::string p(prefix);
+	FILE *fp = fopen((p + ".ann").c_str(), "r");
+	if (!fp) { ssg_err_msg = "cannot open " + p + ".ann"; return SSG_EIO; }
+	long long l_pac; int n_seqs; unsigned seed;
+	if (fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) != 3) { fclose(fp); ssg_err_msg = "bad .ann header"; return SSG_EIO; }
+	std::vector<int64_t> off(n_seqs); std::vector<int32_t> len(n_seqs); std::vector<std::string> names(n_seqs);
+	for (int i = 0; i < n_seqs; ++i) {
+		unsigned gi; char nm[8192]; long long o; int l, na; int c;
+		if (fscanf(fp, "%u%8191s", &gi, nm) != 2) { fclose(fp); ssg_err_msg = "bad .ann record"; return SSG_EIO; }
+		while ((c = fgetc(fp)) != '\n' && c != EOF) {}
+		if (fscanf(fp, "%lld%d%d", &o, &l, &na) != 3) { fclose(fp); ssg_err_msg = "bad .ann record"; return SSG_EIO; }
+		names[i] = nm; off[i] = o; len[i] = l;
+	}
+	fclose(fp);
+	auto slurp = [&](const std::string &fn, std::vector<uint8_t> &buf) -> int {
+		FILE *f = fopen(fn.c_str(), "rb"); if (!f) { ssg_err_msg = "cannot open " + fn; return SSG_EIO; }
+		fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+		buf.resize(sz); if (sz && fread(buf.data(), 1, sz, f) != (size_t)sz) { fclose(f); ssg_err_msg = "short read " + fn; return SSG_EIO; }
+		fclose(f); return 0;
+	};
+	std::vector<uint8_t> bwt, sa, pac;
+	CHK(slurp(p + ".bwt", bwt)); CHK(slurp(p + ".sa", sa)); CHK(slurp(p + ".pac", pac));
+	if (bwt.size() < 40 || sa.size() < 56) { ssg_err_msg = "truncated index"; return SSG_EIO; }
+	uint64_t primary, L2[5] = {0,0,0,0,0}, hdr[7];
+	memcpy(&primary, bwt.data(), 8); memcpy(L2 + 1, bwt.data() + 8, 32);
+	memcpy(hdr, sa.data(), 56);
+	if (hdr[0] != primary || hdr[6] != L2[4]) { ssg_err_msg = ".sa does not match .bwt"; return SSG_EIO; }
+	int sa_intv = (int)hdr[5];
+	uint64_t n_sa = (L2[4] + sa_intv) / sa_intv;
+	if (sa.size() != 56 + (n_sa - 1) * 8) { ssg_err_msg = "unexpected .sa size"; return SSG_EIO; }
+	std::vector<uint64_t> sav(n_sa); sav[0] = (uint64_t)-1; memcpy(sav.data() + 1, sa.data() + 56, (n_sa - 1) * 8);
+	pac.resize((size_t)(l_pac / 4 + 1), 0);
+	int rc = ssg_index_from_arrays((const uint32_t*)(bwt.data() + 40), (bwt.size() - 40) / 4, primary, L2, sav.data(), n_sa, sa_intv,
+	                               pac.data(), l_pac, n_seqs, off.data(), len.data(), out);
+	if (rc == 0) (*out)->names = names;
+	return rc;
+}
+
+void ssg_index_destroy(ssg_index_t *ix)
+{
+	if (!ix) return;
+	rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); rt_free(ix->ctg_off); rt_free(ix->ctg_len);
+	delete ix;
+}
+int64_t ssg_index_l_pac(const ssg_index_t *ix) { return ix->v.l_pac; }
+int ssg_index_n_ctg(const ssg_index_t *ix) { return ix->v.n_ctg; }
+
+/* ------------------------------- SW job batches ------------------------------- */
+int ssg_extend_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_ext_job_t *jobs, const uint8_t *qbuf, size_t qbytes,
+                     const uint8_t *tbuf, size_t tbytes, ssg_ext_res_t *res, uint64_t *cells)
+{
+	CHK(need_device());
+	if (n_jobs <= 0) return 0;
+	for (int i = 0; i < n_jobs; ++i) if (jobs[i].qlen > 254 || jobs[i].qlen < 0 || jobs[i].h0 <= 0) { ssg_err_msg = "ssg_extend_batch: qlen must be <= 254 and h0 > 0"; return SSG_EINVAL; }
+	dbuf<ssg_ext_job_t> dj(n_jobs); dbuf<uint8_t> dq(qbytes + 1), dt(tbytes + 1); dbuf<ssg_ext_res_t> dr(n_jobs); dbuf<unsigned long long> dc(1);
+	CHKA(dj); CHKA(dq); CHKA(dt); CHKA(dr); CHKA(dc);
+	CHK(dj.up(jobs, n_jobs)); CHK(dq.up(qbuf, qbytes)); CHK(dt.up(tbuf, tbytes)); CHK(dc.zero());
+	int wpb = 4;
+	SSG_LAUNCH(ssg_k_extend_jobs, (n_jobs + wpb - 1) / wpb, wpb * 64, 0, *opt, n_jobs, dj.p, dq.p, dt.p, dr.p, dc.p);
+	CHK(rt_sync());
+	CHK(dr.down(res, n_jobs));
+	if (cells) { unsigned long long c; CHK(dc.down(&c, 1)); *cells = c; }
+	return 0;
+}
+
+int ssg_align2_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *jobs, const uint8_t *qbuf, size_t qbytes,
+                     const uint8_t *tbuf, size_t tbytes, ssg_kswr_t *res)
+{
+	CHK(need_device());
+	if (n_jobs <= 0) return 0;
+	int max_t = 1;
+	for (int i = 0; i < n_jobs; ++i) { if (jobs[i].qlen > 256 || jobs[i].qlen < 1) { ssg_err_msg = "ssg_align2_batch: 1 <= qlen <= 256"; return SSG_EINVAL; } max_t = std::max(max_t, jobs[i].tlen); }
+	dbuf<ssg_sw_job_t> dj(n_jobs); dbuf<uint8_t> dq(qbytes + 1), dt(tbytes + 1); dbuf<ssg_kswr_t> dr(n_jobs); dbuf<unsigned long long> db((size_t)n_jobs * (max_t + 1));
+	CHKA(dj); CHKA(dq); CHKA(dt); CHKA(dr); CHKA(db);
+	CHK(dj.up(jobs, n_jobs)); CHK(dq.up(qbuf, qbytes)); CHK(dt.up(tbuf, tbytes));
+	int wpb = 4;
+	SSG_LAUNCH(ssg_k_align2_jobs, (n_jobs + wpb - 1) / wpb, wpb * 64, 0, *opt, n_jobs, dj.p, dq.p, dt.p, dr.p, db.p, max_t + 1);
+	CHK(rt_sync());
+	return dr.down(res, n_jobs);
+}
+
+int ssg_global_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_glb_job_t *jobs, const uint8_t *qbuf, size_t qbytes,
+                     const uint8_t *tbuf, size_t tbytes, int32_t *score, int32_t *n_cigar, uint32_t *cigar, int cap)
+{
+	CHK(need_device());
+	if (n_jobs <= 0) return 0;
+	long zmax = 1;
+	for (int i = 0; i < n_jobs; ++i) {
+		if (jobs[i].qlen > 254 || jobs[i].qlen < 1) { ssg_err_msg = "ssg_global_batch: 1 <= qlen <= 254"; return SSG_EINVAL; }
+		long ncol = std::min(jobs[i].qlen, 2 * jobs[i].w + 1); zmax = std::max(zmax, ncol * jobs[i].tlen);
+	}
+	dbuf<ssg_glb_job_t> dj(n_jobs); dbuf<uint8_t> dq(qbytes + 1), dt(tbytes + 1), dz((size_t)zmax * n_jobs); dbuf<int32_t> ds(n_jobs), dn(n_jobs); dbuf<uint32_t> dcg((size_t)n_jobs * cap);
+	CHKA(dj); CHKA(dq); CHKA(dt); CHKA(dz); CHKA(ds); CHKA(dn); CHKA(dcg);
+	CHK(dj.up(jobs, n_jobs)); CHK(dq.up(qbuf, qbytes)); CHK(dt.up(tbuf, tbytes));
+	int wpb = 4;
+	SSG_LAUNCH(ssg_k_global_jobs, (n_jobs + wpb - 1) / wpb, wpb * 64, 0, *opt, n_jobs, dj.p, dq.p, dt.p, ds.p, dn.p, dcg.p, cap, dz.p, zmax);
+	CHK(rt_sync());
+	CHK(ds.down(score, n_jobs)); CHK(dn.down(n_cigar, n_jobs));
+	return dcg.down(cigar, (size_t)n_jobs * cap);
+}
+
+/* ------------------------------- seeding ------------------------------- */
+struct seed_stage_t {
+	int cap; dbuf<ssg_intv_t> intv; dbuf<int32_t> n_intv;
+};
+
+/* runs the SMEM kernel for all reads (cap0 per read), then re-runs overflowing reads with a
+ * private large capacity and copies their lists back; on return every n_intv[r] >= 0. */
+static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
+                    int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n)
+{
+	const int block = 64;
+	long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * 1024);
+	int scap = max_len + 2;
+	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap);
+	CHKA(scratch);
+	SSG_LAUNCH(ssg_k_smem, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap);
+	CHK(rt_sync());
+	std::vector<int32_t> hn(n_reads);
+	CHK(rt_d2h(hn.data(), d_n, (size_t)n_reads * 4));
+	std::vector<int32_t> ovf;
+	for (int r = 0; r < n_reads; ++r) if (hn[r] < 0) ovf.push_back(r);
+	if (ovf.empty()) return 0;
+	/* slow path: worst case is O(len^2) intervals in theory; len*8 has never been observed to overflow */
+	int bigcap = max_len * 8 + 64, no = (int)ovf.size();
+	dbuf<int32_t> d_ids(no), d_n2(no); dbuf<ssg_intv_t> d_big((size_t)no * bigcap);
+	CHKA(d_ids); CHKA(d_n2); CHKA(d_big);
+	CHK(d_ids.up(ovf.data(), no));
+	long nt2 = ((long)no + block - 1) / block * block;
+	dbuf<ssg_intv_t> scratch2((size_t)nt2 * 3 * bigcap);
+	CHKA(scratch2);
+	SSG_LAUNCH(ssg_k_smem, nt2 / block, block, 0, idx->v, *opt, no, d_ids.p, d_seq, d_off, d_big.p, d_n2.p, bigcap, scratch2.p, bigcap);
+	CHK(rt_sync());
+	std::vector<int32_t> hn2(no);
+	CHK(d_n2.down(hn2.data(), no));
+	for (int i = 0; i < no; ++i) {
+		if (hn2[i] < 0 || hn2[i] > cap) { ssg_err_msg = "SMEM interval list exceeds the per-read capacity"; return SSG_EOVERFLOW; }
+		std::vector<ssg_intv_t> tmp(hn2[i]);
+		CHK(rt_d2h(tmp.data(), d_big.p + (size_t)i * bigcap, (size_t)hn2[i] * sizeof(ssg_intv_t)));
+		CHK(rt_h2d(d_intv + (size_t)ovf[i] * cap, tmp.data(), (size_t)hn2[i] * sizeof(ssg_intv_t)));
+		CHK(rt_h2d(d_n + ovf[i], &hn2[i], 4));
+	}
+	return 0;
+}
+
+int ssg_smem_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
+                   int cap, ssg_intv_t *out_intv, int32_t *out_n)
+{
+	CHK(need_device());
+	if (n_reads <= 0) return 0;
+	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
+	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1); dbuf<ssg_intv_t> d_intv((size_t)n_reads * cap); dbuf<int32_t> d_n(n_reads);
+	CHKA(d_seq); CHKA(d_off); CHKA(d_intv); CHKA(d_n);
+	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1));
+	CHK(run_smem(idx, opt, n_reads, d_seq.p, d_off.p, max_len, cap, d_intv.p, d_n.p));
+	CHK(d_intv.down(out_intv, (size_t)n_reads * cap));
+	return d_n.down(out_n, n_reads);
+}
+
+/* ------------------------------- mem_align1_core for a batch ------------------------------- */
+struct align1_dev_t {	/* device-resident result of stages 1-4 */
+	dbuf<int64_t> seed_off; dbuf<ssg_alnreg_t> regs; dbuf<int32_t> n_reg;
+	std::vector<int64_t> h_seed_off; int64_t tot_seeds;
+};
+
+static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off, int max_len,
+                      align1_dev_t &o, uint64_t stats[8])
+{
+	const int cap = 64 > max_len / 2 ? 64 : max_len / 2;  /* intervals per read in the dense layout */
+	dbuf<ssg_intv_t> d_intv((size_t)n_reads * cap); dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
+	CHKA(d_intv); CHKA(d_nintv); CHKA(d_nseed);
+	CHK(run_smem(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv.p, d_nintv.p));
+	const int block = 256;
+	SSG_LAUNCH(ssg_k_sal_count, (n_reads + block - 1) / block, block, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);
+	CHK(rt_sync());
+	std::vector<int32_t> hns(n_reads);
+	CHK(d_nseed.down(hns.data(), n_reads));
+	o.h_seed_off.resize(n_reads + 1);
+	int64_t tot = 0;
+	for (int r = 0; r < n_reads; ++r) { o.h_seed_off[r] = tot; tot += hns[r]; }
+	o.h_seed_off[n_reads] = tot; o.tot_seeds = tot;
+	if (!o.seed_off.alloc(n_reads + 1)) { ssg_err_msg = "device allocation failed: seed_off"; return SSG_ENOMEM; }
+	CHK(o.seed_off.up(o.h_seed_off.data(), n_reads + 1));
+	size_t ts = (size_t)tot + 1;
+	dbuf<ssg_seed_t> d_seeds(ts); dbuf<int32_t> d_srid(ts), d_order(ts), d_kept(ts), d_cseeds(ts), d_nchain(n_reads), d_err(n_reads);
+	dbuf<ssg_chain_t> d_chains(ts); dbuf<uint64_t> d_srt(ts); dbuf<unsigned long long> d_cells(1);
+	CHKA(d_seeds); CHKA(d_srid); CHKA(d_order); CHKA(d_kept); CHKA(d_cseeds); CHKA(d_nchain); CHKA(d_err); CHKA(d_chains); CHKA(d_srt); CHKA(d_cells);
+	if (!o.regs.alloc(ts) || !o.n_reg.alloc(n_reads)) { ssg_err_msg = "device allocation failed: regs"; return SSG_ENOMEM; }
+	CHK(d_cells.zero());
+	{
+		long g = (long)n_reads * cap;
+		SSG_LAUNCH(ssg_k_sal, (g + block - 1) / block, block, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p);
+	}
+	SSG_LAUNCH(ssg_k_chain, (n_reads + 63) / 64, 64, 0, idx->v, *opt, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+	           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p);
+	{
+		const int wpb = SSG_WAVES_PER_WG;
+		long nwg = ((long)n_reads + wpb - 1) / wpb;
+		dbuf<uint8_t> d_tglb((size_t)nwg * wpb * SSG_TWIN_GLB);
+		CHKA(d_tglb);
+		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
+		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p);
+		CHK(rt_sync());
+	}
+	std::vector<int32_t> herr(n_reads);
+	CHK(d_err.down(herr.data(), n_reads));
+	for (int r = 0; r < n_reads; ++r) if (herr[r]) { ssg_err_msg = "reference window of a chain exceeds SSG_TWIN_GLB"; return SSG_EOVERFLOW; }
+	if (stats) { unsigned long long c; CHK(d_cells.down(&c, 1)); stats[0] = (uint64_t)tot; stats[1] = c; }
+	return 0;
+}
+
+int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
+                     int64_t *reg_off, ssg_alnreg_t **regs, uint64_t stats[8])
+{
+	CHK(need_device());
+	*regs = 0;
+	if (n_reads <= 0) { if (reg_off) reg_off[0] = 0; return 0; }
+	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
+	if (max_len > 254) { ssg_err_msg = "reads longer than 254 bases are outside this build's scope"; return SSG_EINVAL; }
+	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1);
+	CHKA(d_seq); CHKA(d_off);
+	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1));
+	align1_dev_t o;
+	CHK(run_align1(idx, opt, n_reads, d_seq.p, d_off.p, max_len, o, stats));
+	std::vector<int32_t> hn(n_reads);
+	CHK(o.n_reg.down(hn.data(), n_reads));
+	int64_t tot = 0;
+	for (int r = 0; r < n_reads; ++r) { reg_off[r] = tot; tot += hn[r]; }
+	reg_off[n_reads] = tot;
+	ssg_alnreg_t *out = (ssg_alnreg_t*)malloc(sizeof(ssg_alnreg_t) * (size_t)(tot + 1));
+	std::vector<ssg_alnreg_t> all((size_t)o.tot_seeds + 1);
+	CHK(o.regs.down(all.data(), (size_t)o.tot_seeds));
+	for (int r = 0; r < n_reads; ++r) memcpy(out + reg_off[r], all.data() + o.h_seed_off[r], sizeof(ssg_alnreg_t) * (size_t)hn[r]);
+	*regs = out;
+	return 0;
+}
+
+} /* extern "C" */

@@ -1,0 +1,158 @@
+"""Shared test helpers: seeded inputs and the comparison routines used by both the CPU-side tests
+(host-emulation build of the kernel sources) and the `-m gpu` parity tests (HIP build)."""
+import os
+
+import numpy as np
+
+import simreads
+from speedseq_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+EXAMPLE_FA = os.path.join(GOLDEN, "chr20_slice.fa")
+
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+
+def mutate(rng, q, max_sub=8, max_indel=3):
+    tl = list(q)
+    for _ in range(int(rng.integers(0, max_sub))):
+        p = int(rng.integers(0, len(tl)))
+        tl[p] = (tl[p] + 1) % 4
+    for _ in range(int(rng.integers(0, max_indel))):
+        p = int(rng.integers(0, len(tl)))
+        if rng.random() < 0.5:
+            del tl[p:p + int(rng.integers(1, 8))]
+        else:
+            tl[p:p] = list(rng.integers(0, 4, size=int(rng.integers(1, 8))))
+    return tl
+
+
+def make_extend_jobs(n, seed, max_qlen=200):
+    rng = np.random.default_rng(seed)
+    jobs, qs, ts, qo, to = [], [], [], 0, 0
+    for _ in range(n):
+        qlen = int(rng.integers(1, max_qlen))
+        q = rng.integers(0, 4, size=qlen, dtype=np.uint8)
+        mode = rng.integers(0, 4)
+        tl = list(q)
+        if mode >= 1:
+            tl = mutate(rng, q, 6, 1)
+        if mode >= 2:
+            tl = mutate(rng, np.array(tl, dtype=np.uint8), 3, 3)
+        if mode == 3 and len(tl) > 10:
+            tl = tl[:int(len(tl) * rng.random()) + 1] + list(rng.integers(0, 4, size=30))
+        tl += list(rng.integers(0, 4, size=int(rng.integers(0, 120))))
+        t = np.array(tl, dtype=np.uint8)
+        if rng.random() < 0.1:
+            q[rng.integers(0, qlen)] = 4
+        h0 = int(rng.integers(1, 160))
+        w = int(rng.choice([100, 200, 5, 20]))
+        zd = int(rng.choice([100, 100, 0, 20]))
+        jobs.append((qo, qlen, to, len(t), w, 5, zd, h0))
+        qs.append(q)
+        ts.append(t)
+        qo += qlen
+        to += len(t)
+    return np.array(jobs, dtype=capi.EXT_JOB_DT), qs, ts
+
+
+def make_local_jobs(n, seed):
+    rng = np.random.default_rng(seed)
+    jobs, qs, ts, qo, to = [], [], [], 0, 0
+    for _ in range(n):
+        qlen = int(rng.choice([150, 150, 100, 76, 36, 250, 200]))
+        q = rng.integers(0, 4, size=qlen, dtype=np.uint8)
+        mid = mutate(rng, q) if rng.random() < 0.8 else list(rng.integers(0, 4, size=50))
+        if rng.random() < 0.3:
+            mid = mid[:len(mid) // 2]
+        t = np.array(list(rng.integers(0, 4, size=int(rng.integers(0, 300)))) + mid +
+                     list(rng.integers(0, 4, size=int(rng.integers(0, 300)))), dtype=np.uint8)
+        if rng.random() < 0.3:
+            t = np.concatenate([t, np.array(mutate(rng, q), dtype=np.uint8)])
+        xtra = KSW_XSUBO | KSW_XSTART | (KSW_XBYTE if qlen < 250 else 0) | 19
+        jobs.append((qo, qlen, to, len(t), xtra, 0))
+        qs.append(q)
+        ts.append(t)
+        qo += qlen
+        to += len(t)
+    return np.array(jobs, dtype=capi.SW_JOB_DT), qs, ts
+
+
+def make_global_jobs(n, seed):
+    rng = np.random.default_rng(seed)
+    jobs, qs, ts, qo, to = [], [], [], 0, 0
+    for _ in range(n):
+        qlen = int(rng.integers(5, 250))
+        q = rng.integers(0, 4, size=qlen, dtype=np.uint8)
+        t = np.array(mutate(rng, q), dtype=np.uint8)
+        w = abs(len(t) - qlen) + int(rng.integers(3, 40))
+        jobs.append((qo, qlen, to, len(t), w, 0))
+        qs.append(q)
+        ts.append(t)
+        qo += qlen
+        to += len(t)
+    return np.array(jobs, dtype=capi.GLB_JOB_DT), qs, ts
+
+
+def sim_reads(n_pairs, seed, read_len=150, fasta=EXAMPLE_FA, **kw):
+    contigs = simreads.read_fasta(fasta)
+    pairs = simreads.simulate(contigs, n_pairs, seed=seed, read_len=read_len, **kw)
+    seqs = []
+    for _, r1, r2 in pairs:
+        seqs += [r1, r2]
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    return pairs, seqs, np.concatenate(seqs), off
+
+
+REG_FIELDS = ["rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "csub", "w", "seedcov", "seedlen0", "n_comp", "frac_rep"]
+
+
+def check_extend(lib, oracle, n, seed):
+    jobs, qs, ts = make_extend_jobs(n, seed)
+    res, cells = lib.extend_batch(lib.opt_init(), jobs, np.concatenate(qs), np.concatenate(ts))
+    for i in range(n):
+        o = oracle.extend2(qs[i], ts[i], int(jobs[i]["w"]), 5, int(jobs[i]["zdrop"]), int(jobs[i]["h0"]))
+        assert o == tuple(int(x) for x in res[i]), (i, jobs[i], o, res[i])
+    assert cells > 0
+
+
+def check_local(lib, oracle, n, seed):
+    jobs, qs, ts = make_local_jobs(n, seed)
+    res = lib.align2_batch(lib.opt_init(), jobs, np.concatenate(qs), np.concatenate(ts))
+    for i in range(n):
+        o = oracle.align2(qs[i], ts[i], int(jobs[i]["xtra"]))
+        assert o == tuple(int(x) for x in res[i]), (i, jobs[i], o, res[i])
+
+
+def check_global(lib, oracle, n, seed):
+    jobs, qs, ts = make_global_jobs(n, seed)
+    sc, nc, cg = lib.global_batch(lib.opt_init(), jobs, np.concatenate(qs), np.concatenate(ts))
+    for i in range(n):
+        osc, on, ocg = oracle.global2(qs[i], ts[i], int(jobs[i]["w"]))
+        assert osc == sc[i] and on == nc[i] and np.array_equal(ocg[:on], cg[i, :on]), (i, jobs[i])
+
+
+def check_smem(lib, oracle, n_pairs, seed, read_len=150):
+    prefix = EXAMPLE_FA
+    oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
+    _, seqs, seq, off = sim_reads(n_pairs, seed, read_len)
+    intv, cnt = lib.smem_batch(gidx, lib.opt_init(), seq, off, cap=96)
+    for r, s in enumerate(seqs):
+        o = oracle.collect_intv(oidx, s)
+        assert len(o) == cnt[r] and np.array_equal(o, intv[r, :cnt[r]]), r
+    lib.index_destroy(gidx)
+
+
+def check_align1(lib, oracle, n_pairs, seed, read_len=150):
+    prefix = EXAMPLE_FA
+    oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
+    _, seqs, seq, off = sim_reads(n_pairs, seed, read_len)
+    ro, regs, st = lib.align1_batch(gidx, lib.opt_init(), seq, off)
+    oro, oregs = oracle.align1_batch(oidx, seq, off)
+    assert np.array_equal(ro, oro)
+    for f in REG_FIELDS:
+        assert np.array_equal(regs[f], oregs[f]), f
+    lib.index_destroy(gidx)
+    return len(regs)

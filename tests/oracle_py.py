@@ -1,0 +1,74 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+
+import numpy as np
+
+from speedseq_amd.capi import ALNREG_DT, INTV_DT
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, so):
+        self.l = C.CDLL(so)
+        self.l.orc_idx_load.restype = C.c_void_p
+        self.l.orc_idx_load.argtypes = [C.c_char_p]
+        self.l.orc_idx_build_fasta.restype = C.c_void_p
+        self.l.orc_idx_build_fasta.argtypes = [C.c_char_p]
+        self.l.orc_idx_save.argtypes = [C.c_void_p, C.c_char_p]
+        self.l.orc_idx_destroy.argtypes = [C.c_void_p]
+        self.l.orc_api_opt_new.restype = C.c_void_p
+        self.l.orc_api_align1_batch.restype = C.c_int64
+        self.opt = C.c_void_p(self.l.orc_api_opt_new())
+
+    def idx_load(self, prefix):
+        h = self.l.orc_idx_load(prefix.encode())
+        if not h:
+            raise RuntimeError("oracle: cannot load index " + prefix)
+        return C.c_void_p(h)
+
+    def idx_build(self, fasta, save=True):
+        h = self.l.orc_idx_build_fasta(fasta.encode())
+        if not h:
+            raise RuntimeError("oracle: cannot build index from " + fasta)
+        h = C.c_void_p(h)
+        if save:
+            assert self.l.orc_idx_save(h, fasta.encode()) == 0
+        return h
+
+    def extend2(self, q, t, w, end_bonus, zdrop, h0):
+        out = (C.c_int * 6)()
+        self.l.orc_api_extend2(self.opt, C.c_int(len(q)), _ptr(q), C.c_int(len(t)), _ptr(t), C.c_int(w), C.c_int(end_bonus), C.c_int(zdrop), C.c_int(h0), out)
+        return tuple(out)
+
+    def align2(self, q, t, xtra):
+        out = (C.c_int * 7)()
+        self.l.orc_api_align2(self.opt, C.c_int(len(q)), _ptr(q), C.c_int(len(t)), _ptr(t), C.c_int(xtra), out)
+        return tuple(out)
+
+    def global2(self, q, t, w, cap=64):
+        n = C.c_int(0)
+        cig = np.zeros(cap, dtype=np.uint32)
+        sc = self.l.orc_api_global2(self.opt, C.c_int(len(q)), _ptr(q), C.c_int(len(t)), _ptr(t), C.c_int(w), C.byref(n), _ptr(cig), C.c_int(cap))
+        return sc, n.value, cig
+
+    def collect_intv(self, idx, seq, cap=4096):
+        out = np.zeros(cap, dtype=INTV_DT)
+        n = self.l.orc_api_collect_intv(self.opt, idx, C.c_int(len(seq)), _ptr(seq), _ptr(out), C.c_int(cap))
+        return out[:n]
+
+    def align1_batch(self, idx, seq, off):
+        n = len(off) - 1
+        reg_off = np.zeros(n + 1, dtype=np.int64)
+        cap = 64 * n + 1024
+        while True:
+            out = np.zeros(cap, dtype=ALNREG_DT)
+            tot = self.l.orc_api_align1_batch(self.opt, idx, C.c_int(n), _ptr(seq), _ptr(off), _ptr(reg_off), _ptr(out), C.c_int64(cap))
+            if tot <= cap:
+                return reg_off, out[:tot]
+            cap = tot

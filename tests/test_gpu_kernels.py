@@ -1,0 +1,34 @@
+"""GPU parity tests (HIP build on a real MI355X) against the oracle, through the C ABI."""
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_backend(gpu_lib):
+    assert gpu_lib.backend().startswith("hip")
+
+
+def test_gpu_extend(gpu_lib, oracle):
+    common.check_extend(gpu_lib, oracle, 3000, seed=11)
+
+
+def test_gpu_local(gpu_lib, oracle):
+    common.check_local(gpu_lib, oracle, 400, seed=12)
+
+
+def test_gpu_global(gpu_lib, oracle):
+    common.check_global(gpu_lib, oracle, 1000, seed=13)
+
+
+def test_gpu_smem(gpu_lib, oracle):
+    common.check_smem(gpu_lib, oracle, 2000, seed=14)
+
+
+def test_gpu_align1_150(gpu_lib, oracle):
+    assert common.check_align1(gpu_lib, oracle, 4000, seed=15) > 4000
+
+
+def test_gpu_align1_250(gpu_lib, oracle):
+    assert common.check_align1(gpu_lib, oracle, 1000, seed=16, read_len=250) > 1000
