@@ -56,7 +56,9 @@ SSG_DEVFN int ssg_chain_weight(const ssg_chain_t &c, const ssg_seed_t *seeds)
 
 struct ssg_chain_key_lt {
 	const ssg_chain_t *c;
-	SSG_DEVMEM bool operator()(int a, int b) const { return c[a].pos < c[b].pos || (c[a].pos == c[b].pos && c[a].sec < c[b].sec); }
+	/* branch-free on purpose: hipcc -O3 (ROCm 7.2, gfx950) mis-compiles the short-circuit form when it is
+	 * inlined into ssg_introsort's partition loops (the wave never leaves the loop; tools/dbg/sorthang.cpp) */
+	SSG_DEVMEM bool operator()(int a, int b) const { int64_t pa = c[a].pos, pb = c[b].pos; int sa = c[a].sec, sb = c[b].sec; return (pa < pb) | ((pa == pb) & (sa < sb)); }
 };
 struct ssg_chain_w_lt {
 	const ssg_chain_t *c;
@@ -70,12 +72,12 @@ struct ssg_chain_w_lt {
  * order; for each, chains[id].first_seed is rewritten to an offset into chain_seeds[] (absolute
  * index) holding its n seed ids (absolute) in insertion order.
  */
-__global__ void ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads,
+__global__ void ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, ssg_seed_t *seeds, const int32_t *seed_rid,
-                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain)
+                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, int dbg_phase)
 {
-	long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
 	int len = (int)(read_off[r+1] - read_off[r]);
 	long s0 = seed_off[r]; int ns = (int)(seed_off[r+1] - s0);
@@ -122,8 +124,10 @@ __global__ void ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads,
 			++nc;
 		}
 	}
+	if (dbg_phase == 1) return;
 	for (i = 0; i < nc; ++i) ord[i] = i;
 	{ ssg_chain_key_lt lt = { ch }; ssg_introsort(ord, (long)nc, lt); } /* == B-tree in-order traversal (keys are unique) */
+	if (dbg_phase == 2) return;
 	float frac_rep = (float)l_rep / len;
 	/* upstream mem_chain_flt */
 	int n_chn = 0;
@@ -133,6 +137,7 @@ __global__ void ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads,
 		c.w = ssg_chain_weight(c, sd);
 		if (c.w >= opt.min_chain_weight) ord[n_chn++] = ord[i];
 	}
+	if (dbg_phase == 3) return;
 	int n_out = 0;
 	if (n_chn > 0) {
 		{ ssg_chain_w_lt lt = { ch }; ssg_introsort(ord, (long)n_chn, lt); }
@@ -167,6 +172,7 @@ __global__ void ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads,
 		for (; i < n_chn; ++i) if (ch[ord[i]].kept < 3) ch[ord[i]].kept = 0;
 		for (i = 0; i < n_chn; ++i) if (ch[ord[i]].kept != 0) ord[n_out++] = ord[i];
 	}
+	if (dbg_phase == 4) return;
 	/* flatten the seed lists of the surviving chains */
 	int pos = 0;
 	for (i = 0; i < n_out; ++i) {

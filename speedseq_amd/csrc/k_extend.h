@@ -53,7 +53,7 @@ struct ssg_u64_lt { SSG_DEVMEM bool operator()(uint64_t a, uint64_t b) const { r
 struct ssg_reg_re_lt { SSG_DEVMEM bool operator()(const ssg_alnreg_t &a, const ssg_alnreg_t &b) const { return a.re < b.re; } };
 struct ssg_reg_sc_lt {
 	SSG_DEVMEM bool operator()(const ssg_alnreg_t &a, const ssg_alnreg_t &b) const
-	{ return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb))); }
+	{ return (a.score > b.score) | ((a.score == b.score) & ((a.rb < b.rb) | ((a.rb == b.rb) & (a.qb < b.qb)))); } /* branch-free: see ssg_chain_key_lt */
 };
 
 #define SSG_PATCH_MAX_R_BW 0.05f
@@ -169,23 +169,17 @@ SSG_DEVFN int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem_opt_
  * ids), srt[] (u64 work array), regs[] (capacity = #seeds of the read).  n_reg[r] receives the
  * number of regions left after mem_sort_dedup_patch; err[r] != 0 flags a window overflow.
  */
-__global__ void ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
+SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
-                                uint8_t *tglb, int32_t *err, unsigned long long *cells)
+                                uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells)
 {
-	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
-	const int wslot = (int)(threadIdx.x >> 6);
-	const long wid = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
-	if (wid >= n_reads) return;
-	const long r = wid;
 	const uint8_t *query = seq + read_off[r];
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
 	const long s0 = seed_off[r];
 	const ssg_chain_t *ch = chains + s0; const int32_t *ord = order + s0;
 	uint64_t *srt = srt_all + s0;
 	ssg_alnreg_t *av = regs + s0;
-	uint8_t *tg = tglb + wid * (long)SSG_TWIN_GLB;
 	const int64_t l_pac = ix.l_pac;
 	int av_n = 0, myerr = 0;
 	unsigned long long nc = 0;
@@ -216,7 +210,7 @@ __global__ void ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_re
 			rmax[1] = rmax[1] < far_end ? rmax[1] : far_end;
 		}
 		const int span = (int)(rmax[1] - rmax[0]);
-		uint8_t *rseq = span <= SSG_TWIN_LDS ? tlds[wslot] : tg;
+		uint8_t *rseq = span <= SSG_TWIN_LDS ? tlds_w : tg;
 		if (span > SSG_TWIN_GLB) { myerr = 1; continue; }
 		wv_fetch_ref(ix, rmax[0], rmax[1], rseq);
 		SSG_LANE0(for (int t = 0; t < c.n; ++t) srt[t] = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
@@ -293,6 +287,23 @@ __global__ void ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_re
 		}
 	}
 	av_n = wv_sort_dedup_patch(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
-	if (wv_lane() == 0) { n_reg[r] = av_n; err[r] = myerr; if (cells) atomicAdd(cells, nc); }
+	if (wv_lane() == 0) { n_reg[r] = av_n; err[r] = myerr; }
+	*cells += nc;
+}
+
+/* grid-strided: every resident wavefront owns one LDS window and one SSG_TWIN_GLB slab of tglb */
+__global__ void ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
+                                const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
+                                const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
+                                uint8_t *tglb, int32_t *err, unsigned long long *cells)
+{
+	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
+	const int wslot = (int)(threadIdx.x >> 6);
+	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot, nwaves = (long)gridDim.x * (blockDim.x >> 6);
+	unsigned long long nc = 0;
+	for (long r = wave0; r < n_reads; r += nwaves)
+		wv_chain2aln_read(ix, opt, r, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
+		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc);
+	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);
 }
 #endif

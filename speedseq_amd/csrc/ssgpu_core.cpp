@@ -20,6 +20,10 @@
 
 thread_local std::string ssg_err_msg;
 
+/* wave-per-item kernels are grid-strided over at most this many 4-wave workgroups (256 CUs x 4),
+ * so per-wave scratch slabs are sized by residency, not by batch size */
+#define SSG_MAX_RESIDENT_WG 1024
+
 struct ssg_index {
 	ssg_index_view_t v;
 	uint32_t *bwt; uint64_t *sa; uint8_t *pac; int64_t *ctg_off; int32_t *ctg_len;
@@ -29,6 +33,9 @@ struct ssg_index {
 
 #define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CHKA(b) do { if (!(b).ok()) { ssg_err_msg = "device allocation failed: " #b; return SSG_ENOMEM; } } while (0)
+
+static int ssg_debug() { static int d = -1; if (d < 0) d = getenv("SSG_DEBUG") ? atoi(getenv("SSG_DEBUG")) : 0; return d; }
+#define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d\n", name, rc_); fflush(stderr); if (rc_) return rc_; } } while (0)
 
 static int need_device()
 {
@@ -258,9 +265,11 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	dbuf<ssg_intv_t> d_intv((size_t)n_reads * cap); dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
 	CHKA(d_intv); CHKA(d_nintv); CHKA(d_nseed);
 	CHK(run_smem(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv.p, d_nintv.p));
+	STAGE("smem");
 	const int block = 256;
 	SSG_LAUNCH(ssg_k_sal_count, (n_reads + block - 1) / block, block, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);
 	CHK(rt_sync());
+	STAGE("sal_count");
 	std::vector<int32_t> hns(n_reads);
 	CHK(d_nseed.down(hns.data(), n_reads));
 	o.h_seed_off.resize(n_reads + 1);
@@ -279,11 +288,13 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		long g = (long)n_reads * cap;
 		SSG_LAUNCH(ssg_k_sal, (g + block - 1) / block, block, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p);
 	}
-	SSG_LAUNCH(ssg_k_chain, (n_reads + 63) / 64, 64, 0, idx->v, *opt, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-	           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p);
+	STAGE("sal");
+	SSG_LAUNCH(ssg_k_chain, (n_reads + 63) / 64, 64, 0, idx->v, *opt, 0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+	           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, 0);
+	STAGE("chain");
 	{
 		const int wpb = SSG_WAVES_PER_WG;
-		long nwg = ((long)n_reads + wpb - 1) / wpb;
+		long nwg = std::min<long>(((long)n_reads + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
 		dbuf<uint8_t> d_tglb((size_t)nwg * wpb * SSG_TWIN_GLB);
 		CHKA(d_tglb);
 		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,

@@ -17,9 +17,13 @@ KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
 def mutate(rng, q, max_sub=8, max_indel=3):
     tl = list(q)
     for _ in range(int(rng.integers(0, max_sub))):
+        if not tl:
+            break
         p = int(rng.integers(0, len(tl)))
         tl[p] = (tl[p] + 1) % 4
     for _ in range(int(rng.integers(0, max_indel))):
+        if len(tl) < 2:
+            break
         p = int(rng.integers(0, len(tl)))
         if rng.random() < 0.5:
             del tl[p:p + int(rng.integers(1, 8))]
