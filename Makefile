@@ -8,16 +8,16 @@ HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -W
 all: lib oracle emu
 
 lib: speedseq_amd/libssgpu.so
-speedseq_amd/libssgpu.so: $(CSRC)/ssgpu_core.cpp $(KHDRS)
-	$(HIPCC) $(HIPFLAGS) -x hip $(CSRC)/ssgpu_core.cpp -shared -o $@
+speedseq_amd/libssgpu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
+	$(HIPCC) $(HIPFLAGS) -x hip $(CSRC)/ssgpu_core.cpp -x c++ $(CSRC)/sam_format.cpp -shared -o $@
 
 oracle:
 	$(MAKE) -C oracle
 
 emu: tests/emu/libssgpu_emu.so
-tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
+tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
-		$(CSRC)/ssgpu_core.cpp tests/emu/emu.cpp -shared -o $@ -lpthread
+		$(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread
 
 clean:
 	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so

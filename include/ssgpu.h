@@ -79,6 +79,37 @@ int ssg_smem_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads
 int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
                      int64_t *reg_off, ssg_alnreg_t **regs, uint64_t stats[8]);
 
+/* ---- the whole `bwa mem` paired-end hot path for a batch of pairs ----
+ * upstream mem_process_seqs() (bwamem.c): worker1 = mem_align1_core per read, mem_pestat per
+ * upstream batch, worker2 = mem_sam_pe per pair (rows a1-a12).
+ *   seq/off     2*n_pairs reads (read1, read2 interleaved), nt4 codes, off[2*n_pairs+1]
+ *   pair_batch  upstream batch index of every pair (insert-size statistics are per batch, row a9);
+ *               batches are what `bwa mem -t N` would have formed (chunk_size*N bases, even count)
+ *   id0         ordinal of the first pair in the whole input (upstream n_processed>>1; feeds the
+ *               tie-breaking hash of mem_mark_primary_se / mem_pair)
+ *   pes0        NULL to infer insert sizes, or 4 orientation entries as from `-I`
+ * The result holds, per read, the SAM records to print (main records first, then XA entries). */
+typedef struct ssg_pe_result ssg_pe_result_t;
+int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
+                          const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out);
+void ssg_pe_result_free(ssg_pe_result_t *r);
+int64_t ssg_pe_n_req(const ssg_pe_result_t *r);
+const int64_t *ssg_pe_req_off(const ssg_pe_result_t *r);          /* 2*n_pairs+1 offsets into req/alns */
+const ssg_alnreq_t *ssg_pe_req(const ssg_pe_result_t *r);     /* kind 0 = SAM record, 1 = XA entry (owner = region) */
+const ssg_aln_t *ssg_pe_alns(const ssg_pe_result_t *r);
+const ssg_pestat_t *ssg_pe_pes(const ssg_pe_result_t *r);         /* n_batches x 4 (FF, FR, RF, RR) */
+const uint64_t *ssg_pe_stats(const ssg_pe_result_t *r);           /* [0] seeds [1] extension cells [2] rescue cells [3] rescues [4] records */
+
+/* upstream mem_aln2sam() (bwamem.c; row a13): SAM text for every read of the batch, in input order.
+ * names/quals/comments: one C string per read (quals/comments entries may be NULL).  *sam is
+ * malloc'd (release with ssg_free); sam_off[2*n_pairs+1] delimits each read's lines. */
+int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
+                   const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                   const char *rg_id, char **sam, int64_t *sam_off);
+int ssg_index_set_names(ssg_index_t *idx, int n, const char *const *names);
+const char *ssg_index_name(const ssg_index_t *idx, int i);
+int32_t ssg_index_len(const ssg_index_t *idx, int i);
+
 void ssg_free(void *p);
 
 #ifdef __cplusplus

@@ -77,3 +77,26 @@ void orc_api_align2(const orc_opt_t *opt, int qlen, const uint8_t *q, int tlen, 
 	out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.score2; out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
 	free(qc); free(tc);
 }
+
+/* mem_process_seqs (PE) for one upstream batch; returns a malloc'd buffer with the SAM lines of all
+ * reads in input order and fills sam_off[2*n_pairs+1]; pes_out receives the 4 insert-size models */
+char *orc_api_process_pairs(const orc_opt_t *opt, const orc_idx_t *idx, int n_pairs, const uint8_t *seq, const int64_t *off,
+                            const char **names, const char **quals, int64_t n_processed, const char *rg_id, int n_threads,
+                            const orc_pestat_t *pes0, orc_pestat_t *pes_out, int64_t *sam_off)
+{
+	int n = 2 * n_pairs;
+	orc_read_t *s = calloc(n, sizeof(orc_read_t));
+	for (int i = 0; i < n; ++i) {
+		s[i].l_seq = (int)(off[i+1] - off[i]);
+		s[i].seq = malloc(s[i].l_seq + 1); memcpy(s[i].seq, seq + off[i], s[i].l_seq);
+		s[i].name = (char*)names[i]; s[i].qual = quals ? (char*)quals[i] : 0; s[i].comment = 0;
+	}
+	orc_mem_process_pairs(opt, idx, n_processed, n, s, pes0, rg_id, pes_out, n_threads);
+	size_t tot = 0;
+	for (int i = 0; i < n; ++i) tot += strlen(s[i].sam);
+	char *buf = malloc(tot + 1); size_t l = 0;
+	for (int i = 0; i < n; ++i) { size_t k = strlen(s[i].sam); sam_off[i] = (int64_t)l; memcpy(buf + l, s[i].sam, k); l += k; free(s[i].sam); free(s[i].seq); }
+	sam_off[n] = (int64_t)l; buf[l] = 0;
+	free(s);
+	return buf;
+}

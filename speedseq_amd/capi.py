@@ -132,3 +132,65 @@ class Lib:
         regs = np.frombuffer(buf, dtype=ALNREG_DT, count=tot).copy()
         self.l.ssg_free(regs_p)
         return reg_off, regs, stats
+
+
+ALNREQ_DT = np.dtype([("read", "i4"), ("reg", "i4"), ("kind", "i4"), ("owner", "i4"), ("flag", "i4"), ("mapq", "i4"), ("_p0", "i4"), ("_p1", "i4")])
+ALN_DT = np.dtype([("pos", "i8"), ("rid", "i4"), ("flag", "i4"), ("mapq", "i4"), ("NM", "i4"), ("score", "i4"), ("sub", "i4"), ("n_cigar", "i4"),
+                   ("is_rev", "i4"), ("l_md", "i4"), ("reg_idx", "i4"), ("xa_cnt", "i4"), ("_pad", "i4"), ("cigar", "u4", (64,)), ("md", "S320")])
+
+
+class PeResult:
+    """Owner of an ssg_pe_result_t (records of one ssg_mem_process_pairs call)."""
+
+    def __init__(self, lib, handle, n_pairs, n_batches):
+        self.lib, self.h, self.n_pairs, self.n_batches = lib, handle, n_pairs, n_batches
+        l = lib.l
+        n = l.ssg_pe_n_req(handle)
+        self.req_off = np.ctypeslib.as_array(C.cast(l.ssg_pe_req_off(handle), C.POINTER(C.c_int64)), shape=(2 * n_pairs + 1,)).copy()
+        self.req = np.frombuffer((C.c_char * (n * ALNREQ_DT.itemsize)).from_address(l.ssg_pe_req(handle)), dtype=ALNREQ_DT, count=n).copy() if n else np.zeros(0, ALNREQ_DT)
+        self.alns = np.frombuffer((C.c_char * (n * ALN_DT.itemsize)).from_address(l.ssg_pe_alns(handle)), dtype=ALN_DT, count=n).copy() if n else np.zeros(0, ALN_DT)
+        self.pes = np.frombuffer((C.c_char * (n_batches * 4 * PESTAT_DT.itemsize)).from_address(l.ssg_pe_pes(handle)), dtype=PESTAT_DT, count=n_batches * 4).copy()
+        self.stats = np.ctypeslib.as_array(C.cast(l.ssg_pe_stats(handle), C.POINTER(C.c_uint64)), shape=(8,)).copy()
+
+    def close(self):
+        if self.h:
+            self.lib.l.ssg_pe_result_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _bind_pe(lib):
+    l = lib.l
+    l.ssg_pe_n_req.restype = C.c_int64
+    for f in ("ssg_pe_req_off", "ssg_pe_req", "ssg_pe_alns", "ssg_pe_pes", "ssg_pe_stats"):
+        getattr(l, f).restype = C.c_void_p
+        getattr(l, f).argtypes = [C.c_void_p]
+    l.ssg_pe_n_req.argtypes = [C.c_void_p]
+    l.ssg_pe_result_free.argtypes = [C.c_void_p]
+
+
+def mem_process_pairs(lib, idx, opt, seq, off, pair_batch=None, n_batches=1, id0=0, pes0=None):
+    _bind_pe(lib)
+    n_pairs = (len(off) - 1) // 2
+    if pair_batch is None:
+        pair_batch = np.zeros(n_pairs, dtype=np.int32)
+    pair_batch = np.ascontiguousarray(pair_batch, dtype=np.int32)
+    h = C.c_void_p()
+    p0 = _ptr(pes0) if pes0 is not None else None
+    lib._chk(lib.l.ssg_mem_process_pairs(idx, _ptr(opt), C.c_int(n_pairs), _ptr(seq), _ptr(off), _ptr(pair_batch), C.c_int(n_batches),
+                                         C.c_int64(id0), p0, C.byref(h)))
+    return PeResult(lib, h, n_pairs, n_batches)
+
+
+def sam_format(lib, idx, opt, res, names, seq, off, quals=None, rg_id=""):
+    n = 2 * res.n_pairs
+    NA = (C.c_char_p * n)(*[s.encode() for s in names])
+    QA = (C.c_char_p * n)(*[s.encode() for s in quals]) if quals is not None else None
+    sam = C.c_char_p()
+    sam_off = np.zeros(n + 1, dtype=np.int64)
+    lib._chk(lib.l.ssg_sam_format(idx, _ptr(opt), res.h, C.c_int(res.n_pairs), NA, _ptr(seq), _ptr(off), QA, None, rg_id.encode(), C.byref(sam), _ptr(sam_off)))
+    text = C.string_at(sam, int(sam_off[n])).decode()
+    lib.l.ssg_free(sam)
+    return text, sam_off

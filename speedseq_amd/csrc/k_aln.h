@@ -1,0 +1,153 @@
+/*
+ * k_aln.h -- gfx950 kernel turning alignment requests into SAM-ready records:
+ * upstream mem_reg2aln -> bwa_gen_cigar2 -> ksw_global2 (+ NM / MD).  One wavefront per request
+ * (grid-strided): the banded global DP rows run lane-parallel (k_sw.h), the backtrace and the
+ * NM/MD walk are short serial epilogues on lane 0; the direction matrix lives in a per-wave slab.
+ */
+#ifndef SSG_K_ALN_H
+#define SSG_K_ALN_H
+#include "k_pair.h"
+
+#define SSG_Z_CAP (192 * 1024)   /* backtrack bytes per resident wave */
+
+SSG_DEVFN int ssg_infer_bw(int l1, int l2, int score, int a, int q, int r)
+{	/* upstream infer_bw */
+	int w;
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+	if (w < iabs(l1 - l2)) w = iabs(l1 - l2);
+	return w;
+}
+
+SSG_DEVFN int ssg_put_int(char *s, int l, int cap, int v)
+{
+	char b[12]; int n = 0;
+	if (v == 0) b[n++] = '0';
+	while (v > 0) { b[n++] = (char)('0' + v % 10); v /= 10; }
+	while (n > 0) { if (l < cap) s[l] = b[n-1]; ++l; --n; }
+	return l;
+}
+
+/* upstream bwa_gen_cigar2 for one region; fills out->cigar/n_cigar/NM/md; returns the score */
+SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, int w_, int l_query, const uint8_t *query, int64_t rb, int64_t re,
+                           uint8_t *tbuf, uint8_t *z, ssg_aln_t *out, int *err, unsigned long long *cells)
+{
+	const int rlen = (int)(re - rb);
+	int score = 0, n_cigar = 0;
+	wv_fetch_ref(ix, rb, re, tbuf);
+	const bool rev = rb >= ix.l_pac;
+	ssg_seqv_t q = { rev ? query + l_query - 1 : query, rev ? -1 : 1 };
+	ssg_seqv_t t = { rev ? tbuf + rlen - 1 : tbuf, rev ? -1 : 1 };
+	if (l_query == rlen && w_ == 0) {
+		int sc = 0;
+		for (int i = wv_lane(); i < l_query; i += 64) sc += opt.mat[sq_at(t, i) * 5 + sq_at(q, i)];
+		score = wv_sum(sc);
+		SSG_LANE0(out->cigar[0] = (uint32_t)l_query << 4 | 0);
+		n_cigar = 1;
+	} else {
+		int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+		int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+		int max_gap = max_ins > max_del ? max_ins : max_del;
+		max_gap = max_gap > 1 ? max_gap : 1;
+		int w = (max_gap + iabs(rlen - l_query) + 1) >> 1;
+		w = w < w_ ? w : w_;
+		int min_w = iabs(rlen - l_query) + 3;
+		w = w > min_w ? w : min_w;
+		const long ncol = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
+		if (ncol * rlen > SSG_Z_CAP) { *err = 5; return 0; }
+		score = wv_global2_any(opt, l_query, q, rlen, t, w, z, cells);
+		int nc = 0;
+		SSG_LANE0(nc = ssg_global_backtrace(z, l_query, rlen, w, out->cigar, SSG_MAX_CIGAR));
+		n_cigar = wv_bcast(nc, 0);
+		if (n_cigar > SSG_MAX_CIGAR - 2) { *err = 6; n_cigar = SSG_MAX_CIGAR - 2; }
+	}
+	/* NM and MD (lane 0) */
+	int nm = 0, lmd = 0;
+	SSG_LANE0(
+		int k, x, y, u, n_mm = 0, n_gap = 0, l = 0;
+		const char *int2base = rb < ix.l_pac ? "ACGTN" : "TGCAN";
+		for (k = 0, x = y = u = 0; k < n_cigar; ++k) {
+			int op = out->cigar[k] & 0xf, len = (int)(out->cigar[k] >> 4);
+			if (op == 0) {
+				for (int i = 0; i < len; ++i) {
+					int tb = sq_at(t, y + i);
+					if (sq_at(q, x + i) != tb) { l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) out->md[l] = int2base[tb]; ++l; ++n_mm; u = 0; }
+					else ++u;
+				}
+				x += len; y += len;
+			} else if (op == 2) {
+				if (k > 0 && k < n_cigar - 1) {
+					l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) out->md[l] = '^'; ++l;
+					for (int i = 0; i < len; ++i) { if (l < SSG_MAX_MD - 1) out->md[l] = int2base[sq_at(t, y + i)]; ++l; }
+					u = 0; n_gap += len;
+				}
+				y += len;
+			} else if (op == 1) { x += len; n_gap += len; }
+		}
+		l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u);
+		out->md[l < SSG_MAX_MD - 1 ? l : SSG_MAX_MD - 1] = 0;
+		nm = n_mm + n_gap; lmd = l);
+	nm = wv_bcast(nm, 0); lmd = wv_bcast(lmd, 0);
+	if (lmd >= SSG_MAX_MD - 1) *err = 7;
+	SSG_LANE0(out->n_cigar = n_cigar; out->NM = nm; out->l_md = lmd);
+	return score;
+}
+
+__global__ void ssg_k_reg2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
+                              const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, uint8_t *tglb, uint8_t *zglb, int32_t *err, unsigned long long *cells)
+{
+	const int wslot = (int)(threadIdx.x >> 6);
+	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot, nwaves = (long)gridDim.x * (blockDim.x >> 6);
+	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB, *z = zglb + wave0 * (long)SSG_Z_CAP;
+	unsigned long long nc = 0;
+	int myerr = 0;
+	for (long g = wave0; g < n_req; g += nwaves) {
+		const ssg_alnreq_t rq = req[g];
+		ssg_aln_t *a = alns + g;
+		if (rq.reg < 0) { /* upstream mem_reg2aln(ar == 0) */
+			SSG_LANE0(a->pos = -1; a->rid = -1; a->flag = rq.flag | 0x4; a->mapq = 0; a->NM = 0; a->score = 0; a->sub = 0; a->n_cigar = 0;
+			          a->is_rev = 0; a->l_md = 0; a->reg_idx = -1; a->xa_cnt = 0; a->md[0] = 0);
+			continue;
+		}
+		const ssg_alnreg_t ar = regs[rq.reg];
+		const uint8_t *query = seq + read_off[rq.read];
+		const int l_query = (int)(read_off[rq.read + 1] - read_off[rq.read]);
+		int i, w2, tmp, qb = ar.qb, qe = ar.qe, score = 0, last_sc = -(1 << 30), is_rev;
+		int64_t rb = ar.rb, re = ar.re, pos;
+		if (re - rb > SSG_TWIN_GLB || rb < 0 || re > ix.l_pac << 1 || rb >= re || (rb < ix.l_pac && re > ix.l_pac)) { myerr = 8; continue; }
+		tmp = ssg_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
+		w2  = ssg_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+		w2 = w2 > tmp ? w2 : tmp;
+		if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+		i = 0;
+		do {
+			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+			score = wv_gen_cigar(ix, opt, w2, qe - qb, query + qb, rb, re, tg, z, a, &myerr, &nc);
+			if (score == last_sc || w2 == opt.w << 2) break;
+			last_sc = score;
+			w2 <<= 1;
+		} while (++i < 3 && score < ar.truesc - opt.a);
+		pos = ssg_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+		SSG_LANE0(
+			int n_cigar = a->n_cigar;
+			if (n_cigar > 0) { /* squeeze out a leading or trailing deletion */
+				if ((a->cigar[0] & 0xf) == 2) { pos += a->cigar[0] >> 4; --n_cigar; for (int k = 0; k < n_cigar; ++k) a->cigar[k] = a->cigar[k+1]; }
+				else if ((a->cigar[n_cigar-1] & 0xf) == 2) --n_cigar;
+			}
+			if (qb != 0 || qe != l_query) {
+				int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+				if (clip5) { for (int k = n_cigar; k > 0; --k) a->cigar[k] = a->cigar[k-1]; a->cigar[0] = (uint32_t)clip5 << 4 | 3; ++n_cigar; }
+				if (clip3) a->cigar[n_cigar++] = (uint32_t)clip3 << 4 | 3;
+			}
+			a->n_cigar = n_cigar;
+			a->rid = ssg_pos2rid(ix, pos);
+			a->pos = pos - ix.ctg_off[a->rid];
+			a->is_rev = is_rev;
+			a->flag = rq.flag | (ar.secondary >= 0 ? 0x100 : 0);
+			a->mapq = rq.mapq;
+			a->score = ar.score; a->sub = ar.sub > ar.csub ? ar.sub : ar.csub;
+			a->reg_idx = rq.owner; a->xa_cnt = 0; a->_pad = rq.kind);
+	}
+	if (wv_lane() == 0) { if (cells) atomicAdd(cells, nc); if (myerr) atomicMax(err, myerr); }
+}
+#endif

@@ -1,0 +1,96 @@
+/*
+ * k_misc.h -- small data-movement kernels between pipeline stages (HBM streaming, one lane per item).
+ */
+#ifndef SSG_K_MISC_H
+#define SSG_K_MISC_H
+#include "k_pair.h"
+
+/* copy each read's region list into its (larger) slice of the pairing-stage array */
+__global__ void ssg_k_copy_regs(int n_reads, const int64_t *src_off, const ssg_alnreg_t *src, const int32_t *n_reg, const int64_t *dst_off, ssg_alnreg_t *dst)
+{
+	long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const ssg_alnreg_t *s = src + src_off[r]; ssg_alnreg_t *d = dst + dst_off[r];
+	for (int i = 0; i < n_reg[r]; ++i) d[i] = s[i];
+}
+
+/* gather each read's requests into a dense array */
+__global__ void ssg_k_compact_req(int n_reads, const int64_t *src_off, const ssg_alnreq_t *src, const int32_t *n_req, const int64_t *dst_off, ssg_alnreq_t *dst)
+{
+	long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const ssg_alnreq_t *s = src + src_off[r]; ssg_alnreq_t *d = dst + dst_off[r];
+	for (int i = 0; i < n_req[r]; ++i) d[i] = s[i];
+}
+
+/* ---------------- duplicate marking (upstream samblaster, row a14) ---------------- */
+/* primary record of one end as samblaster sees it */
+typedef struct { int32_t seq, pos, flag, lclip, rclip, ralen; } ssg_sbl_end_t;
+typedef struct { uint64_t k0, k1, k2; } ssg_sig_t;
+
+SSG_DEVFN uint64_t ssg_mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+
+/* one lane per pair: 5'-unclipped signature (oracle/orc_samblaster.c header) + 64-bit hash */
+__global__ void ssg_k_sig(long n_pairs, const ssg_sbl_end_t *ends, ssg_sig_t *sig, uint64_t *hash, uint32_t *ord)
+{
+	long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_pairs) return;
+	uint64_t k[2][3]; int m[2];
+	for (int e = 0; e < 2; ++e) {
+		const ssg_sbl_end_t x = ends[2*p + e];
+		m[e] = !(x.flag & 0x4) && x.seq >= 0;
+		uint64_t strand = (x.flag & 0x10) ? 1 : 0;
+		int64_t q = strand ? (int64_t)x.pos + x.ralen - 1 + x.rclip : (int64_t)x.pos - x.lclip;
+		k[e][0] = (uint64_t)(uint32_t)x.seq; k[e][1] = (uint64_t)(q + (1LL << 31)); k[e][2] = strand;
+	}
+	ssg_sig_t s;
+	if (m[0] && m[1]) {
+		int swap = k[0][0] > k[1][0] || (k[0][0] == k[1][0] && (k[0][1] > k[1][1] || (k[0][1] == k[1][1] && k[0][2] > k[1][2])));
+		const uint64_t *lo = swap ? k[1] : k[0], *hi = swap ? k[0] : k[1];
+		s.k0 = lo[0] << 32 | hi[0]; s.k1 = lo[1] << 1 | lo[2]; s.k2 = hi[1] << 1 | hi[2];
+	} else if (m[0] || m[1]) {
+		const uint64_t *a = m[0] ? k[0] : k[1];
+		s.k0 = a[0]; s.k1 = a[1] << 1 | a[2]; s.k2 = 0;
+	} else { s.k0 = s.k1 = s.k2 = ~0ull; } /* never a duplicate */
+	sig[p] = s;
+	hash[p] = (m[0] || m[1]) ? ssg_mix64(s.k0 ^ ssg_mix64(s.k1 ^ ssg_mix64(s.k2))) : ~0ull - (uint64_t)p;
+	ord[p] = (uint32_t)p;
+}
+
+/*
+ * After a STABLE sort of (hash, ordinal) by hash: element i is a duplicate iff an earlier element of
+ * its equal-hash run (smaller ordinal, because the sort is stable) carries the identical signature,
+ * or the signature is already present in the table of previous calls (old_hash sorted, old_sig).
+ */
+__global__ void ssg_k_markdup(long n, const uint64_t *hash_sorted, const uint32_t *ord_sorted, const ssg_sig_t *sig,
+                              long n_old, const uint64_t *old_hash, const ssg_sig_t *old_sig, uint8_t *dup)
+{
+	long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t h = hash_sorted[i]; const uint32_t o = ord_sorted[i];
+	const ssg_sig_t s = sig[o];
+	int d = 0;
+	if (!(s.k0 == ~0ull && s.k1 == ~0ull && s.k2 == ~0ull)) {
+		for (long j = i - 1; j >= 0 && hash_sorted[j] == h && !d; --j) {
+			const ssg_sig_t t = sig[ord_sorted[j]];
+			d = (t.k0 == s.k0) & (t.k1 == s.k1) & (t.k2 == s.k2);
+		}
+		if (!d && n_old > 0) { /* lower bound in the persistent table */
+			long lo = 0, hi = n_old;
+			while (lo < hi) { long mid = (lo + hi) >> 1; if (old_hash[mid] < h) lo = mid + 1; else hi = mid; }
+			for (long j = lo; j < n_old && old_hash[j] == h && !d; ++j) {
+				const ssg_sig_t t = old_sig[j];
+				d = (t.k0 == s.k0) & (t.k1 == s.k1) & (t.k2 == s.k2);
+			}
+		}
+	}
+	dup[o] = (uint8_t)d;
+}
+
+/* gather signatures in sorted order (to extend the persistent table) */
+__global__ void ssg_k_gather_sig(long n, const uint32_t *ord_sorted, const ssg_sig_t *sig, ssg_sig_t *out)
+{
+	long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = sig[ord_sorted[i]];
+}
+#endif

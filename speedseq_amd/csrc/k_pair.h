@@ -18,12 +18,6 @@
 #include <math.h>
 #include "k_extend.h"
 
-/* one SAM record to generate (main record or an XA entry) */
-typedef struct {
-	int32_t read, reg, kind, owner, flag, mapq, _pad0, _pad1;
-} ssg_alnreq_t;
-#define SSG_REQ_MAIN 0
-#define SSG_REQ_XA   1
 
 SSG_DEVFN int ssg_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)
 {	/* upstream mem_infer_dir */

@@ -1,0 +1,175 @@
+/*
+ * sam_format.cpp -- host side of the hot path's output boundary: SAM text from the device-produced
+ * alignment records (upstream mem_aln2sam / mem_reg2sam's printing half and mem_gen_alt's XA
+ * strings, bwamem.c / bwamem_extra.c).  Pure text assembly: every number it
+ * prints was computed on the GPU.
+ */
+#include <string>
+#include <vector>
+#include <string.h>
+#include <stdlib.h>
+#include "../../include/ssgpu.h"
+
+namespace {
+struct sbuf {
+	std::string s;
+	void putl(long long v) { char b[24]; int n = snprintf(b, sizeof(b), "%lld", v); s.append(b, n); }
+	void putc(char c) { s.push_back(c); }
+	void puts(const char *p) { s.append(p); }
+};
+
+inline int get_rlen(int n_cigar, const uint32_t *cigar)
+{
+	int l = 0;
+	for (int k = 0; k < n_cigar; ++k) { int op = cigar[k] & 0xf; if (op == 0 || op == 2) l += cigar[k] >> 4; }
+	return l;
+}
+
+/* the mate as mem_aln2sam sees it (a private copy it may rewrite) */
+struct mate_t { int rid; long long pos; int is_rev, n_cigar; const uint32_t *cigar; };
+
+void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, const uint8_t *seq, const char *qual, const char *comment,
+             int n, const ssg_aln_t *const *list, int which, const mate_t *m_, const std::string *XA, const char *rg_id)
+{	/* upstream mem_aln2sam */
+	const ssg_aln_t &a = *list[which];
+	int flag = a.flag, rid = a.rid, is_rev = a.is_rev, n_cigar = a.n_cigar; long long pos = a.pos;
+	mate_t mt, *m = 0;
+	if (m_) { mt = *m_; m = &mt; }
+	flag |= m ? 0x1 : 0;
+	flag |= rid < 0 ? 0x4 : 0;
+	flag |= m && m->rid < 0 ? 0x8 : 0;
+	if (rid < 0 && m && m->rid >= 0) { rid = m->rid; pos = m->pos; is_rev = m->is_rev; n_cigar = 0; }
+	if (m && m->rid < 0 && rid >= 0) { m->rid = rid; m->pos = pos; m->is_rev = is_rev; m->n_cigar = 0; }
+	flag |= is_rev ? 0x10 : 0;
+	flag |= m && m->is_rev ? 0x20 : 0;
+	str.puts(name); str.putc('\t');
+	str.putl((flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); str.putc('\t');
+	if (rid >= 0) {
+		str.puts(ssg_index_name(idx, rid)); str.putc('\t');
+		str.putl(pos + 1); str.putc('\t');
+		str.putl(a.mapq); str.putc('\t');
+		if (n_cigar) {
+			for (int i = 0; i < n_cigar; ++i) {
+				int c = a.cigar[i] & 0xf;
+				if (c == 3 || c == 4) c = which ? 4 : 3;
+				str.putl(a.cigar[i] >> 4); str.putc("MIDSH"[c]);
+			}
+		} else str.putc('*');
+	} else str.puts("*\t0\t0\t*");
+	str.putc('\t');
+	if (m && m->rid >= 0) {
+		if (rid == m->rid) str.putc('='); else str.puts(ssg_index_name(idx, m->rid));
+		str.putc('\t');
+		str.putl(m->pos + 1); str.putc('\t');
+		if (rid == m->rid) {
+			long long p0 = pos + (is_rev ? get_rlen(n_cigar, a.cigar) - 1 : 0);
+			long long p1 = m->pos + (m->is_rev ? get_rlen(m->n_cigar, m->cigar) - 1 : 0);
+			if (m->n_cigar == 0 || n_cigar == 0) str.putc('0');
+			else str.putl(-(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
+		} else str.putc('0');
+	} else str.puts("*\t0\t0");
+	str.putc('\t');
+	if (flag & 0x100) str.puts("*\t*");
+	else if (!is_rev) {
+		int qb = 0, qe = l_seq;
+		if (n_cigar && which) {
+			if ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3) qb += a.cigar[0] >> 4;
+			if ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3) qe -= a.cigar[n_cigar-1] >> 4;
+		}
+		for (int i = qb; i < qe; ++i) str.putc("ACGTN"[seq[i]]);
+		str.putc('\t');
+		if (qual) str.s.append(qual + qb, qe - qb); else str.putc('*');
+	} else {
+		int qb = 0, qe = l_seq;
+		if (n_cigar && which) {
+			if ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3) qe -= a.cigar[0] >> 4;
+			if ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3) qb += a.cigar[n_cigar-1] >> 4;
+		}
+		for (int i = qe - 1; i >= qb; --i) str.putc("TGCAN"[seq[i]]);
+		str.putc('\t');
+		if (qual) for (int i = qe - 1; i >= qb; --i) str.putc(qual[i]); else str.putc('*');
+	}
+	if (n_cigar) {
+		str.puts("\tNM:i:"); str.putl(a.NM);
+		str.puts("\tMD:Z:"); str.s.append(a.md, a.l_md);
+	}
+	if (a.score >= 0) { str.puts("\tAS:i:"); str.putl(a.score); }
+	if (a.sub >= 0) { str.puts("\tXS:i:"); str.putl(a.sub); }
+	if (rg_id && rg_id[0]) { str.puts("\tRG:Z:"); str.puts(rg_id); }
+	if (!(flag & 0x100)) {
+		int i;
+		for (i = 0; i < n; ++i) if (i != which && !(list[i]->flag & 0x100)) break;
+		if (i < n) {
+			str.puts("\tSA:Z:");
+			for (i = 0; i < n; ++i) {
+				const ssg_aln_t &r = *list[i];
+				if (i == which || (r.flag & 0x100)) continue;
+				str.puts(ssg_index_name(idx, r.rid)); str.putc(',');
+				str.putl(r.pos + 1); str.putc(',');
+				str.putc("+-"[r.is_rev]); str.putc(',');
+				for (int k = 0; k < r.n_cigar; ++k) { str.putl(r.cigar[k] >> 4); str.putc("MIDSH"[r.cigar[k] & 0xf]); }
+				str.putc(','); str.putl(r.mapq);
+				str.putc(','); str.putl(r.NM);
+				str.putc(';');
+			}
+		}
+	}
+	if (XA && !XA->empty()) { str.puts("\tXA:Z:"); str.s.append(*XA); }
+	if (comment) { str.putc('\t'); str.puts(comment); }
+	str.putc('\n');
+}
+} // namespace
+
+extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
+                              const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                              const char *rg_id, char **sam, int64_t *sam_off)
+{
+	(void)opt;
+	const int64_t *req_off = ssg_pe_req_off(res);
+	const ssg_alnreq_t *req = ssg_pe_req(res);
+	const ssg_aln_t *alns = ssg_pe_alns(res);
+	sbuf out;
+	std::vector<const ssg_aln_t*> mains[2];
+	std::vector<std::string> xa[2];
+	ssg_aln_t unmapped; memset(&unmapped, 0, sizeof(unmapped)); unmapped.rid = -1; unmapped.pos = -1;
+	for (int p = 0; p < n_pairs; ++p) {
+		mate_t mate[2];
+		for (int i = 0; i < 2; ++i) {
+			const int r = 2 * p + i;
+			mains[i].clear(); xa[i].clear();
+			std::vector<int> owner;
+			for (int64_t g = req_off[r]; g < req_off[r+1]; ++g) {
+				if (req[g].kind == SSG_REQ_MAIN) { mains[i].push_back(&alns[g]); owner.push_back(req[g].owner); xa[i].emplace_back(); }
+			}
+			for (int64_t g = req_off[r]; g < req_off[r+1]; ++g) {
+				if (req[g].kind != SSG_REQ_XA) continue;
+				const ssg_aln_t &t = alns[g];
+				for (size_t k = 0; k < owner.size(); ++k) {
+					if (owner[k] != req[g].owner || mains[i][k]->rid < 0) continue;
+					sbuf x;
+					x.puts(ssg_index_name(idx, t.rid)); x.putc(','); x.putc("+-"[t.is_rev]); x.putl(t.pos + 1); x.putc(',');
+					for (int c = 0; c < t.n_cigar; ++c) { x.putl(t.cigar[c] >> 4); x.putc("MIDSHN"[t.cigar[c] & 0xf]); }
+					x.putc(','); x.putl(t.NM); x.putc(';');
+					xa[i][k] += x.s;
+				}
+			}
+			if (mains[i].empty()) return SSG_EINVAL;
+			const ssg_aln_t &h = *mains[i][0];   /* the mate record the other end prints against */
+			mate[i].rid = h.rid; mate[i].pos = h.pos; mate[i].is_rev = h.is_rev; mate[i].n_cigar = h.n_cigar; mate[i].cigar = h.cigar;
+		}
+		for (int i = 0; i < 2; ++i) {
+			const int r = 2 * p + i;
+			sam_off[r] = (int64_t)out.s.size();
+			const int l_seq = (int)(off[r+1] - off[r]);
+			for (size_t k = 0; k < mains[i].size(); ++k)
+				aln2sam(idx, out, names[r], l_seq, seq + off[r], quals ? quals[r] : 0, comments ? comments[r] : 0,
+				        (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id);
+		}
+	}
+	sam_off[2 * n_pairs] = (int64_t)out.s.size();
+	char *buf = (char*)malloc(out.s.size() + 1);
+	if (!buf) return SSG_ENOMEM;
+	memcpy(buf, out.s.data(), out.s.size()); buf[out.s.size()] = 0;
+	*sam = buf;
+	return 0;
+}

@@ -70,6 +70,12 @@ typedef struct { int32_t qoff, qlen, toff, tlen, xtra, _pad; } ssg_sw_job_t;
 /* one ksw_global2 / bwa_gen_cigar2 job (a12) */
 typedef struct { int32_t qoff, qlen, toff, tlen, w, _pad; } ssg_glb_job_t;
 
+/* one SAM record to generate: a main record (primary / supplementary / unmapped) or an XA entry;
+ * `owner` = region index (within the read) of the main record the entry belongs to */
+typedef struct { int32_t read, reg, kind, owner, flag, mapq, _pad0, _pad1; } ssg_alnreq_t;
+#define SSG_REQ_MAIN 0
+#define SSG_REQ_XA   1
+
 /* final alignment record (upstream mem_aln_t + the SAM fields mem_aln2sam derives) */
 #define SSG_MAX_CIGAR 64
 #define SSG_MAX_MD    320

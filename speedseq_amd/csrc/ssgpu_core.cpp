@@ -9,6 +9,7 @@
  * dropped silently and nothing falls back to the CPU.
  */
 #include <vector>
+#include <memory>
 #include <algorithm>
 #include <math.h>
 #include "ssg_rt.h"
@@ -333,5 +334,179 @@ int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_rea
 	*regs = out;
 	return 0;
 }
+
+} /* extern "C" */
+
+/* ======================= paired-end stage (rows a9-a12) ======================= */
+#include "k_aln.h"
+#include "k_misc.h"
+
+/* upstream mem_pestat's statistics, from the per-orientation insert-size histogram.  The sorted
+ * isize array upstream walks is the histogram read in bin order, so every double-precision sum is
+ * accumulated in exactly upstream's order. */
+static void host_pestat(const ssg_mem_opt_t *opt, const uint32_t *hist /* [4][SSG_MAX_INS_HIST] */, ssg_pestat_t pes[4])
+{
+	uint64_t n[4]; int d, max = 0;
+	memset(pes, 0, 4 * sizeof(ssg_pestat_t));
+	for (d = 0; d < 4; ++d) {
+		const uint32_t *h = hist + (size_t)d * SSG_MAX_INS_HIST;
+		ssg_pestat_t *r = &pes[d];
+		n[d] = 0;
+		for (int v = 0; v < SSG_MAX_INS_HIST; ++v) n[d] += h[v];
+		if (n[d] < 10) { r->failed = 1; continue; }
+		auto kth = [&](uint64_t k) { uint64_t c = 0; for (int v = 0; v < SSG_MAX_INS_HIST; ++v) { c += h[v]; if (c > k) return v; } return SSG_MAX_INS_HIST - 1; };
+		int p25 = kth((uint64_t)(int)(.25 * n[d] + .499)), p75 = kth((uint64_t)(int)(.75 * n[d] + .499));
+		r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
+		if (r->low < 1) r->low = 1;
+		r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+		uint64_t x = 0; r->avg = 0;
+		for (int v = 0; v < SSG_MAX_INS_HIST; ++v) if (v >= r->low && v <= r->high) for (uint32_t c = 0; c < h[v]; ++c) { r->avg += v; ++x; }
+		r->avg /= (int)x;
+		r->std = 0;
+		for (int v = 0; v < SSG_MAX_INS_HIST; ++v) if (v >= r->low && v <= r->high) for (uint32_t c = 0; c < h[v]; ++c) r->std += (v - r->avg) * (v - r->avg);
+		r->std = sqrt(r->std / (int)x);
+		r->low  = (int)(p25 - 3.0 * (p75 - p25) + .499);
+		r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+		if (r->low  > r->avg - 4.0 * r->std) r->low  = (int)(r->avg - 4.0 * r->std + .499);
+		if (r->high < r->avg + 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
+		if (r->low < 1) r->low = 1;
+	}
+	for (d = 0; d < 4; ++d) max = max > (int)n[d] ? max : (int)n[d];
+	for (d = 0; d < 4; ++d) if (pes[d].failed == 0 && n[d] < max * 0.05) pes[d].failed = 1;
+}
+
+struct ssg_pe_result {
+	int n_reads, n_batches;
+	std::vector<int64_t> req_off;        /* n_reads + 1 */
+	std::vector<ssg_alnreq_t> req;
+	std::vector<ssg_aln_t> alns;
+	std::vector<ssg_pestat_t> pes;        /* n_batches * 4 */
+	uint64_t stats[8];
+};
+
+extern "C" {
+
+int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
+                          const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out)
+{
+	CHK(need_device());
+	*out = 0;
+	const int n_reads = 2 * n_pairs;
+	if (n_pairs <= 0 || n_batches <= 0) { ssg_err_msg = "ssg_mem_process_pairs: empty input"; return SSG_EINVAL; }
+	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
+	if (max_len > 254) { ssg_err_msg = "reads longer than 254 bases are outside this build's scope"; return SSG_EINVAL; }
+	for (int p = 0; p < n_pairs; ++p) if (pair_batch[p] < 0 || pair_batch[p] >= n_batches) { ssg_err_msg = "pair_batch out of range"; return SSG_EINVAL; }
+	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1); dbuf<int32_t> d_pb(n_pairs);
+	CHKA(d_seq); CHKA(d_off); CHKA(d_pb);
+	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1)); CHK(d_pb.up(pair_batch, n_pairs));
+	ssg_pe_result *res = new ssg_pe_result(); res->n_reads = n_reads; res->n_batches = n_batches; memset(res->stats, 0, sizeof(res->stats));
+	std::unique_ptr<ssg_pe_result> guard(res);
+	align1_dev_t a1;
+	CHK(run_align1(idx, opt, n_reads, d_seq.p, d_off.p, max_len, a1, res->stats));
+	const int block = 256;
+	/* ---- insert-size statistics ---- */
+	res->pes.resize((size_t)n_batches * 4);
+	if (pes0) { for (int b = 0; b < n_batches; ++b) memcpy(&res->pes[(size_t)b * 4], pes0, 4 * sizeof(ssg_pestat_t)); }
+	else {
+		dbuf<uint32_t> d_hist((size_t)n_batches * 4 * SSG_MAX_INS_HIST);
+		CHKA(d_hist); CHK(d_hist.zero());
+		SSG_LAUNCH(ssg_k_pestat_hist, (n_pairs + block - 1) / block, block, 0, idx->v, *opt, n_pairs, a1.seed_off.p, a1.regs.p, a1.n_reg.p, d_pb.p, d_hist.p);
+		CHK(rt_sync());
+		std::vector<uint32_t> hh((size_t)n_batches * 4 * SSG_MAX_INS_HIST);
+		CHK(d_hist.down(hh.data(), hh.size()));
+		for (int b = 0; b < n_batches; ++b) host_pestat(opt, hh.data() + (size_t)b * 4 * SSG_MAX_INS_HIST, &res->pes[(size_t)b * 4]);
+	}
+	STAGE("pestat");
+	dbuf<ssg_pestat_t> d_pes((size_t)n_batches * 4);
+	CHKA(d_pes); CHK(d_pes.up(res->pes.data(), res->pes.size()));
+	/* ---- pairing-stage region slices with head-room for rescued hits ---- */
+	std::vector<int32_t> hn(n_reads);
+	CHK(a1.n_reg.down(hn.data(), n_reads));
+	std::vector<int64_t> h_r2off(n_reads + 1), h_reqoff(n_reads + 1);
+	int64_t t2 = 0, tq = 0;
+	for (int r = 0; r < n_reads; ++r) {
+		int mate = r ^ 1;
+		int cap2 = hn[r] + 4 * std::min(hn[mate], opt->max_matesw) + 4;
+		h_r2off[r] = t2; t2 += cap2;
+		h_reqoff[r] = tq; tq += 2 * cap2 + 2;
+	}
+	h_r2off[n_reads] = t2; h_reqoff[n_reads] = tq;
+	dbuf<int64_t> d_r2off(n_reads + 1), d_reqoff(n_reads + 1); dbuf<ssg_alnreg_t> d_regs2((size_t)t2 + 1); dbuf<int32_t> d_perr(n_pairs), d_zbuf((size_t)t2 + 1), d_nreq(n_reads), d_gerr(1);
+	dbuf<unsigned long long> d_cnt(2);
+	CHKA(d_r2off); CHKA(d_reqoff); CHKA(d_regs2); CHKA(d_perr); CHKA(d_zbuf); CHKA(d_nreq); CHKA(d_cnt); CHKA(d_gerr);
+	CHK(d_r2off.up(h_r2off.data(), n_reads + 1)); CHK(d_reqoff.up(h_reqoff.data(), n_reads + 1)); CHK(d_perr.zero()); CHK(d_cnt.zero()); CHK(d_gerr.zero());
+	SSG_LAUNCH(ssg_k_copy_regs, (n_reads + block - 1) / block, block, 0, n_reads, a1.seed_off.p, a1.regs.p, a1.n_reg.p, d_r2off.p, d_regs2.p);
+	const int wpb = SSG_WAVES_PER_WG;
+	{	/* ---- mate rescue ---- */
+		long nwg = std::min<long>(((long)n_pairs + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
+		long nw = nwg * wpb;
+		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB); dbuf<unsigned long long> d_bglb((size_t)nw * SSG_MS_BCAP); dbuf<ssg_alnreg_t> d_bcopy((size_t)nw * 128);
+		CHKA(d_tglb); CHKA(d_bglb); CHKA(d_bcopy);
+		SSG_LAUNCH(ssg_k_matesw, nwg, wpb * 64, 0, idx->v, *opt, n_pairs, d_seq.p, d_off.p, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p,
+		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1);
+		CHK(rt_sync());
+	}
+	STAGE("matesw");
+	dbuf<ssg_alnreq_t> d_req((size_t)tq + 1);
+	CHKA(d_req);
+	{	/* ---- primary marking, pairing, MAPQ, record selection ---- */
+		const int ucap = 1024;
+		long nthr = std::min<long>(((long)n_pairs + 63) / 64 * 64, 32768);
+		dbuf<ssg_pair64_t> d_v((size_t)t2 + 1), d_u((size_t)nthr * ucap);
+		CHKA(d_v); CHKA(d_u);
+		SSG_LAUNCH(ssg_k_pair_final, nthr / 64, 64, 0, idx->v, *opt, n_pairs, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_u.p, ucap,
+		           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p);
+		CHK(rt_sync());
+	}
+	STAGE("pair_final");
+	{
+		std::vector<int32_t> perr(n_pairs);
+		CHK(d_perr.down(perr.data(), n_pairs));
+		for (int p = 0; p < n_pairs; ++p) if (perr[p]) { char b[128]; snprintf(b, sizeof(b), "pair %d exceeded an on-device capacity (code %d)", p, perr[p]); ssg_err_msg = b; return SSG_EOVERFLOW; }
+	}
+	/* ---- compact the requests and generate CIGAR / NM / MD ---- */
+	std::vector<int32_t> hnreq(n_reads);
+	CHK(d_nreq.down(hnreq.data(), n_reads));
+	res->req_off.resize(n_reads + 1);
+	int64_t nreq = 0;
+	for (int r = 0; r < n_reads; ++r) { res->req_off[r] = nreq; nreq += hnreq[r]; }
+	res->req_off[n_reads] = nreq;
+	dbuf<int64_t> d_coff(n_reads + 1); dbuf<ssg_alnreq_t> d_creq((size_t)nreq + 1); dbuf<ssg_aln_t> d_alns((size_t)nreq + 1);
+	CHKA(d_coff); CHKA(d_creq); CHKA(d_alns);
+	CHK(d_coff.up(res->req_off.data(), n_reads + 1));
+	SSG_LAUNCH(ssg_k_compact_req, (n_reads + block - 1) / block, block, 0, n_reads, d_reqoff.p, d_req.p, d_nreq.p, d_coff.p, d_creq.p);
+	{
+		long nwg = std::min<long>(((long)nreq + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
+		long nw = nwg * wpb;
+		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB), d_z((size_t)nw * SSG_Z_CAP);
+		CHKA(d_tglb); CHKA(d_z);
+		SSG_LAUNCH(ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p);
+		CHK(rt_sync());
+	}
+	STAGE("reg2aln");
+	{ int32_t ge; CHK(d_gerr.down(&ge, 1)); if (ge) { char b[96]; snprintf(b, sizeof(b), "CIGAR generation exceeded an on-device capacity (code %d)", ge); ssg_err_msg = b; return SSG_EOVERFLOW; } }
+	res->req.resize((size_t)nreq); res->alns.resize((size_t)nreq);
+	CHK(d_creq.down(res->req.data(), (size_t)nreq)); CHK(d_alns.down(res->alns.data(), (size_t)nreq));
+	{ unsigned long long c[2]; CHK(d_cnt.down(c, 2)); res->stats[2] = c[0]; res->stats[3] = c[1]; res->stats[4] = (uint64_t)nreq; }
+	*out = guard.release();
+	return 0;
+}
+
+int ssg_index_set_names(ssg_index_t *ix, int n, const char *const *names)
+{
+	if (n != ix->v.n_ctg) { ssg_err_msg = "ssg_index_set_names: contig count mismatch"; return SSG_EINVAL; }
+	ix->names.assign(names, names + n);
+	return 0;
+}
+const char *ssg_index_name(const ssg_index_t *ix, int i) { return i >= 0 && i < (int)ix->names.size() ? ix->names[i].c_str() : "*"; }
+int32_t ssg_index_len(const ssg_index_t *ix, int i) { return i >= 0 && i < (int)ix->h_len.size() ? ix->h_len[i] : 0; }
+
+void ssg_pe_result_free(ssg_pe_result_t *r) { delete r; }
+int64_t ssg_pe_n_req(const ssg_pe_result_t *r) { return (int64_t)r->req.size(); }
+const int64_t *ssg_pe_req_off(const ssg_pe_result_t *r) { return r->req_off.data(); }
+const ssg_alnreq_t *ssg_pe_req(const ssg_pe_result_t *r) { return r->req.data(); }
+const ssg_aln_t *ssg_pe_alns(const ssg_pe_result_t *r) { return r->alns.data(); }
+const ssg_pestat_t *ssg_pe_pes(const ssg_pe_result_t *r) { return r->pes.data(); }
+const uint64_t *ssg_pe_stats(const ssg_pe_result_t *r) { return r->stats; }
 
 } /* extern "C" */

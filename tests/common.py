@@ -149,6 +149,32 @@ def check_smem(lib, oracle, n_pairs, seed, read_len=150):
     lib.index_destroy(gidx)
 
 
+def check_pe_sam(lib, oracle, n_pairs, seed, read_len=150, n_threads=8, **kw):
+    """Whole `bwa mem` PE hot path: SAM text from the device records must equal the oracle's."""
+    prefix = EXAMPLE_FA
+    oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
+    pairs, seqs, seq, off = sim_reads(n_pairs, seed, read_len, **kw)
+    names = []
+    for nm, _, _ in pairs:
+        names += [nm, nm]
+    quals = ["I" * len(s) for s in seqs]
+    opt = lib.opt_init()
+    res = capi.mem_process_pairs(lib, gidx, opt, seq, off, id0=0)
+    text, _ = capi.sam_format(lib, gidx, opt, res, names, seq, off, quals, "grp1")
+    otext, _, opes = oracle.process_pairs(oidx, seq, off, names, quals, 0, "grp1", n_threads)
+    for f in ("low", "high", "failed", "avg", "std"):
+        assert np.array_equal(res.pes[f][:4], opes[f]), (f, res.pes, opes)
+    if text != otext:
+        a, b = text.split("\n"), otext.split("\n")
+        assert len(a) == len(b), (len(a), len(b))
+        for x, y in zip(a, b):
+            assert x == y, "\n%s\n%s" % (x, y)
+    stats = res.stats.copy()
+    res.close()
+    lib.index_destroy(gidx)
+    return text, stats
+
+
 def check_align1(lib, oracle, n_pairs, seed, read_len=150):
     prefix = EXAMPLE_FA
     oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)

@@ -72,3 +72,17 @@ class Oracle:
             if tot <= cap:
                 return reg_off, out[:tot]
             cap = tot
+
+    def process_pairs(self, idx, seq, off, names, quals=None, n_processed=0, rg_id="", n_threads=1, pes0=None):
+        from speedseq_amd.capi import PESTAT_DT
+        n = len(off) - 1
+        NA = (C.c_char_p * n)(*[s.encode() for s in names])
+        QA = (C.c_char_p * n)(*[s.encode() for s in quals]) if quals is not None else None
+        pes = np.zeros(4, dtype=PESTAT_DT)
+        sam_off = np.zeros(n + 1, dtype=np.int64)
+        self.l.orc_api_process_pairs.restype = C.c_void_p
+        p = self.l.orc_api_process_pairs(self.opt, idx, C.c_int(n // 2), _ptr(seq), _ptr(off), NA, QA, C.c_int64(n_processed), rg_id.encode(),
+                                         C.c_int(n_threads), _ptr(pes0) if pes0 is not None else None, _ptr(pes), _ptr(sam_off))
+        text = C.string_at(p, int(sam_off[n])).decode()
+        self.l.orc_api_free(C.c_void_p(p))
+        return text, sam_off, pes

@@ -30,5 +30,16 @@ def test_gpu_align1_150(gpu_lib, oracle):
     assert common.check_align1(gpu_lib, oracle, 4000, seed=15) > 4000
 
 
+def test_gpu_pe_sam_150(gpu_lib, oracle):
+    text, stats = common.check_pe_sam(gpu_lib, oracle, 5000, seed=17)
+    assert text.count("\n") >= 10000 and "SA:Z:" in text and "XA:Z:" in text
+    assert stats[3] > 0  # some mate rescues happened
+
+
+def test_gpu_pe_sam_250_long_insert(gpu_lib, oracle):
+    text, stats = common.check_pe_sam(gpu_lib, oracle, 1500, seed=18, read_len=250, ins_mean=800, ins_std=150)
+    assert text.count("\n") >= 3000
+
+
 def test_gpu_align1_250(gpu_lib, oracle):
     assert common.check_align1(gpu_lib, oracle, 1000, seed=16, read_len=250) > 1000
