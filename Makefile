@@ -9,7 +9,9 @@ all: lib oracle emu
 
 lib: speedseq_amd/libssgpu.so
 speedseq_amd/libssgpu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
-	$(HIPCC) $(HIPFLAGS) -x hip $(CSRC)/ssgpu_core.cpp -x c++ $(CSRC)/sam_format.cpp -shared -o $@
+	$(HIPCC) $(HIPFLAGS) -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core.o
+	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core.o $(CSRC)/sam_format.o -o $@
 
 oracle:
 	$(MAKE) -C oracle
