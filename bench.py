@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- `speedseq align` hot path (BWA-MEM seed/extend/pair + SAMBLASTER duplicate marking)
+on MI355X.  Contract: python bench.py --gpus N --steps K --warmup W prints ONE JSON line on rank 0.
+
+A "step" = one pass of the whole hot path (ssg_hotpath_dev) over one batch of synthetic 2x150 bp
+pairs that is already resident in HBM: SMEM seeding -> SAL -> chaining -> banded SW extension ->
+insert-size model -> mate rescue -> pairing/MAPQ -> CIGAR/NM/MD -> duplicate marking, records left
+in HBM.  Reads shard across ranks with no data-path collective (weak scaling: every GPU aligns its
+own pairs against its own index replica).
+
+The reference FASTA the metric names (GRCh37) is not available offline; the workload uses a seeded
+synthetic reference with GRCh37's contig-length proportions and planted repeat families, scaled to
+--ref-mbp (stated in config.workload).  The FM-index is built on the GPU before the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+GRCH37 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747, 135006516,
+          133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520, 48129895, 51304566,
+          155270560, 59373566, 16569]
+GRCH37_NAMES = [str(i) for i in range(1, 23)] + ["X", "Y", "MT"]
+
+
+def synth_reference(total_len, seed, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lens = [max(2000, int(x * total_len / sum(GRCH37))) for x in GRCH37]
+    L = sum(lens)
+    ref = torch.randint(0, 4, (L,), dtype=torch.uint8, device=dev, generator=g)
+    rng = np.random.default_rng(seed)
+    fams = [torch.randint(0, 4, (int(l),), dtype=torch.uint8, device=dev, generator=g) for l in rng.integers(200, 3000, size=16)]
+    planted = 0
+    while planted < 0.05 * L:
+        f = fams[int(rng.integers(0, len(fams)))].clone()
+        div = rng.random() * 0.1
+        m = torch.rand(f.numel(), device=dev, generator=g) < div
+        f[m] = torch.randint(0, 4, (int(m.sum()),), dtype=torch.uint8, device=dev, generator=g)
+        if rng.random() < 0.5:
+            f = (3 - f).flip(0)
+        p = int(rng.integers(0, L - f.numel()))
+        ref[p:p + f.numel()] = f
+        planted += f.numel()
+    return ref, lens
+
+
+def simulate_pairs(ref, lens, n_pairs, rl, seed, dev, ins_mean=400, ins_std=50, err=0.005, dup_frac=0.05, disc_frac=0.01, chim_frac=0.01, indel_frac=0.07):
+    """Vectorised wgsim-like simulator on the GPU: returns uint8 codes [2*n_pairs, rl]."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), device=dev, dtype=torch.int64)
+    lens_t = torch.tensor(lens, device=dev, dtype=torch.int64)
+    ctg = torch.multinomial(lens_t.double() / lens_t.sum(), n_pairs, replacement=True, generator=g)
+    d = (torch.randn(n_pairs, device=dev, generator=g) * ins_std + ins_mean).long().clamp(rl + 10, None)
+    u = torch.rand(n_pairs, device=dev, generator=g)
+    disc = (u >= dup_frac) & (u < dup_frac + disc_frac)
+    d = torch.where(disc, torch.randint(5000, 50000, (n_pairs,), device=dev, generator=g), d)
+    need = rl + 8
+    d = torch.minimum(d, lens_t[ctg] - 1).clamp(need + 1, None)
+    pos = (torch.rand(n_pairs, device=dev, generator=g, dtype=torch.float64) * (lens_t[ctg] - d).clamp(1, None).double()).long()
+    dup = u < dup_frac
+    src = (torch.rand(n_pairs, device=dev, generator=g, dtype=torch.float64) * torch.arange(n_pairs, device=dev).double()).long()
+    ctg = torch.where(dup, ctg[src], ctg)
+    pos = torch.where(dup, pos[src], pos)
+    d = torch.where(dup, d[src], d)
+    gpos = offs[ctg] + pos
+    j = torch.arange(need, device=dev)
+    f1 = ref[gpos[:, None] + j[None, :]]                                   # forward end
+    f2 = 3 - ref[(gpos + d - 1)[:, None] - j[None, :]]                     # reverse-complemented far end
+    chim = (~dup) & (~disc) & (torch.rand(n_pairs, device=dev, generator=g) < chim_frac)
+    c2 = torch.multinomial(lens_t.double() / lens_t.sum(), n_pairs, replacement=True, generator=g)
+    p2 = offs[c2] + (torch.rand(n_pairs, device=dev, generator=g, dtype=torch.float64) * (lens_t[c2] - need - 1).clamp(1, None).double()).long()
+    other = ref[p2[:, None] + j[None, :]]
+    bp = torch.randint(40, rl - 40, (n_pairs,), device=dev, generator=g)
+    f1 = torch.where(chim[:, None] & (j[None, :] >= bp[:, None]), other, f1)
+    flip = torch.rand(n_pairs, device=dev, generator=g) < 0.5
+    r1 = torch.where(flip[:, None], f2, f1)
+    r2 = torch.where(flip[:, None], f1, f2)
+    reads = torch.stack([r1, r2], 1).reshape(2 * n_pairs, need)
+    n = 2 * n_pairs
+    # one indel of 1..5 bases in a fraction of the reads
+    has = torch.rand(n, device=dev, generator=g) < indel_frac
+    ip = torch.randint(5, rl - 5, (n,), device=dev, generator=g)
+    il = torch.randint(1, 6, (n,), device=dev, generator=g)
+    is_del = torch.rand(n, device=dev, generator=g) < 0.5
+    jj = torch.arange(rl, device=dev)[None, :]
+    src_del = jj + torch.where(jj >= ip[:, None], il[:, None], torch.zeros_like(jj))
+    src_ins = jj - torch.where(jj >= (ip + il)[:, None], il[:, None], torch.zeros_like(jj))
+    src_idx = torch.where((has & is_del)[:, None], src_del, torch.where((has & ~is_del)[:, None], src_ins, jj.expand(n, rl))).clamp(0, need - 1)
+    out = torch.gather(reads, 1, src_idx)
+    ins_mask = (has & ~is_del)[:, None] & (jj >= ip[:, None]) & (jj < (ip + il)[:, None])
+    out = torch.where(ins_mask, torch.randint(0, 4, (n, rl), dtype=torch.uint8, device=dev, generator=g), out)
+    sub = torch.rand(n, rl, device=dev, generator=g) < err
+    out = torch.where(sub, (out + torch.randint(1, 4, (n, rl), dtype=torch.uint8, device=dev, generator=g)) % 4, out)
+    nmask = torch.rand(n, rl, device=dev, generator=g) < 0.001
+    out = torch.where(nmask, torch.full_like(out, 4), out)
+    return out.contiguous()
+
+
+def bwa_batches(n_pairs, rl, threads, chunk=10000000):
+    """Upstream main_mem batching: reads are taken until >= chunk*threads bases with an even count."""
+    per = -(-chunk * threads // (2 * rl))           # pairs per batch (ceil)
+    pb = np.arange(n_pairs, dtype=np.int64) // per
+    return pb.astype(np.int32), int(pb[-1]) + 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step (BASELINE.json configs[1]: 1M)")
+    ap.add_argument("--ref-mbp", type=float, default=256.0)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--bwa-threads", type=int, default=16, help="the -t whose batch boundaries (insert-size model scope) are reproduced")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from speedseq_amd import capi, index_build
+    lib = capi.Lib()
+    lib._chk(lib.l.ssg_set_device(C.c_int(local)))
+    opt = lib.opt_init()
+
+    t0 = time.time()
+    ref, lens = synth_reference(int(a.ref_mbp * 1e6), 20150810, dev)
+    ix = index_build.build_index_arrays(ref)
+    bwt = ix["bwt"]
+    # device arrays in the dtypes the kernels read: u32 words, u64 SA samples, u8 pac
+    d_bwt = torch.zeros(bwt.numel() + 64, dtype=torch.int32, device=dev)
+    d_bwt[:bwt.numel()] = torch.where(bwt >= (1 << 31), bwt - (1 << 32), bwt).to(torch.int32)
+    d_sa = ix["sa"].contiguous()
+    d_pac = ix["pac"].contiguous()
+    ctg_off = np.concatenate([[0], np.cumsum(lens)])[:-1]
+    idx = capi.index_from_device(lib, d_bwt.data_ptr(), ix["primary"], ix["L2"], d_sa.data_ptr(), d_pac.data_ptr(), ix["l_pac"], ctg_off, lens)
+    t_index = time.time() - t0
+
+    rl = a.read_len
+    reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev)
+    d_seq = reads.reshape(-1)
+    d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
+    pb, n_batches = bwa_batches(a.pairs, rl, a.bwa_threads)
+    d_pb = torch.from_numpy(pb).to(dev)
+    torch.cuda.synchronize()
+
+    def step(want_dup=False):
+        return capi.hotpath_dev(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0, want_dup)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof = not a.no_profile
+    if prof:
+        lib.l.ssg_prof_reset()
+        lib.l.ssg_prof_enable(C.c_int(1))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        summary, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    kern = capi.prof_get(lib) if prof else {}
+    if prof:
+        lib.l.ssg_prof_enable(C.c_int(0))
+
+    out = {
+        "metric": "paired reads aligned+dup-marked/sec", "value": world * a.pairs * a.steps / dt, "unit": "pairs/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "%d synthetic 2x%d bp PE pairs per GPU vs a seeded synthetic GRCh37-shaped reference of %.0f Mbp "
+                               "(25 contigs, 5%% planted repeats; GRCh37 itself is not available offline), bwa-mem -t %d batch boundaries"
+                               % (a.pairs, rl, sum(lens) / 1e6, a.bwa_threads),
+                   "pairs_per_gpu": a.pairs, "read_len": rl, "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2),
+                   "records": int(summary[0]), "dup_pairs": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
+                   "dedup_scope": "per-GPU shard"},
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
+        if kern:
+            name, (ms, cnt) = max(kern.items(), key=lambda kv: kv[1][0])
+            per_launch_ms = ms / cnt
+            n_ext = float(summary[6])
+            if name == "ssg_k_smem":
+                # algorithmic bytes: every bwt_extend = 2 rank queries = 2 x 64-byte Occ blocks (SURVEY 8d B_fm) + the reads
+                alg = 128.0 * n_ext + 2.0 * a.pairs * rl
+            else:
+                alg = 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": alg / (per_launch_ms * 1e-3) / 1e9 if alg else None, "peak": 8000.0,
+                               "unit": "GB/s", "frac": (alg / (per_launch_ms * 1e-3) / 1e9 / 8000.0) if alg else None, "traffic": None,
+                               "ms_per_launch": per_launch_ms,
+                               "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
+                               "sw_cells_per_step": int(summary[3]) + int(summary[4])}
+        # ---- CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample ----
+        if a.cpu_sample > 0:
+            try:
+                import oracle_py
+                import tempfile
+                ns = min(a.cpu_sample, a.pairs)
+                orc = oracle_py.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+                with tempfile.TemporaryDirectory() as td:
+                    prefix = os.path.join(td, "ref.fa")
+                    index_build.write_index_files(prefix, ix, GRCH37_NAMES, lens)
+                    oidx = orc.idx_load(prefix)
+                hs = reads[:2 * ns].cpu().numpy().reshape(-1)
+                hoff = np.arange(2 * ns + 1, dtype=np.int64) * rl
+                names = ["r%d" % (i // 2) for i in range(2 * ns)]
+                cores = min(os.cpu_count() or 1, 64)
+                tc = time.perf_counter()
+                text, _, _ = orc.process_pairs(oidx, hs, hoff, names, None, 0, "", cores)
+                hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(GRCH37_NAMES, lens))
+                orc.samblaster(hdr + text)
+                tc = time.perf_counter() - tc
+                out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                       "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded" % (ns, cores)}
+            except Exception as e:  # the baseline is informative only
+                out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

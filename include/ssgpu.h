@@ -110,6 +110,27 @@ int ssg_index_set_names(ssg_index_t *idx, int n, const char *const *names);
 const char *ssg_index_name(const ssg_index_t *idx, int i);
 int32_t ssg_index_len(const ssg_index_t *idx, int i);
 
+/* ---- SAMBLASTER duplicate marking (upstream samblaster.cpp markDups; row a14) ----
+ * ends: 2*n_pairs primary records (read1, read2 per pair) in input order; dup[p] = 1 when an
+ * earlier pair of the same call carries the same 5'-unclipped signature (first seen wins). */
+int ssg_sbl_markdup(long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup);
+
+/* ---- the measured hot path with device-resident inputs (bench.py) ----
+ * d_seq / d_off / d_pair_batch are DEVICE pointers; aligned + duplicate-marked records stay in HBM.
+ * summary: [0] records [1] duplicate pairs [2] seeds [3] extension cells [4] rescue cells [5] rescues */
+int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                    const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host);
+
+/* FM-index from arrays already resident in HBM (not copied; the caller keeps them alive) */
+int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,
+                          const uint8_t *d_pac, int64_t l_pac, int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out);
+
+/* per-kernel device time of the calls made since ssg_prof_reset() (HIP events on the launch stream).
+ * ssg_prof_get: returns the number of kernels; name[i] / ms[i] / launches[i] for i < min(n, cap). */
+void ssg_prof_enable(int on);
+void ssg_prof_reset(void);
+int ssg_prof_get(int cap, const char **name, double *ms, long *launches);
+
 void ssg_free(void *p);
 
 #ifdef __cplusplus

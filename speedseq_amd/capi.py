@@ -184,6 +184,45 @@ def mem_process_pairs(lib, idx, opt, seq, off, pair_batch=None, n_batches=1, id0
     return PeResult(lib, h, n_pairs, n_batches)
 
 
+SBL_END_DT = np.dtype([("seq", "i4"), ("pos", "i4"), ("flag", "i4"), ("lclip", "i4"), ("rclip", "i4"), ("ralen", "i4")])
+
+
+def sbl_markdup(lib, ends):
+    """ends: SBL_END_DT array of 2*n_pairs primary records -> uint8 dup flag per pair."""
+    ends = np.ascontiguousarray(ends, dtype=SBL_END_DT)
+    n = len(ends) // 2
+    dup = np.zeros(n, dtype=np.uint8)
+    lib._chk(lib.l.ssg_sbl_markdup(C.c_long(n), _ptr(ends), _ptr(dup)))
+    return dup
+
+
+def index_from_device(lib, d_bwt, primary, L2, d_sa, d_pac, l_pac, ctg_off, ctg_len, sa_intv=32):
+    """d_* are integer device addresses (e.g. torch.Tensor.data_ptr()); the caller keeps the tensors alive."""
+    h = C.c_void_p()
+    L2a = np.asarray(L2, dtype=np.uint64)
+    co = np.asarray(ctg_off, dtype=np.int64)
+    cl = np.asarray(ctg_len, dtype=np.int32)
+    lib._chk(lib.l.ssg_index_from_device(C.c_void_p(d_bwt), C.c_uint64(primary), _ptr(L2a), C.c_void_p(d_sa), C.c_int(sa_intv),
+                                         C.c_void_p(d_pac), C.c_int64(l_pac), C.c_int(len(co)), _ptr(co), _ptr(cl), C.byref(h)))
+    return h
+
+
+def hotpath_dev(lib, idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches=1, id0=0, want_dup=False):
+    summary = np.zeros(8, dtype=np.uint64)
+    dup = np.zeros(n_pairs, dtype=np.uint8) if want_dup else None
+    lib._chk(lib.l.ssg_hotpath_dev(idx, _ptr(opt), C.c_int(n_pairs), C.c_int(max_len), C.c_void_p(d_seq), C.c_void_p(d_off), C.c_void_p(d_pair_batch),
+                                   C.c_int(n_batches), C.c_int64(id0), _ptr(summary), _ptr(dup) if want_dup else None))
+    return summary, dup
+
+
+def prof_get(lib, cap=64):
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    cnt = (C.c_long * cap)()
+    n = lib.l.ssg_prof_get(C.c_int(cap), names, ms, cnt)
+    return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}
+
+
 def sam_format(lib, idx, opt, res, names, seq, off, quals=None, rg_id=""):
     n = 2 * res.n_pairs
     NA = (C.c_char_p * n)(*[s.encode() for s in names])

@@ -25,7 +25,6 @@ __global__ void ssg_k_compact_req(int n_reads, const int64_t *src_off, const ssg
 
 /* ---------------- duplicate marking (upstream samblaster, row a14) ---------------- */
 /* primary record of one end as samblaster sees it */
-typedef struct { int32_t seq, pos, flag, lclip, rclip, ralen; } ssg_sbl_end_t;
 typedef struct { uint64_t k0, k1, k2; } ssg_sig_t;
 
 SSG_DEVFN uint64_t ssg_mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }

@@ -13,7 +13,7 @@
 #define SSG_K_SEED_H
 #include "ssg_dev.h"
 
-struct ssg_ivec_t { ssg_intv_t *a; int n, cap; int ovf; };
+struct ssg_ivec_t { ssg_intv_t *a; int n, cap; int ovf; unsigned nx; /* bwt_extend calls (rank-query accounting) */ };
 SSG_DEVFN void iv_push(ssg_ivec_t &v, const ssg_intv_t &x) { if (v.n < v.cap) v.a[v.n] = x; else v.ovf = 1; ++v.n; }
 SSG_DEVFN void iv_reverse(ssg_ivec_t &v)
 {
@@ -40,7 +40,7 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
 	for (i = x + 1, curr->n = 0; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
-			ssg_bwt_extend(ix, ik, ok, 0);
+			ssg_bwt_extend(ix, ik, ok, 0); ++mem.nx;
 			if (ok[c].x2 != ik.x2) {
 				iv_push(*curr, ik);
 				if (ok[c].x2 < min_intv) break;
@@ -56,7 +56,7 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
 		c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
 		for (j = 0, curr->n = 0; j < prev->n; ++j) {
 			ssg_intv_t p = prev->a[j];
-			if (c >= 0) ssg_bwt_extend(ix, p, ok, 1);
+			if (c >= 0) { ssg_bwt_extend(ix, p, ok, 1); ++mem.nx; }
 			if (c < 0 || ok[c].x2 < min_intv) {
 				if (curr->n == 0) {
 					if (mem.n == 0 || (uint64_t)(i + 1) < (mem.a[mem.n-1].info >> 32)) {
@@ -77,7 +77,7 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
 }
 
 /* upstream bwt_seed_strategy1 */
-SSG_DEVFN int ssg_seed_strategy1(const ssg_index_view_t &ix, int len, const uint8_t *q, int x, int min_len, uint64_t max_intv, ssg_intv_t &mem)
+SSG_DEVFN int ssg_seed_strategy1(const ssg_index_view_t &ix, int len, const uint8_t *q, int x, int min_len, uint64_t max_intv, ssg_intv_t &mem, unsigned &nx)
 {
 	int i, c;
 	ssg_intv_t ik, ok[4];
@@ -87,7 +87,7 @@ SSG_DEVFN int ssg_seed_strategy1(const ssg_index_view_t &ix, int len, const uint
 	for (i = x + 1; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
-			ssg_bwt_extend(ix, ik, ok, 0);
+			ssg_bwt_extend(ix, ik, ok, 0); ++nx;
 			if (ok[c].x2 < max_intv && i - x >= min_len) {
 				mem = ok[c];
 				mem.info = (uint64_t)x << 32 | (uint64_t)(i + 1);
@@ -109,10 +109,11 @@ struct ssg_intv_lt { SSG_DEVMEM bool operator()(const ssg_intv_t &a, const ssg_i
 __global__ void ssg_k_smem(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_intv_t *scratch, int scap)
+                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend)
 {
 	long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
 	ssg_intv_t *my = scratch + gt * 3 * scap;
+	unsigned long long my_nx = 0;
 	for (long it = gt; it < n_reads; it += nt) {
 		int r = read_ids ? read_ids[it] : (int)it;
 		const uint8_t *q = seq + off[r];
@@ -148,7 +149,7 @@ __global__ void ssg_k_smem(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, 
 				while (x < len) {
 					if (q[x] < 4) {
 						ssg_intv_t m;
-						x = ssg_seed_strategy1(ix, len, q, x, opt.min_seed_len, opt.max_mem_intv, m);
+						x = ssg_seed_strategy1(ix, len, q, x, opt.min_seed_len, opt.max_mem_intv, m, mem1.nx);
 						if (m.x2 > 0) iv_push(mem, m);
 					} else ++x;
 				}
@@ -156,7 +157,9 @@ __global__ void ssg_k_smem(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, 
 			if (mem.n <= mem.cap && !mem1.ovf && !va.ovf && !vb.ovf) ssg_introsort(mem.a, (long)mem.n, ssg_intv_lt());
 		}
 		out_n[it] = (mem.ovf || mem1.ovf || va.ovf || vb.ovf) ? -1 : mem.n;
+		my_nx += mem1.nx;
 	}
+	if (n_extend && my_nx) atomicAdd(n_extend, my_nx);
 }
 
 /* number of sampled occurrences of one interval (upstream mem_chain: step/count rule) */

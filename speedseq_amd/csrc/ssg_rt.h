@@ -36,13 +36,40 @@ static inline int rt_check(hipError_t e, const char *what)
 }
 static inline int rt_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 static inline int rt_set_device(int d) { return rt_check(hipSetDevice(d), "hipSetDevice"); }
-static inline void *rt_malloc(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 256) != hipSuccess) { (void)hipGetLastError(); return 0; } return p; }
-static inline void rt_free(void *p) { if (p) (void)hipFree(p); }
+/* HBM arena: freed blocks are kept in size-class free lists and reused by later calls, so the
+ * steady-state hot path performs no hipMalloc/hipFree (288 GB of HBM3E make the slack irrelevant) */
+#include <map>
+#include <unordered_map>
+#include <mutex>
+struct ssg_pool_t {
+	std::mutex mu; std::map<size_t, std::vector<void*> > free_; std::unordered_map<void*, size_t> size_;
+	static size_t cls(size_t n) { size_t c = 256; while (c < n) c <<= 1; if (c > (64u << 20)) { size_t g = 64u << 20; c = (n + g - 1) / g * g; } return c; }
+	void *get(size_t n) {
+		size_t c = cls(n ? n : 1);
+		{ std::lock_guard<std::mutex> l(mu); auto it = free_.find(c); if (it != free_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; } }
+		void *p = 0;
+		if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); release(); if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); return 0; } }
+		std::lock_guard<std::mutex> l(mu); size_[p] = c; return p;
+	}
+	void put(void *p) { if (!p) return; std::lock_guard<std::mutex> l(mu); auto it = size_.find(p); if (it == size_.end()) { (void)hipFree(p); return; } free_[it->second].push_back(p); }
+	void release() { std::lock_guard<std::mutex> l(mu); for (auto &kv : free_) for (void *p : kv.second) { size_.erase(p); (void)hipFree(p); } free_.clear(); }
+};
+extern ssg_pool_t ssg_pool;
+static inline void *rt_malloc(size_t n) { return ssg_pool.get(n); }
+static inline void rt_free(void *p) { ssg_pool.put(p); }
 static inline int rt_h2d(void *d, const void *h, size_t n) { return n ? rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D") : 0; }
 static inline int rt_d2h(void *h, const void *d, size_t n) { return n ? rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
 static inline int rt_memset(void *d, int v, size_t n) { return n ? rt_check(hipMemset(d, v, n), "hipMemset") : 0; }
 static inline int rt_sync() { return rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
-#define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } while (0)
+/* optional per-kernel timing: HIP events recorded on the launch stream (the default stream) */
+#include <vector>
+struct ssg_prof_rec { const char *name; hipEvent_t a, b; };
+extern int ssg_prof_on;
+extern std::vector<ssg_prof_rec> ssg_prof_pending;
+#define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) { \
+	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, 0); \
+		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); (void)hipEventRecord(r_.b, 0); ssg_prof_pending.push_back(r_); } \
+	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } } while (0)
 #endif
 
 /* RAII device buffer */
@@ -54,6 +81,7 @@ template <class T> struct dbuf {
 	dbuf(const dbuf&) = delete; dbuf &operator=(const dbuf&) = delete;
 	bool alloc(size_t n_) { rt_free(p); n = n_; p = (T*)rt_malloc(n_ * sizeof(T)); return p != 0; }
 	bool ok() const { return p != 0; }
+	void swap(dbuf &o) { T *tp = p; p = o.p; o.p = tp; size_t tn = n; n = o.n; o.n = tn; }
 	int up(const T *h, size_t cnt) { return rt_h2d(p, h, cnt * sizeof(T)); }
 	int down(T *h, size_t cnt) const { return rt_d2h(h, p, cnt * sizeof(T)); }
 	int zero() { return rt_memset(p, 0, n * sizeof(T)); }

@@ -70,6 +70,10 @@ typedef struct { int32_t qoff, qlen, toff, tlen, xtra, _pad; } ssg_sw_job_t;
 /* one ksw_global2 / bwa_gen_cigar2 job (a12) */
 typedef struct { int32_t qoff, qlen, toff, tlen, w, _pad; } ssg_glb_job_t;
 
+/* primary record of one read end as samblaster sees it: contig index (-1 unmapped), 1-based POS,
+ * FLAG, leading / trailing clipped bases (S or H) and reference length of the CIGAR */
+typedef struct { int32_t seq, pos, flag, lclip, rclip, ralen; } ssg_sbl_end_t;
+
 /* one SAM record to generate: a main record (primary / supplementary / unmapped) or an XA entry;
  * `owner` = region index (within the read) of the main record the entry belongs to */
 typedef struct { int32_t read, reg, kind, owner, flag, mapq, _pad0, _pad1; } ssg_alnreq_t;

@@ -20,6 +20,11 @@
 #include "../../include/ssgpu.h"
 
 thread_local std::string ssg_err_msg;
+#ifndef SSG_EMU
+ssg_pool_t ssg_pool;
+int ssg_prof_on = 0;
+std::vector<ssg_prof_rec> ssg_prof_pending;
+#endif
 
 /* wave-per-item kernels are grid-strided over at most this many 4-wave workgroups (256 CUs x 4),
  * so per-wave scratch slabs are sized by residency, not by batch size */
@@ -138,6 +143,52 @@ void ssg_index_destroy(ssg_index_t *ix)
 	rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); rt_free(ix->ctg_off); rt_free(ix->ctg_len);
 	delete ix;
 }
+int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,
+                          const uint8_t *d_pac, int64_t l_pac, int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out)
+{
+	CHK(need_device());
+	ssg_index *ix = new ssg_index();
+	ix->bwt = 0; ix->sa = 0; ix->pac = 0; /* borrowed: not freed by ssg_index_destroy */
+	ix->ctg_off = (int64_t*)rt_malloc(n_ctg * 8); ix->ctg_len = (int32_t*)rt_malloc(n_ctg * 4);
+	if (!ix->ctg_off || !ix->ctg_len) { ssg_index_destroy(ix); ssg_err_msg = "index allocation failed"; return SSG_ENOMEM; }
+	if (rt_h2d(ix->ctg_off, ctg_off, n_ctg * 8) | rt_h2d(ix->ctg_len, ctg_len, n_ctg * 4)) { ssg_index_destroy(ix); return SSG_EHIP; }
+	ix->v.bwt = d_bwt; ix->v.sa = d_sa; ix->v.pac = d_pac; ix->v.ctg_off = ix->ctg_off; ix->v.ctg_len = ix->ctg_len;
+	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
+	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
+	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
+	*out = ix;
+	return 0;
+}
+
+/* ---- per-kernel timing ---- */
+#ifndef SSG_EMU
+static std::vector<std::string> prof_names; static std::vector<double> prof_ms; static std::vector<long> prof_cnt;
+static void prof_collect()
+{
+	(void)hipDeviceSynchronize();
+	for (auto &r : ssg_prof_pending) {
+		float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b);
+		size_t i = 0; for (; i < prof_names.size(); ++i) if (prof_names[i] == r.name) break;
+		if (i == prof_names.size()) { prof_names.push_back(r.name); prof_ms.push_back(0); prof_cnt.push_back(0); }
+		prof_ms[i] += ms; prof_cnt[i] += 1;
+		(void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+	}
+	ssg_prof_pending.clear();
+}
+void ssg_prof_enable(int on) { prof_collect(); ssg_prof_on = on; }
+void ssg_prof_reset(void) { prof_collect(); prof_names.clear(); prof_ms.clear(); prof_cnt.clear(); }
+int ssg_prof_get(int cap, const char **name, double *ms, long *launches)
+{
+	prof_collect();
+	for (int i = 0; i < (int)prof_names.size() && i < cap; ++i) { name[i] = prof_names[i].c_str(); ms[i] = prof_ms[i]; launches[i] = prof_cnt[i]; }
+	return (int)prof_names.size();
+}
+#else
+void ssg_prof_enable(int) {}
+void ssg_prof_reset(void) {}
+int ssg_prof_get(int, const char **, double *, long *) { return 0; }
+#endif
+
 int64_t ssg_index_l_pac(const ssg_index_t *ix) { return ix->v.l_pac; }
 int ssg_index_n_ctg(const ssg_index_t *ix) { return ix->v.n_ctg; }
 
@@ -203,14 +254,14 @@ struct seed_stage_t {
 /* runs the SMEM kernel for all reads (cap0 per read), then re-runs overflowing reads with a
  * private large capacity and copies their lists back; on return every n_intv[r] >= 0. */
 static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                    int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n)
+                    int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0)
 {
 	const int block = 64;
 	long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * 1024);
 	int scap = max_len + 2;
 	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap);
 	CHKA(scratch);
-	SSG_LAUNCH(ssg_k_smem, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap);
+	SSG_LAUNCH(ssg_k_smem, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
 	std::vector<int32_t> hn(n_reads);
 	CHK(rt_d2h(hn.data(), d_n, (size_t)n_reads * 4));
@@ -225,7 +276,7 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	long nt2 = ((long)no + block - 1) / block * block;
 	dbuf<ssg_intv_t> scratch2((size_t)nt2 * 3 * bigcap);
 	CHKA(scratch2);
-	SSG_LAUNCH(ssg_k_smem, nt2 / block, block, 0, idx->v, *opt, no, d_ids.p, d_seq, d_off, d_big.p, d_n2.p, bigcap, scratch2.p, bigcap);
+	SSG_LAUNCH(ssg_k_smem, nt2 / block, block, 0, idx->v, *opt, no, d_ids.p, d_seq, d_off, d_big.p, d_n2.p, bigcap, scratch2.p, bigcap, n_extend);
 	CHK(rt_sync());
 	std::vector<int32_t> hn2(no);
 	CHK(d_n2.down(hn2.data(), no));
@@ -265,7 +316,10 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	const int cap = 64 > max_len / 2 ? 64 : max_len / 2;  /* intervals per read in the dense layout */
 	dbuf<ssg_intv_t> d_intv((size_t)n_reads * cap); dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
 	CHKA(d_intv); CHKA(d_nintv); CHKA(d_nseed);
-	CHK(run_smem(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv.p, d_nintv.p));
+	dbuf<unsigned long long> d_next(1);
+	CHKA(d_next); CHK(d_next.zero());
+	CHK(run_smem(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv.p, d_nintv.p, d_next.p));
+	if (stats) { unsigned long long c; CHK(d_next.down(&c, 1)); stats[5] = c; }
 	STAGE("smem");
 	const int block = 256;
 	SSG_LAUNCH(ssg_k_sal_count, (n_reads + block - 1) / block, block, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);
@@ -384,23 +438,21 @@ struct ssg_pe_result {
 	uint64_t stats[8];
 };
 
-extern "C" {
+/* device-resident output of the PE stage (kept in HBM for the duplicate-marking stage / the bench) */
+struct pe_dev_t {
+	dbuf<ssg_alnreq_t> req; dbuf<ssg_aln_t> alns; dbuf<int64_t> req_off; int64_t n_req;
+};
 
-int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
-                          const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out)
+/* the whole PE hot path on device-resident inputs; `keep` != NULL leaves the records in HBM
+ * instead of downloading them into `res` */
+static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *d_seq_p, const int64_t *d_off_p, int max_len,
+                   const int32_t *d_pb_p, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result *res, pe_dev_t *keep)
 {
-	CHK(need_device());
-	*out = 0;
 	const int n_reads = 2 * n_pairs;
-	if (n_pairs <= 0 || n_batches <= 0) { ssg_err_msg = "ssg_mem_process_pairs: empty input"; return SSG_EINVAL; }
-	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
-	if (max_len > 254) { ssg_err_msg = "reads longer than 254 bases are outside this build's scope"; return SSG_EINVAL; }
-	for (int p = 0; p < n_pairs; ++p) if (pair_batch[p] < 0 || pair_batch[p] >= n_batches) { ssg_err_msg = "pair_batch out of range"; return SSG_EINVAL; }
-	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1); dbuf<int32_t> d_pb(n_pairs);
-	CHKA(d_seq); CHKA(d_off); CHKA(d_pb);
-	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1)); CHK(d_pb.up(pair_batch, n_pairs));
-	ssg_pe_result *res = new ssg_pe_result(); res->n_reads = n_reads; res->n_batches = n_batches; memset(res->stats, 0, sizeof(res->stats));
-	std::unique_ptr<ssg_pe_result> guard(res);
+	struct { const uint8_t *p; } d_seq = { d_seq_p };
+	struct { const int64_t *p; } d_off = { d_off_p };
+	struct { const int32_t *p; } d_pb = { d_pb_p };
+	res->n_reads = n_reads; res->n_batches = n_batches; memset(res->stats, 0, sizeof(res->stats));
 	align1_dev_t a1;
 	CHK(run_align1(idx, opt, n_reads, d_seq.p, d_off.p, max_len, a1, res->stats));
 	const int block = 256;
@@ -485,10 +537,123 @@ int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
 	}
 	STAGE("reg2aln");
 	{ int32_t ge; CHK(d_gerr.down(&ge, 1)); if (ge) { char b[96]; snprintf(b, sizeof(b), "CIGAR generation exceeded an on-device capacity (code %d)", ge); ssg_err_msg = b; return SSG_EOVERFLOW; } }
-	res->req.resize((size_t)nreq); res->alns.resize((size_t)nreq);
-	CHK(d_creq.down(res->req.data(), (size_t)nreq)); CHK(d_alns.down(res->alns.data(), (size_t)nreq));
 	{ unsigned long long c[2]; CHK(d_cnt.down(c, 2)); res->stats[2] = c[0]; res->stats[3] = c[1]; res->stats[4] = (uint64_t)nreq; }
-	*out = guard.release();
+	if (keep) { keep->req.swap(d_creq); keep->alns.swap(d_alns); keep->req_off.swap(d_coff); keep->n_req = nreq; }
+	else {
+		res->req.resize((size_t)nreq); res->alns.resize((size_t)nreq);
+		CHK(d_creq.down(res->req.data(), (size_t)nreq)); CHK(d_alns.down(res->alns.data(), (size_t)nreq));
+	}
+	return 0;
+}
+
+/* ---- duplicate marking on device-resident records (row a14) ---- */
+__global__ void ssg_k_ends_from_alns(long n_pairs, const int64_t *req_off, const ssg_alnreq_t *req, const ssg_aln_t *alns, ssg_sbl_end_t *ends)
+{	/* primary record of each end (first main request of the read) -> samblaster's view of it */
+	long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= 2 * n_pairs) return;
+	const ssg_aln_t &a = alns[req_off[r]];
+	ssg_sbl_end_t e; e.seq = a.rid; e.pos = (int32_t)(a.pos + 1); e.flag = a.flag | (a.is_rev ? 0x10 : 0) | (a.rid < 0 ? 0x4 : 0);
+	e.lclip = e.rclip = e.ralen = 0;
+	int first = 1, rc = 0;
+	for (int k = 0; k < a.n_cigar; ++k) {
+		int op = a.cigar[k] & 0xf, len = (int)(a.cigar[k] >> 4);
+		if (op == 3 || op == 4) { if (first) e.lclip += len; rc += len; }
+		else { first = 0; rc = 0; if (op == 0 || op == 2) e.ralen += len; }
+	}
+	e.rclip = a.n_cigar ? rc : 0;
+	if (a.rid < 0) e.seq = -1;
+	ends[r] = e;
+}
+
+#ifndef SSG_EMU
+#include <hipcub/hipcub.hpp>
+#endif
+/* stable sort of (hash, ordinal) by hash: hipCUB radix sort on the GPU */
+static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, long n)
+{
+#ifdef SSG_EMU
+	std::vector<uint32_t> idx(n); for (long i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+	std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return k_in[a] < k_in[b]; });
+	for (long i = 0; i < n; ++i) { k_out[i] = k_in[idx[i]]; v_out[i] = v_in[idx[i]]; }
+	return 0;
+#else
+	size_t tmp_bytes = 0;
+	if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs (size query) failed"; return SSG_EHIP; }
+	dbuf<uint8_t> tmp(tmp_bytes);
+	CHKA(tmp);
+	if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; return SSG_EHIP; }
+	return rt_sync();
+#endif
+}
+
+/* dup[p] for pairs whose ends are in d_ends (device); single call = whole input (first-seen-wins by ordinal) */
+static int dedup_core(long n_pairs, const ssg_sbl_end_t *d_ends, uint8_t *d_dup)
+{
+	const int block = 256;
+	dbuf<ssg_sig_t> d_sig(n_pairs); dbuf<uint64_t> d_h(n_pairs), d_hs(n_pairs); dbuf<uint32_t> d_o(n_pairs), d_os(n_pairs);
+	CHKA(d_sig); CHKA(d_h); CHKA(d_hs); CHKA(d_o); CHKA(d_os);
+	SSG_LAUNCH(ssg_k_sig, (n_pairs + block - 1) / block, block, 0, n_pairs, d_ends, d_sig.p, d_h.p, d_o.p);
+	CHK(rt_sync());
+	CHK(sort_pairs_u64(d_h.p, d_hs.p, d_o.p, d_os.p, n_pairs));
+	SSG_LAUNCH(ssg_k_markdup, (n_pairs + block - 1) / block, block, 0, n_pairs, d_hs.p, d_os.p, d_sig.p, 0L, (const uint64_t*)0, (const ssg_sig_t*)0, d_dup);
+	return rt_sync();
+}
+
+extern "C" {
+
+int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
+                          const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out)
+{
+	CHK(need_device());
+	*out = 0;
+	const int n_reads = 2 * n_pairs;
+	if (n_pairs <= 0 || n_batches <= 0) { ssg_err_msg = "ssg_mem_process_pairs: empty input"; return SSG_EINVAL; }
+	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
+	if (max_len > 254) { ssg_err_msg = "reads longer than 254 bases are outside this build's scope"; return SSG_EINVAL; }
+	for (int p = 0; p < n_pairs; ++p) if (pair_batch[p] < 0 || pair_batch[p] >= n_batches) { ssg_err_msg = "pair_batch out of range"; return SSG_EINVAL; }
+	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1); dbuf<int32_t> d_pb(n_pairs);
+	CHKA(d_seq); CHKA(d_off); CHKA(d_pb);
+	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1)); CHK(d_pb.up(pair_batch, n_pairs));
+	std::unique_ptr<ssg_pe_result> res(new ssg_pe_result());
+	CHK(pe_core(idx, opt, n_pairs, d_seq.p, d_off.p, max_len, d_pb.p, n_batches, id0, pes0, res.get(), 0));
+	*out = res.release();
+	return 0;
+}
+
+/* upstream samblaster duplicate marking (row a14) on per-end records supplied by the caller
+ * (2*n_pairs entries: read1, read2 primaries); dup[p] = 1 when an earlier pair has the same signature */
+int ssg_sbl_markdup(long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup)
+{
+	CHK(need_device());
+	if (n_pairs <= 0) return 0;
+	if (n_pairs >= (1L << 31)) { ssg_err_msg = "ssg_sbl_markdup: more than 2^31 pairs per call"; return SSG_EINVAL; }
+	dbuf<ssg_sbl_end_t> d_ends(2 * n_pairs); dbuf<uint8_t> d_dup(n_pairs);
+	CHKA(d_ends); CHKA(d_dup);
+	CHK(d_ends.up(ends, 2 * n_pairs));
+	CHK(dedup_core(n_pairs, d_ends.p, d_dup.p));
+	return d_dup.down(dup, n_pairs);
+}
+
+/* The measured hot path (bench.py): device-resident reads in, aligned + duplicate-marked records
+ * left in HBM.  d_seq / d_off / d_pair_batch are DEVICE pointers.  summary[0] = records,
+ * [1] = duplicate pairs, [2] = seeds, [3] = extension cells, [4] = rescue cells, [5] = rescues. */
+int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                    const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host /* may be NULL */)
+{
+	CHK(need_device());
+	if (n_pairs <= 0 || max_len > 254) { ssg_err_msg = "ssg_hotpath_dev: bad arguments"; return SSG_EINVAL; }
+	ssg_pe_result res; pe_dev_t keep;
+	CHK(pe_core(idx, opt, n_pairs, d_seq, d_off, max_len, d_pair_batch, n_batches, id0, 0, &res, &keep));
+	dbuf<ssg_sbl_end_t> d_ends(2L * n_pairs); dbuf<uint8_t> d_dup(n_pairs);
+	CHKA(d_ends); CHKA(d_dup);
+	SSG_LAUNCH(ssg_k_ends_from_alns, (2L * n_pairs + 255) / 256, 256, 0, (long)n_pairs, keep.req_off.p, keep.req.p, keep.alns.p, d_ends.p);
+	CHK(dedup_core(n_pairs, d_ends.p, d_dup.p));
+	std::vector<uint8_t> hd(n_pairs);
+	CHK(d_dup.down(hd.data(), n_pairs));
+	uint64_t nd = 0; for (int p = 0; p < n_pairs; ++p) nd += hd[p];
+	if (dup_host) memcpy(dup_host, hd.data(), n_pairs);
+	summary[0] = res.stats[4]; summary[1] = nd; summary[2] = res.stats[0]; summary[3] = res.stats[1]; summary[4] = res.stats[2]; summary[5] = res.stats[3];
+	summary[6] = res.stats[5]; /* bwt_extend calls in the SMEM kernel (2 rank queries = 2 x 64-byte lines each) */
 	return 0;
 }
 

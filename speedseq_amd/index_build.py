@@ -102,7 +102,7 @@ def build_index_arrays(fwd_codes):
     tail = (nblk - 1) * 16 + 8 + last_sym_words
     out[tail:tail + 8:2] = counts[nblk] & 0xffffffff
     out[tail + 1:tail + 8:2] = counts[nblk] >> 32
-    bwt = out[:total].to(torch.int32) if False else (out[:total] & 0xffffffff)
+    bwt = out[:total] & 0xffffffff
     # .pac: 4 bases per byte, MSB first
     npb = l_pac // 4 + 1
     fp = torch.zeros(npb * 4, dtype=torch.int64, device=dev)

@@ -175,6 +175,79 @@ def check_pe_sam(lib, oracle, n_pairs, seed, read_len=150, n_threads=8, **kw):
     return text, stats
 
 
+def sam_primary_ends(text, contig_names):
+    """Per pair: the two primary records as samblaster sees them (capi.SBL_END_DT), from SAM text."""
+    import re
+    idx = {n: i for i, n in enumerate(contig_names)}
+    ends, cur, name = [], {}, None
+
+    def flush():
+        if cur:
+            ends.append(cur.get(0x40, (-1, 0, 0x4, 0, 0, 0)))
+            ends.append(cur.get(0x80, (-1, 0, 0x4, 0, 0, 0)))
+
+    for line in text.split("\n"):
+        if not line or line[0] == "@":
+            continue
+        f = line.split("\t")
+        if f[0] != name:
+            flush()
+            cur, name = {}, f[0]
+        flag = int(f[1])
+        if flag & 0x900:
+            continue
+        ops = re.findall(r"(\d+)([MIDNSH=X])", f[5])
+        lclip = rclip = ralen = 0
+        first = True
+        for n, op in ops:
+            n = int(n)
+            if op in "SH":
+                if first:
+                    lclip += n
+                rclip += n
+            else:
+                first = False
+                rclip = 0
+                if op in "MDN=X":
+                    ralen += n
+        seq = -1 if (flag & 4) or f[2] == "*" else idx[f[2]]
+        cur[flag & 0xc0] = (seq, int(f[3]), flag, lclip, rclip if ops else 0, ralen)
+    flush()
+    return np.array(ends, dtype=capi.SBL_END_DT)
+
+
+def oracle_dup_flags(oracle, sam_text, header):
+    """Run the oracle samblaster over SAM text; returns per-pair dup flags (from read1 primaries)."""
+    out = oracle.samblaster(header + sam_text)
+    flags, name = [], None
+    for line in out.split("\n"):
+        if not line or line[0] == "@":
+            continue
+        f = line.split("\t")
+        if f[0] != name:
+            name = f[0]
+            flags.append(1 if int(f[1]) & 0x400 else 0)
+    return np.array(flags, dtype=np.uint8), out
+
+
+def check_dedup(lib, oracle, n_pairs, seed, dup_frac=0.2):
+    prefix = EXAMPLE_FA
+    oidx = oracle.idx_load(prefix)
+    pairs, seqs, seq, off = sim_reads(n_pairs, seed, dup_frac=dup_frac)
+    names = []
+    for i, (nm, _, _) in enumerate(pairs):
+        names += [nm, nm]
+    otext, _, _ = oracle.process_pairs(oidx, seq, off, names, None, 0, "", 8)
+    header = "@SQ\tSN:20_slice\tLN:321635\n"
+    oflags, _ = oracle_dup_flags(oracle, otext, header)
+    ends = sam_primary_ends(otext, ["20_slice"])
+    dup = capi.sbl_markdup(lib, ends)
+    assert len(dup) == len(oflags) == n_pairs
+    assert np.array_equal(dup, oflags), (int(dup.sum()), int(oflags.sum()))
+    assert dup.sum() > 0
+    return int(dup.sum())
+
+
 def check_align1(lib, oracle, n_pairs, seed, read_len=150):
     prefix = EXAMPLE_FA
     oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)

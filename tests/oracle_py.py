@@ -73,6 +73,24 @@ class Oracle:
                 return reg_off, out[:tot]
             cap = tot
 
+    def samblaster(self, sam_text, exclude_dups=True, add_mate_tags=True, max_split=2, min_non_overlap=20):
+        """Oracle samblaster over SAM text (via temp files); returns the marked SAM text."""
+        import os
+        import subprocess
+        import tempfile
+        exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "orc_bwa")
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "in.sam"), "w") as f:
+                f.write(sam_text)
+            cmd = [exe, "samblaster"] + (["--excludeDups"] if exclude_dups else []) + (["--addMateTags"] if add_mate_tags else []) + \
+                  ["--maxSplitCount", str(max_split), "--minNonOverlap", str(min_non_overlap),
+                   "--splitterFile", os.path.join(d, "spl.sam"), "--discordantFile", os.path.join(d, "disc.sam")]
+            with open(os.path.join(d, "in.sam")) as fi:
+                out = subprocess.run(cmd, stdin=fi, capture_output=True, text=True, check=True).stdout
+            self.last_splitters = open(os.path.join(d, "spl.sam")).read()
+            self.last_discordants = open(os.path.join(d, "disc.sam")).read()
+        return out
+
     def process_pairs(self, idx, seq, off, names, quals=None, n_processed=0, rg_id="", n_threads=1, pes0=None):
         from speedseq_amd.capi import PESTAT_DT
         n = len(off) - 1

@@ -41,5 +41,9 @@ def test_gpu_pe_sam_250_long_insert(gpu_lib, oracle):
     assert text.count("\n") >= 3000
 
 
+def test_gpu_dedup(gpu_lib, oracle):
+    assert common.check_dedup(gpu_lib, oracle, 20000, seed=19) > 1000
+
+
 def test_gpu_align1_250(gpu_lib, oracle):
     assert common.check_align1(gpu_lib, oracle, 1000, seed=16, read_len=250) > 1000

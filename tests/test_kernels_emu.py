@@ -34,5 +34,9 @@ def test_emu_pe_sam_250_long_insert(emu_lib, oracle):
     assert text.count("\n") >= 120
 
 
+def test_emu_dedup(emu_lib, oracle):
+    assert common.check_dedup(emu_lib, oracle, 400, seed=9) > 20
+
+
 def test_emu_align1_250(emu_lib, oracle):
     assert common.check_align1(emu_lib, oracle, 60, seed=6, read_len=250) > 60
