@@ -72,7 +72,7 @@ struct ssg_chain_w_lt {
  * order; for each, chains[id].first_seed is rewritten to an offset into chain_seeds[] (absolute
  * index) holding its n seed ids (absolute) in insertion order.
  */
-__global__ void ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
+__global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, int dbg_phase)

@@ -145,7 +145,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
  * One wavefront per pair (grid-strided).  regs: per-read slices [reg_off[r], reg_off[r+1]) with
  * head-room for rescued hits; n_reg updated in place.
  */
-__global__ void ssg_k_matesw(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const uint8_t *seq, const int64_t *read_off,
+__global__ void __launch_bounds__(256) ssg_k_matesw(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const uint8_t *seq, const int64_t *read_off,
                              const int64_t *reg_off, ssg_alnreg_t *regs, int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                              ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue)
 {
@@ -331,7 +331,7 @@ SSG_DEVFN int ssg_emit_xa(const ssg_mem_opt_t &opt, const ssg_alnreg_t *a, int n
  * zbuf: int32 per region slot.  req: per-read slices [req_off[r], req_off[r+1]); n_req out.
  * XA entries carry `owner` = region index (within the read) of the main record they belong to.
  */
-__global__ void ssg_k_pair_final(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, int64_t id0,
+__global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, int64_t id0,
                                  const int64_t *reg_off, ssg_alnreg_t *regs, const int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                                  int32_t *zbuf, ssg_pair64_t *vbuf, ssg_pair64_t *ubuf, int ucap,
                                  const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err)

@@ -106,7 +106,7 @@ struct ssg_intv_lt { SSG_DEVMEM bool operator()(const ssg_intv_t &a, const ssg_i
  * out_intv: [n_reads x cap] ; out_n: per-read interval count (count > cap => overflow, the host
  * re-runs those reads with a larger cap).  scratch: per launched lane 3*scap intervals.
  */
-__global__ void ssg_k_smem(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
+__global__ void __launch_bounds__(64) ssg_k_smem(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
                            ssg_intv_t *scratch, int scap, unsigned long long *n_extend)

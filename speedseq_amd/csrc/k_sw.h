@@ -2,19 +2,24 @@
  * k_sw.h -- one-wavefront-per-job Smith-Waterman primitives for gfx950 (SURVEY.md 8a rows a7,
  * a10, a12): upstream ksw_extend2, ksw_global2 (+backtrace) and ksw_align2's contract.
  *
- * Layout: lane l of the wave owns query columns j = l + 64*s (s < NS <= 4, i.e. queries up to 255
- * bases, enough for 2x150 and 2x250); H(i-1,j-1)/E(i,j) of upstream's eh[] array live in VGPRs for
- * the whole job, exactly one register pair per column, so even upstream's reads of stale eh[]
- * entries beyond a shrunken band are reproduced for free.  A DP row is processed by all lanes at
- * once:
+ * Layout (blocked): lane l of the wave owns the NS consecutive query columns j = l*NS + s
+ * (NS <= 4, i.e. up to 256 columns: enough for 2x150 and 2x250).  H(i-1,j-1)/E(i,j) of upstream's
+ * eh[] array live in VGPRs for the whole job, exactly one register pair per column, so even
+ * upstream's reads of stale eh[] entries beyond a shrunken band are reproduced for free.
+ * A DP row is processed by all lanes at once:
  *   - the diagonal operand H(i-1,j-1) is the lane's own register (eh[j].h);
- *   - H(i,j-1) for the next row comes from lane j-1 via a wave shift (DPP row_shr/wave_shr);
+ *   - H(i,j-1) for the next row comes from the neighbouring column: the lane's own previous slot,
+ *     or lane l-1's last slot via ONE wave shift (DPP wave_shr:1) per row;
  *   - the horizontal gap F(i,j) depends only on the row's M values (upstream opens E and F from M,
- *     not from H), so F is a max-plus prefix scan: F(i,j) = max_k<j (max(M_k-oe,0) - (j-1-k)*e),
- *     evaluated with a 6-step wave scan; for the textbook local recurrence the same holds with
- *     M replaced by max(M,E,0) because an F-opened-from-F term is dominated when o_ins > 0;
- *   - row maximum / arg-max, band trimming and the z-drop test are wave reductions + ballots, so
- *     beg/end/max/... stay wave-uniform (SGPR-resident after readfirstlane).
+ *     not from H), so F is a max-plus prefix scan: F(i,j) = max_k<j (max(M_k-oe,0) - (j-1-k)*e).
+ *     Each lane combines its NS columns locally, ONE 6-step DPP scan combines the lanes; for the
+ *     textbook local recurrence the same holds with M replaced by max(M,E,0) because an
+ *     F-opened-from-F term is dominated when o_ins > 0;
+ *   - row maximum / arg-max are one more scan + v_readlane, band trimming is a ballot per slot, so
+ *     beg/end/max/z-drop state stays wave-uniform (SGPRs).
+ * The target base of row i+1 is fetched while row i is computed; substitution scores are computed
+ * from (a, b) arithmetically (upstream bwa_fill_scmat: match a, mismatch -b, anything with N -1),
+ * so the row loop touches no memory besides that one byte.
  * All arithmetic is int32 like upstream: results are bit-exact.  No MFMA: this is integer DP.
  */
 #ifndef SSG_K_SW_H
@@ -27,37 +32,38 @@
 struct ssg_seqv_t { const uint8_t *p; int dir; };
 SSG_DEVFN int sq_at(const ssg_seqv_t &s, int k) { return s.p[s.dir * k]; }
 
-/* value of column j-1's v for column j = lane + 64*s ; `first` is returned for j == 0 */
-template <int NS>
-SSG_DEVFN void wv_shift_cols(const int (&v)[NS], int (&out)[NS], int first)
+/* upstream bwa_fill_scmat as arithmetic: t = target code 0..3(4), q = query code 0..4, 5 = pad column */
+SSG_DEVFN int ssg_sc(int a, int b, int t, int q) { return q > 4 ? 0 : (q > 3 || t > 3) ? -1 : (q == t ? a : -b); }
+
+/* uniform position of the first / last set lane of a ballot */
+SSG_DEVFN int ssg_first_lane(unsigned long long m) { return __ffsll(m) - 1; }
+SSG_DEVFN int ssg_last_lane(unsigned long long m) { return 63 - __clzll(m); }
+
+/* select v[idx] for a wave-uniform idx without dynamic register indexing */
+template <int NS> SSG_DEVFN int ssg_pick(const int (&v)[NS], int idx)
 {
-	int lane = wv_lane(), carry = first;
-	SSG_UNROLL for (int s = 0; s < NS; ++s) {
-		int up = wv_shfl(v[s], lane - 1);
-		int last = wv_shfl(v[s], 63);
-		out[s] = lane == 0 ? carry : up;
-		carry = last;
-	}
+	int r = v[0];
+	SSG_UNROLL for (int s = 1; s < NS; ++s) r = idx == s ? v[s] : r;
+	return r;
 }
 
 /* ------------------------------------------------------------------------------------------
- * upstream ksw_extend2.  Returns the score in all lanes; *res filled (uniform).
+ * upstream ksw_extend2.
  * ------------------------------------------------------------------------------------------ */
 template <int NS>
 SSG_DEVFN ssg_ext_res_t wv_extend2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target,
                                    int w, int end_bonus, int zdrop, int h0, unsigned long long *cells)
 {
 	const int lane = wv_lane();
+	const int sa = opt.a, sb = opt.b;
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 	int H[NS], E[NS], qc[NS];
 	int i, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
-	/* first row + query codes */
-	SSG_UNROLL for (int s = 0; s < NS; ++s) {
-		int j = lane + 64 * s;
+	SSG_UNROLL for (int s = 0; s < NS; ++s) { /* first row + query codes */
+		const int j = lane * NS + s;
 		qc[s] = j < qlen ? sq_at(query, j) : 4;
-		int v1 = h0 - oe_ins;                     /* eh[1].h before clamping */
-		int vj = v1 - (j - 1) * e_ins, vjm1 = vj + e_ins;
+		const int v1 = h0 - oe_ins, vj = v1 - (j - 1) * e_ins, vjm1 = vj + e_ins;
 		int h;
 		if (j == 0) h = h0;
 		else if (j == 1) h = v1 > 0 ? v1 : 0;
@@ -65,8 +71,7 @@ SSG_DEVFN ssg_ext_res_t wv_extend2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_
 		H[s] = h; E[s] = 0;
 	}
 	{	/* band clamp */
-		int mx = 0;
-		for (int k = 0; k < 25; ++k) mx = mx > opt.mat[k] ? mx : opt.mat[k];
+		int mx = sa > 0 ? sa : 0;
 		max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
 		max_ins = max_ins > 1 ? max_ins : 1;
 		w = w < max_ins ? w : max_ins;
@@ -77,64 +82,64 @@ SSG_DEVFN ssg_ext_res_t wv_extend2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_
 	max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
 	beg = 0; end = qlen;
 	unsigned long long ncell = 0;
+	int tb = tlen > 0 ? sq_at(target, 0) : 0;
 	for (i = 0; i < tlen; ++i) {
-		int h1_init, m = 0, mj = -1, h_last;
-		const int tb = sq_at(target, i);
+		int h1_init, m, mj, h_last;
+		const int tb_next = i + 1 < tlen ? sq_at(target, i + 1) : 0;   /* in flight during this row */
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
 		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
 		else h1_init = 0;
 		if (beg >= end) { /* empty row: eh[end] = {h1_init, 0}; only the to-end bookkeeping can change */
-			SSG_UNROLL for (int s = 0; s < NS; ++s) if (lane + 64 * s == end) { H[s] = h1_init; E[s] = 0; }
+			SSG_UNROLL for (int s = 0; s < NS; ++s) if (lane * NS + s == end) { H[s] = h1_init; E[s] = 0; }
 			if (beg == qlen) { max_ie = gscore > h1_init ? max_ie : i; gscore = gscore > h1_init ? gscore : h1_init; }
 			break; /* m == 0 */
 		}
 		ncell += (unsigned long long)(end - beg);
-		int hrow[NS], carry = SSG_NEG;
-		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane + 64 * s;
+		int M[NS], p[NS], hrow[NS];
+		SSG_UNROLL for (int s = 0; s < NS; ++s) { /* M(i,j) and the lane-local prefix of the F scan */
+			const int j = lane * NS + s;
 			const bool act = j >= beg && j < end;
-			int M = H[s], e = E[s];
-			M = M ? M + opt.mat[tb * 5 + qc[s]] : 0;
-			int t = M - oe_ins; t = t > 0 ? t : 0;
-			int g = act ? t + j * e_ins : SSG_NEG;
-			int P = wv_scan_max(g);                 /* inclusive over lanes of this slot */
-			P = P > carry ? P : carry;
-			int Pm1 = wv_shfl(P, lane - 1);          /* P of column j-1 */
-			Pm1 = lane == 0 ? carry : Pm1;
-			carry = wv_shfl(P, 63);
-			int f = j == beg ? 0 : Pm1 - (j - 1) * e_ins;
-			int h = M > e ? M : e;
+			int mm = H[s];
+			mm = mm ? mm + ssg_sc(sa, sb, tb, qc[s]) : 0;
+			M[s] = mm;
+			int t = mm - oe_ins; t = t > 0 ? t : 0;
+			const int g = act ? t + j * e_ins : SSG_NEG;
+			p[s] = s ? (p[s-1] > g ? p[s-1] : g) : g;
+		}
+		const int X = wv_prev(wv_scan_max(p[NS-1]), SSG_NEG);    /* best opening in the lanes to the left */
+		SSG_UNROLL for (int s = 0; s < NS; ++s) {
+			const int j = lane * NS + s;
+			const bool act = j >= beg && j < end;
+			const int Pm1 = s ? (X > p[s-1] ? X : p[s-1]) : X;   /* prefix up to column j-1 */
+			const int f = j == beg ? 0 : Pm1 - (j - 1) * e_ins;
+			int e = E[s], h = M[s] > e ? M[s] : e;
 			h = h > f ? h : f;
 			hrow[s] = act ? h : 0;
 			if (act) {
-				t = M - oe_del; t = t > 0 ? t : 0;
+				int t = M[s] - oe_del; t = t > 0 ? t : 0;
 				e -= e_del; e = e > t ? e : t;
 				E[s] = e;
 			}
 		}
 		{	/* row maximum and the LAST column attaining it (upstream: mj = m > h ? mj : j) */
 			int ml = -1, cj = -1;
-			SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane + 64 * s; if (j >= beg && j < end) ml = ml > hrow[s] ? ml : hrow[s]; }
+			SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane * NS + s; if (j >= beg && j < end) ml = ml > hrow[s] ? ml : hrow[s]; }
 			m = wv_max(ml);
-			SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane + 64 * s; if (j >= beg && j < end && hrow[s] == m) cj = j; }
+			SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane * NS + s; if (j >= beg && j < end && hrow[s] == m) cj = j; }
 			mj = wv_max(cj);
 		}
 		/* eh[j].h <- H(i,j-1) for j in (beg,end]; eh[beg].h <- h1_init; eh[end].e <- 0 */
-		int sh[NS];
-		wv_shift_cols<NS>(hrow, sh, 0);
+		const int up = wv_prev(hrow[NS-1], 0);
 		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane + 64 * s;
+			const int j = lane * NS + s;
+			const int hp = s ? hrow[s-1] : up;
 			if (j == beg) H[s] = h1_init;
-			else if (j > beg && j <= end) H[s] = sh[s];
+			else if (j > beg && j <= end) H[s] = hp;
 			if (j == end) E[s] = 0;
 		}
-		{	/* h1 after the loop = H(i,end-1) */
-			int v = 0;
-			SSG_UNROLL for (int s = 0; s < NS; ++s) { int b = wv_shfl(hrow[s], (end - 1) & 63); if (((end - 1) >> 6) == s) v = b; }
-			h_last = v;
-		}
+		h_last = wv_get(ssg_pick<NS>(hrow, (end - 1) % NS), (end - 1) / NS);   /* h1 after the loop = H(i,end-1) */
 		if (end == qlen) { max_ie = gscore > h_last ? max_ie : i; gscore = gscore > h_last ? gscore : h_last; }
 		if (m == 0) break;
 		if (m > max) {
@@ -147,18 +152,19 @@ SSG_DEVFN ssg_ext_res_t wv_extend2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_
 		/* trim the band on the freshly written eh[] */
 		int nbeg = end, jlast;
 		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane + 64 * s;
-			unsigned long long mb = wv_ballot((H[s] != 0 || E[s] != 0) && j >= beg && j < end);
-			if (mb && nbeg == end) nbeg = 64 * s + __ffsll(mb) - 1;
+			const int j = lane * NS + s;
+			const unsigned long long mb = wv_ballot((H[s] != 0 || E[s] != 0) && j >= beg && j < end);
+			if (mb) { const int c = ssg_first_lane(mb) * NS + s; nbeg = nbeg < c ? nbeg : c; }
 		}
 		jlast = nbeg - 1;
 		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane + 64 * s;
-			unsigned long long me = wv_ballot((H[s] != 0 || E[s] != 0) && j >= nbeg && j <= end);
-			if (me) jlast = 64 * s + 63 - __clzll(me);
+			const int j = lane * NS + s;
+			const unsigned long long me = wv_ballot((H[s] != 0 || E[s] != 0) && j >= nbeg && j <= end);
+			if (me) { const int c = ssg_last_lane(me) * NS + s; jlast = jlast > c ? jlast : c; }
 		}
 		beg = nbeg;
 		end = jlast + 2 < qlen ? jlast + 2 : qlen;
+		tb = tb_next;
 	}
 	if (cells) *cells += ncell;
 	ssg_ext_res_t r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
@@ -184,38 +190,45 @@ template <int NS>
 SSG_DEVFN int wv_global2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int w, uint8_t *z, unsigned long long *cells)
 {
 	const int lane = wv_lane();
+	const int sa = opt.a, sb = opt.b;
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	const int NEG2 = SSG_MINUS_INF + SSG_MINUS_INF / 2;   /* below every value the recurrence can produce */
 	int H[NS], E[NS], qc[NS];
 	SSG_UNROLL for (int s = 0; s < NS; ++s) {
-		int j = lane + 64 * s;
+		const int j = lane * NS + s;
 		qc[s] = j < qlen ? sq_at(query, j) : 4;
 		if (j == 0) { H[s] = 0; E[s] = SSG_MINUS_INF; }
 		else if (j <= qlen && j <= w) { H[s] = -(o_ins + e_ins * j); E[s] = SSG_MINUS_INF; }
 		else { H[s] = E[s] = SSG_MINUS_INF; }
 	}
 	unsigned long long ncell = 0;
+	int tb = tlen > 0 ? sq_at(target, 0) : 0;
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = sq_at(target, i);
+		const int tb_next = i + 1 < tlen ? sq_at(target, i + 1) : 0;
 		const int beg = i > w ? i - w : 0;
 		const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : SSG_MINUS_INF;
-		int hrow[NS], carry = SSG_MINUS_INF * 2;
+		int M[NS], p[NS], hrow[NS];
 		if (end > beg) ncell += (unsigned long long)(end - beg);
 		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane + 64 * s;
+			const int j = lane * NS + s;
 			const bool act = j >= beg && j < end;
-			int m = H[s] + opt.mat[tb * 5 + qc[s]], e = E[s];
-			int g = act ? (m - oe_ins) + j * e_ins : SSG_MINUS_INF * 2;
-			int P = wv_scan_max(g);
-			P = P > carry ? P : carry;
-			int Pm1 = wv_shfl(P, lane - 1);
-			Pm1 = lane == 0 ? carry : Pm1;
-			carry = wv_shfl(P, 63);
+			M[s] = H[s] + ssg_sc(sa, sb, tb, qc[s]);
+			const int g = act ? (M[s] - oe_ins) + j * e_ins : NEG2;
+			p[s] = s ? (p[s-1] > g ? p[s-1] : g) : g;
+		}
+		const int X = wv_prev(wv_scan_max(p[NS-1]), NEG2);
+		SSG_UNROLL for (int s = 0; s < NS; ++s) {
+			const int j = lane * NS + s;
+			const bool act = j >= beg && j < end;
+			const int Pm1 = s ? (X > p[s-1] ? X : p[s-1]) : X;
 			/* F(i,j): decayed initial -inf, or the best opening to the left */
 			int f = SSG_MINUS_INF - (j - beg) * e_ins;
-			if (j > beg) { int fs = Pm1 - (j - 1) * e_ins; f = f > fs ? f : fs; }
+			if (j > beg) { const int fs = Pm1 - (j - 1) * e_ins; f = f > fs ? f : fs; }
+			const int m = M[s];
+			int e = E[s];
 			uint8_t d = m >= e ? 0 : 1;
 			int h = m >= e ? m : e;
 			d = h >= f ? d : 2;
@@ -228,26 +241,25 @@ SSG_DEVFN int wv_global2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, i
 				e = e > t ? e : t;
 				E[s] = e;
 				t = m - oe_ins;
-				int f2 = f - e_ins;
+				const int f2 = f - e_ins;
 				d |= f2 > t ? 2 << 4 : 0;
 				if (z) z[(long)i * n_col + (j - beg)] = d;
 			}
 		}
-		int sh[NS];
-		wv_shift_cols<NS>(hrow, sh, 0);
+		const int up = wv_prev(hrow[NS-1], 0);
 		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane + 64 * s;
+			const int j = lane * NS + s;
+			const int hp = s ? hrow[s-1] : up;
 			if (end > beg) {
 				if (j == beg) H[s] = h1_init;
-				else if (j > beg && j <= end) H[s] = sh[s];
+				else if (j > beg && j <= end) H[s] = hp;
 			} else if (j == end) H[s] = h1_init;
 			if (j == end) E[s] = SSG_MINUS_INF;
 		}
+		tb = tb_next;
 	}
 	if (cells) *cells += ncell;
-	int score = 0;
-	SSG_UNROLL for (int s = 0; s < NS; ++s) { int b = wv_shfl(H[s], qlen & 63); if ((qlen >> 6) == s) score = b; }
-	return score;
+	return wv_get(ssg_pick<NS>(H, qlen % NS), qlen / NS);
 }
 
 SSG_DEVFN int wv_global2_any(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int w, uint8_t *z, unsigned long long *cells)
@@ -289,41 +301,46 @@ struct ssg_sw1_t { int score, te, qe, score2, te2; };
 
 template <int NS>
 SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target,
-                             int p, int minsc, int endsc, unsigned long long *bscratch, unsigned long long *cells)
+                             int p_, int minsc, int endsc, unsigned long long *bscratch, unsigned long long *cells)
 {
 	const int lane = wv_lane();
+	const int sa = opt.a, sb = opt.b;
 	const int e_del = opt.e_del, e_ins = opt.e_ins, oe_del = opt.o_del + e_del, oe_ins = opt.o_ins + e_ins;
-	const int slen = (qlen + p - 1) / p, qp = slen * p;
+	const int slen = (qlen + p_ - 1) / p_, qp = slen * p_;
 	int H[NS], E[NS], HM[NS], qc[NS];
-	int gmax = 0, te = -1, n_b = 0, maxsc = 0, last_sc = 0, last_row = -2;
-	for (int k = 0; k < 25; ++k) maxsc = maxsc > opt.mat[k] ? maxsc : opt.mat[k];
-	SSG_UNROLL for (int s = 0; s < NS; ++s) { int j = lane + 64 * s; qc[s] = j < qlen ? sq_at(query, j) : 5; H[s] = E[s] = HM[s] = 0; }
-	int i;
+	int gmax = 0, te = -1, n_b = 0, last_sc = 0, last_row = -2;
+	const int maxsc = sa > 0 ? sa : 0;
+	SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane * NS + s; qc[s] = j < qlen ? sq_at(query, j) : 5; H[s] = E[s] = HM[s] = 0; }
+	int i, tb = tlen > 0 ? sq_at(target, 0) : 0;
 	for (i = 0; i < tlen; ++i) {
-		const int tb = sq_at(target, i);
-		int diag[NS], hrow[NS], carry = SSG_NEG, imax = 0;
-		wv_shift_cols<NS>(H, diag, 0);
+		const int tb_next = i + 1 < tlen ? sq_at(target, i + 1) : 0;
+		int hn[NS], p[NS], hrow[NS];
+		const int up = wv_prev(H[NS-1], 0);          /* H(i-1, j-1) for the lane's first column */
 		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane + 64 * s;
+			const int j = lane * NS + s;
 			const bool act = j < qp;
-			int sc = qc[s] < 5 ? opt.mat[tb * 5 + qc[s]] : 0;
-			int hn = diag[s] + sc, e = E[s];
-			hn = hn > e ? hn : e; hn = hn > 0 ? hn : 0;
-			int g = act ? (hn - oe_ins) + j * e_ins : SSG_NEG;
-			int P = wv_scan_max(g);
-			P = P > carry ? P : carry;
-			int Pm1 = wv_shfl(P, lane - 1);
-			Pm1 = lane == 0 ? carry : Pm1;
-			carry = wv_shfl(P, 63);
+			int v = (s ? H[s-1] : up) + ssg_sc(sa, sb, tb, qc[s]);
+			const int e = E[s];
+			v = v > e ? v : e; v = v > 0 ? v : 0;
+			hn[s] = v;
+			const int g = act ? (v - oe_ins) + j * e_ins : SSG_NEG;
+			p[s] = s ? (p[s-1] > g ? p[s-1] : g) : g;
+		}
+		const int X = wv_prev(wv_scan_max(p[NS-1]), SSG_NEG);
+		int ml = 0;
+		SSG_UNROLL for (int s = 0; s < NS; ++s) {
+			const int j = lane * NS + s;
+			const bool act = j < qp;
+			const int Pm1 = s ? (X > p[s-1] ? X : p[s-1]) : X;
 			int f = j == 0 ? 0 : Pm1 - (j - 1) * e_ins; f = f > 0 ? f : 0;
-			int h = hn > f ? hn : f;
+			const int h = hn[s] > f ? hn[s] : f;
 			hrow[s] = act ? h : 0;
-			e -= e_del; { int t = h - oe_del; e = e > t ? e : t; } e = e > 0 ? e : 0;
+			int e = E[s] - e_del; { const int t = h - oe_del; e = e > t ? e : t; } e = e > 0 ? e : 0;
 			if (act) E[s] = e;
-			int rm = wv_max(act ? h : 0);
-			imax = imax > rm ? imax : rm;
+			ml = ml > hrow[s] ? ml : hrow[s];
 		}
 		SSG_UNROLL for (int s = 0; s < NS; ++s) H[s] = hrow[s];
+		const int imax = wv_max(ml);
 		if (imax >= minsc) { /* b[]: collapse runs of adjacent rows, keep the entry in registers */
 			if (n_b == 0 || last_row + 1 != i) { last_sc = imax; last_row = i; if (lane == 0) bscratch[n_b] = (unsigned long long)imax << 32 | (unsigned)i; ++n_b; }
 			else if (last_sc < imax) { last_sc = imax; last_row = i; if (lane == 0) bscratch[n_b - 1] = (unsigned long long)imax << 32 | (unsigned)i; }
@@ -333,15 +350,16 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 			SSG_UNROLL for (int s = 0; s < NS; ++s) HM[s] = hrow[s];
 			if (gmax >= endsc) break;
 		}
+		tb = tb_next;
 	}
 	if (cells) *cells += (unsigned long long)(i < tlen ? i + 1 : tlen) * qlen;
 	ssg_sw1_t r; r.score = gmax; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1;
 	{	/* smallest padded column holding the row maximum of Hmax */
-		int mx = -1;
-		SSG_UNROLL for (int s = 0; s < NS; ++s) { int j = lane + 64 * s; int v = j < qp ? HM[s] : -1; v = wv_max(v); mx = mx > v ? mx : v; }
-		int best = 1 << 30;
-		SSG_UNROLL for (int s = 0; s < NS; ++s) { int j = lane + 64 * s; int c = (j < qp && HM[s] == mx) ? j : (1 << 30); c = wv_min(c); best = best < c ? best : c; }
-		r.qe = best;
+		int mx = -1, best = 1 << 30;
+		SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane * NS + s; const int v = j < qp ? HM[s] : -1; mx = mx > v ? mx : v; }
+		mx = wv_max(mx);
+		SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane * NS + s; const int c = (j < qp && HM[s] == mx) ? j : (1 << 30); best = best < c ? best : c; }
+		r.qe = wv_min(best);
 	}
 	ssg_wave_memsync();
 	if (n_b) {

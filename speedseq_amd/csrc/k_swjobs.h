@@ -6,7 +6,7 @@
 #define SSG_K_SWJOBS_H
 #include "k_sw.h"
 
-__global__ void ssg_k_align2_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_sw_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,
+__global__ void __launch_bounds__(256) ssg_k_align2_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_sw_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,
                                   ssg_kswr_t *res, unsigned long long *bscratch, int bstride)
 {
 	long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -17,7 +17,7 @@ __global__ void ssg_k_align2_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_sw_jo
 	if (wv_lane() == 0) res[wid] = r;
 }
 
-__global__ void ssg_k_global_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_glb_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,
+__global__ void __launch_bounds__(256) ssg_k_global_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_glb_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,
                                   int32_t *score, int32_t *n_cigar, uint32_t *cigar, int cap, uint8_t *zscratch, long zstride)
 {
 	long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;

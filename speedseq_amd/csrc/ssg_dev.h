@@ -38,36 +38,54 @@ SSG_DEVFN void ssg_wave_memsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wo
 #define SSG_LANE0(...) do { ssg_wave_memsync(); if (wv_lane() == 0) { __VA_ARGS__; } ssg_wave_memsync(); } while (0)
 
 SSG_DEVFN int wv_lane() { return (int)(threadIdx.x & 63); }
-/* value of lane-1 (lane 0 receives `fill`) */
-SSG_DEVFN int wv_up1(int v, int fill) { int l = wv_lane(); int r = wv_shfl(v, l - 1); return l == 0 ? fill : r; }
-SSG_DEVFN int wv_bcast(int v, int src) { return wv_shfl(v, src); }
-SSG_DEVFN long long wv_bcast64(long long v, int src)
-{
-	int lo = wv_shfl((int)(unsigned)(unsigned long long)v, src), hi = wv_shfl((int)((unsigned long long)v >> 32), src);
-	return (long long)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
-}
-SSG_DEVFN int wv_max(int v)
-{
-	for (int d = 1; d < 64; d <<= 1) { int o = wv_shfl(v, wv_lane() ^ d); v = v > o ? v : o; }
-	return v;
-}
-SSG_DEVFN int wv_min(int v)
-{
-	for (int d = 1; d < 64; d <<= 1) { int o = wv_shfl(v, wv_lane() ^ d); v = v < o ? v : o; }
-	return v;
-}
-SSG_DEVFN int wv_sum(int v)
-{
-	for (int d = 1; d < 64; d <<= 1) v += wv_shfl(v, wv_lane() ^ d);
-	return v;
-}
-/* inclusive prefix max over lanes 0..lane */
+
+/*
+ * Cross-lane primitives.  On gfx950 they are DPP modifiers on ordinary VALU instructions
+ * (row_shr:1/2/4/8, row_bcast:15/31, wave_shr:1 -- a few cycles each) and v_readlane_b32 (result in
+ * an SGPR, i.e. broadcast for free); the generic __shfl lowers to ds_bpermute_b32, a round trip
+ * through the LDS crossbar of >100 cycles, and a DP row needs ~40 of these on its critical path.
+ */
+#ifdef SSG_EMU
+SSG_DEVFN int wv_prev(int v, int fill) { int l = wv_lane(); int r = wv_shfl(v, l - 1); return l == 0 ? fill : r; }
+SSG_DEVFN int wv_get(int v, int src) { return wv_shfl(v, src); }          /* src wave-uniform */
 SSG_DEVFN int wv_scan_max(int v)
 {
 	int l = wv_lane();
 	for (int d = 1; d < 64; d <<= 1) { int o = wv_shfl(v, l - d); if (l >= d) v = v > o ? v : o; }
 	return v;
 }
+SSG_DEVFN int wv_sum(int v) { for (int d = 1; d < 64; d <<= 1) v += wv_shfl(v, wv_lane() ^ d); return v; }
+#else
+#define SSG_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
+SSG_DEVFN int wv_prev(int v, int fill) { return SSG_DPP(fill, v, 0x138 /* wave_shr:1 */, 0xf); }
+SSG_DEVFN int wv_get(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+SSG_DEVFN int wv_scan_max(int v)
+{	/* inclusive prefix max over lanes 0..lane: 4 row_shr steps inside each row of 16, then two row broadcasts */
+	int t;
+	t = SSG_DPP(v, v, 0x111, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(v, v, 0x112, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(v, v, 0x114, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(v, v, 0x118, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(v, v, 0x142 /* row_bcast:15 */, 0xa); v = v > t ? v : t;
+	t = SSG_DPP(v, v, 0x143 /* row_bcast:31 */, 0xc); v = v > t ? v : t;
+	return v;
+}
+SSG_DEVFN int wv_sum(int v)
+{
+	v += SSG_DPP(0, v, 0x111, 0xf); v += SSG_DPP(0, v, 0x112, 0xf); v += SSG_DPP(0, v, 0x114, 0xf); v += SSG_DPP(0, v, 0x118, 0xf);
+	v += SSG_DPP(0, v, 0x142, 0xa); v += SSG_DPP(0, v, 0x143, 0xc);
+	return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
+SSG_DEVFN int wv_last(int v) { return wv_get(v, 63); }
+SSG_DEVFN int wv_bcast(int v, int src) { return wv_get(v, src); }
+SSG_DEVFN long long wv_bcast64(long long v, int src)
+{
+	int lo = wv_shfl((int)(unsigned)(unsigned long long)v, src), hi = wv_shfl((int)((unsigned long long)v >> 32), src);
+	return (long long)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
+}
+SSG_DEVFN int wv_max(int v) { return wv_last(wv_scan_max(v)); }
+SSG_DEVFN int wv_min(int v) { return -wv_max(-v); }   /* |v| < 2^31 everywhere it is used */
 SSG_DEVFN int imax(int a, int b) { return a > b ? a : b; }
 SSG_DEVFN int imin(int a, int b) { return a < b ? a : b; }
 SSG_DEVFN int iabs(int a) { return a < 0 ? -a : a; }
