@@ -64,8 +64,8 @@ __global__ void ssg_k_pestat_hist(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_
 
 SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const ssg_pestat_t *pes, const ssg_alnreg_t a,
                         int l_ms, const uint8_t *ms, ssg_alnreg_t *ma, int *ma_n_, int ma_cap,
-                        uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells)
-{	/* upstream mem_matesw */
+                        uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells, unsigned long long *ph)
+{	/* upstream mem_matesw; ph[]: cycle counters per phase (fetch, SW, re-sort, window rows) */
 	const int64_t l_pac = ix.l_pac;
 	int i, r, skip[4], n = 0, rid = -1, ma_n = *ma_n_;
 	for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
@@ -99,7 +99,9 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 		}
 		if (a.rid == rid && re - rb >= opt.min_seed_len) {
 			if (re - rb > tcap || re - rb > SSG_MS_BCAP) { *err = 1; continue; }
+			unsigned long long c0 = ssg_clock();
 			wv_fetch_ref(ix, rb, re, tbuf);
+			ph[0] += ssg_clock() - c0; c0 = ssg_clock();
 			ssg_seqv_t q;
 			if (is_rev) {
 				ssg_wave_memsync();
@@ -110,6 +112,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			ssg_seqv_t t = { tbuf, 1 };
 			int xtra = SSG_KSW_XSUBO | SSG_KSW_XSTART | (l_ms * opt.a < 250 ? SSG_KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
 			ssg_kswr_t aln = wv_align2(opt, l_ms, q, (int)(re - rb), t, xtra, bscratch, cells);
+			ph[1] += ssg_clock() - c0; ph[3] += (unsigned long long)(re - rb);
 			if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
 				ssg_alnreg_t b;
 				b.rb = b.re = 0; b.qb = b.qe = 0; b.truesc = b.sub = b.alt_sc = b.sub_n = b.w = b.secondary_all = b.seedlen0 = b.n_comp = 0; b.frac_rep = 0; b.hash = 0;
@@ -135,7 +138,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			}
 			++n;
 		}
-		if (n) ma_n = wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells);
+		if (n) { unsigned long long c1 = ssg_clock(); ma_n = wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); ph[2] += ssg_clock() - c1; }
 	}
 	*ma_n_ = ma_n;
 	return n;
@@ -155,7 +158,8 @@ __global__ void __launch_bounds__(256) ssg_k_matesw(ssg_index_view_t ix, ssg_mem
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB;
 	unsigned long long *bs = bglb + wave0 * (long)SSG_MS_BCAP;
 	ssg_alnreg_t *bc = bcopy + wave0 * 2L * 64;          /* upstream's b[2] (<= max_matesw used, 64 kept) */
-	unsigned long long nc = 0, nres = 0;
+	unsigned long long nc = 0, nres = 0, ph[5] = {0, 0, 0, 0, 0};
+	const unsigned long long k0 = ssg_clock();
 	for (long p = wave0; p < n_pairs; p += nwaves) {
 		const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
 		int myerr = 0, nb[2] = {0, 0};
@@ -177,12 +181,17 @@ __global__ void __launch_bounds__(256) ssg_k_matesw(ssg_index_view_t ix, ssg_mem
 				for (int j = 0; j < nb[i]; ++j) {
 					const int l_ms = (int)(read_off[2*p + !i + 1] - read_off[2*p + !i]);
 					const uint8_t *ms = seq + read_off[2*p + !i];
-					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc);
+					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph);
 				}
 		}
 		if (wv_lane() == 0) { n_reg[2*p] = an[0]; n_reg[2*p+1] = an[1]; if (myerr) err[p] = myerr; }
 	}
-	if (wv_lane() == 0) { if (cells) atomicAdd(cells, nc); if (n_rescue) atomicAdd(n_rescue, nres); }
+	if (wv_lane() == 0) {
+		if (cells) atomicAdd(cells, nc);
+		if (n_rescue) atomicAdd(n_rescue, nres);
+		ph[4] = ssg_clock() - k0;
+		for (int t = 0; t < 5; ++t) atomicAdd(&ssg_dbg_cyc[t], ph[t]);
+	}
 }
 
 /* ---------------- primary marking, pairing, MAPQ ---------------- */

@@ -27,6 +27,14 @@ SSG_DEVFN unsigned long long wv_ballot(int p) { return __ballot(p); }
 #endif
 
 #define SSG_WAVE 64
+/* phase cycle counters for kernel tuning (read back with ssg_dbg_cycles) */
+#ifdef SSG_EMU
+static unsigned long long ssg_dbg_cyc[8];
+SSG_DEVFN unsigned long long ssg_clock() { return 0; }
+#else
+__device__ unsigned long long ssg_dbg_cyc[8];
+SSG_DEVFN unsigned long long ssg_clock() { return (unsigned long long)clock64(); }
+#endif
 /* make one lane's global stores visible to the other lanes of the same wave */
 #ifdef SSG_EMU
 SSG_DEVFN void ssg_wave_memsync() { (void)emu_ballot(0); } /* fibers are not lock-step: rendezvous */

@@ -189,6 +189,20 @@ void ssg_prof_reset(void) {}
 int ssg_prof_get(int, const char **, double *, long *) { return 0; }
 #endif
 
+/* tuning aid: device phase counters (cycles) accumulated by instrumented kernels; reset on read */
+int ssg_dbg_cycles(unsigned long long out[8])
+{
+#ifdef SSG_EMU
+	memcpy(out, ssg_dbg_cyc, 64); memset(ssg_dbg_cyc, 0, 64);
+	return 0;
+#else
+	unsigned long long z[8] = {0,0,0,0,0,0,0,0};
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 64) != hipSuccess) return SSG_EHIP;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 64) != hipSuccess) return SSG_EHIP;
+	return 0;
+#endif
+}
+
 int64_t ssg_index_l_pac(const ssg_index_t *ix) { return ix->v.l_pac; }
 int ssg_index_n_ctg(const ssg_index_t *ix) { return ix->v.n_ctg; }
 
