@@ -1,11 +1,12 @@
-# Top-level build: product library (HIP, gfx950), CPU oracle, and the test-only emulation build.
+# Top-level build: product library + executables (HIP, gfx950), CPU oracle, and the test-only emulation build.
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 CSRC    = speedseq_amd/csrc
+HOST    = speedseq_amd/host
 KHDRS   = $(wildcard $(CSRC)/*.h) include/ssgpu.h
 HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable
 
-all: lib oracle emu
+all: lib tools oracle emu
 
 lib: speedseq_amd/libssgpu.so
 speedseq_amd/libssgpu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
@@ -13,15 +14,27 @@ speedseq_amd/libssgpu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
 	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core.o $(CSRC)/sam_format.o -o $@
 
+# the executables speedseq.config names (reference bin/speedseq.config:13-14)
+tools: bin/bwa bin/samblaster
+bin/bwa: $(HOST)/bwa_main.cpp include/ssgpu.h speedseq_amd/libssgpu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
+bin/samblaster: $(HOST)/samblaster_main.cpp include/ssgpu.h speedseq_amd/libssgpu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Lspeedseq_amd -lssgpu -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
+
 oracle:
 	$(MAKE) -C oracle
 
-emu: tests/emu/libssgpu_emu.so
+# host emulation of the HIP execution model: same kernel + host sources, CPU-side tests only
+emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu
 tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
 		$(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread
+tests/emu/bwa_emu: $(HOST)/bwa_main.cpp include/ssgpu.h tests/emu/libssgpu_emu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -Wl,-rpath,'$$ORIGIN'
+tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp include/ssgpu.h tests/emu/libssgpu_emu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Ltests/emu -lssgpu_emu -Wl,-rpath,'$$ORIGIN'
 
 clean:
-	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so
+	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so bin/bwa bin/samblaster tests/emu/bwa_emu tests/emu/samblaster_emu $(CSRC)/*.o
 	$(MAKE) -C oracle clean
-.PHONY: all lib oracle emu clean
+.PHONY: all lib tools oracle emu clean

@@ -114,6 +114,12 @@ int32_t ssg_index_len(const ssg_index_t *idx, int i);
  * ends: 2*n_pairs primary records (read1, read2 per pair) in input order; dup[p] = 1 when an
  * earlier pair of the same call carries the same 5'-unclipped signature (first seen wins). */
 int ssg_sbl_markdup(long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup);
+/* streaming form: the signature table persists in HBM between calls (first-seen-wins over the whole
+ * stream, as upstream's single pass) */
+typedef struct ssg_sbl_state ssg_sbl_state_t;
+ssg_sbl_state_t *ssg_sbl_state_new(void);
+void ssg_sbl_state_free(ssg_sbl_state_t *st);
+int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup);
 
 /* ---- the measured hot path with device-resident inputs (bench.py) ----
  * d_seq / d_off / d_pair_batch are DEVICE pointers; aligned + duplicate-marked records stay in HBM.

@@ -648,6 +648,48 @@ int ssg_sbl_markdup(long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup)
 	return d_dup.down(dup, n_pairs);
 }
 
+/* Streaming duplicate marking: the signature table of everything seen so far stays in HBM, sorted by
+ * hash, so first-seen-wins holds across calls exactly as in upstream's single pass over the stream. */
+struct ssg_sbl_state { dbuf<uint64_t> hash; dbuf<ssg_sig_t> sig; long n; };
+
+ssg_sbl_state_t *ssg_sbl_state_new(void) { ssg_sbl_state *s = new ssg_sbl_state(); s->n = 0; return s; }
+void ssg_sbl_state_free(ssg_sbl_state_t *s) { delete s; }
+
+int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup)
+{
+	CHK(need_device());
+	if (n_pairs <= 0) return 0;
+	if (st->n + n_pairs >= (1L << 31)) { ssg_err_msg = "ssg_sbl_markdup_stream: more than 2^31 pairs"; return SSG_EINVAL; }
+	const int block = 256;
+	dbuf<ssg_sbl_end_t> d_ends(2 * n_pairs); dbuf<uint8_t> d_dup(n_pairs);
+	dbuf<ssg_sig_t> d_sig(n_pairs); dbuf<uint64_t> d_h(n_pairs), d_hs(n_pairs); dbuf<uint32_t> d_o(n_pairs), d_os(n_pairs);
+	CHKA(d_ends); CHKA(d_dup); CHKA(d_sig); CHKA(d_h); CHKA(d_hs); CHKA(d_o); CHKA(d_os);
+	CHK(d_ends.up(ends, 2 * n_pairs));
+	SSG_LAUNCH(ssg_k_sig, (n_pairs + block - 1) / block, block, 0, n_pairs, d_ends.p, d_sig.p, d_h.p, d_o.p);
+	CHK(rt_sync());
+	CHK(sort_pairs_u64(d_h.p, d_hs.p, d_o.p, d_os.p, n_pairs));
+	SSG_LAUNCH(ssg_k_markdup, (n_pairs + block - 1) / block, block, 0, n_pairs, d_hs.p, d_os.p, d_sig.p, st->n, st->hash.p, st->sig.p, d_dup.p);
+	CHK(rt_sync());
+	CHK(d_dup.down(dup, n_pairs));
+	/* extend the table: old ++ new (sorted by hash again); duplicates may stay in, they are harmless */
+	long tot = st->n + n_pairs;
+	dbuf<uint64_t> nh(tot), nhs(tot); dbuf<uint32_t> no(tot), nos(tot); dbuf<ssg_sig_t> cat(tot), nsig(tot);
+	CHKA(nh); CHKA(nhs); CHKA(no); CHKA(nos); CHKA(cat); CHKA(nsig);
+#ifdef SSG_EMU
+	if (st->n) { memcpy(nh.p, st->hash.p, st->n * 8); memcpy(cat.p, st->sig.p, st->n * sizeof(ssg_sig_t)); }
+	memcpy(nh.p + st->n, d_h.p, n_pairs * 8); memcpy(cat.p + st->n, d_sig.p, n_pairs * sizeof(ssg_sig_t));
+#else
+	if (st->n) { (void)hipMemcpy(nh.p, st->hash.p, st->n * 8, hipMemcpyDeviceToDevice); (void)hipMemcpy(cat.p, st->sig.p, st->n * sizeof(ssg_sig_t), hipMemcpyDeviceToDevice); }
+	(void)hipMemcpy(nh.p + st->n, d_h.p, n_pairs * 8, hipMemcpyDeviceToDevice); (void)hipMemcpy(cat.p + st->n, d_sig.p, n_pairs * sizeof(ssg_sig_t), hipMemcpyDeviceToDevice);
+#endif
+	{ std::vector<uint32_t> iota(tot); for (long i = 0; i < tot; ++i) iota[i] = (uint32_t)i; CHK(no.up(iota.data(), tot)); }
+	CHK(sort_pairs_u64(nh.p, nhs.p, no.p, nos.p, tot));
+	SSG_LAUNCH(ssg_k_gather_sig, (tot + block - 1) / block, block, 0, tot, nos.p, cat.p, nsig.p);
+	CHK(rt_sync());
+	st->hash.swap(nhs); st->sig.swap(nsig); st->n = tot;
+	return 0;
+}
+
 /* The measured hot path (bench.py): device-resident reads in, aligned + duplicate-marked records
  * left in HBM.  d_seq / d_off / d_pair_batch are DEVICE pointers.  summary[0] = records,
  * [1] = duplicate pairs, [2] = seeds, [3] = extension cells, [4] = rescue cells, [5] = rescues. */
