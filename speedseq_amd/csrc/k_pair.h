@@ -138,7 +138,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			}
 			++n;
 		}
-		if (n) { unsigned long long c1 = ssg_clock(); ma_n = wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); ph[2] += ssg_clock() - c1; }
+		if (n) { unsigned long long c1 = ssg_clock(); const int n_in = ma_n; ma_n = wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1; }
 	}
 	*ma_n_ = ma_n;
 	return n;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) ssg_k_matesw(ssg_index_view_t ix, ssg_mem
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB;
 	unsigned long long *bs = bglb + wave0 * (long)SSG_MS_BCAP;
 	ssg_alnreg_t *bc = bcopy + wave0 * 2L * 64;          /* upstream's b[2] (<= max_matesw used, 64 kept) */
-	unsigned long long nc = 0, nres = 0, ph[5] = {0, 0, 0, 0, 0};
+	unsigned long long nc = 0, nres = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	const unsigned long long k0 = ssg_clock();
 	for (long p = wave0; p < n_pairs; p += nwaves) {
 		const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) ssg_k_matesw(ssg_index_view_t ix, ssg_mem
 		if (cells) atomicAdd(cells, nc);
 		if (n_rescue) atomicAdd(n_rescue, nres);
 		ph[4] = ssg_clock() - k0;
-		for (int t = 0; t < 5; ++t) atomicAdd(&ssg_dbg_cyc[t], ph[t]);
+		for (int t = 0; t < 8; ++t) atomicAdd(&ssg_dbg_cyc[t], ph[t]);
 	}
 }
 

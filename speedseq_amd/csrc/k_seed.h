@@ -188,26 +188,25 @@ __global__ void ssg_k_sal_count(ssg_mem_opt_t opt, int n_reads, const ssg_intv_t
  */
 __global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                           const int64_t *seed_off, ssg_seed_t *seeds, int32_t *seed_rid)
-{
-	long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	long r = g / cap; int ii = (int)(g % cap);
-	if (r >= n_reads || ii >= n_intv[r]) return;
+{	/* one lane per SEED (sampled occurrence): every lane does one independent <=31-step LF walk, so the
+	 * random 64-byte fetches of a wave are 64 independent chains and long intervals cost no tail */
+	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= seed_off[n_reads]) return;
+	long lo = 0, hi = n_reads;                       /* last r with seed_off[r] <= g */
+	while (lo < hi) { long mid = (lo + hi + 1) >> 1; if (seed_off[mid] <= g) lo = mid; else hi = mid - 1; }
+	const long r = lo;
 	const ssg_intv_t *p = intv + r * cap;
-	long base = seed_off[r];
-	for (int i = 0; i < ii; ++i) base += ssg_intv_nocc(opt, p[i].x2);
-	ssg_intv_t v = p[ii];
-	int slen = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
-	uint64_t step = v.x2 > (uint64_t)opt.max_occ ? v.x2 / (uint64_t)opt.max_occ : 1;
-	int count = 0;
-	for (uint64_t k = 0; k < v.x2 && count < opt.max_occ; k += step, ++count) {
-		ssg_seed_t s;
-		s.rbeg = (int64_t)ssg_bwt_sa(ix, v.x0 + k);
-		s.qbeg = (int32_t)(v.info >> 32);
-		s.len = s.score = slen;
-		s.next = -1;
-		int rid = ssg_intv2rid(ix, s.rbeg, s.rbeg + s.len);
-		seeds[base + count] = s;
-		seed_rid[base + count] = rid;
-	}
+	long k = g - seed_off[r];
+	int ii = 0, c;
+	while ((c = ssg_intv_nocc(opt, p[ii].x2)) <= k) { k -= c; ++ii; }
+	const ssg_intv_t v = p[ii];
+	const uint64_t step = v.x2 > (uint64_t)opt.max_occ ? v.x2 / (uint64_t)opt.max_occ : 1;
+	ssg_seed_t s;
+	s.rbeg = (int64_t)ssg_bwt_sa(ix, v.x0 + (uint64_t)k * step);
+	s.qbeg = (int32_t)(v.info >> 32);
+	s.len = s.score = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
+	s.next = -1;
+	seeds[g] = s;
+	seed_rid[g] = ssg_intv2rid(ix, s.rbeg, s.rbeg + s.len);
 }
 #endif

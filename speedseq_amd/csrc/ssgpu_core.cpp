@@ -354,7 +354,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	if (!o.regs.alloc(ts) || !o.n_reg.alloc(n_reads)) { ssg_err_msg = "device allocation failed: regs"; return SSG_ENOMEM; }
 	CHK(d_cells.zero());
 	{
-		long g = (long)n_reads * cap;
+		long g = (long)tot;
 		SSG_LAUNCH(ssg_k_sal, (g + block - 1) / block, block, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p);
 	}
 	STAGE("sal");

@@ -1,0 +1,59 @@
+"""N>1 path on CPU: world_size-2 `gloo` run of the multi-GPU layer (speedseq_amd/dist.py).
+Pairs are dealt to two ranks by upstream batch; the exact global duplicate flags computed through the
+signature all-to-all must equal the oracle samblaster's single-stream flags."""
+import os
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import common
+
+
+def _worker(rank, world, port, ends_path, batch_path, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speedseq_amd import capi, dist as sdist
+    ends = np.load(ends_path)
+    pair_batch = np.load(batch_path)
+    n_batches = int(pair_batch.max()) + 1
+    mine = np.isin(pair_batch, sdist.shard_batches(n_batches, rank, world))
+    ordinal = torch.as_tensor(np.nonzero(mine)[0].astype(np.int64))
+    my_ends = ends.reshape(-1, 2)[mine].reshape(-1)
+    sig, valid = sdist.signatures(my_ends)
+    dup = sdist.global_markdup(sig, valid, ordinal)
+    t = sdist.max_over_ranks(1.0 + rank)
+    assert t == float(world)
+    np.save(os.path.join(out_dir, "dup%d.npy" % rank), np.stack([ordinal.numpy(), dup.numpy().astype(np.int64)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_dedup_two_ranks_gloo(oracle):
+    oidx = oracle.idx_load(common.EXAMPLE_FA)
+    n_pairs = 600
+    pairs, seqs, seq, off = common.sim_reads(n_pairs, 31, dup_frac=0.25)
+    names = []
+    for nm, _, _ in pairs:
+        names += [nm, nm]
+    otext, _, _ = oracle.process_pairs(oidx, seq, off, names, None, 0, "", 4)
+    oflags, _ = common.oracle_dup_flags(oracle, otext, "@SQ\tSN:20_slice\tLN:321635\n")
+    ends = common.sam_primary_ends(otext, ["20_slice"])
+    pair_batch = (np.arange(n_pairs) // 50).astype(np.int32)       # 12 "upstream batches"
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "ends.npy"), ends)
+        np.save(os.path.join(d, "pb.npy"), pair_batch)
+        port = 29500 + os.getpid() % 2000
+        mp.spawn(_worker, args=(2, port, os.path.join(d, "ends.npy"), os.path.join(d, "pb.npy"), d), nprocs=2, join=True)
+        got = np.zeros(n_pairs, dtype=np.uint8)
+        seen = np.zeros(n_pairs, dtype=bool)
+        for r in range(2):
+            o, v = np.load(os.path.join(d, "dup%d.npy" % r))
+            got[o] = v
+            seen[o] = True
+    assert seen.all()
+    assert np.array_equal(got, oflags), (int(got.sum()), int(oflags.sum()))
+    assert got.sum() > 50

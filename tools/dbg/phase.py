@@ -16,3 +16,4 @@ lib.l.ssg_dbg_cycles(out)
 tot = list(out)
 print("matesw phase cycles (sum over waves): fetch=%d sw=%d resort=%d rows=%d wave_total=%d" % tuple(tot[:5]))
 print("fractions of wave time: fetch %.2f sw %.2f resort %.2f" % (tot[0]/tot[4], tot[1]/tot[4], tot[2]/tot[4]))
+print("resort cycles by n_in: <=8: %.2f  9..64: %.2f  >64: %.2f (fractions of resort)" % (tot[5]/max(1,tot[2]), tot[6]/max(1,tot[2]), tot[7]/max(1,tot[2])))
