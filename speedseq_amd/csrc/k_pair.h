@@ -59,12 +59,79 @@ __global__ void ssg_k_pestat_hist(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_
 		atomicAdd(&hist[((long)pair_batch[i] * 4 + dir) * SSG_MAX_INS_HIST + is], 1u);
 }
 
+/* ---------------- region re-sort after a rescue, staged in LDS ----------------
+ * upstream mem_sort_dedup_patch as mem_matesw calls it (no patching).  The serial part runs on
+ * lane 0, but on 32-byte keys and a 16-bit index permutation held in LDS instead of 88-byte records
+ * in HBM (same comparison / swap sequence as the in-place introsort, so the same tie order); the
+ * surviving records are then gathered by all lanes. */
+#define SSG_SDP_CAP 256
+struct ssg_sdp_key_t { int64_t re, rb; int32_t qb, qe, score, rid; };
+struct ssg_sdp_lds_t { ssg_sdp_key_t key[SSG_SDP_CAP]; uint16_t idx[SSG_SDP_CAP]; int32_t m, _pad; };
+struct ssg_key_re_lt { const ssg_sdp_key_t *k; SSG_DEVMEM bool operator()(uint16_t a, uint16_t b) const { return k[a].re < k[b].re; } };
+struct ssg_key_sc_lt {
+	const ssg_sdp_key_t *k;
+	SSG_DEVMEM bool operator()(uint16_t a, uint16_t b) const
+	{ const ssg_sdp_key_t x = k[a], y = k[b]; return (x.score > y.score) | ((x.score == y.score) & ((x.rb < y.rb) | ((x.rb == y.rb) & (x.qb < y.qb)))); }
+};
+
+SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, ssg_alnreg_t *tmp, ssg_sdp_lds_t *L)
+{
+	if (n <= 1) return n;
+	const int lane = wv_lane();
+	ssg_wave_memsync();
+	for (int i = lane; i < n; i += 64) {
+		const ssg_alnreg_t r = a[i];
+		ssg_sdp_key_t k; k.re = r.re; k.rb = r.rb; k.qb = r.qb; k.qe = r.qe; k.score = r.score; k.rid = r.rid;
+		L->key[i] = k; L->idx[i] = (uint16_t)i;
+	}
+	ssg_wave_memsync();
+	if (lane == 0) {
+		ssg_sdp_key_t *key = L->key; uint16_t *idx = L->idx;
+		int i, j, m;
+		{ ssg_key_re_lt lt = { key }; ssg_introsort(idx, (long)n, lt); }
+		for (i = 1; i < n; ++i) {
+			ssg_sdp_key_t *p = &key[idx[i]];
+			if (p->rid != key[idx[i-1]].rid || p->rb >= key[idx[i-1]].re + opt.max_chain_gap) continue;
+			for (j = i - 1; j >= 0 && p->rid == key[idx[j]].rid && p->rb < key[idx[j]].re + opt.max_chain_gap; --j) {
+				ssg_sdp_key_t *q = &key[idx[j]];
+				int64_t or_, oq, mr, mq;
+				if (q->qe == q->qb) continue;
+				or_ = q->re - p->rb;
+				oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+				mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+				mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+				if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq) {
+					if (p->score < q->score) { p->qe = p->qb; break; }
+					else q->qe = q->qb;
+				}
+			}
+		}
+		for (i = 0, m = 0; i < n; ++i) if (key[idx[i]].qe > key[idx[i]].qb) idx[m++] = idx[i];
+		const int n2 = m;
+		{ ssg_key_sc_lt lt = { key }; ssg_introsort(idx, (long)n2, lt); }
+		for (i = 1; i < n2; ++i) {
+			const ssg_sdp_key_t x = key[idx[i]], y = key[idx[i-1]];
+			if (x.score == y.score && x.rb == y.rb && x.qb == y.qb) key[idx[i]].qe = key[idx[i]].qb;
+		}
+		for (i = 1, m = 1; i < n2; ++i) if (key[idx[i]].qe > key[idx[i]].qb) idx[m++] = idx[i];
+		L->m = n2 < 1 ? n2 : m;
+	}
+	ssg_wave_memsync();
+	const int m = L->m;
+	for (int k = lane; k < m; k += 64) { ssg_alnreg_t r = a[L->idx[k]]; r.n_comp = 1; tmp[k] = r; }
+	ssg_wave_memsync();
+	for (int k = lane; k < m; k += 64) a[k] = tmp[k];
+	ssg_wave_memsync();
+	return m;
+}
+
 /* ---------------- mate rescue ---------------- */
 #define SSG_MS_BCAP 32768   /* rows of a rescue window (b[] entries) per resident wave */
 
 SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const ssg_pestat_t *pes, const ssg_alnreg_t a,
                         int l_ms, const uint8_t *ms, ssg_alnreg_t *ma, int *ma_n_, int ma_cap,
-                        uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells, unsigned long long *ph)
+                        uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells, unsigned long long *ph,
+                        ssg_alnreg_t *sdp_tmp, ssg_sdp_lds_t *sdp_lds)
 {	/* upstream mem_matesw; ph[]: cycle counters per phase (fetch, SW, re-sort, window rows) */
 	const int64_t l_pac = ix.l_pac;
 	int i, r, skip[4], n = 0, rid = -1, ma_n = *ma_n_;
@@ -126,19 +193,25 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 				b.secondary = -1;
 				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
 				if (ma_n >= ma_cap) { *err = 2; }
-				else {
-					SSG_LANE0(
-						int t2, k2;
-						for (k2 = 0; k2 < ma_n; ++k2) if (ma[k2].score < b.score) break;
-						t2 = k2;
-						for (k2 = ma_n; k2 > t2; --k2) ma[k2] = ma[k2-1];
-						ma[t2] = b);
+				else { /* insert before the first lower-scoring hit: all lanes search and shift */
+					int t2 = ma_n;
+					for (int k2 = wv_lane(); k2 < ma_n; k2 += 64) if (ma[k2].score < b.score) { t2 = k2; break; }
+					t2 = wv_min(t2);
+					if (ma_n - t2 <= SSG_SDP_CAP) {
+						ssg_wave_memsync();
+						for (int k2 = t2 + wv_lane(); k2 < ma_n; k2 += 64) sdp_tmp[k2 - t2] = ma[k2];
+						ssg_wave_memsync();
+						for (int k2 = t2 + wv_lane(); k2 < ma_n; k2 += 64) ma[k2 + 1] = sdp_tmp[k2 - t2];
+						SSG_LANE0(ma[t2] = b);
+					} else {
+						SSG_LANE0(for (int k2 = ma_n; k2 > t2; --k2) ma[k2] = ma[k2-1]; ma[t2] = b);
+					}
 					++ma_n;
 				}
 			}
 			++n;
 		}
-		if (n) { unsigned long long c1 = ssg_clock(); const int n_in = ma_n; ma_n = wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1; }
+		if (n) { unsigned long long c1 = ssg_clock(); const int n_in = ma_n; ma_n = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds) : wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1; }
 	}
 	*ma_n_ = ma_n;
 	return n;
@@ -153,11 +226,12 @@ __global__ void __launch_bounds__(256) ssg_k_matesw(ssg_index_view_t ix, ssg_mem
                              ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue)
 {
 	__shared__ uint8_t revlds[SSG_WAVES_PER_WG][256];
+	__shared__ ssg_sdp_lds_t sdplds[SSG_WAVES_PER_WG];
 	const int wslot = (int)(threadIdx.x >> 6);
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot, nwaves = (long)gridDim.x * (blockDim.x >> 6);
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB;
 	unsigned long long *bs = bglb + wave0 * (long)SSG_MS_BCAP;
-	ssg_alnreg_t *bc = bcopy + wave0 * 2L * 64;          /* upstream's b[2] (<= max_matesw used, 64 kept) */
+	ssg_alnreg_t *bc = bcopy + wave0 * (128L + SSG_SDP_CAP);   /* upstream's b[2] (2 x 64) + the re-sort gather buffer */
 	unsigned long long nc = 0, nres = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	const unsigned long long k0 = ssg_clock();
 	for (long p = wave0; p < n_pairs; p += nwaves) {
@@ -181,7 +255,7 @@ __global__ void __launch_bounds__(256) ssg_k_matesw(ssg_index_view_t ix, ssg_mem
 				for (int j = 0; j < nb[i]; ++j) {
 					const int l_ms = (int)(read_off[2*p + !i + 1] - read_off[2*p + !i]);
 					const uint8_t *ms = seq + read_off[2*p + !i];
-					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph);
+					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot]);
 				}
 		}
 		if (wv_lane() == 0) { n_reg[2*p] = an[0]; n_reg[2*p+1] = an[1]; if (myerr) err[p] = myerr; }
