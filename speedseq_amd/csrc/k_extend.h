@@ -19,6 +19,11 @@
 #define SSG_TWIN_LDS 1024
 #define SSG_TWIN_GLB 32768
 #define SSG_WAVES_PER_WG 4
+/* the DP rows are chains of dependent DPP/VALU ops: they need >= 4 waves per SIMD to hide their own
+ * latency, so the wave-per-read kernels cap their VGPR budget (cold scalar paths may spill) */
+#ifndef SSG_SW_WAVES_PER_SIMD
+#define SSG_SW_WAVES_PER_SIMD 4
+#endif
 
 __global__ void __launch_bounds__(256) ssg_k_extend_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_ext_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,
                                   ssg_ext_res_t *res, unsigned long long *cells)
@@ -292,7 +297,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 }
 
 /* grid-strided: every resident wavefront owns one LDS window and one SSG_TWIN_GLB slab of tglb */
-__global__ void __launch_bounds__(256) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
+__global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
                                 uint8_t *tglb, int32_t *err, unsigned long long *cells)
