@@ -13,12 +13,16 @@
 #define SSG_K_SEED_H
 #include "ssg_dev.h"
 
-struct ssg_ivec_t { ssg_intv_t *a; int n, cap; int ovf; unsigned nx; /* bwt_extend calls (rank-query accounting) */ };
-SSG_DEVFN void iv_push(ssg_ivec_t &v, const ssg_intv_t &x) { if (v.n < v.cap) v.a[v.n] = x; else v.ovf = 1; ++v.n; }
+/* interval vector; `st` = element stride: the per-lane work vectors are interleaved across the 64
+ * lanes of a wave (entry e of lane l at base[e*64 + l]) so that lanes pushing / reading their e-th
+ * entry together touch one contiguous 2-KB span instead of 64 scattered half-used lines */
+struct ssg_ivec_t { ssg_intv_t *a; int n, cap; int ovf; unsigned nx; /* bwt_extend calls (rank-query accounting) */ int st; };
+#define IV(v, i) ((v).a[(long)(i) * (v).st])
+SSG_DEVFN void iv_push(ssg_ivec_t &v, const ssg_intv_t &x) { if (v.n < v.cap) IV(v, v.n) = x; else v.ovf = 1; ++v.n; }
 SSG_DEVFN void iv_reverse(ssg_ivec_t &v)
 {
 	int n = v.n < v.cap ? v.n : v.cap;
-	for (int j = 0; j < n >> 1; ++j) { ssg_intv_t t = v.a[n-1-j]; v.a[n-1-j] = v.a[j]; v.a[j] = t; }
+	for (int j = 0; j < n >> 1; ++j) { ssg_intv_t t = IV(v, n-1-j); IV(v, n-1-j) = IV(v, j); IV(v, j) = t; }
 }
 SSG_DEVFN void ssg_set_intv(const ssg_index_view_t &ix, int c, ssg_intv_t &ik)
 {
@@ -40,33 +44,34 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
 	for (i = x + 1, curr->n = 0; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
-			ssg_bwt_extend(ix, ik, ok, 0); ++mem.nx;
-			if (ok[c].x2 != ik.x2) {
+			const ssg_intv_t okc = ssg_bwt_extend1(ix, ik, c, 0); ++mem.nx;
+			if (okc.x2 != ik.x2) {
 				iv_push(*curr, ik);
-				if (ok[c].x2 < min_intv) break;
+				if (okc.x2 < min_intv) break;
 			}
-			ik = ok[c]; ik.info = (uint64_t)(i + 1);
+			ik = okc; ik.info = (uint64_t)(i + 1);
 		} else { iv_push(*curr, ik); break; }
 	}
 	if (i == len) iv_push(*curr, ik);
 	iv_reverse(*curr);
-	ret = (int)curr->a[0].info;
+	ret = (int)IV(*curr, 0).info;
 	swap = curr; curr = prev; prev = swap;
 	for (i = x - 1; i >= -1; --i) {
 		c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
 		for (j = 0, curr->n = 0; j < prev->n; ++j) {
-			ssg_intv_t p = prev->a[j];
-			if (c >= 0) { ssg_bwt_extend(ix, p, ok, 1); ++mem.nx; }
-			if (c < 0 || ok[c].x2 < min_intv) {
+			ssg_intv_t p = IV(*prev, j);
+			ssg_intv_t okc; okc.x0 = okc.x1 = okc.x2 = okc.info = 0;
+			if (c >= 0) { okc = ssg_bwt_extend1(ix, p, c, 1); ++mem.nx; }
+			if (c < 0 || okc.x2 < min_intv) {
 				if (curr->n == 0) {
-					if (mem.n == 0 || (uint64_t)(i + 1) < (mem.a[mem.n-1].info >> 32)) {
+					if (mem.n == 0 || (uint64_t)(i + 1) < (IV(mem, mem.n-1).info >> 32)) {
 						ik = p; ik.info |= (uint64_t)(i + 1) << 32;
 						iv_push(mem, ik);
 					}
 				}
-			} else if (curr->n == 0 || ok[c].x2 != curr->a[curr->n-1].x2) {
-				ok[c].info = p.info;
-				iv_push(*curr, ok[c]);
+			} else if (curr->n == 0 || okc.x2 != IV(*curr, curr->n-1).x2) {
+				okc.info = p.info;
+				iv_push(*curr, okc);
 			}
 		}
 		if (curr->n == 0) break;
@@ -87,13 +92,13 @@ SSG_DEVFN int ssg_seed_strategy1(const ssg_index_view_t &ix, int len, const uint
 	for (i = x + 1; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
-			ssg_bwt_extend(ix, ik, ok, 0); ++nx;
-			if (ok[c].x2 < max_intv && i - x >= min_len) {
-				mem = ok[c];
+			const ssg_intv_t okc = ssg_bwt_extend1(ix, ik, c, 0); ++nx;
+			if (okc.x2 < max_intv && i - x >= min_len) {
+				mem = okc;
 				mem.info = (uint64_t)x << 32 | (uint64_t)(i + 1);
 				return i + 1;
 			}
-			ik = ok[c];
+			ik = okc;
 		} else return i + 1;
 	}
 	return len;
@@ -112,14 +117,14 @@ __global__ void __launch_bounds__(64) ssg_k_smem(ssg_index_view_t ix, ssg_mem_op
                            ssg_intv_t *scratch, int scap, unsigned long long *n_extend)
 {
 	long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
-	ssg_intv_t *my = scratch + gt * 3 * scap;
+	ssg_intv_t *my = scratch + (gt >> 6) * 3 * scap * 64 + (gt & 63);   /* wave slab, lane-interleaved */
 	unsigned long long my_nx = 0;
 	for (long it = gt; it < n_reads; it += nt) {
 		int r = read_ids ? read_ids[it] : (int)it;
 		const uint8_t *q = seq + off[r];
 		int len = (int)(off[r+1] - off[r]);
-		ssg_ivec_t mem = { out_intv + (long)it * cap, 0, cap, 0 };
-		ssg_ivec_t mem1 = { my, 0, scap, 0 }, va = { my + scap, 0, scap, 0 }, vb = { my + 2 * scap, 0, scap, 0 };
+		ssg_ivec_t mem = { out_intv + (long)it * cap, 0, cap, 0, 0, 1 };
+		ssg_ivec_t mem1 = { my, 0, scap, 0, 0, 64 }, va = { my + (long)scap * 64, 0, scap, 0, 0, 64 }, vb = { my + 2L * scap * 64, 0, scap, 0, 0, 64 };
 		int x = 0, i, k, old_n;
 		int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 		if (len >= opt.min_seed_len) {
@@ -127,7 +132,7 @@ __global__ void __launch_bounds__(64) ssg_k_smem(ssg_index_view_t ix, ssg_mem_op
 				if (q[x] < 4) {
 					x = ssg_smem1(ix, len, q, x, 1, mem1, va, vb);
 					for (i = 0; i < mem1.n; ++i) {
-						ssg_intv_t p = mem1.a[i];
+						ssg_intv_t p = IV(mem1, i);
 						int slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
 						if (slen >= opt.min_seed_len) iv_push(mem, p);
 					}
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(64) ssg_k_smem(ssg_index_view_t ix, ssg_mem_op
 				if (end - start < split_len || p.x2 > (uint64_t)opt.split_width) continue;
 				ssg_smem1(ix, len, q, (start + end) >> 1, p.x2 + 1, mem1, va, vb);
 				for (i = 0; i < mem1.n; ++i) {
-					ssg_intv_t m = mem1.a[i];
+					ssg_intv_t m = IV(mem1, i);
 					if ((int)((uint32_t)m.info - (uint32_t)(m.info >> 32)) >= opt.min_seed_len) iv_push(mem, m);
 				}
 			}

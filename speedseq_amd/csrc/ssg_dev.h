@@ -114,13 +114,19 @@ SSG_DEVFN void ssg_occ4(const ssg_index_view_t &ix, uint64_t k, uint64_t cnt[4])
 	if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
 	k -= (k >= ix.primary);
 	const uint32_t *p = ix.bwt + ((k >> 7) << 4);
-	const uint64_t *pc = (const uint64_t*)p;
-	uint32_t w[8];
-	SSG_UNROLL for (int i = 0; i < 8; ++i) w[i] = p[8 + i];
-	int r = (int)(k & 127) + 1;
+	struct alignas(16) q16 { uint32_t v[4]; };             /* the 64-byte block as four 16-byte loads */
+	const q16 *pb = (const q16*)p;
+	const q16 c0 = pb[0], c1 = pb[1], w0 = pb[2], w1 = pb[3];
+	const uint32_t w[8] = { w0.v[0], w0.v[1], w0.v[2], w0.v[3], w1.v[0], w1.v[1], w1.v[2], w1.v[3] };
+	const uint64_t pc[4] = { (uint64_t)c0.v[0] | (uint64_t)c0.v[1] << 32, (uint64_t)c0.v[2] | (uint64_t)c0.v[3] << 32,
+	                         (uint64_t)c1.v[0] | (uint64_t)c1.v[1] << 32, (uint64_t)c1.v[2] | (uint64_t)c1.v[3] << 32 };
+	const int r = (int)(k & 127) + 1;
+	/* mask away the symbols past position r once per word, then count each base on the masked words */
+	uint32_t mk[8];
+	SSG_UNROLL for (int i = 0; i < 8; ++i) { int ns = r - i * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns; mk[i] = ns == 16 ? 0x55555555u : ns ? (~((1u << ((16 - ns) << 1)) - 1)) & 0x55555555u : 0u; }
 	SSG_UNROLL for (int c = 0; c < 4; ++c) {
 		int n = 0;
-		SSG_UNROLL for (int i = 0; i < 8; ++i) { int ns = r - i * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns; n += ssg_cnt16(w[i], c, ns); }
+		SSG_UNROLL for (int i = 0; i < 8; ++i) { const uint32_t m = ~(w[i] ^ ((uint32_t)c * 0x55555555u)); n += __popc(m & (m >> 1) & mk[i]); }
 		cnt[c] = pc[c] + (uint64_t)n;
 	}
 }
@@ -157,6 +163,24 @@ SSG_DEVFN void ssg_bwt_extend(const ssg_index_view_t &ix, const ssg_intv_t &ik, 
 		ok[i].x2 = ns[i];
 		if (is_back) { ok[i].x0 = nk[i]; ok[i].x1 = no[i]; } else { ok[i].x1 = nk[i]; ok[i].x0 = no[i]; }
 	}
+}
+/* upstream bwt_extend restricted to the one base the caller follows (all SMEM call sites use a
+ * single ok[c]): same two rank blocks, a quarter of the live registers */
+SSG_DEVFN ssg_intv_t ssg_bwt_extend1(const ssg_index_view_t &ix, const ssg_intv_t &ik, int c, int is_back)
+{
+	uint64_t tk[4], tl[4];
+	const uint64_t kx = is_back ? ik.x0 : ik.x1, ox = is_back ? ik.x1 : ik.x0;
+	ssg_occ4(ix, kx - 1, tk);
+	ssg_occ4(ix, kx - 1 + ik.x2, tl);
+	uint64_t no = ox + (kx <= ix.primary && kx + ik.x2 - 1 >= ix.primary);
+	SSG_UNROLL for (int b = 3; b >= 0; --b) if (b > c) no += tl[b] - tk[b];
+	uint64_t tkc = tk[0], tlc = tl[0];
+	SSG_UNROLL for (int b = 1; b < 4; ++b) if (b == c) { tkc = tk[b]; tlc = tl[b]; }
+	ssg_intv_t o;
+	const uint64_t nk = ix.L2[c] + 1 + tkc;
+	o.x2 = tlc - tkc; o.info = 0;
+	if (is_back) { o.x0 = nk; o.x1 = no; } else { o.x1 = nk; o.x0 = no; }
+	return o;
 }
 /* upstream bwt_sa: LF-walk to a sampled row */
 SSG_DEVFN uint64_t ssg_bwt_sa(const ssg_index_view_t &ix, uint64_t k)
@@ -234,7 +258,7 @@ SSG_DEVFN void ssg_combsort(T *a, long n, LT lt)
 template <class T, class LT>
 SSG_DEVFN void ssg_introsort(T *a, long n, LT lt)
 {
-	struct { T *l, *r; int d; } stack[128]; int top = 0;
+	struct { T *l, *r; int d; } stack[40]; int top = 0;   /* the larger side is pushed: depth <= log2(n) */
 	int d; T rp, *s, *t, *i, *j, *k;
 	if (n < 1) return;
 	if (n == 2) { if (lt(a[1], a[0])) { T x = a[0]; a[0] = a[1]; a[1] = x; } return; }
