@@ -75,10 +75,12 @@ struct ssg_chain_w_lt {
 __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, ssg_seed_t *seeds, const int32_t *seed_rid,
-                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, int dbg_phase)
+                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, int dbg_phase,
+                            const int32_t *work_order)
 {
 	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
+	if (work_order) r = work_order[r];   /* reads sorted by seed count: the lanes of a wave get similar work */
 	int len = (int)(read_off[r+1] - read_off[r]);
 	long s0 = seed_off[r]; int ns = (int)(seed_off[r+1] - s0);
 	ssg_chain_t *ch = chains + s0; int32_t *ord = order + s0, *kp = kept + s0, *cs = chain_seeds + s0;

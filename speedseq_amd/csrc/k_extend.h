@@ -300,15 +300,18 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
-                                uint8_t *tglb, int32_t *err, unsigned long long *cells)
+                                uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue)
 {
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
 	const int wslot = (int)(threadIdx.x >> 6);
-	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot, nwaves = (long)gridDim.x * (blockDim.x >> 6);
+	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
 	unsigned long long nc = 0;
-	for (long r = wave0; r < n_reads; r += nwaves)
-		wv_chain2aln_read(ix, opt, r, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
+	for (;;) { /* waves pull reads from a heaviest-first list: the per-read work is heavy-tailed (repeats) */
+		const long k = wv_queue_pop(queue);
+		if (k >= n_reads) break;
+		wv_chain2aln_read(ix, opt, work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
 		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc);
+	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);
 }
 #endif

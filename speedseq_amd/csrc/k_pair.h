@@ -223,18 +223,22 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
  */
 __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const uint8_t *seq, const int64_t *read_off,
                              const int64_t *reg_off, ssg_alnreg_t *regs, int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
-                             ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue)
+                             ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue,
+                             const int32_t *work_order, unsigned int *queue)
 {
 	__shared__ uint8_t revlds[SSG_WAVES_PER_WG][256];
 	__shared__ ssg_sdp_lds_t sdplds[SSG_WAVES_PER_WG];
 	const int wslot = (int)(threadIdx.x >> 6);
-	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot, nwaves = (long)gridDim.x * (blockDim.x >> 6);
+	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB;
 	unsigned long long *bs = bglb + wave0 * (long)SSG_MS_BCAP;
 	ssg_alnreg_t *bc = bcopy + wave0 * (128L + SSG_SDP_CAP);   /* upstream's b[2] (2 x 64) + the re-sort gather buffer */
 	unsigned long long nc = 0, nres = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	const unsigned long long k0 = ssg_clock();
-	for (long p = wave0; p < n_pairs; p += nwaves) {
+	for (;;) { /* pairs come from a heaviest-first queue (many candidate hits => many rescues) */
+		const long kq = wv_queue_pop(queue);
+		if (kq >= n_pairs) break;
+		const long p = work_order ? work_order[kq] : kq;
 		const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
 		int myerr = 0, nb[2] = {0, 0};
 		ssg_alnreg_t *a[2] = { regs + reg_off[2*p], regs + reg_off[2*p+1] };
@@ -417,11 +421,12 @@ SSG_DEVFN int ssg_emit_xa(const ssg_mem_opt_t &opt, const ssg_alnreg_t *a, int n
 __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, int64_t id0,
                                  const int64_t *reg_off, ssg_alnreg_t *regs, const int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                                  int32_t *zbuf, ssg_pair64_t *vbuf, ssg_pair64_t *ubuf, int ucap,
-                                 const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err)
+                                 const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err, const int32_t *work_order)
 {
 	long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
 	ssg_pair64_t *u = ubuf + gt * (long)ucap;
-	for (long p = gt; p < n_pairs; p += nt) {
+	for (long pq = gt; pq < n_pairs; pq += nt) {
+		const long p = work_order ? work_order[pq] : pq;   /* similar-cost pairs share a wave */
 		const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
 		const int64_t id = id0 + p;
 		ssg_alnreg_t *a[2] = { regs + reg_off[2*p], regs + reg_off[2*p+1] };

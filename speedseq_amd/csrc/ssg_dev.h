@@ -86,6 +86,13 @@ SSG_DEVFN int wv_sum(int v)
 }
 #endif
 SSG_DEVFN int wv_last(int v) { return wv_get(v, 63); }
+/* dynamic work distribution: lane 0 takes the next index of a global queue, the wave shares it */
+SSG_DEVFN long wv_queue_pop(unsigned int *queue)
+{
+	int k = 0;
+	if (wv_lane() == 0) k = (int)atomicAdd(queue, 1u);
+	return (long)(unsigned)wv_get(k, 0);
+}
 SSG_DEVFN int wv_bcast(int v, int src) { return wv_get(v, src); }
 SSG_DEVFN long long wv_bcast64(long long v, int src)
 {

@@ -318,6 +318,18 @@ int ssg_smem_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads
 	return d_n.down(out_n, n_reads);
 }
 
+/* permutation of 0..n-1 by descending key (counting sort on the clipped key; stable) */
+static void order_desc(const std::vector<int32_t> &key, std::vector<int32_t> &order)
+{
+	const int K = 1 << 16;
+	std::vector<int64_t> cnt(K + 1, 0);
+	for (int32_t k : key) ++cnt[K - 1 - std::min(std::max(k, 0), K - 1)];
+	int64_t s = 0;
+	for (int i = 0; i < K; ++i) { int64_t c = cnt[i]; cnt[i] = s; s += c; }
+	order.resize(key.size());
+	for (size_t i = 0; i < key.size(); ++i) order[cnt[K - 1 - std::min(std::max(key[i], 0), K - 1)]++] = (int32_t)i;
+}
+
 /* ------------------------------- mem_align1_core for a batch ------------------------------- */
 struct align1_dev_t {	/* device-resident result of stages 1-4 */
 	dbuf<int64_t> seed_off; dbuf<ssg_alnreg_t> regs; dbuf<int32_t> n_reg;
@@ -358,8 +370,14 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		SSG_LAUNCH(ssg_k_sal, (g + block - 1) / block, block, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p);
 	}
 	STAGE("sal");
+	/* heaviest-first work order (seed count): the per-read cost of chaining / extension is heavy-tailed */
+	std::vector<int32_t> h_work;
+	order_desc(hns, h_work);
+	dbuf<int32_t> d_work(n_reads); dbuf<unsigned int> d_queue(4);
+	CHKA(d_work); CHKA(d_queue);
+	CHK(d_work.up(h_work.data(), n_reads)); CHK(d_queue.zero());
 	SSG_LAUNCH(ssg_k_chain, (n_reads + 63) / 64, 64, 0, idx->v, *opt, 0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-	           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, 0);
+	           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, 0, d_work.p);
 	STAGE("chain");
 	{
 		const int wpb = SSG_WAVES_PER_WG;
@@ -367,7 +385,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		dbuf<uint8_t> d_tglb((size_t)nwg * wpb * SSG_TWIN_GLB);
 		CHKA(d_tglb);
 		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
-		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p);
+		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p);
 		CHK(rt_sync());
 	}
 	std::vector<int32_t> herr(n_reads);
@@ -503,13 +521,22 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	CHK(d_r2off.up(h_r2off.data(), n_reads + 1)); CHK(d_reqoff.up(h_reqoff.data(), n_reads + 1)); CHK(d_perr.zero()); CHK(d_cnt.zero()); CHK(d_gerr.zero());
 	SSG_LAUNCH(ssg_k_copy_regs, (n_reads + block - 1) / block, block, 0, n_reads, a1.seed_off.p, a1.regs.p, a1.n_reg.p, d_r2off.p, d_regs2.p);
 	const int wpb = SSG_WAVES_PER_WG;
+	/* heaviest-first pair order for the pairing-stage kernels (key: candidate regions of both ends) */
+	dbuf<int32_t> d_pw(n_pairs); dbuf<unsigned int> d_q(1);
+	CHKA(d_pw); CHKA(d_q);
+	{
+		std::vector<int32_t> key(n_pairs), h_pw;
+		for (int p = 0; p < n_pairs; ++p) key[p] = hn[2*p] + hn[2*p+1];
+		order_desc(key, h_pw);
+		CHK(d_pw.up(h_pw.data(), n_pairs)); CHK(d_q.zero());
+	}
 	{	/* ---- mate rescue ---- */
 		long nwg = std::min<long>(((long)n_pairs + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
 		long nw = nwg * wpb;
 		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB); dbuf<unsigned long long> d_bglb((size_t)nw * SSG_MS_BCAP); dbuf<ssg_alnreg_t> d_bcopy((size_t)nw * (128 + SSG_SDP_CAP));
 		CHKA(d_tglb); CHKA(d_bglb); CHKA(d_bcopy);
 		SSG_LAUNCH(ssg_k_matesw, nwg, wpb * 64, 0, idx->v, *opt, n_pairs, d_seq.p, d_off.p, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p,
-		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1);
+		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1, d_pw.p, d_q.p);
 		CHK(rt_sync());
 	}
 	STAGE("matesw");
@@ -521,7 +548,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		dbuf<ssg_pair64_t> d_v((size_t)t2 + 1), d_u((size_t)nthr * ucap);
 		CHKA(d_v); CHKA(d_u);
 		SSG_LAUNCH(ssg_k_pair_final, nthr / 64, 64, 0, idx->v, *opt, n_pairs, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_u.p, ucap,
-		           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p);
+		           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p);
 		CHK(rt_sync());
 	}
 	STAGE("pair_final");
