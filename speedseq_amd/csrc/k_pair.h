@@ -59,22 +59,42 @@ __global__ void ssg_k_pestat_hist(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_
 		atomicAdd(&hist[((long)pair_batch[i] * 4 + dir) * SSG_MAX_INS_HIST + is], 1u);
 }
 
-/* ---------------- region re-sort after a rescue, staged in LDS ----------------
- * upstream mem_sort_dedup_patch as mem_matesw calls it (no patching).  The serial part runs on
- * lane 0, but on 32-byte keys and a 16-bit index permutation held in LDS instead of 88-byte records
- * in HBM (same comparison / swap sequence as the in-place introsort, so the same tie order); the
- * surviving records are then gathered by all lanes. */
+/* ---------------- region re-sort after a rescue ----------------
+ * upstream mem_sort_dedup_patch as mem_matesw calls it (no patching), on 32-byte keys and 16-bit index
+ * permutations (LDS for n <= SSG_SDP_CAP, a per-wave HBM slab up to SSG_SDP_BIG) instead of 88-byte
+ * records.  Both sorts are done by all 64 lanes as a rank sort (rank = number of smaller keys); when
+ * all keys are distinct every correct sort yields upstream's permutation, and when two keys tie the
+ * klib introsort is replayed on lane 0 so that the tie order is upstream's.  The redundancy scan and
+ * the compactions are short serial passes on lane 0; survivors are gathered by all lanes. */
 #define SSG_SDP_CAP 256
+#define SSG_SDP_BIG 2048
 struct ssg_sdp_key_t { int64_t re, rb; int32_t qb, qe, score, rid; };
-struct ssg_sdp_lds_t { ssg_sdp_key_t key[SSG_SDP_CAP]; uint16_t idx[SSG_SDP_CAP]; int32_t m, _pad; };
+struct ssg_sdp_lds_t { ssg_sdp_key_t key[SSG_SDP_CAP]; uint16_t idx[SSG_SDP_CAP], idx2[SSG_SDP_CAP]; };
+struct ssg_sdp_big_t { ssg_sdp_key_t key[SSG_SDP_BIG]; uint16_t idx[SSG_SDP_BIG], idx2[SSG_SDP_BIG]; };
 struct ssg_key_re_lt { const ssg_sdp_key_t *k; SSG_DEVMEM bool operator()(uint16_t a, uint16_t b) const { return k[a].re < k[b].re; } };
-struct ssg_key_sc_lt {
-	const ssg_sdp_key_t *k;
-	SSG_DEVMEM bool operator()(uint16_t a, uint16_t b) const
-	{ const ssg_sdp_key_t x = k[a], y = k[b]; return (x.score > y.score) | ((x.score == y.score) & ((x.rb < y.rb) | ((x.rb == y.rb) & (x.qb < y.qb)))); }
-};
+SSG_DEVFN bool ssg_key_sc_less(const ssg_sdp_key_t &x, const ssg_sdp_key_t &y)
+{ return (x.score > y.score) | ((x.score == y.score) & ((x.rb < y.rb) | ((x.rb == y.rb) & (x.qb < y.qb)))); }
+struct ssg_key_sc_lt { const ssg_sdp_key_t *k; SSG_DEVMEM bool operator()(uint16_t a, uint16_t b) const { return ssg_key_sc_less(k[a], k[b]); } };
 
-SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, ssg_alnreg_t *tmp, ssg_sdp_lds_t *L)
+/* rank sort of the n ids in `in` by `less` over key[]; returns (wave-uniform) true when two keys tie,
+ * in which case `out` is garbage and the caller replays the exact introsort */
+template <class LESS>
+SSG_DEVFN bool wv_rank_sort(const ssg_sdp_key_t *key, const uint16_t *in, uint16_t *out, int n, LESS less)
+{
+	int tie = 0;
+	for (int i = wv_lane(); i < n; i += 64) {
+		const uint16_t me = in[i]; const ssg_sdp_key_t km = key[me];
+		int r = 0, eq = 0;
+		for (int j = 0; j < n; ++j) { const ssg_sdp_key_t kj = key[in[j]]; const bool lt = less(kj, km), gt = less(km, kj); r += lt; eq += !(lt | gt); }
+		tie |= eq > 1;
+		if (eq == 1) out[r] = me;
+	}
+	return wv_ballot(tie) != 0;
+}
+struct ssg_re_less { SSG_DEVMEM bool operator()(const ssg_sdp_key_t &a, const ssg_sdp_key_t &b) const { return a.re < b.re; } };
+struct ssg_sc_less { SSG_DEVMEM bool operator()(const ssg_sdp_key_t &a, const ssg_sdp_key_t &b) const { return ssg_key_sc_less(a, b); } };
+
+SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, ssg_alnreg_t *tmp, ssg_sdp_key_t *key, uint16_t *idx, uint16_t *idx2)
 {
 	if (n <= 1) return n;
 	const int lane = wv_lane();
@@ -82,13 +102,16 @@ SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *
 	for (int i = lane; i < n; i += 64) {
 		const ssg_alnreg_t r = a[i];
 		ssg_sdp_key_t k; k.re = r.re; k.rb = r.rb; k.qb = r.qb; k.qe = r.qe; k.score = r.score; k.rid = r.rid;
-		L->key[i] = k; L->idx[i] = (uint16_t)i;
+		key[i] = k; idx2[i] = (uint16_t)i;
 	}
 	ssg_wave_memsync();
+	if (wv_rank_sort(key, idx2, idx, n, ssg_re_less())) { /* ties in `re`: upstream's unstable sort decides */
+		SSG_LANE0(for (int t = 0; t < n; ++t) idx[t] = (uint16_t)t; ssg_key_re_lt lt = { key }; ssg_introsort(idx, (long)n, lt));
+	}
+	ssg_wave_memsync();
+	int n2 = 0;
 	if (lane == 0) {
-		ssg_sdp_key_t *key = L->key; uint16_t *idx = L->idx;
 		int i, j, m;
-		{ ssg_key_re_lt lt = { key }; ssg_introsort(idx, (long)n, lt); }
 		for (i = 1; i < n; ++i) {
 			ssg_sdp_key_t *p = &key[idx[i]];
 			if (p->rid != key[idx[i-1]].rid || p->rb >= key[idx[i-1]].re + opt.max_chain_gap) continue;
@@ -106,19 +129,28 @@ SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *
 				}
 			}
 		}
-		for (i = 0, m = 0; i < n; ++i) if (key[idx[i]].qe > key[idx[i]].qb) idx[m++] = idx[i];
-		const int n2 = m;
-		{ ssg_key_sc_lt lt = { key }; ssg_introsort(idx, (long)n2, lt); }
+		for (i = 0, m = 0; i < n; ++i) if (key[idx[i]].qe > key[idx[i]].qb) idx2[m++] = idx[i];
+		n2 = m;
+	}
+	n2 = wv_bcast(n2, 0);
+	ssg_wave_memsync();
+	if (wv_rank_sort(key, idx2, idx, n2, ssg_sc_less())) { /* identical (score, rb, qb): tie order selects the survivor */
+		SSG_LANE0(for (int t = 0; t < n2; ++t) idx[t] = idx2[t]; ssg_key_sc_lt lt = { key }; ssg_introsort(idx, (long)n2, lt));
+	}
+	ssg_wave_memsync();
+	int m = 0;
+	if (lane == 0) {
+		int i;
 		for (i = 1; i < n2; ++i) {
 			const ssg_sdp_key_t x = key[idx[i]], y = key[idx[i-1]];
 			if (x.score == y.score && x.rb == y.rb && x.qb == y.qb) key[idx[i]].qe = key[idx[i]].qb;
 		}
 		for (i = 1, m = 1; i < n2; ++i) if (key[idx[i]].qe > key[idx[i]].qb) idx[m++] = idx[i];
-		L->m = n2 < 1 ? n2 : m;
+		if (n2 < 1) m = n2;
 	}
+	m = wv_bcast(m, 0);
 	ssg_wave_memsync();
-	const int m = L->m;
-	for (int k = lane; k < m; k += 64) { ssg_alnreg_t r = a[L->idx[k]]; r.n_comp = 1; tmp[k] = r; }
+	for (int k = lane; k < m; k += 64) { ssg_alnreg_t r = a[idx[k]]; r.n_comp = 1; tmp[k] = r; }
 	ssg_wave_memsync();
 	for (int k = lane; k < m; k += 64) a[k] = tmp[k];
 	ssg_wave_memsync();
@@ -131,7 +163,7 @@ SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *
 SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const ssg_pestat_t *pes, const ssg_alnreg_t a,
                         int l_ms, const uint8_t *ms, ssg_alnreg_t *ma, int *ma_n_, int ma_cap,
                         uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells, unsigned long long *ph,
-                        ssg_alnreg_t *sdp_tmp, ssg_sdp_lds_t *sdp_lds)
+                        ssg_alnreg_t *sdp_tmp, ssg_sdp_lds_t *sdp_lds, ssg_sdp_big_t *sdp_big)
 {	/* upstream mem_matesw; ph[]: cycle counters per phase (fetch, SW, re-sort, window rows) */
 	const int64_t l_pac = ix.l_pac;
 	int i, r, skip[4], n = 0, rid = -1, ma_n = *ma_n_;
@@ -197,7 +229,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 					int t2 = ma_n;
 					for (int k2 = wv_lane(); k2 < ma_n; k2 += 64) if (ma[k2].score < b.score) { t2 = k2; break; }
 					t2 = wv_min(t2);
-					if (ma_n - t2 <= SSG_SDP_CAP) {
+					if (ma_n - t2 <= SSG_SDP_BIG) {
 						ssg_wave_memsync();
 						for (int k2 = t2 + wv_lane(); k2 < ma_n; k2 += 64) sdp_tmp[k2 - t2] = ma[k2];
 						ssg_wave_memsync();
@@ -211,7 +243,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			}
 			++n;
 		}
-		if (n) { unsigned long long c1 = ssg_clock(); const int n_in = ma_n; ma_n = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds) : wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1; }
+		if (n) { unsigned long long c1 = ssg_clock(); const int n_in = ma_n; ma_n = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2) : ma_n <= SSG_SDP_BIG ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2) : wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1; }
 	}
 	*ma_n_ = ma_n;
 	return n;
@@ -224,7 +256,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const uint8_t *seq, const int64_t *read_off,
                              const int64_t *reg_off, ssg_alnreg_t *regs, int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                              ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue,
-                             const int32_t *work_order, unsigned int *queue)
+                             const int32_t *work_order, unsigned int *queue, ssg_sdp_big_t *sdpbig)
 {
 	__shared__ uint8_t revlds[SSG_WAVES_PER_WG][256];
 	__shared__ ssg_sdp_lds_t sdplds[SSG_WAVES_PER_WG];
@@ -232,7 +264,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB;
 	unsigned long long *bs = bglb + wave0 * (long)SSG_MS_BCAP;
-	ssg_alnreg_t *bc = bcopy + wave0 * (128L + SSG_SDP_CAP);   /* upstream's b[2] (2 x 64) + the re-sort gather buffer */
+	ssg_alnreg_t *bc = bcopy + wave0 * (128L + SSG_SDP_BIG);   /* upstream's b[2] (2 x 64) + the re-sort gather buffer */
 	unsigned long long nc = 0, nres = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	const unsigned long long k0 = ssg_clock();
 	for (;;) { /* pairs come from a heaviest-first queue (many candidate hits => many rescues) */
@@ -259,7 +291,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 				for (int j = 0; j < nb[i]; ++j) {
 					const int l_ms = (int)(read_off[2*p + !i + 1] - read_off[2*p + !i]);
 					const uint8_t *ms = seq + read_off[2*p + !i];
-					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot]);
+					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot], sdpbig + wave0);
 				}
 		}
 		if (wv_lane() == 0) { n_reg[2*p] = an[0]; n_reg[2*p+1] = an[1]; if (myerr) err[p] = myerr; }

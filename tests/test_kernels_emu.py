@@ -34,6 +34,28 @@ def test_emu_pe_sam_250_long_insert(emu_lib, oracle):
     assert text.count("\n") >= 120
 
 
+def test_emu_pe_edge_cases(emu_lib, oracle):
+    text = common.check_pe_edge_cases(emu_lib, oracle)
+    flags = [int(l.split("\t")[1]) for l in text.split("\n") if l]
+    assert any(f & 4 for f in flags) and any(f & 0x800 for f in flags)
+
+
+def test_abi_argument_errors(emu_lib):
+    import numpy as np
+    import pytest
+    from speedseq_amd import capi
+    opt = emu_lib.opt_init()
+    idx = emu_lib.index_load(common.EXAMPLE_FA)
+    with pytest.raises(capi.SsgError):           # no pairs
+        capi.mem_process_pairs(emu_lib, idx, opt, np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    long_read = np.zeros(600, dtype=np.uint8)     # reads beyond the supported length are refused, not truncated
+    with pytest.raises(capi.SsgError):
+        capi.mem_process_pairs(emu_lib, idx, opt, long_read, np.array([0, 300, 600], dtype=np.int64))
+    with pytest.raises(capi.SsgError):           # missing index files
+        emu_lib.index_load(common.EXAMPLE_FA + ".nope")
+    emu_lib.index_destroy(idx)
+
+
 def test_emu_dedup(emu_lib, oracle):
     assert common.check_dedup(emu_lib, oracle, 400, seed=9) > 20
 
