@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step (BASELINE.json configs[1]: 1M)")
-    ap.add_argument("--ref-mbp", type=float, default=256.0)
+    ap.add_argument("--ref-mbp", type=float, default=1000.0, help="synthetic reference size; the index builder handles < 1073 Mbp this round (GRCh37 = 3100)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--bwa-threads", type=int, default=16, help="the -t whose batch boundaries (insert-size model scope) are reproduced")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle (0 = skip)")
@@ -208,17 +208,31 @@ def main():
         if kern:
             name, (ms, cnt) = max(kern.items(), key=lambda kv: kv[1][0])
             per_launch_ms = ms / cnt
-            n_ext = float(summary[6])
-            if name == "ssg_k_smem":
-                # algorithmic bytes: every bwt_extend = 2 rank queries = 2 x 64-byte Occ blocks (SURVEY 8d B_fm) + the reads
-                alg = 128.0 * n_ext + 2.0 * a.pairs * rl
-            else:
-                alg = 0.0
-            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": alg / (per_launch_ms * 1e-3) / 1e9 if alg else None, "peak": 8000.0,
-                               "unit": "GB/s", "frac": (alg / (per_launch_ms * 1e-3) / 1e9 / 8000.0) if alg else None, "traffic": None,
+            n_ext, seeds, recs, nreads = float(summary[6]), float(summary[2]), float(summary[0]), 2.0 * a.pairs
+            # ALGORITHMIC bytes per launch of each hot kernel (DESIGN.md section 3 states the per-unit figures):
+            alg_bytes = {
+                # every bwt_extend = 2 rank queries = 2 x 64-byte Occ blocks (SURVEY 8d B_fm) + the read itself
+                "ssg_k_smem": 128.0 * n_ext + nreads * rl,
+                # per seed: ~16 LF steps x one 64-byte block + one 8-byte SA sample + the 28-byte seed written
+                "ssg_k_sal": seeds * (16 * 64 + 8 + 28),
+                # per seed: 28 bytes read (seed + contig id); per read <= one 56-byte chain + 4-byte id per seed written
+                "ssg_k_chain": seeds * (28 + 56 + 4),
+                # per read: the read, one 2-bit reference window per chain (~l+400 bases), <= one 88-byte region per seed
+                "ssg_k_chain2aln": nreads * (rl + (rl + 400) / 4.0) + seeds * 28 + recs * 88,
+                # per rescue: mate read + 2-bit window (~insert range + l) + one 88-byte region
+                "ssg_k_matesw": float(summary[5]) * (rl + (rl + 500) / 4.0 + 88),
+                "ssg_k_pair_final": recs * 88 * 2 + recs * 32,
+                "ssg_k_reg2aln": recs * (88 + rl + (rl + 50) / 4.0 + 632),
+            }
+            alg = alg_bytes.get(name, 0.0)
+            ach = alg / (per_launch_ms * 1e-3) / 1e9
+            sw_ms = sum(kern.get(k, (0, 1))[0] for k in ("ssg_k_matesw", "ssg_k_chain2aln", "ssg_k_reg2aln")) / a.steps
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                                "ms_per_launch": per_launch_ms,
                                "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
-                               "sw_cells_per_step": int(summary[3]) + int(summary[4])}
+                               "hbm_gbps_by_kernel": {k: round(alg_bytes[k] / (kern[k][0] / kern[k][1] * 1e-3) / 1e9, 1) for k in alg_bytes if k in kern},
+                               "sw_cells_per_step": int(summary[3]) + int(summary[4]),
+                               "sw_gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None}
         # ---- CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample ----
         if a.cpu_sample > 0:
             try:
