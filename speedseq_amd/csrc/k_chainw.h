@@ -1,0 +1,251 @@
+/*
+ * k_chainw.h -- seed chaining and chain filtering for REPEAT-HEAVY reads, one wavefront per read
+ * (same functions as k_chain.h: upstream mem_chain / test_and_merge,
+ * mem_chain_weight, mem_chain_flt, with identical results).
+ *
+ * A read that falls in a repeat family brings hundreds to thousands of seeds, and chaining them is
+ * order dependent (greedy insertion in seed-visiting order) and quadratic in the filter.  With one
+ * lane per read (k_chain.h) these reads -- ~1.5 % of a human-like batch, ~45 % of its seeds --
+ * serialise behind HBM-latency pointer chasing.  Here the whole state of one read lives in LDS and
+ * the 64 lanes cooperate on every step:
+ *   - the chain set is a position-sorted array; the floor lookup is a two-level 64-ary search
+ *     (2 LDS reads + 2 ballots), insertion is a wave-parallel shift.  (pos, sec) order of k_chain.h:
+ *     among equal positions the first chain stays first, later ones go right behind it, newest
+ *     first; the array is also the final "in-order traversal", so no sort is needed afterwards;
+ *   - test_and_merge reads the chain's first/last seed summary from LDS;
+ *   - chain weights: one lane per chain; the weight sort replays upstream's introsort (ties are the
+ *     norm for repeats, and the unstable tie order selects what is kept) on packed keys in LDS;
+ *   - the filter tests chain i against 64 kept chains at a time: ballot of the `break' condition,
+ *     side effects applied only to the kept chains up to the first break, exactly as the scalar loop.
+ * Per-chain LDS footprint is 36 bytes; CAP = 1024 runs four reads per CU, CAP = 4096 (the 0.1 %
+ * heaviest reads) one per CU.
+ */
+#ifndef SSG_K_CHAINW_H
+#define SSG_K_CHAINW_H
+#include "k_chain.h"
+
+template <int CAP> struct ssg_chw_lds_t {
+	int64_t a8[CAP];   /* insertion: rbeg of the chain's last seed [chain id] | weights [chain id] | filter: kept w<<32 | kept sorted idx<<16 | first shadowed */
+	int64_t b8[CAP];   /* insertion: chain positions, sorted                  | sort/filter: w<<32 | chain id, sorted by w */
+	int32_t rid[CAP];  /* insertion: contig of the chain [chain id]           | filter: kept state [sorted idx] */
+	uint16_t ids[CAP]; /* insertion: chain id of sorted slot                  | filter: query begin of kept chain */
+	uint16_t ls[CAP];  /* last seed [chain id]                                | filter: query end of kept chain */
+	uint16_t fq[CAP], lq[CAP], ll[CAP], n[CAP], fs[CAP]; /* [chain id]: qbeg of first seed, qbeg/len of last seed, #seeds, first seed */
+	uint16_t nx[CAP];  /* [seed]: next seed of the same chain */
+};
+
+struct ssg_whi_gt { SSG_DEVMEM bool operator()(int64_t a, int64_t b) const { return (a >> 32) > (b >> 32); } };
+
+template <int CAP>
+SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const int64_t *read_off, const ssg_intv_t *intv,
+                             const int32_t *n_intv, int cap, const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
+                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, ssg_chw_lds_t<CAP> &L)
+{
+	const int lane = wv_lane();
+	const int len_read = (int)(read_off[r+1] - read_off[r]);
+	const long s0 = seed_off[r]; const int ns = (int)(seed_off[r+1] - s0);
+	ssg_chain_t *ch = chains + s0; int32_t *ord = order + s0, *cs = chain_seeds + s0;
+	const ssg_seed_t *sd = seeds + s0; const int32_t *srid = seed_rid + s0;
+	const int64_t l_pac = ix.l_pac;
+	int nc = 0, i, k;
+	/* frac_rep (upstream mem_chain head); wave-uniform */
+	int b = 0, e = 0, l_rep = 0, ni = n_intv[r] > 0 ? n_intv[r] : 0;
+	const ssg_intv_t *iv = intv + r * cap;
+	for (i = 0; i < ni; ++i) {
+		int sb = (int)(iv[i].info >> 32), se = (int)(uint32_t)iv[i].info;
+		if (iv[i].x2 <= (uint64_t)opt.max_occ) continue;
+		if (sb > e) l_rep += e - b, b = sb, e = se;
+		else e = e > se ? e : se;
+	}
+	l_rep += e - b;
+	const float frac_rep = (float)l_rep / len_read;
+	ssg_wave_ldssync();
+	/* ---- greedy chaining in seed-visiting order ---- */
+	for (int i0 = 0; i0 < ns; i0 += 64) {
+		const int me = i0 + lane;
+		int64_t my_rbeg = 0; int my_q = 0, my_len = 0, my_rid = -1;
+		if (me < ns) { const ssg_seed_t s = sd[me]; my_rbeg = s.rbeg; my_q = s.qbeg; my_len = s.len; my_rid = srid[me]; }
+		const int cn = ns - i0 < 64 ? ns - i0 : 64;
+		for (int t = 0; t < cn; ++t) {
+			const int prid = wv_get(my_rid, t);
+			if (prid < 0) continue;
+			const int sid = i0 + t;
+			const int64_t rbeg = wv_get64(my_rbeg, t);
+			const int qbeg = wv_get(my_q, t), len = wv_get(my_len, t);
+			/* floor of (rbeg, first): cnt = #chains with pos < rbeg */
+			int cnt;
+			if (nc <= 64) cnt = __popcll(wv_ballot(lane < nc && L.b8[lane < nc ? lane : 0] < rbeg));
+			else {
+				const int stride = (nc + 63) >> 6;
+				const int e1 = (lane + 1) * stride - 1;
+				const int nb = __popcll(wv_ballot(e1 < nc && L.b8[e1 < nc ? e1 : 0] < rbeg));   /* blocks wholly below rbeg */
+				const int e2 = nb * stride + lane;
+				const int in = lane < stride && e2 < nc;
+				cnt = nb * stride + __popcll(wv_ballot(in && L.b8[in ? e2 : 0] < rbeg));
+			}
+			const int eq = cnt < nc && L.b8[cnt < nc ? cnt : 0] == rbeg;
+			const int lower = cnt - 1 + eq;
+			int res = 0;
+			if (lower >= 0) { /* upstream test_and_merge against the floor chain */
+				const int c = L.ids[lower];
+				const int64_t f_rbeg = L.b8[lower], l_rbeg = L.a8[c];
+				const int f_q = L.fq[c], l_q = L.lq[c], l_len = L.ll[c];
+				if (prid != L.rid[c]) res = 0;
+				else if (qbeg >= f_q && qbeg + len <= l_q + l_len && rbeg >= f_rbeg && rbeg + len <= l_rbeg + l_len) res = 1;
+				else if ((l_rbeg < l_pac || f_rbeg < l_pac) && rbeg >= l_pac) res = 0;
+				else {
+					const int64_t x = qbeg - l_q, y = rbeg - l_rbeg;
+					if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) res = 2;
+				}
+				if (res == 2) {
+					ssg_wave_ldssync();
+					if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.lq[c] = (uint16_t)qbeg; L.ll[c] = (uint16_t)len; ++L.n[c]; }
+					ssg_wave_ldssync();
+				}
+			}
+			if (res == 0) { /* new chain at slot lower+1 */
+				const int slot = lower + 1;
+				ssg_wave_ldssync();
+				for (int hi = nc; hi > slot; hi -= 64) {
+					const int lo = hi - 64 > slot ? hi - 64 : slot;
+					const int idx = lo + lane;
+					int64_t v = 0; uint16_t w = 0;
+					if (idx < hi) { v = L.b8[idx]; w = L.ids[idx]; }
+					ssg_wave_ldssync();
+					if (idx < hi) { L.b8[idx + 1] = v; L.ids[idx + 1] = w; }
+				}
+				if (lane == 0) {
+					L.b8[slot] = rbeg; L.ids[slot] = (uint16_t)nc; L.a8[nc] = rbeg; L.fq[nc] = L.lq[nc] = (uint16_t)qbeg; L.ll[nc] = (uint16_t)len;
+					L.n[nc] = 1; L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = prid;
+				}
+				ssg_wave_ldssync();
+				++nc;
+			}
+		}
+	}
+	/* ---- upstream mem_chain_weight: one lane per chain ---- */
+	ssg_wave_ldssync();
+	for (int c = lane; c < nc; c += 64) {
+		int w1 = 0, w2 = 0, sid = L.fs[c], end1 = 0; int64_t end2 = 0;
+		const int n = L.n[c];
+		for (int j = 0; j < n; ++j, sid = L.nx[sid]) {
+			const ssg_seed_t s = sd[sid];
+			if (s.qbeg >= end1) w1 += s.len; else if (s.qbeg + s.len > end1) w1 += s.qbeg + s.len - end1;
+			end1 = end1 > s.qbeg + s.len ? end1 : s.qbeg + s.len;
+			if (s.rbeg >= end2) w2 += s.len; else if (s.rbeg + s.len > end2) w2 += (int)(s.rbeg + s.len - end2);
+			end2 = end2 > s.rbeg + s.len ? end2 : s.rbeg + s.len;
+		}
+		int w = w2 < w1 ? w2 : w1;
+		L.a8[c] = w < 1<<30 ? w : (1<<30) - 1;
+	}
+	ssg_wave_ldssync();
+	/* chains in position order with w >= min_chain_weight -> b8[] as (w, id) */
+	int n_chn = 0;
+	for (int e0 = 0; e0 < nc; e0 += 64) {
+		const int sl = e0 + lane;
+		const int id = sl < nc ? L.ids[sl] : 0;
+		const int w = sl < nc ? (int)L.a8[id] : 0;
+		const int keep = sl < nc && w >= opt.min_chain_weight;
+		const unsigned long long bal = wv_ballot(keep);
+		ssg_wave_ldssync();
+		if (keep) L.b8[n_chn + wv_rank_of(bal)] = (int64_t)w << 32 | id;
+		n_chn += __popcll(bal);
+	}
+	ssg_wave_ldssync();
+	int n_out = 0;
+	if (n_chn > 0) {
+		/* ---- upstream mem_chain_flt ---- */
+		if (lane == 0) ssg_introsort(L.b8, (long)n_chn, ssg_whi_gt());
+		ssg_wave_ldssync();
+		for (i = lane; i < n_chn; i += 64) L.rid[i] = 0;
+		int nk = 0;
+		for (i = 0; i < n_chn; ++i) {
+			const int64_t me = L.b8[i];
+			const int id = (int)(uint32_t)me, wi = (int)(me >> 32);
+			const int ib = L.fq[id], ie = L.lq[id] + L.ll[id];
+			int large_ovlp = 0, broke = 0;
+			for (int k0 = 0; k0 < nk && !broke; k0 += 64) {
+				const int kk = k0 + lane;
+				int ov = 0, brk = 0;
+				if (kk < nk) {
+					const int jb = L.ids[kk], je = L.ls[kk], wj = (int)(L.a8[kk] >> 32);
+					const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
+					if (e_min > b_max) {
+						const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj;
+						if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+							ov = 1;
+							brk = (wi < wj * opt.drop_ratio) & (wj - wi >= opt.min_seed_len << 1);
+						}
+					}
+				}
+				const unsigned long long bb = wv_ballot(brk);
+				const int fb = bb ? __builtin_ctzll(bb) : 64;   /* the scalar loop stops at the first break */
+				const int act = ov && lane <= fb;
+				if (act && (L.a8[kk] & 0xffff) == 0xffff) L.a8[kk] = (L.a8[kk] & ~(int64_t)0xffff) | i;
+				large_ovlp |= wv_ballot(act) != 0;
+				broke = bb != 0;
+			}
+			if (!broke) {
+				ssg_wave_ldssync();
+				if (lane == 0) { L.a8[nk] = (int64_t)wi << 32 | (int64_t)i << 16 | 0xffff; L.ids[nk] = (uint16_t)ib; L.ls[nk] = (uint16_t)ie; L.rid[i] = large_ovlp ? 2 : 3; }
+				++nk;
+			}
+			ssg_wave_ldssync();
+		}
+		for (k = lane; k < nk; k += 64) { const int f = (int)(L.a8[k] & 0xffff); if (f != 0xffff) L.rid[f] = 1; }
+		ssg_wave_ldssync();
+		if (opt.max_chain_extend <= n_chn) {
+			if (lane == 0) {
+				for (i = k = 0; i < n_chn; ++i) {
+					const int kk = L.rid[i];
+					if (kk == 0 || kk == 3) continue;
+					if (++k >= opt.max_chain_extend) break;
+				}
+				for (; i < n_chn; ++i) if (L.rid[i] < 3) L.rid[i] = 0;
+			}
+			ssg_wave_ldssync();
+		}
+		/* ---- survivors in weight order: records, seed lists ---- */
+		int pos = 0;
+		for (int e0 = 0; e0 < n_chn; e0 += 64) {
+			const int sl = e0 + lane;
+			const int kept = sl < n_chn ? L.rid[sl] : 0;
+			const int64_t me = sl < n_chn ? L.b8[sl] : 0;
+			const int id = (int)(uint32_t)me;
+			const int n = kept ? L.n[id] : 0;
+			const unsigned long long bal = wv_ballot(kept != 0);
+			const int incl = wv_scan_add(n);
+			if (kept) {
+				const int start = pos + incl - n;
+				int sid = L.fs[id];
+				ssg_chain_t c;
+				c.pos = sd[sid].rbeg; c.first_seed = (int)(s0 + start); c.last_seed = -1; c.n = n; c.rid = srid[sid];
+				c.w = (int)(me >> 32); c.kept = kept; c.first = -1; c.left = c.right = -1; c.frac_rep = frac_rep; c._pad = 0; c.sec = 0;
+				ch[id] = c;
+				ord[n_out + wv_rank_of(bal)] = id;
+				for (int j = 0; j < n; ++j, sid = L.nx[sid]) cs[start + j] = (int)(s0 + sid);
+			}
+			pos += wv_last(incl);
+			n_out += __popcll(bal);
+		}
+	}
+	if (lane == 0) n_chain[r] = n_out;
+	ssg_wave_ldssync();
+}
+
+/* one wavefront per workgroup; waves pull reads work_order[r_first .. r_end) from a queue */
+template <int CAP>
+__global__ void __launch_bounds__(64) ssg_k_chain_wave(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int r_end,
+                            const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
+                            const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
+                            ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain,
+                            const int32_t *work_order, unsigned int *queue)
+{
+	__shared__ ssg_chw_lds_t<CAP> L;
+	for (;;) {
+		const long k = r_first + wv_queue_pop(queue);
+		if (k >= r_end) break;
+		wv_chain_read<CAP>(ix, opt, work_order ? work_order[k] : k, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L);
+	}
+}
+#endif

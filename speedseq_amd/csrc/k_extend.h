@@ -177,7 +177,7 @@ SSG_DEVFN int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem_opt_
 SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
-                                uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells)
+                                uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells, unsigned long long *ph)
 {
 	const uint8_t *query = seq + read_off[r];
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
@@ -189,6 +189,9 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	int av_n = 0, myerr = 0;
 	unsigned long long nc = 0;
 	const int nch = n_chain[r];
+	unsigned long long t0 = 0, t1;
+#define SSG_PH(x) do { if (ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
+	if (ph) { t0 = ssg_clock(); ph[5] += nch; }
 	for (int ci = 0; ci < nch; ++ci) {
 		const ssg_chain_t c = ch[ord[ci]];
 		const int32_t *cs = chain_seeds + c.first_seed;
@@ -220,6 +223,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 		wv_fetch_ref(ix, rmax[0], rmax[1], rseq);
 		SSG_LANE0(for (int t = 0; t < c.n; ++t) srt[t] = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
 		          ssg_introsort(srt, (long)c.n, ssg_u64_lt()));
+		SSG_PH(0);
 		for (k = c.n - 1; k >= 0; --k) {
 			const ssg_seed_t s = seeds[cs[(uint32_t)srt[k]]];
 			for (i = 0; i < av_n; ++i) {
@@ -244,8 +248,10 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
 					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
 				}
-				if (i == c.n) { SSG_LANE0(srt[k] = 0); continue; }
+				if (i == c.n) { SSG_LANE0(srt[k] = 0); SSG_PH(1); continue; }
 			}
+			SSG_PH(1);
+			if (ph) ++ph[6];
 			ssg_alnreg_t a;
 			a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = a.seedcov = a.secondary = a.secondary_all = a.n_comp = 0; a.hash = 0;
 			a.w = aw[0] = aw[1] = opt.w;
@@ -289,9 +295,13 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 			a.frac_rep = c.frac_rep;
 			SSG_LANE0(av[av_n] = a);
 			++av_n;
+			SSG_PH(2);
 		}
 	}
+	if (ph) ph[7] += av_n;
 	av_n = wv_sort_dedup_patch(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
+	SSG_PH(3);
+#undef SSG_PH
 	if (wv_lane() == 0) { n_reg[r] = av_n; err[r] = myerr; }
 	*cells += nc;
 }
@@ -300,18 +310,23 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
-                                uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue)
+                                uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue, int tune)
 {
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
 	const int wslot = (int)(threadIdx.x >> 6);
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
-	unsigned long long nc = 0;
+	unsigned long long nc = 0, ph[8] = {0,0,0,0,0,0,0,0};
+	const unsigned long long k0 = tune ? ssg_clock() : 0;
 	for (;;) { /* waves pull reads from a heaviest-first list: the per-read work is heavy-tailed (repeats) */
 		const long k = wv_queue_pop(queue);
 		if (k >= n_reads) break;
 		wv_chain2aln_read(ix, opt, work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
-		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc);
+		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, tune ? ph : 0);
 	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);
+	if (tune && wv_lane() == 0) { /* tuning: window+seed sort, containment scan, extension, re-sort, wave total; #chains, #extended seeds, #regions */
+		ph[4] = ssg_clock() - k0;
+		for (int t = 0; t < 8; ++t) atomicAdd(&ssg_dbg_cyc[16 + t], ph[t]);
+	}
 }
 #endif

@@ -29,10 +29,10 @@ SSG_DEVFN unsigned long long wv_ballot(int p) { return __ballot(p); }
 #define SSG_WAVE 64
 /* phase cycle counters for kernel tuning (read back with ssg_dbg_cycles) */
 #ifdef SSG_EMU
-static unsigned long long ssg_dbg_cyc[8];
+static unsigned long long ssg_dbg_cyc[24];
 SSG_DEVFN unsigned long long ssg_clock() { return 0; }
 #else
-__device__ unsigned long long ssg_dbg_cyc[8];
+__device__ unsigned long long ssg_dbg_cyc[24];
 SSG_DEVFN unsigned long long ssg_clock() { return (unsigned long long)clock64(); }
 #endif
 /* make one lane's global stores visible to the other lanes of the same wave */
@@ -40,6 +40,13 @@ SSG_DEVFN unsigned long long ssg_clock() { return (unsigned long long)clock64();
 SSG_DEVFN void ssg_wave_memsync() { (void)emu_ballot(0); } /* fibers are not lock-step: rendezvous */
 #else
 SSG_DEVFN void ssg_wave_memsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+#endif
+/* order one lane's LDS stores before the other lanes' LDS loads: the DS queue of a wave is in order, so on
+ * the GPU only the compiler has to be held back; the emulator's fibers need a rendezvous */
+#ifdef SSG_EMU
+SSG_DEVFN void ssg_wave_ldssync() { (void)emu_ballot(0); }
+#else
+SSG_DEVFN void ssg_wave_ldssync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 #endif
 /* A scalar (wave-uniform) mutation of memory shared by the wave: executed by lane 0 only, fenced on
  * both sides so every lane's earlier reads are done and every lane's later reads see it. */
@@ -63,6 +70,12 @@ SSG_DEVFN int wv_scan_max(int v)
 	return v;
 }
 SSG_DEVFN int wv_sum(int v) { for (int d = 1; d < 64; d <<= 1) v += wv_shfl(v, wv_lane() ^ d); return v; }
+SSG_DEVFN int wv_scan_add(int v)
+{
+	int l = wv_lane();
+	for (int d = 1; d < 64; d <<= 1) { int o = wv_shfl(v, l - d); if (l >= d) v += o; }
+	return v;
+}
 #else
 #define SSG_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
 SSG_DEVFN int wv_prev(int v, int fill) { return SSG_DPP(fill, v, 0x138 /* wave_shr:1 */, 0xf); }
@@ -84,6 +97,12 @@ SSG_DEVFN int wv_sum(int v)
 	v += SSG_DPP(0, v, 0x142, 0xa); v += SSG_DPP(0, v, 0x143, 0xc);
 	return __builtin_amdgcn_readlane(v, 63);
 }
+SSG_DEVFN int wv_scan_add(int v)
+{	/* inclusive prefix sum over lanes 0..lane */
+	v += SSG_DPP(0, v, 0x111, 0xf); v += SSG_DPP(0, v, 0x112, 0xf); v += SSG_DPP(0, v, 0x114, 0xf); v += SSG_DPP(0, v, 0x118, 0xf);
+	v += SSG_DPP(0, v, 0x142, 0xa); v += SSG_DPP(0, v, 0x143, 0xc);
+	return v;
+}
 #endif
 SSG_DEVFN int wv_last(int v) { return wv_get(v, 63); }
 /* dynamic work distribution: lane 0 takes the next index of a global queue, the wave shares it */
@@ -99,6 +118,13 @@ SSG_DEVFN long long wv_bcast64(long long v, int src)
 	int lo = wv_shfl((int)(unsigned)(unsigned long long)v, src), hi = wv_shfl((int)((unsigned long long)v >> 32), src);
 	return (long long)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
 }
+SSG_DEVFN long long wv_get64(long long v, int src)
+{	/* src wave-uniform: two v_readlane */
+	int lo = wv_get((int)(unsigned)(unsigned long long)v, src), hi = wv_get((int)((unsigned long long)v >> 32), src);
+	return (long long)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
+}
+/* number of lanes below this one whose predicate holds, given the ballot */
+SSG_DEVFN int wv_rank_of(unsigned long long ballot) { return __popcll(ballot & ((1ull << wv_lane()) - 1ull)); }
 SSG_DEVFN int wv_max(int v) { return wv_last(wv_scan_max(v)); }
 SSG_DEVFN int wv_min(int v) { return -wv_max(-v); }   /* |v| < 2^31 everywhere it is used */
 SSG_DEVFN int imax(int a, int b) { return a > b ? a : b; }

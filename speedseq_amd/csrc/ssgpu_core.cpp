@@ -14,7 +14,7 @@
 #include <math.h>
 #include "ssg_rt.h"
 #include "k_seed.h"
-#include "k_chain.h"
+#include "k_chainw.h"
 #include "k_extend.h"
 #include "k_swjobs.h"
 #include "../../include/ssgpu.h"
@@ -40,6 +40,7 @@ struct ssg_index {
 #define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CHKA(b) do { if (!(b).ok()) { ssg_err_msg = "device allocation failed: " #b; return SSG_ENOMEM; } } while (0)
 
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 static int ssg_debug() { static int d = -1; if (d < 0) d = getenv("SSG_DEBUG") ? atoi(getenv("SSG_DEBUG")) : 0; return d; }
 #define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d\n", name, rc_); fflush(stderr); if (rc_) return rc_; } } while (0)
 
@@ -190,15 +191,15 @@ int ssg_prof_get(int, const char **, double *, long *) { return 0; }
 #endif
 
 /* tuning aid: device phase counters (cycles) accumulated by instrumented kernels; reset on read */
-int ssg_dbg_cycles(unsigned long long out[8])
+int ssg_dbg_cycles(unsigned long long out[24])
 {
 #ifdef SSG_EMU
-	memcpy(out, ssg_dbg_cyc, 64); memset(ssg_dbg_cyc, 0, 64);
+	memcpy(out, ssg_dbg_cyc, 192); memset(ssg_dbg_cyc, 0, 192);
 	return 0;
 #else
-	unsigned long long z[8] = {0,0,0,0,0,0,0,0};
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 64) != hipSuccess) return SSG_EHIP;
-	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 64) != hipSuccess) return SSG_EHIP;
+	unsigned long long z[24]; memset(z, 0, sizeof z);
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 192) != hipSuccess) return SSG_EHIP;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 192) != hipSuccess) return SSG_EHIP;
 	return 0;
 #endif
 }
@@ -373,11 +374,30 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	/* heaviest-first work order (seed count): the per-read cost of chaining / extension is heavy-tailed */
 	std::vector<int32_t> h_work;
 	order_desc(hns, h_work);
+	if (ssg_debug() >= 2) { /* tuning: seeds-per-read histogram (power-of-two bins) */
+		long cnt[20] = {0}, sum[20] = {0};
+		for (int r = 0; r < n_reads; ++r) { int b = 0; while ((1 << b) <= hns[r] && b < 19) ++b; ++cnt[b]; sum[b] += hns[r]; }
+		for (int b = 0; b < 20; ++b) if (cnt[b]) fprintf(stderr, "[ssg] seeds/read < %d: %ld reads, %ld seeds\n", 1 << b, cnt[b], sum[b]);
+	}
 	dbuf<int32_t> d_work(n_reads); dbuf<unsigned int> d_queue(4);
 	CHKA(d_work); CHKA(d_queue);
 	CHK(d_work.up(h_work.data(), n_reads)); CHK(d_queue.zero());
-	SSG_LAUNCH(ssg_k_chain, (n_reads + 63) / 64, 64, 0, idx->v, *opt, 0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-	           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, 0, d_work.p);
+	{	/* h_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), [nC,nC+nB) one wave per read with
+		 * 4096-chain LDS state, the next nA with 1024-chain state, the light rest one lane per read */
+		const int T = env_int("SSG_CHAIN_WAVE_MIN", 64), TB = env_int("SSG_CHAIN_WAVE_BIG", 1024);
+		int nC = 0, nB = 0, nA = 0;
+		for (int r = 0; r < n_reads; ++r) { const int s = hns[r]; if (s > 4096) ++nC; else if (s > TB) ++nB; else if (s >= T && s > 0) ++nA; }
+		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
+		if (nC) SSG_LAUNCH(ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+		if (nB) SSG_LAUNCH(ssg_k_chain_wave<4096>, std::min(nB, 256), 64, 0, idx->v, *opt, nC, nC + nB, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 1);
+		if (nA) SSG_LAUNCH(ssg_k_chain_wave<1024>, std::min(nA, 1024), 64, 0, idx->v, *opt, nC + nB, nC + nB + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 2);
+		const int r0 = nC + nB + nA;
+		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+	}
 	STAGE("chain");
 	{
 		const int wpb = SSG_WAVES_PER_WG;
@@ -385,7 +405,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		dbuf<uint8_t> d_tglb((size_t)nwg * wpb * SSG_TWIN_GLB);
 		CHKA(d_tglb);
 		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
-		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p);
+		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p, ssg_debug() >= 2);
 		CHK(rt_sync());
 	}
 	std::vector<int32_t> herr(n_reads);

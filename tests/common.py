@@ -149,11 +149,10 @@ def check_smem(lib, oracle, n_pairs, seed, read_len=150):
     lib.index_destroy(gidx)
 
 
-def check_pe_sam(lib, oracle, n_pairs, seed, read_len=150, n_threads=8, **kw):
+def check_pe_sam(lib, oracle, n_pairs, seed, read_len=150, n_threads=8, prefix=EXAMPLE_FA, **kw):
     """Whole `bwa mem` PE hot path: SAM text from the device records must equal the oracle's."""
-    prefix = EXAMPLE_FA
     oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
-    pairs, seqs, seq, off = sim_reads(n_pairs, seed, read_len, **kw)
+    pairs, seqs, seq, off = sim_reads(n_pairs, seed, read_len, fasta=prefix, **kw)
     names = []
     for nm, _, _ in pairs:
         names += [nm, nm]
@@ -307,10 +306,9 @@ def check_dedup(lib, oracle, n_pairs, seed, dup_frac=0.2):
     return int(dup.sum())
 
 
-def check_align1(lib, oracle, n_pairs, seed, read_len=150):
-    prefix = EXAMPLE_FA
+def check_align1(lib, oracle, n_pairs, seed, read_len=150, prefix=EXAMPLE_FA):
     oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
-    _, seqs, seq, off = sim_reads(n_pairs, seed, read_len)
+    _, seqs, seq, off = sim_reads(n_pairs, seed, read_len, fasta=prefix)
     ro, regs, st = lib.align1_batch(gidx, lib.opt_init(), seq, off)
     oro, oregs = oracle.align1_batch(oidx, seq, off)
     assert np.array_equal(ro, oro)
@@ -318,3 +316,40 @@ def check_align1(lib, oracle, n_pairs, seed, read_len=150):
         assert np.array_equal(regs[f], oregs[f]), f
     lib.index_destroy(gidx)
     return len(regs)
+
+
+def repeat_reference(oracle, dirname, seed=5, n_copies=(300, 70), fam_len=(600, 350), unique=40000, max_div=0.03):
+    """Writes a small repeat-rich reference (two planted families at 0-3 % divergence, both strands)
+    and its index (built by the oracle) into dirname; returns the prefix.  Reads drawn from it carry
+    hundreds to thousands of seeds -- the regime of the wave-per-read chaining kernels."""
+    prefix = os.path.join(str(dirname), "repeats.fa")
+    if os.path.exists(prefix + ".bwt"):
+        return prefix
+    rng = np.random.default_rng(seed)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    fams = [rng.integers(0, 4, size=l).astype(np.uint8) for l in fam_len]
+    pieces = []
+    for f, n in zip(fams, n_copies):
+        for _ in range(n):
+            c = f.copy()
+            m = rng.random(c.size) < rng.random() * max_div
+            c[m] = rng.integers(0, 4, size=int(m.sum()))
+            if rng.random() < 0.5:
+                c = comp[c[::-1]]
+            pieces.append(c)
+    n_sp = len(pieces) + 1
+    spacers = [rng.integers(0, 4, size=max(20, int(unique / n_sp))).astype(np.uint8) for _ in range(n_sp)]
+    order = rng.permutation(len(pieces))
+    seq = [spacers[0]]
+    for k, i in enumerate(order):
+        seq += [pieces[i], spacers[k + 1]]
+    seq = np.concatenate(seq)
+    cut = seq.size * 2 // 3
+    with open(prefix, "w") as fh:
+        for name, s in (("rep1", seq[:cut]), ("rep2", seq[cut:])):
+            fh.write(">%s\n" % name)
+            txt = "".join("ACGT"[x] for x in s)
+            for i in range(0, len(txt), 60):
+                fh.write(txt[i:i + 60] + "\n")
+    oracle.idx_build(prefix, save=True)
+    return prefix

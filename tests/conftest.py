@@ -50,3 +50,9 @@ def gpu_lib():
     if lib.device_count() < 1:
         pytest.fail("libssgpu.so loaded but no HIP device is visible")
     return lib
+
+
+@pytest.fixture(scope="session")
+def repeat_prefix(oracle, tmp_path_factory):
+    import common
+    return common.repeat_reference(oracle, tmp_path_factory.mktemp("repeats"))

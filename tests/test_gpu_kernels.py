@@ -74,3 +74,19 @@ def test_gpu_dedup(gpu_lib, oracle):
 
 def test_gpu_align1_250(gpu_lib, oracle):
     assert common.check_align1(gpu_lib, oracle, 1000, seed=16, read_len=250) > 1000
+
+
+def test_gpu_repeats_align1(gpu_lib, oracle, repeat_prefix, monkeypatch):
+    # repeat-rich reference: reads with hundreds to thousands of seeds (wave-per-read chaining kernels)
+    assert common.check_align1(gpu_lib, oracle, 300, seed=21, prefix=repeat_prefix) > 10000
+    monkeypatch.setenv("SSG_CHAIN_WAVE_BIG", "100")   # force the 4096-chain LDS variant
+    monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "4")
+    assert common.check_align1(gpu_lib, oracle, 150, seed=22, prefix=repeat_prefix) > 5000
+    monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "100000")  # and the lane-per-read kernel on the same reads
+    monkeypatch.setenv("SSG_CHAIN_WAVE_BIG", "100000")
+    assert common.check_align1(gpu_lib, oracle, 150, seed=22, prefix=repeat_prefix) > 5000
+
+
+def test_gpu_repeats_pe_sam(gpu_lib, oracle, repeat_prefix):
+    text, stats = common.check_pe_sam(gpu_lib, oracle, 300, seed=23, prefix=repeat_prefix)
+    assert "XA:Z:" in text

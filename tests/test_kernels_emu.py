@@ -62,3 +62,19 @@ def test_emu_dedup(emu_lib, oracle):
 
 def test_emu_align1_250(emu_lib, oracle):
     assert common.check_align1(emu_lib, oracle, 60, seed=6, read_len=250) > 60
+
+
+def test_emu_repeats_align1(emu_lib, oracle, repeat_prefix, monkeypatch):
+    # repeat-rich reference: reads with hundreds of seeds go through the wave-per-read chaining kernels
+    assert common.check_align1(emu_lib, oracle, 12, seed=21, prefix=repeat_prefix) > 500
+    monkeypatch.setenv("SSG_CHAIN_WAVE_BIG", "100")   # force the 4096-chain LDS variant
+    monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "4")
+    assert common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix) > 500
+    monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "100000")  # and the lane-per-read kernel on the same reads
+    monkeypatch.setenv("SSG_CHAIN_WAVE_BIG", "100000")
+    assert common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix) > 500
+
+
+def test_emu_repeats_pe_sam(emu_lib, oracle, repeat_prefix):
+    text, stats = common.check_pe_sam(emu_lib, oracle, 10, seed=23, prefix=repeat_prefix)
+    assert "XA:Z:" in text
