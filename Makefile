@@ -14,6 +14,13 @@ speedseq_amd/libssgpu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
 	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core.o $(CSRC)/sam_format.o -o $@
 
+# instrumented build (device phase counters, tools/dbg/phase.py); never the default library
+tune: speedseq_amd/libssgpu_tune.so
+speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
+	$(HIPCC) $(HIPFLAGS) -DSSG_TUNE -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_tune.o
+	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/sam_format.o -o $@
+
 # the executables speedseq.config names (reference bin/speedseq.config:13-14)
 tools: bin/bwa bin/samblaster
 bin/bwa: $(HOST)/bwa_main.cpp include/ssgpu.h speedseq_amd/libssgpu.so

@@ -49,7 +49,7 @@ def _ptr(a):
 
 class Lib:
     def __init__(self, path=None):
-        path = path or DEFAULT_LIB
+        path = path or os.environ.get("SSGPU_LIB") or DEFAULT_LIB   # SSGPU_LIB: e.g. the instrumented build of `make tune`
         if not os.path.exists(path):
             raise SsgError("%s not found: build it with `make lib` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path

@@ -15,12 +15,17 @@
 #ifndef SSG_K_EXTEND_H
 #define SSG_K_EXTEND_H
 #include "k_sw.h"
+#include "k_sdp.h"
+#include "k_extlane.h"
 
 #define SSG_TWIN_LDS 1024
 #define SSG_TWIN_GLB 32768
 #define SSG_WAVES_PER_WG 4
 /* the DP rows are chains of dependent DPP/VALU ops: they need >= 4 waves per SIMD to hide their own
  * latency, so the wave-per-read kernels cap their VGPR budget (cold scalar paths may spill) */
+#ifndef SSG_C2A_WAVES_PER_SIMD
+#define SSG_C2A_WAVES_PER_SIMD 3   /* chain2aln: 168 VGPRs; measured 266 vs 282 ms against 4 waves (128 VGPRs) */
+#endif
 #ifndef SSG_SW_WAVES_PER_SIMD
 #define SSG_SW_WAVES_PER_SIMD 4
 #endif
@@ -61,8 +66,6 @@ struct ssg_reg_sc_lt {
 	{ return (a.score > b.score) | ((a.score == b.score) & ((a.rb < b.rb) | ((a.rb == b.rb) & (a.qb < b.qb)))); } /* branch-free: see ssg_chain_key_lt */
 };
 
-#define SSG_PATCH_MAX_R_BW 0.05f
-#define SSG_PATCH_MIN_SC_RATIO 0.90f
 
 /* score of the banded global alignment of query[qb,qe) vs reference [rb,re) as upstream
  * bwa_gen_cigar2 computes it with n_cigar == NULL (both reversed when on the reverse strand) */
@@ -119,7 +122,7 @@ SSG_DEVFN int wv_patch_reg(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 }
 
 /* upstream mem_sort_dedup_patch (wave-uniform; `patch` enables mem_patch_reg as in mem_align1_core) */
-SSG_DEVFN int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const uint8_t *query, int patch, int n, ssg_alnreg_t *a,
+SSG_DEVFN_COLD int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const uint8_t *query, int patch, int n, ssg_alnreg_t *a,
                                   uint8_t *tbuf, int tcap, int *err, unsigned long long *cells)
 {
 	int m, i, j;
@@ -177,7 +180,9 @@ SSG_DEVFN int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem_opt_
 SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
-                                uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells, unsigned long long *ph)
+                                uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells, unsigned long long *ph,
+                                ssg_sdp_small_t *sdp_lds, ssg_sdp_big_t *sdp_big, ssg_alnreg_t *sdp_tmp,
+                                const int32_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r)
 {
 	const uint8_t *query = seq + read_off[r];
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
@@ -190,55 +195,53 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	unsigned long long nc = 0;
 	const int nch = n_chain[r];
 	unsigned long long t0 = 0, t1;
-#define SSG_PH(x) do { if (ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
-	if (ph) { t0 = ssg_clock(); ph[5] += nch; }
+#define SSG_PH(x) do { if (SSG_TUNING && ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
+	if (SSG_TUNING && ph) { t0 = ssg_clock(); ph[5] += nch; }
 	for (int ci = 0; ci < nch; ++ci) {
 		const ssg_chain_t c = ch[ord[ci]];
 		const int32_t *cs = chain_seeds + c.first_seed;
 		int i, k, max_off[2], aw[2];
 		int64_t rmax[2], tmp;
 		if (c.n == 0) continue;
-		rmax[0] = l_pac << 1; rmax[1] = 0;
-		for (i = 0; i < c.n; ++i) {
-			const ssg_seed_t t = seeds[cs[i]];
-			int64_t b = t.rbeg - (t.qbeg + ssg_cal_max_gap(opt, t.qbeg));
-			int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + ssg_cal_max_gap(opt, l_query - t.qbeg - t.len));
-			rmax[0] = rmax[0] < b ? rmax[0] : b;
-			rmax[1] = rmax[1] > e ? rmax[1] : e;
-		}
-		rmax[0] = rmax[0] > 0 ? rmax[0] : 0;
-		rmax[1] = rmax[1] < l_pac << 1 ? rmax[1] : l_pac << 1;
-		const int64_t rbeg0 = seeds[cs[0]].rbeg;
-		if (rmax[0] < l_pac && l_pac < rmax[1]) { if (rbeg0 < l_pac) rmax[1] = l_pac; else rmax[0] = l_pac; }
-		{	/* upstream bns_fetch_seq: clip to the contig holding the first seed */
-			int is_rev; int rid = ssg_pos2rid(ix, ssg_depos(ix, rbeg0, &is_rev));
-			int64_t far_beg = ix.ctg_off[rid], far_end = far_beg + ix.ctg_len[rid];
-			if (is_rev) { int64_t t2 = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t2; }
-			rmax[0] = rmax[0] > far_beg ? rmax[0] : far_beg;
-			rmax[1] = rmax[1] < far_end ? rmax[1] : far_end;
-		}
+		/* window and first seed's extensions were prepared by ssg_k_ext_prep / ssg_k_ext_lane (k_extlane.h) */
+		const long gid = (long)chain_off[r] + ci;
+		const ssg_xjob_t xj = xjobs[gid];
+		rmax[0] = xj.rmax0; rmax[1] = xj.rmax1;
 		const int span = (int)(rmax[1] - rmax[0]);
 		uint8_t *rseq = span <= SSG_TWIN_LDS ? tlds_w : tg;
-		if (span > SSG_TWIN_GLB) { myerr = 1; continue; }
-		wv_fetch_ref(ix, rmax[0], rmax[1], rseq);
+		if (xj.flag) { myerr = 1; continue; }
+		int fetched = 0;   /* the 1-byte-per-base window is only needed when a later seed of the chain is extended here */
 		SSG_LANE0(for (int t = 0; t < c.n; ++t) srt[t] = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
 		          ssg_introsort(srt, (long)c.n, ssg_u64_lt()));
 		SSG_PH(0);
 		for (k = c.n - 1; k >= 0; --k) {
 			const ssg_seed_t s = seeds[cs[(uint32_t)srt[k]]];
-			for (i = 0; i < av_n; ++i) {
-				const ssg_alnreg_t p = av[i];
-				int64_t rd; int qd, w, max_gap;
-				if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
-				if (s.len - p.seedlen0 > .1 * l_query) continue;
-				qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
-				max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
-				w = max_gap < p.w ? max_gap : p.w;
-				if (qd - rd < w && rd - qd < w) break;
-				qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-				max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
-				w = max_gap < p.w ? max_gap : p.w;
-				if (qd - rd < w && rd - qd < w) break;
+			{	/* is the seed contained in an earlier region?  64 regions per step; the scalar loop's first hit decides */
+				int hit = av_n;
+				for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64) {
+					const int ii = i0 + wv_lane();
+					int h = 0;
+					if (ii < av_n) {
+						const ssg_alnreg_t *p = &av[ii];
+						const int64_t prb = p->rb, pre = p->re; const int pqb = p->qb, pqe = p->qe, pw = p->w, psl = p->seedlen0;
+						if (!(s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) && !(s.len - psl > .1 * l_query)) {
+							int64_t rd; int qd, w, max_gap;
+							qd = s.qbeg - pqb; rd = s.rbeg - prb;
+							max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+							w = max_gap < pw ? max_gap : pw;
+							if (qd - rd < w && rd - qd < w) h = 1;
+							else {
+								qd = pqe - (s.qbeg + s.len); rd = pre - (s.rbeg + s.len);
+								max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+								w = max_gap < pw ? max_gap : pw;
+								if (qd - rd < w && rd - qd < w) h = 1;
+							}
+						}
+					}
+					const unsigned long long bal = wv_ballot(h);
+					if (bal) hit = i0 + __builtin_ctzll(bal);
+				}
+				i = hit;
 			}
 			if (i < av_n) {
 				for (i = k + 1; i < c.n; ++i) {
@@ -251,16 +254,23 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				if (i == c.n) { SSG_LANE0(srt[k] = 0); SSG_PH(1); continue; }
 			}
 			SSG_PH(1);
-			if (ph) ++ph[6];
+			if (SSG_TUNING && ph) ++ph[6];
 			ssg_alnreg_t a;
 			a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = a.seedcov = a.secondary = a.secondary_all = a.n_comp = 0; a.hash = 0;
 			a.w = aw[0] = aw[1] = opt.w;
 			a.score = a.truesc = -1;
 			a.rid = c.rid;
+			const bool ahead = k == c.n - 1;   /* == xj.seed_t: extended ahead of time, one lane per extension */
+			if (!ahead && !fetched) { wv_fetch_ref(ix, rmax[0], rmax[1], rseq); fetched = 1; }
 			if (s.qbeg) { /* left extension: both sequences walked backwards */
 				ssg_ext_res_t x; x.score = -1;
 				tmp = s.rbeg - rmax[0];
 				ssg_seqv_t qs = { query + s.qbeg - 1, -1 }, rs = { rseq + tmp - 1, -1 };
+				if (ahead) {
+					const ssg_xres_t o = xres_l[gid];
+					x.score = o.score; x.qle = o.qle; x.tle = o.tle; x.gtle = o.gtle; x.gscore = o.gscore; x.max_off = o.max_off;
+					aw[0] = o.aw; a.score = o.score; max_off[0] = o.max_off;
+				} else
 				for (i = 0; i < SSG_MAX_BAND_TRY; ++i) {
 					int prev = a.score;
 					aw[0] = opt.w << i;
@@ -276,6 +286,11 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				int qe = s.qbeg + s.len, sc0 = a.score;
 				int re = (int)(s.rbeg + s.len - rmax[0]);
 				ssg_seqv_t qs = { query + qe, 1 }, rs = { rseq + re, 1 };
+				if (ahead) {
+					const ssg_xres_t o = xres_r[gid];
+					x.score = o.score; x.qle = o.qle; x.tle = o.tle; x.gtle = o.gtle; x.gscore = o.gscore; x.max_off = o.max_off;
+					aw[1] = o.aw; a.score = o.score; max_off[1] = o.max_off;
+				} else
 				for (i = 0; i < SSG_MAX_BAND_TRY; ++i) {
 					int prev = a.score;
 					aw[1] = opt.w << i;
@@ -298,8 +313,13 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 			SSG_PH(2);
 		}
 	}
-	if (ph) ph[7] += av_n;
-	av_n = wv_sort_dedup_patch(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
+	if (SSG_TUNING && ph) ph[7] += av_n;
+	{	/* mem_sort_dedup_patch: on compact keys unless a pair of regions has to be globally aligned (patched) */
+		int m = -1;
+		if (av_n <= SSG_SDP_SMALL) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2, l_pac);
+		else if (av_n <= SSG_SDP_BIG) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2, l_pac);
+		av_n = m >= 0 ? m : wv_sort_dedup_patch(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
+	}
 	SSG_PH(3);
 #undef SSG_PH
 	if (wv_lane() == 0) { n_reg[r] = av_n; err[r] = myerr; }
@@ -307,12 +327,15 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 }
 
 /* grid-strided: every resident wavefront owns one LDS window and one SSG_TWIN_GLB slab of tglb */
-__global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
+__global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
-                                uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue, int tune)
+                                uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue, int tune,
+                                ssg_sdp_big_t *sdpbig, ssg_alnreg_t *bcopy,
+                                const int32_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r)
 {
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
+	__shared__ ssg_sdp_small_t sdp[SSG_WAVES_PER_WG];
 	const int wslot = (int)(threadIdx.x >> 6);
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
 	unsigned long long nc = 0, ph[8] = {0,0,0,0,0,0,0,0};
@@ -321,10 +344,10 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_chain2aln(ss
 		const long k = wv_queue_pop(queue);
 		if (k >= n_reads) break;
 		wv_chain2aln_read(ix, opt, work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
-		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, tune ? ph : 0);
+		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r);
 	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);
-	if (tune && wv_lane() == 0) { /* tuning: window+seed sort, containment scan, extension, re-sort, wave total; #chains, #extended seeds, #regions */
+	if (SSG_TUNING && tune && wv_lane() == 0) { /* tuning: window+seed sort, containment scan, extension, re-sort, wave total; #chains, #extended seeds, #regions */
 		ph[4] = ssg_clock() - k0;
 		for (int t = 0; t < 8; ++t) atomicAdd(&ssg_dbg_cyc[16 + t], ph[t]);
 	}

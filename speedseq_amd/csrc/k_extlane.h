@@ -1,0 +1,270 @@
+/*
+ * k_extlane.h -- seed extension with ONE LANE PER EXTENSION (upstream
+ * mem_chain2aln's calls of ksw_extend2), for the seed every chain extends first.
+ *
+ * mem_chain2aln walks the seeds of a chain from the best one down and skips a seed that is already
+ * contained in an earlier region of the read, so within a read the *decision* to extend is sequential.
+ * The *result* of an extension, however, depends only on (read, chain window, seed): it can be computed
+ * ahead of the decision.  The first (best) seed of a chain is extended in all but a few cases, and
+ * for repeat-heavy reads (hundreds of chains, one extended seed each) these extensions are ~all of the
+ * Smith-Waterman work.  So:
+ *   ssg_k_ext_prep   one lane per chain: reference window (rmax) and best seed -> job record
+ *   ssg_k_ext_lane   one lane per job and side (left, then right with the left score as h0): a scalar
+ *                    restatement of ksw_extend2 per lane, 64 independent extensions per wavefront.  The
+ *                    DP row {H,E} and the query live in LDS, one 32-bit word per column and lane
+ *                    (h:16 | e:13 | query code:3; word (j*64 + lane) -> bank = lane, conflict free for
+ *                    any mix of per-lane columns).  Jobs are sorted by query-side length so the lanes of
+ *                    a wave run similar trip counts.  The reference is read straight from the 2-bit pac
+ *                    (one aligned 32-bit word = 16 bases, next word prefetched).
+ *   ssg_k_chain2aln  (k_extend.h) then replays upstream's decisions per read and consumes the results;
+ *                    the rare later seed of a chain that is extended too still goes through the
+ *                    wave-per-extension kernel code there.
+ * No cross-lane operation is used here: per-lane control flow is plain SIMT divergence.
+ */
+#ifndef SSG_K_EXTLANE_H
+#define SSG_K_EXTLANE_H
+#include "k_sw.h"
+
+struct ssg_xjob_t { int64_t rbeg, rmax0, rmax1; int32_t read, flag; int16_t qbeg, len, l_query, seed_t; };   /* 40 bytes */
+struct ssg_xres_t { int32_t score, qle, tle, gtle, gscore, max_off, aw, done; };                            /* 32 bytes */
+
+SSG_DEVFN int ssg_cal_max_gap2(const ssg_mem_opt_t &opt, int qlen)
+{	/* upstream cal_max_gap */
+	int l_del = (int)((double)(qlen * opt.a - opt.o_del) / opt.e_del + 1.);
+	int l_ins = (int)((double)(qlen * opt.a - opt.o_ins) / opt.e_ins + 1.);
+	int l = l_del > l_ins ? l_del : l_ins;
+	l = l > 1 ? l : 1;
+	return l < opt.w << 1 ? l : opt.w << 1;
+}
+
+/* one lane per surviving chain g (global numbering: chain_off[r] + position in the read's order[]) */
+__global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, long n_jobs, const int64_t *read_off,
+                               const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
+                               const int32_t *chain_seeds, const int32_t *chain_off, int twin_cap,
+                               ssg_xjob_t *jobs, uint64_t *key_l, uint64_t *key_r)
+{
+	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_jobs) return;
+	int lo = 0, hi = n_reads - 1;   /* last read with chain_off[r] <= g */
+	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chain_off[mid] <= g) lo = mid; else hi = mid - 1; }
+	const int r = lo, ci = (int)(g - chain_off[r]);
+	const long s0 = seed_off[r];
+	const int l_query = (int)(read_off[r+1] - read_off[r]);
+	const ssg_chain_t c = chains[s0 + order[s0 + ci]];
+	const int32_t *cs = chain_seeds + c.first_seed;
+	const int64_t l_pac = ix.l_pac;
+	ssg_xjob_t jb;
+	jb.read = r; jb.flag = 0; jb.l_query = (int16_t)l_query; jb.rbeg = 0; jb.rmax0 = jb.rmax1 = 0; jb.qbeg = jb.len = 0; jb.seed_t = 0;
+	if (c.n == 0) { jb.flag = 2; jobs[g] = jb; key_l[g] = (uint64_t)255 << 32 | (uint64_t)g; key_r[g] = (uint64_t)255 << 32 | (uint64_t)g; return; }
+	int64_t rmax0 = l_pac << 1, rmax1 = 0;
+	uint64_t best = 0; int best_t = 0;
+	for (int i = 0; i < c.n; ++i) {
+		const ssg_seed_t t = seeds[cs[i]];
+		const int64_t b = t.rbeg - (t.qbeg + ssg_cal_max_gap2(opt, t.qbeg));
+		const int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + ssg_cal_max_gap2(opt, l_query - t.qbeg - t.len));
+		rmax0 = rmax0 < b ? rmax0 : b;
+		rmax1 = rmax1 > e ? rmax1 : e;
+		const uint64_t k = (uint64_t)t.score << 32 | (uint64_t)i;   /* upstream sorts (score<<32 | i) and starts from the largest */
+		if (i == 0 || k > best) { best = k; best_t = i; }
+	}
+	rmax0 = rmax0 > 0 ? rmax0 : 0;
+	rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+	const int64_t rbeg0 = seeds[cs[0]].rbeg;
+	if (rmax0 < l_pac && l_pac < rmax1) { if (rbeg0 < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
+	{	/* upstream bns_fetch_seq: clip to the contig holding the first seed */
+		int is_rev; const int rid = ssg_pos2rid(ix, ssg_depos(ix, rbeg0, &is_rev));
+		int64_t far_beg = ix.ctg_off[rid], far_end = far_beg + ix.ctg_len[rid];
+		if (is_rev) { const int64_t t2 = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t2; }
+		rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+		rmax1 = rmax1 < far_end ? rmax1 : far_end;
+	}
+	const ssg_seed_t s = seeds[cs[best_t]];
+	jb.rbeg = s.rbeg; jb.rmax0 = rmax0; jb.rmax1 = rmax1; jb.qbeg = (int16_t)s.qbeg; jb.len = (int16_t)s.len; jb.seed_t = (int16_t)best_t;
+	if (rmax1 - rmax0 > twin_cap) jb.flag = 1;   /* window beyond the wave kernel's buffer: reported as an error there */
+	jobs[g] = jb;
+	const int ql = jb.flag ? 0 : s.qbeg, qr = jb.flag ? 0 : l_query - s.qbeg - s.len;
+	key_l[g] = (uint64_t)(255 - ql) << 32 | (uint64_t)g;   /* ascending sort = longest query side first; side 0 = nothing to do */
+	key_r[g] = (uint64_t)(255 - qr) << 32 | (uint64_t)g;
+}
+
+/* reference bases along an extension: doubled coordinate p0 + i*dir, read from the forward-strand pac */
+struct ssg_tgt_t {
+	const uint8_t *pac; int64_t f, nbytes, cur_i; int fs, comp; uint32_t cur, nxt;
+};
+SSG_DEVFN uint32_t ssg_pac_word(const ssg_tgt_t &t, int64_t wi)
+{	/* aligned 32-bit word wi of the pac (16 bases), clamped to the array: (l_pac/4 + 1) bytes */
+	const int64_t last = (t.nbytes - 1) >> 2;
+	wi = wi < 0 ? 0 : wi > last ? last : wi;
+	const int64_t b = wi << 2;
+	if (b + 4 <= t.nbytes) return ((const uint32_t*)t.pac)[wi];
+	uint32_t v = 0;
+	for (int k = 0; k < 4; ++k) if (b + k < t.nbytes) v |= (uint32_t)t.pac[b + k] << (8 * k);
+	return v;
+}
+SSG_DEVFN void ssg_tgt_init(ssg_tgt_t &t, const ssg_index_view_t &ix, int64_t p0, int dir)
+{
+	const int64_t l_pac = ix.l_pac;
+	t.pac = ix.pac; t.nbytes = (l_pac >> 2) + 1;
+	if (p0 < l_pac) { t.f = p0; t.fs = dir; t.comp = 0; } else { t.f = (l_pac << 1) - 1 - p0; t.fs = -dir; t.comp = 1; }
+	t.cur_i = t.f >> 4;
+	t.cur = ssg_pac_word(t, t.cur_i); t.nxt = ssg_pac_word(t, t.cur_i + t.fs);
+}
+SSG_DEVFN int ssg_tgt_next(ssg_tgt_t &t)
+{	/* base at t.f, then advance; pac byte k>>2 holds base k at bits (~k&3)*2 and a 32-bit load is little endian */
+	const int64_t wi = t.f >> 4;
+	if (wi != t.cur_i) { t.cur = t.nxt; t.cur_i = wi; t.nxt = ssg_pac_word(t, wi + t.fs); }
+	const int k = (int)(t.f & 15);
+	const int base = (int)(t.cur >> (((k >> 2) << 3) + ((~k & 3) << 1))) & 3;
+	t.f += t.fs;
+	return t.comp ? 3 - base : base;
+}
+
+#define SSG_XL_Q(wd)  ((int)((wd) >> 29))
+#define SSG_XL_E(wd)  ((int)(((wd) >> 16) & 0x1fff))
+#define SSG_XL_H(wd)  ((int)((wd) & 0xffff))
+
+/* upstream ksw_extend2, one lane; Lc[j*64] is this lane's column j (query codes already in bits 29..31) */
+SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_view_t &ix, uint32_t *Lc, int qlen, int tlen, int64_t p0, int dir,
+                                   int w, int end_bonus, int zdrop, int h0, unsigned long long *cells)
+{
+	const int sa = opt.a, sb = opt.b;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	int i, j, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
+	{	/* first row */
+		int prev = h0;
+		for (j = 0; j <= qlen; ++j) {
+			int h;
+			if (j == 0) h = h0;
+			else if (j == 1) h = h0 > oe_ins ? h0 - oe_ins : 0;
+			else h = prev > e_ins ? prev - e_ins : 0;
+			prev = h;
+			Lc[j * 64] = (Lc[j * 64] & 0xe0000000u) | (uint32_t)h;
+		}
+	}
+	{	/* band clamp */
+		const int mx = sa > 0 ? sa : 0;
+		max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
+		max_ins = max_ins > 1 ? max_ins : 1;
+		w = w < max_ins ? w : max_ins;
+		max_del = (int)((double)(qlen * mx + end_bonus - o_del) / e_del + 1.);
+		max_del = max_del > 1 ? max_del : 1;
+		w = w < max_del ? w : max_del;
+	}
+	max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+	beg = 0; end = qlen;
+	unsigned long long ncell = 0;
+	ssg_tgt_t tg;
+	ssg_tgt_init(tg, ix, p0, dir);
+	for (i = 0; i < tlen; ++i) {
+		int f = 0, h1, mm = 0, mj = -1;
+		const int tb = ssg_tgt_next(tg);
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+		else h1 = 0;
+		if (end > beg) {
+			ncell += (unsigned long long)(end - beg);
+			uint32_t wd = Lc[beg * 64];
+			for (j = beg; j < end; ++j) {
+				const uint32_t wn = Lc[(j + 1) * 64];    /* next column in flight while this one is computed */
+				const int q = SSG_XL_Q(wd);
+				int M = SSG_XL_H(wd), e = SSG_XL_E(wd), h, t;
+				const int sc = q > 3 ? -1 : (q == tb ? sa : -sb);
+				M = M ? M + sc : 0;
+				h = M > e ? M : e;
+				h = h > f ? h : f;
+				mj = mm > h ? mj : j;
+				mm = mm > h ? mm : h;
+				t = M - oe_del; t = t > 0 ? t : 0;
+				e -= e_del; e = e > t ? e : t;
+				Lc[j * 64] = (wd & 0xe0000000u) | ((uint32_t)e << 16) | (uint32_t)h1;
+				h1 = h;
+				t = M - oe_ins; t = t > 0 ? t : 0;
+				f -= e_ins; f = f > t ? f : t;
+				wd = wn;
+			}
+			j = end;
+		} else j = beg;
+		Lc[end * 64] = (Lc[end * 64] & 0xe0000000u) | (uint32_t)h1;
+		if (j == qlen) {
+			max_ie = gscore > h1 ? max_ie : i;
+			gscore = gscore > h1 ? gscore : h1;
+		}
+		if (mm == 0) break;
+		if (mm > max) {
+			max = mm; max_i = i; max_j = mj;
+			max_off = max_off > iabs(mj - i) ? max_off : iabs(mj - i);
+		} else if (zdrop > 0) {
+			if (i - max_i > mj - max_j) { if (max - mm - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+			else { if (max - mm - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+		}
+		for (j = beg; j < end && (Lc[j * 64] & 0x1fffffffu) == 0; ++j);
+		beg = j;
+		for (j = end; j >= beg && (Lc[j * 64] & 0x1fffffffu) == 0; --j);
+		end = j + 2 < qlen ? j + 2 : qlen;
+	}
+	if (cells) *cells += ncell;
+	ssg_ext_res_t r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+	return r;
+}
+
+#define SSG_XL_BAND_TRY 2   /* == SSG_MAX_BAND_TRY (upstream MAX_BAND_TRY) */
+
+/* side 0: left extensions (query and reference walked backwards from the seed); side 1: right extensions.
+ * sorted[t] = (255 - side length) << 32 | job id; QCAP+1 columns of LDS per lane. */
+template <int QCAP>
+__global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int side, long n_jobs, const uint64_t *sorted,
+                               const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
+                               unsigned long long *cells)
+{
+	__shared__ uint32_t L[(QCAP + 1) * 64];
+	const long t = (long)blockIdx.x * 64 + threadIdx.x;
+	if (t >= n_jobs) return;
+	const uint64_t key = sorted[t];
+	if ((key >> 32) >= 255) return;   /* nothing on this side */
+	const long g = (long)(uint32_t)key;
+	const ssg_xjob_t jb = jobs[g];
+	if (jb.flag) return;
+	uint32_t *Lc = L + (threadIdx.x & 63);
+	const uint8_t *query = seq + read_off[jb.read];
+	unsigned long long nc = 0;
+	ssg_ext_res_t x; x.score = -1; x.qle = x.tle = x.gtle = x.gscore = x.max_off = 0;
+	int aw = opt.w, score = -1;
+	if (side == 0) {
+		const int qlen = jb.qbeg;
+		if (qlen <= 0 || qlen > QCAP) return;
+		for (int j = 0; j < qlen; ++j) Lc[j * 64] = (uint32_t)query[jb.qbeg - 1 - j] << 29;
+		Lc[qlen * 64] = 0;
+		const int tlen = (int)(jb.rbeg - jb.rmax0);
+		for (int i = 0; i < SSG_XL_BAND_TRY; ++i) {
+			const int prev = score;
+			aw = opt.w << i;
+			x = ln_extend2(opt, ix, Lc, qlen, tlen, jb.rbeg - 1, -1, aw, opt.pen_clip5, opt.zdrop, jb.len * opt.a, &nc);
+			score = x.score;
+			if (score == prev || x.max_off < (aw >> 1) + (aw >> 2)) break;
+		}
+		ssg_xres_t o; o.score = x.score; o.qle = x.qle; o.tle = x.tle; o.gtle = x.gtle; o.gscore = x.gscore; o.max_off = x.max_off; o.aw = aw; o.done = 1;
+		res_l[g] = o;
+	} else {
+		const int qe = jb.qbeg + jb.len, qlen = jb.l_query - qe;
+		if (qlen <= 0 || qlen > QCAP) return;
+		const int sc0 = jb.qbeg ? res_l[g].score : jb.len * opt.a;
+		for (int j = 0; j < qlen; ++j) Lc[j * 64] = (uint32_t)query[qe + j] << 29;
+		Lc[qlen * 64] = 0;
+		const int tlen = (int)(jb.rmax1 - (jb.rbeg + jb.len));
+		score = sc0;
+		for (int i = 0; i < SSG_XL_BAND_TRY; ++i) {
+			const int prev = score;
+			aw = opt.w << i;
+			x = ln_extend2(opt, ix, Lc, qlen, tlen, jb.rbeg + jb.len, 1, aw, opt.pen_clip3, opt.zdrop, sc0, &nc);
+			score = x.score;
+			if (score == prev || x.max_off < (aw >> 1) + (aw >> 2)) break;
+		}
+		ssg_xres_t o; o.score = x.score; o.qle = x.qle; o.tle = x.tle; o.gtle = x.gtle; o.gscore = x.gscore; o.max_off = x.max_off; o.aw = aw; o.done = 1;
+		res_r[g] = o;
+	}
+	if (cells && nc) atomicAdd(cells, nc);
+}
+#endif

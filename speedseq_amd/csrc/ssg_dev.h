@@ -14,6 +14,7 @@
 #include "emu.h"
 #define SSG_DEVFN static inline
 #define SSG_DEVMEM inline
+#define SSG_DEVFN_COLD static
 SSG_DEVFN int wv_shfl(int v, int src) { return emu_shfl_i32(v, src); }
 SSG_DEVFN unsigned long long wv_ballot(int p) { return emu_ballot(p); }
 #define SSG_UNROLL
@@ -21,6 +22,7 @@ SSG_DEVFN unsigned long long wv_ballot(int p) { return emu_ballot(p); }
 #include <hip/hip_runtime.h>
 #define SSG_DEVFN static __device__ __forceinline__
 #define SSG_DEVMEM __device__ __forceinline__
+#define SSG_DEVFN_COLD static __device__ __attribute__((noinline))   /* rarely taken paths: keep them out of the callers' register budget */
 SSG_DEVFN int wv_shfl(int v, int src) { return __shfl(v, src, 64); }
 SSG_DEVFN unsigned long long wv_ballot(int p) { return __ballot(p); }
 #define SSG_UNROLL _Pragma("unroll")
@@ -30,10 +32,17 @@ SSG_DEVFN unsigned long long wv_ballot(int p) { return __ballot(p); }
 /* phase cycle counters for kernel tuning (read back with ssg_dbg_cycles) */
 #ifdef SSG_EMU
 static unsigned long long ssg_dbg_cyc[24];
+#define SSG_TUNING 0
 SSG_DEVFN unsigned long long ssg_clock() { return 0; }
 #else
 __device__ unsigned long long ssg_dbg_cyc[24];
+#ifdef SSG_TUNE   /* `make lib TUNE=1`: instrumented build for tools/dbg/phase.py; the counters cost ~16 VGPRs in the SW kernels */
+#define SSG_TUNING 1
 SSG_DEVFN unsigned long long ssg_clock() { return (unsigned long long)clock64(); }
+#else
+#define SSG_TUNING 0
+SSG_DEVFN unsigned long long ssg_clock() { return 0; }
+#endif
 #endif
 /* make one lane's global stores visible to the other lanes of the same wave */
 #ifdef SSG_EMU

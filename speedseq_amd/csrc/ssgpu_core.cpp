@@ -18,6 +18,9 @@
 #include "k_extend.h"
 #include "k_swjobs.h"
 #include "../../include/ssgpu.h"
+#ifndef SSG_EMU
+#include <hipcub/hipcub.hpp>
+#endif
 
 thread_local std::string ssg_err_msg;
 #ifndef SSG_EMU
@@ -331,6 +334,26 @@ static void order_desc(const std::vector<int32_t> &key, std::vector<int32_t> &or
 	for (size_t i = 0; i < key.size(); ++i) order[cnt[K - 1 - std::min(std::max(key[i], 0), K - 1)]++] = (int32_t)i;
 }
 
+/* radix sort of 64-bit keys on bits [begin_bit, end_bit) (stable) */
+static int sort_keys_u64(uint64_t *k_in, uint64_t *k_out, long n, int begin_bit, int end_bit)
+{
+	if (n <= 0) return 0;
+#ifdef SSG_EMU
+	const uint64_t mask = (end_bit >= 64 ? ~0ull : (1ull << end_bit) - 1) & ~((1ull << begin_bit) - 1);
+	std::vector<uint64_t> v(k_in, k_in + n);
+	std::stable_sort(v.begin(), v.end(), [&](uint64_t a, uint64_t b) { return (a & mask) < (b & mask); });
+	memcpy(k_out, v.data(), (size_t)n * 8);
+	return 0;
+#else
+	size_t tmp_bytes = 0;
+	if (hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, k_in, k_out, (int)n, begin_bit, end_bit) != hipSuccess) { ssg_err_msg = "hipcub SortKeys (size query) failed"; return SSG_EHIP; }
+	dbuf<uint8_t> tmp(tmp_bytes);
+	CHKA(tmp);
+	if (hipcub::DeviceRadixSort::SortKeys(tmp.p, tmp_bytes, k_in, k_out, (int)n, begin_bit, end_bit) != hipSuccess) { ssg_err_msg = "hipcub SortKeys failed"; return SSG_EHIP; }
+	return 0;
+#endif
+}
+
 /* ------------------------------- mem_align1_core for a batch ------------------------------- */
 struct align1_dev_t {	/* device-resident result of stages 1-4 */
 	dbuf<int64_t> seed_off; dbuf<ssg_alnreg_t> regs; dbuf<int32_t> n_reg;
@@ -399,13 +422,36 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
 	}
 	STAGE("chain");
+	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
+	std::vector<int32_t> h_nch(n_reads), h_choff((size_t)n_reads + 1);
+	CHK(d_nchain.down(h_nch.data(), n_reads));
+	{ int64_t t = 0; for (int r = 0; r < n_reads; ++r) { h_choff[r] = (int32_t)t; t += h_nch[r]; } h_choff[n_reads] = (int32_t)t;
+	  if (t >= (int64_t)1 << 31) { ssg_err_msg = "more than 2^31 chains in one call"; return SSG_EOVERFLOW; } }
+	const long n_jobs = h_choff[n_reads];
+	dbuf<int32_t> d_choff((size_t)n_reads + 1); dbuf<ssg_xjob_t> d_xjobs((size_t)n_jobs + 1); dbuf<ssg_xres_t> d_xl((size_t)n_jobs + 1), d_xr((size_t)n_jobs + 1);
+	dbuf<uint64_t> d_kl((size_t)n_jobs + 1), d_kr((size_t)n_jobs + 1), d_sl((size_t)n_jobs + 1), d_sr((size_t)n_jobs + 1);
+	CHKA(d_choff); CHKA(d_xjobs); CHKA(d_xl); CHKA(d_xr); CHKA(d_kl); CHKA(d_kr); CHKA(d_sl); CHKA(d_sr);
+	CHK(d_choff.up(h_choff.data(), (size_t)n_reads + 1));
+	if (n_jobs > 0) {
+		if (opt->a * 2 * max_len + 64 >= 8191) { ssg_err_msg = "match score x read length beyond the 13-bit DP cells of the extension kernel"; return SSG_EINVAL; }
+		SSG_LAUNCH(ssg_k_ext_prep, (n_jobs + 255) / 256, 256, 0, idx->v, *opt, n_reads, n_jobs, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
+		           d_choff.p, (int)SSG_TWIN_GLB, d_xjobs.p, d_kl.p, d_kr.p);
+		CHK(sort_keys_u64(d_kl.p, d_sl.p, n_jobs, 32, 40)); CHK(sort_keys_u64(d_kr.p, d_sr.p, n_jobs, 32, 40));
+		for (int side = 0; side < 2; ++side) {
+			const uint64_t *srt = side ? d_sr.p : d_sl.p;
+			if (max_len <= 136 + opt->min_seed_len) SSG_LAUNCH(ssg_k_ext_lane<136>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
+			else SSG_LAUNCH(ssg_k_ext_lane<256>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
+		}
+	}
+	STAGE("ext_lane");
 	{
 		const int wpb = SSG_WAVES_PER_WG;
-		long nwg = std::min<long>(((long)n_reads + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
-		dbuf<uint8_t> d_tglb((size_t)nwg * wpb * SSG_TWIN_GLB);
-		CHKA(d_tglb);
+		long nwg = std::min<long>(((long)n_reads + wpb - 1) / wpb, 256 * SSG_C2A_WAVES_PER_SIMD);
+		dbuf<uint8_t> d_tglb((size_t)nwg * wpb * SSG_TWIN_GLB); dbuf<ssg_sdp_big_t> d_sdpbig((size_t)nwg * wpb); dbuf<ssg_alnreg_t> d_bcopy((size_t)nwg * wpb * SSG_SDP_BIG);
+		CHKA(d_tglb); CHKA(d_sdpbig); CHKA(d_bcopy);
 		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
-		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p, ssg_debug() >= 2);
+		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p, ssg_debug() >= 2, d_sdpbig.p, d_bcopy.p,
+		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p);
 		CHK(rt_sync());
 	}
 	std::vector<int32_t> herr(n_reads);
@@ -626,9 +672,6 @@ __global__ void ssg_k_ends_from_alns(long n_pairs, const int64_t *req_off, const
 	ends[r] = e;
 }
 
-#ifndef SSG_EMU
-#include <hipcub/hipcub.hpp>
-#endif
 /* stable sort of (hash, ordinal) by hash: hipCUB radix sort on the GPU */
 static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, long n)
 {
