@@ -212,7 +212,7 @@ def main():
             # ALGORITHMIC bytes per launch of each hot kernel (DESIGN.md section 3 states the per-unit figures):
             alg_bytes = {
                 # every bwt_extend = 2 rank queries = 2 x 64-byte Occ blocks (SURVEY 8d B_fm) + the read itself
-                "ssg_k_smem": 128.0 * n_ext + nreads * rl,
+                "ssg_k_smem_quad": 128.0 * n_ext + nreads * rl,
                 # per seed: ~16 LF steps x one 64-byte block + one 8-byte SA sample + the 28-byte seed written
                 "ssg_k_sal": seeds * (16 * 64 + 8 + 28),
                 # per seed: 28 bytes read (seed + contig id); per read <= one 56-byte chain + 4-byte id per seed written

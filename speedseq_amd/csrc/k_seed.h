@@ -1,10 +1,11 @@
 /*
  * k_seed.h -- gfx950 kernels for FM-index seeding.
  *
- *   ssg_k_smem      one lane per read: the three SMEM passes of upstream mem_collect_intv
- *                   (bwt_smem1a x2 + bwt_seed_strategy1), intervals sorted by (start,end).
- *                   Every bwt_extend is two rank queries = two 64-byte HBM lines; the kernel is
- *                   HBM-latency bound and relies on >=16 resident waves per CU to hide it.
+ *   ssg_k_smem_quad four lanes per read, state machine with one bwt_extend site (the product path);
+ *   ssg_k_smem_lane one lane per read, nested loops as upstream writes them (SSG_SMEM_KERNEL=lane: A/B runs);
+ *                   both: the three SMEM passes of upstream mem_collect_intv (bwt_smem1a x2 +
+ *                   bwt_seed_strategy1), intervals sorted by (start,end).  Every bwt_extend is two rank
+ *                   queries = two random 64-byte lines.
  *   ssg_k_sal_count per interval: number of sampled occurrences (<= max_occ) -> prefix sum.
  *   ssg_k_sal       one lane per (interval, occurrence): upstream bwt_sa LF-walk + sampled-SA
  *                   gather, then bns_intv2rid; writes mem_seed_t in upstream visiting order.
@@ -111,7 +112,7 @@ struct ssg_intv_lt { SSG_DEVMEM bool operator()(const ssg_intv_t &a, const ssg_i
  * out_intv: [n_reads x cap] ; out_n: per-read interval count (count > cap => overflow, the host
  * re-runs those reads with a larger cap).  scratch: per launched lane 3*scap intervals.
  */
-__global__ void __launch_bounds__(64) ssg_k_smem(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
+__global__ void __launch_bounds__(64) ssg_k_smem_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
                            ssg_intv_t *scratch, int scap, unsigned long long *n_extend)
@@ -165,6 +166,216 @@ __global__ void __launch_bounds__(64) ssg_k_smem(ssg_index_view_t ix, ssg_mem_op
 		my_nx += mem1.nx;
 	}
 	if (n_extend && my_nx) atomicAdd(n_extend, my_nx);
+}
+
+/*
+ * ssg_k_smem_quad -- upstream mem_collect_intv with FOUR LANES PER READ and a single bwt_extend site.
+ *
+ * Shape of the problem: ~700 dependent bwt_extend per 150-bp read, each two random 64-byte rank blocks;
+ * MI355X sustains ~55 G random lines/s (tools/dbg/gather_probe.cpp) and that, not 8 TB/s of streaming
+ * bandwidth, is the roofline of this kernel.  Two things keep a straightforward one-lane-per-read kernel
+ * (ssg_k_smem_lane below) at a fifth of it: the lanes of a wave sit in different loops of the nested
+ * algorithm, so most extensions issue for a few lanes only, and every step is a chain of dependent round
+ * trips (list entry -> extension -> list append).  Here
+ *   - a quad owns a read: each lane fetches one 16-byte quarter of each rank block (one load instruction
+ *     per block = 16 lines per wave; a per-lane fetch is 4 instructions x 64 lines) and the quad shares the
+ *     popcounts by DPP; a wave runs 16 reads instead of 64, so divergence costs a quarter;
+ *   - the three passes are a per-quad state machine (`advance': registers and LDS only) around ONE
+ *     extension site per loop iteration, where every quad of the wave issues its two block loads and the
+ *     prefetch of its next interval-list entry together: one memory round trip per step;
+ *   - the read sits in LDS as 4-bit codes; the interval being extended, the first entry of each list and
+ *     the prefetched next entry sit in registers.
+ * Result identity with the nested form: SMEMs are appended to the read's output when the backward pass
+ * emits them (the caller's length filter applied there; the "starts left of the previous one" test needs
+ * only the previous start); the list is sorted by (start,end) afterwards (ssg_k_smem_sort), and entries
+ * with equal (start,end) describe the same substring, i.e. are identical records, so the sorted list does
+ * not depend on insertion order.  The forward list is walked from its top instead of being reversed.
+ */
+#define SSG_SM_QWORDS 32   /* 8 bases per word: reads up to 256 bases */
+enum { SM_READ = 0, SM_P1, SM_FWD, SM_FWDEND, SM_BWD, SM_RET, SM_P2, SM_P3, SM_P3F, SM_OUT, SM_FIN };
+enum { SM_PEND_NONE = 0, SM_PEND_FWD, SM_PEND_BWD, SM_PEND_P3 };
+
+#ifndef SSG_SMQ_WAVES
+#define SSG_SMQ_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
+                           const uint8_t *seq, const int64_t *off,
+                           ssg_intv_t *out_intv, int32_t *out_n, int cap,
+                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend)
+{
+	__shared__ uint32_t qlds[SSG_SM_QWORDS * 16];
+	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nq = ((long)gridDim.x * blockDim.x) >> 2;
+	const int lane = (int)(threadIdx.x & 63), Q = lane >> 2, ql = lane & 3;
+	/* per-wave slab of 2 lists x scap entries x 16 quads, entry e of quad Q at [e*16 + Q] */
+	ssg_intv_t *const vec0 = scratch + (gt >> 6) * 2 * scap * 16 + Q, *const vec1 = vec0 + (long)scap * 16;
+	const uint32_t *const ql_ = qlds + Q;
+#define SMQ(i) ((int)((ql_[((i) >> 3) * 16] >> (((i) & 7) << 2)) & 15u))
+#define SMV(v, e) ((v)[(long)(e) * 16])
+#ifdef SSG_EMU
+#define QW 1          /* fibers of a quad are not in lock step: every lane stores the (identical) value it will read back */
+#else
+#define QW (ql == 0)  /* one lane of the quad stores */
+#endif
+	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+	unsigned long long my_nx = 0;
+	long it = (gt >> 2) - nq;
+	int state = SM_READ, pend = SM_PEND_NONE;
+	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0;
+	ssg_intv_t *mem = 0;
+	int sx = 0, i = 0, j = 0, curr_n = 0, prev_n = 0, prev_rev = 0, flip = 0, m1_n = 0, m1_last_beg = 0, ret = 0, e_c = 0;
+	uint64_t min_intv = 1, last_x2 = 0;
+	ssg_intv_t ik, p, pn, c0, first;
+	ik.x0 = ik.x1 = ik.x2 = ik.info = 0; p = pn = c0 = first = ik;
+	for (;;) {
+		while (pend == SM_PEND_NONE && state != SM_FIN) {
+			ssg_intv_t *const curr = flip ? vec1 : vec0;
+			switch (state) {
+			case SM_READ: {
+				it += nq;
+				if (it >= n_reads) { state = SM_FIN; break; }
+				const int r = read_ids ? read_ids[it] : (int)it;
+				const uint8_t *q = seq + off[r];
+				len = (int)(off[r+1] - off[r]);
+				mem = out_intv + (long)it * cap; mem_n = 0; ovf = 0;
+				for (int w = 0; w * 8 < len; ++w) { /* all 4 lanes write the same words: no cross-lane hand-off needed */
+					uint32_t v = 0;
+					for (int b = 0; b < 8 && w * 8 + b < len; ++b) v |= (uint32_t)(q[w * 8 + b] & 15) << (b << 2);
+					qlds[w * 16 + Q] = v;
+				}
+				x = 0;
+				state = len >= opt.min_seed_len ? SM_P1 : SM_OUT;
+			} break;
+			case SM_P1:
+				if (x >= len) { old_n = mem_n < cap ? mem_n : cap; k = 0; state = SM_P2; }
+				else if (SMQ(x) > 3) ++x;
+				else { sx = x; min_intv = 1; caller = 1; state = SM_FWD; m1_n = 0; curr_n = 0; i = sx + 1;
+				       ssg_set_intv(ix, SMQ(sx), ik); ik.info = (uint64_t)(sx + 1); }
+				break;
+			case SM_FWD: /* top of upstream's forward loop: for (i = x + 1; i < len; ++i) */
+				if (i < len && SMQ(i) < 4) { pend = SM_PEND_FWD; e_c = 3 - SMQ(i); }
+				else { if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ik; } else ovf = 1; ++curr_n; state = SM_FWDEND; }
+				break;
+			case SM_FWDEND: /* the forward list becomes `prev', walked from its top (= ik); ret = end of the longest match */
+				ret = (int)ik.info;
+				flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ik;
+				state = SM_BWD;
+				break;
+			case SM_BWD: { /* for (i = x - 1; i >= -1; --i) for (j = 0; j < prev->n; ++j) */
+				if (j >= prev_n) {
+					if (curr_n == 0) { state = SM_RET; break; }
+					flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 0; curr_n = 0; j = 0; --i; first = c0;
+					if (i < -1) state = SM_RET;
+					break;
+				}
+				p = j == 0 ? first : pn;
+				const int cb = i < 0 ? -1 : SMQ(i) < 4 ? SMQ(i) : -1;
+				if (cb >= 0) { pend = SM_PEND_BWD; e_c = cb; }
+				else { /* no base to extend with: only the first (longest) interval of the row can be an SMEM, the rest are no-ops */
+					if (j == 0 && (m1_n == 0 || i + 1 < m1_last_beg)) {
+						++m1_n; m1_last_beg = i + 1;
+						if ((int)(uint32_t)p.info - (i + 1) >= opt.min_seed_len) {
+							ssg_intv_t o = p; o.info |= (uint64_t)(i + 1) << 32;
+							if (mem_n < cap) { if (QW) mem[mem_n] = o; } else ovf = 1;
+							++mem_n;
+						}
+					}
+					j = prev_n;
+				}
+			} break;
+			case SM_RET:
+				if (caller == 1) { x = ret; state = SM_P1; } else { ++k; state = SM_P2; }
+				break;
+			case SM_P2: /* re-seed from the middle of long SMEMs with few occurrences */
+				if (k >= old_n) { x = 0; state = opt.max_mem_intv > 0 ? SM_P3 : SM_OUT; break; }
+				{
+					const ssg_intv_t m = mem[k];
+					const int start = (int)(m.info >> 32), end = (int)(uint32_t)m.info;
+					if (end - start < split_len || m.x2 > (uint64_t)opt.split_width) { ++k; break; }
+					sx = (start + end) >> 1; min_intv = m.x2 + 1; caller = 2; m1_n = 0; curr_n = 0; i = sx + 1;
+					if (SMQ(sx) > 3) { state = SM_RET; break; }   /* bwt_smem1a returns at once on an ambiguous base */
+					ssg_set_intv(ix, SMQ(sx), ik); ik.info = (uint64_t)(sx + 1);
+					state = SM_FWD;
+				}
+				break;
+			case SM_P3: /* upstream bwt_seed_strategy1 from every position */
+				if (x >= len) state = SM_OUT;
+				else if (SMQ(x) > 3) ++x;
+				else { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; }
+				break;
+			case SM_P3F:
+				if (i < len) {
+					if (SMQ(i) < 4) { pend = SM_PEND_P3; e_c = 3 - SMQ(i); }
+					else { x = i + 1; state = SM_P3; }
+				} else { x = len; state = SM_P3; }
+				break;
+			case SM_OUT:
+				if (QW) out_n[it] = ovf ? -1 : mem_n;
+				state = SM_READ;
+				break;
+			}
+		}
+		if (state == SM_FIN) break;
+		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
+		ssg_wave_ldssync();   /* list entries stored by lane 0 of the quad last iteration are read by all four below (same wave: in order on the GPU) */
+		const ssg_intv_t *const prev = flip ? vec0 : vec1;
+		const int back = pend == SM_PEND_BWD;
+		const int jn = back && j + 1 < prev_n ? j + 1 : 0;
+		const ssg_intv_t pf = SMV(prev, jn ? (prev_rev ? prev_n - 1 - jn : jn) : 0);   /* always a valid slot; used only if j+1 < prev_n */
+		const ssg_intv_t okc = ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql);
+		++my_nx;
+		{
+			ssg_intv_t *const curr = flip ? vec1 : vec0;
+			if (pend == SM_PEND_FWD) {
+				if (okc.x2 != ik.x2) {
+					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ik; } else ovf = 1;
+					++curr_n;
+					if (okc.x2 < min_intv) { state = SM_FWDEND; pend = SM_PEND_NONE; continue; }   /* break: ik stays the last pushed */
+				}
+				ik = okc; ik.info = (uint64_t)(i + 1); ++i;
+			} else if (back) {
+				pn = pf;
+				if (okc.x2 < min_intv) {
+					if (curr_n == 0 && (m1_n == 0 || i + 1 < m1_last_beg)) {
+						++m1_n; m1_last_beg = i + 1;
+						if ((int)(uint32_t)p.info - (i + 1) >= opt.min_seed_len) {
+							ssg_intv_t o = p; o.info |= (uint64_t)(i + 1) << 32;
+							if (mem_n < cap) { if (QW) mem[mem_n] = o; } else ovf = 1;
+							++mem_n;
+						}
+					}
+				} else if (curr_n == 0 || okc.x2 != last_x2) {
+					ssg_intv_t o = okc; o.info = p.info;
+					if (curr_n == 0) c0 = o;
+					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = o; } else ovf = 1;
+					++curr_n; last_x2 = okc.x2;
+				}
+				++j;
+			} else { /* SM_PEND_P3 */
+				if (okc.x2 < (uint64_t)opt.max_mem_intv && i - x >= opt.min_seed_len) {
+					if (okc.x2 > 0) {
+						ssg_intv_t o = okc; o.info = (uint64_t)x << 32 | (uint64_t)(i + 1);
+						if (mem_n < cap) { if (QW) mem[mem_n] = o; } else ovf = 1;
+						++mem_n;
+					}
+					x = i + 1; state = SM_P3;
+				} else { ik = okc; ++i; }
+			}
+			pend = SM_PEND_NONE;
+		}
+	}
+#undef SMQ
+#undef SMV
+#undef QW
+	if (n_extend && my_nx && ql == 0) atomicAdd(n_extend, my_nx);
+}
+
+/* one lane per read: intervals by (start,end), upstream's ks_introsort(mem_intv) */
+__global__ void __launch_bounds__(64) ssg_k_smem_sort(int n_reads, ssg_intv_t *intv, const int32_t *n_intv, int cap)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const int n = n_intv[r];
+	if (n > 1 && n <= cap) ssg_introsort(intv + r * cap, (long)n, ssg_intv_lt());
 }
 
 /* number of sampled occurrences of one interval (upstream mem_chain: step/count rule) */

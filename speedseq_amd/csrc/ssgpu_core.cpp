@@ -3,7 +3,7 @@
  * Compiled by hipcc for gfx950 (product) or by g++ with -DSSG_EMU against tests/emu (CPU tests).
  *
  * Stage order for a batch of reads (all intermediates stay in HBM):
- *   ssg_k_smem -> ssg_k_sal_count -> [prefix sum] -> ssg_k_sal -> ssg_k_chain -> ssg_k_chain2aln
+ *   ssg_k_smem_quad -> ssg_k_smem_sort -> ssg_k_sal_count -> [prefix sum] -> ssg_k_sal -> ssg_k_chain -> ssg_k_chain2aln
  * Per-read variable-length outputs are placed by prefix sums over per-read counts; fixed-capacity
  * stages report overflow and the affected reads are re-run with a larger capacity -- nothing is
  * dropped silently and nothing falls back to the CPU.
@@ -275,17 +275,20 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
                     int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0)
 {
 	const int block = 64;
-	long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * 1024);
+	const bool quad = !(getenv("SSG_SMEM_KERNEL") && !strcmp(getenv("SSG_SMEM_KERNEL"), "lane"));
+	const int per_read = quad ? 4 : 1;   /* lanes per read */
+	long nthreads = std::min<long>(((long)n_reads * per_read + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64);
 	int scap = max_len + 2;
-	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap);
+	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap / per_read + 64);
 	CHKA(scratch);
-	SSG_LAUNCH(ssg_k_smem, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
+	if (quad) SSG_LAUNCH(ssg_k_smem_quad, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
+	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
 	std::vector<int32_t> hn(n_reads);
 	CHK(rt_d2h(hn.data(), d_n, (size_t)n_reads * 4));
 	std::vector<int32_t> ovf;
 	for (int r = 0; r < n_reads; ++r) if (hn[r] < 0) ovf.push_back(r);
-	if (ovf.empty()) return 0;
+	if (ovf.empty()) { if (quad) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; }
 	/* slow path: worst case is O(len^2) intervals in theory; len*8 has never been observed to overflow */
 	int bigcap = max_len * 8 + 64, no = (int)ovf.size();
 	dbuf<int32_t> d_ids(no), d_n2(no); dbuf<ssg_intv_t> d_big((size_t)no * bigcap);
@@ -294,7 +297,7 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	long nt2 = ((long)no + block - 1) / block * block;
 	dbuf<ssg_intv_t> scratch2((size_t)nt2 * 3 * bigcap);
 	CHKA(scratch2);
-	SSG_LAUNCH(ssg_k_smem, nt2 / block, block, 0, idx->v, *opt, no, d_ids.p, d_seq, d_off, d_big.p, d_n2.p, bigcap, scratch2.p, bigcap, n_extend);
+	SSG_LAUNCH(ssg_k_smem_lane, nt2 / block, block, 0, idx->v, *opt, no, d_ids.p, d_seq, d_off, d_big.p, d_n2.p, bigcap, scratch2.p, bigcap, n_extend);
 	CHK(rt_sync());
 	std::vector<int32_t> hn2(no);
 	CHK(d_n2.down(hn2.data(), no));
@@ -305,6 +308,7 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 		CHK(rt_h2d(d_intv + (size_t)ovf[i] * cap, tmp.data(), (size_t)hn2[i] * sizeof(ssg_intv_t)));
 		CHK(rt_h2d(d_n + ovf[i], &hn2[i], 4));
 	}
+	if (quad) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap);
 	return 0;
 }
 
