@@ -189,10 +189,5 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 		c.first_seed = (int)(s0 + start);
 	}
 	n_chain[r] = n_out;
-	if (SSG_TUNING && dbg_phase < 0) { /* tuning: per-lane phase cycles (insert, sort, weight, filter, flatten) and chain-count moments */
-		ph[4] = ssg_clock() - t0;
-		for (k = 0; k < 5; ++k) atomicAdd(&ssg_dbg_cyc[8 + k], ph[k]);
-		atomicAdd(&ssg_dbg_cyc[13], (unsigned long long)nc); atomicAdd(&ssg_dbg_cyc[14], (unsigned long long)nc * nc); atomicAdd(&ssg_dbg_cyc[15], (unsigned long long)n_out);
-	}
 }
 #endif

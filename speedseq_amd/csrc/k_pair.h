@@ -217,12 +217,35 @@ struct ssg_reg_hash_lt {
 	{ return (a.score > b.score) | ((a.score == b.score) & (a.hash < b.hash)); } /* branch-free: see ssg_chain_key_lt */
 };
 
-SSG_DEVFN int ssg_mark_primary_se(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, int64_t id, int32_t *z)
+struct ssg_reg_hash_idx_lt {
+	const ssg_alnreg_t *a;
+	SSG_DEVMEM bool operator()(int32_t x, int32_t y) const
+	{ const int sx = a[x].score, sy = a[y].score; const uint64_t hx = a[x].hash, hy = a[y].hash; return (sx > sy) | ((sx == sy) & (hx < hy)); }
+};
+
+SSG_DEVFN int ssg_mark_primary_se(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, int64_t id, int32_t *z, int32_t *idx)
 {	/* upstream mem_mark_primary_se + _core (ALT-free) */
 	int i, k, tmp, zn = 0;
 	if (n == 0) return 0;
 	for (i = 0; i < n; ++i) { a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = ssg_hash64((uint64_t)(id + i)); }
-	ssg_introsort(a, (long)n, ssg_reg_hash_lt());
+	if (n <= 4) ssg_introsort(a, (long)n, ssg_reg_hash_lt());
+	else {	/* (score, hash) keys are distinct (hash_64 is a bijection): sort 4-byte indices, then move each 88-byte record once */
+		for (i = 0; i < n; ++i) idx[i] = i;
+		ssg_reg_hash_idx_lt lt = { a };
+		ssg_introsort(idx, (long)n, lt);
+		for (int s0 = 0; s0 < n; ++s0) {
+			if (idx[s0] < 0 || idx[s0] == s0) continue;
+			const ssg_alnreg_t t = a[s0];
+			int cur = s0;
+			for (;;) {
+				const int src = idx[cur];
+				idx[cur] = -1 - src;
+				if (src == s0) { a[cur] = t; break; }
+				a[cur] = a[src];
+				cur = src;
+			}
+		}
+	}
 	tmp = opt.a + opt.b;
 	tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
 	tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;
@@ -369,8 +392,10 @@ __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_
 		int n_pri[2], z[2] = {0, 0}, o = 0, subo = 0, n_sub = 0, extra_flag = 1, myerr = 0, i, j;
 		ssg_alnreq_t *rq[2] = { req + req_off[2*p], req + req_off[2*p+1] };
 		int nrq[2] = {0, 0};
-		n_pri[0] = ssg_mark_primary_se(opt, an[0], a[0], id << 1 | 0, z0);
-		n_pri[1] = ssg_mark_primary_se(opt, an[1], a[1], id << 1 | 1, z0);
+		unsigned long long tq0 = ssg_clock(), tq1;
+		n_pri[0] = ssg_mark_primary_se(opt, an[0], a[0], id << 1 | 0, z0, (int32_t*)v);
+		n_pri[1] = ssg_mark_primary_se(opt, an[1], a[1], id << 1 | 1, z0, (int32_t*)v);
+		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[8], tq1 - tq0); tq0 = tq1; }
 		bool paired = false;
 		int q_se[2] = {0, 0};
 		if (n_pri[0] && n_pri[1] && (o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, u, ucap, &myerr)) > 0) {
@@ -418,6 +443,7 @@ __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_
 				}
 			}
 		}
+		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[9], tq1 - tq0); tq0 = tq1; }
 		if (!paired) { /* upstream no_pairing: */
 			int hrid[2] = { -1, -1 };
 			for (i = 0; i < 2; ++i) if (an[i] && a[i][0].score >= opt.T) hrid[i] = a[i][0].rid;
@@ -447,6 +473,7 @@ __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_
 				}
 			}
 		}
+		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[10], tq1 - tq0); tq0 = tq1; }
 		for (i = 0; i < 2; ++i) { /* XA entries (upstream mem_gen_alt): count per primary, then emit for the main records */
 			int32_t *cnt = z0; /* reuse */
 			int nmain = nrq[i], tot = 0;
@@ -470,6 +497,7 @@ __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_
 			n_req[2*p + i] = nrq[i];
 		}
 		if (myerr) err[p] = myerr;
+		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[11], tq1 - tq0); atomicAdd(&ssg_dbg_cyc[12], (unsigned long long)(an[0] + an[1]) * (an[0] + an[1])); }
 	}
 }
 #endif

@@ -16,9 +16,10 @@ out = (C.c_ulonglong * 24)()
 lib.l.ssg_dbg_cycles(out)
 t = list(out)
 print("matesw: fetch=%d sw=%d resort=%d rows=%d wave_total=%d" % tuple(t[:5]))
-print("chain (lane cycles): insert=%d sort=%d weight=%d filter=%d flatten=%d | sum nc=%d sum nc^2=%d sum kept=%d" % tuple(t[8:16]))
-s = max(1, sum(t[8:13]))
-print("chain fractions: insert %.3f sort %.3f weight %.3f filter %.3f flatten %.3f" % tuple(x / s for x in t[8:13]))
+print("pair_final (lane cycles): mark_primary=%d mem_pair+mapq=%d no_pairing=%d xa=%d | sum (n0+n1)^2=%d" % tuple(t[8:13]))
+s = max(1, sum(t[8:12]))
+print("pair_final fractions: mark_primary %.3f mem_pair %.3f no_pairing %.3f xa %.3f" % tuple(x / s for x in t[8:12]))
+print("matesw resort by n_in: <=8 %.2f  9..64 %.2f  >64 %.2f (of resort); resort/total %.2f sw/total %.2f" % (t[5]/max(1,t[2]), t[6]/max(1,t[2]), t[7]/max(1,t[2]), t[2]/max(1,t[4]), t[1]/max(1,t[4])))
 print("chain2aln (wave cycles): window+seedsort=%d contain=%d extend=%d resort=%d wave_total=%d | chains=%d ext_seeds=%d regions=%d" % tuple(t[16:24]))
 s = max(1, t[20])
 print("chain2aln fractions of wave time: window %.3f contain %.3f extend %.3f resort %.3f" % tuple(x / s for x in t[16:20]))
