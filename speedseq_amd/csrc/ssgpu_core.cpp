@@ -461,7 +461,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	std::vector<int32_t> herr(n_reads);
 	CHK(d_err.down(herr.data(), n_reads));
 	for (int r = 0; r < n_reads; ++r) if (herr[r]) { ssg_err_msg = "reference window of a chain exceeds SSG_TWIN_GLB"; return SSG_EOVERFLOW; }
-	if (stats) { unsigned long long c; CHK(d_cells.down(&c, 1)); stats[0] = (uint64_t)tot; stats[1] = c; }
+	if (stats) { unsigned long long c; CHK(d_cells.down(&c, 1)); stats[0] = (uint64_t)tot; stats[1] = c; stats[6] = (uint64_t)n_jobs; }
 	return 0;
 }
 
@@ -803,6 +803,7 @@ int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pair
 	uint64_t nd = 0; for (int p = 0; p < n_pairs; ++p) nd += hd[p];
 	if (dup_host) memcpy(dup_host, hd.data(), n_pairs);
 	summary[0] = res.stats[4]; summary[1] = nd; summary[2] = res.stats[0]; summary[3] = res.stats[1]; summary[4] = res.stats[2]; summary[5] = res.stats[3];
+	summary[7] = res.stats[6]; /* chains = first-seed extensions */
 	summary[6] = res.stats[5]; /* bwt_extend calls in the SMEM kernel (2 rank queries = 2 x 64-byte lines each) */
 	return 0;
 }
