@@ -65,8 +65,8 @@ __global__ void ssg_k_pestat_hist(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_
 SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const ssg_pestat_t *pes, const ssg_alnreg_t a,
                         int l_ms, const uint8_t *ms, ssg_alnreg_t *ma, int *ma_n_, int ma_cap,
                         uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells, unsigned long long *ph,
-                        ssg_alnreg_t *sdp_tmp, ssg_sdp_lds_t *sdp_lds, ssg_sdp_big_t *sdp_big)
-{	/* upstream mem_matesw; ph[]: cycle counters per phase (fetch, SW, re-sort, window rows) */
+                        ssg_alnreg_t *sdp_tmp, ssg_sdp_lds_t *sdp_lds, ssg_sdp_big_t *sdp_big, int *ma_fixed)
+{	/* upstream mem_matesw; *ma_fixed: ma[] is the output of an earlier re-sort in this kernel (see wv_sort_dedup_incr); ph[]: cycle counters per phase (fetch, SW, re-sort, window rows) */
 	const int64_t l_pac = ix.l_pac;
 	int i, r, skip[4], n = 0, rid = -1, ma_n = *ma_n_;
 	for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
@@ -77,7 +77,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 	}
 	if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
 	for (r = 0; r < 4; ++r) {
-		int is_rev, is_larger;
+		int is_rev, is_larger, xpos_last = -1;   /* xpos_last: where this window's hit went into ma[] */
 		int64_t rb, re;
 		if (skip[r]) continue;
 		is_rev = (r >> 1 != (r & 1));
@@ -140,12 +140,21 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 					} else {
 						SSG_LANE0(for (int k2 = ma_n; k2 > t2; --k2) ma[k2] = ma[k2-1]; ma[t2] = b);
 					}
-					++ma_n;
+					++ma_n; xpos_last = t2;
 				}
 			}
 			++n;
 		}
-		if (n) { unsigned long long c1 = ssg_clock(); const int n_in = ma_n; ma_n = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2) : ma_n <= SSG_SDP_BIG ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2) : wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells); c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1; }
+		if (n) { /* upstream re-sorts after every attempted window once one was tried */
+			unsigned long long c1 = ssg_clock(); const int n_in = ma_n;
+			int m = -1;
+			if (*ma_fixed && ma_n - 1 <= SSG_SDP_BIG) m = xpos_last < 0 ? ma_n : wv_sort_dedup_incr(opt, ma_n, ma, sdp_tmp, xpos_last);
+			if (m < 0) m = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2)
+			           : ma_n <= SSG_SDP_BIG ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2)
+			           : wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells);
+			ma_n = m; *ma_fixed = 1; xpos_last = -1;
+			c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1;
+		}
 	}
 	*ma_n_ = ma_n;
 	return n;
@@ -186,6 +195,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 			if (nb[i] > 64) { nb[i] = 64; myerr = 3; }
 		}
 		if (nb[0] + nb[1] > 0) {
+			int fixed[2] = { 0, 0 };   /* a[i] has been through a re-sort of this kernel: later ones are incremental */
 			SSG_LANE0(
 				for (int i2 = 0; i2 < 2; ++i2) { int c2 = 0;
 					for (int j2 = 0; j2 < an[i2] && c2 < nb[i2]; ++j2) if (a[i2][j2].score >= a[i2][0].score - opt.pen_unpaired) bc[i2 * 64 + c2++] = a[i2][j2]; });
@@ -193,7 +203,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 				for (int j = 0; j < nb[i]; ++j) {
 					const int l_ms = (int)(read_off[2*p + !i + 1] - read_off[2*p + !i]);
 					const uint8_t *ms = seq + read_off[2*p + !i];
-					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot], sdpbig + wave0);
+					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot], sdpbig + wave0, &fixed[!i]);
 				}
 		}
 		if (wv_lane() == 0) { n_reg[2*p] = an[0]; n_reg[2*p+1] = an[1]; if (myerr) err[p] = myerr; }

@@ -130,4 +130,107 @@ SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *
 	return m;
 }
 
+/* 64-bit wave max (every lane gets the result) */
+SSG_DEVFN int64_t wv_max64(int64_t v)
+{
+	for (int d = 1; d < 64; d <<= 1) { const int64_t o = (int64_t)wv_shfl64_xor(v, d); v = v > o ? v : o; }
+	return v;
+}
+
+/*
+ * mem_sort_dedup_patch (no patching) when a[] is the OUTPUT of a previous such call with ONE new region x
+ * inserted at a[xpos] -- mem_matesw's situation from its second rescue on.  The previous output is a fixed
+ * point of the redundancy scan (every surviving pair inside the chain-gap window was compared and kept),
+ * so only pairs with x can change anything, and the scan's verdicts on them follow from values alone:
+ *   - x against the regions that end before it (same contig, x.rb < y.re + gap), in descending y.re:
+ *     a redundant y with score <= x.score is dropped, the first one with a larger score drops x and stops;
+ *   - if x lived, the regions that end after it (y.rb < x.re + gap), in ascending y.re: a redundant y with
+ *     score < x.score is dropped, the first one with score >= x.score drops x.
+ * Survivors keep their (score, rb, qb) order and x goes to its rank in it.  Whenever the outcome would depend
+ * on the order of equal keys (x ties an old region on `re' or on (score, rb, qb), or a dropped candidate
+ * ties the stopping region on `re'), -1 is returned with a[] untouched and the caller runs the full sort.
+ */
+SSG_DEVFN int wv_sort_dedup_incr(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, ssg_alnreg_t *tmp, int xpos)
+{
+	const int lane = wv_lane();
+	ssg_wave_memsync();
+	const ssg_alnreg_t x = a[xpos];
+	const int64_t gap = opt.max_chain_gap;
+	const int64_t NONE_LO = INT64_MIN, NONE_HI = INT64_MAX;
+	int tie = 0;
+	int64_t ystar = NONE_LO, ycirc = NONE_HI;   /* case 1: largest re that drops x; case 2: smallest re that drops x */
+	for (int i = lane; i < n; i += 64) {
+		if (i == xpos) continue;
+		const ssg_alnreg_t *y = &a[i];
+		const int64_t yre = y->re, yrb = y->rb; const int yqb = y->qb, yqe = y->qe, ysc = y->score;
+		if (yre == x.re) tie = 1;
+		if (ysc == x.score && yrb == x.rb && yqb == x.qb) tie = 1;
+		if (y->rid != x.rid) continue;
+		if (yre < x.re) { /* p = x, q = y */
+			if (x.rb < yre + gap) {
+				const int64_t or_ = yre - x.rb, oq = yqb < x.qb ? yqe - x.qb : x.qe - yqb;
+				const int64_t mr = yre - yrb < x.re - x.rb ? yre - yrb : x.re - x.rb, mq = yqe - yqb < x.qe - x.qb ? yqe - yqb : x.qe - x.qb;
+				if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq && x.score < ysc) ystar = ystar > yre ? ystar : yre;
+			}
+		} else { /* p = y, q = x */
+			if (yrb < x.re + gap) {
+				const int64_t or_ = x.re - yrb, oq = x.qb < yqb ? x.qe - yqb : yqe - x.qb;
+				const int64_t mr = x.re - x.rb < yre - yrb ? x.re - x.rb : yre - yrb, mq = x.qe - x.qb < yqe - yqb ? x.qe - x.qb : yqe - yqb;
+				if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq && !(ysc < x.score)) ycirc = ycirc < yre ? ycirc : yre;
+			}
+		}
+	}
+	if (wv_ballot(tie)) return -1;
+	ystar = wv_max64(ystar); ycirc = -wv_max64(-ycirc);
+	const bool x_dead1 = ystar != NONE_LO, x_dead = x_dead1 || ycirc != NONE_HI;
+	/* second pass: who is dropped, and the new positions */
+	int base = 0, bad = 0, x_rank = 0;
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		const int i = i0 + lane;
+		int alive = 0;
+		ssg_alnreg_t r;
+		if (i < n) {
+			r = a[i];
+			if (i == xpos) alive = !x_dead;
+			else {
+				alive = 1;
+				if (r.rid == x.rid) {
+					if (r.re < x.re) {
+						if (x.rb < r.re + gap) {
+							const int64_t or_ = r.re - x.rb, oq = r.qb < x.qb ? r.qe - x.qb : x.qe - r.qb;
+							const int64_t mr = r.re - r.rb < x.re - x.rb ? r.re - r.rb : x.re - x.rb, mq = r.qe - r.qb < x.qe - x.qb ? r.qe - r.qb : x.qe - x.qb;
+							if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq && !(x.score < r.score)) {
+								if (!x_dead1 || r.re > ystar) alive = 0;
+								else if (r.re == ystar) bad = 1;
+							}
+						}
+					} else if (!x_dead1) {
+						if (r.rb < x.re + gap) {
+							const int64_t or_ = x.re - r.rb, oq = x.qb < r.qb ? x.qe - r.qb : r.qe - x.qb;
+							const int64_t mr = x.re - x.rb < r.re - r.rb ? x.re - x.rb : r.re - r.rb, mq = x.qe - x.qb < r.qe - r.qb ? x.qe - x.qb : r.qe - r.qb;
+							if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq && r.score < x.score) {
+								if (ycirc == NONE_HI || r.re < ycirc) alive = 0;
+								else if (r.re == ycirc) bad = 1;
+							}
+						}
+					}
+				}
+			}
+		}
+		/* survivors keep their (score, rb, qb) order; x (put behind all regions of >= score by mem_matesw) moves to its rank */
+		const int old_alive = alive && i != xpos;
+		const int before_x = old_alive && ((r.score > x.score) | ((r.score == x.score) & ((r.rb < x.rb) | ((r.rb == x.rb) & (r.qb < x.qb)))));
+		const unsigned long long bal = wv_ballot(old_alive);
+		if (old_alive) { r.n_comp = 1; tmp[base + wv_rank_of(bal) + (!x_dead && !before_x)] = r; }
+		base += __popcll(bal);
+		x_rank += __popcll(wv_ballot(before_x));
+	}
+	if (wv_ballot(bad)) return -1;
+	if (!x_dead) { SSG_LANE0(ssg_alnreg_t t = x; t.n_comp = 1; tmp[x_rank] = t); ++base; }
+	ssg_wave_memsync();
+	for (int k = lane; k < base; k += 64) a[k] = tmp[k];
+	ssg_wave_memsync();
+	return base;
+}
+
 #endif

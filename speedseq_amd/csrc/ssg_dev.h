@@ -142,6 +142,12 @@ SSG_DEVFN long long wv_bcast64(long long v, int src)
 	int lo = wv_shfl((int)(unsigned)(unsigned long long)v, src), hi = wv_shfl((int)((unsigned long long)v >> 32), src);
 	return (long long)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
 }
+SSG_DEVFN long long wv_shfl64_xor(long long v, int d)
+{
+	const int src = wv_lane() ^ d;
+	int lo = wv_shfl((int)(unsigned)(unsigned long long)v, src), hi = wv_shfl((int)((unsigned long long)v >> 32), src);
+	return (long long)((unsigned long long)(unsigned)lo | (unsigned long long)(unsigned)hi << 32);
+}
 SSG_DEVFN long long wv_get64(long long v, int src)
 {	/* src wave-uniform: two v_readlane */
 	int lo = wv_get((int)(unsigned)(unsigned long long)v, src), hi = wv_get((int)((unsigned long long)v >> 32), src);

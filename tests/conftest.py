@@ -56,3 +56,11 @@ def gpu_lib():
 def repeat_prefix(oracle, tmp_path_factory):
     import common
     return common.repeat_reference(oracle, tmp_path_factory.mktemp("repeats"))
+
+
+@pytest.fixture(scope="session")
+def repeat_pe_prefix(oracle, tmp_path_factory):
+    """Repeat families inside enough unique sequence for the insert-size model to succeed: mate rescue then
+    runs against region lists of hundreds of entries (incremental re-sort path)."""
+    import common
+    return common.repeat_reference(oracle, tmp_path_factory.mktemp("repeats_pe"), unique=300000)

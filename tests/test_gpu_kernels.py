@@ -90,3 +90,8 @@ def test_gpu_repeats_align1(gpu_lib, oracle, repeat_prefix, monkeypatch):
 def test_gpu_repeats_pe_sam(gpu_lib, oracle, repeat_prefix):
     text, stats = common.check_pe_sam(gpu_lib, oracle, 300, seed=23, prefix=repeat_prefix)
     assert "XA:Z:" in text
+
+
+def test_gpu_repeats_mate_rescue(gpu_lib, oracle, repeat_pe_prefix):
+    text, stats = common.check_pe_sam(gpu_lib, oracle, 1500, seed=5, prefix=repeat_pe_prefix)
+    assert stats[3] > 10000   # rescues

@@ -78,3 +78,8 @@ def test_emu_repeats_align1(emu_lib, oracle, repeat_prefix, monkeypatch):
 def test_emu_repeats_pe_sam(emu_lib, oracle, repeat_prefix):
     text, stats = common.check_pe_sam(emu_lib, oracle, 10, seed=23, prefix=repeat_prefix)
     assert "XA:Z:" in text
+
+
+def test_emu_repeats_mate_rescue(emu_lib, oracle, repeat_pe_prefix):
+    text, stats = common.check_pe_sam(emu_lib, oracle, 250, seed=5, prefix=repeat_pe_prefix)
+    assert stats[3] > 1000   # rescues
