@@ -40,7 +40,7 @@ SSG_DEVFN int ssg_cal_max_gap2(const ssg_mem_opt_t &opt, int qlen)
 /* one lane per surviving chain g (global numbering: chain_off[r] + position in the read's order[]) */
 __global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, long n_jobs, const int64_t *read_off,
                                const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
-                               const int32_t *chain_seeds, const int32_t *chain_off, int twin_cap,
+                               const int32_t *chain_seeds, const int64_t *chain_off, int twin_cap,
                                ssg_xjob_t *jobs, uint64_t *key_l, uint64_t *key_r)
 {
 	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -92,4 +92,31 @@ __global__ void ssg_k_gather_sig(long n, const uint32_t *ord_sorted, const ssg_s
 	long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) out[i] = sig[ord_sorted[i]];
 }
+
+/* ---------------- small device-side bookkeeping (keeps counts, offsets and work orders off the host) ---------------- */
+__global__ void ssg_k_iota(int32_t *a, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = (int32_t)i; }
+__global__ void ssg_k_scan_tail(const int32_t *in, int64_t *out, long n) { if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = n > 0 ? out[n-1] + in[n-1] : 0; }
+/* cnt[0] = #(key > tC), cnt[1] = #(tB < key <= tC), cnt[2] = #(max(tA,1) <= key <= tB), cnt[3] = #(key < 0), cnt[4] = #(key != 0) */
+__global__ void ssg_k_class_counts(const int32_t *key, long n, int tA, int tB, int tC, unsigned int *cnt)
+{	/* one atomic per wave and class */
+	const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int k = i < n ? key[i] : 0;
+	const unsigned long long b0 = wv_ballot(k > tC), b1 = wv_ballot(k <= tC && k > tB), b2 = wv_ballot(k <= tB && k >= tA && k > 0), b3 = wv_ballot(k < 0), b4 = wv_ballot(k != 0);
+	if (wv_lane() == 0) {
+		if (b0) atomicAdd(&cnt[0], (unsigned)__popcll(b0));
+		if (b1) atomicAdd(&cnt[1], (unsigned)__popcll(b1));
+		if (b2) atomicAdd(&cnt[2], (unsigned)__popcll(b2));
+		if (b3) atomicAdd(&cnt[3], (unsigned)__popcll(b3));
+		if (b4) atomicAdd(&cnt[4], (unsigned)__popcll(b4));
+	}
+}
+/* pairing-stage capacities per read: region slots (own regions + up to 4 rescued hits per anchor of the mate) and request slots */
+__global__ void ssg_k_pair_caps(int n_reads, const int32_t *n_reg, int max_matesw, int32_t *cap2, int32_t *capq, int32_t *pair_key)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const int m = n_reg[r ^ 1], c = n_reg[r] + 4 * (m < max_matesw ? m : max_matesw) + 4;
+	cap2[r] = c; capq[r] = 2 * c + 2;
+	if (!(r & 1)) pair_key[r >> 1] = n_reg[r] + n_reg[r + 1];
+}
 #endif

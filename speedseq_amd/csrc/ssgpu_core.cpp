@@ -17,6 +17,8 @@
 #include "k_chainw.h"
 #include "k_extend.h"
 #include "k_swjobs.h"
+#include "k_aln.h"
+#include "k_misc.h"
 #include "../../include/ssgpu.h"
 #ifndef SSG_EMU
 #include <hipcub/hipcub.hpp>
@@ -271,6 +273,7 @@ struct seed_stage_t {
 
 /* runs the SMEM kernel for all reads (cap0 per read), then re-runs overflowing reads with a
  * private large capacity and copies their lists back; on return every n_intv[r] >= 0. */
+static int dev_class_counts(const int32_t *d_key, long n, int tA, int tB, int tC, unsigned int out[5]);
 static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                     int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0)
 {
@@ -284,6 +287,8 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	if (quad) SSG_LAUNCH(ssg_k_smem_quad, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
+	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));
+	  if (!cc[3]) { if (quad) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; } }
 	std::vector<int32_t> hn(n_reads);
 	CHK(rt_d2h(hn.data(), d_n, (size_t)n_reads * 4));
 	std::vector<int32_t> ovf;
@@ -358,6 +363,57 @@ static int sort_keys_u64(uint64_t *k_in, uint64_t *k_out, long n, int begin_bit,
 #endif
 }
 
+/* exclusive prefix sum of n int32 counts into n+1 int64 offsets, on the device; *total = out[n] */
+struct ssg_to_i64 { SSG_DEVMEM int64_t operator()(int32_t v) const { return (int64_t)v; } };
+static int dev_exclusive_scan(const int32_t *d_in, int64_t *d_out, long n, int64_t *total)
+{
+	if (n <= 0) { int64_t z = 0; CHK(rt_h2d(d_out, &z, 8)); *total = 0; return 0; }
+#ifdef SSG_EMU
+	int64_t t = 0; for (long i = 0; i < n; ++i) { d_out[i] = t; t += d_in[i]; } d_out[n] = t; *total = t;
+	return 0;
+#else
+	hipcub::TransformInputIterator<int64_t, ssg_to_i64, const int32_t*> it(d_in, ssg_to_i64());
+	size_t tmp_bytes = 0;
+	if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, it, d_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum (size query) failed"; return SSG_EHIP; }
+	dbuf<uint8_t> tmp(tmp_bytes + 16);
+	CHKA(tmp);
+	if (hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, it, d_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum failed"; return SSG_EHIP; }
+	SSG_LAUNCH(ssg_k_scan_tail, 1, 64, 0, d_in, d_out, n);
+	return rt_d2h(total, d_out + n, 8);
+#endif
+}
+
+/* order[] = indices 0..n-1 by descending key (heaviest-first work lists), on the device */
+static int dev_order_desc(const int32_t *d_key, int32_t *d_order, long n)
+{
+	if (n <= 0) return 0;
+#ifdef SSG_EMU
+	std::vector<int32_t> key(d_key, d_key + n), ord;
+	order_desc(key, ord);
+	memcpy(d_order, ord.data(), (size_t)n * 4);
+	return 0;
+#else
+	dbuf<int32_t> iota(n), kout(n);
+	CHKA(iota); CHKA(kout);
+	SSG_LAUNCH(ssg_k_iota, (n + 255) / 256, 256, 0, iota.p, n);
+	size_t tmp_bytes = 0;
+	if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_key, kout.p, iota.p, d_order, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairsDescending (size query) failed"; return SSG_EHIP; }
+	dbuf<uint8_t> tmp(tmp_bytes + 16);
+	CHKA(tmp);
+	if (hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tmp_bytes, d_key, kout.p, iota.p, d_order, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairsDescending failed"; return SSG_EHIP; }
+	return rt_sync();   /* the temporaries are released on return */
+#endif
+}
+
+/* class counts of a device int32 array (ssg_k_class_counts) brought to the host */
+static int dev_class_counts(const int32_t *d_key, long n, int tA, int tB, int tC, unsigned int out[5])
+{
+	dbuf<unsigned int> d_c(8);
+	CHKA(d_c); CHK(d_c.zero());
+	if (n > 0) SSG_LAUNCH(ssg_k_class_counts, (n + 255) / 256, 256, 0, d_key, n, tA, tB, tC, d_c.p);
+	return d_c.down(out, 5);
+}
+
 /* ------------------------------- mem_align1_core for a batch ------------------------------- */
 struct align1_dev_t {	/* device-resident result of stages 1-4 */
 	dbuf<int64_t> seed_off; dbuf<ssg_alnreg_t> regs; dbuf<int32_t> n_reg;
@@ -379,14 +435,10 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	SSG_LAUNCH(ssg_k_sal_count, (n_reads + block - 1) / block, block, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);
 	CHK(rt_sync());
 	STAGE("sal_count");
-	std::vector<int32_t> hns(n_reads);
-	CHK(d_nseed.down(hns.data(), n_reads));
-	o.h_seed_off.resize(n_reads + 1);
 	int64_t tot = 0;
-	for (int r = 0; r < n_reads; ++r) { o.h_seed_off[r] = tot; tot += hns[r]; }
-	o.h_seed_off[n_reads] = tot; o.tot_seeds = tot;
 	if (!o.seed_off.alloc(n_reads + 1)) { ssg_err_msg = "device allocation failed: seed_off"; return SSG_ENOMEM; }
-	CHK(o.seed_off.up(o.h_seed_off.data(), n_reads + 1));
+	CHK(dev_exclusive_scan(d_nseed.p, o.seed_off.p, n_reads, &tot));
+	o.tot_seeds = tot; o.h_seed_off.clear();
 	size_t ts = (size_t)tot + 1;
 	dbuf<ssg_seed_t> d_seeds(ts); dbuf<int32_t> d_srid(ts), d_order(ts), d_kept(ts), d_cseeds(ts), d_nchain(n_reads), d_err(n_reads);
 	dbuf<ssg_chain_t> d_chains(ts); dbuf<uint64_t> d_srt(ts); dbuf<unsigned long long> d_cells(1);
@@ -399,21 +451,22 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	}
 	STAGE("sal");
 	/* heaviest-first work order (seed count): the per-read cost of chaining / extension is heavy-tailed */
-	std::vector<int32_t> h_work;
-	order_desc(hns, h_work);
+	dbuf<int32_t> d_work(n_reads); dbuf<unsigned int> d_queue(4);
+	CHKA(d_work); CHKA(d_queue);
+	CHK(dev_order_desc(d_nseed.p, d_work.p, n_reads)); CHK(d_queue.zero());
 	if (ssg_debug() >= 2) { /* tuning: seeds-per-read histogram (power-of-two bins) */
+		std::vector<int32_t> hns(n_reads);
+		CHK(d_nseed.down(hns.data(), n_reads));
 		long cnt[20] = {0}, sum[20] = {0};
 		for (int r = 0; r < n_reads; ++r) { int b = 0; while ((1 << b) <= hns[r] && b < 19) ++b; ++cnt[b]; sum[b] += hns[r]; }
 		for (int b = 0; b < 20; ++b) if (cnt[b]) fprintf(stderr, "[ssg] seeds/read < %d: %ld reads, %ld seeds\n", 1 << b, cnt[b], sum[b]);
 	}
-	dbuf<int32_t> d_work(n_reads); dbuf<unsigned int> d_queue(4);
-	CHKA(d_work); CHKA(d_queue);
-	CHK(d_work.up(h_work.data(), n_reads)); CHK(d_queue.zero());
-	{	/* h_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), [nC,nC+nB) one wave per read with
+	{	/* d_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), [nC,nC+nB) one wave per read with
 		 * 4096-chain LDS state, the next nA with 1024-chain state, the light rest one lane per read */
 		const int T = env_int("SSG_CHAIN_WAVE_MIN", 64), TB = env_int("SSG_CHAIN_WAVE_BIG", 1024);
-		int nC = 0, nB = 0, nA = 0;
-		for (int r = 0; r < n_reads; ++r) { const int s = hns[r]; if (s > 4096) ++nC; else if (s > TB) ++nB; else if (s >= T && s > 0) ++nA; }
+		unsigned int cc[5];
+		CHK(dev_class_counts(d_nseed.p, n_reads, T, TB, 4096, cc));
+		const int nC = (int)cc[0], nB = (int)cc[1], nA = (int)cc[2];
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
 		if (nC) SSG_LAUNCH(ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
@@ -427,15 +480,15 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
-	std::vector<int32_t> h_nch(n_reads), h_choff((size_t)n_reads + 1);
-	CHK(d_nchain.down(h_nch.data(), n_reads));
-	{ int64_t t = 0; for (int r = 0; r < n_reads; ++r) { h_choff[r] = (int32_t)t; t += h_nch[r]; } h_choff[n_reads] = (int32_t)t;
-	  if (t >= (int64_t)1 << 31) { ssg_err_msg = "more than 2^31 chains in one call"; return SSG_EOVERFLOW; } }
-	const long n_jobs = h_choff[n_reads];
-	dbuf<int32_t> d_choff((size_t)n_reads + 1); dbuf<ssg_xjob_t> d_xjobs((size_t)n_jobs + 1); dbuf<ssg_xres_t> d_xl((size_t)n_jobs + 1), d_xr((size_t)n_jobs + 1);
+	dbuf<int64_t> d_choff((size_t)n_reads + 1);
+	CHKA(d_choff);
+	int64_t n_jobs64 = 0;
+	CHK(dev_exclusive_scan(d_nchain.p, d_choff.p, n_reads, &n_jobs64));
+	if (n_jobs64 >= (int64_t)1 << 31) { ssg_err_msg = "more than 2^31 chains in one call"; return SSG_EOVERFLOW; }
+	const long n_jobs = (long)n_jobs64;
+	dbuf<ssg_xjob_t> d_xjobs((size_t)n_jobs + 1); dbuf<ssg_xres_t> d_xl((size_t)n_jobs + 1), d_xr((size_t)n_jobs + 1);
 	dbuf<uint64_t> d_kl((size_t)n_jobs + 1), d_kr((size_t)n_jobs + 1), d_sl((size_t)n_jobs + 1), d_sr((size_t)n_jobs + 1);
-	CHKA(d_choff); CHKA(d_xjobs); CHKA(d_xl); CHKA(d_xr); CHKA(d_kl); CHKA(d_kr); CHKA(d_sl); CHKA(d_sr);
-	CHK(d_choff.up(h_choff.data(), (size_t)n_reads + 1));
+	CHKA(d_xjobs); CHKA(d_xl); CHKA(d_xr); CHKA(d_kl); CHKA(d_kr); CHKA(d_sl); CHKA(d_sr);
 	if (n_jobs > 0) {
 		if (opt->a * 2 * max_len + 64 >= 8191) { ssg_err_msg = "match score x read length beyond the 13-bit DP cells of the extension kernel"; return SSG_EINVAL; }
 		SSG_LAUNCH(ssg_k_ext_prep, (n_jobs + 255) / 256, 256, 0, idx->v, *opt, n_reads, n_jobs, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
@@ -458,9 +511,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p);
 		CHK(rt_sync());
 	}
-	std::vector<int32_t> herr(n_reads);
-	CHK(d_err.down(herr.data(), n_reads));
-	for (int r = 0; r < n_reads; ++r) if (herr[r]) { ssg_err_msg = "reference window of a chain exceeds SSG_TWIN_GLB"; return SSG_EOVERFLOW; }
+	{ unsigned int cc[5]; CHK(dev_class_counts(d_err.p, n_reads, 0, 0, 0, cc)); if (cc[4]) { ssg_err_msg = "reference window of a chain exceeds SSG_TWIN_GLB"; return SSG_EOVERFLOW; } }
 	if (stats) { unsigned long long c; CHK(d_cells.down(&c, 1)); stats[0] = (uint64_t)tot; stats[1] = c; stats[6] = (uint64_t)n_jobs; }
 	return 0;
 }
@@ -484,6 +535,8 @@ int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_rea
 	for (int r = 0; r < n_reads; ++r) { reg_off[r] = tot; tot += hn[r]; }
 	reg_off[n_reads] = tot;
 	ssg_alnreg_t *out = (ssg_alnreg_t*)malloc(sizeof(ssg_alnreg_t) * (size_t)(tot + 1));
+	o.h_seed_off.resize((size_t)n_reads + 1);
+	CHK(o.seed_off.down(o.h_seed_off.data(), (size_t)n_reads + 1));
 	std::vector<ssg_alnreg_t> all((size_t)o.tot_seeds + 1);
 	CHK(o.regs.down(all.data(), (size_t)o.tot_seeds));
 	for (int r = 0; r < n_reads; ++r) memcpy(out + reg_off[r], all.data() + o.h_seed_off[r], sizeof(ssg_alnreg_t) * (size_t)hn[r]);
@@ -494,8 +547,6 @@ int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_rea
 } /* extern "C" */
 
 /* ======================= paired-end stage (rows a9-a12) ======================= */
-#include "k_aln.h"
-#include "k_misc.h"
 
 /* upstream mem_pestat's statistics, from the per-orientation insert-size histogram.  The sorted
  * isize array upstream walks is the histogram read in bin order, so every double-precision sum is
@@ -574,32 +625,21 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	dbuf<ssg_pestat_t> d_pes((size_t)n_batches * 4);
 	CHKA(d_pes); CHK(d_pes.up(res->pes.data(), res->pes.size()));
 	/* ---- pairing-stage region slices with head-room for rescued hits ---- */
-	std::vector<int32_t> hn(n_reads);
-	CHK(a1.n_reg.down(hn.data(), n_reads));
-	std::vector<int64_t> h_r2off(n_reads + 1), h_reqoff(n_reads + 1);
+	dbuf<int32_t> d_cap2(n_reads), d_capq(n_reads), d_pkey(n_pairs), d_pw(n_pairs);
+	dbuf<int64_t> d_r2off(n_reads + 1), d_reqoff(n_reads + 1);
+	CHKA(d_cap2); CHKA(d_capq); CHKA(d_pkey); CHKA(d_pw); CHKA(d_r2off); CHKA(d_reqoff);
+	SSG_LAUNCH(ssg_k_pair_caps, (n_reads + block - 1) / block, block, 0, n_reads, a1.n_reg.p, opt->max_matesw, d_cap2.p, d_capq.p, d_pkey.p);
 	int64_t t2 = 0, tq = 0;
-	for (int r = 0; r < n_reads; ++r) {
-		int mate = r ^ 1;
-		int cap2 = hn[r] + 4 * std::min(hn[mate], opt->max_matesw) + 4;
-		h_r2off[r] = t2; t2 += cap2;
-		h_reqoff[r] = tq; tq += 2 * cap2 + 2;
-	}
-	h_r2off[n_reads] = t2; h_reqoff[n_reads] = tq;
-	dbuf<int64_t> d_r2off(n_reads + 1), d_reqoff(n_reads + 1); dbuf<ssg_alnreg_t> d_regs2((size_t)t2 + 1); dbuf<int32_t> d_perr(n_pairs), d_zbuf((size_t)t2 + 1), d_nreq(n_reads), d_gerr(1);
+	CHK(dev_exclusive_scan(d_cap2.p, d_r2off.p, n_reads, &t2)); CHK(dev_exclusive_scan(d_capq.p, d_reqoff.p, n_reads, &tq));
+	CHK(dev_order_desc(d_pkey.p, d_pw.p, n_pairs));   /* heaviest-first pair order for the pairing-stage kernels (key: candidate regions of both ends) */
+	dbuf<ssg_alnreg_t> d_regs2((size_t)t2 + 1); dbuf<int32_t> d_perr(n_pairs), d_zbuf((size_t)t2 + 1), d_nreq(n_reads), d_gerr(1);
 	dbuf<unsigned long long> d_cnt(2);
-	CHKA(d_r2off); CHKA(d_reqoff); CHKA(d_regs2); CHKA(d_perr); CHKA(d_zbuf); CHKA(d_nreq); CHKA(d_cnt); CHKA(d_gerr);
-	CHK(d_r2off.up(h_r2off.data(), n_reads + 1)); CHK(d_reqoff.up(h_reqoff.data(), n_reads + 1)); CHK(d_perr.zero()); CHK(d_cnt.zero()); CHK(d_gerr.zero());
+	CHKA(d_regs2); CHKA(d_perr); CHKA(d_zbuf); CHKA(d_nreq); CHKA(d_cnt); CHKA(d_gerr);
+	CHK(d_perr.zero()); CHK(d_cnt.zero()); CHK(d_gerr.zero());
 	SSG_LAUNCH(ssg_k_copy_regs, (n_reads + block - 1) / block, block, 0, n_reads, a1.seed_off.p, a1.regs.p, a1.n_reg.p, d_r2off.p, d_regs2.p);
 	const int wpb = SSG_WAVES_PER_WG;
-	/* heaviest-first pair order for the pairing-stage kernels (key: candidate regions of both ends) */
-	dbuf<int32_t> d_pw(n_pairs); dbuf<unsigned int> d_q(1);
-	CHKA(d_pw); CHKA(d_q);
-	{
-		std::vector<int32_t> key(n_pairs), h_pw;
-		for (int p = 0; p < n_pairs; ++p) key[p] = hn[2*p] + hn[2*p+1];
-		order_desc(key, h_pw);
-		CHK(d_pw.up(h_pw.data(), n_pairs)); CHK(d_q.zero());
-	}
+	dbuf<unsigned int> d_q(1);
+	CHKA(d_q); CHK(d_q.zero());
 	{	/* ---- mate rescue ---- */
 		long nwg = std::min<long>(((long)n_pairs + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
 		long nw = nwg * wpb;
@@ -623,20 +663,22 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	}
 	STAGE("pair_final");
 	{
-		std::vector<int32_t> perr(n_pairs);
-		CHK(d_perr.down(perr.data(), n_pairs));
-		for (int p = 0; p < n_pairs; ++p) if (perr[p]) { char b[128]; snprintf(b, sizeof(b), "pair %d exceeded an on-device capacity (code %d)", p, perr[p]); ssg_err_msg = b; return SSG_EOVERFLOW; }
+		unsigned int cc[5];
+		CHK(dev_class_counts(d_perr.p, n_pairs, 0, 0, 0, cc));
+		if (cc[4]) {
+			std::vector<int32_t> perr(n_pairs);
+			CHK(d_perr.down(perr.data(), n_pairs));
+			for (int p = 0; p < n_pairs; ++p) if (perr[p]) { char b[128]; snprintf(b, sizeof(b), "pair %d exceeded an on-device capacity (code %d)", p, perr[p]); ssg_err_msg = b; return SSG_EOVERFLOW; }
+		}
 	}
 	/* ---- compact the requests and generate CIGAR / NM / MD ---- */
-	std::vector<int32_t> hnreq(n_reads);
-	CHK(d_nreq.down(hnreq.data(), n_reads));
-	res->req_off.resize(n_reads + 1);
+	dbuf<int64_t> d_coff(n_reads + 1);
+	CHKA(d_coff);
 	int64_t nreq = 0;
-	for (int r = 0; r < n_reads; ++r) { res->req_off[r] = nreq; nreq += hnreq[r]; }
-	res->req_off[n_reads] = nreq;
-	dbuf<int64_t> d_coff(n_reads + 1); dbuf<ssg_alnreq_t> d_creq((size_t)nreq + 1); dbuf<ssg_aln_t> d_alns((size_t)nreq + 1);
-	CHKA(d_coff); CHKA(d_creq); CHKA(d_alns);
-	CHK(d_coff.up(res->req_off.data(), n_reads + 1));
+	CHK(dev_exclusive_scan(d_nreq.p, d_coff.p, n_reads, &nreq));
+	if (!keep) { res->req_off.resize(n_reads + 1); CHK(d_coff.down(res->req_off.data(), (size_t)n_reads + 1)); }
+	dbuf<ssg_alnreq_t> d_creq((size_t)nreq + 1); dbuf<ssg_aln_t> d_alns((size_t)nreq + 1);
+	CHKA(d_creq); CHKA(d_alns);
 	SSG_LAUNCH(ssg_k_compact_req, (n_reads + block - 1) / block, block, 0, n_reads, d_reqoff.p, d_req.p, d_nreq.p, d_coff.p, d_creq.p);
 	{
 		long nwg = std::min<long>(((long)nreq + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
