@@ -384,14 +384,121 @@ SSG_DEVFN int ssg_emit_xa(const ssg_mem_opt_t &opt, const ssg_alnreg_t *a, int n
  * zbuf: int32 per region slot.  req: per-read slices [req_off[r], req_off[r+1]); n_req out.
  * XA entries carry `owner` = region index (within the read) of the main record they belong to.
  */
+/* upstream mem_sam_pe after mem_pair: the pairing / MAPQ decision and the list of records to generate.
+ * o, subo, n_sub, z[] are mem_pair's results (o = 0 when it was not run). */
+SSG_DEVFN void ssg_pair_decide(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const ssg_pestat_t *pes, const long p, ssg_alnreg_t *const a[2], const int an[2],
+                               const int n_pri[2], const int o, int subo, const int n_sub, int z[2], int32_t *z0, const int64_t *reg_off, ssg_alnreq_t *const rq[2], int32_t *n_req)
+{
+	int extra_flag = 1, i, j;
+	int nrq[2] = {0, 0};
+	bool paired = false;
+	int q_se[2] = {0, 0};
+	if (n_pri[0] && n_pri[1] && o > 0) {
+		int is_multi[2], q_pe, score_un;
+		for (i = 0; i < 2; ++i) {
+			for (j = 1; j < n_pri[i]; ++j) if (a[i][j].secondary < 0 && a[i][j].score >= opt.T) break;
+			is_multi[i] = j < n_pri[i] ? 1 : 0;
+		}
+		if (!(is_multi[0] || is_multi[1])) {
+			paired = true;
+			score_un = a[0][0].score + a[1][0].score - opt.pen_unpaired;
+			subo = subo > score_un ? subo : score_un;
+			q_pe = SSG_RAW_MAPQ(o - subo, opt.a);
+			if (n_sub > 0) q_pe -= (int)(4.343 * log((double)(n_sub + 1)) + .499);
+			if (q_pe < 0) q_pe = 0;
+			if (q_pe > 60) q_pe = 60;
+			q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
+			if (o > score_un) {
+				ssg_alnreg_t *c[2] = { &a[0][z[0]], &a[1][z[1]] };
+				for (i = 0; i < 2; ++i) {
+					if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
+					q_se[i] = ssg_approx_mapq_se(opt, *c[i]);
+				}
+				q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+				q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+				extra_flag |= 2;
+				{ int c0 = SSG_RAW_MAPQ(c[0]->score - c[0]->csub, opt.a); q_se[0] = q_se[0] < c0 ? q_se[0] : c0; }
+				{ int c1 = SSG_RAW_MAPQ(c[1]->score - c[1]->csub, opt.a); q_se[1] = q_se[1] < c1 ? q_se[1] : c1; }
+			} else {
+				z[0] = z[1] = 0;
+				q_se[0] = ssg_approx_mapq_se(opt, a[0][0]);
+				q_se[1] = ssg_approx_mapq_se(opt, a[1][0]);
+			}
+			for (i = 0; i < 2; ++i) {
+				int k = a[i][z[i]].secondary_all;
+				if (k >= 0 && k < n_pri[i]) {
+					for (j = 0; j < an[i]; ++j) if (a[i][j].secondary_all == k || j == k) a[i][j].secondary_all = z[i];
+					a[i][z[i]].secondary_all = -1;
+				}
+			}
+			for (i = 0; i < 2; ++i) {
+				ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = (int32_t)(reg_off[2*p+i] + z[i]); q.kind = SSG_REQ_MAIN; q.owner = z[i];
+				q.flag = (0x40 << i) | extra_flag; q.mapq = q_se[i]; q._pad0 = q._pad1 = 0;
+				rq[i][nrq[i]++] = q;
+			}
+		}
+	}
+	if (!paired) { /* upstream no_pairing: */
+		int hrid[2] = { -1, -1 };
+		for (i = 0; i < 2; ++i) if (an[i] && a[i][0].score >= opt.T) hrid[i] = a[i][0].rid;
+		if (hrid[0] == hrid[1] && hrid[0] >= 0) {
+			int64_t dist; int d = ssg_infer_dir(ix.l_pac, a[0][0].rb, a[1][0].rb, &dist);
+			if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
+		}
+		for (i = 0; i < 2; ++i) { /* upstream mem_reg2sam */
+			int l = 0, k, mapq0 = 0;
+			for (k = 0; k < an[i]; ++k) {
+				const ssg_alnreg_t &pr = a[i][k];
+				if (pr.score < opt.T) continue;
+				if (pr.secondary >= 0) continue;
+				ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = (int32_t)(reg_off[2*p+i] + k); q.kind = SSG_REQ_MAIN; q.owner = k;
+				q.flag = (i ? 0x81 : 0x41) | extra_flag; q._pad0 = q._pad1 = 0;
+				q.mapq = pr.secondary < 0 ? ssg_approx_mapq_se(opt, pr) : 0;
+				if (l) q.flag |= 0x800;
+				if (l && q.mapq > mapq0) q.mapq = mapq0;
+				if (!l) mapq0 = q.mapq;
+				rq[i][nrq[i]++] = q;
+				++l;
+			}
+			if (l == 0) {
+				ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = -1; q.kind = SSG_REQ_MAIN; q.owner = -1;
+				q.flag = (i ? 0x81 : 0x41) | extra_flag | 0x4; q.mapq = 0; q._pad0 = q._pad1 = 0;
+				rq[i][nrq[i]++] = q;
+			}
+		}
+	}
+	for (i = 0; i < 2; ++i) { /* XA entries (upstream mem_gen_alt): count per primary, then emit for the main records */
+		int32_t *cnt = z0; /* reuse */
+		int nmain = nrq[i], tot = 0;
+		for (j = 0; j < an[i]; ++j) cnt[j] = 0;
+		for (j = 0; j < an[i]; ++j) {
+			int k = a[i][j].secondary_all;
+			if (k >= 0 && a[i][j].score >= a[i][k].score * (double)opt.XA_drop_ratio) { ++cnt[k]; ++tot; }
+		}
+		if (tot) {
+			for (j = 0; j < an[i]; ++j) {
+				int k = a[i][j].secondary_all;
+				if (!(k >= 0 && a[i][j].score >= a[i][k].score * (double)opt.XA_drop_ratio)) continue;
+				if (cnt[k] > opt.max_XA_hits_alt || cnt[k] > opt.max_XA_hits) continue;
+				bool wanted = false;
+				for (int m2 = 0; m2 < nmain; ++m2) if (rq[i][m2].owner == k && rq[i][m2].reg >= 0) wanted = true;
+				if (!wanted) continue;
+				ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = (int32_t)(reg_off[2*p+i] + j); q.kind = SSG_REQ_XA; q.owner = k; q.flag = 0; q.mapq = 0; q._pad0 = q._pad1 = 0;
+				rq[i][nrq[i]++] = q;
+			}
+		}
+		n_req[2*p + i] = nrq[i];
+	}
+}
+
 __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, int64_t id0,
                                  const int64_t *reg_off, ssg_alnreg_t *regs, const int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                                  int32_t *zbuf, ssg_pair64_t *vbuf, ssg_pair64_t *ubuf, int ucap,
-                                 const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err, const int32_t *work_order)
+                                 const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err, const int32_t *work_order, int pq_first)
 {
 	long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
 	ssg_pair64_t *u = ubuf + gt * (long)ucap;
-	for (long pq = gt; pq < n_pairs; pq += nt) {
+	for (long pq = pq_first + gt; pq < n_pairs; pq += nt) {
 		const long p = work_order ? work_order[pq] : pq;   /* similar-cost pairs share a wave */
 		const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
 		const int64_t id = id0 + p;
@@ -399,115 +506,13 @@ __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_
 		const int an[2] = { n_reg[2*p], n_reg[2*p+1] };
 		int32_t *z0 = zbuf + reg_off[2*p];
 		ssg_pair64_t *v = vbuf + reg_off[2*p];
-		int n_pri[2], z[2] = {0, 0}, o = 0, subo = 0, n_sub = 0, extra_flag = 1, myerr = 0, i, j;
+		int n_pri[2], z[2] = {0, 0}, o = 0, subo = 0, n_sub = 0, myerr = 0;
 		ssg_alnreq_t *rq[2] = { req + req_off[2*p], req + req_off[2*p+1] };
-		int nrq[2] = {0, 0};
-		unsigned long long tq0 = ssg_clock(), tq1;
 		n_pri[0] = ssg_mark_primary_se(opt, an[0], a[0], id << 1 | 0, z0, (int32_t*)v);
 		n_pri[1] = ssg_mark_primary_se(opt, an[1], a[1], id << 1 | 1, z0, (int32_t*)v);
-		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[8], tq1 - tq0); tq0 = tq1; }
-		bool paired = false;
-		int q_se[2] = {0, 0};
-		if (n_pri[0] && n_pri[1] && (o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, u, ucap, &myerr)) > 0) {
-			int is_multi[2], q_pe, score_un;
-			for (i = 0; i < 2; ++i) {
-				for (j = 1; j < n_pri[i]; ++j) if (a[i][j].secondary < 0 && a[i][j].score >= opt.T) break;
-				is_multi[i] = j < n_pri[i] ? 1 : 0;
-			}
-			if (!(is_multi[0] || is_multi[1])) {
-				paired = true;
-				score_un = a[0][0].score + a[1][0].score - opt.pen_unpaired;
-				subo = subo > score_un ? subo : score_un;
-				q_pe = SSG_RAW_MAPQ(o - subo, opt.a);
-				if (n_sub > 0) q_pe -= (int)(4.343 * log((double)(n_sub + 1)) + .499);
-				if (q_pe < 0) q_pe = 0;
-				if (q_pe > 60) q_pe = 60;
-				q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
-				if (o > score_un) {
-					ssg_alnreg_t *c[2] = { &a[0][z[0]], &a[1][z[1]] };
-					for (i = 0; i < 2; ++i) {
-						if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
-						q_se[i] = ssg_approx_mapq_se(opt, *c[i]);
-					}
-					q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
-					q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
-					extra_flag |= 2;
-					{ int c0 = SSG_RAW_MAPQ(c[0]->score - c[0]->csub, opt.a); q_se[0] = q_se[0] < c0 ? q_se[0] : c0; }
-					{ int c1 = SSG_RAW_MAPQ(c[1]->score - c[1]->csub, opt.a); q_se[1] = q_se[1] < c1 ? q_se[1] : c1; }
-				} else {
-					z[0] = z[1] = 0;
-					q_se[0] = ssg_approx_mapq_se(opt, a[0][0]);
-					q_se[1] = ssg_approx_mapq_se(opt, a[1][0]);
-				}
-				for (i = 0; i < 2; ++i) {
-					int k = a[i][z[i]].secondary_all;
-					if (k >= 0 && k < n_pri[i]) {
-						for (j = 0; j < an[i]; ++j) if (a[i][j].secondary_all == k || j == k) a[i][j].secondary_all = z[i];
-						a[i][z[i]].secondary_all = -1;
-					}
-				}
-				for (i = 0; i < 2; ++i) {
-					ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = (int32_t)(reg_off[2*p+i] + z[i]); q.kind = SSG_REQ_MAIN; q.owner = z[i];
-					q.flag = (0x40 << i) | extra_flag; q.mapq = q_se[i]; q._pad0 = q._pad1 = 0;
-					rq[i][nrq[i]++] = q;
-				}
-			}
-		}
-		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[9], tq1 - tq0); tq0 = tq1; }
-		if (!paired) { /* upstream no_pairing: */
-			int hrid[2] = { -1, -1 };
-			for (i = 0; i < 2; ++i) if (an[i] && a[i][0].score >= opt.T) hrid[i] = a[i][0].rid;
-			if (hrid[0] == hrid[1] && hrid[0] >= 0) {
-				int64_t dist; int d = ssg_infer_dir(ix.l_pac, a[0][0].rb, a[1][0].rb, &dist);
-				if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
-			}
-			for (i = 0; i < 2; ++i) { /* upstream mem_reg2sam */
-				int l = 0, k, mapq0 = 0;
-				for (k = 0; k < an[i]; ++k) {
-					const ssg_alnreg_t &pr = a[i][k];
-					if (pr.score < opt.T) continue;
-					if (pr.secondary >= 0) continue;
-					ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = (int32_t)(reg_off[2*p+i] + k); q.kind = SSG_REQ_MAIN; q.owner = k;
-					q.flag = (i ? 0x81 : 0x41) | extra_flag; q._pad0 = q._pad1 = 0;
-					q.mapq = pr.secondary < 0 ? ssg_approx_mapq_se(opt, pr) : 0;
-					if (l) q.flag |= 0x800;
-					if (l && q.mapq > mapq0) q.mapq = mapq0;
-					if (!l) mapq0 = q.mapq;
-					rq[i][nrq[i]++] = q;
-					++l;
-				}
-				if (l == 0) {
-					ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = -1; q.kind = SSG_REQ_MAIN; q.owner = -1;
-					q.flag = (i ? 0x81 : 0x41) | extra_flag | 0x4; q.mapq = 0; q._pad0 = q._pad1 = 0;
-					rq[i][nrq[i]++] = q;
-				}
-			}
-		}
-		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[10], tq1 - tq0); tq0 = tq1; }
-		for (i = 0; i < 2; ++i) { /* XA entries (upstream mem_gen_alt): count per primary, then emit for the main records */
-			int32_t *cnt = z0; /* reuse */
-			int nmain = nrq[i], tot = 0;
-			for (j = 0; j < an[i]; ++j) cnt[j] = 0;
-			for (j = 0; j < an[i]; ++j) {
-				int k = a[i][j].secondary_all;
-				if (k >= 0 && a[i][j].score >= a[i][k].score * (double)opt.XA_drop_ratio) { ++cnt[k]; ++tot; }
-			}
-			if (tot) {
-				for (j = 0; j < an[i]; ++j) {
-					int k = a[i][j].secondary_all;
-					if (!(k >= 0 && a[i][j].score >= a[i][k].score * (double)opt.XA_drop_ratio)) continue;
-					if (cnt[k] > opt.max_XA_hits_alt || cnt[k] > opt.max_XA_hits) continue;
-					bool wanted = false;
-					for (int m2 = 0; m2 < nmain; ++m2) if (rq[i][m2].owner == k && rq[i][m2].reg >= 0) wanted = true;
-					if (!wanted) continue;
-					ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = (int32_t)(reg_off[2*p+i] + j); q.kind = SSG_REQ_XA; q.owner = k; q.flag = 0; q.mapq = 0; q._pad0 = q._pad1 = 0;
-					rq[i][nrq[i]++] = q;
-				}
-			}
-			n_req[2*p + i] = nrq[i];
-		}
+		if (n_pri[0] && n_pri[1]) o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, u, ucap, &myerr);
+		ssg_pair_decide(ix, opt, pes, p, a, an, n_pri, o, subo, n_sub, z, z0, reg_off, rq, n_req);
 		if (myerr) err[p] = myerr;
-		if (SSG_TUNING) { tq1 = ssg_clock(); atomicAdd(&ssg_dbg_cyc[11], tq1 - tq0); atomicAdd(&ssg_dbg_cyc[12], (unsigned long long)(an[0] + an[1]) * (an[0] + an[1])); }
 	}
 }
 #endif

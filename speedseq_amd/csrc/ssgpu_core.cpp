@@ -18,6 +18,7 @@
 #include "k_extend.h"
 #include "k_swjobs.h"
 #include "k_aln.h"
+#include "k_pairw.h"
 #include "k_misc.h"
 #include "../../include/ssgpu.h"
 #ifndef SSG_EMU
@@ -657,8 +658,21 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		long nthr = std::min<long>(((long)n_pairs + 63) / 64 * 64, 32768);
 		dbuf<ssg_pair64_t> d_v((size_t)t2 + 1), d_u((size_t)nthr * ucap);
 		CHKA(d_v); CHKA(d_u);
-		SSG_LAUNCH(ssg_k_pair_final, nthr / 64, 64, 0, idx->v, *opt, n_pairs, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_u.p, ucap,
-		           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p);
+		/* d_pw is heaviest first: pairs with long region lists get a wavefront each (k_pairw.h), the rest a lane each */
+		unsigned int cc[5];
+		CHK(dev_class_counts(d_pkey.p, n_pairs, 0, 0, env_int("SSG_PAIR_WAVE_MIN", 64), cc));
+		const int n_heavy = (int)cc[0];
+		if (n_heavy > 0) {
+			const long nwg = std::min<long>(((long)n_heavy + wpb - 1) / wpb, 512);
+			dbuf<ssg_pw_slab_t> d_slab((size_t)nwg * wpb);
+			CHKA(d_slab); CHK(d_q.zero());
+			SSG_LAUNCH(ssg_k_pair_final_wave, nwg, wpb * 64, 0, idx->v, *opt, n_heavy, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_slab.p,
+			           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, d_q.p);
+			CHK(rt_sync());
+		}
+		if (n_pairs > n_heavy)
+			SSG_LAUNCH(ssg_k_pair_final, nthr / 64, 64, 0, idx->v, *opt, n_pairs, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_u.p, ucap,
+			           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, n_heavy);
 		CHK(rt_sync());
 	}
 	STAGE("pair_final");

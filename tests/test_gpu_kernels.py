@@ -95,3 +95,11 @@ def test_gpu_repeats_pe_sam(gpu_lib, oracle, repeat_prefix):
 def test_gpu_repeats_mate_rescue(gpu_lib, oracle, repeat_pe_prefix):
     text, stats = common.check_pe_sam(gpu_lib, oracle, 1500, seed=5, prefix=repeat_pe_prefix)
     assert stats[3] > 10000   # rescues
+
+
+def test_gpu_pair_wave_kernel_forced(gpu_lib, oracle, repeat_pe_prefix, monkeypatch):
+    # every pair through the wave-per-pair primary-marking / pairing kernel (normally only long region lists)
+    monkeypatch.setenv("SSG_PAIR_WAVE_MIN", "0")
+    common.check_pe_sam(gpu_lib, oracle, 3000, seed=7)
+    common.check_pe_edge_cases(gpu_lib, oracle)
+    common.check_pe_sam(gpu_lib, oracle, 600, seed=8, prefix=repeat_pe_prefix)

@@ -83,3 +83,11 @@ def test_emu_repeats_pe_sam(emu_lib, oracle, repeat_prefix):
 def test_emu_repeats_mate_rescue(emu_lib, oracle, repeat_pe_prefix):
     text, stats = common.check_pe_sam(emu_lib, oracle, 250, seed=5, prefix=repeat_pe_prefix)
     assert stats[3] > 1000   # rescues
+
+
+def test_emu_pair_wave_kernel_forced(emu_lib, oracle, repeat_pe_prefix, monkeypatch):
+    # every pair through the wave-per-pair primary-marking / pairing kernel (normally only long region lists)
+    monkeypatch.setenv("SSG_PAIR_WAVE_MIN", "0")
+    common.check_pe_sam(emu_lib, oracle, 250, seed=7)
+    common.check_pe_edge_cases(emu_lib, oracle)
+    common.check_pe_sam(emu_lib, oracle, 120, seed=8, prefix=repeat_pe_prefix)
