@@ -9,6 +9,7 @@
 #include "k_pair.h"
 
 #define SSG_Z_CAP (192 * 1024)   /* backtrack bytes per resident wave */
+#define SSG_ALN_QLDS 256          /* query bytes staged in LDS per wave */
 
 SSG_DEVFN int ssg_infer_bw(int l1, int l2, int score, int a, int q, int r)
 {	/* upstream infer_bw */
@@ -19,25 +20,30 @@ SSG_DEVFN int ssg_infer_bw(int l1, int l2, int score, int a, int q, int r)
 	return w;
 }
 
-SSG_DEVFN int ssg_put_int(char *s, int l, int cap, int v)
+SSG_DEVFN int ssg_put_int(char *s, int l, int cap, int v, bool wr = true)
 {
 	char b[12]; int n = 0;
 	if (v == 0) b[n++] = '0';
 	while (v > 0) { b[n++] = (char)('0' + v % 10); v /= 10; }
-	while (n > 0) { if (l < cap) s[l] = b[n-1]; ++l; --n; }
+	while (n > 0) { if (wr && l < cap) s[l] = b[n-1]; ++l; --n; }
 	return l;
 }
 
 /* upstream bwa_gen_cigar2 for one region; fills out->cigar/n_cigar/NM/md; returns the score */
 SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, int w_, int l_query, const uint8_t *query, int64_t rb, int64_t re,
-                           uint8_t *tbuf, uint8_t *z, ssg_aln_t *out, int *err, unsigned long long *cells)
+                           uint8_t *tbuf, uint8_t *z, ssg_aln_t *out, int *err, unsigned long long *cells, uint8_t *tlds, uint8_t *qlds)
 {
 	const int rlen = (int)(re - rb);
 	int score = 0, n_cigar = 0;
-	wv_fetch_ref(ix, rb, re, tbuf);
+	/* both sequences in LDS when they fit (the usual record): the DP rows and the NM/MD walk read them many times */
+	uint8_t *tb = rlen <= SSG_TWIN_LDS ? tlds : tbuf;
+	wv_fetch_ref(ix, rb, re, tb);
+	for (int i = wv_lane(); i < l_query && i < SSG_ALN_QLDS; i += 64) qlds[i] = query[i];
+	ssg_wave_ldssync();
+	const uint8_t *qp = l_query <= SSG_ALN_QLDS ? qlds : query;
 	const bool rev = rb >= ix.l_pac;
-	ssg_seqv_t q = { rev ? query + l_query - 1 : query, rev ? -1 : 1 };
-	ssg_seqv_t t = { rev ? tbuf + rlen - 1 : tbuf, rev ? -1 : 1 };
+	ssg_seqv_t q = { rev ? qp + l_query - 1 : qp, rev ? -1 : 1 };
+	ssg_seqv_t t = { rev ? tb + rlen - 1 : tb, rev ? -1 : 1 };
 	if (l_query == rlen && w_ == 0) {
 		int sc = 0;
 		for (int i = wv_lane(); i < l_query; i += 64) sc += opt.mat[sq_at(t, i) * 5 + sq_at(q, i)];
@@ -61,33 +67,45 @@ SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 		n_cigar = wv_bcast(nc, 0);
 		if (n_cigar > SSG_MAX_CIGAR - 2) { *err = 6; n_cigar = SSG_MAX_CIGAR - 2; }
 	}
-	/* NM and MD (lane 0) */
+	/* NM and MD: wave-uniform walk over the CIGAR; match runs are compared 64 bases per step and only the
+	 * mismatches (ballot bits) are visited; lane 0 stores the characters */
 	int nm = 0, lmd = 0;
-	SSG_LANE0(
-		int k, x, y, u, n_mm = 0, n_gap = 0, l = 0;
+	{
+		const bool wr = wv_lane() == 0;
+		int k, x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, l = 0;
 		const char *int2base = rb < ix.l_pac ? "ACGTN" : "TGCAN";
-		for (k = 0, x = y = u = 0; k < n_cigar; ++k) {
-			int op = out->cigar[k] & 0xf, len = (int)(out->cigar[k] >> 4);
+		ssg_wave_memsync();
+		for (k = 0; k < n_cigar; ++k) {
+			const uint32_t cg = out->cigar[k];
+			const int op = cg & 0xf, len = (int)(cg >> 4);
 			if (op == 0) {
-				for (int i = 0; i < len; ++i) {
-					int tb = sq_at(t, y + i);
-					if (sq_at(q, x + i) != tb) { l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) out->md[l] = int2base[tb]; ++l; ++n_mm; u = 0; }
-					else ++u;
+				for (int i0 = 0; i0 < len; i0 += 64) {
+					const int cl = len - i0 < 64 ? len - i0 : 64, i = i0 + wv_lane();
+					unsigned long long bal = wv_ballot(i < len && sq_at(q, x + i) != sq_at(t, y + i));
+					int prev = 0;
+					while (bal) {
+						const int bpos = (int)__builtin_ctzll(bal); bal &= bal - 1;
+						u += bpos - prev;
+						l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u, wr);
+						if (wr && l < SSG_MAX_MD - 1) out->md[l] = int2base[sq_at(t, y + i0 + bpos)];
+						++l; ++n_mm; u = 0; prev = bpos + 1;
+					}
+					u += cl - prev;
 				}
 				x += len; y += len;
 			} else if (op == 2) {
 				if (k > 0 && k < n_cigar - 1) {
-					l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) out->md[l] = '^'; ++l;
-					for (int i = 0; i < len; ++i) { if (l < SSG_MAX_MD - 1) out->md[l] = int2base[sq_at(t, y + i)]; ++l; }
+					l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u, wr); if (wr && l < SSG_MAX_MD - 1) out->md[l] = '^'; ++l;
+					for (int i = 0; i < len; ++i) { if (wr && l < SSG_MAX_MD - 1) out->md[l] = int2base[sq_at(t, y + i)]; ++l; }
 					u = 0; n_gap += len;
 				}
 				y += len;
 			} else if (op == 1) { x += len; n_gap += len; }
 		}
-		l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u);
-		out->md[l < SSG_MAX_MD - 1 ? l : SSG_MAX_MD - 1] = 0;
-		nm = n_mm + n_gap; lmd = l);
-	nm = wv_bcast(nm, 0); lmd = wv_bcast(lmd, 0);
+		l = ssg_put_int(out->md, l, SSG_MAX_MD - 1, u, wr);
+		if (wr) out->md[l < SSG_MAX_MD - 1 ? l : SSG_MAX_MD - 1] = 0;
+		nm = n_mm + n_gap; lmd = l;
+	}
 	if (lmd >= SSG_MAX_MD - 1) *err = 7;
 	SSG_LANE0(out->n_cigar = n_cigar; out->NM = nm; out->l_md = lmd);
 	return score;
@@ -96,6 +114,7 @@ SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 __global__ void __launch_bounds__(256) ssg_k_reg2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
                               const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, uint8_t *tglb, uint8_t *zglb, int32_t *err, unsigned long long *cells)
 {
+	__shared__ uint8_t tlds_[SSG_WAVES_PER_WG][SSG_TWIN_LDS], qlds_[SSG_WAVES_PER_WG][SSG_ALN_QLDS];
 	const int wslot = (int)(threadIdx.x >> 6);
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot, nwaves = (long)gridDim.x * (blockDim.x >> 6);
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB, *z = zglb + wave0 * (long)SSG_Z_CAP;
@@ -122,7 +141,7 @@ __global__ void __launch_bounds__(256) ssg_k_reg2aln(ssg_index_view_t ix, ssg_me
 		i = 0;
 		do {
 			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
-			score = wv_gen_cigar(ix, opt, w2, qe - qb, query + qb, rb, re, tg, z, a, &myerr, &nc);
+			score = wv_gen_cigar(ix, opt, w2, qe - qb, query + qb, rb, re, tg, z, a, &myerr, &nc, tlds_[wslot], qlds_[wslot]);
 			if (score == last_sc || w2 == opt.w << 2) break;
 			last_sc = score;
 			w2 <<= 1;
