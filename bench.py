@@ -226,6 +226,9 @@ def main():
                 # per chain: both read sides + their 2-bit windows + 40-byte job + 2 x 32-byte results
                 "ssg_k_ext_lane<136>": float(summary[7]) * (rl + (rl + 140) / 4.0 + 104) if len(summary) > 7 and summary[7] else 0.0,
             }
+            smk = next((k for k in kern if k.startswith("ssg_k_smem")), None)   # ssg_k_smem_quad<4> / <1> / ssg_k_smem_lane
+            if smk:
+                alg_bytes[smk] = alg_bytes.pop("ssg_k_smem_quad")
             alg = alg_bytes.get(name, 0.0)
             ach = alg / (per_launch_ms * 1e-3) / 1e9
             sw_ms = sum(kern.get(k, (0, 1))[0] for k in ("ssg_k_matesw", "ssg_k_chain2aln", "ssg_k_reg2aln", "ssg_k_ext_lane<136>", "ssg_k_ext_lane<256>")) / a.steps
@@ -234,9 +237,9 @@ def main():
                                "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
                                "hbm_gbps_by_kernel": {k: round(alg_bytes[k] / (kern[k][0] / kern[k][1] * 1e-3) / 1e9, 1) for k in alg_bytes if k in kern},
                                # FM-index kernels read random 64-byte lines: measured MI355X gather peak (tools/dbg/gather_probe.cpp)
-                               "random64B": {"kernel": "ssg_k_smem_quad", "peak_glines_per_s": 55.0, "peak_gbps": 3520.0,
-                                             "achieved_glines_per_s": (2.0 * n_ext / (kern["ssg_k_smem_quad"][0] / kern["ssg_k_smem_quad"][1] * 1e-3) / 1e9) if "ssg_k_smem_quad" in kern else None,
-                                             "frac": (2.0 * n_ext / (kern["ssg_k_smem_quad"][0] / kern["ssg_k_smem_quad"][1] * 1e-3) / 55e9) if "ssg_k_smem_quad" in kern else None},
+                               "random64B": {"kernel": smk, "peak_glines_per_s": 55.0, "peak_gbps": 3520.0,
+                                             "achieved_glines_per_s": (2.0 * n_ext / (kern[smk][0] / kern[smk][1] * 1e-3) / 1e9) if smk else None,
+                                             "frac": (2.0 * n_ext / (kern[smk][0] / kern[smk][1] * 1e-3) / 55e9) if smk else None},
                                "sw_cells_per_step": int(summary[3]) + int(summary[4]),
                                "sw_gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None}
         # ---- CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample ----

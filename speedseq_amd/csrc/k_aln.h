@@ -111,7 +111,10 @@ SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 	return score;
 }
 
-__global__ void __launch_bounds__(256) ssg_k_reg2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
+#ifndef SSG_R2A_WAVES
+#define SSG_R2A_WAVES 4   /* 128 VGPRs: 28 ms against 40 at 2 waves/SIMD (211 VGPRs) */
+#endif
+__global__ void __launch_bounds__(256, SSG_R2A_WAVES) ssg_k_reg2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
                               const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, uint8_t *tglb, uint8_t *zglb, int32_t *err, unsigned long long *cells)
 {
 	__shared__ uint8_t tlds_[SSG_WAVES_PER_WG][SSG_TWIN_LDS], qlds_[SSG_WAVES_PER_WG][SSG_ALN_QLDS];

@@ -198,19 +198,23 @@ enum { SM_PEND_NONE = 0, SM_PEND_FWD, SM_PEND_BWD, SM_PEND_P3 };
 #ifndef SSG_SMQ_WAVES
 #define SSG_SMQ_WAVES 4
 #endif
+/* LPR = lanes per read: 4 (cooperative rank-block fetch) or 1 (each lane fetches whole blocks; 4x fewer wave instructions per read,
+ * 4x more translation work per line -- see tools/dbg/gather_probe.cpp for where that starts to matter) */
+template <int LPR>
 __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
                            ssg_intv_t *scratch, int scap, unsigned long long *n_extend)
 {
-	__shared__ uint32_t qlds[SSG_SM_QWORDS * 16];
-	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nq = ((long)gridDim.x * blockDim.x) >> 2;
-	const int lane = (int)(threadIdx.x & 63), Q = lane >> 2, ql = lane & 3;
+	constexpr int RPW = 64 / LPR;   /* reads per wave */
+	__shared__ uint32_t qlds[SSG_SM_QWORDS * RPW];
+	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nq = ((long)gridDim.x * blockDim.x) / LPR;
+	const int lane = (int)(threadIdx.x & 63), Q = lane / LPR, ql = lane % LPR;
 	/* per-wave slab of 2 lists x scap entries x 16 quads, entry e of quad Q at [e*16 + Q] */
-	ssg_intv_t *const vec0 = scratch + (gt >> 6) * 2 * scap * 16 + Q, *const vec1 = vec0 + (long)scap * 16;
+	ssg_intv_t *const vec0 = scratch + (gt >> 6) * 2 * scap * RPW + Q, *const vec1 = vec0 + (long)scap * RPW;
 	const uint32_t *const ql_ = qlds + Q;
-#define SMQ(i) ((int)((ql_[((i) >> 3) * 16] >> (((i) & 7) << 2)) & 15u))
-#define SMV(v, e) ((v)[(long)(e) * 16])
+#define SMQ(i) ((int)((ql_[((i) >> 3) * RPW] >> (((i) & 7) << 2)) & 15u))
+#define SMV(v, e) ((v)[(long)(e) * RPW])
 #ifdef SSG_EMU
 #define QW 1          /* fibers of a quad are not in lock step: every lane stores the (identical) value it will read back */
 #else
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 #endif
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	unsigned long long my_nx = 0;
-	long it = (gt >> 2) - nq;
+	long it = gt / LPR - nq;
 	int state = SM_READ, pend = SM_PEND_NONE;
 	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0;
 	ssg_intv_t *mem = 0;
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 				for (int w = 0; w * 8 < len; ++w) { /* all 4 lanes write the same words: no cross-lane hand-off needed */
 					uint32_t v = 0;
 					for (int b = 0; b < 8 && w * 8 + b < len; ++b) v |= (uint32_t)(q[w * 8 + b] & 15) << (b << 2);
-					qlds[w * 16 + Q] = v;
+					qlds[w * RPW + Q] = v;
 				}
 				x = 0;
 				state = len >= opt.min_seed_len ? SM_P1 : SM_OUT;
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 		const int back = pend == SM_PEND_BWD;
 		const int jn = back && j + 1 < prev_n ? j + 1 : 0;
 		const ssg_intv_t pf = SMV(prev, jn ? (prev_rev ? prev_n - 1 - jn : jn) : 0);   /* always a valid slot; used only if j+1 < prev_n */
-		const ssg_intv_t okc = ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql);
+		const ssg_intv_t okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1(ix, back ? p : ik, e_c, back);
 		++my_nx;
 		{
 			ssg_intv_t *const curr = flip ? vec1 : vec0;

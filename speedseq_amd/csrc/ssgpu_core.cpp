@@ -280,12 +280,16 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 {
 	const int block = 64;
 	const bool quad = !(getenv("SSG_SMEM_KERNEL") && !strcmp(getenv("SSG_SMEM_KERNEL"), "lane"));
-	const int per_read = quad ? 4 : 1;   /* lanes per read */
+	/* lanes per read: whole-block fetches per lane win while the rank blocks span <= ~2 GB (1.5 x the quad form at 1 GB); beyond
+	 * that a per-lane fetch pays 4x the translation work per line and drops below the quad form (tools/dbg/gather_probe.cpp) */
+	const uint64_t bwt_bytes = (idx->v.seq_len >> 7) * 64;
+	const int lpr = quad ? env_int("SSG_SMEM_LPR", bwt_bytes > (2ull << 30) ? 4 : 1) : 1, per_read = lpr;
 	long nthreads = std::min<long>(((long)n_reads * per_read + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64);
 	int scap = max_len + 2;
 	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap / per_read + 64);
 	CHKA(scratch);
-	if (quad) SSG_LAUNCH(ssg_k_smem_quad, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
+	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
+	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));
