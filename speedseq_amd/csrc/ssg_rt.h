@@ -25,6 +25,9 @@ static inline int rt_d2h(void *h, const void *d, size_t n) { if (n) memcpy(h, d,
 static inline int rt_memset(void *d, int v, size_t n) { if (n) memset(d, v, n); return 0; }
 static inline int rt_sync() { return 0; }
 #define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) emu::launch((unsigned)(grid), (unsigned)(block), (lds), [&]() { kern(__VA_ARGS__); }); } while (0)
+#define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) SSG_LAUNCH(kern, grid, block, lds, __VA_ARGS__)
+static inline void ssg_fork(int) {}
+static inline void ssg_join(int) {}
 #else
 #include <hip/hip_runtime.h>
 #define SSG_BACKEND "hip:gfx950"
@@ -70,6 +73,15 @@ extern std::vector<ssg_prof_rec> ssg_prof_pending;
 	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, 0); \
 		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); (void)hipEventRecord(r_.b, 0); ssg_prof_pending.push_back(r_); } \
 	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } } while (0)
+/* side streams for independent kernels that each leave most of the chip idle (few heavy work items): fork after the work
+ * already queued on the default stream, launch with SSG_LAUNCH_ON(i, ...), join before anything that consumes the results */
+static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[4] = {0, 0, 0, 0}; if (!s[i]) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking); return s[i]; }
+static inline void ssg_fork(int n) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, 0); for (int i = 0; i < n; ++i) (void)hipStreamWaitEvent(ssg_side_stream(i), e, 0); (void)hipEventDestroy(e); }
+static inline void ssg_join(int n) { for (int i = 0; i < n; ++i) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, ssg_side_stream(i)); (void)hipStreamWaitEvent(0, e, 0); (void)hipEventDestroy(e); } }
+#define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) do { if ((grid) > 0) { hipStream_t st_ = ssg_side_stream(si); \
+	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, st_); \
+		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), st_, __VA_ARGS__); (void)hipEventRecord(r_.b, st_); ssg_prof_pending.push_back(r_); } \
+	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), st_, __VA_ARGS__); } } while (0)
 #endif
 
 /* RAII device buffer */

@@ -475,13 +475,16 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
 		if (nC) SSG_LAUNCH(ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		if (nB) SSG_LAUNCH(ssg_k_chain_wave<4096>, std::min(nB, 256), 64, 0, idx->v, *opt, nC, nC + nB, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		/* the three classes are independent and the two wave kernels fill a fraction of the chip each: overlap them */
+		ssg_fork(2);
+		if (nB) SSG_LAUNCH_ON(0, ssg_k_chain_wave<4096>, std::min(nB, 256), 64, 0, idx->v, *opt, nC, nC + nB, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 1);
-		if (nA) SSG_LAUNCH(ssg_k_chain_wave<1024>, std::min(nA, 1024), 64, 0, idx->v, *opt, nC + nB, nC + nB + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		if (nA) SSG_LAUNCH_ON(1, ssg_k_chain_wave<1024>, std::min(nA, 1024), 64, 0, idx->v, *opt, nC + nB, nC + nB + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 2);
 		const int r0 = nC + nB + nA;
 		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+		ssg_join(2);
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
@@ -666,17 +669,17 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		unsigned int cc[5];
 		CHK(dev_class_counts(d_pkey.p, n_pairs, 0, 0, env_int("SSG_PAIR_WAVE_MIN", 64), cc));
 		const int n_heavy = (int)cc[0];
-		if (n_heavy > 0) {
-			const long nwg = std::min<long>(((long)n_heavy + wpb - 1) / wpb, 512);
-			dbuf<ssg_pw_slab_t> d_slab((size_t)nwg * wpb);
-			CHKA(d_slab); CHK(d_q.zero());
-			SSG_LAUNCH(ssg_k_pair_final_wave, nwg, wpb * 64, 0, idx->v, *opt, n_heavy, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_slab.p,
-			           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, d_q.p);
-			CHK(rt_sync());
-		}
+		const long nwg_h = n_heavy > 0 ? std::min<long>(((long)n_heavy + wpb - 1) / wpb, 512) : 0;
+		dbuf<ssg_pw_slab_t> d_slab((size_t)nwg_h * wpb + 1);
+		CHKA(d_slab); CHK(d_q.zero());
+		ssg_fork(1);
+		if (n_heavy > 0)
+			SSG_LAUNCH_ON(0, ssg_k_pair_final_wave, nwg_h, wpb * 64, 0, idx->v, *opt, n_heavy, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_slab.p,
+			              d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, d_q.p);
 		if (n_pairs > n_heavy)
 			SSG_LAUNCH(ssg_k_pair_final, nthr / 64, 64, 0, idx->v, *opt, n_pairs, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_u.p, ucap,
 			           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, n_heavy);
+		ssg_join(1);
 		CHK(rt_sync());
 	}
 	STAGE("pair_final");
