@@ -70,10 +70,15 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 	const int64_t l_pac = ix.l_pac;
 	int i, r, skip[4], n = 0, rid = -1, ma_n = *ma_n_;
 	for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
-	for (i = 0; i < ma_n; ++i) {
-		int64_t dist;
-		r = ssg_infer_dir(l_pac, a.rb, ma[i].rb, &dist);
-		if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+	{	/* a hit already inside the insert-size window of an orientation makes the rescue for it unnecessary: 64 hits per step */
+		int seen = 0;
+		ssg_wave_memsync();
+		for (i = wv_lane(); i < ma_n; i += 64) {
+			int64_t dist;
+			r = ssg_infer_dir(l_pac, a.rb, ma[i].rb, &dist);
+			if (dist >= pes[r].low && dist <= pes[r].high) seen |= 1 << r;
+		}
+		for (r = 0; r < 4; ++r) if (wv_ballot(seen >> r & 1)) skip[r] = 1;
 	}
 	if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
 	for (r = 0; r < 4; ++r) {
@@ -190,15 +195,28 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 		/* b[i] = hits within pen_unpaired of the best, copied BEFORE any rescue (upstream order) */
 		for (int i = 0; i < 2; ++i) {
 			int cnt = 0;
-			for (int j = 0; j < an[i]; ++j) if (a[i][j].score >= a[i][0].score - opt.pen_unpaired) ++cnt;
+			const int thr = an[i] ? a[i][0].score - opt.pen_unpaired : 0;
+			for (int j = wv_lane(); j < an[i]; j += 64) if (a[i][j].score >= thr) ++cnt;
+			cnt = wv_sum(cnt);
 			nb[i] = cnt < opt.max_matesw ? cnt : opt.max_matesw;
 			if (nb[i] > 64) { nb[i] = 64; myerr = 3; }
 		}
 		if (nb[0] + nb[1] > 0) {
 			int fixed[2] = { 0, 0 };   /* a[i] has been through a re-sort of this kernel: later ones are incremental */
-			SSG_LANE0(
-				for (int i2 = 0; i2 < 2; ++i2) { int c2 = 0;
-					for (int j2 = 0; j2 < an[i2] && c2 < nb[i2]; ++j2) if (a[i2][j2].score >= a[i2][0].score - opt.pen_unpaired) bc[i2 * 64 + c2++] = a[i2][j2]; });
+			ssg_wave_memsync();
+			for (int i2 = 0; i2 < 2; ++i2) { /* the first nb[i2] qualifying hits, in list order: 64 per step */
+				const int thr = an[i2] ? a[i2][0].score - opt.pen_unpaired : 0;
+				int c2 = 0;
+				for (int j0 = 0; j0 < an[i2] && c2 < nb[i2]; j0 += 64) {
+					const int j2 = j0 + wv_lane();
+					const int f = j2 < an[i2] && a[i2][j2].score >= thr;
+					const unsigned long long bal = wv_ballot(f);
+					const int at = c2 + wv_rank_of(bal);
+					if (f && at < nb[i2]) bc[i2 * 64 + at] = a[i2][j2];
+					c2 += __popcll(bal);
+				}
+			}
+			ssg_wave_memsync();
 			for (int i = 0; i < 2; ++i)
 				for (int j = 0; j < nb[i]; ++j) {
 					const int l_ms = (int)(read_off[2*p + !i + 1] - read_off[2*p + !i]);

@@ -195,6 +195,13 @@ __global__ void __launch_bounds__(64) ssg_k_smem_lane(ssg_index_view_t ix, ssg_m
 enum { SM_READ = 0, SM_P1, SM_FWD, SM_FWDEND, SM_BWD, SM_RET, SM_P2, SM_P3, SM_P3F, SM_OUT, SM_FIN };
 enum { SM_PEND_NONE = 0, SM_PEND_FWD, SM_PEND_BWD, SM_PEND_P3 };
 
+/* interval-list entries in scratch and in the carried registers: 16 bytes (x0, x1, x2 < 2^40; info = end position < 256) */
+struct alignas(16) ssg_pk_t { uint64_t w0, w1; };
+SSG_DEVFN ssg_pk_t ssg_pk(const ssg_intv_t &v)
+{ ssg_pk_t p; p.w0 = v.x0 | (v.x1 & 0xffffffull) << 40; p.w1 = (v.x1 >> 24) | v.x2 << 16 | v.info << 56; return p; }
+SSG_DEVFN ssg_intv_t ssg_unpk(const ssg_pk_t &p)
+{ ssg_intv_t v; v.x0 = p.w0 & 0xffffffffffull; v.x1 = (p.w0 >> 40) | (p.w1 & 0xffffull) << 24; v.x2 = (p.w1 >> 16) & 0xffffffffffull; v.info = p.w1 >> 56; return v; }
+
 #ifndef SSG_SMQ_WAVES
 #define SSG_SMQ_WAVES 4
 #endif
@@ -211,7 +218,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nq = ((long)gridDim.x * blockDim.x) / LPR;
 	const int lane = (int)(threadIdx.x & 63), Q = lane / LPR, ql = lane % LPR;
 	/* per-wave slab of 2 lists x scap entries x 16 quads, entry e of quad Q at [e*16 + Q] */
-	ssg_intv_t *const vec0 = scratch + (gt >> 6) * 2 * scap * RPW + Q, *const vec1 = vec0 + (long)scap * RPW;
+	ssg_pk_t *const vec0 = (ssg_pk_t*)scratch + (gt >> 6) * 2 * scap * RPW + Q, *const vec1 = vec0 + (long)scap * RPW;
 	const uint32_t *const ql_ = qlds + Q;
 #define SMQ(i) ((int)((ql_[((i) >> 3) * RPW] >> (((i) & 7) << 2)) & 15u))
 #define SMV(v, e) ((v)[(long)(e) * RPW])
@@ -228,11 +235,12 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	ssg_intv_t *mem = 0;
 	int sx = 0, i = 0, j = 0, curr_n = 0, prev_n = 0, prev_rev = 0, flip = 0, m1_n = 0, m1_last_beg = 0, ret = 0, e_c = 0;
 	uint64_t min_intv = 1, last_x2 = 0;
-	ssg_intv_t ik, p, pn, c0, first;
-	ik.x0 = ik.x1 = ik.x2 = ik.info = 0; p = pn = c0 = first = ik;
+	ssg_intv_t ik, p;
+	ik.x0 = ik.x1 = ik.x2 = ik.info = 0; p = ik;
+	ssg_pk_t pn, c0, first; pn.w0 = pn.w1 = 0; c0 = first = pn;
 	for (;;) {
 		while (pend == SM_PEND_NONE && state != SM_FIN) {
-			ssg_intv_t *const curr = flip ? vec1 : vec0;
+			ssg_pk_t *const curr = flip ? vec1 : vec0;
 			switch (state) {
 			case SM_READ: {
 				it += nq;
@@ -257,11 +265,11 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 				break;
 			case SM_FWD: /* top of upstream's forward loop: for (i = x + 1; i < len; ++i) */
 				if (i < len && SMQ(i) < 4) { pend = SM_PEND_FWD; e_c = 3 - SMQ(i); }
-				else { if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ik; } else ovf = 1; ++curr_n; state = SM_FWDEND; }
+				else { if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1; ++curr_n; state = SM_FWDEND; }
 				break;
 			case SM_FWDEND: /* the forward list becomes `prev', walked from its top (= ik); ret = end of the longest match */
 				ret = (int)ik.info;
-				flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ik;
+				flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ssg_pk(ik);
 				state = SM_BWD;
 				break;
 			case SM_BWD: { /* for (i = x - 1; i >= -1; --i) for (j = 0; j < prev->n; ++j) */
@@ -271,7 +279,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 					if (i < -1) state = SM_RET;
 					break;
 				}
-				p = j == 0 ? first : pn;
+				p = ssg_unpk(j == 0 ? first : pn);
 				const int cb = i < 0 ? -1 : SMQ(i) < 4 ? SMQ(i) : -1;
 				if (cb >= 0) { pend = SM_PEND_BWD; e_c = cb; }
 				else { /* no base to extend with: only the first (longest) interval of the row can be an SMEM, the rest are no-ops */
@@ -321,17 +329,18 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 		if (state == SM_FIN) break;
 		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
 		ssg_wave_ldssync();   /* list entries stored by lane 0 of the quad last iteration are read by all four below (same wave: in order on the GPU) */
-		const ssg_intv_t *const prev = flip ? vec0 : vec1;
+		const ssg_pk_t *const prev = flip ? vec0 : vec1;
 		const int back = pend == SM_PEND_BWD;
 		const int jn = back && j + 1 < prev_n ? j + 1 : 0;
-		const ssg_intv_t pf = SMV(prev, jn ? (prev_rev ? prev_n - 1 - jn : jn) : 0);   /* always a valid slot; used only if j+1 < prev_n */
+		ssg_pk_t pf; pf.w0 = pf.w1 = 0;
+		if (jn) pf = SMV(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
 		const ssg_intv_t okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1(ix, back ? p : ik, e_c, back);
 		++my_nx;
 		{
-			ssg_intv_t *const curr = flip ? vec1 : vec0;
+			ssg_pk_t *const curr = flip ? vec1 : vec0;
 			if (pend == SM_PEND_FWD) {
 				if (okc.x2 != ik.x2) {
-					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ik; } else ovf = 1;
+					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1;
 					++curr_n;
 					if (okc.x2 < min_intv) { state = SM_FWDEND; pend = SM_PEND_NONE; continue; }   /* break: ik stays the last pushed */
 				}
@@ -349,8 +358,9 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 					}
 				} else if (curr_n == 0 || okc.x2 != last_x2) {
 					ssg_intv_t o = okc; o.info = p.info;
-					if (curr_n == 0) c0 = o;
-					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = o; } else ovf = 1;
+					const ssg_pk_t po = ssg_pk(o);
+					if (curr_n == 0) c0 = po;
+					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = po; } else ovf = 1;
 					++curr_n; last_x2 = okc.x2;
 				}
 				++j;
