@@ -41,7 +41,7 @@ SSG_DEVFN int ssg_cal_max_gap2(const ssg_mem_opt_t &opt, int qlen)
 __global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, long n_jobs, const int64_t *read_off,
                                const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                const int32_t *chain_seeds, const int64_t *chain_off, int twin_cap,
-                               ssg_xjob_t *jobs, uint64_t *key_l, uint64_t *key_r)
+                               ssg_xjob_t *jobs, uint64_t *key_l, uint64_t *key_r, int short_cap, unsigned int *n_long /* [2]: sides longer than short_cap */)
 {
 	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_jobs) return;
@@ -85,6 +85,10 @@ __global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_m
 	const int ql = jb.flag ? 0 : s.qbeg, qr = jb.flag ? 0 : l_query - s.qbeg - s.len;
 	key_l[g] = (uint64_t)(255 - ql) << 32 | (uint64_t)g;   /* ascending sort = longest query side first; side 0 = nothing to do */
 	key_r[g] = (uint64_t)(255 - qr) << 32 | (uint64_t)g;
+	{	/* one atomic per wave and side */
+		const unsigned long long bl = wv_ballot(ql > short_cap), br = wv_ballot(qr > short_cap), act = wv_ballot(1);
+		if (wv_lane() == (int)__builtin_ctzll(act)) { if (bl) atomicAdd(&n_long[0], (unsigned)__popcll(bl)); if (br) atomicAdd(&n_long[1], (unsigned)__popcll(br)); }
+	}
 }
 
 /* reference bases along an extension: doubled coordinate p0 + i*dir, read from the forward-strand pac */
@@ -215,12 +219,12 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 /* side 0: left extensions (query and reference walked backwards from the seed); side 1: right extensions.
  * sorted[t] = (255 - side length) << 32 | job id; QCAP+1 columns of LDS per lane. */
 template <int QCAP>
-__global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int side, long n_jobs, const uint64_t *sorted,
+__global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int side, long job_first, long n_jobs, const uint64_t *sorted,
                                const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
                                unsigned long long *cells)
 {
 	__shared__ uint32_t L[(QCAP + 1) * 64];
-	const long t = (long)blockIdx.x * 64 + threadIdx.x;
+	const long t = job_first + (long)blockIdx.x * 64 + threadIdx.x;
 	if (t >= n_jobs) return;
 	const uint64_t key = sorted[t];
 	if ((key >> 32) >= 255) return;   /* nothing on this side */

@@ -211,7 +211,7 @@ template <int LPR>
 __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend)
+                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read)
 {
 	constexpr int RPW = 64 / LPR;   /* reads per wave */
 	__shared__ uint32_t qlds[SSG_SM_QWORDS * RPW];
@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 			ssg_pk_t *const curr = flip ? vec1 : vec0;
 			switch (state) {
 			case SM_READ: {
-				it += nq;
+				/* next read: a shared counter when every lane owns a read (evens out the per-read cost), a fixed stride for quads */
+				if (LPR == 1 && next_read) it = (long)atomicAdd(next_read, 1u); else it += nq;
 				if (it >= n_reads) { state = SM_FIN; break; }
 				const int r = read_ids ? read_ids[it] : (int)it;
 				const uint8_t *q = seq + off[r];

@@ -288,8 +288,10 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	int scap = max_len + 2;
 	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap / per_read + 64);
 	CHKA(scratch);
-	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
-	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
+	dbuf<unsigned int> d_nextread(1);
+	CHKA(d_nextread); CHK(d_nextread.zero());
+	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0);
+	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));
@@ -499,13 +501,22 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	CHKA(d_xjobs); CHKA(d_xl); CHKA(d_xr); CHKA(d_kl); CHKA(d_kr); CHKA(d_sl); CHKA(d_sr);
 	if (n_jobs > 0) {
 		if (opt->a * 2 * max_len + 64 >= 8191) { ssg_err_msg = "match score x read length beyond the 13-bit DP cells of the extension kernel"; return SSG_EINVAL; }
+		const int short_cap = 72;   /* sides up to 72 bases run with half the LDS per wave (two waves per SIMD) */
+		dbuf<unsigned int> d_nlong(2);
+		CHKA(d_nlong); CHK(d_nlong.zero());
 		SSG_LAUNCH(ssg_k_ext_prep, (n_jobs + 255) / 256, 256, 0, idx->v, *opt, n_reads, n_jobs, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
-		           d_choff.p, (int)SSG_TWIN_GLB, d_xjobs.p, d_kl.p, d_kr.p);
+		           d_choff.p, (int)SSG_TWIN_GLB, d_xjobs.p, d_kl.p, d_kr.p, short_cap, d_nlong.p);
 		CHK(sort_keys_u64(d_kl.p, d_sl.p, n_jobs, 32, 40)); CHK(sort_keys_u64(d_kr.p, d_sr.p, n_jobs, 32, 40));
+		unsigned int h_nlong[2];
+		CHK(d_nlong.down(h_nlong, 2));
+		if (ssg_debug()) fprintf(stderr, "[ssgpu] ext jobs %ld, long sides %u / %u\n", n_jobs, h_nlong[0], h_nlong[1]);
 		for (int side = 0; side < 2; ++side) {
 			const uint64_t *srt = side ? d_sr.p : d_sl.p;
-			if (max_len <= 136 + opt->min_seed_len) SSG_LAUNCH(ssg_k_ext_lane<136>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
-			else SSG_LAUNCH(ssg_k_ext_lane<256>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
+			const long nl = (long)h_nlong[side];   /* jobs are sorted longest side first */
+			if (max_len <= 136 + opt->min_seed_len) {
+				if (nl) SSG_LAUNCH(ssg_k_ext_lane<136>, (nl + 63) / 64, 64, 0, idx->v, *opt, side, 0L, nl, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
+				if (n_jobs > nl) SSG_LAUNCH(ssg_k_ext_lane<72>, (n_jobs - nl + 63) / 64, 64, 0, idx->v, *opt, side, nl, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
+			} else SSG_LAUNCH(ssg_k_ext_lane<256>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, 0L, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
 		}
 	}
 	STAGE("ext_lane");

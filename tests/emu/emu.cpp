@@ -38,7 +38,7 @@ namespace emu {
 
 static const size_t STACK = 512 << 10;
 
-struct Wave { uint64_t vals[2][64]; int arrived[2], left[2]; int nlive; uint64_t live_mask; };
+struct Wave { uint64_t vals[2][64]; int arrived[2], left[2]; int nlive; uint64_t live_mask, arr_mask[2]; };
 struct Block { int n; int nlive; int bar_arrived[2], bar_left[2]; Wave *waves; };
 struct Fiber { void *sp; char *stack; bool done; unsigned tid; int phase, bphase; Block *blk; };
 
@@ -66,12 +66,12 @@ void wave_exchange(uint64_t v, uint64_t out[64], uint64_t *live_mask)
 {
 	Fiber *f = cur; Wave &w = f->blk->waves[f->tid >> 6];
 	int ph = f->phase, lane = f->tid & 63;
-	w.vals[ph][lane] = v; ++w.arrived[ph];
+	w.vals[ph][lane] = v; ++w.arrived[ph]; w.arr_mask[ph] |= 1ull << lane;
 	while (w.arrived[ph] < w.nlive) yield();
 	memcpy(out, w.vals[ph], sizeof(w.vals[ph]));
-	*live_mask = w.live_mask;
+	*live_mask = w.arr_mask[ph];   /* the participants of THIS rendezvous (lanes may exit right after it) */
 	++w.left[ph];
-	if (w.left[ph] == w.arrived[ph]) w.arrived[ph] = w.left[ph] = 0;
+	if (w.left[ph] == w.arrived[ph]) { w.arrived[ph] = w.left[ph] = 0; w.arr_mask[ph] = 0; }
 	f->phase ^= 1;
 }
 
