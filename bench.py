@@ -231,8 +231,14 @@ def main():
                 alg_bytes[smk] = alg_bytes.pop("ssg_k_smem_quad")
             alg = alg_bytes.get(name, 0.0)
             ach = alg / (per_launch_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
+            # profiles/r01d_pmc_traffic.json, calibrated on the random-gather probe: 1 KiB of FETCH_SIZE = 1024 B for 64-byte lines).
+            # Only valid for the default workload the passes were run on.
+            pmc_traffic = {"ssg_k_smem_quad<1>": 164.9e9, "ssg_k_matesw": 39.1e9, "ssg_k_sal": 40.0e9, "ssg_k_chain2aln": 30.3e9, "ssg_k_reg2aln": 15.8e9}
+            default_workload = a.pairs == 1000000 and abs(a.ref_mbp - 1000.0) < 1e-9 and rl == 150
+            traffic = pmc_traffic.get(name) if default_workload else None
             sw_ms = sum(kern.get(k, (0, 1))[0] for k in ("ssg_k_matesw", "ssg_k_chain2aln", "ssg_k_reg2aln", "ssg_k_ext_lane<136>", "ssg_k_ext_lane<256>")) / a.steps
-            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                                "ms_per_launch": per_launch_ms,
                                "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
                                "hbm_gbps_by_kernel": {k: round(alg_bytes[k] / (kern[k][0] / kern[k][1] * 1e-3) / 1e9, 1) for k in alg_bytes if k in kern},
