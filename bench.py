@@ -131,8 +131,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("SSG_BENCH_FORCE_DIST") == "1"   # single-rank rehearsal of the N>1 code path
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    multi = world > 1 or force_dist
+    saved_stdout = None
+    if multi:
+        # RCCL prints a version banner (and warnings) straight to stdout; this program's stdout is ONE JSON line, so everything
+        # else is sent to stderr until that line is written
+        sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl.%h.%p.log")   # RCCL's banner / warnings off stdout: this program prints ONE JSON line
         import torch.distributed as dist
+        from speedseq_amd import dist as ssdist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
@@ -165,12 +176,24 @@ def main():
     d_pb = torch.from_numpy(pb).to(dev)
     torch.cuda.synchronize()
 
+    d_sig = torch.empty((a.pairs, 3), dtype=torch.int64, device=dev) if multi else None
+    ordinal = (torch.arange(a.pairs, device=dev, dtype=torch.int64) + rank * a.pairs) if multi else None
+    n_dup_global = [0]
+
     def step(want_dup=False):
-        return capi.hotpath_dev(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0, want_dup)
+        if not multi:
+            return capi.hotpath_dev(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0, want_dup)
+        # N > 1: every rank aligns its shard; duplicates are decided over the whole input (first-seen-wins on the global pair
+        # ordinal): signatures routed to an owner rank by hash with one all-to-all, verdicts routed back (speedseq_amd/dist.py)
+        summary, _ = capi.hotpath_dev_sig(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), d_sig.data_ptr(), n_batches, 0)
+        valid = d_sig[:, 0] != -1
+        dup = ssdist.global_markdup(d_sig, valid, ordinal, device=dev)
+        n_dup_global[0] = int(dup.sum())
+        return summary, dup
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     prof = not a.no_profile
@@ -181,10 +204,10 @@ def main():
     for _ in range(a.steps):
         summary, _ = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
@@ -200,8 +223,8 @@ def main():
                                "(25 contigs, 5%% planted repeats; GRCh37 itself is not available offline), bwa-mem -t %d batch boundaries"
                                % (a.pairs, rl, sum(lens) / 1e6, a.bwa_threads),
                    "pairs_per_gpu": a.pairs, "read_len": rl, "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2),
-                   "records": int(summary[0]), "dup_pairs": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
-                   "dedup_scope": "per-GPU shard"},
+                   "records": int(summary[0]), "dup_pairs": n_dup_global[0] if multi else int(summary[1]), "dup_pairs_local_view": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
+                   "dedup_scope": "global over all ranks (all-to-all signature exchange)" if multi else "single GPU = whole input"},
     }
     if rank == 0:
         # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
@@ -272,8 +295,12 @@ def main():
                                        "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded" % (ns, cores)}
             except Exception as e:  # the baseline is informative only
                 out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
-    if world > 1:
+        if saved_stdout is not None:
+            C.CDLL(None).fflush(None); sys.stdout.flush(); os.dup2(saved_stdout, 1)
+        print(json.dumps(out)); sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(2, 1)
+    if multi:
         dist.destroy_process_group()
 
 

@@ -126,6 +126,10 @@ int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_
  * summary: [0] records [1] duplicate pairs [2] seeds [3] extension cells [4] rescue cells [5] rescues */
 int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
                     const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host);
+/* Same, and the 5'-unclipped pair signatures (n_pairs x 3 uint64 in DEVICE memory; all ones = never a duplicate) that ranks
+ * exchange for exact first-seen-wins duplicate marking over a sharded input (samblaster.cpp: the signature set is global). */
+int ssg_hotpath_dev_sig(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                        const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host, uint64_t *d_sig_out);
 
 /* FM-index from arrays already resident in HBM (not copied; the caller keeps them alive) */
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,

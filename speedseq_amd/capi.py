@@ -215,6 +215,14 @@ def hotpath_dev(lib, idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_b
     return summary, dup
 
 
+def hotpath_dev_sig(lib, idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, d_sig, n_batches=1, id0=0):
+    """hotpath_dev that also writes the pair signatures (device pointer d_sig: n_pairs x 3 uint64) for dist.global_markdup."""
+    summary = np.zeros(8, dtype=np.uint64)
+    lib._chk(lib.l.ssg_hotpath_dev_sig(idx, _ptr(opt), C.c_int(n_pairs), C.c_int(max_len), C.c_void_p(d_seq), C.c_void_p(d_off), C.c_void_p(d_pair_batch),
+                                       C.c_int(n_batches), C.c_int64(id0), _ptr(summary), None, C.c_void_p(d_sig)))
+    return summary, None
+
+
 def prof_get(lib, cap=64):
     names = (C.c_char_p * cap)()
     ms = (C.c_double * cap)()

@@ -861,8 +861,8 @@ int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_
 /* The measured hot path (bench.py): device-resident reads in, aligned + duplicate-marked records
  * left in HBM.  d_seq / d_off / d_pair_batch are DEVICE pointers.  summary[0] = records,
  * [1] = duplicate pairs, [2] = seeds, [3] = extension cells, [4] = rescue cells, [5] = rescues. */
-int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
-                    const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host /* may be NULL */)
+static int hotpath_dev_impl(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                            const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host, uint64_t *d_sig_out)
 {
 	CHK(need_device());
 	if (n_pairs <= 0 || max_len > 254) { ssg_err_msg = "ssg_hotpath_dev: bad arguments"; return SSG_EINVAL; }
@@ -871,6 +871,12 @@ int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pair
 	dbuf<ssg_sbl_end_t> d_ends(2L * n_pairs); dbuf<uint8_t> d_dup(n_pairs);
 	CHKA(d_ends); CHKA(d_dup);
 	SSG_LAUNCH(ssg_k_ends_from_alns, (2L * n_pairs + 255) / 256, 256, 0, (long)n_pairs, keep.req_off.p, keep.req.p, keep.alns.p, d_ends.p);
+	if (d_sig_out) { /* signatures for the cross-rank exchange (speedseq_amd/dist.py): three 64-bit words per pair, all ones = never a duplicate */
+		dbuf<uint64_t> d_h(n_pairs); dbuf<uint32_t> d_o(n_pairs);
+		CHKA(d_h); CHKA(d_o);
+		SSG_LAUNCH(ssg_k_sig, (n_pairs + 255) / 256, 256, 0, (long)n_pairs, d_ends.p, (ssg_sig_t*)d_sig_out, d_h.p, d_o.p);
+		CHK(rt_sync());
+	}
 	CHK(dedup_core(n_pairs, d_ends.p, d_dup.p));
 	std::vector<uint8_t> hd(n_pairs);
 	CHK(d_dup.down(hd.data(), n_pairs));
@@ -881,6 +887,15 @@ int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pair
 	summary[6] = res.stats[5]; /* bwt_extend calls in the SMEM kernel (2 rank queries = 2 x 64-byte lines each) */
 	return 0;
 }
+
+int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                    const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host /* may be NULL */)
+{ return hotpath_dev_impl(idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches, id0, summary, dup_host, 0); }
+
+/* same, and the pair signatures (n_pairs x 3 uint64, DEVICE memory) for exact duplicate marking across ranks */
+int ssg_hotpath_dev_sig(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                        const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host, uint64_t *d_sig_out)
+{ return hotpath_dev_impl(idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches, id0, summary, dup_host, d_sig_out); }
 
 int ssg_index_set_names(ssg_index_t *ix, int n, const char *const *names)
 {
