@@ -21,6 +21,11 @@ speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(K
 	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/sam_format.o -o $@
 
+# random 64-byte-line gather probe (the roofline denominator of the FM-index kernels; tools/profile_round.sh runs it)
+probe: tools/dbg/gather_probe
+tools/dbg/gather_probe: tools/dbg/gather_probe.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
+
 # the executables speedseq.config names (reference bin/speedseq.config:13-14)
 tools: bin/bwa bin/samblaster
 bin/bwa: $(HOST)/bwa_main.cpp include/ssgpu.h speedseq_amd/libssgpu.so
