@@ -23,6 +23,9 @@
 #define SSG_WAVES_PER_WG 4
 /* the DP rows are chains of dependent DPP/VALU ops: they need >= 4 waves per SIMD to hide their own
  * latency, so the wave-per-read kernels cap their VGPR budget (cold scalar paths may spill) */
+#ifndef SSG_C2A_SCAN
+#define SSG_C2A_SCAN 2   /* chunks of 64 region keys fetched per round trip of the containment scan */
+#endif
 #ifndef SSG_C2A_WAVES_PER_SIMD
 #define SSG_C2A_WAVES_PER_SIMD 3   /* chain2aln: 168 VGPRs; measured 266 vs 282 ms against 4 waves (128 VGPRs) */
 #endif
@@ -172,6 +175,22 @@ SSG_DEVFN_COLD int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem
 
 #define SSG_MAX_BAND_TRY 2
 
+/* upstream mem_chain2aln: is seed s already covered by region (rb,re,qb,qe) of band w, first seed length seedlen0? */
+SSG_DEVFN int ssg_seed_in_region(const ssg_mem_opt_t &opt, const ssg_seed_t &s, int l_query, int64_t prb, int64_t pre, int pqb, int pqe, int pw, int psl)
+{
+	if (s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) return 0;
+	if (s.len - psl > .1 * l_query) return 0;
+	int64_t rd; int qd, w, max_gap;
+	qd = s.qbeg - pqb; rd = s.rbeg - prb;
+	max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+	w = max_gap < pw ? max_gap : pw;
+	if (qd - rd < w && rd - qd < w) return 1;
+	qd = pqe - (s.qbeg + s.len); rd = pre - (s.rbeg + s.len);
+	max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+	w = max_gap < pw ? max_gap : pw;
+	return qd - rd < w && rd - qd < w;
+}
+
 /*
  * One wavefront per read.  Per-read slices start at seed_off[r]: chains[], order[] (surviving chain
  * ids), srt[] (u64 work array), regs[] (capacity = #seeds of the read).  n_reg[r] receives the
@@ -194,6 +213,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	int av_n = 0, myerr = 0;
 	unsigned long long nc = 0;
 	const int nch = n_chain[r];
+	ssg_sdp_key_t *const ck = sdp_big->key;   /* (rb, re, qb, qe, w -> .score, seedlen0 -> .rid) of av[]: what the containment test reads */
 	unsigned long long t0 = 0, t1;
 #define SSG_PH(x) do { if (SSG_TUNING && ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
 	if (SSG_TUNING && ph) { t0 = ssg_clock(); ph[5] += nch; }
@@ -211,35 +231,43 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 		uint8_t *rseq = span <= SSG_TWIN_LDS ? tlds_w : tg;
 		if (xj.flag) { myerr = 1; continue; }
 		int fetched = 0;   /* the 1-byte-per-base window is only needed when a later seed of the chain is extended here */
-		SSG_LANE0(for (int t = 0; t < c.n; ++t) srt[t] = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
-		          ssg_introsort(srt, (long)c.n, ssg_u64_lt()));
+		if (c.n <= 64) { /* seeds by (score, index): distinct keys, rank = number of smaller keys, one lane per seed */
+			const int t = wv_lane();
+			const uint64_t key = t < c.n ? ((uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t) : ~0ull;
+			int rnk = 0;
+			for (int j = 0; j < c.n; ++j) rnk += (uint64_t)wv_get64((long long)key, j) < key;
+			ssg_wave_memsync();
+			if (t < c.n) srt[rnk] = key;
+			ssg_wave_memsync();
+		} else {
+			SSG_LANE0(for (int t = 0; t < c.n; ++t) srt[t] = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
+			          ssg_introsort(srt, (long)c.n, ssg_u64_lt()));
+		}
 		SSG_PH(0);
 		for (k = c.n - 1; k >= 0; --k) {
 			const ssg_seed_t s = seeds[cs[(uint32_t)srt[k]]];
-			{	/* is the seed contained in an earlier region?  64 regions per step; the scalar loop's first hit decides */
+			{	/* is the seed contained in an earlier region?  Compact keys of the regions (ck[]), SSG_C2A_SCAN x 64 regions per round
+				 * trip; the scalar loop's first hit decides */
 				int hit = av_n;
-				for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64) {
-					const int ii = i0 + wv_lane();
-					int h = 0;
-					if (ii < av_n) {
-						const ssg_alnreg_t *p = &av[ii];
-						const int64_t prb = p->rb, pre = p->re; const int pqb = p->qb, pqe = p->qe, pw = p->w, psl = p->seedlen0;
-						if (!(s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) && !(s.len - psl > .1 * l_query)) {
-							int64_t rd; int qd, w, max_gap;
-							qd = s.qbeg - pqb; rd = s.rbeg - prb;
-							max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
-							w = max_gap < pw ? max_gap : pw;
-							if (qd - rd < w && rd - qd < w) h = 1;
-							else {
-								qd = pqe - (s.qbeg + s.len); rd = pre - (s.rbeg + s.len);
-								max_gap = ssg_cal_max_gap(opt, qd < rd ? qd : (int)rd);
-								w = max_gap < pw ? max_gap : pw;
-								if (qd - rd < w && rd - qd < w) h = 1;
-							}
+				if (av_n <= SSG_SDP_BIG) {
+					for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64 * SSG_C2A_SCAN) {
+						ssg_sdp_key_t kk[SSG_C2A_SCAN];
+						SSG_UNROLL for (int u = 0; u < SSG_C2A_SCAN; ++u) { const int ii = i0 + u * 64 + wv_lane(); if (ii < av_n) kk[u] = ck[ii]; }
+						SSG_UNROLL for (int u = 0; u < SSG_C2A_SCAN; ++u) {
+							const int ii = i0 + u * 64 + wv_lane();
+							const int h = hit == av_n && ii < av_n && ssg_seed_in_region(opt, s, l_query, kk[u].rb, kk[u].re, kk[u].qb, kk[u].qe, kk[u].score, kk[u].rid);
+							const unsigned long long bal = wv_ballot(h);
+							if (bal && hit == av_n) hit = i0 + u * 64 + (int)__builtin_ctzll(bal);
 						}
 					}
-					const unsigned long long bal = wv_ballot(h);
-					if (bal) hit = i0 + __builtin_ctzll(bal);
+				} else {
+					for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64) {
+						const int ii = i0 + wv_lane();
+						int h = 0;
+						if (ii < av_n) { const ssg_alnreg_t *p = &av[ii]; h = ssg_seed_in_region(opt, s, l_query, p->rb, p->re, p->qb, p->qe, p->w, p->seedlen0); }
+						const unsigned long long bal = wv_ballot(h);
+						if (bal) hit = i0 + (int)__builtin_ctzll(bal);
+					}
 				}
 				i = hit;
 			}
@@ -308,7 +336,8 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 			a.w = aw[0] > aw[1] ? aw[0] : aw[1];
 			a.seedlen0 = s.len;
 			a.frac_rep = c.frac_rep;
-			SSG_LANE0(av[av_n] = a);
+			SSG_LANE0(av[av_n] = a;
+			          if (av_n < SSG_SDP_BIG) { ssg_sdp_key_t ka; ka.re = a.re; ka.rb = a.rb; ka.qb = a.qb; ka.qe = a.qe; ka.score = a.w; ka.rid = a.seedlen0; ck[av_n] = ka; });
 			++av_n;
 			SSG_PH(2);
 		}
