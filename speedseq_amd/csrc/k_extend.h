@@ -24,7 +24,7 @@
 /* the DP rows are chains of dependent DPP/VALU ops: they need >= 4 waves per SIMD to hide their own
  * latency, so the wave-per-read kernels cap their VGPR budget (cold scalar paths may spill) */
 #ifndef SSG_C2A_SCAN
-#define SSG_C2A_SCAN 2   /* chunks of 64 region keys fetched per round trip of the containment scan */
+#define SSG_C2A_SCAN 1   /* chunks of 64 region keys fetched per round trip of the containment scan (2 trips the backend's odd-aligned 64-bit reload bug at 168 VGPRs) */
 #endif
 #ifndef SSG_C2A_WAVES_PER_SIMD
 #define SSG_C2A_WAVES_PER_SIMD 3   /* chain2aln: 168 VGPRs; measured 266 vs 282 ms against 4 waves (128 VGPRs) */
@@ -218,20 +218,22 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 #define SSG_PH(x) do { if (SSG_TUNING && ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
 	if (SSG_TUNING && ph) { t0 = ssg_clock(); ph[5] += nch; }
 	for (int ci = 0; ci < nch; ++ci) {
-		const ssg_chain_t c = ch[ord[ci]];
-		const int32_t *cs = chain_seeds + c.first_seed;
+		/* the chain's record (ssg_k_ext_prep): window, best seed, seed count, contig, frac_rep -- no walk through chains[] / order[] */
+		const long gid = (long)chain_off[r] + ci;
+		const ssg_xjob_t xj = xjobs[gid];
+		struct { int n, rid; float frac_rep; } c = { xj.cn, xj.rid, xj.frac_rep };
+		const int32_t *cs = chain_seeds + xj.first_seed;
 		int i, k, max_off[2], aw[2];
 		int64_t rmax[2], tmp;
 		if (c.n == 0) continue;
 		/* window and first seed's extensions were prepared by ssg_k_ext_prep / ssg_k_ext_lane (k_extlane.h) */
-		const long gid = (long)chain_off[r] + ci;
-		const ssg_xjob_t xj = xjobs[gid];
 		rmax[0] = xj.rmax0; rmax[1] = xj.rmax1;
 		const int span = (int)(rmax[1] - rmax[0]);
 		uint8_t *rseq = span <= SSG_TWIN_LDS ? tlds_w : tg;
 		if (xj.flag) { myerr = 1; continue; }
 		int fetched = 0;   /* the 1-byte-per-base window is only needed when a later seed of the chain is extended here */
-		if (c.n <= 64) { /* seeds by (score, index): distinct keys, rank = number of smaller keys, one lane per seed */
+		if (c.n == 1) { /* nothing to order; the only seed is in the record */ }
+		else if (c.n <= 64) { /* seeds by (score, index): distinct keys, rank = number of smaller keys, one lane per seed */
 			const int t = wv_lane();
 			const uint64_t key = t < c.n ? ((uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t) : ~0ull;
 			int rnk = 0;
@@ -245,7 +247,9 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 		}
 		SSG_PH(0);
 		for (k = c.n - 1; k >= 0; --k) {
-			const ssg_seed_t s = seeds[cs[(uint32_t)srt[k]]];
+			ssg_seed_t s;
+			if (k == c.n - 1) { s.rbeg = xj.rbeg; s.qbeg = xj.qbeg; s.len = s.score = xj.len; s.next = -1; }   /* the best seed travels in the record */
+			else s = seeds[cs[(uint32_t)srt[k]]];
 			{	/* is the seed contained in an earlier region?  Compact keys of the regions (ck[]), SSG_C2A_SCAN x 64 regions per round
 				 * trip; the scalar loop's first hit decides */
 				int hit = av_n;
@@ -279,7 +283,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
 					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
 				}
-				if (i == c.n) { SSG_LANE0(srt[k] = 0); SSG_PH(1); continue; }
+				if (i == c.n) { if (c.n > 1) { SSG_LANE0(srt[k] = 0); } SSG_PH(1); continue; }
 			}
 			SSG_PH(1);
 			if (SSG_TUNING && ph) ++ph[6];
@@ -330,7 +334,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				else { a.qe = l_query; a.re = rmax[0] + re + x.gtle; a.truesc += x.gscore - sc0; }
 			} else { a.qe = l_query; a.re = s.rbeg + s.len; }
 			for (i = 0, a.seedcov = 0; i < c.n; ++i) {
-				const ssg_seed_t t = seeds[cs[i]];
+				const ssg_seed_t t = c.n == 1 ? s : seeds[cs[i]];
 				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) a.seedcov += t.len;
 			}
 			a.w = aw[0] > aw[1] ? aw[0] : aw[1];

@@ -25,7 +25,8 @@
 #define SSG_K_EXTLANE_H
 #include "k_sw.h"
 
-struct ssg_xjob_t { int64_t rbeg, rmax0, rmax1; int32_t read, flag; int16_t qbeg, len, l_query, seed_t; };   /* 40 bytes */
+/* everything ssg_k_chain2aln needs to know about a chain, in one record at a computable address (chain_off[r] + position) */
+struct ssg_xjob_t { int64_t rbeg, rmax0, rmax1; int32_t read, flag; int16_t qbeg, len, l_query, seed_t; int32_t cn, rid, first_seed; float frac_rep; };   /* 56 bytes */
 struct ssg_xres_t { int32_t score, qle, tle, gtle, gscore, max_off, aw, done; };                            /* 32 bytes */
 
 SSG_DEVFN int ssg_cal_max_gap2(const ssg_mem_opt_t &opt, int qlen)
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_m
 	const int64_t l_pac = ix.l_pac;
 	ssg_xjob_t jb;
 	jb.read = r; jb.flag = 0; jb.l_query = (int16_t)l_query; jb.rbeg = 0; jb.rmax0 = jb.rmax1 = 0; jb.qbeg = jb.len = 0; jb.seed_t = 0;
+	jb.cn = c.n; jb.rid = c.rid; jb.first_seed = c.first_seed; jb.frac_rep = c.frac_rep;
 	if (c.n == 0) { jb.flag = 2; jobs[g] = jb; key_l[g] = (uint64_t)255 << 32 | (uint64_t)g; key_r[g] = (uint64_t)255 << 32 | (uint64_t)g; return; }
 	int64_t rmax0 = l_pac << 1, rmax1 = 0;
 	uint64_t best = 0; int best_t = 0;
