@@ -23,6 +23,7 @@
 #define SSG_WAVES_PER_WG 4
 /* the DP rows are chains of dependent DPP/VALU ops: they need >= 4 waves per SIMD to hide their own
  * latency, so the wave-per-read kernels cap their VGPR budget (cold scalar paths may spill) */
+#define SSG_C2A_LKEYS 144   /* 144 x 24 bytes = sizeof(ssg_sdp_small_t) */
 #ifndef SSG_C2A_SCAN
 #define SSG_C2A_SCAN 1   /* chunks of 64 region keys fetched per round trip of the containment scan (2 trips the backend's odd-aligned 64-bit reload bug at 168 VGPRs) */
 #endif
@@ -214,6 +215,8 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	unsigned long long nc = 0;
 	const int nch = n_chain[r];
 	ssg_sdp_key_t *const ck = sdp_big->key;   /* (rb, re, qb, qe, w -> .score, seedlen0 -> .rid) of av[]: what the containment test reads */
+	/* the first SSG_C2A_LKEYS of them also in LDS (the re-sort's key area is idle until the read's last chain): 8 + 8 + 8 bytes */
+	int64_t *const lk_rb = (int64_t*)sdp_lds, *const lk_re = lk_rb + SSG_C2A_LKEYS; uint64_t *const lk_m = (uint64_t*)(lk_re + SSG_C2A_LKEYS);
 	unsigned long long t0 = 0, t1;
 #define SSG_PH(x) do { if (SSG_TUNING && ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
 	if (SSG_TUNING && ph) { t0 = ssg_clock(); ph[5] += nch; }
@@ -256,7 +259,13 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				if (av_n <= SSG_SDP_BIG) {
 					for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64 * SSG_C2A_SCAN) {
 						ssg_sdp_key_t kk[SSG_C2A_SCAN];
-						SSG_UNROLL for (int u = 0; u < SSG_C2A_SCAN; ++u) { const int ii = i0 + u * 64 + wv_lane(); if (ii < av_n) kk[u] = ck[ii]; }
+						SSG_UNROLL for (int u = 0; u < SSG_C2A_SCAN; ++u) {
+							const int ii = i0 + u * 64 + wv_lane();
+							if (ii < av_n) {
+								if (ii < SSG_C2A_LKEYS) { const uint64_t m = lk_m[ii]; kk[u].rb = lk_rb[ii]; kk[u].re = lk_re[ii]; kk[u].qb = (int)(m & 0xffff); kk[u].qe = (int)(m >> 16 & 0xffff); kk[u].score = (int)(m >> 32 & 0xffff); kk[u].rid = (int)(m >> 48); }
+								else kk[u] = ck[ii];
+							}
+						}
 						SSG_UNROLL for (int u = 0; u < SSG_C2A_SCAN; ++u) {
 							const int ii = i0 + u * 64 + wv_lane();
 							const int h = hit == av_n && ii < av_n && ssg_seed_in_region(opt, s, l_query, kk[u].rb, kk[u].re, kk[u].qb, kk[u].qe, kk[u].score, kk[u].rid);
@@ -341,7 +350,8 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 			a.seedlen0 = s.len;
 			a.frac_rep = c.frac_rep;
 			SSG_LANE0(av[av_n] = a;
-			          if (av_n < SSG_SDP_BIG) { ssg_sdp_key_t ka; ka.re = a.re; ka.rb = a.rb; ka.qb = a.qb; ka.qe = a.qe; ka.score = a.w; ka.rid = a.seedlen0; ck[av_n] = ka; });
+			          if (av_n < SSG_C2A_LKEYS) { lk_rb[av_n] = a.rb; lk_re[av_n] = a.re; lk_m[av_n] = (uint64_t)(uint16_t)a.qb | (uint64_t)(uint16_t)a.qe << 16 | (uint64_t)(uint16_t)a.w << 32 | (uint64_t)(uint16_t)a.seedlen0 << 48; }
+			          else if (av_n < SSG_SDP_BIG) { ssg_sdp_key_t ka; ka.re = a.re; ka.rb = a.rb; ka.qb = a.qb; ka.qe = a.qe; ka.score = a.w; ka.rid = a.seedlen0; ck[av_n] = ka; });
 			++av_n;
 			SSG_PH(2);
 		}
