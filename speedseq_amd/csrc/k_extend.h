@@ -369,13 +369,137 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	*cells += nc;
 }
 
+/*
+ * Light reads (a few chains, a few seeds each -- 98 % of a batch): one LANE per read.  With a wavefront per read the
+ * 2 M reads of a batch file through ~3000 resident waves, each read a chain of ~40 dependent memory round trips; one lane
+ * per read keeps 64 of those chains in flight per wave.  Everything is the scalar form of wv_chain2aln_read: the first
+ * seed of each chain takes its extension from ssg_k_ext_lane's results; a read that would need anything only the wave
+ * path has (an extension of a later seed, a patch alignment in mem_sort_dedup_patch, long lists) is left untouched
+ * and flagged for the wave kernel.
+ */
+#define SSG_C2A_LANE_CHAINS 6
+#define SSG_C2A_LANE_SEEDS 8
+__global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int64_t *read_off, const int64_t *seed_off,
+                                const ssg_seed_t *seeds, const int32_t *chain_seeds, const int32_t *n_chain, ssg_alnreg_t *regs, int32_t *n_reg,
+                                int32_t *err, const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r,
+                                uint8_t *todo /* out: 1 = the wave kernel has to do this read */)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const int nch = n_chain[r];
+	if (nch > SSG_C2A_LANE_CHAINS) { todo[r] = 1; return; }
+	const int l_query = (int)(read_off[r+1] - read_off[r]);
+	ssg_alnreg_t *av = regs + seed_off[r];
+	const int64_t l_pac = ix.l_pac;
+	int av_n = 0;
+	for (int ci = 0; ci < nch; ++ci) {
+		const long gid = (long)chain_off[r] + ci;
+		const ssg_xjob_t xj = xjobs[gid];
+		const int cn = xj.cn;
+		if (cn == 0) continue;
+		if (xj.flag || cn > SSG_C2A_LANE_SEEDS) { todo[r] = 1; return; }
+		const int32_t *cs = chain_seeds + xj.first_seed;
+		uint64_t srt[SSG_C2A_LANE_SEEDS];
+		if (cn > 1) { /* seeds by (score, index), ascending: distinct keys, insertion sort */
+			for (int t = 0; t < cn; ++t) {
+				const uint64_t key = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
+				int u = t;
+				SSG_UNROLL for (int v = SSG_C2A_LANE_SEEDS - 1; v > 0; --v) if (v <= t && u == v && srt[v-1] > key) { srt[v] = srt[v-1]; u = v - 1; }
+				SSG_UNROLL for (int v = 0; v < SSG_C2A_LANE_SEEDS; ++v) if (v == u) srt[v] = key;
+			}
+		}
+		for (int k = cn - 1; k >= 0; --k) {
+			ssg_seed_t s;
+			uint64_t sk = 0;
+			SSG_UNROLL for (int v = 0; v < SSG_C2A_LANE_SEEDS; ++v) if (v == k) sk = srt[v];
+			if (k == cn - 1) { s.rbeg = xj.rbeg; s.qbeg = xj.qbeg; s.len = s.score = xj.len; s.next = -1; }
+			else { if (sk == 0) continue; s = seeds[cs[(uint32_t)sk]]; }
+			int i;
+			for (i = 0; i < av_n; ++i) { const ssg_alnreg_t *p = &av[i]; if (ssg_seed_in_region(opt, s, l_query, p->rb, p->re, p->qb, p->qe, p->w, p->seedlen0)) break; }
+			if (i < av_n) {
+				for (i = k + 1; i < cn; ++i) {
+					uint64_t ski = 0;
+					SSG_UNROLL for (int v = 0; v < SSG_C2A_LANE_SEEDS; ++v) if (v == i) ski = srt[v];
+					if (ski == 0) continue;
+					ssg_seed_t t;
+					if (i == cn - 1) { t.rbeg = xj.rbeg; t.qbeg = xj.qbeg; t.len = t.score = xj.len; t.next = -1; } else t = seeds[cs[(uint32_t)ski]];
+					if (t.len < s.len * .95) continue;
+					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+				}
+				if (i == cn) { SSG_UNROLL for (int v = 0; v < SSG_C2A_LANE_SEEDS; ++v) if (v == k) srt[v] = 0; continue; }
+			}
+			if (k != cn - 1) { todo[r] = 1; return; }   /* a later seed has to be extended: wave kernel (nothing has been written that it does not rewrite) */
+			ssg_alnreg_t a;
+			a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = a.seedcov = a.secondary = a.secondary_all = a.n_comp = 0; a.hash = 0;
+			int aw0 = opt.w, aw1 = opt.w;
+			a.score = a.truesc = -1;
+			a.rid = xj.rid;
+			if (s.qbeg) {
+				const ssg_xres_t o = xres_l[gid];
+				aw0 = o.aw; a.score = o.score;
+				if (o.gscore <= 0 || o.gscore <= a.score - opt.pen_clip5) { a.qb = s.qbeg - o.qle; a.rb = s.rbeg - o.tle; a.truesc = a.score; }
+				else { a.qb = 0; a.rb = s.rbeg - o.gtle; a.truesc = o.gscore; }
+			} else { a.score = a.truesc = s.len * opt.a; a.qb = 0; a.rb = s.rbeg; }
+			if (s.qbeg + s.len != l_query) {
+				const int qe = s.qbeg + s.len, sc0 = a.score;
+				const int re = (int)(s.rbeg + s.len - xj.rmax0);
+				const ssg_xres_t o = xres_r[gid];
+				aw1 = o.aw; a.score = o.score;
+				if (o.gscore <= 0 || o.gscore <= a.score - opt.pen_clip3) { a.qe = qe + o.qle; a.re = xj.rmax0 + re + o.tle; a.truesc += a.score - sc0; }
+				else { a.qe = l_query; a.re = xj.rmax0 + re + o.gtle; a.truesc += o.gscore - sc0; }
+			} else { a.qe = l_query; a.re = s.rbeg + s.len; }
+			a.seedcov = 0;
+			for (i = 0; i < cn; ++i) {
+				const ssg_seed_t t = cn == 1 ? s : seeds[cs[i]];
+				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) a.seedcov += t.len;
+			}
+			a.w = aw0 > aw1 ? aw0 : aw1;
+			a.seedlen0 = s.len;
+			a.frac_rep = xj.frac_rep;
+			av[av_n++] = a;
+		}
+	}
+	/* upstream mem_sort_dedup_patch, serial; a pair of regions that would reach mem_patch_reg's alignment sends the read to the wave kernel */
+	if (av_n > 1) {
+		ssg_introsort(av, (long)av_n, ssg_reg_re_lt());
+		for (int i = 0; i < av_n; ++i) av[i].n_comp = 1;
+		for (int i = 1; i < av_n; ++i) {
+			ssg_alnreg_t *p = &av[i];
+			if (p->rid != av[i-1].rid || p->rb >= av[i-1].re + opt.max_chain_gap) continue;
+			for (int j = i - 1; j >= 0 && p->rid == av[j].rid && p->rb < av[j].re + opt.max_chain_gap; --j) {
+				ssg_alnreg_t *q = &av[j];
+				if (q->qe == q->qb) continue;
+				const int64_t or_ = q->re - p->rb, oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+				const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb, mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+				if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq) {
+					if (p->score < q->score) { p->qe = p->qb; break; }
+					else q->qe = q->qb;
+				} else if (q->rb < p->rb) {
+					ssg_sdp_key_t kq, kp; kq.re = q->re; kq.rb = q->rb; kq.qb = q->qb; kq.qe = q->qe; kp.re = p->re; kp.rb = p->rb; kp.qb = p->qb; kp.qe = p->qe;
+					if (ssg_patch_candidate(opt, l_pac, kq, kp)) { todo[r] = 1; return; }   /* regs[] is rebuilt from scratch by the wave kernel */
+				}
+			}
+		}
+		int m = 0;
+		for (int t = 0; t < av_n; ++t) if (av[t].qe > av[t].qb) { if (m != t) av[m++] = av[t]; else ++m; }
+		av_n = m;
+		ssg_introsort(av, (long)av_n, ssg_reg_sc_lt());
+		for (int t = 1; t < av_n; ++t) if (av[t].score == av[t-1].score && av[t].rb == av[t-1].rb && av[t].qb == av[t-1].qb) av[t].qe = av[t].qb;
+		int mm = av_n < 1 ? av_n : 1;
+		for (int t = 1; t < av_n; ++t) if (av[t].qe > av[t].qb) { if (mm != t) av[mm] = av[t]; ++mm; }
+		av_n = mm;
+	}   /* upstream returns n <= 1 untouched */
+	n_reg[r] = av_n; err[r] = 0; todo[r] = 0;
+}
+
 /* grid-strided: every resident wavefront owns one LDS window and one SSG_TWIN_GLB slab of tglb */
 __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
                                 uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue, int tune,
                                 ssg_sdp_big_t *sdpbig, ssg_alnreg_t *bcopy,
-                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r)
+                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, const uint8_t *todo)
 {
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
 	__shared__ ssg_sdp_small_t sdp[SSG_WAVES_PER_WG];
@@ -386,6 +510,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 	for (;;) { /* waves pull reads from a heaviest-first list: the per-read work is heavy-tailed (repeats) */
 		const long k = wv_queue_pop(queue);
 		if (k >= n_reads) break;
+		if (todo && !todo[work_order ? work_order[k] : k]) continue;   /* done by ssg_k_chain2aln_lane */
 		wv_chain2aln_read(ix, opt, work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
 		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r);
 	}
