@@ -219,7 +219,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	int64_t *const lk_rb = (int64_t*)sdp_lds, *const lk_re = lk_rb + SSG_C2A_LKEYS; uint64_t *const lk_m = (uint64_t*)(lk_re + SSG_C2A_LKEYS);
 	unsigned long long t0 = 0, t1;
 #define SSG_PH(x) do { if (SSG_TUNING && ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
-	if (SSG_TUNING && ph) { t0 = ssg_clock(); ph[5] += nch; }
+	if (SSG_TUNING && ph) { t0 = ssg_clock(); }
 	for (int ci = 0; ci < nch; ++ci) {
 		/* the chain's record (ssg_k_ext_prep): window, best seed, seed count, contig, frac_rep -- no walk through chains[] / order[] */
 		const long gid = (long)chain_off[r] + ci;
@@ -258,6 +258,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				int hit = av_n;
 				if (av_n <= SSG_SDP_BIG) {
 					for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64 * SSG_C2A_SCAN) {
+						if (SSG_TUNING && ph) ++ph[5];
 						ssg_sdp_key_t kk[SSG_C2A_SCAN];
 						SSG_UNROLL for (int u = 0; u < SSG_C2A_SCAN; ++u) {
 							const int ii = i0 + u * 64 + wv_lane();
@@ -295,7 +296,6 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				if (i == c.n) { if (c.n > 1) { SSG_LANE0(srt[k] = 0); } SSG_PH(1); continue; }
 			}
 			SSG_PH(1);
-			if (SSG_TUNING && ph) ++ph[6];
 			ssg_alnreg_t a;
 			a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = a.seedcov = a.secondary = a.secondary_all = a.n_comp = 0; a.hash = 0;
 			a.w = aw[0] = aw[1] = opt.w;
@@ -349,14 +349,14 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 			a.w = aw[0] > aw[1] ? aw[0] : aw[1];
 			a.seedlen0 = s.len;
 			a.frac_rep = c.frac_rep;
+			SSG_PH(7);
 			SSG_LANE0(av[av_n] = a;
 			          if (av_n < SSG_C2A_LKEYS) { lk_rb[av_n] = a.rb; lk_re[av_n] = a.re; lk_m[av_n] = (uint64_t)(uint16_t)a.qb | (uint64_t)(uint16_t)a.qe << 16 | (uint64_t)(uint16_t)a.w << 32 | (uint64_t)(uint16_t)a.seedlen0 << 48; }
 			          else if (av_n < SSG_SDP_BIG) { ssg_sdp_key_t ka; ka.re = a.re; ka.rb = a.rb; ka.qb = a.qb; ka.qe = a.qe; ka.score = a.w; ka.rid = a.seedlen0; ck[av_n] = ka; });
 			++av_n;
-			SSG_PH(2);
+			SSG_PH(6);
 		}
 	}
-	if (SSG_TUNING && ph) ph[7] += av_n;
 	{	/* mem_sort_dedup_patch: on compact keys unless a pair of regions has to be globally aligned (patched) */
 		int m = -1;
 		if (av_n <= SSG_SDP_SMALL) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2, l_pac);
@@ -382,12 +382,14 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int64_t *read_off, const int64_t *seed_off,
                                 const ssg_seed_t *seeds, const int32_t *chain_seeds, const int32_t *n_chain, ssg_alnreg_t *regs, int32_t *n_reg,
                                 int32_t *err, const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r,
-                                uint8_t *todo /* out: 1 = the wave kernel has to do this read */)
+                                const int32_t *work_order, int32_t *todo_list, unsigned int *n_todo /* out: reads the wave kernel has to do, roughly heaviest first */)
 {
-	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= n_reads) return;
+	const long g_ = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g_ >= n_reads) return;
+	const long r = work_order ? work_order[g_] : g_;
+#define SSG_C2A_TODO() do { todo_list[atomicAdd(n_todo, 1u)] = (int32_t)r; return; } while (0)
 	const int nch = n_chain[r];
-	if (nch > SSG_C2A_LANE_CHAINS) { todo[r] = 1; return; }
+	if (nch > SSG_C2A_LANE_CHAINS) SSG_C2A_TODO();
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
 	ssg_alnreg_t *av = regs + seed_off[r];
 	const int64_t l_pac = ix.l_pac;
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, 
 		const ssg_xjob_t xj = xjobs[gid];
 		const int cn = xj.cn;
 		if (cn == 0) continue;
-		if (xj.flag || cn > SSG_C2A_LANE_SEEDS) { todo[r] = 1; return; }
+		if (xj.flag || cn > SSG_C2A_LANE_SEEDS) SSG_C2A_TODO();
 		const int32_t *cs = chain_seeds + xj.first_seed;
 		uint64_t srt[SSG_C2A_LANE_SEEDS];
 		if (cn > 1) { /* seeds by (score, index), ascending: distinct keys, insertion sort */
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, 
 				}
 				if (i == cn) { SSG_UNROLL for (int v = 0; v < SSG_C2A_LANE_SEEDS; ++v) if (v == k) srt[v] = 0; continue; }
 			}
-			if (k != cn - 1) { todo[r] = 1; return; }   /* a later seed has to be extended: wave kernel (nothing has been written that it does not rewrite) */
+			if (k != cn - 1) SSG_C2A_TODO();   /* a later seed has to be extended: wave kernel (nothing has been written that it does not rewrite) */
 			ssg_alnreg_t a;
 			a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = a.seedcov = a.secondary = a.secondary_all = a.n_comp = 0; a.hash = 0;
 			int aw0 = opt.w, aw1 = opt.w;
@@ -477,7 +479,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, 
 					else q->qe = q->qb;
 				} else if (q->rb < p->rb) {
 					ssg_sdp_key_t kq, kp; kq.re = q->re; kq.rb = q->rb; kq.qb = q->qb; kq.qe = q->qe; kp.re = p->re; kp.rb = p->rb; kp.qb = p->qb; kp.qe = p->qe;
-					if (ssg_patch_candidate(opt, l_pac, kq, kp)) { todo[r] = 1; return; }   /* regs[] is rebuilt from scratch by the wave kernel */
+					if (ssg_patch_candidate(opt, l_pac, kq, kp)) SSG_C2A_TODO();   /* regs[] is rebuilt from scratch by the wave kernel */
 				}
 			}
 		}
@@ -490,7 +492,8 @@ __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, 
 		for (int t = 1; t < av_n; ++t) if (av[t].qe > av[t].qb) { if (mm != t) av[mm] = av[t]; ++mm; }
 		av_n = mm;
 	}   /* upstream returns n <= 1 untouched */
-	n_reg[r] = av_n; err[r] = 0; todo[r] = 0;
+	n_reg[r] = av_n; err[r] = 0;
+#undef SSG_C2A_TODO
 }
 
 /* grid-strided: every resident wavefront owns one LDS window and one SSG_TWIN_GLB slab of tglb */
@@ -499,7 +502,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
                                 uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue, int tune,
                                 ssg_sdp_big_t *sdpbig, ssg_alnreg_t *bcopy,
-                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, const uint8_t *todo)
+                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, const int32_t *todo_list, const unsigned int *n_todo)
 {
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
 	__shared__ ssg_sdp_small_t sdp[SSG_WAVES_PER_WG];
@@ -509,9 +512,8 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 	const unsigned long long k0 = tune ? ssg_clock() : 0;
 	for (;;) { /* waves pull reads from a heaviest-first list: the per-read work is heavy-tailed (repeats) */
 		const long k = wv_queue_pop(queue);
-		if (k >= n_reads) break;
-		if (todo && !todo[work_order ? work_order[k] : k]) continue;   /* done by ssg_k_chain2aln_lane */
-		wv_chain2aln_read(ix, opt, work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
+		if (k >= (todo_list ? (long)*n_todo : (long)n_reads)) break;
+		wv_chain2aln_read(ix, opt, todo_list ? todo_list[k] : work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
 		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r);
 	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);

@@ -526,13 +526,13 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		dbuf<uint8_t> d_tglb((size_t)nwg * wpb * SSG_TWIN_GLB); dbuf<ssg_sdp_big_t> d_sdpbig((size_t)nwg * wpb); dbuf<ssg_alnreg_t> d_bcopy((size_t)nwg * wpb * SSG_SDP_BIG);
 		CHKA(d_tglb); CHKA(d_sdpbig); CHKA(d_bcopy);
 		/* light reads one lane each; what is left (long lists, later-seed extensions, patches) one wave each */
-		dbuf<uint8_t> d_todo((size_t)n_reads);
-		CHKA(d_todo);
+		dbuf<int32_t> d_todo((size_t)n_reads); dbuf<unsigned int> d_ntodo(1);
+		CHKA(d_todo); CHKA(d_ntodo); CHK(d_ntodo.zero());
 		SSG_LAUNCH(ssg_k_chain2aln_lane, (n_reads + 63) / 64, 64, 0, idx->v, *opt, n_reads, d_off, o.seed_off.p, d_seeds.p, d_cseeds.p, d_nchain.p, o.regs.p, o.n_reg.p, d_err.p,
-		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_todo.p);
+		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_work.p, d_todo.p, d_ntodo.p);
 		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
 		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p, ssg_debug() >= 2, d_sdpbig.p, d_bcopy.p,
-		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_todo.p);
+		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_todo.p, d_ntodo.p);
 		CHK(rt_sync());
 	}
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_err.p, n_reads, 0, 0, 0, cc)); if (cc[4]) { ssg_err_msg = "reference window of a chain exceeds SSG_TWIN_GLB"; return SSG_EOVERFLOW; } }

@@ -20,6 +20,6 @@ print("pair_final (lane cycles): mark_primary=%d mem_pair+mapq=%d no_pairing=%d 
 s = max(1, sum(t[8:12]))
 print("pair_final fractions: mark_primary %.3f mem_pair %.3f no_pairing %.3f xa %.3f" % tuple(x / s for x in t[8:12]))
 print("matesw resort by n_in: <=8 %.2f  9..64 %.2f  >64 %.2f (of resort); resort/total %.2f sw/total %.2f" % (t[5]/max(1,t[2]), t[6]/max(1,t[2]), t[7]/max(1,t[2]), t[2]/max(1,t[4]), t[1]/max(1,t[4])))
-print("chain2aln (wave cycles): window+seedsort=%d contain=%d extend=%d resort=%d wave_total=%d | chains=%d ext_seeds=%d regions=%d" % tuple(t[16:24]))
+print("chain2aln (wave cycles): chain record+seed order=%d containment scan=%d (unused)=%d re-sort=%d wave_total=%d | scan chunks=%d append=%d results+build=%d" % tuple(t[16:24]))
 s = max(1, t[20])
-print("chain2aln fractions of wave time: window %.3f contain %.3f extend %.3f resort %.3f" % tuple(x / s for x in t[16:20]))
+print("chain2aln fractions of wave time: record %.3f scan %.3f resort %.3f append %.3f results+build %.3f; cycles per scan chunk %.0f" % (t[16]/s, t[17]/s, t[19]/s, t[22]/s, t[23]/s, t[17]/max(1,t[21])))
