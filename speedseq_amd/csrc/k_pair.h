@@ -169,10 +169,48 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
  * One wavefront per pair (grid-strided).  regs: per-read slices [reg_off[r], reg_off[r+1]) with
  * head-room for rescued hits; n_reg updated in place.
  */
+/* Which pairs can mem_matesw do anything for?  One lane per pair (heaviest-first order): a pair needs the rescue kernel iff
+ * some anchor (a hit within pen_unpaired of its read's best, the first max_matesw of them) has an orientation that is neither
+ * failed nor already served by a mate hit inside its insert-size window -- the test at the top of upstream mem_matesw, on
+ * the lists as they are before any rescue (if no anchor qualifies nothing is ever inserted, so the lists stay as they are).
+ * Pairs with long lists are passed on without looking.  The rescue kernel then pops a list of real work instead of 10^6
+ * pairs through one atomic counter. */
+__global__ void __launch_bounds__(64) ssg_k_matesw_need(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const int64_t *reg_off, const ssg_alnreg_t *regs,
+                                  const int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all, const int32_t *work_order,
+                                  int32_t *todo_list, unsigned int *n_todo)
+{
+	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_pairs) return;
+	const long p = work_order ? work_order[g] : g;
+	const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
+	const ssg_alnreg_t *a[2] = { regs + reg_off[2*p], regs + reg_off[2*p+1] };
+	const int an[2] = { n_reg[2*p], n_reg[2*p+1] };
+	int need = an[0] + an[1] > 32;
+	for (int i = 0; i < 2 && !need; ++i) {
+		if (an[i] == 0) continue;
+		const int thr = a[i][0].score - opt.pen_unpaired;
+		int cnt = 0;
+		for (int j = 0; j < an[i] && cnt < opt.max_matesw && !need; ++j) {
+			if (a[i][j].score < thr) continue;
+			++cnt;
+			int skip[4];
+			for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+			const int64_t arb = a[i][j].rb;
+			for (int m = 0; m < an[!i]; ++m) {
+				int64_t dist;
+				const int r = ssg_infer_dir(ix.l_pac, arb, a[!i][m].rb, &dist);
+				if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+			}
+			if (skip[0] + skip[1] + skip[2] + skip[3] != 4) need = 1;
+		}
+	}
+	if (need) todo_list[atomicAdd(n_todo, 1u)] = (int32_t)p;
+}
+
 __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const uint8_t *seq, const int64_t *read_off,
                              const int64_t *reg_off, ssg_alnreg_t *regs, int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                              ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue,
-                             const int32_t *work_order, unsigned int *queue, ssg_sdp_big_t *sdpbig)
+                             const int32_t *work_order, unsigned int *queue, ssg_sdp_big_t *sdpbig, const unsigned int *n_todo /* work_order[] holds this many pairs */)
 {
 	__shared__ uint8_t revlds[SSG_WAVES_PER_WG][256];
 	__shared__ ssg_sdp_lds_t sdplds[SSG_WAVES_PER_WG];
@@ -185,7 +223,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 	const unsigned long long k0 = ssg_clock();
 	for (;;) { /* pairs come from a heaviest-first queue (many candidate hits => many rescues) */
 		const long kq = wv_queue_pop(queue);
-		if (kq >= n_pairs) break;
+		if (kq >= (n_todo ? (long)*n_todo : (long)n_pairs)) break;
 		const long p = work_order ? work_order[kq] : kq;
 		const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
 		int myerr = 0, nb[2] = {0, 0};

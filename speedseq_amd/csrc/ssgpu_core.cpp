@@ -669,8 +669,11 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		long nw = nwg * wpb;
 		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB); dbuf<unsigned long long> d_bglb((size_t)nw * SSG_MS_BCAP); dbuf<ssg_alnreg_t> d_bcopy((size_t)nw * (128 + SSG_SDP_BIG)); dbuf<ssg_sdp_big_t> d_sdpbig((size_t)nw);
 		CHKA(d_tglb); CHKA(d_bglb); CHKA(d_bcopy); CHKA(d_sdpbig);
+		dbuf<int32_t> d_mtodo((size_t)n_pairs); dbuf<unsigned int> d_nmtodo(1);
+		CHKA(d_mtodo); CHKA(d_nmtodo); CHK(d_nmtodo.zero());
+		SSG_LAUNCH(ssg_k_matesw_need, (n_pairs + 63) / 64, 64, 0, idx->v, *opt, n_pairs, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_pw.p, d_mtodo.p, d_nmtodo.p);
 		SSG_LAUNCH(ssg_k_matesw, nwg, wpb * 64, 0, idx->v, *opt, n_pairs, d_seq.p, d_off.p, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p,
-		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1, d_pw.p, d_q.p, d_sdpbig.p);
+		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1, d_mtodo.p, d_q.p, d_sdpbig.p, d_nmtodo.p);
 		CHK(rt_sync());
 	}
 	STAGE("matesw");
