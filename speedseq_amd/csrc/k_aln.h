@@ -111,11 +111,70 @@ SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 	return score;
 }
 
+/* Records whose region aligns without gaps (upstream bwa_gen_cigar2's first branch: equal lengths and a zero band from
+ * infer_bw -- the bulk of a batch) need no DP: one LANE per record walks the bases once for NM / MD.  The rest (and any
+ * malformed request) goes to the wave-per-record kernel through todo_list. */
+__global__ void __launch_bounds__(64) ssg_k_reg2aln_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
+                              const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, int32_t *err, int32_t *todo_list, unsigned int *n_todo)
+{
+	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_req) return;
+	const ssg_alnreq_t rq = req[g];
+	ssg_aln_t *a = alns + g;
+	if (rq.reg < 0) { /* upstream mem_reg2aln(ar == 0) */
+		a->pos = -1; a->rid = -1; a->flag = rq.flag | 0x4; a->mapq = 0; a->NM = 0; a->score = 0; a->sub = 0; a->n_cigar = 0;
+		a->is_rev = 0; a->l_md = 0; a->reg_idx = -1; a->xa_cnt = 0; a->md[0] = 0;
+		return;
+	}
+	const ssg_alnreg_t ar = regs[rq.reg];
+	const int l_query = (int)(read_off[rq.read + 1] - read_off[rq.read]);
+	const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+	const int64_t rb = ar.rb, re = ar.re;
+	int w2 = -1;
+	if (!(re - rb > SSG_TWIN_GLB || rb < 0 || re > ix.l_pac << 1 || rb >= re || (rb < ix.l_pac && re > ix.l_pac))) {
+		const int tmp = ssg_infer_bw(lq, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
+		w2 = ssg_infer_bw(lq, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+		w2 = w2 > tmp ? w2 : tmp;
+		if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+	}
+	if (w2 != 0 || (int64_t)lq != re - rb) { todo_list[atomicAdd(n_todo, 1u)] = (int32_t)g; return; }
+	const uint8_t *query = seq + read_off[rq.read] + qb;
+	const bool rev = rb >= ix.l_pac;
+	const char *int2base = rev ? "TGCAN" : "ACGTN";
+	int u = 0, n_mm = 0, l = 0;
+	for (int i = 0; i < lq; ++i) {
+		const int tb = ssg_ref_base(ix, rev ? re - 1 - i : rb + i);
+		const int qc = rev ? query[lq - 1 - i] : query[i];
+		if (qc != tb) { l = ssg_put_int(a->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) a->md[l] = int2base[tb]; ++l; ++n_mm; u = 0; }
+		else ++u;
+	}
+	l = ssg_put_int(a->md, l, SSG_MAX_MD - 1, u);
+	a->md[l < SSG_MAX_MD - 1 ? l : SSG_MAX_MD - 1] = 0;
+	if (l >= SSG_MAX_MD - 1) atomicMax(err, 7);
+	int n_cigar = 1, is_rev;
+	a->cigar[0] = (uint32_t)lq << 4 | 0;
+	const int64_t pos = ssg_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+	if (qb != 0 || qe != l_query) {
+		const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+		if (clip5) { a->cigar[1] = a->cigar[0]; a->cigar[0] = (uint32_t)clip5 << 4 | 3; ++n_cigar; }
+		if (clip3) a->cigar[n_cigar++] = (uint32_t)clip3 << 4 | 3;
+	}
+	a->n_cigar = n_cigar; a->NM = n_mm; a->l_md = l;
+	a->rid = ssg_pos2rid(ix, pos);
+	a->pos = pos - ix.ctg_off[a->rid];
+	a->is_rev = is_rev;
+	a->flag = rq.flag | (ar.secondary >= 0 ? 0x100 : 0);
+	a->mapq = rq.mapq;
+	a->score = ar.score; a->sub = ar.sub > ar.csub ? ar.sub : ar.csub;
+	a->reg_idx = rq.owner; a->xa_cnt = 0; a->_pad = rq.kind;
+}
+
 #ifndef SSG_R2A_WAVES
 #define SSG_R2A_WAVES 4   /* 128 VGPRs: 28 ms against 40 at 2 waves/SIMD (211 VGPRs) */
 #endif
 __global__ void __launch_bounds__(256, SSG_R2A_WAVES) ssg_k_reg2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
-                              const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, uint8_t *tglb, uint8_t *zglb, int32_t *err, unsigned long long *cells)
+                              const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, uint8_t *tglb, uint8_t *zglb, int32_t *err, unsigned long long *cells,
+                              const int32_t *todo_list, const unsigned int *n_todo /* the records ssg_k_reg2aln_lane left (NULL: all n_req) */)
 {
 	__shared__ uint8_t tlds_[SSG_WAVES_PER_WG][SSG_TWIN_LDS], qlds_[SSG_WAVES_PER_WG][SSG_ALN_QLDS];
 	const int wslot = (int)(threadIdx.x >> 6);
@@ -123,7 +182,9 @@ __global__ void __launch_bounds__(256, SSG_R2A_WAVES) ssg_k_reg2aln(ssg_index_vi
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB, *z = zglb + wave0 * (long)SSG_Z_CAP;
 	unsigned long long nc = 0;
 	int myerr = 0;
-	for (long g = wave0; g < n_req; g += nwaves) {
+	const long n_work = todo_list ? (long)*n_todo : n_req;
+	for (long gw = wave0; gw < n_work; gw += nwaves) {
+		const long g = todo_list ? todo_list[gw] : gw;
 		const ssg_alnreq_t rq = req[g];
 		ssg_aln_t *a = alns + g;
 		if (rq.reg < 0) { /* upstream mem_reg2aln(ar == 0) */

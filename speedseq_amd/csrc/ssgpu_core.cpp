@@ -725,7 +725,11 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		long nw = nwg * wpb;
 		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB), d_z((size_t)nw * SSG_Z_CAP);
 		CHKA(d_tglb); CHKA(d_z);
-		SSG_LAUNCH(ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p);
+		/* gap-free records one lane each; the records that need the banded global alignment one wave each */
+		dbuf<int32_t> d_rtodo((size_t)nreq + 1); dbuf<unsigned int> d_nrtodo(1);
+		CHKA(d_rtodo); CHKA(d_nrtodo); CHK(d_nrtodo.zero());
+		SSG_LAUNCH(ssg_k_reg2aln_lane, (nreq + 63) / 64, 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_gerr.p, d_rtodo.p, d_nrtodo.p);
+		SSG_LAUNCH(ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
 		CHK(rt_sync());
 	}
 	STAGE("reg2aln");
