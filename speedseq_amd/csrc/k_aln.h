@@ -142,8 +142,10 @@ __global__ void __launch_bounds__(64) ssg_k_reg2aln_lane(ssg_index_view_t ix, ss
 	const bool rev = rb >= ix.l_pac;
 	const char *int2base = rev ? "TGCAN" : "ACGTN";
 	int u = 0, n_mm = 0, l = 0;
+	ssg_tgt_t tg;   /* reference bases from the 2-bit pac, 16 per aligned word (k_extlane.h) */
+	ssg_tgt_init(tg, ix, rev ? re - 1 : rb, rev ? -1 : 1);
 	for (int i = 0; i < lq; ++i) {
-		const int tb = ssg_ref_base(ix, rev ? re - 1 - i : rb + i);
+		const int tb = ssg_tgt_next(tg);
 		const int qc = rev ? query[lq - 1 - i] : query[i];
 		if (qc != tb) { l = ssg_put_int(a->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) a->md[l] = int2base[tb]; ++l; ++n_mm; u = 0; }
 		else ++u;
