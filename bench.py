@@ -272,7 +272,7 @@ def main():
                                "sw_cells_per_step": int(summary[3]) + int(summary[4]),
                                "sw_gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None}
         # ---- CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample ----
-        if a.cpu_sample > 0:
+        if a.cpu_sample > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
             try:
                 import oracle_py
                 import tempfile
