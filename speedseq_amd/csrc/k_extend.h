@@ -31,7 +31,7 @@
 #define SSG_C2A_WAVES_PER_SIMD 3   /* chain2aln: 168 VGPRs; measured 266 vs 282 ms against 4 waves (128 VGPRs) */
 #endif
 #ifndef SSG_SW_WAVES_PER_SIMD
-#define SSG_SW_WAVES_PER_SIMD 4
+#define SSG_SW_WAVES_PER_SIMD 3   /* mate rescue: 168 VGPRs; 91 ms against 106 at 4 waves (128 VGPRs) */
 #endif
 
 __global__ void __launch_bounds__(256) ssg_k_extend_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_ext_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,

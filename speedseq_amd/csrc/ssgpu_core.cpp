@@ -665,7 +665,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	dbuf<unsigned int> d_q(1);
 	CHKA(d_q); CHK(d_q.zero());
 	{	/* ---- mate rescue ---- */
-		long nwg = std::min<long>(((long)n_pairs + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
+		long nwg = std::min<long>(((long)n_pairs + wpb - 1) / wpb, 256 * SSG_SW_WAVES_PER_SIMD);
 		long nw = nwg * wpb;
 		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB); dbuf<unsigned long long> d_bglb((size_t)nw * SSG_MS_BCAP); dbuf<ssg_alnreg_t> d_bcopy((size_t)nw * (128 + SSG_SDP_BIG)); dbuf<ssg_sdp_big_t> d_sdpbig((size_t)nw);
 		CHKA(d_tglb); CHKA(d_bglb); CHKA(d_bcopy); CHKA(d_sdpbig);
