@@ -681,7 +681,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	CHKA(d_req);
 	{	/* ---- primary marking, pairing, MAPQ, record selection ---- */
 		const int ucap = 1024;
-		long nthr = std::min<long>(((long)n_pairs + 63) / 64 * 64, 32768);
+		long nthr = std::min<long>(((long)n_pairs + 63) / 64 * 64, 131072);   /* 8 waves/CU at 2 waves/SIMD (249 VGPRs); 16 KB of candidate scratch per lane */
 		dbuf<ssg_pair64_t> d_v((size_t)t2 + 1), d_u((size_t)nthr * ucap);
 		CHKA(d_v); CHKA(d_u);
 		/* d_pw is heaviest first: pairs with long region lists get a wavefront each (k_pairw.h), the rest a lane each */
