@@ -458,7 +458,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	}
 	STAGE("sal");
 	/* heaviest-first work order (seed count): the per-read cost of chaining / extension is heavy-tailed */
-	dbuf<int32_t> d_work(n_reads); dbuf<unsigned int> d_queue(4);
+	dbuf<int32_t> d_work(n_reads); dbuf<unsigned int> d_queue(8);
 	CHKA(d_work); CHKA(d_queue);
 	CHK(dev_order_desc(d_nseed.p, d_work.p, n_reads)); CHK(d_queue.zero());
 	if (ssg_debug() >= 2) { /* tuning: seeds-per-read histogram (power-of-two bins) */
@@ -468,25 +468,35 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		for (int r = 0; r < n_reads; ++r) { int b = 0; while ((1 << b) <= hns[r] && b < 19) ++b; ++cnt[b]; sum[b] += hns[r]; }
 		for (int b = 0; b < 20; ++b) if (cnt[b]) fprintf(stderr, "[ssg] seeds/read < %d: %ld reads, %ld seeds\n", 1 << b, cnt[b], sum[b]);
 	}
-	{	/* d_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), [nC,nC+nB) one wave per read with
-		 * 4096-chain LDS state, the next nA with 1024-chain state, the light rest one lane per read */
+	{	/* d_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), then one wave per read with 4096- / 2048- /
+		 * 1024-chain LDS state (147 / 74 / 37 KB: a 2048 block leaves room for two 1024 blocks on its CU), the light rest one lane per read */
 		const int T = env_int("SSG_CHAIN_WAVE_MIN", 64), TB = env_int("SSG_CHAIN_WAVE_BIG", 1024);
-		unsigned int cc[5];
-		CHK(dev_class_counts(d_nseed.p, n_reads, T, TB, 4096, cc));
-		const int nC = (int)cc[0], nB = (int)cc[1], nA = (int)cc[2];
+		auto count_gt = [&](int x, int *out) -> int { unsigned int c[5]; int rc = dev_class_counts(d_nseed.p, n_reads, 0, 0, x, c); *out = (int)c[0]; return rc; };
+		int g4096, g2048, gTB, gTBc, gT, gB4;
+		CHK(count_gt(4096, &g4096)); CHK(count_gt(2048, &g2048)); CHK(count_gt(TB, &gTB)); CHK(count_gt(TB < 4096 ? TB : 4096, &gTBc));
+		CHK(count_gt((T > 1 ? T : 1) - 1, &gT)); CHK(count_gt(TB > 2048 ? TB : 2048, &gB4));
+		const int nC = g4096;                                       /* s > 4096 */
+		const int nB4 = gB4 > g4096 ? gB4 - g4096 : 0;              /* max(TB, 2048) < s <= 4096 */
+		const int nB2 = TB < 2048 && gTB > g2048 ? gTB - g2048 : 0; /* TB < s <= 2048 */
+		const int nA = gT > gTBc ? gT - gTBc : 0;                   /* T <= s <= min(TB, 4096) */
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
 		if (nC) SSG_LAUNCH(ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		/* the three classes are independent and the two wave kernels fill a fraction of the chip each: overlap them */
-		ssg_fork(2);
-		if (nB) SSG_LAUNCH_ON(0, ssg_k_chain_wave<4096>, std::min(nB, 256), 64, 0, idx->v, *opt, nC, nC + nB, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		/* the classes are independent and each wave kernel fills a fraction of the chip: overlap them */
+		ssg_fork(3);
+		int r0 = nC;
+		if (nB4) SSG_LAUNCH_ON(0, ssg_k_chain_wave<4096>, std::min(nB4, 256), 64, 0, idx->v, *opt, r0, r0 + nB4, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 1);
-		if (nA) SSG_LAUNCH_ON(1, ssg_k_chain_wave<1024>, std::min(nA, 1024), 64, 0, idx->v, *opt, nC + nB, nC + nB + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		r0 += nB4;
+		if (nB2) SSG_LAUNCH_ON(1, ssg_k_chain_wave<2048>, std::min(nB2, 256), 64, 0, idx->v, *opt, r0, r0 + nB2, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 3);
+		r0 += nB2;
+		if (nA) SSG_LAUNCH_ON(2, ssg_k_chain_wave<1024>, std::min(nA, 1024), 64, 0, idx->v, *opt, r0, r0 + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 2);
-		const int r0 = nC + nB + nA;
+		r0 += nA;
 		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		ssg_join(2);
+		ssg_join(3);
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
