@@ -110,6 +110,17 @@ __global__ void ssg_k_class_counts(const int32_t *key, long n, int tA, int tB, i
 		if (b4) atomicAdd(&cnt[4], (unsigned)__popcll(b4));
 	}
 }
+/* cnt[i] = #(key > t[i]) for six thresholds at once; one atomic per wave and threshold */
+struct ssg_thr6_t { int t[6]; };
+__global__ void ssg_k_count_gt6(const int32_t *key, long n, ssg_thr6_t th, unsigned int *cnt)
+{
+	const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int k = i < n ? key[i] : (-2147483647 - 1);
+	SSG_UNROLL for (int j = 0; j < 6; ++j) {
+		const unsigned long long b = wv_ballot(k > th.t[j]);
+		if (b && wv_lane() == 0) atomicAdd(&cnt[j], (unsigned)__popcll(b));
+	}
+}
 /* pairing-stage capacities per read: region slots (own regions + up to 4 rescued hits per anchor of the mate) and request slots */
 __global__ void ssg_k_pair_caps(int n_reads, const int32_t *n_reg, int max_matesw, int32_t *cap2, int32_t *capq, int32_t *pair_key)
 {

@@ -471,10 +471,15 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	{	/* d_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), then one wave per read with 4096- / 2048- /
 		 * 1024-chain LDS state (147 / 74 / 37 KB: a 2048 block leaves room for two 1024 blocks on its CU), the light rest one lane per read */
 		const int T = env_int("SSG_CHAIN_WAVE_MIN", 64), TB = env_int("SSG_CHAIN_WAVE_BIG", 1024);
-		auto count_gt = [&](int x, int *out) -> int { unsigned int c[5]; int rc = dev_class_counts(d_nseed.p, n_reads, 0, 0, x, c); *out = (int)c[0]; return rc; };
 		int g4096, g2048, gTB, gTBc, gT, gB4;
-		CHK(count_gt(4096, &g4096)); CHK(count_gt(2048, &g2048)); CHK(count_gt(TB, &gTB)); CHK(count_gt(TB < 4096 ? TB : 4096, &gTBc));
-		CHK(count_gt((T > 1 ? T : 1) - 1, &gT)); CHK(count_gt(TB > 2048 ? TB : 2048, &gB4));
+		{	/* six "greater than" counts of the seeds-per-read array in one pass */
+			ssg_thr6_t th = { { 4096, 2048, TB, TB < 4096 ? TB : 4096, (T > 1 ? T : 1) - 1, TB > 2048 ? TB : 2048 } };
+			dbuf<unsigned int> d_c(8); unsigned int c[6];
+			CHKA(d_c); CHK(d_c.zero());
+			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
+			CHK(d_c.down(c, 6));
+			g4096 = (int)c[0]; g2048 = (int)c[1]; gTB = (int)c[2]; gTBc = (int)c[3]; gT = (int)c[4]; gB4 = (int)c[5];
+		}
 		const int nC = g4096;                                       /* s > 4096 */
 		const int nB4 = gB4 > g4096 ? gB4 - g4096 : 0;              /* max(TB, 2048) < s <= 4096 */
 		const int nB2 = TB < 2048 && gTB > g2048 ? gTB - g2048 : 0; /* TB < s <= 2048 */
