@@ -440,4 +440,15 @@ __global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, c
 	seeds[g] = s;
 	seed_rid[g] = ssg_intv2rid(ix, s.rbeg, s.rbeg + s.len);
 }
+/* Denser SA samples for the copy of the index that lives in HBM: entry j = SA[j * new_intv], taken from the on-disk samples
+ * (every old_intv rows) where they exist and by upstream's own LF walk (bwt_sa) elsewhere.  The .sa file keeps upstream's
+ * interval; HBM has room (2 GB per Gbp at interval 8), and ssg_k_sal's walk per seed drops from ~16 dependent rank
+ * queries to ~4 with identical results. */
+__global__ void ssg_k_sa_densify(ssg_index_view_t ix, int new_intv, uint64_t *sa_new, long n_new)
+{
+	const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_new) return;
+	const uint64_t r = (uint64_t)j * (uint64_t)new_intv;
+	sa_new[j] = (r % (uint64_t)ix.sa_intv) == 0 ? ix.sa[r / (uint64_t)ix.sa_intv] : ssg_bwt_sa(ix, r);
+}
 #endif

@@ -81,6 +81,21 @@ void ssg_mem_opt_init(ssg_mem_opt_t *o)
 }
 
 /* ------------------------------- index ------------------------------- */
+/* HBM-resident SA sampled more densely than the file (see ssg_k_sa_densify); SSG_SA_INTV overrides the interval (power of two) */
+static int densify_sa(ssg_index *ix)
+{
+	const int want = env_int("SSG_SA_INTV", 8);
+	if (want <= 0 || want >= ix->v.sa_intv || (want & (want - 1)) || ix->v.sa_intv % want) return 0;
+	const long n_new = (long)((ix->v.seq_len + (uint64_t)want) / (uint64_t)want);
+	uint64_t *d = (uint64_t*)rt_malloc((size_t)n_new * 8);
+	if (!d) { ssg_err_msg = "index allocation failed: dense SA"; return SSG_ENOMEM; }
+	SSG_LAUNCH(ssg_k_sa_densify, (n_new + 255) / 256, 256, 0, ix->v, want, d, n_new);
+	CHK(rt_sync());
+	rt_free(ix->sa);   /* the lower-density copy, when this index owns it */
+	ix->sa = d; ix->v.sa = d; ix->v.sa_intv = want;
+	return 0;
+}
+
 int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t primary, const uint64_t L2[5],
                           const uint64_t *sa, uint64_t n_sa, int sa_intv, const uint8_t *pac, int64_t l_pac,
                           int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out)
@@ -99,6 +114,7 @@ int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t prim
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
+	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }
@@ -163,6 +179,7 @@ int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
+	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }
