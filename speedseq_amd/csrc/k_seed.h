@@ -442,8 +442,8 @@ __global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, c
 }
 /* Denser SA samples for the copy of the index that lives in HBM: entry j = SA[j * new_intv], taken from the on-disk samples
  * (every old_intv rows) where they exist and by upstream's own LF walk (bwt_sa) elsewhere.  The .sa file keeps upstream's
- * interval; HBM has room (2 GB per Gbp at interval 8), and ssg_k_sal's walk per seed drops from ~16 dependent rank
- * queries to ~4 with identical results. */
+ * interval; HBM has room (4 GB per Gbp at interval 4), and ssg_k_sal's walk per seed drops from ~16 dependent rank
+ * queries to ~1.5 with identical results. */
 __global__ void ssg_k_sa_densify(ssg_index_view_t ix, int new_intv, uint64_t *sa_new, long n_new)
 {
 	const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
