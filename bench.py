@@ -236,8 +236,8 @@ def main():
             alg_bytes = {
                 # every bwt_extend = 2 rank queries = 2 x 64-byte Occ blocks (SURVEY 8d B_fm) + the read itself
                 "ssg_k_smem_quad": 128.0 * n_ext + nreads * rl,
-                # per seed: ~16 LF steps x one 64-byte block + one 8-byte SA sample + the 28-byte seed written
-                "ssg_k_sal": seeds * (16 * 64 + 8 + 28),
+                # per seed: ~1.5 LF steps (SA sampled every 4 rows in HBM) x one 64-byte block + one 8-byte SA sample + the 28-byte seed written
+                "ssg_k_sal": seeds * (1.5 * 64 + 8 + 28),
                 # per seed: 28 bytes read (seed + contig id); per read <= one 56-byte chain + 4-byte id per seed written
                 "ssg_k_chain": seeds * (28 + 56 + 4),
                 # per read: the read, one 2-bit reference window per chain (~l+400 bases), <= one 88-byte region per seed
@@ -255,9 +255,9 @@ def main():
             alg = alg_bytes.get(name, 0.0)
             ach = alg / (per_launch_ms * 1e-3) / 1e9
             # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
-            # profiles/r01f_pmc_traffic.json, calibrated on the random-gather probe: 1 KiB of FETCH_SIZE = 1024 B for 64-byte lines).
+            # profiles/r01g_pmc_traffic.json, calibrated on the random-gather probe: 1 KiB of FETCH_SIZE = 1024 B for 64-byte lines).
             # Only valid for the default workload the passes were run on.
-            pmc_traffic = {"ssg_k_smem_quad<1>": 164.9e9, "ssg_k_matesw": 24.6e9, "ssg_k_sal": 40.0e9, "ssg_k_chain2aln": 10.5e9, "ssg_k_reg2aln": 6.1e9}
+            pmc_traffic = {"ssg_k_smem_quad<1>": 164.9e9, "ssg_k_matesw": 24.6e9, "ssg_k_sal": 5.6e9, "ssg_k_chain2aln": 10.5e9, "ssg_k_reg2aln": 6.1e9}
             default_workload = a.pairs == 1000000 and abs(a.ref_mbp - 1000.0) < 1e-9 and rl == 150
             traffic = pmc_traffic.get(name) if default_workload else None
             sw_ms = sum(kern.get(k, (0, 1))[0] for k in ("ssg_k_matesw", "ssg_k_chain2aln", "ssg_k_reg2aln", "ssg_k_ext_lane<136>", "ssg_k_ext_lane<256>")) / a.steps
