@@ -42,6 +42,8 @@ void ssg_mem_opt_init(ssg_mem_opt_t *opt);
 /* ---- FM-index (upstream bwa_idx_load / bwa_idx_destroy, bwa.c; row a1) ---- */
 typedef struct ssg_index ssg_index_t;
 int ssg_index_load(const char *prefix, ssg_index_t **out);      /* reads prefix.{bwt,sa,pac,ann} into HBM */
+/* (All index constructors fill the HBM copy of the suffix-array samples to every 4th row -- SSG_SA_INTV overrides -- with
+ *  upstream's bwt_sa walk: 2 bytes of HBM per reference base, same locations, ~6x less work per located seed.) */
 int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t primary, const uint64_t L2[5],
                           const uint64_t *sa, uint64_t n_sa, int sa_intv,
                           const uint8_t *pac, int64_t l_pac,
