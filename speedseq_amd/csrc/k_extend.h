@@ -3,14 +3,16 @@
  *
  *   ssg_k_extend_jobs   one wavefront per ksw_extend2 job (stage-level entry point; also the
  *                       kernel the SW micro-benchmark and rocprof roofline line are taken from).
- *   ssg_k_chain2aln     one wavefront per read: upstream mem_chain2aln over the read's surviving
- *                       chains (left/right banded extension of each seed with the w, 2w retry),
- *                       then mem_sort_dedup_patch.  The per-read control flow is inherently
- *                       sequential (every seed is tested against the regions produced so far), so
- *                       it runs wave-uniform on all lanes while the DP rows run lane-parallel.
+ *   ssg_k_chain2aln_lane  one LANE per light read (a few chains with a few seeds): the scalar replay of upstream
+ *                       mem_chain2aln + mem_sort_dedup_patch on the extension results of k_extlane.h; reads it cannot
+ *                       finish go to a to-do list.
+ *   ssg_k_chain2aln     one WAVEFRONT per read of that list (long chain lists of repeat-heavy reads, later-seed
+ *                       extensions, patch alignments).  The per-read control flow is inherently sequential (every
+ *                       seed is tested against the regions produced so far): it runs wave-uniform while region scans,
+ *                       re-sorts and the DP rows of the rare in-place extension run lane-parallel.
  *
- * The reference window of a chain is decoded from the 2-bit .pac into LDS once per chain
- * (<= SSG_TWIN_LDS bases per wave; longer windows use a per-wave global slab).
+ * The first seed of every chain is extended ahead of time, one lane per extension (k_extlane.h); the 1-byte-per-base
+ * window of a chain is decoded from the 2-bit .pac only when a later seed has to be extended here.
  */
 #ifndef SSG_K_EXTEND_H
 #define SSG_K_EXTEND_H
@@ -21,8 +23,7 @@
 #define SSG_TWIN_LDS 1024
 #define SSG_TWIN_GLB 32768
 #define SSG_WAVES_PER_WG 4
-/* the DP rows are chains of dependent DPP/VALU ops: they need >= 4 waves per SIMD to hide their own
- * latency, so the wave-per-read kernels cap their VGPR budget (cold scalar paths may spill) */
+/* register budgets of the wave-per-item kernels are set by measurement (launch bounds below) */
 #define SSG_C2A_LKEYS 144   /* 144 x 24 bytes = sizeof(ssg_sdp_small_t) */
 #ifndef SSG_C2A_SCAN
 #define SSG_C2A_SCAN 1   /* chunks of 64 region keys fetched per round trip of the containment scan (2 trips the backend's odd-aligned 64-bit reload bug at 168 VGPRs) */
