@@ -103,3 +103,16 @@ def test_gpu_pair_wave_kernel_forced(gpu_lib, oracle, repeat_pe_prefix, monkeypa
     common.check_pe_sam(gpu_lib, oracle, 3000, seed=7)
     common.check_pe_edge_cases(gpu_lib, oracle)
     common.check_pe_sam(gpu_lib, oracle, 600, seed=8, prefix=repeat_pe_prefix)
+
+
+def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
+    # the quad-cooperative form (default for indexes beyond ~2 GB of rank blocks) and the nested-loop form, on the same reads
+    monkeypatch.setenv("SSG_SMEM_LPR", "4")
+    common.check_smem(gpu_lib, oracle, 1500, seed=31)
+    assert common.check_align1(gpu_lib, oracle, 1500, seed=32) > 1500
+    monkeypatch.delenv("SSG_SMEM_LPR")
+    monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")
+    common.check_smem(gpu_lib, oracle, 1500, seed=31)
+    monkeypatch.delenv("SSG_SMEM_KERNEL")
+    monkeypatch.setenv("SSG_SA_INTV", "32")   # the file's own suffix-array density
+    assert common.check_align1(gpu_lib, oracle, 1500, seed=33) > 1500

@@ -91,3 +91,14 @@ def test_emu_pair_wave_kernel_forced(emu_lib, oracle, repeat_pe_prefix, monkeypa
     common.check_pe_sam(emu_lib, oracle, 250, seed=7)
     common.check_pe_edge_cases(emu_lib, oracle)
     common.check_pe_sam(emu_lib, oracle, 120, seed=8, prefix=repeat_pe_prefix)
+
+
+def test_emu_smem_kernel_variants(emu_lib, oracle, monkeypatch):
+    monkeypatch.setenv("SSG_SMEM_LPR", "4")
+    common.check_smem(emu_lib, oracle, 150, seed=31)
+    monkeypatch.delenv("SSG_SMEM_LPR")
+    monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")
+    common.check_smem(emu_lib, oracle, 150, seed=31)
+    monkeypatch.delenv("SSG_SMEM_KERNEL")
+    monkeypatch.setenv("SSG_SA_INTV", "32")
+    assert common.check_align1(emu_lib, oracle, 150, seed=33) > 150
