@@ -86,7 +86,6 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 	ssg_chain_t *ch = chains + s0; int32_t *ord = order + s0, *kp = kept + s0, *cs = chain_seeds + s0;
 	ssg_seed_t *sd = seeds + s0; const int32_t *srid = seed_rid + s0;
 	int nc = 0, root = -1, ins_ctr = 0, i, k;
-	unsigned long long t0 = ssg_clock(), t1, ph[6] = {0,0,0,0,0,0};
 	/* frac_rep (upstream mem_chain head) */
 	int b = 0, e = 0, l_rep = 0, ni = n_intv[r] > 0 ? n_intv[r] : 0;
 	const ssg_intv_t *iv = intv + r * cap;
@@ -128,11 +127,9 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 		}
 	}
 	if (dbg_phase == 1) return;
-	t1 = ssg_clock(); ph[0] = t1 - t0; t0 = t1;
 	for (i = 0; i < nc; ++i) ord[i] = i;
 	{ ssg_chain_key_lt lt = { ch }; ssg_introsort(ord, (long)nc, lt); } /* == B-tree in-order traversal (keys are unique) */
 	if (dbg_phase == 2) return;
-	t1 = ssg_clock(); ph[1] = t1 - t0; t0 = t1;
 	float frac_rep = (float)l_rep / len;
 	/* upstream mem_chain_flt */
 	int n_chn = 0;
@@ -143,7 +140,6 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 		if (c.w >= opt.min_chain_weight) ord[n_chn++] = ord[i];
 	}
 	if (dbg_phase == 3) return;
-	t1 = ssg_clock(); ph[2] = t1 - t0; t0 = t1;
 	int n_out = 0;
 	if (n_chn > 0) {
 		{ ssg_chain_w_lt lt = { ch }; ssg_introsort(ord, (long)n_chn, lt); }
@@ -179,7 +175,6 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 		for (i = 0; i < n_chn; ++i) if (ch[ord[i]].kept != 0) ord[n_out++] = ord[i];
 	}
 	if (dbg_phase == 4) return;
-	t1 = ssg_clock(); ph[3] = t1 - t0; t0 = t1;
 	/* flatten the seed lists of the surviving chains */
 	int pos = 0;
 	for (i = 0; i < n_out; ++i) {

@@ -208,7 +208,6 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	const uint8_t *query = seq + read_off[r];
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
 	const long s0 = seed_off[r];
-	const ssg_chain_t *ch = chains + s0; const int32_t *ord = order + s0;
 	uint64_t *srt = srt_all + s0;
 	ssg_alnreg_t *av = regs + s0;
 	const int64_t l_pac = ix.l_pac;

@@ -35,7 +35,7 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
                         ssg_ivec_t &mem, ssg_ivec_t &va, ssg_ivec_t &vb)
 {
 	int i, j, c, ret;
-	ssg_intv_t ik, ok[4];
+	ssg_intv_t ik;
 	ssg_ivec_t *prev = &va, *curr = &vb, *swap;
 	mem.n = 0;
 	if (q[x] > 3) return x + 1;
@@ -86,7 +86,7 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
 SSG_DEVFN int ssg_seed_strategy1(const ssg_index_view_t &ix, int len, const uint8_t *q, int x, int min_len, uint64_t max_intv, ssg_intv_t &mem, unsigned &nx)
 {
 	int i, c;
-	ssg_intv_t ik, ok[4];
+	ssg_intv_t ik;
 	mem.x0 = mem.x1 = mem.x2 = mem.info = 0;
 	if (q[x] > 3) return x + 1;
 	ssg_set_intv(ix, q[x], ik);
