@@ -57,3 +57,32 @@ def test_global_dedup_two_ranks_gloo(oracle):
     assert seen.all()
     assert np.array_equal(got, oflags), (int(got.sum()), int(oflags.sum()))
     assert got.sum() > 50
+
+
+def test_device_signatures_through_the_exchange(emu_lib, oracle):
+    """The N>1 bench path: ssg_hotpath_dev_sig's signatures (device layout) through dist.global_markdup on one
+    rank must give the flags of the library's own duplicate marking."""
+    import ctypes as C
+    from speedseq_amd import capi, dist as sdist
+    n_pairs = 400
+    pairs, seqs, seq, off = common.sim_reads(n_pairs, 33, dup_frac=0.25)
+    idx = emu_lib.index_load(common.EXAMPLE_FA)
+    opt = emu_lib.opt_init()
+    pb = np.zeros(n_pairs, dtype=np.int32)
+    sig = np.zeros((n_pairs, 3), dtype=np.uint64)
+    dup_local = np.zeros(n_pairs, dtype=np.uint8)
+    summary = np.zeros(8, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    emu_lib._chk(emu_lib.l.ssg_hotpath_dev_sig(idx, p(opt), C.c_int(n_pairs), C.c_int(150), p(seq), p(off), p(pb), C.c_int(1), C.c_int64(0),
+                                               p(summary), p(dup_local), p(sig)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29400 + os.getpid() % 500)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        s = torch.from_numpy(sig.view(np.int64).copy())
+        valid = s[:, 0] != -1
+        dup = sdist.global_markdup(s, valid, torch.arange(n_pairs, dtype=torch.int64))
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(dup.numpy(), dup_local) and dup_local.sum() > 30
+    emu_lib.index_destroy(idx)
