@@ -488,24 +488,26 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	{	/* d_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), then one wave per read with 4096- / 2048- /
 		 * 1024-chain LDS state (147 / 74 / 37 KB: a 2048 block leaves room for two 1024 blocks on its CU), the light rest one lane per read */
 		const int T = env_int("SSG_CHAIN_WAVE_MIN", 64), TB = env_int("SSG_CHAIN_WAVE_BIG", 1024);
-		int g4096, g2048, gTB, gTBc, gT, gB4;
+		int g4096, g2048, gS, gTBc, gT, gB4;
+		const int Sp = 256 < (TB < 4096 ? TB : 4096) ? 256 : (TB < 4096 ? TB : 4096);   /* split of the 1024 class: up to 256 seeds -> 256-chain LDS state */
 		{	/* six "greater than" counts of the seeds-per-read array in one pass */
-			ssg_thr6_t th = { { 4096, 2048, TB, TB < 4096 ? TB : 4096, (T > 1 ? T : 1) - 1, TB > 2048 ? TB : 2048 } };
+			ssg_thr6_t th = { { 4096, 2048, Sp, TB < 4096 ? TB : 4096, (T > 1 ? T : 1) - 1, TB > 2048 ? TB : 2048 } };
 			dbuf<unsigned int> d_c(8); unsigned int c[6];
 			CHKA(d_c); CHK(d_c.zero());
 			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
 			CHK(d_c.down(c, 6));
-			g4096 = (int)c[0]; g2048 = (int)c[1]; gTB = (int)c[2]; gTBc = (int)c[3]; gT = (int)c[4]; gB4 = (int)c[5];
+			g4096 = (int)c[0]; g2048 = (int)c[1]; gS = (int)c[2] < (int)c[4] ? (int)c[2] : (int)c[4]; gTBc = (int)c[3]; gT = (int)c[4]; gB4 = (int)c[5];
 		}
 		const int nC = g4096;                                       /* s > 4096 */
 		const int nB4 = gB4 > g4096 ? gB4 - g4096 : 0;              /* max(TB, 2048) < s <= 4096 */
-		const int nB2 = TB < 2048 && gTB > g2048 ? gTB - g2048 : 0; /* TB < s <= 2048 */
-		const int nA = gT > gTBc ? gT - gTBc : 0;                   /* T <= s <= min(TB, 4096) */
+		const int nB2 = TB < 2048 && gTBc > g2048 ? gTBc - g2048 : 0; /* TB < s <= 2048 */
+		const int nA = gS > gTBc ? gS - gTBc : 0;                   /* max(T, 257) <= s <= min(TB, 4096) */
+		const int nA1 = gT > gS ? gT - gS : 0;                      /* T <= s <= 256 */
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
 		if (nC) SSG_LAUNCH(ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
 		/* the classes are independent and each wave kernel fills a fraction of the chip: overlap them */
-		ssg_fork(3);
+		ssg_fork(4);
 		int r0 = nC;
 		if (nB4) SSG_LAUNCH_ON(0, ssg_k_chain_wave<4096>, std::min(nB4, 256), 64, 0, idx->v, *opt, r0, r0 + nB4, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 1);
@@ -516,9 +518,12 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		if (nA) SSG_LAUNCH_ON(2, ssg_k_chain_wave<1024>, std::min(nA, 1024), 64, 0, idx->v, *opt, r0, r0 + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 2);
 		r0 += nA;
+		if (nA1) SSG_LAUNCH_ON(3, ssg_k_chain_wave<256>, std::min(nA1, 4096), 64, 0, idx->v, *opt, r0, r0 + nA1, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 4);
+		r0 += nA1;
 		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		ssg_join(3);
+		ssg_join(4);
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
