@@ -17,8 +17,7 @@
  *     norm for repeats, and the unstable tie order selects what is kept) on packed keys in LDS;
  *   - the filter tests chain i against 64 kept chains at a time: ballot of the `break' condition,
  *     side effects applied only to the kept chains up to the first break, exactly as the scalar loop.
- * Per-chain LDS footprint is 36 bytes; CAP = 1024 runs four reads per CU, CAP = 4096 (the 0.1 %
- * heaviest reads) one per CU.
+ * Per-chain LDS footprint is 31 bytes; CAP = 256 / 1024 / 2048 / 4096 run 20 / 5 / 2 / 1 reads per CU.
  */
 #ifndef SSG_K_CHAINW_H
 #define SSG_K_CHAINW_H
@@ -27,10 +26,11 @@
 template <int CAP> struct ssg_chw_lds_t {
 	int64_t a8[CAP];   /* insertion: rbeg of the chain's last seed [chain id] | weights [chain id] | filter: kept w<<32 | kept sorted idx<<16 | first shadowed */
 	int64_t b8[CAP];   /* insertion: chain positions, sorted                  | sort/filter: w<<32 | chain id, sorted by w */
-	int32_t rid[CAP];  /* insertion: contig of the chain [chain id]           | filter: kept state [sorted idx] */
+	int16_t rid[CAP];  /* insertion: contig of the chain [chain id] (< 32768 contigs: host-checked) | filter: kept state [sorted idx] */
 	uint16_t ids[CAP]; /* insertion: chain id of sorted slot                  | filter: query begin of kept chain */
 	uint16_t ls[CAP];  /* last seed [chain id]                                | filter: query end of kept chain */
-	uint16_t fq[CAP], lq[CAP], ll[CAP], n[CAP], fs[CAP]; /* [chain id]: qbeg of first seed, qbeg/len of last seed, #seeds, first seed */
+	uint16_t n[CAP], fs[CAP];            /* [chain id]: #seeds, first seed */
+	uint8_t fq[CAP], lq[CAP], ll[CAP];   /* [chain id]: qbeg of first seed, qbeg/len of last seed (reads are < 255 bases) */
 	uint16_t nx[CAP];  /* [seed]: next seed of the same chain */
 };
 
@@ -99,7 +99,7 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 				}
 				if (res == 2) {
 					ssg_wave_ldssync();
-					if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.lq[c] = (uint16_t)qbeg; L.ll[c] = (uint16_t)len; ++L.n[c]; }
+					if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.lq[c] = (uint8_t)qbeg; L.ll[c] = (uint8_t)len; ++L.n[c]; }
 					ssg_wave_ldssync();
 				}
 			}
@@ -115,8 +115,8 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 					if (idx < hi) { L.b8[idx + 1] = v; L.ids[idx + 1] = w; }
 				}
 				if (lane == 0) {
-					L.b8[slot] = rbeg; L.ids[slot] = (uint16_t)nc; L.a8[nc] = rbeg; L.fq[nc] = L.lq[nc] = (uint16_t)qbeg; L.ll[nc] = (uint16_t)len;
-					L.n[nc] = 1; L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = prid;
+					L.b8[slot] = rbeg; L.ids[slot] = (uint16_t)nc; L.a8[nc] = rbeg; L.fq[nc] = L.lq[nc] = (uint8_t)qbeg; L.ll[nc] = (uint8_t)len;
+					L.n[nc] = 1; L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
 				}
 				ssg_wave_ldssync();
 				++nc;

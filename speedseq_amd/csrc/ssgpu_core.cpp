@@ -487,7 +487,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	}
 	{	/* d_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), then one wave per read with 4096- / 2048- /
 		 * 1024-chain LDS state (147 / 74 / 37 KB: a 2048 block leaves room for two 1024 blocks on its CU), the light rest one lane per read */
-		const int T = env_int("SSG_CHAIN_WAVE_MIN", 64), TB = env_int("SSG_CHAIN_WAVE_BIG", 1024);
+		/* (the LDS kernels keep contig ids in 16 bits: an index with more contigs chains every read in the lane kernel) */
+		const int T = idx->v.n_ctg > 32767 ? 1 << 30 : env_int("SSG_CHAIN_WAVE_MIN", 64), TB = idx->v.n_ctg > 32767 ? 1 << 30 : env_int("SSG_CHAIN_WAVE_BIG", 1024);
 		int g4096, g2048, gS, gTBc, gT, gB4;
 		const int Sp = 256 < (TB < 4096 ? TB : 4096) ? 256 : (TB < 4096 ? TB : 4096);   /* split of the 1024 class: up to 256 seeds -> 256-chain LDS state */
 		{	/* six "greater than" counts of the seeds-per-read array in one pass */
@@ -512,13 +513,13 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		if (nB4) SSG_LAUNCH_ON(0, ssg_k_chain_wave<4096>, std::min(nB4, 256), 64, 0, idx->v, *opt, r0, r0 + nB4, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 1);
 		r0 += nB4;
-		if (nB2) SSG_LAUNCH_ON(1, ssg_k_chain_wave<2048>, std::min(nB2, 256), 64, 0, idx->v, *opt, r0, r0 + nB2, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		if (nB2) SSG_LAUNCH_ON(1, ssg_k_chain_wave<2048>, std::min(nB2, 512), 64, 0, idx->v, *opt, r0, r0 + nB2, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 3);
 		r0 += nB2;
-		if (nA) SSG_LAUNCH_ON(2, ssg_k_chain_wave<1024>, std::min(nA, 1024), 64, 0, idx->v, *opt, r0, r0 + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		if (nA) SSG_LAUNCH_ON(2, ssg_k_chain_wave<1024>, std::min(nA, 1280), 64, 0, idx->v, *opt, r0, r0 + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 2);
 		r0 += nA;
-		if (nA1) SSG_LAUNCH_ON(3, ssg_k_chain_wave<256>, std::min(nA1, 4096), 64, 0, idx->v, *opt, r0, r0 + nA1, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
+		if (nA1) SSG_LAUNCH_ON(3, ssg_k_chain_wave<256>, std::min(nA1, 5120), 64, 0, idx->v, *opt, r0, r0 + nA1, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
 		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 4);
 		r0 += nA1;
 		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
