@@ -9,10 +9,15 @@ HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -W
 all: lib tools oracle emu
 
 lib: speedseq_amd/libssgpu.so
-speedseq_amd/libssgpu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
-	$(HIPCC) $(HIPFLAGS) -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core.o
-	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core.o $(CSRC)/sam_format.o -o $@
+$(CSRC)/ssgpu_core.o: $(CSRC)/ssgpu_core.cpp $(KHDRS)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(CSRC)/ssg_index_build.o: $(CSRC)/ssg_index_build.cpp $(CSRC)/k_index.h $(CSRC)/ssg_prim.h $(CSRC)/ssg_rt.h $(CSRC)/ssg_dev.h $(CSRC)/ssg_index_int.h include/ssgpu.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp include/ssgpu.h $(CSRC)/ssg_types.h
+	$(CXX) -O2 -std=c++17 -fPIC -c $< -o $@
+LIBOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o
+speedseq_amd/libssgpu.so: $(LIBOBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(LIBOBJS) -o $@ -lz
 
 # instrumented build (device phase counters, tools/dbg/phase.py); never the default library
 tune: speedseq_amd/libssgpu_tune.so
@@ -38,9 +43,9 @@ oracle:
 
 # host emulation of the HIP execution model: same kernel + host sources, CPU-side tests only
 emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu
-tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
+tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
-		$(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread
+		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
 tests/emu/bwa_emu: $(HOST)/bwa_main.cpp include/ssgpu.h tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -Wl,-rpath,'$$ORIGIN'
 tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp include/ssgpu.h tests/emu/libssgpu_emu.so

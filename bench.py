@@ -9,8 +9,11 @@ in HBM.  Reads shard across ranks with no data-path collective (weak scaling: ev
 own pairs against its own index replica).
 
 The reference FASTA the metric names (GRCh37) is not available offline; the workload uses a seeded
-synthetic reference with GRCh37's contig-length proportions and planted repeat families, scaled to
---ref-mbp (stated in config.workload).  The FM-index is built on the GPU before the timed region.
+synthetic reference of GRCh37's size and contig-length proportions (order-6 Markov model of the
+bundled chr20 slice + planted repeat families; stated in config.workload).  The FM-index
+is built on the GPU (`bwa index` kernels, k_index.h) before the timed region.  After the timed region
+a sample of the same batch is aligned by the CPU oracle and compared record by record with the GPU's
+output (parity gate: a mismatch voids `value`); the same oracle run is the reported cpu_baseline.
 """
 import argparse
 import ctypes as C
@@ -33,26 +36,59 @@ GRCH37 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 1591
 GRCH37_NAMES = [str(i) for i in range(1, 23)] + ["X", "Y", "MT"]
 
 
-def synth_reference(total_len, seed, dev):
+def markov_table(order):
+    """order-k transition CDF (4^k x 3 thresholds) trained on the reference's bundled chr20 slice (tests/golden/chr20_slice.fa,
+    a copy of /root/reference/example/data/*.fasta), add-one smoothed"""
+    import simreads
+    codes = np.concatenate([c for _, c in simreads.read_fasta(os.path.join(ROOT, "tests", "golden", "chr20_slice.fa"))]).astype(np.int64)
+    codes = codes[codes < 4]
+    ctx = np.zeros(codes.size - order, dtype=np.int64)
+    for k in range(order):
+        ctx = ctx * 4 + codes[k:codes.size - order + k]
+    cnt = np.ones((4 ** order, 4), dtype=np.float64)
+    np.add.at(cnt, (ctx, codes[order:]), 1.0)
+    cdf = np.cumsum(cnt / cnt.sum(1, keepdims=True), axis=1)
+    return cdf[:, :3].astype(np.float32)
+
+
+def synth_reference(total_len, seed, dev, order=6):
+    """25 contigs with GRCh37's length proportions; sequence from a seeded order-k Markov model of the
+    bundled chr20 slice; >= 5 % of the bases planted as repeat families of 10..10^4 copies at 0-10 % divergence, both strands."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     lens = [max(2000, int(x * total_len / sum(GRCH37))) for x in GRCH37]
     L = sum(lens)
-    ref = torch.randint(0, 4, (L,), dtype=torch.uint8, device=dev, generator=g)
+    cdf = torch.from_numpy(markov_table(order)).to(dev)
+    S = 1 << 20 if L >= (1 << 26) else 1 << 12           # independent streams, each a contiguous stretch of the genome
+    steps = -(-L // S)
+    out = torch.empty((steps, S), dtype=torch.uint8, device=dev)
+    ctx = torch.randint(0, 4 ** order, (S,), device=dev, generator=g)
+    mask = 4 ** order - 1
+    for t in range(steps):
+        u = torch.rand(S, device=dev, generator=g)
+        th = cdf[ctx]
+        nxt = (u > th[:, 0]).long() + (u > th[:, 1]).long() + (u > th[:, 2]).long()
+        out[t] = nxt.to(torch.uint8)
+        ctx = ((ctx << 2) | nxt) & mask
+    ref = out.t().contiguous().reshape(-1)[:L].clone()
+    del out
     rng = np.random.default_rng(seed)
-    fams = [torch.randint(0, 4, (int(l),), dtype=torch.uint8, device=dev, generator=g) for l in rng.integers(200, 3000, size=16)]
-    planted = 0
+    planted, n_fam = 0, 0
     while planted < 0.05 * L:
-        f = fams[int(rng.integers(0, len(fams)))].clone()
-        div = rng.random() * 0.1
-        m = torch.rand(f.numel(), device=dev, generator=g) < div
-        f[m] = torch.randint(0, 4, (int(m.sum()),), dtype=torch.uint8, device=dev, generator=g)
-        if rng.random() < 0.5:
-            f = (3 - f).flip(0)
-        p = int(rng.integers(0, L - f.numel()))
-        ref[p:p + f.numel()] = f
-        planted += f.numel()
-    return ref, lens
+        flen = int(rng.integers(200, 3000))
+        copies = int(min(10 ** rng.uniform(1, 4), max(10, 0.01 * L / flen)))
+        fam = torch.randint(0, 4, (flen,), dtype=torch.uint8, device=dev, generator=g)
+        c = fam[None, :].repeat(copies, 1)
+        div = torch.rand(copies, 1, device=dev, generator=g) * 0.1
+        m = torch.rand(copies, flen, device=dev, generator=g) < div
+        c = torch.where(m, torch.randint(0, 4, (copies, flen), dtype=torch.uint8, device=dev, generator=g), c)
+        rev = torch.rand(copies, device=dev, generator=g) < 0.5
+        c = torch.where(rev[:, None], (3 - c).flip(1), c)
+        pos = (torch.rand(copies, device=dev, generator=g, dtype=torch.float64) * (L - flen)).long()
+        ref[(pos[:, None] + torch.arange(flen, device=dev)[None, :]).reshape(-1)] = c.reshape(-1)
+        planted += copies * flen
+        n_fam += 1
+    return ref, lens, n_fam
 
 
 def simulate_pairs(ref, lens, n_pairs, rl, seed, dev, ins_mean=400, ins_std=50, err=0.005, dup_frac=0.05, disc_frac=0.01, chim_frac=0.01, indel_frac=0.07):
@@ -115,16 +151,27 @@ def bwa_batches(n_pairs, rl, threads, chunk=10000000):
     return pb.astype(np.int32), int(pb[-1]) + 1
 
 
+def gpu_sample_sam(lib, idx, opt, hs, hoff, names, contig_names, lens):
+    """The product path for the parity sample: ssg_mem_process_pairs -> ssg_sam_format -> ssg_sbl_markdup (all through the C ABI)."""
+    import common
+    from speedseq_amd import capi
+    res = capi.mem_process_pairs(lib, idx, opt, hs, hoff, id0=0)
+    text, _ = capi.sam_format(lib, idx, opt, res, names, hs, hoff, None, "")
+    res.close()
+    dup = capi.sbl_markdup(lib, common.sam_primary_ends(text, contig_names))
+    return text, dup
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step (BASELINE.json configs[1]: 1M)")
-    ap.add_argument("--ref-mbp", type=float, default=1000.0, help="synthetic reference size; the index builder handles < 1073 Mbp this round (GRCh37 = 3100)")
+    ap.add_argument("--ref-mbp", type=float, default=3100.0, help="synthetic GRCh37-shaped reference size (GRCh37 = 3100)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--bwa-threads", type=int, default=16, help="the -t whose batch boundaries (insert-size model scope) are reproduced")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload aligned by the CPU oracle: parity gate + cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
 
@@ -150,22 +197,19 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from speedseq_amd import capi, index_build
+    from speedseq_amd import capi
     lib = capi.Lib()
     lib._chk(lib.l.ssg_set_device(C.c_int(local)))
     opt = lib.opt_init()
 
     t0 = time.time()
-    ref, lens = synth_reference(int(a.ref_mbp * 1e6), 20150810, dev)
-    ix = index_build.build_index_arrays(ref)
-    bwt = ix["bwt"]
-    # device arrays in the dtypes the kernels read: u32 words, u64 SA samples, u8 pac
-    d_bwt = torch.zeros(bwt.numel() + 64, dtype=torch.int32, device=dev)
-    d_bwt[:bwt.numel()] = torch.where(bwt >= (1 << 31), bwt - (1 << 32), bwt).to(torch.int32)
-    d_sa = ix["sa"].contiguous()
-    d_pac = ix["pac"].contiguous()
+    ref, lens, n_fam = synth_reference(int(a.ref_mbp * 1e6), 20150810, dev)
+    torch.cuda.synchronize()
+    t_ref = time.time() - t0
     ctg_off = np.concatenate([[0], np.cumsum(lens)])[:-1]
-    idx = capi.index_from_device(lib, d_bwt.data_ptr(), ix["primary"], ix["L2"], d_sa.data_ptr(), d_pac.data_ptr(), ix["l_pac"], ctg_off, lens)
+    t0 = time.time()
+    torch.cuda.empty_cache()
+    idx = lib.index_build_dev(ref.data_ptr(), int(ref.numel()), ctg_off, lens, GRCH37_NAMES)   # `bwa index` on the device (k_index.h)
     t_index = time.time() - t0
 
     rl = a.read_len
@@ -174,6 +218,8 @@ def main():
     d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
     pb, n_batches = bwa_batches(a.pairs, rl, a.bwa_threads)
     d_pb = torch.from_numpy(pb).to(dev)
+    del ref
+    torch.cuda.empty_cache()
     torch.cuda.synchronize()
 
     d_sig = torch.empty((a.pairs, 3), dtype=torch.int64, device=dev) if multi else None
@@ -215,15 +261,17 @@ def main():
     if prof:
         lib.l.ssg_prof_enable(C.c_int(0))
 
+    workload = ("%d synthetic 2x%d bp PE pairs per GPU vs a seeded synthetic GRCh37-shaped reference of %.0f Mbp (25 contigs, order-6 Markov "
+                "model of the bundled chr20 slice + %d planted repeat families of 10..10^4 copies at 0-10%% divergence = 5%% of the bases; "
+                "GRCh37 itself is not available offline), bwa-mem -t %d batch boundaries" % (a.pairs, rl, sum(lens) / 1e6, n_fam, a.bwa_threads))
     out = {
         "metric": "paired reads aligned+dup-marked/sec", "value": world * a.pairs * a.steps / dt, "unit": "pairs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "%d synthetic 2x%d bp PE pairs per GPU vs a seeded synthetic GRCh37-shaped reference of %.0f Mbp "
-                               "(25 contigs, 5%% planted repeats; GRCh37 itself is not available offline), bwa-mem -t %d batch boundaries"
-                               % (a.pairs, rl, sum(lens) / 1e6, a.bwa_threads),
-                   "pairs_per_gpu": a.pairs, "read_len": rl, "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2),
+        "config": {"workload": workload,
+                   "pairs_per_gpu": a.pairs, "read_len": rl, "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2), "ref_synth_s": round(t_ref, 2),
                    "records": int(summary[0]), "dup_pairs": n_dup_global[0] if multi else int(summary[1]), "dup_pairs_local_view": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
+                   "bwt_extends": int(summary[6]), "chains": int(summary[7]),
                    "dedup_scope": "global over all ranks (all-to-all signature exchange)" if multi else "single GPU = whole input"},
     }
     if rank == 0:
@@ -249,18 +297,23 @@ def main():
                 # per chain: both read sides + their 2-bit windows + 40-byte job + 2 x 32-byte results
                 "ssg_k_ext_lane<136>": float(summary[7]) * (rl + (rl + 140) / 4.0 + 104) if len(summary) > 7 and summary[7] else 0.0,
             }
-            smk = next((k for k in kern if k.startswith("ssg_k_smem")), None)   # ssg_k_smem_quad<4> / <1> / ssg_k_smem_lane
+            smk = next((k for k in kern if k.startswith("ssg_k_smem") and not k.startswith("ssg_k_smem_sort")), None)   # ssg_k_smem_quad<4> / <1> / ssg_k_smem_lane
             if smk:
                 alg_bytes[smk] = alg_bytes.pop("ssg_k_smem_quad")
             alg = alg_bytes.get(name, 0.0)
             ach = alg / (per_launch_ms * 1e-3) / 1e9
-            # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
-            # profiles/r01g_pmc_traffic.json, calibrated on the random-gather probe: 1 KiB of FETCH_SIZE = 1024 B for 64-byte lines).
-            # Only valid for the default workload the passes were run on.
-            pmc_traffic = {"ssg_k_smem_quad<1>": 164.9e9, "ssg_k_matesw": 24.6e9, "ssg_k_sal": 5.6e9, "ssg_k_chain2aln": 10.5e9, "ssg_k_reg2aln": 6.1e9}
-            default_workload = a.pairs == 1000000 and abs(a.ref_mbp - 1000.0) < 1e-9 and rl == 150
-            traffic = pmc_traffic.get(name) if default_workload else None
-            sw_ms = sum(kern.get(k, (0, 1))[0] for k in ("ssg_k_matesw", "ssg_k_chain2aln", "ssg_k_reg2aln", "ssg_k_ext_lane<136>", "ssg_k_ext_lane<256>")) / a.steps
+            # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+            # tools/profile_round.sh; units calibrated on the random-gather probe): read from the committed summary when it was
+            # taken on this workload, otherwise null -- never a constant in this file
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                if pm.get("pairs") == a.pairs and pm.get("read_len") == rl and abs(pm.get("ref_mbp", 0) - a.ref_mbp) < 1e-6:
+                    traffic = pm.get("bytes_per_launch", {}).get(name)
+            except Exception:
+                pass
+            sw_names = [k for k in kern if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need")]
+            sw_ms = sum(kern[k][0] for k in sw_names) / a.steps
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                                "ms_per_launch": per_launch_ms,
                                "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
@@ -269,32 +322,48 @@ def main():
                                "random64B": {"kernel": smk, "peak_glines_per_s": 55.0, "peak_gbps": 3520.0,
                                              "achieved_glines_per_s": (2.0 * n_ext / (kern[smk][0] / kern[smk][1] * 1e-3) / 1e9) if smk else None,
                                              "frac": (2.0 * n_ext / (kern[smk][0] / kern[smk][1] * 1e-3) / 55e9) if smk else None},
-                               "sw_cells_per_step": int(summary[3]) + int(summary[4]),
-                               "sw_gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None}
-        # ---- CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample ----
-        if a.cpu_sample > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
-            try:
-                import oracle_py
-                import tempfile
-                ns = min(a.cpu_sample, a.pairs)
-                orc = oracle_py.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
-                with tempfile.TemporaryDirectory() as td:
-                    prefix = os.path.join(td, "ref.fa")
-                    index_build.write_index_files(prefix, ix, GRCH37_NAMES, lens)
-                    oidx = orc.idx_load(prefix)
-                hs = reads[:2 * ns].cpu().numpy().reshape(-1)
-                hoff = np.arange(2 * ns + 1, dtype=np.int64) * rl
-                names = ["r%d" % (i // 2) for i in range(2 * ns)]
-                cores = min(os.cpu_count() or 1, 64)
-                tc = time.perf_counter()
-                text, _, _ = orc.process_pairs(oidx, hs, hoff, names, None, 0, "", cores)
-                hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(GRCH37_NAMES, lens))
-                orc.samblaster(hdr + text)
-                tc = time.perf_counter() - tc
-                out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
-                                       "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded" % (ns, cores)}
-            except Exception as e:  # the baseline is informative only
-                out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+                               "sw": {"cells_per_step": int(summary[3]) + int(summary[4]), "kernels": sorted(sw_names),
+                                      "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None}}
+        # ---- parity gate + CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample of the same batch ----
+        if a.cpu_sample > 0 and world == 1:   # rank 0 at N = 1 only
+            import oracle_py
+            import tempfile
+            ns = min(a.cpu_sample, a.pairs)
+            orc = oracle_py.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            with tempfile.TemporaryDirectory(dir=shm) as td:
+                prefix = os.path.join(td, "ref.fa")
+                tw = time.time()
+                lib.index_save(idx, prefix)           # the five `bwa index` files of the device-built index
+                oidx = orc.idx_load(prefix)           # ... loaded by the oracle: the index bytes cross the file format both ways
+                t_files = time.time() - tw
+            hs = reads[:2 * ns].cpu().numpy().reshape(-1)
+            hoff = np.arange(2 * ns + 1, dtype=np.int64) * rl
+            names = ["r%d" % (i // 2) for i in range(2 * ns)]
+            cores = min(os.cpu_count() or 1, 64)
+            hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(GRCH37_NAMES, lens))
+            tc = time.perf_counter()
+            otext, _, _ = orc.process_pairs(oidx, hs, hoff, names, None, 0, "", cores)
+            import common
+            odup, _ = common.oracle_dup_flags(orc, otext, hdr)
+            tc = time.perf_counter() - tc
+            gtext, gdup = gpu_sample_sam(lib, idx, opt, hs, hoff, names, GRCH37_NAMES, lens)
+            ok = gtext == otext and np.array_equal(gdup, odup)
+            n_rec_diff = 0
+            if gtext != otext:
+                ga, oa = gtext.split("\n"), otext.split("\n")
+                n_rec_diff = sum(1 for x, y in zip(ga, oa) if x != y) + abs(len(ga) - len(oa))
+                for x, y in list((x, y) for x, y in zip(ga, oa) if x != y)[:5]:
+                    sys.stderr.write("[bench] PARITY MISMATCH\n  gpu    %s\n  oracle %s\n" % (x, y))
+            out["parity"] = {"parity_checked_pairs": ns, "parity_ok": bool(ok), "records_compared": otext.count("\n"), "records_differing": n_rec_diff,
+                             "dup_flags_differing": int((gdup != odup).sum()) if len(gdup) == len(odup) else -1, "dup_pairs_in_sample": int(odup.sum()),
+                             "what": "SAM text (all fields and tags) + samblaster duplicate flags of the first %d pairs of the timed batch: libssgpu C ABI vs oracle/ "
+                                     "on the index files written by ssg_index_save" % ns, "index_files_roundtrip_s": round(t_files, 1)}
+            out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded" % (ns, cores)}
+            if not ok:   # no timing counts without parity
+                out["value"] = None
+                out["invalid"] = "parity gate failed: GPU records differ from the oracle on the sample"
         if saved_stdout is not None:
             C.CDLL(None).fflush(None); sys.stdout.flush(); os.dup2(saved_stdout, 1)
         print(json.dumps(out)); sys.stdout.flush()

@@ -48,6 +48,15 @@ int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t prim
                           const uint64_t *sa, uint64_t n_sa, int sa_intv,
                           const uint8_t *pac, int64_t l_pac,
                           int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out);
+/* upstream `bwa index` (bwtindex.c bwa_idx_build -> bntseq.c bns_fasta2bntseq + bwt_pac2bwt + bwt_bwtupdate_core + bwt_cal_sa;
+ * the reference runs it at bin/speedseq:386-391 when any of the five index files is missing).  The suffix array
+ * of fwd || revcomp(fwd) is built in HBM with 64-bit positions (no 2^31 / 2^32 limit); non-ACGT bases become lrand48() & 3
+ * after srand48(11) and are recorded as .amb holes, as upstream does.  `fasta` may be gzip-compressed. */
+int ssg_index_build_fasta(const char *fasta, ssg_index_t **out);
+/* same from forward-strand nt4 codes (0..3, no holes) already resident in HBM; contigs are named "1".."n" until ssg_index_set_names */
+int ssg_index_build_dev(const uint8_t *d_fwd, int64_t l_pac, int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out);
+/* upstream bns_dump + bwt_dump_bwt + bwt_dump_sa: prefix.{amb,ann,pac,bwt,sa} byte-identical to `bwa index` output (.sa interval 32) */
+int ssg_index_save(const ssg_index_t *idx, const char *prefix);
 void ssg_index_destroy(ssg_index_t *idx);
 int64_t ssg_index_l_pac(const ssg_index_t *idx);
 int ssg_index_n_ctg(const ssg_index_t *idx);

@@ -218,6 +218,7 @@ static orc_bwt_t *bwt_from_pac(const uint8_t *pac, int64_t l_pac)
 	return bwt;
 }
 
+static const char **g_annos;   /* FASTA comments for the next orc_idx_build_mem call (upstream keeps seq->comment as anno) */
 orc_idx_t *orc_idx_build_mem(int n_seqs, const char **names, const char **seqs)
 {	/* upstream bns_fasta2bntseq (forward pac only, N -> lrand48()&3 with srand48(11)) + bwt build */
 	orc_idx_t *idx = calloc(1, sizeof(orc_idx_t));
@@ -232,7 +233,7 @@ orc_idx_t *orc_idx_build_mem(int n_seqs, const char **names, const char **seqs)
 		orc_ann_t *p = &bns->anns[s];
 		int64_t l = strlen(seqs[s]);
 		int lasts = 0;
-		p->name = strdup(names[s]); p->anno = strdup(""); p->gi = 0; p->len = (int32_t)l;
+		p->name = strdup(names[s]); p->anno = strdup(g_annos ? g_annos[s] : ""); p->gi = 0; p->len = (int32_t)l;
 		p->offset = bns->l_pac; p->n_ambs = 0;
 		for (int64_t i = 0; i < l; ++i) {
 			int c = nt4_tab[(uint8_t)seqs[s][i]];
@@ -259,13 +260,15 @@ orc_idx_t *orc_idx_build_fasta(const char *fasta)
 {
 	FILE *fp = fopen(fasta, "r");
 	if (!fp) return 0;
-	int n = 0, m = 0; char **names = 0, **seqs = 0; size_t *ls = 0, *ms = 0;
+	int n = 0, m = 0; char **names = 0, **seqs = 0, **annos = 0; size_t *ls = 0, *ms = 0;
 	char *line = 0; size_t cap = 0; ssize_t r;
 	while ((r = getline(&line, &cap, fp)) > 0) {
 		while (r > 0 && (line[r-1] == '\n' || line[r-1] == '\r')) line[--r] = 0;
 		if (line[0] == '>') {
-			if (n == m) { m = m ? m << 1 : 8; names = realloc(names, m * sizeof(char*)); seqs = realloc(seqs, m * sizeof(char*)); ls = realloc(ls, m * sizeof(size_t)); ms = realloc(ms, m * sizeof(size_t)); }
-			char *e = line + 1; while (*e && !isspace((unsigned char)*e)) ++e; *e = 0;
+			if (n == m) { m = m ? m << 1 : 8; names = realloc(names, m * sizeof(char*)); annos = realloc(annos, m * sizeof(char*)); seqs = realloc(seqs, m * sizeof(char*)); ls = realloc(ls, m * sizeof(size_t)); ms = realloc(ms, m * sizeof(size_t)); }
+			char *e = line + 1; while (*e && !isspace((unsigned char)*e)) ++e;
+			char *c = e; while (*c && isspace((unsigned char)*c)) ++c;   /* kseq: comment = rest of the header line */
+			annos[n] = strdup(c); *e = 0;
 			names[n] = strdup(line + 1); seqs[n] = calloc(1, 1); ls[n] = 0; ms[n] = 1; ++n;
 		} else if (n) {
 			if (ls[n-1] + r + 1 > ms[n-1]) { ms[n-1] = (ls[n-1] + r + 1) * 2; seqs[n-1] = realloc(seqs[n-1], ms[n-1]); }
@@ -273,9 +276,11 @@ orc_idx_t *orc_idx_build_fasta(const char *fasta)
 		}
 	}
 	free(line); fclose(fp);
+	g_annos = (const char**)annos;
 	orc_idx_t *idx = orc_idx_build_mem(n, (const char**)names, (const char**)seqs);
-	for (int i = 0; i < n; ++i) { free(names[i]); free(seqs[i]); }
-	free(names); free(seqs); free(ls); free(ms);
+	g_annos = 0;
+	for (int i = 0; i < n; ++i) { free(names[i]); free(seqs[i]); free(annos[i]); }
+	free(names); free(annos); free(seqs); free(ls); free(ms);
 	return idx;
 }
 

@@ -85,6 +85,26 @@ class Lib:
         self._chk(self.l.ssg_index_load(prefix.encode(), C.byref(h)))
         return h
 
+    def index_build_fasta(self, fasta):
+        """upstream `bwa index` on the GPU (ssg_index_build_fasta); returns the index handle."""
+        h = C.c_void_p()
+        self._chk(self.l.ssg_index_build_fasta(fasta.encode(), C.byref(h)))
+        return h
+
+    def index_build_dev(self, d_fwd, l_pac, ctg_off, ctg_len, names=None):
+        """index of forward-strand nt4 codes resident in HBM (d_fwd = device address)."""
+        h = C.c_void_p()
+        co = np.asarray(ctg_off, dtype=np.int64)
+        cl = np.asarray(ctg_len, dtype=np.int32)
+        self._chk(self.l.ssg_index_build_dev(C.c_void_p(d_fwd), C.c_int64(l_pac), C.c_int(len(co)), _ptr(co), _ptr(cl), C.byref(h)))
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+            self._chk(self.l.ssg_index_set_names(h, C.c_int(len(names)), arr))
+        return h
+
+    def index_save(self, h, prefix):
+        self._chk(self.l.ssg_index_save(h, prefix.encode()))
+
     def index_destroy(self, h):
         self.l.ssg_index_destroy(h)
 

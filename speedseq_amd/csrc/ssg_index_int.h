@@ -1,0 +1,25 @@
+/*
+ * ssg_index_int.h -- the FM-index object shared by the translation units of libssgpu
+ * (ssgpu_core.cpp: load / use; ssg_index_build.cpp: construction, upstream `bwa index`).
+ */
+#ifndef SSG_INDEX_INT_H
+#define SSG_INDEX_INT_H
+#include <vector>
+#include <string>
+#include "ssg_types.h"
+
+struct ssg_hole_t { int64_t offset; int32_t len; char amb; };   /* upstream bntamb1_t (.amb) */
+
+struct ssg_index {
+	ssg_index_view_t v;
+	/* owned device arrays (NULL when borrowed from the caller, ssg_index_from_device) */
+	uint32_t *bwt; uint64_t *sa; uint8_t *pac; int64_t *ctg_off; int32_t *ctg_len;
+	uint64_t bwt_words;                     /* u32 words of the .bwt body (0 when borrowed) */
+	bool raw_alloc;                         /* bwt/sa/pac came from rt_malloc_raw (index builder) */
+	std::vector<std::string> names, annos;  /* .ann: name and FASTA comment ("" = upstream's "(null)") */
+	std::vector<int32_t> n_ambs;            /* .ann: holes per contig */
+	std::vector<ssg_hole_t> holes;          /* .amb */
+	std::vector<int64_t> h_off; std::vector<int32_t> h_len;
+	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), bwt_words(0), raw_alloc(false) { memset(&v, 0, sizeof(v)); }
+};
+#endif

@@ -24,6 +24,10 @@ static inline int rt_h2d(void *d, const void *h, size_t n) { if (n) memcpy(d, h,
 static inline int rt_d2h(void *h, const void *d, size_t n) { if (n) memcpy(h, d, n); return 0; }
 static inline int rt_memset(void *d, int v, size_t n) { if (n) memset(d, v, n); return 0; }
 static inline int rt_sync() { return 0; }
+static inline void *rt_malloc_raw(size_t n) { return calloc(n ? n : 1, 1); }
+static inline void rt_free_raw(void *p) { free(p); }
+static inline void rt_pool_release() {}
+static inline int rt_d2d(void *d, const void *s, size_t n) { if (n) memmove(d, s, n); return 0; }
 #define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) emu::launch((unsigned)(grid), (unsigned)(block), (lds), [&]() { kern(__VA_ARGS__); }); } while (0)
 #define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) SSG_LAUNCH(kern, grid, block, lds, __VA_ARGS__)
 static inline void ssg_fork(int) {}
@@ -64,6 +68,11 @@ static inline int rt_h2d(void *d, const void *h, size_t n) { return n ? rt_check
 static inline int rt_d2h(void *h, const void *d, size_t n) { return n ? rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
 static inline int rt_memset(void *d, int v, size_t n) { return n ? rt_check(hipMemset(d, v, n), "hipMemset") : 0; }
 static inline int rt_sync() { return rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+/* multi-gigabyte, build-time-only arrays (index construction) bypass the arena: they must return to the driver when freed */
+static inline void *rt_malloc_raw(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); ssg_pool.release(); if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return 0; } } return p; }
+static inline void rt_free_raw(void *p) { if (p) (void)hipFree(p); }
+static inline void rt_pool_release() { ssg_pool.release(); }
+static inline int rt_d2d(void *d, const void *s, size_t n) { return n ? rt_check(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice), "hipMemcpy D2D") : 0; }
 /* optional per-kernel timing: HIP events recorded on the launch stream (the default stream) */
 #include <vector>
 struct ssg_prof_rec { const char *name; hipEvent_t a, b; };

@@ -21,6 +21,7 @@
 #include "k_pairw.h"
 #include "k_misc.h"
 #include "../../include/ssgpu.h"
+#include "ssg_index_int.h"
 #ifndef SSG_EMU
 #include <hipcub/hipcub.hpp>
 #endif
@@ -35,13 +36,6 @@ std::vector<ssg_prof_rec> ssg_prof_pending;
 /* wave-per-item kernels are grid-strided over at most this many 4-wave workgroups (256 CUs x 4),
  * so per-wave scratch slabs are sized by residency, not by batch size */
 #define SSG_MAX_RESIDENT_WG 1024
-
-struct ssg_index {
-	ssg_index_view_t v;
-	uint32_t *bwt; uint64_t *sa; uint8_t *pac; int64_t *ctg_off; int32_t *ctg_len;
-	std::vector<std::string> names;
-	std::vector<int64_t> h_off; std::vector<int32_t> h_len;
-};
 
 #define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CHKA(b) do { if (!(b).ok()) { ssg_err_msg = "device allocation failed: " #b; return SSG_ENOMEM; } } while (0)
@@ -103,6 +97,7 @@ int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t prim
 	CHK(need_device());
 	ssg_index *ix = new ssg_index();
 	size_t pac_bytes = (size_t)(l_pac / 4 + 1);
+	ix->bwt_words = bwt_words;
 	ix->bwt = (uint32_t*)rt_malloc(bwt_words * 4 + 64); ix->sa = (uint64_t*)rt_malloc(n_sa * 8);
 	ix->pac = (uint8_t*)rt_malloc(pac_bytes); ix->ctg_off = (int64_t*)rt_malloc(n_ctg * 8); ix->ctg_len = (int32_t*)rt_malloc(n_ctg * 4);
 	if (!ix->bwt || !ix->sa || !ix->pac || !ix->ctg_off || !ix->ctg_len) { ssg_index_destroy(ix); ssg_err_msg = "index allocation failed"; return SSG_ENOMEM; }
@@ -163,7 +158,9 @@ int ssg_index_load(const char *prefix, ssg_index_t **out)
 void ssg_index_destroy(ssg_index_t *ix)
 {
 	if (!ix) return;
-	rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); rt_free(ix->ctg_off); rt_free(ix->ctg_len);
+	if (ix->raw_alloc) { rt_free_raw(ix->bwt); rt_free_raw(ix->sa); rt_free_raw(ix->pac); }
+	else { rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); }
+	rt_free(ix->ctg_off); rt_free(ix->ctg_len);
 	delete ix;
 }
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,

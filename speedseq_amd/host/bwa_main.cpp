@@ -76,12 +76,22 @@ static std::string unescape(const char *s)
 }
 
 static int main_index(int argc, char **argv)
-{	/* FM-index construction runs on the GPU in speedseq_amd/index_build.py */
-	if (argc < 2) { fprintf(stderr, "usage: bwa index <ref.fa>\n"); return 1; }
-	std::string self(argv[-1]);   /* argv[-1] is the executable path (see main) */
-	size_t k = self.rfind('/'); std::string root = (k == std::string::npos ? std::string(".") : self.substr(0, k)) + "/..";
-	std::string cmd = "PYTHONPATH=" + root + ":$PYTHONPATH python3 -m speedseq_amd.index_cli '" + std::string(argv[argc - 1]) + "'";
-	return system(cmd.c_str()) == 0 ? 0 : 1;
+{	/* upstream bwa_index (bwtindex.c): `bwa index [-p prefix] [-a algo] <in.fasta>`; the FM-index is built on the GPU by libssgpu (ssg_index_build_fasta) */
+	const char *prefix = 0; int ai = 1;
+	for (; ai < argc && argv[ai][0] == '-' && argv[ai][1]; ++ai) {
+		if (!strcmp(argv[ai], "-p") && ai + 1 < argc) prefix = argv[++ai];
+		else if (!strcmp(argv[ai], "-a") && ai + 1 < argc) ++ai;          /* construction algorithm: irrelevant here, same bytes */
+		else if (!strcmp(argv[ai], "-b") && ai + 1 < argc) ++ai;
+		else if (!strcmp(argv[ai], "-6")) ;
+		else { fprintf(stderr, "[bwa] index: unsupported option %s\n", argv[ai]); return 1; }
+	}
+	if (ai >= argc) { fprintf(stderr, "usage: bwa index [-p prefix] <ref.fa>\n"); return 1; }
+	ssg_index_t *idx;
+	if (ssg_index_build_fasta(argv[ai], &idx)) die("index construction failed");
+	if (ssg_index_save(idx, prefix ? prefix : argv[ai])) die("writing the index failed");
+	fprintf(stderr, "[bwa] index: %lld bp in %d sequence(s) indexed on %s\n", (long long)ssg_index_l_pac(idx), ssg_index_n_ctg(idx), ssg_backend());
+	ssg_index_destroy(idx);
+	return 0;
 }
 
 static int main_mem(int argc, char **argv)
