@@ -30,7 +30,14 @@ template <class T> struct rbuf {
 #define RALLOC(b, cnt) do { if (!(b).alloc(cnt)) { ssg_err_msg = "index construction: device allocation failed (" #b ")"; return SSG_ENOMEM; } } while (0)
 
 static int idx_verbose() { const char *e = getenv("SSG_INDEX_VERBOSE"); return e && *e ? atoi(e) : 0; }
-static inline long nblk256(int64_t n) { return (long)((n + 255) / 256); }
+/* grid of 256-lane workgroups for n items; capped (the kernels are grid-stride): a HIP launch must stay below 2^32 threads */
+static inline long nblk256(int64_t n)
+{
+	static long cap = 0;
+	if (!cap) { const char *e = getenv("SSG_INDEX_MAX_WG"); cap = e && atol(e) > 0 ? atol(e) : (1L << 20); }   /* the tests shrink it to exercise the stride */
+	const int64_t b = (n + 255) / 256;
+	return (long)(b < cap ? b : cap);
+}
 
 /* suffix array of T[0..n) (implicit smallest terminator) into d_SA; d_T is zero-padded by >= 64 bytes */
 static int build_suffix_array(const uint8_t *d_T, int64_t n, uint64_t *d_SA)

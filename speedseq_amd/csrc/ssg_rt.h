@@ -67,7 +67,7 @@ static inline void rt_free(void *p) { ssg_pool.put(p); }
 static inline int rt_h2d(void *d, const void *h, size_t n) { return n ? rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D") : 0; }
 static inline int rt_d2h(void *h, const void *d, size_t n) { return n ? rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
 static inline int rt_memset(void *d, int v, size_t n) { return n ? rt_check(hipMemset(d, v, n), "hipMemset") : 0; }
-static inline int rt_sync() { return rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+static inline int rt_sync() { int rc = rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
 /* multi-gigabyte, build-time-only arrays (index construction) bypass the arena: they must return to the driver when freed */
 static inline void *rt_malloc_raw(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); ssg_pool.release(); if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return 0; } } return p; }
 static inline void rt_free_raw(void *p) { if (p) (void)hipFree(p); }

@@ -290,7 +290,7 @@ struct seed_stage_t {
  * private large capacity and copies their lists back; on return every n_intv[r] >= 0. */
 static int dev_class_counts(const int32_t *d_key, long n, int tA, int tB, int tC, unsigned int out[5]);
 static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
-                    int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0)
+                    int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0, int *need_cap = 0)
 {
 	const int block = 64;
 	const bool quad = !(getenv("SSG_SMEM_KERNEL") && !strcmp(getenv("SSG_SMEM_KERNEL"), "lane"));
@@ -327,8 +327,13 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	CHK(rt_sync());
 	std::vector<int32_t> hn2(no);
 	CHK(d_n2.down(hn2.data(), no));
+	for (int i = 0; i < no; ++i) if (hn2[i] < 0) { ssg_err_msg = "SMEM interval list exceeds 8 x read length"; return SSG_EOVERFLOW; }
+	for (int i = 0; i < no; ++i) if (hn2[i] > cap) {   /* the dense per-read layout is too narrow for this batch: the caller widens it and calls again */
+		if (!need_cap) { ssg_err_msg = "SMEM interval list exceeds the per-read capacity"; return SSG_EOVERFLOW; }
+		*need_cap = std::max(*need_cap, (int)hn2[i]);
+	}
+	if (need_cap && *need_cap > cap) return 0;
 	for (int i = 0; i < no; ++i) {
-		if (hn2[i] < 0 || hn2[i] > cap) { ssg_err_msg = "SMEM interval list exceeds the per-read capacity"; return SSG_EOVERFLOW; }
 		std::vector<ssg_intv_t> tmp(hn2[i]);
 		CHK(rt_d2h(tmp.data(), d_big.p + (size_t)i * bigcap, (size_t)hn2[i] * sizeof(ssg_intv_t)));
 		CHK(rt_h2d(d_intv + (size_t)ovf[i] * cap, tmp.data(), (size_t)hn2[i] * sizeof(ssg_intv_t)));
@@ -444,12 +449,23 @@ struct align1_dev_t {	/* device-resident result of stages 1-4 */
 static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off, int max_len,
                       align1_dev_t &o, uint64_t stats[8])
 {
-	const int cap = 64 > max_len / 2 ? 64 : max_len / 2;  /* intervals per read in the dense layout */
-	dbuf<ssg_intv_t> d_intv((size_t)n_reads * cap); dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
-	CHKA(d_intv); CHKA(d_nintv); CHKA(d_nseed);
+	/* intervals per read in the dense layout: upstream's list is unbounded; a batch that needs more widens the layout for itself
+	 * and for the calls after it (low-complexity reads collect > len / 2 intervals from the re-seeding passes) */
+	static int learned_cap = 0;
+	int cap = std::max(64 > max_len / 2 ? 64 : max_len / 2, learned_cap);
+	dbuf<ssg_intv_t> d_intv; dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
+	CHKA(d_nintv); CHKA(d_nseed);
 	dbuf<unsigned long long> d_next(1);
-	CHKA(d_next); CHK(d_next.zero());
-	CHK(run_smem(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv.p, d_nintv.p, d_next.p));
+	CHKA(d_next);
+	for (;;) {
+		int need = 0;
+		if (!d_intv.alloc((size_t)n_reads * cap)) { ssg_err_msg = "device allocation failed: d_intv"; return SSG_ENOMEM; }
+		CHK(d_next.zero());
+		CHK(run_smem(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv.p, d_nintv.p, d_next.p, &need));
+		if (need <= cap) break;
+		cap = (need + 31) / 32 * 32; learned_cap = cap;
+		if (ssg_debug()) fprintf(stderr, "[ssgpu] SMEM interval capacity widened to %d per read\n", cap);
+	}
 	if (stats) { unsigned long long c; CHK(d_next.down(&c, 1)); stats[5] = c; }
 	STAGE("smem");
 	const int block = 256;

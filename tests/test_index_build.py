@@ -54,7 +54,8 @@ def _vs_oracle(lib, oracle, tmp_path, monkeypatch):
                 assert filecmp.cmp(fa + "." + ext, ofa + "." + ext, shallow=False), (seed, p, ext)
 
 
-def test_index_build_emu_matches_golden(emu_lib, tmp_path):
+def test_index_build_emu_matches_golden(emu_lib, tmp_path, monkeypatch):
+    monkeypatch.setenv("SSG_INDEX_MAX_WG", "7")     # grid-stride path of every construction kernel (read once per process)
     _golden(emu_lib, tmp_path)
 
 
