@@ -74,6 +74,13 @@ typedef struct { int32_t qoff, qlen, toff, tlen, w, _pad; } ssg_glb_job_t;
  * FLAG, leading / trailing clipped bases (S or H) and reference length of the CIGAR */
 typedef struct { int32_t seq, pos, flag, lclip, rclip, ralen; } ssg_sbl_end_t;
 
+/* one SAM line as samblaster reads it: contig index (-1 = '*'), 1-based POS, FLAG, MAPQ, and the CIGAR sums it derives --
+ * leading / trailing clipped bases (S or H), query bases aligned (M I = X), reference bases covered (M D N = X) */
+typedef struct { int32_t seq, pos, flag, mapq, lclip, rclip, qalen, ralen; } ssg_sbl_line_t;
+/* samblaster's command-line switches (the reference passes --excludeDups --addMateTags --maxSplitCount --minNonOverlap,
+ * bin/speedseq:439; maxUnmappedBases / minIndelSize keep upstream's defaults 50 / 50) */
+typedef struct { int32_t exclude_dups, add_mate_tags, max_split_count, min_non_overlap, max_unmapped_bases, min_indel_size; } ssg_sbl_opt_t;
+
 /* one SAM record to generate: a main record (primary / supplementary / unmapped) or an XA entry;
  * `owner` = region index (within the read) of the main record the entry belongs to */
 typedef struct { int32_t read, reg, kind, owner, flag, mapq, _pad0, _pad1; } ssg_alnreq_t;
