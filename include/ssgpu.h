@@ -132,6 +132,18 @@ ssg_sbl_state_t *ssg_sbl_state_new(void);
 void ssg_sbl_state_free(ssg_sbl_state_t *st);
 int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup);
 
+/* upstream samblaster's per-block decisions on the device (samblaster.cpp block processing; rows a14-a17): `lines` are the SAM
+ * lines of n_blocks name-grouped blocks (blk_off[n_blocks+1]) as numbers; on return line_bits[i] has SSG_SBL_DUP (OR 0x400 into
+ * FLAG), SSG_SBL_DISC (copy to --discordantFile), SSG_SBL_SPLIT (copy to --splitterFile with _1/_2) and mate_line[i] is the
+ * line whose CIGAR / MAPQ fill MC:Z / MQ:i (-1: none).  The duplicate set persists in `st` across calls (first seen wins
+ * over the whole stream); st == NULL restricts it to this call. */
+#define SSG_SBL_DUP   1
+#define SSG_SBL_DISC  2
+#define SSG_SBL_SPLIT 4
+void ssg_sbl_opt_init(ssg_sbl_opt_t *o);
+int ssg_sbl_process(ssg_sbl_state_t *st, const ssg_sbl_opt_t *o, long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines,
+                    uint8_t *line_bits, int64_t *mate_line);
+
 /* ---- the measured hot path with device-resident inputs (bench.py) ----
  * d_seq / d_off / d_pair_batch are DEVICE pointers; aligned + duplicate-marked records stay in HBM.
  * summary: [0] records [1] duplicate pairs [2] seeds [3] extension cells [4] rescue cells [5] rescues */
@@ -141,6 +153,18 @@ int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pair
  * exchange for exact first-seen-wins duplicate marking over a sharded input (samblaster.cpp: the signature set is global). */
 int ssg_hotpath_dev_sig(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
                         const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host, uint64_t *d_sig_out);
+
+/* The whole path incl. samblaster's classification (rows a1-a12, a14-a17).  summary[0..7] as above, [8] discordant-stream lines,
+ * [9] splitter-stream lines, [10] SAM lines.  sbl == NULL = the reference's switches (--excludeDups --addMateTags, bin/speedseq:439).
+ * local_dedup = 0 + d_sig_out + keep: sharded input -- the caller exchanges the signatures between ranks, then classifies the
+ * records still resident in HBM with the global verdicts (d_dup: DEVICE, one byte per pair; counts: dup pairs, discordant
+ * lines, splitter lines, SAM lines). */
+typedef struct ssg_dev_records ssg_dev_records_t;
+int ssg_hotpath_dev_ex(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                       const int32_t *d_pair_batch, int n_batches, int64_t id0, const ssg_sbl_opt_t *sbl, int local_dedup,
+                       uint64_t summary[16], uint8_t *dup_host, uint64_t *d_sig_out, ssg_dev_records_t **keep);
+int ssg_dev_records_classify(ssg_dev_records_t *r, const ssg_sbl_opt_t *sbl, const uint8_t *d_dup, uint64_t counts[4]);
+void ssg_dev_records_free(ssg_dev_records_t *r);
 
 /* FM-index from arrays already resident in HBM (not copied; the caller keeps them alive) */
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,

@@ -56,43 +56,6 @@ __global__ void ssg_k_sig(long n_pairs, const ssg_sbl_end_t *ends, ssg_sig_t *si
 	ord[p] = (uint32_t)p;
 }
 
-/*
- * After a STABLE sort of (hash, ordinal) by hash: element i is a duplicate iff an earlier element of
- * its equal-hash run (smaller ordinal, because the sort is stable) carries the identical signature,
- * or the signature is already present in the table of previous calls (old_hash sorted, old_sig).
- */
-__global__ void ssg_k_markdup(long n, const uint64_t *hash_sorted, const uint32_t *ord_sorted, const ssg_sig_t *sig,
-                              long n_old, const uint64_t *old_hash, const ssg_sig_t *old_sig, uint8_t *dup)
-{
-	long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint64_t h = hash_sorted[i]; const uint32_t o = ord_sorted[i];
-	const ssg_sig_t s = sig[o];
-	int d = 0;
-	if (!(s.k0 == ~0ull && s.k1 == ~0ull && s.k2 == ~0ull)) {
-		for (long j = i - 1; j >= 0 && hash_sorted[j] == h && !d; --j) {
-			const ssg_sig_t t = sig[ord_sorted[j]];
-			d = (t.k0 == s.k0) & (t.k1 == s.k1) & (t.k2 == s.k2);
-		}
-		if (!d && n_old > 0) { /* lower bound in the persistent table */
-			long lo = 0, hi = n_old;
-			while (lo < hi) { long mid = (lo + hi) >> 1; if (old_hash[mid] < h) lo = mid + 1; else hi = mid; }
-			for (long j = lo; j < n_old && old_hash[j] == h && !d; ++j) {
-				const ssg_sig_t t = old_sig[j];
-				d = (t.k0 == s.k0) & (t.k1 == s.k1) & (t.k2 == s.k2);
-			}
-		}
-	}
-	dup[o] = (uint8_t)d;
-}
-
-/* gather signatures in sorted order (to extend the persistent table) */
-__global__ void ssg_k_gather_sig(long n, const uint32_t *ord_sorted, const ssg_sig_t *sig, ssg_sig_t *out)
-{
-	long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = sig[ord_sorted[i]];
-}
-
 /* ---------------- small device-side bookkeeping (keeps counts, offsets and work orders off the host) ---------------- */
 __global__ void ssg_k_iota(int32_t *a, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = (int32_t)i; }
 __global__ void ssg_k_scan_tail(const int32_t *in, int64_t *out, long n) { if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = n > 0 ? out[n-1] + in[n-1] : 0; }

@@ -16,9 +16,11 @@
 #define SSG_K_SBL_H
 #include "k_misc.h"
 
+#ifndef SSG_SBL_DUP
 #define SSG_SBL_DUP   1   /* OR 0x400 into the line's FLAG */
 #define SSG_SBL_DISC  2   /* line goes to --discordantFile */
 #define SSG_SBL_SPLIT 4   /* line goes to --splitterFile (QNAME + _1 / _2) */
+#endif
 #define SSG_SBL_MAX_SPLIT 16
 
 /* primaries of block b (first 0x40 / first 0x80 line without 0x100 | 0x800) -> ends[2b], ends[2b+1]; prim[2b], prim[2b+1] = line index or -1 */
@@ -151,6 +153,19 @@ __global__ void ssg_k_sbl_classify(ssg_sbl_opt_t o, long n_blocks, const int64_t
 	ssg_sbl_mark_splitters(o, lines, b0, b1, 0x80, out);
 }
 
+/* c[0] += duplicate pairs, c[1] += discordant-stream lines, c[2] += splitter-stream lines; one atomic per wave and counter */
+__global__ void ssg_k_sbl_count_bits(int64_t n_lines, const uint8_t *bits, long n_pairs, const uint8_t *dup, unsigned int *c)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int b = i < n_lines ? bits[i] : 0, d = i < n_pairs ? dup[i] : 0;
+	const unsigned long long b0 = wv_ballot(d != 0), b1 = wv_ballot(b & SSG_SBL_DISC), b2 = wv_ballot(b & SSG_SBL_SPLIT);
+	if (wv_lane() == 0) {
+		if (b0) atomicAdd(&c[0], (unsigned)__popcll(b0));
+		if (b1) atomicAdd(&c[1], (unsigned)__popcll(b1));
+		if (b2) atomicAdd(&c[2], (unsigned)__popcll(b2));
+	}
+}
+
 /* fused path: the SAM lines a pair's device records will print as (main requests only; XA entries are tags, not lines).
  * n_line[p] is counted first (ssg_k_sbl_count_lines), offsets by prefix sum, then the lines are filled. */
 __global__ void ssg_k_sbl_count_lines(long n_pairs, const int64_t *req_off, const ssg_alnreq_t *req, int32_t *n_line)
@@ -184,7 +199,7 @@ __global__ void ssg_k_sbl_lines_from_alns(long n_pairs, const int64_t *req_off, 
 			flag |= is_rev ? 0x10 : 0;
 			flag |= m_rev ? 0x20 : 0;
 			flag = (flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0);
-			ssg_sbl_line_t l; l.seq = rid; l.pos = (int32_t)(pos + 1); l.flag = flag; l.mapq = rid >= 0 && a.rid >= 0 ? a.mapq : 0;
+			ssg_sbl_line_t l; l.seq = rid; l.pos = (int32_t)(pos + 1); l.flag = flag; l.mapq = rid >= 0 ? a.mapq : 0;
 			l.lclip = l.rclip = l.qalen = l.ralen = 0;
 			int first = 1, rc = 0;
 			for (int k = 0; k < n_cigar; ++k) {

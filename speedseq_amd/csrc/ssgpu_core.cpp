@@ -19,7 +19,7 @@
 #include "k_swjobs.h"
 #include "k_aln.h"
 #include "k_pairw.h"
-#include "k_misc.h"
+#include "k_sbl.h"
 #include "../../include/ssgpu.h"
 #include "ssg_index_int.h"
 #ifndef SSG_EMU
@@ -794,25 +794,6 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	return 0;
 }
 
-/* ---- duplicate marking on device-resident records (row a14) ---- */
-__global__ void ssg_k_ends_from_alns(long n_pairs, const int64_t *req_off, const ssg_alnreq_t *req, const ssg_aln_t *alns, ssg_sbl_end_t *ends)
-{	/* primary record of each end (first main request of the read) -> samblaster's view of it */
-	long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= 2 * n_pairs) return;
-	const ssg_aln_t &a = alns[req_off[r]];
-	ssg_sbl_end_t e; e.seq = a.rid; e.pos = (int32_t)(a.pos + 1); e.flag = a.flag | (a.is_rev ? 0x10 : 0) | (a.rid < 0 ? 0x4 : 0);
-	e.lclip = e.rclip = e.ralen = 0;
-	int first = 1, rc = 0;
-	for (int k = 0; k < a.n_cigar; ++k) {
-		int op = a.cigar[k] & 0xf, len = (int)(a.cigar[k] >> 4);
-		if (op == 3 || op == 4) { if (first) e.lclip += len; rc += len; }
-		else { first = 0; rc = 0; if (op == 0 || op == 2) e.ralen += len; }
-	}
-	e.rclip = a.n_cigar ? rc : 0;
-	if (a.rid < 0) e.seq = -1;
-	ends[r] = e;
-}
-
 /* stable sort of (hash, ordinal) by hash: hipCUB radix sort on the GPU */
 static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, long n)
 {
@@ -831,16 +812,58 @@ static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint3
 #endif
 }
 
-/* dup[p] for pairs whose ends are in d_ends (device); single call = whole input (first-seen-wins by ordinal) */
-static int dedup_core(long n_pairs, const ssg_sbl_end_t *d_ends, uint8_t *d_dup)
+/* ---- the persistent duplicate set (k_sbl.h): open-addressing table in HBM ---- */
+struct ssg_sbl_state {
+	uint64_t *th; ssg_sig_t *ts; uint64_t slots, n;     /* slots = power of two (0 = no table yet), n = signatures held */
+	ssg_sbl_state() : th(0), ts(0), slots(0), n(0) {}
+	~ssg_sbl_state() { rt_free_raw(th); rt_free_raw(ts); }
+};
+static int sbl_table_reserve(ssg_sbl_state *st, uint64_t more)
+{	/* load factor <= 1/2 after `more` insertions */
+	uint64_t want = st->slots ? st->slots : (uint64_t)std::max(16, env_int("SSG_SBL_TABLE_SLOTS", 1 << 20));   /* power of two; the tests start small to exercise the growth */
+	while ((st->n + more) * 2 > want) want <<= 1;
+	if (want == st->slots) return 0;
+	uint64_t *nh = (uint64_t*)rt_malloc_raw(want * 8); ssg_sig_t *ns = (ssg_sig_t*)rt_malloc_raw(want * sizeof(ssg_sig_t));
+	if (!nh || !ns) { rt_free_raw(nh); rt_free_raw(ns); ssg_err_msg = "device allocation failed: duplicate-signature table"; return SSG_ENOMEM; }
+	CHK(rt_memset(nh, 0, want * 8));
+	if (st->slots) SSG_LAUNCH(ssg_k_sbl_rehash, (st->slots + 255) / 256, 256, 0, st->slots, st->th, st->ts, nh, ns, want - 1);
+	CHK(rt_sync());
+	rt_free_raw(st->th); rt_free_raw(st->ts);
+	st->th = nh; st->ts = ns; st->slots = want;
+	return 0;
+}
+/* dup[p] for the pairs whose ends are in d_ends (device), first-seen-wins by position in the call; with a state, signatures seen in
+ * earlier calls count and this call's new signatures are added (upstream's single pass over the whole stream) */
+static int dedup_core(ssg_sbl_state *st, long n_pairs, const ssg_sbl_end_t *d_ends, uint8_t *d_dup, ssg_sig_t *d_sig_out = 0)
 {
 	const int block = 256;
-	dbuf<ssg_sig_t> d_sig(n_pairs); dbuf<uint64_t> d_h(n_pairs), d_hs(n_pairs); dbuf<uint32_t> d_o(n_pairs), d_os(n_pairs);
-	CHKA(d_sig); CHKA(d_h); CHKA(d_hs); CHKA(d_o); CHKA(d_os);
-	SSG_LAUNCH(ssg_k_sig, (n_pairs + block - 1) / block, block, 0, n_pairs, d_ends, d_sig.p, d_h.p, d_o.p);
-	CHK(rt_sync());
+	dbuf<ssg_sig_t> d_sigb; dbuf<uint64_t> d_h(n_pairs), d_hs(n_pairs); dbuf<uint32_t> d_o(n_pairs), d_os(n_pairs); dbuf<uint8_t> d_fresh;
+	if (!d_sig_out) { if (!d_sigb.alloc(n_pairs)) { ssg_err_msg = "device allocation failed: signatures"; return SSG_ENOMEM; } d_sig_out = d_sigb.p; }
+	CHKA(d_h); CHKA(d_hs); CHKA(d_o); CHKA(d_os);
+	if (st) { if (!d_fresh.alloc(n_pairs)) { ssg_err_msg = "device allocation failed: fresh flags"; return SSG_ENOMEM; } CHK(sbl_table_reserve(st, (uint64_t)n_pairs)); }
+	SSG_LAUNCH(ssg_k_sig, (n_pairs + block - 1) / block, block, 0, n_pairs, d_ends, d_sig_out, d_h.p, d_o.p);
 	CHK(sort_pairs_u64(d_h.p, d_hs.p, d_o.p, d_os.p, n_pairs));
-	SSG_LAUNCH(ssg_k_markdup, (n_pairs + block - 1) / block, block, 0, n_pairs, d_hs.p, d_os.p, d_sig.p, 0L, (const uint64_t*)0, (const ssg_sig_t*)0, d_dup);
+	SSG_LAUNCH(ssg_k_sbl_markdup, (n_pairs + block - 1) / block, block, 0, n_pairs, d_hs.p, d_os.p, d_sig_out,
+	           st ? st->th : (const uint64_t*)0, st ? st->ts : (const ssg_sig_t*)0, st ? st->slots - 1 : 0, d_dup, st ? d_fresh.p : (uint8_t*)0);
+	if (st) {
+		SSG_LAUNCH(ssg_k_sbl_insert, (n_pairs + block - 1) / block, block, 0, n_pairs, d_h.p, d_sig_out, d_fresh.p, st->th, st->ts, st->slots - 1);
+		st->n += (uint64_t)n_pairs;   /* upper bound (duplicates and never-duplicate pairs are not inserted): only steers the growth */
+	}
+	return rt_sync();
+}
+
+/* rows a14-a17 for a chunk of name-grouped blocks resident in HBM: duplicate bits (through the state's table), mate lines, side-stream bits */
+static int sbl_process_dev(ssg_sbl_state *st, const ssg_sbl_opt_t *o, long n_blocks, const int64_t *d_blk_off, const ssg_sbl_line_t *d_lines,
+                           uint8_t *d_out, int64_t *d_mate, uint8_t *d_dup_out /* may be NULL */)
+{
+	const int block = 256;
+	if (o->max_split_count > SSG_SBL_MAX_SPLIT) { ssg_err_msg = "samblaster: --maxSplitCount above 16 is not supported"; return SSG_EINVAL; }
+	dbuf<ssg_sbl_end_t> d_ends(2 * n_blocks); dbuf<int64_t> d_prim(2 * n_blocks); dbuf<uint8_t> d_dupb;
+	CHKA(d_ends); CHKA(d_prim);
+	if (!d_dup_out) { if (!d_dupb.alloc(n_blocks)) { ssg_err_msg = "device allocation failed: dup flags"; return SSG_ENOMEM; } d_dup_out = d_dupb.p; }
+	SSG_LAUNCH(ssg_k_sbl_ends, (n_blocks + block - 1) / block, block, 0, n_blocks, d_blk_off, d_lines, d_ends.p, d_prim.p);
+	CHK(dedup_core(st, n_blocks, d_ends.p, d_dup_out));
+	SSG_LAUNCH(ssg_k_sbl_classify, (n_blocks + block - 1) / block, block, 0, *o, n_blocks, d_blk_off, d_lines, d_prim.p, d_dup_out, d_out, d_mate);
 	return rt_sync();
 }
 
@@ -875,90 +898,144 @@ int ssg_sbl_markdup(long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup)
 	dbuf<ssg_sbl_end_t> d_ends(2 * n_pairs); dbuf<uint8_t> d_dup(n_pairs);
 	CHKA(d_ends); CHKA(d_dup);
 	CHK(d_ends.up(ends, 2 * n_pairs));
-	CHK(dedup_core(n_pairs, d_ends.p, d_dup.p));
+	CHK(dedup_core(0, n_pairs, d_ends.p, d_dup.p));
 	return d_dup.down(dup, n_pairs);
 }
 
-/* Streaming duplicate marking: the signature table of everything seen so far stays in HBM, sorted by
- * hash, so first-seen-wins holds across calls exactly as in upstream's single pass over the stream. */
-struct ssg_sbl_state { dbuf<uint64_t> hash; dbuf<ssg_sig_t> sig; long n; };
-
-ssg_sbl_state_t *ssg_sbl_state_new(void) { ssg_sbl_state *s = new ssg_sbl_state(); s->n = 0; return s; }
+/* Streaming duplicate marking: the signatures of everything seen so far stay in an HBM hash table (k_sbl.h), so first-seen-wins
+ * holds across calls exactly as in upstream's single pass over the stream; each call costs O(its own pairs). */
+ssg_sbl_state_t *ssg_sbl_state_new(void) { return new ssg_sbl_state(); }
 void ssg_sbl_state_free(ssg_sbl_state_t *s) { delete s; }
 
 int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup)
 {
 	CHK(need_device());
 	if (n_pairs <= 0) return 0;
-	if (st->n + n_pairs >= (1L << 31)) { ssg_err_msg = "ssg_sbl_markdup_stream: more than 2^31 pairs"; return SSG_EINVAL; }
-	const int block = 256;
+	if (n_pairs >= (1L << 31)) { ssg_err_msg = "ssg_sbl_markdup_stream: more than 2^31 pairs per call"; return SSG_EINVAL; }
 	dbuf<ssg_sbl_end_t> d_ends(2 * n_pairs); dbuf<uint8_t> d_dup(n_pairs);
-	dbuf<ssg_sig_t> d_sig(n_pairs); dbuf<uint64_t> d_h(n_pairs), d_hs(n_pairs); dbuf<uint32_t> d_o(n_pairs), d_os(n_pairs);
-	CHKA(d_ends); CHKA(d_dup); CHKA(d_sig); CHKA(d_h); CHKA(d_hs); CHKA(d_o); CHKA(d_os);
+	CHKA(d_ends); CHKA(d_dup);
 	CHK(d_ends.up(ends, 2 * n_pairs));
-	SSG_LAUNCH(ssg_k_sig, (n_pairs + block - 1) / block, block, 0, n_pairs, d_ends.p, d_sig.p, d_h.p, d_o.p);
-	CHK(rt_sync());
-	CHK(sort_pairs_u64(d_h.p, d_hs.p, d_o.p, d_os.p, n_pairs));
-	SSG_LAUNCH(ssg_k_markdup, (n_pairs + block - 1) / block, block, 0, n_pairs, d_hs.p, d_os.p, d_sig.p, st->n, st->hash.p, st->sig.p, d_dup.p);
-	CHK(rt_sync());
-	CHK(d_dup.down(dup, n_pairs));
-	/* extend the table: old ++ new (sorted by hash again); duplicates may stay in, they are harmless */
-	long tot = st->n + n_pairs;
-	dbuf<uint64_t> nh(tot), nhs(tot); dbuf<uint32_t> no(tot), nos(tot); dbuf<ssg_sig_t> cat(tot), nsig(tot);
-	CHKA(nh); CHKA(nhs); CHKA(no); CHKA(nos); CHKA(cat); CHKA(nsig);
-#ifdef SSG_EMU
-	if (st->n) { memcpy(nh.p, st->hash.p, st->n * 8); memcpy(cat.p, st->sig.p, st->n * sizeof(ssg_sig_t)); }
-	memcpy(nh.p + st->n, d_h.p, n_pairs * 8); memcpy(cat.p + st->n, d_sig.p, n_pairs * sizeof(ssg_sig_t));
-#else
-	if (st->n) { (void)hipMemcpy(nh.p, st->hash.p, st->n * 8, hipMemcpyDeviceToDevice); (void)hipMemcpy(cat.p, st->sig.p, st->n * sizeof(ssg_sig_t), hipMemcpyDeviceToDevice); }
-	(void)hipMemcpy(nh.p + st->n, d_h.p, n_pairs * 8, hipMemcpyDeviceToDevice); (void)hipMemcpy(cat.p + st->n, d_sig.p, n_pairs * sizeof(ssg_sig_t), hipMemcpyDeviceToDevice);
-#endif
-	{ std::vector<uint32_t> iota(tot); for (long i = 0; i < tot; ++i) iota[i] = (uint32_t)i; CHK(no.up(iota.data(), tot)); }
-	CHK(sort_pairs_u64(nh.p, nhs.p, no.p, nos.p, tot));
-	SSG_LAUNCH(ssg_k_gather_sig, (tot + block - 1) / block, block, 0, tot, nos.p, cat.p, nsig.p);
-	CHK(rt_sync());
-	st->hash.swap(nhs); st->sig.swap(nsig); st->n = tot;
+	CHK(dedup_core(st, n_pairs, d_ends.p, d_dup.p));
+	return d_dup.down(dup, n_pairs);
+}
+
+void ssg_sbl_opt_init(ssg_sbl_opt_t *o)
+{	/* upstream samblaster defaults */
+	o->exclude_dups = 0; o->add_mate_tags = 0; o->max_split_count = 2; o->min_non_overlap = 20; o->max_unmapped_bases = 50; o->min_indel_size = 50;
+}
+
+/* upstream samblaster's per-block decisions (rows a14-a17) for a chunk of the stream; host buffers */
+int ssg_sbl_process(ssg_sbl_state_t *st, const ssg_sbl_opt_t *o, long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines,
+                    uint8_t *line_bits, int64_t *mate_line)
+{
+	CHK(need_device());
+	if (n_blocks <= 0) return 0;
+	if (n_blocks >= (1L << 31)) { ssg_err_msg = "ssg_sbl_process: more than 2^31 blocks per call"; return SSG_EINVAL; }
+	const int64_t n_lines = blk_off[n_blocks];
+	dbuf<int64_t> d_off(n_blocks + 1), d_mate(n_lines + 1); dbuf<ssg_sbl_line_t> d_lines(n_lines + 1); dbuf<uint8_t> d_out(n_lines + 1);
+	CHKA(d_off); CHKA(d_mate); CHKA(d_lines); CHKA(d_out);
+	CHK(d_off.up(blk_off, n_blocks + 1)); CHK(d_lines.up(lines, n_lines));
+	CHK(sbl_process_dev(st, o, n_blocks, d_off.p, d_lines.p, d_out.p, d_mate.p, 0));
+	CHK(d_out.down(line_bits, n_lines));
+	return d_mate.down(mate_line, n_lines);
+}
+
+/* aligned records of one call kept in HBM with their samblaster view (lines, primaries), for the stages after alignment */
+struct ssg_dev_records {
+	pe_dev_t keep; long n_pairs; int64_t n_lines;
+	dbuf<int64_t> line_off, line_req, prim, mate; dbuf<ssg_sbl_line_t> lines; dbuf<ssg_sbl_end_t> ends; dbuf<uint8_t> bits, dup;
+};
+
+/* SAM lines of the kept records (k_sbl.h) and the two primary ends per pair */
+static int records_lines(ssg_dev_records *R)
+{
+	const long n_pairs = R->n_pairs; const int block = 256;
+	dbuf<int32_t> d_nl(n_pairs);
+	CHKA(d_nl);
+	if (!R->line_off.alloc(n_pairs + 1)) { ssg_err_msg = "device allocation failed: line offsets"; return SSG_ENOMEM; }
+	SSG_LAUNCH(ssg_k_sbl_count_lines, (n_pairs + block - 1) / block, block, 0, n_pairs, R->keep.req_off.p, R->keep.req.p, d_nl.p);
+	CHK(dev_exclusive_scan(d_nl.p, R->line_off.p, n_pairs, &R->n_lines));
+	const size_t nl = (size_t)R->n_lines + 1;
+	if (!R->lines.alloc(nl) || !R->line_req.alloc(nl) || !R->prim.alloc(2 * n_pairs) || !R->mate.alloc(nl) || !R->bits.alloc(nl) || !R->ends.alloc(2 * n_pairs) || !R->dup.alloc(n_pairs)) {
+		ssg_err_msg = "device allocation failed: samblaster lines"; return SSG_ENOMEM; }
+	SSG_LAUNCH(ssg_k_sbl_lines_from_alns, (n_pairs + block - 1) / block, block, 0, n_pairs, R->keep.req_off.p, R->keep.req.p, R->keep.alns.p, R->line_off.p, R->lines.p, R->line_req.p);
+	SSG_LAUNCH(ssg_k_sbl_ends, (n_pairs + block - 1) / block, block, 0, n_pairs, R->line_off.p, R->lines.p, R->ends.p, R->prim.p);
+	return 0;
+}
+static int records_classify(ssg_dev_records *R, const ssg_sbl_opt_t *o, const uint8_t *d_dup, uint64_t counts[4])
+{	/* counts: [0] duplicate pairs [1] lines to the discordant stream [2] lines to the splitter stream [3] SAM lines */
+	const long n_pairs = R->n_pairs; const int block = 256;
+	if (o->max_split_count > SSG_SBL_MAX_SPLIT) { ssg_err_msg = "samblaster: --maxSplitCount above 16 is not supported"; return SSG_EINVAL; }
+	SSG_LAUNCH(ssg_k_sbl_classify, (n_pairs + block - 1) / block, block, 0, *o, n_pairs, R->line_off.p, R->lines.p, R->prim.p, d_dup, R->bits.p, R->mate.p);
+	dbuf<unsigned int> d_c(4);
+	CHKA(d_c); CHK(d_c.zero());
+	SSG_LAUNCH(ssg_k_sbl_count_bits, (R->n_lines + block - 1) / block, block, 0, R->n_lines, R->bits.p, n_pairs, d_dup, d_c.p);
+	unsigned int c[4];
+	CHK(d_c.down(c, 4));
+	counts[0] = c[0]; counts[1] = c[1]; counts[2] = c[2]; counts[3] = (uint64_t)R->n_lines;
 	return 0;
 }
 
-/* The measured hot path (bench.py): device-resident reads in, aligned + duplicate-marked records
- * left in HBM.  d_seq / d_off / d_pair_batch are DEVICE pointers.  summary[0] = records,
- * [1] = duplicate pairs, [2] = seeds, [3] = extension cells, [4] = rescue cells, [5] = rescues. */
-static int hotpath_dev_impl(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
-                            const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host, uint64_t *d_sig_out)
+/* The measured hot path (bench.py): device-resident reads in; aligned, duplicate-marked and side-stream-classified records
+ * left in HBM (rows a1-a12, a14-a17).  d_seq / d_off / d_pair_batch are DEVICE pointers.  summary[0] = records,
+ * [1] = duplicate pairs, [2] = seeds, [3] = extension cells, [4] = rescue cells, [5] = rescues, [6] = bwt_extend calls, [7] = chains,
+ * [8] = discordant-stream lines, [9] = splitter-stream lines, [10] = SAM lines.
+ * local_dedup = 0 leaves duplicate marking and classification to the caller (sharded input: signatures in d_sig_out are
+ * exchanged between ranks first, then ssg_dev_records_classify runs on the global verdicts). */
+int ssg_hotpath_dev_ex(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
+                       const int32_t *d_pair_batch, int n_batches, int64_t id0, const ssg_sbl_opt_t *sbl, int local_dedup,
+                       uint64_t summary[16], uint8_t *dup_host, uint64_t *d_sig_out, ssg_dev_records_t **keep_out)
 {
 	CHK(need_device());
+	if (keep_out) *keep_out = 0;
 	if (n_pairs <= 0 || max_len > 254) { ssg_err_msg = "ssg_hotpath_dev: bad arguments"; return SSG_EINVAL; }
-	ssg_pe_result res; pe_dev_t keep;
-	CHK(pe_core(idx, opt, n_pairs, d_seq, d_off, max_len, d_pair_batch, n_batches, id0, 0, &res, &keep));
-	dbuf<ssg_sbl_end_t> d_ends(2L * n_pairs); dbuf<uint8_t> d_dup(n_pairs);
-	CHKA(d_ends); CHKA(d_dup);
-	SSG_LAUNCH(ssg_k_ends_from_alns, (2L * n_pairs + 255) / 256, 256, 0, (long)n_pairs, keep.req_off.p, keep.req.p, keep.alns.p, d_ends.p);
-	if (d_sig_out) { /* signatures for the cross-rank exchange (speedseq_amd/dist.py): three 64-bit words per pair, all ones = never a duplicate */
-		dbuf<uint64_t> d_h(n_pairs); dbuf<uint32_t> d_o(n_pairs);
-		CHKA(d_h); CHKA(d_o);
-		SSG_LAUNCH(ssg_k_sig, (n_pairs + 255) / 256, 256, 0, (long)n_pairs, d_ends.p, (ssg_sig_t*)d_sig_out, d_h.p, d_o.p);
-		CHK(rt_sync());
+	ssg_sbl_opt_t so; if (sbl) so = *sbl; else { ssg_sbl_opt_init(&so); so.exclude_dups = 1; so.add_mate_tags = 1; }   /* the reference's command line */
+	ssg_pe_result res; std::unique_ptr<ssg_dev_records> R(new ssg_dev_records());
+	R->n_pairs = n_pairs;
+	CHK(pe_core(idx, opt, n_pairs, d_seq, d_off, max_len, d_pair_batch, n_batches, id0, 0, &res, &R->keep));
+	CHK(records_lines(R.get()));
+	memset(summary, 0, 16 * sizeof(uint64_t));
+	if (local_dedup || d_sig_out) {
+		dbuf<ssg_sig_t> d_sigb;
+		CHK(dedup_core(0, n_pairs, R->ends.p, R->dup.p, (ssg_sig_t*)d_sig_out));
 	}
-	CHK(dedup_core(n_pairs, d_ends.p, d_dup.p));
-	std::vector<uint8_t> hd(n_pairs);
-	CHK(d_dup.down(hd.data(), n_pairs));
-	uint64_t nd = 0; for (int p = 0; p < n_pairs; ++p) nd += hd[p];
-	if (dup_host) memcpy(dup_host, hd.data(), n_pairs);
-	summary[0] = res.stats[4]; summary[1] = nd; summary[2] = res.stats[0]; summary[3] = res.stats[1]; summary[4] = res.stats[2]; summary[5] = res.stats[3];
+	if (local_dedup) {
+		uint64_t c[4];
+		CHK(records_classify(R.get(), &so, R->dup.p, c));
+		summary[1] = c[0]; summary[8] = c[1]; summary[9] = c[2]; summary[10] = c[3];
+		if (dup_host) CHK(R->dup.down(dup_host, n_pairs));
+	}
+	summary[0] = res.stats[4]; summary[2] = res.stats[0]; summary[3] = res.stats[1]; summary[4] = res.stats[2]; summary[5] = res.stats[3];
 	summary[7] = res.stats[6]; /* chains = first-seed extensions */
 	summary[6] = res.stats[5]; /* bwt_extend calls in the SMEM kernel (2 rank queries = 2 x 64-byte lines each) */
+	if (keep_out) *keep_out = R.release();
 	return 0;
 }
+int ssg_dev_records_classify(ssg_dev_records_t *R, const ssg_sbl_opt_t *sbl, const uint8_t *d_dup, uint64_t counts[4])
+{
+	ssg_sbl_opt_t so; if (sbl) so = *sbl; else { ssg_sbl_opt_init(&so); so.exclude_dups = 1; so.add_mate_tags = 1; }
+	return records_classify(R, &so, d_dup, counts);
+}
+void ssg_dev_records_free(ssg_dev_records_t *R) { delete R; }
 
 int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
                     const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host /* may be NULL */)
-{ return hotpath_dev_impl(idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches, id0, summary, dup_host, 0); }
+{
+	uint64_t s16[16];
+	CHK(ssg_hotpath_dev_ex(idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches, id0, 0, 1, s16, dup_host, 0, 0));
+	memcpy(summary, s16, 8 * sizeof(uint64_t));
+	return 0;
+}
 
 /* same, and the pair signatures (n_pairs x 3 uint64, DEVICE memory) for exact duplicate marking across ranks */
 int ssg_hotpath_dev_sig(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
                         const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host, uint64_t *d_sig_out)
-{ return hotpath_dev_impl(idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches, id0, summary, dup_host, d_sig_out); }
+{
+	uint64_t s16[16];
+	CHK(ssg_hotpath_dev_ex(idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches, id0, 0, 1, s16, dup_host, d_sig_out, 0));
+	memcpy(summary, s16, 8 * sizeof(uint64_t));
+	return 0;
+}
 
 int ssg_index_set_names(ssg_index_t *ix, int n, const char *const *names)
 {

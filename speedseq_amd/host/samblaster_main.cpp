@@ -3,207 +3,219 @@
  * bin/speedseq.config:14, invoked at bin/speedseq:439,469):
  *   samblaster [--excludeDups] --addMateTags --maxSplitCount INT --minNonOverlap INT
  *              --splitterFile PATH --discordantFile PATH      (SAM on stdin -> SAM on stdout)
- * Host side of the drop-in boundary: SAM block parsing and the text rules (mate tags, discordant /
- * splitter extraction); duplicate marking (row a14) runs on the MI355X
- * through ssg_sbl_markdup_stream, whose signature table persists in HBM over the whole stream.
- * The two side paths are FIFOs in the reference script: they are opened before the first record is
- * read and always closed, even when empty.
+ * Host side of the drop-in boundary.  The text is scanned in place (no per-line allocation: only the six leading
+ * fields are read, the rest of a line is skipped by memchr), every decision -- duplicate (a14), mate tags' source
+ * line (a15), discordant (a16) and splitter (a17) membership -- is taken on the MI355X by ssg_sbl_process over the
+ * numeric view of a chunk of blocks, whose duplicate set persists in HBM over the whole stream; the writer then
+ * patches FLAG / appends MC,MQ / copies lines to the side streams.  The two side paths are FIFOs in the reference
+ * script: they are opened before the first record is read and always closed, even when empty.
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdint.h>
+#include <unistd.h>
+#include <errno.h>
 #include <string>
 #include <vector>
-#include <map>
-#include <algorithm>
+#include <unordered_map>
 #include "../../include/ssgpu.h"
 
-struct line_t {
-	std::string raw; std::vector<std::string> f; std::string opt;   /* 11 mandatory fields + the rest */
-	int flag, seq, pos, lclip, rclip, qalen, ralen, sqo, eqo; bool split;
+struct out_t {           /* buffered writer on a file descriptor */
+	int fd; std::vector<char> b; size_t n;
+	explicit out_t(int fd_) : fd(fd_), b(4u << 20), n(0) {}
+	void flush() { size_t o = 0; while (o < n) { ssize_t w = write(fd, b.data() + o, n - o); if (w < 0) { if (errno == EINTR) continue; perror("[samblaster] write"); exit(1); } o += (size_t)w; } n = 0; }
+	inline void put(const char *p, size_t l) { if (n + l > b.size()) { flush(); if (l > b.size()) b.resize(l * 2); } memcpy(b.data() + n, p, l); n += l; }
+	inline void putc(char c) { if (n == b.size()) flush(); b[n++] = c; }
+	inline void puti(int v) { char t[16]; int k = 0; if (v == 0) t[k++] = '0'; unsigned u = (unsigned)v; char r[16]; int m = 0; while (u) { r[m++] = (char)('0' + u % 10); u /= 10; } while (m) t[k++] = r[--m]; put(t, (size_t)k); }
 };
-struct opts_t { bool exclude_dups, add_mate_tags; int max_split, min_non_overlap, max_unmapped, min_indel; };
 
-static void parse_cigar(line_t &l)
-{
-	l.lclip = l.rclip = l.qalen = l.ralen = 0;
-	const std::string &c = l.f[5];
-	if (c == "*") { l.sqo = 0; l.eqo = -1; return; }
-	bool first = true; int rc = 0; size_t i = 0;
-	while (i < c.size()) {
-		int n = 0; while (i < c.size() && isdigit((unsigned char)c[i])) n = n * 10 + (c[i++] - '0');
-		char op = c[i++];
-		if (op == 'S' || op == 'H') { if (first) l.lclip += n; rc += n; }
-		else {
-			first = false; rc = 0;
-			if (op == 'M' || op == '=' || op == 'X') { l.qalen += n; l.ralen += n; }
-			else if (op == 'I') l.qalen += n;
-			else if (op == 'D' || op == 'N') l.ralen += n;
-		}
+struct lrec_t {          /* one SAM line inside the chunk buffer */
+	size_t off; uint32_t len;            /* line without '\n' */
+	uint32_t qn_len, flag_end, cig_off, cig_len, mq_off, mq_len, opt_off;   /* relative to off; opt_off = 0: no optional fields */
+};
+
+static inline int parse_uint(const char *p, const char *e) { int v = 0; bool neg = p < e && *p == '-'; if (neg) ++p; while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0'); return neg ? -v : v; }
+
+static bool has_tag(const char *p, const char *e, const char *tag)
+{	/* optional fields p..e: does one start with tag (5 chars)? */
+	while (p < e) {
+		if (e - p >= 5 && memcmp(p, tag, 5) == 0) return true;
+		const char *t = (const char*)memchr(p, '\t', (size_t)(e - p));
+		if (!t) break;
+		p = t + 1;
 	}
-	l.rclip = (l.qalen + l.ralen) ? rc : 0;
-	l.sqo = (l.flag & 0x10) ? l.rclip : l.lclip;
-	l.eqo = l.sqo + l.qalen - 1;
-}
-
-static bool parse_line(line_t &l, const std::map<std::string, int> &seqs)
-{
-	l.f.clear(); l.opt.clear();
-	size_t p = 0;
-	for (int k = 0; k < 11; ++k) {
-		size_t t = l.raw.find('\t', p);
-		if (t == std::string::npos) { if (k == 10) { l.f.push_back(l.raw.substr(p)); p = l.raw.size(); break; } return false; }
-		l.f.push_back(l.raw.substr(p, t - p)); p = t + 1;
-	}
-	if (l.f.size() < 11) return false;
-	if (p < l.raw.size()) l.opt = l.raw.substr(p);
-	l.flag = atoi(l.f[1].c_str()); l.pos = atoi(l.f[3].c_str());
-	auto it = seqs.find(l.f[2]);
-	l.seq = (l.f[2] == "*" || it == seqs.end()) ? -1 : it->second;
-	l.split = false;
-	parse_cigar(l);
-	return true;
-}
-
-static bool has_tag(const line_t &l, const char *tag)
-{
-	size_t p = 0;
-	while (p < l.opt.size()) { if (l.opt.compare(p, 5, tag) == 0) return true; p = l.opt.find('\t', p); if (p == std::string::npos) break; ++p; }
 	return false;
-}
-
-static void write_line(FILE *fp, const line_t &l, const char *suffix, const std::string &extra)
-{
-	fputs(l.f[0].c_str(), fp); if (suffix) fputs(suffix, fp);
-	fprintf(fp, "\t%d", l.flag);
-	for (int i = 2; i < 11; ++i) { fputc('\t', fp); fputs(l.f[i].c_str(), fp); }
-	if (!l.opt.empty()) { fputc('\t', fp); fputs(l.opt.c_str(), fp); }
-	fputs(extra.c_str(), fp);
-	fputc('\n', fp);
-}
-
-static void mark_splitters(const opts_t &o, std::vector<line_t> &blk, int mask)
-{
-	std::vector<line_t*> arr;
-	for (auto &l : blk) if (l.flag & mask) arr.push_back(&l);
-	if (arr.size() < 2 || (int)arr.size() > o.max_split) return;
-	for (auto *l : arr) if ((l->flag & 0x4) || l->seq < 0) return;
-	std::stable_sort(arr.begin(), arr.end(), [](const line_t *a, const line_t *b) { return a->sqo < b->sqo; });
-	line_t *left = arr[0];
-	for (size_t i = 1; i < arr.size(); ++i) {
-		line_t *right = arr[i];
-		int lo = std::max(left->sqo, right->sqo), hi = std::min(left->eqo, right->eqo);
-		int overlap = std::max(1 + hi - lo, 0);
-		int alen1 = 1 + left->eqo - left->sqo, alen2 = 1 + right->eqo - right->sqo;
-		int mno = std::min(alen1, alen2) - overlap;
-		int desert = right->sqo - left->eqo - 1; bool ok = true;
-		if (mno < o.min_non_overlap) ok = false;
-		else if (left->seq == right->seq && (left->flag & 0x10) == (right->flag & 0x10)) {
-			long long ld, rd, ins;
-			if (!(left->flag & 0x10)) { ld = (long long)left->pos - left->sqo; rd = (long long)right->pos - right->sqo; ins = rd - ld; }
-			else { ld = (long long)left->pos + left->ralen - 1 + left->sqo; rd = (long long)right->pos + right->ralen - 1 + right->sqo; ins = ld - rd; }
-			if (desert > 0 && desert - (ins > 0 ? ins : 0) > o.max_unmapped) ok = false;
-			if ((ins < 0 ? -ins : ins) < o.min_indel) ok = false;
-		} else if (desert > o.max_unmapped) ok = false;
-		if (ok) left->split = right->split = true;
-		left = right;
-	}
 }
 
 int main(int argc, char **argv)
 {
-	opts_t o = { false, false, 2, 20, 50, 50 };
+	ssg_sbl_opt_t o; ssg_sbl_opt_init(&o);
 	const char *spl_path = 0, *disc_path = 0;
 	for (int i = 1; i < argc; ++i) {
-		if (!strcmp(argv[i], "--excludeDups")) o.exclude_dups = true;
-		else if (!strcmp(argv[i], "--addMateTags")) o.add_mate_tags = true;
-		else if (!strcmp(argv[i], "--maxSplitCount") && i + 1 < argc) o.max_split = atoi(argv[++i]);
+		if (!strcmp(argv[i], "--excludeDups")) o.exclude_dups = 1;
+		else if (!strcmp(argv[i], "--addMateTags")) o.add_mate_tags = 1;
+		else if (!strcmp(argv[i], "--maxSplitCount") && i + 1 < argc) o.max_split_count = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--minNonOverlap") && i + 1 < argc) o.min_non_overlap = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--maxUnmappedBases") && i + 1 < argc) o.max_unmapped_bases = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--minIndelSize") && i + 1 < argc) o.min_indel_size = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--splitterFile") && i + 1 < argc) spl_path = argv[++i];
 		else if (!strcmp(argv[i], "--discordantFile") && i + 1 < argc) disc_path = argv[++i];
 		else { fprintf(stderr, "[samblaster] unsupported option %s\n", argv[i]); return 1; }
 	}
-	FILE *spl = spl_path ? fopen(spl_path, "w") : 0, *disc = disc_path ? fopen(disc_path, "w") : 0;
-	if ((spl_path && !spl) || (disc_path && !disc)) { fprintf(stderr, "[samblaster] cannot open a side file\n"); return 1; }
+	FILE *splf = spl_path ? fopen(spl_path, "w") : 0, *discf = disc_path ? fopen(disc_path, "w") : 0;
+	if ((spl_path && !splf) || (disc_path && !discf)) { fprintf(stderr, "[samblaster] cannot open a side file\n"); return 1; }
+	out_t out(1); out_t *spl = splf ? new out_t(fileno(splf)) : 0, *disc = discf ? new out_t(fileno(discf)) : 0;
 	ssg_sbl_state_t *st = ssg_sbl_state_new();
-	std::map<std::string, int> seqs;
+	std::unordered_map<std::string, int> seqs;
 	const char *pg = "@PG\tID:SAMBLASTER\tVN:0.1.22-ssgpu\tCL:samblaster\n";
-	const size_t CHUNK = 1u << 18;     /* pairs per GPU call */
-	std::vector<std::vector<line_t> > blocks;
-	char *buf = 0; size_t cap = 0; ssize_t r; bool in_header = true;
+	size_t CHUNK = 1u << 18;     /* blocks per device call */
+	{ const char *e = getenv("SSG_SBL_CHUNK"); if (e && atol(e) > 0) CHUNK = (size_t)atol(e); }
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
 
-	auto flush = [&]() {
-		if (blocks.empty()) return;
-		std::vector<ssg_sbl_end_t> ends(2 * blocks.size()); std::vector<uint8_t> dup(blocks.size(), 0);
-		std::vector<std::pair<line_t*, line_t*> > prim(blocks.size());
-		for (size_t b = 0; b < blocks.size(); ++b) {
-			line_t *r1 = 0, *r2 = 0;
-			for (auto &l : blocks[b]) {
-				if (l.flag & (0x100 | 0x800)) continue;
-				if ((l.flag & 0x40) && !r1) r1 = &l; else if ((l.flag & 0x80) && !r2) r2 = &l;
+	std::vector<char> buf(64u << 20); size_t have = 0;       /* chunk text; complete lines are parsed in place */
+	std::vector<lrec_t> L; std::vector<ssg_sbl_line_t> N; std::vector<int64_t> blk_off; std::vector<uint8_t> bits; std::vector<int64_t> mate;
+	bool in_header = true, eof = false;
+	size_t scan = 0;            /* first unparsed byte */
+	std::string last_rname; int last_seq = -1;
+
+	auto parse_line = [&](size_t off, size_t len) -> bool {
+		const char *s = buf.data() + off, *e = s + len, *f[12]; int nf = 0;
+		f[nf++] = s;
+		for (const char *p = s; nf < 7; ) { const char *t = (const char*)memchr(p, '\t', (size_t)(e - p)); if (!t) break; f[nf++] = t + 1; p = t + 1; }
+		if (nf < 7) return false;
+		const char *p = f[6]; int more = 0;                   /* fields 7..11 are skipped, not read */
+		const char *opt = 0;
+		while (more < 5) { const char *t = (const char*)memchr(p, '\t', (size_t)(e - p)); if (!t) break; p = t + 1; ++more; }
+		if (more < 4) return false;                           /* fewer than 11 mandatory fields */
+		if (more == 5) opt = p;
+		lrec_t r; r.off = off; r.len = (uint32_t)len; r.qn_len = (uint32_t)(f[1] - 1 - s); r.flag_end = (uint32_t)(f[2] - 1 - s);
+		r.mq_off = (uint32_t)(f[4] - s); r.mq_len = (uint32_t)(f[5] - 1 - f[4]); r.cig_off = (uint32_t)(f[5] - s); r.cig_len = (uint32_t)(f[6] - 1 - f[5]);
+		r.opt_off = opt ? (uint32_t)(opt - s) : 0;
+		ssg_sbl_line_t n; n.flag = parse_uint(f[1], f[2] - 1); n.pos = parse_uint(f[3], f[4] - 1); n.mapq = parse_uint(f[4], f[5] - 1);
+		const size_t rl = (size_t)(f[3] - 1 - f[2]);
+		if (rl == 1 && f[2][0] == '*') n.seq = -1;
+		else if (rl == last_rname.size() && memcmp(f[2], last_rname.data(), rl) == 0) n.seq = last_seq;
+		else { last_rname.assign(f[2], rl); auto it = seqs.find(last_rname); last_seq = n.seq = it == seqs.end() ? -1 : it->second; }
+		n.lclip = n.rclip = n.qalen = n.ralen = 0;
+		const char *c = f[5], *ce = f[6] - 1;
+		if (!(ce - c == 1 && *c == '*')) {
+			bool first = true; int rc = 0;
+			while (c < ce) {
+				int k = 0; while (c < ce && *c >= '0' && *c <= '9') k = k * 10 + (*c++ - '0');
+				const char op = c < ce ? *c++ : 0;
+				if (op == 'S' || op == 'H') { if (first) n.lclip += k; rc += k; }
+				else { first = false; rc = 0; if (op == 'M' || op == '=' || op == 'X') { n.qalen += k; n.ralen += k; } else if (op == 'I') n.qalen += k; else if (op == 'D' || op == 'N') n.ralen += k; }
 			}
-			prim[b] = std::make_pair(r1, r2);
-			for (int e = 0; e < 2; ++e) {
-				const line_t *l = e ? r2 : r1; ssg_sbl_end_t &x = ends[2 * b + e];
-				if (r1 && r2) { x.seq = ((l->flag & 0x4) || l->seq < 0) ? -1 : l->seq; x.pos = l->pos; x.flag = l->flag | (x.seq < 0 ? 0x4 : 0); x.lclip = l->lclip; x.rclip = l->rclip; x.ralen = l->ralen; }
-				else { x.seq = -1; x.pos = 0; x.flag = 0x4; x.lclip = x.rclip = x.ralen = 0; }   /* unpaired block: never a duplicate */
-			}
+			n.rclip = (n.qalen + n.ralen) ? rc : 0;
 		}
-		if (ssg_sbl_markdup_stream(st, (long)blocks.size(), ends.data(), dup.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); exit(1); }
-		for (size_t b = 0; b < blocks.size(); ++b) {
-			auto &blk = blocks[b]; line_t *r1 = prim[b].first, *r2 = prim[b].second;
-			bool d = dup[b] && r1 && r2;
-			if (r1 && r2) { ++n_pairs; if (d) ++n_dups; }
-			std::vector<std::string> extra(blk.size());
-			for (size_t i = 0; i < blk.size(); ++i) {
-				line_t &l = blk[i];
-				if (d) l.flag |= 0x400;
-				if (o.add_mate_tags && r1 && r2) {
-					const line_t *mate = (l.flag & 0x40) ? r2 : (l.flag & 0x80) ? r1 : 0;
-					if (mate) {
-						if (!has_tag(l, "MC:Z:")) extra[i] += "\tMC:Z:" + mate->f[5];
-						if (!has_tag(l, "MQ:i:")) extra[i] += "\tMQ:i:" + mate->f[4];
-					}
-				}
-				write_line(stdout, l, 0, extra[i]);
-			}
-			if (!(d && o.exclude_dups) && r1 && r2) {
-				if (disc && !(r1->flag & 0x4) && !(r2->flag & 0x4) && r1->seq >= 0 && r2->seq >= 0 && !(r1->flag & 0x2)) {
-					write_line(disc, *r1, 0, extra[r1 - &blk[0]]); write_line(disc, *r2, 0, extra[r2 - &blk[0]]); ++n_disc;
-				}
-				if (spl) {
-					mark_splitters(o, blk, 0x40); mark_splitters(o, blk, 0x80);
-					for (size_t i = 0; i < blk.size(); ++i) if (blk[i].split) { write_line(spl, blk[i], (blk[i].flag & 0x40) ? "_1" : "_2", extra[i]); ++n_spl; }
-				}
-			}
+		L.push_back(r); N.push_back(n);
+		return true;
+	};
+	auto same_qname = [&](const lrec_t &a, const lrec_t &b) { return a.qn_len == b.qn_len && memcmp(buf.data() + a.off, buf.data() + b.off, a.qn_len) == 0; };
+
+	auto emit = [&](out_t &w, const lrec_t &r, int flag, bool patch_flag, const char *suffix, const lrec_t *m, bool add_mc, bool add_mq) {
+		const char *s = buf.data() + r.off;
+		if (!patch_flag && !suffix) w.put(s, r.len);
+		else {
+			w.put(s, r.qn_len); if (suffix) w.put(suffix, 2);
+			w.putc('\t'); w.puti(flag);
+			w.put(s + r.flag_end, r.len - r.flag_end);
 		}
-		blocks.clear();
+		if (m) {
+			const char *ms = buf.data() + m->off;
+			if (add_mc) { w.put("\tMC:Z:", 6); w.put(ms + m->cig_off, m->cig_len); }
+			if (add_mq) { w.put("\tMQ:i:", 6); w.put(ms + m->mq_off, m->mq_len); }
+		}
+		w.putc('\n');
 	};
 
-	std::vector<line_t> cur;
-	while ((r = getline(&buf, &cap, stdin)) > 0) {
-		while (r > 0 && (buf[r-1] == '\n' || buf[r-1] == '\r')) buf[--r] = 0;
-		if (in_header && buf[0] == '@') {
-			if (!strncmp(buf, "@SQ", 3)) { const char *sn = strstr(buf, "\tSN:"); if (sn) { sn += 4; const char *e = strchr(sn, '\t'); std::string nm = e ? std::string(sn, e - sn) : std::string(sn); int id = (int)seqs.size(); seqs[nm] = id; } }
-			fputs(buf, stdout); fputc('\n', stdout);
-			if (spl) { fputs(buf, spl); fputc('\n', spl); }
-			if (disc) { fputs(buf, disc); fputc('\n', disc); }
-			continue;
+	/* decide and write the blocks whose line offsets are offs[0..n_blocks] */
+	auto flush_blocks = [&](const std::vector<int64_t> &offs) {
+		const size_t n_blocks = offs.size() - 1;
+		if (!n_blocks) return;
+		const size_t nl = (size_t)offs[n_blocks];
+		bits.resize(nl); mate.resize(nl);
+		if (ssg_sbl_process(st, &o, (long)n_blocks, offs.data(), N.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); exit(1); }
+		auto tags = [&](int64_t i, const lrec_t *&m, bool &add_mc, bool &add_mq) {
+			const lrec_t &r = L[i];
+			m = (o.add_mate_tags && mate[i] >= 0) ? &L[mate[i]] : 0; add_mc = add_mq = false;
+			if (m) { const char *op = r.opt_off ? buf.data() + r.off + r.opt_off : 0, *oe = buf.data() + r.off + r.len; add_mc = !(op && has_tag(op, oe, "MC:Z:")); add_mq = !(op && has_tag(op, oe, "MQ:i:")); }
+		};
+		for (size_t b = 0; b < n_blocks; ++b) {
+			bool paired = false, dup = false; int64_t d1 = -1, d2 = -1;
+			for (int64_t i = offs[b]; i < offs[b + 1]; ++i) {
+				const int bt = bits[i];
+				if (mate[i] >= 0) paired = true;
+				if (bt & SSG_SBL_DUP) dup = true;
+				if (bt & SSG_SBL_DISC) { if (N[i].flag & 0x40) d1 = i; else d2 = i; }
+				const lrec_t *m; bool add_mc, add_mq; tags(i, m, add_mc, add_mq);
+				emit(out, L[i], N[i].flag | ((bt & SSG_SBL_DUP) ? 0x400 : 0), (bt & SSG_SBL_DUP) != 0, 0, m, add_mc, add_mq);
+			}
+			if (paired) { ++n_pairs; if (dup) ++n_dups; }
+			if (disc && d1 >= 0 && d2 >= 0) {   /* upstream order: read 1's primary, then read 2's */
+				for (int64_t i : { d1, d2 }) { const lrec_t *m; bool add_mc, add_mq; tags(i, m, add_mc, add_mq); emit(*disc, L[i], N[i].flag | (dup ? 0x400 : 0), dup, 0, m, add_mc, add_mq); }
+				++n_disc;
+			}
+			if (spl) for (int64_t i = offs[b]; i < offs[b + 1]; ++i) if (bits[i] & SSG_SBL_SPLIT) {
+				const lrec_t *m; bool add_mc, add_mq; tags(i, m, add_mc, add_mq);
+				emit(*spl, L[i], N[i].flag | (dup ? 0x400 : 0), true, (N[i].flag & 0x40) ? "_1" : "_2", m, add_mc, add_mq); ++n_spl;
+			}
 		}
-		if (in_header) { in_header = false; fputs(pg, stdout); if (spl) fputs(pg, spl); if (disc) fputs(pg, disc); }
-		line_t l; l.raw.assign(buf, r);
-		if (!parse_line(l, seqs)) { fprintf(stderr, "[samblaster] malformed SAM line\n"); return 1; }
-		if (!cur.empty() && cur[0].f[0] != l.f[0]) { blocks.push_back(std::move(cur)); cur.clear(); if (blocks.size() >= CHUNK) flush(); }
-		cur.push_back(std::move(l));
+	};
+
+	for (;;) {
+		if (!eof) {   /* fill */
+			if (have == buf.size()) buf.resize(buf.size() * 2);
+			ssize_t r = read(0, buf.data() + have, buf.size() - have);
+			if (r < 0) { if (errno == EINTR) continue; perror("[samblaster] read"); return 1; }
+			if (r == 0) { eof = true; if (have > scan && buf[have - 1] != '\n') { if (have == buf.size()) buf.resize(buf.size() + 1); buf[have++] = '\n'; } }
+			else have += (size_t)r;
+		}
+		/* parse complete lines */
+		while (scan < have) {
+			const char *nlp = (const char*)memchr(buf.data() + scan, '\n', have - scan);
+			if (!nlp) break;
+			size_t len = (size_t)(nlp - (buf.data() + scan)), lo = scan;
+			scan += len + 1;
+			while (len && buf[lo + len - 1] == '\r') --len;
+			if (in_header && len && buf[lo] == '@') {
+				if (len > 3 && !memcmp(buf.data() + lo, "@SQ", 3)) {
+					std::string ln(buf.data() + lo, len); size_t q = ln.find("\tSN:");
+					if (q != std::string::npos) { q += 4; size_t e = ln.find('\t', q); std::string nm = ln.substr(q, e == std::string::npos ? std::string::npos : e - q); int id = (int)seqs.size(); seqs.emplace(nm, id); }
+				}
+				out.put(buf.data() + lo, len); out.putc('\n');
+				if (spl) { spl->put(buf.data() + lo, len); spl->putc('\n'); }
+				if (disc) { disc->put(buf.data() + lo, len); disc->putc('\n'); }
+				continue;
+			}
+			if (in_header) { in_header = false; out.put(pg, strlen(pg)); if (spl) spl->put(pg, strlen(pg)); if (disc) disc->put(pg, strlen(pg)); }
+			if (!len) continue;
+			if (!parse_line(lo, len)) { fprintf(stderr, "[samblaster] malformed SAM line\n"); return 1; }
+			const size_t i = L.size() - 1;
+			if (i == 0 || !same_qname(L[i - 1], L[i])) blk_off.push_back((int64_t)i);
+		}
+		/* blocks complete so far: all but the last (it may continue in the next read) unless EOF */
+		const size_t n_open = blk_off.size(), n_done = eof ? n_open : (n_open ? n_open - 1 : 0);
+		if (n_done >= CHUNK || (eof && n_done)) {
+			const int64_t cut_line = eof ? (int64_t)L.size() : blk_off[n_done];
+			std::vector<int64_t> offs(blk_off.begin(), blk_off.begin() + n_done); offs.push_back(cut_line);
+			flush_blocks(offs);
+			/* compact: keep the lines of the open block and the unparsed tail */
+			const size_t cut_byte = (size_t)cut_line < L.size() ? L[(size_t)cut_line].off : scan;
+			memmove(buf.data(), buf.data() + cut_byte, have - cut_byte);
+			have -= cut_byte; scan -= cut_byte;
+			L.erase(L.begin(), L.begin() + cut_line); N.erase(N.begin(), N.begin() + cut_line);
+			for (auto &r : L) r.off -= cut_byte;
+			blk_off.clear(); if (!L.empty()) blk_off.push_back(0);
+		}
+		if (eof) break;
 	}
-	if (in_header) { fputs(pg, stdout); if (spl) fputs(pg, spl); if (disc) fputs(pg, disc); }
-	if (!cur.empty()) blocks.push_back(std::move(cur));
-	flush();
-	if (spl) fclose(spl);
-	if (disc) fclose(disc);
+	if (in_header) { out.put(pg, strlen(pg)); if (spl) spl->put(pg, strlen(pg)); if (disc) disc->put(pg, strlen(pg)); }
+	out.flush();
+	if (spl) { spl->flush(); fclose(splf); }
+	if (disc) { disc->flush(); fclose(discf); }
 	ssg_sbl_state_free(st);
-	free(buf);
-	fprintf(stderr, "[samblaster] pairs=%llu dups=%llu discordant_pairs=%llu splitter_lines=%llu (dedup on %s)\n", n_pairs, n_dups, n_disc, n_spl, ssg_backend());
+	fprintf(stderr, "[samblaster] pairs=%llu dups=%llu discordant_pairs=%llu splitter_lines=%llu (decisions on %s)\n", n_pairs, n_dups, n_disc, n_spl, ssg_backend());
 	return 0;
 }

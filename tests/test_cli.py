@@ -42,6 +42,14 @@ def test_cli_emu_matches_oracle(tmp_path, emu_lib):
     _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 300, seed=21)
 
 
+def test_cli_emu_samblaster_small_chunks(tmp_path, emu_lib, monkeypatch):
+    """device calls of 7 blocks each: the duplicate set in HBM must carry first-seen-wins across calls (and grow)"""
+    monkeypatch.setenv("SSG_SBL_CHUNK", "7")
+    monkeypatch.setenv("SSG_SBL_TABLE_SLOTS", "16")
+    emu = os.path.join(ROOT, "tests", "emu")
+    _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 200, seed=24)
+
+
 def test_cli_emu_insert_override(tmp_path, emu_lib):
     emu = os.path.join(ROOT, "tests", "emu")
     _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 120, seed=22, extra_bwa=("-I", "400,50"))
