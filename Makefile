@@ -33,8 +33,8 @@ tools/dbg/gather_probe: tools/dbg/gather_probe.cpp
 
 # the executables speedseq.config names (reference bin/speedseq.config:13-14)
 tools: bin/bwa bin/samblaster
-bin/bwa: $(HOST)/bwa_main.cpp include/ssgpu.h speedseq_amd/libssgpu.so
-	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
+bin/bwa: $(HOST)/bwa_main.cpp $(HOST)/fastq.h include/ssgpu.h speedseq_amd/libssgpu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
 bin/samblaster: $(HOST)/samblaster_main.cpp include/ssgpu.h speedseq_amd/libssgpu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Lspeedseq_amd -lssgpu -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
 
@@ -46,8 +46,8 @@ emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu
 tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
 		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
-tests/emu/bwa_emu: $(HOST)/bwa_main.cpp include/ssgpu.h tests/emu/libssgpu_emu.so
-	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -Wl,-rpath,'$$ORIGIN'
+tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOST)/fastq.h include/ssgpu.h tests/emu/libssgpu_emu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp include/ssgpu.h tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Ltests/emu -lssgpu_emu -Wl,-rpath,'$$ORIGIN'
 

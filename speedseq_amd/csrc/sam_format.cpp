@@ -6,6 +6,7 @@
  */
 #include <string>
 #include <vector>
+#include <thread>
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/ssgpu.h"
@@ -120,19 +121,16 @@ void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, con
 }
 } // namespace
 
-extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
-                              const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
-                              const char *rg_id, char **sam, int64_t *sam_off)
+/* pairs [p0, p1) into out; sam_off entries relative to out's start */
+static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, int p0, int p1, const char *const *names, const uint8_t *seq, const int64_t *off,
+                        const char *const *quals, const char *const *comments, const char *rg_id, sbuf &out, int64_t *sam_off)
 {
-	(void)opt;
 	const int64_t *req_off = ssg_pe_req_off(res);
 	const ssg_alnreq_t *req = ssg_pe_req(res);
 	const ssg_aln_t *alns = ssg_pe_alns(res);
-	sbuf out;
 	std::vector<const ssg_aln_t*> mains[2];
 	std::vector<std::string> xa[2];
-	ssg_aln_t unmapped; memset(&unmapped, 0, sizeof(unmapped)); unmapped.rid = -1; unmapped.pos = -1;
-	for (int p = 0; p < n_pairs; ++p) {
+	for (int p = p0; p < p1; ++p) {
 		mate_t mate[2];
 		for (int i = 0; i < 2; ++i) {
 			const int r = 2 * p + i;
@@ -166,10 +164,37 @@ extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, 
 				        (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id);
 		}
 	}
-	sam_off[2 * n_pairs] = (int64_t)out.s.size();
-	char *buf = (char*)malloc(out.s.size() + 1);
+	return 0;
+}
+
+/* Text assembly is split over host threads by ranges of pairs (opt->n_threads, as upstream's worker2 threads print), then joined in input order. */
+extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
+                              const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                              const char *rg_id, char **sam, int64_t *sam_off)
+{
+	int T = opt && opt->n_threads > 1 ? opt->n_threads : 1;
+	{ const char *e = getenv("SSG_FMT_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
+	if (T > 64) T = 64;
+	if (T > (n_pairs + 1023) / 1024) T = (n_pairs + 1023) / 1024;
+	if (T < 1) T = 1;
+	std::vector<sbuf> outs(T); std::vector<int> rcs(T, 0); std::vector<std::thread> th;
+	auto lo = [&](int t) { return (int)((int64_t)n_pairs * t / T); };
+	for (int t = 0; t < T; ++t) {
+		auto work = [&, t]() { outs[t].s.reserve((size_t)(lo(t + 1) - lo(t)) * 1000); rcs[t] = format_range(idx, res, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, outs[t], sam_off); };
+		if (T == 1) work(); else th.emplace_back(work);
+	}
+	for (auto &x : th) x.join();
+	size_t tot = 0;
+	for (int t = 0; t < T; ++t) { if (rcs[t]) return rcs[t]; tot += outs[t].s.size(); }
+	char *buf = (char*)malloc(tot + 1);
 	if (!buf) return SSG_ENOMEM;
-	memcpy(buf, out.s.data(), out.s.size()); buf[out.s.size()] = 0;
+	size_t base = 0;
+	for (int t = 0; t < T; ++t) {
+		memcpy(buf + base, outs[t].s.data(), outs[t].s.size());
+		for (int r = 2 * lo(t); r < 2 * lo(t + 1); ++r) sam_off[r] += (int64_t)base;
+		base += outs[t].s.size();
+	}
+	buf[tot] = 0; sam_off[2 * n_pairs] = (int64_t)tot;
 	*sam = buf;
 	return 0;
 }

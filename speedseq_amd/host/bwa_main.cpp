@@ -13,55 +13,14 @@
 #include <ctype.h>
 #include <string>
 #include <vector>
+#include <thread>
+#include <memory>
 #include <zlib.h>
 #include <unistd.h>
+#include "fastq.h"
 #include "../../include/ssgpu.h"
 
 static void die(const char *what) { fprintf(stderr, "[bwa] %s: %s\n", what, ssg_last_error()); exit(1); }
-
-struct fq_t {
-	gzFile fp; std::vector<char> buf;
-	bool getline(std::string &out)
-	{
-		out.clear();
-		if (buf.empty()) buf.resize(1 << 16);
-		for (;;) {
-			if (!gzgets(fp, buf.data(), (int)buf.size())) return !out.empty();
-			out.append(buf.data());
-			if (!out.empty() && out.back() == '\n') break;
-		}
-		while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
-		return true;
-	}
-};
-struct read_t { std::string name, comment, qual; std::vector<uint8_t> seq; bool has_qual; };
-
-static uint8_t nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
-
-/* one FASTQ/FASTA record with kseq semantics (name up to first blank, optional comment);
- * upstream bseq trims a trailing /1 or /2 */
-static int read1(fq_t &f, read_t &r, bool keep_comment)
-{
-	std::string l;
-	do { if (!f.getline(l)) return -1; } while (l.empty());
-	if (l[0] != '@' && l[0] != '>') return -2;
-	bool is_fq = l[0] == '@';
-	size_t e = 1; while (e < l.size() && !isspace((unsigned char)l[e])) ++e;
-	r.name = l.substr(1, e - 1);
-	while (e < l.size() && isspace((unsigned char)l[e])) ++e;
-	r.comment = keep_comment ? l.substr(e) : std::string();
-	if (r.name.size() > 2 && r.name[r.name.size() - 2] == '/' && isdigit((unsigned char)r.name.back())) r.name.resize(r.name.size() - 2);
-	if (!f.getline(l)) return -2;
-	r.seq.resize(l.size());
-	for (size_t i = 0; i < l.size(); ++i) r.seq[i] = nt4(l[i]);
-	r.has_qual = false;
-	if (is_fq) {
-		if (!f.getline(l) || l.empty() || l[0] != '+') return -2;
-		if (!f.getline(l) || l.size() != r.seq.size()) return -2;
-		r.qual = l; r.has_qual = true;
-	}
-	return 0;
-}
 
 static std::string unescape(const char *s)
 {	/* upstream bwa_set_rg: "\t" -> TAB */
@@ -104,7 +63,7 @@ static int main_mem(int argc, char **argv)
 		const char *a = argv[ai];
 		if (!strcmp(a, "-p")) interleaved = true;
 		else if (!strcmp(a, "-C")) keep_comment = true;
-		else if (!strcmp(a, "-M")) ;
+		else if (!strcmp(a, "-M")) { fprintf(stderr, "[bwa] -M (mark shorter split hits as secondary) is not supported; speedseq align does not pass it\n"); return 1; }
 		else if (!strcmp(a, "-t") && ai + 1 < argc) opt.n_threads = atoi(argv[++ai]);
 		else if (!strcmp(a, "-R") && ai + 1 < argc) rg = unescape(argv[++ai]);
 		else if (!strcmp(a, "-I") && ai + 1 < argc) { /* upstream main_mem -I: FR orientation only */
@@ -131,53 +90,107 @@ static int main_mem(int argc, char **argv)
 	}
 	ssg_index_t *idx;
 	if (ssg_index_load(argv[ai], &idx)) die("fail to load the index");
-	fq_t f1, f2; f1.fp = gzopen(argv[ai + 1], "r"); f2.fp = 0;
-	if (!f1.fp) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 1]); return 1; }
-	if (argc - ai >= 3) { f2.fp = gzopen(argv[ai + 2], "r"); if (!f2.fp) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 2]); return 1; } }
-	if (!interleaved && !f2.fp) { fprintf(stderr, "[bwa] single-end input is not supported: speedseq align is paired-end\n"); return 1; }
+	gzFile fp1 = gzopen(argv[ai + 1], "r"), fp2 = 0;
+	if (!fp1) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 1]); return 1; }
+	if (argc - ai >= 3) { fp2 = gzopen(argv[ai + 2], "r"); if (!fp2) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 2]); return 1; } }
+	if (!interleaved && !fp2) { fprintf(stderr, "[bwa] single-end input is not supported: speedseq align is paired-end\n"); return 1; }
 	/* header: upstream bwa_print_sam_hdr + @PG */
 	for (int i = 0; i < ssg_index_n_ctg(idx); ++i) printf("@SQ\tSN:%s\tLN:%d\n", ssg_index_name(idx, i), ssg_index_len(idx, i));
 	if (!rg.empty()) printf("%s\n", rg.c_str());
 	{ std::string cl = "bwa"; for (int i = 0; i < argc; ++i) { cl += ' '; cl += argv[i]; } printf("@PG\tID:bwa\tPN:bwa\tVN:0.7.12-ssgpu\tCL:%s\n", cl.c_str()); }
+	fflush(stdout);
+
+	/* Three overlapped stages, one batch each: (1) assemble upstream's batches from the reader threads' blocks, (2) align on the
+	 * MI355X, (3) format SAM (threads inside ssg_sam_format) and write.  Several upstream batches (bseq_read's chunk_size * n_threads
+	 * bases, even read count: the scope of the insert-size model) travel to the GPU in one call. */
+	struct batch_t {
+		std::vector<char> txt, qual; std::vector<uint8_t> seq; std::vector<int64_t> off;
+		std::vector<size_t> name_o, com_o, qual_o;            /* SIZE_MAX = absent */
+		std::vector<int32_t> pair_batch; int n_batches; int64_t id0;
+		ssg_pe_result_t *res;
+		batch_t() : n_batches(0), id0(0), res(0) { off.push_back(0); }
+		int n() const { return (int)name_o.size(); }
+		void add(const fq_block_t &b, int i)
+		{
+			name_o.push_back(txt.size()); txt.insert(txt.end(), b.txt.data() + b.name_o[i], b.txt.data() + b.name_o[i] + strlen(b.txt.data() + b.name_o[i]) + 1);
+			if (b.com_o[i] != UINT32_MAX) { com_o.push_back(txt.size()); txt.insert(txt.end(), b.txt.data() + b.com_o[i], b.txt.data() + b.com_o[i] + strlen(b.txt.data() + b.com_o[i]) + 1); } else com_o.push_back(SIZE_MAX);
+			seq.insert(seq.end(), b.seq.begin() + b.seq_o[i], b.seq.begin() + b.seq_o[i + 1]); off.push_back((int64_t)seq.size());
+			if (b.has_q[i]) { qual_o.push_back(qual.size()); const size_t l = b.seq_o[i + 1] - b.seq_o[i]; qual.insert(qual.end(), b.qual.data() + b.qual_o[i], b.qual.data() + b.qual_o[i] + l + 1); } else qual_o.push_back(SIZE_MAX);
+		}
+	};
 	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
-	const size_t max_pairs_per_call = 1u << 20;     /* several upstream batches go to the GPU at once */
-	int64_t id0 = 0; bool eof = false;
-	while (!eof) {
-		std::vector<read_t> reads; std::vector<int32_t> pair_batch; int n_batches = 0;
-		while (!eof && reads.size() / 2 < max_pairs_per_call) { /* upstream bseq_read: one batch */
-			int64_t size = 0; size_t n0 = reads.size();
-			for (;;) {
-				read_t a, b; int rc = read1(f1, a, keep_comment);
-				if (rc == -1) { eof = true; break; }
-				if (rc < 0 || read1(f2.fp ? f2 : f1, b, keep_comment) < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ (paired reads expected)\n"); return 1; }
-				if (a.name != b.name) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", a.name.c_str(), b.name.c_str()); return 1; }
-				size += (int64_t)a.seq.size() + (int64_t)b.seq.size();
-				reads.push_back(std::move(a)); reads.push_back(std::move(b));
-				if (size >= chunk) break;
+	size_t max_pairs_per_call = 1u << 20;
+	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
+	fq_feed_t feed1(fp1, keep_comment, 16384); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384) : 0);
+	chan_t<std::unique_ptr<batch_t> > to_gpu(1), to_fmt(1);
+	int fail = 0;
+	std::thread t_asm([&]() {
+		fq_cursor_t c1(feed1); std::unique_ptr<fq_cursor_t> c2(feed2 ? new fq_cursor_t(*feed2) : 0);
+		int64_t id0 = 0; bool eof = false;
+		while (!eof && !fail) {
+			std::unique_ptr<batch_t> B(new batch_t()); B->id0 = id0;
+			while (!eof && (size_t)B->n() / 2 < max_pairs_per_call) {   /* upstream bseq_read: one batch */
+				int64_t size = 0; const int n0 = B->n();
+				for (;;) {
+					const fq_block_t *ba, *bb; int ia, ib;
+					int rc = c1.next(&ba, &ia);
+					if (rc == -1) { eof = true; break; }
+					if (rc < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ\n"); fail = 1; eof = true; break; }
+					B->add(*ba, ia);
+					rc = (c2 ? *c2 : c1).next(&bb, &ib);
+					if (rc < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ (paired reads expected)\n"); fail = 1; eof = true; break; }
+					B->add(*bb, ib);
+					const int n = B->n();
+					if (strcmp(B->txt.data() + B->name_o[n - 2], B->txt.data() + B->name_o[n - 1]) != 0) {
+						fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", B->txt.data() + B->name_o[n - 2], B->txt.data() + B->name_o[n - 1]); fail = 1; eof = true; break; }
+					size += (B->off[n - 1] - B->off[n - 2]) + (B->off[n] - B->off[n - 1]);
+					if (size >= chunk) break;
+				}
+				if (fail) break;
+				if (B->n() > n0) { for (int p = n0 / 2; p < B->n() / 2; ++p) B->pair_batch.push_back(B->n_batches); ++B->n_batches; }
 			}
-			if (reads.size() > n0) { for (size_t p = n0 / 2; p < reads.size() / 2; ++p) pair_batch.push_back(n_batches); ++n_batches; }
+			if (fail || B->n() == 0) break;
+			id0 += B->n() / 2;
+			to_gpu.push(std::move(B));
 		}
-		if (reads.empty()) break;
-		const int n = (int)reads.size();
-		std::vector<int64_t> off(n + 1); std::vector<uint8_t> seq; std::vector<const char*> names(n), quals(n), comments(n);
-		off[0] = 0;
-		for (int i = 0; i < n; ++i) {
-			seq.insert(seq.end(), reads[i].seq.begin(), reads[i].seq.end()); off[i + 1] = (int64_t)seq.size();
-			names[i] = reads[i].name.c_str(); quals[i] = reads[i].has_qual ? reads[i].qual.c_str() : 0; comments[i] = reads[i].comment.empty() ? 0 : reads[i].comment.c_str();
+		to_gpu.close();
+	});
+	std::thread t_gpu([&]() {
+		std::unique_ptr<batch_t> B;
+		while (to_gpu.pop(B)) {
+			if (!fail && ssg_mem_process_pairs(idx, &opt, B->n() / 2, B->seq.data(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
+				fprintf(stderr, "[bwa] alignment failed: %s\n", ssg_last_error()); fail = 1; }
+			if (!fail) to_fmt.push(std::move(B));
 		}
-		ssg_pe_result_t *res; char *sam; std::vector<int64_t> sam_off(n + 1);
-		if (ssg_mem_process_pairs(idx, &opt, n / 2, seq.data(), off.data(), pair_batch.data(), n_batches, id0, pes, &res)) die("alignment failed");
-		if (ssg_sam_format(idx, &opt, res, n / 2, names.data(), seq.data(), off.data(), quals.data(), comments.data(), rg_id, &sam, sam_off.data())) die("SAM formatting failed");
-		fwrite(sam, 1, (size_t)sam_off[n], stdout);
-		const ssg_pestat_t *pp = ssg_pe_pes(res);
-		fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
-		        n, n_batches, ssg_backend(), pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
-		ssg_free(sam); ssg_pe_result_free(res);
-		id0 += n / 2;
+		to_fmt.close();
+	});
+	{	/* this thread: format + write */
+		std::unique_ptr<batch_t> B;
+		while (to_fmt.pop(B)) {
+			if (fail) { if (B->res) ssg_pe_result_free(B->res); continue; }
+			const int n = B->n();
+			std::vector<const char*> names(n), quals(n), comments(n);
+			for (int i = 0; i < n; ++i) {
+				names[i] = B->txt.data() + B->name_o[i];
+				quals[i] = B->qual_o[i] == SIZE_MAX ? 0 : B->qual.data() + B->qual_o[i];
+				comments[i] = B->com_o[i] == SIZE_MAX ? 0 : B->txt.data() + B->com_o[i];
+			}
+			char *sam; std::vector<int64_t> sam_off(n + 1);
+			if (ssg_sam_format(idx, &opt, B->res, n / 2, names.data(), B->seq.data(), B->off.data(), quals.data(), comments.data(), rg_id, &sam, sam_off.data())) {
+				fprintf(stderr, "[bwa] SAM formatting failed: %s\n", ssg_last_error()); fail = 1; ssg_pe_result_free(B->res); continue; }
+			for (size_t o = 0, tot = (size_t)sam_off[n]; o < tot; ) { ssize_t w = write(1, sam + o, tot - o); if (w < 0) { perror("[bwa] write"); fail = 1; break; } o += (size_t)w; }
+			const ssg_pestat_t *pp = ssg_pe_pes(B->res);
+			fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
+			        n, B->n_batches, ssg_backend(), pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
+			ssg_free(sam); ssg_pe_result_free(B->res);
+		}
 	}
-	gzclose(f1.fp); if (f2.fp) gzclose(f2.fp);
+	t_asm.join(); t_gpu.join();
+	{ std::unique_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
+	feed1.th.join(); if (feed2) feed2->th.join();
+	gzclose(fp1); if (fp2) gzclose(fp2);
 	ssg_index_destroy(idx);
-	return 0;
+	return fail;
 }
 
 int main(int argc, char **argv)

@@ -1,0 +1,154 @@
+/*
+ * fastq.h -- FASTQ / FASTA ingest for `bwa mem`: the record grammar of klib's kseq_read
+ * (/root/reference/src/samtools-1.3.1/htslib-1.3.1/htslib/kseq.h:189-229 -- header char '>' or '@', name up to the
+ * first blank, the rest of the line as comment, sequence lines until a line starting with '>', '+' or '@',
+ * quality lines until as many characters as bases; -2 on a truncated quality string) followed by upstream bseq.c's
+ * trim_readno ("/1", "/2" suffixes dropped).  One reader thread per input file inflates (zlib) and parses into
+ * blocks of records held in flat arenas -- no per-read allocation -- and hands them to the batch assembler through a
+ * bounded channel, so inflate + parse of both files overlap each other and the GPU.
+ */
+#ifndef SSG_FASTQ_H
+#define SSG_FASTQ_H
+#include <stdint.h>
+#include <string.h>
+#include <ctype.h>
+#include <zlib.h>
+#include <vector>
+#include <deque>
+#include <mutex>
+#include <condition_variable>
+#include <thread>
+#include <memory>
+
+template <class T> struct chan_t {      /* bounded single-producer / single-consumer channel */
+	std::mutex mu; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed;
+	explicit chan_t(size_t cap_ = 2) : cap(cap_), closed(false) {}
+	void push(T v) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(v)); cv.notify_all(); }
+	bool pop(T &v) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+	void close() { std::lock_guard<std::mutex> l(mu); closed = true; cv.notify_all(); }
+};
+
+struct fq_block_t {                     /* a run of consecutive records of one file */
+	std::vector<char> txt;              /* names and comments, NUL-terminated */
+	std::vector<uint32_t> name_o, com_o;    /* offsets into txt; com_o = UINT32_MAX: no comment */
+	std::vector<uint8_t> seq;           /* nt4 codes, concatenated */
+	std::vector<char> qual;             /* quality strings, each NUL-terminated, only for records with has_q */
+	std::vector<uint32_t> seq_o, qual_o;    /* n + 1 / n offsets */
+	std::vector<uint8_t> has_q;
+	int n, err;                         /* err: 0, or -2 truncated / malformed */
+	fq_block_t() : n(0), err(0) { seq_o.push_back(0); }
+};
+
+struct fq_stream_t {                    /* kstream over gzread */
+	gzFile fp; std::vector<unsigned char> buf; int begin, end; bool is_eof;
+	explicit fq_stream_t(gzFile f) : fp(f), buf(1 << 20), begin(0), end(0), is_eof(false) { gzbuffer(fp, 1 << 20); }
+	inline bool fill() { if (is_eof) return false; begin = 0; end = gzread(fp, buf.data(), (unsigned)buf.size()); if (end <= 0) { end = 0; is_eof = true; return false; } return true; }
+	inline int getc() { if (begin >= end && !fill()) return -1; return buf[begin++]; }
+	/* ks_getuntil2: append to out until the delimiter (0 = any blank, 2 = end of line); returns -1 at EOF with nothing read; *dret = delimiter */
+	template <class V> int getuntil(int delim, V &out, int *dret)
+	{
+		bool got = false; size_t l0 = out.size();
+		if (dret) *dret = 0;
+		for (;;) {
+			if (begin >= end) { if (!fill()) break; }
+			int i;
+			if (delim == 2) { const unsigned char *p = (const unsigned char*)memchr(buf.data() + begin, '\n', (size_t)(end - begin)); i = p ? (int)(p - buf.data()) : end; }
+			else { for (i = begin; i < end; ++i) if (isspace(buf[i])) break; }
+			got = true;
+			out.insert(out.end(), buf.data() + begin, buf.data() + i);
+			begin = i + 1;
+			if (i < end) { if (dret) *dret = buf[i]; break; }
+		}
+		if (!got && is_eof && begin >= end) return -1;
+		if (delim == 2 && out.size() - l0 > 1 && out.back() == '\r') out.pop_back();
+		return (int)(out.size() - l0);
+	}
+};
+
+static inline uint8_t fq_nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+
+struct fq_reader_t {
+	fq_stream_t ks; int last_char; bool keep_comment;
+	fq_reader_t(gzFile f, bool kc) : ks(f), last_char(0), keep_comment(kc) {}
+	/* kseq_read + kseq2bseq1 + trim_readno into block b; >= 0 length, -1 EOF, -2 truncated quality */
+	int next(fq_block_t &b)
+	{
+		int c;
+		if (last_char == 0) { while ((c = ks.getc()) != -1 && c != '>' && c != '@') {} if (c == -1) return -1; last_char = c; }
+		const size_t name0 = b.txt.size();
+		if (ks.getuntil(0, b.txt, &c) < 0) return -1;
+		size_t name_end = b.txt.size();
+		if (name_end - name0 > 2 && b.txt[name_end - 2] == '/' && isdigit((unsigned char)b.txt[name_end - 1])) { b.txt.resize(name_end - 2); name_end -= 2; }   /* trim_readno */
+		b.txt.push_back(0);
+		uint32_t com = UINT32_MAX;
+		if (c != '\n') {
+			const size_t c0 = b.txt.size();
+			ks.getuntil(2, b.txt, 0);
+			if (keep_comment && b.txt.size() > c0) { b.txt.push_back(0); com = (uint32_t)c0; } else b.txt.resize(c0);
+		}
+		const size_t s0 = b.seq.size();
+		while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
+			if (c == '\n') continue;
+			b.seq.push_back((uint8_t)c);
+			ks.getuntil(2, b.seq, 0);
+		}
+		if (c == '>' || c == '@') last_char = c;
+		const size_t l_seq = b.seq.size() - s0;
+		bool hq = false; const size_t q0 = b.qual.size();
+		if (c == '+') {
+			while ((c = ks.getc()) != -1 && c != '\n') {}
+			if (c == -1) return -2;
+			while (ks.getuntil(2, b.qual, 0) >= 0 && b.qual.size() - q0 < l_seq) {}
+			last_char = 0;
+			if (b.qual.size() - q0 != l_seq) return -2;
+			b.qual.push_back(0); hq = true;
+		}
+		for (size_t i = s0; i < b.seq.size(); ++i) b.seq[i] = fq_nt4(b.seq[i]);
+		b.name_o.push_back((uint32_t)name0); b.com_o.push_back(com); b.seq_o.push_back((uint32_t)b.seq.size());
+		b.qual_o.push_back((uint32_t)q0); b.has_q.push_back(hq ? 1 : 0); ++b.n;
+		return (int)l_seq;
+	}
+};
+
+/* reader thread: blocks of up to `per_block` records into the channel; the last block carries err / a short count, then the channel closes */
+struct fq_feed_t {
+	chan_t<std::unique_ptr<fq_block_t> > ch; std::thread th;
+	fq_feed_t(gzFile fp, bool keep_comment, int per_block) : ch(4)
+	{
+		th = std::thread([this, fp, keep_comment, per_block]() {
+			fq_reader_t rd(fp, keep_comment);
+			for (;;) {
+				std::unique_ptr<fq_block_t> b(new fq_block_t());
+				b->txt.reserve((size_t)per_block * 48); b->seq.reserve((size_t)per_block * 160); b->qual.reserve((size_t)per_block * 160);
+				int rc = 0;
+				while (b->n < per_block && (rc = rd.next(*b)) >= 0) {}
+				if (rc == -2) b->err = -2;
+				const bool last = rc < 0;
+				if (b->n || b->err) ch.push(std::move(b));
+				if (last) break;
+			}
+			ch.close();
+		});
+	}
+	~fq_feed_t() { if (th.joinable()) th.join(); }
+};
+
+/* sequential view over a feed: one record at a time */
+struct fq_cursor_t {
+	fq_feed_t &feed; std::unique_ptr<fq_block_t> cur; int i;
+	explicit fq_cursor_t(fq_feed_t &f) : feed(f), i(0) {}
+	/* 0: record (*blk, *idx) available; -1 EOF; -2 malformed */
+	int next(const fq_block_t **blk, int *idx)
+	{
+		while (!cur || i >= cur->n) {
+			if (cur && cur->err) return cur->err;
+			std::unique_ptr<fq_block_t> nb;
+			if (!feed.ch.pop(nb)) return -1;
+			cur = std::move(nb); i = 0;
+			if (cur->n == 0 && cur->err) return cur->err;
+		}
+		*blk = cur.get(); *idx = i++;
+		return 0;
+	}
+};
+#endif

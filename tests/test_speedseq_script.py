@@ -1,8 +1,11 @@
-"""BASELINE.json configs[0]: the reference's own `speedseq align` script (bin/speedseq:189-504), run
-UNMODIFIED from /root/reference with a speedseq.config that names this repo's executables -- here
-the CPU oracle builds of `bwa` / `samblaster` plus the sambamba / parallel shims (CPU plumbing, no
-GPU).  Skipped where the reference checkout is absent (e.g. on the GPU box)."""
-import gzip
+"""BASELINE.json configs[0]: the reference's own `speedseq align` script (bin/speedseq:189-504), run UNMODIFIED with a
+speedseq.config that names this repo's executables (the reference's plugin mechanism, bin/speedseq.config:13-14):
+  * the CPU oracle's `bwa` / `samblaster`        (plumbing baseline),
+  * the host-emulation build of the product's    (same sources as bin/bwa, bin/samblaster; CPU box),
+  * the product executables on the MI355X        (-m gpu),
+each time with this repo's sambamba / parallel.  The three BAMs of the product runs must decode (samtools view) to the
+same records as the oracle run's.  The script comes from /root/reference when present, else from the fixture copy
+tests/golden/speedseq_ref_script.sh (tests/golden/make_golden.sh)."""
 import os
 import shutil
 import subprocess
@@ -12,50 +15,99 @@ import pytest
 import simreads
 from common import EXAMPLE_FA, ROOT
 
-REF_SCRIPT = "/root/reference/bin/speedseq"
+REF_SCRIPT = "/root/reference/bin/speedseq" if os.path.exists("/root/reference/bin/speedseq") else os.path.join(ROOT, "tests", "golden", "speedseq_ref_script.sh")
 SAMTOOLS = os.path.join(ROOT, "oracle", "_ref", "samtools")
+ORC = os.path.join(ROOT, "oracle", "orc_bwa")
+EMU = os.path.join(ROOT, "tests", "emu")
 
 
-@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not present")
-def test_reference_align_script_with_oracle_tools(tmp_path):
-    if not os.path.exists(SAMTOOLS):
+def _need_tools():
+    if not os.path.exists(SAMTOOLS) and os.path.exists("/root/reference"):
         subprocess.check_call(["sh", os.path.join(ROOT, "oracle", "build_ref_tools.sh")])
     if not os.path.exists(SAMTOOLS) or shutil.which("mawk") is None:
         pytest.skip("samtools (oracle/_ref) or mawk unavailable")
-    orc = os.path.join(ROOT, "oracle", "orc_bwa")
-    if not os.path.exists(orc):
+    if not os.path.exists(ORC):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-    bindir = tmp_path / "bin"
-    bindir.mkdir()
-    (bindir / "bwa").write_text("#!/bin/sh\nexec %s \"$@\"\n" % orc)
-    (bindir / "samblaster").write_text("#!/bin/sh\nexec %s samblaster \"$@\"\n" % orc)
-    for f in ("bwa", "samblaster"):
-        os.chmod(bindir / f, 0o755)
-    os.symlink(shutil.which("mawk"), bindir / "gawk")        # the script hard-codes `gawk`
-    cfg = tmp_path / "speedseq.config"
-    cfg.write_text("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s/bin/sambamba\nPARALLEL=%s/bin/parallel\n" % (bindir, bindir, ROOT, ROOT))
-    ref = tmp_path / "ref.fa"
+
+
+def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4):
+    """runs the reference script in directory d with wrappers around the given executables; returns the output prefix"""
+    os.makedirs(d)
+    bindir = os.path.join(d, "bin")
+    os.makedirs(bindir)
+    for name, cmd in (("bwa", bwa_cmd), ("samblaster", samblaster_cmd)):
+        with open(os.path.join(bindir, name), "w") as f:
+            f.write("#!/bin/sh\nexec %s \"$@\"\n" % cmd)
+        os.chmod(os.path.join(bindir, name), 0o755)
+    os.symlink(shutil.which("mawk"), os.path.join(bindir, "gawk"))        # the script hard-codes `gawk`
+    cfg = os.path.join(d, "speedseq.config")
+    with open(cfg, "w") as f:
+        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s/bin/sambamba\nPARALLEL=%s/bin/parallel\n" % (bindir, bindir, ROOT, ROOT))
+    ref = os.path.join(d, "ref.fa")
     shutil.copy(EXAMPLE_FA, ref)   # no index next to it: the script must call `$BWA index`
-    contigs = simreads.read_fasta(str(ref))
-    pairs = simreads.simulate(contigs, 1500, seed=11)
-    fq = tmp_path / "reads.fq.gz"
-    simreads.write_fastq(str(fq), pairs)
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
-    out = tmp_path / "example"
-    r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", str(cfg), "-o", str(out), "-M", "3", "-t", "4", "-p",
-                        "-R", "@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1", str(ref), str(fq)],
-                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    out = os.path.join(d, "example")
+    r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", out, "-M", "3", "-t", str(n_threads), "-p",
+                        "-R", "@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1", ref, fq],
+                       cwd=d, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for ext in ("amb", "ann", "bwt", "pac", "sa"):     # `$BWA index` ran and wrote upstream's bytes
+        assert open(ref + "." + ext, "rb").read() == open(EXAMPLE_FA + "." + ext, "rb").read(), ext
+    return out
+
+
+def _view(bam):
+    txt = subprocess.check_output([SAMTOOLS, "view", "-h", bam], text=True)
+    return [l for l in txt.split("\n") if not l.startswith("@PG")]
+
+
+def _check_outputs(out):
     for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
-        assert os.path.getsize(str(out) + suffix) > 0
-        assert os.path.exists(str(out) + suffix + ".bai")
-    n = int(subprocess.check_output([SAMTOOLS, "view", "-c", str(out) + ".bam"]))
-    assert n >= 3000
-    dups = int(subprocess.check_output([SAMTOOLS, "view", "-c", "-f", "1024", str(out) + ".bam"]))
-    assert dups > 50                                            # simulated 5 % duplicate fragments
-    hdr = subprocess.check_output([SAMTOOLS, "view", "-H", str(out) + ".bam"], text=True)
+        assert os.path.getsize(out + suffix) > 0
+        assert os.path.exists(out + suffix + ".bai")
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", out + ".bam"])) >= 3000
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", "-f", "1024", out + ".bam"])) > 50     # simulated 5 % duplicate fragments
+    hdr = subprocess.check_output([SAMTOOLS, "view", "-H", out + ".bam"], text=True)
     assert "SO:coordinate" in hdr and "@RG\tID:NA12878" in hdr
-    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", str(out) + ".splitters.bam"])) > 0
-    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", str(out) + ".discordants.bam"])) > 0
-    rec = subprocess.check_output([SAMTOOLS, "view", str(out) + ".splitters.bam"], text=True).split("\n")[0].split("\t")
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", out + ".splitters.bam"])) > 0
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", out + ".discordants.bam"])) > 0
+    rec = subprocess.check_output([SAMTOOLS, "view", out + ".splitters.bam"], text=True).split("\n")[0].split("\t")
     assert rec[9] == "*" and rec[10] == "*" and (rec[0].endswith("_1") or rec[0].endswith("_2"))
+
+
+def _fastq(tmp_path, n_pairs=1500):
+    fq = str(tmp_path / "reads.fq.gz")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=11))
+    return fq
+
+
+def _compare(out, exp):
+    for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
+        assert _view(out + suffix) == _view(exp + suffix), suffix
+
+
+def test_reference_align_script_with_oracle_tools(tmp_path):
+    _need_tools()
+    out = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", _fastq(tmp_path))
+    _check_outputs(out)
+
+
+def test_reference_align_script_with_product_sources_emulated(tmp_path, emu_lib):
+    """the product's bwa / samblaster host code + kernel sources (host-emulation build) behind the unmodified script"""
+    _need_tools()
+    fq = _fastq(tmp_path)
+    exp = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", fq)
+    out = _run_align(str(tmp_path / "emu"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq)
+    _check_outputs(out)
+    _compare(out, exp)
+
+
+@pytest.mark.gpu
+def test_reference_align_script_with_product_executables(tmp_path, gpu_lib):
+    """the product executables on the MI355X behind the unmodified script; BAMs decode-equal to the oracle run's"""
+    _need_tools()
+    fq = _fastq(tmp_path, 4000)
+    exp = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", fq)
+    out = _run_align(str(tmp_path / "gpu"), os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster"), fq)
+    _check_outputs(out)
+    _compare(out, exp)
