@@ -162,6 +162,79 @@ def gpu_sample_sam(lib, idx, opt, hs, hoff, names, contig_names, lens):
     return text, dup
 
 
+def write_fastq(path, reads_np, rl, first_pair=0):
+    """interleaved FASTQ of the uint8 codes [2n, rl]; fixed-width names p%09d, constant quality"""
+    n2 = reads_np.shape[0]
+    name_w = 10
+    rec = np.empty((n2, 1 + name_w + 1 + rl + 3 + rl + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("p")
+    ids = (np.arange(n2, dtype=np.int64) // 2) + first_pair
+    for k in range(9):
+        rec[:, 2 + k] = ord("0") + (ids // 10 ** (8 - k)) % 10
+    c = 1 + name_w
+    rec[:, c] = 10
+    rec[:, c + 1:c + 1 + rl] = np.frombuffer(b"ACGTN", dtype=np.uint8)[reads_np]
+    rec[:, c + 1 + rl] = 10
+    rec[:, c + 2 + rl] = ord("+")
+    rec[:, c + 3 + rl] = 10
+    rec[:, c + 4 + rl:c + 4 + 2 * rl] = ord("I")
+    rec[:, c + 4 + 2 * rl] = 10
+    rec.tofile(path)
+
+
+def e2e_leg(a, td, prefix, reads, rl, ns, orc_exe):
+    """The plugin path as the reference wires it (bin/speedseq:438-439): FASTQ file -> `bwa mem -t T -p` | `samblaster --excludeDups
+    --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile --discordantFile` -> three SAM streams on files, wall clock.
+    The index is loaded from the files written by ssg_index_save; the rate excludes that one-off load (reported separately).
+    A sample of the same FASTQ goes through the oracle's executables and the three streams must be byte-identical (modulo @PG)."""
+    import subprocess
+    import re
+    bwa, sbl = os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster")
+    rn = reads.cpu().numpy()
+    fq = os.path.join(td, "reads.fq")
+    write_fastq(fq, rn, rl)
+    sfq = os.path.join(td, "sample.fq")
+    write_fastq(sfq, rn[:2 * ns], rl)
+    res = {"pairs": int(rn.shape[0] // 2), "bwa_threads": a.bwa_threads, "fastq": "uncompressed interleaved file in /dev/shm, 3 SAM streams written to /dev/shm"}
+
+    def run(bwa_cmd, sbl_cmd, fastq, tag, threads):
+        o, sp, di = (os.path.join(td, tag + x) for x in (".sam", ".spl.sam", ".disc.sam"))
+        cmd = "%s mem -t %d -p %s %s 2> %s.bwa.err | %s --excludeDups --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile %s --discordantFile %s > %s 2> %s.sbl.err" % (
+            bwa_cmd, threads, prefix, fastq, os.path.join(td, tag), sbl_cmd, sp, di, o, os.path.join(td, tag))
+        t = time.perf_counter()
+        rc = subprocess.call(["bash", "-c", "set -o pipefail; " + cmd])
+        t = time.perf_counter() - t
+        err = open(os.path.join(td, tag + ".bwa.err")).read()
+        if rc != 0:
+            raise RuntimeError("pipeline %s failed rc=%d: %s %s" % (tag, rc, err[-500:], open(os.path.join(td, tag + ".sbl.err")).read()[-500:]))
+        return t, err, (o, sp, di)
+
+    t, err, files = run(bwa, sbl, fq, "full", a.bwa_threads)
+    m = re.search(r"wall: index load ([0-9.]+) s, reads -> SAM ([0-9.]+) s", err)
+    t_load, t_run = (float(m.group(1)), float(m.group(2))) if m else (None, None)
+    res.update({"wall_s": round(t, 2), "index_load_s": t_load, "reads_to_sam_s": t_run,
+                "pairs_per_s": res["pairs"] / (t - t_load) if t_load is not None else res["pairs"] / t,
+                "pairs_per_s_incl_index_load": res["pairs"] / t,
+                "sam_bytes": os.path.getsize(files[0]), "splitter_bytes": os.path.getsize(files[1]), "discordant_bytes": os.path.getsize(files[2])})
+    # gz input (the reference pipeline reads .fq.gz): one inflate stream bounds the ingest
+    if subprocess.call(["bash", "-c", "gzip -1 -c %s > %s.gz" % (fq, fq)]) == 0:
+        tg, errg, _ = run(bwa, sbl, fq + ".gz", "fullgz", a.bwa_threads)
+        mg = re.search(r"wall: index load ([0-9.]+) s", errg)
+        res["pairs_per_s_gz_input"] = res["pairs"] / (tg - float(mg.group(1))) if mg else res["pairs"] / tg
+    # parity of the executables on the sample
+    _, _, gf = run(bwa, sbl, sfq, "s_gpu", a.bwa_threads)
+    _, _, of = run(orc_exe, orc_exe + " samblaster", sfq, "s_orc", min(os.cpu_count() or 1, 64))   # one upstream batch either way: -t only sets the worker count
+
+    def nopg(p):
+        return [l for l in open(p).read().split("\n") if not l.startswith("@PG")]
+    same = [nopg(x) == nopg(y) for x, y in zip(gf, of)]
+    res["sample_pairs"] = ns
+    res["sample_streams_identical"] = bool(all(same))
+    res["sample_streams"] = {"sam": same[0], "splitters": same[1], "discordants": same[2]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +246,7 @@ def main():
     ap.add_argument("--bwa-threads", type=int, default=16, help="the -t whose batch boundaries (insert-size model scope) are reproduced")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload aligned by the CPU oracle: parity gate + cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,13 +302,18 @@ def main():
 
     def step(want_dup=False):
         if not multi:
-            return capi.hotpath_dev(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0, want_dup)
+            return capi.hotpath_dev_ex(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0)
         # N > 1: every rank aligns its shard; duplicates are decided over the whole input (first-seen-wins on the global pair
-        # ordinal): signatures routed to an owner rank by hash with one all-to-all, verdicts routed back (speedseq_amd/dist.py)
-        summary, _ = capi.hotpath_dev_sig(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), d_sig.data_ptr(), n_batches, 0)
+        # ordinal): signatures routed to an owner rank by hash with one all-to-all, verdicts routed back (speedseq_amd/dist.py);
+        # the side-stream classification (discordant / splitter, --excludeDups) then runs on the records still resident in HBM
+        summary, h = capi.hotpath_dev_ex(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0,
+                                         local_dedup=False, d_sig=d_sig.data_ptr(), keep=True)
         valid = d_sig[:, 0] != -1
-        dup = ssdist.global_markdup(d_sig, valid, ordinal, device=dev)
-        n_dup_global[0] = int(dup.sum())
+        dup = ssdist.global_markdup(d_sig, valid, ordinal, device=dev).to(torch.uint8).contiguous()
+        c = capi.dev_records_classify(lib, h, dup.data_ptr())
+        capi.dev_records_free(lib, h)
+        summary[1], summary[8], summary[9], summary[10] = c[0], c[1], c[2], c[3]
+        n_dup_global[0] = int(c[0])
         return summary, dup
 
     for _ in range(a.warmup):
@@ -272,6 +351,7 @@ def main():
                    "pairs_per_gpu": a.pairs, "read_len": rl, "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2), "ref_synth_s": round(t_ref, 2),
                    "records": int(summary[0]), "dup_pairs": n_dup_global[0] if multi else int(summary[1]), "dup_pairs_local_view": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
                    "bwt_extends": int(summary[6]), "chains": int(summary[7]),
+                   "sam_lines": int(summary[10]), "discordant_stream_lines": int(summary[8]), "splitter_stream_lines": int(summary[9]),
                    "dedup_scope": "global over all ranks (all-to-all signature exchange)" if multi else "single GPU = whole input"},
     }
     if rank == 0:
@@ -331,12 +411,13 @@ def main():
             ns = min(a.cpu_sample, a.pairs)
             orc = oracle_py.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
             shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-            with tempfile.TemporaryDirectory(dir=shm) as td:
-                prefix = os.path.join(td, "ref.fa")
-                tw = time.time()
-                lib.index_save(idx, prefix)           # the five `bwa index` files of the device-built index
-                oidx = orc.idx_load(prefix)           # ... loaded by the oracle: the index bytes cross the file format both ways
-                t_files = time.time() - tw
+            td_obj = tempfile.TemporaryDirectory(dir=shm)
+            td = td_obj.name
+            prefix = os.path.join(td, "ref.fa")
+            tw = time.time()
+            lib.index_save(idx, prefix)           # the five `bwa index` files of the device-built index
+            oidx = orc.idx_load(prefix)           # ... loaded by the oracle: the index bytes cross the file format both ways
+            t_files = time.time() - tw
             hs = reads[:2 * ns].cpu().numpy().reshape(-1)
             hoff = np.arange(2 * ns + 1, dtype=np.int64) * rl
             names = ["r%d" % (i // 2) for i in range(2 * ns)]
@@ -361,6 +442,14 @@ def main():
                                      "on the index files written by ssg_index_save" % ns, "index_files_roundtrip_s": round(t_files, 1)}
             out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
                                    "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded" % (ns, cores)}
+            if a.e2e:
+                try:
+                    out["e2e"] = e2e_leg(a, td, prefix, reads, rl, ns, orc_exe=os.path.join(ROOT, "oracle", "orc_bwa"))
+                    if not out["e2e"].get("sample_streams_identical", True):
+                        ok = False
+                except Exception as e:      # the plugin-path measurement must not take the headline down with it
+                    out["e2e"] = {"error": repr(e)}
+            td_obj.cleanup()
             if not ok:   # no timing counts without parity
                 out["value"] = None
                 out["invalid"] = "parity gate failed: GPU records differ from the oracle on the sample"

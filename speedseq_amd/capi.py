@@ -235,6 +235,27 @@ def hotpath_dev(lib, idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_b
     return summary, dup
 
 
+def hotpath_dev_ex(lib, idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, n_batches=1, id0=0, local_dedup=True, d_sig=None, keep=False):
+    """ssg_hotpath_dev_ex: summary[16] (see include/ssgpu.h) and, with keep=True, the handle of the records left in HBM."""
+    summary = np.zeros(16, dtype=np.uint64)
+    h = C.c_void_p()
+    lib._chk(lib.l.ssg_hotpath_dev_ex(idx, _ptr(opt), C.c_int(n_pairs), C.c_int(max_len), C.c_void_p(d_seq), C.c_void_p(d_off), C.c_void_p(d_pair_batch),
+                                      C.c_int(n_batches), C.c_int64(id0), None, C.c_int(1 if local_dedup else 0), _ptr(summary), None,
+                                      C.c_void_p(d_sig) if d_sig else None, C.byref(h) if keep else None))
+    return summary, (h if keep else None)
+
+
+def dev_records_classify(lib, h, d_dup):
+    """samblaster's classification of kept records with externally decided duplicate flags (device pointer, one byte per pair)."""
+    counts = np.zeros(4, dtype=np.uint64)
+    lib._chk(lib.l.ssg_dev_records_classify(h, None, C.c_void_p(d_dup), _ptr(counts)))
+    return counts
+
+
+def dev_records_free(lib, h):
+    lib.l.ssg_dev_records_free(h)
+
+
 def hotpath_dev_sig(lib, idx, opt, n_pairs, max_len, d_seq, d_off, d_pair_batch, d_sig, n_batches=1, id0=0):
     """hotpath_dev that also writes the pair signatures (device pointer d_sig: n_pairs x 3 uint64) for dist.global_markdup."""
     summary = np.zeros(8, dtype=np.uint64)

@@ -20,6 +20,8 @@
 #include "fastq.h"
 #include "../../include/ssgpu.h"
 
+#include <time.h>
+static double wall() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static void die(const char *what) { fprintf(stderr, "[bwa] %s: %s\n", what, ssg_last_error()); exit(1); }
 
 static std::string unescape(const char *s)
@@ -89,7 +91,9 @@ static int main_mem(int argc, char **argv)
 		rg_id[i] = 0;
 	}
 	ssg_index_t *idx;
+	const double t_start = wall();
 	if (ssg_index_load(argv[ai], &idx)) die("fail to load the index");
+	const double t_loaded = wall();
 	gzFile fp1 = gzopen(argv[ai + 1], "r"), fp2 = 0;
 	if (!fp1) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 1]); return 1; }
 	if (argc - ai >= 3) { fp2 = gzopen(argv[ai + 2], "r"); if (!fp2) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 2]); return 1; } }
@@ -186,6 +190,7 @@ static int main_mem(int argc, char **argv)
 		}
 	}
 	t_asm.join(); t_gpu.join();
+	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> SAM %.2f s\n", t_loaded - t_start, wall() - t_loaded);
 	{ std::unique_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
 	feed1.th.join(); if (feed2) feed2->th.join();
 	gzclose(fp1); if (fp2) gzclose(fp2);
