@@ -35,8 +35,8 @@ tools/dbg/gather_probe: tools/dbg/gather_probe.cpp
 tools: bin/bwa bin/samblaster
 bin/bwa: $(HOST)/bwa_main.cpp $(HOST)/fastq.h include/ssgpu.h speedseq_amd/libssgpu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
-bin/samblaster: $(HOST)/samblaster_main.cpp include/ssgpu.h speedseq_amd/libssgpu.so
-	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Lspeedseq_amd -lssgpu -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
+bin/samblaster: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h include/ssgpu.h speedseq_amd/libssgpu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
 
 oracle:
 	$(MAKE) -C oracle
@@ -48,8 +48,8 @@ tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(
 		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
 tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOST)/fastq.h include/ssgpu.h tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
-tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp include/ssgpu.h tests/emu/libssgpu_emu.so
-	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Ltests/emu -lssgpu_emu -Wl,-rpath,'$$ORIGIN'
+tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h include/ssgpu.h tests/emu/libssgpu_emu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so bin/bwa bin/samblaster tests/emu/bwa_emu tests/emu/samblaster_emu $(CSRC)/*.o

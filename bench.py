@@ -183,7 +183,7 @@ def write_fastq(path, reads_np, rl, first_pair=0):
     rec.tofile(path)
 
 
-def e2e_leg(a, td, prefix, reads, rl, ns, orc_exe):
+def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
     """The plugin path as the reference wires it (bin/speedseq:438-439): FASTQ file -> `bwa mem -t T -p` | `samblaster --excludeDups
     --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile --discordantFile` -> three SAM streams on files, wall clock.
     The index is loaded from the files written by ssg_index_save; the rate excludes that one-off load (reported separately).
@@ -192,6 +192,8 @@ def e2e_leg(a, td, prefix, reads, rl, ns, orc_exe):
     import re
     bwa, sbl = os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster")
     rn = reads.cpu().numpy()
+    if reads2 is not None:
+        rn = np.concatenate([rn, reads2.numpy()])      # the timed batch + a second one: several device calls, so the stages overlap
     fq = os.path.join(td, "reads.fq")
     write_fastq(fq, rn, rl)
     sfq = os.path.join(td, "sample.fq")
@@ -212,6 +214,9 @@ def e2e_leg(a, td, prefix, reads, rl, ns, orc_exe):
 
     t, err, files = run(bwa, sbl, fq, "full", a.bwa_threads)
     m = re.search(r"wall: index load ([0-9.]+) s, reads -> SAM ([0-9.]+) s", err)
+    mb = re.search(r"stage busy time: (.*)", err)
+    if mb:
+        res["bwa_stage_busy"] = mb.group(1)
     t_load, t_run = (float(m.group(1)), float(m.group(2))) if m else (None, None)
     res.update({"wall_s": round(t, 2), "index_load_s": t_load, "reads_to_sam_s": t_run,
                 "pairs_per_s": res["pairs"] / (t - t_load) if t_load is not None else res["pairs"] / t,
@@ -288,6 +293,7 @@ def main():
 
     rl = a.read_len
     reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev)
+    reads_e2e = simulate_pairs(ref, lens, a.pairs, rl, 1012, dev).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0) else None   # second million for the plugin-path leg
     d_seq = reads.reshape(-1)
     d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
     pb, n_batches = bwa_batches(a.pairs, rl, a.bwa_threads)
@@ -444,7 +450,7 @@ def main():
                                    "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded" % (ns, cores)}
             if a.e2e:
                 try:
-                    out["e2e"] = e2e_leg(a, td, prefix, reads, rl, ns, orc_exe=os.path.join(ROOT, "oracle", "orc_bwa"))
+                    out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, ns, orc_exe=os.path.join(ROOT, "oracle", "orc_bwa"))
                     if not out["e2e"].get("sample_streams_identical", True):
                         ok = False
                 except Exception as e:      # the plugin-path measurement must not take the headline down with it

@@ -17,6 +17,8 @@
 #include <memory>
 #include <zlib.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <errno.h>
 #include "fastq.h"
 #include "../../include/ssgpu.h"
 
@@ -103,6 +105,9 @@ static int main_mem(int argc, char **argv)
 	if (!rg.empty()) printf("%s\n", rg.c_str());
 	{ std::string cl = "bwa"; for (int i = 0; i < argc; ++i) { cl += ' '; cl += argv[i]; } printf("@PG\tID:bwa\tPN:bwa\tVN:0.7.12-ssgpu\tCL:%s\n", cl.c_str()); }
 	fflush(stdout);
+#ifdef F_SETPIPE_SZ
+	(void)fcntl(1, F_SETPIPE_SZ, 1 << 20);   /* fewer wake-ups on the pipe to samblaster */
+#endif
 
 	/* Three overlapped stages, one batch each: (1) assemble upstream's batches from the reader threads' blocks, (2) align on the
 	 * MI355X, (3) format SAM (threads inside ssg_sam_format) and write.  Several upstream batches (bseq_read's chunk_size * n_threads
@@ -123,15 +128,16 @@ static int main_mem(int argc, char **argv)
 		}
 	};
 	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
-	size_t max_pairs_per_call = 1u << 20;
+	size_t max_pairs_per_call = 1u << 19;   /* upstream batches are grouped up to this many pairs per device call (one batch alone may exceed it) */
 	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
 	fq_feed_t feed1(fp1, keep_comment, 16384); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384) : 0);
 	chan_t<std::unique_ptr<batch_t> > to_gpu(1), to_fmt(1);
-	int fail = 0;
+	int fail = 0; double tm_asm = 0, tm_gpu = 0;
 	std::thread t_asm([&]() {
 		fq_cursor_t c1(feed1); std::unique_ptr<fq_cursor_t> c2(feed2 ? new fq_cursor_t(*feed2) : 0);
 		int64_t id0 = 0; bool eof = false;
 		while (!eof && !fail) {
+			const double t0 = wall();
 			std::unique_ptr<batch_t> B(new batch_t()); B->id0 = id0;
 			while (!eof && (size_t)B->n() / 2 < max_pairs_per_call) {   /* upstream bseq_read: one batch */
 				int64_t size = 0; const int n0 = B->n();
@@ -155,6 +161,7 @@ static int main_mem(int argc, char **argv)
 			}
 			if (fail || B->n() == 0) break;
 			id0 += B->n() / 2;
+			tm_asm += wall() - t0;
 			to_gpu.push(std::move(B));
 		}
 		to_gpu.close();
@@ -162,16 +169,29 @@ static int main_mem(int argc, char **argv)
 	std::thread t_gpu([&]() {
 		std::unique_ptr<batch_t> B;
 		while (to_gpu.pop(B)) {
+			const double t0 = wall();
 			if (!fail && ssg_mem_process_pairs(idx, &opt, B->n() / 2, B->seq.data(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
 				fprintf(stderr, "[bwa] alignment failed: %s\n", ssg_last_error()); fail = 1; }
+			tm_gpu += wall() - t0;
 			if (!fail) to_fmt.push(std::move(B));
 		}
 		to_fmt.close();
 	});
-	{	/* this thread: format + write */
+	struct text_t { char *sam; size_t len; };
+	chan_t<text_t> to_write(2);
+	std::thread t_write([&]() {   /* stdout is a pipe in the reference's pipeline: its reader sets the pace, so writing gets its own thread */
+		text_t t;
+		while (to_write.pop(t)) {
+			for (size_t o = 0; o < t.len && !fail; ) { ssize_t w = write(1, t.sam + o, t.len - o); if (w < 0) { if (errno == EINTR) continue; perror("[bwa] write"); fail = 1; break; } o += (size_t)w; }
+			ssg_free(t.sam);
+		}
+	});
+	double tm_fmt = 0;
+	{	/* this thread: format */
 		std::unique_ptr<batch_t> B;
 		while (to_fmt.pop(B)) {
 			if (fail) { if (B->res) ssg_pe_result_free(B->res); continue; }
+			const double t0 = wall();
 			const int n = B->n();
 			std::vector<const char*> names(n), quals(n), comments(n);
 			for (int i = 0; i < n; ++i) {
@@ -182,15 +202,19 @@ static int main_mem(int argc, char **argv)
 			char *sam; std::vector<int64_t> sam_off(n + 1);
 			if (ssg_sam_format(idx, &opt, B->res, n / 2, names.data(), B->seq.data(), B->off.data(), quals.data(), comments.data(), rg_id, &sam, sam_off.data())) {
 				fprintf(stderr, "[bwa] SAM formatting failed: %s\n", ssg_last_error()); fail = 1; ssg_pe_result_free(B->res); continue; }
-			for (size_t o = 0, tot = (size_t)sam_off[n]; o < tot; ) { ssize_t w = write(1, sam + o, tot - o); if (w < 0) { perror("[bwa] write"); fail = 1; break; } o += (size_t)w; }
+			tm_fmt += wall() - t0;
 			const ssg_pestat_t *pp = ssg_pe_pes(B->res);
 			fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
 			        n, B->n_batches, ssg_backend(), pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
-			ssg_free(sam); ssg_pe_result_free(B->res);
+			ssg_pe_result_free(B->res);
+			text_t t; t.sam = sam; t.len = (size_t)sam_off[n];
+			to_write.push(t);
 		}
 	}
+	to_write.close(); t_write.join();
 	t_asm.join(); t_gpu.join();
 	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> SAM %.2f s\n", t_loaded - t_start, wall() - t_loaded);
+	fprintf(stderr, "[bwa] stage busy time: assemble %.2f s, device call %.2f s, format %.2f s\n", tm_asm, tm_gpu, tm_fmt);
 	{ std::unique_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
 	feed1.th.join(); if (feed2) feed2->th.join();
 	gzclose(fp1); if (fp2) gzclose(fp2);

@@ -16,10 +16,14 @@
 #include <stdint.h>
 #include <unistd.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <memory>
+#include <thread>
 #include "../../include/ssgpu.h"
+#include "fastq.h"   /* chan_t */
 
 struct out_t {           /* buffered writer on a file descriptor */
 	int fd; std::vector<char> b; size_t n;
@@ -66,6 +70,9 @@ int main(int argc, char **argv)
 	FILE *splf = spl_path ? fopen(spl_path, "w") : 0, *discf = disc_path ? fopen(disc_path, "w") : 0;
 	if ((spl_path && !splf) || (disc_path && !discf)) { fprintf(stderr, "[samblaster] cannot open a side file\n"); return 1; }
 	out_t out(1); out_t *spl = splf ? new out_t(fileno(splf)) : 0, *disc = discf ? new out_t(fileno(discf)) : 0;
+#ifdef F_SETPIPE_SZ
+	(void)fcntl(0, F_SETPIPE_SZ, 1 << 20); (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);
+#endif
 	ssg_sbl_state_t *st = ssg_sbl_state_new();
 	std::unordered_map<std::string, int> seqs;
 	const char *pg = "@PG\tID:SAMBLASTER\tVN:0.1.22-ssgpu\tCL:samblaster\n";
@@ -73,14 +80,19 @@ int main(int argc, char **argv)
 	{ const char *e = getenv("SSG_SBL_CHUNK"); if (e && atol(e) > 0) CHUNK = (size_t)atol(e); }
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
 
-	std::vector<char> buf(64u << 20); size_t have = 0;       /* chunk text; complete lines are parsed in place */
-	std::vector<lrec_t> L; std::vector<ssg_sbl_line_t> N; std::vector<int64_t> blk_off; std::vector<uint8_t> bits; std::vector<int64_t> mate;
-	bool in_header = true, eof = false;
-	size_t scan = 0;            /* first unparsed byte */
+	/* a chunk of the stream: text + the in-place view of its complete blocks.  The reader thread fills and parses chunks, this
+	 * thread takes the device decisions and writes; the two overlap through a bounded channel. */
+	struct chunk_t {
+		std::vector<char> buf; size_t have, scan; std::string header;   /* header: @-lines (+ the @PG line) that precede this chunk's records */
+		std::vector<lrec_t> L; std::vector<ssg_sbl_line_t> N; std::vector<int64_t> offs;   /* offs: block starts, then the end */
+		chunk_t() : buf(64u << 20), have(0), scan(0) {}
+	};
+	chan_t<std::unique_ptr<chunk_t> > ch(2);
+	bool in_header = true; int parse_fail = 0;
 	std::string last_rname; int last_seq = -1;
 
-	auto parse_line = [&](size_t off, size_t len) -> bool {
-		const char *s = buf.data() + off, *e = s + len, *f[12]; int nf = 0;
+	auto parse_line = [&](chunk_t &C, size_t off, size_t len) -> bool {
+		const char *s = C.buf.data() + off, *e = s + len, *f[12]; int nf = 0;
 		f[nf++] = s;
 		for (const char *p = s; nf < 7; ) { const char *t = (const char*)memchr(p, '\t', (size_t)(e - p)); if (!t) break; f[nf++] = t + 1; p = t + 1; }
 		if (nf < 7) return false;
@@ -109,34 +121,86 @@ int main(int argc, char **argv)
 			}
 			n.rclip = (n.qalen + n.ralen) ? rc : 0;
 		}
-		L.push_back(r); N.push_back(n);
+		C.L.push_back(r); C.N.push_back(n);
 		return true;
 	};
-	auto same_qname = [&](const lrec_t &a, const lrec_t &b) { return a.qn_len == b.qn_len && memcmp(buf.data() + a.off, buf.data() + b.off, a.qn_len) == 0; };
 
-	auto emit = [&](out_t &w, const lrec_t &r, int flag, bool patch_flag, const char *suffix, const lrec_t *m, bool add_mc, bool add_mq) {
-		const char *s = buf.data() + r.off;
-		if (!patch_flag && !suffix) w.put(s, r.len);
-		else {
-			w.put(s, r.qn_len); if (suffix) w.put(suffix, 2);
-			w.putc('\t'); w.puti(flag);
-			w.put(s + r.flag_end, r.len - r.flag_end);
+	std::thread reader([&]() {
+		std::unique_ptr<chunk_t> C(new chunk_t()); bool eof = false;
+		while (!eof && !parse_fail) {
+			if (C->have == C->buf.size()) C->buf.resize(C->buf.size() * 2);
+			ssize_t r = read(0, C->buf.data() + C->have, C->buf.size() - C->have);
+			if (r < 0) { if (errno == EINTR) continue; perror("[samblaster] read"); parse_fail = 1; break; }
+			if (r == 0) { eof = true; if (C->have > C->scan && C->buf[C->have - 1] != '\n') { if (C->have == C->buf.size()) C->buf.resize(C->buf.size() + 1); C->buf[C->have++] = '\n'; } }
+			else C->have += (size_t)r;
+			while (C->scan < C->have) {   /* parse complete lines */
+				const char *nlp = (const char*)memchr(C->buf.data() + C->scan, '\n', C->have - C->scan);
+				if (!nlp) break;
+				size_t len = (size_t)(nlp - (C->buf.data() + C->scan)), lo = C->scan;
+				C->scan += len + 1;
+				while (len && C->buf[lo + len - 1] == '\r') --len;
+				if (in_header && len && C->buf[lo] == '@') {
+					if (len > 3 && !memcmp(C->buf.data() + lo, "@SQ", 3)) {
+						std::string ln(C->buf.data() + lo, len); size_t q = ln.find("\tSN:");
+						if (q != std::string::npos) { q += 4; size_t e = ln.find('\t', q); std::string nm = ln.substr(q, e == std::string::npos ? std::string::npos : e - q); int id = (int)seqs.size(); seqs.emplace(nm, id); }
+					}
+					C->header.append(C->buf.data() + lo, len); C->header.push_back('\n');
+					continue;
+				}
+				if (in_header) { in_header = false; C->header.append(pg); }
+				if (!len) continue;
+				if (!parse_line(*C, lo, len)) { fprintf(stderr, "[samblaster] malformed SAM line\n"); parse_fail = 1; break; }
+				const size_t i = C->L.size() - 1;
+				if (i == 0 || !(C->L[i - 1].qn_len == C->L[i].qn_len && memcmp(C->buf.data() + C->L[i - 1].off, C->buf.data() + C->L[i].off, C->L[i].qn_len) == 0)) C->offs.push_back((int64_t)i);
+			}
+			/* blocks complete so far: all but the last (it may continue in the next read) unless EOF */
+			const size_t n_open = C->offs.size(), n_done = eof ? n_open : (n_open ? n_open - 1 : 0);
+			if (n_done >= CHUNK || eof) {
+				const int64_t cut_line = eof ? (int64_t)C->L.size() : C->offs[n_done];
+				std::unique_ptr<chunk_t> nx;
+				if (!eof) {   /* the open block's lines and the unparsed tail start the next chunk (re-parsed there) */
+					nx.reset(new chunk_t());
+					const size_t cut_byte = (size_t)cut_line < C->L.size() ? C->L[(size_t)cut_line].off : C->scan;
+					const size_t keep = C->have - cut_byte;
+					if (keep > nx->buf.size()) nx->buf.resize(keep * 2);
+					memcpy(nx->buf.data(), C->buf.data() + cut_byte, keep); nx->have = keep;
+				}
+				C->L.resize((size_t)cut_line); C->N.resize((size_t)cut_line); C->offs.resize(n_done); C->offs.push_back(cut_line);
+				ch.push(std::move(C));
+				C = std::move(nx);
+			}
 		}
-		if (m) {
-			const char *ms = buf.data() + m->off;
-			if (add_mc) { w.put("\tMC:Z:", 6); w.put(ms + m->cig_off, m->cig_len); }
-			if (add_mq) { w.put("\tMQ:i:", 6); w.put(ms + m->mq_off, m->mq_len); }
-		}
-		w.putc('\n');
-	};
+		ch.close();
+	});
 
-	/* decide and write the blocks whose line offsets are offs[0..n_blocks] */
-	auto flush_blocks = [&](const std::vector<int64_t> &offs) {
+	std::vector<uint8_t> bits; std::vector<int64_t> mate;
+	std::unique_ptr<chunk_t> C;
+	bool wrote_header = false;
+	while (ch.pop(C)) {
+		chunk_t &K = *C;
+		if (!K.header.empty()) { out.put(K.header.data(), K.header.size()); if (spl) spl->put(K.header.data(), K.header.size()); if (disc) disc->put(K.header.data(), K.header.size()); wrote_header = true; }
+		const std::vector<int64_t> &offs = K.offs;
 		const size_t n_blocks = offs.size() - 1;
-		if (!n_blocks) return;
+		if (!n_blocks) continue;
+		const std::vector<lrec_t> &L = K.L; const std::vector<ssg_sbl_line_t> &N = K.N; const std::vector<char> &buf = K.buf;
 		const size_t nl = (size_t)offs[n_blocks];
 		bits.resize(nl); mate.resize(nl);
 		if (ssg_sbl_process(st, &o, (long)n_blocks, offs.data(), N.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); exit(1); }
+		auto emit = [&](out_t &w, const lrec_t &r, int flag, bool patch_flag, const char *suffix, const lrec_t *m, bool add_mc, bool add_mq) {
+			const char *s = buf.data() + r.off;
+			if (!patch_flag && !suffix) w.put(s, r.len);
+			else {
+				w.put(s, r.qn_len); if (suffix) w.put(suffix, 2);
+				w.putc('\t'); w.puti(flag);
+				w.put(s + r.flag_end, r.len - r.flag_end);
+			}
+			if (m) {
+				const char *ms = buf.data() + m->off;
+				if (add_mc) { w.put("\tMC:Z:", 6); w.put(ms + m->cig_off, m->cig_len); }
+				if (add_mq) { w.put("\tMQ:i:", 6); w.put(ms + m->mq_off, m->mq_len); }
+			}
+			w.putc('\n');
+		};
 		auto tags = [&](int64_t i, const lrec_t *&m, bool &add_mc, bool &add_mq) {
 			const lrec_t &r = L[i];
 			m = (o.add_mate_tags && mate[i] >= 0) ? &L[mate[i]] : 0; add_mc = add_mq = false;
@@ -162,55 +226,10 @@ int main(int argc, char **argv)
 				emit(*spl, L[i], N[i].flag | (dup ? 0x400 : 0), true, (N[i].flag & 0x40) ? "_1" : "_2", m, add_mc, add_mq); ++n_spl;
 			}
 		}
-	};
-
-	for (;;) {
-		if (!eof) {   /* fill */
-			if (have == buf.size()) buf.resize(buf.size() * 2);
-			ssize_t r = read(0, buf.data() + have, buf.size() - have);
-			if (r < 0) { if (errno == EINTR) continue; perror("[samblaster] read"); return 1; }
-			if (r == 0) { eof = true; if (have > scan && buf[have - 1] != '\n') { if (have == buf.size()) buf.resize(buf.size() + 1); buf[have++] = '\n'; } }
-			else have += (size_t)r;
-		}
-		/* parse complete lines */
-		while (scan < have) {
-			const char *nlp = (const char*)memchr(buf.data() + scan, '\n', have - scan);
-			if (!nlp) break;
-			size_t len = (size_t)(nlp - (buf.data() + scan)), lo = scan;
-			scan += len + 1;
-			while (len && buf[lo + len - 1] == '\r') --len;
-			if (in_header && len && buf[lo] == '@') {
-				if (len > 3 && !memcmp(buf.data() + lo, "@SQ", 3)) {
-					std::string ln(buf.data() + lo, len); size_t q = ln.find("\tSN:");
-					if (q != std::string::npos) { q += 4; size_t e = ln.find('\t', q); std::string nm = ln.substr(q, e == std::string::npos ? std::string::npos : e - q); int id = (int)seqs.size(); seqs.emplace(nm, id); }
-				}
-				out.put(buf.data() + lo, len); out.putc('\n');
-				if (spl) { spl->put(buf.data() + lo, len); spl->putc('\n'); }
-				if (disc) { disc->put(buf.data() + lo, len); disc->putc('\n'); }
-				continue;
-			}
-			if (in_header) { in_header = false; out.put(pg, strlen(pg)); if (spl) spl->put(pg, strlen(pg)); if (disc) disc->put(pg, strlen(pg)); }
-			if (!len) continue;
-			if (!parse_line(lo, len)) { fprintf(stderr, "[samblaster] malformed SAM line\n"); return 1; }
-			const size_t i = L.size() - 1;
-			if (i == 0 || !same_qname(L[i - 1], L[i])) blk_off.push_back((int64_t)i);
-		}
-		/* blocks complete so far: all but the last (it may continue in the next read) unless EOF */
-		const size_t n_open = blk_off.size(), n_done = eof ? n_open : (n_open ? n_open - 1 : 0);
-		if (n_done >= CHUNK || (eof && n_done)) {
-			const int64_t cut_line = eof ? (int64_t)L.size() : blk_off[n_done];
-			std::vector<int64_t> offs(blk_off.begin(), blk_off.begin() + n_done); offs.push_back(cut_line);
-			flush_blocks(offs);
-			/* compact: keep the lines of the open block and the unparsed tail */
-			const size_t cut_byte = (size_t)cut_line < L.size() ? L[(size_t)cut_line].off : scan;
-			memmove(buf.data(), buf.data() + cut_byte, have - cut_byte);
-			have -= cut_byte; scan -= cut_byte;
-			L.erase(L.begin(), L.begin() + cut_line); N.erase(N.begin(), N.begin() + cut_line);
-			for (auto &r : L) r.off -= cut_byte;
-			blk_off.clear(); if (!L.empty()) blk_off.push_back(0);
-		}
-		if (eof) break;
 	}
+	reader.join();
+	if (parse_fail) return 1;
+	(void)wrote_header;
 	if (in_header) { out.put(pg, strlen(pg)); if (spl) spl->put(pg, strlen(pg)); if (disc) disc->put(pg, strlen(pg)); }
 	out.flush();
 	if (spl) { spl->flush(); fclose(splf); }
