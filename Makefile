@@ -32,7 +32,9 @@ tools/dbg/gather_probe: tools/dbg/gather_probe.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 
 # the executables speedseq.config names (reference bin/speedseq.config:13-14)
-tools: bin/bwa bin/samblaster
+tools: bin/bwa bin/samblaster bin/sambamba
+bin/sambamba: $(HOST)/sambamba_main.cpp $(HOST)/bamio.h include/ssgpu.h speedseq_amd/libssgpu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/sambamba_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
 bin/bwa: $(HOST)/bwa_main.cpp $(HOST)/fastq.h include/ssgpu.h speedseq_amd/libssgpu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
 bin/samblaster: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h include/ssgpu.h speedseq_amd/libssgpu.so
@@ -42,7 +44,7 @@ oracle:
 	$(MAKE) -C oracle
 
 # host emulation of the HIP execution model: same kernel + host sources, CPU-side tests only
-emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu
+emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu
 tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
 		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
@@ -51,7 +53,10 @@ tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOST)/fastq.h include/ssgpu.h tests/em
 tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h include/ssgpu.h tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 
+tests/emu/sambamba_emu: $(HOST)/sambamba_main.cpp $(HOST)/bamio.h include/ssgpu.h tests/emu/libssgpu_emu.so
+	$(CXX) -O2 -std=c++17 $(HOST)/sambamba_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
+
 clean:
-	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so bin/bwa bin/samblaster tests/emu/bwa_emu tests/emu/samblaster_emu $(CSRC)/*.o
+	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so bin/bwa bin/samblaster bin/sambamba tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu $(CSRC)/*.o
 	$(MAKE) -C oracle clean
 .PHONY: all lib tools oracle emu clean

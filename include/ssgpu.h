@@ -144,6 +144,10 @@ void ssg_sbl_opt_init(ssg_sbl_opt_t *o);
 int ssg_sbl_process(ssg_sbl_state_t *st, const ssg_sbl_opt_t *o, long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines,
                     uint8_t *line_bits, int64_t *mate_line);
 
+/* stable device radix sort of 64-bit keys, returned as a permutation: the coordinate sort of BAM records (samtools bam_sort.c:1607-1614
+ * key tid<<32 | (pos+1)<<1 | reverse; ties keep input order) for the `sambamba sort` the reference runs at bin/speedseq:427 (row f1) */
+int ssg_sort_u64_perm(const uint64_t *keys, int64_t n, uint32_t *perm);
+
 /* ---- the measured hot path with device-resident inputs (bench.py) ----
  * d_seq / d_off / d_pair_batch are DEVICE pointers; aligned + duplicate-marked records stay in HBM.
  * summary: [0] records [1] duplicate pairs [2] seeds [3] extension cells [4] rescue cells [5] rescues */

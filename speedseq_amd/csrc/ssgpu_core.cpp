@@ -294,10 +294,10 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 {
 	const int block = 64;
 	const bool quad = !(getenv("SSG_SMEM_KERNEL") && !strcmp(getenv("SSG_SMEM_KERNEL"), "lane"));
-	/* lanes per read: whole-block fetches per lane win while the rank blocks span <= ~2 GB (1.5 x the quad form at 1 GB); beyond
-	 * that a per-lane fetch pays 4x the translation work per line and drops below the quad form (tools/dbg/gather_probe.cpp) */
-	const uint64_t bwt_bytes = (idx->v.seq_len >> 7) * 64;
-	const int lpr = quad ? env_int("SSG_SMEM_LPR", bwt_bytes > (2ull << 30) ? 4 : 1) : 1, per_read = lpr;
+	/* lanes per read: 1 (each lane fetches whole rank blocks; 64 reads per wave keep the state machine's instruction count per
+	 * extension low) or 4 (quad-cooperative fetch: a quarter of the translation work per line, but 16 reads per wave make the kernel
+	 * VALU-bound).  Measured at the 3.1 Gbp headline size: 154 ms (LPR 1, at the per-lane gather rate of 21 G lines/s) vs 178 ms (LPR 4). */
+	const int lpr = quad ? env_int("SSG_SMEM_LPR", 1) : 1, per_read = lpr;
 	long nthreads = std::min<long>(((long)n_reads * per_read + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64);
 	int scap = max_len + 2;
 	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap / per_read + 64);
@@ -804,10 +804,10 @@ static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint3
 	return 0;
 #else
 	size_t tmp_bytes = 0;
-	if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs (size query) failed"; return SSG_EHIP; }
+	if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int64_t)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes);
 	CHKA(tmp);
-	if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; return SSG_EHIP; }
+	if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int64_t)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; return SSG_EHIP; }
 	return rt_sync();
 #endif
 }
@@ -917,6 +917,22 @@ int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_
 	CHK(d_ends.up(ends, 2 * n_pairs));
 	CHK(dedup_core(st, n_pairs, d_ends.p, d_dup.p));
 	return d_dup.down(dup, n_pairs);
+}
+
+/* stable sort of 64-bit keys on the device: perm[i] = input index of the i-th smallest key (equal keys keep input order).
+ * The coordinate sort of BAM records (samtools bam_sort.c:1607-1614 key, stable) is this call on the record keys (row f1). */
+__global__ void ssg_k_iota_u32(uint32_t *a, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = (uint32_t)i; }
+int ssg_sort_u64_perm(const uint64_t *keys, int64_t n, uint32_t *perm)
+{
+	CHK(need_device());
+	if (n <= 0) return 0;
+	if (n >= (1LL << 32)) { ssg_err_msg = "ssg_sort_u64_perm: more than 2^32 keys per call"; return SSG_EINVAL; }
+	dbuf<uint64_t> d_k(n), d_ks(n); dbuf<uint32_t> d_v(n), d_vs(n);
+	CHKA(d_k); CHKA(d_ks); CHKA(d_v); CHKA(d_vs);
+	CHK(d_k.up(keys, n));
+	SSG_LAUNCH(ssg_k_iota_u32, (n + 255) / 256, 256, 0, d_v.p, (long)n);
+	CHK(sort_pairs_u64(d_k.p, d_ks.p, d_v.p, d_vs.p, n));
+	return d_vs.down(perm, n);
 }
 
 void ssg_sbl_opt_init(ssg_sbl_opt_t *o)

@@ -1,0 +1,264 @@
+/*
+ * sambamba_main.cpp -- the `sambamba` executable speedseq.config names (reference bin/speedseq.config:9), with the
+ * sub-commands the reference's scripts issue:
+ *   view -S -f bam [-l N] /dev/stdin          SAM text -> BAM on stdout               bin/speedseq:426,433,440,447
+ *   view -H <in.bam>                          header text                             bin/speedseq:682,1032,1179
+ *   sort -t N -m XG --tmpdir=DIR -o out <in>  coordinate sort                         bin/speedseq:427,431,434,1950
+ *   index <in.bam>                            <in.bam>.bai                            bin/speedseq:486-494
+ *   merge -t N out.bam in1.bam in2.bam ...    merge of coordinate-sorted files        bin/speedseq:2002-2004
+ * Formats and orders follow the in-tree samtools / htslib 1.3.1 (bamio.h cites the lines).  Text parsing, BGZF (de)compression
+ * and the gather of sorted records run on host threads; the coordinate sort itself -- a stable sort of the 64-bit keys
+ * tid<<32 | (pos+1)<<1 | reverse -- runs on the MI355X through libssgpu (ssg_sort_u64_perm), chunk by chunk when the input
+ * exceeds the -m budget (chunks are spilled to --tmpdir and merged; ties keep input order, as samtools' merge of sorted blocks).
+ */
+#include <queue>
+#include <memory>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include "bamio.h"
+#include "../../include/ssgpu.h"
+
+static int hw_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)std::min(n, 32u) : 4; }
+static void die(const std::string &m) { fprintf(stderr, "[sambamba] %s\n", m.c_str()); exit(1); }
+static int open_in(const char *p) { if (!strcmp(p, "/dev/stdin") || !strcmp(p, "-")) return 0; int fd = open(p, O_RDONLY); if (fd < 0) die(std::string("cannot open ") + p); return fd; }
+
+/* ---------------- view ---------------- */
+static int cmd_view(int argc, char **argv)
+{
+	int level = -1, threads = hw_threads(); bool hdr_only = false, sam_in = false; const char *in = 0, *fmt = "sam";
+	for (int i = 0; i < argc; ++i) {
+		const char *a = argv[i];
+		if (!strcmp(a, "-S")) sam_in = true;
+		else if (!strcmp(a, "-H")) hdr_only = true;
+		else if (!strcmp(a, "-h")) ;
+		else if (!strcmp(a, "-f") && i + 1 < argc) fmt = argv[++i];
+		else if (!strcmp(a, "-l") && i + 1 < argc) level = atoi(argv[++i]);
+		else if (!strcmp(a, "-t") && i + 1 < argc) threads = atoi(argv[++i]);
+		else if (a[0] == '-' && a[1] && strcmp(a, "-")) die(std::string("view: unsupported option ") + a);
+		else in = a;
+	}
+	if (!in) die("usage: sambamba view [-S] [-f bam] [-l N] [-H] <in>");
+	const int fd = open_in(in);
+	if (hdr_only) {
+		bgzf_in_t bi(fd, 1); bam_hdr_t h;
+		if (!hdr_read(bi, h)) die("view -H: not a BAM file");
+		io_write_all(1, h.text.data(), h.text.size());
+		return 0;
+	}
+	if (!sam_in || strcmp(fmt, "bam")) die("view: only `-S -f bam` (SAM text to BAM) and `-H` are supported");
+	bgzf_out_t out(1, level, threads);
+	bam_hdr_t h; bool hdr_done = false;
+	std::vector<char> buf((size_t)64 << 20); size_t have = 0; bool eof = false;
+	while (!eof || have) {
+		if (!eof) {
+			if (have == buf.size()) buf.resize(buf.size() * 2);
+			ssize_t r = read(fd, buf.data() + have, buf.size() - have);
+			if (r < 0) { if (errno == EINTR) continue; die("view: read error"); }
+			if (r == 0) { eof = true; if (have && buf[have - 1] != '\n') { if (have == buf.size()) buf.resize(have + 1); buf[have++] = '\n'; } }
+			else have += (size_t)r;
+			if (!eof && have < buf.size() / 2) continue;      /* work on large pieces */
+		}
+		size_t end = have;
+		while (end > 0 && buf[end - 1] != '\n') --end;           /* complete lines only */
+		if (end == 0) { if (eof) break; continue; }
+		size_t p = 0;
+		while (!hdr_done && p < end) {
+			if (buf[p] != '@') { hdr_done = true; hdr_from_text(h); hdr_write(out, h); break; }
+			const char *nl = (const char*)memchr(buf.data() + p, '\n', end - p);
+			h.text.append(buf.data() + p, (size_t)(nl - (buf.data() + p)) + 1);
+			p = (size_t)(nl - buf.data()) + 1;
+		}
+		if (hdr_done && p < end) {
+			/* line starts, then threads encode contiguous ranges of lines */
+			std::vector<size_t> ls;
+			for (size_t q = p; q < end; ) { ls.push_back(q); const char *nl = (const char*)memchr(buf.data() + q, '\n', end - q); q = (size_t)(nl - buf.data()) + 1; }
+			ls.push_back(end);
+			const size_t nl_ = ls.size() - 1;
+			std::vector<std::vector<uint8_t> > enc((size_t)threads); std::vector<std::string> errs((size_t)threads);
+			parallel_for(threads, nl_, [&](size_t a, size_t b, int t) {
+				enc[(size_t)t].reserve((b - a) * 400);
+				for (size_t i = a; i < b && errs[(size_t)t].empty(); ++i) {
+					const char *s = buf.data() + ls[i], *e = buf.data() + ls[i + 1] - 1;
+					while (e > s && e[-1] == '\r') --e;
+					if (e == s) continue;
+					std::string er;
+					if (sam_line_to_bam(s, e, h, enc[(size_t)t], er)) errs[(size_t)t] = er + ": " + std::string(s, std::min<size_t>(80, (size_t)(e - s)));
+				}
+			});
+			for (auto &er : errs) if (!er.empty()) die("view: malformed SAM line (" + er + ")");
+			for (auto &v : enc) for (size_t o = 0; o < v.size(); ) { uint32_t bs; memcpy(&bs, v.data() + o, 4); out.record(v.data() + o, 4 + (size_t)bs); o += 4 + (size_t)bs; }
+		}
+		memmove(buf.data(), buf.data() + end, have - end); have -= end;
+		if (eof && !have) break;
+	}
+	if (!hdr_done) { hdr_from_text(h); hdr_write(out, h); }
+	out.finish();
+	return 0;
+}
+
+/* ---------------- sort ---------------- */
+static void change_so(std::string &text, const char *so)
+{	/* samtools bam_sort.c change_SO: @HD ... SO:<so> (added when there is no @HD line) */
+	if (text.size() > 3 && !text.compare(0, 3, "@HD")) {
+		size_t nl = text.find('\n'); if (nl == std::string::npos) return;
+		size_t q = text.find("\tSO:");
+		if (q != std::string::npos && q < nl) {
+			size_t e = q + 4; while (e < text.size() && text[e] != '\n' && text[e] != '\t') ++e;
+			if (text.compare(q + 4, e - q - 4, so) == 0) return;
+			text.replace(q, e - q, std::string("\tSO:") + so);
+		} else text.insert(nl, std::string("\tSO:") + so);
+	} else text = std::string("@HD\tVN:1.3\tSO:") + so + "\n" + text;
+}
+
+struct rec_store_t { std::vector<uint8_t> bytes; std::vector<uint64_t> off, key; };   /* off: start of each record's block_size word */
+
+static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads)
+{
+	bgzf_out_t out(fd, level, threads);
+	hdr_write(out, h);
+	for (size_t i = 0; i < perm.size(); ++i) { const uint64_t o = S.off[perm[i]]; uint32_t bs; memcpy(&bs, S.bytes.data() + o, 4); out.record(S.bytes.data() + o, 4 + (size_t)bs); }
+	out.finish();
+}
+static void gpu_perm(const rec_store_t &S, std::vector<uint32_t> &perm)
+{
+	perm.resize(S.key.size());
+	if (S.key.empty()) return;
+	if (ssg_sort_u64_perm(S.key.data(), (int64_t)S.key.size(), perm.data())) die(std::string("sort: ") + ssg_last_error());
+}
+
+struct merge_src_t {   /* one coordinate-sorted BAM being merged */
+	int fd; std::unique_ptr<bgzf_in_t> in; bam_hdr_t h; std::vector<uint8_t> rec; uint64_t key; bool ok;
+	bool next() { uint32_t bs; if (in->get(&bs, 4) != 4) { ok = false; return false; } rec.resize(4 + (size_t)bs); memcpy(rec.data(), &bs, 4); if (in->get(rec.data() + 4, bs) != bs) die("merge: truncated BAM"); key = bam_sort_key(rec.data() + 4); ok = true; return true; }
+};
+static void kway_merge(std::vector<merge_src_t> &src, bgzf_out_t &out)
+{	/* smallest key first; equal keys in source order (samtools bam_sort.c:1347-1375 heap order) */
+	typedef std::pair<uint64_t, size_t> ent_t;
+	std::priority_queue<ent_t, std::vector<ent_t>, std::greater<ent_t> > pq;
+	for (size_t i = 0; i < src.size(); ++i) if (src[i].next()) pq.push(ent_t(src[i].key, i));
+	while (!pq.empty()) {
+		const size_t i = pq.top().second; pq.pop();
+		out.record(src[i].rec.data(), src[i].rec.size());
+		if (src[i].next()) pq.push(ent_t(src[i].key, i));
+	}
+}
+
+static int cmd_sort(int argc, char **argv)
+{
+	int threads = hw_threads(), level = -1; double mem_gb = 2; std::string tmpdir = ".", outp; const char *in = 0;
+	for (int i = 0; i < argc; ++i) {
+		const char *a = argv[i];
+		if (!strcmp(a, "-t") && i + 1 < argc) threads = atoi(argv[++i]);
+		else if (!strcmp(a, "-m") && i + 1 < argc) { const char *v = argv[++i]; char *e; mem_gb = strtod(v, &e); if (*e == 'M' || *e == 'm') mem_gb /= 1024; else if (*e == 'K' || *e == 'k') mem_gb /= 1048576; else if (!*e) mem_gb /= 1073741824.0; }
+		else if (!strncmp(a, "--tmpdir=", 9)) tmpdir = a + 9;
+		else if (!strcmp(a, "--tmpdir") && i + 1 < argc) tmpdir = argv[++i];
+		else if (!strcmp(a, "-o") && i + 1 < argc) outp = argv[++i];
+		else if (!strcmp(a, "-l") && i + 1 < argc) level = atoi(argv[++i]);
+		else if (a[0] == '-' && a[1] && strcmp(a, "-")) die(std::string("sort: unsupported option ") + a);
+		else in = a;
+	}
+	if (!in || outp.empty()) die("usage: sambamba sort [-t N] [-m XG] [--tmpdir=DIR] -o out.bam <in.bam>");
+	if (threads < 1) threads = 1;
+	const int fd = open_in(in);
+	bgzf_in_t bi(fd, threads); bam_hdr_t h;
+	if (!hdr_read(bi, h)) die("sort: not a BAM file");
+	change_so(h.text, "coordinate");
+	uint64_t budget = (uint64_t)(std::max(mem_gb, 0.25) * 0.6 * 1073741824.0);   /* record bytes per in-memory chunk; the rest is keys, offsets, output blocks */
+	{ const char *e = getenv("SSG_SORT_CHUNK_BYTES"); if (e && atoll(e) > 0) budget = (uint64_t)atoll(e); }   /* the tests force the spill-and-merge path */
+	rec_store_t S; std::vector<std::string> spills;
+	mkdir(tmpdir.c_str(), 0777);
+	auto spill = [&]() {
+		std::vector<uint32_t> perm; gpu_perm(S, perm);
+		char nm[64]; snprintf(nm, sizeof(nm), "/ssg_sort_%d_%04zu.bam", (int)getpid(), spills.size());
+		const std::string p = tmpdir + nm;
+		int ofd = open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + p);
+		write_sorted(S, perm, h, ofd, 1, threads); close(ofd);
+		spills.push_back(p); S.bytes.clear(); S.off.clear(); S.key.clear();
+	};
+	for (;;) {
+		uint32_t bs;
+		if (bi.get(&bs, 4) != 4) break;
+		const size_t o = S.bytes.size(); S.bytes.resize(o + 4 + (size_t)bs);
+		memcpy(S.bytes.data() + o, &bs, 4);
+		if (bi.get(S.bytes.data() + o + 4, bs) != bs) die("sort: truncated BAM");
+		S.off.push_back(o); S.key.push_back(bam_sort_key(S.bytes.data() + o + 4));
+		if (S.bytes.size() >= budget || S.key.size() >= 0xfffffff0u) spill();
+	}
+	int ofd = open(outp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + outp);
+	if (spills.empty()) { std::vector<uint32_t> perm; gpu_perm(S, perm); write_sorted(S, perm, h, ofd, level, threads); }
+	else {
+		if (!S.key.empty()) spill();
+		std::vector<merge_src_t> src(spills.size());
+		for (size_t i = 0; i < spills.size(); ++i) { src[i].fd = open_in(spills[i].c_str()); src[i].in.reset(new bgzf_in_t(src[i].fd, 2)); if (!hdr_read(*src[i].in, src[i].h)) die("sort: bad spill file"); }
+		bgzf_out_t out(ofd, level, threads); hdr_write(out, h);
+		kway_merge(src, out); out.finish();
+		for (size_t i = 0; i < spills.size(); ++i) { close(src[i].fd); unlink(spills[i].c_str()); }
+	}
+	close(ofd);
+	return 0;
+}
+
+/* ---------------- index ---------------- */
+static int cmd_index(int argc, char **argv)
+{
+	const char *in = 0; int threads = hw_threads();
+	for (int i = 0; i < argc; ++i) { if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]); else if (argv[i][0] != '-') { if (!in) in = argv[i]; } }
+	if (!in) die("usage: sambamba index <in.bam>");
+	const int fd = open_in(in);
+	bgzf_in_t bi(fd, threads); bam_hdr_t h;
+	if (!hdr_read(bi, h)) die("index: not a BAM file");
+	bai_t idx((int)h.names.size(), bi.tell());
+	std::vector<uint8_t> rec;
+	for (;;) {
+		uint32_t bs;
+		if (bi.get(&bs, 4) != 4) break;
+		rec.resize(bs);
+		if (bi.get(rec.data(), bs) != bs) die("index: truncated BAM");
+		bam_core_t c; memcpy(&c, rec.data(), 32);
+		if (idx.push(c.tid, c.pos, bam_endpos(rec.data()), bi.tell(), !((c.flag_nc >> 16) & 4)) < 0) die("index: the file is not coordinate-sorted");
+	}
+	idx.finish(bi.tell());
+	idx.save((std::string(in) + ".bai").c_str());
+	return 0;
+}
+
+/* ---------------- merge ---------------- */
+static int cmd_merge(int argc, char **argv)
+{
+	int threads = hw_threads(), level = -1; std::vector<const char*> files;
+	for (int i = 0; i < argc; ++i) {
+		if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-l") && i + 1 < argc) level = atoi(argv[++i]);
+		else if (argv[i][0] == '-' && argv[i][1]) die(std::string("merge: unsupported option ") + argv[i]);
+		else files.push_back(argv[i]);
+	}
+	if (files.size() < 2) die("usage: sambamba merge [-t N] out.bam in1.bam [in2.bam ...]");
+	std::vector<merge_src_t> src(files.size() - 1);
+	for (size_t i = 0; i < src.size(); ++i) { src[i].fd = open_in(files[i + 1]); src[i].in.reset(new bgzf_in_t(src[i].fd, 2)); if (!hdr_read(*src[i].in, src[i].h)) die(std::string("merge: not a BAM file: ") + files[i + 1]); }
+	/* header: the first file's, plus the @RG / @PG / @CO lines of the others that it does not hold yet; the references must agree */
+	bam_hdr_t h = src[0].h;
+	for (size_t i = 1; i < src.size(); ++i) {
+		if (src[i].h.names != h.names || src[i].h.lens != h.lens) die("merge: the inputs have different reference sequences");
+		size_t p = 0; const std::string &t = src[i].h.text;
+		while (p < t.size()) {
+			size_t e = t.find('\n', p); if (e == std::string::npos) e = t.size();
+			const std::string line = t.substr(p, e - p);
+			if (line.size() > 3 && (!line.compare(0, 3, "@RG") || !line.compare(0, 3, "@PG") || !line.compare(0, 3, "@CO")) && ("\n" + h.text).find("\n" + line + "\n") == std::string::npos) h.text += line + "\n";
+			p = e + 1;
+		}
+	}
+	int ofd = open(files[0], O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die(std::string("merge: cannot write ") + files[0]);
+	bgzf_out_t out(ofd, level, threads); hdr_write(out, h);
+	kway_merge(src, out); out.finish(); close(ofd);
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) { fprintf(stderr, "usage: sambamba <view|sort|index|merge> ...  (libssgpu %s, %s)\n", ssg_version(), ssg_backend()); return 1; }
+	if (!strcmp(argv[1], "view")) return cmd_view(argc - 2, argv + 2);
+	if (!strcmp(argv[1], "sort")) return cmd_sort(argc - 2, argv + 2);
+	if (!strcmp(argv[1], "index")) return cmd_index(argc - 2, argv + 2);
+	if (!strcmp(argv[1], "merge")) return cmd_merge(argc - 2, argv + 2);
+	fprintf(stderr, "[sambamba] unsupported sub-command %s\n", argv[1]);
+	return 2;
+}

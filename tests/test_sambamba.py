@@ -1,0 +1,112 @@
+"""Row f1: the native `sambamba` (speedseq_amd/host/sambamba_main.cpp + bamio.h) against the reference's own
+samtools 1.3.1 built into oracle/_ref/ (the tool the round-1 shim wrapped): SAM->BAM records, coordinate order incl. ties,
+BGZF readability, BAI content, merge.  CPU side: the host-emulation build (device sort emulated); -m gpu: bin/sambamba."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+import simreads
+from common import EXAMPLE_FA, ROOT
+
+SAMTOOLS = os.path.join(ROOT, "oracle", "_ref", "samtools")
+ORC = os.path.join(ROOT, "oracle", "orc_bwa")
+
+
+def _sam(tmp_path, n_pairs=1200, seed=31, rg="g"):
+    """name-grouped SAM of the oracle's bwa mem | samblaster (duplicates, supplementary lines, unmapped reads, tags)"""
+    if not os.path.exists(SAMTOOLS):
+        pytest.skip("oracle/_ref/samtools not built")
+    fq = str(tmp_path / "r.fq.gz")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=seed))
+    p1 = subprocess.run([ORC, "mem", "-t", "4", "-p", "-R", "@RG\\tID:%s\\tSM:s" % rg, EXAMPLE_FA, fq], capture_output=True, check=True)
+    p2 = subprocess.run([ORC, "samblaster", "--addMateTags"], input=p1.stdout, capture_output=True, check=True)
+    sam = str(tmp_path / "in.sam")
+    with open(sam, "wb") as f:
+        f.write(p2.stdout)
+        # aux types beyond what bwa prints: negative / wide integers, float, hex, arrays, char
+        f.write(b"xt1\t4\t*\t0\t0\t*\t*\t0\t0\tACGTNacgtn\t*\tXa:A:Q\tXb:i:-7\tXc:i:-300\tXd:i:-70000\tXe:i:255\tXf:i:256\tXg:i:70000\tXh:f:1.5\tXi:H:1AE3\tXj:B:c,-1,2\tXk:B:S,1,65535\tXl:B:f,0.5,2\tXm:Z:x y\n")
+    return sam
+
+
+def _view(bam, region=None):
+    cmd = [SAMTOOLS, "view", "-h", bam] + ([region] if region else [])
+    return subprocess.check_output(cmd, text=True)
+
+
+def _parse_bai(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"BAI\1"
+    n_ref, = struct.unpack_from("<i", b, 4)
+    o, refs = 8, []
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", b, o); o += 4
+        bins = {}
+        for _ in range(n_bin):
+            bid, n_chunk = struct.unpack_from("<Ii", b, o); o += 8
+            bins[bid] = [struct.unpack_from("<QQ", b, o + 16 * k) for k in range(n_chunk)]; o += 16 * n_chunk
+        n_intv, = struct.unpack_from("<i", b, o); o += 4
+        lin = list(struct.unpack_from("<%dQ" % n_intv, b, o)); o += 8 * n_intv
+        refs.append((bins, lin))
+    n_no_coor = struct.unpack_from("<Q", b, o)[0] if o + 8 <= len(b) else None
+    return refs, n_no_coor
+
+
+def _check(sambamba, tmp_path, monkeypatch):
+    sam = _sam(tmp_path)
+    d = str(tmp_path)
+    # view: SAM -> BAM, uncompressed and compressed
+    for lvl, tag in ((["-l", "0"], "u"), ([], "c")):
+        with open(sam, "rb") as fi, open("%s/mine_%s.bam" % (d, tag), "wb") as fo:
+            subprocess.run(sambamba + ["view", "-S", "-f", "bam"] + lvl + ["/dev/stdin"], stdin=fi, stdout=fo, check=True)
+    subprocess.run([SAMTOOLS, "view", "-b", "-u", "-o", d + "/ref_u.bam", sam], check=True)
+    assert _view(d + "/mine_u.bam") == _view(d + "/ref_u.bam") == _view(d + "/mine_c.bam")
+    assert subprocess.check_output(sambamba + ["view", "-H", d + "/mine_c.bam"], text=True) == subprocess.check_output([SAMTOOLS, "view", "-H", d + "/ref_u.bam"], text=True)
+    # sort: identical record order (ties keep input order), SO:coordinate header
+    subprocess.run(sambamba + ["sort", "-t", "3", "-m", "1G", "--tmpdir=" + d + "/tmp1", "-o", d + "/mine_s.bam", d + "/mine_u.bam"], check=True)
+    subprocess.run([SAMTOOLS, "sort", "-o", d + "/ref_s.bam", d + "/ref_u.bam"], check=True)
+    assert _view(d + "/mine_s.bam") == _view(d + "/ref_s.bam")
+    # ... also through the spill-and-merge path and from a pipe
+    monkeypatch.setenv("SSG_SORT_CHUNK_BYTES", "200000")
+    with open(d + "/mine_u.bam", "rb") as fi:
+        subprocess.run(sambamba + ["sort", "-t", "2", "-m", "1G", "--tmpdir=" + d + "/tmp2", "-o", d + "/mine_s2.bam", "/dev/stdin"], stdin=fi, check=True)
+    monkeypatch.delenv("SSG_SORT_CHUNK_BYTES")
+    assert _view(d + "/mine_s2.bam") == _view(d + "/ref_s.bam")
+    assert os.listdir(d + "/tmp2") == []
+    # index: same bins / chunks / linear index as samtools builds for the same file; region queries through it
+    subprocess.run(sambamba + ["index", d + "/mine_s.bam"], check=True)
+    os.rename(d + "/mine_s.bam.bai", d + "/mine.bai")
+    subprocess.run([SAMTOOLS, "index", d + "/mine_s.bam"], check=True)
+    assert _parse_bai(d + "/mine.bai") == _parse_bai(d + "/mine_s.bam.bai")
+    os.replace(d + "/mine.bai", d + "/mine_s.bam.bai")
+    subprocess.run([SAMTOOLS, "index", d + "/ref_s.bam"], check=True)
+    for region in ("20_slice:1000-5000", "20_slice:150000-151000", "20_slice:300000"):
+        assert _view(d + "/mine_s.bam", region) == _view(d + "/ref_s.bam", region)
+        assert len(_view(d + "/mine_s.bam", region).split("\n")) > 10
+    # merge of two coordinate-sorted files
+    (tmp_path / "second").mkdir()
+    sam2 = _sam(tmp_path / "second", 300, seed=32, rg="h")      # another library: its own read group, as in `speedseq realign`
+    subprocess.run([SAMTOOLS, "view", "-b", "-o", d + "/b2u.bam", sam2], check=True)
+    subprocess.run([SAMTOOLS, "sort", "-o", d + "/b2.bam", d + "/b2u.bam"], check=True)
+    subprocess.run(sambamba + ["merge", "-t", "2", d + "/mine_m.bam", d + "/ref_s.bam", d + "/b2.bam"], check=True)
+    subprocess.run([SAMTOOLS, "merge", "-f", d + "/ref_m.bam", d + "/ref_s.bam", d + "/b2.bam"], check=True)
+    def body(t):     # samtools merge re-appends the RG tag it translates: compare with the optional fields in canonical order
+        out = []
+        for l in t.split("\n"):
+            if l and not l.startswith("@"):
+                f = l.split("\t")
+                out.append(f[:11] + sorted(f[11:]))
+        return out
+    assert body(_view(d + "/mine_m.bam")) == body(_view(d + "/ref_m.bam"))
+    hdr = _view(d + "/mine_m.bam")
+    assert "@RG\tID:g\t" in hdr and "@RG\tID:h\t" in hdr and "SO:coordinate" in hdr
+
+
+def test_sambamba_emu_matches_samtools(tmp_path, emu_lib, monkeypatch):
+    _check([os.path.join(ROOT, "tests", "emu", "sambamba_emu")], tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_sambamba_gpu_matches_samtools(tmp_path, gpu_lib, monkeypatch):
+    _check([os.path.join(ROOT, "bin", "sambamba")], tmp_path, monkeypatch)

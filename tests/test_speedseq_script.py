@@ -3,7 +3,8 @@ speedseq.config that names this repo's executables (the reference's plugin mecha
   * the CPU oracle's `bwa` / `samblaster`        (plumbing baseline),
   * the host-emulation build of the product's    (same sources as bin/bwa, bin/samblaster; CPU box),
   * the product executables on the MI355X        (-m gpu),
-each time with this repo's sambamba / parallel.  The three BAMs of the product runs must decode (samtools view) to the
+the product runs with this repo's native sambamba (SAM->BAM, device coordinate sort, BGZF, BAI), the oracle run with the reference's
+samtools behind sambamba's command line (tools/sambamba_samtools_shim.sh) as the comparator; bin/parallel throughout.  The three BAMs of the product runs must decode (samtools view) to the
 same records as the oracle run's.  The script comes from /root/reference when present, else from the fixture copy
 tests/golden/speedseq_ref_script.sh (tests/golden/make_golden.sh)."""
 import os
@@ -19,6 +20,7 @@ REF_SCRIPT = "/root/reference/bin/speedseq" if os.path.exists("/root/reference/b
 SAMTOOLS = os.path.join(ROOT, "oracle", "_ref", "samtools")
 ORC = os.path.join(ROOT, "oracle", "orc_bwa")
 EMU = os.path.join(ROOT, "tests", "emu")
+SHIM = os.path.join(ROOT, "tools", "sambamba_samtools_shim.sh")   # comparator: the reference's samtools behind sambamba's command line
 
 
 def _need_tools():
@@ -30,7 +32,7 @@ def _need_tools():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
-def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4):
+def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM):
     """runs the reference script in directory d with wrappers around the given executables; returns the output prefix"""
     os.makedirs(d)
     bindir = os.path.join(d, "bin")
@@ -42,7 +44,7 @@ def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4):
     os.symlink(shutil.which("mawk"), os.path.join(bindir, "gawk"))        # the script hard-codes `gawk`
     cfg = os.path.join(d, "speedseq.config")
     with open(cfg, "w") as f:
-        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s/bin/sambamba\nPARALLEL=%s/bin/parallel\n" % (bindir, bindir, ROOT, ROOT))
+        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\n" % (bindir, bindir, sambamba, ROOT))
     ref = os.path.join(d, "ref.fa")
     shutil.copy(EXAMPLE_FA, ref)   # no index next to it: the script must call `$BWA index`
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
@@ -97,7 +99,7 @@ def test_reference_align_script_with_product_sources_emulated(tmp_path, emu_lib)
     _need_tools()
     fq = _fastq(tmp_path)
     exp = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", fq)
-    out = _run_align(str(tmp_path / "emu"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq)
+    out = _run_align(str(tmp_path / "emu"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, sambamba=os.path.join(EMU, "sambamba_emu"))
     _check_outputs(out)
     _compare(out, exp)
 
@@ -108,6 +110,6 @@ def test_reference_align_script_with_product_executables(tmp_path, gpu_lib):
     _need_tools()
     fq = _fastq(tmp_path, 4000)
     exp = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", fq)
-    out = _run_align(str(tmp_path / "gpu"), os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster"), fq)
+    out = _run_align(str(tmp_path / "gpu"), os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster"), fq, sambamba=os.path.join(ROOT, "bin", "sambamba"))
     _check_outputs(out)
     _compare(out, exp)

@@ -1,8 +1,7 @@
 #!/bin/sh
-# sambamba shim for `speedseq align` (reference bin/speedseq:440-448,491-495):
-# maps the four sambamba invocations the script issues onto samtools (env SSG_SAMTOOLS or the
-# reference's vendored samtools 1.3.1 built into oracle/_ref/).  sambamba itself is out of scope
-# (next).
+# TEST INFRASTRUCTURE (comparator for bin/sambamba, tests/test_speedseq_script.py): sambamba's command line as the
+# reference issues it (bin/speedseq:440-448,491-495) mapped onto the reference's vendored samtools 1.3.1
+# built into oracle/_ref/ (or env SSG_SAMTOOLS).  The product's sambamba is speedseq_amd/host/sambamba_main.cpp.
 HERE=$(cd "$(dirname "$0")" && pwd)
 ST=${SSG_SAMTOOLS:-$HERE/../oracle/_ref/samtools}
 [ -x "$ST" ] || { echo "sambamba shim: samtools not found ($ST); set SSG_SAMTOOLS" >&2; exit 127; }
