@@ -346,7 +346,7 @@ SSG_DEVFN void ssg_smem_machine(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 		if (jn) pf = SMV(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
 		ssg_intv_t okc;
 		if constexpr (COOP) okc = ssg_bwt_extend1_coop(ix, back ? p : ik, e_c, back, pend != SM_PEND_NONE, coop_lds);
-		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1(ix, back ? p : ik, e_c, back);
+		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
 		if (COOP && pend == SM_PEND_NONE) continue;   /* a finished lane only helped the others fetch */
 		++my_nx;
 		{

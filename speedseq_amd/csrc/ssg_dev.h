@@ -300,6 +300,52 @@ SSG_DEVFN ssg_intv_t ssg_bwt_extend1_quad(const ssg_index_view_t &ix, const ssg_
 	return o;
 }
 
+/* ssg_bwt_extend1 that fetches only the quarters of each rank block the followed base needs.  With T = k + 1 symbols up to and
+ * including stored position k, sum over b > c of occ_b equals T - occ_0 (c = 0), T - occ_0 - occ_1 (c = 1), occ_3 (c = 2), 0 (c = 3):
+ * at most two of the four running counts -- one 16-byte quarter -- and two popcount passes instead of four; of the symbol words
+ * only those below the position: the third quarter, and the fourth only past the block's middle.  2.5 loads per block on average
+ * instead of 4: on a multi-GB table the per-lane fetch is bound by address translations per load instruction, not by bytes. */
+SSG_DEVFN void ssg_occ_lean(const ssg_index_view_t &ix, uint64_t k, int c, uint64_t &occ_c, uint64_t &occ_gt)
+{
+	if (k == (uint64_t)-1) { occ_c = 0; occ_gt = 0; return; }
+	k -= (k >= ix.primary);
+	struct alignas(16) q16 { uint32_t v[4]; };
+	const q16 *pb = (const q16*)(ix.bwt + ((k >> 7) << 4));
+	const int r = (int)(k & 127) + 1;
+	const q16 cq = pb[c >> 1];                       /* counts of bases (0,1) or (2,3) */
+	const q16 w0 = pb[2];
+	q16 w1; w1.v[0] = w1.v[1] = w1.v[2] = w1.v[3] = 0;
+	if (r > 64) w1 = pb[3];
+	const uint32_t w[8] = { w0.v[0], w0.v[1], w0.v[2], w0.v[3], w1.v[0], w1.v[1], w1.v[2], w1.v[3] };
+	uint32_t mk[8];
+	SSG_UNROLL for (int i = 0; i < 8; ++i) { int ns = r - i * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns; mk[i] = ns == 16 ? 0x55555555u : ns ? (~((1u << ((16 - ns) << 1)) - 1)) & 0x55555555u : 0u; }
+	const int ba = c & 2, bb = ba + 1;               /* the two bases whose counts were fetched */
+	int na = 0, nb = 0;
+	SSG_UNROLL for (int i = 0; i < 8; ++i) {
+		const uint32_t xa = ~(w[i] ^ ((uint32_t)ba * 0x55555555u)), xb = ~(w[i] ^ ((uint32_t)bb * 0x55555555u));
+		na += __popc(xa & (xa >> 1) & mk[i]); nb += __popc(xb & (xb >> 1) & mk[i]);
+	}
+	const uint64_t oa = ((uint64_t)cq.v[0] | (uint64_t)cq.v[1] << 32) + (uint64_t)na, ob = ((uint64_t)cq.v[2] | (uint64_t)cq.v[3] << 32) + (uint64_t)nb;
+	const uint64_t T = k + 1;
+	occ_c = (c & 1) ? ob : oa;
+	occ_gt = c == 0 ? T - oa : c == 1 ? T - oa - ob : c == 2 ? ob : 0;
+}
+SSG_DEVFN ssg_intv_t ssg_bwt_extend1_lean(const ssg_index_view_t &ix, const ssg_intv_t &ik, int c, int is_back)
+{
+	const uint64_t kx = is_back ? ik.x0 : ik.x1, ox = is_back ? ik.x1 : ik.x0;
+	uint64_t tkc, tkg, tlc, tlg;
+	ssg_occ_lean(ix, kx - 1, c, tkc, tkg);
+	ssg_occ_lean(ix, kx - 1 + ik.x2, c, tlc, tlg);
+	const uint64_t no = ox + (kx <= ix.primary && kx + ik.x2 - 1 >= ix.primary) + (tlg - tkg);
+	uint64_t l2c = ix.L2[0];
+	SSG_UNROLL for (int bi = 1; bi < 4; ++bi) if (bi == c) l2c = ix.L2[bi];
+	ssg_intv_t o;
+	const uint64_t nk = l2c + 1 + tkc;
+	o.x2 = tlc - tkc; o.info = 0;
+	if (is_back) { o.x0 = nk; o.x1 = no; } else { o.x1 = nk; o.x0 = no; }
+	return o;
+}
+
 /* ssg_bwt_extend1 for all 64 lanes of a wave at once, each lane its own interval, with the rank blocks fetched the way the
  * memory system likes it: per load instruction the four lanes of a quad read the four 16-byte quarters of ONE block (16 whole
  * lines per instruction, one translation per line), eight instructions cover the 128 blocks of the wave.  A lane that fetches

@@ -111,7 +111,7 @@ def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
     common.check_smem(gpu_lib, oracle, 1500, seed=31)
     assert common.check_align1(gpu_lib, oracle, 1500, seed=32) > 1500
     monkeypatch.delenv("SSG_SMEM_LPR")
-    monkeypatch.setenv("SSG_SMEM_COOP", "0")      # lane per read with per-lane rank-block fetches (the default fetches them wave-cooperatively)
+    monkeypatch.setenv("SSG_SMEM_COOP", "1")      # lane per read with the rank blocks of the wave fetched quad-cooperatively (experimental; the default fetches per lane)
     common.check_smem(gpu_lib, oracle, 1500, seed=31)
     monkeypatch.delenv("SSG_SMEM_COOP")
     monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")
