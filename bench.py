@@ -448,6 +448,18 @@ def main():
                                      "on the index files written by ssg_index_save" % ns, "index_files_roundtrip_s": round(t_files, 1)}
             out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
                                    "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded" % (ns, cores)}
+            try:   # oracle-independent validation of the same records (tests/validators.py): reference bases from the .pac just written
+                import validators
+                pac = validators.pac_contigs(prefix)
+                v1, v2, v3 = validators.md_nm_consistency(gtext, pac), validators.as_from_cigar(gtext, pac), validators.mate_symmetry(gtext)
+                out["parity"]["oracle_independent"] = {"md_nm_rebuilds_reference": {"records": v1[0], "bad": v1[1]},
+                                                       "as_rescored_from_cigar": {"records": v2[0], "outside_[AS-10,AS]": v2[1]},
+                                                       "mate_fields_mirror": {"checks": v3[0], "bad": v3[1]}}
+                if v1[1] or v3[1] or v2[1] > v2[0] // 1000:
+                    ok = False
+                del pac
+            except Exception as e:
+                out["parity"]["oracle_independent"] = {"error": repr(e)}
             if a.e2e:
                 try:
                     out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, ns, orc_exe=os.path.join(ROOT, "oracle", "orc_bwa"))
