@@ -376,135 +376,6 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 	return r;
 }
 
-/* ------------------------------------------------------------------------------------------
- * The same contract on packed 16-bit lanes, striped: the whole DP row of a rescue lives in NSEG
- * registers per lane (two columns per register: v_pk_add / v_pk_max_i16), column j = s + NSEG * (2 * lane + half)
- * for segment s -- upstream ksw_i16's own striping, 128 columns per wave instruction.  The diagonal
- * operand of segment s is the previous row's segment s - 1 (segment 0: the last segment shifted by one
- * element across the wave), the horizontal gap F runs through the segments of an element and is
- * completed by upstream's lazy-F loop (shift by one element, re-apply, stop when no column can still
- * gain), so a row costs ~20 packed instructions + ~16 for the usual one or two lazy passes instead of
- * two wave-wide max-plus scans.  The row maximum is only reduced across the wave when some element
- * exceeds what matters (the running maximum, or minsc for the second-best list b[]).
- * Exact DP (E is re-derived from an F-raised H as in the int32 form): same H matrix, same results.
- * ------------------------------------------------------------------------------------------ */
-#ifdef SSG_EMU
-SSG_DEVFN uint32_t pk_mk(int lo, int hi) { return (uint32_t)(uint16_t)(int16_t)lo | (uint32_t)(uint16_t)(int16_t)hi << 16; }
-SSG_DEVFN int pk_lo(uint32_t a) { return (int16_t)(uint16_t)a; }
-SSG_DEVFN int pk_hi(uint32_t a) { return (int16_t)(uint16_t)(a >> 16); }
-SSG_DEVFN uint32_t pk_add(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) + pk_lo(b), pk_hi(a) + pk_hi(b)); }
-SSG_DEVFN uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_mk(pk_lo(a) - pk_lo(b), pk_hi(a) - pk_hi(b)); }
-SSG_DEVFN uint32_t pk_max(uint32_t a, uint32_t b) { return pk_mk(imax(pk_lo(a), pk_lo(b)), imax(pk_hi(a), pk_hi(b))); }
-#else
-typedef short ssg_s2_t __attribute__((ext_vector_type(2)));
-SSG_DEVFN uint32_t pk_mk(int lo, int hi) { return (uint32_t)(uint16_t)(int16_t)lo | (uint32_t)(uint16_t)(int16_t)hi << 16; }
-SSG_DEVFN int pk_lo(uint32_t a) { return (int16_t)(uint16_t)a; }
-SSG_DEVFN int pk_hi(uint32_t a) { return (int16_t)(uint16_t)(a >> 16); }
-SSG_DEVFN uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (ssg_s2_t)(__builtin_bit_cast(ssg_s2_t, a) + __builtin_bit_cast(ssg_s2_t, b))); }
-SSG_DEVFN uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (ssg_s2_t)(__builtin_bit_cast(ssg_s2_t, a) - __builtin_bit_cast(ssg_s2_t, b))); }
-SSG_DEVFN uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ssg_s2_t, a), __builtin_bit_cast(ssg_s2_t, b))); }
-#endif
-/* element m = 2 * lane + half takes the value of element m - 1 (element 0: zero) */
-SSG_DEVFN uint32_t pk_shift1(uint32_t v) { return v << 16 | (uint32_t)wv_prev((int)v, 0) >> 16; }
-
-template <int NSEG>
-SSG_DEVFN ssg_sw1_t wv_local_pk(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target,
-                                int p_, int minsc, int endsc, unsigned long long *bscratch, unsigned long long *cells)
-{
-	const int lane = wv_lane();
-	const int sa = opt.a, sb = opt.b;
-	const uint32_t Pe_del = pk_mk(opt.e_del, opt.e_del), Pe_ins = pk_mk(opt.e_ins, opt.e_ins);
-	const uint32_t Poe_del = pk_mk(opt.o_del + opt.e_del, opt.o_del + opt.e_del), Poe_ins = pk_mk(opt.o_ins + opt.e_ins, opt.o_ins + opt.e_ins);
-	const int slen = (qlen + p_ - 1) / p_, qp = slen * p_;
-	const int maxsc = sa > 0 ? sa : 0;
-	uint32_t prof[5][NSEG], act[NSEG], H[NSEG], E[NSEG], HM[NSEG];
-	SSG_UNROLL for (int s = 0; s < NSEG; ++s) {
-		const int j0 = s + NSEG * (2 * lane), j1 = j0 + NSEG;
-		const int c0 = j0 < qlen ? sq_at(query, j0) : 5, c1 = j1 < qlen ? sq_at(query, j1) : 5;
-		SSG_UNROLL for (int t = 0; t < 5; ++t) prof[t][s] = pk_mk(ssg_sc(sa, sb, t, c0), ssg_sc(sa, sb, t, c1));
-		act[s] = (j0 < qp ? 0xffffu : 0u) | (j1 < qp ? 0xffff0000u : 0u);
-		H[s] = E[s] = HM[s] = 0;
-	}
-	int gmax = 0, te = -1, n_b = 0, last_sc = 0, last_row = -2;
-	int i, tb = tlen > 0 ? sq_at(target, 0) : 0;
-	for (i = 0; i < tlen; ++i) {
-		const int tb_next = i + 1 < tlen ? sq_at(target, i + 1) : 0;
-		uint32_t pr[NSEG];
-		SSG_UNROLL for (int s = 0; s < NSEG; ++s) { pr[s] = prof[0][s]; SSG_UNROLL for (int t = 1; t < 5; ++t) pr[s] = tb == t ? prof[t][s] : pr[s]; }   /* tb is wave-uniform */
-		uint32_t f = 0, hd = pk_shift1(H[NSEG - 1]), hm = 0;
-		SSG_UNROLL for (int s = 0; s < NSEG; ++s) {
-			uint32_t h = pk_add(hd, pr[s]);
-			h = pk_max(h, E[s]); h = pk_max(h, f); h = pk_max(h, 0u) & act[s];
-			hd = H[s]; H[s] = h;
-			E[s] = pk_max(pk_max(pk_sub(E[s], Pe_del), pk_sub(h, Poe_del)), 0u) & act[s];
-			f = pk_max(pk_max(pk_sub(f, Pe_ins), pk_sub(h, Poe_ins)), 0u);
-		}
-		for (;;) {   /* lazy F: what the last segment leaves over enters the first segment of the next element */
-			f = pk_shift1(f);
-			bool more = false;
-			SSG_UNROLL for (int s = 0; s < NSEG; ++s) {
-				const uint32_t h = pk_max(H[s], f & act[s]);
-				E[s] = pk_max(E[s], pk_max(pk_sub(h, Poe_del), 0u) & act[s]);
-				H[s] = h;
-				const uint32_t g = pk_max(pk_sub(h, Poe_ins), 0u);
-				f = pk_max(pk_sub(f, Pe_ins), 0u);
-				more = pk_max(f, g) != g;           /* some column's running gap still beats a gap opened from its H */
-				if (!wv_ballot(more)) break;
-			}
-			if (!wv_ballot(more)) break;
-		}
-		SSG_UNROLL for (int s = 0; s < NSEG; ++s) hm = pk_max(hm, H[s]);
-		{
-			const int thr = (minsc < gmax + 1 ? minsc : gmax + 1) - 1;
-			const uint32_t Pthr = pk_mk(thr, thr);
-			if (wv_ballot(pk_max(hm, Pthr) != Pthr)) {
-				const int hmx = pk_lo(hm) > pk_hi(hm) ? pk_lo(hm) : pk_hi(hm);
-				const int imax = wv_max(hmx);
-				if (imax >= minsc) { /* b[]: collapse runs of adjacent rows, keep the entry in registers */
-					if (n_b == 0 || last_row + 1 != i) { last_sc = imax; last_row = i; if (lane == 0) bscratch[n_b] = (unsigned long long)imax << 32 | (unsigned)i; ++n_b; }
-					else if (last_sc < imax) { last_sc = imax; last_row = i; if (lane == 0) bscratch[n_b - 1] = (unsigned long long)imax << 32 | (unsigned)i; }
-				}
-				if (imax > gmax) {
-					gmax = imax; te = i;
-					SSG_UNROLL for (int s = 0; s < NSEG; ++s) HM[s] = H[s];
-					if (gmax >= endsc) break;
-				}
-			}
-		}
-		tb = tb_next;
-	}
-	if (cells) *cells += (unsigned long long)(i < tlen ? i + 1 : tlen) * qlen;
-	ssg_sw1_t r; r.score = gmax; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1;
-	{	/* smallest padded column holding the row maximum of Hmax */
-		int mx = -1, best = 1 << 30;
-		SSG_UNROLL for (int s = 0; s < NSEG; ++s) {
-			const int j0 = s + NSEG * (2 * lane), j1 = j0 + NSEG;
-			const int v0 = j0 < qp ? pk_lo(HM[s]) : -1, v1 = j1 < qp ? pk_hi(HM[s]) : -1;
-			mx = imax(mx, imax(v0, v1));
-		}
-		mx = wv_max(mx);
-		SSG_UNROLL for (int s = 0; s < NSEG; ++s) {
-			const int j0 = s + NSEG * (2 * lane), j1 = j0 + NSEG;
-			if (j0 < qp && pk_lo(HM[s]) == mx) best = imin(best, j0);
-			if (j1 < qp && pk_hi(HM[s]) == mx) best = imin(best, j1);
-		}
-		r.qe = wv_min(best);
-	}
-	ssg_wave_memsync();
-	if (n_b) {
-		int k = (r.score + maxsc - 1) / maxsc, low = te - k, high = te + k;
-		int bs = -1, bi = 1 << 30;
-		for (int t = lane; t < n_b; t += 64) {
-			unsigned long long v = bscratch[t]; int e = (int)(uint32_t)v, sc = (int)(v >> 32);
-			if ((e < low || e > high) && sc > bs) { bs = sc; bi = t; }
-		}
-		int gs = wv_max(bs);
-		int gi = wv_min(bs == gs ? bi : (1 << 30));
-		if (gs > -1) { r.score2 = gs; r.te2 = (int)(uint32_t)bscratch[gi]; }
-	}
-	return r;
-}
-
 /* upstream ksw_align2 (forward pass, then the reversed pass for the start when KSW_XSTART) */
 #define SSG_KSW_XBYTE  0x10000
 #define SSG_KSW_XSTOP  0x20000
@@ -528,32 +399,10 @@ SSG_DEVFN ssg_kswr_t wv_align2_t(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t 
 	if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
 	return r;
 }
-template <int NSEG>
-SSG_DEVFN ssg_kswr_t wv_align2_pk(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int xtra,
-                                  unsigned long long *bscratch, unsigned long long *cells)
-{
-	ssg_kswr_t r; r.tb = r.qb = -1;
-	const int p = (xtra & SSG_KSW_XBYTE) ? 16 : 8;
-	const int minsc = (xtra & SSG_KSW_XSUBO) ? xtra & 0xffff : 0x10000;
-	const int endsc = (xtra & SSG_KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-	ssg_sw1_t f = wv_local_pk<NSEG>(opt, qlen, query, tlen, target, p, minsc, endsc, bscratch, cells);
-	r.score = f.score; r.te = f.te; r.qe = f.qe; r.score2 = f.score2; r.te2 = f.te2;
-	if ((xtra & SSG_KSW_XSTART) == 0 || ((xtra & SSG_KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
-	ssg_seqv_t rq = { query.p + query.dir * r.qe, -query.dir }, rt = { target.p + target.dir * r.te, -target.dir };
-	ssg_sw1_t rr = wv_local_pk<NSEG>(opt, r.qe + 1, rq, r.te + 1, rt, p, 0x10000, r.score, bscratch, cells);
-	if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
-	return r;
-}
-/* bit 0 of opt._pad[0] (SSG_SW_INT32=1) keeps the int32 row-scan form: A/B runs and the parity tests of both */
 SSG_DEVFN ssg_kswr_t wv_align2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int xtra,
                                unsigned long long *bscratch, unsigned long long *cells)
 {
 	int qp = ((qlen + 7) / 8) * 8; if (xtra & SSG_KSW_XBYTE) qp = ((qlen + 15) / 16) * 16;
-	const bool fits16 = opt.a * qlen < 30000 && opt.b < 1000 && opt.o_del + opt.e_del < 1000 && opt.o_ins + opt.e_ins < 1000 && qp <= 256;
-	if (fits16 && !(opt._pad[0] & 1)) {
-		if (qp <= 128) return wv_align2_pk<1>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
-		return wv_align2_pk<2>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
-	}
 	if (qp <= 64)  return wv_align2_t<1>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 128) return wv_align2_t<2>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 192) return wv_align2_t<3>(opt, qlen, query, tlen, target, xtra, bscratch, cells);

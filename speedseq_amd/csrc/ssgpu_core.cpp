@@ -72,7 +72,6 @@ void ssg_mem_opt_init(ssg_mem_opt_t *o)
 	o->mapQ_coef_len = 50; o->mapQ_coef_fac = (int)log((double)o->mapQ_coef_len);
 	for (int i = 0, k = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) o->mat[k++] = i == j ? o->a : -o->b; o->mat[k++] = -1; }
 	for (int j = 0; j < 5; ++j) o->mat[20 + j] = -1;
-	o->_pad[0] = (int8_t)(env_int("SSG_SW_INT32", 0) ? 1 : 0);   /* kernel-variant switch: int32 row-scan local SW instead of the packed 16-bit striped one */
 }
 
 /* ------------------------------- index ------------------------------- */

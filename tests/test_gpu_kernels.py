@@ -14,9 +14,7 @@ def test_gpu_extend(gpu_lib, oracle):
     common.check_extend(gpu_lib, oracle, 3000, seed=11)
 
 
-def test_gpu_local(gpu_lib, oracle, monkeypatch):
-    common.check_local(gpu_lib, oracle, 2000, seed=12)          # packed 16-bit striped form (default)
-    monkeypatch.setenv("SSG_SW_INT32", "1")                     # int32 row-scan form
+def test_gpu_local(gpu_lib, oracle):
     common.check_local(gpu_lib, oracle, 400, seed=12)
 
 

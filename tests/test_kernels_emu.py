@@ -7,10 +7,8 @@ def test_emu_extend(emu_lib, oracle):
     common.check_extend(emu_lib, oracle, 400, seed=1)
 
 
-def test_emu_local(emu_lib, oracle, monkeypatch):
-    common.check_local(emu_lib, oracle, 60, seed=2)             # packed 16-bit striped form (default)
-    monkeypatch.setenv("SSG_SW_INT32", "1")                     # int32 row-scan form
-    common.check_local(emu_lib, oracle, 30, seed=2)
+def test_emu_local(emu_lib, oracle):
+    common.check_local(emu_lib, oracle, 60, seed=2)
 
 
 def test_emu_global(emu_lib, oracle):
