@@ -1,8 +1,7 @@
 /*
  * k_seed.h -- gfx950 kernels for FM-index seeding.
  *
- *   ssg_k_smem_coop one lane per read, state machine with one bwt_extend site whose rank blocks the wave fetches cooperatively (the product path);
- *   ssg_k_smem_quad the same machine with four lanes (or one lane, per-lane fetch) per read (SSG_SMEM_COOP=0 / SSG_SMEM_LPR: A/B runs);
+ *   ssg_k_smem_quad one lane per read (or four: SSG_SMEM_LPR=4, quad-cooperative rank-block fetch), state machine with one bwt_extend site (the product path);
  *   ssg_k_smem_lane one lane per read, nested loops as upstream writes them (SSG_SMEM_KERNEL=lane: A/B runs);
  *                   both: the three SMEM passes of upstream mem_collect_intv (bwt_smem1a x2 +
  *                   bwt_seed_strategy1), intervals sorted by (start,end).  Every bwt_extend is two rank
@@ -208,21 +207,14 @@ SSG_DEVFN ssg_intv_t ssg_unpk(const ssg_pk_t &p)
 #endif
 /* LPR = lanes per read: 4 (cooperative rank-block fetch) or 1 (each lane fetches whole blocks; 4x fewer wave instructions per read,
  * 4x more translation work per line -- see tools/dbg/gather_probe.cpp for where that starts to matter) */
-/* COOP (with LPR = 1): every lane owns a read, and the rank blocks of the whole wave are fetched quad-cooperatively at the one
- * extension site (ssg_bwt_extend1_coop): the state machine's cost per extension of the per-lane form, the memory shape of the
- * quad form.  QWORDS: LDS words per read for its 4-bit codes (8 bases each). */
-struct ssg_no_lds_t { uint32_t unused; };
-template <int COOP> struct ssg_coop_sel { typedef ssg_no_lds_t T; };
-template <> struct ssg_coop_sel<1> { typedef ssg_coop_lds_t T; };
-template <int LPR, int COOP, int QWORDS>
-SSG_DEVFN void ssg_smem_machine(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, int n_reads, const int32_t *read_ids,
+template <int LPR>
+__global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
                            ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read)
 {
 	constexpr int RPW = 64 / LPR;   /* reads per wave */
-	__shared__ uint32_t qlds[QWORDS * RPW];
-	__shared__ typename ssg_coop_sel<COOP>::T coop_lds;
+	__shared__ uint32_t qlds[SSG_SM_QWORDS * RPW];
 	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nq = ((long)gridDim.x * blockDim.x) / LPR;
 	const int lane = (int)(threadIdx.x & 63), Q = lane / LPR, ql = lane % LPR;
 	/* per-wave slab of 2 lists x scap entries x 16 quads, entry e of quad Q at [e*16 + Q] */
@@ -335,8 +327,7 @@ SSG_DEVFN void ssg_smem_machine(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 				break;
 			}
 		}
-		if (COOP) { if (!wv_ballot(state != SM_FIN)) break; }   /* the cooperative fetch needs every lane of the wave until the last read is done */
-		else if (state == SM_FIN) break;
+		if (state == SM_FIN) break;
 		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
 		ssg_wave_ldssync();   /* list entries stored by lane 0 of the quad last iteration are read by all four below (same wave: in order on the GPU) */
 		const ssg_pk_t *const prev = flip ? vec0 : vec1;
@@ -344,10 +335,7 @@ SSG_DEVFN void ssg_smem_machine(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 		const int jn = back && j + 1 < prev_n ? j + 1 : 0;
 		ssg_pk_t pf; pf.w0 = pf.w1 = 0;
 		if (jn) pf = SMV(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
-		ssg_intv_t okc;
-		if constexpr (COOP) okc = ssg_bwt_extend1_coop(ix, back ? p : ik, e_c, back, pend != SM_PEND_NONE, coop_lds);
-		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
-		if (COOP && pend == SM_PEND_NONE) continue;   /* a finished lane only helped the others fetch */
+		const ssg_intv_t okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
 		++my_nx;
 		{
 			ssg_pk_t *const curr = flip ? vec1 : vec0;
@@ -395,18 +383,6 @@ SSG_DEVFN void ssg_smem_machine(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 #undef QW
 	if (n_extend && my_nx && ql == 0) atomicAdd(n_extend, my_nx);
 }
-template <int LPR>
-__global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
-                           const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read)
-{ ssg_smem_machine<LPR, 0, SSG_SM_QWORDS>(ix, opt, n_reads, read_ids, seq, off, out_intv, out_n, cap, scratch, scap, n_extend, next_read); }
-/* the product path: lane per read + wave-cooperative rank-block fetch; QWORDS = 20 (reads <= 160 bases: 16 waves per CU fit in LDS) or 32 */
-template <int QWORDS>
-__global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_coop(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
-                           const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read)
-{ ssg_smem_machine<1, 1, QWORDS>(ix, opt, n_reads, read_ids, seq, off, out_intv, out_n, cap, scratch, scap, n_extend, next_read); }
-
 /* one lane per read: intervals by (start,end), upstream's ks_introsort(mem_intv) */
 __global__ void __launch_bounds__(64) ssg_k_smem_sort(int n_reads, ssg_intv_t *intv, const int32_t *n_intv, int cap)
 {

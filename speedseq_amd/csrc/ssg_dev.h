@@ -346,83 +346,6 @@ SSG_DEVFN ssg_intv_t ssg_bwt_extend1_lean(const ssg_index_view_t &ix, const ssg_
 	return o;
 }
 
-/* ssg_bwt_extend1 for all 64 lanes of a wave at once, each lane its own interval, with the rank blocks fetched the way the
- * memory system likes it: per load instruction the four lanes of a quad read the four 16-byte quarters of ONE block (16 whole
- * lines per instruction, one translation per line), eight instructions cover the 128 blocks of the wave.  A lane that fetches
- * a quarter also counts it (for the owner's base and position, staged through LDS), the quad adds up, and the owner picks the
- * two sums per block from LDS.  Per-lane whole-block fetches (4 x 16 B per line from each lane) run at 21 G lines/s on a 6 GB
- * table, this shape at the quad rate (~43 G lines/s, tools/dbg/gather_probe.cpp) while the caller keeps 64 reads per wave. */
-struct alignas(16) ssg_coop_lds_t { uint32_t stage[64][4]; uint64_t res[64][2][2]; };
-SSG_DEVFN ssg_intv_t ssg_bwt_extend1_coop(const ssg_index_view_t &ix, const ssg_intv_t &ik, int c, int is_back, int valid, ssg_coop_lds_t &L)
-{
-	struct alignas(16) q16 { uint32_t v[4]; };
-	const int lane = wv_lane(), ql = lane & 3, Q = lane >> 2;
-	const uint64_t kx = is_back ? ik.x0 : ik.x1, ox = is_back ? ik.x1 : ik.x0;
-	{
-		uint64_t k1 = kx - 1, k2 = kx - 1 + ik.x2;
-		const bool z1 = k1 == (uint64_t)-1, z2 = k2 == (uint64_t)-1;   /* occ(-1) = 0 */
-		k1 = z1 ? 0 : k1 - (k1 >= ix.primary);
-		k2 = z2 ? 0 : k2 - (k2 >= ix.primary);
-		const uint32_t f = ((uint32_t)c << 8) | (valid ? 1u << 10 : 0u);
-		q16 st;
-		st.v[0] = (uint32_t)(k1 >> 7); st.v[1] = f | (z1 ? 0u : (uint32_t)(k1 & 127) + 1u);
-		st.v[2] = (uint32_t)(k2 >> 7); st.v[3] = f | (z2 ? 0u : (uint32_t)(k2 & 127) + 1u);
-		*(q16*)L.stage[lane] = st;
-	}
-	ssg_wave_ldssync();
-	q16 a[8]; uint32_t mt[8];
-	SSG_UNROLL for (int t = 0; t < 8; ++t) {   /* round t: quad Q serves block (t & 1) of lane 16 * (t >> 1) + Q */
-		const int o = ((t >> 1) << 4) + Q;
-		const uint32_t blk = L.stage[o][(t & 1) * 2], m = L.stage[o][(t & 1) * 2 + 1];
-		mt[t] = m;
-		a[t].v[0] = a[t].v[1] = a[t].v[2] = a[t].v[3] = 0;
-		if (m & (1u << 10)) a[t] = ((const q16*)(ix.bwt + ((uint64_t)blk << 4)))[ql];
-	}
-	SSG_UNROLL for (int t = 0; t < 8; ++t) {
-		const int o = ((t >> 1) << 4) + Q, r = (int)(mt[t] & 0xff), cc = (int)(mt[t] >> 8) & 3;
-		uint64_t sc = 0, sg = 0;   /* this quarter's share of occ(c) and of the sum of occ(b), b > c */
-		if (ql < 2) {
-			if (r) {
-				const uint64_t c0 = (uint64_t)a[t].v[0] | (uint64_t)a[t].v[1] << 32, c1 = (uint64_t)a[t].v[2] | (uint64_t)a[t].v[3] << 32;
-				const int b0 = 2 * ql, b1 = 2 * ql + 1;
-				sc = (b0 == cc ? c0 : 0) + (b1 == cc ? c1 : 0);
-				sg = (b0 > cc ? c0 : 0) + (b1 > cc ? c1 : 0);
-			}
-		} else {
-			const int w0 = (ql - 2) * 4;
-			uint32_t mk[4];
-			SSG_UNROLL for (int i = 0; i < 4; ++i) {
-				int ns = r - (w0 + i) * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns;
-				mk[i] = ns == 16 ? 0x55555555u : ns ? (~((1u << ((16 - ns) << 1)) - 1)) & 0x55555555u : 0u;
-			}
-			int nc = 0, ng = 0;
-			SSG_UNROLL for (int bi = 0; bi < 4; ++bi) {
-				int n = 0;
-				SSG_UNROLL for (int i = 0; i < 4; ++i) { const uint32_t x = ~(a[t].v[i] ^ ((uint32_t)bi * 0x55555555u)); n += __popc(x & (x >> 1) & mk[i]); }
-				if (bi == cc) nc = n;
-				if (bi > cc) ng += n;
-			}
-			sc = (uint64_t)nc; sg = (uint64_t)ng;
-		}
-		sc = wv_quad_sum64(sc); sg = wv_quad_sum64(sg);
-#ifdef SSG_EMU
-		{ L.res[o][t & 1][0] = sc; L.res[o][t & 1][1] = sg; }   /* fibers of a quad are not in lock step: all four store the same values */
-#else
-		if (ql == 0) { L.res[o][t & 1][0] = sc; L.res[o][t & 1][1] = sg; }
-#endif
-	}
-	ssg_wave_ldssync();
-	const uint64_t tkc = L.res[lane][0][0], tkg = L.res[lane][0][1], tlc = L.res[lane][1][0], tlg = L.res[lane][1][1];
-	ssg_wave_ldssync();   /* the staging area is rewritten by the next call */
-	const uint64_t no = ox + (kx <= ix.primary && kx + ik.x2 - 1 >= ix.primary) + (tlg - tkg);
-	uint64_t l2c = ix.L2[0];
-	SSG_UNROLL for (int bi = 1; bi < 4; ++bi) if (bi == c) l2c = ix.L2[bi];
-	ssg_intv_t o;
-	const uint64_t nk = l2c + 1 + tkc;
-	o.x2 = tlc - tkc; o.info = 0;
-	if (is_back) { o.x0 = nk; o.x1 = no; } else { o.x1 = nk; o.x0 = no; }
-	return o;
-}
 /* upstream bwt_sa: LF-walk to a sampled row */
 SSG_DEVFN uint64_t ssg_bwt_sa(const ssg_index_view_t &ix, uint64_t k)
 {

@@ -106,14 +106,11 @@ def test_gpu_pair_wave_kernel_forced(gpu_lib, oracle, repeat_pe_prefix, monkeypa
 
 
 def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
-    # the quad-cooperative form (default for indexes beyond ~2 GB of rank blocks) and the nested-loop form, on the same reads
+    # the quad-cooperative form and the nested-loop form, on the same reads (default: lane per read, lean per-lane fetch)
     monkeypatch.setenv("SSG_SMEM_LPR", "4")
     common.check_smem(gpu_lib, oracle, 1500, seed=31)
     assert common.check_align1(gpu_lib, oracle, 1500, seed=32) > 1500
     monkeypatch.delenv("SSG_SMEM_LPR")
-    monkeypatch.setenv("SSG_SMEM_COOP", "1")      # lane per read with the rank blocks of the wave fetched quad-cooperatively (experimental; the default fetches per lane)
-    common.check_smem(gpu_lib, oracle, 1500, seed=31)
-    monkeypatch.delenv("SSG_SMEM_COOP")
     monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")
     common.check_smem(gpu_lib, oracle, 1500, seed=31)
     monkeypatch.delenv("SSG_SMEM_KERNEL")

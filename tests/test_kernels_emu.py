@@ -97,9 +97,6 @@ def test_emu_smem_kernel_variants(emu_lib, oracle, monkeypatch):
     monkeypatch.setenv("SSG_SMEM_LPR", "4")
     common.check_smem(emu_lib, oracle, 150, seed=31)
     monkeypatch.delenv("SSG_SMEM_LPR")
-    monkeypatch.setenv("SSG_SMEM_COOP", "1")      # lane per read with the rank blocks of the wave fetched quad-cooperatively (experimental; the default fetches per lane)
-    common.check_smem(emu_lib, oracle, 40, seed=31)
-    monkeypatch.delenv("SSG_SMEM_COOP")
     monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")
     common.check_smem(emu_lib, oracle, 150, seed=31)
     monkeypatch.delenv("SSG_SMEM_KERNEL")
