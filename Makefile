@@ -27,7 +27,9 @@ speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(K
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/sam_format.o -o $@
 
 # random 64-byte-line gather probe (the roofline denominator of the FM-index kernels; tools/profile_round.sh runs it)
-probe: tools/dbg/gather_probe
+probe: tools/dbg/gather_probe tools/dbg/valu_probe
+tools/dbg/valu_probe: tools/dbg/valu_probe.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 tools/dbg/gather_probe: tools/dbg/gather_probe.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 

@@ -1,17 +1,23 @@
 #!/bin/bash
-# Round profile on the GPU box: bench line, rocprofv3 kernel stats, and separate PMC passes (FETCH_SIZE / WRITE_SIZE) for
-# the ssg_k_* kernels plus a calibration pass on the random-gather probe.  Usage: tools/profile_round.sh r01d
+# Round profile on the GPU box (usage: tools/profile_round.sh r02): bench line, rocprofv3 kernel stats, separate PMC passes
+# (HBM traffic: FETCH_SIZE / WRITE_SIZE; SQ issue counters), the two roofline probes with a FETCH_SIZE calibration pass.
+# Counters are collected with --kernel-trace only (no sys/hip/hsa trace domains).  Summaries: tools/pmc_summarize.py.
 tag=${1:-rXX}; out=$PWD/gpurun_out; mkdir -p $out
-timeout 280 python bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
+B="python $PWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-profile"
 cd /tmp && export TMPDIR=/tmp
-timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python /root/repo/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $out/${tag}_rocprof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $B > $out/${tag}_bench_under_rocprof.log 2>&1
 find /tmp/prof_$tag -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 280 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$c -o pmc -- python /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-profile > $out/${tag}_pmc_$c.log 2>&1
-  f=$(find /tmp/pmc_${tag}_$c -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then (head -1 $f; grep "ssg_k_" $f) > $out/${tag}_pmc_$c.csv; fi
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM"; do
+  n=$(echo $c | cut -d' ' -f1)
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$n -o pmc -- $B > $out/${tag}_pmc_$n.log 2>&1
+  f=$(find /tmp/pmc_${tag}_$n -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then (head -1 $f; grep "ssg_k_" $f) > $out/${tag}_pmc_$n.csv; fi
 done
-timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_${tag}_probe -o pmc -- /root/repo/tools/dbg/gather_probe > $out/${tag}_probe.log 2>&1
+$PWD/../repo/tools/dbg/gather_probe > $out/${tag}_gather_probe.txt 2>&1 || /root/repo/tools/dbg/gather_probe > $out/${tag}_gather_probe.txt 2>&1
+/root/repo/tools/dbg/valu_probe > $out/${tag}_valu_probe.txt 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_${tag}_probe -o pmc -- /root/repo/tools/dbg/gather_probe > $out/${tag}_probe_under_pmc.log 2>&1
 f=$(find /tmp/pmc_${tag}_probe -name "*counter_collection.csv" | head -1)
-if [ -n "$f" ]; then (head -1 $f; grep "probe" $f) > $out/${tag}_pmc_probe.csv; fi
-ls -la $out | tail -12
+if [ -n "$f" ]; then (head -1 $f; grep "probe" $f) > $out/${tag}_pmc_probe_calibration.csv; fi
+rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|Counter).*(TCC_HIT|TCC_MISS|TCC_REQ|SQ_INSTS_VALU|FETCH_SIZE)" | head -20 > $out/${tag}_counter_names.txt
+ls -la $out | tail -20
+cat $out/${tag}_valu_probe.txt; grep -E "3.10 GB|4.00 GB" $out/${tag}_gather_probe.txt | head -14
