@@ -6,7 +6,7 @@ HOST    = speedseq_amd/host
 KHDRS   = $(wildcard $(CSRC)/*.h) include/ssgpu.h
 HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable
 
-all: lib tools oracle emu
+all: lib tools oracle emu synth
 
 lib: speedseq_amd/libssgpu.so
 $(CSRC)/ssgpu_core.o: $(CSRC)/ssgpu_core.cpp $(KHDRS)
@@ -25,6 +25,11 @@ speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(K
 	$(HIPCC) $(HIPFLAGS) -DSSG_TUNE -DSSG_C2A_WAVES_PER_SIMD=2 -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_tune.o
 	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/sam_format.o -o $@
+
+# bench utility: synthetic reference generator (one kernel launch)
+synth: tools/synth/libsynthref.so
+tools/synth/libsynthref.so: tools/synth/synth_ref.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -shared -fPIC $< -o $@
 
 # random 64-byte-line gather probe (the roofline denominator of the FM-index kernels; tools/profile_round.sh runs it)
 probe: tools/dbg/gather_probe tools/dbg/valu_probe

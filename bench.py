@@ -60,18 +60,10 @@ def synth_reference(total_len, seed, dev, order=6):
     L = sum(lens)
     cdf = torch.from_numpy(markov_table(order)).to(dev)
     S = 1 << 20 if L >= (1 << 26) else 1 << 12           # independent streams, each a contiguous stretch of the genome
-    steps = -(-L // S)
-    out = torch.empty((steps, S), dtype=torch.uint8, device=dev)
-    ctx = torch.randint(0, 4 ** order, (S,), device=dev, generator=g)
-    mask = 4 ** order - 1
-    for t in range(steps):
-        u = torch.rand(S, device=dev, generator=g)
-        th = cdf[ctx]
-        nxt = (u > th[:, 0]).long() + (u > th[:, 1]).long() + (u > th[:, 2]).long()
-        out[t] = nxt.to(torch.uint8)
-        ctx = ((ctx << 2) | nxt) & mask
-    ref = out.t().contiguous().reshape(-1)[:L].clone()
-    del out
+    ref = torch.empty(L, dtype=torch.uint8, device=dev)
+    syn = C.CDLL(os.path.join(ROOT, "tools", "synth", "libsynthref.so"))       # one kernel launch (tools/synth/synth_ref.cpp)
+    if syn.synth_markov(C.c_void_p(ref.data_ptr()), C.c_int64(L), C.c_int64(S), C.c_void_p(cdf.data_ptr()), C.c_int(order), C.c_uint64(seed)) != 0:
+        raise RuntimeError("synthetic reference kernel failed")
     rng = np.random.default_rng(seed)
     planted, n_fam = 0, 0
     while planted < 0.05 * L:

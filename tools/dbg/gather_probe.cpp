@@ -14,8 +14,7 @@ __device__ __forceinline__ uint64_t mix(uint64_t z) { z += 0x9e3779b97f4a7c15ull
 __global__ void fill(uint4 *buf, size_t n16) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; for (; i < n16; i += (size_t)gridDim.x * blockDim.x) { uint64_t a = mix(i), b = mix(a); buf[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); } }
 
 // mode 0: one 16-B load per step; 1: the four 16-B quarters of one line; 2: two lines x four quarters (bwt_extend shape);
-// 3: quad-cooperative, one line per quad per step (each lane one quarter); 4: quad-cooperative, two lines per step;
-// 5: two lines, of each only the quarters a bwt_extend for one base needs (one of the count quarters, the third, and the fourth half of the time)
+// 3: quad-cooperative, one line per quad per step (each lane one quarter); 4: quad-cooperative, two lines per step
 template <int MODE>
 __global__ void __launch_bounds__(256) probe(const uint4 *buf, uint64_t nlines, int iters, uint64_t *sink)
 {
@@ -28,8 +27,6 @@ __global__ void __launch_bounds__(256) probe(const uint4 *buf, uint64_t nlines, 
 		if (MODE == 0) { uint4 a = buf[l1 * 4 + (s >> 40 & 3)]; v = a.x ^ a.w; }
 		else if (MODE == 1) { for (int k = 0; k < 4; ++k) { uint4 a = buf[l1 * 4 + k]; v += __popc(a.x) + __popc(a.y) + __popc(a.z) + a.w; } }
 		else if (MODE == 2) { for (int k = 0; k < 4; ++k) { uint4 a = buf[l1 * 4 + k], b = buf[l2 * 4 + k]; v += __popc(a.x) + __popc(a.y) + a.w + __popc(b.x) + __popc(b.z) + b.w; } }
-		else if (MODE == 5) { const int cq = (int)(s >> 41 & 1); uint4 a = buf[l1 * 4 + cq], b = buf[l2 * 4 + cq], c = buf[l1 * 4 + 2], d = buf[l2 * 4 + 2]; v = a.x + __popc(c.x) + b.w + __popc(d.y);
-			if (s >> 43 & 1) { uint4 e = buf[l1 * 4 + 3]; v += __popc(e.x); } if (s >> 44 & 1) { uint4 e = buf[l2 * 4 + 3]; v += __popc(e.z); } }
 		else if (MODE == 3) { uint4 a = buf[l1 * 4 + qlane]; v = __popc(a.x) + __popc(a.y) + a.w; v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); }
 		else { uint4 a = buf[l1 * 4 + qlane], b = buf[l2 * 4 + qlane]; v = __popc(a.x) + a.w + __popc(b.y) + b.w; v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); }
 		acc += v;
@@ -47,7 +44,7 @@ template <int MODE> static void run(const uint4 *buf, uint64_t nlines, int nbloc
 	probe<MODE><<<nblocks, 256>>>(buf, nlines, iters, sink);
 	CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
 	float ms; CK(hipEventElapsedTime(&ms, a, b));
-	const double lanes = (double)nblocks * 256, lines_per_step = MODE == 0 ? 1 : MODE == 1 ? 1 : MODE == 2 ? 2 : MODE == 3 ? 0.25 : MODE == 5 ? 2 : 0.5;
+	const double lanes = (double)nblocks * 256, lines_per_step = MODE == 0 ? 1 : MODE == 1 ? 1 : MODE == 2 ? 2 : MODE == 3 ? 0.25 : 0.5;
 	const double lines = lanes * iters * lines_per_step;
 	printf("%-34s buf %5.2f GB  waves/CU %5.1f  %8.2f ms  %7.2f G lines/s  (%7.1f GB/s at 64 B)  %6.2f us per step\n", name, gb, nblocks * 4 / 256.0, ms, lines / ms / 1e6,
 	       lines * 64 / ms / 1e6, ms * 1e3 / iters);
@@ -70,7 +67,6 @@ int main(int argc, char **argv)
 			run<2>(buf, nlines, nb, iters, sink, "lane: two lines (8 x 16 B)", gb);
 			run<3>(buf, nlines, nb, iters, sink, "quad: one line (1 x 16 B per lane)", gb);
 			run<4>(buf, nlines, nb, iters, sink, "quad: two lines", gb);
-			run<5>(buf, nlines, nb, iters, sink, "lane: two lines, needed quarters", gb);
 		}
 		CK(hipFree(buf));
 	}

@@ -15,9 +15,10 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST
 done
 $PWD/../repo/tools/dbg/gather_probe > $out/${tag}_gather_probe.txt 2>&1 || /root/repo/tools/dbg/gather_probe > $out/${tag}_gather_probe.txt 2>&1
 /root/repo/tools/dbg/valu_probe > $out/${tag}_valu_probe.txt 2>&1
+/root/repo/tools/dbg/libm_probe > $out/${tag}_libm_probe.txt 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_${tag}_probe -o pmc -- /root/repo/tools/dbg/gather_probe > $out/${tag}_probe_under_pmc.log 2>&1
 f=$(find /tmp/pmc_${tag}_probe -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ]; then (head -1 $f; grep "probe" $f) > $out/${tag}_pmc_probe_calibration.csv; fi
 rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|Counter).*(TCC_HIT|TCC_MISS|TCC_REQ|SQ_INSTS_VALU|FETCH_SIZE)" | head -20 > $out/${tag}_counter_names.txt
 ls -la $out | tail -20
-cat $out/${tag}_valu_probe.txt; grep -E "3.10 GB|4.00 GB" $out/${tag}_gather_probe.txt | head -14
+cat $out/${tag}_libm_probe.txt; grep -c ssg_k $out/${tag}_pmc_*.csv
