@@ -296,7 +296,8 @@ def main():
 
     d_sig = torch.empty((a.pairs, 3), dtype=torch.int64, device=dev) if multi else None
     ordinal = (torch.arange(a.pairs, device=dev, dtype=torch.int64) + rank * a.pairs) if multi else None
-    n_dup_global = [0]
+    n_dup_global, merge_bytes = [0], [0]
+    rec_bytes = capi.dev_record_bytes(lib)
 
     def step(want_dup=False):
         if not multi:
@@ -309,7 +310,16 @@ def main():
         valid = d_sig[:, 0] != -1
         dup = ssdist.global_markdup(d_sig, valid, ordinal, device=dev).to(torch.uint8).contiguous()
         c = capi.dev_records_classify(lib, h, dup.data_ptr())
+        # ... and the coordinate-sorted merge (coupling 3): keys + fixed-size records of every SAM line travel to the rank that owns
+        # their key range (sample sort: one all-to-all), where they are sorted by (key, global ordinal)
+        nl = capi.dev_records_n_lines(lib, h)
+        d_keys = torch.empty(nl, dtype=torch.int64, device=dev)
+        d_recs = torch.empty((nl, rec_bytes), dtype=torch.uint8, device=dev)
+        capi.dev_records_export(lib, h, d_keys.data_ptr(), d_recs.data_ptr())
         capi.dev_records_free(lib, h)
+        line_ord = torch.arange(nl, device=dev, dtype=torch.int64) + (rank << 40)       # global ordinal: rank-major input order
+        _, _, _, sent = ssdist.coordinate_range_exchange(d_keys, line_ord, d_recs, device=dev)
+        merge_bytes[0] = sent
         summary[1], summary[8], summary[9], summary[10] = c[0], c[1], c[2], c[3]
         n_dup_global[0] = int(c[0])
         return summary, dup
@@ -350,7 +360,8 @@ def main():
                    "records": int(summary[0]), "dup_pairs": n_dup_global[0] if multi else int(summary[1]), "dup_pairs_local_view": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
                    "bwt_extends": int(summary[6]), "chains": int(summary[7]),
                    "sam_lines": int(summary[10]), "discordant_stream_lines": int(summary[8]), "splitter_stream_lines": int(summary[9]),
-                   "dedup_scope": "global over all ranks (all-to-all signature exchange)" if multi else "single GPU = whole input"},
+                   "dedup_scope": "global over all ranks (all-to-all signature exchange)" if multi else "single GPU = whole input",
+                   "sorted_merge": ("coordinate range exchange of %d-byte records by samtools' key inside the step; %.1f MB sent by rank 0 per step" % (rec_bytes, merge_bytes[0] / 1e6)) if multi else "single GPU: bin/sambamba sort (device radix sort of the keys)"},
     }
     if rank == 0:
         # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
@@ -390,6 +401,12 @@ def main():
                     traffic = pm.get("bytes_per_launch", {}).get(name)
             except Exception:
                 pass
+            valu = {}
+            try:   # fraction of the measured int32 VALU issue peak (tools/dbg/valu_probe) from the committed SQ counter pass of this workload
+                pq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+                valu = {k: round(v["valu_frac_of_probe_peak"], 3) for k, v in pq["kernels"].items() if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_smem")) and "valu_frac_of_probe_peak" in v and not k.endswith("_need")}
+            except Exception:
+                pass
             sw_names = [k for k in kern if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need")]
             sw_ms = sum(kern[k][0] for k in sw_names) / a.steps
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
@@ -401,7 +418,8 @@ def main():
                                              "achieved_glines_per_s": (2.0 * n_ext / (kern[smk][0] / kern[smk][1] * 1e-3) / 1e9) if smk else None,
                                              "frac": (2.0 * n_ext / (kern[smk][0] / kern[smk][1] * 1e-3) / 55e9) if smk else None},
                                "sw": {"cells_per_step": int(summary[3]) + int(summary[4]), "kernels": sorted(sw_names),
-                                      "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None}}
+                                      "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None,
+                                      "valu_frac": valu or None, "valu_frac_source": "profiles/r02_pmc_sq.json (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
         # ---- parity gate + CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample of the same batch ----
         if a.cpu_sample > 0 and world == 1:   # rank 0 at N = 1 only
             import oracle_py

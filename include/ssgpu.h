@@ -169,6 +169,12 @@ int ssg_hotpath_dev_ex(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_p
                        uint64_t summary[16], uint8_t *dup_host, uint64_t *d_sig_out, ssg_dev_records_t **keep);
 int ssg_dev_records_classify(ssg_dev_records_t *r, const ssg_sbl_opt_t *sbl, const uint8_t *d_dup, uint64_t counts[4]);
 void ssg_dev_records_free(ssg_dev_records_t *r);
+/* for the coordinate-sorted merge across ranks (SURVEY 8e coupling 3): per SAM line of the kept records, in line order, the sort key
+ * of samtools bam_sort.c:1607-1614 (tid<<32 | (pos+1)<<1 | reverse), the fixed-size device record and the side-stream bits,
+ * written to DEVICE buffers of the caller (d_recs / d_bits may be NULL) */
+int64_t ssg_dev_records_n_lines(const ssg_dev_records_t *r);
+size_t ssg_dev_record_bytes(void);
+int ssg_dev_records_export(const ssg_dev_records_t *r, uint64_t *d_keys, void *d_recs, uint8_t *d_bits);
 
 /* FM-index from arrays already resident in HBM (not copied; the caller keeps them alive) */
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,

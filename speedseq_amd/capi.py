@@ -252,6 +252,21 @@ def dev_records_classify(lib, h, d_dup):
     return counts
 
 
+def dev_records_n_lines(lib, h):
+    lib.l.ssg_dev_records_n_lines.restype = C.c_int64
+    return int(lib.l.ssg_dev_records_n_lines(h))
+
+
+def dev_record_bytes(lib):
+    lib.l.ssg_dev_record_bytes.restype = C.c_size_t
+    return int(lib.l.ssg_dev_record_bytes())
+
+
+def dev_records_export(lib, h, d_keys, d_recs=None, d_bits=None):
+    """sort keys / fixed-size records / side-stream bits of the kept records into device buffers (addresses)"""
+    lib._chk(lib.l.ssg_dev_records_export(h, C.c_void_p(d_keys), C.c_void_p(d_recs) if d_recs else None, C.c_void_p(d_bits) if d_bits else None))
+
+
 def dev_records_free(lib, h):
     lib.l.ssg_dev_records_free(h)
 

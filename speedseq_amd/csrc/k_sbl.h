@@ -153,6 +153,21 @@ __global__ void ssg_k_sbl_classify(ssg_sbl_opt_t o, long n_blocks, const int64_t
 	ssg_sbl_mark_splitters(o, lines, b0, b1, 0x80, out);
 }
 
+/* coordinate-sort key of every SAM line (samtools bam_sort.c:1607-1614: tid<<32 | (pos+1)<<1 | reverse, unplaced lines last) and its
+ * fixed-size device record, gathered in line order: what a rank hands to the range exchange of the sorted merge (SURVEY.md 8e coupling 3) */
+__global__ void ssg_k_sbl_export(int64_t n_lines, const ssg_sbl_line_t *lines, const int64_t *line_req, const ssg_aln_t *alns, const uint8_t *bits,
+                                 uint64_t *key, ssg_aln_t *recs, uint8_t *bits_out)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_lines) return;
+	const ssg_sbl_line_t l = lines[i];
+	const uint64_t tid = l.seq < 0 ? 0xffffffffull : (uint64_t)(uint32_t)l.seq;
+	const uint32_t pos1 = l.seq < 0 ? 0u : (uint32_t)l.pos;          /* BAM pos + 1 = SAM POS */
+	key[i] = tid << 32 | (uint64_t)(pos1 << 1) | ((l.flag & 0x10) ? 1u : 0u);
+	if (recs) recs[i] = alns[line_req[i]];
+	if (bits_out) bits_out[i] = bits[i];
+}
+
 /* c[0] += duplicate pairs, c[1] += discordant-stream lines, c[2] += splitter-stream lines; one atomic per wave and counter */
 __global__ void ssg_k_sbl_count_bits(int64_t n_lines, const uint8_t *bits, long n_pairs, const uint8_t *dup, unsigned int *c)
 {

@@ -1033,6 +1033,14 @@ int ssg_dev_records_classify(ssg_dev_records_t *R, const ssg_sbl_opt_t *sbl, con
 	return records_classify(R, &so, d_dup, counts);
 }
 void ssg_dev_records_free(ssg_dev_records_t *R) { delete R; }
+int64_t ssg_dev_records_n_lines(const ssg_dev_records_t *R) { return R->n_lines; }
+size_t ssg_dev_record_bytes(void) { return sizeof(ssg_aln_t); }
+/* keys (n_lines x u64), records (n_lines x ssg_dev_record_bytes(), may be NULL) and side-stream bits (n_lines, may be NULL) into DEVICE buffers of the caller */
+int ssg_dev_records_export(const ssg_dev_records_t *R, uint64_t *d_keys, void *d_recs, uint8_t *d_bits)
+{
+	if (R->n_lines > 0) SSG_LAUNCH(ssg_k_sbl_export, (R->n_lines + 255) / 256, 256, 0, R->n_lines, R->lines.p, R->line_req.p, R->keep.alns.p, R->bits.p, d_keys, (ssg_aln_t*)d_recs, d_bits);
+	return rt_sync();
+}
 
 int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
                     const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host /* may be NULL */)

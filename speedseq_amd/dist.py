@@ -82,3 +82,47 @@ def max_over_ranks(seconds, device="cpu"):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def coordinate_range_exchange(keys, ordinal, recs, device="cpu", n_samples=1024):
+    """Coupling 3 of SURVEY.md 8e, the one exchange the north star names: the coordinate-sorted merge as a SAMPLE SORT, not a
+    gather.  Every rank holds records with their samtools sort key (bam_sort.c:1607-1614: tid<<32 | (pos+1)<<1 | reverse) and
+    global input ordinal.  Ranks all-gather a sample of their keys, agree on world-1 splitters, send every record to the rank
+    that owns its key range (one all-to-all over all xGMI links at once), and sort what they received by (key, ordinal) --
+    rank r then holds the r-th contiguous stretch of the coordinate-sorted file, ties in input order exactly as samtools'
+    stable sort / merge leaves them.
+    keys: int64 [n] (the 64-bit key reinterpreted), ordinal: int64 [n], recs: uint8 [n, R].  Returns (keys, ordinal, recs) of this
+    rank's stretch, sorted, and the number of payload bytes this rank sent to other ranks."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    keys, ordinal, recs = keys.to(device), ordinal.to(device), recs.to(device)
+    n = keys.numel()
+    # unsigned order on the int64 view: flip the sign bit
+    ukey = keys ^ torch.iinfo(torch.int64).min
+    if world > 1:
+        srt = torch.sort(ukey).values
+        pick = (torch.arange(n_samples, device=device, dtype=torch.int64) * max(n, 1)) // n_samples
+        sample = srt[pick.clamp(max=max(n - 1, 0))] if n else torch.full((n_samples,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=device)
+        allsamp = [torch.empty_like(sample) for _ in range(world)]
+        dist.all_gather(allsamp, sample)
+        allsamp = torch.sort(torch.cat(allsamp)).values
+        splitters = allsamp[(torch.arange(1, world, device=device) * allsamp.numel()) // world]
+        dest = torch.bucketize(ukey, splitters, right=False)      # equal keys share a destination: ties never straddle two ranks
+    else:
+        dest = torch.zeros(n, dtype=torch.int64, device=device)
+    order = torch.argsort(dest, stable=True)
+    send_counts = torch.bincount(dest, minlength=world)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    meta = torch.stack([ukey, ordinal], 1)[order].contiguous()
+    meta_r = torch.empty(sum(rc), 2, dtype=torch.int64, device=device)
+    dist.all_to_all_single(meta_r, meta, output_split_sizes=rc, input_split_sizes=sc)
+    recs_s = recs[order].contiguous()
+    recs_r = torch.empty((sum(rc),) + tuple(recs.shape[1:]), dtype=recs.dtype, device=device)
+    dist.all_to_all_single(recs_r, recs_s, output_split_sizes=rc, input_split_sizes=sc)
+    # local order: by key, ties by global input ordinal (two stable passes)
+    o1 = torch.argsort(meta_r[:, 1], stable=True)
+    o2 = torch.argsort(meta_r[o1, 0], stable=True)
+    perm = o1[o2]
+    sent = (n - sc[rank]) * (16 + int(np.prod(recs.shape[1:])) * recs.element_size())
+    return meta_r[perm, 0] ^ torch.iinfo(torch.int64).min, meta_r[perm, 1], recs_r[perm], sent

@@ -86,3 +86,42 @@ def test_device_signatures_through_the_exchange(emu_lib, oracle):
         dist.destroy_process_group()
     assert np.array_equal(dup.numpy(), dup_local) and dup_local.sum() > 30
     emu_lib.index_destroy(idx)
+
+
+def _sort_worker(rank, world, port, d):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speedseq_amd import dist as sdist
+    keys = torch.from_numpy(np.load(os.path.join(d, "keys.npy")))
+    n = keys.numel()
+    mine = torch.arange(rank, n, world)                 # records dealt round-robin: every rank holds keys from the whole range
+    recs = torch.stack([(mine % 251).to(torch.uint8), (mine // 251 % 251).to(torch.uint8), (keys[mine] & 0xff).to(torch.uint8)], 1)
+    k, o, r, sent = sdist.coordinate_range_exchange(keys[mine], mine, recs, n_samples=64)
+    np.save(os.path.join(d, "out%d.npy" % rank), np.stack([k.numpy(), o.numpy()]))
+    np.save(os.path.join(d, "rec%d.npy" % rank), r.numpy())
+    assert sent >= 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coordinate_range_exchange_three_ranks_gloo():
+    """SURVEY 8e coupling 3: the sample-sort merge by samtools' coordinate key leaves rank r with the r-th stretch of the globally
+    sorted stream, ties in input order (stable), for keys with heavy ties and the unplaced (tid = -1: top bits set) tail."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    tid = rng.integers(0, 3, size=n).astype(np.uint64)
+    tid[rng.random(n) < 0.05] = 0xffffffff                                   # unplaced lines sort last (uint64 order)
+    pos = rng.integers(0, 500, size=n).astype(np.uint64)                      # many equal keys
+    keys = ((tid << np.uint64(32)) | (pos << np.uint64(1)) | rng.integers(0, 2, size=n).astype(np.uint64)).view(np.int64)
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "keys.npy"), keys)
+        port = 31500 + os.getpid() % 2000
+        mp.spawn(_sort_worker, args=(3, port, d), nprocs=3, join=True)
+        outs = [np.load(os.path.join(d, "out%d.npy" % r)) for r in range(3)]
+        recs = [np.load(os.path.join(d, "rec%d.npy" % r)) for r in range(3)]
+    got_k = np.concatenate([o[0] for o in outs]); got_o = np.concatenate([o[1] for o in outs]); got_r = np.concatenate(recs)
+    exp = np.lexsort((np.arange(n), keys.view(np.uint64)))                    # stable by unsigned key
+    assert np.array_equal(got_o, exp) and np.array_equal(got_k, keys[exp])
+    assert np.array_equal(got_r[:, 0], (exp % 251).astype(np.uint8)) and np.array_equal(got_r[:, 2], (keys[exp] & 0xff).astype(np.uint8))
+    assert all(len(o[0]) > n // 10 for o in outs)                             # the splitters balance the ranges
