@@ -32,7 +32,9 @@ tools/synth/libsynthref.so: tools/synth/synth_ref.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 -shared -fPIC $< -o $@
 
 # random 64-byte-line gather probe (the roofline denominator of the FM-index kernels; tools/profile_round.sh runs it)
-probe: tools/dbg/gather_probe tools/dbg/valu_probe
+probe: tools/dbg/gather_probe tools/dbg/valu_probe tools/dbg/libm_probe
+tools/dbg/libm_probe: tools/dbg/libm_probe.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -ffp-contract=off $< -o $@
 tools/dbg/valu_probe: tools/dbg/valu_probe.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 tools/dbg/gather_probe: tools/dbg/gather_probe.cpp
