@@ -4,8 +4,7 @@ CXX     ?= g++
 CSRC    = speedseq_amd/csrc
 HOST    = speedseq_amd/host
 KHDRS   = $(wildcard $(CSRC)/*.h) include/ssgpu.h
-# per-thread default stream: two host threads can drive independent parts of a batch concurrently (ssg_hotpath_dev_ex)
-HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fgpu-default-stream=per-thread -Wall -Wno-unused-function -Wno-unused-variable
+HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable
 
 all: lib tools oracle emu synth
 

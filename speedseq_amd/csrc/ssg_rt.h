@@ -67,8 +67,7 @@ static inline void rt_free(void *p) { ssg_pool.put(p); }
 static inline int rt_h2d(void *d, const void *h, size_t n) { return n ? rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D") : 0; }
 static inline int rt_d2h(void *h, const void *d, size_t n) { return n ? rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
 static inline int rt_memset(void *d, int v, size_t n) { return n ? rt_check(hipMemset(d, v, n), "hipMemset") : 0; }
-/* the calling thread's stream (the library is compiled with -fgpu-default-stream=per-thread: stream 0 is per host thread) */
-static inline int rt_sync() { int rc = rt_check(hipStreamSynchronize(0), "hipStreamSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
+static inline int rt_sync() { int rc = rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
 /* multi-gigabyte, build-time-only arrays (index construction) bypass the arena: they must return to the driver when freed */
 static inline void *rt_malloc_raw(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); ssg_pool.release(); if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return 0; } } return p; }
 static inline void rt_free_raw(void *p) { if (p) (void)hipFree(p); }
@@ -79,20 +78,18 @@ static inline int rt_d2d(void *d, const void *s, size_t n) { return n ? rt_check
 struct ssg_prof_rec { const char *name; hipEvent_t a, b; };
 extern int ssg_prof_on;
 extern std::vector<ssg_prof_rec> ssg_prof_pending;
-extern std::mutex ssg_prof_mu;
-static inline void ssg_prof_push(const ssg_prof_rec &r) { std::lock_guard<std::mutex> l(ssg_prof_mu); ssg_prof_pending.push_back(r); }
 #define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) { \
 	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, 0); \
-		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); (void)hipEventRecord(r_.b, 0); ssg_prof_push(r_); } \
+		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); (void)hipEventRecord(r_.b, 0); ssg_prof_pending.push_back(r_); } \
 	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } } while (0)
 /* side streams for independent kernels that each leave most of the chip idle (few heavy work items): fork after the work
  * already queued on the default stream, launch with SSG_LAUNCH_ON(i, ...), join before anything that consumes the results */
-static inline hipStream_t ssg_side_stream(int i) { static thread_local hipStream_t s[4] = {0, 0, 0, 0}; if (!s[i]) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking); return s[i]; }
+static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[4] = {0, 0, 0, 0}; if (!s[i]) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking); return s[i]; }
 static inline void ssg_fork(int n) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, 0); for (int i = 0; i < n; ++i) (void)hipStreamWaitEvent(ssg_side_stream(i), e, 0); (void)hipEventDestroy(e); }
 static inline void ssg_join(int n) { for (int i = 0; i < n; ++i) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, ssg_side_stream(i)); (void)hipStreamWaitEvent(0, e, 0); (void)hipEventDestroy(e); } }
 #define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) do { if ((grid) > 0) { hipStream_t st_ = ssg_side_stream(si); \
 	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, st_); \
-		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), st_, __VA_ARGS__); (void)hipEventRecord(r_.b, st_); ssg_prof_push(r_); } \
+		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), st_, __VA_ARGS__); (void)hipEventRecord(r_.b, st_); ssg_prof_pending.push_back(r_); } \
 	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), st_, __VA_ARGS__); } } while (0)
 #endif
 

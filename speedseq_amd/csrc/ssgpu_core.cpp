@@ -11,8 +11,6 @@
 #include <vector>
 #include <memory>
 #include <algorithm>
-#include <thread>
-#include <mutex>
 #include <math.h>
 #include "ssg_rt.h"
 #include "k_seed.h"
@@ -33,7 +31,6 @@ thread_local std::string ssg_err_msg;
 ssg_pool_t ssg_pool;
 int ssg_prof_on = 0;
 std::vector<ssg_prof_rec> ssg_prof_pending;
-std::mutex ssg_prof_mu;
 #endif
 
 /* wave-per-item kernels are grid-strided over at most this many 4-wave workgroups (256 CUs x 4),
@@ -1009,76 +1006,25 @@ int ssg_hotpath_dev_ex(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_p
 	if (keep_out) *keep_out = 0;
 	if (n_pairs <= 0 || max_len > 254) { ssg_err_msg = "ssg_hotpath_dev: bad arguments"; return SSG_EINVAL; }
 	ssg_sbl_opt_t so; if (sbl) so = *sbl; else { ssg_sbl_opt_init(&so); so.exclude_dups = 1; so.add_mate_tags = 1; }   /* the reference's command line */
-	/* Parts: groups of whole upstream batches (the scope of the insert-size model; results do not depend on the grouping) are driven
-	 * by separate host threads on their own streams, so the latency-bound tail of one part (reads with thousands of seeds chain one
-	 * wave each) overlaps the throughput-bound kernels of the other.  Duplicate marking then runs once over all pairs in input order. */
-	int n_parts = keep_out || n_batches < 2 ? 1 : env_int("SSG_HOTPATH_PARTS", 2);
-#ifdef SSG_EMU
-	n_parts = 1;
-#endif
-	if (n_parts > n_batches) n_parts = n_batches;
-	if (n_parts > 4) n_parts = 4;
-	std::vector<int> p0(n_parts + 1, 0);
-	p0[n_parts] = n_pairs;
-	if (n_parts > 1) {
-		std::vector<int32_t> pb(n_pairs);
-		CHK(rt_d2h(pb.data(), d_pair_batch, (size_t)n_pairs * 4));
-		for (int k = 1; k < n_parts; ++k) {   /* first pair of the batch that starts the k-th share */
-			const int b = (int)((long)n_batches * k / n_parts);
-			p0[k] = (int)(std::lower_bound(pb.begin(), pb.end(), b) - pb.begin());
-		}
-	}
-	std::vector<ssg_pe_result> res(n_parts); std::vector<std::unique_ptr<ssg_dev_records> > R(n_parts);
-	std::vector<int> rcs(n_parts, 0); std::vector<std::string> errs(n_parts);
-	auto run_part = [&](int k) {
-		R[k].reset(new ssg_dev_records());
-		const int np = p0[k + 1] - p0[k];
-		R[k]->n_pairs = np;
-		if (np <= 0) return;
-		int rc = pe_core(idx, opt, np, d_seq, d_off + 2L * p0[k], max_len, d_pair_batch + p0[k], n_batches, id0 + p0[k], 0, &res[k], &R[k]->keep);
-		if (!rc) rc = records_lines(R[k].get());
-		if (!rc) rc = rt_sync();
-		rcs[k] = rc; if (rc) errs[k] = ssg_err_msg;
-	};
-	if (n_parts == 1) run_part(0);
-	else {
-#ifndef SSG_EMU
-		int dev = 0; (void)hipGetDevice(&dev);
-		std::vector<std::thread> th;
-		for (int k = 1; k < n_parts; ++k) th.emplace_back([&, k, dev]() { (void)hipSetDevice(dev); run_part(k); });
-		run_part(0);
-		for (auto &t : th) t.join();
-#endif
-	}
-	for (int k = 0; k < n_parts; ++k) if (rcs[k]) { ssg_err_msg = errs[k]; return rcs[k]; }
+	ssg_pe_result res; std::unique_ptr<ssg_dev_records> R(new ssg_dev_records());
+	R->n_pairs = n_pairs;
+	CHK(pe_core(idx, opt, n_pairs, d_seq, d_off, max_len, d_pair_batch, n_batches, id0, 0, &res, &R->keep));
+	CHK(records_lines(R.get()));
 	memset(summary, 0, 16 * sizeof(uint64_t));
-	dbuf<uint8_t> d_dup(n_pairs); dbuf<ssg_sbl_end_t> d_ends_all;
-	CHKA(d_dup);
 	if (local_dedup || d_sig_out) {
-		const ssg_sbl_end_t *ends = R[0]->ends.p;
-		if (n_parts > 1) {   /* the primary ends of all parts, in input order */
-			if (!d_ends_all.alloc(2L * n_pairs)) { ssg_err_msg = "device allocation failed: ends"; return SSG_ENOMEM; }
-			for (int k = 0; k < n_parts; ++k) CHK(rt_d2d(d_ends_all.p + 2L * p0[k], R[k]->ends.p, (size_t)(p0[k + 1] - p0[k]) * 2 * sizeof(ssg_sbl_end_t)));
-			ends = d_ends_all.p;
-		}
-		CHK(dedup_core(0, n_pairs, ends, d_dup.p, (ssg_sig_t*)d_sig_out));
+		dbuf<ssg_sig_t> d_sigb;
+		CHK(dedup_core(0, n_pairs, R->ends.p, R->dup.p, (ssg_sig_t*)d_sig_out));
 	}
 	if (local_dedup) {
-		for (int k = 0; k < n_parts; ++k) {
-			if (R[k]->n_pairs <= 0) continue;
-			uint64_t c[4];
-			CHK(records_classify(R[k].get(), &so, d_dup.p + p0[k], c));
-			summary[1] += c[0]; summary[8] += c[1]; summary[9] += c[2]; summary[10] += c[3];
-		}
-		if (dup_host) CHK(d_dup.down(dup_host, n_pairs));
+		uint64_t c[4];
+		CHK(records_classify(R.get(), &so, R->dup.p, c));
+		summary[1] = c[0]; summary[8] = c[1]; summary[9] = c[2]; summary[10] = c[3];
+		if (dup_host) CHK(R->dup.down(dup_host, n_pairs));
 	}
-	for (int k = 0; k < n_parts; ++k) {
-		if (R[k]->n_pairs <= 0) continue;
-		summary[0] += res[k].stats[4]; summary[2] += res[k].stats[0]; summary[3] += res[k].stats[1]; summary[4] += res[k].stats[2]; summary[5] += res[k].stats[3];
-		summary[7] += res[k].stats[6]; /* chains = first-seed extensions */
-		summary[6] += res[k].stats[5]; /* bwt_extend calls in the SMEM kernel (2 rank queries = 2 x 64-byte lines each) */
-	}
-	if (keep_out) { if (local_dedup || d_sig_out) CHK(rt_d2d(R[0]->dup.p, d_dup.p, (size_t)n_pairs)); *keep_out = R[0].release(); }
+	summary[0] = res.stats[4]; summary[2] = res.stats[0]; summary[3] = res.stats[1]; summary[4] = res.stats[2]; summary[5] = res.stats[3];
+	summary[7] = res.stats[6]; /* chains = first-seed extensions */
+	summary[6] = res.stats[5]; /* bwt_extend calls in the SMEM kernel (2 rank queries = 2 x 64-byte lines each) */
+	if (keep_out) *keep_out = R.release();
 	return 0;
 }
 int ssg_dev_records_classify(ssg_dev_records_t *R, const ssg_sbl_opt_t *sbl, const uint8_t *d_dup, uint64_t counts[4])

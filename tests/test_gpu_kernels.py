@@ -116,41 +116,6 @@ def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
     monkeypatch.delenv("SSG_SMEM_KERNEL")
     monkeypatch.setenv("SSG_SA_INTV", "32")   # the file's own suffix-array density
     assert common.check_align1(gpu_lib, oracle, 1500, seed=33) > 1500
-
-
-def test_gpu_hotpath_parts_and_dups(gpu_lib, oracle, monkeypatch):
-    """ssg_hotpath_dev (the bench's step): upstream batches driven as 1, 2 or 3 concurrent parts give the same records and duplicate
-    flags, and those equal the oracle's `bwa mem` (one insert-size model per upstream batch) + samblaster over the whole input."""
-    import torch
-    from speedseq_amd import capi
-    n_pairs, per = 3000, 1000
-    pairs, seqs, seq, off = common.sim_reads(n_pairs, seed=41, dup_frac=0.1)
-    pb = (np.arange(n_pairs) // per).astype(np.int32)
-    gidx, oidx = gpu_lib.index_load(common.EXAMPLE_FA), oracle.idx_load(common.EXAMPLE_FA)
-    opt = gpu_lib.opt_init()
-    d_seq, d_off, d_pb = torch.from_numpy(seq).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(pb).cuda()
-    torch.cuda.synchronize()
-    got = {}
-    for parts in ("1", "2", "3"):
-        monkeypatch.setenv("SSG_HOTPATH_PARTS", parts)
-        summary, dup = capi.hotpath_dev(gpu_lib, gidx, opt, n_pairs, 150, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), 3, 0, True)
-        got[parts] = (summary.copy(), dup.copy())
-    for parts in ("2", "3"):
-        assert np.array_equal(got[parts][0], got["1"][0]) and np.array_equal(got[parts][1], got["1"][1]), parts
-    names = []
-    for nm, _, _ in pairs:
-        names += [nm, nm]
-    text = ""
-    for b in range(3):
-        lo, hi = 2 * per * b, 2 * per * (b + 1)
-        t, _, _ = oracle.process_pairs(oidx, seq[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], names[lo:hi], None, lo, "", 4)
-        text += t
-    oflags, _ = common.oracle_dup_flags(oracle, text, "@SQ\tSN:20_slice\tLN:321635\n")
-    assert np.array_equal(got["1"][1], oflags) and oflags.sum() > 100
-    assert int(got["1"][0][0]) == text.count("\n") + sum(l.count(";") for l in text.split("\n") if "\tXA:Z:" in l for l in [l.split("\tXA:Z:")[1].split("\t")[0]]) or int(got["1"][0][0]) >= text.count("\n")
-    gpu_lib.index_destroy(gidx)
-
-
 def test_gpu_hotpath_batches_and_dups(gpu_lib, oracle):
     """ssg_hotpath_dev (the bench's step) on device-resident reads in three upstream batches: duplicate flags equal the oracle's
     `bwa mem` (one insert-size model per upstream batch) + samblaster over the whole input; the device classification counts lines."""
