@@ -21,10 +21,10 @@ speedseq_amd/libssgpu.so: $(LIBOBJS)
 
 # instrumented build (device phase counters, tools/dbg/phase.py); never the default library
 tune: speedseq_amd/libssgpu_tune.so
-speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/sam_format.cpp $(KHDRS)
+speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.cpp $(KHDRS)
 	$(HIPCC) $(HIPFLAGS) -DSSG_TUNE -DSSG_C2A_WAVES_PER_SIMD=2 -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_tune.o
 	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/sam_format.o -o $@
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o -o $@ -lz
 
 # bench utility: synthetic reference generator (one kernel launch)
 synth: tools/synth/libsynthref.so

@@ -60,6 +60,7 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 	l_rep += e - b;
 	const float frac_rep = (float)l_rep / len_read;
 	ssg_wave_ldssync();
+	const unsigned long long ph_t0 = ssg_clock();
 	/* ---- greedy chaining in seed-visiting order ---- */
 	for (int i0 = 0; i0 < ns; i0 += 64) {
 		const int me = i0 + lane;
@@ -124,6 +125,7 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 		}
 	}
 	/* ---- upstream mem_chain_weight: one lane per chain ---- */
+	const unsigned long long ph_t1 = ssg_clock();
 	ssg_wave_ldssync();
 	for (int c = lane; c < nc; c += 64) {
 		int w1 = 0, w2 = 0, sid = L.fs[c], end1 = 0; int64_t end2 = 0;
@@ -139,6 +141,7 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 		L.a8[c] = w < 1<<30 ? w : (1<<30) - 1;
 	}
 	ssg_wave_ldssync();
+	const unsigned long long ph_t2 = ssg_clock();
 	/* chains in position order with w >= min_chain_weight -> b8[] as (w, id) */
 	int n_chn = 0;
 	for (int e0 = 0; e0 < nc; e0 += 64) {
@@ -155,8 +158,10 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 	int n_out = 0;
 	if (n_chn > 0) {
 		/* ---- upstream mem_chain_flt ---- */
+		const unsigned long long ph_t3 = ssg_clock();
 		if (lane == 0) ssg_introsort(L.b8, (long)n_chn, ssg_whi_gt());
 		ssg_wave_ldssync();
+		const unsigned long long ph_t4 = ssg_clock();
 		for (i = lane; i < n_chn; i += 64) L.rid[i] = 0;
 		int nk = 0;
 		for (i = 0; i < n_chn; ++i) {
@@ -205,6 +210,8 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 			}
 			ssg_wave_ldssync();
 		}
+		const unsigned long long ph_t5 = ssg_clock();
+		if (SSG_TUNING && lane == 0 && CAP >= 2048) { atomicAdd(&ssg_dbg_cyc[8], ph_t1 - ph_t0); atomicAdd(&ssg_dbg_cyc[9], ph_t2 - ph_t1); atomicAdd(&ssg_dbg_cyc[10], ph_t4 - ph_t3); atomicAdd(&ssg_dbg_cyc[11], ph_t5 - ph_t4); atomicAdd(&ssg_dbg_cyc[12], 1ull); atomicAdd(&ssg_dbg_cyc[13], (unsigned long long)ns); atomicAdd(&ssg_dbg_cyc[14], (unsigned long long)nc); }
 		/* ---- survivors in weight order: records, seed lists ---- */
 		int pos = 0;
 		for (int e0 = 0; e0 < n_chn; e0 += 64) {
