@@ -17,29 +17,51 @@
  *     norm for repeats, and the unstable tie order selects what is kept) on packed keys in LDS;
  *   - the filter tests chain i against 64 kept chains at a time: ballot of the `break' condition,
  *     side effects applied only to the kept chains up to the first break, exactly as the scalar loop.
- * Per-chain LDS footprint is 31 bytes; CAP = 256 / 1024 / 2048 / 4096 run 20 / 5 / 2 / 1 reads per CU.
+ * Per-chain LDS footprint is 27 bytes + 4.1 per seed; 256 / 1024 / 2048 / 4096 chains = seeds run 20 / 5 / 2 / 1 reads per CU, and
+ * reads of up to 16384 seeds fit with 3072 chains (the few that make more fall back to the lane kernel).
  */
 #ifndef SSG_K_CHAINW_H
 #define SSG_K_CHAINW_H
 #include "k_chain.h"
 
-template <int CAP> struct ssg_chw_lds_t {
-	int64_t a8[CAP];   /* insertion: rbeg of the chain's last seed [chain id] | weights [chain id] | filter: kept w<<32 | kept sorted idx<<16 | first shadowed */
-	int64_t b8[CAP];   /* insertion: chain positions, sorted                  | sort/filter: w<<32 | chain id, sorted by w */
-	int16_t rid[CAP];  /* insertion: contig of the chain [chain id] (< 32768 contigs: host-checked) | filter: kept state [sorted idx] */
-	uint16_t ids[CAP]; /* insertion: chain id of sorted slot                  | filter: query begin of kept chain */
-	uint16_t ls[CAP];  /* last seed [chain id]                                | filter: query end of kept chain */
-	uint16_t n[CAP], fs[CAP];            /* [chain id]: #seeds, first seed */
-	uint8_t fq[CAP], lq[CAP], ll[CAP];   /* [chain id]: qbeg of first seed, qbeg/len of last seed (reads are < 255 bases) */
-	uint16_t nx[CAP];  /* [seed]: next seed of the same chain */
+/* CAPC chains, CAPS seeds (CAPS >= CAPC) */
+template <int CAPC, int CAPS> struct ssg_chw_lds_t {
+	int64_t a8[CAPC];   /* insertion: rbeg of the chain's last seed [chain id] | weights [chain id] | filter: kept w<<32 | kept sorted idx<<16 | first shadowed */
+	int64_t b8[CAPC];   /* insertion: chain position [chain id] (shifting form: positions, sorted [slot]) | sort/filter: w<<32 | chain id, sorted by w */
+	int16_t rid[CAPC];  /* insertion: contig of the chain [chain id] (< 32768 contigs: host-checked) | filter: kept state [sorted idx] */
+	uint16_t ls[CAPC];  /* last seed [chain id]                                | filter: query end of kept chain */
+	uint16_t n[CAPC], fs[CAPC];            /* [chain id]: #seeds, first seed */
+	uint8_t fq[CAPC], lq[CAPC], ll[CAPC];  /* [chain id]: qbeg of first seed, qbeg/len of last seed (reads are < 255 bases) */
+	uint16_t ids[CAPS]; /* insertion: chain id at position RANK (shifting form: of sorted slot) | filter: query begin of kept chain */
+	uint16_t nx[CAPS];  /* [seed]: next seed of the same chain */
+	uint64_t bm[CAPS / 64];                  /* ranks that hold a chain */
+	uint64_t bms[(CAPS / 64 + 63) / 64];     /* words of bm[] that are not empty */
 };
+
+/* largest rank <= r whose bit is set, or -1 (r may be -1); wave-uniform, every lane reads the same words */
+template <int CAPC, int CAPS> SSG_DEVFN int chw_prev_set(const ssg_chw_lds_t<CAPC, CAPS> &L, int r)
+{
+	if (r < 0) return -1;
+	const int w = r >> 6, bit = r & 63;
+	const uint64_t m = L.bm[w] & (bit == 63 ? ~0ull : (1ull << (bit + 1)) - 1);
+	if (m) return (w << 6) + 63 - __clzll(m);
+	int sw = w >> 6;
+	uint64_t sm = L.bms[sw] & ((1ull << (w & 63)) - 1);
+	while (!sm && sw > 0) { --sw; sm = L.bms[sw]; }
+	if (!sm) return -1;
+	const int w2 = (sw << 6) + 63 - __clzll(sm);
+	return (w2 << 6) + 63 - __clzll(L.bm[w2]);
+}
 
 struct ssg_whi_gt { SSG_DEVMEM bool operator()(int64_t a, int64_t b) const { return (a >> 32) > (b >> 32); } };
 
-template <int CAP>
-SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const int64_t *read_off, const ssg_intv_t *intv,
+/* rank: this read's seeds ranked by (reference position, visiting order), or NULL for the shifting form (needs #seeds <= CAPC).
+ * Returns 0, or -1 when the ranked form meets what it does not cover (more chains than CAPC, or a third chain at one position:
+ * upstream's order among three equal positions is not rank order) -- the caller then chains the read another way. */
+template <int CAPC, int CAPS>
+SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const int64_t *read_off, const ssg_intv_t *intv,
                              const int32_t *n_intv, int cap, const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
-                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, ssg_chw_lds_t<CAP> &L)
+                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, ssg_chw_lds_t<CAPC, CAPS> &L, const uint16_t *rank, int capc_lim)
 {
 	const int lane = wv_lane();
 	const int len_read = (int)(read_off[r+1] - read_off[r]);
@@ -62,6 +84,60 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 	ssg_wave_ldssync();
 	const unsigned long long ph_t0 = ssg_clock();
 	/* ---- greedy chaining in seed-visiting order ---- */
+	if (rank) {
+		/* The set of chains is a bitmap over position ranks (the universe of possible chain positions is the read's own seeds, ranked
+		 * once for the whole batch by a device radix sort): the floor lookup is a few bit scans, a new chain is one bit -- O(1) per
+		 * seed instead of a shift of the sorted array (O(chains / 64)), which is what the reads with thousands of seeds paid. */
+		for (i = lane; i < (ns + 63) / 64; i += 64) L.bm[i] = 0;
+		for (i = lane; i < ((ns + 63) / 64 + 63) / 64; i += 64) L.bms[i] = 0;
+		ssg_wave_ldssync();
+		for (int i0 = 0; i0 < ns; i0 += 64) {
+			const int me = i0 + lane;
+			int64_t my_rbeg = 0; int my_q = 0, my_len = 0, my_rid = -1, my_rk = 0;
+			if (me < ns) { const ssg_seed_t sdd = sd[me]; my_rbeg = sdd.rbeg; my_q = sdd.qbeg; my_len = sdd.len; my_rid = srid[me]; my_rk = rank[me]; }
+			const int cn = ns - i0 < 64 ? ns - i0 : 64;
+			for (int t = 0; t < cn; ++t) {
+				const int prid = wv_get(my_rid, t);
+				if (prid < 0) continue;
+				const int sid = i0 + t, rk = wv_get(my_rk, t);
+				const int64_t rbeg = wv_get64(my_rbeg, t);
+				const int qbeg = wv_get(my_q, t), len = wv_get(my_len, t);
+				int fl = chw_prev_set(L, rk), two_equal = 0, res = 0;
+				if (fl >= 0 && L.b8[L.ids[fl]] == rbeg) {   /* a chain at this very position: upstream tests the FIRST of them */
+					const int f2 = chw_prev_set(L, fl - 1);
+					if (f2 >= 0 && L.b8[L.ids[f2]] == rbeg) { fl = f2; two_equal = 1; }
+				}
+				if (fl >= 0) { /* upstream test_and_merge against the floor chain */
+					const int c = L.ids[fl];
+					const int64_t f_rbeg = L.b8[c], l_rbeg = L.a8[c];
+					const int f_q = L.fq[c], l_q = L.lq[c], l_len = L.ll[c];
+					if (prid != L.rid[c]) res = 0;
+					else if (qbeg >= f_q && qbeg + len <= l_q + l_len && rbeg >= f_rbeg && rbeg + len <= l_rbeg + l_len) res = 1;
+					else if ((l_rbeg < l_pac || f_rbeg < l_pac) && rbeg >= l_pac) res = 0;
+					else {
+						const int64_t x = qbeg - l_q, y = rbeg - l_rbeg;
+						if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) res = 2;
+					}
+					if (res == 2) {
+						ssg_wave_ldssync();
+						if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.lq[c] = (uint8_t)qbeg; L.ll[c] = (uint8_t)len; ++L.n[c]; }
+						ssg_wave_ldssync();
+					}
+				}
+				if (res == 0) { /* new chain; its place in position order is its seed's rank */
+					if (two_equal || nc >= capc_lim) return -1;
+					ssg_wave_ldssync();
+					if (lane == 0) {
+						L.bm[rk >> 6] |= 1ull << (rk & 63); L.bms[rk >> 12] |= 1ull << ((rk >> 6) & 63);
+						L.ids[rk] = (uint16_t)nc; L.b8[nc] = rbeg; L.a8[nc] = rbeg; L.fq[nc] = L.lq[nc] = (uint8_t)qbeg; L.ll[nc] = (uint8_t)len;
+						L.n[nc] = 1; L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
+					}
+					ssg_wave_ldssync();
+					++nc;
+				}
+			}
+		}
+	} else
 	for (int i0 = 0; i0 < ns; i0 += 64) {
 		const int me = i0 + lane;
 		int64_t my_rbeg = 0; int my_q = 0, my_len = 0, my_rid = -1;
@@ -144,6 +220,19 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 	const unsigned long long ph_t2 = ssg_clock();
 	/* chains in position order with w >= min_chain_weight -> b8[] as (w, id) */
 	int n_chn = 0;
+	if (rank) {   /* position order = rank order of the set bits; the (w, id) list goes to b8[], whose positions are no longer needed */
+		for (int e0 = 0; e0 < ns; e0 += 64) {
+			const int rk = e0 + lane;
+			const int set = rk < ns && ((L.bm[rk >> 6] >> (rk & 63)) & 1);
+			const int id = set ? L.ids[rk] : 0;
+			const int w = set ? (int)L.a8[id] : 0;
+			const int keep = set && w >= opt.min_chain_weight;
+			const unsigned long long bal = wv_ballot(keep);
+			ssg_wave_ldssync();
+			if (keep) L.b8[n_chn + wv_rank_of(bal)] = (int64_t)w << 32 | id;
+			n_chn += __popcll(bal);
+		}
+	} else
 	for (int e0 = 0; e0 < nc; e0 += 64) {
 		const int sl = e0 + lane;
 		const int id = sl < nc ? L.ids[sl] : 0;
@@ -211,7 +300,7 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 			ssg_wave_ldssync();
 		}
 		const unsigned long long ph_t5 = ssg_clock();
-		if (SSG_TUNING && lane == 0 && CAP >= 2048) { atomicAdd(&ssg_dbg_cyc[8], ph_t1 - ph_t0); atomicAdd(&ssg_dbg_cyc[9], ph_t2 - ph_t1); atomicAdd(&ssg_dbg_cyc[10], ph_t4 - ph_t3); atomicAdd(&ssg_dbg_cyc[11], ph_t5 - ph_t4); atomicAdd(&ssg_dbg_cyc[12], 1ull); atomicAdd(&ssg_dbg_cyc[13], (unsigned long long)ns); atomicAdd(&ssg_dbg_cyc[14], (unsigned long long)nc); }
+		if (SSG_TUNING && lane == 0 && CAPS >= 2048) { atomicAdd(&ssg_dbg_cyc[8], ph_t1 - ph_t0); atomicAdd(&ssg_dbg_cyc[9], ph_t2 - ph_t1); atomicAdd(&ssg_dbg_cyc[10], ph_t4 - ph_t3); atomicAdd(&ssg_dbg_cyc[11], ph_t5 - ph_t4); atomicAdd(&ssg_dbg_cyc[12], 1ull); atomicAdd(&ssg_dbg_cyc[13], (unsigned long long)ns); atomicAdd(&ssg_dbg_cyc[14], (unsigned long long)nc); }
 		/* ---- survivors in weight order: records, seed lists ---- */
 		int pos = 0;
 		for (int e0 = 0; e0 < n_chn; e0 += 64) {
@@ -238,21 +327,48 @@ SSG_DEVFN void wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &op
 	}
 	if (lane == 0) n_chain[r] = n_out;
 	ssg_wave_ldssync();
+	return 0;
 }
 
-/* one wavefront per workgroup; waves pull reads work_order[r_first .. r_end) from a queue */
-template <int CAP>
+/* one wavefront per workgroup; waves pull reads work_order[r_first .. r_end) from a queue.  hrank / hoff: position ranks of the
+ * seeds of the heaviest reads (work_order[0 ..)), read k's at hrank[hoff[k] ..]; NULL selects the shifting form.  A read the ranked
+ * form does not cover is redone in the shifting form when it fits (#seeds <= CAPC), else left with n_chain = -1 for the caller. */
+template <int CAPC, int CAPS>
 __global__ void __launch_bounds__(64) ssg_k_chain_wave(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int r_end,
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain,
-                            const int32_t *work_order, unsigned int *queue)
+                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* <= CAPC; smaller only in tests */)
 {
-	__shared__ ssg_chw_lds_t<CAP> L;
+	__shared__ ssg_chw_lds_t<CAPC, CAPS> L;
 	for (;;) {
 		const long k = r_first + wv_queue_pop(queue);
 		if (k >= r_end) break;
-		wv_chain_read<CAP>(ix, opt, work_order ? work_order[k] : k, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L);
+		const long r = work_order ? work_order[k] : k;
+		int rc = wv_chain_read<CAPC, CAPS>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, hrank ? hrank + hoff[k] : (const uint16_t*)0, capc_lim);
+		if (rc && seed_off[r + 1] - seed_off[r] <= (capc_lim < CAPC ? capc_lim * 16 : CAPC)) rc =   /* (the test limit splits the failed reads between both fall-backs) */ wv_chain_read<CAPC, CAPS>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, (const uint16_t*)0, CAPC);
+		if (rc && wv_lane() == 0) n_chain[r] = -1;
 	}
+}
+
+/* ---- position ranks of the seeds of the heaviest n_heavy reads (work_order[0 .. n_heavy)), for the ranked form ---- */
+__global__ void ssg_k_chw_count(int n_heavy, const int32_t *work_order, const int64_t *seed_off, int32_t *hns)
+{
+	const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (k < n_heavy) { const long r = work_order[k]; hns[k] = (int32_t)(seed_off[r + 1] - seed_off[r]); }
+}
+/* key = heavy-read index << 34 | reference position (< 2^34); value = slot of the seed in the heavy list; one workgroup per read */
+__global__ void ssg_k_chw_keys(int n_heavy, const int32_t *work_order, const int64_t *seed_off, const ssg_seed_t *seeds, const int64_t *hoff, uint64_t *key, uint32_t *val)
+{
+	const int k = (int)blockIdx.x;
+	if (k >= n_heavy) return;
+	const long r = work_order[k], s0 = seed_off[r]; const int ns = (int)(seed_off[r + 1] - s0);
+	for (int j = (int)threadIdx.x; j < ns; j += (int)blockDim.x) { key[hoff[k] + j] = (uint64_t)k << 34 | (uint64_t)seeds[s0 + j].rbeg; val[hoff[k] + j] = (uint32_t)(hoff[k] + j); }
+}
+/* after the stable sort by key: sorted place p holds seed val[p] of read key >> 34; its rank is p minus the read's first place */
+__global__ void ssg_k_chw_ranks(long n, const uint64_t *key_sorted, const uint32_t *val_sorted, const int64_t *hoff, uint16_t *hrank)
+{
+	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p < n) hrank[val_sorted[p]] = (uint16_t)(p - hoff[key_sorted[p] >> 34]);
 }
 #endif

@@ -84,7 +84,7 @@ extern std::vector<ssg_prof_rec> ssg_prof_pending;
 	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } } while (0)
 /* side streams for independent kernels that each leave most of the chip idle (few heavy work items): fork after the work
  * already queued on the default stream, launch with SSG_LAUNCH_ON(i, ...), join before anything that consumes the results */
-static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[4] = {0, 0, 0, 0}; if (!s[i]) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking); return s[i]; }
+static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (!s[i]) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking); return s[i]; }
 static inline void ssg_fork(int n) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, 0); for (int i = 0; i < n; ++i) (void)hipStreamWaitEvent(ssg_side_stream(i), e, 0); (void)hipEventDestroy(e); }
 static inline void ssg_join(int n) { for (int i = 0; i < n; ++i) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, ssg_side_stream(i)); (void)hipStreamWaitEvent(0, e, 0); (void)hipEventDestroy(e); } }
 #define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) do { if ((grid) > 0) { hipStream_t st_ = ssg_side_stream(si); \

@@ -189,8 +189,10 @@ static void prof_collect()
 	(void)hipDeviceSynchronize();
 	for (auto &r : ssg_prof_pending) {
 		float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b);
-		size_t i = 0; for (; i < prof_names.size(); ++i) if (prof_names[i] == r.name) break;
-		if (i == prof_names.size()) { prof_names.push_back(r.name); prof_ms.push_back(0); prof_cnt.push_back(0); }
+		std::string nm(r.name);
+		if (nm.size() > 2 && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);   /* template instances with two arguments are launched as (kernel<A, B>) */
+		size_t i = 0; for (; i < prof_names.size(); ++i) if (prof_names[i] == nm) break;
+		if (i == prof_names.size()) { prof_names.push_back(nm); prof_ms.push_back(0); prof_cnt.push_back(0); }
 		prof_ms[i] += ms; prof_cnt[i] += 1;
 		(void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
 	}
@@ -289,6 +291,7 @@ struct seed_stage_t {
 /* runs the SMEM kernel for all reads (cap0 per read), then re-runs overflowing reads with a
  * private large capacity and copies their lists back; on return every n_intv[r] >= 0. */
 static int dev_class_counts(const int32_t *d_key, long n, int tA, int tB, int tC, unsigned int out[5]);
+static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, long n);
 static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                     int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0, int *need_cap = 0)
 {
@@ -498,46 +501,79 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		for (int r = 0; r < n_reads; ++r) { int b = 0; while ((1 << b) <= hns[r] && b < 19) ++b; ++cnt[b]; sum[b] += hns[r]; }
 		for (int b = 0; b < 20; ++b) if (cnt[b]) fprintf(stderr, "[ssg] seeds/read < %d: %ld reads, %ld seeds\n", 1 << b, cnt[b], sum[b]);
 	}
-	{	/* d_work is heaviest first: [0,nC) beyond the LDS kernels' capacity (lane kernel), then one wave per read with 4096- / 2048- /
-		 * 1024-chain LDS state (147 / 74 / 37 KB: a 2048 block leaves room for two 1024 blocks on its CU), the light rest one lane per read */
-		/* (the LDS kernels keep contig ids in 16 bits: an index with more contigs chains every read in the lane kernel) */
-		const int T = idx->v.n_ctg > 32767 ? 1 << 30 : env_int("SSG_CHAIN_WAVE_MIN", 64), TB = idx->v.n_ctg > 32767 ? 1 << 30 : env_int("SSG_CHAIN_WAVE_BIG", 1024);
-		int g4096, g2048, gS, gTBc, gT, gB4;
-		const int Sp = 256 < (TB < 4096 ? TB : 4096) ? 256 : (TB < 4096 ? TB : 4096);   /* split of the 1024 class: up to 256 seeds -> 256-chain LDS state */
+	{	/* d_work is heaviest first.  Reads with >= T seeds chain one wave each with their state in LDS, in five size classes that run
+		 * concurrently (up to 16384 seeds / 3072 chains, 4096, 2048, 1024, 256 seeds = chains); the light rest one lane per read;
+		 * the (very few) reads beyond 16384 seeds one lane each on their own stream.  The LDS kernels keep contig ids in 16 bits: an
+		 * index with more contigs chains every read in the lane kernel.  SSG_CHAIN_WAVE_BIG = n sends every wave-class read with more
+		 * than n seeds to the 4096 class, SSG_CHAIN_CLASS16K = n reads with more than n (instead of 4096) to the 16384-seed class (tests);
+		 * SSG_CHAIN_RANKED = 0 selects the array-shifting form of the insertion (A/B, tests). */
+		const int T = idx->v.n_ctg > 32767 ? 1 << 30 : std::max(1, env_int("SSG_CHAIN_WAVE_MIN", 64));
+		const int TB = env_int("SSG_CHAIN_WAVE_BIG", 0) > 0 ? env_int("SSG_CHAIN_WAVE_BIG", 0) : 1 << 30;
+		const bool ranked = env_int("SSG_CHAIN_RANKED", 1) != 0;
+		const int cap_lim = env_int("SSG_CHAIN_CAP_TEST", 1 << 30);   /* tests: pretend the LDS holds fewer chains, to walk the fall-back paths */
+		int g[6];
 		{	/* six "greater than" counts of the seeds-per-read array in one pass */
-			ssg_thr6_t th = { { 4096, 2048, Sp, TB < 4096 ? TB : 4096, (T > 1 ? T : 1) - 1, TB > 2048 ? TB : 2048 } };
+			ssg_thr6_t th = { { 16384, env_int("SSG_CHAIN_CLASS16K", 4096), std::min(2048, TB), std::min(1024, TB), std::min(256, TB), T - 1 } };
 			dbuf<unsigned int> d_c(8); unsigned int c[6];
 			CHKA(d_c); CHK(d_c.zero());
 			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
 			CHK(d_c.down(c, 6));
-			g4096 = (int)c[0]; g2048 = (int)c[1]; gS = (int)c[2] < (int)c[4] ? (int)c[2] : (int)c[4]; gTBc = (int)c[3]; gT = (int)c[4]; gB4 = (int)c[5];
+			for (int i = 0; i < 6; ++i) g[i] = (int)std::min(c[i], c[5]);
 		}
-		const int nC = g4096;                                       /* s > 4096 */
-		const int nB4 = gB4 > g4096 ? gB4 - g4096 : 0;              /* max(TB, 2048) < s <= 4096 */
-		const int nB2 = TB < 2048 && gTBc > g2048 ? gTBc - g2048 : 0; /* TB < s <= 2048 */
-		const int nA = gS > gTBc ? gS - gTBc : 0;                   /* max(T, 257) <= s <= min(TB, 4096) */
-		const int nA1 = gT > gS ? gT - gS : 0;                      /* T <= s <= 256 */
+		const int n_heavy = g[5];
+		int nC = g[0], n16 = g[1] - g[0];
+		const int n4096 = g[2] - g[1], n2048 = g[3] - g[2], n1024 = g[4] - g[3], n256 = g[5] - g[4];
+		if (!ranked) { nC += n16; n16 = 0; }   /* the 16384-seed class exists in the ranked form only */
+		/* position ranks of the heavy reads' seeds: one stable radix sort of (read, reference position) over all of them */
+		dbuf<uint16_t> d_hrank; dbuf<int64_t> d_hoff;
+		if (ranked && n_heavy > nC) {
+			dbuf<int32_t> d_hns(n_heavy);
+			CHKA(d_hns);
+			if (!d_hoff.alloc((size_t)n_heavy + 1)) { ssg_err_msg = "device allocation failed: d_hoff"; return SSG_ENOMEM; }
+			SSG_LAUNCH(ssg_k_chw_count, (n_heavy + 255) / 256, 256, 0, n_heavy, d_work.p, o.seed_off.p, d_hns.p);
+			int64_t n_hs = 0;
+			CHK(dev_exclusive_scan(d_hns.p, d_hoff.p, n_heavy, &n_hs));
+			if (n_hs >= (1LL << 32)) { ssg_err_msg = "more than 2^32 seeds in repeat-heavy reads of one call"; return SSG_EOVERFLOW; }
+			dbuf<uint64_t> d_hk((size_t)n_hs + 1), d_hks((size_t)n_hs + 1); dbuf<uint32_t> d_hv((size_t)n_hs + 1), d_hvs((size_t)n_hs + 1);
+			CHKA(d_hk); CHKA(d_hks); CHKA(d_hv); CHKA(d_hvs);
+			if (!d_hrank.alloc((size_t)n_hs + 1)) { ssg_err_msg = "device allocation failed: d_hrank"; return SSG_ENOMEM; }
+			SSG_LAUNCH(ssg_k_chw_keys, n_heavy, 64, 0, n_heavy, d_work.p, o.seed_off.p, d_seeds.p, d_hoff.p, d_hk.p, d_hv.p);
+			CHK(sort_pairs_u64(d_hk.p, d_hks.p, d_hv.p, d_hvs.p, (long)n_hs));
+			SSG_LAUNCH(ssg_k_chw_ranks, (n_hs + 255) / 256, 256, 0, (long)n_hs, d_hks.p, d_hvs.p, d_hoff.p, d_hrank.p);
+			CHK(rt_sync());
+		}
+		const uint16_t *hr = ranked ? d_hrank.p : (const uint16_t*)0; const int64_t *ho = ranked ? d_hoff.p : (const int64_t*)0;
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
-		if (nC) SSG_LAUNCH(ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+		/* the classes are independent and each of the heavy ones fills a fraction of the chip: overlap them */
+		ssg_fork(6);
+		if (nC) SSG_LAUNCH_ON(4, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		/* the classes are independent and each wave kernel fills a fraction of the chip: overlap them */
-		ssg_fork(4);
 		int r0 = nC;
-		if (nB4) SSG_LAUNCH_ON(0, ssg_k_chain_wave<4096>, std::min(nB4, 256), 64, 0, idx->v, *opt, r0, r0 + nB4, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
-		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 1);
-		r0 += nB4;
-		if (nB2) SSG_LAUNCH_ON(1, ssg_k_chain_wave<2048>, std::min(nB2, 512), 64, 0, idx->v, *opt, r0, r0 + nB2, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
-		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 3);
-		r0 += nB2;
-		if (nA) SSG_LAUNCH_ON(2, ssg_k_chain_wave<1024>, std::min(nA, 1280), 64, 0, idx->v, *opt, r0, r0 + nA, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
-		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 2);
-		r0 += nA;
-		if (nA1) SSG_LAUNCH_ON(3, ssg_k_chain_wave<256>, std::min(nA1, 5120), 64, 0, idx->v, *opt, r0, r0 + nA1, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p,
-		                   d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + 4);
-		r0 += nA1;
+#define SSG_CHW_LAUNCH(si, CC, CS, cnt, maxwg, qi) do { if (cnt) SSG_LAUNCH_ON(si, (ssg_k_chain_wave<CC, CS>), std::min((int)(cnt), (int)(maxwg)), 64, 0, idx->v, *opt, r0, r0 + (cnt), d_off, d_intv.p, d_nintv.p, cap, \
+		o.seed_off.p, d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + (qi), hr, ho, std::min((int)(CC), cap_lim)); r0 += (cnt); } while (0)
+		SSG_CHW_LAUNCH(5, 3072, 16384, n16, 256, 5);
+		SSG_CHW_LAUNCH(0, 4096, 4096, n4096, 256, 1);
+		SSG_CHW_LAUNCH(1, 2048, 2048, n2048, 512, 3);
+		SSG_CHW_LAUNCH(2, 1024, 1024, n1024, 1280, 2);
+		SSG_CHW_LAUNCH(3, 256, 256, n256, 5120, 4);
+#undef SSG_CHW_LAUNCH
 		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		ssg_join(4);
+		ssg_join(6);
+		if (n16) {   /* reads of the 16384-seed class that made more than 3072 chains (or three chains at one position): one lane each */
+			unsigned int cc[5];
+			CHK(dev_class_counts(d_nchain.p, n_reads, 0, 0, 0, cc));
+			if (cc[3]) {
+				std::vector<int32_t> hn(n_reads), redo;
+				CHK(d_nchain.down(hn.data(), n_reads));
+				for (int r = 0; r < n_reads; ++r) if (hn[r] < 0) redo.push_back(r);
+				dbuf<int32_t> d_redo(redo.size());
+				CHKA(d_redo); CHK(d_redo.up(redo.data(), redo.size()));
+				SSG_LAUNCH(ssg_k_chain, ((int)redo.size() + 63) / 64, 64, 0, idx->v, *opt, 0, (int)redo.size(), d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+				           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_redo.p);
+				CHK(rt_sync());
+			}
+		}
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
