@@ -513,12 +513,14 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int cap_lim = env_int("SSG_CHAIN_CAP_TEST", 1 << 30);   /* tests: pretend the LDS holds fewer chains, to walk the fall-back paths */
 		int g[6];
 		{	/* six "greater than" counts of the seeds-per-read array in one pass */
-			ssg_thr6_t th = { { 16384, env_int("SSG_CHAIN_CLASS16K", 4096), std::min(2048, TB), std::min(1024, TB), std::min(256, TB), T - 1 } };
+			const int t16 = std::min(16384, std::max(1, env_int("SSG_CHAIN_CLASS16K", 4096)));
+			ssg_thr6_t th = { { 16384, t16, std::min(std::min(2048, TB), t16), std::min(std::min(1024, TB), t16), std::min(std::min(256, TB), t16), T - 1 } };   /* descending: the counts ascend */
 			dbuf<unsigned int> d_c(8); unsigned int c[6];
 			CHKA(d_c); CHK(d_c.zero());
 			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
 			CHK(d_c.down(c, 6));
 			for (int i = 0; i < 6; ++i) g[i] = (int)std::min(c[i], c[5]);
+			for (int i = 1; i < 6; ++i) g[i] = std::max(g[i], g[i - 1]);
 		}
 		const int n_heavy = g[5];
 		int nC = g[0], n16 = g[1] - g[0];
