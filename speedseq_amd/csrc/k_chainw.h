@@ -17,15 +17,14 @@
  *     norm for repeats, and the unstable tie order selects what is kept) on packed keys in LDS;
  *   - the filter tests chain i against 64 kept chains at a time: ballot of the `break' condition,
  *     side effects applied only to the kept chains up to the first break, exactly as the scalar loop.
- * Per-chain LDS footprint is 27 bytes + 4.1 per seed; 256 / 1024 / 2048 / 4096 chains = seeds run 20 / 5 / 2 / 1 reads per CU, and
- * reads of up to 16384 seeds fit with 3072 chains (the few that make more fall back to the lane kernel).
+ * LDS footprint: 31.1 bytes per seed (27 per chain + 4.1 per seed, chains <= seeds); 256 / 1024 / 2048 / 5120 seeds run 20 / 5 / 2 / 1
+ * reads per CU.
  */
 #ifndef SSG_K_CHAINW_H
 #define SSG_K_CHAINW_H
 #include "k_chain.h"
 
-/* CAPC chains, CAPS seeds (CAPS >= CAPC) */
-template <int CAPC, int CAPS> struct ssg_chw_lds_t {
+template <int CAPC, int CAPS = CAPC> struct ssg_chw_lds_t {   /* CAPC chains, CAPS seeds: the kernels use CAPS = CAPC, so a read that fits can always fall back to the shifting form */
 	int64_t a8[CAPC];   /* insertion: rbeg of the chain's last seed [chain id] | weights [chain id] | filter: kept w<<32 | kept sorted idx<<16 | first shadowed */
 	int64_t b8[CAPC];   /* insertion: chain position [chain id] (shifting form: positions, sorted [slot]) | sort/filter: w<<32 | chain id, sorted by w */
 	int16_t rid[CAPC];  /* insertion: contig of the chain [chain id] (< 32768 contigs: host-checked) | filter: kept state [sorted idx] */
@@ -83,6 +82,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 	const float frac_rep = (float)l_rep / len_read;
 	ssg_wave_ldssync();
 	const unsigned long long ph_t0 = ssg_clock();
+	int fail = 0;   /* wave-uniform (scalar): set when the ranked form gives the read up; everything after the insertion is skipped then */
 	/* ---- greedy chaining in seed-visiting order ---- */
 	if (rank) {
 		/* The set of chains is a bitmap over position ranks (the universe of possible chain positions is the read's own seeds, ranked
@@ -91,7 +91,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		for (i = lane; i < (ns + 63) / 64; i += 64) L.bm[i] = 0;
 		for (i = lane; i < ((ns + 63) / 64 + 63) / 64; i += 64) L.bms[i] = 0;
 		ssg_wave_ldssync();
-		for (int i0 = 0; i0 < ns; i0 += 64) {
+		for (int i0 = 0; i0 < ns && !fail; i0 += 64) {
 			const int me = i0 + lane;
 			int64_t my_rbeg = 0; int my_q = 0, my_len = 0, my_rid = -1, my_rk = 0;
 			if (me < ns) { const ssg_seed_t sdd = sd[me]; my_rbeg = sdd.rbeg; my_q = sdd.qbeg; my_len = sdd.len; my_rid = srid[me]; my_rk = rank[me]; }
@@ -124,8 +124,10 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 						ssg_wave_ldssync();
 					}
 				}
+				/* not covered here: the caller redoes the read.  (Decided on a scalar, outside the lane-conditional regions, so that the exit out of
+				 * both loops is a plain scalar branch.) */
+				if (wv_get((res == 0 && (two_equal || nc >= capc_lim)) ? 1 : 0, 0)) { fail = 1; break; }
 				if (res == 0) { /* new chain; its place in position order is its seed's rank */
-					if (two_equal || nc >= capc_lim) return -1;
 					ssg_wave_ldssync();
 					if (lane == 0) {
 						L.bm[rk >> 6] |= 1ull << (rk & 63); L.bms[rk >> 12] |= 1ull << ((rk >> 6) & 63);
@@ -200,6 +202,8 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			}
 		}
 	}
+	int n_out = 0;
+	if (!fail) {
 	/* ---- upstream mem_chain_weight: one lane per chain ---- */
 	const unsigned long long ph_t1 = ssg_clock();
 	ssg_wave_ldssync();
@@ -244,7 +248,6 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		n_chn += __popcll(bal);
 	}
 	ssg_wave_ldssync();
-	int n_out = 0;
 	if (n_chn > 0) {
 		/* ---- upstream mem_chain_flt ---- */
 		const unsigned long long ph_t3 = ssg_clock();
@@ -326,28 +329,29 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		}
 	}
 	if (lane == 0) n_chain[r] = n_out;
+	}
 	ssg_wave_ldssync();
-	return 0;
+	return -fail;
 }
 
 /* one wavefront per workgroup; waves pull reads work_order[r_first .. r_end) from a queue.  hrank / hoff: position ranks of the
  * seeds of the heaviest reads (work_order[0 ..)), read k's at hrank[hoff[k] ..]; NULL selects the shifting form.  A read the ranked
- * form does not cover is redone in the shifting form when it fits (#seeds <= CAPC), else left with n_chain = -1 for the caller. */
-template <int CAPC, int CAPS>
+ * form gives up (a third chain at one position; capc_lim in the tests) is redone in the shifting form, which covers everything. */
+template <int CAP>
 __global__ void __launch_bounds__(64) ssg_k_chain_wave(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int r_end,
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain,
-                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* <= CAPC; smaller only in tests */)
+                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */)
 {
-	__shared__ ssg_chw_lds_t<CAPC, CAPS> L;
+	__shared__ ssg_chw_lds_t<CAP, CAP> L;
 	for (;;) {
 		const long k = r_first + wv_queue_pop(queue);
 		if (k >= r_end) break;
 		const long r = work_order ? work_order[k] : k;
-		int rc = wv_chain_read<CAPC, CAPS>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, hrank ? hrank + hoff[k] : (const uint16_t*)0, capc_lim);
-		if (rc && seed_off[r + 1] - seed_off[r] <= (capc_lim < CAPC ? capc_lim * 16 : CAPC)) rc =   /* (the test limit splits the failed reads between both fall-backs) */ wv_chain_read<CAPC, CAPS>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, (const uint16_t*)0, CAPC);
-		if (rc && wv_lane() == 0) n_chain[r] = -1;
+		int rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, hrank ? hrank + hoff[k] : (const uint16_t*)0, capc_lim);
+		rc = wv_get(rc, 0);
+		if (rc) rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, (const uint16_t*)0, CAP);
 	}
 }
 

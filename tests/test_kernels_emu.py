@@ -73,12 +73,9 @@ def test_emu_repeats_align1(emu_lib, oracle, repeat_prefix, monkeypatch):
     monkeypatch.setenv("SSG_CHAIN_RANKED", "0")         # the array-shifting insertion instead of the position-rank bitmap
     common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix)
     monkeypatch.delenv("SSG_CHAIN_RANKED")
-    monkeypatch.delenv("SSG_CHAIN_WAVE_BIG")
-    monkeypatch.setenv("SSG_CHAIN_CLASS16K", "150")     # the 16384-seed / 3072-chain class for every read above 150 seeds
+    monkeypatch.setenv("SSG_CHAIN_CAP_TEST", "40")      # the ranked form gives up at 40 chains: its fall-back, the shifting form, redoes those reads
     common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix)
-    monkeypatch.setenv("SSG_CHAIN_CAP_TEST", "40")      # ... with room for 40 chains only: the fall-backs (shifting form, lane kernel)
-    common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix)
-    monkeypatch.delenv("SSG_CHAIN_CAP_TEST"); monkeypatch.delenv("SSG_CHAIN_CLASS16K")
+    monkeypatch.delenv("SSG_CHAIN_CAP_TEST")
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "100000")  # and the lane-per-read kernel on the same reads
     monkeypatch.setenv("SSG_CHAIN_WAVE_BIG", "100000")
     assert common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix) > 500
