@@ -250,10 +250,27 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 				const uint8_t *q = seq + off[r];
 				len = (int)(off[r+1] - off[r]);
 				mem = out_intv + (long)it * cap; mem_n = 0; ovf = 0;
-				for (int w = 0; w * 8 < len; ++w) { /* all 4 lanes write the same words: no cross-lane hand-off needed */
-					uint32_t v = 0;
-					for (int b = 0; b < 8 && w * 8 + b < len; ++b) v |= (uint32_t)(q[w * 8 + b] & 15) << (b << 2);
-					qlds[w * RPW + Q] = v;
+				{	/* the read as 4-bit codes, 8 per LDS word (all lanes of a quad write the same words: no cross-lane hand-off needed).
+					 * Fetched as aligned 8-byte words, four LDS words per round trip: this runs with one lane of the wave active. */
+					const unsigned al = (unsigned)((uintptr_t)q & 7), sh8 = al << 3;
+					const uint64_t *const qa = (const uint64_t*)(q - al);
+					const int nw = (len + 7) >> 3, nb = (int)al + len;   /* nb: bytes from qa to the read's end */
+					for (int w0 = 0; w0 < nw; w0 += 4) {
+						uint64_t t[5];
+						SSG_UNROLL for (int jj = 0; jj < 5; ++jj) t[jj] = (w0 + jj) * 8 < nb ? qa[w0 + jj] : 0;
+						SSG_UNROLL for (int jj = 0; jj < 4; ++jj) {
+							const int w = w0 + jj;
+							if (w >= nw) break;
+							uint64_t v = sh8 ? (t[jj] >> sh8) | (t[jj + 1] << (64 - sh8)) : t[jj];
+							v &= 0x0f0f0f0f0f0f0f0full;
+							v = (v | v >> 4) & 0x00ff00ff00ff00ffull;
+							v = (v | v >> 8) & 0x0000ffff0000ffffull;
+							uint32_t v32 = (uint32_t)(v | v >> 16);
+							const int nv = len - w * 8;
+							if (nv < 8) v32 &= (1u << (nv << 2)) - 1u;
+							qlds[w * RPW + Q] = v32;
+						}
+					}
 				}
 				x = 0;
 				state = len >= opt.min_seed_len ? SM_P1 : SM_OUT;

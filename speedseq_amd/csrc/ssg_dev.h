@@ -303,42 +303,69 @@ SSG_DEVFN ssg_intv_t ssg_bwt_extend1_quad(const ssg_index_view_t &ix, const ssg_
 /* ssg_bwt_extend1 that fetches only the quarters of each rank block the followed base needs.  With T = k + 1 symbols up to and
  * including stored position k, sum over b > c of occ_b equals T - occ_0 (c = 0), T - occ_0 - occ_1 (c = 1), occ_3 (c = 2), 0 (c = 3):
  * at most two of the four running counts -- one 16-byte quarter -- and two popcount passes instead of four; of the symbol words
- * only those below the position: the third quarter, and the fourth only past the block's middle.  2.5 loads per block on average
- * instead of 4: on a multi-GB table the per-lane fetch is bound by address translations per load instruction, not by bytes. */
-SSG_DEVFN void ssg_occ_lean(const ssg_index_view_t &ix, uint64_t k, int c, uint64_t &occ_c, uint64_t &occ_gt)
+ * only those below the position: the third quarter, and the fourth only past the block's middle.
+ * Both rank queries of an extension are issued together (one memory round trip), and when they fall into the same block -- the
+ * rule once the interval is narrower than 128 rows, i.e. for most of a read -- the block is fetched once (upstream bwt_2occ4 has the
+ * same special case for its cache).  On a multi-GB table the per-lane fetch is bound by the number of distinct lines and of load
+ * instructions in flight, not by bytes. */
+struct alignas(16) ssg_q16_t { uint32_t v[4]; };
+/* among the first r (1..128) symbols of the block's 8 words: na = #symbols == (c & 2), nb = #symbols == (c & 2) + 1.
+ * `hs': even bits set where the symbol's high bit matches, shifted so that only the first r symbols remain (a word wholly above r
+ * is shifted by 31: bit 31 of the even-bit mask is never set). */
+SSG_DEVFN void ssg_cnt_pair(const ssg_q16_t &w0, const ssg_q16_t &w1, int r, int c, int &na, int &nb)
 {
-	if (k == (uint64_t)-1) { occ_c = 0; occ_gt = 0; return; }
-	k -= (k >= ix.primary);
-	struct alignas(16) q16 { uint32_t v[4]; };
-	const q16 *pb = (const q16*)(ix.bwt + ((k >> 7) << 4));
-	const int r = (int)(k & 127) + 1;
-	const q16 cq = pb[c >> 1];                       /* counts of bases (0,1) or (2,3) */
-	const q16 w0 = pb[2];
-	q16 w1; w1.v[0] = w1.v[1] = w1.v[2] = w1.v[3] = 0;
-	if (r > 64) w1 = pb[3];
 	const uint32_t w[8] = { w0.v[0], w0.v[1], w0.v[2], w0.v[3], w1.v[0], w1.v[1], w1.v[2], w1.v[3] };
-	uint32_t mk[8];
-	SSG_UNROLL for (int i = 0; i < 8; ++i) { int ns = r - i * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns; mk[i] = ns == 16 ? 0x55555555u : ns ? (~((1u << ((16 - ns) << 1)) - 1)) & 0x55555555u : 0u; }
-	const int ba = c & 2, bb = ba + 1;               /* the two bases whose counts were fetched */
-	int na = 0, nb = 0;
+	const uint32_t hc = (c & 2) ? 0u : 0xffffffffu;
+	const int r2 = r << 1;
+	int nt = 0, n1 = 0;
 	SSG_UNROLL for (int i = 0; i < 8; ++i) {
-		const uint32_t xa = ~(w[i] ^ ((uint32_t)ba * 0x55555555u)), xb = ~(w[i] ^ ((uint32_t)bb * 0x55555555u));
-		na += __popc(xa & (xa >> 1) & mk[i]); nb += __popc(xb & (xb >> 1) & mk[i]);
+		int sh = 32 * (i + 1) - r2; sh = sh < 0 ? 0 : sh > 31 ? 31 : sh;
+		const uint32_t hs = (((w[i] >> 1) ^ hc) & 0x55555555u) >> sh;
+		nt += __popc(hs); n1 += __popc(hs & (w[i] >> sh));
 	}
-	const uint64_t oa = ((uint64_t)cq.v[0] | (uint64_t)cq.v[1] << 32) + (uint64_t)na, ob = ((uint64_t)cq.v[2] | (uint64_t)cq.v[3] << 32) + (uint64_t)nb;
-	const uint64_t T = k + 1;
-	occ_c = (c & 1) ? ob : oa;
-	occ_gt = c == 0 ? T - oa : c == 1 ? T - oa - ob : c == 2 ? ob : 0;
+	na = nt - n1; nb = n1;
 }
 SSG_DEVFN ssg_intv_t ssg_bwt_extend1_lean(const ssg_index_view_t &ix, const ssg_intv_t &ik, int c, int is_back)
 {
 	const uint64_t kx = is_back ? ik.x0 : ik.x1, ox = is_back ? ik.x1 : ik.x0;
-	uint64_t tkc, tkg, tlc, tlg;
-	ssg_occ_lean(ix, kx - 1, c, tkc, tkg);
-	ssg_occ_lean(ix, kx - 1 + ik.x2, c, tlc, tlg);
+	const uint64_t k = kx - 1, l = k + ik.x2;
+	const bool kneg = k == (uint64_t)-1, lneg = l == (uint64_t)-1;
+	const uint64_t k2 = kneg ? 0 : k - (k >= ix.primary), l2 = lneg ? 0 : l - (l >= ix.primary);   /* k2 <= l2 */
+	const ssg_q16_t *const pk = (const ssg_q16_t*)(ix.bwt + ((k2 >> 7) << 4)), *const pl = (const ssg_q16_t*)(ix.bwt + ((l2 >> 7) << 4));
+	const int rk = (int)(k2 & 127) + 1, rl = (int)(l2 & 127) + 1;
+	const bool same = (k2 >> 7) == (l2 >> 7);
+	ssg_q16_t z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0;
+	/* all loads first: the upper query's block, then (other block only) the lower query's */
+	const ssg_q16_t cql = pl[c >> 1], w0l = pl[2];
+	ssg_q16_t w1l = z;
+	if (rl > 64) w1l = pl[3];
+	ssg_q16_t cqk = z, w0k = z, w1k = z;
+	if (!same) { cqk = pk[c >> 1]; w0k = pk[2]; if (rk > 64) w1k = pk[3]; }
+	/* same block: rk <= rl, so the fourth quarter is there whenever rk needs it (selected after the loads are out: a register copy
+	 * of the upper block here would wait for it before the lower block's loads are issued) */
+	uint32_t sm = same ? 0xffffffffu : 0u;            /* (x_l & sm) | x_k with x_k = 0 where nothing was loaded; opaque to the optimizer */
+#ifndef SSG_EMU
+	asm("" : "+v"(sm));
+#endif
+	SSG_UNROLL for (int i = 0; i < 4; ++i) { cqk.v[i] |= cql.v[i] & sm; w0k.v[i] |= w0l.v[i] & sm; w1k.v[i] |= w1l.v[i] & sm; }
+	int nak, nbk, nal, nbl;
+	ssg_cnt_pair(w0k, w1k, rk, c, nak, nbk);
+	ssg_cnt_pair(w0l, w1l, rl, c, nal, nbl);
+	const uint64_t oak = ((uint64_t)cqk.v[0] | (uint64_t)cqk.v[1] << 32) + (uint64_t)nak, obk = ((uint64_t)cqk.v[2] | (uint64_t)cqk.v[3] << 32) + (uint64_t)nbk;
+	const uint64_t oal = ((uint64_t)cql.v[0] | (uint64_t)cql.v[1] << 32) + (uint64_t)nal, obl = ((uint64_t)cql.v[2] | (uint64_t)cql.v[3] << 32) + (uint64_t)nbl;
+	const uint64_t Tk = k2 + 1, Tl = l2 + 1;
+	uint64_t tkc = (c & 1) ? obk : oak, tkg = c == 0 ? Tk - oak : c == 1 ? Tk - oak - obk : c == 2 ? obk : 0;
+	uint64_t tlc = (c & 1) ? obl : oal, tlg = c == 0 ? Tl - oal : c == 1 ? Tl - oal - obl : c == 2 ? obl : 0;
+	if (kneg) tkc = tkg = 0;
+	if (lneg) tlc = tlg = 0;
 	const uint64_t no = ox + (kx <= ix.primary && kx + ik.x2 - 1 >= ix.primary) + (tlg - tkg);
-	uint64_t l2c = ix.L2[0];
-	SSG_UNROLL for (int bi = 1; bi < 4; ++bi) if (bi == c) l2c = ix.L2[bi];
+	/* L2[c] by selects over scalars (left to itself the compiler makes it a per-lane load from the kernel-argument segment: a
+	 * dependent memory round trip per extension) */
+	uint64_t L0 = ix.L2[0], L1 = ix.L2[1], L2v = ix.L2[2], L3 = ix.L2[3];
+#ifndef SSG_EMU
+	asm("" : "+s"(L0)); asm("" : "+s"(L1)); asm("" : "+s"(L2v)); asm("" : "+s"(L3));
+#endif
+	const uint64_t l2c = c == 0 ? L0 : c == 1 ? L1 : c == 2 ? L2v : L3;
 	ssg_intv_t o;
 	const uint64_t nk = l2c + 1 + tkc;
 	o.x2 = tlc - tkc; o.info = 0;
