@@ -125,9 +125,18 @@ SSG_DEVFN int ssg_tgt_next(ssg_tgt_t &t)
 	return t.comp ? 3 - base : base;
 }
 
-#define SSG_XL_Q(wd)  ((int)((wd) >> 29))
-#define SSG_XL_E(wd)  ((int)(((wd) >> 16) & 0x1fff))
-#define SSG_XL_H(wd)  ((int)((wd) & 0xffff))
+/* LDS word of a column: h:13 | e:13 | 6 x query code:6 (DP values stay below 8191: checked on the host).  The query field is the
+ * bit offset of the column's score in the row's score table T (five signed 6-bit fields, rebuilt per target base). */
+#define SSG_XL_QS(wd) ((unsigned)((wd) >> 26))
+#define SSG_XL_E(wd)  ((int)(((wd) >> 13) & 0x1fff))
+#define SSG_XL_H(wd)  ((int)((wd) & 0x1fff))
+#define SSG_XL_QMASK  0xfc000000u
+#define SSG_XL_QWORD(code) ((uint32_t)((code) * 6) << 26)
+#ifdef SSG_EMU
+SSG_DEVFN int ssg_sbfe6(uint32_t t, unsigned off) { return (int)(t << (26 - off)) >> 26; }
+#else
+SSG_DEVFN int ssg_sbfe6(uint32_t t, unsigned off) { return __builtin_amdgcn_sbfe((int)t, off, 6u); }
+#endif
 
 /* upstream ksw_extend2, one lane; Lc[j*64] is this lane's column j (query codes already in bits 29..31) */
 SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_view_t &ix, uint32_t *Lc, int qlen, int tlen, int64_t p0, int dir,
@@ -145,7 +154,7 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 			else if (j == 1) h = h0 > oe_ins ? h0 - oe_ins : 0;
 			else h = prev > e_ins ? prev - e_ins : 0;
 			prev = h;
-			Lc[j * 64] = (Lc[j * 64] & 0xe0000000u) | (uint32_t)h;
+			Lc[j * 64] = (Lc[j * 64] & SSG_XL_QMASK) | (uint32_t)h;
 		}
 	}
 	{	/* band clamp */
@@ -162,9 +171,13 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 	unsigned long long ncell = 0;
 	ssg_tgt_t tg;
 	ssg_tgt_init(tg, ix, p0, dir);
+	/* score table of a row: field q (bits 6q..6q+5) = score of query code q against the row's target base */
+	uint32_t t_mis = (uint32_t)(-1 & 63) << 24;
+	for (int q = 0; q < 4; ++q) t_mis |= (uint32_t)(-sb & 63) << (6 * q);
 	for (i = 0; i < tlen; ++i) {
 		int f = 0, h1, mm = 0, mj = -1;
 		const int tb = ssg_tgt_next(tg);
+		const uint32_t T = (t_mis & ~(63u << (6 * tb))) | (uint32_t)(sa & 63) << (6 * tb);
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
@@ -172,28 +185,34 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 		else h1 = 0;
 		if (end > beg) {
 			ncell += (unsigned long long)(end - beg);
-			uint32_t wd = Lc[beg * 64];
-			for (j = beg; j < end; ++j) {
-				const uint32_t wn = Lc[(j + 1) * 64];    /* next column in flight while this one is computed */
-				const int q = SSG_XL_Q(wd);
+			int mk = -1;                                 /* max over the row of (h << 8 | j): the largest h, at its last column */
+			auto cell = [&](const uint32_t wd, const int jj) -> uint32_t {
 				int M = SSG_XL_H(wd), e = SSG_XL_E(wd), h, t;
-				const int sc = q > 3 ? -1 : (q == tb ? sa : -sb);
+				const int sc = ssg_sbfe6(T, SSG_XL_QS(wd));
 				M = M ? M + sc : 0;
 				h = M > e ? M : e;
 				h = h > f ? h : f;
-				mj = mm > h ? mj : j;
-				mm = mm > h ? mm : h;
+				{ const int k = h << 8 | jj; mk = mk > k ? mk : k; }
 				t = M - oe_del; t = t > 0 ? t : 0;
 				e -= e_del; e = e > t ? e : t;
-				Lc[j * 64] = (wd & 0xe0000000u) | ((uint32_t)e << 16) | (uint32_t)h1;
+				const uint32_t out = (wd & SSG_XL_QMASK) | ((uint32_t)e << 13) | (uint32_t)h1;
 				h1 = h;
 				t = M - oe_ins; t = t > 0 ? t : 0;
 				f -= e_ins; f = f > t ? f : t;
-				wd = wn;
+				return out;
+			};
+			/* two columns per trip, the next two in flight meanwhile (the long class runs one wave per SIMD: nothing else hides LDS latency) */
+			uint32_t w0 = Lc[beg * 64], w1 = Lc[(beg + 1) * 64];
+			for (j = beg; j < end; j += 2) {
+				const uint32_t n0 = Lc[(j + 2) * 64], n1 = Lc[(j + 3) * 64];
+				Lc[j * 64] = cell(w0, j);
+				if (j + 1 < end) Lc[(j + 1) * 64] = cell(w1, j + 1);
+				w0 = n0; w1 = n1;
 			}
+			mm = mk >> 8; mj = mk & 255;                 /* end > beg: at least one column */
 			j = end;
 		} else j = beg;
-		Lc[end * 64] = (Lc[end * 64] & 0xe0000000u) | (uint32_t)h1;
+		Lc[end * 64] = (Lc[end * 64] & SSG_XL_QMASK) | (uint32_t)h1;
 		if (j == qlen) {
 			max_ie = gscore > h1 ? max_ie : i;
 			gscore = gscore > h1 ? gscore : h1;
@@ -206,9 +225,9 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 			if (i - max_i > mj - max_j) { if (max - mm - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
 			else { if (max - mm - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
 		}
-		for (j = beg; j < end && (Lc[j * 64] & 0x1fffffffu) == 0; ++j);
+		for (j = beg; j < end && (Lc[j * 64] & ~SSG_XL_QMASK) == 0; ++j);
 		beg = j;
-		for (j = end; j >= beg && (Lc[j * 64] & 0x1fffffffu) == 0; --j);
+		for (j = end; j >= beg && (Lc[j * 64] & ~SSG_XL_QMASK) == 0; --j);
 		end = j + 2 < qlen ? j + 2 : qlen;
 	}
 	if (cells) *cells += ncell;
@@ -225,7 +244,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
                                const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
                                unsigned long long *cells)
 {
-	__shared__ uint32_t L[(QCAP + 1) * 64];
+	__shared__ uint32_t L[(QCAP + 4) * 64];   /* columns 0..qlen, and the three the cell loop may read ahead */
 	const long t = job_first + (long)blockIdx.x * 64 + threadIdx.x;
 	if (t >= n_jobs) return;
 	const uint64_t key = sorted[t];
@@ -241,7 +260,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 	if (side == 0) {
 		const int qlen = jb.qbeg;
 		if (qlen <= 0 || qlen > QCAP) return;
-		for (int j = 0; j < qlen; ++j) Lc[j * 64] = (uint32_t)query[jb.qbeg - 1 - j] << 29;
+		for (int j = 0; j < qlen; ++j) Lc[j * 64] = SSG_XL_QWORD(query[jb.qbeg - 1 - j]);
 		Lc[qlen * 64] = 0;
 		const int tlen = (int)(jb.rbeg - jb.rmax0);
 		for (int i = 0; i < SSG_XL_BAND_TRY; ++i) {
@@ -257,7 +276,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 		const int qe = jb.qbeg + jb.len, qlen = jb.l_query - qe;
 		if (qlen <= 0 || qlen > QCAP) return;
 		const int sc0 = jb.qbeg ? res_l[g].score : jb.len * opt.a;
-		for (int j = 0; j < qlen; ++j) Lc[j * 64] = (uint32_t)query[qe + j] << 29;
+		for (int j = 0; j < qlen; ++j) Lc[j * 64] = SSG_XL_QWORD(query[qe + j]);
 		Lc[qlen * 64] = 0;
 		const int tlen = (int)(jb.rmax1 - (jb.rbeg + jb.len));
 		score = sc0;

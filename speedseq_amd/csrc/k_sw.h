@@ -310,20 +310,29 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 	int H[NS], E[NS], HM[NS], qc[NS];
 	int gmax = 0, te = -1, n_b = 0, last_sc = 0, last_row = -2;
 	const int maxsc = sa > 0 ? sa : 0;
-	SSG_UNROLL for (int s = 0; s < NS; ++s) { const int j = lane * NS + s; qc[s] = j < qlen ? sq_at(query, j) : 5; H[s] = E[s] = HM[s] = 0; }
+	/* per column, in registers: the substitution score against a target base equal to / different from / N (ssg_sc's cases), and the
+	 * column's constants of the F recurrence (an inactive padded column gets g = -inf through its constant) */
+	int sce[NS], scd[NS], scn[NS], cg[NS], cf[NS];
+	SSG_UNROLL for (int s = 0; s < NS; ++s) {
+		const int j = lane * NS + s;
+		qc[s] = j < qlen ? sq_at(query, j) : 5; H[s] = E[s] = HM[s] = 0;
+		sce[s] = ssg_sc(sa, sb, qc[s] < 4 ? qc[s] : 0, qc[s]); scd[s] = ssg_sc(sa, sb, qc[s] < 4 ? qc[s] ^ 1 : 0, qc[s]); scn[s] = ssg_sc(sa, sb, 4, qc[s]);
+		cg[s] = j < qp ? j * e_ins - oe_ins : SSG_NEG;
+		cf[s] = (j - 1) * e_ins;
+	}
 	int i, tb = tlen > 0 ? sq_at(target, 0) : 0;
 	for (i = 0; i < tlen; ++i) {
 		const int tb_next = i + 1 < tlen ? sq_at(target, i + 1) : 0;
 		int hn[NS], p[NS], hrow[NS];
 		const int up = wv_prev(H[NS-1], 0);          /* H(i-1, j-1) for the lane's first column */
+		const bool tn = tb > 3;
 		SSG_UNROLL for (int s = 0; s < NS; ++s) {
-			const int j = lane * NS + s;
-			const bool act = j < qp;
-			int v = (s ? H[s-1] : up) + ssg_sc(sa, sb, tb, qc[s]);
+			const int sc = tn ? scn[s] : qc[s] == tb ? sce[s] : scd[s];
+			int v = (s ? H[s-1] : up) + sc;
 			const int e = E[s];
 			v = v > e ? v : e; v = v > 0 ? v : 0;
 			hn[s] = v;
-			const int g = act ? (v - oe_ins) + j * e_ins : SSG_NEG;
+			const int g = v + cg[s];
 			p[s] = s ? (p[s-1] > g ? p[s-1] : g) : g;
 		}
 		const int X = wv_prev(wv_scan_max(p[NS-1]), SSG_NEG);
@@ -332,14 +341,18 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 			const int j = lane * NS + s;
 			const bool act = j < qp;
 			const int Pm1 = s ? (X > p[s-1] ? X : p[s-1]) : X;
-			int f = j == 0 ? 0 : Pm1 - (j - 1) * e_ins; f = f > 0 ? f : 0;
+			/* F = max(Pm1 - (j-1) e_ins, 0) (column 0: -inf from X); hn >= 0 already, so h = max(hn, F) needs no clamp of F */
+			const int f = Pm1 - cf[s];
 			const int h = hn[s] > f ? hn[s] : f;
 			hrow[s] = act ? h : 0;
-			int e = E[s] - e_del; { const int t = h - oe_del; e = e > t ? e : t; } e = e > 0 ? e : 0;
-			if (act) E[s] = e;
+			int e = E[s] - e_del; { const int t = hrow[s] - oe_del; e = e > t ? e : t; } e = e > 0 ? e : 0;
+			E[s] = e;                                  /* a padded column stays at 0 */
 			ml = ml > hrow[s] ? ml : hrow[s];
 		}
 		SSG_UNROLL for (int s = 0; s < NS; ++s) H[s] = hrow[s];
+		/* the row maximum matters only when it reaches minsc (b[]) or exceeds the running maximum: one compare + ballot on most rows */
+		const int need = minsc < gmax + 1 ? minsc : gmax + 1;
+		if (wv_ballot(ml >= need) == 0) { tb = tb_next; continue; }
 		const int imax = wv_max(ml);
 		if (imax >= minsc) { /* b[]: collapse runs of adjacent rows, keep the entry in registers */
 			if (n_b == 0 || last_row + 1 != i) { last_sc = imax; last_row = i; if (lane == 0) bscratch[n_b] = (unsigned long long)imax << 32 | (unsigned)i; ++n_b; }

@@ -91,13 +91,15 @@ SSG_DEVFN int wv_prev(int v, int fill) { return SSG_DPP(fill, v, 0x138 /* wave_s
 SSG_DEVFN int wv_get(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
 SSG_DEVFN int wv_scan_max(int v)
 {	/* inclusive prefix max over lanes 0..lane: 4 row_shr steps inside each row of 16, then two row broadcasts */
+	/* `old' = the identity of max: lets the compiler fold each step into one v_max_i32_dpp (with old = v it emits mov + mov_dpp + max) */
 	int t;
-	t = SSG_DPP(v, v, 0x111, 0xf); v = v > t ? v : t;
-	t = SSG_DPP(v, v, 0x112, 0xf); v = v > t ? v : t;
-	t = SSG_DPP(v, v, 0x114, 0xf); v = v > t ? v : t;
-	t = SSG_DPP(v, v, 0x118, 0xf); v = v > t ? v : t;
-	t = SSG_DPP(v, v, 0x142 /* row_bcast:15 */, 0xa); v = v > t ? v : t;
-	t = SSG_DPP(v, v, 0x143 /* row_bcast:31 */, 0xc); v = v > t ? v : t;
+	const int id = (int)0x80000000;
+	t = SSG_DPP(id, v, 0x111, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(id, v, 0x112, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(id, v, 0x114, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(id, v, 0x118, 0xf); v = v > t ? v : t;
+	t = SSG_DPP(id, v, 0x142 /* row_bcast:15 */, 0xa); v = v > t ? v : t;
+	t = SSG_DPP(id, v, 0x143 /* row_bcast:31 */, 0xc); v = v > t ? v : t;
 	return v;
 }
 SSG_DEVFN int wv_sum(int v)

@@ -571,6 +571,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	CHKA(d_xjobs); CHKA(d_xl); CHKA(d_xr); CHKA(d_kl); CHKA(d_kr); CHKA(d_sl); CHKA(d_sr);
 	if (n_jobs > 0) {
 		if (opt->a * 2 * max_len + 64 >= 8191) { ssg_err_msg = "match score x read length beyond the 13-bit DP cells of the extension kernel"; return SSG_EINVAL; }
+		if (opt->a > 31 || opt->a < 0 || opt->b > 32 || opt->b < 0) { ssg_err_msg = "match score above 31 or mismatch penalty above 32: beyond the 6-bit score table of the extension kernel"; return SSG_EINVAL; }
 		const int short_cap = 72;   /* sides up to 72 bases run with half the LDS per wave (two waves per SIMD) */
 		dbuf<unsigned int> d_nlong(2);
 		CHKA(d_nlong); CHK(d_nlong.zero());
