@@ -69,3 +69,8 @@ clean:
 	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so bin/bwa bin/samblaster bin/sambamba tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu $(CSRC)/*.o
 	$(MAKE) -C oracle clean
 .PHONY: all lib tools oracle emu clean
+
+# A/B builds of the device library with other compile-time parameters (bench: SSGPU_LIB=speedseq_amd/libssgpu_$(NAME).so); never the default
+variant: $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o
+	$(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_$(NAME).o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_$(NAME).o $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o -o speedseq_amd/libssgpu_$(NAME).so -lz

@@ -138,7 +138,8 @@ SSG_DEVFN int ssg_sbfe6(uint32_t t, unsigned off) { return (int)(t << (26 - off)
 SSG_DEVFN int ssg_sbfe6(uint32_t t, unsigned off) { return __builtin_amdgcn_sbfe((int)t, off, 6u); }
 #endif
 
-/* upstream ksw_extend2, one lane; Lc[j*64] is this lane's column j (query codes already in bits 29..31) */
+/* upstream ksw_extend2, one lane; Lc[j*64] is this lane's column j (query field already set); U = columns per trip of the cell loop */
+template <int U>
 SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_view_t &ix, uint32_t *Lc, int qlen, int tlen, int64_t p0, int dir,
                                    int w, int end_bonus, int zdrop, int h0, unsigned long long *cells)
 {
@@ -201,13 +202,15 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 				f -= e_ins; f = f > t ? f : t;
 				return out;
 			};
-			/* two columns per trip, the next two in flight meanwhile (the long class runs one wave per SIMD: nothing else hides LDS latency) */
-			uint32_t w0 = Lc[beg * 64], w1 = Lc[(beg + 1) * 64];
-			for (j = beg; j < end; j += 2) {
-				const uint32_t n0 = Lc[(j + 2) * 64], n1 = Lc[(j + 3) * 64];
-				Lc[j * 64] = cell(w0, j);
-				if (j + 1 < end) Lc[(j + 1) * 64] = cell(w1, j + 1);
-				w0 = n0; w1 = n1;
+			/* U columns per trip, the next U in flight meanwhile (the long class runs one wave per SIMD: nothing else hides LDS latency) */
+			uint32_t wc[U];
+			SSG_UNROLL for (int u = 0; u < U; ++u) wc[u] = Lc[(beg + u) * 64];
+			for (j = beg; j < end; j += U) {
+				uint32_t wn[U];
+				SSG_UNROLL for (int u = 0; u < U; ++u) wn[u] = Lc[(j + U + u) * 64];
+				Lc[j * 64] = cell(wc[0], j);
+				SSG_UNROLL for (int u = 1; u < U; ++u) if (j + u < end) Lc[(j + u) * 64] = cell(wc[u], j + u);
+				SSG_UNROLL for (int u = 0; u < U; ++u) wc[u] = wn[u];
 			}
 			mm = mk >> 8; mj = mk & 255;                 /* end > beg: at least one column */
 			j = end;
@@ -244,7 +247,8 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
                                const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
                                unsigned long long *cells)
 {
-	__shared__ uint32_t L[(QCAP + 4) * 64];   /* columns 0..qlen, and the three the cell loop may read ahead */
+	constexpr int U = QCAP > 72 ? 4 : 2;
+	__shared__ uint32_t L[(QCAP + 2 * U) * 64];   /* columns 0..qlen, and the 2U - 1 the cell loop may read ahead */
 	const long t = job_first + (long)blockIdx.x * 64 + threadIdx.x;
 	if (t >= n_jobs) return;
 	const uint64_t key = sorted[t];
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 		for (int i = 0; i < SSG_XL_BAND_TRY; ++i) {
 			const int prev = score;
 			aw = opt.w << i;
-			x = ln_extend2(opt, ix, Lc, qlen, tlen, jb.rbeg - 1, -1, aw, opt.pen_clip5, opt.zdrop, jb.len * opt.a, &nc);
+			x = ln_extend2<U>(opt, ix, Lc, qlen, tlen, jb.rbeg - 1, -1, aw, opt.pen_clip5, opt.zdrop, jb.len * opt.a, &nc);
 			score = x.score;
 			if (score == prev || x.max_off < (aw >> 1) + (aw >> 2)) break;
 		}
@@ -283,7 +287,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 		for (int i = 0; i < SSG_XL_BAND_TRY; ++i) {
 			const int prev = score;
 			aw = opt.w << i;
-			x = ln_extend2(opt, ix, Lc, qlen, tlen, jb.rbeg + jb.len, 1, aw, opt.pen_clip3, opt.zdrop, sc0, &nc);
+			x = ln_extend2<U>(opt, ix, Lc, qlen, tlen, jb.rbeg + jb.len, 1, aw, opt.pen_clip3, opt.zdrop, sc0, &nc);
 			score = x.score;
 			if (score == prev || x.max_off < (aw >> 1) + (aw >> 2)) break;
 		}

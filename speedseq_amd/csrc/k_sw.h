@@ -320,9 +320,12 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 		cg[s] = j < qp ? j * e_ins - oe_ins : SSG_NEG;
 		cf[s] = (j - 1) * e_ins;
 	}
-	int i, tb = tlen > 0 ? sq_at(target, 0) : 0;
+	/* target bases: lane l holds base 64c + l of the current chunk of 64 rows (one coalesced load per 64 rows, the next chunk in flight
+	 * meanwhile); a row reads its base with v_readlane into a scalar */
+	int i, tch = lane < tlen ? sq_at(target, lane) : 0, tchn = 0;
 	for (i = 0; i < tlen; ++i) {
-		const int tb_next = i + 1 < tlen ? sq_at(target, i + 1) : 0;
+		if ((i & 63) == 0) { if (i) tch = tchn; const int k = i + 64 + lane; tchn = k < tlen ? sq_at(target, k) : 0; }
+		const int tb = wv_get(tch, i & 63);
 		int hn[NS], p[NS], hrow[NS];
 		const int up = wv_prev(H[NS-1], 0);          /* H(i-1, j-1) for the lane's first column */
 		const bool tn = tb > 3;
@@ -352,7 +355,7 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 		SSG_UNROLL for (int s = 0; s < NS; ++s) H[s] = hrow[s];
 		/* the row maximum matters only when it reaches minsc (b[]) or exceeds the running maximum: one compare + ballot on most rows */
 		const int need = minsc < gmax + 1 ? minsc : gmax + 1;
-		if (wv_ballot(ml >= need) == 0) { tb = tb_next; continue; }
+		if (wv_ballot(ml >= need) == 0) continue;
 		const int imax = wv_max(ml);
 		if (imax >= minsc) { /* b[]: collapse runs of adjacent rows, keep the entry in registers */
 			if (n_b == 0 || last_row + 1 != i) { last_sc = imax; last_row = i; if (lane == 0) bscratch[n_b] = (unsigned long long)imax << 32 | (unsigned)i; ++n_b; }
@@ -363,7 +366,6 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 			SSG_UNROLL for (int s = 0; s < NS; ++s) HM[s] = hrow[s];
 			if (gmax >= endsc) break;
 		}
-		tb = tb_next;
 	}
 	if (cells) *cells += (unsigned long long)(i < tlen ? i + 1 : tlen) * qlen;
 	ssg_sw1_t r; r.score = gmax; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1;

@@ -502,7 +502,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		for (int b = 0; b < 20; ++b) if (cnt[b]) fprintf(stderr, "[ssg] seeds/read < %d: %ld reads, %ld seeds\n", 1 << b, cnt[b], sum[b]);
 	}
 	{	/* d_work is heaviest first.  Reads with >= T seeds chain one wave each with their state in LDS, in four size classes that run
-		 * concurrently (up to 5120, 2048, 1024, 256 seeds = chains: 155 / 62 / 31 / 8 KB); the light rest one lane per read; the (very
+		 * concurrently (up to 5120, 2048, 1024, 512, 256 seeds = chains: 155 / 62 / 31 / 16 / 8 KB); the light rest one lane per read; the (very
 		 * few) reads beyond 5120 seeds one lane each on their own stream.  The LDS kernels keep contig ids in 16 bits: an index with
 		 * more contigs chains every read in the lane kernel.  SSG_CHAIN_WAVE_BIG = n sends every wave-class read with more than n seeds
 		 * to the top class (tests); SSG_CHAIN_RANKED = 0 selects the array-shifting form of the insertion (A/B, tests). */
@@ -510,18 +510,18 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int TB = env_int("SSG_CHAIN_WAVE_BIG", 0) > 0 ? env_int("SSG_CHAIN_WAVE_BIG", 0) : 1 << 30;
 		const bool ranked = env_int("SSG_CHAIN_RANKED", 1) != 0;
 		const int cap_lim = env_int("SSG_CHAIN_CAP_TEST", 1 << 30);   /* tests: pretend the ranked form holds fewer chains, to walk its fall-back (the shifting form) */
-		int g[6];
+		int g[7];
 		{	/* "greater than" counts of the seeds-per-read array in one pass (thresholds descending: the counts ascend) */
-			ssg_thr6_t th = { { 1 << 30, 5120, std::min(2048, TB), std::min(1024, TB), std::min(256, TB), T - 1 } };
-			dbuf<unsigned int> d_c(8); unsigned int c[6];
+			ssg_thr6_t th = { { 1 << 30, 5120, std::min(2048, TB), std::min(1024, TB), std::min(512, TB), std::min(256, TB), T - 1 } };
+			dbuf<unsigned int> d_c(8); unsigned int c[7];
 			CHKA(d_c); CHK(d_c.zero());
 			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
-			CHK(d_c.down(c, 6));
-			for (int i = 0; i < 6; ++i) g[i] = (int)std::min(c[i], c[5]);
-			for (int i = 1; i < 6; ++i) g[i] = std::max(g[i], g[i - 1]);
+			CHK(d_c.down(c, 7));
+			for (int i = 0; i < 7; ++i) g[i] = (int)std::min(c[i], c[6]);
+			for (int i = 1; i < 7; ++i) g[i] = std::max(g[i], g[i - 1]);
 		}
-		const int n_heavy = g[5];
-		const int nC = g[1], n5120 = g[2] - g[1], n2048 = g[3] - g[2], n1024 = g[4] - g[3], n256 = g[5] - g[4];
+		const int n_heavy = g[6];
+		const int nC = g[1], n5120 = g[2] - g[1], n2048 = g[3] - g[2], n1024 = g[4] - g[3], n512 = g[5] - g[4], n256 = g[6] - g[5];
 		/* position ranks of the heavy reads' seeds: one stable radix sort of (read, reference position) over all of them */
 		dbuf<uint16_t> d_hrank; dbuf<int64_t> d_hoff;
 		if (ranked && n_heavy > nC) {
@@ -543,20 +543,23 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const uint16_t *hr = ranked ? d_hrank.p : (const uint16_t*)0; const int64_t *ho = ranked ? d_hoff.p : (const int64_t*)0;
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
 		/* the classes are independent and each of the heavy ones fills a fraction of the chip: overlap them */
-		ssg_fork(5);
-		if (nC) SSG_LAUNCH_ON(4, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+		/* four queues: the two big classes one each, the short jobs (top class, small classes, then the one-lane monsters) in a row on the third,
+		 * the light reads' lane kernel on the default stream (more streams than hardware queues serialize behind one another anyway) */
+		ssg_fork(3);
 		int r0 = nC;
 #define SSG_CHW_LAUNCH(si, CC, cnt, maxwg, qi) do { if ((cnt) > 0) SSG_LAUNCH_ON(si, ssg_k_chain_wave<CC>, std::min((int)(cnt), (int)(maxwg)), 64, 0, idx->v, *opt, r0, r0 + (cnt), d_off, d_intv.p, d_nintv.p, cap, \
 		o.seed_off.p, d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + (qi), hr, ho, std::min((int)(CC), cap_lim)); r0 += (cnt); } while (0)
 		SSG_CHW_LAUNCH(0, 5120, n5120, 256, 1);
 		SSG_CHW_LAUNCH(1, 2048, n2048, 512, 3);
 		SSG_CHW_LAUNCH(2, 1024, n1024, 1280, 2);
-		SSG_CHW_LAUNCH(3, 256, n256, 5120, 4);
+		SSG_CHW_LAUNCH(0, 512, n512, 2560, 5);
+		SSG_CHW_LAUNCH(0, 256, n256, 5120, 4);
 #undef SSG_CHW_LAUNCH
+		if (nC) SSG_LAUNCH_ON(0, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
 		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		ssg_join(5);
+		ssg_join(3);
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
