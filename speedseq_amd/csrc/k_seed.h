@@ -205,6 +205,9 @@ SSG_DEVFN ssg_intv_t ssg_unpk(const ssg_pk_t &p)
 #ifndef SSG_SMQ_WAVES
 #define SSG_SMQ_WAVES 4
 #endif
+#ifndef SSG_SMQ_TRIPS
+#define SSG_SMQ_TRIPS 2
+#endif
 /* LPR = lanes per read: 4 (cooperative rank-block fetch) or 1 (each lane fetches whole blocks; 4x fewer wave instructions per read,
  * 4x more translation work per line -- see tools/dbg/gather_probe.cpp for where that starts to matter) */
 template <int LPR>
@@ -239,7 +242,9 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	ik.x0 = ik.x1 = ik.x2 = ik.info = 0; p = ik;
 	ssg_pk_t pn, c0, first; pn.w0 = pn.w1 = 0; c0 = first = pn;
 	for (;;) {
-		while (pend == SM_PEND_NONE && state != SM_FIN) {
+		/* a bounded number of state-machine steps per extension round: a lane in the middle of a transition sits the round out instead of
+		 * making the whole wave spin through the switch again (the wave pays for every trip, whoever needs it) */
+		SSG_UNROLL for (int trip = 0; trip < SSG_SMQ_TRIPS; ++trip) if (pend == SM_PEND_NONE && state != SM_FIN) {
 			ssg_pk_t *const curr = flip ? vec1 : vec0;
 			switch (state) {
 			case SM_READ: {
@@ -345,6 +350,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 			}
 		}
 		if (state == SM_FIN) break;
+		if (pend == SM_PEND_NONE) continue;
 		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
 		ssg_wave_ldssync();   /* list entries stored by lane 0 of the quad last iteration are read by all four below (same wave: in order on the GPU) */
 		const ssg_pk_t *const prev = flip ? vec0 : vec1;
