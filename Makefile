@@ -41,7 +41,11 @@ tools/dbg/gather_probe: tools/dbg/gather_probe.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 
 # the executables speedseq.config names (reference bin/speedseq.config:13-14)
-tools: bin/bwa bin/samblaster bin/sambamba
+tools: bin/bwa bin/samblaster bin/sambamba bin/bamkit
+# the helpers `speedseq realign` runs through $$PYTHON (bin/pyrun), under the names speedseq.config gives them
+bin/bamkit: $(HOST)/bamkit_main.cpp $(HOST)/bamio.h
+	$(CXX) -O2 -std=c++17 $(HOST)/bamkit_main.cpp -o $@ -lz -lpthread
+	for t in bamtofastq bamheadrg bamcleanheader bamlibs; do ln -sf bamkit bin/$$t.py; done
 bin/sambamba: $(HOST)/sambamba_main.cpp $(HOST)/bamio.h include/ssgpu.h speedseq_amd/libssgpu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/sambamba_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
 bin/bwa: $(HOST)/bwa_main.cpp $(HOST)/fastq.h include/ssgpu.h speedseq_amd/libssgpu.so
