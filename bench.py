@@ -215,10 +215,13 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
                 "pairs_per_s_incl_index_load": res["pairs"] / t,
                 "sam_bytes": os.path.getsize(files[0]), "splitter_bytes": os.path.getsize(files[1]), "discordant_bytes": os.path.getsize(files[2])})
     # gz input (the reference pipeline reads .fq.gz): one inflate stream bounds the ingest
-    if subprocess.call(["bash", "-c", "gzip -1 -c %s > %s.gz" % (fq, fq)]) == 0:
+    n_gz = min(res["pairs"], 2000000)                     # fixed-width records: a byte prefix is a whole number of pairs
+    rec_bytes = os.path.getsize(fq) // (2 * res["pairs"])
+    if subprocess.call(["bash", "-c", "head -c %d %s | gzip -1 -c > %s.gz" % (2 * n_gz * rec_bytes, fq, fq)]) == 0:
         tg, errg, _ = run(bwa, sbl, fq + ".gz", "fullgz", a.bwa_threads)
         mg = re.search(r"wall: index load ([0-9.]+) s", errg)
-        res["pairs_per_s_gz_input"] = res["pairs"] / (tg - float(mg.group(1))) if mg else res["pairs"] / tg
+        res["pairs_per_s_gz_input"] = n_gz / (tg - float(mg.group(1))) if mg else n_gz / tg
+        res["gz_input_pairs"] = n_gz
     # parity of the executables on the sample
     _, _, gf = run(bwa, sbl, sfq, "s_gpu", a.bwa_threads)
     _, _, of = run(orc_exe, orc_exe + " samblaster", sfq, "s_orc", min(os.cpu_count() or 1, 64))   # one upstream batch either way: -t only sets the worker count
@@ -244,6 +247,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload aligned by the CPU oracle: parity gate + cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
+    ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs in the FASTQ file of the plugin-path leg (the timed batch + freshly simulated ones): enough device calls for the pipeline's steady state to show")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -285,7 +289,8 @@ def main():
 
     rl = a.read_len
     reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev)
-    reads_e2e = simulate_pairs(ref, lens, a.pairs, rl, 1012, dev).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0) else None   # second million for the plugin-path leg
+    n_more = max(0, a.e2e_pairs - a.pairs)
+    reads_e2e = simulate_pairs(ref, lens, n_more, rl, 1012, dev).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0 and n_more > 0) else None   # further pairs for the plugin-path leg
     d_seq = reads.reshape(-1)
     d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
     pb, n_batches = bwa_batches(a.pairs, rl, a.bwa_threads)

@@ -28,6 +28,8 @@ static inline void *rt_malloc_raw(size_t n) { return calloc(n ? n : 1, 1); }
 static inline void rt_free_raw(void *p) { free(p); }
 static inline void rt_pool_release() {}
 static inline int rt_d2d(void *d, const void *s, size_t n) { if (n) memmove(d, s, n); return 0; }
+static inline void *rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
+static inline void rt_host_free(void *p) { free(p); }
 #define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) emu::launch((unsigned)(grid), (unsigned)(block), (lds), [&]() { kern(__VA_ARGS__); }); } while (0)
 #define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) SSG_LAUNCH(kern, grid, block, lds, __VA_ARGS__)
 static inline void ssg_fork(int) {}
@@ -73,6 +75,38 @@ static inline void *rt_malloc_raw(size_t n) { void *p = 0; if (hipMalloc(&p, n ?
 static inline void rt_free_raw(void *p) { if (p) (void)hipFree(p); }
 static inline void rt_pool_release() { ssg_pool.release(); }
 static inline int rt_d2d(void *d, const void *s, size_t n) { return n ? rt_check(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice), "hipMemcpy D2D") : 0; }
+/* page-locked host memory for the results a call hands to its caller.  A pageable destination costs a staging copy plus first-touch
+ * faults and zero-fill of a fresh multi-hundred-MB block per call; page-locked blocks copy at PCIe speed but are expensive to make,
+ * so freed blocks wait here for the next call (at most 4 GB of them). */
+struct ssg_hostpool_t {
+	std::mutex mu; std::unordered_map<void*, size_t> cap_; std::vector<void*> free_; size_t free_bytes = 0;
+	void *get(size_t n)
+	{
+		if (!n) n = 1;
+		{	std::lock_guard<std::mutex> l(mu);
+			int best = -1;
+			for (int i = 0; i < (int)free_.size(); ++i) { const size_t c = cap_[free_[i]]; if (c >= n && c <= 2 * n + ((size_t)1 << 20) && (best < 0 || c < cap_[free_[best]])) best = i; }
+			if (best >= 0) { void *p = free_[best]; free_.erase(free_.begin() + best); free_bytes -= cap_[p]; return p; }
+		}
+		void *p = 0; const size_t c = n + n / 4;
+		if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
+		std::lock_guard<std::mutex> l(mu); cap_[p] = c;
+		return p;
+	}
+	void put(void *p)
+	{
+		if (!p) return;
+		std::vector<void*> drop;
+		{	std::lock_guard<std::mutex> l(mu);
+			free_.push_back(p); free_bytes += cap_[p];
+			while (free_bytes > ((size_t)4 << 30) && !free_.empty()) { void *q = free_.front(); free_.erase(free_.begin()); free_bytes -= cap_[q]; cap_.erase(q); drop.push_back(q); }
+		}
+		for (void *q : drop) (void)hipHostFree(q);
+	}
+};
+extern ssg_hostpool_t ssg_hostpool;
+static inline void *rt_host_alloc(size_t n) { return ssg_hostpool.get(n); }
+static inline void rt_host_free(void *p) { ssg_hostpool.put(p); }
 /* optional per-kernel timing: HIP events recorded on the launch stream (the default stream) */
 #include <vector>
 struct ssg_prof_rec { const char *name; hipEvent_t a, b; };
@@ -106,5 +140,16 @@ template <class T> struct dbuf {
 	int up(const T *h, size_t cnt) { return rt_h2d(p, h, cnt * sizeof(T)); }
 	int down(T *h, size_t cnt) const { return rt_d2h(h, p, cnt * sizeof(T)); }
 	int zero() { return rt_memset(p, 0, n * sizeof(T)); }
+};
+/* host-side result array in page-locked pooled memory (contents undefined after resize) */
+template <class T> struct hbuf {
+	T *p; size_t n, cap;
+	hbuf() : p(0), n(0), cap(0) {}
+	~hbuf() { rt_host_free(p); }
+	hbuf(const hbuf&) = delete; hbuf &operator=(const hbuf&) = delete;
+	bool resize(size_t n_) { if (n_ > cap) { rt_host_free(p); p = (T*)rt_host_alloc(n_ * sizeof(T)); cap = p ? n_ : 0; } n = p || !n_ ? n_ : 0; return p != 0 || n_ == 0; }
+	T *data() { return p; }
+	const T *data() const { return p; }
+	size_t size() const { return n; }
 };
 #endif

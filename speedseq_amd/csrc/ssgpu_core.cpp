@@ -10,6 +10,7 @@
  */
 #include <vector>
 #include <memory>
+#include <chrono>
 #include <algorithm>
 #include <math.h>
 #include "ssg_rt.h"
@@ -29,6 +30,7 @@
 thread_local std::string ssg_err_msg;
 #ifndef SSG_EMU
 ssg_pool_t ssg_pool;
+ssg_hostpool_t ssg_hostpool;
 int ssg_prof_on = 0;
 std::vector<ssg_prof_rec> ssg_prof_pending;
 #endif
@@ -42,7 +44,8 @@ std::vector<ssg_prof_rec> ssg_prof_pending;
 
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 static int ssg_debug() { static int d = -1; if (d < 0) d = getenv("SSG_DEBUG") ? atoi(getenv("SSG_DEBUG")) : 0; return d; }
-#define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d\n", name, rc_); fflush(stderr); if (rc_) return rc_; } } while (0)
+static double ssg_stage_ms() { static thread_local std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); const auto t1 = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; return ms; }
+#define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d  +%.1f ms\n", name, rc_, ssg_stage_ms()); fflush(stderr); if (rc_) return rc_; } } while (0)
 
 static int need_device()
 {
@@ -683,8 +686,8 @@ static void host_pestat(const ssg_mem_opt_t *opt, const uint32_t *hist /* [4][SS
 struct ssg_pe_result {
 	int n_reads, n_batches;
 	std::vector<int64_t> req_off;        /* n_reads + 1 */
-	std::vector<ssg_alnreq_t> req;
-	std::vector<ssg_aln_t> alns;
+	hbuf<ssg_alnreq_t> req;              /* page-locked, recycled across calls */
+	hbuf<ssg_aln_t> alns;
 	std::vector<ssg_pestat_t> pes;        /* n_batches * 4 */
 	uint64_t stats[8];
 };
@@ -811,8 +814,9 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	{ unsigned long long c[2]; CHK(d_cnt.down(c, 2)); res->stats[2] = c[0]; res->stats[3] = c[1]; res->stats[4] = (uint64_t)nreq; }
 	if (keep) { keep->req.swap(d_creq); keep->alns.swap(d_alns); keep->req_off.swap(d_coff); keep->n_req = nreq; }
 	else {
-		res->req.resize((size_t)nreq); res->alns.resize((size_t)nreq);
+		if (!res->req.resize((size_t)nreq) || !res->alns.resize((size_t)nreq)) { ssg_err_msg = "host allocation failed: result records"; return SSG_ENOMEM; }
 		CHK(d_creq.down(res->req.data(), (size_t)nreq)); CHK(d_alns.down(res->alns.data(), (size_t)nreq));
+		STAGE("download");
 	}
 	return 0;
 }
@@ -904,7 +908,9 @@ int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
 	for (int p = 0; p < n_pairs; ++p) if (pair_batch[p] < 0 || pair_batch[p] >= n_batches) { ssg_err_msg = "pair_batch out of range"; return SSG_EINVAL; }
 	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1); dbuf<int32_t> d_pb(n_pairs);
 	CHKA(d_seq); CHKA(d_off); CHKA(d_pb);
+	if (ssg_debug()) (void)ssg_stage_ms();
 	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1)); CHK(d_pb.up(pair_batch, n_pairs));
+	STAGE("upload");
 	std::unique_ptr<ssg_pe_result> res(new ssg_pe_result());
 	CHK(pe_core(idx, opt, n_pairs, d_seq.p, d_off.p, max_len, d_pb.p, n_batches, id0, pes0, res.get(), 0));
 	*out = res.release();
