@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) ssg_k_smem_lane(ssg_index_view_t ix, ssg_m
  * not depend on insertion order.  The forward list is walked from its top instead of being reversed.
  */
 #define SSG_SM_QWORDS 32   /* 8 bases per word: reads up to 256 bases */
-enum { SM_READ = 0, SM_P1, SM_FWD, SM_FWDEND, SM_BWD, SM_RET, SM_P2, SM_P3, SM_P3F, SM_OUT, SM_FIN };
+enum { SM_FWD = 0, SM_BWD, SM_P3F, SM_READ, SM_P1, SM_P2, SM_P3, SM_OUT, SM_FIN };   /* the three hot states first: the compiler lowers the dispatch to a comparison tree over the value */
 enum { SM_PEND_NONE = 0, SM_PEND_FWD, SM_PEND_BWD, SM_PEND_P3 };
 
 /* interval-list entries in scratch and in the carried registers: 16 bytes (x0, x1, x2 < 2^40; info = end position < 256) */
@@ -241,11 +241,51 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	ssg_intv_t ik, p;
 	ik.x0 = ik.x1 = ik.x2 = ik.info = 0; p = ik;
 	ssg_pk_t pn, c0, first; pn.w0 = pn.w1 = 0; c0 = first = pn;
+	/* transitions done where they arise instead of through a state of their own (one dispatch less on the way):
+	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
+#define SM_DO_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ssg_pk(ik); state = SM_BWD; } while (0)
+/* next start position of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
+#define SM_DO_P3() do { while (x < len && SMQ(x) > 3) ++x; if (x >= len) state = SM_OUT; else { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } } while (0)
+#define SM_DO_RET() do { if (caller == 1) { x = ret; state = SM_P1; } else { ++k; state = SM_P2; } } while (0)
 	for (;;) {
 		/* a bounded number of state-machine steps per extension round: a lane in the middle of a transition sits the round out instead of
 		 * making the whole wave spin through the switch again (the wave pays for every trip, whoever needs it) */
 		SSG_UNROLL for (int trip = 0; trip < SSG_SMQ_TRIPS; ++trip) if (pend == SM_PEND_NONE && state != SM_FIN) {
 			ssg_pk_t *const curr = flip ? vec1 : vec0;
+			/* the three states a lane is in nearly all the time (forward loop, backward loop, third pass) first, straight-line; a wave whose
+			 * lanes are all there skips the switch over the rare states with one branch */
+			if (state == SM_FWD) { /* top of upstream's forward loop: for (i = x + 1; i < len; ++i) */
+				if (i < len && SMQ(i) < 4) { pend = SM_PEND_FWD; e_c = 3 - SMQ(i); }
+				else { if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1; ++curr_n; SM_DO_FWDEND(); }
+			} else if (state == SM_BWD) { /* for (i = x - 1; i >= -1; --i) for (j = 0; j < prev->n; ++j) */
+				if (j >= prev_n) {
+					if (curr_n == 0) SM_DO_RET();
+					else {
+						flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 0; curr_n = 0; j = 0; --i; first = c0;
+						if (i < -1) SM_DO_RET();
+					}
+				} else {
+					p = ssg_unpk(j == 0 ? first : pn);
+					const int cb = i < 0 ? -1 : SMQ(i) < 4 ? SMQ(i) : -1;
+					if (cb >= 0) { pend = SM_PEND_BWD; e_c = cb; }
+					else { /* no base to extend with: only the first (longest) interval of the row can be an SMEM, the rest are no-ops */
+						if (j == 0 && (m1_n == 0 || i + 1 < m1_last_beg)) {
+							++m1_n; m1_last_beg = i + 1;
+							if ((int)(uint32_t)p.info - (i + 1) >= opt.min_seed_len) {
+								ssg_intv_t o = p; o.info |= (uint64_t)(i + 1) << 32;
+								if (mem_n < cap) { if (QW) mem[mem_n] = o; } else ovf = 1;
+								++mem_n;
+							}
+						}
+						j = prev_n;
+					}
+				}
+			} else if (state == SM_P3F) {
+				if (i < len) {
+					if (SMQ(i) < 4) { pend = SM_PEND_P3; e_c = 3 - SMQ(i); }
+					else { x = i + 1; SM_DO_P3(); }
+				} else { x = len; state = SM_OUT; }
+			} else
 			switch (state) {
 			case SM_READ: {
 				/* next read: a shared counter when every lane owns a read (evens out the per-read cost), a fixed stride for quads */
@@ -286,40 +326,6 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 				else { sx = x; min_intv = 1; caller = 1; state = SM_FWD; m1_n = 0; curr_n = 0; i = sx + 1;
 				       ssg_set_intv(ix, SMQ(sx), ik); ik.info = (uint64_t)(sx + 1); }
 				break;
-			case SM_FWD: /* top of upstream's forward loop: for (i = x + 1; i < len; ++i) */
-				if (i < len && SMQ(i) < 4) { pend = SM_PEND_FWD; e_c = 3 - SMQ(i); }
-				else { if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1; ++curr_n; state = SM_FWDEND; }
-				break;
-			case SM_FWDEND: /* the forward list becomes `prev', walked from its top (= ik); ret = end of the longest match */
-				ret = (int)ik.info;
-				flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ssg_pk(ik);
-				state = SM_BWD;
-				break;
-			case SM_BWD: { /* for (i = x - 1; i >= -1; --i) for (j = 0; j < prev->n; ++j) */
-				if (j >= prev_n) {
-					if (curr_n == 0) { state = SM_RET; break; }
-					flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 0; curr_n = 0; j = 0; --i; first = c0;
-					if (i < -1) state = SM_RET;
-					break;
-				}
-				p = ssg_unpk(j == 0 ? first : pn);
-				const int cb = i < 0 ? -1 : SMQ(i) < 4 ? SMQ(i) : -1;
-				if (cb >= 0) { pend = SM_PEND_BWD; e_c = cb; }
-				else { /* no base to extend with: only the first (longest) interval of the row can be an SMEM, the rest are no-ops */
-					if (j == 0 && (m1_n == 0 || i + 1 < m1_last_beg)) {
-						++m1_n; m1_last_beg = i + 1;
-						if ((int)(uint32_t)p.info - (i + 1) >= opt.min_seed_len) {
-							ssg_intv_t o = p; o.info |= (uint64_t)(i + 1) << 32;
-							if (mem_n < cap) { if (QW) mem[mem_n] = o; } else ovf = 1;
-							++mem_n;
-						}
-					}
-					j = prev_n;
-				}
-			} break;
-			case SM_RET:
-				if (caller == 1) { x = ret; state = SM_P1; } else { ++k; state = SM_P2; }
-				break;
 			case SM_P2: /* re-seed from the middle of long SMEMs with few occurrences */
 				if (k >= old_n) { x = 0; state = opt.max_mem_intv > 0 ? SM_P3 : SM_OUT; break; }
 				{
@@ -327,21 +333,13 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 					const int start = (int)(m.info >> 32), end = (int)(uint32_t)m.info;
 					if (end - start < split_len || m.x2 > (uint64_t)opt.split_width) { ++k; break; }
 					sx = (start + end) >> 1; min_intv = m.x2 + 1; caller = 2; m1_n = 0; curr_n = 0; i = sx + 1;
-					if (SMQ(sx) > 3) { state = SM_RET; break; }   /* bwt_smem1a returns at once on an ambiguous base */
+					if (SMQ(sx) > 3) { SM_DO_RET(); break; }   /* bwt_smem1a returns at once on an ambiguous base */
 					ssg_set_intv(ix, SMQ(sx), ik); ik.info = (uint64_t)(sx + 1);
 					state = SM_FWD;
 				}
 				break;
-			case SM_P3: /* upstream bwt_seed_strategy1 from every position */
-				if (x >= len) state = SM_OUT;
-				else if (SMQ(x) > 3) ++x;
-				else { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; }
-				break;
-			case SM_P3F:
-				if (i < len) {
-					if (SMQ(i) < 4) { pend = SM_PEND_P3; e_c = 3 - SMQ(i); }
-					else { x = i + 1; state = SM_P3; }
-				} else { x = len; state = SM_P3; }
+			case SM_P3:
+				SM_DO_P3();
 				break;
 			case SM_OUT:
 				if (QW) out_n[it] = ovf ? -1 : mem_n;
@@ -366,7 +364,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 				if (okc.x2 != ik.x2) {
 					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1;
 					++curr_n;
-					if (okc.x2 < min_intv) { state = SM_FWDEND; pend = SM_PEND_NONE; continue; }   /* break: ik stays the last pushed */
+					if (okc.x2 < min_intv) { SM_DO_FWDEND(); pend = SM_PEND_NONE; continue; }   /* break: ik stays the last pushed */
 				}
 				ik = okc; ik.info = (uint64_t)(i + 1); ++i;
 			} else if (back) {
@@ -395,7 +393,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 						if (mem_n < cap) { if (QW) mem[mem_n] = o; } else ovf = 1;
 						++mem_n;
 					}
-					x = i + 1; state = SM_P3;
+					x = i + 1; SM_DO_P3();
 				} else { ik = okc; ++i; }
 			}
 			pend = SM_PEND_NONE;
@@ -404,6 +402,9 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 #undef SMQ
 #undef SMV
 #undef QW
+#undef SM_DO_FWDEND
+#undef SM_DO_RET
+#undef SM_DO_P3
 	if (n_extend && my_nx && ql == 0) atomicAdd(n_extend, my_nx);
 }
 /* one lane per read: intervals by (start,end), upstream's ks_introsort(mem_intv) */
