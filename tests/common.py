@@ -353,3 +353,36 @@ def repeat_reference(oracle, dirname, seed=5, n_copies=(300, 70), fam_len=(600, 
                 fh.write(txt[i:i + 60] + "\n")
     oracle.idx_build(prefix, save=True)
     return prefix
+
+
+def check_hotpath(lib, oracle, n_pairs, per, read_len, to_dev):
+    """ssg_hotpath_dev_ex (the bench's step: alignment, duplicate marking, discordant / splitter classification, all on the device) on
+    device-resident reads in n_pairs / per upstream batches: duplicate flags equal the oracle's `bwa mem` (one insert-size model per
+    upstream batch) + samblaster over the whole input; SAM / discordant / splitter line counts equal the oracle's streams.
+    to_dev(numpy array) -> (keep-alive object, device pointer)."""
+    from speedseq_amd import capi
+    kw = dict(ins_mean=800, ins_std=150) if read_len > 200 else {}
+    pairs, seqs, seq, off = sim_reads(n_pairs, seed=41, read_len=read_len, dup_frac=0.1, **kw)
+    nb = n_pairs // per
+    pb = (np.arange(n_pairs) // per).astype(np.int32)
+    gidx, oidx = lib.index_load(EXAMPLE_FA), oracle.idx_load(EXAMPLE_FA)
+    opt = lib.opt_init()
+    keep = [to_dev(seq), to_dev(off), to_dev(pb)]
+    (d_seq, d_off, d_pb) = [k[1] for k in keep]
+    summary, dup = capi.hotpath_dev(lib, gidx, opt, n_pairs, read_len, d_seq, d_off, d_pb, nb, 0, True)
+    s16, _ = capi.hotpath_dev_ex(lib, gidx, opt, n_pairs, read_len, d_seq, d_off, d_pb, nb, 0)
+    names = []
+    for nm, _, _ in pairs:
+        names += [nm, nm]
+    text = ""
+    for b in range(nb):
+        lo, hi = 2 * per * b, 2 * per * (b + 1)
+        t, _, _ = oracle.process_pairs(oidx, seq[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], names[lo:hi], None, lo, "", 4)
+        text += t
+    oflags, marked = oracle_dup_flags(oracle, text, "@SQ\tSN:20_slice\tLN:321635\n")
+    assert np.array_equal(dup, oflags) and oflags.sum() > n_pairs // 40, (int(dup.sum()), int(oflags.sum()))
+    assert int(s16[10]) == text.count("\n") and int(s16[1]) == int(oflags.sum()), (s16, text.count("\n"))
+    n_disc = sum(1 for l in oracle.last_discordants.split("\n") if l and l[0] != "@")
+    n_spl = sum(1 for l in oracle.last_splitters.split("\n") if l and l[0] != "@")
+    assert (int(s16[8]), int(s16[9])) == (n_disc, n_spl) and n_disc > 0 and (n_spl > 0 or n_pairs < 2000), (s16, n_disc, n_spl)
+    return int(s16[10]), int(s16[1]), n_disc, n_spl

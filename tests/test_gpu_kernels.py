@@ -122,12 +122,16 @@ def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
     monkeypatch.delenv("SSG_SMEM_KERNEL")
     monkeypatch.setenv("SSG_SA_INTV", "32")   # the file's own suffix-array density
     assert common.check_align1(gpu_lib, oracle, 1500, seed=33) > 1500
-def test_gpu_hotpath_batches_and_dups(gpu_lib):
-    """ssg_hotpath_dev_ex (the bench's step) on device-resident reads in three upstream batches against the oracle; runs in its own
+
+
+@pytest.mark.parametrize("read_len", [150, 250])
+def test_gpu_hotpath_batches_and_dups(gpu_lib, read_len):
+    """ssg_hotpath_dev_ex (the bench's step: alignment, duplicate marking, discordant / splitter classification on the device) on
+    device-resident reads in three upstream batches against the oracle, at 2x150 and 2x250 with long inserts; runs in its own
     process (tests/hotpath_check.py) because torch must initialise its HIP runtime before libssgpu is loaded, as in bench.py."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "hotpath_check.py")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(here, "hotpath_check.py"), str(read_len)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "hotpath ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -1,5 +1,7 @@
 """CPU-side logic tests: the product's kernel sources, compiled against the host wave emulator
 (tests/emu), must agree with the oracle bit for bit.  (The HIP build is tested by test_gpu_*.py.)"""
+import pytest
+
 import common
 
 
@@ -108,3 +110,10 @@ def test_emu_smem_kernel_variants(emu_lib, oracle, monkeypatch):
     monkeypatch.delenv("SSG_SMEM_KERNEL")
     monkeypatch.setenv("SSG_SA_INTV", "32")
     assert common.check_align1(emu_lib, oracle, 150, seed=33) > 150
+
+
+@pytest.mark.parametrize("read_len", [150, 250])
+def test_emu_hotpath_dedup_and_classification(emu_lib, oracle, read_len):
+    """the bench's step through ssg_hotpath_dev_ex (rows a1-a17 in one call, samblaster's decisions on the device records) vs the oracle"""
+    r = common.check_hotpath(emu_lib, oracle, 600, 200, read_len, lambda a: (a, a.ctypes.data))
+    assert r[0] >= 1200
