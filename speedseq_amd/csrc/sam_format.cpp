@@ -12,11 +12,18 @@
 #include "../../include/ssgpu.h"
 
 namespace {
-struct sbuf {
+struct alignas(128) sbuf {   /* one per formatting thread, side by side in a vector: its length field is written on every append, so it gets cache lines of its own */
 	std::string s;
-	void putl(long long v) { char b[24]; int n = snprintf(b, sizeof(b), "%lld", v); s.append(b, n); }
+	void putl(long long v)
+	{	/* decimal, by hand: a SAM line prints a dozen integers and snprintf was a third of the formatter's time */
+		char b[24]; int n = 24; unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+		do { b[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+		if (v < 0) b[--n] = '-';
+		s.append(b + n, (size_t)(24 - n));
+	}
 	void putc(char c) { s.push_back(c); }
 	void puts(const char *p) { s.append(p); }
+	char *grow(size_t n) { const size_t o = s.size(); s.resize(o + n); return &s[o]; }   /* n bytes to be written by the caller */
 };
 
 inline int get_rlen(int n_cigar, const uint32_t *cigar)
@@ -77,7 +84,7 @@ void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, con
 			if ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3) qb += a.cigar[0] >> 4;
 			if ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3) qe -= a.cigar[n_cigar-1] >> 4;
 		}
-		for (int i = qb; i < qe; ++i) str.putc("ACGTN"[seq[i]]);
+		{ char *d = str.grow((size_t)(qe > qb ? qe - qb : 0)); for (int i = qb; i < qe; ++i) *d++ = "ACGTN"[seq[i]]; }
 		str.putc('\t');
 		if (qual) str.s.append(qual + qb, qe - qb); else str.putc('*');
 	} else {
@@ -86,9 +93,9 @@ void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, con
 			if ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3) qe -= a.cigar[0] >> 4;
 			if ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3) qb += a.cigar[n_cigar-1] >> 4;
 		}
-		for (int i = qe - 1; i >= qb; --i) str.putc("TGCAN"[seq[i]]);
+		{ char *d = str.grow((size_t)(qe > qb ? qe - qb : 0)); for (int i = qe - 1; i >= qb; --i) *d++ = "TGCAN"[seq[i]]; }
 		str.putc('\t');
-		if (qual) for (int i = qe - 1; i >= qb; --i) str.putc(qual[i]); else str.putc('*');
+		if (qual) { char *d = str.grow((size_t)(qe > qb ? qe - qb : 0)); for (int i = qe - 1; i >= qb; --i) *d++ = qual[i]; } else str.putc('*');
 	}
 	if (n_cigar) {
 		str.puts("\tNM:i:"); str.putl(a.NM);
@@ -130,12 +137,12 @@ static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, int 
 	const ssg_aln_t *alns = ssg_pe_alns(res);
 	std::vector<const ssg_aln_t*> mains[2];
 	std::vector<std::string> xa[2];
+	std::vector<int> owner;
 	for (int p = p0; p < p1; ++p) {
 		mate_t mate[2];
 		for (int i = 0; i < 2; ++i) {
 			const int r = 2 * p + i;
-			mains[i].clear(); xa[i].clear();
-			std::vector<int> owner;
+			mains[i].clear(); xa[i].clear(); owner.clear();
 			for (int64_t g = req_off[r]; g < req_off[r+1]; ++g) {
 				if (req[g].kind == SSG_REQ_MAIN) { mains[i].push_back(&alns[g]); owner.push_back(req[g].owner); xa[i].emplace_back(); }
 			}
@@ -177,23 +184,28 @@ extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, 
 	if (T > 64) T = 64;
 	if (T > (n_pairs + 1023) / 1024) T = (n_pairs + 1023) / 1024;
 	if (T < 1) T = 1;
-	std::vector<sbuf> outs(T); std::vector<int> rcs(T, 0); std::vector<std::thread> th;
+	/* the per-thread text buffers persist across calls of the calling thread (bwa's formatter thread): after the first batch they
+	 * are warm memory instead of hundreds of MB of fresh pages per call */
+	static thread_local std::vector<sbuf> outs_keep;
+	if ((int)outs_keep.size() < T) outs_keep.resize(T);
+	std::vector<sbuf> &outs = outs_keep;
+	std::vector<int> rcs(T, 0); std::vector<std::thread> th;
 	auto lo = [&](int t) { return (int)((int64_t)n_pairs * t / T); };
 	for (int t = 0; t < T; ++t) {
-		auto work = [&, t]() { outs[t].s.reserve((size_t)(lo(t + 1) - lo(t)) * 1000); rcs[t] = format_range(idx, res, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, outs[t], sam_off); };
+		auto work = [&, t]() { outs[t].s.clear(); outs[t].s.reserve((size_t)(lo(t + 1) - lo(t)) * 1000); rcs[t] = format_range(idx, res, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, outs[t], sam_off); };
 		if (T == 1) work(); else th.emplace_back(work);
 	}
 	for (auto &x : th) x.join();
-	size_t tot = 0;
-	for (int t = 0; t < T; ++t) { if (rcs[t]) return rcs[t]; tot += outs[t].s.size(); }
+	th.clear();
+	size_t tot = 0; std::vector<size_t> base(T + 1, 0);
+	for (int t = 0; t < T; ++t) { if (rcs[t]) return rcs[t]; base[t] = tot; tot += outs[t].s.size(); }
 	char *buf = (char*)malloc(tot + 1);
 	if (!buf) return SSG_ENOMEM;
-	size_t base = 0;
-	for (int t = 0; t < T; ++t) {
-		memcpy(buf + base, outs[t].s.data(), outs[t].s.size());
-		for (int r = 2 * lo(t); r < 2 * lo(t + 1); ++r) sam_off[r] += (int64_t)base;
-		base += outs[t].s.size();
+	for (int t = 0; t < T; ++t) {   /* joined in input order, each part copied by its own thread */
+		auto work = [&, t]() { memcpy(buf + base[t], outs[t].s.data(), outs[t].s.size()); for (int r = 2 * lo(t); r < 2 * lo(t + 1); ++r) sam_off[r] += (int64_t)base[t]; };
+		if (T == 1) work(); else th.emplace_back(work);
 	}
+	for (auto &x : th) x.join();
 	buf[tot] = 0; sam_off[2 * n_pairs] = (int64_t)tot;
 	*sam = buf;
 	return 0;

@@ -112,19 +112,40 @@ static int main_mem(int argc, char **argv)
 	/* Three overlapped stages, one batch each: (1) assemble upstream's batches from the reader threads' blocks, (2) align on the
 	 * MI355X, (3) format SAM (threads inside ssg_sam_format) and write.  Several upstream batches (bseq_read's chunk_size * n_threads
 	 * bases, even read count: the scope of the insert-size model) travel to the GPU in one call. */
-	struct batch_t {
-		std::vector<char> txt, qual; std::vector<uint8_t> seq; std::vector<int64_t> off;
-		std::vector<size_t> name_o, com_o, qual_o;            /* SIZE_MAX = absent */
+	struct batch_t {   /* names, comments and qualities stay where the reader put them (the batch holds on to those blocks); the bases are gathered
+	                    * for the device when the batch is complete, by several threads (the blocks were written by another core) */
+		std::vector<std::shared_ptr<fq_block_t> > hold;
+		std::vector<const char*> names, quals, comments;      /* 0 = absent */
+		std::vector<const uint8_t*> src;
+		std::unique_ptr<uint8_t[]> seq; std::vector<int64_t> off;
 		std::vector<int32_t> pair_batch; int n_batches; int64_t id0;
 		ssg_pe_result_t *res;
 		batch_t() : n_batches(0), id0(0), res(0) { off.push_back(0); }
-		int n() const { return (int)name_o.size(); }
-		void add(const fq_block_t &b, int i)
+		int n() const { return (int)names.size(); }
+		void add(const std::shared_ptr<fq_block_t> &h, int i)
 		{
-			name_o.push_back(txt.size()); txt.insert(txt.end(), b.txt.data() + b.name_o[i], b.txt.data() + b.name_o[i] + strlen(b.txt.data() + b.name_o[i]) + 1);
-			if (b.com_o[i] != UINT32_MAX) { com_o.push_back(txt.size()); txt.insert(txt.end(), b.txt.data() + b.com_o[i], b.txt.data() + b.com_o[i] + strlen(b.txt.data() + b.com_o[i]) + 1); } else com_o.push_back(SIZE_MAX);
-			seq.insert(seq.end(), b.seq.begin() + b.seq_o[i], b.seq.begin() + b.seq_o[i + 1]); off.push_back((int64_t)seq.size());
-			if (b.has_q[i]) { qual_o.push_back(qual.size()); const size_t l = b.seq_o[i + 1] - b.seq_o[i]; qual.insert(qual.end(), b.qual.data() + b.qual_o[i], b.qual.data() + b.qual_o[i] + l + 1); } else qual_o.push_back(SIZE_MAX);
+			const fq_block_t &b = *h;
+			if (hold.empty() || hold.back().get() != h.get()) {
+				bool seen = false;                                  /* two input files alternate between two blocks */
+				for (size_t k = hold.size(); k-- > 0 && k + 4 > hold.size(); ) if (hold[k].get() == h.get()) { seen = true; break; }
+				if (!seen) hold.push_back(h);
+			}
+			names.push_back(b.txt.data() + b.name_o[i]);
+			comments.push_back(b.com_o[i] != UINT32_MAX ? b.txt.data() + b.com_o[i] : 0);
+			quals.push_back(b.has_q[i] ? b.qual.data() + b.qual_o[i] : 0);
+			src.push_back(b.seq.data() + b.seq_o[i]);
+			off.push_back(off.back() + (int64_t)(b.seq_o[i + 1] - b.seq_o[i]));
+		}
+		void gather(int n_threads)
+		{
+			const size_t nr = src.size();
+			seq.reset(new uint8_t[(size_t)off[nr] + 1]);              /* not value-initialised: first touched by the copying threads */
+			const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, nr / 65536 + 1));
+			std::vector<std::thread> th;
+			for (int t = 0; t < T; ++t) th.emplace_back([this, t, T, nr]() {
+				for (size_t r = nr * (size_t)t / (size_t)T, e = nr * (size_t)(t + 1) / (size_t)T; r < e; ++r) memcpy(seq.get() + off[r], src[r], (size_t)(off[r + 1] - off[r]));
+			});
+			for (std::thread &x : th) x.join();
 		}
 	};
 	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
@@ -143,16 +164,17 @@ static int main_mem(int argc, char **argv)
 				int64_t size = 0; const int n0 = B->n();
 				for (;;) {
 					const fq_block_t *ba, *bb; int ia, ib;
+					(void)ba; (void)bb;
 					int rc = c1.next(&ba, &ia);
 					if (rc == -1) { eof = true; break; }
 					if (rc < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ\n"); fail = 1; eof = true; break; }
-					B->add(*ba, ia);
+					B->add(c1.cur, ia);
 					rc = (c2 ? *c2 : c1).next(&bb, &ib);
 					if (rc < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ (paired reads expected)\n"); fail = 1; eof = true; break; }
-					B->add(*bb, ib);
+					B->add((c2 ? *c2 : c1).cur, ib);
 					const int n = B->n();
-					if (strcmp(B->txt.data() + B->name_o[n - 2], B->txt.data() + B->name_o[n - 1]) != 0) {
-						fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", B->txt.data() + B->name_o[n - 2], B->txt.data() + B->name_o[n - 1]); fail = 1; eof = true; break; }
+					if (strcmp(B->names[n - 2], B->names[n - 1]) != 0) {
+						fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", B->names[n - 2], B->names[n - 1]); fail = 1; eof = true; break; }
 					size += (B->off[n - 1] - B->off[n - 2]) + (B->off[n] - B->off[n - 1]);
 					if (size >= chunk) break;
 				}
@@ -160,6 +182,7 @@ static int main_mem(int argc, char **argv)
 				if (B->n() > n0) { for (int p = n0 / 2; p < B->n() / 2; ++p) B->pair_batch.push_back(B->n_batches); ++B->n_batches; }
 			}
 			if (fail || B->n() == 0) break;
+			B->gather(std::min(8, std::max(1, opt.n_threads)));
 			id0 += B->n() / 2;
 			tm_asm += wall() - t0;
 			to_gpu.push(std::move(B));
@@ -170,7 +193,7 @@ static int main_mem(int argc, char **argv)
 		std::unique_ptr<batch_t> B;
 		while (to_gpu.pop(B)) {
 			const double t0 = wall();
-			if (!fail && ssg_mem_process_pairs(idx, &opt, B->n() / 2, B->seq.data(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
+			if (!fail && ssg_mem_process_pairs(idx, &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
 				fprintf(stderr, "[bwa] alignment failed: %s\n", ssg_last_error()); fail = 1; }
 			tm_gpu += wall() - t0;
 			if (!fail) to_fmt.push(std::move(B));
@@ -193,14 +216,8 @@ static int main_mem(int argc, char **argv)
 			if (fail) { if (B->res) ssg_pe_result_free(B->res); continue; }
 			const double t0 = wall();
 			const int n = B->n();
-			std::vector<const char*> names(n), quals(n), comments(n);
-			for (int i = 0; i < n; ++i) {
-				names[i] = B->txt.data() + B->name_o[i];
-				quals[i] = B->qual_o[i] == SIZE_MAX ? 0 : B->qual.data() + B->qual_o[i];
-				comments[i] = B->com_o[i] == SIZE_MAX ? 0 : B->txt.data() + B->com_o[i];
-			}
 			char *sam; std::vector<int64_t> sam_off(n + 1);
-			if (ssg_sam_format(idx, &opt, B->res, n / 2, names.data(), B->seq.data(), B->off.data(), quals.data(), comments.data(), rg_id, &sam, sam_off.data())) {
+			if (ssg_sam_format(idx, &opt, B->res, n / 2, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), B->comments.data(), rg_id, &sam, sam_off.data())) {
 				fprintf(stderr, "[bwa] SAM formatting failed: %s\n", ssg_last_error()); fail = 1; ssg_pe_result_free(B->res); continue; }
 			tm_fmt += wall() - t0;
 			const ssg_pestat_t *pp = ssg_pe_pes(B->res);
@@ -215,7 +232,7 @@ static int main_mem(int argc, char **argv)
 	t_asm.join(); t_gpu.join();
 	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> SAM %.2f s\n", t_loaded - t_start, wall() - t_loaded);
 	fprintf(stderr, "[bwa] stage busy time: assemble %.2f s, device call %.2f s, format %.2f s\n", tm_asm, tm_gpu, tm_fmt);
-	{ std::unique_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
+	{ std::shared_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
 	feed1.th.join(); if (feed2) feed2->th.join();
 	gzclose(fp1); if (fp2) gzclose(fp2);
 	ssg_index_destroy(idx);

@@ -53,7 +53,7 @@ struct fq_stream_t {                    /* kstream over gzread */
 			if (begin >= end) { if (!fill()) break; }
 			int i;
 			if (delim == 2) { const unsigned char *p = (const unsigned char*)memchr(buf.data() + begin, '\n', (size_t)(end - begin)); i = p ? (int)(p - buf.data()) : end; }
-			else { for (i = begin; i < end; ++i) if (isspace(buf[i])) break; }
+			else { for (i = begin; i < end; ++i) { const unsigned c = buf[i]; if (c == ' ' || (c - 9u) <= 4u) break; } }   /* isspace in the C locale, inline */
 			got = true;
 			out.insert(out.end(), buf.data() + begin, buf.data() + i);
 			begin = i + 1;
@@ -65,7 +65,9 @@ struct fq_stream_t {                    /* kstream over gzread */
 	}
 };
 
-static inline uint8_t fq_nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+struct fq_nt4_tab_t { uint8_t t[256]; fq_nt4_tab_t() { memset(t, 4, 256); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; } };
+static inline const uint8_t *fq_nt4_tab() { static const fq_nt4_tab_t T; return T.t; }
+static inline uint8_t fq_nt4(int c) { return fq_nt4_tab()[(unsigned char)c]; }
 
 struct fq_reader_t {
 	fq_stream_t ks; int last_char; bool keep_comment;
@@ -103,7 +105,7 @@ struct fq_reader_t {
 			if (b.qual.size() - q0 != l_seq) return -2;
 			b.qual.push_back(0); hq = true;
 		}
-		for (size_t i = s0; i < b.seq.size(); ++i) b.seq[i] = fq_nt4(b.seq[i]);
+		{ const uint8_t *const T = fq_nt4_tab(); uint8_t *const q = b.seq.data(); const size_t e = b.seq.size(); for (size_t i = s0; i < e; ++i) q[i] = T[q[i]]; }
 		b.name_o.push_back((uint32_t)name0); b.com_o.push_back(com); b.seq_o.push_back((uint32_t)b.seq.size());
 		b.qual_o.push_back((uint32_t)q0); b.has_q.push_back(hq ? 1 : 0); ++b.n;
 		return (int)l_seq;
@@ -111,14 +113,30 @@ struct fq_reader_t {
 };
 
 /* reader thread: blocks of up to `per_block` records into the channel; the last block carries err / a short count, then the channel closes */
+struct fq_block_pool_t {                /* blocks go back to the reader when their last user lets go: warm memory instead of fresh pages per block */
+	std::mutex mu; std::vector<fq_block_t*> free_;
+	~fq_block_pool_t() { for (fq_block_t *b : free_) delete b; }
+	fq_block_t *get()
+	{
+		fq_block_t *b = 0;
+		{ std::lock_guard<std::mutex> l(mu); if (!free_.empty()) { b = free_.back(); free_.pop_back(); } }
+		if (!b) return new fq_block_t();
+		b->txt.clear(); b->name_o.clear(); b->com_o.clear(); b->seq.clear(); b->qual.clear(); b->seq_o.clear(); b->qual_o.clear(); b->has_q.clear();
+		b->seq_o.push_back(0); b->n = 0; b->err = 0;
+		return b;
+	}
+	void put(fq_block_t *b) { std::lock_guard<std::mutex> l(mu); if (free_.size() < 4096) { free_.push_back(b); return; } delete b; }
+};
 struct fq_feed_t {
-	chan_t<std::unique_ptr<fq_block_t> > ch; std::thread th;
-	fq_feed_t(gzFile fp, bool keep_comment, int per_block) : ch(4)
+	chan_t<std::shared_ptr<fq_block_t> > ch; std::thread th;   /* shared: a batch keeps the blocks its names and qualities point into */
+	std::shared_ptr<fq_block_pool_t> pool;
+	fq_feed_t(gzFile fp, bool keep_comment, int per_block) : ch(4), pool(new fq_block_pool_t())
 	{
 		th = std::thread([this, fp, keep_comment, per_block]() {
 			fq_reader_t rd(fp, keep_comment);
 			for (;;) {
-				std::unique_ptr<fq_block_t> b(new fq_block_t());
+				std::shared_ptr<fq_block_pool_t> pl = pool;
+				std::shared_ptr<fq_block_t> b(pl->get(), [pl](fq_block_t *x) { pl->put(x); });
 				b->txt.reserve((size_t)per_block * 48); b->seq.reserve((size_t)per_block * 160); b->qual.reserve((size_t)per_block * 160);
 				int rc = 0;
 				while (b->n < per_block && (rc = rd.next(*b)) >= 0) {}
@@ -135,14 +153,14 @@ struct fq_feed_t {
 
 /* sequential view over a feed: one record at a time */
 struct fq_cursor_t {
-	fq_feed_t &feed; std::unique_ptr<fq_block_t> cur; int i;
+	fq_feed_t &feed; std::shared_ptr<fq_block_t> cur; int i;
 	explicit fq_cursor_t(fq_feed_t &f) : feed(f), i(0) {}
 	/* 0: record (*blk, *idx) available; -1 EOF; -2 malformed */
 	int next(const fq_block_t **blk, int *idx)
 	{
 		while (!cur || i >= cur->n) {
 			if (cur && cur->err) return cur->err;
-			std::unique_ptr<fq_block_t> nb;
+			std::shared_ptr<fq_block_t> nb;
 			if (!feed.ch.pop(nb)) return -1;
 			cur = std::move(nb); i = 0;
 			if (cur->n == 0 && cur->err) return cur->err;
