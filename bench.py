@@ -77,8 +77,14 @@ def synth_reference(total_len, seed, dev, order=6):
         rev = torch.rand(copies, device=dev, generator=g) < 0.5
         c = torch.where(rev[:, None], (3 - c).flip(1), c)
         pos = (torch.rand(copies, device=dev, generator=g, dtype=torch.float64) * (L - flen)).long()
+        pos, _ = torch.sort(pos)                              # copies of one family must not overlap: an indexed store with duplicate
+        keep = torch.ones(copies, dtype=torch.bool, device=dev)   # targets has no defined winner, and the reference must be the same every run
+        keep[1:] = (pos[1:] - pos[:-1]) >= flen
+        last = torch.cummax(torch.where(keep, pos, torch.zeros_like(pos)), 0)[0]   # start of the last kept copy at or before each one
+        keep[1:] &= (pos[1:] - last[:-1]) >= flen
+        pos, c = pos[keep], c[keep]
         ref[(pos[:, None] + torch.arange(flen, device=dev)[None, :]).reshape(-1)] = c.reshape(-1)
-        planted += copies * flen
+        planted += int(pos.numel()) * flen
         n_fam += 1
     return ref, lens, n_fam
 

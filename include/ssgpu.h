@@ -104,6 +104,9 @@ typedef struct ssg_pe_result ssg_pe_result_t;
 int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
                           const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out);
 void ssg_pe_result_free(ssg_pe_result_t *r);
+/* optional warm-up: page-locks the host blocks the records of `n_calls` concurrent ssg_mem_process_pairs results of about `n_pairs`
+ * pairs will land in (the first calls make them otherwise, ~0.2 s each); bin/bwa runs it next to the index load */
+int ssg_pe_reserve(int n_pairs, int n_calls);
 int64_t ssg_pe_n_req(const ssg_pe_result_t *r);
 const int64_t *ssg_pe_req_off(const ssg_pe_result_t *r);          /* 2*n_pairs+1 offsets into req/alns */
 const ssg_alnreq_t *ssg_pe_req(const ssg_pe_result_t *r);     /* kind 0 = SAM record, 1 = XA entry (owner = region) */

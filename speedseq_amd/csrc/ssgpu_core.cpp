@@ -1100,6 +1100,19 @@ const char *ssg_index_name(const ssg_index_t *ix, int i) { return i >= 0 && i < 
 int32_t ssg_index_len(const ssg_index_t *ix, int i) { return i >= 0 && i < (int)ix->h_len.size() ? ix->h_len[i] : 0; }
 
 void ssg_pe_result_free(ssg_pe_result_t *r) { delete r; }
+int ssg_pe_reserve(int n_pairs, int n_calls)
+{
+	CHK(need_device());
+	if (n_pairs <= 0 || n_calls <= 0 || n_calls > 8) { ssg_err_msg = "ssg_pe_reserve: bad arguments"; return SSG_EINVAL; }
+	const size_t nrec = (size_t)n_pairs * 2 + (size_t)n_pairs / 4;      /* records per pair: 2 + supplementary / XA entries */
+	std::vector<void*> a, b;
+	for (int i = 0; i < n_calls; ++i) { a.push_back(rt_host_alloc(nrec * sizeof(ssg_aln_t))); b.push_back(rt_host_alloc(nrec * sizeof(ssg_alnreq_t))); }
+	int rc = 0;
+	for (void *p : a) { if (!p) rc = SSG_ENOMEM; rt_host_free(p); }
+	for (void *p : b) { if (!p) rc = SSG_ENOMEM; rt_host_free(p); }
+	if (rc) ssg_err_msg = "host allocation failed: page-locked result blocks";
+	return rc;
+}
 int64_t ssg_pe_n_req(const ssg_pe_result_t *r) { return (int64_t)r->req.size(); }
 const int64_t *ssg_pe_req_off(const ssg_pe_result_t *r) { return r->req_off.data(); }
 const ssg_alnreq_t *ssg_pe_req(const ssg_pe_result_t *r) { return r->req.data(); }

@@ -94,7 +94,11 @@ static int main_mem(int argc, char **argv)
 	}
 	ssg_index_t *idx;
 	const double t_start = wall();
-	if (ssg_index_load(argv[ai], &idx)) die("fail to load the index");
+	size_t max_pairs_per_call = 1u << 19;   /* upstream batches are grouped up to this many pairs per device call (one batch alone may exceed it) */
+	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
+	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
+	if (ssg_index_load(argv[ai], &idx)) { t_warm.join(); die("fail to load the index"); }
+	t_warm.join();
 	const double t_loaded = wall();
 	gzFile fp1 = gzopen(argv[ai + 1], "r"), fp2 = 0;
 	if (!fp1) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 1]); return 1; }
@@ -149,8 +153,6 @@ static int main_mem(int argc, char **argv)
 		}
 	};
 	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
-	size_t max_pairs_per_call = 1u << 19;   /* upstream batches are grouped up to this many pairs per device call (one batch alone may exceed it) */
-	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
 	fq_feed_t feed1(fp1, keep_comment, 16384); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384) : 0);
 	chan_t<std::unique_ptr<batch_t> > to_gpu(1), to_fmt(1);
 	int fail = 0; double tm_asm = 0, tm_gpu = 0;
