@@ -22,44 +22,76 @@
 
 static double now(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + 1e-6 * tv.tv_usec; }
 
-typedef struct { gzFile fp; char *buf; size_t cap; int have; } fq_t;
-static int fq_getline(fq_t *f)
-{	/* returns length or -1 at EOF; strips \n and \r */
-	size_t l = 0;
+/* klib kseq_read (htslib/kseq.h:189-229) over gzgetc, restated call for call: the record grammar is whatever that routine accepts
+ * -- '>' or '@' headers, name up to the first blank, the rest of the header line as comment, sequence lines until a line that
+ * starts with '>', '+' or '@', quality lines until as many characters as bases (so a quality line may start with '@') -- and
+ * upstream bseq.c's kseq2bseq1 + trim_readno on top. */
+typedef struct { gzFile fp; int last_char; char *name, *comment, *seq, *qual; size_t nl, cl, sl, ql, nm, cm, sm, qm; } fq_t;
+static void fq_putc(char **s, size_t *l, size_t *m, int c)
+{
+	if (*l + 2 > *m) { *m = *m ? *m << 1 : 256; *s = realloc(*s, *m); }
+	(*s)[(*l)++] = (char)c; (*s)[*l] = 0;
+}
+/* ks_getuntil2: delimiter 0 = any blank (isspace), 2 = end of line; appends; returns the appended length or -1 at EOF with nothing read */
+static int fq_getuntil(fq_t *f, int delim, char **s, size_t *l, size_t *m, int *dret)
+{
+	int c, got = 0; size_t l0 = *l;
+	if (dret) *dret = 0;
+	if (!*s) { *m = 256; *s = malloc(*m); (*s)[0] = 0; }
 	for (;;) {
-		if (f->cap < l + 4096) { f->cap = (l + 4096) * 2; f->buf = realloc(f->buf, f->cap); }
-		if (!gzgets(f->fp, f->buf + l, (int)(f->cap - l))) { if (l == 0) return -1; break; }
-		l += strlen(f->buf + l);
-		if (l && f->buf[l-1] == '\n') break;
+		c = gzgetc(f->fp);
+		if (c == -1) break;
+		got = 1;
+		if (delim == 2 ? c == '\n' : isspace(c)) { if (dret) *dret = c; break; }
+		fq_putc(s, l, m, c);
 	}
-	while (l && (f->buf[l-1] == '\n' || f->buf[l-1] == '\r')) f->buf[--l] = 0;
-	return (int)l;
+	if (!got) return -1;
+	if (delim == 2 && *l > 1 && (*s)[*l - 1] == '\r') (*s)[--*l] = 0;
+	return (int)(*l - l0);
 }
 static uint8_t nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
 
+static int fq_kseq_read(fq_t *f)
+{
+	int c;
+	if (f->last_char == 0) {
+		while ((c = gzgetc(f->fp)) != -1 && c != '>' && c != '@') {}
+		if (c == -1) return -1;
+		f->last_char = c;
+	}
+	f->nl = f->cl = f->sl = f->ql = 0;
+	if (f->name) f->name[0] = 0;
+	if (f->comment) f->comment[0] = 0;
+	if (fq_getuntil(f, 0, &f->name, &f->nl, &f->nm, &c) < 0) return -1;
+	if (c != '\n') fq_getuntil(f, 2, &f->comment, &f->cl, &f->cm, 0);
+	while ((c = gzgetc(f->fp)) != -1 && c != '>' && c != '+' && c != '@') {
+		if (c == '\n') continue;
+		fq_putc(&f->seq, &f->sl, &f->sm, c);
+		fq_getuntil(f, 2, &f->seq, &f->sl, &f->sm, 0);
+	}
+	if (c == '>' || c == '@') f->last_char = c;
+	if (c != '+') return (int)f->sl;
+	while ((c = gzgetc(f->fp)) != -1 && c != '\n') {}
+	if (c == -1) return -2;
+	while (fq_getuntil(f, 2, &f->qual, &f->ql, &f->qm, 0) >= 0 && f->ql < f->sl) {}
+	f->last_char = 0;
+	if (f->sl != f->ql) return -2;
+	return (int)f->sl;
+}
+
 static int fq_read1(fq_t *f, orc_read_t *r, int keep_comment)
-{	/* one 4-line FASTQ (or 2-line FASTA) record */
-	int l;
-	do { l = fq_getline(f); if (l < 0) return -1; } while (l == 0);
-	if (f->buf[0] != '@' && f->buf[0] != '>') return -2;
-	int is_fq = f->buf[0] == '@';
-	char *p = f->buf + 1, *e = p; while (*e && !isspace((unsigned char)*e)) ++e;
-	r->name = strndup(p, e - p);
-	while (*e && isspace((unsigned char)*e)) ++e;
-	r->comment = (keep_comment && *e) ? strdup(e) : 0;
-	{	/* upstream trim_readno: strip a trailing /1 or /2 */
+{	/* kseq_read, then upstream kseq2bseq1 (comment kept only with -C and when not empty) and trim_readno */
+	const int l = fq_kseq_read(f);
+	if (l < 0) return l;
+	r->name = strdup(f->name ? f->name : "");
+	r->comment = (keep_comment && f->cl) ? strdup(f->comment) : 0;
+	{
 		size_t nl = strlen(r->name);
 		if (nl > 2 && r->name[nl-2] == '/' && isdigit((unsigned char)r->name[nl-1])) r->name[nl-2] = 0;
 	}
-	l = fq_getline(f); if (l < 0) return -2;
-	r->l_seq = l; r->seq = malloc(l + 1);
-	for (int i = 0; i < l; ++i) r->seq[i] = nt4(f->buf[i]);
-	r->qual = 0;
-	if (is_fq) {
-		l = fq_getline(f); if (l < 0 || f->buf[0] != '+') return -2;
-		l = fq_getline(f); if (l != r->l_seq) return -2;
-		r->qual = strdup(f->buf);
-	}
+	r->l_seq = l; r->seq = malloc((size_t)l + 1);
+	for (int i = 0; i < l; ++i) r->seq[i] = nt4(f->seq[i]);
+	r->qual = f->ql ? strdup(f->qual) : 0;
 	r->sam = 0;
 	return 0;
 }
@@ -123,7 +155,8 @@ static int main_mem(int argc, char **argv)
 	double t0 = now();
 	orc_idx_t *idx = orc_idx_load(argv[ai]);
 	if (!idx) { fprintf(stderr, "[orc_bwa] fail to load index %s\n", argv[ai]); return 1; }
-	fq_t f1 = { gzopen(argv[ai+1], "r"), 0, 0, 0 }, f2 = { 0, 0, 0, 0 };
+	fq_t f1, f2; memset(&f1, 0, sizeof(f1)); memset(&f2, 0, sizeof(f2));
+	f1.fp = gzopen(argv[ai+1], "r");
 	if (!f1.fp) { fprintf(stderr, "[orc_bwa] fail to open %s\n", argv[ai+1]); return 1; }
 	if (argc - ai >= 3) { f2.fp = gzopen(argv[ai+2], "r"); if (!f2.fp) { fprintf(stderr, "[orc_bwa] fail to open %s\n", argv[ai+2]); return 1; } }
 	if (!interleaved && !f2.fp) { fprintf(stderr, "[orc_bwa] single-end input is outside the oracle's scope (speedseq align is paired-end)\n"); return 1; }

@@ -66,3 +66,57 @@ def test_cli_error_behaviour(tmp_path, emu_lib):
 @pytest.mark.gpu
 def test_cli_gpu_matches_oracle(tmp_path, gpu_lib):
     _check([os.path.join(ROOT, "bin", "bwa")], [os.path.join(ROOT, "bin", "samblaster")], tmp_path, 6000, seed=23)
+
+
+def _grammar_fastq(pairs, style):
+    """the same reads in the shapes klib's kseq grammar admits: wrapped sequence / quality lines, FASTA records (no qualities),
+    /1 /2 suffixes, comments, CRLF, lower case, blank lines between records"""
+    out = []
+    for k, (name, r1, r2) in enumerate(pairs):
+        for end, r in ((1, r1), (2, r2)):
+            s = "".join("ACGTN"[c] for c in r)
+            q = "".join(chr(33 + (7 * i + k) % 40) for i in range(len(s)))
+            nm = name + ("/%d" % end if style in ("suffix", "mixed") else "")
+            com = " BC:Z:%04d\tXY:i:%d" % (k, end) if style in ("comment", "mixed") else ""
+            eol = "\r\n" if style == "crlf" else "\n"
+            if style == "lower":
+                s = s.lower()
+            if style == "fasta" or (style == "mixed" and k % 3 == 0):
+                out.append(">" + nm + com + eol + s[:70] + eol + s[70:] + eol)
+            elif style in ("wrapped", "mixed"):
+                out.append("@" + nm + com + eol + s[:61] + eol + s[61:] + eol + "+" + nm + eol + q[:33] + eol + q[33:] + eol + (eol if k % 2 else ""))
+            else:
+                out.append("@" + nm + com + eol + s + eol + "+" + eol + q + eol)
+    return "".join(out)
+
+
+@pytest.mark.parametrize("style", ["plain", "wrapped", "fasta", "suffix", "comment", "crlf", "lower", "mixed"])
+def test_cli_emu_fastq_grammar(tmp_path, emu_lib, style):
+    """bin/bwa's reader (host/fastq.h) against the oracle's restatement of kseq_read + trim_readno, through `bwa mem [-C]`"""
+    emu = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 40, seed=77)
+    fq = str(tmp_path / "g.fq")
+    open(fq, "w", newline="").write(_grammar_fastq(pairs, style))
+    extra = ["-C"] if style in ("comment", "mixed") else []
+    got = subprocess.run([emu, "mem", "-t", "2", "-p"] + extra + [EXAMPLE_FA, fq], capture_output=True, check=True).stdout.decode()
+    exp = subprocess.run([ORC, "mem", "-t", "2", "-p"] + extra + [EXAMPLE_FA, fq], capture_output=True, check=True).stdout.decode()
+    assert _no_pg(got) == _no_pg(exp)
+    assert got.count("\n") > 80
+
+
+def test_cli_emu_two_files_and_truncation(tmp_path, emu_lib):
+    emu = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 60, seed=78)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    for path, which in ((f1, 1), (f2, 2)):
+        with open(path, "w") as f:
+            for name, r1, r2 in pairs:
+                r = r1 if which == 1 else r2
+                f.write("@%s/%d\n%s\n+\n%s\n" % (name, which, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    got = subprocess.run([emu, "mem", "-t", "2", EXAMPLE_FA, f1, f2], capture_output=True, check=True).stdout.decode()
+    exp = subprocess.run([ORC, "mem", "-t", "2", EXAMPLE_FA, f1, f2], capture_output=True, check=True).stdout.decode()
+    assert _no_pg(got) == _no_pg(exp)
+    bad = str(tmp_path / "bad.fq")
+    open(bad, "w").write(open(f1).read()[:-40])      # quality string cut short
+    r = subprocess.run([emu, "mem", "-p", EXAMPLE_FA, bad], capture_output=True)
+    assert r.returncode != 0
