@@ -237,7 +237,9 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
         res["gz_input_pairs"] = n_gz
     # parity of the executables on the sample
     _, _, gf = run(bwa, sbl, sfq, "s_gpu", a.bwa_threads)
-    _, _, of = run(orc_exe, orc_exe + " samblaster", sfq, "s_orc", min(os.cpu_count() or 1, 64))   # one upstream batch either way: -t only sets the worker count
+    t_orc, err_orc, of = run(orc_exe, orc_exe + " samblaster", sfq, "s_orc", min(os.cpu_count() or 1, 64))   # one upstream batch either way: -t only sets the worker count
+    res["oracle_cli"] = {"what": "the same command line on the oracle's executables (scalar C port), FASTQ file -> three SAM streams, index load included",
+                         "pairs": ns, "threads": min(os.cpu_count() or 1, 64), "wall_s": round(t_orc, 2), "pairs_per_s": ns / t_orc}
 
     def nopg(p):
         return [l for l in open(p).read().split("\n") if not l.startswith("@PG")]
