@@ -81,8 +81,12 @@ typedef struct { int score, te, qe, score2, te2, tb, qb; } orc_kswr_t;
 #define ORC_KSW_XSTART 0x80000
 orc_kswr_t orc_ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
                           int o_del, int e_del, int o_ins, int e_ins, int xtra);
-extern uint64_t orc_cnt_cells; /* SW cell counter */
-extern uint64_t orc_cnt_extend, orc_cnt_lf, orc_cnt_sa; /* FM-index work counters */
+/* work counters: per thread -- a shared counter bumped in the inner loops makes the worker threads fight over one cache
+ * line -- and folded into the totals by orc_cnt_flush() when a worker is done */
+extern __thread uint64_t orc_cnt_cells __attribute__((tls_model("initial-exec")));                              /* SW cells */
+extern __thread uint64_t orc_cnt_extend __attribute__((tls_model("initial-exec"))), orc_cnt_lf __attribute__((tls_model("initial-exec"))), orc_cnt_sa __attribute__((tls_model("initial-exec")));     /* FM-index work */
+extern uint64_t orc_tot_cells, orc_tot_extend, orc_tot_lf, orc_tot_sa;
+void orc_cnt_flush(void);
 
 /* ---------- seeding / chaining / extension (upstream bwamem.c) ---------- */
 typedef struct { int64_t rbeg; int32_t qbeg, len, score; } orc_seed_t;

@@ -14,7 +14,14 @@
 #include <ctype.h>
 #include "orc.h"
 
-uint64_t orc_cnt_extend, orc_cnt_lf, orc_cnt_sa;
+__thread uint64_t orc_cnt_extend, orc_cnt_lf, orc_cnt_sa;
+uint64_t orc_tot_cells, orc_tot_extend, orc_tot_lf, orc_tot_sa;
+void orc_cnt_flush(void)
+{
+	__atomic_fetch_add(&orc_tot_cells, orc_cnt_cells, __ATOMIC_RELAXED); __atomic_fetch_add(&orc_tot_extend, orc_cnt_extend, __ATOMIC_RELAXED);
+	__atomic_fetch_add(&orc_tot_lf, orc_cnt_lf, __ATOMIC_RELAXED); __atomic_fetch_add(&orc_tot_sa, orc_cnt_sa, __ATOMIC_RELAXED);
+	orc_cnt_cells = orc_cnt_extend = orc_cnt_lf = orc_cnt_sa = 0;
+}
 
 static const uint8_t nt4_table_init[5] = {'A','C','G','T','N'};
 static uint8_t nt4_tab[256]; static int nt4_ready;

@@ -12,7 +12,7 @@
 #include <assert.h>
 #include "orc.h"
 
-uint64_t orc_cnt_cells;
+__thread uint64_t orc_cnt_cells;
 
 typedef struct { int32_t h, e; } eh_t;
 

@@ -192,7 +192,7 @@ static int main_mem(int argc, char **argv)
 		if (rc < 0) break;
 	}
 	fprintf(stderr, "[orc_bwa] %lld reads in %.3f s; cells=%llu extend=%llu lf=%llu sa=%llu\n", (long long)n_processed, now() - t0,
-	        (unsigned long long)orc_cnt_cells, (unsigned long long)orc_cnt_extend, (unsigned long long)orc_cnt_lf, (unsigned long long)orc_cnt_sa);
+	        (unsigned long long)orc_tot_cells, (unsigned long long)orc_tot_extend, (unsigned long long)orc_tot_lf, (unsigned long long)orc_tot_sa);
 	gzclose(f1.fp); if (f2.fp) gzclose(f2.fp);
 	orc_idx_destroy(idx);
 	return 0;
