@@ -45,7 +45,7 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
 	for (i = x + 1, curr->n = 0; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
-			const ssg_intv_t okc = ssg_bwt_extend1(ix, ik, c, 0); ++mem.nx;
+			const ssg_intv_t okc = ssg_bwt_extend1_lean(ix, ik, c, 0); ++mem.nx;
 			if (okc.x2 != ik.x2) {
 				iv_push(*curr, ik);
 				if (okc.x2 < min_intv) break;
@@ -62,7 +62,7 @@ SSG_DEVFN int ssg_smem1(const ssg_index_view_t &ix, int len, const uint8_t *q, i
 		for (j = 0, curr->n = 0; j < prev->n; ++j) {
 			ssg_intv_t p = IV(*prev, j);
 			ssg_intv_t okc; okc.x0 = okc.x1 = okc.x2 = okc.info = 0;
-			if (c >= 0) { okc = ssg_bwt_extend1(ix, p, c, 1); ++mem.nx; }
+			if (c >= 0) { okc = ssg_bwt_extend1_lean(ix, p, c, 1); ++mem.nx; }
 			if (c < 0 || okc.x2 < min_intv) {
 				if (curr->n == 0) {
 					if (mem.n == 0 || (uint64_t)(i + 1) < (IV(mem, mem.n-1).info >> 32)) {
@@ -93,7 +93,7 @@ SSG_DEVFN int ssg_seed_strategy1(const ssg_index_view_t &ix, int len, const uint
 	for (i = x + 1; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
-			const ssg_intv_t okc = ssg_bwt_extend1(ix, ik, c, 0); ++nx;
+			const ssg_intv_t okc = ssg_bwt_extend1_lean(ix, ik, c, 0); ++nx;
 			if (okc.x2 < max_intv && i - x >= min_len) {
 				mem = okc;
 				mem.info = (uint64_t)x << 32 | (uint64_t)(i + 1);
