@@ -19,6 +19,8 @@
 #include <condition_variable>
 #include <thread>
 #include <memory>
+#include <atomic>
+#include <unistd.h>
 
 template <class T> struct chan_t {      /* bounded single-producer / single-consumer channel */
 	std::mutex mu; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed;
@@ -39,10 +41,43 @@ struct fq_block_t {                     /* a run of consecutive records of one f
 	fq_block_t() : n(0), err(0) { seq_o.push_back(0); }
 };
 
-struct fq_stream_t {                    /* kstream over gzread */
-	gzFile fp; std::vector<unsigned char> buf; int begin, end; bool is_eof;
-	explicit fq_stream_t(gzFile f) : fp(f), buf(1 << 20), begin(0), end(0), is_eof(false) { gzbuffer(fp, 1 << 20); }
-	inline bool fill() { if (is_eof) return false; begin = 0; end = gzread(fp, buf.data(), (unsigned)buf.size()); if (end <= 0) { end = 0; is_eof = true; return false; } return true; }
+struct fq_stream_t {                    /* kstream over gzread; for compressed input the inflate runs in a thread of its own, a few 4-MB chunks ahead of the parser */
+	typedef std::vector<unsigned char> chunk_t;
+	gzFile fp; chunk_t buf; int begin, end; bool is_eof;
+	chan_t<std::unique_ptr<chunk_t> > full, empty; std::thread th;
+	std::atomic<bool> stop{false};
+	bool threaded;                      /* compressed input only: for a plain file the hand-over costs more than the read */
+	explicit fq_stream_t(gzFile f) : fp(f), begin(0), end(0), is_eof(false), full(4), empty(8)
+	{
+		gzbuffer(fp, 1 << 20);
+		threaded = !gzdirect(fp);
+		if (!threaded) { buf.resize((size_t)1 << 20); return; }
+		th = std::thread([this]() {
+			while (!stop.load()) {
+				std::unique_ptr<chunk_t> c;
+				{ std::unique_lock<std::mutex> l(empty.mu); if (!empty.q.empty()) { c = std::move(empty.q.front()); empty.q.pop_front(); } }   /* a recycled chunk if one is back */
+				if (!c) c.reset(new chunk_t());
+				c->resize((size_t)4 << 20);
+				const int n = gzread(fp, c->data(), (unsigned)c->size());
+				if (n <= 0) break;
+				c->resize((size_t)n);
+				full.push(std::move(c));
+			}
+			full.close();
+		});
+	}
+	~fq_stream_t() { stop.store(true); if (threaded) { std::unique_ptr<chunk_t> c; while (full.pop(c)) {} } if (th.joinable()) th.join(); }
+	inline bool fill()
+	{
+		if (is_eof) return false;
+		if (!threaded) { begin = 0; end = gzread(fp, buf.data(), (unsigned)buf.size()); if (end <= 0) { end = 0; is_eof = true; return false; } return true; }
+		std::unique_ptr<chunk_t> c;
+		if (!full.pop(c)) { begin = end = 0; is_eof = true; return false; }
+		buf.swap(*c);
+		{ std::lock_guard<std::mutex> l(empty.mu); if (empty.q.size() < 8) empty.q.push_back(std::move(c)); }
+		begin = 0; end = (int)buf.size();
+		return true;
+	}
 	inline int getc() { if (begin >= end && !fill()) return -1; return buf[begin++]; }
 	/* ks_getuntil2: append to out until the delimiter (0 = any blank, 2 = end of line); returns -1 at EOF with nothing read; *dret = delimiter */
 	template <class V> int getuntil(int delim, V &out, int *dret)
