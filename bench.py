@@ -250,6 +250,39 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
     return res
 
 
+def script_leg(td, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, sort_mem_gb=40):
+    """SURVEY.md 8d's own definition of the metric: the reference's `speedseq align` (the script itself, unmodified -- the fixture copy
+    tests/golden/speedseq_ref_script.sh, or /root/reference/bin/speedseq where that exists) on the product executables, wall clock from
+    FASTQ open to the three coordinate-sorted, indexed BAMs closed.  The index files are already next to `ref_prefix`."""
+    import shutil
+    import subprocess
+    script = "/root/reference/bin/speedseq" if os.path.exists("/root/reference/bin/speedseq") else os.path.join(ROOT, "tests", "golden", "speedseq_ref_script.sh")
+    awk = shutil.which("gawk") or shutil.which("mawk") or shutil.which("awk")
+    if not os.path.exists(script) or awk is None:
+        return {"skipped": "reference script fixture or awk not available"}
+    d = os.path.join(td, "script")
+    bindir = os.path.join(d, "bin")
+    os.makedirs(bindir)
+    if not shutil.which("gawk"):
+        os.symlink(awk, os.path.join(bindir, "gawk"))           # the script hard-codes `gawk`
+    if not os.path.exists(ref_prefix):
+        open(ref_prefix, "w").write(">placeholder: the five index files next to this name are what bwa mem reads\n")
+    cfg = os.path.join(d, "speedseq.config")
+    open(cfg, "w").write("BWA=%s\nSAMBLASTER=%s\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\n" % (bwa, samblaster, sambamba, ROOT))
+    out = os.path.join(d, "out")
+    env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
+    t = time.perf_counter()
+    r = subprocess.run(["bash", script, "align", "-K", cfg, "-o", out, "-M", str(sort_mem_gb), "-t", str(threads), "-p",
+                        "-R", "@RG\\tID:bench\\tSM:bench\\tLB:lib1", ref_prefix, fq], cwd=d, env=env, capture_output=True, text=True)
+    t = time.perf_counter() - t
+    if r.returncode != 0:
+        return {"error": (r.stdout[-400:] + r.stderr[-400:])}
+    sizes = {x: os.path.getsize(out + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
+    ok = all(os.path.exists(out + x + ".bai") for x in sizes)
+    return {"what": "`speedseq align -t %d -p` (the reference's script, unmodified) on bin/bwa, bin/samblaster, bin/sambamba: FASTQ file -> three coordinate-sorted BAMs + BAI, wall clock incl. index load" % threads,
+            "pairs": n_pairs, "wall_s": round(t, 2), "pairs_per_s": n_pairs / t, "bam_bytes": sizes, "bai_written": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -497,6 +530,11 @@ def main():
                     out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, ns, orc_exe=os.path.join(ROOT, "oracle", "orc_bwa"))
                     if not out["e2e"].get("sample_streams_identical", True):
                         ok = False
+                    b = lambda n: os.path.join(ROOT, "bin", n)
+                    try:
+                        out["e2e"]["speedseq_align_script"] = script_leg(td, prefix, os.path.join(td, "reads.fq"), out["e2e"]["pairs"], a.bwa_threads, b("bwa"), b("samblaster"), b("sambamba"))
+                    except Exception as e:
+                        out["e2e"]["speedseq_align_script"] = {"error": repr(e)}
                 except Exception as e:      # the plugin-path measurement must not take the headline down with it
                     out["e2e"] = {"error": repr(e)}
             td_obj.cleanup()
