@@ -247,6 +247,9 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
     res["sample_pairs"] = ns
     res["sample_streams_identical"] = bool(all(same))
     res["sample_streams"] = {"sam": same[0], "splitters": same[1], "discordants": same[2]}
+    for f in os.listdir(td):                              # the multi-GB SAM streams of the timed runs: free /dev/shm for what follows
+        if f.startswith(("full.", "fullgz.", "dbg.")) or f.endswith(".fq.gz"):
+            os.remove(os.path.join(td, f))
     return res
 
 
