@@ -124,7 +124,6 @@ struct bgzf_in_t {
 	bool fill_raw(size_t need)
 	{
 		while (raw.size() - raw_pos < need && !eof) {
-			if (raw_pos > ((size_t)32 << 20)) { raw.erase(raw.begin(), raw.begin() + raw_pos); raw_pos = 0; }
 			const size_t old = raw.size(); raw.resize(old + ((size_t)8 << 20));
 			ssize_t r = read(fd, raw.data() + old, (size_t)8 << 20);
 			if (r < 0) { if (errno == EINTR) { raw.resize(old); continue; } perror("[sambamba] read"); exit(1); }
@@ -137,6 +136,7 @@ struct bgzf_in_t {
 	{	/* up to 512 blocks */
 		struct span_t { size_t off, len; uint64_t addr; };
 		std::vector<span_t> sp;
+		if (raw_pos > ((size_t)8 << 20)) { raw.erase(raw.begin(), raw.begin() + raw_pos); raw_pos = 0; }   /* consumed bytes go here, between batches: the spans below are offsets into raw */
 		while (sp.size() < 512) {
 			if (!fill_raw(18)) break;
 			const uint8_t *h = raw.data() + raw_pos;

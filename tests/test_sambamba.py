@@ -110,3 +110,28 @@ def test_sambamba_emu_matches_samtools(tmp_path, emu_lib, monkeypatch):
 @pytest.mark.gpu
 def test_sambamba_gpu_matches_samtools(tmp_path, gpu_lib, monkeypatch):
     _check([os.path.join(ROOT, "bin", "sambamba")], tmp_path, monkeypatch)
+
+
+def test_sambamba_emu_stream_of_many_blocks(tmp_path, emu_lib):
+    """`view -S -f bam -l 0 | sort` as the reference wires it (bin/speedseq:440-441) on a stream of > 512 BGZF blocks of 64 KB
+    (45 MB): the reader's read-ahead buffer is compacted between batches of blocks, not inside one (it used to be: 'inflate failed'
+    on any BAM with more than ~32 MB per 512 blocks, i.e. every real one at compression level 0)"""
+    sambamba = os.path.join(ROOT, "tests", "emu", "sambamba_emu")
+    sam = _sam(tmp_path, n_pairs=1500, seed=33)
+    lines = open(sam).read().split("\n")
+    hdr = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if l and not l.startswith("@")]
+    big = str(tmp_path / "big.sam")
+    with open(big, "w") as f:
+        f.write("\n".join(hdr) + "\n")
+        for k in range(45):
+            f.write("\n".join(body) + "\n")
+    out = str(tmp_path / "sorted.bam")
+    subprocess.check_call("%s view -S -f bam -l 0 %s | %s sort -t 4 -m 8G --tmpdir=%s -o %s /dev/stdin" % (sambamba, big, sambamba, str(tmp_path), out), shell=True)
+    subprocess.check_call([sambamba, "index", out])
+    assert os.path.getsize(big) > 40 << 20
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", out])) == 45 * len(body)
+    ref = str(tmp_path / "ref.bam")
+    subprocess.check_call("%s view -b -u %s | %s sort -o %s -" % (SAMTOOLS, big, SAMTOOLS, ref), shell=True, stderr=subprocess.DEVNULL)
+    assert _view(out).split("\n")[len(hdr):] == _view(ref).split("\n")[len(hdr):] or \
+        [l for l in _view(out).split("\n") if not l.startswith("@")] == [l for l in _view(ref).split("\n") if not l.startswith("@")]
