@@ -165,6 +165,7 @@ static int main_mem(int argc, char **argv)
 		for (i = 0; i < argc && l < sizeof(cl) - 1; ++i) l += snprintf(cl + l, sizeof(cl) - l, "%s%s", i ? " " : "bwa ", argv[i]);
 		char *h = orc_sam_header(idx, rg, cl); fputs(h, stdout); free(h);
 	}
+	{ const char *e = getenv("ORC_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: many batches from a small input */
 	int64_t n_processed = 0, chunk = (int64_t)opt.chunk_size * opt.n_threads;
 	for (;;) {
 		orc_read_t *s = 0; int n = 0, m = 0; int64_t size = 0; int rc = 0;

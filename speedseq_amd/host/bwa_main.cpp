@@ -152,6 +152,7 @@ static int main_mem(int argc, char **argv)
 			for (std::thread &x : th) x.join();
 		}
 	};
+	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
 	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
 	fq_feed_t feed1(fp1, keep_comment, 16384); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384) : 0);
 	chan_t<std::unique_ptr<batch_t> > to_gpu(1), to_fmt(1);

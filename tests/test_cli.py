@@ -120,3 +120,24 @@ def test_cli_emu_two_files_and_truncation(tmp_path, emu_lib):
     open(bad, "w").write(open(f1).read()[:-40])      # quality string cut short
     r = subprocess.run([emu, "mem", "-p", EXAMPLE_FA, bad], capture_output=True)
     assert r.returncode != 0
+
+
+def test_cli_emu_many_batches_and_device_calls(tmp_path, emu_lib, monkeypatch):
+    """upstream batches of ~130 pairs (one insert-size model each), grouped two or three to a device call, over a dozen calls: the
+    batch assembly, pair ordinals and per-batch models of bin/bwa against the oracle's loop, through samblaster"""
+    monkeypatch.setenv("SSG_BWA_CHUNK_BASES", "20000")
+    monkeypatch.setenv("ORC_CHUNK_BASES", "20000")
+    monkeypatch.setenv("SSG_BWA_CALL_PAIRS", "300")
+    monkeypatch.setenv("SSG_SBL_CHUNK", "113")
+    emu = os.path.join(ROOT, "tests", "emu")
+    _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 1700, seed=29)
+
+
+@pytest.mark.gpu
+def test_cli_gpu_many_batches_and_device_calls(tmp_path, gpu_lib, monkeypatch):
+    monkeypatch.setenv("SSG_BWA_CHUNK_BASES", "20000")
+    monkeypatch.setenv("ORC_CHUNK_BASES", "20000")
+    monkeypatch.setenv("SSG_BWA_CALL_PAIRS", "700")
+    monkeypatch.setenv("SSG_SBL_CHUNK", "313")
+    b = os.path.join(ROOT, "bin")
+    _check([os.path.join(b, "bwa")], [os.path.join(b, "samblaster")], tmp_path, 5000, seed=30)
