@@ -16,6 +16,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include "bamio.h"
+#include "fastq.h"   /* chan_t */
 #include "../../include/ssgpu.h"
 
 static int hw_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)std::min(n, 32u) : 4; }
@@ -48,19 +49,35 @@ static int cmd_view(int argc, char **argv)
 	if (!sam_in || strcmp(fmt, "bam")) die("view: only `-S -f bam` (SAM text to BAM) and `-H` are supported");
 	bgzf_out_t out(1, level, threads);
 	bam_hdr_t h; bool hdr_done = false;
-	std::vector<char> buf((size_t)64 << 20); size_t have = 0; bool eof = false;
-	while (!eof || have) {
-		if (!eof) {
-			if (have == buf.size()) buf.resize(buf.size() * 2);
-			ssize_t r = read(fd, buf.data() + have, buf.size() - have);
-			if (r < 0) { if (errno == EINTR) continue; die("view: read error"); }
-			if (r == 0) { eof = true; if (have && buf[have - 1] != '\n') { if (have == buf.size()) buf.resize(have + 1); buf[have++] = '\n'; } }
-			else have += (size_t)r;
-			if (!eof && have < buf.size() / 2) continue;      /* work on large pieces */
+	/* a reader thread cuts stdin into pieces of whole lines (the pipe from samblaster is read while the previous piece is encoded) */
+	struct piece_t { std::vector<char> buf; size_t end; };
+	chan_t<std::unique_ptr<piece_t> > ch(2);
+	std::thread reader([&]() {
+		std::vector<char> carry; bool eof = false;
+		while (!eof) {
+			std::unique_ptr<piece_t> P(new piece_t());
+			P->buf.resize((size_t)48 << 20);
+			size_t have = carry.size();
+			if (have > P->buf.size() / 2) P->buf.resize(have * 2 + ((size_t)1 << 20));
+			memcpy(P->buf.data(), carry.data(), have); carry.clear();
+			while (!eof && have < P->buf.size()) {
+				ssize_t r = read(fd, P->buf.data() + have, P->buf.size() - have);
+				if (r < 0) { if (errno == EINTR) continue; die("view: read error"); }
+				if (r == 0) { eof = true; break; }
+				have += (size_t)r;
+			}
+			if (eof && have && P->buf[have - 1] != '\n') { if (have == P->buf.size()) P->buf.resize(have + 1); P->buf[have++] = '\n'; }
+			size_t end = have;
+			while (end > 0 && P->buf[end - 1] != '\n') --end;       /* complete lines only; the rest starts the next piece */
+			carry.assign(P->buf.data() + end, P->buf.data() + have);
+			P->end = end;
+			if (end) ch.push(std::move(P));
 		}
-		size_t end = have;
-		while (end > 0 && buf[end - 1] != '\n') --end;           /* complete lines only */
-		if (end == 0) { if (eof) break; continue; }
+		ch.close();
+	});
+	std::unique_ptr<piece_t> P;
+	while (ch.pop(P)) {
+		const std::vector<char> &buf = P->buf; const size_t end = P->end;
 		size_t p = 0;
 		while (!hdr_done && p < end) {
 			if (buf[p] != '@') { hdr_done = true; hdr_from_text(h); hdr_write(out, h); break; }
@@ -69,28 +86,34 @@ static int cmd_view(int argc, char **argv)
 			p = (size_t)(nl - buf.data()) + 1;
 		}
 		if (hdr_done && p < end) {
-			/* line starts, then threads encode contiguous ranges of lines */
-			std::vector<size_t> ls;
-			for (size_t q = p; q < end; ) { ls.push_back(q); const char *nl = (const char*)memchr(buf.data() + q, '\n', end - q); q = (size_t)(nl - buf.data()) + 1; }
-			ls.push_back(end);
-			const size_t nl_ = ls.size() - 1;
-			std::vector<std::vector<uint8_t> > enc((size_t)threads); std::vector<std::string> errs((size_t)threads);
-			parallel_for(threads, nl_, [&](size_t a, size_t b, int t) {
-				enc[(size_t)t].reserve((b - a) * 400);
-				for (size_t i = a; i < b && errs[(size_t)t].empty(); ++i) {
-					const char *s = buf.data() + ls[i], *e = buf.data() + ls[i + 1] - 1;
-					while (e > s && e[-1] == '\r') --e;
-					if (e == s) continue;
-					std::string er;
-					if (sam_line_to_bam(s, e, h, enc[(size_t)t], er)) errs[(size_t)t] = er + ": " + std::string(s, std::min<size_t>(80, (size_t)(e - s)));
+			/* threads take byte ranges cut at line ends and encode the lines inside */
+			const size_t T = (size_t)std::max(1, threads);
+			std::vector<size_t> cutp(T + 1, end); cutp[0] = p;
+			for (size_t t = 1; t < T; ++t) {
+				size_t q = p + (end - p) * t / T;
+				if (q < cutp[t - 1]) q = cutp[t - 1];
+				const char *nl = q < end ? (const char*)memchr(buf.data() + q, '\n', end - q) : 0;
+				cutp[t] = nl ? (size_t)(nl - buf.data()) + 1 : end;
+			}
+			std::vector<std::vector<uint8_t> > enc(T); std::vector<std::string> errs(T);
+			parallel_for((int)T, T, [&](size_t a, size_t b, int) {
+				for (size_t t = a; t < b; ++t) {
+					enc[t].reserve((cutp[t + 1] - cutp[t]) * 9 / 10 + 1024);
+					for (size_t q = cutp[t]; q < cutp[t + 1] && errs[t].empty(); ) {
+						const char *s = buf.data() + q, *nl = (const char*)memchr(s, '\n', cutp[t + 1] - q), *e = nl;
+						q = (size_t)(nl - buf.data()) + 1;
+						while (e > s && e[-1] == '\r') --e;
+						if (e == s) continue;
+						std::string er;
+						if (sam_line_to_bam(s, e, h, enc[t], er)) errs[t] = er + ": " + std::string(s, std::min<size_t>(80, (size_t)(e - s)));
+					}
 				}
 			});
 			for (auto &er : errs) if (!er.empty()) die("view: malformed SAM line (" + er + ")");
-			for (auto &v : enc) for (size_t o = 0; o < v.size(); ) { uint32_t bs; memcpy(&bs, v.data() + o, 4); out.record(v.data() + o, 4 + (size_t)bs); o += 4 + (size_t)bs; }
+			for (auto &v : enc) out.put(v.data(), v.size());        /* records may straddle BGZF blocks (bgzf_write), as in any BAM stream */
 		}
-		memmove(buf.data(), buf.data() + end, have - end); have -= end;
-		if (eof && !have) break;
 	}
+	reader.join();
 	if (!hdr_done) { hdr_from_text(h); hdr_write(out, h); }
 	out.finish();
 	return 0;
