@@ -13,6 +13,7 @@
 #include <ctype.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <thread>
 #include <memory>
 #include <zlib.h>
@@ -96,6 +97,7 @@ static int main_mem(int argc, char **argv)
 	const double t_start = wall();
 	size_t max_pairs_per_call = 1u << 19;   /* upstream batches are grouped up to this many pairs per device call (one batch alone may exceed it) */
 	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
+	if (getenv("SSG_BWA_PROF")) { ssg_prof_reset(); ssg_prof_enable(1); }
 	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
 	if (ssg_index_load(argv[ai], &idx)) { t_warm.join(); die("fail to load the index"); }
 	t_warm.join();
@@ -235,6 +237,13 @@ static int main_mem(int argc, char **argv)
 	t_asm.join(); t_gpu.join();
 	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> SAM %.2f s\n", t_loaded - t_start, wall() - t_loaded);
 	fprintf(stderr, "[bwa] stage busy time: assemble %.2f s, device call %.2f s, format %.2f s\n", tm_asm, tm_gpu, tm_fmt);
+	if (getenv("SSG_BWA_PROF")) {   /* per-kernel device time of the whole run (HIP events; the profiling was switched on before the first call) */
+		const char *nm[256]; double ms[256]; long cnt[256];
+		const int n = std::min(ssg_prof_get(256, nm, ms, cnt), 256);
+		std::vector<int> o(n); for (int i = 0; i < n; ++i) o[i] = i;
+		std::sort(o.begin(), o.end(), [&](int a, int b) { return ms[a] > ms[b]; });
+		for (int i = 0; i < n && i < 24; ++i) fprintf(stderr, "[bwa] kernel %-28s %9.1f ms in %ld launches\n", nm[o[i]], ms[o[i]], cnt[o[i]]);
+	}
 	{ std::shared_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
 	feed1.th.join(); if (feed2) feed2->th.join();
 	gzclose(fp1); if (fp2) gzclose(fp2);
