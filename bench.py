@@ -222,11 +222,13 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
                 "sam_bytes": os.path.getsize(files[0]), "splitter_bytes": os.path.getsize(files[1]), "discordant_bytes": os.path.getsize(files[2])})
     if os.environ.get("SSG_E2E_STAGE_LOG"):              # diagnostics: the same run with the library's per-stage wall times (adds a sync per stage)
         os.environ["SSG_DEBUG"] = "1"
+        os.environ["SSG_BWA_PROF"] = "1"                 # ... and its per-kernel device time over the whole run
         try:
             _, errd, _ = run(bwa, sbl, fq, "dbg", a.bwa_threads)
             open(os.environ["SSG_E2E_STAGE_LOG"], "w").write(errd)
         finally:
             del os.environ["SSG_DEBUG"]
+            del os.environ["SSG_BWA_PROF"]
     # gz input (the reference pipeline reads .fq.gz): one inflate stream bounds the ingest
     n_gz = min(res["pairs"], 2000000)                     # fixed-width records: a byte prefix is a whole number of pairs
     rec_bytes = os.path.getsize(fq) // (2 * res["pairs"])
