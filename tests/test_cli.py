@@ -132,12 +132,3 @@ def test_cli_emu_many_batches_and_device_calls(tmp_path, emu_lib, monkeypatch):
     emu = os.path.join(ROOT, "tests", "emu")
     _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 1700, seed=29)
 
-
-@pytest.mark.gpu
-def test_cli_gpu_many_batches_and_device_calls(tmp_path, gpu_lib, monkeypatch):
-    monkeypatch.setenv("SSG_BWA_CHUNK_BASES", "20000")
-    monkeypatch.setenv("ORC_CHUNK_BASES", "20000")
-    monkeypatch.setenv("SSG_BWA_CALL_PAIRS", "700")
-    monkeypatch.setenv("SSG_SBL_CHUNK", "313")
-    b = os.path.join(ROOT, "bin")
-    _check([os.path.join(b, "bwa")], [os.path.join(b, "samblaster")], tmp_path, 5000, seed=30)
