@@ -32,7 +32,7 @@ def _need_tools():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
-def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM):
+def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM, fq2=None):
     """runs the reference script in directory d with wrappers around the given executables; returns the output prefix"""
     os.makedirs(d)
     bindir = os.path.join(d, "bin")
@@ -49,8 +49,8 @@ def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM):
     shutil.copy(EXAMPLE_FA, ref)   # no index next to it: the script must call `$BWA index`
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
     out = os.path.join(d, "example")
-    r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", out, "-M", "3", "-t", str(n_threads), "-p",
-                        "-R", "@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1", ref, fq],
+    r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", out, "-M", "3", "-t", str(n_threads)] + ([] if fq2 else ["-p"]) +
+                       ["-R", "@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1", ref, fq] + ([fq2] if fq2 else []),
                        cwd=d, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for ext in ("amb", "ann", "bwt", "pac", "sa"):     # `$BWA index` ran and wrote upstream's bytes
@@ -113,3 +113,26 @@ def test_reference_align_script_with_product_executables(tmp_path, gpu_lib):
     out = _run_align(str(tmp_path / "gpu"), os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster"), fq, sambamba=os.path.join(ROOT, "bin", "sambamba"))
     _check_outputs(out)
     _compare(out, exp)
+
+
+def test_reference_align_script_two_fastq_files_emulated(tmp_path, emu_lib):
+    """`speedseq align ref.fa in1.fq.gz in2.fq.gz` (bin/speedseq:468-469: `bwa mem` without -p on two files)"""
+    _need_tools()
+    import gzip
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 700, seed=12)
+    f1, f2 = str(tmp_path / "r1.fq.gz"), str(tmp_path / "r2.fq.gz")
+    for path, which in ((f1, 1), (f2, 2)):
+        with gzip.open(path, "wt") as f:
+            for name, r1, r2 in pairs:
+                r = r1 if which == 1 else r2
+                f.write("@%s/%d\n%s\n+\n%s\n" % (name, which, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    exp = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", f1, fq2=f2)
+    out = _run_align(str(tmp_path / "emu"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), f1, sambamba=os.path.join(EMU, "sambamba_emu"), fq2=f2)
+    _check_outputs_min(out)
+    _compare(out, exp)
+
+
+def _check_outputs_min(out):
+    for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
+        assert os.path.getsize(out + suffix) > 0 and os.path.exists(out + suffix + ".bai")
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", out + ".bam"])) >= 1400
