@@ -158,3 +158,32 @@ def test_reference_realign_script_with_product_executables(tmp_path, gpu_lib):
     src = ts._run_align(str(tmp_path / "align"), b("bwa"), b("samblaster"), fq, sambamba=b("sambamba"))
     out = _run_realign(str(tmp_path / "realign"), src + ".bam", b("bwa"), b("samblaster"), b("sambamba"))
     _check_realigned(out, src)
+
+
+def test_reference_realign_script_two_libraries_emulated(tmp_path, emu_lib):
+    """a BAM with two read groups in two libraries: the script realigns each library on its own (bamlibs, bamtofastq -r), then
+    `sambamba merge`s the three kinds of BAM and indexes them (bin/speedseq:1986-2025)"""
+    ts._need_tools(); _need_bamkit()
+    emu = lambda n: os.path.join(ts.EMU, n)
+    srcs = []
+    for k, (rgid, lib, seed) in enumerate((("rgA", "L1", 41), ("rgB", "L2", 42))):
+        fq = str(tmp_path / ("reads%d.fq.gz" % k))
+        simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 400, seed=seed, prefix="q%d_" % k))
+        srcs.append(ts._run_align(str(tmp_path / ("align%d" % k)), emu("bwa_emu"), emu("samblaster_emu"), fq, sambamba=emu("sambamba_emu"),
+                                  rg="@RG\\tID:%s\\tSM:s\\tLB:%s" % (rgid, lib)))
+    merged = str(tmp_path / "both.bam")
+    subprocess.check_call([emu("sambamba_emu"), "merge", "-t", "2", merged, srcs[0] + ".bam", srcs[1] + ".bam"])
+    out = _run_realign(str(tmp_path / "realign"), merged, emu("bwa_emu"), emu("samblaster_emu"), emu("sambamba_emu"))
+    for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
+        assert os.path.getsize(out + suffix) > 0 and os.path.exists(out + suffix + ".bai")
+    hdr = subprocess.check_output([ts.SAMTOOLS, "view", "-H", out + ".bam"], text=True)
+    assert "@RG\tID:rgA\tSM:s\tLB:L1" in hdr and "@RG\tID:rgB\tSM:s\tLB:L2" in hdr and "SO:coordinate" in hdr
+    a, b = _primary(merged), _primary(out + ".bam")
+    assert set(a) == set(b) and len(a) == 1600
+    rg = lambda f: [t for t in f[11:] if t.startswith("RG:Z:")][0]
+    assert all(rg(a[k]) == rg(b[k]) for k in a)
+    assert all(rg(b[k]) == ("RG:Z:rgA" if k[0].startswith("q0_") else "RG:Z:rgB") for k in b)
+    same = sum(1 for k in a if a[k][2:4] == b[k][2:4] and a[k][5] == b[k][5])
+    assert same >= 0.99 * len(a), (same, len(a))
+    pos = [(l.split("\t")[2], int(l.split("\t")[3])) for l in subprocess.check_output([ts.SAMTOOLS, "view", "-F", "4", out + ".bam"], text=True).split("\n") if l]
+    assert pos == sorted(pos, key=lambda x: (x[0] != "20_slice", x[1]))                      # merged output is coordinate-sorted

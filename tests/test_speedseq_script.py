@@ -32,7 +32,7 @@ def _need_tools():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
-def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM, fq2=None):
+def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM, fq2=None, rg="@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1"):
     """runs the reference script in directory d with wrappers around the given executables; returns the output prefix"""
     os.makedirs(d)
     bindir = os.path.join(d, "bin")
@@ -50,7 +50,7 @@ def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM, fq2=N
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
     out = os.path.join(d, "example")
     r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", out, "-M", "3", "-t", str(n_threads)] + ([] if fq2 else ["-p"]) +
-                       ["-R", "@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1", ref, fq] + ([fq2] if fq2 else []),
+                       ["-R", rg, ref, fq] + ([fq2] if fq2 else []),
                        cwd=d, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for ext in ("amb", "ann", "bwt", "pac", "sa"):     # `$BWA index` ran and wrote upstream's bytes
