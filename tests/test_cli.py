@@ -132,3 +132,24 @@ def test_cli_emu_many_batches_and_device_calls(tmp_path, emu_lib, monkeypatch):
     emu = os.path.join(ROOT, "tests", "emu")
     _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 1700, seed=29)
 
+
+
+@pytest.mark.parametrize("opts", [
+    [],                                                                          # no --excludeDups (speedseq align -i), no mate tags
+    ["--addMateTags"],
+    ["--excludeDups", "--addMateTags", "--maxSplitCount", "1", "--minNonOverlap", "50"],
+    ["--excludeDups", "--maxSplitCount", "3", "--minNonOverlap", "5"],
+])
+def test_cli_emu_samblaster_option_sets(tmp_path, emu_lib, opts):
+    """the option sets `speedseq align` can produce (-i, -c, -m: bin/speedseq:228-243) and samblaster's own defaults, vs the oracle"""
+    emu = os.path.join(ROOT, "tests", "emu")
+    fq = str(tmp_path / "r.fq.gz")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 500, seed=51, chim_frac=0.05, disc_frac=0.05, dup_frac=0.1))
+    sam = subprocess.run([ORC, "mem", "-t", "4", "-p", EXAMPLE_FA, fq], capture_output=True, check=True).stdout
+    res = []
+    for tag, exe in (("got", [os.path.join(emu, "samblaster_emu")]), ("exp", [ORC, "samblaster"])):
+        spl, disc = str(tmp_path / (tag + ".spl")), str(tmp_path / (tag + ".disc"))
+        p = subprocess.run(exe + opts + ["--splitterFile", spl, "--discordantFile", disc], input=sam, capture_output=True, check=True)
+        res.append((_no_pg(p.stdout.decode()), _no_pg(open(spl).read()), _no_pg(open(disc).read())))
+    assert res[0] == res[1]
+    assert res[0][2].count("\n") > 5 and (res[0][1].count("\n") > 5 or "1" in opts[opts.index("--maxSplitCount") + 1:][:1])   # one piece per read can never be a split
