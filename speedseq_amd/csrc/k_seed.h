@@ -247,7 +247,9 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 /* next start position of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
 #define SM_DO_P3() do { while (x < len && SMQ(x) > 3) ++x; if (x >= len) state = SM_OUT; else { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } } while (0)
 #define SM_DO_RET() do { if (caller == 1) { x = ret; state = SM_P1; } else { ++k; state = SM_P2; } } while (0)
+	unsigned long long tn_adv = 0, tn_ext = 0, tn_rounds = 0, tn_ready = 0, tn_alive = 0, tn_t0 = 0;   /* SSG_TUNING only: cycles in the state machine / at the extension site, rounds, ready and live lanes per round */
 	for (;;) {
+		if (SSG_TUNING) tn_t0 = ssg_clock();
 		/* a bounded number of state-machine steps per extension round: a lane in the middle of a transition sits the round out instead of
 		 * making the whole wave spin through the switch again (the wave pays for every trip, whoever needs it) */
 		SSG_UNROLL for (int trip = 0; trip < SSG_SMQ_TRIPS; ++trip) if (pend == SM_PEND_NONE && state != SM_FIN) {
@@ -347,6 +349,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 				break;
 			}
 		}
+		if (SSG_TUNING) { const unsigned long long t1 = ssg_clock(); tn_adv += t1 - tn_t0; tn_t0 = t1; ++tn_rounds; tn_ready += (unsigned long long)__popcll(wv_ballot(pend != SM_PEND_NONE)); tn_alive += (unsigned long long)__popcll(wv_ballot(state != SM_FIN)); }
 		if (state == SM_FIN) break;
 		if (pend == SM_PEND_NONE) continue;
 		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
@@ -398,6 +401,11 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 			}
 			pend = SM_PEND_NONE;
 		}
+		if (SSG_TUNING) tn_ext += ssg_clock() - tn_t0;
+	}
+	if (SSG_TUNING) {   /* slots 24..28: the lane that ran longest speaks for its wave (all live lanes of a wave count the same rounds) */
+		const int a = wv_max((int)(tn_adv >> 4)), e = wv_max((int)(tn_ext >> 4)), r = wv_max((int)tn_rounds), y = wv_max((int)(tn_ready >> 6)), v = wv_max((int)(tn_alive >> 6));
+		if (lane == 0) { atomicAdd(&ssg_dbg_cyc[24], (unsigned long long)a << 4); atomicAdd(&ssg_dbg_cyc[25], (unsigned long long)e << 4); atomicAdd(&ssg_dbg_cyc[26], (unsigned long long)r); atomicAdd(&ssg_dbg_cyc[27], (unsigned long long)y); atomicAdd(&ssg_dbg_cyc[28], (unsigned long long)v); }
 	}
 #undef SMQ
 #undef SMV

@@ -216,15 +216,15 @@ int ssg_prof_get(int, const char **, double *, long *) { return 0; }
 #endif
 
 /* tuning aid: device phase counters (cycles) accumulated by instrumented kernels; reset on read */
-int ssg_dbg_cycles(unsigned long long out[24])
+int ssg_dbg_cycles(unsigned long long out[32])
 {
 #ifdef SSG_EMU
-	memcpy(out, ssg_dbg_cyc, 192); memset(ssg_dbg_cyc, 0, 192);
+	memcpy(out, ssg_dbg_cyc, 256); memset(ssg_dbg_cyc, 0, 256);
 	return 0;
 #else
-	unsigned long long z[24]; memset(z, 0, sizeof z);
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 192) != hipSuccess) return SSG_EHIP;
-	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 192) != hipSuccess) return SSG_EHIP;
+	unsigned long long z[32]; memset(z, 0, sizeof z);
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 256) != hipSuccess) return SSG_EHIP;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 256) != hipSuccess) return SSG_EHIP;
 	return 0;
 #endif
 }

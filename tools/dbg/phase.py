@@ -12,7 +12,7 @@ print(d["value"], d["ms_per_step"], d["roofline"]["kernels_ms_per_step"])
 sys.path.insert(0, '.')
 from speedseq_amd import capi
 lib = capi.Lib()
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 32)()
 lib.l.ssg_dbg_cycles(out)
 t = list(out)
 print("matesw: fetch=%d sw=%d resort=%d rows=%d wave_total=%d" % tuple(t[:5]))
@@ -23,3 +23,5 @@ print("matesw resort by n_in: <=8 %.2f  9..64 %.2f  >64 %.2f (of resort); resort
 print("chain2aln (wave cycles): chain record+seed order=%d containment scan=%d (unused)=%d re-sort=%d wave_total=%d | scan chunks=%d append=%d results+build=%d" % tuple(t[16:24]))
 s = max(1, t[20])
 print("chain2aln fractions of wave time: record %.3f scan %.3f resort %.3f append %.3f results+build %.3f; cycles per scan chunk %.0f" % (t[16]/s, t[17]/s, t[19]/s, t[22]/s, t[23]/s, t[17]/max(1,t[21])))
+r = max(1, t[26])
+print("smem (wave cycles): state machine=%d extension site=%d | rounds=%d, ready lanes per round %.1f of %.1f alive" % (t[24], t[25], t[26], 64.0 * t[27] / r, 64.0 * t[28] / r))

@@ -11,7 +11,7 @@ print(d["ms_per_step"], {x: k[x] for x in k if "chain" in x})
 sys.path.insert(0, ".")
 from speedseq_amd import capi
 lib = capi.Lib()
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 32)()
 lib.l.ssg_dbg_cycles(out)
 t = list(out)
 n = max(1, t[12])
