@@ -120,6 +120,17 @@ const uint64_t *ssg_pe_stats(const ssg_pe_result_t *r);           /* [0] seeds [
 int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
                    const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
                    const char *rg_id, char **sam, int64_t *sam_off);
+/* the same for a selection of the batch's pairs: sel[0..n_sel) are pair indices, sam_off[2*n_sel+1] */
+int ssg_sam_format_sel(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, const int32_t *sel, int n_sel,
+                       const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                       const char *rg_id, char **sam, int64_t *sam_off);
+/* the records of ssg_sam_format's lines as BAM (what `sambamba view -S -f bam`, the next stage of the reference's pipeline at
+ * /root/reference/bin/speedseq:440, makes of that text: htslib-1.3.1 sam.c:835-1028 sam_parse1, sam.c:443-473 bam_write1): block_size-prefixed
+ * records of every read in input order; bam_off[2*n_pairs+1] delimits each read's records.  Used by the fused plugin path,
+ * where `bwa mem` hands binary records to samblaster / sambamba instead of SAM text.  *bam is malloc'd (ssg_free). */
+int ssg_bam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
+                   const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals,
+                   const char *rg_id, uint8_t **bam, int64_t *bam_off);
 int ssg_index_set_names(ssg_index_t *idx, int n, const char *const *names);
 const char *ssg_index_name(const ssg_index_t *idx, int i);
 int32_t ssg_index_len(const ssg_index_t *idx, int i);

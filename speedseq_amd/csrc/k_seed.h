@@ -471,15 +471,39 @@ __global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, c
 	seeds[g] = s;
 	seed_rid[g] = ssg_intv2rid(ix, s.rbeg, s.rbeg + s.len);
 }
-/* Denser SA samples for the copy of the index that lives in HBM: entry j = SA[j * new_intv], taken from the on-disk samples
- * (every old_intv rows) where they exist and by upstream's own LF walk (bwt_sa) elsewhere.  The .sa file keeps upstream's
- * interval; HBM has room (4 GB per Gbp at interval 4), and ssg_k_sal's walk per seed drops from ~16 dependent rank
- * queries to ~1.5 with identical results. */
-__global__ void ssg_k_sa_densify(ssg_index_view_t ix, int new_intv, uint64_t *sa_new, long n_new)
+/* HBM copy of the suffix array sampled every `new_intv` rows instead of the file's sa_intv (upstream's .sa keeps every 32nd row; a seed
+ * located through a denser table walks ~new_intv LF steps instead of ~32).  Each sampled row of the file starts a walk: LF(row with
+ * SA = v) is the row with SA = v - 1, so the walk fills every row it passes whose index is a multiple of new_intv and ends at the next
+ * sampled row -- the walks partition the LF cycle, every row is visited once (seq_len line fetches in all; asking bwt_sa for each new
+ * sample instead walks ~sa_intv steps per sample: 7 x the fetches at 32 -> 4).  Walk lengths are geometric, so lanes take new
+ * walks from a counter as they finish (one atomic per wave and refill). */
+__global__ void ssg_k_sa_densify_walk(ssg_index_view_t ix, int new_intv, uint64_t *sa_new, unsigned long long n_old, unsigned long long *next)
 {
-	const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= n_new) return;
-	const uint64_t r = (uint64_t)j * (uint64_t)new_intv;
-	sa_new[j] = (r % (uint64_t)ix.sa_intv) == 0 ? ix.sa[r / (uint64_t)ix.sa_intv] : ssg_bwt_sa(ix, r);
+	const uint64_t omask = (uint64_t)ix.sa_intv - 1, nmask = (uint64_t)new_intv - 1;
+	int nshift = 0; while ((1 << nshift) < new_intv) ++nshift;
+	const int lane = wv_lane();
+	bool have = false, done = false; uint64_t r = 0, v = 0;
+	for (;;) {
+		const unsigned long long need = wv_ballot(!have && !done);
+		if (need) {
+			const int leader = __ffsll(need) - 1;
+			unsigned long long base = 0;
+			if (lane == leader) base = atomicAdd(next, (unsigned long long)__popcll(need));
+			base = (unsigned long long)wv_bcast64((long long)base, leader);
+			if (!have && !done) {
+				const unsigned long long s = base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+				if (s >= n_old) done = true;
+				else { const uint64_t sv = ix.sa[s]; r = s * (uint64_t)ix.sa_intv; v = s == 0 ? ix.seq_len : sv; sa_new[r >> nshift] = sv; have = true; }
+			}
+		}
+		if (!wv_ballot(have)) break;
+		if (have) {
+			if (r == ix.primary) r = 0;
+			else { const int c = ssg_bwt_sym(ix, r - (r > ix.primary)); r = ix.L2[c] + ssg_occ1(ix, r, c); }
+			--v;
+			if ((r & omask) == 0) have = false;
+			else if ((r & nmask) == 0) sa_new[r >> nshift] = v;
+		}
+	}
 }
 #endif

@@ -9,6 +9,8 @@
 #include <thread>
 #include <string.h>
 #include <stdlib.h>
+#include <stdint.h>
+#include <type_traits>
 #include "../../include/ssgpu.h"
 
 namespace {
@@ -126,11 +128,129 @@ void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, con
 	if (comment) { str.putc('\t'); str.puts(comment); }
 	str.putc('\n');
 }
+
+/* ---- the same record as the bytes `sambamba view -S -f bam` makes of aln2sam's line (htslib sam.c:835-1028 sam_parse1 rules and
+ * sam.c:443-473 bam_write1 layout): block_size, refID, pos, bin<<16|mapq<<8|l_qname, flag<<16|n_cigar, l_seq, mate refID / pos, tlen,
+ * qname, cigar, 4-bit seq, qual, aux with the smallest integer types.  Field values follow aln2sam line for line. ---- */
+inline int reg2bin(int64_t beg, int64_t end)
+{	/* hts_reg2bin(beg, end, 14, 5), hts.h:580-586 */
+	int l, s = 14, t = ((1 << 15) - 1) / 7;
+	for (--end, l = 5; l > 0; --l, s += 3, t -= 1 << ((l << 1) + l)) if (beg >> s == end >> s) return t + (int)(beg >> s);
+	return 0;
+}
+struct alignas(128) bbuf {
+	std::vector<uint8_t> b;
+	void put(const void *p, size_t n) { b.insert(b.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
+	void tag_int(const char *t, long long v)
+	{	/* sam_parse1's integer typing (sam.c:964-988) */
+		b.push_back((uint8_t)t[0]); b.push_back((uint8_t)t[1]);
+		if (v < 0) {
+			if (v >= INT8_MIN) { b.push_back('c'); b.push_back((uint8_t)(int8_t)v); }
+			else if (v >= INT16_MIN) { int16_t y = (int16_t)v; b.push_back('s'); put(&y, 2); }
+			else { int32_t y = (int32_t)v; b.push_back('i'); put(&y, 4); }
+		} else {
+			if (v <= UINT8_MAX) { b.push_back('C'); b.push_back((uint8_t)v); }
+			else if (v <= UINT16_MAX) { uint16_t y = (uint16_t)v; b.push_back('S'); put(&y, 2); }
+			else { uint32_t y = (uint32_t)v; b.push_back('I'); put(&y, 4); }
+		}
+	}
+	void tag_str(const char *t, const char *v, size_t n) { b.push_back((uint8_t)t[0]); b.push_back((uint8_t)t[1]); b.push_back('Z'); put(v, n); b.push_back(0); }
+};
+
+void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, const uint8_t *seq, const char *qual,
+             int n, const ssg_aln_t *const *list, int which, const mate_t *m_, const std::string *XA, const char *rg_id)
+{
+	const ssg_aln_t &a = *list[which];
+	int flag = a.flag, rid = a.rid, is_rev = a.is_rev, n_cigar = a.n_cigar; long long pos = a.pos;
+	mate_t mt, *m = 0;
+	if (m_) { mt = *m_; m = &mt; }
+	flag |= m ? 0x1 : 0;
+	flag |= rid < 0 ? 0x4 : 0;
+	flag |= m && m->rid < 0 ? 0x8 : 0;
+	if (rid < 0 && m && m->rid >= 0) { rid = m->rid; pos = m->pos; is_rev = m->is_rev; n_cigar = 0; }
+	if (m && m->rid < 0 && rid >= 0) { m->rid = rid; m->pos = pos; m->is_rev = is_rev; m->n_cigar = 0; }
+	flag |= is_rev ? 0x10 : 0;
+	flag |= m && m->is_rev ? 0x20 : 0;
+	flag = (flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0);
+	const size_t base = out.b.size();
+	out.b.resize(base + 36);
+	const size_t l_qname = strlen(name) + 1;
+	out.put(name, l_qname);
+	int32_t tid = -1, bpos = -1, mapq = 0; int64_t rl = 0;
+	if (rid >= 0) {
+		tid = rid; bpos = (int32_t)pos; mapq = a.mapq;
+		for (int i = 0; i < n_cigar; ++i) {
+			int c = a.cigar[i] & 0xf;
+			if (c == 3 || c == 4) c = which ? 4 : 3;
+			const uint32_t len = a.cigar[i] >> 4, v = len << 4 | (uint32_t)(c <= 2 ? c : c + 1);   /* "MIDSH" -> BAM codes M0 I1 D2 S4 H5 */
+			out.put(&v, 4);
+			if (c == 0 || c == 2) rl += len;
+		}
+		if (!n_cigar) flag |= 4;            /* sam_parse1: a record without CIGAR is treated as unmapped */
+	} else { n_cigar = 0; flag |= 4; }
+	const int64_t rlen = (!(flag & 4) && n_cigar) ? rl : 1;
+	const int bin = reg2bin(bpos, bpos + rlen);
+	int32_t mtid = -1, mpos = -1, isize = 0;
+	if (m && m->rid >= 0) {
+		mtid = m->rid; mpos = (int32_t)m->pos;
+		if (rid == m->rid) {
+			long long p0 = pos + (is_rev ? get_rlen(n_cigar, a.cigar) - 1 : 0);
+			long long p1 = m->pos + (m->is_rev ? get_rlen(m->n_cigar, m->cigar) - 1 : 0);
+			if (!(m->n_cigar == 0 || n_cigar == 0)) isize = (int32_t)(-(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
+		}
+	}
+	int32_t l_qseq = 0;
+	if (!(flag & 0x100)) {
+		int qb = 0, qe = l_seq;
+		const bool cl0 = n_cigar && which && ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3), cl1 = n_cigar && which && ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3);
+		if (!is_rev) { if (cl0) qb += a.cigar[0] >> 4; if (cl1) qe -= a.cigar[n_cigar-1] >> 4; }
+		else { if (cl0) qe -= a.cigar[0] >> 4; if (cl1) qb += a.cigar[n_cigar-1] >> 4; }
+		l_qseq = qe > qb ? qe - qb : 0;
+		static const uint8_t fw[5] = { 1, 2, 4, 8, 15 }, rv[5] = { 8, 4, 2, 1, 15 };
+		const size_t o = out.b.size();
+		out.b.resize(o + (size_t)((l_qseq + 1) >> 1) + (size_t)l_qseq, 0);
+		uint8_t *ps = out.b.data() + o, *pq = ps + ((l_qseq + 1) >> 1);
+		if (!is_rev) for (int i = 0; i < l_qseq; ++i) ps[i >> 1] |= (uint8_t)(fw[seq[qb + i]] << ((~i & 1) << 2));
+		else for (int i = 0; i < l_qseq; ++i) ps[i >> 1] |= (uint8_t)(rv[seq[qe - 1 - i]] << ((~i & 1) << 2));
+		if (!qual) memset(pq, 0xff, (size_t)l_qseq);
+		else if (!is_rev) for (int i = 0; i < l_qseq; ++i) pq[i] = (uint8_t)(qual[qb + i] - 33);
+		else for (int i = 0; i < l_qseq; ++i) pq[i] = (uint8_t)(qual[qe - 1 - i] - 33);
+	}
+	if (n_cigar) { out.tag_int("NM", a.NM); out.tag_str("MD", a.md, (size_t)a.l_md); }
+	if (a.score >= 0) out.tag_int("AS", a.score);
+	if (a.sub >= 0) out.tag_int("XS", a.sub);
+	if (rg_id && rg_id[0]) out.tag_str("RG", rg_id, strlen(rg_id));
+	if (!(flag & 0x100)) {
+		int i;
+		for (i = 0; i < n; ++i) if (i != which && !(list[i]->flag & 0x100)) break;
+		if (i < n) {
+			sbuf sa;
+			for (i = 0; i < n; ++i) {
+				const ssg_aln_t &r = *list[i];
+				if (i == which || (r.flag & 0x100)) continue;
+				sa.puts(ssg_index_name(idx, r.rid)); sa.putc(',');
+				sa.putl(r.pos + 1); sa.putc(',');
+				sa.putc("+-"[r.is_rev]); sa.putc(',');
+				for (int k = 0; k < r.n_cigar; ++k) { sa.putl(r.cigar[k] >> 4); sa.putc("MIDSH"[r.cigar[k] & 0xf]); }
+				sa.putc(','); sa.putl(r.mapq);
+				sa.putc(','); sa.putl(r.NM);
+				sa.putc(';');
+			}
+			out.tag_str("SA", sa.s.data(), sa.s.size());
+		}
+	}
+	if (XA && !XA->empty()) out.tag_str("XA", XA->data(), XA->size());
+	uint32_t x[9];
+	x[0] = (uint32_t)(out.b.size() - base - 4);
+	x[1] = (uint32_t)tid; x[2] = (uint32_t)bpos; x[3] = (uint32_t)bin << 16 | (uint32_t)(mapq & 0xff) << 8 | (uint32_t)l_qname;
+	x[4] = (uint32_t)flag << 16 | (uint32_t)n_cigar; x[5] = (uint32_t)l_qseq; x[6] = (uint32_t)mtid; x[7] = (uint32_t)mpos; x[8] = (uint32_t)isize;
+	memcpy(out.b.data() + base, x, 36);
+}
 } // namespace
 
-/* pairs [p0, p1) into out; sam_off entries relative to out's start */
-static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, int p0, int p1, const char *const *names, const uint8_t *seq, const int64_t *off,
-                        const char *const *quals, const char *const *comments, const char *rg_id, sbuf &out, int64_t *sam_off)
+/* pairs sel[p0..p1) (or p0..p1 themselves when sel == NULL) into `out` (text) or `bout` (BAM records); offs entries relative to the buffer's start */
+static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, const int32_t *sel, int p0, int p1, const char *const *names, const uint8_t *seq, const int64_t *off,
+                        const char *const *quals, const char *const *comments, const char *rg_id, sbuf *out, bbuf *bout, int64_t *offs)
 {
 	const int64_t *req_off = ssg_pe_req_off(res);
 	const ssg_alnreq_t *req = ssg_pe_req(res);
@@ -138,7 +258,8 @@ static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, int 
 	std::vector<const ssg_aln_t*> mains[2];
 	std::vector<std::string> xa[2];
 	std::vector<int> owner;
-	for (int p = p0; p < p1; ++p) {
+	for (int q = p0; q < p1; ++q) {
+		const int p = sel ? sel[q] : q;
 		mate_t mate[2];
 		for (int i = 0; i < 2; ++i) {
 			const int r = 2 * p + i;
@@ -164,49 +285,76 @@ static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, int 
 		}
 		for (int i = 0; i < 2; ++i) {
 			const int r = 2 * p + i;
-			sam_off[r] = (int64_t)out.s.size();
+			offs[2 * q + i] = (int64_t)(out ? out->s.size() : bout->b.size());
 			const int l_seq = (int)(off[r+1] - off[r]);
-			for (size_t k = 0; k < mains[i].size(); ++k)
-				aln2sam(idx, out, names[r], l_seq, seq + off[r], quals ? quals[r] : 0, comments ? comments[r] : 0,
-				        (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id);
+			for (size_t k = 0; k < mains[i].size(); ++k) {
+				if (out) aln2sam(idx, *out, names[r], l_seq, seq + off[r], quals ? quals[r] : 0, comments ? comments[r] : 0,
+				                 (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id);
+				else aln2bam(idx, *bout, names[r], l_seq, seq + off[r], quals ? quals[r] : 0,
+				             (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id);
+			}
 		}
 	}
 	return 0;
 }
 
-/* Text assembly is split over host threads by ranges of pairs (opt->n_threads, as upstream's worker2 threads print), then joined in input order. */
-extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
-                              const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
-                              const char *rg_id, char **sam, int64_t *sam_off)
+/* Assembly is split over host threads by ranges of pairs (opt->n_threads, as upstream's worker2 threads print), then joined in input order. */
+template <class BUF, class GET>
+static int format_all(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, const int32_t *sel, int n_pairs,
+                      const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                      const char *rg_id, std::vector<BUF> &outs, GET bytes_of, bool text, char **outp, int64_t *offs)
 {
 	int T = opt && opt->n_threads > 1 ? opt->n_threads : 1;
 	{ const char *e = getenv("SSG_FMT_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
 	if (T > 64) T = 64;
 	if (T > (n_pairs + 1023) / 1024) T = (n_pairs + 1023) / 1024;
 	if (T < 1) T = 1;
-	/* the per-thread text buffers persist across calls of the calling thread (bwa's formatter thread): after the first batch they
-	 * are warm memory instead of hundreds of MB of fresh pages per call */
-	static thread_local std::vector<sbuf> outs_keep;
-	if ((int)outs_keep.size() < T) outs_keep.resize(T);
-	std::vector<sbuf> &outs = outs_keep;
+	if ((int)outs.size() < T) outs.resize(T);
 	std::vector<int> rcs(T, 0); std::vector<std::thread> th;
 	auto lo = [&](int t) { return (int)((int64_t)n_pairs * t / T); };
 	for (int t = 0; t < T; ++t) {
-		auto work = [&, t]() { outs[t].s.clear(); outs[t].s.reserve((size_t)(lo(t + 1) - lo(t)) * 1000); rcs[t] = format_range(idx, res, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, outs[t], sam_off); };
+		auto work = [&, t]() {
+			auto &B = bytes_of(outs[t]); B.clear(); B.reserve((size_t)(lo(t + 1) - lo(t)) * (text ? 1000 : 800));
+			sbuf *so = 0; bbuf *bo = 0;
+			if constexpr (std::is_same<BUF, sbuf>::value) so = &outs[t]; else bo = &outs[t];
+			rcs[t] = format_range(idx, res, sel, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, so, bo, offs); };
 		if (T == 1) work(); else th.emplace_back(work);
 	}
 	for (auto &x : th) x.join();
 	th.clear();
 	size_t tot = 0; std::vector<size_t> base(T + 1, 0);
-	for (int t = 0; t < T; ++t) { if (rcs[t]) return rcs[t]; base[t] = tot; tot += outs[t].s.size(); }
+	for (int t = 0; t < T; ++t) { if (rcs[t]) return rcs[t]; base[t] = tot; tot += bytes_of(outs[t]).size(); }
 	char *buf = (char*)malloc(tot + 1);
 	if (!buf) return SSG_ENOMEM;
 	for (int t = 0; t < T; ++t) {   /* joined in input order, each part copied by its own thread */
-		auto work = [&, t]() { memcpy(buf + base[t], outs[t].s.data(), outs[t].s.size()); for (int r = 2 * lo(t); r < 2 * lo(t + 1); ++r) sam_off[r] += (int64_t)base[t]; };
+		auto work = [&, t]() { memcpy(buf + base[t], bytes_of(outs[t]).data(), bytes_of(outs[t]).size()); for (int r = 2 * lo(t); r < 2 * lo(t + 1); ++r) offs[r] += (int64_t)base[t]; };
 		if (T == 1) work(); else th.emplace_back(work);
 	}
 	for (auto &x : th) x.join();
-	buf[tot] = 0; sam_off[2 * n_pairs] = (int64_t)tot;
-	*sam = buf;
+	buf[tot] = 0; offs[2 * n_pairs] = (int64_t)tot;
+	*outp = buf;
 	return 0;
+}
+
+/* the per-thread buffers persist across calls of the calling thread (bwa's formatter thread): after the first batch they are warm
+ * memory instead of hundreds of MB of fresh pages per call */
+extern "C" int ssg_sam_format_sel(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, const int32_t *sel, int n_sel,
+                                  const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                                  const char *rg_id, char **sam, int64_t *sam_off)
+{
+	static thread_local std::vector<sbuf> keep;
+	return format_all(idx, opt, res, sel, n_sel, names, seq, off, quals, comments, rg_id, keep, [](sbuf &b) -> std::string& { return b.s; }, true, sam, sam_off);
+}
+extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
+                              const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                              const char *rg_id, char **sam, int64_t *sam_off)
+{
+	return ssg_sam_format_sel(idx, opt, res, 0, n_pairs, names, seq, off, quals, comments, rg_id, sam, sam_off);
+}
+extern "C" int ssg_bam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
+                              const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals,
+                              const char *rg_id, uint8_t **bam, int64_t *bam_off)
+{
+	static thread_local std::vector<bbuf> keep;
+	return format_all(idx, opt, res, 0, n_pairs, names, seq, off, quals, 0, rg_id, keep, [](bbuf &b) -> std::vector<uint8_t>& { return b.b; }, false, (char**)bam, bam_off);
 }

@@ -16,8 +16,10 @@ extern thread_local std::string ssg_err_msg;
 #ifdef SSG_EMU
 #include "emu.h"
 #define SSG_BACKEND "emu"
-static inline int rt_device_count() { return 1; }
-static inline int rt_set_device(int) { return 0; }
+/* SSG_EMU_DEVICES = n pretends n devices (multi-device host logic under test); they share the host's memory */
+extern thread_local int ssg_cur_dev;
+static inline int rt_device_count() { const char *e = getenv("SSG_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
+static inline int rt_set_device(int d) { if (d < 0 || d >= rt_device_count()) { ssg_err_msg = "ssg_set_device: no such device"; return -22; } ssg_cur_dev = d; return 0; }
 static inline void *rt_malloc(size_t n) { return calloc(n ? n : 1, 1); }
 static inline void rt_free(void *p) { free(p); }
 static inline int rt_h2d(void *d, const void *h, size_t n) { if (n) memcpy(d, h, n); return 0; }
@@ -34,6 +36,7 @@ static inline void rt_host_free(void *p) { free(p); }
 #define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) SSG_LAUNCH(kern, grid, block, lds, __VA_ARGS__)
 static inline void ssg_fork(int) {}
 static inline void ssg_join(int) {}
+static inline void ssg_prof_flush() {}
 #else
 #include <hip/hip_runtime.h>
 #define SSG_BACKEND "hip:gfx950"
@@ -44,7 +47,11 @@ static inline int rt_check(hipError_t e, const char *what)
 	return -1000;
 }
 static inline int rt_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
-static inline int rt_set_device(int d) { return rt_check(hipSetDevice(d), "hipSetDevice"); }
+/* one host thread drives one device at a time (hipSetDevice is per thread); every piece of per-device state below -- HBM arena, side
+ * streams -- is selected by the calling thread's current device, so N threads can drive N devices through the same entry points */
+#define SSG_MAX_DEV 16
+extern thread_local int ssg_cur_dev;
+static inline int rt_set_device(int d) { if (d < 0 || d >= SSG_MAX_DEV) { ssg_err_msg = "ssg_set_device: device index out of range"; return -22; } int rc = rt_check(hipSetDevice(d), "hipSetDevice"); if (!rc) ssg_cur_dev = d; return rc; }
 /* HBM arena: freed blocks are kept in size-class free lists and reused by later calls, so the
  * steady-state hot path performs no hipMalloc/hipFree (288 GB of HBM3E make the slack irrelevant) */
 #include <map>
@@ -60,12 +67,19 @@ struct ssg_pool_t {
 		if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); release(); if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); return 0; } }
 		std::lock_guard<std::mutex> l(mu); size_[p] = c; return p;
 	}
-	void put(void *p) { if (!p) return; std::lock_guard<std::mutex> l(mu); auto it = size_.find(p); if (it == size_.end()) { (void)hipFree(p); return; } free_[it->second].push_back(p); }
+	bool put(void *p) { std::lock_guard<std::mutex> l(mu); auto it = size_.find(p); if (it == size_.end()) return false; free_[it->second].push_back(p); return true; }
 	void release() { std::lock_guard<std::mutex> l(mu); for (auto &kv : free_) for (void *p : kv.second) { size_.erase(p); (void)hipFree(p); } free_.clear(); }
 };
-extern ssg_pool_t ssg_pool;
+extern ssg_pool_t ssg_pools[SSG_MAX_DEV];
+#define ssg_pool (ssg_pools[ssg_cur_dev])
 static inline void *rt_malloc(size_t n) { return ssg_pool.get(n); }
-static inline void rt_free(void *p) { ssg_pool.put(p); }
+static inline void rt_free(void *p)
+{	/* back to the arena of the device it came from (normally the caller's) */
+	if (!p) return;
+	if (ssg_pool.put(p)) return;
+	for (int d = 0; d < SSG_MAX_DEV; ++d) if (d != ssg_cur_dev && ssg_pools[d].put(p)) return;
+	(void)hipFree(p);
+}
 static inline int rt_h2d(void *d, const void *h, size_t n) { return n ? rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D") : 0; }
 static inline int rt_d2h(void *h, const void *d, size_t n) { return n ? rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
 static inline int rt_memset(void *d, int v, size_t n) { return n ? rt_check(hipMemset(d, v, n), "hipMemset") : 0; }
@@ -89,7 +103,7 @@ struct ssg_hostpool_t {
 			if (best >= 0) { void *p = free_[best]; free_.erase(free_.begin() + best); free_bytes -= cap_[p]; return p; }
 		}
 		void *p = 0; const size_t c = n + n / 4;
-		if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
+		if (hipHostMalloc(&p, c, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return 0; }
 		std::lock_guard<std::mutex> l(mu); cap_[p] = c;
 		return p;
 	}
@@ -111,14 +125,15 @@ static inline void rt_host_free(void *p) { ssg_hostpool.put(p); }
 #include <vector>
 struct ssg_prof_rec { const char *name; hipEvent_t a, b; };
 extern int ssg_prof_on;
-extern std::vector<ssg_prof_rec> ssg_prof_pending;
+extern thread_local std::vector<ssg_prof_rec> ssg_prof_pending;   /* launches of this host thread; ssg_prof_flush() moves them to the process-wide table */
+void ssg_prof_flush();
 #define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) { \
 	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, 0); \
 		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); (void)hipEventRecord(r_.b, 0); ssg_prof_pending.push_back(r_); } \
 	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } } while (0)
 /* side streams for independent kernels that each leave most of the chip idle (few heavy work items): fork after the work
  * already queued on the default stream, launch with SSG_LAUNCH_ON(i, ...), join before anything that consumes the results */
-static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (!s[i]) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking); return s[i]; }
+static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[SSG_MAX_DEV][8]; hipStream_t &x = s[ssg_cur_dev][i]; if (!x) (void)hipStreamCreateWithFlags(&x, hipStreamNonBlocking); return x; }
 static inline void ssg_fork(int n) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, 0); for (int i = 0; i < n; ++i) (void)hipStreamWaitEvent(ssg_side_stream(i), e, 0); (void)hipEventDestroy(e); }
 static inline void ssg_join(int n) { for (int i = 0; i < n; ++i) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, ssg_side_stream(i)); (void)hipStreamWaitEvent(0, e, 0); (void)hipEventDestroy(e); } }
 #define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) do { if ((grid) > 0) { hipStream_t st_ = ssg_side_stream(si); \

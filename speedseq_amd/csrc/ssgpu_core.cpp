@@ -13,6 +13,12 @@
 #include <chrono>
 #include <algorithm>
 #include <math.h>
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
 #include "ssg_rt.h"
 #include "k_seed.h"
 #include "k_chainw.h"
@@ -28,16 +34,21 @@
 #endif
 
 thread_local std::string ssg_err_msg;
+thread_local int ssg_cur_dev = 0;
 #ifndef SSG_EMU
-ssg_pool_t ssg_pool;
+ssg_pool_t ssg_pools[SSG_MAX_DEV];
 ssg_hostpool_t ssg_hostpool;
 int ssg_prof_on = 0;
-std::vector<ssg_prof_rec> ssg_prof_pending;
+thread_local std::vector<ssg_prof_rec> ssg_prof_pending;
 #endif
 
 /* wave-per-item kernels are grid-strided over at most this many 4-wave workgroups (256 CUs x 4),
  * so per-wave scratch slabs are sized by residency, not by batch size */
 #define SSG_MAX_RESIDENT_WG 1024
+/* longest read the DP kernels are laid out for (LDS rows, 8-bit columns) */
+#define SSG_MAX_READ_LEN 254
+#define SSG_STR_(x) #x
+#define SSG_STR(x) SSG_STR_(x)
 
 #define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CHKA(b) do { if (!(b).ok()) { ssg_err_msg = "device allocation failed: " #b; return SSG_ENOMEM; } } while (0)
@@ -86,7 +97,12 @@ static int densify_sa(ssg_index *ix)
 	const long n_new = (long)((ix->v.seq_len + (uint64_t)want) / (uint64_t)want);
 	uint64_t *d = (uint64_t*)rt_malloc((size_t)n_new * 8);
 	if (!d) { ssg_err_msg = "index allocation failed: dense SA"; return SSG_ENOMEM; }
-	SSG_LAUNCH(ssg_k_sa_densify, (n_new + 255) / 256, 256, 0, ix->v, want, d, n_new);
+	const unsigned long long n_old = (unsigned long long)((ix->v.seq_len + (uint64_t)ix->v.sa_intv) / (uint64_t)ix->v.sa_intv);
+	dbuf<unsigned long long> d_next(1);
+	if (!d_next.ok()) { rt_free(d); ssg_err_msg = "index allocation failed: dense SA"; return SSG_ENOMEM; }
+	CHK(d_next.zero());
+	const long n_wg = std::min<long>((long)((n_old + 255) / 256), 256L * env_int("SSG_DENSIFY_WG_PER_CU", 8));   /* persistent: lanes refill from the counter */
+	SSG_LAUNCH(ssg_k_sa_densify_walk, n_wg, 256, 0, ix->v, want, d, n_old, d_next.p);
 	CHK(rt_sync());
 	rt_free(ix->sa);   /* the lower-density copy, when this index owns it */
 	ix->sa = d; ix->v.sa = d; ix->v.sa_intv = want;
@@ -117,9 +133,60 @@ int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t prim
 	return 0;
 }
 
+/* file bytes -> HBM for the index load: reader threads pread() 16 MB pieces into page-locked staging blocks and send each to the
+ * device with an asynchronous copy on the thread's own stream, two blocks per thread, so reading the next piece overlaps the copy
+ * of the previous one and nothing is staged in pageable memory (round 2 read the files into zero-filled vectors one after the other
+ * and copied them synchronously: 4.6 s of an 8.6 s run at the 3.1 Gbp size) */
+struct load_item_t { int fd; uint64_t foff; uint8_t *dst; size_t n; };
+static int stream_files_to_device(const std::vector<load_item_t> &items, int n_threads)
+{
+	const size_t PIECE = (size_t)16 << 20;
+	struct piece_t { int fd; uint64_t foff; uint8_t *dst; size_t n; };
+	std::vector<piece_t> pieces;
+	for (const load_item_t &it : items) for (size_t o = 0; o < it.n; o += PIECE) { piece_t q; q.fd = it.fd; q.foff = it.foff + o; q.dst = it.dst + o; q.n = std::min(PIECE, it.n - o); pieces.push_back(q); }
+	if (pieces.empty()) return 0;
+	n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, pieces.size()));
+	std::atomic<size_t> next(0); std::atomic<int> fail(0);
+	const int dev = ssg_cur_dev;
+	auto pread_all = [](int fd, void *buf, size_t n, uint64_t off) -> bool {
+		uint8_t *b = (uint8_t*)buf;
+		while (n) { ssize_t r = pread(fd, b, n, (off_t)off); if (r < 0) { if (errno == EINTR) continue; return false; } if (r == 0) return false; b += r; n -= (size_t)r; off += (uint64_t)r; }
+		return true;
+	};
+	auto worker = [&]() {
+#ifdef SSG_EMU
+		for (;;) { const size_t i = next.fetch_add(1); if (i >= pieces.size() || fail) break; if (!pread_all(pieces[i].fd, pieces[i].dst, pieces[i].n, pieces[i].foff)) fail = 1; }
+#else
+		if (rt_set_device(dev)) { fail = 2; return; }
+		void *stage[2] = { rt_host_alloc(PIECE), rt_host_alloc(PIECE) }; hipStream_t st = 0; hipEvent_t ev[2]; bool busy[2] = { false, false };
+		if (!stage[0] || !stage[1] || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { fail = 2; rt_host_free(stage[0]); rt_host_free(stage[1]); return; }
+		(void)hipEventCreateWithFlags(&ev[0], hipEventDisableTiming); (void)hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+		for (int k = 0; ; k ^= 1) {
+			const size_t i = next.fetch_add(1);
+			if (i >= pieces.size() || fail) break;
+			if (busy[k]) { if (hipEventSynchronize(ev[k]) != hipSuccess) { fail = 2; break; } busy[k] = false; }
+			if (!pread_all(pieces[i].fd, stage[k], pieces[i].n, pieces[i].foff)) { fail = 1; break; }
+			if (hipMemcpyAsync(pieces[i].dst, stage[k], pieces[i].n, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { fail = 2; break; }
+			busy[k] = true;
+		}
+		if (hipStreamSynchronize(st) != hipSuccess) fail = 2;
+		(void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); (void)hipStreamDestroy(st);
+		rt_host_free(stage[0]); rt_host_free(stage[1]);
+#endif
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < n_threads; ++t) th.emplace_back(worker);
+	worker();
+	for (std::thread &x : th) x.join();
+	if (fail == 1) { ssg_err_msg = "short read of an index file"; return SSG_EIO; }
+	if (fail) { ssg_err_msg = "index upload failed"; return SSG_EHIP; }
+	return 0;
+}
+
 int ssg_index_load(const char *prefix, ssg_index_t **out)
 {	/* on-disk layout: SURVEY.md Appendix A (verified against the bundled example index) */
 	CHK(need_device());
+	const auto t_begin = std::chrono::steady_clock::now();
 	std::string p(prefix);
 	FILE *fp = fopen((p + ".ann").c_str(), "r");
 	if (!fp) { ssg_err_msg = "cannot open " + p + ".ann"; return SSG_EIO; }
@@ -134,28 +201,53 @@ int ssg_index_load(const char *prefix, ssg_index_t **out)
 		names[i] = nm; off[i] = o; len[i] = l;
 	}
 	fclose(fp);
-	auto slurp = [&](const std::string &fn, std::vector<uint8_t> &buf) -> int {
-		FILE *f = fopen(fn.c_str(), "rb"); if (!f) { ssg_err_msg = "cannot open " + fn; return SSG_EIO; }
-		fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
-		buf.resize(sz); if (sz && fread(buf.data(), 1, sz, f) != (size_t)sz) { fclose(f); ssg_err_msg = "short read " + fn; return SSG_EIO; }
-		fclose(f); return 0;
+	struct fd_t { int fd; uint64_t size; fd_t() : fd(-1), size(0) {} ~fd_t() { if (fd >= 0) close(fd); } };
+	fd_t f_bwt, f_sa, f_pac;
+	auto open_ro = [&](const std::string &fn, fd_t &f) -> int {
+		f.fd = open(fn.c_str(), O_RDONLY); struct stat sb;
+		if (f.fd < 0 || fstat(f.fd, &sb) != 0) { ssg_err_msg = "cannot open " + fn; return SSG_EIO; }
+		f.size = (uint64_t)sb.st_size; return 0;
 	};
-	std::vector<uint8_t> bwt, sa, pac;
-	CHK(slurp(p + ".bwt", bwt)); CHK(slurp(p + ".sa", sa)); CHK(slurp(p + ".pac", pac));
-	if (bwt.size() < 40 || sa.size() < 56) { ssg_err_msg = "truncated index"; return SSG_EIO; }
-	uint64_t primary, L2[5] = {0,0,0,0,0}, hdr[7];
-	memcpy(&primary, bwt.data(), 8); memcpy(L2 + 1, bwt.data() + 8, 32);
-	memcpy(hdr, sa.data(), 56);
+	CHK(open_ro(p + ".bwt", f_bwt)); CHK(open_ro(p + ".sa", f_sa)); CHK(open_ro(p + ".pac", f_pac));
+	if (f_bwt.size < 40 || f_sa.size < 56) { ssg_err_msg = "truncated index"; return SSG_EIO; }
+	uint64_t primary, L2[5] = {0,0,0,0,0}, hb[5], hdr[7];
+	if (pread(f_bwt.fd, hb, 40, 0) != 40 || pread(f_sa.fd, hdr, 56, 0) != 56) { ssg_err_msg = "cannot read the index headers"; return SSG_EIO; }
+	primary = hb[0]; memcpy(L2 + 1, hb + 1, 32);
 	if (hdr[0] != primary || hdr[6] != L2[4]) { ssg_err_msg = ".sa does not match .bwt"; return SSG_EIO; }
-	int sa_intv = (int)hdr[5];
-	uint64_t n_sa = (L2[4] + sa_intv) / sa_intv;
-	if (sa.size() != 56 + (n_sa - 1) * 8) { ssg_err_msg = "unexpected .sa size"; return SSG_EIO; }
-	std::vector<uint64_t> sav(n_sa); sav[0] = (uint64_t)-1; memcpy(sav.data() + 1, sa.data() + 56, (n_sa - 1) * 8);
-	pac.resize((size_t)(l_pac / 4 + 1), 0);
-	int rc = ssg_index_from_arrays((const uint32_t*)(bwt.data() + 40), (bwt.size() - 40) / 4, primary, L2, sav.data(), n_sa, sa_intv,
-	                               pac.data(), l_pac, n_seqs, off.data(), len.data(), out);
-	if (rc == 0) (*out)->names = names;
-	return rc;
+	const int sa_intv = (int)hdr[5];
+	if (sa_intv <= 0) { ssg_err_msg = "bad .sa interval"; return SSG_EIO; }
+	const uint64_t n_sa = (L2[4] + sa_intv) / sa_intv;
+	if (f_sa.size != 56 + (n_sa - 1) * 8) { ssg_err_msg = "unexpected .sa size"; return SSG_EIO; }
+	const size_t pac_bytes = (size_t)(l_pac / 4 + 1), bwt_bytes = (size_t)(f_bwt.size - 40);
+	ssg_index *ix = new ssg_index();
+	ix->bwt_words = bwt_bytes / 4;
+	ix->bwt = (uint32_t*)rt_malloc(bwt_bytes + 64); ix->sa = (uint64_t*)rt_malloc(n_sa * 8);
+	ix->pac = (uint8_t*)rt_malloc(pac_bytes); ix->ctg_off = (int64_t*)rt_malloc((size_t)n_seqs * 8); ix->ctg_len = (int32_t*)rt_malloc((size_t)n_seqs * 4);
+	if (!ix->bwt || !ix->sa || !ix->pac || !ix->ctg_off || !ix->ctg_len) { ssg_index_destroy(ix); ssg_err_msg = "index allocation failed"; return SSG_ENOMEM; }
+	const size_t pac_have = (size_t)std::min<uint64_t>(f_pac.size, pac_bytes);
+	int rc = 0;
+	if (pac_have < pac_bytes) rc |= rt_memset(ix->pac + pac_have, 0, pac_bytes - pac_have);
+	{ const uint64_t none = (uint64_t)-1; rc |= rt_h2d(ix->sa, &none, 8); }                 /* row 0 (the terminator) is not stored in the file */
+	rc |= rt_h2d(ix->ctg_off, off.data(), (size_t)n_seqs * 8); rc |= rt_h2d(ix->ctg_len, len.data(), (size_t)n_seqs * 4);
+	if (rc) { ssg_index_destroy(ix); return SSG_EHIP; }
+	std::vector<load_item_t> items(3);
+	items[0].fd = f_bwt.fd; items[0].foff = 40; items[0].dst = (uint8_t*)ix->bwt; items[0].n = bwt_bytes;
+	items[1].fd = f_sa.fd; items[1].foff = 56; items[1].dst = (uint8_t*)(ix->sa + 1); items[1].n = (size_t)(n_sa - 1) * 8;
+	items[2].fd = f_pac.fd; items[2].foff = 0; items[2].dst = ix->pac; items[2].n = pac_have;
+	{ const int rc2 = stream_files_to_device(items, std::max(1, env_int("SSG_LOAD_THREADS", 8))); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	const auto t_up = std::chrono::steady_clock::now();
+	ix->v.bwt = ix->bwt; ix->v.sa = ix->sa; ix->v.pac = ix->pac; ix->v.ctg_off = ix->ctg_off; ix->v.ctg_len = ix->ctg_len;
+	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
+	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_seqs; ix->v.sa_intv = sa_intv;
+	ix->h_off = off; ix->h_len = len; ix->names = names;
+	{ const int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	if (ssg_debug()) {
+		const auto t_end = std::chrono::steady_clock::now();
+		fprintf(stderr, "[ssgpu] index load: files -> HBM %.3f s (%.2f GB), SA samples to every %d rows %.3f s\n", std::chrono::duration<double>(t_up - t_begin).count(),
+		        (double)(bwt_bytes + n_sa * 8 + pac_have) / 1e9, ix->v.sa_intv, std::chrono::duration<double>(t_end - t_up).count());
+	}
+	*out = ix;
+	return 0;
 }
 
 void ssg_index_destroy(ssg_index_t *ix)
@@ -186,10 +278,16 @@ int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_
 
 /* ---- per-kernel timing ---- */
 #ifndef SSG_EMU
-static std::vector<std::string> prof_names; static std::vector<double> prof_ms; static std::vector<long> prof_cnt;
+} /* extern "C" */
+static void prof_collect();
+void ssg_prof_flush() { prof_collect(); }
+extern "C" {
+static std::vector<std::string> prof_names; static std::vector<double> prof_ms; static std::vector<long> prof_cnt; static std::mutex prof_mu;
 static void prof_collect()
-{
+{	/* the calling thread's launches (on its current device) into the process-wide table */
+	if (ssg_prof_pending.empty()) return;
 	(void)hipDeviceSynchronize();
+	std::lock_guard<std::mutex> lk(prof_mu);
 	for (auto &r : ssg_prof_pending) {
 		float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b);
 		std::string nm(r.name);
@@ -202,10 +300,11 @@ static void prof_collect()
 	ssg_prof_pending.clear();
 }
 void ssg_prof_enable(int on) { prof_collect(); ssg_prof_on = on; }
-void ssg_prof_reset(void) { prof_collect(); prof_names.clear(); prof_ms.clear(); prof_cnt.clear(); }
+void ssg_prof_reset(void) { prof_collect(); std::lock_guard<std::mutex> lk(prof_mu); prof_names.clear(); prof_ms.clear(); prof_cnt.clear(); }
 int ssg_prof_get(int cap, const char **name, double *ms, long *launches)
 {
 	prof_collect();
+	std::lock_guard<std::mutex> lk(prof_mu);
 	for (int i = 0; i < (int)prof_names.size() && i < cap; ++i) { name[i] = prof_names[i].c_str(); ms[i] = prof_ms[i]; launches[i] = prof_cnt[i]; }
 	return (int)prof_names.size();
 }
@@ -457,8 +556,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 {
 	/* intervals per read in the dense layout: upstream's list is unbounded; a batch that needs more widens the layout for itself
 	 * and for the calls after it (low-complexity reads collect > len / 2 intervals from the re-seeding passes) */
-	static int learned_cap = 0;
-	int cap = std::max(64 > max_len / 2 ? 64 : max_len / 2, learned_cap);
+	static std::atomic<int> learned_cap(0);
+	int cap = std::max(64 > max_len / 2 ? 64 : max_len / 2, learned_cap.load());
 	dbuf<ssg_intv_t> d_intv; dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
 	CHKA(d_nintv); CHKA(d_nseed);
 	dbuf<unsigned long long> d_next(1);
@@ -469,7 +568,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		CHK(d_next.zero());
 		CHK(run_smem(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv.p, d_nintv.p, d_next.p, &need));
 		if (need <= cap) break;
-		cap = (need + 31) / 32 * 32; learned_cap = cap;
+		cap = (need + 31) / 32 * 32;
+		{ int seen = learned_cap.load(); while (seen < cap && !learned_cap.compare_exchange_weak(seen, cap)) {} }
 		if (ssg_debug()) fprintf(stderr, "[ssgpu] SMEM interval capacity widened to %d per read\n", cap);
 	}
 	if (stats) { unsigned long long c; CHK(d_next.down(&c, 1)); stats[5] = c; }
@@ -896,27 +996,14 @@ static int sbl_process_dev(ssg_sbl_state *st, const ssg_sbl_opt_t *o, long n_blo
 
 extern "C" {
 
+static int process_pairs_host(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
+                              const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out);
+
 int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
                           const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out)
 {
-	CHK(need_device());
-	*out = 0;
-	const int n_reads = 2 * n_pairs;
-	if (n_pairs <= 0 || n_batches <= 0) { ssg_err_msg = "ssg_mem_process_pairs: empty input"; return SSG_EINVAL; }
-	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
-	if (max_len > 254) { ssg_err_msg = "reads longer than 254 bases are outside this build's scope"; return SSG_EINVAL; }
-	for (int p = 0; p < n_pairs; ++p) if (pair_batch[p] < 0 || pair_batch[p] >= n_batches) { ssg_err_msg = "pair_batch out of range"; return SSG_EINVAL; }
-	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1); dbuf<int32_t> d_pb(n_pairs);
-	CHKA(d_seq); CHKA(d_off); CHKA(d_pb);
-	if (ssg_debug()) (void)ssg_stage_ms();
-	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1)); CHK(d_pb.up(pair_batch, n_pairs));
-	STAGE("upload");
-	std::unique_ptr<ssg_pe_result> res(new ssg_pe_result());
-	CHK(pe_core(idx, opt, n_pairs, d_seq.p, d_off.p, max_len, d_pb.p, n_batches, id0, pes0, res.get(), 0));
-	*out = res.release();
-	return 0;
+	return process_pairs_host(idx, opt, n_pairs, seq, off, pair_batch, n_batches, id0, pes0, out);
 }
-
 /* upstream samblaster duplicate marking (row a14) on per-end records supplied by the caller
  * (2*n_pairs entries: read1, read2 primaries); dup[p] = 1 when an earlier pair has the same signature */
 int ssg_sbl_markdup(long n_pairs, const ssg_sbl_end_t *ends, uint8_t *dup)
@@ -992,7 +1079,7 @@ struct ssg_dev_records {
 };
 
 /* SAM lines of the kept records (k_sbl.h) and the two primary ends per pair */
-static int records_lines(ssg_dev_records *R)
+static int records_lines(struct ssg_dev_records *R)
 {
 	const long n_pairs = R->n_pairs; const int block = 256;
 	dbuf<int32_t> d_nl(n_pairs);
@@ -1005,6 +1092,27 @@ static int records_lines(ssg_dev_records *R)
 		ssg_err_msg = "device allocation failed: samblaster lines"; return SSG_ENOMEM; }
 	SSG_LAUNCH(ssg_k_sbl_lines_from_alns, (n_pairs + block - 1) / block, block, 0, n_pairs, R->keep.req_off.p, R->keep.req.p, R->keep.alns.p, R->line_off.p, R->lines.p, R->line_req.p);
 	SSG_LAUNCH(ssg_k_sbl_ends, (n_pairs + block - 1) / block, block, 0, n_pairs, R->line_off.p, R->lines.p, R->ends.p, R->prim.p);
+	return 0;
+}
+static int process_pairs_host(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
+                              const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out)
+{
+	CHK(need_device());
+	*out = 0;
+	const int n_reads = 2 * n_pairs;
+	if (n_pairs <= 0 || n_batches <= 0) { ssg_err_msg = "ssg_mem_process_pairs: empty input"; return SSG_EINVAL; }
+	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
+	if (max_len > SSG_MAX_READ_LEN) { ssg_err_msg = "reads longer than " SSG_STR(SSG_MAX_READ_LEN) " bases are outside this build's scope"; return SSG_EINVAL; }
+	for (int p = 0; p < n_pairs; ++p) if (pair_batch[p] < 0 || pair_batch[p] >= n_batches) { ssg_err_msg = "pair_batch out of range"; return SSG_EINVAL; }
+	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1); dbuf<int32_t> d_pb(n_pairs);
+	CHKA(d_seq); CHKA(d_off); CHKA(d_pb);
+	if (ssg_debug()) (void)ssg_stage_ms();
+	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1)); CHK(d_pb.up(pair_batch, n_pairs));
+	STAGE("upload");
+	std::unique_ptr<ssg_pe_result> res(new ssg_pe_result());
+	CHK(pe_core(idx, opt, n_pairs, d_seq.p, d_off.p, max_len, d_pb.p, n_batches, id0, pes0, res.get(), 0));
+	ssg_prof_flush();
+	*out = res.release();
 	return 0;
 }
 static int records_classify(ssg_dev_records *R, const ssg_sbl_opt_t *o, const uint8_t *d_dup, uint64_t counts[4])

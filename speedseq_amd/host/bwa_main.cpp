@@ -20,7 +20,12 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <errno.h>
+#include <map>
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
 #include "fastq.h"
+#include "fused.h"
 #include "../../include/ssgpu.h"
 
 #include <time.h>
@@ -93,40 +98,63 @@ static int main_mem(int argc, char **argv)
 		size_t i = 0; for (p += 4; p < rg.size() && rg[p] != '\t' && rg[p] != '\n' && i < 255; ++p) rg_id[i++] = rg[p];
 		rg_id[i] = 0;
 	}
-	ssg_index_t *idx;
 	const double t_start = wall();
 	size_t max_pairs_per_call = 1u << 19;   /* upstream batches are grouped up to this many pairs per device call (one batch alone may exceed it) */
 	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
 	if (getenv("SSG_BWA_PROF")) { ssg_prof_reset(); ssg_prof_enable(1); }
-	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
-	if (ssg_index_load(argv[ai], &idx)) { t_warm.join(); die("fail to load the index"); }
-	t_warm.join();
-	const double t_loaded = wall();
+	/* fused mode (fused.h): BAM records in frames instead of SAM text when speedseq.config exported SSG_FUSED=1; never with -C */
+	const bool fused = fu_enabled() && !keep_comment;
 	gzFile fp1 = gzopen(argv[ai + 1], "r"), fp2 = 0;
 	if (!fp1) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 1]); return 1; }
 	if (argc - ai >= 3) { fp2 = gzopen(argv[ai + 2], "r"); if (!fp2) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 2]); return 1; } }
 	if (!interleaved && !fp2) { fprintf(stderr, "[bwa] single-end input is not supported: speedseq align is paired-end\n"); return 1; }
+	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
+	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
+	/* the readers (inflate + parse) start now: the first batches are parsed while the index travels to the device(s) */
+	fq_feed_t feed1(fp1, keep_comment, 16384); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384) : 0);
+
+	/* One worker thread per visible device (SURVEY 8e coupling 1: whole upstream batches go to the GPUs, no collective): each loads its
+	 * own replica of the index and takes the next assembled batch when it is free; results are re-serialised in input order. */
+	int n_dev = ssg_device_count();
+	{ const char *e = getenv("SSG_BWA_DEVICES"); if (e && atoi(e) > 0) n_dev = std::min(n_dev, atoi(e)); }
+	if (n_dev < 1) { fprintf(stderr, "[bwa] no MI355X visible: %s has no CPU path\n", ssg_backend()); return 1; }
+	if (n_dev > 16) n_dev = 16;
+	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
+	std::atomic<int> fail(0);
+	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
+	{
+		std::vector<std::thread> ld;
+		for (int g = 0; g < n_dev; ++g) ld.emplace_back([&, g]() {
+			if (ssg_set_device(g) || ssg_index_load(argv[ai], &idxs[(size_t)g])) { fprintf(stderr, "[bwa] fail to load the index on device %d: %s\n", g, ssg_last_error()); fail = 1; } });
+		for (std::thread &x : ld) x.join();
+	}
+	t_warm.join();
+	if (fail) return 1;
+	ssg_index_t *idx = idxs[0];
+	const double t_loaded = wall();
 	/* header: upstream bwa_print_sam_hdr + @PG */
-	for (int i = 0; i < ssg_index_n_ctg(idx); ++i) printf("@SQ\tSN:%s\tLN:%d\n", ssg_index_name(idx, i), ssg_index_len(idx, i));
-	if (!rg.empty()) printf("%s\n", rg.c_str());
-	{ std::string cl = "bwa"; for (int i = 0; i < argc; ++i) { cl += ' '; cl += argv[i]; } printf("@PG\tID:bwa\tPN:bwa\tVN:0.7.12-ssgpu\tCL:%s\n", cl.c_str()); }
-	fflush(stdout);
+	std::string hdr;
+	for (int i = 0; i < ssg_index_n_ctg(idx); ++i) { char b[64]; snprintf(b, sizeof(b), "\tLN:%d\n", ssg_index_len(idx, i)); hdr += "@SQ\tSN:"; hdr += ssg_index_name(idx, i); hdr += b; }
+	if (!rg.empty()) { hdr += rg; hdr += '\n'; }
+	{ hdr += "@PG\tID:bwa\tPN:bwa\tVN:0.7.12-ssgpu\tCL:bwa"; for (int i = 0; i < argc; ++i) { hdr += ' '; hdr += argv[i]; } hdr += '\n'; }
 #ifdef F_SETPIPE_SZ
 	(void)fcntl(1, F_SETPIPE_SZ, 1 << 20);   /* fewer wake-ups on the pipe to samblaster */
 #endif
+	if (fused) { if (!fu_write_full(1, FU_MAGIC, 8) || !fu_write_frame(1, FU_HEADER, hdr.data(), hdr.size())) { perror("[bwa] write"); return 1; } }
+	else if (!fu_write_full(1, hdr.data(), hdr.size())) { perror("[bwa] write"); return 1; }
 
-	/* Three overlapped stages, one batch each: (1) assemble upstream's batches from the reader threads' blocks, (2) align on the
-	 * MI355X, (3) format SAM (threads inside ssg_sam_format) and write.  Several upstream batches (bseq_read's chunk_size * n_threads
-	 * bases, even read count: the scope of the insert-size model) travel to the GPU in one call. */
+	/* Overlapped stages, one batch each: (1) assemble upstream's batches from the reader threads' blocks, (2) align on an MI355X,
+	 * (3) format (SAM text, or BAM records in fused mode; threads inside libssgpu) and (4) write.  Several upstream batches
+	 * (bseq_read's chunk_size * n_threads bases, even read count: the scope of the insert-size model) travel to the GPU in one call. */
 	struct batch_t {   /* names, comments and qualities stay where the reader put them (the batch holds on to those blocks); the bases are gathered
 	                    * for the device when the batch is complete, by several threads (the blocks were written by another core) */
 		std::vector<std::shared_ptr<fq_block_t> > hold;
 		std::vector<const char*> names, quals, comments;      /* 0 = absent */
 		std::vector<const uint8_t*> src;
 		std::unique_ptr<uint8_t[]> seq; std::vector<int64_t> off;
-		std::vector<int32_t> pair_batch; int n_batches; int64_t id0;
-		ssg_pe_result_t *res;
-		batch_t() : n_batches(0), id0(0), res(0) { off.push_back(0); }
+		std::vector<int32_t> pair_batch; int n_batches; int64_t id0, seqno;
+		ssg_pe_result_t *res; int dev;
+		batch_t() : n_batches(0), id0(0), seqno(0), res(0), dev(0) { off.push_back(0); }
 		int n() const { return (int)names.size(); }
 		void add(const std::shared_ptr<fq_block_t> &h, int i)
 		{
@@ -142,6 +170,7 @@ static int main_mem(int argc, char **argv)
 			src.push_back(b.seq.data() + b.seq_o[i]);
 			off.push_back(off.back() + (int64_t)(b.seq_o[i + 1] - b.seq_o[i]));
 		}
+		void drop_last() { names.pop_back(); comments.pop_back(); quals.pop_back(); src.pop_back(); off.pop_back(); }
 		void gather(int n_threads)
 		{
 			const size_t nr = src.size();
@@ -154,27 +183,45 @@ static int main_mem(int argc, char **argv)
 			for (std::thread &x : th) x.join();
 		}
 	};
-	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
-	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
-	fq_feed_t feed1(fp1, keep_comment, 16384); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384) : 0);
-	chan_t<std::unique_ptr<batch_t> > to_gpu(1), to_fmt(1);
-	int fail = 0; double tm_asm = 0, tm_gpu = 0;
+	chan_t<std::unique_ptr<batch_t> > to_gpu((size_t)n_dev);
+	/* aligned batches wait here for their turn: the formatter takes them in input order whichever device finished first */
+	struct reorder_t {
+		std::mutex mu; std::condition_variable cv; std::map<int64_t, std::unique_ptr<batch_t> > ready; int64_t next; int open_workers; size_t cap;
+		reorder_t(int w, size_t c) : next(0), open_workers(w), cap(c) {}
+		void put(std::unique_ptr<batch_t> B) { std::unique_lock<std::mutex> l(mu); const int64_t s = B->seqno; cv.wait(l, [&] { return s == next || ready.size() < cap; }); ready[s] = std::move(B); cv.notify_all(); }
+		void worker_done() { std::lock_guard<std::mutex> l(mu); --open_workers; cv.notify_all(); }
+		bool take(std::unique_ptr<batch_t> &B)
+		{
+			std::unique_lock<std::mutex> l(mu);
+			cv.wait(l, [&] { return (!ready.empty() && ready.begin()->first == next) || open_workers == 0; });
+			if (ready.empty() || ready.begin()->first != next) {
+				if (ready.empty()) return false;
+				next = ready.begin()->first;             /* a batch was lost to an error upstream: drain what is left */
+			}
+			B = std::move(ready.begin()->second); ready.erase(ready.begin()); ++next; cv.notify_all(); return true;
+		}
+	} to_fmt(n_dev, (size_t)n_dev + 1);
+	double tm_asm = 0; std::vector<double> tm_gpu((size_t)n_dev, 0.0); std::vector<long> calls((size_t)n_dev, 0);
 	std::thread t_asm([&]() {
 		fq_cursor_t c1(feed1); std::unique_ptr<fq_cursor_t> c2(feed2 ? new fq_cursor_t(*feed2) : 0);
-		int64_t id0 = 0; bool eof = false;
+		int64_t id0 = 0, seqno = 0; bool eof = false;
 		while (!eof && !fail) {
 			const double t0 = wall();
-			std::unique_ptr<batch_t> B(new batch_t()); B->id0 = id0;
+			std::unique_ptr<batch_t> B(new batch_t()); B->id0 = id0; B->seqno = seqno;
 			while (!eof && (size_t)B->n() / 2 < max_pairs_per_call) {   /* upstream bseq_read: one batch */
 				int64_t size = 0; const int n0 = B->n();
 				for (;;) {
-					const fq_block_t *ba, *bb; int ia, ib;
+					const fq_block_t *ba, *bb; int ia = 0, ib = 0;
 					(void)ba; (void)bb;
 					int rc = c1.next(&ba, &ia);
 					if (rc == -1) { eof = true; break; }
 					if (rc < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ\n"); fail = 1; eof = true; break; }
 					B->add(c1.cur, ia);
 					rc = (c2 ? *c2 : c1).next(&bb, &ib);
+					if (rc == -1) {   /* upstream bseq_read / main_mem: the complete pairs read so far are aligned and printed, the odd read is dropped */
+						fprintf(stderr, c2 ? "[W::bseq_read] the 2nd file has fewer sequences.\n" : "[W::main_mem] odd number of reads in the PE mode; last read dropped\n");
+						B->drop_last(); eof = true; break;
+					}
 					if (rc < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ (paired reads expected)\n"); fail = 1; eof = true; break; }
 					B->add((c2 ? *c2 : c1).cur, ib);
 					const int n = B->n();
@@ -188,55 +235,96 @@ static int main_mem(int argc, char **argv)
 			}
 			if (fail || B->n() == 0) break;
 			B->gather(std::min(8, std::max(1, opt.n_threads)));
-			id0 += B->n() / 2;
+			id0 += B->n() / 2; ++seqno;
 			tm_asm += wall() - t0;
 			to_gpu.push(std::move(B));
 		}
 		to_gpu.close();
 	});
-	std::thread t_gpu([&]() {
+	std::vector<std::thread> t_gpu;
+	for (int g = 0; g < n_dev; ++g) t_gpu.emplace_back([&, g]() {
 		std::unique_ptr<batch_t> B;
+		if (ssg_set_device(g)) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; }
 		while (to_gpu.pop(B)) {
 			const double t0 = wall();
-			if (!fail && ssg_mem_process_pairs(idx, &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
-				fprintf(stderr, "[bwa] alignment failed: %s\n", ssg_last_error()); fail = 1; }
-			tm_gpu += wall() - t0;
-			if (!fail) to_fmt.push(std::move(B));
+			B->dev = g;
+			if (!fail && ssg_mem_process_pairs(idxs[(size_t)g], &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
+				fprintf(stderr, "[bwa] alignment failed on device %d: %s\n", g, ssg_last_error()); fail = 1; }
+			tm_gpu[(size_t)g] += wall() - t0; ++calls[(size_t)g];
+			if (!fail) to_fmt.put(std::move(B));
 		}
-		to_fmt.close();
+		to_fmt.worker_done();
 	});
-	struct text_t { char *sam; size_t len; };
-	chan_t<text_t> to_write(2);
+	struct text_t { char *p; size_t len; uint32_t frame; };   /* frame: 0 = raw bytes, otherwise the fused frame type to wrap them in */
+	chan_t<text_t> to_write(4);
 	std::thread t_write([&]() {   /* stdout is a pipe in the reference's pipeline: its reader sets the pace, so writing gets its own thread */
 		text_t t;
 		while (to_write.pop(t)) {
-			for (size_t o = 0; o < t.len && !fail; ) { ssize_t w = write(1, t.sam + o, t.len - o); if (w < 0) { if (errno == EINTR) continue; perror("[bwa] write"); fail = 1; break; } o += (size_t)w; }
-			ssg_free(t.sam);
+			if (!fail && !(t.frame ? fu_write_frame(1, t.frame, t.p, t.len) : fu_write_full(1, t.p, t.len))) { perror("[bwa] write"); fail = 1; }
+			ssg_free(t.p);
 		}
 	});
 	double tm_fmt = 0;
-	{	/* this thread: format */
+	{	/* this thread: format, in input order */
 		std::unique_ptr<batch_t> B;
-		while (to_fmt.pop(B)) {
+		std::vector<int32_t> cand; std::vector<int64_t> sam_off;
+		while (to_fmt.take(B)) {
 			if (fail) { if (B->res) ssg_pe_result_free(B->res); continue; }
 			const double t0 = wall();
 			const int n = B->n();
-			char *sam; std::vector<int64_t> sam_off(n + 1);
-			if (ssg_sam_format(idx, &opt, B->res, n / 2, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), B->comments.data(), rg_id, &sam, sam_off.data())) {
-				fprintf(stderr, "[bwa] SAM formatting failed: %s\n", ssg_last_error()); fail = 1; ssg_pe_result_free(B->res); continue; }
+			text_t t; t.p = 0; t.len = 0; t.frame = 0;
+			sam_off.resize((size_t)n + 1);
+			if (!fused) {
+				char *sam;
+				if (ssg_sam_format(idx, &opt, B->res, n / 2, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), B->comments.data(), rg_id, &sam, sam_off.data())) {
+					fprintf(stderr, "[bwa] SAM formatting failed: %s\n", ssg_last_error()); fail = 1; ssg_pe_result_free(B->res); continue; }
+				t.p = sam; t.len = (size_t)sam_off[(size_t)n];
+			} else {
+				/* BAM records of every read + the SAM text of the pairs samblaster may copy to a side stream: a read with supplementary
+				 * lines (splitter test) or both ends mapped without the proper-pair flag (discordant test) -- a superset under any options */
+				const int64_t *req_off = ssg_pe_req_off(B->res); const ssg_alnreq_t *req = ssg_pe_req(B->res); const ssg_aln_t *alns = ssg_pe_alns(B->res);
+				std::vector<int32_t> nmain((size_t)n); cand.clear();
+				for (int r = 0; r < n; ++r) { int c = 0; for (int64_t g = req_off[r]; g < req_off[r + 1]; ++g) c += req[g].kind == SSG_REQ_MAIN; nmain[(size_t)r] = c; }
+				for (int p = 0; p < n / 2; ++p) {
+					const ssg_aln_t &a1 = alns[req_off[2 * p]], &a2 = alns[req_off[2 * p + 1]];
+					if (nmain[2 * (size_t)p] > 1 || nmain[2 * (size_t)p + 1] > 1 || (a1.rid >= 0 && a2.rid >= 0 && !(a1.flag & 0x2))) cand.push_back(p);
+				}
+				uint8_t *bam; char *ctext = 0; std::vector<int64_t> bam_off((size_t)n + 1), c_off(2 * cand.size() + 1, 0);
+				if (ssg_bam_format(idx, &opt, B->res, n / 2, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), rg_id, &bam, bam_off.data())
+				    || (!cand.empty() && ssg_sam_format_sel(idx, &opt, B->res, cand.data(), (int)cand.size(), B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), 0, rg_id, &ctext, c_off.data()))) {
+					fprintf(stderr, "[bwa] record formatting failed: %s\n", ssg_last_error()); fail = 1; ssg_pe_result_free(B->res); continue; }
+				std::vector<int64_t> rec0((size_t)n / 2 + 1, 0);      /* ordinal of each pair's first record within the batch */
+				for (int p = 0; p < n / 2; ++p) rec0[(size_t)p + 1] = rec0[(size_t)p] + nmain[2 * (size_t)p] + nmain[2 * (size_t)p + 1];
+				fu_batch_t bh; bh.n_rec = (uint64_t)rec0[(size_t)n / 2]; bh.bam_bytes = (uint64_t)bam_off[(size_t)n]; bh.n_cand = cand.size(); bh.text_bytes = (uint64_t)c_off[2 * cand.size()];
+				t.len = sizeof(bh) + cand.size() * sizeof(fu_cand_t) + (size_t)bh.text_bytes + (size_t)bh.bam_bytes; t.frame = FU_BATCH;
+				t.p = (char*)malloc(t.len ? t.len : 1);
+				if (!t.p) { fprintf(stderr, "[bwa] out of memory\n"); fail = 1; ssg_pe_result_free(B->res); continue; }
+				char *w = t.p; memcpy(w, &bh, sizeof(bh)); w += sizeof(bh);
+				for (size_t k = 0; k < cand.size(); ++k) { fu_cand_t c; c.first_rec = (uint64_t)rec0[(size_t)cand[k]]; c.n_rec = (uint64_t)(rec0[(size_t)cand[k] + 1] - rec0[(size_t)cand[k]]); c.text_off = (uint64_t)c_off[2 * k]; memcpy(w, &c, sizeof(c)); w += sizeof(c); }
+				if (bh.text_bytes) memcpy(w, ctext, (size_t)bh.text_bytes);
+				w += bh.text_bytes;
+				{	/* the record blob, copied by a few threads */
+					const size_t nb = (size_t)bh.bam_bytes; const int T = (int)std::max<size_t>(1, std::min<size_t>(8, nb >> 24));
+					std::vector<std::thread> th;
+					for (int k = 0; k < T; ++k) th.emplace_back([=]() { const size_t a = nb * (size_t)k / (size_t)T, e = nb * (size_t)(k + 1) / (size_t)T; memcpy(w + a, bam + a, e - a); });
+					for (std::thread &x : th) x.join();
+				}
+				ssg_free(bam); ssg_free(ctext);
+			}
 			tm_fmt += wall() - t0;
 			const ssg_pestat_t *pp = ssg_pe_pes(B->res);
-			fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
-			        n, B->n_batches, ssg_backend(), pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
+			fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s device %d; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
+			        n, B->n_batches, ssg_backend(), B->dev, pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
 			ssg_pe_result_free(B->res);
-			text_t t; t.sam = sam; t.len = (size_t)sam_off[n];
 			to_write.push(t);
 		}
 	}
+	if (fused && !fail) { text_t t; t.p = 0; t.len = 0; t.frame = FU_END; t.p = (char*)malloc(1); to_write.push(t); }
 	to_write.close(); t_write.join();
-	t_asm.join(); t_gpu.join();
-	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> SAM %.2f s\n", t_loaded - t_start, wall() - t_loaded);
-	fprintf(stderr, "[bwa] stage busy time: assemble %.2f s, device call %.2f s, format %.2f s\n", tm_asm, tm_gpu, tm_fmt);
+	t_asm.join(); for (std::thread &x : t_gpu) x.join();
+	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> %s %.2f s\n", t_loaded - t_start, fused ? "BAM records (fused)" : "SAM", wall() - t_loaded);
+	{ double g = 0; for (double x : tm_gpu) g += x; fprintf(stderr, "[bwa] stage busy time: assemble %.2f s, device call %.2f s, format %.2f s\n", tm_asm, g, tm_fmt); }
+	if (n_dev > 1) for (int g = 0; g < n_dev; ++g) fprintf(stderr, "[bwa] device %d: %ld calls, %.2f s busy\n", g, calls[(size_t)g], tm_gpu[(size_t)g]);
 	if (getenv("SSG_BWA_PROF")) {   /* per-kernel device time of the whole run (HIP events; the profiling was switched on before the first call) */
 		const char *nm[256]; double ms[256]; long cnt[256];
 		const int n = std::min(ssg_prof_get(256, nm, ms, cnt), 256);
@@ -247,8 +335,8 @@ static int main_mem(int argc, char **argv)
 	{ std::shared_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
 	feed1.th.join(); if (feed2) feed2->th.join();
 	gzclose(fp1); if (fp2) gzclose(fp2);
-	ssg_index_destroy(idx);
-	return fail;
+	for (int g = 0; g < n_dev; ++g) { (void)ssg_set_device(g); ssg_index_destroy(idxs[(size_t)g]); }
+	return fail ? 1 : 0;
 }
 
 int main(int argc, char **argv)

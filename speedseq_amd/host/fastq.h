@@ -80,9 +80,12 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	}
 	inline int getc() { if (begin >= end && !fill()) return -1; return buf[begin++]; }
 	/* ks_getuntil2: append to out until the delimiter (0 = any blank, 2 = end of line); returns -1 at EOF with nothing read; *dret = delimiter */
-	template <class V> int getuntil(int delim, V &out, int *dret)
+	/* field0: where the string this call appends to began (kseq strips a trailing CR when the WHOLE string is longer than one character,
+	 * ks_getuntil2's `str->l > 1`: a sequence or quality line continues a string the caller already started) */
+	template <class V> int getuntil(int delim, V &out, int *dret, size_t field0 = (size_t)-1)
 	{
 		bool got = false; size_t l0 = out.size();
+		if (field0 == (size_t)-1) field0 = l0;
 		if (dret) *dret = 0;
 		for (;;) {
 			if (begin >= end) { if (!fill()) break; }
@@ -95,8 +98,8 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 			if (i < end) { if (dret) *dret = buf[i]; break; }
 		}
 		if (!got && is_eof && begin >= end) return -1;
-		if (delim == 2 && out.size() - l0 > 1 && out.back() == '\r') out.pop_back();
-		return (int)(out.size() - l0);
+		if (delim == 2 && out.size() - field0 > 1 && out.back() == '\r') out.pop_back();
+		return out.size() > l0 ? (int)(out.size() - l0) : 0;
 	}
 };
 
@@ -127,7 +130,7 @@ struct fq_reader_t {
 		while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
 			if (c == '\n') continue;
 			b.seq.push_back((uint8_t)c);
-			ks.getuntil(2, b.seq, 0);
+			ks.getuntil(2, b.seq, 0, s0);
 		}
 		if (c == '>' || c == '@') last_char = c;
 		const size_t l_seq = b.seq.size() - s0;
@@ -135,7 +138,7 @@ struct fq_reader_t {
 		if (c == '+') {
 			while ((c = ks.getc()) != -1 && c != '\n') {}
 			if (c == -1) return -2;
-			while (ks.getuntil(2, b.qual, 0) >= 0 && b.qual.size() - q0 < l_seq) {}
+			while (ks.getuntil(2, b.qual, 0, q0) >= 0 && b.qual.size() - q0 < l_seq) {}
 			last_char = 0;
 			if (b.qual.size() - q0 != l_seq) return -2;
 			b.qual.push_back(0); hq = true;

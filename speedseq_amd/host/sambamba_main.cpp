@@ -17,6 +17,10 @@
 #include <sys/stat.h>
 #include "bamio.h"
 #include "fastq.h"   /* chan_t */
+#include "fused.h"
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
 #include "../../include/ssgpu.h"
 
 static int hw_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)std::min(n, 32u) : 4; }
@@ -47,13 +51,22 @@ static int cmd_view(int argc, char **argv)
 		return 0;
 	}
 	if (!sam_in || strcmp(fmt, "bam")) die("view: only `-S -f bam` (SAM text to BAM) and `-H` are supported");
+	/* fused stream (fused.h): the records already are BAM records; they pass through to `sambamba sort` untouched */
+	char first[8]; size_t n_first = 0;
+	while (n_first < 8) { ssize_t r = read(fd, first + n_first, 8 - n_first); if (r < 0) { if (errno == EINTR) continue; die("view: read error"); } if (r == 0) break; n_first += (size_t)r; }
+	if (n_first == 8 && !memcmp(first, FU_MAGIC, 8)) {
+		io_write_all(1, first, 8);
+		std::vector<char> b((size_t)4 << 20);
+		for (;;) { ssize_t r = read(fd, b.data(), b.size()); if (r < 0) { if (errno == EINTR) continue; die("view: read error"); } if (r == 0) break; io_write_all(1, b.data(), (size_t)r); }
+		return 0;
+	}
 	bgzf_out_t out(1, level, threads);
 	bam_hdr_t h; bool hdr_done = false;
 	/* a reader thread cuts stdin into pieces of whole lines (the pipe from samblaster is read while the previous piece is encoded) */
 	struct piece_t { std::vector<char> buf; size_t end; };
 	chan_t<std::unique_ptr<piece_t> > ch(2);
 	std::thread reader([&]() {
-		std::vector<char> carry; bool eof = false;
+		std::vector<char> carry(first, first + n_first); bool eof = false;
 		while (!eof) {
 			std::unique_ptr<piece_t> P(new piece_t());
 			P->buf.resize((size_t)48 << 20);
@@ -133,20 +146,87 @@ static void change_so(std::string &text, const char *so)
 	} else text = std::string("@HD\tVN:1.3\tSO:") + so + "\n" + text;
 }
 
-struct rec_store_t { std::vector<uint8_t> bytes; std::vector<uint64_t> off, key; };   /* off: start of each record's block_size word */
+/* records of the input, held in the chunks they arrived in (a fused frame, or ~64 MB assembled from the BGZF stream): nothing is
+ * copied or re-allocated while the input streams in; a record is (chunk << 40 | offset of its block_size word) */
+struct rec_store_t {
+	std::vector<std::unique_ptr<uint8_t[]> > chunk; std::vector<size_t> chunk_len;
+	std::vector<uint64_t> loc, key; uint64_t bytes;
+	rec_store_t() : bytes(0) {}
+	const uint8_t *rec(size_t i) const { return chunk[(size_t)(loc[i] >> 40)].get() + (loc[i] & (((uint64_t)1 << 40) - 1)); }
+	void clear() { chunk.clear(); chunk_len.clear(); loc.clear(); key.clear(); bytes = 0; }
+	/* index the whole records of chunk c[0..len) */
+	bool add_chunk(std::unique_ptr<uint8_t[]> c, size_t len)
+	{
+		const uint64_t id = chunk.size(); const uint8_t *p = c.get(); size_t o = 0;
+		while (o + 4 <= len) { uint32_t bs; memcpy(&bs, p + o, 4); if (o + 4 + (size_t)bs > len || bs < 32) return false; loc.push_back(id << 40 | (uint64_t)o); key.push_back(bam_sort_key(p + o + 4)); o += 4 + (size_t)bs; }
+		if (o != len) return false;
+		chunk.push_back(std::move(c)); chunk_len.push_back(len); bytes += len;
+		return true;
+	}
+};
 
-static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads)
-{
-	bgzf_out_t out(fd, level, threads);
-	hdr_write(out, h);
-	for (size_t i = 0; i < perm.size(); ++i) { const uint64_t o = S.off[perm[i]]; uint32_t bs; memcpy(&bs, S.bytes.data() + o, 4); out.record(S.bytes.data() + o, 4 + (size_t)bs); }
-	out.finish();
-}
 static void gpu_perm(const rec_store_t &S, std::vector<uint32_t> &perm)
 {
 	perm.resize(S.key.size());
 	if (S.key.empty()) return;
 	if (ssg_sort_u64_perm(S.key.data(), (int64_t)S.key.size(), perm.data())) die(std::string("sort: ") + ssg_last_error());
+}
+
+/* the sorted records as a BGZF stream.  Blocks are cut exactly as bgzf_out_t::record cuts them (a record does not straddle blocks
+ * unless it is larger than one); the gather of a block's records and its deflate run on the thread pool, groups of blocks are
+ * written in order by the calling thread while later groups are still being compressed. */
+static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads)
+{
+	{ bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
+	const size_t n = perm.size();
+	const int lvl = level < 0 ? 6 : level;
+	/* virtual byte offsets of the sorted stream and the block cuts */
+	std::vector<uint64_t> cum(n + 1); cum[0] = 0;
+	parallel_for(threads, n, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) { uint32_t bs; memcpy(&bs, S.rec(perm[i]), 4); cum[i + 1] = 4 + (uint64_t)bs; } });
+	for (size_t i = 0; i < n; ++i) cum[i + 1] += cum[i];
+	std::vector<uint64_t> cut; cut.push_back(0);
+	{	uint64_t open = 0;   /* start of the open block */
+		for (size_t i = 0; i < n; ++i) {
+			const uint64_t sz = cum[i + 1] - cum[i];
+			if (cum[i] > open && cum[i] - open + sz > BGZF_MAX_PAYLOAD) { cut.push_back(cum[i]); open = cum[i]; }
+			while (cum[i + 1] - open >= BGZF_MAX_PAYLOAD) { open += BGZF_MAX_PAYLOAD; cut.push_back(open); }   /* a record larger than a block fills whole blocks */
+		}
+		if (cum[n] > cut.back()) cut.push_back(cum[n]);
+	}
+	const size_t nb = cut.size() - 1, GRP = 128, ng = (nb + GRP - 1) / GRP;
+	struct grp_t { std::vector<uint8_t> bytes; bool done; grp_t() : done(false) {} };
+	std::vector<grp_t> grp(ng);
+	std::mutex mu; std::condition_variable cv; size_t next_write = 0; std::atomic<size_t> next_grp(0);
+	const size_t window = (size_t)std::max(4, threads * 3);   /* groups compressed ahead of the writer */
+	auto worker = [&]() {
+		std::vector<uint8_t> payload(BGZF_MAX_PAYLOAD), blk(65536);
+		for (;;) {
+			const size_t g = next_grp.fetch_add(1);
+			if (g >= ng) break;
+			{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return g < next_write + window; }); }
+			std::vector<uint8_t> ob; ob.reserve(GRP * (lvl ? 24576 : 65536));
+			for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
+				const uint64_t v0 = cut[bk], v1 = cut[bk + 1];
+				size_t i = (size_t)(std::upper_bound(cum.begin(), cum.end(), v0) - cum.begin()) - 1; size_t w = 0;
+				for (uint64_t v = v0; v < v1; ++i) { const uint8_t *r = S.rec(perm[i]); const uint64_t a = v - cum[i], e = std::min(cum[i + 1], v1) - cum[i]; memcpy(payload.data() + w, r + a, (size_t)(e - a)); w += (size_t)(e - a); v = cum[i] + e; }
+				const size_t k = bgzf_make_block(payload.data(), w, lvl, blk.data());
+				ob.insert(ob.end(), blk.data(), blk.data() + k);
+			}
+			{ std::lock_guard<std::mutex> l(mu); grp[g].bytes.swap(ob); grp[g].done = true; }
+			cv.notify_all();
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 0; t < std::max(1, threads); ++t) th.emplace_back(worker);
+	for (size_t g = 0; g < ng; ++g) {
+		std::vector<uint8_t> ob;
+		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); }
+		io_write_all(fd, ob.data(), ob.size());
+		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; }
+		cv.notify_all();
+	}
+	for (auto &x : th) x.join();
+	io_write_all(fd, BGZF_EOF, 28);
 }
 
 struct merge_src_t {   /* one coordinate-sorted BAM being merged */
@@ -181,38 +261,82 @@ static int cmd_sort(int argc, char **argv)
 	}
 	if (!in || outp.empty()) die("usage: sambamba sort [-t N] [-m XG] [--tmpdir=DIR] -o out.bam <in.bam>");
 	if (threads < 1) threads = 1;
+	{ const char *e = getenv("SSG_BAM_LEVEL"); if (level < 0 && e && *e) level = atoi(e); }   /* deflate level of the sorted file when -l is not given (default: zlib's 6, as sambamba's) */
+	/* compression is CPU work the reference's `-t` undersizes on a host with hundreds of cores next to an MI355X: the pool may use more (SSG_SORT_THREADS) */
+	int pool = threads; { const char *e = getenv("SSG_SORT_THREADS"); if (e && atoi(e) > 0) pool = atoi(e); }
 	const int fd = open_in(in);
-	bgzf_in_t bi(fd, threads); bam_hdr_t h;
-	if (!hdr_read(bi, h)) die("sort: not a BAM file");
-	change_so(h.text, "coordinate");
-	uint64_t budget = (uint64_t)(std::max(mem_gb, 0.25) * 0.6 * 1073741824.0);   /* record bytes per in-memory chunk; the rest is keys, offsets, output blocks */
+	char first[8]; size_t n_first = 0;
+	while (n_first < 8) { ssize_t r = read(fd, first + n_first, 8 - n_first); if (r < 0) { if (errno == EINTR) continue; die("sort: read error"); } if (r == 0) break; n_first += (size_t)r; }
+	const bool fused = n_first == 8 && !memcmp(first, FU_MAGIC, 8);
+	uint64_t budget = (uint64_t)(std::max(mem_gb, 0.25) * 0.6 * 1073741824.0);   /* record bytes per in-memory run; the rest is keys, locations, output blocks */
 	{ const char *e = getenv("SSG_SORT_CHUNK_BYTES"); if (e && atoll(e) > 0) budget = (uint64_t)atoll(e); }   /* the tests force the spill-and-merge path */
-	rec_store_t S; std::vector<std::string> spills;
-	mkdir(tmpdir.c_str(), 0777);
+	rec_store_t S; std::vector<std::string> spills; bam_hdr_t h;
+	if (mkdir(tmpdir.c_str(), 0777) != 0 && errno != EEXIST) die("sort: cannot create " + tmpdir + ": " + strerror(errno));
 	auto spill = [&]() {
 		std::vector<uint32_t> perm; gpu_perm(S, perm);
 		char nm[64]; snprintf(nm, sizeof(nm), "/ssg_sort_%d_%04zu.bam", (int)getpid(), spills.size());
 		const std::string p = tmpdir + nm;
 		int ofd = open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + p);
-		write_sorted(S, perm, h, ofd, 1, threads); close(ofd);
-		spills.push_back(p); S.bytes.clear(); S.off.clear(); S.key.clear();
+		write_sorted(S, perm, h, ofd, 1, pool); close(ofd);
+		spills.push_back(p); S.clear();
 	};
-	for (;;) {
-		uint32_t bs;
-		if (bi.get(&bs, 4) != 4) break;
-		const size_t o = S.bytes.size(); S.bytes.resize(o + 4 + (size_t)bs);
-		memcpy(S.bytes.data() + o, &bs, 4);
-		if (bi.get(S.bytes.data() + o + 4, bs) != bs) die("sort: truncated BAM");
-		S.off.push_back(o); S.key.push_back(bam_sort_key(S.bytes.data() + o + 4));
-		if (S.bytes.size() >= budget || S.key.size() >= 0xfffffff0u) spill();
+	if (fused) {
+		/* frames straight from samblaster (fused.h): a reader thread takes them off the pipe, this thread indexes the records (keys +
+		 * locations) of each while the next arrives -- the sort's input work overlaps the alignment upstream */
+		struct frame_t { fu_frame_t fh; std::unique_ptr<uint8_t[]> p; };
+		chan_t<std::unique_ptr<frame_t> > ch(2); std::atomic<int> rd_fail(0);
+		std::thread reader([&]() {
+			for (;;) {
+				std::unique_ptr<frame_t> F(new frame_t());
+				if (!fu_read_full(fd, &F->fh, sizeof(F->fh))) { rd_fail = 1; break; }
+				if (F->fh.len) { F->p.reset(new uint8_t[F->fh.len]); if (!fu_read_full(fd, F->p.get(), (size_t)F->fh.len)) { rd_fail = 1; break; } }
+				const bool end = F->fh.type == FU_END;
+				ch.push(std::move(F));
+				if (end) break;
+			}
+			ch.close();
+		});
+		std::unique_ptr<frame_t> F; bool ended = false;
+		while (ch.pop(F)) {
+			if (F->fh.type == FU_END) { ended = true; break; }
+			if (F->fh.type == FU_HEADER) { h.text.assign((const char*)F->p.get(), (size_t)F->fh.len); hdr_from_text(h); change_so(h.text, "coordinate"); continue; }
+			if (F->fh.type != FU_MAIN) die("sort: unexpected frame in the fused stream");
+			if (!F->fh.len) continue;
+			if (!S.add_chunk(std::move(F->p), (size_t)F->fh.len)) die("sort: malformed record frame");
+			if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill();
+		}
+		{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
+		reader.join();
+		if (rd_fail || !ended) die("sort: the fused stream ended early");
+		if (h.names.empty() && h.text.empty()) change_so(h.text, "coordinate");
+	} else {
+		bgzf_in_t bi(fd, threads);
+		bi.raw.assign((const uint8_t*)first, (const uint8_t*)first + n_first);
+		if (!hdr_read(bi, h)) die("sort: not a BAM file");
+		change_so(h.text, "coordinate");
+		const size_t CH = (size_t)64 << 20;
+		std::unique_ptr<uint8_t[]> cur(new uint8_t[CH]); size_t cap = CH, len = 0;
+		auto flush = [&]() { if (!len) return; if (!S.add_chunk(std::move(cur), len)) die("sort: malformed BAM record"); cur.reset(new uint8_t[CH]); cap = CH; len = 0; if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill(); };
+		for (;;) {
+			uint32_t bs;
+			if (bi.get(&bs, 4) != 4) break;
+			if (len + 4 + (size_t)bs > cap) {
+				flush();
+				if (4 + (size_t)bs > cap) { cap = 4 + (size_t)bs; cur.reset(new uint8_t[cap]); }
+			}
+			memcpy(cur.get() + len, &bs, 4);
+			if (bi.get(cur.get() + len + 4, bs) != bs) die("sort: truncated BAM");
+			len += 4 + (size_t)bs;
+		}
+		flush();
 	}
 	int ofd = open(outp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + outp);
-	if (spills.empty()) { std::vector<uint32_t> perm; gpu_perm(S, perm); write_sorted(S, perm, h, ofd, level, threads); }
+	if (spills.empty()) { std::vector<uint32_t> perm; gpu_perm(S, perm); write_sorted(S, perm, h, ofd, level, pool); }
 	else {
 		if (!S.key.empty()) spill();
 		std::vector<merge_src_t> src(spills.size());
 		for (size_t i = 0; i < spills.size(); ++i) { src[i].fd = open_in(spills[i].c_str()); src[i].in.reset(new bgzf_in_t(src[i].fd, 2)); if (!hdr_read(*src[i].in, src[i].h)) die("sort: bad spill file"); }
-		bgzf_out_t out(ofd, level, threads); hdr_write(out, h);
+		bgzf_out_t out(ofd, level, pool); hdr_write(out, h);
 		kway_merge(src, out); out.finish();
 		for (size_t i = 0; i < spills.size(); ++i) { close(src[i].fd); unlink(spills[i].c_str()); }
 	}

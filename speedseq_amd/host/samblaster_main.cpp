@@ -22,8 +22,22 @@
 #include <unordered_map>
 #include <memory>
 #include <thread>
+#include <atomic>
+#include <algorithm>
+#include <functional>
 #include "../../include/ssgpu.h"
 #include "fastq.h"   /* chan_t */
+#include "fused.h"
+
+static inline void parallel_ranges(int n_threads, size_t n, const std::function<void(size_t, size_t)> &fn)
+{
+	if (n_threads < 1) n_threads = 1;
+	if ((size_t)n_threads > n) n_threads = n ? (int)n : 1;
+	if (n_threads == 1) { fn(0, n); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < n_threads; ++t) th.emplace_back([&, t]() { fn(n * (size_t)t / (size_t)n_threads, n * (size_t)(t + 1) / (size_t)n_threads); });
+	for (auto &x : th) x.join();
+}
 
 struct out_t {           /* buffered writer on a file descriptor */
 	int fd; std::vector<char> b; size_t n;
@@ -52,6 +66,230 @@ static bool has_tag(const char *p, const char *e, const char *tag)
 	return false;
 }
 
+/* the offsets `emit` needs, from one SAM line (no '\n'); false when the line has fewer than 11 fields */
+static bool scan_fields(const char *s, size_t len, size_t off, lrec_t &r, const char **f /* [7] field starts */, const char **opt_out)
+{
+	const char *e = s + len; int nf = 0;
+	f[nf++] = s;
+	for (const char *p = s; nf < 7; ) { const char *t = (const char*)memchr(p, '\t', (size_t)(e - p)); if (!t) break; f[nf++] = t + 1; p = t + 1; }
+	if (nf < 7) return false;
+	const char *p = f[6]; int more = 0;                   /* fields 7..11 are skipped, not read */
+	const char *opt = 0;
+	while (more < 5) { const char *t = (const char*)memchr(p, '\t', (size_t)(e - p)); if (!t) break; p = t + 1; ++more; }
+	if (more < 4) return false;                           /* fewer than 11 mandatory fields */
+	if (more == 5) opt = p;
+	r.off = off; r.len = (uint32_t)len; r.qn_len = (uint32_t)(f[1] - 1 - s); r.flag_end = (uint32_t)(f[2] - 1 - s);
+	r.mq_off = (uint32_t)(f[4] - s); r.mq_len = (uint32_t)(f[5] - 1 - f[4]); r.cig_off = (uint32_t)(f[5] - s); r.cig_len = (uint32_t)(f[6] - 1 - f[5]);
+	r.opt_off = opt ? (uint32_t)(opt - s) : 0;
+	if (opt_out) *opt_out = opt;
+	return true;
+}
+
+/* ---------------- fused mode (fused.h): BAM records in, BAM records out, side streams as text ---------------- */
+#include <zlib.h>
+struct bam_view_t {                     /* fields of one BAM record (after block_size) */
+	const uint8_t *p; uint32_t bs;
+	int32_t tid() const { int32_t v; memcpy(&v, p, 4); return v; }
+	int32_t pos() const { int32_t v; memcpy(&v, p + 4, 4); return v; }
+	uint32_t bmn() const { uint32_t v; memcpy(&v, p + 8, 4); return v; }
+	uint32_t fnc() const { uint32_t v; memcpy(&v, p + 12, 4); return v; }
+	int32_t l_seq() const { int32_t v; memcpy(&v, p + 16, 4); return v; }
+	uint32_t l_qname() const { return bmn() & 0xff; }
+	uint32_t n_cigar() const { return fnc() & 0xffff; }
+	uint32_t flag() const { return fnc() >> 16; }
+	uint32_t mapq() const { return (bmn() >> 8) & 0xff; }
+	const char *qname() const { return (const char*)p + 32; }
+	const uint8_t *cigar() const { return p + 32 + l_qname(); }
+	const uint8_t *aux() const { return cigar() + 4 * n_cigar() + ((l_seq() + 1) >> 1) + l_seq(); }
+	const uint8_t *end() const { return p + bs; }
+};
+static bool bam_has_tag(const bam_view_t &v, char a, char b)
+{	/* walk of the aux fields (htslib sam.c skip_aux) */
+	const uint8_t *s = v.aux(), *e = v.end();
+	while (s + 3 <= e) {
+		if (s[0] == (uint8_t)a && s[1] == (uint8_t)b) return true;
+		const uint8_t t = s[2]; s += 3;
+		switch (t) {
+			case 'A': case 'c': case 'C': s += 1; break;
+			case 's': case 'S': s += 2; break;
+			case 'i': case 'I': case 'f': s += 4; break;
+			case 'd': s += 8; break;
+			case 'Z': case 'H': while (s < e && *s) ++s; ++s; break;
+			case 'B': { if (s + 5 > e) return false; const uint8_t st = s[0]; uint32_t n; memcpy(&n, s + 1, 4); const int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; s += 5 + (size_t)n * sz; break; }
+			default: return false;
+		}
+	}
+	return false;
+}
+
+static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *splf, FILE *discf, const char *pg)
+{
+	ssg_sbl_state_t *st = ssg_sbl_state_new();
+	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
+	int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	{ const char *e = getenv("SSG_SBL_THREADS"); if (e && atoi(e) > 0) threads = atoi(e); }
+	if (!fu_write_full(1, FU_MAGIC, 8)) { perror("[samblaster] write"); return 1; }
+	bool got_header = false, ended = false;
+	/* frames are read by a thread of their own so that the next batch arrives while this one is decided and written */
+	struct frame_t { fu_frame_t h; std::unique_ptr<uint8_t[]> p; };
+	chan_t<std::unique_ptr<frame_t> > ch(2); std::atomic<int> rd_fail(0);
+	std::thread reader([&]() {
+		for (;;) {
+			std::unique_ptr<frame_t> F(new frame_t());
+			if (!fu_read_full(0, &F->h, sizeof(F->h))) { rd_fail = 1; break; }
+			if (F->h.len) { F->p.reset(new uint8_t[F->h.len]); if (!fu_read_full(0, F->p.get(), (size_t)F->h.len)) { rd_fail = 1; break; } }
+			const bool end = F->h.type == FU_END;
+			ch.push(std::move(F));
+			if (end) break;
+		}
+		ch.close();
+	});
+	std::vector<uint64_t> rec_off; std::vector<ssg_sbl_line_t> lines; std::vector<uint8_t> newblk, bits; std::vector<int64_t> blk_off, mate;
+	std::vector<std::pair<const char*, uint32_t> > ltext;
+	std::unique_ptr<frame_t> F;
+	int rc = 0;
+	while (!rc && ch.pop(F)) {
+		if (F->h.type == FU_END) { ended = true; break; }
+		if (F->h.type == FU_HEADER) {
+			std::string h((const char*)F->p.get(), (size_t)F->h.len); h += pg;
+			if (!fu_write_frame(1, FU_HEADER, h.data(), h.size())) { perror("[samblaster] write"); rc = 1; break; }
+			if (spl) spl->put(h.data(), h.size());
+			if (disc) disc->put(h.data(), h.size());
+			got_header = true; continue;
+		}
+		if (F->h.type != FU_BATCH || F->h.len < sizeof(fu_batch_t)) { fprintf(stderr, "[samblaster] unexpected frame in the fused stream\n"); rc = 1; break; }
+		fu_batch_t bh; memcpy(&bh, F->p.get(), sizeof(bh));
+		if (sizeof(bh) + bh.n_cand * sizeof(fu_cand_t) + bh.text_bytes + bh.bam_bytes != F->h.len) { fprintf(stderr, "[samblaster] malformed batch frame\n"); rc = 1; break; }
+		const fu_cand_t *cand = (const fu_cand_t*)(F->p.get() + sizeof(bh));
+		const char *text = (const char*)(cand + bh.n_cand);
+		const uint8_t *bam = (const uint8_t*)text + bh.text_bytes;
+		const size_t nr = (size_t)bh.n_rec;
+		if (!nr) continue;
+		rec_off.resize(nr + 1);
+		{ uint64_t o2 = 0; size_t i = 0; for (; i < nr && o2 + 4 <= bh.bam_bytes; ++i) { rec_off[i] = o2; uint32_t bs; memcpy(&bs, bam + o2, 4); o2 += 4 + (uint64_t)bs; } rec_off[nr] = o2;
+		  if (i != nr || o2 != bh.bam_bytes) { fprintf(stderr, "[samblaster] record count does not match the batch frame\n"); rc = 1; break; } }
+		lines.resize(nr); newblk.resize(nr); bits.resize(nr); mate.resize(nr);
+		auto view = [&](size_t i) { bam_view_t v; v.p = bam + rec_off[i] + 4; v.bs = (uint32_t)(rec_off[i + 1] - rec_off[i] - 4); return v; };
+		/* samblaster's numeric view of every line, from the BAM fields the text would have carried */
+		parallel_ranges(threads, nr, [&](size_t a, size_t b) {
+			for (size_t i = a; i < b; ++i) {
+				const bam_view_t v = view(i); ssg_sbl_line_t n;
+				n.flag = (int32_t)v.flag(); n.pos = v.pos() + 1; n.mapq = (int32_t)v.mapq(); n.seq = v.tid() < 0 ? -1 : v.tid();
+				n.lclip = n.rclip = n.qalen = n.ralen = 0;
+				bool first = true; int rcl = 0; const uint8_t *c = v.cigar();
+				for (uint32_t k = 0; k < v.n_cigar(); ++k) {
+					uint32_t x; memcpy(&x, c + 4 * k, 4); const int op = (int)(x & 0xf), len = (int)(x >> 4);
+					if (op == 4 || op == 5) { if (first) n.lclip += len; rcl += len; }
+					else { first = false; rcl = 0; if (op == 0 || op == 7 || op == 8) { n.qalen += len; n.ralen += len; } else if (op == 1) n.qalen += len; else if (op == 2 || op == 3) n.ralen += len; }
+				}
+				n.rclip = (n.qalen + n.ralen) ? rcl : 0;
+				lines[i] = n;
+				newblk[i] = (i == 0 || strcmp(view(i - 1).qname(), v.qname()) != 0) ? 1 : 0;
+			}
+		});
+		blk_off.clear();
+		for (size_t i = 0; i < nr; ++i) if (newblk[i]) blk_off.push_back((int64_t)i);
+		const size_t n_blocks = blk_off.size(); blk_off.push_back((int64_t)nr);
+		if (ssg_sbl_process(st, &o, (long)n_blocks, blk_off.data(), lines.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); rc = 1; break; }
+		/* main stream: the records with 0x400 and MC / MQ, rebuilt by threads over ranges of blocks, written in order as one frame */
+		const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 4096 + 1));
+		std::vector<std::vector<uint8_t> > outb((size_t)T);
+		parallel_ranges(T, (size_t)T, [&](size_t ta, size_t tb) {
+			for (size_t t = ta; t < tb; ++t) {
+				const size_t b0 = n_blocks * t / (size_t)T, b1 = n_blocks * (t + 1) / (size_t)T;
+				std::vector<uint8_t> &ob = outb[t];
+				ob.reserve((size_t)((rec_off[(size_t)blk_off[b1]] - rec_off[(size_t)blk_off[b0]]) * 21 / 20) + 4096);
+				char cg[16];
+				for (size_t i = (size_t)blk_off[b0]; i < (size_t)blk_off[b1]; ++i) {
+					const bam_view_t v = view(i);
+					const size_t base = ob.size();
+					ob.insert(ob.end(), bam + rec_off[i], bam + rec_off[i + 1]);
+					if (bits[i] & SSG_SBL_DUP) { uint32_t fnc; memcpy(&fnc, ob.data() + base + 4 + 12, 4); fnc |= 0x400u << 16; memcpy(ob.data() + base + 4 + 12, &fnc, 4); }
+					if (o.add_mate_tags && mate[i] >= 0) {
+						const bam_view_t m = view((size_t)mate[i]);
+						if (!bam_has_tag(v, 'M', 'C')) {
+							ob.push_back('M'); ob.push_back('C'); ob.push_back('Z');
+							if (!m.n_cigar()) ob.push_back('*');
+							for (uint32_t k = 0; k < m.n_cigar(); ++k) {
+								uint32_t x; memcpy(&x, m.cigar() + 4 * k, 4); uint32_t len = x >> 4; int n = 0;
+								do { cg[n++] = (char)('0' + len % 10); len /= 10; } while (len);
+								while (n) ob.push_back((uint8_t)cg[--n]);
+								ob.push_back((uint8_t)"MIDNSHP=XB"[x & 0xf]);
+							}
+							ob.push_back(0);
+						}
+						if (!bam_has_tag(v, 'M', 'Q')) { ob.push_back('M'); ob.push_back('Q'); ob.push_back('C'); ob.push_back((uint8_t)m.mapq()); }   /* MAPQ <= 255: sam_parse1 types it 'C' */
+						const uint32_t nbs = (uint32_t)(ob.size() - base - 4); memcpy(ob.data() + base, &nbs, 4);
+					}
+				}
+			}
+		});
+		{	uint64_t tot = 0; for (auto &v : outb) tot += v.size();
+			fu_frame_t fh; fh.type = FU_MAIN; fh.zero = 0; fh.len = tot;
+			bool ok = fu_write_full(1, &fh, sizeof(fh));
+			for (auto &v : outb) ok = ok && fu_write_full(1, v.data(), v.size());
+			if (!ok) { perror("[samblaster] write"); rc = 1; break; } }
+		/* side streams, from the text bwa attached for the pairs that can qualify */
+		ltext.assign(nr, std::pair<const char*, uint32_t>((const char*)0, 0u));
+		for (uint64_t c = 0; c < bh.n_cand; ++c) {
+			const char *p = text + cand[c].text_off, *e = text + (c + 1 < bh.n_cand ? cand[c + 1].text_off : bh.text_bytes);
+			for (uint64_t k = 0; k < cand[c].n_rec && p < e; ++k) {
+				const char *nl = (const char*)memchr(p, '\n', (size_t)(e - p)); if (!nl) nl = e;
+				if (cand[c].first_rec + k < nr) ltext[(size_t)(cand[c].first_rec + k)] = std::make_pair(p, (uint32_t)(nl - p));
+				p = nl < e ? nl + 1 : e;
+			}
+		}
+		auto side = [&](out_t &w, size_t i, int flag, bool patch, const char *suffix) -> bool {
+			if (!ltext[i].first) return false;
+			lrec_t r, mr; const char *f[12]; const char *opt = 0;
+			if (!scan_fields(ltext[i].first, ltext[i].second, 0, r, f, &opt)) return false;
+			const lrec_t *m = 0; bool add_mc = false, add_mq = false; const char *mbase = 0;
+			if (o.add_mate_tags && mate[i] >= 0) {
+				const size_t mi = (size_t)mate[i]; const char *g[12];
+				if (!ltext[mi].first || !scan_fields(ltext[mi].first, ltext[mi].second, 0, mr, g, 0)) return false;
+				m = &mr; mbase = ltext[mi].first;
+				const char *oe = ltext[i].first + ltext[i].second;
+				add_mc = !(opt && has_tag(opt, oe, "MC:Z:")); add_mq = !(opt && has_tag(opt, oe, "MQ:i:"));
+			}
+			/* emit_line addresses the line and its mate through one base pointer: write the two parts separately */
+			const char *s0 = ltext[i].first;
+			if (!patch && !suffix) w.put(s0, r.len);
+			else { w.put(s0, r.qn_len); if (suffix) w.put(suffix, 2); w.putc('\t'); w.puti(flag); w.put(s0 + r.flag_end, r.len - r.flag_end); }
+			if (m) { if (add_mc) { w.put("\tMC:Z:", 6); w.put(mbase + m->cig_off, m->cig_len); } if (add_mq) { w.put("\tMQ:i:", 6); w.put(mbase + m->mq_off, m->mq_len); } }
+			w.putc('\n');
+			return true;
+		};
+		for (size_t b = 0; b < n_blocks && !rc; ++b) {
+			bool paired = false, dup = false; int64_t d1 = -1, d2 = -1;
+			for (int64_t i = blk_off[b]; i < blk_off[b + 1]; ++i) {
+				const int bt = bits[(size_t)i];
+				if (mate[(size_t)i] >= 0) paired = true;
+				if (bt & SSG_SBL_DUP) dup = true;
+				if (bt & SSG_SBL_DISC) { if (lines[(size_t)i].flag & 0x40) d1 = i; else d2 = i; }
+			}
+			if (paired) { ++n_pairs; if (dup) ++n_dups; }
+			if (disc && d1 >= 0 && d2 >= 0) {
+				for (int64_t i : { d1, d2 }) if (!side(*disc, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), dup, 0)) { fprintf(stderr, "[samblaster] fused stream: a discordant line came without its text\n"); rc = 1; }
+				++n_disc;
+			}
+			if (spl) for (int64_t i = blk_off[b]; i < blk_off[b + 1]; ++i) if (bits[(size_t)i] & SSG_SBL_SPLIT) {
+				if (!side(*spl, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), true, (lines[(size_t)i].flag & 0x40) ? "_1" : "_2")) { fprintf(stderr, "[samblaster] fused stream: a splitter line came without its text\n"); rc = 1; }
+				++n_spl;
+			}
+		}
+	}
+	{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
+	reader.join();
+	if (!rc && (rd_fail || !ended)) { fprintf(stderr, "[samblaster] the fused stream ended early\n"); rc = 1; }
+	if (!rc && !got_header) { if (spl) spl->put(pg, strlen(pg)); if (disc) disc->put(pg, strlen(pg)); }
+	if (!rc && !fu_write_frame(1, FU_END, 0, 0)) rc = 1;
+	if (spl) { spl->flush(); fclose(splf); }
+	if (disc) { disc->flush(); fclose(discf); }
+	ssg_sbl_state_free(st);
+	fprintf(stderr, "[samblaster] pairs=%llu dups=%llu discordant_pairs=%llu splitter_lines=%llu (fused stream: BAM records; decisions on %s)\n", n_pairs, n_dups, n_disc, n_spl, ssg_backend());
+	return rc;
+}
+
 int main(int argc, char **argv)
 {
 	ssg_sbl_opt_t o; ssg_sbl_opt_init(&o);
@@ -73,9 +311,13 @@ int main(int argc, char **argv)
 #ifdef F_SETPIPE_SZ
 	(void)fcntl(0, F_SETPIPE_SZ, 1 << 20); (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);
 #endif
+	const char *pg = "@PG\tID:SAMBLASTER\tVN:0.1.22-ssgpu\tCL:samblaster\n";
+	/* the first bytes say whether bwa sent SAM text or the fused stream of BAM records (fused.h) */
+	char first[8]; size_t n_first = 0;
+	while (n_first < 8) { ssize_t r = read(0, first + n_first, 8 - n_first); if (r < 0) { if (errno == EINTR) continue; perror("[samblaster] read"); return 1; } if (r == 0) break; n_first += (size_t)r; }
+	if (n_first == 8 && !memcmp(first, FU_MAGIC, 8)) return fused_main(o, spl, disc, splf, discf, pg);
 	ssg_sbl_state_t *st = ssg_sbl_state_new();
 	std::unordered_map<std::string, int> seqs;
-	const char *pg = "@PG\tID:SAMBLASTER\tVN:0.1.22-ssgpu\tCL:samblaster\n";
 	size_t CHUNK = 1u << 18;     /* blocks per device call */
 	{ const char *e = getenv("SSG_SBL_CHUNK"); if (e && atol(e) > 0) CHUNK = (size_t)atol(e); }
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
@@ -127,6 +369,7 @@ int main(int argc, char **argv)
 
 	std::thread reader([&]() {
 		std::unique_ptr<chunk_t> C(new chunk_t()); bool eof = false;
+		memcpy(C->buf.data(), first, n_first); C->have = n_first;          /* the bytes the format check consumed */
 		while (!eof && !parse_fail) {
 			if (C->have == C->buf.size()) C->buf.resize(C->buf.size() * 2);
 			ssize_t r = read(0, C->buf.data() + C->have, C->buf.size() - C->have);

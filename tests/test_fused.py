@@ -1,0 +1,118 @@
+"""The fused plugin path (speedseq_amd/host/fused.h) and the multi-device `bwa mem` against the text path.
+
+speedseq.config is `source`d by the reference's script (bin/speedseq:21), so `export SSG_FUSED=1` in it reaches every stage: `bwa mem`
+then hands BAM records to `samblaster` / `sambamba` in frames instead of SAM text.  The text path is the parity path; the fused run of
+the UNMODIFIED script must give the same three BAM files record for record -- compared here as the raw BAM record bytes after the
+header (field values, aux order and integer types included), and decode-equal to the oracle's run.
+`bwa mem` drives every visible device with whole upstream batches (SURVEY 8e coupling 1); its output must not depend on how many
+devices took part (the emulation build pretends SSG_EMU_DEVICES devices; on the GPU box the test passes with the one device there)."""
+import gzip
+import os
+import struct
+import subprocess
+
+import pytest
+
+import simreads
+import test_speedseq_script as T
+from common import EXAMPLE_FA, ROOT
+
+EMU = T.EMU
+
+
+def _records(bam):
+    """raw record bytes of a BAM file (BGZF members inflated, header skipped)"""
+    raw = gzip.open(bam, "rb").read()
+    assert raw[:4] == b"BAM\1"
+    l_text, = struct.unpack_from("<i", raw, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, o)
+    o += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, o)
+        o += 4 + l_name + 4
+    return raw[o:]
+
+
+def _same_bam_records(a, b):
+    for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
+        ra, rb = _records(a + suffix), _records(b + suffix)
+        assert len(ra) > 0 and ra == rb, suffix
+
+
+FUSED = "export SSG_FUSED=1\n"
+
+
+def test_fused_script_equals_text_path_emulated(tmp_path, emu_lib):
+    T._need_tools()
+    fq = T._fastq(tmp_path)
+    tools = dict(sambamba=os.path.join(EMU, "sambamba_emu"))
+    text = T._run_align(str(tmp_path / "text"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, **tools)
+    fused = T._run_align(str(tmp_path / "fused"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, config_extra=FUSED, **tools)
+    T._check_outputs(fused)
+    _same_bam_records(fused, text)
+    exp = T._run_align(str(tmp_path / "orc"), T.ORC, T.ORC + " samblaster", fq)
+    T._compare(fused, exp)
+
+
+def test_fused_script_many_calls_two_devices_emulated(tmp_path, emu_lib):
+    """several device calls per run, two (emulated) devices, small sort runs with spill: same BAMs as the text path on one device"""
+    T._need_tools()
+    fq = T._fastq(tmp_path, 1200)
+    tools = dict(sambamba=os.path.join(EMU, "sambamba_emu"))
+    small = {"SSG_BWA_CHUNK_BASES": "6000", "SSG_BWA_CALL_PAIRS": "150"}
+    text = T._run_align(str(tmp_path / "text"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, env_extra=small, **tools)
+    fused = T._run_align(str(tmp_path / "fused"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, config_extra=FUSED,
+                         env_extra=dict(small, SSG_EMU_DEVICES="2", SSG_SORT_CHUNK_BYTES="200000"), **tools)
+    _same_bam_records(fused, text)
+
+
+def _bwa_sam(exe, d, fq, env):
+    ref = os.path.join(d, "ref.fa")
+    if not os.path.exists(ref + ".bwt"):
+        import shutil
+        shutil.copy(EXAMPLE_FA, ref)
+        for ext in ("amb", "ann", "bwt", "pac", "sa"):
+            shutil.copy(EXAMPLE_FA + "." + ext, ref + "." + ext)
+    r = subprocess.run([exe, "mem", "-t", "2", "-p", "-R", "@RG\\tID:x\\tSM:x", ref, fq], capture_output=True, env=dict(os.environ, **env), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout, r.stderr.decode()
+
+
+def test_bwa_mem_output_independent_of_device_count_emulated(tmp_path, emu_lib):
+    fq = T._fastq(tmp_path, 900)
+    d = str(tmp_path)
+    small = {"SSG_BWA_CHUNK_BASES": "5000", "SSG_BWA_CALL_PAIRS": "100"}
+    one, _ = _bwa_sam(os.path.join(EMU, "bwa_emu"), d, fq, small)
+    three, err = _bwa_sam(os.path.join(EMU, "bwa_emu"), d, fq, dict(small, SSG_EMU_DEVICES="3"))
+    assert one == three and one.count(b"\n") > 1800
+    used = {l.split("device ")[1].split(";")[0] for l in err.split("\n") if l.startswith("[bwa] processed")}
+    assert len(used) >= 2, err[-1500:]                      # more than one device took batches
+
+
+def test_bwa_mem_keeps_complete_pairs_of_short_input_emulated(tmp_path, emu_lib):
+    """upstream bseq_read / main_mem: an odd interleaved file (or a shorter 2nd file) loses its last read, the complete pairs are aligned (rc 0)"""
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 40, seed=5)
+    fq = str(tmp_path / "odd.fq")
+    with open(fq, "w") as f:
+        for i, (name, r1, r2) in enumerate(pairs):
+            for r in ((r1, r2) if i < 39 else (r1,)):
+                f.write("@%s\n%s\n+\n%s\n" % (name, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    out, err = _bwa_sam(os.path.join(EMU, "bwa_emu"), str(tmp_path), fq, {})
+    names = {l.split(b"\t")[0] for l in out.split(b"\n") if l and not l.startswith(b"@")}
+    assert len(names) == 39 and "last read dropped" in err
+
+
+@pytest.mark.gpu
+def test_fused_script_equals_text_path_gpu(tmp_path, gpu_lib):
+    """the product executables on the MI355X: fused run of the unmodified script == text run == oracle run"""
+    T._need_tools()
+    fq = T._fastq(tmp_path, 6000)
+    b = lambda n: os.path.join(ROOT, "bin", n)
+    small = {"SSG_BWA_CHUNK_BASES": "40000", "SSG_BWA_CALL_PAIRS": "1000"}
+    text = T._run_align(str(tmp_path / "text"), b("bwa"), b("samblaster"), fq, sambamba=b("sambamba"), env_extra=small)
+    fused = T._run_align(str(tmp_path / "fused"), b("bwa"), b("samblaster"), fq, sambamba=b("sambamba"), config_extra=FUSED, env_extra=small)
+    T._check_outputs(fused)
+    _same_bam_records(fused, text)
+    exp = T._run_align(str(tmp_path / "orc"), T.ORC, T.ORC + " samblaster", fq)
+    T._compare(fused, exp)

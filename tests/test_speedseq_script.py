@@ -32,7 +32,7 @@ def _need_tools():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
-def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM, fq2=None, rg="@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1"):
+def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM, fq2=None, rg="@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1", config_extra="", env_extra=None):
     """runs the reference script in directory d with wrappers around the given executables; returns the output prefix"""
     os.makedirs(d)
     bindir = os.path.join(d, "bin")
@@ -44,10 +44,11 @@ def _run_align(d, bwa_cmd, samblaster_cmd, fq, n_threads=4, sambamba=SHIM, fq2=N
     os.symlink(shutil.which("mawk"), os.path.join(bindir, "gawk"))        # the script hard-codes `gawk`
     cfg = os.path.join(d, "speedseq.config")
     with open(cfg, "w") as f:
-        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\n" % (bindir, bindir, sambamba, ROOT))
+        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\n%s" % (bindir, bindir, sambamba, ROOT, config_extra))
     ref = os.path.join(d, "ref.fa")
     shutil.copy(EXAMPLE_FA, ref)   # no index next to it: the script must call `$BWA index`
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
+    env.update(env_extra or {})
     out = os.path.join(d, "example")
     r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", out, "-M", "3", "-t", str(n_threads)] + ([] if fq2 else ["-p"]) +
                        ["-R", rg, ref, fq] + ([fq2] if fq2 else []),
