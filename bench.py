@@ -255,27 +255,34 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
     return res
 
 
-def script_leg(td, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, sort_mem_gb=40):
+def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, sort_mem_gb=40, config_extra="", env_extra=None):
     """SURVEY.md 8d's own definition of the metric: the reference's `speedseq align` (the script itself, unmodified -- the fixture copy
-    tests/golden/speedseq_ref_script.sh, or /root/reference/bin/speedseq where that exists) on the product executables, wall clock from
-    FASTQ open to the three coordinate-sorted, indexed BAMs closed.  The index files are already next to `ref_prefix`."""
+    tests/golden/speedseq_ref_script.sh, or /root/reference/bin/speedseq where that exists) on the executables speedseq.config names,
+    wall clock from FASTQ open to the three coordinate-sorted, indexed BAMs closed.  The index files are already next to `ref_prefix`.
+    config_extra: further lines of speedseq.config (the script `source`s it: `export SSG_FUSED=1` switches the product's stages to
+    the binary hand-off of speedseq_amd/host/fused.h)."""
     import shutil
     import subprocess
     script = "/root/reference/bin/speedseq" if os.path.exists("/root/reference/bin/speedseq") else os.path.join(ROOT, "tests", "golden", "speedseq_ref_script.sh")
     awk = shutil.which("gawk") or shutil.which("mawk") or shutil.which("awk")
     if not os.path.exists(script) or awk is None:
         return {"skipped": "reference script fixture or awk not available"}
-    d = os.path.join(td, "script")
+    d = os.path.join(td, "script_" + tag)
     bindir = os.path.join(d, "bin")
     os.makedirs(bindir)
     if not shutil.which("gawk"):
         os.symlink(awk, os.path.join(bindir, "gawk"))           # the script hard-codes `gawk`
+    for name, cmd in (("bwa", bwa), ("samblaster", samblaster)):  # wrappers: a config entry must be one file, the oracle's samblaster is `orc_bwa samblaster`
+        with open(os.path.join(bindir, name), "w") as f:
+            f.write("#!/bin/sh\nexec %s \"$@\"\n" % cmd)
+        os.chmod(os.path.join(bindir, name), 0o755)
     if not os.path.exists(ref_prefix):
         open(ref_prefix, "w").write(">placeholder: the five index files next to this name are what bwa mem reads\n")
     cfg = os.path.join(d, "speedseq.config")
-    open(cfg, "w").write("BWA=%s\nSAMBLASTER=%s\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\n" % (bwa, samblaster, sambamba, ROOT))
+    open(cfg, "w").write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\n%s" % (bindir, bindir, sambamba, ROOT, config_extra))
     out = os.path.join(d, "out")
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
+    env.update(env_extra or {})
     t = time.perf_counter()
     r = subprocess.run(["bash", script, "align", "-K", cfg, "-o", out, "-M", str(sort_mem_gb), "-t", str(threads), "-p",
                         "-R", "@RG\\tID:bench\\tSM:bench\\tLB:lib1", ref_prefix, fq], cwd=d, env=env, capture_output=True, text=True)
@@ -284,8 +291,78 @@ def script_leg(td, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, 
         return {"error": (r.stdout[-400:] + r.stderr[-400:])}
     sizes = {x: os.path.getsize(out + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
     ok = all(os.path.exists(out + x + ".bai") for x in sizes)
-    return {"what": "`speedseq align -t %d -p` (the reference's script, unmodified) on bin/bwa, bin/samblaster, bin/sambamba: FASTQ file -> three coordinate-sorted BAMs + BAI, wall clock incl. index load" % threads,
-            "pairs": n_pairs, "wall_s": round(t, 2), "pairs_per_s": n_pairs / t, "bam_bytes": sizes, "bai_written": ok}
+    stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs"))]
+    return {"pairs": n_pairs, "threads": threads, "wall_s": round(t, 2), "pairs_per_s": n_pairs / t, "bam_bytes": sizes, "bai_written": ok, "out": out, "stage_log": stages}
+
+
+def bam_view(samtools, bam):
+    """decoded records + header (modulo @PG) of a BAM through the reference's samtools (oracle/_ref, built from /root/reference/src/samtools-1.3.1)"""
+    import subprocess
+    txt = subprocess.check_output([samtools, "view", "-h", bam], text=True)
+    return [l for l in txt.split("\n") if not l.startswith("@PG")]
+
+
+def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
+    """The metric as SURVEY.md 8d words it -- wall clock, FASTQ open -> three coordinate-sorted BAMs + BAI closed -- through the reference's own
+    script (unmodified) on the product executables: text hand-off (the parity path) on a prefix of the file, fused hand-off (SSG_FUSED=1 in
+    speedseq.config) on --script-pairs pairs; the fused run's BAMs of the sample must decode to the records of the oracle's run; the CPU
+    baseline is the same script on the oracle's executables + the reference's samtools."""
+    fq = os.path.join(td, "reads.fq")
+    rec_bytes = 2 * (1 + 10 + 1 + rl + 3 + rl + 1)                      # bytes per pair of write_fastq's fixed-width records
+    n_all = os.path.getsize(fq) // rec_bytes
+    samtools = os.path.join(ROOT, "oracle", "_ref", "samtools")
+    shim = os.path.join(ROOT, "tools", "sambamba_samtools_shim.sh")
+    fused_cfg = "export SSG_FUSED=1\nexport SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128)
+    res = {"metric": "paired reads aligned+dup-marked/sec, FASTQ file -> out.bam + out.splitters.bam + out.discordants.bam (+ .bai), `speedseq align` wall clock incl. index load"}
+
+    def head(n, name):
+        p = os.path.join(td, name)
+        with open(fq, "rb") as f, open(p, "wb") as g:
+            left = n * rec_bytes
+            while left:
+                blk = f.read(min(left, 64 << 20)); g.write(blk); left -= len(blk)
+        return p
+    n_fused = min(a.script_pairs, n_all)
+    fq_f = fq if n_fused == n_all else head(n_fused, "fused.fq")
+    r = script_leg(td, "fused", prefix, fq_f, n_fused, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=fused_cfg)
+    r.pop("out", None)
+    r["what"] = "`speedseq align -t %d -p` (the reference's script, unmodified) on bin/bwa, bin/samblaster, bin/sambamba with `export SSG_FUSED=1` in speedseq.config (binary hand-off between the stages, speedseq_amd/host/fused.h)" % a.script_threads
+    res["fused"] = r
+    res["value"] = r.get("pairs_per_s")
+    res["unit"] = "pairs/s"
+    n_text = min(2000000, n_all)
+    r = script_leg(td, "text", prefix, head(n_text, "text.fq"), n_text, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"))
+    r.pop("out", None)
+    r["what"] = "the same without SSG_FUSED: SAM text on every pipe (the parity path)"
+    res["text"] = r
+    os.remove(os.path.join(td, "text.fq"))
+    # parity of the fused path on the sample: product (fused) vs the oracle's executables behind the same script
+    sfq = os.path.join(td, "sample.fq")
+    if os.path.exists(samtools) and os.path.exists(sfq):
+        rp = script_leg(td, "s_fused", prefix, sfq, ns, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=fused_cfg)
+        ro = script_leg(td, "s_orc", prefix, sfq, ns, a.script_threads, orc_exe, orc_exe + " samblaster", shim, sort_mem_gb=8)
+        if "out" in rp and "out" in ro:
+            same = {x: bam_view(samtools, rp["out"] + x) == bam_view(samtools, ro["out"] + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
+            res["sample_bams_equal_oracle"] = bool(all(same.values()))
+            res["sample_bams"] = dict(same, pairs=ns, what="samtools view -h of the three BAMs (header modulo @PG): fused product run vs the oracle's executables + the reference's samtools behind the same script")
+        else:
+            res["sample_bams"] = {"error": (rp.get("error") or "") + (ro.get("error") or "")}
+    # CPU baseline, BASELINE.md section 3: `speedseq align -t <cores>` on the oracle's executables, median of 3 runs
+    if a.cpu_script_pairs > 0 and os.path.exists(samtools):
+        nc = min(a.cpu_script_pairs, n_all)
+        cfq = head(nc, "cpu.fq")
+        cores = min(os.cpu_count() or 1, 128)
+        runs = []
+        for k in range(3):
+            rc = script_leg(td, "cpu%d" % k, prefix, cfq, nc, cores, orc_exe, orc_exe + " samblaster", shim, sort_mem_gb=8)
+            if "wall_s" in rc:
+                runs.append(rc["wall_s"])
+        if runs:
+            med = sorted(runs)[len(runs) // 2]
+            res["cpu_script"] = {"value": nc / med, "unit": "pairs/s", "cores": cores, "kind": "port", "pairs": nc, "runs_wall_s": runs,
+                                 "what": "`speedseq align -t %d -p` (the reference's script) with oracle/orc_bwa as bwa and samblaster and the reference's samtools 1.3.1 behind sambamba's command line, "
+                                         "FASTQ -> three sorted BAMs + BAI, index load included, median of %d runs (the first also warms the page cache)" % (cores, len(runs))}
+    return res
 
 
 def main():
@@ -297,7 +374,10 @@ def main():
     ap.add_argument("--ref-mbp", type=float, default=3100.0, help="synthetic GRCh37-shaped reference size (GRCh37 = 3100)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--bwa-threads", type=int, default=16, help="the -t whose batch boundaries (insert-size model scope) are reproduced")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload aligned by the CPU oracle: parity gate + cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs of the timed batch aligned by the CPU oracle: parity gate on the timed call + cpu_baseline (-1 = the whole batch, 0 = skip)")
+    ap.add_argument("--script-pairs", type=int, default=8000000, help="pairs in the FASTQ of the literal-metric leg: the reference's `speedseq align` script on the product executables, FASTQ -> three sorted BAMs + BAI")
+    ap.add_argument("--script-threads", type=int, default=32, help="-t of the script legs on the product executables")
+    ap.add_argument("--cpu-script-pairs", type=int, default=200000, help="pairs of the CPU baseline through the script (`speedseq align -t <cores>` on the oracle's executables; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
     ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs in the FASTQ file of the plugin-path leg (the timed batch + freshly simulated ones): enough device calls for the pipeline's steady state to show")
@@ -341,8 +421,10 @@ def main():
     t_index = time.time() - t0
 
     rl = a.read_len
+    if a.cpu_sample < 0:
+        a.cpu_sample = a.pairs
     reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev)
-    n_more = max(0, a.e2e_pairs - a.pairs)
+    n_more = max(0, max(a.e2e_pairs, a.script_pairs) - a.pairs)
     reads_e2e = simulate_pairs(ref, lens, n_more, rl, 1012, dev).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0 and n_more > 0) else None   # further pairs for the plugin-path leg
     d_seq = reads.reshape(-1)
     d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
@@ -478,11 +560,15 @@ def main():
                                "sw": {"cells_per_step": int(summary[3]) + int(summary[4]), "kernels": sorted(sw_names),
                                       "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None,
                                       "valu_frac": valu or None, "valu_frac_source": "profiles/r02_pmc_sq.json (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
-        # ---- parity gate + CPU baseline: the oracle (scalar C restatement of bwa mem + samblaster) on a bounded sample of the same batch ----
+        # ---- parity gate ON THE TIMED CALL + CPU baseline: the step is run once more on the same device-resident inputs with its records
+        # kept in HBM (identical inputs -> identical records; the summaries are compared), the records and samblaster's per-line decisions
+        # are downloaded, and the oracle (scalar C restatement of bwa mem + samblaster) aligns the same pairs in the same upstream batches ----
         if a.cpu_sample > 0 and world == 1:   # rank 0 at N = 1 only
             import oracle_py
             import tempfile
+            import common
             ns = min(a.cpu_sample, a.pairs)
+            full = ns == a.pairs
             orc = oracle_py.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
             shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
             td_obj = tempfile.TemporaryDirectory(dir=shm)
@@ -492,36 +578,60 @@ def main():
             lib.index_save(idx, prefix)           # the five `bwa index` files of the device-built index
             oidx = orc.idx_load(prefix)           # ... loaded by the oracle: the index bytes cross the file format both ways
             t_files = time.time() - tw
-            hs = reads[:2 * ns].cpu().numpy().reshape(-1)
+            hs_all = reads.cpu().numpy().reshape(-1)
+            hs = hs_all[:2 * ns * rl]
             hoff = np.arange(2 * ns + 1, dtype=np.int64) * rl
             names = ["r%d" % (i // 2) for i in range(2 * ns)]
-            cores = min(os.cpu_count() or 1, 64)
+            cores = min(os.cpu_count() or 1, 128)
             hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(GRCH37_NAMES, lens))
             nw = min(ns, 2000)                         # untimed: the worker threads' allocator heaps and the index pages they touch first
             orc.process_pairs(oidx, hs[:2 * nw * rl], hoff[:2 * nw + 1], names[:2 * nw], None, 0, "", cores)
             tc = time.perf_counter()
-            otext, _, _ = orc.process_pairs(oidx, hs, hoff, names, None, 0, "", cores)
-            import common
-            odup, _ = common.oracle_dup_flags(orc, otext, hdr)
+            otext = ""
+            nb_s = int(pb[ns - 1]) + 1
+            for bi in range(nb_s):                     # one oracle call per upstream batch: the scope of the insert-size model
+                lo = int(np.searchsorted(pb, bi, "left")); hi = min(ns, int(np.searchsorted(pb, bi, "right")))
+                t_, _, _ = orc.process_pairs(oidx, hs[2 * lo * rl:2 * hi * rl], hoff[2 * lo:2 * hi + 1] - hoff[2 * lo], names[2 * lo:2 * hi], None, 2 * lo, "", cores)
+                otext += t_
             tc = time.perf_counter() - tc
-            gtext, gdup = gpu_sample_sam(lib, idx, opt, hs, hoff, names, GRCH37_NAMES, lens)
-            ok = gtext == otext and np.array_equal(gdup, odup)
+            om, od, os_ = common.oracle_streams(orc, otext, hdr)
+            # the device side: the timed call itself when the whole batch is checked, else the same entry point on the sample's pairs
+            if full:
+                s2, hrec = capi.hotpath_dev_ex(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0, keep=True)
+                same_summary = bool(np.array_equal(np.asarray(s2), np.asarray(summary)))
+            else:
+                d_pbs = d_pb[:ns].contiguous()
+                s2, hrec = capi.hotpath_dev_ex(lib, idx, opt, ns, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pbs.data_ptr(), nb_s, 0, keep=True)
+                same_summary = None
+            res, bits, mate = capi.dev_records_download(lib, hrec, ns)
+            gtext, _ = capi.sam_format(lib, idx, opt, res, names, hs, hoff, None, "")
+            res.close(); capi.dev_records_free(lib, hrec)
+            gm, gd, gs = common.sbl_streams_from_bits(gtext, bits, mate)
+            ok_text = gtext == otext
+            ok = bool(ok_text and gm == om and gd == od and gs == os_ and same_summary is not False)
             n_rec_diff = 0
-            if gtext != otext:
+            if not ok_text:
                 ga, oa = gtext.split("\n"), otext.split("\n")
                 n_rec_diff = sum(1 for x, y in zip(ga, oa) if x != y) + abs(len(ga) - len(oa))
                 for x, y in list((x, y) for x, y in zip(ga, oa) if x != y)[:5]:
                     sys.stderr.write("[bench] PARITY MISMATCH\n  gpu    %s\n  oracle %s\n" % (x, y))
-            out["parity"] = {"parity_checked_pairs": ns, "parity_ok": bool(ok), "records_compared": otext.count("\n"), "records_differing": n_rec_diff,
-                             "dup_flags_differing": int((gdup != odup).sum()) if len(gdup) == len(odup) else -1, "dup_pairs_in_sample": int(odup.sum()),
-                             "what": "SAM text (all fields and tags) + samblaster duplicate flags of the first %d pairs of the timed batch: libssgpu C ABI vs oracle/ "
-                                     "on the index files written by ssg_index_save" % ns, "index_files_roundtrip_s": round(t_files, 1)}
+            out["parity"] = {"parity_checked_pairs": ns, "parity_ok": ok, "records_compared": otext.count("\n"), "records_differing": n_rec_diff,
+                             "on_the_timed_call": full, "timed_call_summary_reproduced": same_summary,
+                             "streams": {"sam_lines": [len(gm), len(om), gm == om], "discordant_lines": [len(gd), len(od), gd == od], "splitter_lines": [len(gs), len(os_), gs == os_]},
+                             "dup_lines": int((bits & 1).sum()),
+                             "what": ("ssg_hotpath_dev_ex -- the timed entry point, same device-resident inputs and upstream batches%s -- with its records kept in HBM: printed "
+                                      "through ssg_sam_format they are the oracle's SAM text (all fields and tags), and their per-line duplicate / discordant / splitter bits and "
+                                      "MC/MQ source lines reproduce the three streams of the oracle's samblaster line for line; index files written by ssg_index_save"
+                                      % ("" if full else ", first %d pairs" % ns)),
+                             "index_files_roundtrip_s": round(t_files, 1)}
             out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d pairs of the same batch, oracle/ (scalar C restatement of bwa mem PE + samblaster), %d threads for alignment, samblaster single-threaded; after an untimed pass over %d pairs" % (ns, cores, nw)}
+                                   "sample": "%s of the timed batch (%d pairs) in its upstream batches, oracle/ (scalar C restatement of bwa mem PE) in process, %d threads, alignment only; after an untimed pass over %d pairs. "
+                                             "The script-level baseline (`speedseq align -t <cores>` on the oracle's executables) is cpu_baseline.script" % ("all" if full else "the first pairs", ns, cores, nw)}
             try:   # oracle-independent validation of the same records (tests/validators.py): reference bases from the .pac just written
                 import validators
+                vtext = "\n".join(gtext.split("\n", 40001)[:40000]) + "\n"
                 pac = validators.pac_contigs(prefix)
-                v1, v2, v3 = validators.md_nm_consistency(gtext, pac), validators.as_from_cigar(gtext, pac), validators.mate_symmetry(gtext)
+                v1, v2, v3 = validators.md_nm_consistency(vtext, pac), validators.as_from_cigar(vtext, pac), validators.mate_symmetry(vtext)
                 out["parity"]["oracle_independent"] = {"md_nm_rebuilds_reference": {"records": v1[0], "bad": v1[1]},
                                                        "as_rescored_from_cigar": {"records": v2[0], "outside_[AS-10,AS]": v2[1]},
                                                        "mate_fields_mirror": {"checks": v3[0], "bad": v3[1]}}
@@ -530,22 +640,29 @@ def main():
                 del pac
             except Exception as e:
                 out["parity"]["oracle_independent"] = {"error": repr(e)}
+            del gtext, otext, gm, gd, gs, om, od, os_
             if a.e2e:
+                b = lambda n: os.path.join(ROOT, "bin", n)
+                orc_exe = os.path.join(ROOT, "oracle", "orc_bwa")
+                nse = min(20000, ns)
                 try:
-                    out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, ns, orc_exe=os.path.join(ROOT, "oracle", "orc_bwa"))
+                    out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, nse, orc_exe=orc_exe)
                     if not out["e2e"].get("sample_streams_identical", True):
                         ok = False
-                    b = lambda n: os.path.join(ROOT, "bin", n)
-                    try:
-                        out["e2e"]["speedseq_align_script"] = script_leg(td, prefix, os.path.join(td, "reads.fq"), out["e2e"]["pairs"], a.bwa_threads, b("bwa"), b("samblaster"), b("sambamba"))
-                    except Exception as e:
-                        out["e2e"]["speedseq_align_script"] = {"error": repr(e)}
                 except Exception as e:      # the plugin-path measurement must not take the headline down with it
                     out["e2e"] = {"error": repr(e)}
+                try:
+                    out["literal"] = literal_legs(a, td, prefix, rl, nse, b, orc_exe)
+                    if out["literal"].get("sample_bams_equal_oracle") is False:
+                        ok = False
+                    if "cpu_script" in out["literal"]:
+                        out["cpu_baseline"]["script"] = out["literal"].pop("cpu_script")
+                except Exception as e:
+                    out["literal"] = {"error": repr(e)}
             td_obj.cleanup()
             if not ok:   # no timing counts without parity
                 out["value"] = None
-                out["invalid"] = "parity gate failed: GPU records differ from the oracle on the sample"
+                out["invalid"] = "parity gate failed: GPU records differ from the oracle"
         if saved_stdout is not None:
             C.CDLL(None).fflush(None); sys.stdout.flush(); os.dup2(saved_stdout, 1)
         print(json.dumps(out)); sys.stdout.flush()

@@ -189,6 +189,9 @@ void ssg_dev_records_free(ssg_dev_records_t *r);
 int64_t ssg_dev_records_n_lines(const ssg_dev_records_t *r);
 size_t ssg_dev_record_bytes(void);
 int ssg_dev_records_export(const ssg_dev_records_t *r, uint64_t *d_keys, void *d_recs, uint8_t *d_bits);
+/* the kept records as a host result (release with ssg_pe_result_free; prints through ssg_sam_format) and, per SAM line in line order
+ * (ssg_dev_records_n_lines entries, HOST buffers, either may be NULL), samblaster's decisions: SSG_SBL_* bits and the mate line */
+int ssg_dev_records_download(const ssg_dev_records_t *r, ssg_pe_result_t **res, uint8_t *line_bits, int64_t *mate_line);
 
 /* FM-index from arrays already resident in HBM (not copied; the caller keeps them alive) */
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,

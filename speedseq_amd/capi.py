@@ -169,7 +169,7 @@ class PeResult:
         self.req_off = np.ctypeslib.as_array(C.cast(l.ssg_pe_req_off(handle), C.POINTER(C.c_int64)), shape=(2 * n_pairs + 1,)).copy()
         self.req = np.frombuffer((C.c_char * (n * ALNREQ_DT.itemsize)).from_address(l.ssg_pe_req(handle)), dtype=ALNREQ_DT, count=n).copy() if n else np.zeros(0, ALNREQ_DT)
         self.alns = np.frombuffer((C.c_char * (n * ALN_DT.itemsize)).from_address(l.ssg_pe_alns(handle)), dtype=ALN_DT, count=n).copy() if n else np.zeros(0, ALN_DT)
-        self.pes = np.frombuffer((C.c_char * (n_batches * 4 * PESTAT_DT.itemsize)).from_address(l.ssg_pe_pes(handle)), dtype=PESTAT_DT, count=n_batches * 4).copy()
+        self.pes = np.frombuffer((C.c_char * (n_batches * 4 * PESTAT_DT.itemsize)).from_address(l.ssg_pe_pes(handle)), dtype=PESTAT_DT, count=n_batches * 4).copy() if n_batches else np.zeros(0, PESTAT_DT)
         self.stats = np.ctypeslib.as_array(C.cast(l.ssg_pe_stats(handle), C.POINTER(C.c_uint64)), shape=(8,)).copy()
 
     def close(self):
@@ -265,6 +265,17 @@ def dev_record_bytes(lib):
 def dev_records_export(lib, h, d_keys, d_recs=None, d_bits=None):
     """sort keys / fixed-size records / side-stream bits of the kept records into device buffers (addresses)"""
     lib._chk(lib.l.ssg_dev_records_export(h, C.c_void_p(d_keys), C.c_void_p(d_recs) if d_recs else None, C.c_void_p(d_bits) if d_bits else None))
+
+
+def dev_records_download(lib, h, n_pairs):
+    """records kept in HBM by hotpath_dev_ex(keep=True) -> (PeResult, per-line SSG_SBL_* bits, per-line mate line index)"""
+    _bind_pe(lib)
+    nl = dev_records_n_lines(lib, h)
+    bits = np.zeros(nl, dtype=np.uint8)
+    mate = np.zeros(nl, dtype=np.int64)
+    r = C.c_void_p()
+    lib._chk(lib.l.ssg_dev_records_download(h, C.byref(r), _ptr(bits), _ptr(mate)))
+    return PeResult(lib, r, n_pairs, 0), bits, mate
 
 
 def dev_records_free(lib, h):

@@ -1179,6 +1179,26 @@ int ssg_dev_records_export(const ssg_dev_records_t *R, uint64_t *d_keys, void *d
 	return rt_sync();
 }
 
+/* the kept records back on the host as an ssg_pe_result_t (ssg_pe_* accessors, ssg_sam_format) together with, per SAM line in line
+ * order, the side-stream bits and the line whose CIGAR / MAPQ fill MC / MQ: what a checker needs to compare the device step
+ * record by record with upstream's `bwa mem | samblaster` output (bench.py's parity gate on the timed call, tests) */
+int ssg_dev_records_download(const ssg_dev_records_t *R, ssg_pe_result_t **out, uint8_t *line_bits, int64_t *mate_line)
+{
+	CHK(need_device());
+	*out = 0;
+	std::unique_ptr<ssg_pe_result> res(new ssg_pe_result());
+	const int n_reads = (int)(2 * R->n_pairs); const size_t nreq = (size_t)R->keep.n_req;
+	res->n_reads = n_reads; res->n_batches = 0; memset(res->stats, 0, sizeof(res->stats));
+	res->req_off.resize((size_t)n_reads + 1);
+	if (!res->req.resize(nreq) || !res->alns.resize(nreq)) { ssg_err_msg = "host allocation failed: result records"; return SSG_ENOMEM; }
+	CHK(rt_sync());
+	CHK(R->keep.req_off.down(res->req_off.data(), (size_t)n_reads + 1)); CHK(R->keep.req.down(res->req.data(), nreq)); CHK(R->keep.alns.down(res->alns.data(), nreq));
+	if (line_bits) CHK(R->bits.down(line_bits, (size_t)R->n_lines));
+	if (mate_line) CHK(R->mate.down(mate_line, (size_t)R->n_lines));
+	*out = res.release();
+	return 0;
+}
+
 int ssg_hotpath_dev(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, int max_len, const uint8_t *d_seq, const int64_t *d_off,
                     const int32_t *d_pair_batch, int n_batches, int64_t id0, uint64_t summary[8], uint8_t *dup_host /* may be NULL */)
 {

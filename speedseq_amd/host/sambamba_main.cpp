@@ -23,6 +23,9 @@
 #include <condition_variable>
 #include "../../include/ssgpu.h"
 
+#include <time.h>
+static double wall() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static bool dbg() { static int d = -1; if (d < 0) d = (getenv("SSG_DEBUG") || getenv("SSG_SORT_LOG")) ? 1 : 0; return d != 0; }
 static int hw_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)std::min(n, 32u) : 4; }
 static void die(const std::string &m) { fprintf(stderr, "[sambamba] %s\n", m.c_str()); exit(1); }
 static int open_in(const char *p) { if (!strcmp(p, "/dev/stdin") || !strcmp(p, "-")) return 0; int fd = open(p, O_RDONLY); if (fd < 0) die(std::string("cannot open ") + p); return fd; }
@@ -261,6 +264,7 @@ static int cmd_sort(int argc, char **argv)
 	}
 	if (!in || outp.empty()) die("usage: sambamba sort [-t N] [-m XG] [--tmpdir=DIR] -o out.bam <in.bam>");
 	if (threads < 1) threads = 1;
+	const double t_start = wall();
 	{ const char *e = getenv("SSG_BAM_LEVEL"); if (level < 0 && e && *e) level = atoi(e); }   /* deflate level of the sorted file when -l is not given (default: zlib's 6, as sambamba's) */
 	/* compression is CPU work the reference's `-t` undersizes on a host with hundreds of cores next to an MI355X: the pool may use more (SSG_SORT_THREADS) */
 	int pool = threads; { const char *e = getenv("SSG_SORT_THREADS"); if (e && atoi(e) > 0) pool = atoi(e); }
@@ -330,8 +334,15 @@ static int cmd_sort(int argc, char **argv)
 		}
 		flush();
 	}
+	const double t_in = wall();
 	int ofd = open(outp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + outp);
-	if (spills.empty()) { std::vector<uint32_t> perm; gpu_perm(S, perm); write_sorted(S, perm, h, ofd, level, pool); }
+	if (spills.empty()) {
+		std::vector<uint32_t> perm; gpu_perm(S, perm);
+		const double t_perm = wall();
+		write_sorted(S, perm, h, ofd, level, pool);
+		if (dbg()) fprintf(stderr, "[sambamba] sort: %zu records, %.2f GB: input %.2f s (from start), device sort of the keys %.2f s, gather + deflate (level %d, %d threads) + write %.2f s\n",
+		                   S.key.size(), (double)S.bytes / 1e9, t_in - t_start, t_perm - t_in, level < 0 ? 6 : level, pool, wall() - t_perm);
+	}
 	else {
 		if (!S.key.empty()) spill();
 		std::vector<merge_src_t> src(spills.size());

@@ -355,10 +355,69 @@ def repeat_reference(oracle, dirname, seed=5, n_copies=(300, 70), fam_len=(600, 
     return prefix
 
 
+def sbl_streams_from_bits(text, bits, mate, exclude_dups=True, add_mate_tags=True):
+    """The three streams samblaster's writer makes of name-grouped SAM lines and the per-line decisions of the device (SSG_SBL_* bits,
+    mate line): 0x400 into FLAG of a duplicate block's lines, MC / MQ from the mate's primary line, both primaries of a discordant pair
+    (read 1 first) to the discordant stream, splitter lines with _1 / _2 to the splitter stream -- the emit rules of
+    speedseq_amd/host/samblaster_main.cpp, restated here so that a device step can be compared with the oracle's streams line by line."""
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    assert len(lines) == len(bits) == len(mate), (len(lines), len(bits), len(mate))
+    f = [l.split("\t", 6) for l in lines]
+    main, disc, spl = [], [], []
+
+    def emit(i, flag, patch, suffix):
+        l = lines[i]
+        if patch or suffix:
+            x = f[i]
+            l = x[0] + (suffix or "") + "\t" + str(flag) + l[len(x[0]) + 1 + len(x[1]):]
+        m = int(mate[i])
+        if add_mate_tags and m >= 0:
+            if "\tMC:Z:" not in l:
+                l += "\tMC:Z:" + f[m][5]
+            if "\tMQ:i:" not in l:
+                l += "\tMQ:i:" + f[m][4]
+        return l
+
+    n, b0 = len(lines), 0
+    while b0 < n:
+        b1 = b0 + 1
+        while b1 < n and f[b1][0] == f[b0][0]:
+            b1 += 1
+        dup = any(bits[i] & 1 for i in range(b0, b1))
+        d1 = d2 = -1
+        for i in range(b0, b1):
+            flag = int(f[i][1])
+            if bits[i] & 2:
+                if flag & 0x40:
+                    d1 = i
+                else:
+                    d2 = i
+            main.append(emit(i, flag | (0x400 if bits[i] & 1 else 0), bool(bits[i] & 1), None))
+        if d1 >= 0 and d2 >= 0:
+            for i in (d1, d2):
+                disc.append(emit(i, int(f[i][1]) | (0x400 if dup else 0), dup, None))
+        for i in range(b0, b1):
+            if bits[i] & 4:
+                flag = int(f[i][1])
+                spl.append(emit(i, flag | (0x400 if dup else 0), True, "_1" if flag & 0x40 else "_2"))
+        b0 = b1
+    return main, disc, spl
+
+
+def oracle_streams(oracle, text, header):
+    """oracle samblaster (the reference's switches) over header + text: record lines of the three streams"""
+    out = oracle.samblaster(header + text)
+    rec = lambda t: [l for l in t.split("\n") if l and l[0] != "@"]
+    return rec(out), rec(oracle.last_discordants), rec(oracle.last_splitters)
+
+
 def check_hotpath(lib, oracle, n_pairs, per, read_len, to_dev):
     """ssg_hotpath_dev_ex (the bench's step: alignment, duplicate marking, discordant / splitter classification, all on the device) on
-    device-resident reads in n_pairs / per upstream batches: duplicate flags equal the oracle's `bwa mem` (one insert-size model per
-    upstream batch) + samblaster over the whole input; SAM / discordant / splitter line counts equal the oracle's streams.
+    device-resident reads in n_pairs / per upstream batches, against the oracle's `bwa mem` (one insert-size model per upstream batch)
+    + samblaster over the whole input: the records left in HBM, printed, are the oracle's SAM text; their per-line decisions
+    (duplicate / discordant / splitter bits, MC / MQ source line) give the oracle's three streams line for line.
     to_dev(numpy array) -> (keep-alive object, device pointer)."""
     from speedseq_amd import capi
     kw = dict(ins_mean=800, ins_std=150) if read_len > 200 else {}
@@ -370,7 +429,7 @@ def check_hotpath(lib, oracle, n_pairs, per, read_len, to_dev):
     keep = [to_dev(seq), to_dev(off), to_dev(pb)]
     (d_seq, d_off, d_pb) = [k[1] for k in keep]
     summary, dup = capi.hotpath_dev(lib, gidx, opt, n_pairs, read_len, d_seq, d_off, d_pb, nb, 0, True)
-    s16, _ = capi.hotpath_dev_ex(lib, gidx, opt, n_pairs, read_len, d_seq, d_off, d_pb, nb, 0)
+    s16, h = capi.hotpath_dev_ex(lib, gidx, opt, n_pairs, read_len, d_seq, d_off, d_pb, nb, 0, keep=True)
     names = []
     for nm, _, _ in pairs:
         names += [nm, nm]
@@ -379,10 +438,17 @@ def check_hotpath(lib, oracle, n_pairs, per, read_len, to_dev):
         lo, hi = 2 * per * b, 2 * per * (b + 1)
         t, _, _ = oracle.process_pairs(oidx, seq[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], names[lo:hi], None, lo, "", 4)
         text += t
-    oflags, marked = oracle_dup_flags(oracle, text, "@SQ\tSN:20_slice\tLN:321635\n")
+    header = "@SQ\tSN:20_slice\tLN:321635\n"
+    oflags, marked = oracle_dup_flags(oracle, text, header)
     assert np.array_equal(dup, oflags) and oflags.sum() > n_pairs // 40, (int(dup.sum()), int(oflags.sum()))
     assert int(s16[10]) == text.count("\n") and int(s16[1]) == int(oflags.sum()), (s16, text.count("\n"))
-    n_disc = sum(1 for l in oracle.last_discordants.split("\n") if l and l[0] != "@")
-    n_spl = sum(1 for l in oracle.last_splitters.split("\n") if l and l[0] != "@")
-    assert (int(s16[8]), int(s16[9])) == (n_disc, n_spl) and n_disc > 0 and (n_spl > 0 or n_pairs < 2000), (s16, n_disc, n_spl)
-    return int(s16[10]), int(s16[1]), n_disc, n_spl
+    res, bits, mate = capi.dev_records_download(lib, h, n_pairs)
+    gtext, _ = capi.sam_format(lib, gidx, opt, res, names, seq, off, None, "")
+    res.close(); capi.dev_records_free(lib, h)
+    assert gtext == text                                        # the records the step left in HBM print as the oracle's SAM text
+    gm, gd, gs = sbl_streams_from_bits(gtext, bits, mate)
+    om, od, os_ = oracle_streams(oracle, text, header)
+    assert gm == om and gd == od and gs == os_, (len(gm), len(om), len(gd), len(od), len(gs), len(os_))
+    n_disc, n_spl = len(od) // 2, len(os_)
+    assert (int(s16[8]), int(s16[9])) == (len(od), n_spl) and n_disc > 0 and (n_spl > 0 or n_pairs < 2000), (s16, n_disc, n_spl)
+    return int(s16[10]), int(s16[1]), len(od), n_spl
