@@ -270,11 +270,13 @@ orc_idx_t *orc_idx_build_fasta(const char *fasta)
 	int n = 0, m = 0; char **names = 0, **seqs = 0, **annos = 0; size_t *ls = 0, *ms = 0;
 	char *line = 0; size_t cap = 0; ssize_t r;
 	while ((r = getline(&line, &cap, fp)) > 0) {
-		while (r > 0 && (line[r-1] == '\n' || line[r-1] == '\r')) line[--r] = 0;
+		if (r > 0 && line[r-1] == '\n') line[--r] = 0;
+		if (line[0] != '>') while (r > 0 && line[r-1] == '\r') line[--r] = 0;
 		if (line[0] == '>') {
 			if (n == m) { m = m ? m << 1 : 8; names = realloc(names, m * sizeof(char*)); annos = realloc(annos, m * sizeof(char*)); seqs = realloc(seqs, m * sizeof(char*)); ls = realloc(ls, m * sizeof(size_t)); ms = realloc(ms, m * sizeof(size_t)); }
 			char *e = line + 1; while (*e && !isspace((unsigned char)*e)) ++e;
-			char *c = e; while (*c && isspace((unsigned char)*c)) ++c;   /* kseq: comment = rest of the header line */
+			char *c = *e ? e + 1 : e;   /* kseq_read (kseq.h:199-200): one delimiter after the name is consumed, the comment is the rest of the line ... */
+			{ size_t cl = strlen(c); if (cl > 1 && c[cl-1] == '\r') c[cl-1] = 0; }   /* ... minus a trailing CR when longer than one character (ks_getuntil2, kseq.h:143) */
 			annos[n] = strdup(c); *e = 0;
 			names[n] = strdup(line + 1); seqs[n] = calloc(1, 1); ls[n] = 0; ms[n] = 1; ++n;
 		} else if (n) {

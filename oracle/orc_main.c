@@ -173,12 +173,23 @@ static int main_mem(int argc, char **argv)
 			if (n + 2 > m) { m = m ? m << 1 : 1024; s = realloc(s, m * sizeof(orc_read_t)); }
 			rc = fq_read1(&f1, &s[n], keep_comment); if (rc < 0) break;
 			size += s[n++].l_seq;
-			if (f2.fp) { rc = fq_read1(&f2, &s[n], keep_comment); if (rc < 0) { rc = -2; break; } size += s[n++].l_seq; }
+			if (f2.fp) {
+				rc = fq_read1(&f2, &s[n], keep_comment);
+				if (rc == -1) { /* upstream bseq_read: the complete pairs read so far are kept */
+					fprintf(stderr, "[W::bseq_read] the 2nd file has fewer sequences.\n");
+					--n; free(s[n].name); free(s[n].comment); free(s[n].seq); free(s[n].qual); break;
+				}
+				if (rc < 0) { rc = -2; break; }
+				size += s[n++].l_seq;
+			}
 			if (size >= chunk && (n & 1) == 0) break;
 		}
 		if (rc == -2) { fprintf(stderr, "[orc_bwa] truncated / malformed FASTQ\n"); return 1; }
+		if (n & 1) { /* upstream main_mem, PE mode: the odd read at the end of the input is dropped */
+			fprintf(stderr, "[W::main_mem] odd number of reads in the PE mode; last read dropped\n");
+			--n; free(s[n].name); free(s[n].comment); free(s[n].seq); free(s[n].qual);
+		}
 		if (n == 0) { free(s); break; }
-		if (n & 1) { fprintf(stderr, "[orc_bwa] odd number of reads in paired-end mode\n"); return 1; }
 		for (i = 0; i < n; i += 2)
 			if (strcmp(s[i].name, s[i+1].name) != 0) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", s[i].name, s[i+1].name); return 1; }
 		orc_pestat_t pes_out[4];

@@ -202,6 +202,38 @@ SSG_DEVFN ssg_pk_t ssg_pk(const ssg_intv_t &v)
 SSG_DEVFN ssg_intv_t ssg_unpk(const ssg_pk_t &p)
 { ssg_intv_t v; v.x0 = p.w0 & 0xffffffffffull; v.x1 = (p.w0 >> 40) | (p.w1 & 0xffffull) << 24; v.x2 = (p.w1 >> 16) & 0xffffffffffull; v.info = p.w1 >> 56; return v; }
 
+/* ---- table of short-pattern intervals (ssg_index_view_t.ktab) ---- */
+SSG_DEVFN long ssg_ktab_off(int j) { return (long)(((1ull << (2 * j)) - 4ull) / 3ull); }   /* entries of the levels below j */
+/* level j from level j - 1: the four one-base left extensions of every pattern, by upstream's own bwt_extend (is_back = 1), so an
+ * entry is bit for bit what the extension it stands in for returns (the interval of a pattern does not depend on the order in
+ * which it was extended to).  Pattern code: little-endian base 4 (first base least significant): children of p are 4p .. 4p + 3. */
+__global__ void ssg_k_ktab_level(ssg_index_view_t ix, int j, ssg_pk_t *tab)
+{
+	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= (1L << (2 * (j - 1)))) return;
+	ssg_pk_t *const out = tab + ssg_ktab_off(j) + 4 * p;
+	ssg_intv_t ok[4];
+	if (j == 1) { for (int c = 0; c < 4; ++c) ssg_set_intv(ix, c, ok[c]); }
+	else ssg_bwt_extend(ix, ssg_unpk(tab[ssg_ktab_off(j - 1) + p]), ok, 1);
+	for (int c = 0; c < 4; ++c) { ok[c].info = 0; out[c] = ssg_pk(ok[c]); }
+}
+/* code of the n <= 15 bases from position b of a read held as 4-bit codes, 8 per LDS word (word w of the read at qw[w * stride]); no base of the window is ambiguous */
+SSG_DEVFN uint64_t ssg_smq_window(const uint32_t *qw, int stride, int b)
+{	/* the 16 codes from position b, 4 bits each, first base lowest */
+	const int w0 = b >> 3, sh = (b & 7) << 2;
+	const int w1 = w0 + 1 < SSG_SM_QWORDS ? w0 + 1 : SSG_SM_QWORDS - 1, w2 = w0 + 2 < SSG_SM_QWORDS ? w0 + 2 : SSG_SM_QWORDS - 1;
+	uint64_t v = ((uint64_t)qw[w0 * stride] | (uint64_t)qw[w1 * stride] << 32) >> sh;
+	if (sh) v |= (uint64_t)qw[w2 * stride] << (64 - sh);
+	return v;
+}
+SSG_DEVFN uint32_t ssg_smq_code(const uint32_t *qw, int stride, int b, int n)
+{
+	uint64_t v = ssg_smq_window(qw, stride, b);
+	v &= 0x3333333333333333ull; v = (v | v >> 2) & 0x0f0f0f0f0f0f0f0full; v = (v | v >> 4) & 0x00ff00ff00ff00ffull;
+	v = (v | v >> 8) & 0x0000ffff0000ffffull; v = (v | v >> 16) & 0xffffffffull;
+	return (uint32_t)v & ((1u << (2 * n)) - 1u);
+}
+
 #ifndef SSG_SMQ_WAVES
 #define SSG_SMQ_WAVES 4
 #endif
@@ -245,9 +277,25 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
 #define SM_DO_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ssg_pk(ik); state = SM_BWD; } while (0)
 /* next start position of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
-#define SM_DO_P3() do { while (x < len && SMQ(x) > 3) ++x; if (x >= len) state = SM_OUT; else { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } } while (0)
+/* With the table of short-pattern intervals the first ktab_k - 1 extensions of a start collapse into one look-up: upstream records nothing
+ * before the pattern has min_seed_len (> ktab_k) bases, so only an ambiguous base or the read's end inside the window matters -- the
+ * start then moves past it exactly as upstream's loop returns (the skipped bwt_extend calls still count as algorithmic work). */
+#define SM_DO_P3() do { for (;;) { \
+		while (x < len && SMQ(x) > 3) ++x; \
+		if (x >= len) { state = SM_OUT; break; } \
+		const int kk_ = ix.ktab_k; \
+		if (kk_ < 2 || kk_ >= opt.min_seed_len) { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; break; } \
+		const unsigned long long nm_ = ssg_smq_window(ql_, RPW, x) & 0x4444444444444444ull; \
+		int run_ = nm_ ? (__ffsll((unsigned long long)nm_) - 1) >> 2 : 16; \
+		if (run_ > len - x) run_ = len - x; \
+		if (run_ >= kk_) { ik = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(kk_) + (long)ssg_smq_code(ql_, RPW, x, kk_)]); i = x + kk_; my_nx += (unsigned long long)(kk_ - 1); state = SM_P3F; break; } \
+		my_nx += (unsigned long long)(run_ - 1); \
+		if (x + run_ >= len) { x = len; state = SM_OUT; break; } \
+		x += run_ + 1; \
+	} } while (0)
 #define SM_DO_RET() do { if (caller == 1) { x = ret; state = SM_P1; } else { ++k; state = SM_P2; } } while (0)
 	unsigned long long tn_adv = 0, tn_ext = 0, tn_rounds = 0, tn_ready = 0, tn_alive = 0, tn_t0 = 0;   /* SSG_TUNING only: cycles in the state machine / at the extension site, rounds, ready and live lanes per round */
+	const unsigned long long tn_wall0 = SSG_TUNING ? ssg_wall() : 0;                                   /* ... and how long each lane had work (the read pool runs dry before the last reads finish) */
 	for (;;) {
 		if (SSG_TUNING) tn_t0 = ssg_clock();
 		/* a bounded number of state-machine steps per extension round: a lane in the middle of a transition sits the round out instead of
@@ -350,7 +398,10 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 			}
 		}
 		if (SSG_TUNING) { const unsigned long long t1 = ssg_clock(); tn_adv += t1 - tn_t0; tn_t0 = t1; ++tn_rounds; tn_ready += (unsigned long long)__popcll(wv_ballot(pend != SM_PEND_NONE)); tn_alive += (unsigned long long)__popcll(wv_ballot(state != SM_FIN)); }
-		if (state == SM_FIN) break;
+		if (state == SM_FIN) {
+			if (SSG_TUNING) { const unsigned long long d = ssg_wall() - tn_wall0; atomicAdd(&ssg_dbg_cyc[29], d); atomicMax(&ssg_dbg_cyc[30], d); atomicAdd(&ssg_dbg_cyc[31], 1ull); }
+			break;
+		}
 		if (pend == SM_PEND_NONE) continue;
 		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
 		ssg_wave_ldssync();   /* list entries stored by lane 0 of the quad last iteration are read by all four below (same wave: in order on the GPU) */
@@ -359,7 +410,11 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 		const int jn = back && j + 1 < prev_n ? j + 1 : 0;
 		ssg_pk_t pf; pf.w0 = pf.w1 = 0;
 		if (jn) pf = SMV(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
-		const ssg_intv_t okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
+		/* the pattern the extension ends with: [i, end of p) going left, [start, i] going right; up to ktab_k bases its interval is in the table */
+		const int pat_b = back ? i : pend == SM_PEND_FWD ? sx : x, pat_n = (back ? (int)p.info : i + 1) - pat_b;
+		ssg_intv_t okc;
+		if (pat_n <= ix.ktab_k) okc = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
+		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
 		++my_nx;
 		{
 			ssg_pk_t *const curr = flip ? vec1 : vec0;

@@ -242,6 +242,7 @@ int ssg_index_build_dev(const uint8_t *d_fwd, int64_t l_pac, int n_ctg, const in
 	ssg_index *ix = new ssg_index();
 	int rc = build_from_fwd(d_fwd, l_pac, ix);
 	if (!rc) rc = set_contigs(ix, n_ctg, ctg_off, ctg_len);
+	if (!rc) rc = ssg_index_build_ktab(ix);
 	if (rc) { ssg_index_destroy(ix); return rc; }
 	ix->names.resize(n_ctg); ix->annos.assign(n_ctg, ""); ix->n_ambs.assign(n_ctg, 0);
 	for (int i = 0; i < n_ctg; ++i) ix->names[i] = std::to_string(i + 1);
@@ -269,8 +270,10 @@ int ssg_index_build_fasta(const char *fasta, ssg_index_t **out)
 	auto begin_seq = [&]() {
 		size_t e = 0; while (e < hdr.size() && !isspace((unsigned char)hdr[e])) ++e;
 		ix->names.push_back(hdr.substr(0, e));
-		while (e < hdr.size() && isspace((unsigned char)hdr[e])) ++e;
-		std::string c = hdr.substr(e); while (!c.empty() && (c.back() == '\r' || c.back() == '\n')) c.pop_back();
+		/* kseq_read: the name ends at the first blank, which alone is consumed; the comment is the rest of the line (further blanks
+		 * included), minus one trailing CR when it is longer than one character (ks_getuntil2, kseq.h:143) */
+		std::string c = e < hdr.size() ? hdr.substr(e + 1) : std::string();
+		if (c.size() > 1 && c.back() == '\r') c.pop_back();
 		ix->annos.push_back(c); ix->n_ambs.push_back(0);
 		off.push_back((int64_t)codes.size()); cur_len = 0; lasts = 0;
 	};
@@ -305,6 +308,7 @@ int ssg_index_build_fasta(const char *fasta, ssg_index_t **out)
 	{ std::vector<uint8_t>().swap(codes); }
 	if (!rc) rc = build_from_fwd(d_fwd.p, l_pac, ix);
 	if (!rc) rc = set_contigs(ix, (int)off.size(), off.data(), len.data());
+	if (!rc) rc = ssg_index_build_ktab(ix);
 	if (rc) { ssg_index_destroy(ix); return rc; }
 	*out = ix;
 	return 0;

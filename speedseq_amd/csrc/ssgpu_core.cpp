@@ -109,6 +109,24 @@ static int densify_sa(ssg_index *ix)
 	return 0;
 }
 
+/* table of the intervals of all patterns up to K bases (ssg_index_view_t.ktab, k_seed.h): K = SSG_KTAB_K, by default 13 capped at
+ * log4(text length) - 2 (1.4 GB for a human-size index; built level by level with upstream's bwt_extend, ~90 M extensions) */
+int ssg_index_build_ktab(ssg_index *ix)
+{
+	int lg = 0; while ((ix->v.seq_len >> (2 * (lg + 1))) != 0) ++lg;    /* floor(log4(seq_len)) */
+	int K = env_int("SSG_KTAB_K", std::min(13, lg - 2));
+	if (K > 14) K = 14;
+	ix->v.ktab = 0; ix->v.ktab_k = 0;
+	if (K < 1 || ix->v.seq_len >= (1ull << 40)) return 0;
+	const size_t n_ent = (size_t)((((1ull << (2 * (K + 1))) - 4ull) / 3ull));
+	ix->ktab = (uint64_t*)rt_malloc(n_ent * 16);
+	if (!ix->ktab) { ssg_err_msg = "index allocation failed: k-mer interval table"; return SSG_ENOMEM; }
+	for (int j = 1; j <= K; ++j) { const long np = 1L << (2 * (j - 1)); SSG_LAUNCH(ssg_k_ktab_level, (np + 255) / 256, 256, 0, ix->v, j, (ssg_pk_t*)ix->ktab); }
+	CHK(rt_sync());
+	ix->v.ktab = ix->ktab; ix->v.ktab_k = K;
+	return 0;
+}
+
 int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t primary, const uint64_t L2[5],
                           const uint64_t *sa, uint64_t n_sa, int sa_intv, const uint8_t *pac, int64_t l_pac,
                           int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out)
@@ -128,7 +146,7 @@ int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t prim
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
-	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }
@@ -240,7 +258,7 @@ int ssg_index_load(const char *prefix, ssg_index_t **out)
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_seqs; ix->v.sa_intv = sa_intv;
 	ix->h_off = off; ix->h_len = len; ix->names = names;
-	{ const int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	if (ssg_debug()) {
 		const auto t_end = std::chrono::steady_clock::now();
 		fprintf(stderr, "[ssgpu] index load: files -> HBM %.3f s (%.2f GB), SA samples to every %d rows %.3f s\n", std::chrono::duration<double>(t_up - t_begin).count(),
@@ -255,7 +273,7 @@ void ssg_index_destroy(ssg_index_t *ix)
 	if (!ix) return;
 	if (ix->raw_alloc) { rt_free_raw(ix->bwt); rt_free_raw(ix->sa); rt_free_raw(ix->pac); }
 	else { rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); }
-	rt_free(ix->ctg_off); rt_free(ix->ctg_len);
+	rt_free(ix->ctg_off); rt_free(ix->ctg_len); rt_free(ix->ktab);
 	delete ix;
 }
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,
@@ -271,7 +289,7 @@ int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
-	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }

@@ -180,6 +180,18 @@ struct bgzf_in_t {
 		}
 		return got;
 	}
+	/* advance n bytes without copying them; returns the count */
+	size_t skip(size_t n)
+	{
+		size_t got = 0;
+		while (got < n) {
+			while (qi < q.size() && qo >= q[qi].data.size()) { ++qi; qo = 0; }
+			if (qi >= q.size()) { if (!next_batch()) break; continue; }
+			const size_t k = std::min(n - got, q[qi].data.size() - qo);
+			got += k; qo += k;
+		}
+		return got;
+	}
 	/* bgzf_tell after the last get(): the block holding the next unread byte (an exhausted block reports the next block's address, offset 0) */
 	uint64_t tell()
 	{

@@ -366,12 +366,17 @@ static int cmd_index(int argc, char **argv)
 	if (!hdr_read(bi, h)) die("index: not a BAM file");
 	bai_t idx((int)h.names.size(), bi.tell());
 	std::vector<uint8_t> rec;
-	for (;;) {
+	for (;;) {   /* only the fixed fields, the name and the CIGAR of a record are looked at: the rest (sequence, qualities, tags) is skipped in place */
 		uint32_t bs;
 		if (bi.get(&bs, 4) != 4) break;
-		rec.resize(bs);
-		if (bi.get(rec.data(), bs) != bs) die("index: truncated BAM");
+		if (bs < 32) die("index: malformed BAM record");
+		rec.resize(32);
+		if (bi.get(rec.data(), 32) != 32) die("index: truncated BAM");
 		bam_core_t c; memcpy(&c, rec.data(), 32);
+		const size_t var = (size_t)(c.bin_mq_nl & 0xff) + 4 * (size_t)(c.flag_nc & 0xffff);
+		if (32 + var > bs) die("index: malformed BAM record");
+		rec.resize(32 + var);
+		if (bi.get(rec.data() + 32, var) != var || bi.skip(bs - 32 - var) != bs - 32 - var) die("index: truncated BAM");
 		if (idx.push(c.tid, c.pos, bam_endpos(rec.data()), bi.tell(), !((c.flag_nc >> 16) & 4)) < 0) die("index: the file is not coordinate-sorted");
 	}
 	idx.finish(bi.tell());
