@@ -36,6 +36,14 @@ GRCH37 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 1591
 GRCH37_NAMES = [str(i) for i in range(1, 23)] + ["X", "Y", "MT"]
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """progress on stderr with the time since start: a run cut short still says where its time went"""
+    sys.stderr.write("[bench %7.1f s] %s\n" % (time.time() - _T0, msg)); sys.stderr.flush()
+
+
 def markov_table(order):
     """order-k transition CDF (4^k x 3 thresholds) trained on the reference's bundled chr20 slice (tests/golden/chr20_slice.fa,
     a copy of /root/reference/example/data/*.fasta), add-one smoothed"""
@@ -181,14 +189,14 @@ def write_fastq(path, reads_np, rl, first_pair=0):
     rec.tofile(path)
 
 
-def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
+def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe, b=None):
     """The plugin path as the reference wires it (bin/speedseq:438-439): FASTQ file -> `bwa mem -t T -p` | `samblaster --excludeDups
     --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile --discordantFile` -> three SAM streams on files, wall clock.
     The index is loaded from the files written by ssg_index_save; the rate excludes that one-off load (reported separately).
     A sample of the same FASTQ goes through the oracle's executables and the three streams must be byte-identical (modulo @PG)."""
     import subprocess
     import re
-    bwa, sbl = os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster")
+    bwa, sbl = (b("bwa"), b("samblaster")) if b else (os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster"))
     rn = reads.cpu().numpy()
     if reads2 is not None:
         rn = np.concatenate([rn, reads2.numpy()])      # the timed batch + a second one: several device calls, so the stages overlap
@@ -203,7 +211,10 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
         cmd = "%s mem -t %d -p %s %s 2> %s.bwa.err | %s --excludeDups --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile %s --discordantFile %s > %s 2> %s.sbl.err" % (
             bwa_cmd, threads, prefix, fastq, os.path.join(td, tag), sbl_cmd, sp, di, o, os.path.join(td, tag))
         t = time.perf_counter()
-        rc = subprocess.call(["bash", "-c", "set -o pipefail; " + cmd])
+        try:
+            rc = subprocess.call(["bash", "-c", "set -o pipefail; " + cmd], timeout=300)
+        except subprocess.TimeoutExpired:
+            raise RuntimeError("pipeline %s: no result within 300 s" % tag)
         t = time.perf_counter() - t
         err = open(os.path.join(td, tag + ".bwa.err")).read()
         if rc != 0:
@@ -255,7 +266,7 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe):
     return res
 
 
-def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, sort_mem_gb=40, config_extra="", env_extra=None):
+def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, sort_mem_gb=40, config_extra="", env_extra=None, limit_s=300):
     """SURVEY.md 8d's own definition of the metric: the reference's `speedseq align` (the script itself, unmodified -- the fixture copy
     tests/golden/speedseq_ref_script.sh, or /root/reference/bin/speedseq where that exists) on the executables speedseq.config names,
     wall clock from FASTQ open to the three coordinate-sorted, indexed BAMs closed.  The index files are already next to `ref_prefix`.
@@ -283,10 +294,18 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
     out = os.path.join(d, "out")
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
     env.update(env_extra or {})
+    import signal
     t = time.perf_counter()
-    r = subprocess.run(["bash", script, "align", "-K", cfg, "-o", out, "-M", str(sort_mem_gb), "-t", str(threads), "-p",
-                        "-R", "@RG\\tID:bench\\tSM:bench\\tLB:lib1", ref_prefix, fq], cwd=d, env=env, capture_output=True, text=True)
+    p = subprocess.Popen(["bash", script, "align", "-K", cfg, "-o", out, "-M", str(sort_mem_gb), "-t", str(threads), "-p",
+                          "-R", "@RG\\tID:bench\\tSM:bench\\tLB:lib1", ref_prefix, fq], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)                       # the whole pipeline (the script's children share the session)
+        so, se = p.communicate()
+        return {"error": "no result within %d s; stderr tail: %s" % (limit_s, se[-600:])}
     t = time.perf_counter() - t
+    r = type("R", (), {"returncode": p.returncode, "stdout": so, "stderr": se})
     if r.returncode != 0:
         return {"error": (r.stdout[-400:] + r.stderr[-400:])}
     sizes = {x: os.path.getsize(out + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
@@ -328,6 +347,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     r.pop("out", None)
     r["what"] = "`speedseq align -t %d -p` (the reference's script, unmodified) on bin/bwa, bin/samblaster, bin/sambamba with `export SSG_FUSED=1` in speedseq.config (binary hand-off between the stages, speedseq_amd/host/fused.h)" % a.script_threads
     res["fused"] = r
+    log('script, fused hand-off: %s pairs in %s s' % (r.get('pairs'), r.get('wall_s')))
     res["value"] = r.get("pairs_per_s")
     res["unit"] = "pairs/s"
     n_text = min(2000000, n_all)
@@ -335,6 +355,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     r.pop("out", None)
     r["what"] = "the same without SSG_FUSED: SAM text on every pipe (the parity path)"
     res["text"] = r
+    log('script, text hand-off: %s pairs in %s s' % (r.get('pairs'), r.get('wall_s')))
     os.remove(os.path.join(td, "text.fq"))
     # parity of the fused path on the sample: product (fused) vs the oracle's executables behind the same script
     sfq = os.path.join(td, "sample.fq")
@@ -357,6 +378,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
             rc = script_leg(td, "cpu%d" % k, prefix, cfq, nc, cores, orc_exe, orc_exe + " samblaster", shim, sort_mem_gb=8)
             if "wall_s" in rc:
                 runs.append(rc["wall_s"])
+            log('script on the oracle executables, run %d: %s' % (k, rc.get('wall_s', rc.get('error'))))
         if runs:
             med = sorted(runs)[len(runs) // 2]
             res["cpu_script"] = {"value": nc / med, "unit": "pairs/s", "cores": cores, "kind": "port", "pairs": nc, "runs_wall_s": runs,
@@ -381,6 +403,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
     ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs in the FASTQ file of the plugin-path leg (the timed batch + freshly simulated ones): enough device calls for the pipeline's steady state to show")
+    ap.add_argument("--emu-selftest", action="store_true", help="TEST INFRASTRUCTURE, never a measurement: walk this script's whole flow on the CPU with the host-emulation build "
+                    "(tests/emu) and the bundled chr20 slice as the reference, at toy sizes -- catches a broken leg before it costs GPU minutes")
+    ap.add_argument("--partial", default=os.path.join(ROOT, "gpurun_out", "bench_partial.json"), help="the line so far is also written here after every leg (a run that is cut short leaves its numbers)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -400,25 +425,41 @@ def main():
         import torch.distributed as dist
         from speedseq_amd import dist as ssdist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
+    emu = a.emu_selftest
+    if not emu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if emu:
+        class _NoCuda:                                       # the flow below calls torch.cuda.* between legs
+            def __getattr__(self, _):
+                return lambda *x, **k: None
+        torch.cuda = _NoCuda()
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
 
     from speedseq_amd import capi
-    lib = capi.Lib()
+    lib = capi.Lib(os.path.join(ROOT, "tests", "emu", "libssgpu_emu.so") if emu else None)
     lib._chk(lib.l.ssg_set_device(C.c_int(local)))
     opt = lib.opt_init()
 
     t0 = time.time()
-    ref, lens, n_fam = synth_reference(int(a.ref_mbp * 1e6), 20150810, dev)
+    if emu:
+        import simreads
+        codes = np.concatenate([c for _, c in simreads.read_fasta(os.path.join(ROOT, "tests", "golden", "chr20_slice.fa"))]).astype(np.uint8)
+        codes[codes > 3] = 0
+        ref, lens, n_fam = torch.from_numpy(codes), [int(codes.size)], 0
+    else:
+        ref, lens, n_fam = synth_reference(int(a.ref_mbp * 1e6), 20150810, dev)
     torch.cuda.synchronize()
     t_ref = time.time() - t0
     ctg_off = np.concatenate([[0], np.cumsum(lens)])[:-1]
     t0 = time.time()
     torch.cuda.empty_cache()
-    idx = lib.index_build_dev(ref.data_ptr(), int(ref.numel()), ctg_off, lens, GRCH37_NAMES)   # `bwa index` on the device (k_index.h)
+    ctg_names = GRCH37_NAMES[:len(lens)]
+    idx = lib.index_build_dev(ref.data_ptr(), int(ref.numel()), ctg_off, lens, ctg_names)   # `bwa index` on the device (k_index.h)
     t_index = time.time() - t0
+    log('reference (%.1f s) and index (%.1f s) on the device' % (t_ref, t_index))
 
     rl = a.read_len
     if a.cpu_sample < 0:
@@ -448,7 +489,7 @@ def main():
         summary, h = capi.hotpath_dev_ex(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0,
                                          local_dedup=False, d_sig=d_sig.data_ptr(), keep=True)
         valid = d_sig[:, 0] != -1
-        dup = ssdist.global_markdup(d_sig, valid, ordinal, device=dev).to(torch.uint8).contiguous()
+        dup = ssdist.global_markdup(d_sig, valid, ordinal, device=dev, lib=lib).to(torch.uint8).contiguous()
         c = capi.dev_records_classify(lib, h, dup.data_ptr())
         # ... and the coordinate-sorted merge (coupling 3): keys + fixed-size records of every SAM line travel to the rank that owns
         # their key range (sample sort: one all-to-all), where they are sorted by (key, global ordinal)
@@ -485,6 +526,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     kern = capi.prof_get(lib) if prof else {}
+    log('timed steps done: %.1f ms/step' % (1e3 * dt / a.steps))
     if prof:
         lib.l.ssg_prof_enable(C.c_int(0))
 
@@ -503,7 +545,15 @@ def main():
                    "dedup_scope": "global over all ranks (all-to-all signature exchange)" if multi else "single GPU = whole input",
                    "sorted_merge": ("coordinate range exchange of %d-byte records by samtools' key inside the step; %.1f MB sent by rank 0 per step" % (rec_bytes, merge_bytes[0] / 1e6)) if multi else "single GPU: bin/sambamba sort (device radix sort of the keys)"},
     }
+    def save_partial():
+        try:
+            os.makedirs(os.path.dirname(a.partial), exist_ok=True)
+            with open(a.partial, "w") as f:
+                json.dump(out, f)
+        except Exception:
+            pass
     if rank == 0:
+        save_partial()
         # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
         if kern:
             name, (ms, cnt) = max(kern.items(), key=lambda kv: kv[1][0])
@@ -578,12 +628,13 @@ def main():
             lib.index_save(idx, prefix)           # the five `bwa index` files of the device-built index
             oidx = orc.idx_load(prefix)           # ... loaded by the oracle: the index bytes cross the file format both ways
             t_files = time.time() - tw
+            log('index files written and loaded by the oracle (%.1f s)' % t_files)
             hs_all = reads.cpu().numpy().reshape(-1)
             hs = hs_all[:2 * ns * rl]
             hoff = np.arange(2 * ns + 1, dtype=np.int64) * rl
             names = ["r%d" % (i // 2) for i in range(2 * ns)]
-            cores = min(os.cpu_count() or 1, 128)
-            hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(GRCH37_NAMES, lens))
+            cores = min(os.cpu_count() or 1, 64)
+            hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(ctg_names, lens))
             nw = min(ns, 2000)                         # untimed: the worker threads' allocator heaps and the index pages they touch first
             orc.process_pairs(oidx, hs[:2 * nw * rl], hoff[:2 * nw + 1], names[:2 * nw], None, 0, "", cores)
             tc = time.perf_counter()
@@ -594,7 +645,9 @@ def main():
                 t_, _, _ = orc.process_pairs(oidx, hs[2 * lo * rl:2 * hi * rl], hoff[2 * lo:2 * hi + 1] - hoff[2 * lo], names[2 * lo:2 * hi], None, 2 * lo, "", cores)
                 otext += t_
             tc = time.perf_counter() - tc
+            log('oracle aligned %d pairs on %d threads in %.1f s' % (ns, cores, tc))
             om, od, os_ = common.oracle_streams(orc, otext, hdr)
+            log('oracle samblaster done')
             # the device side: the timed call itself when the whole batch is checked, else the same entry point on the sample's pairs
             if full:
                 s2, hrec = capi.hotpath_dev_ex(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0, keep=True)
@@ -606,7 +659,9 @@ def main():
             res, bits, mate = capi.dev_records_download(lib, hrec, ns)
             gtext, _ = capi.sam_format(lib, idx, opt, res, names, hs, hoff, None, "")
             res.close(); capi.dev_records_free(lib, hrec)
+            log('device records downloaded and printed')
             gm, gd, gs = common.sbl_streams_from_bits(gtext, bits, mate)
+            log('streams rebuilt from the device decisions')
             ok_text = gtext == otext
             ok = bool(ok_text and gm == om and gd == od and gs == os_ and same_summary is not False)
             n_rec_diff = 0
@@ -642,15 +697,19 @@ def main():
                 out["parity"]["oracle_independent"] = {"error": repr(e)}
             del gtext, otext, gm, gd, gs, om, od, os_
             if a.e2e:
-                b = lambda n: os.path.join(ROOT, "bin", n)
+                b = (lambda n: os.path.join(ROOT, "tests", "emu", n + "_emu")) if emu else (lambda n: os.path.join(ROOT, "bin", n))
                 orc_exe = os.path.join(ROOT, "oracle", "orc_bwa")
                 nse = min(20000, ns)
+                log('parity gate done: %s' % ok)
+                save_partial()
                 try:
-                    out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, nse, orc_exe=orc_exe)
+                    out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, nse, orc_exe=orc_exe, b=b)
                     if not out["e2e"].get("sample_streams_identical", True):
                         ok = False
                 except Exception as e:      # the plugin-path measurement must not take the headline down with it
                     out["e2e"] = {"error": repr(e)}
+                log('plugin-path leg done')
+                save_partial()
                 try:
                     out["literal"] = literal_legs(a, td, prefix, rl, nse, b, orc_exe)
                     if out["literal"].get("sample_bams_equal_oracle") is False:
@@ -659,6 +718,8 @@ def main():
                         out["cpu_baseline"]["script"] = out["literal"].pop("cpu_script")
                 except Exception as e:
                     out["literal"] = {"error": repr(e)}
+            log('script legs done')
+            save_partial()
             td_obj.cleanup()
             if not ok:   # no timing counts without parity
                 out["value"] = None

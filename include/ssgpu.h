@@ -182,6 +182,10 @@ int ssg_hotpath_dev_ex(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_p
                        const int32_t *d_pair_batch, int n_batches, int64_t id0, const ssg_sbl_opt_t *sbl, int local_dedup,
                        uint64_t summary[16], uint8_t *dup_host, uint64_t *d_sig_out, ssg_dev_records_t **keep);
 int ssg_dev_records_classify(ssg_dev_records_t *r, const ssg_sbl_opt_t *sbl, const uint8_t *d_dup, uint64_t counts[4]);
+/* the owner rank's side of that exchange (samblaster.cpp's set is global: the first pair of a signature in INPUT order survives): for n
+ * signatures received from all ranks (DEVICE: d_sig n x 3 uint64, all ones = never a duplicate; d_ordinal = global input ordinal of the
+ * pair, non-negative) d_dup[i] = 1 iff an element with the same signature and a smaller ordinal exists.  Same kernels as ssg_sbl_markdup. */
+int ssg_markdup_sig_dev(long n, const uint64_t *d_sig, const int64_t *d_ordinal, uint8_t *d_dup);
 void ssg_dev_records_free(ssg_dev_records_t *r);
 /* for the coordinate-sorted merge across ranks (SURVEY 8e coupling 3): per SAM line of the kept records, in line order, the sort key
  * of samtools bam_sort.c:1607-1614 (tid<<32 | (pos+1)<<1 | reverse), the fixed-size device record and the side-stream bits,

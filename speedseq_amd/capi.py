@@ -252,6 +252,11 @@ def dev_records_classify(lib, h, d_dup):
     return counts
 
 
+def markdup_sig_dev(lib, n, d_sig, d_ordinal, d_dup):
+    """owner-side first-seen-wins over received signatures (device addresses): ssg_markdup_sig_dev"""
+    lib._chk(lib.l.ssg_markdup_sig_dev(C.c_long(n), C.c_void_p(d_sig), C.c_void_p(d_ordinal), C.c_void_p(d_dup)))
+
+
 def dev_records_n_lines(lib, h):
     lib.l.ssg_dev_records_n_lines.restype = C.c_int64
     return int(lib.l.ssg_dev_records_n_lines(h))

@@ -997,6 +997,38 @@ static int dedup_core(ssg_sbl_state *st, long n_pairs, const ssg_sbl_end_t *d_en
 	return rt_sync();
 }
 
+__global__ void ssg_k_iota_u32(uint32_t *a, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = (uint32_t)i; }
+/* first-seen-wins over signatures that arrive from several ranks (SURVEY 8e coupling 2, the owner's side of the exchange): element i
+ * is a duplicate iff another element with the same signature has a smaller ordinal.  All-ones signatures never are.  One radix
+ * sort by ordinal puts the elements in input order; from there it is the single-process duplicate marking (hash sort + run scan). */
+__global__ void ssg_k_sigdup_gather(long n, const uint32_t *perm, const ssg_sig_t *sig, ssg_sig_t *sig_o, uint64_t *hash, uint32_t *ord)
+{
+	const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const ssg_sig_t s = sig[perm[i]];
+	sig_o[i] = s; ord[i] = (uint32_t)i;
+	hash[i] = ssg_sig_never(s) ? ~0ull - (uint64_t)i : ssg_mix64(s.k0 ^ ssg_mix64(s.k1 ^ ssg_mix64(s.k2)));
+}
+__global__ void ssg_k_sigdup_scatter(long n, const uint32_t *perm, const uint8_t *dup_o, uint8_t *dup)
+{
+	const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dup[perm[i]] = dup_o[i];
+}
+static int sigdup_core(long n, const ssg_sig_t *d_sig, const uint64_t *d_ordinal, uint8_t *d_dup)
+{
+	const int block = 256;
+	dbuf<uint64_t> d_k(n), d_ks(n), d_h(n), d_hs(n); dbuf<uint32_t> d_v(n), d_perm(n), d_o(n), d_os(n); dbuf<ssg_sig_t> d_so(n); dbuf<uint8_t> d_do(n);
+	CHKA(d_k); CHKA(d_ks); CHKA(d_h); CHKA(d_hs); CHKA(d_v); CHKA(d_perm); CHKA(d_o); CHKA(d_os); CHKA(d_so); CHKA(d_do);
+	CHK(rt_d2d(d_k.p, d_ordinal, (size_t)n * 8));
+	SSG_LAUNCH(ssg_k_iota_u32, (n + block - 1) / block, block, 0, d_v.p, n);
+	CHK(sort_pairs_u64(d_k.p, d_ks.p, d_v.p, d_perm.p, n));
+	SSG_LAUNCH(ssg_k_sigdup_gather, (n + block - 1) / block, block, 0, n, d_perm.p, d_sig, d_so.p, d_h.p, d_o.p);
+	CHK(sort_pairs_u64(d_h.p, d_hs.p, d_o.p, d_os.p, n));
+	SSG_LAUNCH(ssg_k_sbl_markdup, (n + block - 1) / block, block, 0, n, d_hs.p, d_os.p, d_so.p, (const uint64_t*)0, (const ssg_sig_t*)0, (uint64_t)0, d_do.p, (uint8_t*)0);
+	SSG_LAUNCH(ssg_k_sigdup_scatter, (n + block - 1) / block, block, 0, n, d_perm.p, d_do.p, d_dup);
+	return rt_sync();
+}
+
 /* rows a14-a17 for a chunk of name-grouped blocks resident in HBM: duplicate bits (through the state's table), mate lines, side-stream bits */
 static int sbl_process_dev(ssg_sbl_state *st, const ssg_sbl_opt_t *o, long n_blocks, const int64_t *d_blk_off, const ssg_sbl_line_t *d_lines,
                            uint8_t *d_out, int64_t *d_mate, uint8_t *d_dup_out /* may be NULL */)
@@ -1053,9 +1085,18 @@ int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_
 	return d_dup.down(dup, n_pairs);
 }
 
+/* the owner's side of the duplicate exchange between ranks (speedseq_amd/dist.py global_markdup): DEVICE pointers; d_sig n x 3 uint64 as
+ * ssg_hotpath_dev_ex wrote them on the sending ranks (all ones = never a duplicate), d_ordinal the global input ordinal of each pair */
+int ssg_markdup_sig_dev(long n, const uint64_t *d_sig, const int64_t *d_ordinal, uint8_t *d_dup)
+{
+	CHK(need_device());
+	if (n <= 0) return 0;
+	if (n >= (1L << 32)) { ssg_err_msg = "ssg_markdup_sig_dev: more than 2^32 signatures per call"; return SSG_EINVAL; }
+	return sigdup_core(n, (const ssg_sig_t*)d_sig, (const uint64_t*)d_ordinal, d_dup);
+}
+
 /* stable sort of 64-bit keys on the device: perm[i] = input index of the i-th smallest key (equal keys keep input order).
  * The coordinate sort of BAM records (samtools bam_sort.c:1607-1614 key, stable) is this call on the record keys (row f1). */
-__global__ void ssg_k_iota_u32(uint32_t *a, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = (uint32_t)i; }
 int ssg_sort_u64_perm(const uint64_t *keys, int64_t n, uint32_t *perm)
 {
 	CHK(need_device());

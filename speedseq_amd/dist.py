@@ -51,7 +51,28 @@ def _mix(x):
     return x
 
 
-def global_markdup(sig, valid, ordinal, device="cpu"):
+def _owner_verdicts(recv, lib):
+    """owner side: an element is a duplicate iff the same signature arrived with a smaller global ordinal.  With libssgpu (device tensors)
+    this is ssg_markdup_sig_dev -- the kernels of the single-GPU duplicate marking (radix sort by ordinal, hash sort, run scan); without
+    it (the gloo tests on CPU tensors) the same rule in torch."""
+    if lib is not None and recv.is_cuda:
+        from . import capi
+        n = recv.shape[0]
+        sig = recv[:, :3].clone()
+        sig[recv[:, 4] == 0] = -1                      # not valid: never a duplicate (all ones)
+        sig = sig.contiguous(); ordi = recv[:, 3].contiguous()
+        verdict = torch.empty(n, dtype=torch.uint8, device=recv.device)
+        if n:
+            torch.cuda.current_stream().synchronize()   # libssgpu launches on the default stream
+            capi.markdup_sig_dev(lib, n, sig.data_ptr(), ordi.data_ptr(), verdict.data_ptr())
+        return verdict
+    keys, inv = torch.unique(recv[:, :3], dim=0, return_inverse=True)
+    first = torch.full((keys.shape[0],), torch.iinfo(torch.int64).max, dtype=torch.int64, device=recv.device)
+    first = first.scatter_reduce(0, inv, recv[:, 3], reduce="amin")
+    return ((recv[:, 3] > first[inv]) & (recv[:, 4] != 0)).to(torch.uint8)
+
+
+def global_markdup(sig, valid, ordinal, device="cpu", lib=None):
     """Exact first-seen-wins duplicate flags across all ranks.  sig int64 [n,3], valid bool [n],
     ordinal int64 [n] = global input index of each local pair.  Returns uint8 [n]."""
     world, n = dist.get_world_size(), sig.shape[0]
@@ -66,11 +87,7 @@ def global_markdup(sig, valid, ordinal, device="cpu"):
     sc, rc = send_counts.tolist(), recv_counts.tolist()
     recv = torch.empty(sum(rc), 5, dtype=torch.int64, device=device)
     dist.all_to_all_single(recv, payload, output_split_sizes=rc, input_split_sizes=sc)
-    # owner side: minimum ordinal per signature
-    keys, inv = torch.unique(recv[:, :3], dim=0, return_inverse=True)
-    first = torch.full((keys.shape[0],), torch.iinfo(torch.int64).max, dtype=torch.int64, device=device)
-    first = first.scatter_reduce(0, inv, recv[:, 3], reduce="amin")
-    verdict = ((recv[:, 3] > first[inv]) & (recv[:, 4] != 0)).to(torch.uint8)
+    verdict = _owner_verdicts(recv, lib)
     back = torch.empty(n, dtype=torch.uint8, device=device)
     dist.all_to_all_single(back, verdict.contiguous(), output_split_sizes=sc, input_split_sizes=rc)
     dup = torch.empty(n, dtype=torch.uint8, device=device)

@@ -117,3 +117,24 @@ def test_emu_hotpath_dedup_and_classification(emu_lib, oracle, read_len):
     """the bench's step through ssg_hotpath_dev_ex (rows a1-a17 in one call, samblaster's decisions on the device records) vs the oracle"""
     r = common.check_hotpath(emu_lib, oracle, 600, 200, read_len, lambda a: (a, a.ctypes.data))
     assert r[0] >= 1200
+
+
+def test_emu_owner_side_dedup_matches_min_ordinal_rule(emu_lib):
+    """ssg_markdup_sig_dev (the owner rank's side of the signature exchange, SURVEY 8e coupling 2): an element is a duplicate iff the same
+    signature came with a smaller global ordinal; all-ones signatures never are -- against the rule written out in numpy"""
+    import numpy as np
+    from speedseq_amd import capi
+    rng = np.random.default_rng(7)
+    n = 5000
+    sig = rng.integers(0, 6, size=(n, 3)).astype(np.uint64)           # many collisions
+    sig[rng.random(n) < 0.1] = np.uint64(0xffffffffffffffff)           # never-duplicate entries
+    ordinal = rng.permutation(n * 3)[:n].astype(np.int64)             # arrival order is not input order
+    dup = np.zeros(n, dtype=np.uint8)
+    capi.markdup_sig_dev(emu_lib, n, sig.ctypes.data, ordinal.ctypes.data, dup.ctypes.data)
+    first = {}
+    for i in np.argsort(ordinal):
+        k = tuple(int(x) for x in sig[i])
+        first.setdefault(k, int(ordinal[i]))
+    never = (0xffffffffffffffff,) * 3
+    exp = np.array([0 if tuple(int(x) for x in sig[i]) == never else int(ordinal[i] > first[tuple(int(x) for x in sig[i])]) for i in range(n)], dtype=np.uint8)
+    assert np.array_equal(dup, exp) and exp.sum() > n // 2
