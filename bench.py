@@ -395,6 +395,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step (BASELINE.json configs[1]: 1M)")
     ap.add_argument("--ref-mbp", type=float, default=3100.0, help="synthetic GRCh37-shaped reference size (GRCh37 = 3100)")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--ins-mean", type=int, default=0, help="fragment length mean (0: 400, or 800 for reads of 250 bases and more -- BASELINE.json configs[4]: wgsim -d 800 -s 150)")
+    ap.add_argument("--ins-std", type=int, default=0)
     ap.add_argument("--bwa-threads", type=int, default=16, help="the -t whose batch boundaries (insert-size model scope) are reproduced")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs of the timed batch aligned by the CPU oracle: parity gate on the timed call + cpu_baseline (-1 = the whole batch, 0 = skip)")
     ap.add_argument("--script-pairs", type=int, default=8000000, help="pairs in the FASTQ of the literal-metric leg: the reference's `speedseq align` script on the product executables, FASTQ -> three sorted BAMs + BAI")
@@ -464,9 +466,10 @@ def main():
     rl = a.read_len
     if a.cpu_sample < 0:
         a.cpu_sample = a.pairs
-    reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev)
+    ins = dict(ins_mean=a.ins_mean or (800 if rl >= 250 else 400), ins_std=a.ins_std or (150 if rl >= 250 else 50))
+    reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev, **ins)
     n_more = max(0, max(a.e2e_pairs, a.script_pairs) - a.pairs)
-    reads_e2e = simulate_pairs(ref, lens, n_more, rl, 1012, dev).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0 and n_more > 0) else None   # further pairs for the plugin-path leg
+    reads_e2e = simulate_pairs(ref, lens, n_more, rl, 1012, dev, **ins).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0 and n_more > 0) else None   # further pairs for the plugin-path leg
     d_seq = reads.reshape(-1)
     d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
     pb, n_batches = bwa_batches(a.pairs, rl, a.bwa_threads)
@@ -538,7 +541,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": workload,
-                   "pairs_per_gpu": a.pairs, "read_len": rl, "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2), "ref_synth_s": round(t_ref, 2),
+                   "pairs_per_gpu": a.pairs, "read_len": rl, "fragment_mean_std": [ins["ins_mean"], ins["ins_std"]], "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2), "ref_synth_s": round(t_ref, 2),
                    "records": int(summary[0]), "dup_pairs": n_dup_global[0] if multi else int(summary[1]), "dup_pairs_local_view": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
                    "bwt_extends": int(summary[6]), "chains": int(summary[7]),
                    "sam_lines": int(summary[10]), "discordant_stream_lines": int(summary[8]), "splitter_stream_lines": int(summary[9]),

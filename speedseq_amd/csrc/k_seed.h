@@ -217,6 +217,18 @@ __global__ void ssg_k_ktab_level(ssg_index_view_t ix, int j, ssg_pk_t *tab)
 	else ssg_bwt_extend(ix, ssg_unpk(tab[ssg_ktab_off(j - 1) + p]), ok, 1);
 	for (int c = 0; c < 4; ++c) { ok[c].info = 0; out[c] = ssg_pk(ok[c]); }
 }
+/* self-check of the table (SSG_KTAB_VERIFY=1): every `stride`-th pattern of level j once more, this time the way the seeding kernel
+ * would have reached it without the table -- from its first base by forward extensions (ssg_bwt_extend1_lean) -- and compared */
+__global__ void ssg_k_ktab_verify(ssg_index_view_t ix, int j, long stride, const ssg_pk_t *tab, unsigned long long *bad)
+{
+	const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, code = t * stride;
+	if (code >= (1L << (2 * j))) return;
+	ssg_intv_t ik;
+	ssg_set_intv(ix, (int)(code & 3), ik);
+	for (int k = 1; k < j; ++k) ik = ssg_bwt_extend1_lean(ix, ik, 3 - (int)((code >> (2 * k)) & 3), 0);
+	const ssg_intv_t e = ssg_unpk(tab[ssg_ktab_off(j) + code]);
+	if (ik.x2 != e.x2 || (ik.x2 && (ik.x0 != e.x0 || ik.x1 != e.x1))) atomicAdd(&bad[j], 1ull);
+}
 /* code of the n <= 15 bases from position b of a read held as 4-bit codes, 8 per LDS word (word w of the read at qw[w * stride]); no base of the window is ambiguous */
 SSG_DEVFN uint64_t ssg_smq_window(const uint32_t *qw, int stride, int b)
 {	/* the 16 codes from position b, 4 bits each, first base lowest */

@@ -114,7 +114,7 @@ static int densify_sa(ssg_index *ix)
 int ssg_index_build_ktab(ssg_index *ix)
 {
 	int lg = 0; while ((ix->v.seq_len >> (2 * (lg + 1))) != 0) ++lg;    /* floor(log4(seq_len)) */
-	int K = env_int("SSG_KTAB_K", std::min(13, lg - 2));
+	int K = env_int("SSG_KTAB_K", 0 * std::min(13, lg - 2));   /* opt-in (SSG_KTAB_K=13) until the MI355X run of its self-check is clean: emulation agrees with the oracle, the first GPU run did not */
 	if (K > 14) K = 14;
 	ix->v.ktab = 0; ix->v.ktab_k = 0;
 	if (K < 1 || ix->v.seq_len >= (1ull << 40)) return 0;
@@ -123,6 +123,15 @@ int ssg_index_build_ktab(ssg_index *ix)
 	if (!ix->ktab) { ssg_err_msg = "index allocation failed: k-mer interval table"; return SSG_ENOMEM; }
 	for (int j = 1; j <= K; ++j) { const long np = 1L << (2 * (j - 1)); SSG_LAUNCH(ssg_k_ktab_level, (np + 255) / 256, 256, 0, ix->v, j, (ssg_pk_t*)ix->ktab); }
 	CHK(rt_sync());
+	if (env_int("SSG_KTAB_VERIFY", 0)) {
+		dbuf<unsigned long long> d_bad(16); unsigned long long bad[16];
+		CHKA(d_bad); CHK(d_bad.zero());
+		for (int j = 1; j <= K; ++j) { const long np = 1L << (2 * j), stride = np > (1L << 22) ? np >> 22 : 1, nt = (np + stride - 1) / stride; SSG_LAUNCH(ssg_k_ktab_verify, (nt + 255) / 256, 256, 0, ix->v, j, stride, (const ssg_pk_t*)ix->ktab, d_bad.p); }
+		CHK(rt_sync()); CHK(d_bad.down(bad, 16));
+		fprintf(stderr, "[ssgpu] k-mer interval table K=%d, entries differing from forward extension per level:", K);
+		for (int j = 1; j <= K; ++j) fprintf(stderr, " %llu", bad[j]);
+		fprintf(stderr, "\n");
+	}
 	ix->v.ktab = ix->ktab; ix->v.ktab_k = K;
 	return 0;
 }

@@ -111,7 +111,7 @@ static int main_mem(int argc, char **argv)
 	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
 	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
 	/* the readers (inflate + parse) start now: the first batches are parsed while the index travels to the device(s) */
-	fq_feed_t feed1(fp1, keep_comment, 16384); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384) : 0);
+	fq_feed_t feed1(fp1, keep_comment, 16384, argv[ai + 1]); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2]) : 0);
 
 	/* One worker thread per visible device (SURVEY 8e coupling 1: whole upstream batches go to the GPUs, no collective): each loads its
 	 * own replica of the index and takes the next assembled batch when it is free; results are re-serialised in input order. */

@@ -19,8 +19,12 @@
 #include <condition_variable>
 #include <thread>
 #include <memory>
+#include <string>
 #include <atomic>
 #include <unistd.h>
+#include <fcntl.h>
+#include <errno.h>
+#include <sys/stat.h>
 
 template <class T> struct chan_t {      /* bounded single-producer / single-consumer channel */
 	std::mutex mu; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed;
@@ -47,11 +51,78 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	chan_t<std::unique_ptr<chunk_t> > full, empty; std::thread th;
 	std::atomic<bool> stop{false};
 	bool threaded;                      /* compressed input only: for a plain file the hand-over costs more than the read */
-	explicit fq_stream_t(gzFile f) : fp(f), begin(0), end(0), is_eof(false), full(4), empty(8)
+	bool bgzf;                          /* blocked gzip (bgzip, htslib bgzf.c:298-342): independent <= 64 KB members with their size in the header, inflated by several threads */
+	/* BGZF member at p (n bytes available): its total size, or 0 when p does not start one */
+	static size_t bgzf_member(const unsigned char *p, size_t n)
+	{
+		if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+		const size_t xlen = p[10] | (size_t)p[11] << 8;
+		if (n < 12 + xlen) return 0;
+		for (size_t o = 12; o + 4 <= 12 + xlen; ) { const size_t sl = p[o + 2] | (size_t)p[o + 3] << 8; if (p[o] == 'B' && p[o + 1] == 'C' && sl == 2) return (size_t)(p[o + 4] | (size_t)p[o + 5] << 8) + 1; o += 4 + sl; }
+		return 0;
+	}
+	void bgzf_loop(int fd, int n_threads)
+	{	/* batches of members: located by their headers, inflated in parallel, handed to the parser in file order */
+		std::vector<unsigned char> raw; size_t pos = 0; bool eof = false;
+		while (!stop.load()) {
+			if (pos > ((size_t)8 << 20)) { raw.erase(raw.begin(), raw.begin() + (long)pos); pos = 0; }
+			while (!eof && raw.size() - pos < ((size_t)24 << 20)) {
+				const size_t old = raw.size(); raw.resize(old + ((size_t)8 << 20));
+				ssize_t r = read(fd, raw.data() + old, (size_t)8 << 20);
+				if (r < 0) { if (errno == EINTR) { raw.resize(old); continue; } r = 0; }
+				raw.resize(old + (size_t)r);
+				if (r == 0) eof = true;
+			}
+			struct span_t { size_t off, len, isz, out; };
+			std::vector<span_t> sp; size_t total = 0, q = pos;
+			while (sp.size() < 512) {
+				const size_t m = bgzf_member(raw.data() + q, raw.size() - q);
+				if (!m || q + m > raw.size()) break;
+				span_t x; x.off = q; x.len = m; x.isz = raw[q + m - 4] | (size_t)raw[q + m - 3] << 8 | (size_t)raw[q + m - 2] << 16 | (size_t)raw[q + m - 1] << 24; x.out = total;
+				total += x.isz; q += m; sp.push_back(x);
+			}
+			if (sp.empty()) break;                               /* end of file (or a trailing fragment that is not a member) */
+			pos = q;
+			std::unique_ptr<chunk_t> c(new chunk_t(total));
+			std::atomic<size_t> next(0); std::atomic<int> bad(0);
+			auto work = [&]() {
+				for (;;) {
+					const size_t k = next.fetch_add(1);
+					if (k >= sp.size()) break;
+					if (!sp[k].isz) continue;
+					const unsigned char *h = raw.data() + sp[k].off; const size_t xlen = h[10] | (size_t)h[11] << 8;
+					z_stream zs; memset(&zs, 0, sizeof(zs));
+					zs.next_in = (Bytef*)(h + 12 + xlen); zs.avail_in = (uInt)(sp[k].len - 12 - xlen - 8); zs.next_out = c->data() + sp[k].out; zs.avail_out = (uInt)sp[k].isz;
+					if (inflateInit2(&zs, -15) != Z_OK || inflate(&zs, Z_FINISH) != Z_STREAM_END) bad = 1;
+					inflateEnd(&zs);
+				}
+			};
+			std::vector<std::thread> w;
+			for (int t = 1; t < n_threads; ++t) w.emplace_back(work);
+			work();
+			for (auto &x : w) x.join();
+			if (bad) break;                                      /* the parser sees a truncated stream and reports it */
+			if (total) full.push(std::move(c));
+		}
+		full.close();
+	}
+	explicit fq_stream_t(gzFile f, const char *path = 0) : fp(f), begin(0), end(0), is_eof(false), full(4), empty(8), bgzf(false)
 	{
 		gzbuffer(fp, 1 << 20);
 		threaded = !gzdirect(fp);
 		if (!threaded) { buf.resize((size_t)1 << 20); return; }
+		if (path) {
+			struct stat sb;
+			const int fd = (stat(path, &sb) == 0 && S_ISREG(sb.st_mode)) ? open(path, O_RDONLY) : -1;   /* a pipe must not lose bytes to this look */
+			unsigned char h[18];
+			if (fd >= 0 && read(fd, h, 18) == 18 && bgzf_member(h, 18) && lseek(fd, 0, SEEK_SET) == 0) {
+				bgzf = true;
+				int nt = 8; { const char *e = getenv("SSG_BGZF_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
+				th = std::thread([this, fd, nt]() { bgzf_loop(fd, nt); close(fd); });
+				return;
+			}
+			if (fd >= 0) close(fd);
+		}
 		th = std::thread([this]() {
 			while (!stop.load()) {
 				std::unique_ptr<chunk_t> c;
@@ -109,7 +180,7 @@ static inline uint8_t fq_nt4(int c) { return fq_nt4_tab()[(unsigned char)c]; }
 
 struct fq_reader_t {
 	fq_stream_t ks; int last_char; bool keep_comment;
-	fq_reader_t(gzFile f, bool kc) : ks(f), last_char(0), keep_comment(kc) {}
+	fq_reader_t(gzFile f, bool kc, const char *path = 0) : ks(f, path), last_char(0), keep_comment(kc) {}
 	/* kseq_read + kseq2bseq1 + trim_readno into block b; >= 0 length, -1 EOF, -2 truncated quality */
 	int next(fq_block_t &b)
 	{
@@ -168,10 +239,11 @@ struct fq_block_pool_t {                /* blocks go back to the reader when the
 struct fq_feed_t {
 	chan_t<std::shared_ptr<fq_block_t> > ch; std::thread th;   /* shared: a batch keeps the blocks its names and qualities point into */
 	std::shared_ptr<fq_block_pool_t> pool;
-	fq_feed_t(gzFile fp, bool keep_comment, int per_block) : ch(4), pool(new fq_block_pool_t())
+	fq_feed_t(gzFile fp, bool keep_comment, int per_block, const char *path = 0) : ch(4), pool(new fq_block_pool_t())
 	{
-		th = std::thread([this, fp, keep_comment, per_block]() {
-			fq_reader_t rd(fp, keep_comment);
+		const std::string pth(path ? path : "");
+		th = std::thread([this, fp, keep_comment, per_block, pth]() {
+			fq_reader_t rd(fp, keep_comment, pth.empty() ? 0 : pth.c_str());
 			for (;;) {
 				std::shared_ptr<fq_block_pool_t> pl = pool;
 				std::shared_ptr<fq_block_t> b(pl->get(), [pl](fq_block_t *x) { pl->put(x); });

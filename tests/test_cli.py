@@ -153,3 +153,26 @@ def test_cli_emu_samblaster_option_sets(tmp_path, emu_lib, opts):
         res.append((_no_pg(p.stdout.decode()), _no_pg(open(spl).read()), _no_pg(open(disc).read())))
     assert res[0] == res[1]
     assert res[0][2].count("\n") > 5 and (res[0][1].count("\n") > 5 or "1" in opts[opts.index("--maxSplitCount") + 1:][:1])   # one piece per read can never be a split
+
+
+def test_cli_emu_bgzf_fastq_input(tmp_path, emu_lib):
+    """blocked gzip (bgzip) FASTQ: members located by their headers and inflated by several threads (fastq.h bgzf_loop) -- same SAM as the plain file"""
+    import struct
+    import zlib
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 300, seed=21)
+    fq = str(tmp_path / "r.fq")
+    simreads.write_fastq(fq, pairs)
+    data = open(fq, "rb").read()
+    out = b""
+    for o in range(0, len(data), 7001):                      # many small members, cut in the middle of records
+        c = data[o:o + 7001]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = co.compress(c) + co.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(c), len(c))
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    open(fq + ".gz", "wb").write(out)
+    exe = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    a = subprocess.run([exe, "mem", "-p", EXAMPLE_FA, fq], capture_output=True, env=dict(os.environ, SSG_BGZF_THREADS="3"))
+    b = subprocess.run([exe, "mem", "-p", EXAMPLE_FA, fq + ".gz"], capture_output=True, env=dict(os.environ, SSG_BGZF_THREADS="3"))
+    strip = lambda x: [l for l in x.split(b"\n") if not l.startswith(b"@PG")]
+    assert a.returncode == 0 and b.returncode == 0 and strip(a.stdout) == strip(b.stdout) and len(a.stdout) > 100000
