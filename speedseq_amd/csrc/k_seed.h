@@ -217,6 +217,19 @@ __global__ void ssg_k_ktab_level(ssg_index_view_t ix, int j, ssg_pk_t *tab)
 	else ssg_bwt_extend(ix, ssg_unpk(tab[ssg_ktab_off(j - 1) + p]), ok, 1);
 	for (int c = 0; c < 4; ++c) { ok[c].info = 0; out[c] = ssg_pk(ok[c]); }
 }
+/* the same level from level j - 1 by one-base RIGHT extensions with the seeding kernel's own ssg_bwt_extend1_lean (SSG_KTAB_BUILD=fwd):
+ * pattern p of j - 1 bases followed by base c is entry p + c * 4^(j-1) */
+__global__ void ssg_k_ktab_level_fwd(ssg_index_view_t ix, int j, ssg_pk_t *tab)
+{
+	const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, np = 1L << (2 * (j - 1));
+	if (t >= 4 * np) return;
+	const long p = t % np; const int c = (int)(t / np);
+	ssg_intv_t o;
+	if (j == 1) ssg_set_intv(ix, c, o);
+	else o = ssg_bwt_extend1_lean(ix, ssg_unpk(tab[ssg_ktab_off(j - 1) + p]), 3 - c, 0);
+	o.info = 0;
+	tab[ssg_ktab_off(j) + p + (long)c * np] = ssg_pk(o);
+}
 /* self-check of the table (SSG_KTAB_VERIFY=1): every `stride`-th pattern of level j once more, this time the way the seeding kernel
  * would have reached it without the table -- from its first base by forward extensions (ssg_bwt_extend1_lean) -- and compared */
 __global__ void ssg_k_ktab_verify(ssg_index_view_t ix, int j, long stride, const ssg_pk_t *tab, unsigned long long *bad)
@@ -254,7 +267,9 @@ SSG_DEVFN uint32_t ssg_smq_code(const uint32_t *qw, int stride, int b, int n)
 #endif
 /* LPR = lanes per read: 4 (cooperative rank-block fetch) or 1 (each lane fetches whole blocks; 4x fewer wave instructions per read,
  * 4x more translation work per line -- see tools/dbg/gather_probe.cpp for where that starts to matter) */
-template <int LPR>
+/* KT = use the table of short-pattern intervals (ssg_index_view_t.ktab): an extension whose result pattern has at most ktab_k bases is one
+ * 16-byte load, and the third pass starts ktab_k bases in.  KT = false compiles none of it (the kernel of rounds 1-2, unchanged). */
+template <int LPR, bool KT = false>
 __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
@@ -289,22 +304,23 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
 #define SM_DO_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ssg_pk(ik); state = SM_BWD; } while (0)
 /* next start position of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
-/* With the table of short-pattern intervals the first ktab_k - 1 extensions of a start collapse into one look-up: upstream records nothing
- * before the pattern has min_seed_len (> ktab_k) bases, so only an ambiguous base or the read's end inside the window matters -- the
- * start then moves past it exactly as upstream's loop returns (the skipped bwt_extend calls still count as algorithmic work). */
-#define SM_DO_P3() do { for (;;) { \
+/* With the table (KT) the first ktab_k - 1 extensions of a start collapse into one look-up: upstream records nothing before the pattern has
+ * min_seed_len (> ktab_k) bases, so only an ambiguous base or the read's end inside the window matters -- the start then moves past it
+ * exactly as upstream's loop returns, one window per trip (state SM_P3 comes back here); the skipped bwt_extend calls still count as
+ * algorithmic work. */
+#define SM_DO_P3() do { \
 		while (x < len && SMQ(x) > 3) ++x; \
-		if (x >= len) { state = SM_OUT; break; } \
-		const int kk_ = ix.ktab_k; \
-		if (kk_ < 2 || kk_ >= opt.min_seed_len) { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; break; } \
-		const unsigned long long nm_ = ssg_smq_window(ql_, RPW, x) & 0x4444444444444444ull; \
-		int run_ = nm_ ? (__ffsll((unsigned long long)nm_) - 1) >> 2 : 16; \
-		if (run_ > len - x) run_ = len - x; \
-		if (run_ >= kk_) { ik = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(kk_) + (long)ssg_smq_code(ql_, RPW, x, kk_)]); i = x + kk_; my_nx += (unsigned long long)(kk_ - 1); state = SM_P3F; break; } \
-		my_nx += (unsigned long long)(run_ - 1); \
-		if (x + run_ >= len) { x = len; state = SM_OUT; break; } \
-		x += run_ + 1; \
-	} } while (0)
+		if (x >= len) state = SM_OUT; \
+		else if (!KT || ix.ktab_k < 2 || ix.ktab_k >= opt.min_seed_len) { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } \
+		else { \
+			const int kk_ = ix.ktab_k; \
+			const unsigned long long nm_ = ssg_smq_window(ql_, RPW, x) & 0x4444444444444444ull; \
+			int run_ = nm_ ? (int)((__ffsll((unsigned long long)nm_) - 1) >> 2) : 16; \
+			run_ = run_ > len - x ? len - x : run_; \
+			if (run_ >= kk_) { ik = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(kk_) + (long)ssg_smq_code(ql_, RPW, x, kk_)]); i = x + kk_; my_nx += (unsigned long long)(kk_ - 1); state = SM_P3F; } \
+			else { my_nx += (unsigned long long)(run_ - 1); if (x + run_ >= len) { x = len; state = SM_OUT; } else { x += run_ + 1; state = SM_P3; } } \
+		} \
+	} while (0)
 #define SM_DO_RET() do { if (caller == 1) { x = ret; state = SM_P1; } else { ++k; state = SM_P2; } } while (0)
 	unsigned long long tn_adv = 0, tn_ext = 0, tn_rounds = 0, tn_ready = 0, tn_alive = 0, tn_t0 = 0;   /* SSG_TUNING only: cycles in the state machine / at the extension site, rounds, ready and live lanes per round */
 	const unsigned long long tn_wall0 = SSG_TUNING ? ssg_wall() : 0;                                   /* ... and how long each lane had work (the read pool runs dry before the last reads finish) */
@@ -425,7 +441,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 		/* the pattern the extension ends with: [i, end of p) going left, [start, i] going right; up to ktab_k bases its interval is in the table */
 		const int pat_b = back ? i : pend == SM_PEND_FWD ? sx : x, pat_n = (back ? (int)p.info : i + 1) - pat_b;
 		ssg_intv_t okc;
-		if (pat_n <= ix.ktab_k) okc = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
+		if (KT && pat_n <= ix.ktab_k) okc = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
 		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
 		++my_nx;
 		{
@@ -572,5 +588,14 @@ __global__ void ssg_k_sa_densify_walk(ssg_index_view_t ix, int new_intv, uint64_
 			else if ((r & nmask) == 0) sa_new[r >> nshift] = v;
 		}
 	}
+}
+/* self-check of the denser table (SSG_SA_VERIFY=1): every `stride`-th entry against upstream's own bwt_sa walk on the file's samples */
+__global__ void ssg_k_sa_verify(ssg_index_view_t ix, int new_intv, const uint64_t *sa_new, long n_new, long stride, unsigned long long *bad)
+{
+	const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+	if (j >= n_new) return;
+	const uint64_t r = (uint64_t)j * (uint64_t)new_intv;
+	const uint64_t want = (r % (uint64_t)ix.sa_intv) == 0 ? ix.sa[r / (uint64_t)ix.sa_intv] : ssg_bwt_sa(ix, r);
+	if (sa_new[j] != want) atomicAdd(bad, 1ull);
 }
 #endif

@@ -104,6 +104,14 @@ static int densify_sa(ssg_index *ix)
 	const long n_wg = std::min<long>((long)((n_old + 255) / 256), 256L * env_int("SSG_DENSIFY_WG_PER_CU", 8));   /* persistent: lanes refill from the counter */
 	SSG_LAUNCH(ssg_k_sa_densify_walk, n_wg, 256, 0, ix->v, want, d, n_old, d_next.p);
 	CHK(rt_sync());
+	if (env_int("SSG_SA_VERIFY", 0)) {
+		const long stride = n_new > (1L << 24) ? n_new >> 24 : 1, nt = (n_new + stride - 1) / stride;
+		unsigned long long bad = 0;
+		CHK(d_next.zero());
+		SSG_LAUNCH(ssg_k_sa_verify, (nt + 255) / 256, 256, 0, ix->v, want, (const uint64_t*)d, n_new, stride, d_next.p);
+		CHK(rt_sync()); CHK(d_next.down(&bad, 1));
+		fprintf(stderr, "[ssgpu] SA samples every %d rows: %llu of %ld checked entries differ from bwt_sa on the file's samples\n", want, bad, nt);
+	}
 	rt_free(ix->sa);   /* the lower-density copy, when this index owns it */
 	ix->sa = d; ix->v.sa = d; ix->v.sa_intv = want;
 	return 0;
@@ -121,7 +129,12 @@ int ssg_index_build_ktab(ssg_index *ix)
 	const size_t n_ent = (size_t)((((1ull << (2 * (K + 1))) - 4ull) / 3ull));
 	ix->ktab = (uint64_t*)rt_malloc(n_ent * 16);
 	if (!ix->ktab) { ssg_err_msg = "index allocation failed: k-mer interval table"; return SSG_ENOMEM; }
-	for (int j = 1; j <= K; ++j) { const long np = 1L << (2 * (j - 1)); SSG_LAUNCH(ssg_k_ktab_level, (np + 255) / 256, 256, 0, ix->v, j, (ssg_pk_t*)ix->ktab); }
+	const bool fwd = getenv("SSG_KTAB_BUILD") && !strcmp(getenv("SSG_KTAB_BUILD"), "fwd");
+	for (int j = 1; j <= K; ++j) {
+		const long np = 1L << (2 * (j - 1));
+		if (fwd) SSG_LAUNCH(ssg_k_ktab_level_fwd, (4 * np + 255) / 256, 256, 0, ix->v, j, (ssg_pk_t*)ix->ktab);
+		else SSG_LAUNCH(ssg_k_ktab_level, (np + 255) / 256, 256, 0, ix->v, j, (ssg_pk_t*)ix->ktab);
+	}
 	CHK(rt_sync());
 	if (env_int("SSG_KTAB_VERIFY", 0)) {
 		dbuf<unsigned long long> d_bad(16); unsigned long long bad[16];
@@ -437,6 +450,7 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	dbuf<unsigned int> d_nextread(1);
 	CHKA(d_nextread); CHK(d_nextread.zero());
 	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0);
+	else if (quad && idx->v.ktab_k > 0) SSG_LAUNCH((ssg_k_smem_quad<1, true>), nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p);
 	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
