@@ -202,7 +202,7 @@ SSG_DEVFN ssg_pk_t ssg_pk(const ssg_intv_t &v)
 SSG_DEVFN ssg_intv_t ssg_unpk(const ssg_pk_t &p)
 { ssg_intv_t v; v.x0 = p.w0 & 0xffffffffffull; v.x1 = (p.w0 >> 40) | (p.w1 & 0xffffull) << 24; v.x2 = (p.w1 >> 16) & 0xffffffffffull; v.info = p.w1 >> 56; return v; }
 
-/* ---- table of short-pattern intervals (ssg_index_view_t.ktab) ---- */
+/* ---- table of short-pattern intervals (ssg_index.ktab) ---- */
 SSG_DEVFN long ssg_ktab_off(int j) { return (long)(((1ull << (2 * j)) - 4ull) / 3ull); }   /* entries of the levels below j */
 /* level j from level j - 1: the four one-base left extensions of every pattern, by upstream's own bwt_extend (is_back = 1), so an
  * entry is bit for bit what the extension it stands in for returns (the interval of a pattern does not depend on the order in
@@ -267,13 +267,13 @@ SSG_DEVFN uint32_t ssg_smq_code(const uint32_t *qw, int stride, int b, int n)
 #endif
 /* LPR = lanes per read: 4 (cooperative rank-block fetch) or 1 (each lane fetches whole blocks; 4x fewer wave instructions per read,
  * 4x more translation work per line -- see tools/dbg/gather_probe.cpp for where that starts to matter) */
-/* KT = use the table of short-pattern intervals (ssg_index_view_t.ktab): an extension whose result pattern has at most ktab_k bases is one
+/* KT = use the table of short-pattern intervals (kt_tab, kt_k): an extension whose result pattern has at most kt_k bases is one
  * 16-byte load, and the third pass starts ktab_k bases in.  KT = false compiles none of it (the kernel of rounds 1-2, unchanged). */
 template <int LPR, bool KT = false>
 __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read)
+                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, const ssg_pk_t *kt_tab, int kt_k)
 {
 	constexpr int RPW = 64 / LPR;   /* reads per wave */
 	__shared__ uint32_t qlds[SSG_SM_QWORDS * RPW];
@@ -304,20 +304,20 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
 #define SM_DO_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ssg_pk(ik); state = SM_BWD; } while (0)
 /* next start position of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
-/* With the table (KT) the first ktab_k - 1 extensions of a start collapse into one look-up: upstream records nothing before the pattern has
- * min_seed_len (> ktab_k) bases, so only an ambiguous base or the read's end inside the window matters -- the start then moves past it
+/* With the table (KT) the first kt_k - 1 extensions of a start collapse into one look-up: upstream records nothing before the pattern has
+ * min_seed_len (> kt_k) bases, so only an ambiguous base or the read's end inside the window matters -- the start then moves past it
  * exactly as upstream's loop returns, one window per trip (state SM_P3 comes back here); the skipped bwt_extend calls still count as
  * algorithmic work. */
 #define SM_DO_P3() do { \
 		while (x < len && SMQ(x) > 3) ++x; \
 		if (x >= len) state = SM_OUT; \
-		else if (!KT || ix.ktab_k < 2 || ix.ktab_k >= opt.min_seed_len) { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } \
+		else if (!KT || kt_k < 2 || kt_k >= opt.min_seed_len) { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } \
 		else { \
-			const int kk_ = ix.ktab_k; \
+			const int kk_ = kt_k; \
 			const unsigned long long nm_ = ssg_smq_window(ql_, RPW, x) & 0x4444444444444444ull; \
 			int run_ = nm_ ? (int)((__ffsll((unsigned long long)nm_) - 1) >> 2) : 16; \
 			run_ = run_ > len - x ? len - x : run_; \
-			if (run_ >= kk_) { ik = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(kk_) + (long)ssg_smq_code(ql_, RPW, x, kk_)]); i = x + kk_; my_nx += (unsigned long long)(kk_ - 1); state = SM_P3F; } \
+			if (run_ >= kk_) { ik = ssg_unpk(kt_tab[ssg_ktab_off(kk_) + (long)ssg_smq_code(ql_, RPW, x, kk_)]); i = x + kk_; my_nx += (unsigned long long)(kk_ - 1); state = SM_P3F; } \
 			else { my_nx += (unsigned long long)(run_ - 1); if (x + run_ >= len) { x = len; state = SM_OUT; } else { x += run_ + 1; state = SM_P3; } } \
 		} \
 	} while (0)
@@ -438,10 +438,10 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 		const int jn = back && j + 1 < prev_n ? j + 1 : 0;
 		ssg_pk_t pf; pf.w0 = pf.w1 = 0;
 		if (jn) pf = SMV(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
-		/* the pattern the extension ends with: [i, end of p) going left, [start, i] going right; up to ktab_k bases its interval is in the table */
+		/* the pattern the extension ends with: [i, end of p) going left, [start, i] going right; up to kt_k bases its interval is in the table */
 		const int pat_b = back ? i : pend == SM_PEND_FWD ? sx : x, pat_n = (back ? (int)p.info : i + 1) - pat_b;
 		ssg_intv_t okc;
-		if (KT && pat_n <= ix.ktab_k) okc = ssg_unpk(((const ssg_pk_t*)ix.ktab)[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
+		if (KT && pat_n <= kt_k) okc = ssg_unpk(kt_tab[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
 		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
 		++my_nx;
 		{

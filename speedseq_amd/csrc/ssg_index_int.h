@@ -13,14 +13,18 @@ struct ssg_hole_t { int64_t offset; int32_t len; char amb; };   /* upstream bnta
 struct ssg_index {
 	ssg_index_view_t v;
 	/* owned device arrays (NULL when borrowed from the caller, ssg_index_from_device) */
-	uint32_t *bwt; uint64_t *sa; uint8_t *pac; int64_t *ctg_off; int32_t *ctg_len; uint64_t *ktab;
+	uint32_t *bwt; uint64_t *sa; uint8_t *pac; int64_t *ctg_off; int32_t *ctg_len;
+	/* optional (SSG_KTAB_K): bidirectional intervals of every pattern of 1..ktab_k bases, 16 bytes each (x0, x1, x2 in 40 bits), level j (4^j
+	 * entries, little-endian base-4 pattern code) after the levels below it; handed to the seeding kernel's table instance as its own
+	 * arguments -- the by-value view every kernel takes stays as it was in rounds 1-2 */
+	uint64_t *ktab; int ktab_k;
 	uint64_t bwt_words;                     /* u32 words of the .bwt body (0 when borrowed) */
 	bool raw_alloc;                         /* bwt/sa/pac came from rt_malloc_raw (index builder) */
 	std::vector<std::string> names, annos;  /* .ann: name and FASTA comment ("" = upstream's "(null)") */
 	std::vector<int32_t> n_ambs;            /* .ann: holes per contig */
 	std::vector<ssg_hole_t> holes;          /* .amb */
 	std::vector<int64_t> h_off; std::vector<int32_t> h_len;
-	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), ktab(0), bwt_words(0), raw_alloc(false) { memset(&v, 0, sizeof(v)); }
+	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), ktab(0), ktab_k(0), bwt_words(0), raw_alloc(false) { memset(&v, 0, sizeof(v)); }
 };
 /* fills v.ktab (ssgpu_core.cpp); every constructor of an index ends with it */
 extern "C" int ssg_index_build_ktab(ssg_index *ix);

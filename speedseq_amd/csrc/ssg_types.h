@@ -35,11 +35,6 @@ typedef struct {
 	uint64_t primary, L2[5], seq_len;
 	int64_t l_pac;
 	int32_t n_ctg, sa_intv;
-	/* device; bidirectional intervals of every pattern of 1..ktab_k bases, 16 bytes each (x0, x1, x2 in 40 bits), level j (4^j
-	 * entries, little-endian base-4 pattern code) after the levels below it; NULL / 0 = none.  A bwt_extend whose result pattern
-	 * is that short is one 16-byte load instead of two rank blocks (k_seed.h). */
-	const uint64_t *ktab;
-	int32_t ktab_k, _pad;
 } ssg_index_view_t;
 
 typedef struct { uint64_t x0, x1, x2, info; } ssg_intv_t;          /* upstream bwtintv_t */

@@ -117,14 +117,14 @@ static int densify_sa(ssg_index *ix)
 	return 0;
 }
 
-/* table of the intervals of all patterns up to K bases (ssg_index_view_t.ktab, k_seed.h): K = SSG_KTAB_K, by default 13 capped at
+/* table of the intervals of all patterns up to K bases (ssg_index.ktab, k_seed.h): K = SSG_KTAB_K, by default 13 capped at
  * log4(text length) - 2 (1.4 GB for a human-size index; built level by level with upstream's bwt_extend, ~90 M extensions) */
 int ssg_index_build_ktab(ssg_index *ix)
 {
 	int lg = 0; while ((ix->v.seq_len >> (2 * (lg + 1))) != 0) ++lg;    /* floor(log4(seq_len)) */
 	int K = env_int("SSG_KTAB_K", 0 * std::min(13, lg - 2));   /* opt-in (SSG_KTAB_K=13) until the MI355X run of its self-check is clean: emulation agrees with the oracle, the first GPU run did not */
 	if (K > 14) K = 14;
-	ix->v.ktab = 0; ix->v.ktab_k = 0;
+	rt_free(ix->ktab); ix->ktab = 0; ix->ktab_k = 0;
 	if (K < 1 || ix->v.seq_len >= (1ull << 40)) return 0;
 	const size_t n_ent = (size_t)((((1ull << (2 * (K + 1))) - 4ull) / 3ull));
 	ix->ktab = (uint64_t*)rt_malloc(n_ent * 16);
@@ -145,7 +145,7 @@ int ssg_index_build_ktab(ssg_index *ix)
 		for (int j = 1; j <= K; ++j) fprintf(stderr, " %llu", bad[j]);
 		fprintf(stderr, "\n");
 	}
-	ix->v.ktab = ix->ktab; ix->v.ktab_k = K;
+	ix->ktab_k = K;
 	return 0;
 }
 
@@ -449,9 +449,9 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	CHKA(scratch);
 	dbuf<unsigned int> d_nextread(1);
 	CHKA(d_nextread); CHK(d_nextread.zero());
-	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0);
-	else if (quad && idx->v.ktab_k > 0) SSG_LAUNCH((ssg_k_smem_quad<1, true>), nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p);
-	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p);
+	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0, (const ssg_pk_t*)0, 0);
+	else if (quad && idx->ktab_k > 0) SSG_LAUNCH((ssg_k_smem_quad<1, true>), nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p, (const ssg_pk_t*)idx->ktab, idx->ktab_k);
+	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p, (const ssg_pk_t*)0, 0);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));
