@@ -15,16 +15,18 @@ $(CSRC)/ssg_index_build.o: $(CSRC)/ssg_index_build.cpp $(CSRC)/k_index.h $(CSRC)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 $(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp include/ssgpu.h $(CSRC)/ssg_types.h
 	$(CXX) -O2 -std=c++17 -fPIC -c $< -o $@
-LIBOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o
+$(CSRC)/ssg_ktab.o: $(CSRC)/ssg_ktab.cpp $(CSRC)/k_seed_kt.h $(CSRC)/ssg_dev.h $(CSRC)/ssg_rt.h $(CSRC)/ssg_types.h $(CSRC)/ssg_index_int.h include/ssgpu.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+LIBOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o
 speedseq_amd/libssgpu.so: $(LIBOBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(LIBOBJS) -o $@ -lz
 
 # instrumented build (device phase counters, tools/dbg/phase.py); never the default library
 tune: speedseq_amd/libssgpu_tune.so
-speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.cpp $(KHDRS)
+speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.cpp $(KHDRS)
 	$(HIPCC) $(HIPFLAGS) -DSSG_TUNE -DSSG_C2A_WAVES_PER_SIMD=2 -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_tune.o
 	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o -o $@ -lz
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o -o $@ -lz
 
 # bench utility: synthetic reference generator (one kernel launch)
 synth: tools/synth/libsynthref.so
@@ -58,9 +60,9 @@ oracle:
 
 # host emulation of the HIP execution model: same kernel + host sources, CPU-side tests only
 emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu
-tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
+tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_ktab.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
-		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
+		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_ktab.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
 tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOST)/fastq.h $(HOST)/fused.h include/ssgpu.h tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h $(HOST)/fused.h include/ssgpu.h tests/emu/libssgpu_emu.so
@@ -75,6 +77,6 @@ clean:
 .PHONY: all lib tools oracle emu clean
 
 # A/B builds of the device library with other compile-time parameters (bench: SSGPU_LIB=speedseq_amd/libssgpu_$(NAME).so); never the default
-variant: $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o
+variant: $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o
 	$(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_$(NAME).o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_$(NAME).o $(CSRC)/ssg_index_build.o $(CSRC)/sam_format.o -o speedseq_amd/libssgpu_$(NAME).so -lz
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_$(NAME).o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o -o speedseq_amd/libssgpu_$(NAME).so -lz

@@ -202,63 +202,6 @@ SSG_DEVFN ssg_pk_t ssg_pk(const ssg_intv_t &v)
 SSG_DEVFN ssg_intv_t ssg_unpk(const ssg_pk_t &p)
 { ssg_intv_t v; v.x0 = p.w0 & 0xffffffffffull; v.x1 = (p.w0 >> 40) | (p.w1 & 0xffffull) << 24; v.x2 = (p.w1 >> 16) & 0xffffffffffull; v.info = p.w1 >> 56; return v; }
 
-/* ---- table of short-pattern intervals (ssg_index.ktab) ---- */
-SSG_DEVFN long ssg_ktab_off(int j) { return (long)(((1ull << (2 * j)) - 4ull) / 3ull); }   /* entries of the levels below j */
-/* level j from level j - 1: the four one-base left extensions of every pattern, by upstream's own bwt_extend (is_back = 1), so an
- * entry is bit for bit what the extension it stands in for returns (the interval of a pattern does not depend on the order in
- * which it was extended to).  Pattern code: little-endian base 4 (first base least significant): children of p are 4p .. 4p + 3. */
-__global__ void ssg_k_ktab_level(ssg_index_view_t ix, int j, ssg_pk_t *tab)
-{
-	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= (1L << (2 * (j - 1)))) return;
-	ssg_pk_t *const out = tab + ssg_ktab_off(j) + 4 * p;
-	ssg_intv_t ok[4];
-	if (j == 1) { for (int c = 0; c < 4; ++c) ssg_set_intv(ix, c, ok[c]); }
-	else ssg_bwt_extend(ix, ssg_unpk(tab[ssg_ktab_off(j - 1) + p]), ok, 1);
-	for (int c = 0; c < 4; ++c) { ok[c].info = 0; out[c] = ssg_pk(ok[c]); }
-}
-/* the same level from level j - 1 by one-base RIGHT extensions with the seeding kernel's own ssg_bwt_extend1_lean (SSG_KTAB_BUILD=fwd):
- * pattern p of j - 1 bases followed by base c is entry p + c * 4^(j-1) */
-__global__ void ssg_k_ktab_level_fwd(ssg_index_view_t ix, int j, ssg_pk_t *tab)
-{
-	const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, np = 1L << (2 * (j - 1));
-	if (t >= 4 * np) return;
-	const long p = t % np; const int c = (int)(t / np);
-	ssg_intv_t o;
-	if (j == 1) ssg_set_intv(ix, c, o);
-	else o = ssg_bwt_extend1_lean(ix, ssg_unpk(tab[ssg_ktab_off(j - 1) + p]), 3 - c, 0);
-	o.info = 0;
-	tab[ssg_ktab_off(j) + p + (long)c * np] = ssg_pk(o);
-}
-/* self-check of the table (SSG_KTAB_VERIFY=1): every `stride`-th pattern of level j once more, this time the way the seeding kernel
- * would have reached it without the table -- from its first base by forward extensions (ssg_bwt_extend1_lean) -- and compared */
-__global__ void ssg_k_ktab_verify(ssg_index_view_t ix, int j, long stride, const ssg_pk_t *tab, unsigned long long *bad)
-{
-	const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, code = t * stride;
-	if (code >= (1L << (2 * j))) return;
-	ssg_intv_t ik;
-	ssg_set_intv(ix, (int)(code & 3), ik);
-	for (int k = 1; k < j; ++k) ik = ssg_bwt_extend1_lean(ix, ik, 3 - (int)((code >> (2 * k)) & 3), 0);
-	const ssg_intv_t e = ssg_unpk(tab[ssg_ktab_off(j) + code]);
-	if (ik.x2 != e.x2 || (ik.x2 && (ik.x0 != e.x0 || ik.x1 != e.x1))) atomicAdd(&bad[j], 1ull);
-}
-/* code of the n <= 15 bases from position b of a read held as 4-bit codes, 8 per LDS word (word w of the read at qw[w * stride]); no base of the window is ambiguous */
-SSG_DEVFN uint64_t ssg_smq_window(const uint32_t *qw, int stride, int b)
-{	/* the 16 codes from position b, 4 bits each, first base lowest */
-	const int w0 = b >> 3, sh = (b & 7) << 2;
-	const int w1 = w0 + 1 < SSG_SM_QWORDS ? w0 + 1 : SSG_SM_QWORDS - 1, w2 = w0 + 2 < SSG_SM_QWORDS ? w0 + 2 : SSG_SM_QWORDS - 1;
-	uint64_t v = ((uint64_t)qw[w0 * stride] | (uint64_t)qw[w1 * stride] << 32) >> sh;
-	if (sh) v |= (uint64_t)qw[w2 * stride] << (64 - sh);
-	return v;
-}
-SSG_DEVFN uint32_t ssg_smq_code(const uint32_t *qw, int stride, int b, int n)
-{
-	uint64_t v = ssg_smq_window(qw, stride, b);
-	v &= 0x3333333333333333ull; v = (v | v >> 2) & 0x0f0f0f0f0f0f0f0full; v = (v | v >> 4) & 0x00ff00ff00ff00ffull;
-	v = (v | v >> 8) & 0x0000ffff0000ffffull; v = (v | v >> 16) & 0xffffffffull;
-	return (uint32_t)v & ((1u << (2 * n)) - 1u);
-}
-
 #ifndef SSG_SMQ_WAVES
 #define SSG_SMQ_WAVES 4
 #endif
@@ -267,13 +210,11 @@ SSG_DEVFN uint32_t ssg_smq_code(const uint32_t *qw, int stride, int b, int n)
 #endif
 /* LPR = lanes per read: 4 (cooperative rank-block fetch) or 1 (each lane fetches whole blocks; 4x fewer wave instructions per read,
  * 4x more translation work per line -- see tools/dbg/gather_probe.cpp for where that starts to matter) */
-/* KT = use the table of short-pattern intervals (kt_tab, kt_k): an extension whose result pattern has at most kt_k bases is one
- * 16-byte load, and the third pass starts ktab_k bases in.  KT = false compiles none of it (the kernel of rounds 1-2, unchanged). */
-template <int LPR, bool KT = false>
+template <int LPR>
 __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, const ssg_pk_t *kt_tab, int kt_k)
+                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read)
 {
 	constexpr int RPW = 64 / LPR;   /* reads per wave */
 	__shared__ uint32_t qlds[SSG_SM_QWORDS * RPW];
@@ -304,26 +245,9 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
 #define SM_DO_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = ssg_pk(ik); state = SM_BWD; } while (0)
 /* next start position of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
-/* With the table (KT) the first kt_k - 1 extensions of a start collapse into one look-up: upstream records nothing before the pattern has
- * min_seed_len (> kt_k) bases, so only an ambiguous base or the read's end inside the window matters -- the start then moves past it
- * exactly as upstream's loop returns, one window per trip (state SM_P3 comes back here); the skipped bwt_extend calls still count as
- * algorithmic work. */
-#define SM_DO_P3() do { \
-		while (x < len && SMQ(x) > 3) ++x; \
-		if (x >= len) state = SM_OUT; \
-		else if (!KT || kt_k < 2 || kt_k >= opt.min_seed_len) { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } \
-		else { \
-			const int kk_ = kt_k; \
-			const unsigned long long nm_ = ssg_smq_window(ql_, RPW, x) & 0x4444444444444444ull; \
-			int run_ = nm_ ? (int)((__ffsll((unsigned long long)nm_) - 1) >> 2) : 16; \
-			run_ = run_ > len - x ? len - x : run_; \
-			if (run_ >= kk_) { ik = ssg_unpk(kt_tab[ssg_ktab_off(kk_) + (long)ssg_smq_code(ql_, RPW, x, kk_)]); i = x + kk_; my_nx += (unsigned long long)(kk_ - 1); state = SM_P3F; } \
-			else { my_nx += (unsigned long long)(run_ - 1); if (x + run_ >= len) { x = len; state = SM_OUT; } else { x += run_ + 1; state = SM_P3; } } \
-		} \
-	} while (0)
+#define SM_DO_P3() do { while (x < len && SMQ(x) > 3) ++x; if (x >= len) state = SM_OUT; else { ssg_set_intv(ix, SMQ(x), ik); i = x + 1; state = SM_P3F; } } while (0)
 #define SM_DO_RET() do { if (caller == 1) { x = ret; state = SM_P1; } else { ++k; state = SM_P2; } } while (0)
 	unsigned long long tn_adv = 0, tn_ext = 0, tn_rounds = 0, tn_ready = 0, tn_alive = 0, tn_t0 = 0;   /* SSG_TUNING only: cycles in the state machine / at the extension site, rounds, ready and live lanes per round */
-	const unsigned long long tn_wall0 = SSG_TUNING ? ssg_wall() : 0;                                   /* ... and how long each lane had work (the read pool runs dry before the last reads finish) */
 	for (;;) {
 		if (SSG_TUNING) tn_t0 = ssg_clock();
 		/* a bounded number of state-machine steps per extension round: a lane in the middle of a transition sits the round out instead of
@@ -426,10 +350,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 			}
 		}
 		if (SSG_TUNING) { const unsigned long long t1 = ssg_clock(); tn_adv += t1 - tn_t0; tn_t0 = t1; ++tn_rounds; tn_ready += (unsigned long long)__popcll(wv_ballot(pend != SM_PEND_NONE)); tn_alive += (unsigned long long)__popcll(wv_ballot(state != SM_FIN)); }
-		if (state == SM_FIN) {
-			if (SSG_TUNING) { const unsigned long long d = ssg_wall() - tn_wall0; atomicAdd(&ssg_dbg_cyc[29], d); atomicMax(&ssg_dbg_cyc[30], d); atomicAdd(&ssg_dbg_cyc[31], 1ull); }
-			break;
-		}
+		if (state == SM_FIN) break;
 		if (pend == SM_PEND_NONE) continue;
 		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
 		ssg_wave_ldssync();   /* list entries stored by lane 0 of the quad last iteration are read by all four below (same wave: in order on the GPU) */
@@ -438,11 +359,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_v
 		const int jn = back && j + 1 < prev_n ? j + 1 : 0;
 		ssg_pk_t pf; pf.w0 = pf.w1 = 0;
 		if (jn) pf = SMV(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
-		/* the pattern the extension ends with: [i, end of p) going left, [start, i] going right; up to kt_k bases its interval is in the table */
-		const int pat_b = back ? i : pend == SM_PEND_FWD ? sx : x, pat_n = (back ? (int)p.info : i + 1) - pat_b;
-		ssg_intv_t okc;
-		if (KT && pat_n <= kt_k) okc = ssg_unpk(kt_tab[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
-		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
+		const ssg_intv_t okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
 		++my_nx;
 		{
 			ssg_pk_t *const curr = flip ? vec1 : vec0;
@@ -588,14 +505,5 @@ __global__ void ssg_k_sa_densify_walk(ssg_index_view_t ix, int new_intv, uint64_
 			else if ((r & nmask) == 0) sa_new[r >> nshift] = v;
 		}
 	}
-}
-/* self-check of the denser table (SSG_SA_VERIFY=1): every `stride`-th entry against upstream's own bwt_sa walk on the file's samples */
-__global__ void ssg_k_sa_verify(ssg_index_view_t ix, int new_intv, const uint64_t *sa_new, long n_new, long stride, unsigned long long *bad)
-{
-	const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) * stride;
-	if (j >= n_new) return;
-	const uint64_t r = (uint64_t)j * (uint64_t)new_intv;
-	const uint64_t want = (r % (uint64_t)ix.sa_intv) == 0 ? ix.sa[r / (uint64_t)ix.sa_intv] : ssg_bwt_sa(ix, r);
-	if (sa_new[j] != want) atomicAdd(bad, 1ull);
 }
 #endif

@@ -34,17 +34,14 @@ SSG_DEVFN unsigned long long wv_ballot(int p) { return __ballot(p); }
 static unsigned long long ssg_dbg_cyc[32];
 #define SSG_TUNING 0
 SSG_DEVFN unsigned long long ssg_clock() { return 0; }
-SSG_DEVFN unsigned long long ssg_wall() { return 0; }
 #else
 __device__ unsigned long long ssg_dbg_cyc[32];
 #ifdef SSG_TUNE   /* `make lib TUNE=1`: instrumented build for tools/dbg/phase.py; the counters cost ~16 VGPRs in the SW kernels */
 #define SSG_TUNING 1
 SSG_DEVFN unsigned long long ssg_clock() { return (unsigned long long)clock64(); }
-SSG_DEVFN unsigned long long ssg_wall() { return (unsigned long long)wall_clock64(); }   /* constant-rate counter shared by all CUs (100 MHz) */
 #else
 #define SSG_TUNING 0
 SSG_DEVFN unsigned long long ssg_clock() { return 0; }
-SSG_DEVFN unsigned long long ssg_wall() { return 0; }
 #endif
 #endif
 /* make one lane's global stores visible to the other lanes of the same wave */

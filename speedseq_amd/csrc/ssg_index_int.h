@@ -26,6 +26,9 @@ struct ssg_index {
 	std::vector<int64_t> h_off; std::vector<int32_t> h_len;
 	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), ktab(0), ktab_k(0), bwt_words(0), raw_alloc(false) { memset(&v, 0, sizeof(v)); }
 };
-/* fills v.ktab (ssgpu_core.cpp); every constructor of an index ends with it */
+/* ssg_ktab.cpp: the optional table (every constructor of an index ends with ssg_index_build_ktab), its seeding-kernel instance, the SA self-check */
 extern "C" int ssg_index_build_ktab(ssg_index *ix);
+extern "C" int ssg_ktab_launch_smem(const ssg_index *idx, const ssg_mem_opt_t *opt, long n_wg, int block, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
+                                    ssg_intv_t *d_intv, int32_t *d_n, int cap, ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read);
+extern "C" int ssg_sa_verify(const ssg_index *ix, int new_intv, const uint64_t *d_sa_new, long n_new);
 #endif

@@ -104,48 +104,9 @@ static int densify_sa(ssg_index *ix)
 	const long n_wg = std::min<long>((long)((n_old + 255) / 256), 256L * env_int("SSG_DENSIFY_WG_PER_CU", 8));   /* persistent: lanes refill from the counter */
 	SSG_LAUNCH(ssg_k_sa_densify_walk, n_wg, 256, 0, ix->v, want, d, n_old, d_next.p);
 	CHK(rt_sync());
-	if (env_int("SSG_SA_VERIFY", 0)) {
-		const long stride = n_new > (1L << 24) ? n_new >> 24 : 1, nt = (n_new + stride - 1) / stride;
-		unsigned long long bad = 0;
-		CHK(d_next.zero());
-		SSG_LAUNCH(ssg_k_sa_verify, (nt + 255) / 256, 256, 0, ix->v, want, (const uint64_t*)d, n_new, stride, d_next.p);
-		CHK(rt_sync()); CHK(d_next.down(&bad, 1));
-		fprintf(stderr, "[ssgpu] SA samples every %d rows: %llu of %ld checked entries differ from bwt_sa on the file's samples\n", want, bad, nt);
-	}
+	if (env_int("SSG_SA_VERIFY", 0)) CHK(ssg_sa_verify(ix, want, d, n_new));
 	rt_free(ix->sa);   /* the lower-density copy, when this index owns it */
 	ix->sa = d; ix->v.sa = d; ix->v.sa_intv = want;
-	return 0;
-}
-
-/* table of the intervals of all patterns up to K bases (ssg_index.ktab, k_seed.h): K = SSG_KTAB_K, by default 13 capped at
- * log4(text length) - 2 (1.4 GB for a human-size index; built level by level with upstream's bwt_extend, ~90 M extensions) */
-int ssg_index_build_ktab(ssg_index *ix)
-{
-	int lg = 0; while ((ix->v.seq_len >> (2 * (lg + 1))) != 0) ++lg;    /* floor(log4(seq_len)) */
-	int K = env_int("SSG_KTAB_K", 0 * std::min(13, lg - 2));   /* opt-in (SSG_KTAB_K=13) until the MI355X run of its self-check is clean: emulation agrees with the oracle, the first GPU run did not */
-	if (K > 14) K = 14;
-	rt_free(ix->ktab); ix->ktab = 0; ix->ktab_k = 0;
-	if (K < 1 || ix->v.seq_len >= (1ull << 40)) return 0;
-	const size_t n_ent = (size_t)((((1ull << (2 * (K + 1))) - 4ull) / 3ull));
-	ix->ktab = (uint64_t*)rt_malloc(n_ent * 16);
-	if (!ix->ktab) { ssg_err_msg = "index allocation failed: k-mer interval table"; return SSG_ENOMEM; }
-	const bool fwd = getenv("SSG_KTAB_BUILD") && !strcmp(getenv("SSG_KTAB_BUILD"), "fwd");
-	for (int j = 1; j <= K; ++j) {
-		const long np = 1L << (2 * (j - 1));
-		if (fwd) SSG_LAUNCH(ssg_k_ktab_level_fwd, (4 * np + 255) / 256, 256, 0, ix->v, j, (ssg_pk_t*)ix->ktab);
-		else SSG_LAUNCH(ssg_k_ktab_level, (np + 255) / 256, 256, 0, ix->v, j, (ssg_pk_t*)ix->ktab);
-	}
-	CHK(rt_sync());
-	if (env_int("SSG_KTAB_VERIFY", 0)) {
-		dbuf<unsigned long long> d_bad(16); unsigned long long bad[16];
-		CHKA(d_bad); CHK(d_bad.zero());
-		for (int j = 1; j <= K; ++j) { const long np = 1L << (2 * j), stride = np > (1L << 22) ? np >> 22 : 1, nt = (np + stride - 1) / stride; SSG_LAUNCH(ssg_k_ktab_verify, (nt + 255) / 256, 256, 0, ix->v, j, stride, (const ssg_pk_t*)ix->ktab, d_bad.p); }
-		CHK(rt_sync()); CHK(d_bad.down(bad, 16));
-		fprintf(stderr, "[ssgpu] k-mer interval table K=%d, entries differing from forward extension per level:", K);
-		for (int j = 1; j <= K; ++j) fprintf(stderr, " %llu", bad[j]);
-		fprintf(stderr, "\n");
-	}
-	ix->ktab_k = K;
 	return 0;
 }
 
@@ -449,9 +410,9 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	CHKA(scratch);
 	dbuf<unsigned int> d_nextread(1);
 	CHKA(d_nextread); CHK(d_nextread.zero());
-	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0, (const ssg_pk_t*)0, 0);
-	else if (quad && idx->ktab_k > 0) SSG_LAUNCH((ssg_k_smem_quad<1, true>), nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p, (const ssg_pk_t*)idx->ktab, idx->ktab_k);
-	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p, (const ssg_pk_t*)0, 0);
+	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0);
+	else if (quad && idx->ktab_k > 0) CHK(ssg_ktab_launch_smem(idx, opt, nthreads / block, block, n_reads, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p));   /* opt-in table instance, ssg_ktab.cpp */
+	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));

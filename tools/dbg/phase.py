@@ -26,5 +26,3 @@ s = max(1, t[20])
 print("chain2aln fractions of wave time: record %.3f scan %.3f resort %.3f append %.3f results+build %.3f; cycles per scan chunk %.0f" % (t[16]/s, t[17]/s, t[19]/s, t[22]/s, t[23]/s, t[17]/max(1,t[21])))
 r = max(1, t[26])
 print("smem (wave cycles): state machine=%d extension site=%d | rounds=%d, ready lanes per round %.1f of %.1f alive" % (t[24], t[25], t[26], 64.0 * t[27] / r, 64.0 * t[28] / r))
-n = max(1, t[31])
-print("smem lanes: %d lane-launches, mean busy time %.1f us of the longest %.1f us (wall clock, 100 MHz): lanes had work %.3f of the kernel's duration" % (t[31], t[29] / n / 100.0, t[30] / 100.0, t[29] / n / max(1, t[30])))
