@@ -1,0 +1,21 @@
+"""The product kernels' gfx950 machine code is the code whose results were checked on the MI355X (tools/isa_pin.py).
+
+Why a CPU-side test looks at machine code: in round 3 the GPU results of the seeding kernel went wrong -- emulation of the same source still
+agreed with the oracle -- after unrelated device code had been added to its translation unit; hipcc (ROCm 7.2) had changed the code of 24
+untouched kernels (profiles/r03f_gpu_bisect.log).  A change of any pinned kernel's code must go through `pytest -m gpu`
+and the bench's parity gate, then `python tools/isa_pin.py --write`."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_product_kernels_machine_code_is_the_gpu_checked_build():
+    lib = os.path.join(ROOT, "speedseq_amd", "libssgpu.so")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or not os.path.exists(lib):
+        pytest.skip("llvm-objdump or libssgpu.so not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_pin.py")], capture_output=True, text=True)
+    assert r.returncode == 0, "kernel machine code differs from the GPU-checked build:\n" + r.stdout[-3000:]
