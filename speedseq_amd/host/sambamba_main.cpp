@@ -178,9 +178,32 @@ static void gpu_perm(const rec_store_t &S, std::vector<uint32_t> &perm)
 /* the sorted records as a BGZF stream.  Blocks are cut exactly as bgzf_out_t::record cuts them (a record does not straddle blocks
  * unless it is larger than one); the gather of a block's records and its deflate run on the thread pool, groups of blocks are
  * written in order by the calling thread while later groups are still being compressed. */
-static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads)
+/* <bam>.bai.ssg: "size mtime_s mtime_ns crc32(bai)" of a BAM and the index `sambamba sort` wrote with it */
+static bool bai_note_make(const std::string &bam, std::string &note)
+{
+	struct stat sb; if (stat(bam.c_str(), &sb) != 0) return false;
+	FILE *f = fopen((bam + ".bai").c_str(), "rb"); if (!f) return false;
+	uLong crc = crc32(0L, Z_NULL, 0); uint8_t buf[65536]; size_t k;
+	while ((k = fread(buf, 1, sizeof(buf), f)) > 0) crc = crc32(crc, buf, (uInt)k);
+	fclose(f);
+	char t[128]; snprintf(t, sizeof(t), "%lld %lld %ld %lu\n", (long long)sb.st_size, (long long)sb.st_mtim.tv_sec, (long)sb.st_mtim.tv_nsec, (unsigned long)crc);
+	note = t; return true;
+}
+static void bai_note_write(const std::string &bam)
+{
+	std::string note; if (!bai_note_make(bam, note)) return;
+	FILE *f = fopen((bam + ".bai.ssg").c_str(), "w"); if (!f) return;
+	fputs(note.c_str(), f); fclose(f);
+}
+
+/* bai_path != NULL (the final file, a regular file): the .bai is written as well -- every field `sambamba index` would read back from the
+ * file is in memory here -- with a note next to it (<bai>.ssg: size and mtime of the BAM, CRC of the index) that lets `sambamba index`,
+ * which the reference runs right after the sort (bin/speedseq:491-495), recognise the pair as current instead of inflating the BAM again */
+static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads, const char *bai_path = 0)
 {
 	{ bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
+	const off_t hdr_end = bai_path ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+	if (hdr_end < 0) bai_path = 0;
 	const size_t n = perm.size();
 	const int lvl = level < 0 ? 6 : level;
 	/* virtual byte offsets of the sorted stream and the block cuts */
@@ -197,7 +220,8 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		if (cum[n] > cut.back()) cut.push_back(cum[n]);
 	}
 	const size_t nb = cut.size() - 1, GRP = 128, ng = (nb + GRP - 1) / GRP;
-	struct grp_t { std::vector<uint8_t> bytes; bool done; grp_t() : done(false) {} };
+	struct grp_t { std::vector<uint8_t> bytes; std::vector<uint32_t> bsz; bool done; grp_t() : done(false) {} };
+	std::vector<uint64_t> blk_coff(bai_path ? nb + 1 : 0);      /* file offset of every block */
 	std::vector<grp_t> grp(ng);
 	std::mutex mu; std::condition_variable cv; size_t next_write = 0; std::atomic<size_t> next_grp(0);
 	const size_t window = (size_t)std::max(4, threads * 3);   /* groups compressed ahead of the writer */
@@ -208,28 +232,49 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 			if (g >= ng) break;
 			{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return g < next_write + window; }); }
 			std::vector<uint8_t> ob; ob.reserve(GRP * (lvl ? 24576 : 65536));
+			std::vector<uint32_t> bsz;
 			for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
 				const uint64_t v0 = cut[bk], v1 = cut[bk + 1];
 				size_t i = (size_t)(std::upper_bound(cum.begin(), cum.end(), v0) - cum.begin()) - 1; size_t w = 0;
 				for (uint64_t v = v0; v < v1; ++i) { const uint8_t *r = S.rec(perm[i]); const uint64_t a = v - cum[i], e = std::min(cum[i + 1], v1) - cum[i]; memcpy(payload.data() + w, r + a, (size_t)(e - a)); w += (size_t)(e - a); v = cum[i] + e; }
 				const size_t k = bgzf_make_block(payload.data(), w, lvl, blk.data());
-				ob.insert(ob.end(), blk.data(), blk.data() + k);
+				ob.insert(ob.end(), blk.data(), blk.data() + k); bsz.push_back((uint32_t)k);
 			}
-			{ std::lock_guard<std::mutex> l(mu); grp[g].bytes.swap(ob); grp[g].done = true; }
+			{ std::lock_guard<std::mutex> l(mu); grp[g].bytes.swap(ob); grp[g].bsz.swap(bsz); grp[g].done = true; }
 			cv.notify_all();
 		}
 	};
 	std::vector<std::thread> th;
 	for (int t = 0; t < std::max(1, threads); ++t) th.emplace_back(worker);
+	uint64_t coff = (uint64_t)(hdr_end > 0 ? hdr_end : 0);
 	for (size_t g = 0; g < ng; ++g) {
-		std::vector<uint8_t> ob;
-		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); }
+		std::vector<uint8_t> ob; std::vector<uint32_t> bsz;
+		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz); }
 		io_write_all(fd, ob.data(), ob.size());
+		if (bai_path) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }
 		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; }
 		cv.notify_all();
 	}
 	for (auto &x : th) x.join();
 	io_write_all(fd, BGZF_EOF, 28);
+	if (!bai_path) return;
+	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets) */
+	blk_coff[nb] = coff;
+	const uint64_t file_end = (coff + 28) << 16;
+	struct ent_t { int32_t tid, pos, end; uint8_t mapped; };
+	std::vector<ent_t> ent(n);
+	parallel_for(threads, n, [&](size_t a, size_t b, int) {
+		for (size_t i = a; i < b; ++i) { const uint8_t *r = S.rec(perm[i]) + 4; bam_core_t c; memcpy(&c, r, 32); ent[i].tid = c.tid; ent[i].pos = c.pos; ent[i].end = bam_endpos(r); ent[i].mapped = !((c.flag_nc >> 16) & 4); }
+	});
+	auto voff = [&](size_t i, size_t &bk) -> uint64_t { while (cut[bk + 1] <= cum[i]) ++bk; return blk_coff[bk] << 16 | (cum[i] - cut[bk]); };
+	size_t bk = 0;
+	bai_t idx((int)h.names.size(), n ? voff(0, bk) : file_end);
+	for (size_t i = 0; i < n; ++i) {
+		const uint64_t after = i + 1 < n ? voff(i + 1, bk) : file_end;
+		if (idx.push(ent[i].tid, ent[i].pos, ent[i].end, after, ent[i].mapped != 0) < 0) return;     /* cannot happen on a sorted stream; `sambamba index` will say so */
+	}
+	idx.finish(file_end);
+	idx.save(bai_path);
 }
 
 struct merge_src_t {   /* one coordinate-sorted BAM being merged */
@@ -275,6 +320,9 @@ static int cmd_sort(int argc, char **argv)
 	uint64_t budget = (uint64_t)(std::max(mem_gb, 0.25) * 0.6 * 1073741824.0);   /* record bytes per in-memory run; the rest is keys, locations, output blocks */
 	{ const char *e = getenv("SSG_SORT_CHUNK_BYTES"); if (e && atoll(e) > 0) budget = (uint64_t)atoll(e); }   /* the tests force the spill-and-merge path */
 	rec_store_t S; std::vector<std::string> spills; bam_hdr_t h;
+	/* the device is first needed when the last record has arrived: bring the runtime up now, next to the input, not then */
+	std::thread warm([]() { const uint64_t k[2] = { 1, 0 }; uint32_t pm[2]; (void)ssg_sort_u64_perm(k, 2, pm); });
+	struct joiner_t { std::thread &t; ~joiner_t() { if (t.joinable()) t.join(); } } warm_join = { warm };
 	if (mkdir(tmpdir.c_str(), 0777) != 0 && errno != EEXIST) die("sort: cannot create " + tmpdir + ": " + strerror(errno));
 	auto spill = [&]() {
 		std::vector<uint32_t> perm; gpu_perm(S, perm);
@@ -335,11 +383,14 @@ static int cmd_sort(int argc, char **argv)
 		flush();
 	}
 	const double t_in = wall();
+	bool bai_note = false;
 	int ofd = open(outp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + outp);
 	if (spills.empty()) {
 		std::vector<uint32_t> perm; gpu_perm(S, perm);
 		const double t_perm = wall();
-		write_sorted(S, perm, h, ofd, level, pool);
+		const std::string bai = outp + ".bai";
+		write_sorted(S, perm, h, ofd, level, pool, getenv("SSG_SORT_NO_BAI") ? 0 : bai.c_str());
+		bai_note = !getenv("SSG_SORT_NO_BAI");
 		if (dbg()) fprintf(stderr, "[sambamba] sort: %zu records, %.2f GB: input %.2f s (from start), device sort of the keys %.2f s, gather + deflate (level %d, %d threads) + write %.2f s\n",
 		                   S.key.size(), (double)S.bytes / 1e9, t_in - t_start, t_perm - t_in, level < 0 ? 6 : level, pool, wall() - t_perm);
 	}
@@ -352,6 +403,7 @@ static int cmd_sort(int argc, char **argv)
 		for (size_t i = 0; i < spills.size(); ++i) { close(src[i].fd); unlink(spills[i].c_str()); }
 	}
 	close(ofd);
+	if (bai_note) bai_note_write(outp);
 	return 0;
 }
 
@@ -361,6 +413,16 @@ static int cmd_index(int argc, char **argv)
 	const char *in = 0; int threads = hw_threads();
 	for (int i = 0; i < argc; ++i) { if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]); else if (argv[i][0] != '-') { if (!in) in = argv[i]; } }
 	if (!in) die("usage: sambamba index <in.bam>");
+	{	/* the sort of this repository left the index of exactly this file next to it: nothing to do (the note goes, the pair stays) */
+		const std::string note_p = std::string(in) + ".bai.ssg";
+		FILE *f = fopen(note_p.c_str(), "r");
+		if (f) {
+			char have[128] = ""; if (!fgets(have, sizeof(have), f)) have[0] = 0;
+			fclose(f); unlink(note_p.c_str());
+			std::string now;
+			if (bai_note_make(in, now) && now == have) { if (dbg()) fprintf(stderr, "[sambamba] index: %s.bai written by the sort is current\n", in); return 0; }
+		}
+	}
 	const int fd = open_in(in);
 	bgzf_in_t bi(fd, threads); bam_hdr_t h;
 	if (!hdr_read(bi, h)) die("index: not a BAM file");

@@ -126,18 +126,25 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 {
 	ssg_sbl_state_t *st = ssg_sbl_state_new();
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
-	int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	int threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
 	{ const char *e = getenv("SSG_SBL_THREADS"); if (e && atoi(e) > 0) threads = atoi(e); }
 	if (!fu_write_full(1, FU_MAGIC, 8)) { perror("[samblaster] write"); return 1; }
 	bool got_header = false, ended = false;
 	/* frames are read by a thread of their own so that the next batch arrives while this one is decided and written */
-	struct frame_t { fu_frame_t h; std::unique_ptr<uint8_t[]> p; };
+	struct frame_t { fu_frame_t h; std::unique_ptr<uint8_t[]> p; size_t cap; frame_t() : cap(0) {} };
 	chan_t<std::unique_ptr<frame_t> > ch(2); std::atomic<int> rd_fail(0);
+	/* frame buffers go back to the reader when a batch is done: hundreds of MB of warm memory instead of fresh pages per frame */
+	std::mutex pool_mu; std::vector<std::unique_ptr<frame_t> > pool;
 	std::thread reader([&]() {
 		for (;;) {
-			std::unique_ptr<frame_t> F(new frame_t());
+			std::unique_ptr<frame_t> F;
+			{ std::lock_guard<std::mutex> l(pool_mu); if (!pool.empty()) { F = std::move(pool.back()); pool.pop_back(); } }
+			if (!F) F.reset(new frame_t());
 			if (!fu_read_full(0, &F->h, sizeof(F->h))) { rd_fail = 1; break; }
-			if (F->h.len) { F->p.reset(new uint8_t[F->h.len]); if (!fu_read_full(0, F->p.get(), (size_t)F->h.len)) { rd_fail = 1; break; } }
+			if (F->h.len) {
+				if (F->cap < F->h.len) { F->p.reset(new uint8_t[F->h.len + F->h.len / 8]); F->cap = (size_t)(F->h.len + F->h.len / 8); }
+				if (!fu_read_full(0, F->p.get(), (size_t)F->h.len)) { rd_fail = 1; break; }
+			}
 			const bool end = F->h.type == FU_END;
 			ch.push(std::move(F));
 			if (end) break;
@@ -146,6 +153,7 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	});
 	std::vector<uint64_t> rec_off; std::vector<ssg_sbl_line_t> lines; std::vector<uint8_t> newblk, bits; std::vector<int64_t> blk_off, mate;
 	std::vector<std::pair<const char*, uint32_t> > ltext;
+	std::vector<std::vector<uint8_t> > outb;                  /* per-thread output of a batch, kept across batches */
 	std::unique_ptr<frame_t> F;
 	int rc = 0;
 	while (!rc && ch.pop(F)) {
@@ -193,7 +201,8 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 		if (ssg_sbl_process(st, &o, (long)n_blocks, blk_off.data(), lines.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); rc = 1; break; }
 		/* main stream: the records with 0x400 and MC / MQ, rebuilt by threads over ranges of blocks, written in order as one frame */
 		const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 4096 + 1));
-		std::vector<std::vector<uint8_t> > outb((size_t)T);
+		if (outb.size() < (size_t)T) outb.resize((size_t)T);
+		for (auto &v : outb) v.clear();
 		parallel_ranges(T, (size_t)T, [&](size_t ta, size_t tb) {
 			for (size_t t = ta; t < tb; ++t) {
 				const size_t b0 = n_blocks * t / (size_t)T, b1 = n_blocks * (t + 1) / (size_t)T;
@@ -277,6 +286,7 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 				++n_spl;
 			}
 		}
+		{ std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 3) pool.push_back(std::move(F)); }
 	}
 	{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
 	reader.join();

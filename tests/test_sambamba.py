@@ -74,8 +74,15 @@ def _check(sambamba, tmp_path, monkeypatch):
     monkeypatch.delenv("SSG_SORT_CHUNK_BYTES")
     assert _view(d + "/mine_s2.bam") == _view(d + "/ref_s.bam")
     assert os.listdir(d + "/tmp2") == []
-    # index: same bins / chunks / linear index as samtools builds for the same file; region queries through it
+    # the sort left the index of its output and a note next to it: `index` recognises the pair as current (and drops the note); the index
+    # computed from the file alone is the same bytes; a BAM that changed since is indexed again
+    assert os.path.exists(d + "/mine_s.bam.bai") and os.path.exists(d + "/mine_s.bam.bai.ssg")
+    by_sort = open(d + "/mine_s.bam.bai", "rb").read()
     subprocess.run(sambamba + ["index", d + "/mine_s.bam"], check=True)
+    assert not os.path.exists(d + "/mine_s.bam.bai.ssg") and open(d + "/mine_s.bam.bai", "rb").read() == by_sort
+    subprocess.run(sambamba + ["index", d + "/mine_s.bam"], check=True)                      # no note any more: computed from the file
+    assert open(d + "/mine_s.bam.bai", "rb").read() == by_sort
+    assert os.path.exists(d + "/mine_s2.bam.bai.ssg") is False                                # spill-and-merge output: no index from the sort
     os.rename(d + "/mine_s.bam.bai", d + "/mine.bai")
     subprocess.run([SAMTOOLS, "index", d + "/mine_s.bam"], check=True)
     assert _parse_bai(d + "/mine.bai") == _parse_bai(d + "/mine_s.bam.bai")
