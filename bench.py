@@ -416,6 +416,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
     ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs in the FASTQ file of the plugin-path leg (the timed batch + freshly simulated ones): enough device calls for the pipeline's steady state to show")
+    ap.add_argument("--config5-pairs", type=int, default=200000, help="pairs of the 2x250 leg (BASELINE.json configs[4]: long fragments, wider bands), 0 = skip")
+    ap.add_argument("--no-dist-rehearsal", dest="dist_rehearsal", action="store_false", help="skip the one-rank rehearsal of the N > 1 code path (a second process)")
     ap.add_argument("--emu-selftest", action="store_true", help="TEST INFRASTRUCTURE, never a measurement: walk this script's whole flow on the CPU with the host-emulation build "
                     "(tests/emu) and the bundled chr20 slice as the reference, at toy sizes -- catches a broken leg before it costs GPU minutes")
     ap.add_argument("--partial", default=os.path.join(ROOT, "gpurun_out", "bench_partial.json"), help="the line so far is also written here after every leg (a run that is cut short leaves its numbers)")
@@ -481,6 +483,7 @@ def main():
     reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev, **ins)
     n_more = max(0, max(a.e2e_pairs, a.script_pairs) - a.pairs)
     reads_e2e = simulate_pairs(ref, lens, n_more, rl, 1012, dev, **ins).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0 and n_more > 0) else None   # further pairs for the plugin-path leg
+    reads5 = simulate_pairs(ref, lens, a.config5_pairs, 250, 512, dev, ins_mean=800, ins_std=150) if (a.config5_pairs > 0 and rl == 150 and world == 1 and a.cpu_sample > 0) else None
     d_seq = reads.reshape(-1)
     d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
     pb, n_batches = bwa_batches(a.pairs, rl, a.bwa_threads)
@@ -710,6 +713,39 @@ def main():
             except Exception as e:
                 out["parity"]["oracle_independent"] = {"error": repr(e)}
             del gtext, otext, gm, gd, gs, om, od, os_
+            if reads5 is not None:
+                try:   # BASELINE.json configs[4]: 2x250, fragments 800 +- 150 -- the same entry point, timed and checked the same way on a smaller batch
+                    n5, r5 = a.config5_pairs, 250
+                    d5 = reads5.reshape(-1)
+                    o5 = (torch.arange(2 * n5 + 1, device=dev, dtype=torch.int64) * r5).contiguous()
+                    pb5, nb5 = bwa_batches(n5, r5, a.bwa_threads)
+                    dpb5 = torch.from_numpy(pb5).to(dev)
+                    run5 = lambda keep=False: capi.hotpath_dev_ex(lib, idx, opt, n5, r5, d5.data_ptr(), o5.data_ptr(), dpb5.data_ptr(), nb5, 0, keep=keep)
+                    run5(); torch.cuda.synchronize()
+                    t5 = time.perf_counter()
+                    for _ in range(3):
+                        s5, _ = run5()
+                    torch.cuda.synchronize()
+                    t5 = (time.perf_counter() - t5) / 3
+                    ns5 = min(5000, n5)
+                    h5 = reads5[:2 * ns5].cpu().numpy().reshape(-1); ho5 = np.arange(2 * ns5 + 1, dtype=np.int64) * r5
+                    nm5 = ["q%d" % (i // 2) for i in range(2 * ns5)]
+                    ot5, _, _ = orc.process_pairs(oidx, h5, ho5, nm5, None, 0, "", cores)
+                    _, hr5 = capi.hotpath_dev_ex(lib, idx, opt, ns5, r5, d5.data_ptr(), o5.data_ptr(), dpb5[:ns5].contiguous().data_ptr(), int(pb5[ns5 - 1]) + 1, 0, keep=True)
+                    res5, b5, m5 = capi.dev_records_download(lib, hr5, ns5)
+                    gt5, _ = capi.sam_format(lib, idx, opt, res5, nm5, h5, ho5, None, "")
+                    res5.close(); capi.dev_records_free(lib, hr5)
+                    same5 = gt5 == ot5 and common.sbl_streams_from_bits(gt5, b5, m5) == common.oracle_streams(orc, ot5, hdr)
+                    out["config5"] = {"workload": "%d synthetic 2x250 bp pairs, fragments 800 +- 150 (BASELINE.json configs[4]), same reference and entry point" % n5,
+                                      "ms_per_step": 1e3 * t5, "pairs_per_s": n5 / t5, "records": int(s5[0]), "rescues": int(s5[5]), "sw_cells": int(s5[3]) + int(s5[4]),
+                                      "parity_checked_pairs": ns5, "parity_ok": bool(same5)}
+                    if not same5:
+                        ok = False
+                    del d5, o5, dpb5
+                except Exception as e:
+                    out["config5"] = {"error": repr(e)}
+                log('2x250 leg done')
+                save_partial()
             if a.e2e:
                 b = (lambda n: os.path.join(ROOT, "tests", "emu", n + "_emu")) if emu else (lambda n: os.path.join(ROOT, "bin", n))
                 orc_exe = os.path.join(ROOT, "oracle", "orc_bwa")
@@ -733,6 +769,19 @@ def main():
                 except Exception as e:
                     out["literal"] = {"error": repr(e)}
             log('script legs done')
+            if a.dist_rehearsal and not emu and time.time() - _T0 < 360:
+                try:   # the N > 1 code path (signature exchange, owner-side marking, range exchange of the records) on one rank, in a process of its own:
+                       # what the exchange layer costs before a byte crosses xGMI.  No scaling curve exists until an 8-GPU box runs this script.
+                    import subprocess
+                    env = dict(os.environ, SSG_BENCH_FORCE_DIST="1", MASTER_PORT="29533")
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-e2e", "--cpu-sample", "0", "--no-profile",
+                                        "--pairs", str(a.pairs), "--ref-mbp", str(a.ref_mbp), "--partial", a.partial + ".dist"], env=env, capture_output=True, text=True, timeout=240)
+                    dj = json.loads(r.stdout.strip().split("\n")[-1])
+                    out["dist_rehearsal"] = {"what": "SSG_BENCH_FORCE_DIST=1: the N > 1 step on one rank (nccl group of size 1)", "ms_per_step": dj["ms_per_step"],
+                                             "overhead_ms_vs_single": dj["ms_per_step"] - out["ms_per_step"], "sorted_merge": dj["config"].get("sorted_merge")}
+                except Exception as e:
+                    out["dist_rehearsal"] = {"error": repr(e)[:300]}
+                log('N > 1 rehearsal done')
             save_partial()
             td_obj.cleanup()
             if not ok:   # no timing counts without parity

@@ -340,7 +340,7 @@ int main(int argc, char **argv)
 		chunk_t() : buf(64u << 20), have(0), scan(0) {}
 	};
 	chan_t<std::unique_ptr<chunk_t> > ch(2);
-	bool in_header = true; int parse_fail = 0;
+	std::atomic<bool> in_header(true); std::atomic<int> parse_fail(0);   /* written by the reader thread, read by this one */
 	std::string last_rname; int last_seq = -1;
 
 	auto parse_line = [&](chunk_t &C, size_t off, size_t len) -> bool {
