@@ -559,7 +559,7 @@ def main():
                    "records": int(summary[0]), "dup_pairs": n_dup_global[0] if multi else int(summary[1]), "dup_pairs_local_view": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
                    "bwt_extends": int(summary[6]), "chains": int(summary[7]),
                    "sam_lines": int(summary[10]), "discordant_stream_lines": int(summary[8]), "splitter_stream_lines": int(summary[9]),
-                   "dedup_scope": "global over all ranks (all-to-all signature exchange)" if multi else "single GPU = whole input",
+                   "dedup_scope": ("global over all ranks (all-to-all signature exchange; owner side: %s)" % ssdist.OWNER_PATH[0]) if multi else "single GPU = whole input",
                    "sorted_merge": ("coordinate range exchange of %d-byte records by samtools' key inside the step; %.1f MB sent by rank 0 per step" % (rec_bytes, merge_bytes[0] / 1e6)) if multi else "single GPU: bin/sambamba sort (device radix sort of the keys)"},
     }
     def save_partial():

@@ -51,6 +51,9 @@ def _mix(x):
     return x
 
 
+OWNER_PATH = ["torch"]        # which implementation took the owner-side decisions last (bench.py reports it)
+
+
 def _owner_verdicts(recv, lib):
     """owner side: an element is a duplicate iff the same signature arrived with a smaller global ordinal.  With libssgpu (device tensors)
     this is ssg_markdup_sig_dev -- the kernels of the single-GPU duplicate marking (radix sort by ordinal, hash sort, run scan); without
@@ -62,10 +65,16 @@ def _owner_verdicts(recv, lib):
         sig[recv[:, 4] == 0] = -1                      # not valid: never a duplicate (all ones)
         sig = sig.contiguous(); ordi = recv[:, 3].contiguous()
         verdict = torch.empty(n, dtype=torch.uint8, device=recv.device)
-        if n:
-            torch.cuda.current_stream().synchronize()   # libssgpu launches on the default stream
-            capi.markdup_sig_dev(lib, n, sig.data_ptr(), ordi.data_ptr(), verdict.data_ptr())
-        return verdict
+        try:
+            if n:
+                torch.cuda.current_stream().synchronize()   # libssgpu launches on the default stream
+                capi.markdup_sig_dev(lib, n, sig.data_ptr(), ordi.data_ptr(), verdict.data_ptr())
+            OWNER_PATH[0] = "libssgpu (ssg_markdup_sig_dev)"
+            return verdict
+        except Exception as e:   # the same rule in torch below; said out loud, never silently
+            import sys
+            sys.stderr.write("[dist] ssg_markdup_sig_dev failed (%r): owner-side duplicate marking falls back to torch\n" % (e,))
+            OWNER_PATH[0] = "torch (libssgpu path failed: %r)" % (e,)
     keys, inv = torch.unique(recv[:, :3], dim=0, return_inverse=True)
     first = torch.full((keys.shape[0],), torch.iinfo(torch.int64).max, dtype=torch.int64, device=recv.device)
     first = first.scatter_reduce(0, inv, recv[:, 3], reduce="amin")
