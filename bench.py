@@ -412,7 +412,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs of the timed batch aligned by the CPU oracle: parity gate on the timed call + cpu_baseline (-1 = the whole batch, 0 = skip)")
     ap.add_argument("--script-pairs", type=int, default=8000000, help="pairs in the FASTQ of the literal-metric leg: the reference's `speedseq align` script on the product executables, FASTQ -> three sorted BAMs + BAI")
     ap.add_argument("--script-threads", type=int, default=32, help="-t of the script legs on the product executables")
-    ap.add_argument("--cpu-script-pairs", type=int, default=200000, help="pairs of the CPU baseline through the script (`speedseq align -t <cores>` on the oracle's executables; 0 = skip)")
+    ap.add_argument("--cpu-script-pairs", type=int, default=100000, help="pairs of the CPU baseline through the script (`speedseq align -t <cores>` on the oracle's executables; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
     ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs in the FASTQ file of the plugin-path leg (the timed batch + freshly simulated ones): enough device calls for the pipeline's steady state to show")
