@@ -336,7 +336,8 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     n_all = os.path.getsize(fq) // rec_bytes
     samtools = os.path.join(ROOT, "oracle", "_ref", "samtools")
     shim = os.path.join(ROOT, "tools", "sambamba_samtools_shim.sh")
-    fused_cfg = "export SSG_FUSED=1\nexport SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128)
+    host_cfg = "export SSG_SORT_THREADS=%d\nexport SSG_FMT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % (min(os.cpu_count() or 8, 128), min(os.cpu_count() or 8, 48))   # the script's -t sizes upstream's batches; the host pools are sized for the box
+    fused_cfg = "export SSG_FUSED=1\n" + host_cfg
     res = {"metric": "paired reads aligned+dup-marked/sec, FASTQ file -> out.bam + out.splitters.bam + out.discordants.bam (+ .bai), `speedseq align` wall clock incl. index load"}
 
     def head(n, name):
@@ -359,7 +360,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     fused_ok = "pairs_per_s" in r
     n_text = min(2000000, n_all) if fused_ok else n_fused            # the text hand-off carries the literal number when the fused run gave none
     r = script_leg(td, "text", prefix, fq_f if n_text == n_fused else head(n_text, "text.fq"), n_text, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"),
-                   config_extra="export SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128))
+                   config_extra=host_cfg)
     r.pop("out", None)
     r["what"] = "the same without SSG_FUSED: SAM text on every pipe (the parity path)"
     res["text"] = r
@@ -371,7 +372,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     # parity of the fused path on the sample: product (fused) vs the oracle's executables behind the same script
     sfq = os.path.join(td, "sample.fq")
     if os.path.exists(samtools) and os.path.exists(sfq):
-        rp = script_leg(td, "s_fused", prefix, sfq, ns, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=fused_cfg if fused_ok else "", limit_s=120)
+        rp = script_leg(td, "s_fused", prefix, sfq, ns, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=fused_cfg if fused_ok else host_cfg, limit_s=120)
         ro = script_leg(td, "s_orc", prefix, sfq, ns, a.script_threads, orc_exe, orc_exe + " samblaster", shim, sort_mem_gb=8)
         if "out" in rp and "out" in ro:
             same = {x: bam_view(samtools, rp["out"] + x) == bam_view(samtools, ro["out"] + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
@@ -411,7 +412,7 @@ def main():
     ap.add_argument("--bwa-threads", type=int, default=16, help="the -t whose batch boundaries (insert-size model scope) are reproduced")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs of the timed batch aligned by the CPU oracle: parity gate on the timed call + cpu_baseline (-1 = the whole batch, 0 = skip)")
     ap.add_argument("--script-pairs", type=int, default=8000000, help="pairs in the FASTQ of the literal-metric leg: the reference's `speedseq align` script on the product executables, FASTQ -> three sorted BAMs + BAI")
-    ap.add_argument("--script-threads", type=int, default=32, help="-t of the script legs on the product executables")
+    ap.add_argument("--script-threads", type=int, default=16, help="-t of the script legs on the product executables")
     ap.add_argument("--cpu-script-pairs", type=int, default=100000, help="pairs of the CPU baseline through the script (`speedseq align -t <cores>` on the oracle's executables; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
