@@ -116,3 +116,44 @@ def test_fused_script_equals_text_path_gpu(tmp_path, gpu_lib):
     _same_bam_records(fused, text)
     exp = T._run_align(str(tmp_path / "orc"), T.ORC, T.ORC + " samblaster", fq)
     T._compare(fused, exp)
+
+
+def _pipe(d, fq, fused, tag):
+    """bwa mem | samblaster | sambamba view | sambamba sort by hand (no script): the three outputs of one hand-off mode"""
+    e = lambda n: os.path.join(EMU, n + "_emu")
+    env = dict(os.environ, SSG_FUSED="1" if fused else "0")
+    spl, disc, out = (os.path.join(d, tag + x) for x in (".spl.sam", ".disc.sam", ".bam"))
+    cmd = ("%s mem -p -R '@RG\\tID:x\\tSM:x' %s %s | %s --excludeDups --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile %s --discordantFile %s"
+           " | %s view -S -f bam -l 0 /dev/stdin | %s sort -t 2 -m 1G --tmpdir=%s -o %s /dev/stdin"
+           % (e("bwa"), EXAMPLE_FA, fq, e("samblaster"), spl, disc, e("sambamba"), e("sambamba"), os.path.join(d, "t" + tag), out))
+    r = subprocess.run(["bash", "-c", "set -o pipefail; " + cmd], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    return _records(out), open(spl).read(), open(disc).read()
+
+
+def test_fused_edge_inputs_emulated(tmp_path, emu_lib):
+    """no reads at all; reads that align nowhere (every record unmapped, no side-stream candidates); a mix -- both hand-off modes agree"""
+    import numpy as np
+    d = str(tmp_path)
+    rng = np.random.default_rng(3)
+    empty = os.path.join(d, "empty.fq")
+    open(empty, "w").close()
+    junk = os.path.join(d, "junk.fq")
+    with open(junk, "w") as f:
+        for i in range(40):
+            for _ in range(2):
+                f.write("@j%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in rng.integers(0, 4, 150)), "I" * 150))
+    mix = os.path.join(d, "mix.fq")
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 120, seed=13)
+    with open(mix, "w") as f:
+        for i, (name, r1, r2) in enumerate(pairs):
+            if i % 7 == 3:
+                r2 = rng.integers(0, 4, len(r2))                 # one end maps, its mate does not
+            for r in (r1, r2):
+                f.write("@%s\n%s\n+\n%s\n" % (name, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    for fq, tag, min_bytes in ((empty, "e", 0), (junk, "j", 1000), (mix, "m", 10000)):
+        t = _pipe(d, fq, False, tag + "t")
+        f = _pipe(d, fq, True, tag + "f")
+        strip = lambda x: "\n".join(l for l in x.split("\n") if not l.startswith("@PG"))
+        assert t[0] == f[0] and len(t[0]) >= min_bytes, tag
+        assert strip(t[1]) == strip(f[1]) and strip(t[2]) == strip(f[2]), tag
