@@ -21,6 +21,7 @@
 #include <memory>
 #include <string>
 #include <atomic>
+#include <algorithm>
 #include <unistd.h>
 #include <fcntl.h>
 #include <errno.h>
@@ -52,6 +53,7 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	std::atomic<bool> stop{false};
 	bool threaded;                      /* compressed input only: for a plain file the hand-over costs more than the read */
 	bool bgzf;                          /* blocked gzip (bgzip, htslib bgzf.c:298-342): independent <= 64 KB members with their size in the header, inflated by several threads */
+	int rfd; size_t roff, rend;         /* ranged mode (fq_feed_t's parallel parse of a plain file): bytes [roff, rend) of rfd through pread */
 	/* BGZF member at p (n bytes available): its total size, or 0 when p does not start one */
 	static size_t bgzf_member(const unsigned char *p, size_t n)
 	{
@@ -106,7 +108,8 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 		}
 		full.close();
 	}
-	explicit fq_stream_t(gzFile f, const char *path = 0) : fp(f), begin(0), end(0), is_eof(false), full(4), empty(8), bgzf(false)
+	fq_stream_t(int fd, size_t off, size_t lim) : fp(0), begin(0), end(0), is_eof(false), full(1), empty(1), threaded(false), bgzf(false), rfd(fd), roff(off), rend(lim) { buf.resize((size_t)1 << 20); }
+	explicit fq_stream_t(gzFile f, const char *path = 0) : fp(f), begin(0), end(0), is_eof(false), full(4), empty(8), bgzf(false), rfd(-1), roff(0), rend(0)
 	{
 		gzbuffer(fp, 1 << 20);
 		threaded = !gzdirect(fp);
@@ -141,6 +144,17 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	inline bool fill()
 	{
 		if (is_eof) return false;
+		if (rfd >= 0) {
+			begin = end = 0;
+			while (roff < rend) {
+				const ssize_t r = pread(rfd, buf.data(), std::min(buf.size(), rend - roff), (off_t)roff);
+				if (r < 0 && errno == EINTR) continue;
+				if (r > 0) { end = (int)r; roff += (size_t)r; }
+				break;
+			}
+			if (end <= 0) { is_eof = true; return false; }
+			return true;
+		}
 		if (!threaded) { begin = 0; end = gzread(fp, buf.data(), (unsigned)buf.size()); if (end <= 0) { end = 0; is_eof = true; return false; } return true; }
 		std::unique_ptr<chunk_t> c;
 		if (!full.pop(c)) { begin = end = 0; is_eof = true; return false; }
@@ -180,7 +194,9 @@ static inline uint8_t fq_nt4(int c) { return fq_nt4_tab()[(unsigned char)c]; }
 
 struct fq_reader_t {
 	fq_stream_t ks; int last_char; bool keep_comment;
-	fq_reader_t(gzFile f, bool kc, const char *path = 0) : ks(f, path), last_char(0), keep_comment(kc) {}
+	bool qual_eof;                      /* the quality loop ran into the end of the stream: only the end of the FILE may do that */
+	fq_reader_t(gzFile f, bool kc, const char *path = 0) : ks(f, path), last_char(0), keep_comment(kc), qual_eof(false) {}
+	fq_reader_t(int fd, size_t off, size_t lim, bool kc) : ks(fd, off, lim), last_char(0), keep_comment(kc), qual_eof(false) {}
 	/* kseq_read + kseq2bseq1 + trim_readno into block b; >= 0 length, -1 EOF, -2 truncated quality */
 	int next(fq_block_t &b)
 	{
@@ -209,7 +225,9 @@ struct fq_reader_t {
 		if (c == '+') {
 			while ((c = ks.getc()) != -1 && c != '\n') {}
 			if (c == -1) return -2;
-			while (ks.getuntil(2, b.qual, 0, q0) >= 0 && b.qual.size() - q0 < l_seq) {}
+			int r;
+			while ((r = ks.getuntil(2, b.qual, 0, q0)) >= 0 && b.qual.size() - q0 < l_seq) {}
+			if (r < 0) qual_eof = true;
 			last_char = 0;
 			if (b.qual.size() - q0 != l_seq) return -2;
 			b.qual.push_back(0); hq = true;
@@ -239,21 +257,111 @@ struct fq_block_pool_t {                /* blocks go back to the reader when the
 struct fq_feed_t {
 	chan_t<std::shared_ptr<fq_block_t> > ch; std::thread th;   /* shared: a batch keeps the blocks its names and qualities point into */
 	std::shared_ptr<fq_block_pool_t> pool;
+	typedef std::shared_ptr<fq_block_t> blk_t;
+	blk_t fresh(int per_block)
+	{
+		std::shared_ptr<fq_block_pool_t> pl = pool;
+		blk_t b(pl->get(), [pl](fq_block_t *x) { pl->put(x); });
+		b->txt.reserve((size_t)per_block * 48); b->seq.reserve((size_t)per_block * 160); b->qual.reserve((size_t)per_block * 160);
+		return b;
+	}
+	/* everything `rd` holds, as blocks of up to per_block records through `sink`; true when the stream ended in the middle of a record */
+	template <class F> bool drain(fq_reader_t &rd, int per_block, F sink)
+	{
+		for (;;) {
+			blk_t b = fresh(per_block);
+			int rc = 0;
+			while (b->n < per_block && (rc = rd.next(*b)) >= 0) {}
+			if (rc == -2) b->err = -2;
+			const bool last = rc < 0;
+			if (b->n || b->err) sink(std::move(b));
+			if (last) return rc == -2 || rd.qual_eof;
+		}
+	}
+	/* A record may start at q (a line start): '@' line, a line that does not start with '@' '+' '>', a '+' line, a line as long as the
+	 * second one.  Only a hint -- parse_plain() proves every cut it uses. */
+	static bool looks_like_record(const unsigned char *p, size_t n, size_t q)
+	{
+		if (q >= n || p[q] != '@') return false;
+		size_t l[5]; l[0] = q;
+		for (int k = 1; k < 5; ++k) { const unsigned char *e = (const unsigned char*)memchr(p + l[k - 1], '\n', n - l[k - 1]); if (!e) return false; l[k] = (size_t)(e - p) + 1; }
+		if (l[2] - l[1] < 2 || p[l[1]] == '@' || p[l[1]] == '+' || p[l[1]] == '>' || p[l[2]] != '+') return false;
+		return l[4] - l[3] == l[2] - l[1] && (l[4] >= n || p[l[4]] == '@');
+	}
+	/* A plain (not compressed) regular file, parsed by several threads: the file is cut at lines that look like record starts, each
+	 * piece goes through the same kseq grammar as the serial reader (fq_reader_t over a byte range) and the pieces are handed on in
+	 * file order.  What makes this exact for ANY input, wrapped or malformed ones included: a piece that was entered at a true
+	 * record start and does not run out of bytes inside a quality string leaves the parser where the serial one would be (between
+	 * records, or after a sequence without quality -- and the next piece starts with '@' at a line start, which ends such a
+	 * sequence in the serial parser too).  The first piece starts at byte 0, so by induction every cut is a true record start as long
+	 * as no earlier piece ended inside a quality string; the first piece that does (a '@' quality line was taken for a header, or
+	 * the file really is truncated there) is thrown away and the rest of the file is parsed serially from that piece's start. */
+	bool parse_plain(const std::string &path, bool keep_comment, int per_block)
+	{
+		size_t piece = (size_t)48 << 20; int T = 4;
+		{ const char *e = getenv("SSG_FASTQ_PIECE"); if (e && atol(e) > 0) piece = (size_t)atol(e); }
+		{ const char *e = getenv("SSG_FASTQ_THREADS"); if (e) T = atoi(e); }
+		if (T < 2) return false;
+		struct stat sb;
+		if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < 2 * piece) return false;
+		const int fd = open(path.c_str(), O_RDONLY);
+		if (fd < 0) return false;
+		unsigned char magic[2];
+		if (pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) { close(fd); return false; }   /* gzip: the inflating readers */
+		const size_t size = (size_t)sb.st_size;
+		std::vector<size_t> cut(1, 0);
+		{
+			std::vector<unsigned char> w((size_t)256 << 10);
+			for (size_t pos = piece; pos < size; pos += piece) {
+				const ssize_t r = pread(fd, w.data(), w.size(), (off_t)pos);
+				if (r <= 0) break;
+				const size_t n = (size_t)r;
+				const unsigned char *e = (const unsigned char*)memchr(w.data(), '\n', n);
+				while (e) {
+					const size_t q = (size_t)(e - w.data()) + 1;
+					if (looks_like_record(w.data(), n, q)) { if (pos + q > cut.back()) cut.push_back(pos + q); break; }
+					e = q < n ? (const unsigned char*)memchr(w.data() + q, '\n', n - q) : 0;
+				}
+			}
+			cut.push_back(size);
+		}
+		const int np = (int)cut.size() - 1;
+		if (np < 2) { close(fd); return false; }
+		std::mutex mu; std::condition_variable cv; int next = 0, delivered = 0; bool abort = false;
+		const int window = 2 * T;
+		auto work = [&]() {
+			for (;;) {
+				int i;
+				{ std::unique_lock<std::mutex> l(mu); i = next++; if (i >= np) return; cv.wait(l, [&] { return abort || i < delivered + window; }); if (abort) return; }
+				std::vector<blk_t> out;
+				fq_reader_t rd(fd, cut[(size_t)i], cut[(size_t)i + 1], keep_comment);
+				const bool cut_short = drain(rd, per_block, [&](blk_t b) { out.push_back(std::move(b)); });
+				{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return abort || delivered == i; }); if (abort) return; }
+				if (cut_short && i + 1 < np) {
+					{ std::lock_guard<std::mutex> l(mu); abort = true; cv.notify_all(); }
+					if (getenv("SSG_DEBUG")) fprintf(stderr, "[fastq] %s: not one record per four lines near byte %zu; one thread from there\n", path.c_str(), cut[(size_t)i + 1]);
+					out.clear();
+					fq_reader_t rest(fd, cut[(size_t)i], size, keep_comment);
+					(void)drain(rest, per_block, [&](blk_t b) { ch.push(std::move(b)); });
+					return;
+				}
+				for (blk_t &b : out) ch.push(std::move(b));
+				{ std::lock_guard<std::mutex> l(mu); delivered = i + 1; cv.notify_all(); }
+			}
+		};
+		std::vector<std::thread> w;
+		for (int t = 0; t < std::min(T, np); ++t) w.emplace_back(work);
+		for (std::thread &x : w) x.join();
+		close(fd);
+		return true;
+	}
 	fq_feed_t(gzFile fp, bool keep_comment, int per_block, const char *path = 0) : ch(4), pool(new fq_block_pool_t())
 	{
 		const std::string pth(path ? path : "");
 		th = std::thread([this, fp, keep_comment, per_block, pth]() {
-			fq_reader_t rd(fp, keep_comment, pth.empty() ? 0 : pth.c_str());
-			for (;;) {
-				std::shared_ptr<fq_block_pool_t> pl = pool;
-				std::shared_ptr<fq_block_t> b(pl->get(), [pl](fq_block_t *x) { pl->put(x); });
-				b->txt.reserve((size_t)per_block * 48); b->seq.reserve((size_t)per_block * 160); b->qual.reserve((size_t)per_block * 160);
-				int rc = 0;
-				while (b->n < per_block && (rc = rd.next(*b)) >= 0) {}
-				if (rc == -2) b->err = -2;
-				const bool last = rc < 0;
-				if (b->n || b->err) ch.push(std::move(b));
-				if (last) break;
+			if (pth.empty() || !parse_plain(pth, keep_comment, per_block)) {
+				fq_reader_t rd(fp, keep_comment, pth.empty() ? 0 : pth.c_str());
+				(void)drain(rd, per_block, [this](blk_t b) { ch.push(std::move(b)); });
 			}
 			ch.close();
 		});

@@ -1,0 +1,122 @@
+"""bin/bwa's several-thread reader of plain FASTQ files (speedseq_amd/host/fastq.h, fq_feed_t::parse_plain) against its one-thread
+reader on the same bytes: the records and the end state (EOF / truncated) must be the same for ANY input, because every piece runs
+the kseq grammar (htslib-1.3.1/htslib/kseq.h:189-229) and a cut that turns out not to be a record start sends the rest of the
+file through one thread."""
+import os
+import random
+import subprocess
+
+import pytest
+
+from common import ROOT
+
+FQ_DUMP = os.path.join(ROOT, "tests", "emu", "fq_dump")
+
+
+def dump(path, threads, piece=None):
+    env = dict(os.environ, SSG_FASTQ_THREADS=str(threads), SSG_DEBUG="1")
+    if piece:
+        env["SSG_FASTQ_PIECE"] = str(piece)
+    r = subprocess.run([FQ_DUMP, path], env=env, capture_output=True, check=True)
+    return r.stdout, r.stderr.decode()
+
+
+def four_line(rng, n, nl="\n", qual_chars="@+>ABCDEFGHIJ!~", var_len=True):
+    out = []
+    for i in range(n):
+        l = rng.randint(1, 160) if var_len else 100
+        out.append("@r%d%s%s%s%s+%s%s%s" % (i, rng.choice(["", "/1", " c:x", "\tBC:Z:AC"]), nl,
+                                             "".join(rng.choices("ACGTNacgt", k=l)), nl,
+                                             rng.choice(["", "r%d" % i]) + nl, "".join(rng.choices(qual_chars, k=l)), nl))
+    return "".join(out)
+
+
+def wrapped(rng, n, width):
+    """multi-line FASTQ: sequence and quality wrapped at `width`; quality lines begin with '@' and '+' often"""
+    out = []
+    for i in range(n):
+        l = rng.randint(1, 4 * width)
+        s = "".join(rng.choices("ACGT", k=l))
+        q = "".join(rng.choices("@+I", k=l))
+        out.append("@w%d\n" % i)
+        out += [s[k:k + width] + "\n" for k in range(0, l, width)]
+        out.append("+\n")
+        out += [q[k:k + width] + "\n" for k in range(0, l, width)]
+    return "".join(out)
+
+
+CASES = {
+    "four_line": lambda rng: four_line(rng, 3000),
+    "fixed_len": lambda rng: four_line(rng, 3000, var_len=False),
+    "crlf": lambda rng: four_line(rng, 2000, nl="\r\n"),
+    "wrapped": lambda rng: wrapped(rng, 1500, 20),
+    "wrapped_after_clean": lambda rng: four_line(rng, 1500) + wrapped(rng, 800, 17) + four_line(rng, 500),
+    "fasta_mix": lambda rng: four_line(rng, 500) + "".join(">f%d d\n%s\n" % (i, "ACGTTGCA" * rng.randint(1, 9)) for i in range(700)) + four_line(rng, 500),
+    "junk_between": lambda rng: "".join(four_line(rng, 1) + rng.choice(["", "\n", "junk line\n", "\n\n"]) for _ in range(2000)),
+    "truncated_middle": lambda rng: four_line(rng, 1000) + "@bad\nACGTACGT\n+\nIIII\n" + four_line(rng, 1000),
+    "truncated_end": lambda rng: four_line(rng, 2000) + "@bad\nACGTACGT\n+\nIIII",
+    "no_final_newline": lambda rng: four_line(rng, 2000)[:-1],
+    "empty_reads": lambda rng: "".join(four_line(rng, 1) + rng.choice(["", "@e\n\n+\n\n"]) for _ in range(2000)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("piece", [257, 4096, 50000])
+def test_same_records_as_one_thread(tmp_path, case, piece):
+    rng = random.Random(hash((case, piece)) & 0xffff)
+    p = tmp_path / "x.fq"
+    p.write_text(CASES[case](rng))
+    ref, _ = dump(str(p), 1)
+    got, _ = dump(str(p), 4, piece)
+    assert ref.splitlines()[-1].startswith(b"end\t")
+    assert got == ref
+    got3, _ = dump(str(p), 3, piece + 13)
+    assert got3 == ref
+
+
+def test_fallback_is_taken_and_reported(tmp_path):
+    """a wrapped file whose quality lines look like headers: some cut lands inside a quality string and the reader says so"""
+    rng = random.Random(5)
+    p = tmp_path / "w.fq"
+    out = []
+    for i in range(3000):   # every wrapped quality line is a perfect fake record start: '@' line, bases-like line, '+' line, same length
+        out.append("@w%d\nACGTACGT\nACGTACGT\nACGTACGT\nACGTACGT\n+\n@CGTACGT\nACGTACGT\n+CGTACGT\nACGTACGT\n" % i)
+    p.write_text("".join(out))
+    ref, _ = dump(str(p), 1)
+    got, err = dump(str(p), 4, 1000)
+    assert got == ref
+    assert "one thread from there" in err
+    assert ref.splitlines()[-1] == b"end\t-1\t3000"
+
+
+def test_gzip_and_small_files_use_the_serial_reader(tmp_path):
+    import gzip
+    rng = random.Random(9)
+    txt = four_line(rng, 500)
+    p = tmp_path / "s.fq"
+    p.write_text(txt)
+    g = tmp_path / "s.fq.gz"
+    with gzip.open(g, "wt") as f:
+        f.write(txt)
+    a, _ = dump(str(p), 4)            # smaller than two default pieces
+    b, _ = dump(str(g), 4, 300)       # gzip magic
+    assert a == b
+
+
+def test_bwa_emu_same_sam_with_pieces(tmp_path, emu_lib):
+    """bin/bwa (emulation build) on two plain files: the SAM text does not depend on how the files were cut"""
+    import simreads
+    from common import EXAMPLE_FA
+    bwa = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    contigs = simreads.read_fasta(EXAMPLE_FA)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    simreads.write_fastq(f1, simreads.simulate(contigs, 400, seed=77), interleaved=False, path2=f2)
+    outs = []
+    for threads, piece in ((1, None), (4, 3000), (3, 777)):
+        env = dict(os.environ, SSG_FASTQ_THREADS=str(threads))
+        if piece:
+            env["SSG_FASTQ_PIECE"] = str(piece)
+        r = subprocess.run([bwa, "mem", "-t", "4", EXAMPLE_FA, f1, f2], env=env, capture_output=True, check=True)
+        outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
+    assert outs[0].count(b"\n") > 800
+    assert outs[1] == outs[0] and outs[2] == outs[0]
