@@ -28,9 +28,11 @@
 #include <sys/stat.h>
 
 template <class T> struct chan_t {      /* bounded single-producer / single-consumer channel */
-	std::mutex mu; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed;
-	explicit chan_t(size_t cap_ = 2) : cap(cap_), closed(false) {}
-	void push(T v) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(v)); cv.notify_all(); }
+	std::mutex mu; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed, dead;
+	explicit chan_t(size_t cap_ = 2) : cap(cap_), closed(false), dead(false) {}
+	void push(T v) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return q.size() < cap || dead; }); if (dead) return; q.push_back(std::move(v)); cv.notify_all(); }
+	void abandon() { std::lock_guard<std::mutex> l(mu); dead = true; q.clear(); cv.notify_all(); }   /* the consumer is gone: producers must not wait for it */
+	bool is_dead() { std::lock_guard<std::mutex> l(mu); return dead; }
 	bool pop(T &v) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
 	void close() { std::lock_guard<std::mutex> l(mu); closed = true; cv.notify_all(); }
 };
@@ -276,6 +278,7 @@ struct fq_feed_t {
 			const bool last = rc < 0;
 			if (b->n || b->err) sink(std::move(b));
 			if (last) return rc == -2 || rd.qual_eof;
+			if (ch.is_dead()) return false;
 		}
 	}
 	/* A record may start at q (a line start): '@' line, a line that does not start with '@' '+' '>', a '+' line, a line as long as the
@@ -333,6 +336,7 @@ struct fq_feed_t {
 			for (;;) {
 				int i;
 				{ std::unique_lock<std::mutex> l(mu); i = next++; if (i >= np) return; cv.wait(l, [&] { return abort || i < delivered + window; }); if (abort) return; }
+				if (ch.is_dead()) { std::lock_guard<std::mutex> l(mu); abort = true; cv.notify_all(); return; }
 				std::vector<blk_t> out;
 				fq_reader_t rd(fd, cut[(size_t)i], cut[(size_t)i + 1], keep_comment);
 				const bool cut_short = drain(rd, per_block, [&](blk_t b) { out.push_back(std::move(b)); });
@@ -366,7 +370,7 @@ struct fq_feed_t {
 			ch.close();
 		});
 	}
-	~fq_feed_t() { if (th.joinable()) th.join(); }
+	~fq_feed_t() { ch.abandon(); if (th.joinable()) th.join(); }
 };
 
 /* sequential view over a feed: one record at a time */

@@ -61,6 +61,14 @@ def test_cli_error_behaviour(tmp_path, emu_lib):
     assert r.returncode != 0 and b"not started with @RG" in r.stderr
     r = subprocess.run([emu, "mem", "-p", EXAMPLE_FA + ".missing", "/dev/null"], capture_output=True)
     assert r.returncode != 0
+    # the readers are already running when the index fails to load: more records than their channel holds must not keep the process alive
+    big = tmp_path / "many.fq"
+    big.write_text("".join("@r%d\nACGT\n+\nIIII\n" % i for i in range(200000)))
+    r = subprocess.run([emu, "mem", "-p", EXAMPLE_FA + ".missing", str(big)], capture_output=True, timeout=60)
+    assert r.returncode != 0 and b"fail to load the index" in r.stderr
+    for env in ({"SSG_FASTQ_THREADS": "4", "SSG_FASTQ_PIECE": "20000"}, {}):
+        r = subprocess.run([emu, "mem", EXAMPLE_FA + ".missing", str(big), str(big)], capture_output=True, timeout=60, env=dict(os.environ, **env))
+        assert r.returncode != 0 and b"fail to load the index" in r.stderr
 
 
 @pytest.mark.gpu
