@@ -140,6 +140,7 @@ static int main_mem(int argc, char **argv)
 #ifdef F_SETPIPE_SZ
 	(void)fcntl(1, F_SETPIPE_SZ, 1 << 20);   /* fewer wake-ups on the pipe to samblaster */
 #endif
+	if (fused) fu_seg_sweep();
 	if (fused) { if (!fu_write_full(1, FU_MAGIC, 8) || !fu_write_frame(1, FU_HEADER, hdr.data(), hdr.size())) { perror("[bwa] write"); return 1; } }
 	else if (!fu_write_full(1, hdr.data(), hdr.size())) { perror("[bwa] write"); return 1; }
 
@@ -255,11 +256,17 @@ static int main_mem(int argc, char **argv)
 		}
 		to_fmt.worker_done();
 	});
-	struct text_t { char *p; size_t len; uint32_t frame; };   /* frame: 0 = raw bytes, otherwise the fused frame type to wrap them in */
+	struct text_t { char *p; size_t len; uint32_t frame; fu_buf_t *seg; std::string *seg_path; };   /* frame: 0 = raw bytes, otherwise the fused frame type to wrap them in; seg: the payload sits in a mapped segment (fused.h REF) */
 	chan_t<text_t> to_write(4);
 	std::thread t_write([&]() {   /* stdout is a pipe in the reference's pipeline: its reader sets the pace, so writing gets its own thread */
 		text_t t;
 		while (to_write.pop(t)) {
+			if (t.seg) {
+				if (fail) { t.seg->reset(); unlink(t.seg_path->c_str()); }
+				else if (!fu_seg_send(1, t.frame, *t.seg, *t.seg_path)) { perror("[bwa] write"); fail = 1; }
+				delete t.seg; delete t.seg_path;
+				continue;
+			}
 			if (!fail && !(t.frame ? fu_write_frame(1, t.frame, t.p, t.len) : fu_write_full(1, t.p, t.len))) { perror("[bwa] write"); fail = 1; }
 			ssg_free(t.p);
 		}
@@ -272,7 +279,7 @@ static int main_mem(int argc, char **argv)
 			if (fail) { if (B->res) ssg_pe_result_free(B->res); continue; }
 			const double t0 = wall();
 			const int n = B->n();
-			text_t t; t.p = 0; t.len = 0; t.frame = 0;
+			text_t t; t.p = 0; t.len = 0; t.frame = 0; t.seg = 0; t.seg_path = 0;
 			sam_off.resize((size_t)n + 1);
 			if (!fused) {
 				char *sam;
@@ -297,7 +304,9 @@ static int main_mem(int argc, char **argv)
 				for (int p = 0; p < n / 2; ++p) rec0[(size_t)p + 1] = rec0[(size_t)p] + nmain[2 * (size_t)p] + nmain[2 * (size_t)p + 1];
 				fu_batch_t bh; bh.n_rec = (uint64_t)rec0[(size_t)n / 2]; bh.bam_bytes = (uint64_t)bam_off[(size_t)n]; bh.n_cand = cand.size(); bh.text_bytes = (uint64_t)c_off[2 * cand.size()];
 				t.len = sizeof(bh) + cand.size() * sizeof(fu_cand_t) + (size_t)bh.text_bytes + (size_t)bh.bam_bytes; t.frame = FU_BATCH;
-				t.p = (char*)malloc(t.len ? t.len : 1);
+				{	std::unique_ptr<fu_buf_t> sg(new fu_buf_t()); std::unique_ptr<std::string> sp(new std::string());
+					if (fu_seg_create(t.len, *sg, *sp)) { t.seg = sg.release(); t.seg_path = sp.release(); t.p = (char*)t.seg->p; }
+					else t.p = (char*)malloc(t.len ? t.len : 1); }
 				if (!t.p) { fprintf(stderr, "[bwa] out of memory\n"); fail = 1; ssg_pe_result_free(B->res); continue; }
 				char *w = t.p; memcpy(w, &bh, sizeof(bh)); w += sizeof(bh);
 				for (size_t k = 0; k < cand.size(); ++k) { fu_cand_t c; c.first_rec = (uint64_t)rec0[(size_t)cand[k]]; c.n_rec = (uint64_t)(rec0[(size_t)cand[k] + 1] - rec0[(size_t)cand[k]]); c.text_off = (uint64_t)c_off[2 * k]; memcpy(w, &c, sizeof(c)); w += sizeof(c); }
@@ -319,7 +328,7 @@ static int main_mem(int argc, char **argv)
 			to_write.push(t);
 		}
 	}
-	if (fused && !fail) { text_t t; t.p = 0; t.len = 0; t.frame = FU_END; t.p = (char*)malloc(1); to_write.push(t); }
+	if (fused && !fail) { text_t t; t.len = 0; t.frame = FU_END; t.seg = 0; t.seg_path = 0; t.p = (char*)malloc(1); to_write.push(t); }
 	to_write.close(); t_write.join();
 	t_asm.join(); for (std::thread &x : t_gpu) x.join();
 	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> %s %.2f s\n", t_loaded - t_start, fused ? "BAM records (fused)" : "SAM", wall() - t_loaded);

@@ -17,6 +17,12 @@
  *   BATCH   bwa -> samblaster: fu_batch_t, candidate table, candidate text, BAM records
  *   MAIN    samblaster -> sort: BAM records (block_size-prefixed, htslib sam.c:443-473)
  *   END     no payload
+ *   REF     the payload of a BATCH / MAIN frame lives in a file on a memory file system instead of travelling through the pipe:
+ *           fu_ref_t (the frame's own type and payload size) followed by the path.  The writer fills the mapped file with several
+ *           threads and sends only this note; the reader maps the file and unlinks it at once, so the pages go away with the last
+ *           mapping.  A pipe moves ~1 GB/s through one thread on each side, and the reference's pipeline has three of them in a
+ *           row on the main stream; at several hundred MB per device call that was the pace of the whole fused pipeline.
+ *           Directory: SSG_FUSED_SHM (default /dev/shm; "0" or an unusable directory = payloads through the pipe as before).
  */
 #ifndef SSG_FUSED_H
 #define SSG_FUSED_H
@@ -25,10 +31,23 @@
 #include <stdlib.h>
 #include <errno.h>
 #include <unistd.h>
+#include <stdio.h>
+#include <fcntl.h>
+#include <time.h>
+#include <signal.h>
+#include <dirent.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/statvfs.h>
+#include <string>
+#include <atomic>
 
 #define FU_MAGIC "SSGFUSE1"
-enum { FU_HEADER = 1, FU_BATCH = 2, FU_MAIN = 3, FU_END = 4 };
+enum { FU_HEADER = 1, FU_BATCH = 2, FU_MAIN = 3, FU_END = 4, FU_REF = 5 };
 struct fu_frame_t { uint32_t type, zero; uint64_t len; };
+struct fu_ref_t { uint32_t type, zero; uint64_t len; };   /* REF payload: this, then the path of the file holding the `len` payload bytes */
+#define FU_SEG_PREFIX "ssgfuse."
+static inline size_t fu_seg_min() { const char *e = getenv("SSG_FUSED_SHM_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)1 << 20; }   /* smaller payloads go through the pipe */
 /* BATCH payload: fu_batch_t | fu_cand_t[n_cand] | text[text_bytes] | bam[bam_bytes].  A candidate names its first record (ordinal within
  * the batch) and owns text[text_off .. next candidate's text_off): the SAM lines of those records, one per record, in order. */
 struct fu_batch_t { uint64_t n_rec, bam_bytes, n_cand, text_bytes; };
@@ -51,5 +70,114 @@ static inline bool fu_write_frame(int fd, uint32_t type, const void *payload, ui
 {
 	fu_frame_t f; f.type = type; f.zero = 0; f.len = len;
 	return fu_write_full(fd, &f, sizeof(f)) && (!len || fu_write_full(fd, payload, (size_t)len));
+}
+
+/* payload of one frame: heap memory (capacity kept when reused) or a mapped segment */
+struct fu_buf_t {
+	uint8_t *p; size_t len, cap; bool mapped;
+	fu_buf_t() : p(0), len(0), cap(0), mapped(false) {}
+	fu_buf_t(fu_buf_t &&o) : p(o.p), len(o.len), cap(o.cap), mapped(o.mapped) { o.p = 0; o.len = o.cap = 0; o.mapped = false; }
+	fu_buf_t &operator=(fu_buf_t &&o) { if (this != &o) { reset(); p = o.p; len = o.len; cap = o.cap; mapped = o.mapped; o.p = 0; o.len = o.cap = 0; o.mapped = false; } return *this; }
+	fu_buf_t(const fu_buf_t&) = delete; fu_buf_t &operator=(const fu_buf_t&) = delete;
+	~fu_buf_t() { reset(); }
+	void reset() { if (p) { if (mapped) munmap(p, cap); else free(p); } p = 0; len = cap = 0; mapped = false; }
+	bool heap(size_t n)                                   /* n bytes of heap memory, contents undefined */
+	{
+		if (mapped) reset();
+		if (cap < n) { free(p); cap = n + n / 8; p = (uint8_t*)malloc(cap ? cap : 1); if (!p) { cap = 0; return false; } }
+		len = n; return true;
+	}
+};
+
+/* directory for segments, or NULL when they are switched off */
+static inline const char *fu_seg_dir()
+{
+	const char *e = getenv("SSG_FUSED_SHM");
+	if (!e) return "/dev/shm";
+	return (*e && strcmp(e, "0")) ? e : 0;
+}
+/* a fresh segment of `len` bytes, mapped for writing; false = send the payload through the pipe instead */
+static inline bool fu_seg_create(size_t len, fu_buf_t &b, std::string &path)
+{
+	const char *dir = fu_seg_dir();
+	if (!dir || len < fu_seg_min()) return false;
+	struct statvfs vs;
+	if (statvfs(dir, &vs) != 0 || (double)vs.f_bavail * (double)vs.f_frsize < 2.0 * (double)len + 1073741824.0) return false;   /* a full tmpfs is a SIGBUS, not an error code */
+	static std::atomic<unsigned long> seq(0);
+	char nm[96]; snprintf(nm, sizeof(nm), "/" FU_SEG_PREFIX "%ld.%lu", (long)getpid(), seq.fetch_add(1));
+	path = std::string(dir) + nm;
+	const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_CLOEXEC, 0600);
+	if (fd < 0) return false;
+	void *m = ftruncate(fd, (off_t)len) == 0 ? mmap(0, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+	close(fd);
+	if (m == MAP_FAILED) { unlink(path.c_str()); return false; }
+	b.reset(); b.p = (uint8_t*)m; b.len = b.cap = len; b.mapped = true;
+	return true;
+}
+/* hand a filled segment to the reader of `fd` as a frame of `type`; the mapping is released here */
+static inline bool fu_seg_send(int fd, uint32_t type, fu_buf_t &b, const std::string &path)
+{
+	fu_ref_t r; r.type = type; r.zero = 0; r.len = b.len;
+	std::string pl((const char*)&r, sizeof(r)); pl += path;
+	b.reset();
+	if (fu_write_frame(fd, FU_REF, pl.data(), pl.size())) return true;
+	unlink(path.c_str());
+	return false;
+}
+/* next frame of the stream: h = its type and payload size, b = the payload (heap, or the mapped segment of a REF frame) */
+static inline bool fu_read_frame(int fd, fu_frame_t &h, fu_buf_t &b)
+{
+	if (!fu_read_full(fd, &h, sizeof(h))) return false;
+	if (h.type != FU_REF) { if (!b.heap((size_t)h.len)) return false; return !h.len || fu_read_full(fd, b.p, (size_t)h.len); }
+	if (h.len <= sizeof(fu_ref_t) || h.len > sizeof(fu_ref_t) + 4096) return false;
+	std::string pl((size_t)h.len, '\0');
+	if (!fu_read_full(fd, &pl[0], pl.size())) return false;
+	fu_ref_t r; memcpy(&r, pl.data(), sizeof(r));
+	const std::string path = pl.substr(sizeof(r));
+	const size_t sl = path.rfind('/');
+	if (path.compare(sl == std::string::npos ? 0 : sl + 1, strlen(FU_SEG_PREFIX), FU_SEG_PREFIX) != 0 || r.type == FU_REF) return false;   /* only files this protocol made are opened and unlinked */
+	const int sfd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+	if (sfd < 0) return false;
+	struct stat sb;
+	void *m = (fstat(sfd, &sb) == 0 && (uint64_t)sb.st_size >= r.len && r.len) ? mmap(0, (size_t)r.len, PROT_READ, MAP_SHARED, sfd, 0) : MAP_FAILED;
+	close(sfd); unlink(path.c_str());
+	if (m == MAP_FAILED) return false;
+	b.reset(); b.p = (uint8_t*)m; b.len = b.cap = (size_t)r.len; b.mapped = true;
+	h.type = r.type; h.len = r.len;
+	return true;
+}
+/* after a broken frame: unlink the segments the rest of the stream names (best effort; stops at the first thing that is not a frame) */
+static inline void fu_discard_rest(int fd)
+{
+	std::string pl; char sink[65536];
+	for (;;) {
+		fu_frame_t h;
+		if (!fu_read_full(fd, &h, sizeof(h)) || h.type < FU_HEADER || h.type > FU_REF || h.zero) return;
+		if (h.type == FU_REF) {
+			if (h.len <= sizeof(fu_ref_t) || h.len > sizeof(fu_ref_t) + 4096) return;
+			pl.resize((size_t)h.len);
+			if (!fu_read_full(fd, &pl[0], pl.size())) return;
+			const std::string path = pl.substr(sizeof(fu_ref_t));
+			const size_t sl = path.rfind('/');
+			if (path.compare(sl == std::string::npos ? 0 : sl + 1, strlen(FU_SEG_PREFIX), FU_SEG_PREFIX) == 0) unlink(path.c_str());
+		} else for (uint64_t left = h.len; left; ) { const size_t k = (size_t)(left < sizeof(sink) ? left : sizeof(sink)); if (!fu_read_full(fd, sink, k)) return; left -= k; }
+		if (h.type == FU_END) return;
+	}
+}
+/* segments left behind by a pipeline that died between a writer's send and its reader's open: removed when their writer is gone and
+ * they are older than an hour (a live pipeline's writer may exit before its last segments are read) */
+static inline void fu_seg_sweep()
+{
+	const char *dir = fu_seg_dir(); if (!dir) return;
+	DIR *d = opendir(dir); if (!d) return;
+	const time_t now = time(0);
+	while (struct dirent *e = readdir(d)) {
+		if (strncmp(e->d_name, FU_SEG_PREFIX, strlen(FU_SEG_PREFIX)) != 0) continue;
+		const long pid = atol(e->d_name + strlen(FU_SEG_PREFIX));
+		const std::string p = std::string(dir) + "/" + e->d_name;
+		struct stat sb;
+		if (pid > 0 && stat(p.c_str(), &sb) == 0 && now - sb.st_mtime > 3600 && kill((pid_t)pid, 0) != 0 && errno == ESRCH) unlink(p.c_str());
+	}
+	closedir(d);
 }
 #endif

@@ -152,15 +152,15 @@ static void change_so(std::string &text, const char *so)
 /* records of the input, held in the chunks they arrived in (a fused frame, or ~64 MB assembled from the BGZF stream): nothing is
  * copied or re-allocated while the input streams in; a record is (chunk << 40 | offset of its block_size word) */
 struct rec_store_t {
-	std::vector<std::unique_ptr<uint8_t[]> > chunk; std::vector<size_t> chunk_len;
+	std::vector<fu_buf_t> chunk; std::vector<size_t> chunk_len;        /* heap memory, or the mapped segment a fused frame arrived in (fused.h) */
 	std::vector<uint64_t> loc, key; uint64_t bytes;
 	rec_store_t() : bytes(0) {}
-	const uint8_t *rec(size_t i) const { return chunk[(size_t)(loc[i] >> 40)].get() + (loc[i] & (((uint64_t)1 << 40) - 1)); }
+	const uint8_t *rec(size_t i) const { return chunk[(size_t)(loc[i] >> 40)].p + (loc[i] & (((uint64_t)1 << 40) - 1)); }
 	void clear() { chunk.clear(); chunk_len.clear(); loc.clear(); key.clear(); bytes = 0; }
 	/* index the whole records of chunk c[0..len) */
-	bool add_chunk(std::unique_ptr<uint8_t[]> c, size_t len)
+	bool add_chunk(fu_buf_t c, size_t len)
 	{
-		const uint64_t id = chunk.size(); const uint8_t *p = c.get(); size_t o = 0;
+		const uint64_t id = chunk.size(); const uint8_t *p = c.p; size_t o = 0;
 		while (o + 4 <= len) { uint32_t bs; memcpy(&bs, p + o, 4); if (o + 4 + (size_t)bs > len || bs < 32) return false; loc.push_back(id << 40 | (uint64_t)o); key.push_back(bam_sort_key(p + o + 4)); o += 4 + (size_t)bs; }
 		if (o != len) return false;
 		chunk.push_back(std::move(c)); chunk_len.push_back(len); bytes += len;
@@ -335,30 +335,32 @@ static int cmd_sort(int argc, char **argv)
 	if (fused) {
 		/* frames straight from samblaster (fused.h): a reader thread takes them off the pipe, this thread indexes the records (keys +
 		 * locations) of each while the next arrives -- the sort's input work overlaps the alignment upstream */
-		struct frame_t { fu_frame_t fh; std::unique_ptr<uint8_t[]> p; };
+		struct frame_t { fu_frame_t fh; fu_buf_t p; };
 		chan_t<std::unique_ptr<frame_t> > ch(2); std::atomic<int> rd_fail(0);
 		std::thread reader([&]() {
 			for (;;) {
 				std::unique_ptr<frame_t> F(new frame_t());
-				if (!fu_read_full(fd, &F->fh, sizeof(F->fh))) { rd_fail = 1; break; }
-				if (F->fh.len) { F->p.reset(new uint8_t[F->fh.len]); if (!fu_read_full(fd, F->p.get(), (size_t)F->fh.len)) { rd_fail = 1; break; } }
+				if (!fu_read_frame(fd, F->fh, F->p)) { rd_fail = 1; fu_discard_rest(fd); break; }
 				const bool end = F->fh.type == FU_END;
 				ch.push(std::move(F));
 				if (end) break;
 			}
 			ch.close();
 		});
-		std::unique_ptr<frame_t> F; bool ended = false;
-		while (ch.pop(F)) {
+		std::unique_ptr<frame_t> F; bool ended = false; double t_wait = 0, t_index = 0; const char *bad = 0;
+		for (;;) {
+			{ const double t0 = wall(); const bool got = ch.pop(F); t_wait += wall() - t0; if (!got) break; }
 			if (F->fh.type == FU_END) { ended = true; break; }
-			if (F->fh.type == FU_HEADER) { h.text.assign((const char*)F->p.get(), (size_t)F->fh.len); hdr_from_text(h); change_so(h.text, "coordinate"); continue; }
-			if (F->fh.type != FU_MAIN) die("sort: unexpected frame in the fused stream");
+			if (F->fh.type == FU_HEADER) { h.text.assign((const char*)F->p.p, (size_t)F->fh.len); hdr_from_text(h); change_so(h.text, "coordinate"); continue; }
+			if (F->fh.type != FU_MAIN) { bad = "sort: unexpected frame in the fused stream"; break; }
 			if (!F->fh.len) continue;
-			if (!S.add_chunk(std::move(F->p), (size_t)F->fh.len)) die("sort: malformed record frame");
+			{ const double t0 = wall(); if (!S.add_chunk(std::move(F->p), (size_t)F->fh.len)) { bad = "sort: malformed record frame"; break; } t_index += wall() - t0; }
 			if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill();
 		}
+		if (dbg()) fprintf(stderr, "[sambamba] sort: input thread waited %.2f s for frames, indexed records for %.2f s\n", t_wait, t_index);
 		{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
-		reader.join();
+		reader.join();                                           /* the rest of the stream was taken in (and its segments released) even after an error */
+		if (bad) die(bad);
 		if (rd_fail || !ended) die("sort: the fused stream ended early");
 		if (h.names.empty() && h.text.empty()) change_so(h.text, "coordinate");
 	} else {
@@ -367,17 +369,18 @@ static int cmd_sort(int argc, char **argv)
 		if (!hdr_read(bi, h)) die("sort: not a BAM file");
 		change_so(h.text, "coordinate");
 		const size_t CH = (size_t)64 << 20;
-		std::unique_ptr<uint8_t[]> cur(new uint8_t[CH]); size_t cap = CH, len = 0;
-		auto flush = [&]() { if (!len) return; if (!S.add_chunk(std::move(cur), len)) die("sort: malformed BAM record"); cur.reset(new uint8_t[CH]); cap = CH; len = 0; if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill(); };
+		fu_buf_t cur; size_t cap = CH, len = 0;
+		if (!cur.heap(CH)) die("sort: out of memory");
+		auto flush = [&]() { if (!len) return; if (!S.add_chunk(std::move(cur), len)) die("sort: malformed BAM record"); cap = CH; len = 0; if (!cur.heap(CH)) die("sort: out of memory"); if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill(); };
 		for (;;) {
 			uint32_t bs;
 			if (bi.get(&bs, 4) != 4) break;
 			if (len + 4 + (size_t)bs > cap) {
 				flush();
-				if (4 + (size_t)bs > cap) { cap = 4 + (size_t)bs; cur.reset(new uint8_t[cap]); }
+				if (4 + (size_t)bs > cap) { cap = 4 + (size_t)bs; if (!cur.heap(cap)) die("sort: out of memory"); }
 			}
-			memcpy(cur.get() + len, &bs, 4);
-			if (bi.get(cur.get() + len + 4, bs) != bs) die("sort: truncated BAM");
+			memcpy(cur.p + len, &bs, 4);
+			if (bi.get(cur.p + len + 4, bs) != bs) die("sort: truncated BAM");
 			len += 4 + (size_t)bs;
 		}
 		flush();

@@ -22,6 +22,7 @@
 #include <unordered_map>
 #include <memory>
 #include <thread>
+#include <chrono>
 #include <atomic>
 #include <algorithm>
 #include <functional>
@@ -131,20 +132,16 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	if (!fu_write_full(1, FU_MAGIC, 8)) { perror("[samblaster] write"); return 1; }
 	bool got_header = false, ended = false;
 	/* frames are read by a thread of their own so that the next batch arrives while this one is decided and written */
-	struct frame_t { fu_frame_t h; std::unique_ptr<uint8_t[]> p; size_t cap; frame_t() : cap(0) {} };
+	struct frame_t { fu_frame_t h; fu_buf_t b; };
 	chan_t<std::unique_ptr<frame_t> > ch(2); std::atomic<int> rd_fail(0);
-	/* frame buffers go back to the reader when a batch is done: hundreds of MB of warm memory instead of fresh pages per frame */
+	/* heap frame buffers go back to the reader when a batch is done: hundreds of MB of warm memory instead of fresh pages per frame */
 	std::mutex pool_mu; std::vector<std::unique_ptr<frame_t> > pool;
 	std::thread reader([&]() {
 		for (;;) {
 			std::unique_ptr<frame_t> F;
 			{ std::lock_guard<std::mutex> l(pool_mu); if (!pool.empty()) { F = std::move(pool.back()); pool.pop_back(); } }
 			if (!F) F.reset(new frame_t());
-			if (!fu_read_full(0, &F->h, sizeof(F->h))) { rd_fail = 1; break; }
-			if (F->h.len) {
-				if (F->cap < F->h.len) { F->p.reset(new uint8_t[F->h.len + F->h.len / 8]); F->cap = (size_t)(F->h.len + F->h.len / 8); }
-				if (!fu_read_full(0, F->p.get(), (size_t)F->h.len)) { rd_fail = 1; break; }
-			}
+			if (!fu_read_frame(0, F->h, F->b)) { rd_fail = 1; fu_discard_rest(0); break; }
 			const bool end = F->h.type == FU_END;
 			ch.push(std::move(F));
 			if (end) break;
@@ -156,23 +153,27 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	std::vector<std::vector<uint8_t> > outb;                  /* per-thread output of a batch, kept across batches */
 	std::unique_ptr<frame_t> F;
 	int rc = 0;
-	while (!rc && ch.pop(F)) {
+	double tm[6] = { 0, 0, 0, 0, 0, 0 };                     /* wait for a frame, numeric view, decisions, records rebuilt, main stream written, side streams */
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	for (;;) {
+		{ const double t0 = now(); const bool got = !rc && ch.pop(F); tm[0] += now() - t0; if (!got) break; }
 		if (F->h.type == FU_END) { ended = true; break; }
 		if (F->h.type == FU_HEADER) {
-			std::string h((const char*)F->p.get(), (size_t)F->h.len); h += pg;
+			std::string h((const char*)F->b.p, (size_t)F->h.len); h += pg;
 			if (!fu_write_frame(1, FU_HEADER, h.data(), h.size())) { perror("[samblaster] write"); rc = 1; break; }
 			if (spl) spl->put(h.data(), h.size());
 			if (disc) disc->put(h.data(), h.size());
 			got_header = true; continue;
 		}
 		if (F->h.type != FU_BATCH || F->h.len < sizeof(fu_batch_t)) { fprintf(stderr, "[samblaster] unexpected frame in the fused stream\n"); rc = 1; break; }
-		fu_batch_t bh; memcpy(&bh, F->p.get(), sizeof(bh));
+		fu_batch_t bh; memcpy(&bh, F->b.p, sizeof(bh));
 		if (sizeof(bh) + bh.n_cand * sizeof(fu_cand_t) + bh.text_bytes + bh.bam_bytes != F->h.len) { fprintf(stderr, "[samblaster] malformed batch frame\n"); rc = 1; break; }
-		const fu_cand_t *cand = (const fu_cand_t*)(F->p.get() + sizeof(bh));
+		const fu_cand_t *cand = (const fu_cand_t*)(F->b.p + sizeof(bh));
 		const char *text = (const char*)(cand + bh.n_cand);
 		const uint8_t *bam = (const uint8_t*)text + bh.text_bytes;
 		const size_t nr = (size_t)bh.n_rec;
 		if (!nr) continue;
+		double t0 = now();
 		rec_off.resize(nr + 1);
 		{ uint64_t o2 = 0; size_t i = 0; for (; i < nr && o2 + 4 <= bh.bam_bytes; ++i) { rec_off[i] = o2; uint32_t bs; memcpy(&bs, bam + o2, 4); o2 += 4 + (uint64_t)bs; } rec_off[nr] = o2;
 		  if (i != nr || o2 != bh.bam_bytes) { fprintf(stderr, "[samblaster] record count does not match the batch frame\n"); rc = 1; break; } }
@@ -198,8 +199,10 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 		blk_off.clear();
 		for (size_t i = 0; i < nr; ++i) if (newblk[i]) blk_off.push_back((int64_t)i);
 		const size_t n_blocks = blk_off.size(); blk_off.push_back((int64_t)nr);
+		tm[1] += now() - t0; t0 = now();
 		if (ssg_sbl_process(st, &o, (long)n_blocks, blk_off.data(), lines.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); rc = 1; break; }
 		/* main stream: the records with 0x400 and MC / MQ, rebuilt by threads over ranges of blocks, written in order as one frame */
+		tm[2] += now() - t0; t0 = now();
 		const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 4096 + 1));
 		if (outb.size() < (size_t)T) outb.resize((size_t)T);
 		for (auto &v : outb) v.clear();
@@ -233,11 +236,20 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 				}
 			}
 		});
-		{	uint64_t tot = 0; for (auto &v : outb) tot += v.size();
-			fu_frame_t fh; fh.type = FU_MAIN; fh.zero = 0; fh.len = tot;
-			bool ok = fu_write_full(1, &fh, sizeof(fh));
-			for (auto &v : outb) ok = ok && fu_write_full(1, v.data(), v.size());
+		tm[3] += now() - t0; t0 = now();
+		{	uint64_t tot = 0; std::vector<uint64_t> at(outb.size() + 1, 0);
+			for (size_t k = 0; k < outb.size(); ++k) { at[k] = tot; tot += outb[k].size(); }
+			fu_buf_t seg; std::string seg_path; bool ok;
+			if (fu_seg_create((size_t)tot, seg, seg_path)) {       /* the frame as a mapped segment: filled by the threads, only its name travels */
+				parallel_ranges((int)outb.size(), outb.size(), [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) if (!outb[k].empty()) memcpy(seg.p + at[k], outb[k].data(), outb[k].size()); });
+				ok = fu_seg_send(1, FU_MAIN, seg, seg_path);
+			} else {
+				fu_frame_t fh; fh.type = FU_MAIN; fh.zero = 0; fh.len = tot;
+				ok = fu_write_full(1, &fh, sizeof(fh));
+				for (auto &v : outb) ok = ok && fu_write_full(1, v.data(), v.size());
+			}
 			if (!ok) { perror("[samblaster] write"); rc = 1; break; } }
+		tm[4] += now() - t0; t0 = now();
 		/* side streams, from the text bwa attached for the pairs that can qualify */
 		ltext.assign(nr, std::pair<const char*, uint32_t>((const char*)0, 0u));
 		for (uint64_t c = 0; c < bh.n_cand; ++c) {
@@ -286,8 +298,11 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 				++n_spl;
 			}
 		}
+		if (F->b.mapped) F->b.reset();                           /* the segment's pages go back to the system now */
 		{ std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 3) pool.push_back(std::move(F)); }
+		tm[5] += now() - t0;
 	}
+	if (getenv("SSG_SBL_LOG")) fprintf(stderr, "[samblaster] main thread: waiting for frames %.2f s, numeric view %.2f s, decisions %.2f s, records %.2f s, main stream written %.2f s, side streams %.2f s\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
 	{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
 	reader.join();
 	if (!rc && (rd_fail || !ended)) { fprintf(stderr, "[samblaster] the fused stream ended early\n"); rc = 1; }

@@ -67,6 +67,69 @@ def test_fused_script_many_calls_two_devices_emulated(tmp_path, emu_lib):
     _same_bam_records(fused, text)
 
 
+@pytest.mark.parametrize("seg", ["segments", "pipe_only", "unusable_dir"])
+def test_fused_frames_as_mapped_segments_emulated(tmp_path, emu_lib, seg):
+    """fused.h REF frames: every BATCH / MAIN payload in a file of its own on a memory file system (here: forced for every frame, in a
+    directory of the test's), or all of them through the pipe (segments switched off / directory not usable) -- same three BAMs as
+    the text path, several device calls and a spilling sort included, and no segment is left behind"""
+    T._need_tools()
+    fq = T._fastq(tmp_path, 900)
+    tools = dict(sambamba=os.path.join(EMU, "sambamba_emu"))
+    small = {"SSG_BWA_CHUNK_BASES": "6000", "SSG_BWA_CALL_PAIRS": "150"}
+    segdir = tmp_path / "seg"
+    segdir.mkdir()
+    cfg = {"segments": "export SSG_FUSED_SHM=%s\nexport SSG_FUSED_SHM_MIN=1\n" % segdir,
+           "pipe_only": "export SSG_FUSED_SHM=0\n",
+           "unusable_dir": "export SSG_FUSED_SHM=%s/nowhere\nexport SSG_FUSED_SHM_MIN=1\n" % segdir}[seg]
+    text = T._run_align(str(tmp_path / "text"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, env_extra=small, **tools)
+    fused = T._run_align(str(tmp_path / "fused"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, config_extra=FUSED + cfg,
+                         env_extra=dict(small, SSG_SORT_CHUNK_BYTES="150000"), **tools)
+    _same_bam_records(fused, text)
+    assert os.listdir(str(segdir)) == []
+
+
+def test_fused_segment_frames_on_the_wire(tmp_path, emu_lib):
+    """what `bwa mem` writes with segments forced: REF frames naming files that exist until their reader maps them; `samblaster` consumes
+    and unlinks them, and its own MAIN frames arrive as segments at the next stage"""
+    fq = T._fastq(tmp_path, 300)
+    segdir = tmp_path / "seg"
+    segdir.mkdir()
+    env = dict(os.environ, SSG_FUSED="1", SSG_FUSED_SHM=str(segdir), SSG_FUSED_SHM_MIN="1", SSG_BWA_CHUNK_BASES="6000", SSG_BWA_CALL_PAIRS="100")
+    r = subprocess.run([os.path.join(EMU, "bwa_emu"), "mem", "-t", "2", "-p", "-R", "@RG\\tID:x\\tSM:x\\tLB:l", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def frames(buf):
+        assert buf[:8] == b"SSGFUSE1"
+        o, out = 8, []
+        while o < len(buf):
+            t, z, l = struct.unpack_from("<IIQ", buf, o)
+            out.append((t, buf[o + 16:o + 16 + l]))
+            o += 16 + l
+        return out
+    fr = frames(r.stdout)
+    assert fr[0][0] == 1 and fr[-1][0] == 4
+    refs = [f for f in fr if f[0] == 5]
+    assert len(refs) >= 3 and not any(f[0] == 2 for f in fr)
+    for _, pl in refs:
+        t, z, l = struct.unpack_from("<IIQ", pl, 0)
+        path = pl[16:].decode()
+        assert t == 2 and os.path.dirname(path) == str(segdir) and os.path.getsize(path) == l
+    r2 = subprocess.run([os.path.join(EMU, "samblaster_emu"), "--addMateTags"], input=r.stdout, capture_output=True, env=env, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    fr2 = frames(r2.stdout)
+    refs2 = [f for f in fr2 if f[0] == 5]
+    assert len(refs2) == len(refs) and not any(f[0] == 3 for f in fr2)
+    left = sorted(os.listdir(str(segdir)))
+    assert len(left) == len(refs2)                    # bwa's segments are gone, samblaster's wait for their reader
+    assert sorted(os.path.basename(pl[16:].decode()) for _, pl in refs2) == left
+    # a reader that finds a REF frame whose file is gone reports the stream as broken instead of waiting or crashing
+    os.remove(os.path.join(str(segdir), left[0]))
+    r3 = subprocess.run([os.path.join(EMU, "sambamba_emu"), "sort", "-t", "2", "-m", "1G", "--tmpdir", str(tmp_path / "t"), "-o", str(tmp_path / "o.bam"), "/dev/stdin"],
+                        input=r2.stdout, capture_output=True, env=env, timeout=900)
+    assert r3.returncode != 0 and b"ended early" in r3.stderr
+    assert os.listdir(str(segdir)) == []              # ... and releases the segments named by the rest of the stream
+
+
 def _bwa_sam(exe, d, fq, env):
     ref = os.path.join(d, "ref.fa")
     if not os.path.exists(ref + ".bwt"):
