@@ -315,7 +315,7 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
         return {"error": (r.stdout[-400:] + r.stderr[-400:])}
     sizes = {x: os.path.getsize(out + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
     ok = all(os.path.exists(out + x + ".bai") for x in sizes)
-    stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs"))]
+    stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs", "[samblaster] main thread", "[ssgpu] index load"))]
     return {"pairs": n_pairs, "threads": threads, "wall_s": round(t, 2), "pairs_per_s": n_pairs / t, "bam_bytes": sizes, "bai_written": ok, "out": out, "stage_log": stages}
 
 
@@ -336,7 +336,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     n_all = os.path.getsize(fq) // rec_bytes
     samtools = os.path.join(ROOT, "oracle", "_ref", "samtools")
     shim = os.path.join(ROOT, "tools", "sambamba_samtools_shim.sh")
-    host_cfg = "export SSG_SORT_THREADS=%d\nexport SSG_FMT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % (min(os.cpu_count() or 8, 128), min(os.cpu_count() or 8, 48))   # the script's -t sizes upstream's batches; the host pools are sized for the box
+    host_cfg = "export SSG_SORT_THREADS=%d\nexport SSG_FMT_THREADS=%d\nexport SSG_SORT_LOG=1\nexport SSG_SBL_LOG=1\nexport SSG_LOAD_LOG=1\n" % (min(os.cpu_count() or 8, 128), min(os.cpu_count() or 8, 48))   # the script's -t sizes upstream's batches; the host pools are sized for the box
     fused_cfg = "export SSG_FUSED=1\n" + host_cfg
     res = {"metric": "paired reads aligned+dup-marked/sec, FASTQ file -> out.bam + out.splitters.bam + out.discordants.bam (+ .bai), `speedseq align` wall clock incl. index load"}
 
@@ -422,6 +422,9 @@ def main():
     ap.add_argument("--emu-selftest", action="store_true", help="TEST INFRASTRUCTURE, never a measurement: walk this script's whole flow on the CPU with the host-emulation build "
                     "(tests/emu) and the bundled chr20 slice as the reference, at toy sizes -- catches a broken leg before it costs GPU minutes")
     ap.add_argument("--partial", default=os.path.join(ROOT, "gpurun_out", "bench_partial.json"), help="the line so far is also written here after every leg (a run that is cut short leaves its numbers)")
+    if "--emu-selftest" in sys.argv:                         # toy sizes unless given: the emulation runs the kernels lane by lane on the CPU
+        ap.set_defaults(pairs=600, steps=1, warmup=0, bwa_threads=1, e2e_pairs=1200, script_pairs=1200, script_threads=2, cpu_script_pairs=200, config5_pairs=300,
+                        no_profile=True, partial="/tmp/bench_emu_partial.json")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

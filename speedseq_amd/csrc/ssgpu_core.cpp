@@ -242,7 +242,7 @@ int ssg_index_load(const char *prefix, ssg_index_t **out)
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_seqs; ix->v.sa_intv = sa_intv;
 	ix->h_off = off; ix->h_len = len; ix->names = names;
 	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
-	if (ssg_debug()) {
+	if (ssg_debug() || getenv("SSG_LOAD_LOG")) {
 		const auto t_end = std::chrono::steady_clock::now();
 		fprintf(stderr, "[ssgpu] index load: files -> HBM %.3f s (%.2f GB), SA samples to every %d rows %.3f s\n", std::chrono::duration<double>(t_up - t_begin).count(),
 		        (double)(bwt_bytes + n_sa * 8 + pac_have) / 1e9, ix->v.sa_intv, std::chrono::duration<double>(t_end - t_up).count());
