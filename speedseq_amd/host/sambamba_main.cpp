@@ -206,6 +206,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	if (hdr_end < 0) bai_path = 0;
 	const size_t n = perm.size();
 	const int lvl = level < 0 ? 6 : level;
+	const double tw0 = wall();
 	/* virtual byte offsets of the sorted stream and the block cuts */
 	std::vector<uint64_t> cum(n + 1); cum[0] = 0;
 	parallel_for(threads, n, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) { uint32_t bs; memcpy(&bs, S.rec(perm[i]), 4); cum[i + 1] = 4 + (uint64_t)bs; } });
@@ -219,6 +220,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		}
 		if (cum[n] > cut.back()) cut.push_back(cum[n]);
 	}
+	const double tw1 = wall();
 	const size_t nb = cut.size() - 1, GRP = 128, ng = (nb + GRP - 1) / GRP;
 	struct grp_t { std::vector<uint8_t> bytes; std::vector<uint32_t> bsz; bool done; grp_t() : done(false) {} };
 	std::vector<uint64_t> blk_coff(bai_path ? nb + 1 : 0);      /* file offset of every block */
@@ -257,6 +259,8 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	}
 	for (auto &x : th) x.join();
 	io_write_all(fd, BGZF_EOF, 28);
+	const double tw2 = wall();
+	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s\n", tw1 - tw0, nb, tw2 - tw1);
 	if (!bai_path) return;
 	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets) */
 	blk_coff[nb] = coff;
@@ -275,6 +279,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	}
 	idx.finish(file_end);
 	idx.save(bai_path);
+	if (dbg()) fprintf(stderr, "[sambamba] sort: write: index %.2f s\n", wall() - tw2);
 }
 
 struct merge_src_t {   /* one coordinate-sorted BAM being merged */
