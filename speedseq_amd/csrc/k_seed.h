@@ -210,11 +210,20 @@ SSG_DEVFN ssg_intv_t ssg_unpk(const ssg_pk_t &p)
 #endif
 /* LPR = lanes per read: 4 (cooperative rank-block fetch) or 1 (each lane fetches whole blocks; 4x fewer wave instructions per read,
  * 4x more translation work per line -- see tools/dbg/gather_probe.cpp for where that starts to matter) */
+/* SSG_SMQ_PROBE (diagnostic builds only, tools/dbg/smem_variants.sh): two unused trailing arguments -- the kernarg layout of the round-3
+ * builds whose GPU results were wrong although nothing they execute differs */
+#ifdef SSG_SMQ_PROBE
+#define SSG_SMQ_EXTRA_PARAM , const void *probe_p, int probe_i
+#define SSG_SMQ_EXTRA_ARG , (const void*)0, 0
+#else
+#define SSG_SMQ_EXTRA_PARAM
+#define SSG_SMQ_EXTRA_ARG
+#endif
 template <int LPR>
 __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off,
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read)
+                           ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read SSG_SMQ_EXTRA_PARAM)
 {
 	constexpr int RPW = 64 / LPR;   /* reads per wave */
 	__shared__ uint32_t qlds[SSG_SM_QWORDS * RPW];

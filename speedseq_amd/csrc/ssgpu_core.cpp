@@ -410,9 +410,9 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	CHKA(scratch);
 	dbuf<unsigned int> d_nextread(1);
 	CHKA(d_nextread); CHK(d_nextread.zero());
-	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0);
+	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0 SSG_SMQ_EXTRA_ARG);
 	else if (quad && idx->ktab_k > 0) CHK(ssg_ktab_launch_smem(idx, opt, nthreads / block, block, n_reads, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p));   /* opt-in table instance, ssg_ktab.cpp */
-	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p);
+	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p SSG_SMQ_EXTRA_ARG);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
 	CHK(rt_sync());
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));

@@ -1,8 +1,8 @@
 """The product kernels' gfx950 machine code is the code whose results were checked on the MI355X (tools/isa_pin.py).
 
-Why a CPU-side test looks at machine code: in round 3 the GPU results of the seeding kernel went wrong -- emulation of the same source still
-agreed with the oracle -- after unrelated device code had been added to its translation unit; hipcc (ROCm 7.2) had changed the code of 24
-untouched kernels (profiles/r03f_gpu_bisect.log).  A change of any pinned kernel's code must go through `pytest -m gpu`
+Why a CPU-side test looks at machine code: in round 3 builds of the seeding kernel that execute the same statements as the checked one
+(different kernarg layout and register allocation) gave wrong results on the GPU while the emulation of the same source still agreed
+with the oracle; the cause is open (profiles/r03f_gpu_bisect.log).  Until it is understood, a change of any pinned kernel's code must go through `pytest -m gpu`
 and the bench's parity gate, then `python tools/isa_pin.py --write`."""
 import os
 import subprocess

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Pins the machine code of the product kernels (gfx950) to the build whose results were checked on the MI355X.
 
-Round 3 found that the ROCm 7.2 toolchain changes the code it makes of an UNTOUCHED kernel when unrelated device code is added to the same
-translation unit -- and that the changed seeding kernel gave wrong intervals on the GPU while the host emulation of the same source kept
-agreeing with the oracle (profiles/r03f_gpu_bisect.log).  The CPU-side suite cannot see that, so it checks the next
+Round 3 had builds whose seeding kernel gave wrong intervals on the GPU while the host emulation of the same source kept agreeing with
+the oracle; they differed from the good build in kernarg layout and register allocation, not in the statements executed, and the cause
+is still open (profiles/r03f_gpu_bisect.log).  The CPU-side suite cannot see such a thing, so it checks the next
 best thing: every ssg_k_* kernel of ssgpu_core.cpp's code object still is, instruction for instruction, the code of the build that last
 passed `pytest -m gpu` and the bench's parity gate (tests/golden/kernel_isa.sha256).  After an intended kernel change: run the GPU suite,
 then `python tools/isa_pin.py --write`.
