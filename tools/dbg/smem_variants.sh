@@ -16,4 +16,5 @@ out=gpurun_out; mkdir -p $out
 for lib in speedseq_amd/libssgpu.so $(ls speedseq_amd/libssgpu_probe*.so speedseq_amd/libssgpu_base_*.so 2>/dev/null); do
   echo "== $lib"
   SSGPU_LIB=$PWD/$lib timeout 300 python -m pytest tests/test_gpu_kernels.py -q -x -k "smem or pe_sam" 2>&1 | tail -3
+  SSGPU_LIB=$PWD/$lib timeout 120 python tools/dbg/smem_dump.py 500 2>&1 | tail -16    # which intervals are extra / missing, for the first reads that differ
 done 2>&1 | tee $out/smem_variants.log
