@@ -220,3 +220,47 @@ def test_fused_edge_inputs_emulated(tmp_path, emu_lib):
         strip = lambda x: "\n".join(l for l in x.split("\n") if not l.startswith("@PG"))
         assert t[0] == f[0] and len(t[0]) >= min_bytes, tag
         assert strip(t[1]) == strip(f[1]) and strip(t[2]) == strip(f[2]), tag
+
+
+@pytest.mark.parametrize("opts", [
+    [],                                                                          # no --excludeDups (speedseq align -i), no mate tags
+    ["--addMateTags"],
+    ["--excludeDups", "--addMateTags", "--maxSplitCount", "1", "--minNonOverlap", "50"],
+    ["--excludeDups", "--maxSplitCount", "3", "--minNonOverlap", "5"],
+])
+def test_fused_samblaster_option_sets_emulated(tmp_path, emu_lib, opts):
+    """the candidate set `bwa mem` attaches in fused mode must cover the side streams under ANY samblaster options (fused.h): for the option
+    sets the script can produce, fused `bwa | samblaster` gives the records `sambamba view` makes of the text path's main stream, byte for
+    byte, and the same two side streams"""
+    bwa, sbl, smb = (os.path.join(EMU, x) for x in ("bwa_emu", "samblaster_emu", "sambamba_emu"))
+    fq = str(tmp_path / "r.fq.gz")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 500, seed=51, chim_frac=0.05, disc_frac=0.05, dup_frac=0.1))
+    got = {}
+    for mode in ("text", "fused"):
+        env = dict(os.environ, SSG_BWA_CHUNK_BASES="30000", SSG_BWA_CALL_PAIRS="200")
+        if mode == "fused":
+            env["SSG_FUSED"] = "1"
+        spl, disc = str(tmp_path / (mode + ".spl")), str(tmp_path / (mode + ".disc"))
+        p1 = subprocess.run([bwa, "mem", "-t", "2", "-p", "-R", "@RG\\tID:g\\tSM:s\\tLB:l", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=900)
+        assert p1.returncode == 0, p1.stderr[-1500:]
+        p2 = subprocess.run([sbl] + opts + ["--splitterFile", spl, "--discordantFile", disc], input=p1.stdout, capture_output=True, env=env, timeout=900)
+        assert p2.returncode == 0, p2.stderr[-1500:]
+        if mode == "text":
+            bam = str(tmp_path / "text.bam")
+            p3 = subprocess.run([smb, "view", "-S", "-f", "bam", "-l", "0", "/dev/stdin"], input=p2.stdout, capture_output=True, timeout=900)
+            assert p3.returncode == 0, p3.stderr[-1500:]
+            open(bam, "wb").write(p3.stdout)
+            main = _records(bam)
+        else:
+            buf, o, main = p2.stdout, 8, b""
+            assert buf[:8] == b"SSGFUSE1"
+            while o < len(buf):
+                t, z, l = struct.unpack_from("<IIQ", buf, o)
+                if t == 3:
+                    main += buf[o + 16:o + 16 + l]
+                o += 16 + l
+        strip = lambda x: "\n".join(l for l in x.split("\n") if not l.startswith("@PG"))
+        got[mode] = (main, strip(open(spl).read()), strip(open(disc).read()))
+    assert len(got["text"][0]) > 100000 and got["fused"][0] == got["text"][0]
+    assert got["fused"][1] == got["text"][1] and got["fused"][2] == got["text"][2]
+    assert got["text"][2].count("\n") > 5
