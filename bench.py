@@ -336,7 +336,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     n_all = os.path.getsize(fq) // rec_bytes
     samtools = os.path.join(ROOT, "oracle", "_ref", "samtools")
     shim = os.path.join(ROOT, "tools", "sambamba_samtools_shim.sh")
-    host_cfg = "export SSG_SORT_THREADS=%d\nexport SSG_FMT_THREADS=%d\nexport SSG_SORT_LOG=1\nexport SSG_SBL_LOG=1\nexport SSG_LOAD_LOG=1\n" % (min(os.cpu_count() or 8, 128), min(os.cpu_count() or 8, 48))   # the script's -t sizes upstream's batches; the host pools are sized for the box
+    host_cfg = "export SSG_SORT_THREADS=%d\nexport SSG_FMT_THREADS=%d\nexport SSG_SORT_LOG=1\nexport SSG_SBL_LOG=1\nexport SSG_LOAD_LOG=1\n" % (min(os.cpu_count() or 8, 256), min(os.cpu_count() or 8, 48))   # the script's -t sizes upstream's batches; the host pools are sized for the box
     host_cfg += os.environ.get("SSG_BENCH_CONFIG_EXTRA", "").replace(";", "\n") + "\n"   # A/B runs: further `export X=Y` lines for speedseq.config
     fused_cfg = "export SSG_FUSED=1\n" + host_cfg
     res = {"metric": "paired reads aligned+dup-marked/sec, FASTQ file -> out.bam + out.splitters.bam + out.discordants.bam (+ .bai), `speedseq align` wall clock incl. index load"}

@@ -246,6 +246,30 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 			cv.notify_all();
 		}
 	};
+	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets), built by a thread of
+	 * its own that follows the writer: a record's virtual offset is known as soon as the group holding its block has its file offset */
+	struct ent_t { int32_t tid, pos, end; uint8_t mapped; };
+	std::vector<ent_t> ent(bai_path ? n : 0);
+	if (bai_path) parallel_for(threads, n, [&](size_t a, size_t b, int) {
+		for (size_t i = a; i < b; ++i) { const uint8_t *r = S.rec(perm[i]) + 4; bam_core_t c; memcpy(&c, r, 32); ent[i].tid = c.tid; ent[i].pos = c.pos; ent[i].end = bam_endpos(r); ent[i].mapped = !((c.flag_nc >> 16) & 4); }
+	});
+	std::atomic<size_t> blocks_placed(0);                       /* blk_coff[0 .. blocks_placed) are final */
+	std::atomic<uint64_t> file_end_v(0);                        /* virtual offset of the end of the file, 0 until the last block is placed */
+	bai_t idx((int)h.names.size(), 0); bool idx_ok = true; double t_idx_wait = 0;
+	std::thread t_idx;
+	if (bai_path) t_idx = std::thread([&]() {
+		size_t bk = 0;
+		auto wait_blocks = [&](size_t need) { if (blocks_placed.load(std::memory_order_acquire) >= need) return; const double t0 = wall(); std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return blocks_placed.load(std::memory_order_acquire) >= need; }); t_idx_wait += wall() - t0; };
+		auto voff = [&](size_t i) -> uint64_t { while (cut[bk + 1] <= cum[i]) ++bk; wait_blocks(bk + 1); return blk_coff[bk] << 16 | (cum[i] - cut[bk]); };
+		auto end_of_file = [&]() -> uint64_t { wait_blocks(nb + 1); return file_end_v.load(); };
+		const uint64_t first = n ? voff(0) : end_of_file();
+		idx = bai_t((int)h.names.size(), first);
+		for (size_t i = 0; i < n; ++i) {
+			const uint64_t after = i + 1 < n ? voff(i + 1) : end_of_file();
+			if (idx.push(ent[i].tid, ent[i].pos, ent[i].end, after, ent[i].mapped != 0) < 0) { idx_ok = false; break; }   /* cannot happen on a sorted stream; `sambamba index` will say so */
+		}
+		if (idx_ok) idx.finish(end_of_file());
+	});
 	std::vector<std::thread> th;
 	for (int t = 0; t < std::max(1, threads); ++t) th.emplace_back(worker);
 	uint64_t coff = (uint64_t)(hdr_end > 0 ? hdr_end : 0);
@@ -254,7 +278,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz); }
 		io_write_all(fd, ob.data(), ob.size());
 		if (bai_path) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }
-		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; }
+		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; if (bai_path) blocks_placed.store(std::min(nb, (g + 1) * GRP), std::memory_order_release); }
 		cv.notify_all();
 	}
 	for (auto &x : th) x.join();
@@ -262,24 +286,13 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	const double tw2 = wall();
 	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s\n", tw1 - tw0, nb, tw2 - tw1);
 	if (!bai_path) return;
-	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets) */
 	blk_coff[nb] = coff;
-	const uint64_t file_end = (coff + 28) << 16;
-	struct ent_t { int32_t tid, pos, end; uint8_t mapped; };
-	std::vector<ent_t> ent(n);
-	parallel_for(threads, n, [&](size_t a, size_t b, int) {
-		for (size_t i = a; i < b; ++i) { const uint8_t *r = S.rec(perm[i]) + 4; bam_core_t c; memcpy(&c, r, 32); ent[i].tid = c.tid; ent[i].pos = c.pos; ent[i].end = bam_endpos(r); ent[i].mapped = !((c.flag_nc >> 16) & 4); }
-	});
-	auto voff = [&](size_t i, size_t &bk) -> uint64_t { while (cut[bk + 1] <= cum[i]) ++bk; return blk_coff[bk] << 16 | (cum[i] - cut[bk]); };
-	size_t bk = 0;
-	bai_t idx((int)h.names.size(), n ? voff(0, bk) : file_end);
-	for (size_t i = 0; i < n; ++i) {
-		const uint64_t after = i + 1 < n ? voff(i + 1, bk) : file_end;
-		if (idx.push(ent[i].tid, ent[i].pos, ent[i].end, after, ent[i].mapped != 0) < 0) return;     /* cannot happen on a sorted stream; `sambamba index` will say so */
-	}
-	idx.finish(file_end);
+	{ std::lock_guard<std::mutex> l(mu); file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release); }
+	cv.notify_all();
+	t_idx.join();
+	if (!idx_ok) return;
 	idx.save(bai_path);
-	if (dbg()) fprintf(stderr, "[sambamba] sort: write: index %.2f s\n", wall() - tw2);
+	if (dbg()) fprintf(stderr, "[sambamba] sort: write: index finished %.2f s after the last block (its thread waited %.2f s for block offsets)\n", wall() - tw2, t_idx_wait);
 }
 
 struct merge_src_t {   /* one coordinate-sorted BAM being merged */
