@@ -44,7 +44,12 @@ def emu_lib():
 
 
 @pytest.fixture(scope="session")
-def gpu_lib():
+def gpu_lib(gpu_lib_session):
+    return gpu_lib_session
+
+
+@pytest.fixture(scope="session")
+def gpu_lib_session():
     from speedseq_amd import capi
     lib = capi.Lib()  # raises if the HIP build is missing: no fallback
     if lib.device_count() < 1:

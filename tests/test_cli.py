@@ -101,7 +101,10 @@ def _grammar_fastq(pairs, style):
 @pytest.mark.parametrize("style", ["plain", "wrapped", "fasta", "suffix", "comment", "crlf", "lower", "mixed"])
 def test_cli_emu_fastq_grammar(tmp_path, emu_lib, style):
     """bin/bwa's reader (host/fastq.h) against the oracle's restatement of kseq_read + trim_readno, through `bwa mem [-C]`"""
-    emu = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    _grammar(tmp_path, os.path.join(ROOT, "tests", "emu", "bwa_emu"), style)
+
+
+def _grammar(tmp_path, emu, style):
     pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 40, seed=77)
     fq = str(tmp_path / "g.fq")
     open(fq, "w", newline="").write(_grammar_fastq(pairs, style))
@@ -113,7 +116,10 @@ def test_cli_emu_fastq_grammar(tmp_path, emu_lib, style):
 
 
 def test_cli_emu_two_files_and_truncation(tmp_path, emu_lib):
-    emu = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    _two_files(tmp_path, os.path.join(ROOT, "tests", "emu", "bwa_emu"))
+
+
+def _two_files(tmp_path, emu):
     pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 60, seed=78)
     f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
     for path, which in ((f1, 1), (f2, 2)):
@@ -150,12 +156,15 @@ def test_cli_emu_many_batches_and_device_calls(tmp_path, emu_lib, monkeypatch):
 ])
 def test_cli_emu_samblaster_option_sets(tmp_path, emu_lib, opts):
     """the option sets `speedseq align` can produce (-i, -c, -m: bin/speedseq:228-243) and samblaster's own defaults, vs the oracle"""
-    emu = os.path.join(ROOT, "tests", "emu")
+    _option_sets(tmp_path, os.path.join(ROOT, "tests", "emu", "samblaster_emu"), opts)
+
+
+def _option_sets(tmp_path, samblaster_exe, opts):
     fq = str(tmp_path / "r.fq.gz")
     simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 500, seed=51, chim_frac=0.05, disc_frac=0.05, dup_frac=0.1))
     sam = subprocess.run([ORC, "mem", "-t", "4", "-p", EXAMPLE_FA, fq], capture_output=True, check=True).stdout
     res = []
-    for tag, exe in (("got", [os.path.join(emu, "samblaster_emu")]), ("exp", [ORC, "samblaster"])):
+    for tag, exe in (("got", [samblaster_exe]), ("exp", [ORC, "samblaster"])):
         spl, disc = str(tmp_path / (tag + ".spl")), str(tmp_path / (tag + ".disc"))
         p = subprocess.run(exe + opts + ["--splitterFile", spl, "--discordantFile", disc], input=sam, capture_output=True, check=True)
         res.append((_no_pg(p.stdout.decode()), _no_pg(open(spl).read()), _no_pg(open(disc).read())))

@@ -69,20 +69,24 @@ def test_fused_script_many_calls_two_devices_emulated(tmp_path, emu_lib):
 
 @pytest.mark.parametrize("seg", ["segments", "pipe_only", "unusable_dir"])
 def test_fused_frames_as_mapped_segments_emulated(tmp_path, emu_lib, seg):
+    _fused_segments(tmp_path, seg, os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), os.path.join(EMU, "sambamba_emu"))
+
+
+def _fused_segments(tmp_path, seg, bwa, sbl, smb, n_pairs=900):
     """fused.h REF frames: every BATCH / MAIN payload in a file of its own on a memory file system (here: forced for every frame, in a
     directory of the test's), or all of them through the pipe (segments switched off / directory not usable) -- same three BAMs as
     the text path, several device calls and a spilling sort included, and no segment is left behind"""
     T._need_tools()
-    fq = T._fastq(tmp_path, 900)
-    tools = dict(sambamba=os.path.join(EMU, "sambamba_emu"))
+    fq = T._fastq(tmp_path, n_pairs)
+    tools = dict(sambamba=smb)
     small = {"SSG_BWA_CHUNK_BASES": "6000", "SSG_BWA_CALL_PAIRS": "150"}
     segdir = tmp_path / "seg"
     segdir.mkdir()
     cfg = {"segments": "export SSG_FUSED_SHM=%s\nexport SSG_FUSED_SHM_MIN=1\n" % segdir,
            "pipe_only": "export SSG_FUSED_SHM=0\n",
            "unusable_dir": "export SSG_FUSED_SHM=%s/nowhere\nexport SSG_FUSED_SHM_MIN=1\n" % segdir}[seg]
-    text = T._run_align(str(tmp_path / "text"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, env_extra=small, **tools)
-    fused = T._run_align(str(tmp_path / "fused"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, config_extra=FUSED + cfg,
+    text = T._run_align(str(tmp_path / "text"), bwa, sbl, fq, env_extra=small, **tools)
+    fused = T._run_align(str(tmp_path / "fused"), bwa, sbl, fq, config_extra=FUSED + cfg,
                          env_extra=dict(small, SSG_SORT_CHUNK_BYTES="150000"), **tools)
     _same_bam_records(fused, text)
     assert os.listdir(str(segdir)) == []
@@ -229,12 +233,15 @@ def test_fused_edge_inputs_emulated(tmp_path, emu_lib):
     ["--excludeDups", "--maxSplitCount", "3", "--minNonOverlap", "5"],
 ])
 def test_fused_samblaster_option_sets_emulated(tmp_path, emu_lib, opts):
+    _fused_option_sets(tmp_path, opts, *(os.path.join(EMU, x) for x in ("bwa_emu", "samblaster_emu", "sambamba_emu")))
+
+
+def _fused_option_sets(tmp_path, opts, bwa, sbl, smb, n_pairs=500):
     """the candidate set `bwa mem` attaches in fused mode must cover the side streams under ANY samblaster options (fused.h): for the option
     sets the script can produce, fused `bwa | samblaster` gives the records `sambamba view` makes of the text path's main stream, byte for
     byte, and the same two side streams"""
-    bwa, sbl, smb = (os.path.join(EMU, x) for x in ("bwa_emu", "samblaster_emu", "sambamba_emu"))
     fq = str(tmp_path / "r.fq.gz")
-    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 500, seed=51, chim_frac=0.05, disc_frac=0.05, dup_frac=0.1))
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=51, chim_frac=0.05, disc_frac=0.05, dup_frac=0.1))
     got = {}
     for mode in ("text", "fused"):
         env = dict(os.environ, SSG_BWA_CHUNK_BASES="30000", SSG_BWA_CALL_PAIRS="200")
