@@ -42,6 +42,12 @@ void ssg_mem_opt_init(ssg_mem_opt_t *opt);
 /* ---- FM-index (upstream bwa_idx_load / bwa_idx_destroy, bwa.c; row a1) ---- */
 typedef struct ssg_index ssg_index_t;
 int ssg_index_load(const char *prefix, ssg_index_t **out);      /* reads prefix.{bwt,sa,pac,ann} into HBM */
+/* The denser copy of the suffix array this library locates seeds through (every 4th row instead of the file's every 32nd) costs one
+ * LF walk over the whole text when the index is loaded; it pays for itself after some tens of millions of reads.  A caller that does
+ * not know how much input is coming loads with the file's density (defer_dense_sa != 0: same results, seed location walks further)
+ * and calls ssg_index_densify() once the input has proved long -- between device calls, never while one runs on this index. */
+int ssg_index_load2(const char *prefix, int defer_dense_sa, ssg_index_t **out);
+int ssg_index_densify(ssg_index_t *idx);                         /* no-op when the index already is as dense as SSG_SA_INTV asks */
 /* (All index constructors fill the HBM copy of the suffix-array samples to every 4th row -- SSG_SA_INTV overrides -- with
  *  upstream's bwt_sa walk: 2 bytes of HBM per reference base, same locations, ~6x less work per located seed.) */
 int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t primary, const uint64_t L2[5],

@@ -184,7 +184,14 @@ static int stream_files_to_device(const std::vector<load_item_t> &items, int n_t
 	return 0;
 }
 
-int ssg_index_load(const char *prefix, ssg_index_t **out)
+int ssg_index_load(const char *prefix, ssg_index_t **out) { return ssg_index_load2(prefix, 0, out); }
+int ssg_index_densify(ssg_index_t *ix)
+{
+	CHK(need_device());
+	if (!ix) { ssg_err_msg = "ssg_index_densify: no index"; return SSG_EINVAL; }
+	return densify_sa(ix);
+}
+int ssg_index_load2(const char *prefix, int defer_dense_sa, ssg_index_t **out)
 {	/* on-disk layout: SURVEY.md Appendix A (verified against the bundled example index) */
 	CHK(need_device());
 	const auto t_begin = std::chrono::steady_clock::now();
@@ -241,7 +248,7 @@ int ssg_index_load(const char *prefix, ssg_index_t **out)
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_seqs; ix->v.sa_intv = sa_intv;
 	ix->h_off = off; ix->h_len = len; ix->names = names;
-	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = defer_dense_sa ? 0 : densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	if (ssg_debug() || getenv("SSG_LOAD_LOG")) {
 		const auto t_end = std::chrono::steady_clock::now();
 		fprintf(stderr, "[ssgpu] index load: files -> HBM %.3f s (%.2f GB), SA samples to every %d rows %.3f s\n", std::chrono::duration<double>(t_up - t_begin).count(),

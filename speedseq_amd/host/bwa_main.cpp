@@ -120,12 +120,16 @@ static int main_mem(int argc, char **argv)
 	if (n_dev < 1) { fprintf(stderr, "[bwa] no MI355X visible: %s has no CPU path\n", ssg_backend()); return 1; }
 	if (n_dev > 16) n_dev = 16;
 	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
+	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms
+	 * per million pairs: a run does not know how long its input is, so each device makes the copy once it has aligned this many pairs
+	 * (the point where the walk has been paid for once over; 0 = at load time).  Results do not depend on it. */
+	long densify_after = 32000000; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
 	std::atomic<int> fail(0);
 	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
 	{
 		std::vector<std::thread> ld;
 		for (int g = 0; g < n_dev; ++g) ld.emplace_back([&, g]() {
-			if (ssg_set_device(g) || ssg_index_load(argv[ai], &idxs[(size_t)g])) { fprintf(stderr, "[bwa] fail to load the index on device %d: %s\n", g, ssg_last_error()); fail = 1; } });
+			if (ssg_set_device(g) || ssg_index_load2(argv[ai], densify_after > 0, &idxs[(size_t)g])) { fprintf(stderr, "[bwa] fail to load the index on device %d: %s\n", g, ssg_last_error()); fail = 1; } });
 		for (std::thread &x : ld) x.join();
 	}
 	t_warm.join();
@@ -244,11 +248,17 @@ static int main_mem(int argc, char **argv)
 	});
 	std::vector<std::thread> t_gpu;
 	for (int g = 0; g < n_dev; ++g) t_gpu.emplace_back([&, g]() {
-		std::unique_ptr<batch_t> B;
+		std::unique_ptr<batch_t> B; long pairs_here = 0; bool dense = densify_after <= 0;
 		if (ssg_set_device(g)) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; }
 		while (to_gpu.pop(B)) {
 			const double t0 = wall();
 			B->dev = g;
+			if (!dense && !fail && pairs_here >= densify_after) {
+				dense = true;
+				if (ssg_index_densify(idxs[(size_t)g])) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; }
+				else fprintf(stderr, "[bwa] device %d: denser suffix-array copy made after %ld pairs (%.2f s)\n", g, pairs_here, wall() - t0);
+			}
+			pairs_here += B->n() / 2;
 			if (!fail && ssg_mem_process_pairs(idxs[(size_t)g], &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
 				fprintf(stderr, "[bwa] alignment failed on device %d: %s\n", g, ssg_last_error()); fail = 1; }
 			tm_gpu[(size_t)g] += wall() - t0; ++calls[(size_t)g];

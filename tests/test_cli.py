@@ -193,3 +193,21 @@ def test_cli_emu_bgzf_fastq_input(tmp_path, emu_lib):
     b = subprocess.run([exe, "mem", "-p", EXAMPLE_FA, fq + ".gz"], capture_output=True, env=dict(os.environ, SSG_BGZF_THREADS="3"))
     strip = lambda x: [l for l in x.split(b"\n") if not l.startswith(b"@PG")]
     assert a.returncode == 0 and b.returncode == 0 and strip(a.stdout) == strip(b.stdout) and len(a.stdout) > 100000
+
+
+def test_cli_emu_deferred_dense_suffix_array(tmp_path, emu_lib):
+    """bin/bwa makes the denser suffix-array copy only once the input has proved long (SSG_BWA_DENSIFY_AFTER pairs per device; 0 = when
+    the index is loaded): the SAM text is the same whether seeds were located through the file's samples, the dense copy, or first one
+    then the other in the middle of a run"""
+    exe = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    fq = str(tmp_path / "r.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 600, seed=91))
+    outs, errs = [], []
+    for after in ("0", "250", "1000000"):
+        env = dict(os.environ, SSG_BWA_DENSIFY_AFTER=after, SSG_BWA_CHUNK_BASES="20000", SSG_BWA_CALL_PAIRS="100", SSG_EMU_DEVICES="2")
+        r = subprocess.run([exe, "mem", "-t", "2", "-p", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(_no_pg(r.stdout.decode()))
+        errs.append(r.stderr.decode())
+    assert outs[0].count("\n") > 1200 and outs[1] == outs[0] and outs[2] == outs[0]
+    assert "denser suffix-array copy made after" in errs[1] and "denser suffix-array" not in errs[0] and "denser suffix-array" not in errs[2]

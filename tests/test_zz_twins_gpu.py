@@ -60,3 +60,17 @@ def test_gpu_bwa_same_sam_with_fastq_pieces(tmp_path, gpu_lib):
         r = subprocess.run([B("bwa"), "mem", "-t", "4", EXAMPLE_FA, f1, f2], env=env, capture_output=True, check=True, timeout=600)
         outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
     assert outs[0].count(b"\n") > 6000 and outs[1] == outs[0]
+
+
+def test_gpu_deferred_dense_suffix_array(tmp_path, gpu_lib):
+    """the denser suffix-array copy made at load time, in the middle of the run, or never: same SAM"""
+    fq = str(tmp_path / "r.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 3000, seed=91))
+    outs = []
+    for after in ("0", "1400", "100000000"):
+        env = dict(os.environ, SSG_BWA_DENSIFY_AFTER=after, SSG_BWA_CHUNK_BASES="60000", SSG_BWA_CALL_PAIRS="700")
+        r = subprocess.run([B("bwa"), "mem", "-t", "2", "-p", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
+        assert (b"denser suffix-array copy made after" in r.stderr) == (after == "1400")
+    assert outs[0].count(b"\n") > 6000 and outs[1] == outs[0] and outs[2] == outs[0]
