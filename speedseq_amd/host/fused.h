@@ -108,7 +108,11 @@ static inline bool fu_seg_create(size_t len, fu_buf_t &b, std::string &path)
 	path = std::string(dir) + nm;
 	const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_CLOEXEC, 0600);
 	if (fd < 0) return false;
-	void *m = ftruncate(fd, (off_t)len) == 0 ? mmap(0, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+	/* the pages are reserved here, in one call (measured: 0.07 s + 0.07 s to fill 670 MB with 8 threads, against 0.14-0.55 s when every
+	 * first touch allocates), and a file system without room says so now instead of with a SIGBUS in the middle of the copy */
+	bool room = ftruncate(fd, (off_t)len) == 0;
+	if (room && fallocate(fd, 0, 0, (off_t)len) != 0 && errno != EOPNOTSUPP && errno != ENOSYS) room = false;
+	void *m = room ? mmap(0, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
 	close(fd);
 	if (m == MAP_FAILED) { unlink(path.c_str()); return false; }
 	b.reset(); b.p = (uint8_t*)m; b.len = b.cap = len; b.mapped = true;
