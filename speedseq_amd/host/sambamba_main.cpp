@@ -199,11 +199,15 @@ static void bai_note_write(const std::string &bam)
 /* bai_path != NULL (the final file, a regular file): the .bai is written as well -- every field `sambamba index` would read back from the
  * file is in memory here -- with a note next to it (<bai>.ssg: size and mtime of the BAM, CRC of the index) that lets `sambamba index`,
  * which the reference runs right after the sort (bin/speedseq:491-495), recognise the pair as current instead of inflating the BAM again */
-static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads, const char *bai_path = 0)
+/* force_at != NULL (a sorted run on its way to the temporary directory, cmd_sort): no header; a block starts at each of these record
+ * indices (ascending, <= n) and force_off receives the file offset of that block -- the run's segments, one per range of the genome */
+static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads, const char *bai_path = 0,
+                         const std::vector<size_t> *force_at = 0, std::vector<uint64_t> *force_off = 0)
 {
-	{ bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
-	const off_t hdr_end = bai_path ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+	if (!force_at) { bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
+	const off_t hdr_end = force_at ? (off_t)0 : bai_path ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
 	if (hdr_end < 0) bai_path = 0;
+	const bool want_off = bai_path || force_at;
 	const size_t n = perm.size();
 	const int lvl = level < 0 ? 6 : level;
 	const double tw0 = wall();
@@ -212,9 +216,15 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	parallel_for(threads, n, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) { uint32_t bs; memcpy(&bs, S.rec(perm[i]), 4); cum[i + 1] = 4 + (uint64_t)bs; } });
 	for (size_t i = 0; i < n; ++i) cum[i + 1] += cum[i];
 	std::vector<uint64_t> cut; cut.push_back(0);
+	std::vector<size_t> force_blk(force_at ? force_at->size() : 0, 0);   /* block that starts at each forced index */
 	{	uint64_t open = 0;   /* start of the open block */
+		size_t fk = 0;
 		for (size_t i = 0; i < n; ++i) {
 			const uint64_t sz = cum[i + 1] - cum[i];
+			if (force_at && fk < force_at->size() && (*force_at)[fk] == i) {
+				if (cum[i] > open) { cut.push_back(cum[i]); open = cum[i]; }
+				while (fk < force_at->size() && (*force_at)[fk] == i) force_blk[fk++] = cut.size() - 1;
+			}
 			if (cum[i] > open && cum[i] - open + sz > BGZF_MAX_PAYLOAD) { cut.push_back(cum[i]); open = cum[i]; }
 			while (cum[i + 1] - open >= BGZF_MAX_PAYLOAD) { open += BGZF_MAX_PAYLOAD; cut.push_back(open); }   /* a record larger than a block fills whole blocks */
 		}
@@ -223,7 +233,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	const double tw1 = wall();
 	const size_t nb = cut.size() - 1, GRP = 128, ng = (nb + GRP - 1) / GRP;
 	struct grp_t { std::vector<uint8_t> bytes; std::vector<uint32_t> bsz; bool done; grp_t() : done(false) {} };
-	std::vector<uint64_t> blk_coff(bai_path ? nb + 1 : 0);      /* file offset of every block */
+	std::vector<uint64_t> blk_coff(want_off ? nb + 1 : 0);      /* file offset of every block */
 	std::vector<grp_t> grp(ng);
 	std::mutex mu; std::condition_variable cv; size_t next_write = 0; std::atomic<size_t> next_grp(0);
 	const size_t window = (size_t)std::max(4, threads * 3);   /* groups compressed ahead of the writer */
@@ -277,11 +287,17 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		std::vector<uint8_t> ob; std::vector<uint32_t> bsz;
 		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz); }
 		io_write_all(fd, ob.data(), ob.size());
-		if (bai_path) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }
+		if (want_off) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }
 		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; if (bai_path) blocks_placed.store(std::min(nb, (g + 1) * GRP), std::memory_order_release); }
 		cv.notify_all();
 	}
 	for (auto &x : th) x.join();
+	if (force_at) {   /* a run: no end-of-file block; the offsets of its segments (indices at n = the end of the data) */
+		blk_coff[nb] = coff;
+		force_off->resize(force_at->size());
+		for (size_t k = 0; k < force_at->size(); ++k) (*force_off)[k] = (*force_at)[k] >= n ? coff : blk_coff[force_blk[k]];
+		return;
+	}
 	io_write_all(fd, BGZF_EOF, 28);
 	const double tw2 = wall();
 	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s\n", tw1 - tw0, nb, tw2 - tw1);
@@ -309,6 +325,128 @@ static void kway_merge(std::vector<merge_src_t> &src, bgzf_out_t &out)
 		out.record(src[i].rec.data(), src[i].rec.size());
 		if (src[i].next()) pq.push(ent_t(src[i].key, i));
 	}
+}
+
+/* ---- sorted runs in the temporary directory (input larger than -m allows in memory) ----
+ * A run is written in segments, one per range of the genome (the ranges are fixed from the header's contig lengths before the first
+ * run is written), each starting at a BGZF block of its own whose file offset is kept.  The final pass then is not one k-way merge
+ * over whole runs -- a single thread moving every record -- but an independent small merge per range, run by the pool, each inflating
+ * only its own byte range of every run and compressing its own stretch of the output; a writer puts the stretches out in order.  Ties
+ * keep input order: equal keys share a range, and within a range the earlier run wins. */
+struct run_t { std::string path; int fd; std::vector<uint64_t> seg; };   /* seg[g] .. seg[g + 1]: the run's records of range g */
+
+static void make_ranges(const bam_hdr_t &h, size_t G, std::vector<uint64_t> &lo)
+{	/* lo[g] = smallest sort key of range g (equal shares of the genome's length); reads without a position sort last: the last range */
+	lo.assign(1, 0);
+	uint64_t L = 0; for (int32_t l : h.lens) L += (uint64_t)(l > 0 ? l : 0);
+	if (G < 2 || !L) return;
+	size_t tid = 0; uint64_t base = 0;
+	for (size_t g = 1; g < G; ++g) {
+		const uint64_t X = (uint64_t)((unsigned __int128)L * g / G);
+		while (tid < h.lens.size() && base + (uint64_t)std::max(h.lens[tid], 0) <= X) { base += (uint64_t)std::max(h.lens[tid], 0); ++tid; }
+		if (tid >= h.lens.size()) break;
+		const uint64_t key = (uint64_t)tid << 32 | (uint64_t)(uint32_t)((X - base + 1) << 1);
+		if (key > lo.back()) lo.push_back(key);
+	}
+}
+
+struct run_reader_t {   /* the records of one byte range of a run file, in order */
+	int fd; uint64_t pos, end; std::vector<uint8_t> raw, buf; size_t bo; std::vector<uint8_t> rec; uint64_t key; bool ok;
+	run_reader_t(int fd_, uint64_t a, uint64_t b) : fd(fd_), pos(a), end(b), bo(0), key(0), ok(false) {}
+	bool fill()
+	{
+		buf.clear(); bo = 0;
+		if (pos >= end) return false;
+		const size_t want = (size_t)std::min<uint64_t>(end - pos, (uint64_t)1 << 20);
+		raw.resize(want);
+		for (size_t got = 0; got < want; ) { const ssize_t r = pread(fd, raw.data() + got, want - got, (off_t)(pos + got)); if (r < 0 && errno == EINTR) continue; if (r <= 0) die("sort: cannot read a sorted run back"); got += (size_t)r; }
+		size_t o = 0;
+		while (o + 18 <= want) {
+			const uint8_t *b = raw.data() + o;
+			if (b[0] != 0x1f || b[1] != 0x8b || !(b[3] & 4) || b[12] != 'B' || b[13] != 'C') die("sort: a sorted run is damaged");
+			const size_t bsize = (size_t)(b[16] | (size_t)b[17] << 8) + 1, xlen = b[10] | (size_t)b[11] << 8;
+			if (o + bsize > want) break;
+			uint32_t isz; memcpy(&isz, b + bsize - 4, 4);
+			const size_t at = buf.size(); buf.resize(at + isz);
+			if (isz) {
+				z_stream zs; memset(&zs, 0, sizeof(zs));
+				zs.next_in = (Bytef*)(b + 12 + xlen); zs.avail_in = (uInt)(bsize - 12 - xlen - 8); zs.next_out = buf.data() + at; zs.avail_out = isz;
+				if (inflateInit2(&zs, -15) != Z_OK || inflate(&zs, Z_FINISH) != Z_STREAM_END) die("sort: a sorted run does not inflate");
+				inflateEnd(&zs);
+			}
+			o += bsize;
+		}
+		if (!o) die("sort: a sorted run is damaged");
+		pos += o;
+		return true;
+	}
+	size_t get(void *dst, size_t n)
+	{
+		uint8_t *d = (uint8_t*)dst; size_t got = 0;
+		while (got < n) {
+			if (bo >= buf.size() && !fill()) break;
+			const size_t k = std::min(n - got, buf.size() - bo);
+			memcpy(d + got, buf.data() + bo, k); got += k; bo += k;
+		}
+		return got;
+	}
+	bool next()
+	{
+		uint32_t bs;
+		if (get(&bs, 4) != 4) { ok = false; return false; }
+		rec.resize(4 + (size_t)bs); memcpy(rec.data(), &bs, 4);
+		if (bs < 32 || get(rec.data() + 4, bs) != bs) die("sort: a sorted run is damaged");
+		key = bam_sort_key(rec.data() + 4); ok = true;
+		return true;
+	}
+};
+
+static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, int fd, int level, int threads)
+{
+	{ bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
+	const int lvl = level < 0 ? 6 : level;
+	struct part_t { std::vector<uint8_t> bytes; bool done; part_t() : done(false) {} };
+	std::vector<part_t> part(G);
+	std::mutex mu; std::condition_variable cv; size_t next_write = 0; std::atomic<size_t> next_g(0);
+	const size_t window = (size_t)std::max(2, threads * 2);
+	auto worker = [&]() {
+		std::vector<uint8_t> payload, blk(65536); payload.reserve(BGZF_MAX_PAYLOAD);
+		for (;;) {
+			const size_t g = next_g.fetch_add(1);
+			if (g >= G) break;
+			{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return g < next_write + window; }); }
+			std::vector<uint8_t> ob;
+			auto flush = [&]() { if (payload.empty()) return; const size_t k = bgzf_make_block(payload.data(), payload.size(), lvl, blk.data()); ob.insert(ob.end(), blk.data(), blk.data() + k); payload.clear(); };
+			std::vector<std::unique_ptr<run_reader_t> > rd;
+			typedef std::pair<uint64_t, size_t> ent_t;
+			std::priority_queue<ent_t, std::vector<ent_t>, std::greater<ent_t> > pq;
+			for (size_t r = 0; r < runs.size(); ++r) {
+				rd.emplace_back(new run_reader_t(runs[r].fd, runs[r].seg[g], runs[r].seg[g + 1]));
+				if (runs[r].seg[g + 1] > runs[r].seg[g] && rd[r]->next()) pq.push(ent_t(rd[r]->key, r));
+			}
+			while (!pq.empty()) {
+				const size_t r = pq.top().second; pq.pop();
+				const uint8_t *p = rd[r]->rec.data(); size_t n = rd[r]->rec.size();
+				if (payload.size() + n > BGZF_MAX_PAYLOAD) flush();                       /* bgzf_flush_try */
+				while (n) { const size_t k = std::min(n, (size_t)BGZF_MAX_PAYLOAD - payload.size()); payload.insert(payload.end(), p, p + k); p += k; n -= k; if (payload.size() == BGZF_MAX_PAYLOAD) flush(); }
+				if (rd[r]->next()) pq.push(ent_t(rd[r]->key, r));
+			}
+			flush();
+			{ std::lock_guard<std::mutex> l(mu); part[g].bytes.swap(ob); part[g].done = true; }
+			cv.notify_all();
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 0; t < std::max(1, std::min<int>(threads, (int)G)); ++t) th.emplace_back(worker);
+	for (size_t g = 0; g < G; ++g) {
+		std::vector<uint8_t> ob;
+		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return part[g].done; }); ob.swap(part[g].bytes); }
+		io_write_all(fd, ob.data(), ob.size());
+		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; }
+		cv.notify_all();
+	}
+	for (auto &x : th) x.join();
+	io_write_all(fd, BGZF_EOF, 28);
 }
 
 static int cmd_sort(int argc, char **argv)
@@ -342,13 +480,26 @@ static int cmd_sort(int argc, char **argv)
 	std::thread warm([]() { const uint64_t k[2] = { 1, 0 }; uint32_t pm[2]; (void)ssg_sort_u64_perm(k, 2, pm); });
 	struct joiner_t { std::thread &t; ~joiner_t() { if (t.joinable()) t.join(); } } warm_join = { warm };
 	if (mkdir(tmpdir.c_str(), 0777) != 0 && errno != EEXIST) die("sort: cannot create " + tmpdir + ": " + strerror(errno));
+	std::vector<run_t> runs; std::vector<uint64_t> range_lo;
 	auto spill = [&]() {
 		std::vector<uint32_t> perm; gpu_perm(S, perm);
-		char nm[64]; snprintf(nm, sizeof(nm), "/ssg_sort_%d_%04zu.bam", (int)getpid(), spills.size());
-		const std::string p = tmpdir + nm;
-		int ofd = open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + p);
-		write_sorted(S, perm, h, ofd, 1, pool); close(ofd);
-		spills.push_back(p); S.clear();
+		if (runs.empty()) {   /* the ranges of the genome, fixed now: about 4 MB of a run each, so that one range of all runs is a small merge */
+			size_t G = (size_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, S.bytes >> 22));
+			{ const char *e = getenv("SSG_SORT_RANGES"); if (e && atol(e) > 0) G = (size_t)atol(e); }
+			make_ranges(h, G, range_lo);
+		}
+		const size_t G = range_lo.size(), n = perm.size();
+		std::vector<size_t> at(G + 1, n);
+		for (size_t g = 0; g < G; ++g) {   /* first record of the sorted order whose key reaches the range */
+			size_t a = 0, b = n;
+			while (a < b) { const size_t m = (a + b) >> 1; if (S.key[perm[m]] < range_lo[g]) a = m + 1; else b = m; }
+			at[g] = a;
+		}
+		char nm[64]; snprintf(nm, sizeof(nm), "/ssg_sort_%d_%04zu.run", (int)getpid(), runs.size());
+		run_t R; R.path = tmpdir + nm;
+		R.fd = open(R.path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644); if (R.fd < 0) die("sort: cannot write " + R.path);
+		write_sorted(S, perm, h, R.fd, 1, pool, 0, &at, &R.seg);
+		runs.push_back(R); spills.push_back(R.path); S.clear();
 	};
 	if (fused) {
 		/* frames straight from samblaster (fused.h): a reader thread takes them off the pipe, this thread indexes the records (keys +
@@ -417,11 +568,10 @@ static int cmd_sort(int argc, char **argv)
 	}
 	else {
 		if (!S.key.empty()) spill();
-		std::vector<merge_src_t> src(spills.size());
-		for (size_t i = 0; i < spills.size(); ++i) { src[i].fd = open_in(spills[i].c_str()); src[i].in.reset(new bgzf_in_t(src[i].fd, 2)); if (!hdr_read(*src[i].in, src[i].h)) die("sort: bad spill file"); }
-		bgzf_out_t out(ofd, level, pool); hdr_write(out, h);
-		kway_merge(src, out); out.finish();
-		for (size_t i = 0; i < spills.size(); ++i) { close(src[i].fd); unlink(spills[i].c_str()); }
+		const double t_m = wall();
+		merge_runs(runs, range_lo.size(), h, ofd, level, pool);
+		if (dbg()) fprintf(stderr, "[sambamba] sort: input %.2f s (from start), %zu sorted runs merged in %zu ranges of the genome by %d threads: %.2f s\n", t_in - t_start, runs.size(), range_lo.size(), pool, wall() - t_m);
+		for (run_t &R : runs) { close(R.fd); unlink(R.path.c_str()); }
 	}
 	close(ofd);
 	if (bai_note) bai_note_write(outp);
