@@ -301,7 +301,7 @@ struct fq_feed_t {
 	 * the file really is truncated there) is thrown away and the rest of the file is parsed serially from that piece's start. */
 	bool parse_plain(const std::string &path, bool keep_comment, int per_block)
 	{
-		size_t piece = (size_t)48 << 20; int T = 4;
+		size_t piece = (size_t)48 << 20; int T = std::thread::hardware_concurrency() >= 32 ? 6 : 4;
 		{ const char *e = getenv("SSG_FASTQ_PIECE"); if (e && atol(e) > 0) piece = (size_t)atol(e); }
 		{ const char *e = getenv("SSG_FASTQ_THREADS"); if (e) T = atoi(e); }
 		if (T < 2) return false;
