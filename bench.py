@@ -444,7 +444,10 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl.%h.%p.log")   # RCCL's banner / warnings off stdout: this program prints ONE JSON line
         import torch.distributed as dist
         from speedseq_amd import dist as ssdist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.emu_selftest:
+            dist.init_process_group("gloo")                   # the flow check of the N > 1 step on the host emulation
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     emu = a.emu_selftest
     if not emu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")

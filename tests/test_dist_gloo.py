@@ -2,6 +2,7 @@
 Pairs are dealt to two ranks by upstream batch; the exact global duplicate flags computed through the
 signature all-to-all must equal the oracle samblaster's single-stream flags."""
 import os
+import subprocess
 import tempfile
 
 import numpy as np
@@ -10,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import common
+from common import ROOT
 
 
 def _worker(rank, world, port, ends_path, batch_path, out_dir):
@@ -125,3 +127,22 @@ def test_coordinate_range_exchange_three_ranks_gloo():
     assert np.array_equal(got_o, exp) and np.array_equal(got_k, keys[exp])
     assert np.array_equal(got_r[:, 0], (exp % 251).astype(np.uint8)) and np.array_equal(got_r[:, 2], (keys[exp] & 0xff).astype(np.uint8))
     assert all(len(o[0]) > n // 10 for o in outs)                             # the splitters balance the ranges
+
+
+def test_bench_two_rank_flow_on_the_emulation(emu_lib, tmp_path):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one JSON line from rank 0), on the host emulation with gloo in
+    place of RCCL: the N > 1 step (global duplicate marking, coordinate range exchange) end to end at toy size.  Test infrastructure:
+    never a number."""
+    import json
+    import sys
+    env = dict(os.environ, SSG_EMU_DEVICES="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29583",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emu-selftest", "--no-e2e", "--cpu-sample", "0", "--partial", str(tmp_path / "p.json")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "range exchange" in d["config"]["sorted_merge"]
