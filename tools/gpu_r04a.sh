@@ -6,6 +6,8 @@
 #   3. the same script leg with the frame payloads back on the pipes (SSG_FUSED_SHM=0): what the segments are worth on this box
 #   4. config 3 soak: 40 M pairs through the script on one GPU (rate, peak RSS, spills, flagstat-level invariants)
 #   5. kernel-trace stats of the device step for profiles/r04_*
+#   6. the reproducer for DESIGN.md section 9's open item (run `tools/dbg/smem_variants.sh build` HERE before the gpurun call: the variant
+#      libraries travel with the snapshot)
 out=$PWD/gpurun_out; mkdir -p $out; repo=$PWD
 timeout 900 python -m pytest tests -m gpu -x -q > $out/r04a_pytest_gpu.log 2>&1; tail -3 $out/r04a_pytest_gpu.log
 timeout 900 python bench.py --steps 5 --warmup 2 > $out/r04a_bench.json 2> $out/r04a_bench.err; tail -4 $out/r04a_bench.err
@@ -29,3 +31,4 @@ timeout 900 python tools/soak.py --pairs 40000000 > $out/r04a_soak.json 2> $out/
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $repo/bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-e2e --no-profile --config5-pairs 0 --no-dist-rehearsal > $out/r04a_bench_under_rocprof.json 2> $out/r04a_rocprof.err
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then (head -1 $f; grep ssg_k $f) > $out/r04a_kernel_stats_ssg.csv; head -8 $out/r04a_kernel_stats_ssg.csv; fi
+cd $repo && bash tools/dbg/smem_variants.sh run
