@@ -110,8 +110,6 @@ static int main_mem(int argc, char **argv)
 	if (!interleaved && !fp2) { fprintf(stderr, "[bwa] single-end input is not supported: speedseq align is paired-end\n"); return 1; }
 	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
 	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
-	/* the readers (inflate + parse) start now: the first batches are parsed while the index travels to the device(s) */
-	fq_feed_t feed1(fp1, keep_comment, 16384, argv[ai + 1]); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2]) : 0);
 
 	/* One worker thread per visible device (SURVEY 8e coupling 1: whole upstream batches go to the GPUs, no collective): each loads its
 	 * own replica of the index and takes the next assembled batch when it is free; results are re-serialised in input order. */
@@ -119,6 +117,10 @@ static int main_mem(int argc, char **argv)
 	{ const char *e = getenv("SSG_BWA_DEVICES"); if (e && atoi(e) > 0) n_dev = std::min(n_dev, atoi(e)); }
 	if (n_dev < 1) { fprintf(stderr, "[bwa] no MI355X visible: %s has no CPU path\n", ssg_backend()); return 1; }
 	if (n_dev > 16) n_dev = 16;
+	/* the readers (inflate + parse) start now: the first batches are parsed while the index travels to the device(s); several devices
+	 * take proportionally more parse threads on plain files (one thread parses about what one MI355X aligns) */
+	const int parse_hint = n_dev > 1 ? std::min(48, (fp2 ? 3 : 5) * n_dev) : 0;
+	fq_feed_t feed1(fp1, keep_comment, 16384, argv[ai + 1], parse_hint); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2], parse_hint) : 0);
 	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
 	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms
 	 * per million pairs: a run does not know how long its input is, so each device makes the copy once it has aligned this many pairs

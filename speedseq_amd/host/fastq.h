@@ -299,9 +299,9 @@ struct fq_feed_t {
 	 * sequence in the serial parser too).  The first piece starts at byte 0, so by induction every cut is a true record start as long
 	 * as no earlier piece ended inside a quality string; the first piece that does (a '@' quality line was taken for a header, or
 	 * the file really is truncated there) is thrown away and the rest of the file is parsed serially from that piece's start. */
-	bool parse_plain(const std::string &path, bool keep_comment, int per_block)
+	bool parse_plain(const std::string &path, bool keep_comment, int per_block, int threads_hint)
 	{
-		size_t piece = (size_t)48 << 20; int T = std::thread::hardware_concurrency() >= 32 ? 6 : 4;
+		size_t piece = (size_t)48 << 20; int T = threads_hint > 0 ? threads_hint : std::thread::hardware_concurrency() >= 32 ? 6 : 4;
 		{ const char *e = getenv("SSG_FASTQ_PIECE"); if (e && atol(e) > 0) piece = (size_t)atol(e); }
 		{ const char *e = getenv("SSG_FASTQ_THREADS"); if (e) T = atoi(e); }
 		if (T < 2) return false;
@@ -359,11 +359,12 @@ struct fq_feed_t {
 		close(fd);
 		return true;
 	}
-	fq_feed_t(gzFile fp, bool keep_comment, int per_block, const char *path = 0) : ch(4), pool(new fq_block_pool_t())
+	/* threads_hint: parse threads for a plain file when the caller knows better than the default (several GPUs to feed); SSG_FASTQ_THREADS wins */
+	fq_feed_t(gzFile fp, bool keep_comment, int per_block, const char *path = 0, int threads_hint = 0) : ch(4), pool(new fq_block_pool_t())
 	{
 		const std::string pth(path ? path : "");
-		th = std::thread([this, fp, keep_comment, per_block, pth]() {
-			if (pth.empty() || !parse_plain(pth, keep_comment, per_block)) {
+		th = std::thread([this, fp, keep_comment, per_block, pth, threads_hint]() {
+			if (pth.empty() || !parse_plain(pth, keep_comment, per_block, threads_hint)) {
 				fq_reader_t rd(fp, keep_comment, pth.empty() ? 0 : pth.c_str());
 				(void)drain(rd, per_block, [this](blk_t b) { ch.push(std::move(b)); });
 			}
