@@ -11,7 +11,7 @@ all: lib tools oracle emu synth
 lib: speedseq_amd/libssgpu.so
 $(CSRC)/ssgpu_core.o: $(CSRC)/ssgpu_core.cpp $(KHDRS)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
-$(CSRC)/ssg_index_build.o: $(CSRC)/ssg_index_build.cpp $(CSRC)/k_index.h $(CSRC)/ssg_prim.h $(CSRC)/ssg_rt.h $(CSRC)/ssg_dev.h $(CSRC)/ssg_index_int.h include/ssgpu.h
+$(CSRC)/ssg_index_build.o: $(CSRC)/ssg_index_build.cpp $(CSRC)/k_index.h $(CSRC)/ssg_prim.h $(CSRC)/ssg_rt.h $(CSRC)/ssg_dev.h $(CSRC)/ssg_index_int.h $(CSRC)/ssg_types.h include/ssgpu.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 $(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp include/ssgpu.h $(CSRC)/ssg_types.h
 	$(CXX) -O2 -std=c++17 -fPIC -c $< -o $@

@@ -31,7 +31,7 @@ static inline int prim_sort_pairs_u64(const uint64_t *k_in, uint64_t *k_out, con
 	PRIM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, n, b0, b1), "hipcub SortPairs (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { ssg_err_msg = "device allocation failed: sort temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, k_in, k_out, v_in, v_out, n, b0, b1);
+	hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, k_in, k_out, v_in, v_out, n, b0, b1, ssg_stream);
 	int rc = rt_sync(); rt_free(tmp);
 	if (e != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
@@ -57,7 +57,7 @@ static inline int prim_scan_max_i64(const int64_t *in, int64_t *out, int64_t n)
 	PRIM_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tb, in, out, prim_max_i64(), n), "hipcub InclusiveScan (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { ssg_err_msg = "device allocation failed: scan temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceScan::InclusiveScan(tmp, tb, in, out, prim_max_i64(), n);
+	hipError_t e = hipcub::DeviceScan::InclusiveScan(tmp, tb, in, out, prim_max_i64(), n, ssg_stream);
 	int rc = rt_sync(); rt_free(tmp);
 	if (e != hipSuccess) { ssg_err_msg = "hipcub InclusiveScan failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
@@ -79,7 +79,7 @@ static inline int prim_exsum_u32_u64(const uint32_t *in, uint64_t *out, int64_t 
 	PRIM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, out, n + 1), "hipcub ExclusiveSum (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { ssg_err_msg = "device allocation failed: scan temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, it, out, n + 1);
+	hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, it, out, n + 1, ssg_stream);
 	int rc = rt_sync(); rt_free(tmp);
 	if (e != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
@@ -101,7 +101,7 @@ static inline int prim_count_flags(const uint8_t *flag, int64_t n, uint64_t *cou
 	PRIM_TRY(hipcub::DeviceReduce::Sum(nullptr, tb, it, d_out, n), "hipcub Reduce (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp || !d_out) { ssg_err_msg = "device allocation failed: reduce temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceReduce::Sum(tmp, tb, it, d_out, n);
+	hipError_t e = hipcub::DeviceReduce::Sum(tmp, tb, it, d_out, n, ssg_stream);
 	int rc = rt_sync();
 	if (!rc) rc = rt_d2h(count, d_out, 8);
 	rt_free(tmp); rt_free(d_out);
@@ -128,8 +128,8 @@ static inline int prim_select_u64(const uint64_t *in, uint64_t base, const uint8
 	else { PRIM_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb, cit, flag, out, d_cnt, n), "hipcub Select (size query)"); }
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { rt_free(d_cnt); ssg_err_msg = "device allocation failed: select temporaries"; return -12; }
-	if (in) e = hipcub::DeviceSelect::Flagged(tmp, tb, in, flag, out, d_cnt, n);
-	else e = hipcub::DeviceSelect::Flagged(tmp, tb, cit, flag, out, d_cnt, n);
+	if (in) e = hipcub::DeviceSelect::Flagged(tmp, tb, in, flag, out, d_cnt, n, ssg_stream);
+	else e = hipcub::DeviceSelect::Flagged(tmp, tb, cit, flag, out, d_cnt, n, ssg_stream);
 	int rc = rt_sync();
 	if (!rc) rc = rt_d2h(n_out, d_cnt, 8);
 	rt_free(tmp); rt_free(d_cnt);

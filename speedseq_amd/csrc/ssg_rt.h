@@ -20,6 +20,9 @@ extern thread_local std::string ssg_err_msg;
 extern thread_local int ssg_cur_dev;
 static inline int rt_device_count() { const char *e = getenv("SSG_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
 static inline int rt_set_device(int d) { if (d < 0 || d >= rt_device_count()) { ssg_err_msg = "ssg_set_device: no such device"; return -22; } ssg_cur_dev = d; return 0; }
+#define SSG_MAX_LANE 4
+extern thread_local int ssg_lane;
+static inline int rt_set_lane(int l) { if (l < 0 || l >= SSG_MAX_LANE) { ssg_err_msg = "ssg_set_lane: lane out of range"; return -22; } ssg_lane = l; return 0; }
 static inline void *rt_malloc(size_t n) { return calloc(n ? n : 1, 1); }
 static inline void rt_free(void *p) { free(p); }
 static inline int rt_h2d(void *d, const void *h, size_t n) { if (n) memcpy(d, h, n); return 0; }
@@ -51,7 +54,24 @@ static inline int rt_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hi
  * streams -- is selected by the calling thread's current device, so N threads can drive N devices through the same entry points */
 #define SSG_MAX_DEV 16
 extern thread_local int ssg_cur_dev;
-static inline int rt_set_device(int d) { if (d < 0 || d >= SSG_MAX_DEV) { ssg_err_msg = "ssg_set_device: device index out of range"; return -22; } int rc = rt_check(hipSetDevice(d), "hipSetDevice"); if (!rc) ssg_cur_dev = d; return rc; }
+/* Lanes: several calls in flight on ONE device (ssg_set_lane, bin/bwa's SSG_BWA_INFLIGHT).  Lane 0 is the default stream, one call at a
+ * time per device, as ever.  A thread on lane k > 0 does everything -- launches, copies, fills, library primitives, the fork / join of
+ * its side streams -- on the stream of (device, k), waits only for that stream, and allocates from an arena of its own: an arena
+ * hands a freed block to the next request in stream order, which holds within a lane and not across two. */
+#define SSG_MAX_LANE 4
+extern thread_local int ssg_lane;
+extern thread_local hipStream_t ssg_stream;
+#include <mutex>
+static inline hipStream_t ssg_lane_stream(int dev, int lane)
+{
+	static hipStream_t s[SSG_MAX_DEV][SSG_MAX_LANE]; static std::mutex mu;
+	if (lane <= 0) return 0;
+	std::lock_guard<std::mutex> l(mu);
+	if (!s[dev][lane]) (void)hipStreamCreateWithFlags(&s[dev][lane], hipStreamNonBlocking);
+	return s[dev][lane];
+}
+static inline int rt_set_device(int d) { if (d < 0 || d >= SSG_MAX_DEV) { ssg_err_msg = "ssg_set_device: device index out of range"; return -22; } int rc = rt_check(hipSetDevice(d), "hipSetDevice"); if (!rc) { ssg_cur_dev = d; ssg_stream = ssg_lane_stream(d, ssg_lane); } return rc; }
+static inline int rt_set_lane(int l) { if (l < 0 || l >= SSG_MAX_LANE) { ssg_err_msg = "ssg_set_lane: lane out of range"; return -22; } ssg_lane = l; ssg_stream = ssg_lane_stream(ssg_cur_dev, l); if (l && !ssg_stream) { ssg_err_msg = "ssg_set_lane: cannot create a stream"; return -1000; } return 0; }
 /* HBM arena: freed blocks are kept in size-class free lists and reused by later calls, so the
  * steady-state hot path performs no hipMalloc/hipFree (288 GB of HBM3E make the slack irrelevant) */
 #include <map>
@@ -70,25 +90,30 @@ struct ssg_pool_t {
 	bool put(void *p) { std::lock_guard<std::mutex> l(mu); auto it = size_.find(p); if (it == size_.end()) return false; free_[it->second].push_back(p); return true; }
 	void release() { std::lock_guard<std::mutex> l(mu); for (auto &kv : free_) for (void *p : kv.second) { size_.erase(p); (void)hipFree(p); } free_.clear(); }
 };
-extern ssg_pool_t ssg_pools[SSG_MAX_DEV];
-#define ssg_pool (ssg_pools[ssg_cur_dev])
+extern ssg_pool_t ssg_pools[SSG_MAX_DEV][SSG_MAX_LANE];
+#define ssg_pool (ssg_pools[ssg_cur_dev][ssg_lane])
 static inline void *rt_malloc(size_t n) { return ssg_pool.get(n); }
 static inline void rt_free(void *p)
 {	/* back to the arena of the device it came from (normally the caller's) */
 	if (!p) return;
 	if (ssg_pool.put(p)) return;
-	for (int d = 0; d < SSG_MAX_DEV; ++d) if (d != ssg_cur_dev && ssg_pools[d].put(p)) return;
+	for (int d = 0; d < SSG_MAX_DEV; ++d) for (int l = 0; l < SSG_MAX_LANE; ++l) if ((d != ssg_cur_dev || l != ssg_lane) && ssg_pools[d][l].put(p)) return;
 	(void)hipFree(p);
 }
-static inline int rt_h2d(void *d, const void *h, size_t n) { return n ? rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D") : 0; }
-static inline int rt_d2h(void *h, const void *d, size_t n) { return n ? rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
-static inline int rt_memset(void *d, int v, size_t n) { return n ? rt_check(hipMemset(d, v, n), "hipMemset") : 0; }
-static inline int rt_sync() { int rc = rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
+static inline int rt_lane_copy(void *d, const void *s, size_t n, hipMemcpyKind k, const char *what)
+{	/* on a lane: queued on its stream, and the host side may touch its buffer again when this returns */
+	int rc = rt_check(hipMemcpyAsync(d, s, n, k, ssg_stream), what);
+	return rc ? rc : rt_check(hipStreamSynchronize(ssg_stream), what);
+}
+static inline int rt_h2d(void *d, const void *h, size_t n) { return !n ? 0 : ssg_stream ? rt_lane_copy(d, h, n, hipMemcpyHostToDevice, "hipMemcpyAsync H2D") : rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+static inline int rt_d2h(void *h, const void *d, size_t n) { return !n ? 0 : ssg_stream ? rt_lane_copy(h, d, n, hipMemcpyDeviceToHost, "hipMemcpyAsync D2H") : rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+static inline int rt_memset(void *d, int v, size_t n) { return !n ? 0 : ssg_stream ? rt_check(hipMemsetAsync(d, v, n, ssg_stream), "hipMemsetAsync") : rt_check(hipMemset(d, v, n), "hipMemset"); }
+static inline int rt_sync() { int rc = ssg_stream ? rt_check(hipStreamSynchronize(ssg_stream), "hipStreamSynchronize") : rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
 /* multi-gigabyte, build-time-only arrays (index construction) bypass the arena: they must return to the driver when freed */
 static inline void *rt_malloc_raw(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); ssg_pool.release(); if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return 0; } } return p; }
 static inline void rt_free_raw(void *p) { if (p) (void)hipFree(p); }
 static inline void rt_pool_release() { ssg_pool.release(); }
-static inline int rt_d2d(void *d, const void *s, size_t n) { return n ? rt_check(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice), "hipMemcpy D2D") : 0; }
+static inline int rt_d2d(void *d, const void *s, size_t n) { return !n ? 0 : ssg_stream ? rt_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ssg_stream), "hipMemcpyAsync D2D") : rt_check(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice), "hipMemcpy D2D"); }
 /* page-locked host memory for the results a call hands to its caller.  A pageable destination costs a staging copy plus first-touch
  * faults and zero-fill of a fresh multi-hundred-MB block per call; page-locked blocks copy at PCIe speed but are expensive to make,
  * so freed blocks wait here for the next call (at most 4 GB of them). */
@@ -128,14 +153,14 @@ extern int ssg_prof_on;
 extern thread_local std::vector<ssg_prof_rec> ssg_prof_pending;   /* launches of this host thread; ssg_prof_flush() moves them to the process-wide table */
 void ssg_prof_flush();
 #define SSG_LAUNCH(kern, grid, block, lds, ...) do { if ((grid) > 0) { \
-	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, 0); \
-		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); (void)hipEventRecord(r_.b, 0); ssg_prof_pending.push_back(r_); } \
-	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), 0, __VA_ARGS__); } } while (0)
+	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, ssg_stream); \
+		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), ssg_stream, __VA_ARGS__); (void)hipEventRecord(r_.b, ssg_stream); ssg_prof_pending.push_back(r_); } \
+	else hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), ssg_stream, __VA_ARGS__); } } while (0)
 /* side streams for independent kernels that each leave most of the chip idle (few heavy work items): fork after the work
  * already queued on the default stream, launch with SSG_LAUNCH_ON(i, ...), join before anything that consumes the results */
-static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[SSG_MAX_DEV][8]; hipStream_t &x = s[ssg_cur_dev][i]; if (!x) (void)hipStreamCreateWithFlags(&x, hipStreamNonBlocking); return x; }
-static inline void ssg_fork(int n) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, 0); for (int i = 0; i < n; ++i) (void)hipStreamWaitEvent(ssg_side_stream(i), e, 0); (void)hipEventDestroy(e); }
-static inline void ssg_join(int n) { for (int i = 0; i < n; ++i) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, ssg_side_stream(i)); (void)hipStreamWaitEvent(0, e, 0); (void)hipEventDestroy(e); } }
+static inline hipStream_t ssg_side_stream(int i) { static hipStream_t s[SSG_MAX_DEV][SSG_MAX_LANE][8]; hipStream_t &x = s[ssg_cur_dev][ssg_lane][i]; if (!x) (void)hipStreamCreateWithFlags(&x, hipStreamNonBlocking); return x; }   /* a (device, lane) belongs to one thread at a time */
+static inline void ssg_fork(int n) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, ssg_stream); for (int i = 0; i < n; ++i) (void)hipStreamWaitEvent(ssg_side_stream(i), e, 0); (void)hipEventDestroy(e); }
+static inline void ssg_join(int n) { for (int i = 0; i < n; ++i) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); (void)hipEventRecord(e, ssg_side_stream(i)); (void)hipStreamWaitEvent(ssg_stream, e, 0); (void)hipEventDestroy(e); } }
 #define SSG_LAUNCH_ON(si, kern, grid, block, lds, ...) do { if ((grid) > 0) { hipStream_t st_ = ssg_side_stream(si); \
 	if (ssg_prof_on) { ssg_prof_rec r_; r_.name = #kern; (void)hipEventCreate(&r_.a); (void)hipEventCreate(&r_.b); (void)hipEventRecord(r_.a, st_); \
 		hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (lds), st_, __VA_ARGS__); (void)hipEventRecord(r_.b, st_); ssg_prof_pending.push_back(r_); } \

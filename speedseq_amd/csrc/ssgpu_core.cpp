@@ -35,8 +35,10 @@
 
 thread_local std::string ssg_err_msg;
 thread_local int ssg_cur_dev = 0;
+thread_local int ssg_lane = 0;
 #ifndef SSG_EMU
-ssg_pool_t ssg_pools[SSG_MAX_DEV];
+ssg_pool_t ssg_pools[SSG_MAX_DEV][SSG_MAX_LANE];
+thread_local hipStream_t ssg_stream = 0;
 ssg_hostpool_t ssg_hostpool;
 int ssg_prof_on = 0;
 thread_local std::vector<ssg_prof_rec> ssg_prof_pending;
@@ -70,6 +72,7 @@ const char *ssg_version(void) { return "0.1.0"; }
 const char *ssg_backend(void) { return SSG_BACKEND; }
 int ssg_device_count(void) { return rt_device_count(); }
 int ssg_set_device(int dev) { return rt_set_device(dev); }
+int ssg_set_lane(int lane) { return rt_set_lane(lane); }
 const char *ssg_last_error(void) { return ssg_err_msg.c_str(); }
 void ssg_free(void *p) { free(p); }
 
@@ -498,7 +501,7 @@ static int sort_keys_u64(uint64_t *k_in, uint64_t *k_out, long n, int begin_bit,
 	if (hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, k_in, k_out, (int)n, begin_bit, end_bit) != hipSuccess) { ssg_err_msg = "hipcub SortKeys (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes);
 	CHKA(tmp);
-	if (hipcub::DeviceRadixSort::SortKeys(tmp.p, tmp_bytes, k_in, k_out, (int)n, begin_bit, end_bit) != hipSuccess) { ssg_err_msg = "hipcub SortKeys failed"; return SSG_EHIP; }
+	if (hipcub::DeviceRadixSort::SortKeys(tmp.p, tmp_bytes, k_in, k_out, (int)n, begin_bit, end_bit, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub SortKeys failed"; return SSG_EHIP; }
 	return 0;
 #endif
 }
@@ -517,7 +520,7 @@ static int dev_exclusive_scan(const int32_t *d_in, int64_t *d_out, long n, int64
 	if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, it, d_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes + 16);
 	CHKA(tmp);
-	if (hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, it, d_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum failed"; return SSG_EHIP; }
+	if (hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, it, d_out, (int)n, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum failed"; return SSG_EHIP; }
 	SSG_LAUNCH(ssg_k_scan_tail, 1, 64, 0, d_in, d_out, n);
 	return rt_d2h(total, d_out + n, 8);
 #endif
@@ -540,7 +543,7 @@ static int dev_order_desc(const int32_t *d_key, int32_t *d_order, long n)
 	if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_key, kout.p, iota.p, d_order, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairsDescending (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes + 16);
 	CHKA(tmp);
-	if (hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tmp_bytes, d_key, kout.p, iota.p, d_order, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairsDescending failed"; return SSG_EHIP; }
+	if (hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tmp_bytes, d_key, kout.p, iota.p, d_order, (int)n, 0, 32, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub SortPairsDescending failed"; return SSG_EHIP; }
 	return rt_sync();   /* the temporaries are released on return */
 #endif
 }
@@ -943,7 +946,7 @@ static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint3
 	if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int64_t)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes);
 	CHKA(tmp);
-	if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int64_t)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; return SSG_EHIP; }
+	if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int64_t)n, 0, 64, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; return SSG_EHIP; }
 	return rt_sync();
 #endif
 }

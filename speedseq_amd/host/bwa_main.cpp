@@ -21,6 +21,7 @@
 #include <fcntl.h>
 #include <errno.h>
 #include <map>
+#include <shared_mutex>
 #include <atomic>
 #include <mutex>
 #include <condition_variable>
@@ -190,7 +191,11 @@ static int main_mem(int argc, char **argv)
 			for (std::thread &x : th) x.join();
 		}
 	};
-	chan_t<std::unique_ptr<batch_t> > to_gpu((size_t)n_dev);
+	/* SSG_BWA_INFLIGHT = k > 1: k worker threads per device, each on a lane of its own (ssg_set_lane: own stream, own arena), so that the
+	 * upload and download of one call run under the kernels of another; default 1 = the default stream */
+	int inflight = 1; { const char *e = getenv("SSG_BWA_INFLIGHT"); if (e && atoi(e) > 0) inflight = std::min(3, atoi(e)); }
+	const int n_work = n_dev * inflight;
+	chan_t<std::unique_ptr<batch_t> > to_gpu((size_t)n_work);
 	/* aligned batches wait here for their turn: the formatter takes them in input order whichever device finished first */
 	struct reorder_t {
 		std::mutex mu; std::condition_variable cv; std::map<int64_t, std::unique_ptr<batch_t> > ready; int64_t next; int open_workers; size_t cap;
@@ -207,7 +212,7 @@ static int main_mem(int argc, char **argv)
 			}
 			B = std::move(ready.begin()->second); ready.erase(ready.begin()); ++next; cv.notify_all(); return true;
 		}
-	} to_fmt(n_dev, (size_t)n_dev + 1);
+	} to_fmt(n_work, (size_t)n_work + 1);
 	double tm_asm = 0; std::vector<double> tm_gpu((size_t)n_dev, 0.0); std::vector<long> calls((size_t)n_dev, 0);
 	std::thread t_asm([&]() {
 		fq_cursor_t c1(feed1); std::unique_ptr<fq_cursor_t> c2(feed2 ? new fq_cursor_t(*feed2) : 0);
@@ -249,21 +254,31 @@ static int main_mem(int argc, char **argv)
 		to_gpu.close();
 	});
 	std::vector<std::thread> t_gpu;
-	for (int g = 0; g < n_dev; ++g) t_gpu.emplace_back([&, g]() {
-		std::unique_ptr<batch_t> B; long pairs_here = 0; bool dense = densify_after <= 0;
-		if (ssg_set_device(g)) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; }
+	/* per device: calls hold the index shared, the one-off densification holds it alone */
+	struct dev_state_t { std::shared_mutex mu; std::atomic<long> pairs{0}; std::atomic<bool> dense{false}; std::mutex tm; };
+	std::vector<std::unique_ptr<dev_state_t> > ds; for (int g = 0; g < n_dev; ++g) { ds.emplace_back(new dev_state_t()); ds.back()->dense = densify_after <= 0; }
+	for (int w = 0; w < n_work; ++w) t_gpu.emplace_back([&, w]() {
+		const int g = w / inflight, lane = inflight > 1 ? 1 + w % inflight : 0;
+		dev_state_t &D = *ds[(size_t)g];
+		std::unique_ptr<batch_t> B;
+		if (ssg_set_device(g) || ssg_set_lane(lane)) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; }
 		while (to_gpu.pop(B)) {
 			const double t0 = wall();
 			B->dev = g;
-			if (!dense && !fail && pairs_here >= densify_after) {
-				dense = true;
-				if (ssg_index_densify(idxs[(size_t)g])) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; }
-				else fprintf(stderr, "[bwa] device %d: denser suffix-array copy made after %ld pairs (%.2f s)\n", g, pairs_here, wall() - t0);
+			if (!fail && !D.dense.load() && D.pairs.load() >= densify_after) {
+				std::unique_lock<std::shared_mutex> l(D.mu);
+				if (!D.dense.load()) {
+					if (ssg_index_densify(idxs[(size_t)g])) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; }
+					else fprintf(stderr, "[bwa] device %d: denser suffix-array copy made after %ld pairs (%.2f s)\n", g, D.pairs.load(), wall() - t0);
+					D.dense = true;
+				}
 			}
-			pairs_here += B->n() / 2;
-			if (!fail && ssg_mem_process_pairs(idxs[(size_t)g], &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
-				fprintf(stderr, "[bwa] alignment failed on device %d: %s\n", g, ssg_last_error()); fail = 1; }
-			tm_gpu[(size_t)g] += wall() - t0; ++calls[(size_t)g];
+			D.pairs += B->n() / 2;
+			{	std::shared_lock<std::shared_mutex> l(D.mu);
+				if (!fail && ssg_mem_process_pairs(idxs[(size_t)g], &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
+					fprintf(stderr, "[bwa] alignment failed on device %d: %s\n", g, ssg_last_error()); fail = 1; }
+			}
+			{ std::lock_guard<std::mutex> l(D.tm); tm_gpu[(size_t)g] += wall() - t0; ++calls[(size_t)g]; }
 			if (!fail) to_fmt.put(std::move(B));
 		}
 		to_fmt.worker_done();

@@ -211,3 +211,18 @@ def test_cli_emu_deferred_dense_suffix_array(tmp_path, emu_lib):
         errs.append(r.stderr.decode())
     assert outs[0].count("\n") > 1200 and outs[1] == outs[0] and outs[2] == outs[0]
     assert "denser suffix-array copy made after" in errs[1] and "denser suffix-array" not in errs[0] and "denser suffix-array" not in errs[2]
+
+
+def test_cli_emu_several_calls_in_flight(tmp_path, emu_lib):
+    """SSG_BWA_INFLIGHT = 2 or 3 worker threads per device, each on a lane of its own (ssg_set_lane), with the suffix-array densification
+    falling between their calls: the SAM text is that of one call at a time"""
+    exe = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    fq = str(tmp_path / "r.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 900, seed=93))
+    outs = []
+    for inflight, devices, after in (("1", "1", "0"), ("2", "2", "300"), ("3", "1", "200")):
+        env = dict(os.environ, SSG_BWA_INFLIGHT=inflight, SSG_EMU_DEVICES=devices, SSG_BWA_DENSIFY_AFTER=after, SSG_BWA_CHUNK_BASES="20000", SSG_BWA_CALL_PAIRS="90")
+        r = subprocess.run([exe, "mem", "-t", "2", "-p", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(_no_pg(r.stdout.decode()))
+    assert outs[0].count("\n") > 1800 and outs[1] == outs[0] and outs[2] == outs[0]

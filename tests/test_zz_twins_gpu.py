@@ -74,3 +74,17 @@ def test_gpu_deferred_dense_suffix_array(tmp_path, gpu_lib):
         outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
         assert (b"denser suffix-array copy made after" in r.stderr) == (after == "1400")
     assert outs[0].count(b"\n") > 6000 and outs[1] == outs[0] and outs[2] == outs[0]
+
+
+def test_gpu_zz_two_calls_in_flight(tmp_path, gpu_lib):
+    """SSG_BWA_INFLIGHT=2 (two lanes per device: own streams and arenas, ssg_set_lane) against one call at a time: same SAM.  Last of the
+    file: the lanes had not run on an MI355X when this was written; a run that does not finish is cut off after two minutes."""
+    fq = str(tmp_path / "r.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 4000, seed=93))
+    outs = []
+    for inflight in ("1", "2"):
+        env = dict(os.environ, SSG_BWA_INFLIGHT=inflight, SSG_BWA_CHUNK_BASES="60000", SSG_BWA_CALL_PAIRS="500", SSG_BWA_DENSIFY_AFTER="1500")
+        r = subprocess.run([B("bwa"), "mem", "-t", "2", "-p", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
+    assert outs[0].count(b"\n") > 8000 and outs[1] == outs[0]
