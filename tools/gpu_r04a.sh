@@ -4,6 +4,7 @@
 #   2. the bench line as the driver runs it (literal metric on 8 M pairs with the stage timers: index load split, samblaster's main thread,
 #      the sort's input / write / index split)
 #   3. the same script leg with the frame payloads back on the pipes (SSG_FUSED_SHM=0): what the segments are worth on this box
+#   3b. the same leg with two device calls in flight per GPU (SSG_BWA_INFLIGHT=2, lanes)
 #   4. config 3 soak: 40 M pairs through the script on one GPU (rate, peak RSS, spills, flagstat-level invariants)
 #   5. kernel-trace stats of the device step for profiles/r04_*
 #   6. the reproducer for DESIGN.md section 9's open item (run `tools/dbg/smem_variants.sh build` HERE before the gpurun call: the variant
@@ -26,6 +27,13 @@ import json
 d=json.load(open('gpurun_out/r04a_bench_pipes.json')); r=d.get('literal',{}).get('fused',{})
 print('payloads on the pipes:', {x:r.get(x) for x in ('pairs','wall_s','pairs_per_s','error')})
 for l in r.get('stage_log',[]): print('   ', l)
+PY
+SSG_BENCH_CONFIG_EXTRA="export SSG_BWA_INFLIGHT=2" timeout 600 python bench.py --steps 2 --warmup 1 --cpu-sample 2000 --config5-pairs 0 --cpu-script-pairs 0 --no-dist-rehearsal --no-profile > $out/r04a_bench_inflight2.json 2> $out/r04a_bench_inflight2.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r04a_bench_inflight2.json')); r=d.get('literal',{}).get('fused',{})
+print('two calls in flight per GPU:', {x:r.get(x) for x in ('pairs','wall_s','pairs_per_s','error')}, 'sample BAMs equal oracle:', d.get('literal',{}).get('sample_bams_equal_oracle'))
+for l in r.get('stage_log',[])[:4]: print('   ', l)
 PY
 timeout 900 python tools/soak.py --pairs 40000000 > $out/r04a_soak.json 2> $out/r04a_soak.err; tail -3 $out/r04a_soak.err; head -c 1500 $out/r04a_soak.json
 cd /tmp && export TMPDIR=/tmp
