@@ -307,6 +307,13 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
         os.killpg(p.pid, signal.SIGKILL)                       # the whole pipeline (the script's children share the session)
         so, se = p.communicate()
         shutil.rmtree(bindir, ignore_errors=True)
+        for f in os.listdir("/dev/shm") if os.path.isdir("/dev/shm") else []:   # frame payloads of the killed pipeline (fused.h segments): their writers are gone
+            m = f.split(".")
+            if f.startswith("ssgfuse.") and len(m) == 3 and m[1].isdigit() and not os.path.exists("/proc/" + m[1]):
+                try:
+                    os.remove(os.path.join("/dev/shm", f))
+                except OSError:
+                    pass
         return {"error": "no result within %d s; stderr tail: %s" % (limit_s, se[-600:])}
     t = time.perf_counter() - t
     shutil.rmtree(bindir, ignore_errors=True)
