@@ -271,3 +271,28 @@ def _fused_option_sets(tmp_path, opts, bwa, sbl, smb, n_pairs=500):
     assert len(got["text"][0]) > 100000 and got["fused"][0] == got["text"][0]
     assert got["fused"][1] == got["text"][1] and got["fused"][2] == got["text"][2]
     assert got["text"][2].count("\n") > 5
+
+
+def test_fused_sweep_of_stale_segments(tmp_path, emu_lib):
+    """a fused `bwa mem` removes the segments a dead pipeline left behind -- only those whose writer is gone AND that are older than an
+    hour (a live pipeline's writer may exit before its last segments are read)"""
+    import time
+    segdir = tmp_path / "seg"
+    segdir.mkdir()
+    dead = 4194000                                   # above any pid this container hands out
+    while os.path.exists("/proc/%d" % dead):
+        dead += 1
+    old = time.time() - 7200
+    stale = segdir / ("ssgfuse.%d.0" % dead)
+    fresh = segdir / ("ssgfuse.%d.1" % dead)
+    alive = segdir / ("ssgfuse.%d.0" % os.getpid())
+    other = segdir / "unrelated.bin"
+    for f in (stale, fresh, alive, other):
+        f.write_bytes(b"x" * 100)
+    for f in (stale, alive, other):
+        os.utime(str(f), (old, old))
+    fq = T._fastq(tmp_path, 50)
+    env = dict(os.environ, SSG_FUSED="1", SSG_FUSED_SHM=str(segdir))
+    r = subprocess.run([os.path.join(EMU, "bwa_emu"), "mem", "-t", "2", "-p", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert sorted(os.listdir(str(segdir))) == sorted([fresh.name, alive.name, other.name])
