@@ -36,6 +36,7 @@ print('two calls in flight per GPU:', {x:r.get(x) for x in ('pairs','wall_s','pa
 for l in r.get('stage_log',[])[:4]: print('   ', l)
 PY
 timeout 900 python tools/soak.py --pairs 40000000 > $out/r04a_soak.json 2> $out/r04a_soak.err; tail -3 $out/r04a_soak.err; head -c 1500 $out/r04a_soak.json
+timeout 600 python tools/soak.py --pairs 20000000 --mem 12 > $out/r04a_soak_spill.json 2> $out/r04a_soak_spill.err; head -c 1500 $out/r04a_soak_spill.json   # -M 12: sorted runs + the merge per range of the genome
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $repo/bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-e2e --no-profile --config5-pairs 0 --no-dist-rehearsal > $out/r04a_bench_under_rocprof.json 2> $out/r04a_rocprof.err
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then (head -1 $f; grep ssg_k $f) > $out/r04a_kernel_stats_ssg.csv; head -8 $out/r04a_kernel_stats_ssg.csv; fi
