@@ -299,9 +299,18 @@ static int main_mem(int argc, char **argv)
 		}
 	});
 	double tm_fmt = 0;
-	{	/* this thread: format, in input order */
+	/* formatters: batches are taken in input order, formatted (threads inside libssgpu), and handed to the writer in input order again;
+	 * one formatter keeps up with two devices, so there are more of them when there are more devices (SSG_BWA_FORMATTERS) */
+	int n_fmt = n_dev > 2 ? std::min(4, (n_dev + 1) / 2) : 1; { const char *e = getenv("SSG_BWA_FORMATTERS"); if (e && atoi(e) > 0) n_fmt = std::min(8, atoi(e)); }
+	struct ordered_t { std::mutex mu; std::map<int64_t, text_t> pend; int64_t next; ordered_t() : next(0) {} } ord;
+	auto emit = [&](int64_t seq, const text_t &t) {
+		std::lock_guard<std::mutex> l(ord.mu);
+		ord.pend[seq] = t;
+		while (!ord.pend.empty() && ord.pend.begin()->first == ord.next) { to_write.push(ord.pend.begin()->second); ord.pend.erase(ord.pend.begin()); ++ord.next; }
+	};
+	auto fmt_loop = [&]() {
 		std::unique_ptr<batch_t> B;
-		std::vector<int32_t> cand; std::vector<int64_t> sam_off;
+		std::vector<int32_t> cand; std::vector<int64_t> sam_off; double busy = 0;
 		while (to_fmt.take(B)) {
 			if (fail) { if (B->res) ssg_pe_result_free(B->res); continue; }
 			const double t0 = wall();
@@ -347,12 +356,22 @@ static int main_mem(int argc, char **argv)
 				}
 				ssg_free(bam); ssg_free(ctext);
 			}
-			tm_fmt += wall() - t0;
+			busy += wall() - t0;
 			const ssg_pestat_t *pp = ssg_pe_pes(B->res);
 			fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s device %d; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
 			        n, B->n_batches, ssg_backend(), B->dev, pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
 			ssg_pe_result_free(B->res);
-			to_write.push(t);
+			emit(B->seqno, t);
+		}
+		std::lock_guard<std::mutex> l(ord.mu); tm_fmt += busy;
+	};
+	{	std::vector<std::thread> t_fmt;
+		for (int k = 1; k < n_fmt; ++k) t_fmt.emplace_back(fmt_loop);
+		fmt_loop();
+		for (std::thread &x : t_fmt) x.join();
+		for (auto &kv : ord.pend) {   /* only after a failure: batches behind a lost one */
+			text_t &t = kv.second;
+			if (t.seg) { t.seg->reset(); unlink(t.seg_path->c_str()); delete t.seg; delete t.seg_path; } else ssg_free(t.p);
 		}
 	}
 	if (fused && !fail) { text_t t; t.len = 0; t.frame = FU_END; t.seg = 0; t.seg_path = 0; t.p = (char*)malloc(1); to_write.push(t); }

@@ -220,8 +220,8 @@ def test_cli_emu_several_calls_in_flight(tmp_path, emu_lib):
     fq = str(tmp_path / "r.fq")
     simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 900, seed=93))
     outs = []
-    for inflight, devices, after in (("1", "1", "0"), ("2", "2", "300"), ("3", "1", "200")):
-        env = dict(os.environ, SSG_BWA_INFLIGHT=inflight, SSG_EMU_DEVICES=devices, SSG_BWA_DENSIFY_AFTER=after, SSG_BWA_CHUNK_BASES="20000", SSG_BWA_CALL_PAIRS="90")
+    for inflight, devices, after, fmts in (("1", "1", "0", "1"), ("2", "2", "300", "3"), ("3", "1", "200", "2")):   # ... and several formatter threads behind them
+        env = dict(os.environ, SSG_BWA_INFLIGHT=inflight, SSG_EMU_DEVICES=devices, SSG_BWA_DENSIFY_AFTER=after, SSG_BWA_FORMATTERS=fmts, SSG_BWA_CHUNK_BASES="20000", SSG_BWA_CALL_PAIRS="90")
         r = subprocess.run([exe, "mem", "-t", "2", "-p", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=900)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(_no_pg(r.stdout.decode()))

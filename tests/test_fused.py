@@ -63,7 +63,7 @@ def test_fused_script_many_calls_two_devices_emulated(tmp_path, emu_lib):
     small = {"SSG_BWA_CHUNK_BASES": "6000", "SSG_BWA_CALL_PAIRS": "150"}
     text = T._run_align(str(tmp_path / "text"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, env_extra=small, **tools)
     fused = T._run_align(str(tmp_path / "fused"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, config_extra=FUSED,
-                         env_extra=dict(small, SSG_EMU_DEVICES="2", SSG_SORT_CHUNK_BYTES="200000"), **tools)
+                         env_extra=dict(small, SSG_EMU_DEVICES="2", SSG_SORT_CHUNK_BYTES="200000", SSG_BWA_FORMATTERS="3", SSG_BWA_INFLIGHT="2"), **tools)   # ... three formatter threads, two calls in flight per device
     _same_bam_records(fused, text)
 
 
