@@ -498,6 +498,9 @@ def main():
     reads = simulate_pairs(ref, lens, a.pairs, rl, 12 + rank, dev, **ins)
     n_more = max(0, max(a.e2e_pairs, a.script_pairs) - a.pairs)
     reads_e2e = simulate_pairs(ref, lens, n_more, rl, 1012, dev, **ins).cpu() if (a.e2e and world == 1 and a.cpu_sample > 0 and n_more > 0) else None   # further pairs for the plugin-path leg
+    # N > 1: rank 0 also times the reference's script on `bin/bwa mem` over all N devices (the product's own multi-GPU path) once the step is measured
+    n_ml = min(a.script_pairs, 4000000 * world) if (world > 1 and a.e2e and rank == 0) else 0
+    reads_ml = simulate_pairs(ref, lens, n_ml, rl, 2012, dev, **ins).cpu() if n_ml > 0 else None
     reads5 = simulate_pairs(ref, lens, a.config5_pairs, 250, 512, dev, ins_mean=800, ins_std=150) if (a.config5_pairs > 0 and rl == 150 and world == 1 and a.cpu_sample > 0) else None
     d_seq = reads.reshape(-1)
     d_off = (torch.arange(2 * a.pairs + 1, device=dev, dtype=torch.int64) * rl).contiguous()
@@ -804,6 +807,26 @@ def main():
             if not ok:   # no timing counts without parity
                 out["value"] = None
                 out["invalid"] = "parity gate failed: GPU records differ from the oracle"
+        if reads_ml is not None:
+            try:   # `speedseq align` (unmodified script, fused hand-off) with bin/bwa driving all N devices; the other ranks wait at the barrier below
+                import tempfile
+                shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+                with tempfile.TemporaryDirectory(dir=shm) as td:
+                    prefix = os.path.join(td, "ref.fa")
+                    lib.index_save(idx, prefix)
+                    fq = os.path.join(td, "reads.fq")
+                    write_fastq(fq, reads_ml.numpy(), rl)
+                    b = (lambda n: os.path.join(ROOT, "tests", "emu", n + "_emu")) if emu else (lambda n: os.path.join(ROOT, "bin", n))
+                    cfg = ("export SSG_FUSED=1\nexport SSG_BWA_DEVICES=%d\nexport SSG_SORT_THREADS=%d\nexport SSG_FMT_THREADS=%d\nexport SSG_SORT_LOG=1\nexport SSG_SBL_LOG=1\nexport SSG_LOAD_LOG=1\n"
+                           % (world, min(os.cpu_count() or 8, 256), min(os.cpu_count() or 8, 64)))
+                    r = script_leg(td, "multi", prefix, fq, n_ml, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=cfg, limit_s=180)
+                    r.pop("out", None)
+                    r["devices"] = world
+                    r["what"] = "`speedseq align -t %d -p` (reference script, unmodified; SSG_FUSED=1) with bin/bwa mem driving %d devices: whole upstream batches per device, no collective; FASTQ -> three sorted BAMs + BAI, index load on every device included" % (a.script_threads, world)
+                    out["literal_multi"] = r
+                    log('script on %d devices: %s pairs in %s s' % (world, r.get('pairs'), r.get('wall_s')))
+            except Exception as e:
+                out["literal_multi"] = {"error": repr(e)[:400]}
         if saved_stdout is not None:
             C.CDLL(None).fflush(None); sys.stdout.flush(); os.dup2(saved_stdout, 1)
         print(json.dumps(out)); sys.stdout.flush()

@@ -139,10 +139,12 @@ def test_bench_two_rank_flow_on_the_emulation(emu_lib, tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29583",
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emu-selftest", "--no-e2e", "--cpu-sample", "0", "--partial", str(tmp_path / "p.json")],
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emu-selftest", "--cpu-sample", "0", "--partial", str(tmp_path / "p.json")],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "range exchange" in d["config"]["sorted_merge"]
+    m = d["literal_multi"]                              # rank 0 also runs the reference's script with bin/bwa on both (emulated) devices
+    assert m.get("devices") == 2 and m.get("pairs_per_s", 0) > 0 and m.get("bai_written") is True, m
