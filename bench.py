@@ -427,6 +427,7 @@ def main():
     ap.add_argument("--script-threads", type=int, default=16, help="-t of the script legs on the product executables")
     ap.add_argument("--cpu-script-pairs", type=int, default=100000, help="pairs of the CPU baseline through the script (`speedseq align -t <cores>` on the oracle's executables; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile", dest="no_profile", action="store_false", help="(with --emu-selftest, which switches the per-kernel timing off) keep it on")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
     ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs in the FASTQ file of the plugin-path leg (the timed batch + freshly simulated ones): enough device calls for the pipeline's steady state to show")
     ap.add_argument("--config5-pairs", type=int, default=200000, help="pairs of the 2x250 leg (BASELINE.json configs[4]: long fragments, wider bands), 0 = skip")
@@ -630,10 +631,14 @@ def main():
                     traffic = pm.get("bytes_per_launch", {}).get(name)
             except Exception:
                 pass
-            valu = {}
+            valu = {}; sw_lane_ops = None
             try:   # fraction of the measured int32 VALU issue peak (tools/dbg/valu_probe) from the committed SQ counter pass of this workload
                 pq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
                 valu = {k: round(v["valu_frac_of_probe_peak"], 3) for k, v in pq["kernels"].items() if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_smem")) and "valu_frac_of_probe_peak" in v and not k.endswith("_need")}
+                # vector instructions of the SW kernels per step (committed counters of the same kernels' code: the ISA is pinned) x 64 lanes
+                pmc_steps = max(1, pq["kernels"].get("ssg_k_matesw", {}).get("launches", 1))   # one mate-rescue launch per step of the counter run
+                sw_lane_ops = 64.0 * sum(v["SQ_INSTS_VALU_per_launch"] * v["launches"] / pmc_steps for k, v in pq["kernels"].items()
+                                         if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need") and "SQ_INSTS_VALU_per_launch" in v)
             except Exception:
                 pass
             sw_names = [k for k in kern if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need")]
@@ -648,6 +653,7 @@ def main():
                                              "frac": (2.0 * n_ext / (kern[smk][0] / kern[smk][1] * 1e-3) / 55e9) if smk else None},
                                "sw": {"cells_per_step": int(summary[3]) + int(summary[4]), "kernels": sorted(sw_names),
                                       "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None,
+                                      "lane_ops_per_cell": (sw_lane_ops / (int(summary[3]) + int(summary[4]))) if sw_lane_ops and (int(summary[3]) + int(summary[4])) else None,   # SQ_INSTS_VALU x 64 of the SW kernels (committed counters, pinned ISA) over this run's DP cells
                                       "valu_frac": valu or None, "valu_frac_source": "profiles/r02_pmc_sq.json (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
         # ---- parity gate ON THE TIMED CALL + CPU baseline: the step is run once more on the same device-resident inputs with its records
         # kept in HBM (identical inputs -> identical records; the summaries are compared), the records and samblaster's per-line decisions
