@@ -346,7 +346,7 @@ SSG_DEVFN ssg_intv_t ssg_bwt_extend1_lean(const ssg_index_view_t &ix, const ssg_
 	/* same block: rk <= rl, so the fourth quarter is there whenever rk needs it (selected after the loads are out: a register copy
 	 * of the upper block here would wait for it before the lower block's loads are issued) */
 	uint32_t sm = same ? 0xffffffffu : 0u;            /* (x_l & sm) | x_k with x_k = 0 where nothing was loaded; opaque to the optimizer */
-#ifndef SSG_EMU
+#if !defined(SSG_EMU) && !defined(SSG_NO_ASM_PINS)   /* SSG_NO_ASM_PINS: diagnostic builds only (tools/dbg/smem_variants.sh) */
 	asm("" : "+v"(sm));
 #endif
 	SSG_UNROLL for (int i = 0; i < 4; ++i) { cqk.v[i] |= cql.v[i] & sm; w0k.v[i] |= w0l.v[i] & sm; w1k.v[i] |= w1l.v[i] & sm; }
@@ -364,7 +364,7 @@ SSG_DEVFN ssg_intv_t ssg_bwt_extend1_lean(const ssg_index_view_t &ix, const ssg_
 	/* L2[c] by selects over scalars (left to itself the compiler makes it a per-lane load from the kernel-argument segment: a
 	 * dependent memory round trip per extension) */
 	uint64_t L0 = ix.L2[0], L1 = ix.L2[1], L2v = ix.L2[2], L3 = ix.L2[3];
-#ifndef SSG_EMU
+#if !defined(SSG_EMU) && !defined(SSG_NO_ASM_PINS)
 	asm("" : "+s"(L0)); asm("" : "+s"(L1)); asm("" : "+s"(L2v)); asm("" : "+s"(L3));
 #endif
 	const uint64_t l2c = c == 0 ? L0 : c == 1 ? L1 : c == 2 ? L2v : L3;
