@@ -26,6 +26,7 @@
 #include <fcntl.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include "fast_inflate.h"
 
 template <class T> struct chan_t {      /* bounded single-producer / single-consumer channel */
 	std::mutex mu; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed, dead;
@@ -53,6 +54,7 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	gzFile fp; chunk_t buf; int begin, end; bool is_eof;
 	chan_t<std::unique_ptr<chunk_t> > full, empty; std::thread th;
 	std::atomic<bool> stop{false};
+	std::atomic<int> io_err{0};         /* the compressed stream was damaged or cut short: the parser reports the file as malformed at its end */
 	bool threaded;                      /* compressed input only: for a plain file the hand-over costs more than the read */
 	bool bgzf;                          /* blocked gzip (bgzip, htslib bgzf.c:298-342): independent <= 64 KB members with their size in the header, inflated by several threads */
 	int rfd; size_t roff, rend;         /* ranged mode (fq_feed_t's parallel parse of a plain file): bytes [roff, rend) of rfd through pread */
@@ -64,6 +66,35 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 		if (n < 12 + xlen) return 0;
 		for (size_t o = 12; o + 4 <= 12 + xlen; ) { const size_t sl = p[o + 2] | (size_t)p[o + 3] << 8; if (p[o] == 'B' && p[o + 1] == 'C' && sl == 2) return (size_t)(p[o + 4] | (size_t)p[o + 5] << 8) + 1; o += 4 + sl; }
 		return 0;
+	}
+	void fast_gz_loop(int fd)
+	{	/* inflate (fast_inflate.h) -> CRC-32 of every member against its trailer -> the parser: three threads in a row, 4 MB chunks */
+		struct piece_t { std::unique_ptr<chunk_t> c; bool member_end; uint32_t crc; };
+		chan_t<piece_t> mid(4);
+		std::thread t_crc([this, &mid]() {
+			uLong crc = crc32(0L, Z_NULL, 0); piece_t p;
+			while (mid.pop(p)) {
+				if (io_err.load()) continue;
+				if (p.c && !p.c->empty()) crc = crc32(crc, p.c->data(), (uInt)p.c->size());
+				if (p.member_end) { if ((uint32_t)crc != p.crc) { io_err = 1; continue; } crc = crc32(0L, Z_NULL, 0); }
+				if (p.c && !p.c->empty()) full.push(std::move(p.c));
+			}
+			full.close();
+		});
+		fast_gz_t g(fd);
+		while (!stop.load() && !io_err.load()) {
+			const uint8_t *d; bool mend = false;
+			const long n = g.read_chunk(&d, (size_t)4 << 20, &mend);
+			if (n < 0) { io_err = 1; break; }
+			if (!n && !mend) break;
+			piece_t p; p.member_end = mend; p.crc = g.crc_expect;
+			{ std::unique_lock<std::mutex> l(empty.mu); if (!empty.q.empty()) { p.c = std::move(empty.q.front()); empty.q.pop_front(); } }
+			if (!p.c) p.c.reset(new chunk_t());
+			p.c->assign(d, d + n);
+			mid.push(std::move(p));
+		}
+		mid.close();
+		t_crc.join();
 	}
 	void bgzf_loop(int fd, int n_threads)
 	{	/* batches of members: located by their headers, inflated in parallel, handed to the parser in file order */
@@ -105,7 +136,7 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 			for (int t = 1; t < n_threads; ++t) w.emplace_back(work);
 			work();
 			for (auto &x : w) x.join();
-			if (bad) break;                                      /* the parser sees a truncated stream and reports it */
+			if (bad) { io_err = 1; break; }                      /* the parser reports the file as malformed at its end */
 			if (total) full.push(std::move(c));
 		}
 		full.close();
@@ -119,11 +150,17 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 		if (path) {
 			struct stat sb;
 			const int fd = (stat(path, &sb) == 0 && S_ISREG(sb.st_mode)) ? open(path, O_RDONLY) : -1;   /* a pipe must not lose bytes to this look */
-			unsigned char h[18];
-			if (fd >= 0 && read(fd, h, 18) == 18 && bgzf_member(h, 18) && lseek(fd, 0, SEEK_SET) == 0) {
+			unsigned char h[18] = { 0 };
+			const ssize_t nh = fd >= 0 ? read(fd, h, 18) : -1;
+			if (nh == 18 && bgzf_member(h, 18) && lseek(fd, 0, SEEK_SET) == 0) {
 				bgzf = true;
 				int nt = 8; { const char *e = getenv("SSG_BGZF_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
 				th = std::thread([this, fd, nt]() { bgzf_loop(fd, nt); close(fd); });
+				return;
+			}
+			const char *gf = getenv("SSG_GZ_FAST");
+			if (nh >= 2 && h[0] == 0x1f && h[1] == 0x8b && !(gf && !strcmp(gf, "0")) && lseek(fd, 0, SEEK_SET) == 0) {
+				th = std::thread([this, fd]() { fast_gz_loop(fd); close(fd); });   /* plain gzip in a regular file: this repository's decoder, CRC on a thread of its own */
 				return;
 			}
 			if (fd >= 0) close(fd);
@@ -135,6 +172,7 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 				if (!c) c.reset(new chunk_t());
 				c->resize((size_t)4 << 20);
 				const int n = gzread(fp, c->data(), (unsigned)c->size());
+				if (n < 0) io_err = 1;
 				if (n <= 0) break;
 				c->resize((size_t)n);
 				full.push(std::move(c));
@@ -203,9 +241,9 @@ struct fq_reader_t {
 	int next(fq_block_t &b)
 	{
 		int c;
-		if (last_char == 0) { while ((c = ks.getc()) != -1 && c != '>' && c != '@') {} if (c == -1) return -1; last_char = c; }
+		if (last_char == 0) { while ((c = ks.getc()) != -1 && c != '>' && c != '@') {} if (c == -1) return ks.io_err.load() ? -2 : -1; last_char = c; }   /* a damaged compressed stream ends early: that is an error, not the end of the reads */
 		const size_t name0 = b.txt.size();
-		if (ks.getuntil(0, b.txt, &c) < 0) return -1;
+		if (ks.getuntil(0, b.txt, &c) < 0) return ks.io_err.load() ? -2 : -1;
 		size_t name_end = b.txt.size();
 		if (name_end - name0 > 2 && b.txt[name_end - 2] == '/' && isdigit((unsigned char)b.txt[name_end - 1])) { b.txt.resize(name_end - 2); name_end -= 2; }   /* trim_readno */
 		b.txt.push_back(0);

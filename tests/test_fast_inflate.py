@@ -1,0 +1,130 @@
+"""bin/bwa's gzip decoder (speedseq_amd/host/fast_inflate.h) against zlib: same bytes (size + CRC-32 of the output, and the decoder's own
+check of each member's CRC / length trailer) for every kind of stream zlib can write, and an error -- not wrong bytes, not a hang -- for
+truncated and damaged ones."""
+import os
+import random
+import struct
+import subprocess
+import zlib
+
+import pytest
+
+from common import ROOT
+
+FI = os.path.join(ROOT, "tests", "emu", "fi_test")
+
+
+def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strategy)
+    return c.compress(data) + c.flush()
+
+
+def run(path):
+    r = subprocess.run([FI, path, "crc"], capture_output=True, text=True, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+def check(tmp_path, blob, expect, members=None, name="x.gz"):
+    p = tmp_path / name
+    p.write_bytes(blob)
+    rc, out, err = run(str(p))
+    assert rc == 0, err
+    import re
+    m = re.match(r"(\d+) bytes, (\d+) members, crc ([0-9a-f]{8}),", out)
+    assert m and int(m.group(1)) == len(expect) and m.group(3) == "%08x" % zlib.crc32(expect), out
+    if members is not None:
+        assert int(m.group(2)) == members
+
+
+def fastq(rng, n):
+    out = []
+    for i in range(n):
+        l = rng.randint(50, 150)
+        out.append("@r%d/1\n%s\n+\n%s\n" % (i, "".join(rng.choices("ACGTN", k=l)), "".join(rng.choices("IIIIIHHGF#", k=l))))
+    return "".join(out).encode()
+
+
+SAMPLES = {
+    "fastq": lambda rng: fastq(rng, 40000),
+    "empty": lambda rng: b"",
+    "one_byte": lambda rng: b"A",
+    "random": lambda rng: bytes(rng.getrandbits(8) for _ in range(300000)),
+    "zeros": lambda rng: bytes(3000000),
+    "short_periods": lambda rng: b"".join((b"ab" * 700, b"abc" * 500, b"abcdefg" * 300, b"x" * 5000, b"0123456789ABCDE" * 400)) * 20,
+    "skewed": lambda rng: bytes(rng.choices(range(256), weights=[2.0 ** -(i % 23) for i in range(256)], k=400000)),   # long and short codes side by side
+    "text_far_matches": lambda rng: (fastq(rng, 300) + bytes(rng.getrandbits(8) for _ in range(30000))) * 12,       # matches 30 KB back, across chunks
+}
+
+
+@pytest.mark.parametrize("name", sorted(SAMPLES))
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 9])
+def test_same_bytes_as_zlib(tmp_path, name, level):
+    data = SAMPLES[name](random.Random(hash(name) & 0xffff))
+    check(tmp_path, gz(data, level), data, members=1)
+
+
+@pytest.mark.parametrize("strategy", [zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])
+def test_block_kinds(tmp_path, strategy):
+    rng = random.Random(5)
+    data = fastq(rng, 20000) + bytes(100000) + bytes(rng.getrandbits(8) for _ in range(50000))
+    check(tmp_path, gz(data, 6, strategy), data)
+    check(tmp_path, gz(data, 6, strategy, mem=1), data)     # small deflate memory: many short blocks
+
+
+def test_members_headers_and_trailing_bytes(tmp_path):
+    rng = random.Random(9)
+    a, b, c = fastq(rng, 5000), b"", fastq(rng, 7000)
+    blob = gz(a, 6) + gz(b, 6) + gz(c, 1)
+    check(tmp_path, blob, a + b + c, members=3)
+    # header with FEXTRA, FNAME, FCOMMENT and FHCRC (RFC 1952): skipped field by field
+    body = gz(a, 6)[10:]
+    hdr = b"\x1f\x8b\x08" + bytes([4 | 8 | 16 | 2]) + bytes(6) + struct.pack("<H", 5) + b"EXTRA" + b"name.fq\0" + b"a comment\0"
+    hdr += struct.pack("<H", zlib.crc32(hdr) & 0xffff)
+    check(tmp_path, hdr + body, a, members=1)
+    # bytes that are not a member after a complete one are ignored (gzread does the same)
+    check(tmp_path, gz(a, 6) + bytes(700), a, members=1)
+    # many members, some across the decoder's input refills
+    parts = [fastq(rng, rng.randint(1, 3000)) for _ in range(60)]
+    check(tmp_path, b"".join(gz(x, rng.choice([1, 6, 9])) for x in parts), b"".join(parts), members=60)
+
+
+def test_large_stream_many_chunks(tmp_path):
+    rng = random.Random(11)
+    data = fastq(rng, 200000)                        # ~50 MB of text: a dozen output chunks, input refills
+    check(tmp_path, gz(data, 6), data, members=1)
+
+
+def test_truncated_and_damaged_streams_are_errors(tmp_path):
+    rng = random.Random(13)
+    data = fastq(rng, 30000)
+    blob = gz(data, 6)
+    p = tmp_path / "t.gz"
+    for cut in [1, 5, 10, 11, 50, len(blob) // 3, len(blob) // 2, len(blob) - 9, len(blob) - 8, len(blob) - 1]:
+        p.write_bytes(blob[:cut])
+        rc, out, err = run(str(p))
+        assert rc == 1 and "error" in err, (cut, out, err)
+    stored = gz(data, 0)
+    for cut in [12, 14, 40000, len(stored) - 3]:
+        p.write_bytes(stored[:cut])
+        rc, out, err = run(str(p))
+        assert rc == 1, cut
+    bad = 0
+    for k in range(40):                               # a flipped byte is a structural error or a CRC / length mismatch -- never silence
+        pos = rng.randrange(12, len(blob) - 8)
+        dam = bytearray(blob)
+        dam[pos] ^= 1 << rng.randrange(8)
+        p.write_bytes(bytes(dam))
+        rc, out, err = run(str(p))
+        assert rc == 1, (pos, out)
+        bad += 1
+    assert bad == 40
+    p.write_bytes(b"not gzip at all")
+    assert run(str(p))[0] == 1
+    tr = bytearray(blob)
+    tr[-1] ^= 0x40                                    # length field of the trailer
+    p.write_bytes(bytes(tr))
+    assert run(str(p))[0] == 1
+    tr = bytearray(blob)
+    tr[-6] ^= 0x40                                    # CRC field of the trailer
+    p.write_bytes(bytes(tr))
+    assert run(str(p))[0] == 1

@@ -120,3 +120,31 @@ def test_bwa_emu_same_sam_with_pieces(tmp_path, emu_lib):
         outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
     assert outs[0].count(b"\n") > 800
     assert outs[1] == outs[0] and outs[2] == outs[0]
+
+
+@pytest.mark.parametrize("case", ["four_line", "wrapped", "fasta_mix", "truncated_end", "no_final_newline"])
+def test_gzip_input_through_the_fast_decoder(tmp_path, case):
+    """plain gzip files go through this repository's decoder (host/fast_inflate.h) with the CRC on a thread of its own: same records and end
+    state as through zlib (SSG_GZ_FAST=0) and as the uncompressed file; several members; a damaged or cut file is an error, not a short input"""
+    import gzip
+    rng = random.Random(hash(case) & 0xfff)
+    txt = CASES[case](rng).encode()
+    p = tmp_path / "x.fq"
+    p.write_bytes(txt)
+    g = tmp_path / "x.fq.gz"
+    g.write_bytes(gzip.compress(txt[:len(txt) // 2], 6) + gzip.compress(txt[len(txt) // 2:], 1))
+    ref, _ = dump(str(p), 1)
+
+    def dump_gz(path, fast):
+        env = dict(os.environ, SSG_GZ_FAST="1" if fast else "0")
+        return subprocess.run([FQ_DUMP, path], env=env, capture_output=True, check=True).stdout
+    assert dump_gz(str(g), True) == ref and dump_gz(str(g), False) == ref
+    blob = g.read_bytes()
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(blob[:len(blob) * 2 // 3])
+    out = dump_gz(str(cut), True)
+    assert out.splitlines()[-1].split(b"\t")[1] == b"-2"          # reported as malformed
+    dam = bytearray(blob)
+    dam[len(dam) // 3] ^= 0x10
+    cut.write_bytes(bytes(dam))
+    assert dump_gz(str(cut), True).splitlines()[-1].split(b"\t")[1] == b"-2"
