@@ -258,7 +258,10 @@ struct fast_gz_t {
 					if (dist > hist0 + (o - o0) || dist > WIN) { bad = "distance too far back"; break; }
 					const uint8_t *sp = ob + o - dist; uint8_t *t = ob + o;
 					o += len;
-					if (dist >= 8) { do { uint64_t w; memcpy(&w, sp, 8); memcpy(t, &w, 8); sp += 8; t += 8; } while (t < ob + o); }
+					if (__builtin_expect(dist >= 8, 1)) {                    /* eight bytes at once never read what they are about to write */
+						uint64_t w; memcpy(&w, sp, 8); memcpy(t, &w, 8);
+						if (__builtin_expect(len > 8, 0)) { memcpy(&w, sp + 8, 8); memcpy(t + 8, &w, 8); if (len > 16) { sp += 16; t += 16; do { memcpy(&w, sp, 8); memcpy(t, &w, 8); sp += 8; t += 8; } while (t < ob + o); } }
+					}
 					else if (dist == 1) { memset(t, sp[0], len); }
 					else { while (len--) *t++ = *sp++; }
 				}
