@@ -22,10 +22,13 @@
 
 struct fast_gz_t {
 	enum { PB_LIT = 11, PB_DIST = 8, WIN = 32768, SLACK = 512 };
-	/* table entry: bits 0-7 code bits to drop, 8-15 extra bits (length / distance) or sub-table bits (link), 16-29 value (literal, base,
-	 * or sub-table offset), 30-31 kind */
+	/* table entry: bits 0-7 bits to drop, 8-15 sub-table bits (link; lengths and distances: see mkbase), 16-29 value (literal, length
+	 * base, distance symbol, or sub-table offset), 30-31 kind */
 	enum { K_LIT = 0u, K_BASE = 1u, K_EOB = 2u, K_LINK = 3u };
 	static inline uint32_t mk(uint32_t kind, uint32_t val, uint32_t extra, uint32_t nbits) { return kind << 30 | val << 16 | extra << 8 | nbits; }
+	/* length / distance entries drop code and extra bits with ONE shift (the serial chain through the bit buffer is what bounds the
+	 * decoder): bits 0-7 code + extra bits, 8-11 code bits, 12-15 extra bits */
+	static inline uint32_t mkbase(uint32_t val, uint32_t extra, uint32_t nbits) { return K_BASE << 30 | val << 16 | extra << 12 | nbits << 8 | (nbits + extra); }
 	static const uint32_t BAD = 0xffffffffu;
 
 	int fd; bool eof_in;                                   /* input file, and whether read() has returned 0 */
@@ -105,7 +108,7 @@ struct fast_gz_t {
 		if (s < 256) return mk(K_LIT, (uint32_t)s, 0, nb);
 		if (s == 256) return mk(K_EOB, 0, 0, nb);
 		if (s > 285) return BAD;
-		return mk(K_BASE, base[s - 257], extra[s - 257], nb);
+		return mkbase(base[s - 257], extra[s - 257], nb);
 	}
 	static uint32_t ent_dist(int s, uint32_t nb)
 	{
@@ -114,7 +117,7 @@ struct fast_gz_t {
 		if (s > 29) return BAD;
 		/* the base does not fit the 14-bit value field: the symbol goes there, the base is looked up when the entry is used */
 		(void)base;
-		return mk(K_BASE, (uint32_t)s, extra[s], nb);
+		return mkbase((uint32_t)s, extra[s], nb);
 	}
 	static inline uint32_t dist_base(uint32_t s)
 	{
@@ -228,6 +231,7 @@ struct fast_gz_t {
 					FI_REFILL();
 					uint32_t e = L[bb & ((1u << PB_LIT) - 1)];
 					if ((e >> 30) == K_LINK) { if (e == BAD) { bad = "damaged literal / length code"; break; } bb >>= PB_LIT; bc -= PB_LIT; e = L[((e >> 16) & 0x3fff) + (bb & ((1u << ((e >> 8) & 0xff)) - 1))]; if (e == BAD) { bad = "damaged literal / length code"; break; } }
+					uint64_t sv = bb;
 					bb >>= (e & 0xff); bc -= (int)(e & 0xff);
 					uint32_t kind = e >> 30;
 					if (kind == K_LIT) {
@@ -245,16 +249,14 @@ struct fast_gz_t {
 						continue;
 					}
 					if (kind == K_EOB) { eob = true; break; }
-					/* length, then distance: at most 5 + 15 + 13 further bits; the refill above left at least 56 - 15 */
-					uint32_t len = ((e >> 16) & 0x3fff) + (uint32_t)(bb & ((1u << ((e >> 8) & 0xff)) - 1));
-					bb >>= ((e >> 8) & 0xff); bc -= (int)((e >> 8) & 0xff);
+					/* length (code + extra bits already dropped), then distance: at most 15 + 13 further bits; the refill above left at least 56 - 20 */
+					uint32_t len = ((e >> 16) & 0x3fff) + (uint32_t)((sv >> ((e >> 8) & 0xf)) & ((1u << ((e >> 12) & 0xf)) - 1));
 					uint32_t d = D[bb & ((1u << PB_DIST) - 1)];
 					if ((d >> 30) == K_LINK) { if (d == BAD) { bad = "damaged distance code"; break; } bb >>= PB_DIST; bc -= PB_DIST; d = D[((d >> 16) & 0x3fff) + (bb & ((1u << ((d >> 8) & 0xff)) - 1))]; }
 					if ((d >> 30) != K_BASE) { bad = "damaged distance code"; break; }
+					sv = bb;
 					bb >>= (d & 0xff); bc -= (int)(d & 0xff);
-					const uint32_t dx = (d >> 8) & 0xff;
-					const size_t dist = dist_base((d >> 16) & 0x3fff) + (size_t)(bb & (((uint64_t)1 << dx) - 1));
-					bb >>= dx; bc -= (int)dx;
+					const size_t dist = dist_base((d >> 16) & 0x3fff) + (size_t)((sv >> ((d >> 8) & 0xf)) & (((uint64_t)1 << ((d >> 12) & 0xf)) - 1));
 					if (dist > hist0 + (o - o0) || dist > WIN) { bad = "distance too far back"; break; }
 					const uint8_t *sp = ob + o - dist; uint8_t *t = ob + o;
 					o += len;
