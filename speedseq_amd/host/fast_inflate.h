@@ -32,7 +32,7 @@ struct fast_gz_t {
 	static const uint32_t BAD = 0xffffffffu;
 
 	int fd; bool eof_in;                                   /* input file, and whether read() has returned 0 */
-	std::vector<uint8_t> ibuf; size_t ip, iend, ireal;     /* ibuf[ip..iend) unread; iend may include zero padding after the file's end (ireal) */
+	std::vector<uint8_t> ibuf; const uint8_t *ib; size_t ip, iend, ireal;   /* ib[ip..iend) unread (ib = ibuf, or a caller's buffer: fast_inflate_mt.h); iend may include zero padding after the file's end (ireal) */
 	uint64_t bitbuf; int bitcnt;
 	std::vector<uint8_t> obuf; size_t op, obase;           /* obuf[obase..op) = decoded and not yet handed out; WIN bytes of history before obase */
 	enum { S_HEADER, S_BLOCK, S_STORED, S_HUFF, S_TRAILER, S_DONE, S_ERROR } st;
@@ -40,10 +40,11 @@ struct fast_gz_t {
 	std::vector<uint32_t> tl, td;                          /* litlen / dist tables (primary + sub-tables) */
 	uint32_t crc_expect, isize_expect; uint64_t member_out; bool member_done;   /* set when a member's trailer has been read */
 	const char *err;
+	bool strict; int last_left;                            /* strict: a dynamic block header must describe complete codes (the block-boundary search of fast_inflate_mt.h) */
 
-	explicit fast_gz_t(int fd_) : fd(fd_), eof_in(false), ip(0), iend(0), ireal(0), bitbuf(0), bitcnt(0), op(WIN), obase(WIN), st(S_HEADER), last_block(false),
-		stored_left(0), crc_expect(0), isize_expect(0), member_out(0), member_done(false), err(0)
-	{ ibuf.resize((size_t)4 << 20); tl.resize(((size_t)1 << PB_LIT) + 2048); td.resize(((size_t)1 << PB_DIST) + 2048); }
+	explicit fast_gz_t(int fd_) : fd(fd_), eof_in(false), ib(0), ip(0), iend(0), ireal(0), bitbuf(0), bitcnt(0), op(WIN), obase(WIN), st(S_HEADER), last_block(false),
+		stored_left(0), crc_expect(0), isize_expect(0), member_out(0), member_done(false), err(0), strict(false), last_left(0)
+	{ if (fd >= 0) ibuf.resize((size_t)4 << 20); ib = ibuf.data(); tl.resize(((size_t)1 << PB_LIT) + 2048); td.resize(((size_t)1 << PB_DIST) + 2048); }
 
 	/* ---- input ---- */
 	bool fill_input()
@@ -61,7 +62,7 @@ struct fast_gz_t {
 		if (eof_in && iend == ireal) { const size_t pad = std::min<size_t>(4096, ibuf.size() - iend); memset(ibuf.data() + iend, 0, pad); iend += pad; }
 		return true;
 	}
-	inline void refill() { uint64_t w; memcpy(&w, ibuf.data() + ip, 8); bitbuf |= w << bitcnt; ip += (size_t)((63 - bitcnt) >> 3); bitcnt |= 56; }
+	inline void refill() { uint64_t w; memcpy(&w, ib + ip, 8); bitbuf |= w << bitcnt; ip += (size_t)((63 - bitcnt) >> 3); bitcnt |= 56; }
 	inline uint32_t bits(int n) { const uint32_t v = (uint32_t)(bitbuf & (((uint64_t)1 << n) - 1)); bitbuf >>= n; bitcnt -= n; return v; }
 	size_t consumed() const { return ip - (size_t)(bitcnt >> 3); }      /* input offset of the first byte not (wholly) used */
 	void byte_align() { const int drop = bitcnt & 7; bitbuf >>= drop; bitcnt -= drop; ip -= (size_t)(bitcnt >> 3); bitbuf = 0; bitcnt = 0; }
@@ -75,6 +76,7 @@ struct fast_gz_t {
 		cnt[0] = 0;
 		int left = 1, maxl = 0;
 		for (int l = 1; l <= 15; ++l) { left = (left << 1) - cnt[l]; if (left < 0) return false; if (cnt[l]) maxl = l; }   /* over-subscribed */
+		last_left = left;                                                   /* 0: the code is complete */
 		if (maxl == 0) { for (size_t i = 0; i < ((size_t)1 << pb); ++i) t[i] = BAD; return true; }                       /* no codes: any use is an error */
 		uint32_t next[16]; { uint32_t c = 0; for (int l = 1; l <= 15; ++l) { c = (c + (uint32_t)cnt[l - 1]) << 1; next[l] = c; } }
 		for (size_t i = 0; i < ((size_t)1 << pb); ++i) t[i] = BAD;
@@ -156,11 +158,73 @@ struct fast_gz_t {
 			while (rep--) lens[i++] = v;
 		}
 		if (lens[256] == 0) return false;                                  /* no end-of-block code */
-		return build(lens, hlit, PB_LIT, tl, ent_lit) && build(lens + hlit, hdist, PB_DIST, td, ent_dist);
+		if (!build(lens, hlit, PB_LIT, tl, ent_lit) || (strict && last_left != 0)) return false;
+		if (!build(lens + hlit, hdist, PB_DIST, td, ent_dist)) return false;
+		if (strict && last_left != 0) { int used = 0; for (int k = 0; k < hdist; ++k) used += lens[hlit + k] != 0; if (used > 1) return false; }   /* one distance code (or none) may stand alone */
+		return true;
+	}
+
+	/* the symbols of a Huffman block into ob[o..): stops at `limit`, at the end of the buffered input (both 0), at the end of the block (1),
+	 * on damage (-1, err).  E = uint8_t, or uint16_t when the 32 KB before the start are not known yet and stand in the buffer as markers
+	 * (fast_inflate_mt.h); `avail` = elements before o that a distance may reach.  Works on local copies of the bit buffer: the stores to
+	 * the output may alias anything the compiler cannot see through. */
+	template <class E> int huff_run(E *const ob, size_t &o_io, const size_t limit, const uint64_t avail)
+	{
+		const uint32_t *const L = tl.data(), *const D = td.data(); const uint8_t *const ibl = ib;
+		size_t o = o_io, ipl = ip; const size_t o0 = o_io;
+		uint64_t bb = bitbuf; int bc = bitcnt;
+		const size_t in_stop = iend >= 16 ? iend - 16 : 0;              /* 8-byte loads stay inside the (padded) buffer */
+		const size_t EW = 8 / sizeof(E);                                /* elements per 8-byte word */
+		int ret = 0; const char *bad = 0;
+#define FI_REFILL() do { uint64_t w_; memcpy(&w_, ibl + ipl, 8); bb |= w_ << bc; ipl += (size_t)((63 - bc) >> 3); bc |= 56; } while (0)
+		while (o < limit && ipl < in_stop) {
+			FI_REFILL();
+			uint32_t e = L[bb & ((1u << PB_LIT) - 1)];
+			if ((e >> 30) == K_LINK) { if (e == BAD) { bad = "damaged literal / length code"; break; } bb >>= PB_LIT; bc -= PB_LIT; e = L[((e >> 16) & 0x3fff) + (bb & ((1u << ((e >> 8) & 0xff)) - 1))]; if (e == BAD) { bad = "damaged literal / length code"; break; } }
+			uint64_t sv = bb;
+			bb >>= (e & 0xff); bc -= (int)(e & 0xff);
+			const uint32_t kind = e >> 30;
+			if (kind == K_LIT) {
+				ob[o++] = (E)(uint8_t)(e >> 16);
+				/* up to three more literals from the same top-up (each <= 11 bits, the first symbol took <= 15) */
+				e = L[bb & ((1u << PB_LIT) - 1)];
+				if ((e >> 30) != K_LIT) continue;
+				bb >>= (e & 0xff); bc -= (int)(e & 0xff); ob[o++] = (E)(uint8_t)(e >> 16);
+				e = L[bb & ((1u << PB_LIT) - 1)];
+				if ((e >> 30) != K_LIT) continue;
+				bb >>= (e & 0xff); bc -= (int)(e & 0xff); ob[o++] = (E)(uint8_t)(e >> 16);
+				e = L[bb & ((1u << PB_LIT) - 1)];
+				if ((e >> 30) != K_LIT) continue;
+				bb >>= (e & 0xff); bc -= (int)(e & 0xff); ob[o++] = (E)(uint8_t)(e >> 16);
+				continue;
+			}
+			if (kind == K_EOB) { ret = 1; break; }
+			/* length (code + extra bits already dropped), then distance: at most 15 + 13 further bits; the top-up left at least 56 - 20 */
+			uint32_t len = ((e >> 16) & 0x3fff) + (uint32_t)((sv >> ((e >> 8) & 0xf)) & ((1u << ((e >> 12) & 0xf)) - 1));
+			uint32_t d = D[bb & ((1u << PB_DIST) - 1)];
+			if ((d >> 30) == K_LINK) { if (d == BAD) { bad = "damaged distance code"; break; } bb >>= PB_DIST; bc -= PB_DIST; d = D[((d >> 16) & 0x3fff) + (bb & ((1u << ((d >> 8) & 0xff)) - 1))]; }
+			if ((d >> 30) != K_BASE) { bad = "damaged distance code"; break; }
+			sv = bb;
+			bb >>= (d & 0xff); bc -= (int)(d & 0xff);
+			const size_t dist = dist_base((d >> 16) & 0x3fff) + (size_t)((sv >> ((d >> 8) & 0xf)) & (((uint64_t)1 << ((d >> 12) & 0xf)) - 1));
+			if (dist > avail + (o - o0) || dist > WIN) { bad = "distance too far back"; break; }
+			const E *sp = ob + o - dist; E *t = ob + o;
+			o += len;
+			if (__builtin_expect(dist >= EW, 1)) {                      /* a word at once never reads what it is about to write */
+				uint64_t w; memcpy(&w, sp, 8); memcpy(t, &w, 8);
+				if (__builtin_expect(len > EW, 0)) { sp += EW; t += EW; do { memcpy(&w, sp, 8); memcpy(t, &w, 8); sp += EW; t += EW; } while (t < ob + o); }
+			}
+			else if (dist == 1) { const E v = sp[0]; while (len--) *t++ = v; }
+			else { while (len--) *t++ = *sp++; }
+		}
+#undef FI_REFILL
+		bitbuf = bb; bitcnt = bc; ip = ipl; o_io = o;
+		if (bad) { err = bad; return -1; }
+		return ret;
 	}
 
 	/* ---- gzip member header / trailer (byte-aligned, through the same buffer) ---- */
-	int byte() { if (ip >= ireal) return -1; return ibuf[ip++]; }
+	int byte() { if (ip >= ireal) return -1; return ib[ip++]; }
 	bool header()
 	{
 		if (!fill_input()) return false;
@@ -175,7 +239,7 @@ struct fast_gz_t {
 		for (int i = 0; i < 6; ++i) if (byte() < 0) { err = "truncated gzip header"; return false; }
 		if (flg & 4) { const int lo = byte(), hi = byte(); if (hi < 0) { err = "truncated gzip header"; return false; } size_t n = (size_t)lo | (size_t)hi << 8;
 			while (n) { if (!fill_input()) return false; if (ip >= ireal) { err = "truncated gzip header"; return false; } const size_t k = std::min(n, ireal - ip); ip += k; n -= k; } }
-		for (int f = 8; f <= 16; f <<= 1) if (flg & f) for (;;) { if (ip >= ireal) { if (!fill_input()) return false; if (ip >= ireal) { err = "truncated gzip header"; return false; } } if (ibuf[ip++] == 0) break; }
+		for (int f = 8; f <= 16; f <<= 1) if (flg & f) for (;;) { if (ip >= ireal) { if (!fill_input()) return false; if (ip >= ireal) { err = "truncated gzip header"; return false; } } if (ib[ip++] == 0) break; }
 		if (flg & 2) { if (byte() < 0 || byte() < 0) { err = "truncated gzip header"; return false; } }
 		bitbuf = 0; bitcnt = 0; member_out = 0; member_done = false;
 		st = S_BLOCK;
@@ -204,7 +268,7 @@ struct fast_gz_t {
 				if (type == 0) {
 					byte_align();
 					if (ireal - ip < 4) { err = "truncated stored block"; st = S_ERROR; return -1; }
-					const uint32_t len = ibuf[ip] | (uint32_t)ibuf[ip + 1] << 8, nlen = ibuf[ip + 2] | (uint32_t)ibuf[ip + 3] << 8;
+					const uint32_t len = ib[ip] | (uint32_t)ib[ip + 1] << 8, nlen = ib[ip + 2] | (uint32_t)ib[ip + 3] << 8;
 					if ((len ^ 0xffffu) != nlen) { err = "damaged stored block"; st = S_ERROR; return -1; }
 					ip += 4; stored_left = len; st = S_STORED;
 				} else if (type == 1) { if (!fixed_tables()) { err = "internal: fixed tables"; st = S_ERROR; return -1; } st = S_HUFF; }
@@ -215,70 +279,22 @@ struct fast_gz_t {
 				size_t k = std::min<size_t>(stored_left, ireal > ip ? ireal - ip : 0);
 				k = std::min(k, obuf.size() - SLACK - op);
 				if (!k && stored_left) { if (ip >= ireal && eof_in) { err = "truncated stored block"; st = S_ERROR; return -1; } if (op >= limit) break; }
-				memcpy(obuf.data() + op, ibuf.data() + ip, k); op += k; ip += k; stored_left -= (uint32_t)k; member_out += k;
+				memcpy(obuf.data() + op, ib + ip, k); op += k; ip += k; stored_left -= (uint32_t)k; member_out += k;
 				if (!stored_left) st = last_block ? S_TRAILER : S_BLOCK;
 			} break;
 			case S_HUFF: {
-				/* the hot loop works on local copies: the byte stores to the output may alias anything the compiler cannot see through */
-				uint8_t *const ob = obuf.data(); const uint32_t *const L = tl.data(), *const D = td.data(); const uint8_t *const ib = ibuf.data();
-				size_t o = op, ipl = ip; const size_t o0 = op;
-				uint64_t bb = bitbuf; int bc = bitcnt;
-				const size_t in_stop = iend - 16;                           /* 8-byte loads stay inside the (padded) buffer */
-				const uint64_t hist0 = member_out;                          /* bytes of this member before o0 */
-				bool eob = false; const char *bad = 0;
-#define FI_REFILL() do { uint64_t w_; memcpy(&w_, ib + ipl, 8); bb |= w_ << bc; ipl += (size_t)((63 - bc) >> 3); bc |= 56; } while (0)
-				while (o < limit && ipl < in_stop) {
-					FI_REFILL();
-					uint32_t e = L[bb & ((1u << PB_LIT) - 1)];
-					if ((e >> 30) == K_LINK) { if (e == BAD) { bad = "damaged literal / length code"; break; } bb >>= PB_LIT; bc -= PB_LIT; e = L[((e >> 16) & 0x3fff) + (bb & ((1u << ((e >> 8) & 0xff)) - 1))]; if (e == BAD) { bad = "damaged literal / length code"; break; } }
-					uint64_t sv = bb;
-					bb >>= (e & 0xff); bc -= (int)(e & 0xff);
-					uint32_t kind = e >> 30;
-					if (kind == K_LIT) {
-						ob[o++] = (uint8_t)(e >> 16);
-						/* up to three more literals from the same refill (each <= 11 bits, the first symbol took <= 15): FASTQ text is mostly literals */
-						e = L[bb & ((1u << PB_LIT) - 1)];
-						if ((e >> 30) != K_LIT) continue;
-						bb >>= (e & 0xff); bc -= (int)(e & 0xff); ob[o++] = (uint8_t)(e >> 16);
-						e = L[bb & ((1u << PB_LIT) - 1)];
-						if ((e >> 30) != K_LIT) continue;
-						bb >>= (e & 0xff); bc -= (int)(e & 0xff); ob[o++] = (uint8_t)(e >> 16);
-						e = L[bb & ((1u << PB_LIT) - 1)];
-						if ((e >> 30) != K_LIT) continue;
-						bb >>= (e & 0xff); bc -= (int)(e & 0xff); ob[o++] = (uint8_t)(e >> 16);
-						continue;
-					}
-					if (kind == K_EOB) { eob = true; break; }
-					/* length (code + extra bits already dropped), then distance: at most 15 + 13 further bits; the refill above left at least 56 - 20 */
-					uint32_t len = ((e >> 16) & 0x3fff) + (uint32_t)((sv >> ((e >> 8) & 0xf)) & ((1u << ((e >> 12) & 0xf)) - 1));
-					uint32_t d = D[bb & ((1u << PB_DIST) - 1)];
-					if ((d >> 30) == K_LINK) { if (d == BAD) { bad = "damaged distance code"; break; } bb >>= PB_DIST; bc -= PB_DIST; d = D[((d >> 16) & 0x3fff) + (bb & ((1u << ((d >> 8) & 0xff)) - 1))]; }
-					if ((d >> 30) != K_BASE) { bad = "damaged distance code"; break; }
-					sv = bb;
-					bb >>= (d & 0xff); bc -= (int)(d & 0xff);
-					const size_t dist = dist_base((d >> 16) & 0x3fff) + (size_t)((sv >> ((d >> 8) & 0xf)) & (((uint64_t)1 << ((d >> 12) & 0xf)) - 1));
-					if (dist > hist0 + (o - o0) || dist > WIN) { bad = "distance too far back"; break; }
-					const uint8_t *sp = ob + o - dist; uint8_t *t = ob + o;
-					o += len;
-					if (__builtin_expect(dist >= 8, 1)) {                    /* eight bytes at once never read what they are about to write */
-						uint64_t w; memcpy(&w, sp, 8); memcpy(t, &w, 8);
-						if (__builtin_expect(len > 8, 0)) { memcpy(&w, sp + 8, 8); memcpy(t + 8, &w, 8); if (len > 16) { sp += 16; t += 16; do { memcpy(&w, sp, 8); memcpy(t, &w, 8); sp += 8; t += 8; } while (t < ob + o); } }
-					}
-					else if (dist == 1) { memset(t, sp[0], len); }
-					else { while (len--) *t++ = *sp++; }
-				}
-#undef FI_REFILL
-				bitbuf = bb; bitcnt = bc; ip = ipl;
+				size_t o = op; const size_t o0 = op;
+				const int r = huff_run<uint8_t>(obuf.data(), o, limit, member_out);
 				member_out += o - o0; op = o;
-				if (bad) { err = bad; st = S_ERROR; return -1; }
-				if (eob) st = last_block ? S_TRAILER : S_BLOCK;
+				if (r < 0) { st = S_ERROR; return -1; }
+				if (r == 1) st = last_block ? S_TRAILER : S_BLOCK;
 				else if (consumed() > ireal) { err = "truncated deflate stream"; st = S_ERROR; return -1; }
 			} break;
 			case S_TRAILER: {
 				byte_align();
 				if (ip > ireal) { err = "truncated deflate stream"; st = S_ERROR; return -1; }
 				if (ireal - ip < 8) { err = "truncated gzip trailer"; st = S_ERROR; return -1; }
-				memcpy(&crc_expect, ibuf.data() + ip, 4); memcpy(&isize_expect, ibuf.data() + ip + 4, 4); ip += 8;
+				memcpy(&crc_expect, ib + ip, 4); memcpy(&isize_expect, ib + ip + 4, 4); ip += 8;
 				if ((uint32_t)member_out != isize_expect) { err = "length in the gzip trailer does not match"; st = S_ERROR; return -1; }
 				member_done = true; st = S_HEADER;
 				/* the caller checks crc_expect against the CRC-32 of the bytes of this member: a chunk never spans two members */

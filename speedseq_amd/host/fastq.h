@@ -27,6 +27,7 @@
 #include <errno.h>
 #include <sys/stat.h>
 #include "fast_inflate.h"
+#include "fast_inflate_mt.h"
 
 template <class T> struct chan_t {      /* bounded single-producer / single-consumer channel */
 	std::mutex mu; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed, dead;
@@ -69,29 +70,44 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	}
 	void fast_gz_loop(int fd)
 	{	/* inflate (fast_inflate.h) -> CRC-32 of every member against its trailer -> the parser: three threads in a row, 4 MB chunks */
-		struct piece_t { std::unique_ptr<chunk_t> c; bool member_end; uint32_t crc; };
+		struct piece_t { std::unique_ptr<chunk_t> c; bool member_end; uint32_t crc; bool check; };   /* check: the CRC is this pipeline's to verify (one decoding thread); several threads verify it themselves */
 		chan_t<piece_t> mid(4);
 		std::thread t_crc([this, &mid]() {
 			uLong crc = crc32(0L, Z_NULL, 0); piece_t p;
 			while (mid.pop(p)) {
 				if (io_err.load()) continue;
-				if (p.c && !p.c->empty()) crc = crc32(crc, p.c->data(), (uInt)p.c->size());
-				if (p.member_end) { if ((uint32_t)crc != p.crc) { io_err = 1; continue; } crc = crc32(0L, Z_NULL, 0); }
+				if (p.check && p.c && !p.c->empty()) crc = crc32(crc, p.c->data(), (uInt)p.c->size());
+				if (p.check && p.member_end) { if ((uint32_t)crc != p.crc) { io_err = 1; continue; } crc = crc32(0L, Z_NULL, 0); }
 				if (p.c && !p.c->empty()) full.push(std::move(p.c));
 			}
 			full.close();
 		});
-		fast_gz_t g(fd);
-		while (!stop.load() && !io_err.load()) {
-			const uint8_t *d; bool mend = false;
-			const long n = g.read_chunk(&d, (size_t)4 << 20, &mend);
-			if (n < 0) { io_err = 1; break; }
-			if (!n && !mend) break;
-			piece_t p; p.member_end = mend; p.crc = g.crc_expect;
+		bool check_crc = true;
+		auto hand_on = [&](const uint8_t *d, size_t n, bool mend, uint32_t crc_expect) -> bool {
+			piece_t p; p.member_end = mend; p.crc = crc_expect; p.check = check_crc;
 			{ std::unique_lock<std::mutex> l(empty.mu); if (!empty.q.empty()) { p.c = std::move(empty.q.front()); empty.q.pop_front(); } }
 			if (!p.c) p.c.reset(new chunk_t());
 			p.c->assign(d, d + n);
 			mid.push(std::move(p));
+			return !stop.load() && !io_err.load();
+		};
+		/* several decoding threads for the one stream (fast_inflate_mt.h) where the host has cores to spare: SSG_GZ_THREADS, default 8 on
+		 * hosts with 32 hardware threads or more, otherwise one */
+		int gt = std::thread::hardware_concurrency() >= 32 ? 8 : 1; { const char *e = getenv("SSG_GZ_THREADS"); if (e && atoi(e) > 0) gt = atoi(e); }
+		if (gt > 1) {
+			check_crc = false;
+			size_t gc = (size_t)2 << 20; { const char *e = getenv("SSG_GZ_CHUNK"); if (e && atol(e) > 0) gc = (size_t)atol(e); }   /* compressed bytes per thread and wave (tests make it small) */
+			fast_gz_mt_t g(fd, gt, gc);
+			if (!g.run(hand_on) && !stop.load()) io_err = 1;
+		} else {
+			fast_gz_t g(fd);
+			while (!stop.load() && !io_err.load()) {
+				const uint8_t *d; bool mend = false;
+				const long n = g.read_chunk(&d, (size_t)4 << 20, &mend);
+				if (n < 0) { io_err = 1; break; }
+				if (!n && !mend) break;
+				if (!hand_on(d, (size_t)n, mend, g.crc_expect)) break;
+			}
 		}
 		mid.close();
 		t_crc.join();

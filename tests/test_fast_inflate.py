@@ -12,6 +12,10 @@ import pytest
 from common import ROOT
 
 FI = os.path.join(ROOT, "tests", "emu", "fi_test")
+FI_MT = os.path.join(ROOT, "tests", "emu", "fi_mt_test")
+# every check runs through the one-thread decoder and through the several-thread one (fast_inflate_mt.h) with chunks small enough that
+# the test streams span many of them: block-boundary search, markers for the unknown window, stitching, the one-thread fall-back
+MODES = [[FI], [FI_MT, "3", "70000"], [FI_MT, "5", "300000"]]
 
 
 def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
@@ -19,21 +23,23 @@ def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
     return c.compress(data) + c.flush()
 
 
-def run(path):
-    r = subprocess.run([FI, path, "crc"], capture_output=True, text=True, timeout=300)
+def run(path, mode=None):
+    cmd = [FI, path, "crc"] if not mode or mode[0] == FI else [mode[0], path] + mode[1:]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     return r.returncode, r.stdout, r.stderr
 
 
 def check(tmp_path, blob, expect, members=None, name="x.gz"):
+    import re
     p = tmp_path / name
     p.write_bytes(blob)
-    rc, out, err = run(str(p))
-    assert rc == 0, err
-    import re
-    m = re.match(r"(\d+) bytes, (\d+) members, crc ([0-9a-f]{8}),", out)
-    assert m and int(m.group(1)) == len(expect) and m.group(3) == "%08x" % zlib.crc32(expect), out
-    if members is not None:
-        assert int(m.group(2)) == members
+    for mode in MODES:
+        rc, out, err = run(str(p), mode)
+        assert rc == 0, (mode, err)
+        m = re.match(r"(\d+) bytes, (\d+) members, crc ([0-9a-f]{8}),", out)
+        assert m and int(m.group(1)) == len(expect) and m.group(3) == "%08x" % zlib.crc32(expect), (mode, out)
+        if members is not None:
+            assert int(m.group(2)) == members, (mode, out)
 
 
 def fastq(rng, n):
@@ -101,21 +107,23 @@ def test_truncated_and_damaged_streams_are_errors(tmp_path):
     p = tmp_path / "t.gz"
     for cut in [1, 5, 10, 11, 50, len(blob) // 3, len(blob) // 2, len(blob) - 9, len(blob) - 8, len(blob) - 1]:
         p.write_bytes(blob[:cut])
-        rc, out, err = run(str(p))
-        assert rc == 1 and "error" in err, (cut, out, err)
+        for mode in MODES:
+            rc, out, err = run(str(p), mode)
+            assert rc == 1 and "error" in err, (mode, cut, out, err)
     stored = gz(data, 0)
     for cut in [12, 14, 40000, len(stored) - 3]:
         p.write_bytes(stored[:cut])
-        rc, out, err = run(str(p))
-        assert rc == 1, cut
+        for mode in MODES:
+            assert run(str(p), mode)[0] == 1, (mode, cut)
     bad = 0
     for k in range(40):                               # a flipped byte is a structural error or a CRC / length mismatch -- never silence
         pos = rng.randrange(12, len(blob) - 8)
         dam = bytearray(blob)
         dam[pos] ^= 1 << rng.randrange(8)
         p.write_bytes(bytes(dam))
-        rc, out, err = run(str(p))
-        assert rc == 1, (pos, out)
+        for mode in MODES:
+            rc, out, err = run(str(p), mode)
+            assert rc == 1, (mode, pos, out)
         bad += 1
     assert bad == 40
     p.write_bytes(b"not gzip at all")

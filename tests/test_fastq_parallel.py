@@ -135,16 +135,36 @@ def test_gzip_input_through_the_fast_decoder(tmp_path, case):
     g.write_bytes(gzip.compress(txt[:len(txt) // 2], 6) + gzip.compress(txt[len(txt) // 2:], 1))
     ref, _ = dump(str(p), 1)
 
-    def dump_gz(path, fast):
-        env = dict(os.environ, SSG_GZ_FAST="1" if fast else "0")
+    def dump_gz(path, fast, threads=1):
+        env = dict(os.environ, SSG_GZ_FAST="1" if fast else "0", SSG_GZ_THREADS=str(threads), SSG_GZ_CHUNK="20000")
         return subprocess.run([FQ_DUMP, path], env=env, capture_output=True, check=True).stdout
     assert dump_gz(str(g), True) == ref and dump_gz(str(g), False) == ref
+    assert dump_gz(str(g), True, threads=3) == ref                 # several decoding threads for the one stream (fast_inflate_mt.h)
     blob = g.read_bytes()
     cut = tmp_path / "cut.fq.gz"
-    cut.write_bytes(blob[:len(blob) * 2 // 3])
-    out = dump_gz(str(cut), True)
-    assert out.splitlines()[-1].split(b"\t")[1] == b"-2"          # reported as malformed
     dam = bytearray(blob)
     dam[len(dam) // 3] ^= 0x10
-    cut.write_bytes(bytes(dam))
-    assert dump_gz(str(cut), True).splitlines()[-1].split(b"\t")[1] == b"-2"
+    for threads in (1, 3):
+        cut.write_bytes(blob[:len(blob) * 2 // 3])
+        out = dump_gz(str(cut), True, threads)
+        assert out.splitlines()[-1].split(b"\t")[1] == b"-2"      # reported as malformed
+        cut.write_bytes(bytes(dam))
+        assert dump_gz(str(cut), True, threads).splitlines()[-1].split(b"\t")[1] == b"-2"
+
+
+def test_bwa_emu_gz_input_several_decoding_threads(tmp_path, emu_lib):
+    """bin/bwa on a gz file that spans many chunks of the several-thread decoder: same SAM as with zlib"""
+    import gzip
+    import simreads
+    from common import EXAMPLE_FA
+    bwa = os.path.join(ROOT, "tests", "emu", "bwa_emu")
+    fq = str(tmp_path / "r.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 1500, seed=79))
+    gzp = fq + ".gz"
+    with open(fq, "rb") as f, gzip.open(gzp, "wb", 6) as g:
+        g.write(f.read())
+    outs = []
+    for env in ({"SSG_GZ_FAST": "0"}, {"SSG_GZ_THREADS": "1"}, {"SSG_GZ_THREADS": "4", "SSG_GZ_CHUNK": "30000"}):
+        r = subprocess.run([bwa, "mem", "-t", "4", "-p", EXAMPLE_FA, gzp], env=dict(os.environ, **env), capture_output=True, check=True, timeout=900)
+        outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
+    assert outs[0].count(b"\n") > 3000 and outs[1] == outs[0] and outs[2] == outs[0]
