@@ -59,6 +59,7 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	bool threaded;                      /* compressed input only: for a plain file the hand-over costs more than the read */
 	bool bgzf;                          /* blocked gzip (bgzip, htslib bgzf.c:298-342): independent <= 64 KB members with their size in the header, inflated by several threads */
 	int rfd; size_t roff, rend;         /* ranged mode (fq_feed_t's parallel parse of a plain file): bytes [roff, rend) of rfd through pread */
+	const unsigned char *mp; size_t mn, mo; fq_stream_t *chain;   /* memory mode (rfd = -2): bytes mp[0..mn), then -- if chain -- the decoded chunks of another stream (fq_feed_t::parse_stream) */
 	/* BGZF member at p (n bytes available): its total size, or 0 when p does not start one */
 	static size_t bgzf_member(const unsigned char *p, size_t n)
 	{
@@ -157,8 +158,10 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 		}
 		full.close();
 	}
-	fq_stream_t(int fd, size_t off, size_t lim) : fp(0), begin(0), end(0), is_eof(false), full(1), empty(1), threaded(false), bgzf(false), rfd(fd), roff(off), rend(lim) { buf.resize((size_t)1 << 20); }
-	explicit fq_stream_t(gzFile f, const char *path = 0) : fp(f), begin(0), end(0), is_eof(false), full(4), empty(8), bgzf(false), rfd(-1), roff(0), rend(0)
+	fq_stream_t(int fd, size_t off, size_t lim) : fp(0), begin(0), end(0), is_eof(false), full(1), empty(1), threaded(false), bgzf(false), rfd(fd), roff(off), rend(lim), mp(0), mn(0), mo(0), chain(0) { buf.resize((size_t)1 << 20); }
+	fq_stream_t(const unsigned char *p, size_t n, fq_stream_t *then) : fp(0), begin(0), end(0), is_eof(false), full(1), empty(1), threaded(false), bgzf(false), rfd(-2), roff(0), rend(0), mp(p), mn(n), mo(0), chain(then) { buf.resize((size_t)1 << 20); }
+	bool had_io_err() const { return io_err.load() != 0 || (chain && chain->io_err.load() != 0); }
+	explicit fq_stream_t(gzFile f, const char *path = 0) : fp(f), begin(0), end(0), is_eof(false), full(4), empty(8), bgzf(false), rfd(-1), roff(0), rend(0), mp(0), mn(0), mo(0), chain(0)
 	{
 		gzbuffer(fp, 1 << 20);
 		threaded = !gzdirect(fp);
@@ -200,6 +203,21 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 	inline bool fill()
 	{
 		if (is_eof) return false;
+		if (rfd == -2) {
+			if (mo < mn) { const size_t k = std::min(buf.size(), mn - mo); memcpy(buf.data(), mp + mo, k); mo += k; begin = 0; end = (int)k; return true; }
+			if (chain && !chain->threaded) {                        /* an uncompressed stream: its own read, its buffer taken over */
+				if (!chain->fill()) { begin = end = 0; is_eof = true; return false; }
+				buf.swap(chain->buf); begin = chain->begin; end = chain->end; chain->begin = chain->end = 0;
+				if (chain->buf.size() < ((size_t)1 << 20)) chain->buf.resize((size_t)1 << 20);
+				return true;
+			}
+			std::unique_ptr<chunk_t> c;
+			if (!chain || !chain->full.pop(c)) { begin = end = 0; is_eof = true; return false; }
+			buf.swap(*c);
+			{ std::lock_guard<std::mutex> l(chain->empty.mu); if (chain->empty.q.size() < 8) chain->empty.q.push_back(std::move(c)); }
+			begin = 0; end = (int)buf.size();
+			return true;
+		}
 		if (rfd >= 0) {
 			begin = end = 0;
 			while (roff < rend) {
@@ -253,13 +271,14 @@ struct fq_reader_t {
 	bool qual_eof;                      /* the quality loop ran into the end of the stream: only the end of the FILE may do that */
 	fq_reader_t(gzFile f, bool kc, const char *path = 0) : ks(f, path), last_char(0), keep_comment(kc), qual_eof(false) {}
 	fq_reader_t(int fd, size_t off, size_t lim, bool kc) : ks(fd, off, lim), last_char(0), keep_comment(kc), qual_eof(false) {}
+	fq_reader_t(const unsigned char *p, size_t n, fq_stream_t *then, bool kc) : ks(p, n, then), last_char(0), keep_comment(kc), qual_eof(false) {}
 	/* kseq_read + kseq2bseq1 + trim_readno into block b; >= 0 length, -1 EOF, -2 truncated quality */
 	int next(fq_block_t &b)
 	{
 		int c;
-		if (last_char == 0) { while ((c = ks.getc()) != -1 && c != '>' && c != '@') {} if (c == -1) return ks.io_err.load() ? -2 : -1; last_char = c; }   /* a damaged compressed stream ends early: that is an error, not the end of the reads */
+		if (last_char == 0) { while ((c = ks.getc()) != -1 && c != '>' && c != '@') {} if (c == -1) return ks.had_io_err() ? -2 : -1; last_char = c; }   /* a damaged compressed stream ends early: that is an error, not the end of the reads */
 		const size_t name0 = b.txt.size();
-		if (ks.getuntil(0, b.txt, &c) < 0) return ks.io_err.load() ? -2 : -1;
+		if (ks.getuntil(0, b.txt, &c) < 0) return ks.had_io_err() ? -2 : -1;
 		size_t name_end = b.txt.size();
 		if (name_end - name0 > 2 && b.txt[name_end - 2] == '/' && isdigit((unsigned char)b.txt[name_end - 1])) { b.txt.resize(name_end - 2); name_end -= 2; }   /* trim_readno */
 		b.txt.push_back(0);
@@ -413,14 +432,107 @@ struct fq_feed_t {
 		close(fd);
 		return true;
 	}
-	/* threads_hint: parse threads for a plain file when the caller knows better than the default (several GPUs to feed); SSG_FASTQ_THREADS wins */
+	/* A compressed file whose decoder outruns one parsing thread (fast_inflate_mt.h): the decoded chunks are gathered into slabs, a slab
+	 * is cut at lines that look like record starts and its pieces go through the kseq grammar on several threads, delivered in order.
+	 * Same induction as parse_plain(): the first piece starts at a record start (the stream's first byte, or the cut the previous slab
+	 * ended on: the bytes after a slab's last cut are not parsed with it but carried into the next, so every parsed piece is closed by a
+	 * cut); a piece that runs out of bytes inside a quality string shows that its closing cut was no record start -- everything
+	 * from that piece's first byte on, the rest of the stream included, then goes through one thread. */
+	void parse_stream(fq_stream_t &src, bool keep_comment, int per_block, int T)
+	{
+		typedef fq_stream_t::chunk_t chunk_t;
+		size_t SLAB = (size_t)64 << 20, PIECE = (size_t)4 << 20;
+		{ const char *e = getenv("SSG_FASTQ_SLAB"); if (e && atol(e) > 0) SLAB = (size_t)atol(e); }
+		{ const char *e = getenv("SSG_FASTQ_PIECE"); if (e && atol(e) > 0) PIECE = (size_t)atol(e); }
+		std::vector<unsigned char> slab[2], carry; int cur = 0;
+		std::vector<size_t> cut[2];
+		std::vector<std::thread> workers;
+		std::mutex mu; std::condition_variable cv; int next = 0, delivered = 0, np_now = 0; bool abort = false; long fb_piece = -1;
+		bool eof = false;
+		auto serial_from = [&](std::vector<unsigned char> &P) {   /* P, then whatever the decoder still delivers, by one thread */
+			fq_reader_t rest(P.data(), P.size(), &src, keep_comment);
+			(void)drain(rest, per_block, [this](blk_t b) { ch.push(std::move(b)); });
+		};
+		auto join_prev = [&]() { for (std::thread &x : workers) x.join(); workers.clear(); };
+		while (!eof) {
+			std::vector<unsigned char> &S = slab[cur]; std::vector<size_t> &C = cut[cur];
+			S.clear(); S.insert(S.end(), carry.begin(), carry.end()); carry.clear();
+			const size_t target = std::max(SLAB, S.size() + 1);             /* a slab that ended without a cut comes back as carry: it must grow */
+			while (S.size() < target) {
+				std::unique_ptr<chunk_t> c;
+				if (!src.full.pop(c)) { eof = true; break; }
+				S.insert(S.end(), c->begin(), c->end());
+				{ std::lock_guard<std::mutex> l(src.empty.mu); if (src.empty.q.size() < 8) src.empty.q.push_back(std::move(c)); }
+			}
+			join_prev();                                                   /* the other slab's pieces are all delivered (or given up) now */
+			if (fb_piece >= 0 || ch.is_dead()) {
+				if (fb_piece >= 0 && !ch.is_dead()) {
+					const std::vector<unsigned char> &Sp = slab[cur ^ 1]; const std::vector<size_t> &Cp = cut[cur ^ 1];
+					if (getenv("SSG_DEBUG")) fprintf(stderr, "[fastq] not one record per four lines in the decoded stream; one thread from there\n");
+					std::vector<unsigned char> P(Sp.begin() + (long)Cp[(size_t)fb_piece], Sp.begin() + (long)Cp.back());   /* what the other slab had not delivered; its tail already heads S */
+					P.insert(P.end(), S.begin(), S.end());
+					serial_from(P);
+				}
+				return;
+			}
+			/* cuts: 0, then the first line that looks like a record start at or after every PIECE bytes */
+			const unsigned char *p = S.data(); const size_t n = S.size();
+			C.assign(1, 0);
+			for (size_t pos = PIECE; pos < n; pos += PIECE) {
+				const unsigned char *e = (const unsigned char*)memchr(p + pos, '\n', std::min(n - pos, (size_t)1 << 18));
+				while (e) {
+					const size_t q = (size_t)(e - p) + 1;
+					if (q >= n) break;
+					if (looks_like_record(p, n, q)) { if (q > C.back()) C.push_back(q); break; }
+					e = q - pos < ((size_t)1 << 18) ? (const unsigned char*)memchr(p + q, '\n', std::min(n - q, ((size_t)1 << 18) - (q - pos))) : 0;
+				}
+			}
+			if (eof) C.push_back(n);
+			else {
+				if (C.size() < 2) {                                         /* nothing that looks like a record start: not a four-line file; one thread from here */
+					if (S.size() < 4 * SLAB) { carry.swap(S); continue; }
+					serial_from(S); return;
+				}
+				carry.assign(S.begin() + (long)C.back(), S.end());          /* parsed with the next slab */
+			}
+			np_now = (int)C.size() - 1; next = 0; delivered = 0; abort = false;
+			const bool last_slab = eof;
+			const unsigned char *base = S.data(); const std::vector<size_t> *Cc = &C;
+			auto work = [&, base, Cc, last_slab]() {
+				for (;;) {
+					int i;
+					{ std::lock_guard<std::mutex> l(mu); i = next++; if (i >= np_now || abort) return; }
+					std::vector<blk_t> out;
+					fq_reader_t rd(base + (*Cc)[(size_t)i], (*Cc)[(size_t)i + 1] - (*Cc)[(size_t)i], 0, keep_comment);
+					const bool cut_short = drain(rd, per_block, [&](blk_t b) { out.push_back(std::move(b)); });
+					{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return abort || delivered == i; }); if (abort) return; }
+					if (cut_short && !(last_slab && i + 1 == np_now)) { std::lock_guard<std::mutex> l(mu); abort = true; fb_piece = i; cv.notify_all(); return; }
+					for (blk_t &b : out) ch.push(std::move(b));
+					{ std::lock_guard<std::mutex> l(mu); delivered = i + 1; if (ch.is_dead()) abort = true; cv.notify_all(); }
+				}
+			};
+			for (int t = 0; t < std::min(T, np_now); ++t) workers.emplace_back(work);
+			cur ^= 1;
+		}
+		join_prev();
+		if (fb_piece >= 0 && !ch.is_dead()) {                              /* in the last slab: the rest of it by one thread */
+			const std::vector<unsigned char> &Sp = slab[cur ^ 1]; const std::vector<size_t> &Cp = cut[cur ^ 1];
+			std::vector<unsigned char> P(Sp.begin() + (long)Cp[(size_t)fb_piece], Sp.end());
+			serial_from(P);
+		}
+		if (src.had_io_err() && !ch.is_dead()) { blk_t b = fresh(1); b->err = -2; ch.push(std::move(b)); }   /* the decoder gave up: the file is malformed, not merely at its end */
+	}
+	/* threads_hint: parse threads when the caller knows better than the default (several GPUs to feed); SSG_FASTQ_THREADS wins */
 	fq_feed_t(gzFile fp, bool keep_comment, int per_block, const char *path = 0, int threads_hint = 0) : ch(4), pool(new fq_block_pool_t())
 	{
 		const std::string pth(path ? path : "");
 		th = std::thread([this, fp, keep_comment, per_block, pth, threads_hint]() {
 			if (pth.empty() || !parse_plain(pth, keep_comment, per_block, threads_hint)) {
-				fq_reader_t rd(fp, keep_comment, pth.empty() ? 0 : pth.c_str());
-				(void)drain(rd, per_block, [this](blk_t b) { ch.push(std::move(b)); });
+				fq_stream_t src(fp, pth.empty() ? 0 : pth.c_str());
+				int T = threads_hint > 0 ? threads_hint : std::thread::hardware_concurrency() >= 32 ? 4 : 1;
+				{ const char *e = getenv("SSG_FASTQ_THREADS"); if (e) T = atoi(e); }
+				if (src.threaded && T > 1) parse_stream(src, keep_comment, per_block, T);
+				else { fq_reader_t rd((const unsigned char*)0, 0, &src, keep_comment); (void)drain(rd, per_block, [this](blk_t b) { ch.push(std::move(b)); }); }
 			}
 			ch.close();
 		});

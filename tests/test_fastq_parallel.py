@@ -17,7 +17,7 @@ def dump(path, threads, piece=None):
     env = dict(os.environ, SSG_FASTQ_THREADS=str(threads), SSG_DEBUG="1")
     if piece:
         env["SSG_FASTQ_PIECE"] = str(piece)
-    r = subprocess.run([FQ_DUMP, path], env=env, capture_output=True, check=True)
+    r = subprocess.run([FQ_DUMP, path], env=env, capture_output=True, check=True, timeout=120)
     return r.stdout, r.stderr.decode()
 
 
@@ -137,7 +137,7 @@ def test_gzip_input_through_the_fast_decoder(tmp_path, case):
 
     def dump_gz(path, fast, threads=1):
         env = dict(os.environ, SSG_GZ_FAST="1" if fast else "0", SSG_GZ_THREADS=str(threads), SSG_GZ_CHUNK="20000")
-        return subprocess.run([FQ_DUMP, path], env=env, capture_output=True, check=True).stdout
+        return subprocess.run([FQ_DUMP, path], env=env, capture_output=True, check=True, timeout=120).stdout
     assert dump_gz(str(g), True) == ref and dump_gz(str(g), False) == ref
     assert dump_gz(str(g), True, threads=3) == ref                 # several decoding threads for the one stream (fast_inflate_mt.h)
     blob = g.read_bytes()
@@ -168,3 +168,24 @@ def test_bwa_emu_gz_input_several_decoding_threads(tmp_path, emu_lib):
         r = subprocess.run([bwa, "mem", "-t", "4", "-p", EXAMPLE_FA, gzp], env=dict(os.environ, **env), capture_output=True, check=True, timeout=900)
         outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
     assert outs[0].count(b"\n") > 3000 and outs[1] == outs[0] and outs[2] == outs[0]
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("slab,piece", [(20000, 3000), (400, 150), (90, 40), (1000000, 40000)])
+def test_compressed_input_parsed_by_several_threads(tmp_path, case, slab, piece):
+    """gz and bgzip input whose decoded stream is cut into slabs and pieces and parsed by several threads (fq_feed_t::parse_stream): same
+    records and end state as one thread, for four-line files and for everything else (wrapped, FASTA, junk, truncated: the fall-back to
+    one thread happens in the middle of the stream)"""
+    import gzip
+    rng = random.Random(hash((case, slab)) & 0xffff)
+    txt = CASES[case](rng).encode()
+    p = tmp_path / "x.fq"
+    p.write_bytes(txt)
+    g = tmp_path / "x.fq.gz"
+    g.write_bytes(gzip.compress(txt, 6))
+    ref, _ = dump(str(p), 1)
+    env = dict(os.environ, SSG_FASTQ_THREADS="4", SSG_FASTQ_SLAB=str(slab), SSG_FASTQ_PIECE=str(piece), SSG_GZ_THREADS="3", SSG_GZ_CHUNK="30000", SSG_DEBUG="1")
+    r = subprocess.run([FQ_DUMP, str(g)], env=env, capture_output=True, check=True, timeout=60)
+    assert r.stdout == ref
+    env["SSG_GZ_FAST"] = "0"                            # ... and behind zlib's decoder
+    assert subprocess.run([FQ_DUMP, str(g)], env=env, capture_output=True, check=True, timeout=60).stdout == ref
