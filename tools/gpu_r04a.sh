@@ -19,6 +19,7 @@ print('ms/step', round(d['ms_per_step'],1), 'value', d.get('value'), 'parity', d
 for k in ('fused','text'):
     r=L.get(k,{}); print(k, {x:r.get(x) for x in ('pairs','wall_s','pairs_per_s','error')})
     for l in r.get('stage_log',[]): print('   ', l)
+e=d.get('e2e',{}); print('plugin path (text hand-off):', {k:e.get(k) for k in ('pairs','pairs_per_s','index_load_s','pairs_per_s_gz_input','gz_input_pairs')})   # gz: decoder of our own, several threads on the one stream + several parse threads
 print('config5', d.get('config5')); print('dist', d.get('dist_rehearsal')); print('cpu script', d.get('cpu_baseline',{}).get('script'))
 PY
 SSG_BENCH_CONFIG_EXTRA="export SSG_FUSED_SHM=0" timeout 600 python bench.py --steps 2 --warmup 1 --cpu-sample 2000 --config5-pairs 0 --cpu-script-pairs 0 --no-dist-rehearsal --no-profile > $out/r04a_bench_pipes.json 2> $out/r04a_bench_pipes.err
