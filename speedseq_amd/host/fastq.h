@@ -92,9 +92,10 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 			mid.push(std::move(p));
 			return !stop.load() && !io_err.load();
 		};
-		/* several decoding threads for the one stream (fast_inflate_mt.h) where the host has cores to spare: SSG_GZ_THREADS, default 8 on
-		 * hosts with 32 hardware threads or more, otherwise one */
-		int gt = std::thread::hardware_concurrency() >= 32 ? 8 : 1; { const char *e = getenv("SSG_GZ_THREADS"); if (e && atoi(e) > 0) gt = atoi(e); }
+		/* several decoding threads for the one stream (fast_inflate_mt.h) where the host has cores to spare: SSG_GZ_THREADS, default 12 on
+		 * hosts with 64 hardware threads or more, 8 from 32, otherwise one */
+		const unsigned hw = std::thread::hardware_concurrency();
+		int gt = hw >= 64 ? 12 : hw >= 32 ? 8 : 1; { const char *e = getenv("SSG_GZ_THREADS"); if (e && atoi(e) > 0) gt = atoi(e); }
 		if (gt > 1) {
 			check_crc = false;
 			size_t gc = (size_t)2 << 20; { const char *e = getenv("SSG_GZ_CHUNK"); if (e && atol(e) > 0) gc = (size_t)atol(e); }   /* compressed bytes per thread and wave (tests make it small) */
