@@ -28,6 +28,9 @@
 #include <vector>
 #include <thread>
 #include <functional>
+#include <memory>
+#include <mutex>
+#include <condition_variable>
 #include <algorithm>
 #include <zlib.h>   /* crc32, crc32_combine */
 #include "fast_inflate.h"
@@ -125,42 +128,118 @@ struct fast_gz_mt_t {
 
 	template <class F> void parallel(int n, F f) { std::vector<std::thread> th; for (int t = 1; t < n; ++t) th.emplace_back(f, t); f(0); for (auto &x : th) x.join(); }
 
-	/* the whole file; false on error (err) */
+	/* one wave as the producer hands it to the stitcher: the chunks that abut, in stream order, and what ends with them */
+	struct wave_t {
+		uint64_t A; std::vector<chunk_t> ch; std::vector<int> chain; int fail_idx;     /* fail_idx: chunk the one-thread decoder takes over from, or -1 */
+		bool new_member, member_end; uint32_t crc_expect, isize; bool stream_end;      /* stream_end: nothing follows this wave */
+		wave_t() : A(0), fail_idx(-1), new_member(false), member_end(false), crc_expect(0), isize(0), stream_end(false) {}
+	};
+	/* the whole file; false on error (err).  The calling thread reads, searches and decodes wave after wave (T threads); a second thread
+	 * stitches the waves behind it (markers -> bytes and CRC by T threads, bytes to the sink): a wave's decode needs only the bit where
+	 * the previous one ended, not its window */
 	bool run(const sink_t &sink)
 	{
 		struct stat sb; if (fstat(fd, &sb) != 0) { err = "cannot stat the input"; return false; }
 		file_size = (uint64_t)sb.st_size;
+		std::mutex mu; std::condition_variable cv; std::vector<std::unique_ptr<wave_t> > ready, spare; bool closed = false; std::atomic<bool> stop(false);
+		const char *stitch_err = 0; bool stitch_ok = true;
+		for (int k = 0; k < 3; ++k) spare.emplace_back(new wave_t());
+		/* the stitcher's helpers run beside the next wave's decoders: as many as those where the host has the cores, half otherwise */
+		const int R = std::thread::hardware_concurrency() >= (unsigned)(3 * T) ? T : std::max(1, T / 2);
+		std::thread stitcher([&]() {
+			std::vector<uint8_t> window, bytes; uint64_t member_out = 0; uLong member_crc = crc32(0L, Z_NULL, 0);
+			std::vector<uLong> part_crc((size_t)R); std::vector<size_t> part_len((size_t)R);
+			for (;;) {
+				std::unique_ptr<wave_t> W;
+				{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !ready.empty() || closed; }); if (ready.empty()) break; W = std::move(ready.front()); ready.erase(ready.begin()); }
+				if (stitch_ok) {
+					if (W->new_member) { window.clear(); member_out = 0; member_crc = crc32(0L, Z_NULL, 0); }
+					for (size_t ci = 0; ci < W->chain.size() && stitch_ok; ++ci) {
+						chunk_t &c = W->ch[(size_t)W->chain[ci]];
+						if (W->chain[ci] == W->fail_idx) {   /* the rest of the member (and of the file) through the one-thread decoder, from the bit where the last good piece ended */
+							if (!serial_rest(sink, W->A * 8 + c.start, window, member_out, member_crc)) { stitch_err = err; stitch_ok = false; }
+							break;
+						}
+						bytes.resize(c.n);
+						const uint16_t *src = c.out.data() + WIN; const uint8_t *wnd = window.data(); const size_t wn = window.size();
+						std::atomic<bool> bad(false);
+						parallel(R, [&](int t) {
+							const size_t a = c.n * (size_t)t / (size_t)R, b = c.n * (size_t)(t + 1) / (size_t)R;
+							part_len[(size_t)t] = b - a;
+							for (size_t i0 = a; i0 < b; i0 += 1024) {   /* blocks of 1024: a plain narrowing loop (vectorised); only blocks that hold a marker are done again */
+								const size_t i1 = std::min(b, i0 + 1024); uint16_t any = 0;
+								for (size_t i = i0; i < i1; ++i) { const uint16_t v = src[i]; any |= v; bytes[i] = (uint8_t)v; }
+								if (!(any & 0x8000u)) continue;
+								for (size_t i = i0; i < i1; ++i) {
+									const uint16_t v = src[i];
+									if (v & 0x8000u) { const size_t m = v & 0x7fffu; if (m + wn < (size_t)WIN) { bad = true; bytes[i] = 0; } else bytes[i] = wnd[m - ((size_t)WIN - wn)]; }
+								}
+							}
+							part_crc[(size_t)t] = b > a ? crc32(crc32(0L, Z_NULL, 0), bytes.data() + a, (uInt)(b - a)) : crc32(0L, Z_NULL, 0);
+						});
+						if (bad) { stitch_err = "distance too far back"; stitch_ok = false; break; }
+						for (int t = 0; t < R; ++t) if (part_len[(size_t)t]) member_crc = crc32_combine(member_crc, part_crc[(size_t)t], (z_off_t)part_len[(size_t)t]);
+						member_out += c.n;
+						if (c.n >= (size_t)WIN) window.assign(bytes.end() - WIN, bytes.end());
+						else { window.insert(window.end(), bytes.begin(), bytes.end()); if (window.size() > (size_t)WIN) window.erase(window.begin(), window.end() - WIN); }
+						const bool closes = c.final && W->member_end;
+						if (closes) {
+							if ((uint32_t)member_out != W->isize) { stitch_err = "length in the gzip trailer does not match"; stitch_ok = false; break; }
+							if ((uint32_t)member_crc != W->crc_expect) { stitch_err = "CRC-32 in the gzip trailer does not match"; stitch_ok = false; break; }
+						}
+						size_t o2 = 0;                                          /* the bytes go on in pieces of <= 4 MB; the last piece of a member says so */
+						do {
+							const size_t k = std::min<size_t>(c.n - o2, (size_t)4 << 20); const bool lastp = o2 + k == c.n;
+							if (!sink(bytes.data() + o2, k, lastp && closes, W->crc_expect)) { stitch_err = "cancelled"; stitch_ok = false; break; }
+							o2 += k;
+						} while (o2 < c.n);
+					}
+					if (!stitch_ok) stop = true;
+				}
+				{ std::lock_guard<std::mutex> l(mu); spare.push_back(std::move(W)); }
+				cv.notify_all();
+			}
+		});
+		auto finish = [&](bool ok, const char *e) -> bool {
+			{ std::lock_guard<std::mutex> l(mu); closed = true; }
+			cv.notify_all(); stitcher.join();
+			if (!ok) { err = e; return false; }
+			if (!stitch_ok) { err = stitch_err ? stitch_err : "damaged deflate stream"; return false; }
+			return true;
+		};
 		uint64_t member_byte = 0;                                          /* file offset of the member being decoded */
 		const size_t SLACK = (size_t)4 << 20;
-		std::vector<uint8_t> wbuf, window, bytes; std::vector<chunk_t> ch;
+		std::vector<uint8_t> wbuf;
 		bool first_member = true;
-		while (member_byte < file_size) {
+		while (member_byte < file_size && !stop) {
 			/* ---- member header (one thread, through the ordinary decoder's parser) ---- */
 			uint64_t pos;                                                  /* bit position in the FILE of the next block */
 			{
 				const size_t n = (size_t)std::min<uint64_t>(file_size - member_byte, 70000);
 				std::vector<uint8_t> hb(n + 16, 0);
-				if (!pread_all(fd, hb.data(), n, member_byte)) { err = "read error"; return false; }
+				if (!pread_all(fd, hb.data(), n, member_byte)) return finish(false, "read error");
 				fast_gz_t g(-1); g.ib = hb.data(); g.ireal = n; g.iend = n + 16; g.eof_in = true; g.ip = 0; g.member_done = !first_member;
-				if (!g.header()) { err = g.err ? g.err : "damaged gzip header"; return false; }
-				if (g.st == fast_gz_t::S_DONE) return true;                 /* bytes that are no member after a complete one */
+				if (!g.header()) return finish(false, g.err ? g.err : "damaged gzip header");
+				if (g.st == fast_gz_t::S_DONE) return finish(true, 0);        /* bytes that are no member after a complete one */
 				pos = (member_byte + g.ip) * 8;
 			}
 			first_member = false;
-			window.clear();
-			uint64_t member_out = 0; bool member_end = false; uint32_t crc_expect = 0; uLong member_crc = crc32(0L, Z_NULL, 0);
-			std::vector<uLong> part_crc((size_t)T); std::vector<size_t> part_len((size_t)T);
-			while (!member_end) {
-				/* ---- one wave ---- */
+			bool member_end = false, new_member = true;
+			while (!member_end && !stop) {
+				/* ---- one wave: read, find block starts, decode ---- */
+				std::unique_ptr<wave_t> W;
+				{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !spare.empty() || stop.load(); }); if (spare.empty()) break; W = std::move(spare.back()); spare.pop_back(); }
 				const uint64_t A = pos >> 3;                                 /* file offset of wbuf[0] */
 				const size_t want = (size_t)std::min<uint64_t>(file_size - A, (uint64_t)T * C + SLACK);
 				if (wbuf.size() < want + 64) wbuf.resize(want + 64);
-				if (!pread_all(fd, wbuf.data(), want, A)) { err = "read error"; return false; }
+				if (!pread_all(fd, wbuf.data(), want, A)) return finish(false, "read error");
 				memset(wbuf.data() + want, 0, 64);
 				const size_t real = want, padded = want + 64;
 				const uint64_t soft_end = std::min<uint64_t>((uint64_t)T * C, want) * 8;
+				std::vector<chunk_t> &ch = W->ch;
 				if (ch.size() != (size_t)T) ch.resize((size_t)T);
 				for (chunk_t &c : ch) { c.start = c.end = 0; c.valid = c.final = c.failed = false; c.n = 0; }
+				W->A = A; W->chain.clear(); W->fail_idx = -1; W->new_member = new_member; W->member_end = false; W->stream_end = false; new_member = false;
 				ch[0].start = pos - A * 8; ch[0].valid = true;
 				parallel(T, [&](int k) {
 					if (k == 0 || (uint64_t)k * C >= want) return;
@@ -171,63 +250,30 @@ struct fast_gz_mt_t {
 				for (int k = 1; k < T; ++k) if (ch[(size_t)k].valid) stops.push_back(ch[(size_t)k].start);
 				const bool to_eof = A + want == file_size;
 				parallel(T, [&](int k) { if (ch[(size_t)k].valid) decode_chunk(ch[(size_t)k], wbuf.data(), real, padded, stops, soft_end, to_eof); });
-				/* ---- stitch: the chunks that abut, in stream order ---- */
-				size_t cur = 0; bool wave_done = false;
-				while (!wave_done) {
+				/* ---- the chunks that abut, in stream order (no window needed for this) ---- */
+				bool handed_over = false;
+				for (size_t cur = 0;;) {
 					chunk_t &c = ch[cur];
-					if (c.failed) {
-						/* the rest of the member through the one-thread decoder, from the bit where the last good piece ended */
-						return serial_rest(sink, A * 8 + c.start, window, member_out, member_crc);
-					}
-					/* markers -> bytes with the window before this chunk */
-					bytes.resize(c.n);
-					const uint16_t *src = c.out.data() + WIN; const uint8_t *wnd = window.data(); const size_t wn = window.size();
-					std::atomic<bool> bad(false);
-					parallel(T, [&](int t) {
-						const size_t a = c.n * (size_t)t / (size_t)T, b = c.n * (size_t)(t + 1) / (size_t)T;
-						part_len[(size_t)t] = b - a;
-						for (size_t i0 = a; i0 < b; i0 += 1024) {   /* blocks of 1024: a plain narrowing loop (vectorised); only blocks that hold a marker are done again */
-							const size_t i1 = std::min(b, i0 + 1024); uint16_t any = 0;
-							for (size_t i = i0; i < i1; ++i) { const uint16_t v = src[i]; any |= v; bytes[i] = (uint8_t)v; }
-							if (!(any & 0x8000u)) continue;
-							for (size_t i = i0; i < i1; ++i) {
-								const uint16_t v = src[i];
-								if (v & 0x8000u) { const size_t m = v & 0x7fffu; if (m + wn < (size_t)WIN) { bad = true; bytes[i] = 0; } else bytes[i] = wnd[m - ((size_t)WIN - wn)]; }
-							}
-						}
-						part_crc[(size_t)t] = b > a ? crc32(crc32(0L, Z_NULL, 0), bytes.data() + a, (uInt)(b - a)) : crc32(0L, Z_NULL, 0);
-					});
-					if (bad) { err = "distance too far back"; return false; }
-					for (int t = 0; t < T; ++t) if (part_len[(size_t)t]) member_crc = crc32_combine(member_crc, part_crc[(size_t)t], (z_off_t)part_len[(size_t)t]);
-					member_out += c.n;
-					/* the next window: the last 32 KB of window + bytes */
-					if (c.n >= (size_t)WIN) window.assign(bytes.end() - WIN, bytes.end());
-					else { window.insert(window.end(), bytes.begin(), bytes.end()); if (window.size() > (size_t)WIN) window.erase(window.begin(), window.end() - WIN); }
+					W->chain.push_back((int)cur);
+					if (c.failed) { W->fail_idx = (int)cur; handed_over = true; break; }
 					pos = A * 8 + c.end;
-					if (c.final) {
-						/* trailer: CRC-32 and length of the member, byte-aligned after the final block */
+					if (c.final) {   /* trailer: CRC-32 and length of the member, byte-aligned after the final block */
 						const uint64_t tb = (pos + 7) >> 3; uint8_t tr[8];
-						if (tb + 8 > file_size || !pread_all(fd, tr, 8, tb)) { err = "truncated gzip trailer"; return false; }
-						uint32_t isz; memcpy(&crc_expect, tr, 4); memcpy(&isz, tr + 4, 4);
-						if ((uint32_t)member_out != isz) { err = "length in the gzip trailer does not match"; return false; }
-						if ((uint32_t)member_crc != crc_expect) { err = "CRC-32 in the gzip trailer does not match"; return false; }
-						member_end = true; member_byte = tb + 8;
+						if (tb + 8 > file_size || !pread_all(fd, tr, 8, tb)) return finish(false, "truncated gzip trailer");
+						memcpy(&W->crc_expect, tr, 4); memcpy(&W->isize, tr + 4, 4);
+						W->member_end = true; member_end = true; member_byte = tb + 8;
+						break;
 					}
-					{	size_t o2 = 0;                                          /* hand the bytes on in pieces of <= 4 MB; the last piece of a member says so */
-						do {
-							const size_t k = std::min<size_t>(c.n - o2, (size_t)4 << 20); const bool lastp = o2 + k == c.n;
-							if (!sink(bytes.data() + o2, k, lastp && c.final, crc_expect)) { err = "cancelled"; return false; }
-							o2 += k;
-						} while (o2 < c.n);
-					}
-					if (c.final) break;
-					/* which chunk starts where this one ended? */
 					size_t nxt = cur + 1; while (nxt < (size_t)T && !(ch[nxt].valid && ch[nxt].start == c.end)) ++nxt;
-					if (nxt < (size_t)T) cur = nxt; else wave_done = true;        /* the next wave starts at pos */
+					if (nxt >= (size_t)T) break;                               /* the next wave starts at pos */
+					cur = nxt;
 				}
+				{ std::lock_guard<std::mutex> l(mu); ready.push_back(std::move(W)); }
+				cv.notify_all();
+				if (handed_over) return finish(true, 0);                      /* the stitcher's one-thread decoder finishes the file */
 			}
 		}
-		return true;
+		return finish(true, 0);
 	}
 
 	/* rest of the current member (and whatever follows it) by the one-thread decoder: entered at file bit `bit` with `window` before it */
