@@ -76,6 +76,7 @@ def test_gpu_deferred_dense_suffix_array(tmp_path, gpu_lib):
     assert outs[0].count(b"\n") > 6000 and outs[1] == outs[0] and outs[2] == outs[0]
 
 
+@pytest.mark.skipif(not DRY and not os.environ.get("SSG_TEST_INFLIGHT"), reason="lanes have not run on an MI355X yet: first under tools/gpu_r04a.sh (SSG_TEST_INFLIGHT=1), not in the round-end tier")
 def test_gpu_zz_two_calls_in_flight(tmp_path, gpu_lib):
     """SSG_BWA_INFLIGHT=2 (two lanes per device: own streams and arenas, ssg_set_lane) against one call at a time: same SAM.  Last of the
     file: the lanes had not run on an MI355X when this was written; a run that does not finish is cut off after two minutes."""

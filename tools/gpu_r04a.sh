@@ -11,6 +11,7 @@
 #      libraries travel with the snapshot)
 out=$PWD/gpurun_out; mkdir -p $out; repo=$PWD
 timeout 900 python -m pytest tests -m gpu -x -q > $out/r04a_pytest_gpu.log 2>&1; tail -3 $out/r04a_pytest_gpu.log
+SSG_TEST_INFLIGHT=1 timeout 400 python -m pytest tests/test_zz_twins_gpu.py -m gpu -q -k in_flight > $out/r04a_pytest_inflight.log 2>&1; tail -2 $out/r04a_pytest_inflight.log   # lanes: two device calls in flight per GPU
 timeout 900 python bench.py --steps 5 --warmup 2 > $out/r04a_bench.json 2> $out/r04a_bench.err; tail -4 $out/r04a_bench.err
 python - <<'PY'
 import json
