@@ -305,6 +305,7 @@ static int format_all(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ss
                       const char *rg_id, std::vector<BUF> &outs, GET bytes_of, bool text, char **outp, int64_t *offs)
 {
 	int T = opt && opt->n_threads > 1 ? opt->n_threads : 1;
+	{ const int spare = (int)std::min(48u, std::thread::hardware_concurrency() / 4); if (T > 1 && spare > T) T = spare; }   /* -t sizes upstream's batches; printing has to keep up with an MI355X, not with -t CPU aligners */
 	{ const char *e = getenv("SSG_FMT_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
 	if (T > 64) T = 64;
 	if (T > (n_pairs + 1023) / 1024) T = (n_pairs + 1023) / 1024;
