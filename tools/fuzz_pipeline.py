@@ -42,9 +42,10 @@ def main():
             n = rng.randint(200, 900)
             simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n, seed=100 + seed, chim_frac=rng.random() * 0.1, disc_frac=rng.random() * 0.1, dup_frac=rng.random() * 0.3))
             opts = rng.choice([[], ["--addMateTags"], ["--excludeDups", "--addMateTags", "--maxSplitCount", "2", "--minNonOverlap", "20"]])
+            chunk_bases = str(rng.choice([8000, 30000, 100000]))   # upstream's batch size: the scope of the insert-size model, i.e. part of the INPUT -- the same for both runs
             outs = {}
             for mode in ("text", "fused"):
-                env = dict(os.environ, SSG_BWA_CHUNK_BASES=str(rng.choice([8000, 30000, 100000])), SSG_BWA_CALL_PAIRS=str(rng.choice([50, 200, 1000])),
+                env = dict(os.environ, SSG_BWA_CHUNK_BASES=chunk_bases, SSG_BWA_CALL_PAIRS=str(rng.choice([50, 200, 1000])),
                            SSG_EMU_DEVICES=str(rng.choice([1, 2, 3])), SSG_BWA_INFLIGHT=str(rng.choice([1, 2])), SSG_BWA_FORMATTERS=str(rng.choice([1, 3])),
                            SSG_FUSED_SHM_MIN=str(rng.choice([1, 10 ** 9])), SSG_GZ_THREADS=str(rng.choice([1, 3])), SSG_GZ_CHUNK="30000",
                            SSG_FASTQ_THREADS=str(rng.choice([1, 3])), SSG_FASTQ_SLAB="40000", SSG_FASTQ_PIECE="5000", SSG_BWA_DENSIFY_AFTER=str(rng.choice([0, 100, 10 ** 9])))
