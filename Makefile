@@ -9,24 +9,22 @@ HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -W
 all: lib tools oracle emu synth
 
 lib: speedseq_amd/libssgpu.so
-$(CSRC)/ssgpu_core.o: $(CSRC)/ssgpu_core.cpp $(KHDRS)
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
-$(CSRC)/ssg_index_build.o: $(CSRC)/ssg_index_build.cpp $(CSRC)/k_index.h $(CSRC)/ssg_prim.h $(CSRC)/ssg_rt.h $(CSRC)/ssg_dev.h $(CSRC)/ssg_index_int.h $(CSRC)/ssg_types.h include/ssgpu.h
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
-$(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp include/ssgpu.h $(CSRC)/ssg_types.h
-	$(CXX) -O2 -std=c++17 -fPIC -c $< -o $@
-$(CSRC)/ssg_ktab.o: $(CSRC)/ssg_ktab.cpp $(CSRC)/k_seed_kt.h $(CSRC)/ssg_dev.h $(CSRC)/ssg_rt.h $(CSRC)/ssg_types.h $(CSRC)/ssg_index_int.h include/ssgpu.h
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
-LIBOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o
+# Every object's prerequisites come from the compiler (-MMD): no hand-kept header lists, so no object can be stale against a shared
+# declaration (round 3 shipped variant libraries linked from objects of different ages).
+HIPOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/ssg_seed.o
+$(HIPOBJS): $(CSRC)/%.o: $(CSRC)/%.cpp
+	$(HIPCC) $(HIPFLAGS) -MMD -MP -x hip -c $< -o $@
+$(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp
+	$(CXX) -O2 -std=c++17 -fPIC -MMD -MP -c $< -o $@
+-include $(wildcard $(CSRC)/*.d)
+LIBOBJS = $(HIPOBJS) $(CSRC)/sam_format.o
 speedseq_amd/libssgpu.so: $(LIBOBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(LIBOBJS) -o $@ -lz
 
 # instrumented build (device phase counters, tools/dbg/phase.py); never the default library
 tune: speedseq_amd/libssgpu_tune.so
-speedseq_amd/libssgpu_tune.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.cpp $(KHDRS)
-	$(HIPCC) $(HIPFLAGS) -DSSG_TUNE -DSSG_C2A_WAVES_PER_SIMD=2 -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_tune.o
-	$(CXX) -O2 -std=c++17 -fPIC -c $(CSRC)/sam_format.cpp -o $(CSRC)/sam_format.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_tune.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o -o $@ -lz
+speedseq_amd/libssgpu_tune.so: $(LIBOBJS)
+	$(MAKE) variant NAME=tune VFLAGS="-DSSG_TUNE -DSSG_C2A_WAVES_PER_SIMD=2"
 
 # bench utility: synthetic reference generator (one kernel launch)
 synth: tools/synth/libsynthref.so
@@ -66,9 +64,9 @@ tests/emu/fi_test: tools/dbg/fi_test.cpp $(HOST)/fast_inflate.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fi_test.cpp -o $@ -lz
 tests/emu/fq_dump: tools/dbg/fq_dump.cpp $(HOST)/fastq.h $(HOST)/fast_inflate.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fq_dump.cpp -o $@ -lz -lpthread
-tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_ktab.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
+tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_ktab.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
-		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_ktab.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
+		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_ktab.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
 tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOST)/fastq.h $(HOST)/fused.h include/ssgpu.h tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h $(HOST)/fused.h include/ssgpu.h tests/emu/libssgpu_emu.so
@@ -78,11 +76,20 @@ tests/emu/sambamba_emu: $(HOST)/sambamba_main.cpp $(HOST)/bamio.h $(HOST)/fastq.
 	$(CXX) -O2 -std=c++17 $(HOST)/sambamba_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 
 clean:
-	rm -f speedseq_amd/libssgpu.so tests/emu/libssgpu_emu.so bin/bwa bin/samblaster bin/sambamba tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu tests/emu/fq_dump tests/emu/fi_test tests/emu/fi_mt_test $(CSRC)/*.o
+	rm -rf build; rm -f speedseq_amd/libssgpu.so speedseq_amd/libssgpu_*.so $(CSRC)/*.d tests/emu/libssgpu_emu.so bin/bwa bin/samblaster bin/sambamba tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu tests/emu/fq_dump tests/emu/fi_test tests/emu/fi_mt_test $(CSRC)/*.o
 	$(MAKE) -C oracle clean
-.PHONY: all lib tools oracle emu clean
+.PHONY: all lib tools oracle emu clean variant tune
 
-# A/B builds of the device library with other compile-time parameters (bench: SSGPU_LIB=speedseq_amd/libssgpu_$(NAME).so); never the default
-variant: $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o
-	$(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/ssgpu_core.cpp -o $(CSRC)/ssgpu_core_$(NAME).o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/ssgpu_core_$(NAME).o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_ktab.o $(CSRC)/sam_format.o -o speedseq_amd/libssgpu_$(NAME).so -lz
+# A/B builds of the device library with other compile-time parameters (bench / tests: SSGPU_LIB=speedseq_amd/libssgpu_$(NAME).so); never the
+# default.  The units named in VUNITS (default: all) are compiled with VFLAGS into build/$(NAME)/; the others are the product build's
+# objects, which `lib` has just brought up to date against every header they include (-MMD), so no stale object can be linked.
+#   make variant NAME=x VFLAGS="-D..."                   all translation units
+#   make variant NAME=x VFLAGS="-D..." VUNITS=ssg_seed   only that unit (seconds)
+VUNITS ?= ssgpu_core ssg_index_build ssg_ktab ssg_seed
+variant: lib
+	mkdir -p build/$(NAME) && rm -f build/$(NAME)/*.o
+	for u in ssgpu_core ssg_index_build ssg_ktab ssg_seed; do \
+	  case " $(VUNITS) " in *" $$u "*) $(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/$$u.cpp -o build/$(NAME)/$$u.o || exit 1;; \
+	  *) cp $(CSRC)/$$u.o build/$(NAME)/$$u.o;; esac; done
+	cp $(CSRC)/sam_format.o build/$(NAME)/sam_format.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC build/$(NAME)/*.o -o speedseq_amd/libssgpu_$(NAME).so -lz

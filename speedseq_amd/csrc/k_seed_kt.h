@@ -88,6 +88,26 @@ SSG_DEVFN uint32_t ssg_smq_code(const uint32_t *qw, int stride, int b, int n)
 #ifndef SSG_SMQ_TRIPS
 #define SSG_SMQ_TRIPS 2
 #endif
+/* diagnostic builds only (`make ktvariant`, tools/dbg/kt_variants.sh): counters / kernarg echo read back by ssg_ktab_dbg_read */
+#ifdef SSG_KT_DBG
+#ifdef SSG_EMU
+static unsigned long long ssg_kt_dbg[64];
+#else
+__device__ unsigned long long ssg_kt_dbg[64];
+#endif
+#ifdef SSG_EMU
+#define KTD(i, v) (ssg_kt_dbg[i] += (unsigned long long)(v))
+#else
+#define KTD(i, v) atomicAdd(&ssg_kt_dbg[i], (unsigned long long)(v))
+#endif
+#else
+#define KTD(i, v) ((void)0)
+#endif
+#ifdef SSG_KT_NOTAB
+#define SSG_KT_ON false
+#else
+#define SSG_KT_ON true
+#endif
 /* ssg_k_smem_quad with the table of short-pattern intervals (kt_tab, kt_k): an extension whose result pattern has at most kt_k bases is one
  * 16-byte load, and the third pass starts kt_k bases in.  A kernel of its own, so that the default kernel above keeps the exact text (and
  * machine code) of rounds 1-2; opt-in with SSG_KTAB_K until its GPU results match the oracle. */
@@ -97,7 +117,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
                            ssg_intv_t *out_intv, int32_t *out_n, int cap,
                            ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, const ssg_pk_t *kt_tab, int kt_k)
 {
-	constexpr bool KT = true;
+	constexpr bool KT = SSG_KT_ON;
 	constexpr int RPW = 64 / LPR;   /* reads per wave */
 	__shared__ uint32_t qlds[SSG_SM_QWORDS * RPW];
 	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nq = ((long)gridDim.x * blockDim.x) / LPR;
@@ -113,6 +133,15 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
 #define QW (ql == 0)  /* one lane of the quad stores */
 #endif
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+#ifdef SSG_KT_DBG
+	if (gt == 0) {   /* what the kernel sees of its by-value arguments */
+		unsigned long long *d = ssg_kt_dbg + 16;
+		d[0] = (unsigned long long)opt.min_seed_len; d[1] = (unsigned long long)opt.split_width; d[2] = opt.max_mem_intv; { uint32_t sfb; memcpy(&sfb, &opt.split_factor, 4); d[3] = sfb; }
+		d[4] = (unsigned long long)split_len; d[5] = (unsigned long long)kt_k; d[6] = ix.primary; d[11] = ix.L2[4];
+		d[12] = ix.seq_len; d[13] = (unsigned long long)scap; d[14] = (unsigned long long)cap; d[15] = (unsigned long long)n_reads; d[16] = (unsigned long long)(uintptr_t)kt_tab; d[17] = (unsigned long long)(uintptr_t)ix.bwt;
+		d[18] = (unsigned long long)gridDim.x; d[19] = (unsigned long long)blockDim.x; d[20] = (unsigned long long)opt.max_occ; d[21] = (unsigned long long)ix.sa_intv;
+	}
+#endif
 	unsigned long long my_nx = 0;
 	long it = gt / LPR - nq;
 	int state = SM_READ, pend = SM_PEND_NONE;
@@ -248,8 +277,14 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
 			}
 		}
 		if (SSG_TUNING) { const unsigned long long t1 = ssg_clock(); tn_adv += t1 - tn_t0; tn_t0 = t1; ++tn_rounds; tn_ready += (unsigned long long)__popcll(wv_ballot(pend != SM_PEND_NONE)); tn_alive += (unsigned long long)__popcll(wv_ballot(state != SM_FIN)); }
+#ifdef SSG_KT_UNIFORM   /* wave-uniform loop exit, the extension site as one predicated block: no divergent break / continue */
+		if (!wv_ballot(state != SM_FIN)) break;
+		if (pend != SM_PEND_NONE) {
+#else
 		if (state == SM_FIN) break;
 		if (pend == SM_PEND_NONE) continue;
+#endif
+		KTD(0, 1); if (pend == SM_PEND_NONE) KTD(1, 1); if (state == SM_FIN) KTD(2, 1); if (pend < 0 || pend > SM_PEND_P3) KTD(3, 1);
 		/* ---- the one extension site: two rank-block quarters per lane + the next list entry ---- */
 		ssg_wave_ldssync();   /* list entries stored by lane 0 of the quad last iteration are read by all four below (same wave: in order on the GPU) */
 		const ssg_pk_t *const prev = flip ? vec0 : vec1;
@@ -260,18 +295,37 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
 		/* the pattern the extension ends with: [i, end of p) going left, [start, i] going right; up to kt_k bases its interval is in the table */
 		const int pat_b = back ? i : pend == SM_PEND_FWD ? sx : x, pat_n = (back ? (int)p.info : i + 1) - pat_b;
 		ssg_intv_t okc;
-		if (KT && pat_n <= kt_k) okc = ssg_unpk(kt_tab[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
+#ifdef SSG_KT_CHECK   /* both ways; the extension's result is used, a differing table entry counted */
+		okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
+		if (KT && pat_n <= kt_k) {
+			const ssg_intv_t te = ssg_unpk(kt_tab[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]);
+			KTD(4, 1);
+			if (te.x2 != okc.x2 || (te.x2 && (te.x0 != okc.x0 || te.x1 != okc.x1))) { KTD(5, 1); if (back) KTD(6, 1); else if (pend == SM_PEND_FWD) KTD(7, 1); else KTD(8, 1); }
+		}
+#else
+		if (KT && pat_n <= kt_k) { okc = ssg_unpk(kt_tab[ssg_ktab_off(pat_n) + (long)ssg_smq_code(ql_, RPW, pat_b, pat_n)]); KTD(4, 1); }
 		else okc = LPR == 4 ? ssg_bwt_extend1_quad(ix, back ? p : ik, e_c, back, ql) : ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
+#endif
 		++my_nx;
 		{
 			ssg_pk_t *const curr = flip ? vec1 : vec0;
 			if (pend == SM_PEND_FWD) {
+#ifdef SSG_KT_UNIFORM
+				bool fwd_end = false;
+				if (okc.x2 != ik.x2) {
+					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1;
+					++curr_n;
+					if (okc.x2 < min_intv) { SM_DO_FWDEND(); fwd_end = true; }   /* break: ik stays the last pushed */
+				}
+				if (!fwd_end) { ik = okc; ik.info = (uint64_t)(i + 1); ++i; }
+#else
 				if (okc.x2 != ik.x2) {
 					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1;
 					++curr_n;
 					if (okc.x2 < min_intv) { SM_DO_FWDEND(); pend = SM_PEND_NONE; continue; }   /* break: ik stays the last pushed */
 				}
 				ik = okc; ik.info = (uint64_t)(i + 1); ++i;
+#endif
 			} else if (back) {
 				pn = pf;
 				if (okc.x2 < min_intv) {
@@ -303,6 +357,9 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
 			}
 			pend = SM_PEND_NONE;
 		}
+#ifdef SSG_KT_UNIFORM
+		}
+#endif
 		if (SSG_TUNING) tn_ext += ssg_clock() - tn_t0;
 	}
 	if (SSG_TUNING) {   /* slots 24..28: the lane that ran longest speaks for its wave (all live lanes of a wave count the same rounds) */

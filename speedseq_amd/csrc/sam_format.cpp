@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/ssgpu.h"
+#include "ssg_index_int.h"
+SSG_ABI_FP_DEFINE(sam_format)
 
 namespace {
 struct alignas(128) sbuf {   /* one per formatting thread, side by side in a vector: its length field is written on every append, so it gets cache lines of its own */

@@ -232,12 +232,14 @@ static int set_contigs(ssg_index *ix, int n_ctg, const int64_t *ctg_off, const i
 	return 0;
 }
 
+SSG_ABI_FP_DEFINE(index_build)
 extern "C" {
 
 int ssg_index_build_dev(const uint8_t *d_fwd, int64_t l_pac, int n_ctg, const int64_t *ctg_off, const int32_t *ctg_len, ssg_index_t **out)
 {
 	*out = 0;
 	if (rt_device_count() < 1) { ssg_err_msg = "no HIP device visible: libssgpu has no CPU path"; return SSG_ENODEV; }
+	{ const int rc0 = ssg_abi_selfcheck(); if (rc0) return rc0; }
 	if (n_ctg < 1) { ssg_err_msg = "ssg_index_build_dev: no contigs"; return SSG_EINVAL; }
 	ssg_index *ix = new ssg_index();
 	int rc = build_from_fwd(d_fwd, l_pac, ix);
@@ -256,6 +258,7 @@ int ssg_index_build_fasta(const char *fasta, ssg_index_t **out)
 {
 	*out = 0;
 	if (rt_device_count() < 1) { ssg_err_msg = "no HIP device visible: libssgpu has no CPU path"; return SSG_ENODEV; }
+	{ const int rc0 = ssg_abi_selfcheck(); if (rc0) return rc0; }
 	gzFile fp = gzopen(fasta, "r");
 	if (!fp) { ssg_err_msg = std::string("cannot open ") + fasta; return SSG_EIO; }
 	gzbuffer(fp, 1 << 20);

@@ -31,4 +31,34 @@ extern "C" int ssg_index_build_ktab(ssg_index *ix);
 extern "C" int ssg_ktab_launch_smem(const ssg_index *idx, const ssg_mem_opt_t *opt, long n_wg, int block, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                                     ssg_intv_t *d_intv, int32_t *d_n, int cap, ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read);
 extern "C" int ssg_sa_verify(const ssg_index *ix, int new_intv, const uint64_t *d_sa_new, long n_new);
+
+/* Layout fingerprint of the declarations the translation units of libssgpu share (and that kernels take by value).  Every unit defines
+ * one with SSG_ABI_FP_DEFINE(<unit>); ssg_abi_selfcheck() (ssgpu_core.cpp, run before the first index is made) compares them and refuses
+ * to go on when two units were compiled against different declarations -- an object left over from before a header changed would
+ * otherwise read another unit's structures at the wrong offsets without any diagnostic. */
+#include <stddef.h>
+struct ssg_abi_fp_t { uint32_t v[20]; };
+#ifdef __clang__
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winvalid-offsetof"
+#else
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Winvalid-offsetof"
+#endif
+static inline ssg_abi_fp_t ssg_abi_fp_make()
+{
+	ssg_abi_fp_t f = {{ (uint32_t)sizeof(ssg_index_view_t), (uint32_t)sizeof(ssg_mem_opt_t), (uint32_t)sizeof(ssg_index), (uint32_t)sizeof(ssg_intv_t),
+		(uint32_t)offsetof(ssg_index_view_t, primary), (uint32_t)offsetof(ssg_index_view_t, L2), (uint32_t)offsetof(ssg_index_view_t, l_pac), (uint32_t)offsetof(ssg_index_view_t, sa_intv),
+		(uint32_t)offsetof(ssg_mem_opt_t, min_seed_len), (uint32_t)offsetof(ssg_mem_opt_t, split_width), (uint32_t)offsetof(ssg_mem_opt_t, max_mem_intv), (uint32_t)offsetof(ssg_mem_opt_t, split_factor),
+		(uint32_t)offsetof(ssg_mem_opt_t, mat), (uint32_t)offsetof(ssg_index, bwt), (uint32_t)offsetof(ssg_index, ktab), (uint32_t)offsetof(ssg_index, bwt_words),
+		(uint32_t)offsetof(ssg_index, names), (uint32_t)sizeof(ssg_seed_t), (uint32_t)sizeof(ssg_alnreg_t), (uint32_t)sizeof(ssg_aln_t) }};
+	return f;
+}
+#ifdef __clang__
+#pragma clang diagnostic pop
+#else
+#pragma GCC diagnostic pop
+#endif
+#define SSG_ABI_FP_DEFINE(unit) extern "C" void ssg_abi_fp_##unit(ssg_abi_fp_t *out) { *out = ssg_abi_fp_make(); }
+extern "C" int ssg_abi_selfcheck(void);   /* 0, or SSG_EINVAL with the differing unit / field in ssg_last_error() */
 #endif

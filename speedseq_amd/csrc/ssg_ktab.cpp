@@ -9,6 +9,7 @@
 #include "../../include/ssgpu.h"
 #include "ssg_index_int.h"
 
+SSG_ABI_FP_DEFINE(ktab)
 #define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 
@@ -52,6 +53,22 @@ extern "C" int ssg_ktab_launch_smem(const ssg_index *idx, const ssg_mem_opt_t *o
 	           (const ssg_pk_t*)idx->ktab, idx->ktab_k);
 	return 0;
 }
+
+#ifdef SSG_KT_DBG
+/* diagnostic builds only: the counters / kernarg echo of ssg_k_smem_quad_kt (64 words), cleared by the read */
+extern "C" int ssg_ktab_dbg_read(unsigned long long *out)
+{
+#ifdef SSG_EMU
+	memcpy(out, ssg_kt_dbg, sizeof(ssg_kt_dbg)); memset(ssg_kt_dbg, 0, sizeof(ssg_kt_dbg));
+#else
+	CHK(rt_sync());
+	CHK(rt_check(hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_kt_dbg), 64 * sizeof(unsigned long long)), "hipMemcpyFromSymbol"));
+	unsigned long long z[64]; memset(z, 0, sizeof(z));
+	CHK(rt_check(hipMemcpyToSymbol(HIP_SYMBOL(ssg_kt_dbg), z, sizeof(z)), "hipMemcpyToSymbol"));
+#endif
+	return 0;
+}
+#endif
 
 /* SSG_SA_VERIFY: every `stride`-th entry of the denser SA table against upstream's bwt_sa on the file's samples (view = the index before the swap) */
 extern "C" int ssg_sa_verify(const ssg_index *ix, int new_intv, const uint64_t *d_sa_new, long n_new)

@@ -60,10 +60,28 @@ static int ssg_debug() { static int d = -1; if (d < 0) d = getenv("SSG_DEBUG") ?
 static double ssg_stage_ms() { static thread_local std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); const auto t1 = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; return ms; }
 #define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d  +%.1f ms\n", name, rc_, ssg_stage_ms()); fflush(stderr); if (rc_) return rc_; } } while (0)
 
+SSG_ABI_FP_DEFINE(core)
+extern "C" void ssg_abi_fp_index_build(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_ktab(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_seed(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_sam_format(ssg_abi_fp_t*);
+extern "C" int ssg_abi_selfcheck(void)
+{	/* every translation unit of the library was compiled against the same shared declarations (ssg_index_int.h) */
+	static const char *const field[20] = { "sizeof(ssg_index_view_t)", "sizeof(ssg_mem_opt_t)", "sizeof(ssg_index)", "sizeof(ssg_intv_t)", "ssg_index_view_t.primary", "ssg_index_view_t.L2",
+		"ssg_index_view_t.l_pac", "ssg_index_view_t.sa_intv", "ssg_mem_opt_t.min_seed_len", "ssg_mem_opt_t.split_width", "ssg_mem_opt_t.max_mem_intv", "ssg_mem_opt_t.split_factor", "ssg_mem_opt_t.mat",
+		"ssg_index.bwt", "ssg_index.ktab", "ssg_index.bwt_words", "ssg_index.names", "sizeof(ssg_seed_t)", "sizeof(ssg_alnreg_t)", "sizeof(ssg_aln_t)" };
+	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_ktab", ssg_abi_fp_ktab }, { "ssg_seed", ssg_abi_fp_seed }, { "sam_format", ssg_abi_fp_sam_format } };
+	ssg_abi_fp_t mine; ssg_abi_fp_core(&mine);
+	for (const auto &u : units) {
+		ssg_abi_fp_t o; u.fn(&o);
+		for (int i = 0; i < 20; ++i) if (o.v[i] != mine.v[i]) {
+			ssg_err_msg = std::string("libssgpu was linked from objects compiled against different declarations: ") + field[i] + " is " + std::to_string(mine.v[i]) + " in ssgpu_core and " + std::to_string(o.v[i]) + " in " + u.unit + " (rebuild: make clean lib)";
+			return SSG_EINVAL;
+		}
+	}
+	return 0;
+}
 static int need_device()
 {
 	if (rt_device_count() < 1) { ssg_err_msg = "no HIP device visible: libssgpu has no CPU path"; return SSG_ENODEV; }
-	return 0;
+	return ssg_abi_selfcheck();
 }
 
 extern "C" {
