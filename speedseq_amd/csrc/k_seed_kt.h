@@ -103,6 +103,11 @@ __device__ unsigned long long ssg_kt_dbg[64];
 #else
 #define KTD(i, v) ((void)0)
 #endif
+#ifdef SSG_KT_UNIFORM   /* = all three: wave-uniform loop exit, the site as one predicated block, no `continue' out of the middle of the site */
+#define SSG_KT_U_EXIT
+#define SSG_KT_U_SITE
+#define SSG_KT_U_INNER
+#endif
 #ifdef SSG_KT_NOTAB
 #define SSG_KT_ON false
 #else
@@ -277,11 +282,14 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
 			}
 		}
 		if (SSG_TUNING) { const unsigned long long t1 = ssg_clock(); tn_adv += t1 - tn_t0; tn_t0 = t1; ++tn_rounds; tn_ready += (unsigned long long)__popcll(wv_ballot(pend != SM_PEND_NONE)); tn_alive += (unsigned long long)__popcll(wv_ballot(state != SM_FIN)); }
-#ifdef SSG_KT_UNIFORM   /* wave-uniform loop exit, the extension site as one predicated block: no divergent break / continue */
+#ifdef SSG_KT_U_EXIT   /* wave-uniform loop exit */
 		if (!wv_ballot(state != SM_FIN)) break;
-		if (pend != SM_PEND_NONE) {
 #else
 		if (state == SM_FIN) break;
+#endif
+#ifdef SSG_KT_U_SITE   /* the extension site as one predicated block */
+		if (pend != SM_PEND_NONE) {
+#else
 		if (pend == SM_PEND_NONE) continue;
 #endif
 		KTD(0, 1); if (pend == SM_PEND_NONE) KTD(1, 1); if (state == SM_FIN) KTD(2, 1); if (pend < 0 || pend > SM_PEND_P3) KTD(3, 1);
@@ -310,7 +318,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
 		{
 			ssg_pk_t *const curr = flip ? vec1 : vec0;
 			if (pend == SM_PEND_FWD) {
-#ifdef SSG_KT_UNIFORM
+#ifdef SSG_KT_U_INNER
 				bool fwd_end = false;
 				if (okc.x2 != ik.x2) {
 					if (curr_n < scap) { if (QW) SMV(curr, curr_n) = ssg_pk(ik); } else ovf = 1;
@@ -357,7 +365,7 @@ __global__ void __launch_bounds__(64, SSG_SMQ_WAVES) ssg_k_smem_quad_kt(ssg_inde
 			}
 			pend = SM_PEND_NONE;
 		}
-#ifdef SSG_KT_UNIFORM
+#ifdef SSG_KT_U_SITE
 		}
 #endif
 		if (SSG_TUNING) tn_ext += ssg_clock() - tn_t0;

@@ -1,4 +1,237 @@
+/*
+ * k_smem2.h -- the seeding kernel of the product path: upstream mem_collect_intv = bwt_smem1a from every
+ * position the previous call returned (pass 1), bwt_smem1a with min_intv = occurrences + 1 from the middle of long SMEMs with few
+ * occurrences (pass 2), bwt_seed_strategy1 (pass 3); oracle/orc_smem.c restates them from upstream bwt.c / bwamem.c.
+ *
+ * One lane per read; the three passes are a per-lane state machine around ONE bwt_extend site per loop iteration, so that every lane of
+ * the wave that has an extension pending issues its two rank-block fetches (and the fetch of its next interval-list entry) in the same
+ * memory round trip, whatever loop of the nested algorithm it is in.  A read's three passes cost ~800 dependent extensions of two random
+ * 64-byte lines each; what bounds the kernel is the rate of random lines (tools/dbg/gather_probe.cpp), not streaming bandwidth.
+ *
+ * Control flow discipline (measured on the MI355X in round 4): the loop has ONE exit and it is wave-uniform
+ * (`no lane has work'), and the extension site is one predicated block -- no divergent `break' or `continue' anywhere in the loop.  The
+ * round-3 form of this kernel left the loop per lane (`if (state == FIN) break; if (pend == NONE) continue;' plus a `continue' out of the
+ * middle of the site); hipcc 7.2 compiled some instances of that text into code that computes different intervals on the GPU (second-pass
+ * SMEMs cut short) while the same text is right under the host emulation, and which instance went wrong depended on nothing one would
+ * touch on purpose (the translation unit the kernel sat in, two unused arguments).  The uniform form of the same statements is right in
+ * every build that was tried.
+ *
+ * Per-read budget: a read whose extensions exceed `max_ext' is given up (out_n = -2, nothing of it is kept) and the caller hands it to the
+ * wave-per-read kernel: a repeat-heavy read costs 10-50x the average, every one of its extensions is a dependent round trip, and a lane
+ * that picked one up late used to hold the whole launch open long after the pool of reads had run dry.
+ */
 #ifndef SSG_K_SMEM2_H
 #define SSG_K_SMEM2_H
 #include "ssg_dev.h"
+
+#define SSG_S2_QWORDS 32   /* the read as 4-bit codes, 8 per LDS word: reads up to 256 bases */
+enum { S2_FWD = 0, S2_BWD, S2_P3F, S2_READ, S2_P1, S2_P2, S2_P3, S2_OUT, S2_FIN };
+enum { S2_PEND_NONE = 0, S2_PEND_FWD, S2_PEND_BWD, S2_PEND_P3 };
+
+/* interval-list entry, 16 bytes: x0, x1, x2 < 2^40, info = end position < 256 */
+struct alignas(16) ssg_pk2_t { uint64_t w0, w1; };
+SSG_DEVFN ssg_pk2_t s2_pk(const ssg_intv_t &v)
+{ ssg_pk2_t p; p.w0 = v.x0 | (v.x1 & 0xffffffull) << 40; p.w1 = (v.x1 >> 24) | v.x2 << 16 | v.info << 56; return p; }
+SSG_DEVFN ssg_intv_t s2_unpk(const ssg_pk2_t &p)
+{ ssg_intv_t v; v.x0 = p.w0 & 0xffffffffffull; v.x1 = (p.w0 >> 40) | (p.w1 & 0xffffull) << 24; v.x2 = (p.w1 >> 16) & 0xffffffffffull; v.info = p.w1 >> 56; return v; }
+SSG_DEVFN void s2_set_intv(const ssg_index_view_t &ix, int c, ssg_intv_t &ik)
+{	/* upstream bwt_set_intv */
+	ik.x0 = ix.L2[c] + 1; ik.x2 = ix.L2[c+1] - ix.L2[c]; ik.x1 = ix.L2[3-c] + 1; ik.info = 0;
+}
+
+/* launch statistics of the instrumented instance (TUNE): [0] first lane started, [1] first lane that found the pool of reads empty, [2] last
+ * lane done (100 MHz wall clock); [3] reads given up; [8 + b] reads whose extension count has b significant bits; [48] wave rounds,
+ * [49] lanes with an extension pending, summed over rounds, [50] lanes with a read */
+#ifdef SSG_EMU
+static unsigned long long ssg_s2_stat[64];
+SSG_DEVFN unsigned long long s2_wall() { return 1; }
+#else
+__device__ unsigned long long ssg_s2_stat[64];
+SSG_DEVFN unsigned long long s2_wall() { return (unsigned long long)wall_clock64(); }
+#endif
+#define S2_STAT_MIN(i, v) atomicMin(&ssg_s2_stat[i], (unsigned long long)(v))
+#define S2_STAT_MAX(i, v) atomicMax(&ssg_s2_stat[i], (unsigned long long)(v))
+#define S2_STAT_ADD(i, v) atomicAdd(&ssg_s2_stat[i], (unsigned long long)(v))
+
+#ifndef SSG_S2_WAVES
+#define SSG_S2_WAVES 4
+#endif
+#ifndef SSG_S2_TRIPS
+#define SSG_S2_TRIPS 2
+#endif
+
+/*
+ * seq: concatenated nt4 codes, off[r]..off[r+1] delimit read r.  out_intv: [n_reads x cap]; out_n: per-read interval count (-1: the
+ * per-read capacity or a work list overflowed, -2: given up at max_ext extensions).  scratch: per launched wave 2 lists x scap entries x
+ * 64 lanes of 16 bytes, entry e of lane l at [e * 64 + l] (lanes pushing their e-th entries together write one 1-KB span).
+ * next_read: shared counter the lanes take their reads from (evens out the per-read cost).  n_ext_read (optional): extensions per read.
+ */
+template <bool TUNE>
+__global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
+                           const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap,
+                           ssg_pk2_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, unsigned int max_ext, uint32_t *n_ext_read)
+{
+	__shared__ uint32_t qlds[SSG_S2_QWORDS * 64];
+	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = (int)(threadIdx.x & 63);
+	ssg_pk2_t *const vec0 = scratch + (gt >> 6) * 2 * scap * 64 + lane, *const vec1 = vec0 + (long)scap * 64;
+	const uint32_t *const ql_ = qlds + lane;
+#define S2Q(i) ((int)((ql_[((i) >> 3) * 64] >> (((i) & 7) << 2)) & 15u))
+#define S2V(v, e) ((v)[(long)(e) * 64])
+	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+	unsigned long long my_nx = 0;
+	unsigned int rd_nx = 0;          /* extensions of the current read */
+	long it = 0;
+	int state = S2_READ, pend = S2_PEND_NONE;
+	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0;
+	ssg_intv_t *mem = 0;
+	int sx = 0, i = 0, j = 0, curr_n = 0, prev_n = 0, prev_rev = 0, flip = 0, m1_n = 0, m1_last_beg = 0, ret = 0, e_c = 0;
+	uint64_t min_intv = 1, last_x2 = 0;
+	ssg_intv_t ik, p;
+	ik.x0 = ik.x1 = ik.x2 = ik.info = 0; p = ik;
+	ssg_pk2_t pn, c0, first; pn.w0 = pn.w1 = 0; c0 = first = pn;
+	if (TUNE) S2_STAT_MIN(0, s2_wall());
+	/* transitions done where they arise (no state of their own):
+	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
+#define S2_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = s2_pk(ik); state = S2_BWD; } while (0)
+	/* next start of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
+#define S2_P3START() do { while (x < len && S2Q(x) > 3) ++x; if (x >= len) state = S2_OUT; else { s2_set_intv(ix, S2Q(x), ik); i = x + 1; state = S2_P3F; } } while (0)
+#define S2_RET() do { if (caller == 1) { x = ret; state = S2_P1; } else { ++k; state = S2_P2; } } while (0)
+	/* an SMEM leaves the backward pass: upstream keeps it when it starts left of the previous one of the call; the caller's length filter applied here */
+#define S2_EMIT(pp, beg) do { if (m1_n == 0 || (beg) < m1_last_beg) { ++m1_n; m1_last_beg = (beg); \
+		if ((int)(uint32_t)(pp).info - (beg) >= opt.min_seed_len) { ssg_intv_t o_ = (pp); o_.info |= (uint64_t)(beg) << 32; if (mem_n < cap) mem[mem_n] = o_; else ovf = 1; ++mem_n; } } } while (0)
+	for (;;) {
+		/* a bounded number of state-machine steps per extension round: a lane in the middle of a transition sits the round out instead of
+		 * making the whole wave walk through the dispatch again */
+		SSG_UNROLL for (int trip = 0; trip < SSG_S2_TRIPS; ++trip) if (pend == S2_PEND_NONE && state != S2_FIN) {
+			ssg_pk2_t *const curr = flip ? vec1 : vec0;
+			if (state == S2_FWD) { /* top of upstream's forward loop: for (i = x + 1; i < len; ++i) */
+				if (i < len && S2Q(i) < 4) { pend = S2_PEND_FWD; e_c = 3 - S2Q(i); }
+				else { if (curr_n < scap) S2V(curr, curr_n) = s2_pk(ik); else ovf = 1; ++curr_n; S2_FWDEND(); }
+			} else if (state == S2_BWD) { /* for (i = x - 1; i >= -1; --i) for (j = 0; j < prev->n; ++j) */
+				if (j >= prev_n) {
+					bool back_to_caller = curr_n == 0;
+					if (!back_to_caller) { flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 0; curr_n = 0; j = 0; --i; first = c0; back_to_caller = i < -1; }
+					if (back_to_caller) S2_RET();
+				} else {
+					p = s2_unpk(j == 0 ? first : pn);
+					const int cb = i < 0 ? -1 : S2Q(i) < 4 ? S2Q(i) : -1;
+					if (cb >= 0) { pend = S2_PEND_BWD; e_c = cb; }
+					else { /* no base to extend with: only the first (longest) interval of the row can be an SMEM, the rest are no-ops */
+						if (j == 0) S2_EMIT(p, i + 1);
+						j = prev_n;
+					}
+				}
+			} else if (state == S2_P3F) {
+				if (i >= len) { x = len; state = S2_OUT; }
+				else if (S2Q(i) < 4) { pend = S2_PEND_P3; e_c = 3 - S2Q(i); }
+				else { x = i + 1; S2_P3START(); }
+			} else if (state == S2_READ) {
+				it = (long)atomicAdd(next_read, 1u);
+				if (it >= n_reads) { state = S2_FIN; if (TUNE) S2_STAT_MIN(1, s2_wall()); }
+				else {
+					const int r = read_ids ? read_ids[it] : (int)it;
+					const uint8_t *q = seq + off[r];
+					len = (int)(off[r+1] - off[r]);
+					mem = out_intv + (long)it * cap; mem_n = 0; ovf = 0; rd_nx = 0;
+					/* the read as 4-bit codes, 8 per LDS word, fetched as aligned 8-byte words, four LDS words per round trip (this runs with few lanes active) */
+					const unsigned al = (unsigned)((uintptr_t)q & 7), sh8 = al << 3;
+					const uint64_t *const qa = (const uint64_t*)(q - al);
+					const int nw = (len + 7) >> 3, nb = (int)al + len;   /* nb: bytes from qa to the read's end */
+					for (int w0 = 0; w0 < nw; w0 += 4) {
+						uint64_t t[5];
+						SSG_UNROLL for (int jj = 0; jj < 5; ++jj) t[jj] = (w0 + jj) * 8 < nb ? qa[w0 + jj] : 0;
+						SSG_UNROLL for (int jj = 0; jj < 4; ++jj) {
+							const int w = w0 + jj;
+							if (w < nw) {
+								uint64_t v = sh8 ? (t[jj] >> sh8) | (t[jj + 1] << (64 - sh8)) : t[jj];
+								v &= 0x0f0f0f0f0f0f0f0full;
+								v = (v | v >> 4) & 0x00ff00ff00ff00ffull;
+								v = (v | v >> 8) & 0x0000ffff0000ffffull;
+								uint32_t v32 = (uint32_t)(v | v >> 16);
+								const int nv = len - w * 8;
+								if (nv < 8) v32 &= (1u << (nv << 2)) - 1u;
+								qlds[w * 64 + lane] = v32;
+							}
+						}
+					}
+					x = 0;
+					state = len >= opt.min_seed_len ? S2_P1 : S2_OUT;
+				}
+			} else if (state == S2_P1) {
+				if (x >= len) { old_n = mem_n < cap ? mem_n : cap; k = 0; state = S2_P2; }
+				else if (S2Q(x) > 3) ++x;
+				else { sx = x; min_intv = 1; caller = 1; state = S2_FWD; m1_n = 0; curr_n = 0; i = sx + 1; s2_set_intv(ix, S2Q(sx), ik); ik.info = (uint64_t)(sx + 1); }
+			} else if (state == S2_P2) { /* re-seed from the middle of long SMEMs with few occurrences */
+				if (k >= old_n) { x = 0; state = opt.max_mem_intv > 0 ? S2_P3 : S2_OUT; }
+				else {
+					const ssg_intv_t m = mem[k];
+					const int start = (int)(m.info >> 32), end = (int)(uint32_t)m.info;
+					if (end - start < split_len || m.x2 > (uint64_t)opt.split_width) ++k;
+					else {
+						sx = (start + end) >> 1; min_intv = m.x2 + 1; caller = 2; m1_n = 0; curr_n = 0; i = sx + 1;
+						if (S2Q(sx) > 3) S2_RET();   /* bwt_smem1a returns at once on an ambiguous base */
+						else { s2_set_intv(ix, S2Q(sx), ik); ik.info = (uint64_t)(sx + 1); state = S2_FWD; }
+					}
+				}
+			} else if (state == S2_P3) {
+				S2_P3START();
+			} else { /* S2_OUT */
+				const bool given_up = rd_nx > max_ext;
+				out_n[it] = given_up ? -2 : ovf ? -1 : mem_n;
+				if (n_ext_read) n_ext_read[it] = rd_nx;
+				if (TUNE) { S2_STAT_ADD(8 + (64 - __clzll((unsigned long long)(rd_nx | 1u))), 1); if (given_up) S2_STAT_ADD(3, 1); }
+				state = S2_READ;
+			}
+		}
+		if (TUNE) { const unsigned long long rdy = wv_ballot(pend != S2_PEND_NONE), alv = wv_ballot(state != S2_FIN); if (lane == 0) { S2_STAT_ADD(48, 1); S2_STAT_ADD(49, __popcll(rdy)); S2_STAT_ADD(50, __popcll(alv)); } }
+		if (!wv_ballot(state != S2_FIN)) break;   /* the only exit: no lane of the wave has work */
+		if (pend != S2_PEND_NONE) {
+			/* ---- the one extension site: the rank-block quarters of both queries + the next list entry, one memory round trip ---- */
+			const ssg_pk2_t *const prev = flip ? vec0 : vec1;
+			ssg_pk2_t *const curr = flip ? vec1 : vec0;
+			const bool back = pend == S2_PEND_BWD;
+			const int jn = back && j + 1 < prev_n ? j + 1 : 0;
+			ssg_pk2_t pf; pf.w0 = pf.w1 = 0;
+			if (jn) pf = S2V(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
+			const ssg_intv_t okc = ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
+			++my_nx; ++rd_nx;
+			if (pend == S2_PEND_FWD) {
+				bool fwd_end = false;
+				if (okc.x2 != ik.x2) {
+					if (curr_n < scap) S2V(curr, curr_n) = s2_pk(ik); else ovf = 1;
+					++curr_n;
+					if (okc.x2 < min_intv) { S2_FWDEND(); fwd_end = true; }   /* upstream's break: ik stays the last pushed */
+				}
+				if (!fwd_end) { ik = okc; ik.info = (uint64_t)(i + 1); ++i; }
+			} else if (back) {
+				pn = pf;
+				if (okc.x2 < min_intv) { if (curr_n == 0) S2_EMIT(p, i + 1); }
+				else if (curr_n == 0 || okc.x2 != last_x2) {
+					ssg_intv_t o = okc; o.info = p.info;
+					const ssg_pk2_t po = s2_pk(o);
+					if (curr_n == 0) c0 = po;
+					if (curr_n < scap) S2V(curr, curr_n) = po; else ovf = 1;
+					++curr_n; last_x2 = okc.x2;
+				}
+				++j;
+			} else { /* S2_PEND_P3 */
+				if (okc.x2 < (uint64_t)opt.max_mem_intv && i - x >= opt.min_seed_len) {
+					if (okc.x2 > 0) { ssg_intv_t o = okc; o.info = (uint64_t)x << 32 | (uint64_t)(i + 1); if (mem_n < cap) mem[mem_n] = o; else ovf = 1; ++mem_n; }
+					x = i + 1; S2_P3START();
+				} else { ik = okc; ++i; }
+			}
+			pend = S2_PEND_NONE;
+			if (rd_nx > max_ext) state = S2_OUT;   /* given up: the wave-per-read kernel takes the read from its start */
+		}
+	}
+	if (TUNE) S2_STAT_MAX(2, s2_wall());
+#undef S2Q
+#undef S2V
+#undef S2_FWDEND
+#undef S2_P3START
+#undef S2_RET
+#undef S2_EMIT
+	if (n_extend && my_nx) atomicAdd(n_extend, my_nx);
+}
 #endif

@@ -30,6 +30,9 @@ struct ssg_index {
 extern "C" int ssg_index_build_ktab(ssg_index *ix);
 extern "C" int ssg_ktab_launch_smem(const ssg_index *idx, const ssg_mem_opt_t *opt, long n_wg, int block, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                                     ssg_intv_t *d_intv, int32_t *d_n, int cap, ssg_intv_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read);
+/* ssg_seed.cpp: the product's seeding kernel (k_smem2.h) */
+extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off, int max_len, int cap,
+                              ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend, unsigned int max_ext, uint32_t *d_n_ext_read);
 extern "C" int ssg_sa_verify(const ssg_index *ix, int new_intv, const uint64_t *d_sa_new, long n_new);
 
 /* Layout fingerprint of the declarations the translation units of libssgpu share (and that kernels take by value).  Every unit defines

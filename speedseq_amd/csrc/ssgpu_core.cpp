@@ -427,18 +427,21 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
                     int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0, int *need_cap = 0)
 {
 	const int block = 64;
-	const bool quad = !(getenv("SSG_SMEM_KERNEL") && !strcmp(getenv("SSG_SMEM_KERNEL"), "lane"));
+	const char *const kern = getenv("SSG_SMEM_KERNEL") ? getenv("SSG_SMEM_KERNEL") : "smem2";   /* smem2 (product, ssg_seed.cpp) | quad (round 1-3 form) | lane (nested loops as upstream writes them) */
+	const bool quad = strcmp(kern, "lane") != 0;
+	const bool smem2 = quad && strcmp(kern, "quad") != 0 && env_int("SSG_SMEM_LPR", 1) == 1 && idx->ktab_k == 0;
 	/* lanes per read: 1 (each lane fetches whole rank blocks; 64 reads per wave keep the state machine's instruction count per
 	 * extension low) or 4 (quad-cooperative fetch: a quarter of the translation work per line, but 16 reads per wave make the kernel
 	 * VALU-bound).  Measured at the 3.1 Gbp headline size: 154 ms (LPR 1, at the per-lane gather rate of 21 G lines/s) vs 178 ms (LPR 4). */
 	const int lpr = quad ? env_int("SSG_SMEM_LPR", 1) : 1, per_read = lpr;
 	long nthreads = std::min<long>(((long)n_reads * per_read + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64);
 	int scap = max_len + 2;
-	dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap / per_read + 64);
+	dbuf<ssg_intv_t> scratch(smem2 ? 64 : (size_t)nthreads * 3 * scap / per_read + 64);
 	CHKA(scratch);
 	dbuf<unsigned int> d_nextread(1);
 	CHKA(d_nextread); CHK(d_nextread.zero());
-	if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0 SSG_SMQ_EXTRA_ARG);
+	if (smem2) CHK(ssg_seed_smem2(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv, d_n, n_extend, (unsigned int)env_int("SSG_SMEM_MAX_EXT", 0x7fffffff), (uint32_t*)0));
+	else if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0 SSG_SMQ_EXTRA_ARG);
 	else if (quad && idx->ktab_k > 0) CHK(ssg_ktab_launch_smem(idx, opt, nthreads / block, block, n_reads, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p));   /* opt-in table instance, ssg_ktab.cpp */
 	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p SSG_SMQ_EXTRA_ARG);
 	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
