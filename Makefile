@@ -93,3 +93,4 @@ variant: lib
 	  *) cp $(CSRC)/$$u.o build/$(NAME)/$$u.o;; esac; done
 	cp $(CSRC)/sam_format.o build/$(NAME)/sam_format.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC build/$(NAME)/*.o -o speedseq_amd/libssgpu_$(NAME).so -lz
+	rm -rf build/$(NAME)
