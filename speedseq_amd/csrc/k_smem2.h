@@ -16,7 +16,7 @@
  * touch on purpose (the translation unit the kernel sat in, two unused arguments).  The uniform form of the same statements is right in
  * every build that was tried.
  *
- * Per-read budget: a read whose extensions exceed `max_ext' is given up (out_n = -2, nothing of it is kept) and the caller hands it to the
+ * Per-read budget: a read whose extensions exceed `max_ext', or whose forward pass leaves a row of more than `max_row' intervals, is given up (out_n = -2, nothing of it is kept) and the caller hands it to the
  * wave-per-read kernel: a repeat-heavy read costs 10-50x the average, every one of its extensions is a dependent round trip, and a lane
  * that picked one up late used to hold the whole launch open long after the pool of reads had run dry.
  */
@@ -60,16 +60,154 @@ SSG_DEVFN unsigned long long s2_wall() { return (unsigned long long)wall_clock64
 #define SSG_S2_TRIPS 2
 #endif
 
+/* ---- uniform values: every lane of the wave holds the same value; tell the compiler (scalar registers, scalar branches) ---- */
+#ifdef SSG_EMU
+SSG_DEVFN int wv_uni(int v) { return v; }
+SSG_DEVFN uint64_t wv_uni64(uint64_t v) { return v; }
+#else
+SSG_DEVFN int wv_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+SSG_DEVFN uint64_t wv_uni64(uint64_t v) { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32; }
+#endif
+SSG_DEVFN ssg_intv_t wv_uni_intv(const ssg_intv_t &v) { ssg_intv_t o; o.x0 = wv_uni64(v.x0); o.x1 = wv_uni64(v.x1); o.x2 = wv_uni64(v.x2); o.info = wv_uni64(v.info); return o; }
+
+/*
+ * ssg_k_smem_heavy -- one WAVE per read, for the reads the lane kernel gave up (repeat-heavy: thousands of extensions, nearly all of them
+ * in the backward passes of bwt_smem1a, where every entry of a long list is extended by the same base).  The wave walks upstream's
+ * nested loops as written; what is wave-wide is the inner loop of the backward pass: lane l extends entry base + l of the row, and the
+ * row's survivors are appended in list order by ballot + rank.  Upstream appends a survivor when its occurrence count differs from the
+ * last appended one's; along a row the counts are non-decreasing (each entry's pattern is a prefix of the one before it), so that is the
+ * same as `differs from the previous survivor's'.  Of the dead entries only the row's first can be an SMEM (upstream's test on the start of
+ * the call's previous SMEM fails for all the others once it was decided for the first).  The forward extensions and the third pass are
+ * chains of dependent extensions and run uniformly on all lanes (same addresses: one fetch per wave).
+ * SC = list capacity (> longest read + 1), lists and the read in LDS.  ids: the reads to do (positions in the batch), n_ids on the device.
+ */
+/* one read by the whole wave (see ssg_k_smem_heavy); qb: >= 264 bytes of LDS for the read, l0 / l1: two lists of > len + 1 entries in LDS.
+ * Returns the read's extension count (uniform). */
+SSG_DEVFN unsigned long long s2_wave_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const int split_len, const int it, const int32_t *read_ids, const uint8_t *seq, const int64_t *off,
+                                          ssg_intv_t *out_intv, int32_t *out_n, const int cap, uint8_t *qb, ssg_pk2_t *l0, ssg_pk2_t *l1)
+{
+	const int lane = wv_lane();
+	unsigned long long nx = 0;
+	const int r = read_ids ? read_ids[it] : it;
+	const uint8_t *q = seq + off[r];
+	const int len = (int)(off[r+1] - off[r]);
+	ssg_wave_ldssync();
+	for (int b = lane; b < len; b += 64) qb[b] = q[b];
+	ssg_wave_ldssync();
+	ssg_intv_t *const mem = out_intv + (long)it * cap;
+	int mem_n = 0, ovf = 0;
+	/* one call of upstream bwt_smem1a (max_intv = 0): start sx, smallest occurrence count min_intv; returns where the next call starts */
+	auto smem1 = [&](const int sx, uint64_t min_intv) -> int {
+		if (min_intv < 1) min_intv = 1;
+		ssg_intv_t ik; s2_set_intv(ix, (int)qb[sx], ik); ik.info = (uint64_t)(sx + 1);
+		int n = 0, i = sx + 1;
+		bool stop = false;
+		while (!stop && i < len) {   /* forward: the intervals of [sx, i) at every change of the occurrence count, shortest first */
+			const int cq = wv_uni((int)qb[i]);
+			if (cq < 4) {
+				const ssg_intv_t ok = wv_uni_intv(ssg_bwt_extend1_lean(ix, ik, 3 - cq, 0)); ++nx;
+				if (ok.x2 != ik.x2) { l0[n++] = s2_pk(ik); stop = ok.x2 < min_intv; }
+				if (!stop) { ik = ok; ik.info = (uint64_t)(i + 1); ++i; }
+			} else { l0[n++] = s2_pk(ik); stop = true; }
+		}
+		if (!stop) l0[n++] = s2_pk(ik);
+		const int ret = (int)ik.info;
+		int cur = 0, prev_n = n, rev = 1, m1_n = 0, m1_last_beg = 0;
+		bool more = true;
+		for (int ib = sx - 1; more && ib >= -1; --ib) {   /* backward: every interval of the row by the base left of it */
+			const int cb = ib < 0 ? -1 : wv_uni((int)qb[ib]) < 4 ? wv_uni((int)qb[ib]) : -1;
+			int curr_n = 0; bool have_last = false; uint64_t last_x2 = 0;
+			ssg_wave_ldssync();
+			for (int base = 0; base < prev_n; base += 64) {
+				const int jj = base + lane; const bool valid = jj < prev_n;
+				ssg_intv_t p; p.x0 = p.x1 = p.x2 = p.info = 0;
+				if (valid) p = s2_unpk((cur ? l1 : l0)[rev ? prev_n - 1 - jj : jj]);
+				ssg_intv_t okc; okc.x0 = okc.x1 = okc.x2 = okc.info = 0;
+				if (valid && cb >= 0) okc = ssg_bwt_extend1_lean(ix, p, cb, 1);
+				if (cb >= 0) nx += (unsigned long long)(prev_n - base < 64 ? prev_n - base : 64);
+				const bool alive = valid && cb >= 0 && okc.x2 >= min_intv;
+				if (base == 0 && !wv_get((int)alive, 0)) {   /* the row's first entry dies here: an SMEM if it starts left of the call's previous one */
+					const int beg = ib + 1;
+					if (m1_n == 0 || beg < m1_last_beg) {
+						++m1_n; m1_last_beg = beg;
+						const int end0 = wv_get((int)(uint32_t)p.info, 0);
+						if (end0 - beg >= opt.min_seed_len) {
+							if (mem_n < cap) { if (lane == 0) { ssg_intv_t o = p; o.info |= (uint64_t)beg << 32; mem[mem_n] = o; } } else ovf = 1;
+							++mem_n;
+						}
+					}
+				}
+				const unsigned long long am = wv_ballot(alive);
+				if (am) {
+					const unsigned long long below = am & ((1ull << lane) - 1ull);
+					const int pl = below ? 63 - __clzll(below) : 0;
+					const uint64_t px2 = (uint64_t)wv_shfl64_xor((long long)okc.x2, lane ^ pl);   /* okc.x2 of lane pl */
+					const bool push = alive && (below ? okc.x2 != px2 : (!have_last || okc.x2 != last_x2));
+					const unsigned long long pm = wv_ballot(push);
+					if (push) { ssg_intv_t o = okc; o.info = p.info; (cur ? l0 : l1)[curr_n + __popcll(pm & ((1ull << lane) - 1ull))] = s2_pk(o); }
+					curr_n += __popcll(pm);
+					have_last = true; last_x2 = (uint64_t)wv_get64((long long)okc.x2, 63 - __clzll(am));
+				}
+			}
+			if (curr_n == 0) more = false;
+			else { cur ^= 1; rev = 0; prev_n = curr_n; }
+		}
+		ssg_wave_ldssync();
+		return ret;
+	};
+	if (len >= opt.min_seed_len) {
+		int x = 0;
+		while (x < len) { if (wv_uni((int)qb[x]) < 4) x = smem1(x, 1); else ++x; }   /* pass 1 */
+		const int old_n = mem_n < cap ? mem_n : cap;
+		ssg_wave_memsync();
+		for (int k = 0; k < old_n; ++k) {   /* pass 2: re-seed from the middle of long SMEMs with few occurrences */
+			const ssg_intv_t m = wv_uni_intv(mem[k]);
+			const int start = (int)(m.info >> 32), end = (int)(uint32_t)m.info;
+			if (end - start >= split_len && m.x2 <= (uint64_t)opt.split_width) {
+				const int sx = (start + end) >> 1;
+				if (wv_uni((int)qb[sx]) < 4) (void)smem1(sx, m.x2 + 1);
+			}
+		}
+		if (opt.max_mem_intv > 0) {   /* pass 3: upstream bwt_seed_strategy1 from every position it returns */
+			x = 0;
+			while (x < len) {
+				if (wv_uni((int)qb[x]) > 3) ++x;
+				else {
+					ssg_intv_t ik; s2_set_intv(ix, (int)qb[x], ik);
+					int i = x + 1, nxt = len; bool stop = false;
+					while (!stop && i < len) {
+						const int cq = wv_uni((int)qb[i]);
+						if (cq < 4) {
+							const ssg_intv_t ok = wv_uni_intv(ssg_bwt_extend1_lean(ix, ik, 3 - cq, 0)); ++nx;
+							if (ok.x2 < (uint64_t)opt.max_mem_intv && i - x >= opt.min_seed_len) {
+								if (ok.x2 > 0) {
+									if (mem_n < cap) { if (lane == 0) { ssg_intv_t o = ok; o.info = (uint64_t)x << 32 | (uint64_t)(i + 1); mem[mem_n] = o; } } else ovf = 1;
+									++mem_n;
+								}
+								nxt = i + 1; stop = true;
+							} else { ik = ok; ++i; }
+						} else { nxt = i + 1; stop = true; }
+					}
+					x = nxt;
+				}
+			}
+		}
+	}
+	if (lane == 0) out_n[it] = ovf ? -1 : mem_n;
+	return nx;
+}
+
 /*
  * seq: concatenated nt4 codes, off[r]..off[r+1] delimit read r.  out_intv: [n_reads x cap]; out_n: per-read interval count (-1: the
  * per-read capacity or a work list overflowed, -2: given up at max_ext extensions).  scratch: per launched wave 2 lists x scap entries x
  * 64 lanes of 16 bytes, entry e of lane l at [e * 64 + l] (lanes pushing their e-th entries together write one 1-KB span).
  * next_read: shared counter the lanes take their reads from (evens out the per-read cost).  n_ext_read (optional): extensions per read.
+ * heavy_ids / n_heavy (optional): the given-up reads, appended in no particular order, for ssg_k_smem_heavy (launched behind this kernel).
  */
 template <bool TUNE>
 __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_pk2_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, unsigned int max_ext, uint32_t *n_ext_read)
+                           ssg_pk2_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, unsigned int max_ext, int max_row, uint32_t *n_ext_read, int32_t *heavy_ids, unsigned int *n_heavy)
 {
 	__shared__ uint32_t qlds[SSG_S2_QWORDS * 64];
 	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +221,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 	unsigned int rd_nx = 0;          /* extensions of the current read */
 	long it = 0;
 	int state = S2_READ, pend = S2_PEND_NONE;
-	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0;
+	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0, heavy = 0;
 	ssg_intv_t *mem = 0;
 	int sx = 0, i = 0, j = 0, curr_n = 0, prev_n = 0, prev_rev = 0, flip = 0, m1_n = 0, m1_last_beg = 0, ret = 0, e_c = 0;
 	uint64_t min_intv = 1, last_x2 = 0;
@@ -93,7 +231,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 	if (TUNE) S2_STAT_MIN(0, s2_wall());
 	/* transitions done where they arise (no state of their own):
 	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
-#define S2_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = s2_pk(ik); state = S2_BWD; } while (0)
+#define S2_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = s2_pk(ik); state = S2_BWD; if (prev_n > max_row) { heavy = 1; state = S2_OUT; } } while (0)
 	/* next start of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
 #define S2_P3START() do { while (x < len && S2Q(x) > 3) ++x; if (x >= len) state = S2_OUT; else { s2_set_intv(ix, S2Q(x), ik); i = x + 1; state = S2_P3F; } } while (0)
 #define S2_RET() do { if (caller == 1) { x = ret; state = S2_P1; } else { ++k; state = S2_P2; } } while (0)
@@ -133,7 +271,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 					const int r = read_ids ? read_ids[it] : (int)it;
 					const uint8_t *q = seq + off[r];
 					len = (int)(off[r+1] - off[r]);
-					mem = out_intv + (long)it * cap; mem_n = 0; ovf = 0; rd_nx = 0;
+					mem = out_intv + (long)it * cap; mem_n = 0; ovf = 0; rd_nx = 0; heavy = 0;
 					/* the read as 4-bit codes, 8 per LDS word, fetched as aligned 8-byte words, four LDS words per round trip (this runs with few lanes active) */
 					const unsigned al = (unsigned)((uintptr_t)q & 7), sh8 = al << 3;
 					const uint64_t *const qa = (const uint64_t*)(q - al);
@@ -177,8 +315,10 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 			} else if (state == S2_P3) {
 				S2_P3START();
 			} else { /* S2_OUT */
-				const bool given_up = rd_nx > max_ext;
+				const bool given_up = heavy != 0;
 				out_n[it] = given_up ? -2 : ovf ? -1 : mem_n;
+				if (given_up && heavy_ids) heavy_ids[atomicAdd(n_heavy, 1u)] = (int32_t)it;
+				if (given_up) my_nx -= rd_nx;   /* n_extend counts the algorithm's extensions (upstream's own count): the wave kernel counts this read's */
 				if (n_ext_read) n_ext_read[it] = rd_nx;
 				if (TUNE) { S2_STAT_ADD(8 + (64 - __clzll((unsigned long long)(rd_nx | 1u))), 1); if (given_up) S2_STAT_ADD(3, 1); }
 				state = S2_READ;
@@ -222,7 +362,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 				} else { ik = okc; ++i; }
 			}
 			pend = S2_PEND_NONE;
-			if (rd_nx > max_ext) state = S2_OUT;   /* given up: the wave-per-read kernel takes the read from its start */
+			if (rd_nx > max_ext) { heavy = 1; state = S2_OUT; }   /* given up: the wave-per-read kernel takes the read from its start */
 		}
 	}
 	if (TUNE) S2_STAT_MAX(2, s2_wall());
@@ -233,5 +373,22 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 #undef S2_RET
 #undef S2_EMIT
 	if (n_extend && my_nx) atomicAdd(n_extend, my_nx);
+}
+
+template <int SC>
+__global__ void __launch_bounds__(64) ssg_k_smem_heavy(ssg_index_view_t ix, ssg_mem_opt_t opt, const int32_t *ids, const unsigned int *n_ids, const int32_t *read_ids,
+                           const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap, unsigned long long *n_extend, unsigned int *next)
+{
+	__shared__ uint8_t qb[264];
+	__shared__ ssg_pk2_t lst[2][SC];
+	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+	const int n_todo = (int)*n_ids;
+	unsigned long long nx = 0;
+	for (;;) {
+		const long t = wv_queue_pop(next);
+		if (t >= n_todo) break;
+		nx += s2_wave_read(ix, opt, split_len, ids[t], read_ids, seq, off, out_intv, out_n, cap, qb, lst[0], lst[1]);
+	}
+	if (n_extend && nx && wv_lane() == 0) atomicAdd(n_extend, nx);
 }
 #endif

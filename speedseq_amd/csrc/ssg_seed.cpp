@@ -12,6 +12,8 @@
 SSG_ABI_FP_DEFINE(seed)
 #define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+/* rows (interval lists of one backward step) longer than this send a read to the wave-per-read kernel; only with an extension budget */
+static int budget_row(unsigned int max_ext) { return max_ext < 0x7fffffffu ? env_int("SSG_SMEM_MAX_ROW", 32) : 0x7fffffff; }
 
 /* ssg_k_smem2 over all reads: d_n[r] = interval count, -1 (a capacity overflowed) or -2 (given up at max_ext extensions); lists unsorted.
  * SSG_S2_TUNE=1 runs the instrumented instance and prints its launch statistics (tools/dbg/smem_timeline.py reads them). */
@@ -19,12 +21,16 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
                               ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend, unsigned int max_ext, uint32_t *d_n_ext_read)
 {
 	const int block = 64;
-	const long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 4 * SSG_S2_WAVES) * 64);
+	const long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 12) * 64)   /* 12 resident waves per CU measured better than the 16 that fit (round 4: 61.6 -> 58.0 ms) */;
 	const int scap = max_len + 2;
 	dbuf<ssg_pk2_t> scratch((size_t)nthreads * 2 * scap + 64);
-	dbuf<unsigned int> d_next(1);
-	if (!scratch.ok() || !d_next.ok()) { ssg_err_msg = "device allocation failed: seeding work lists"; return SSG_ENOMEM; }
+	dbuf<unsigned int> d_next(4);   /* [0] next read of the lane kernel, [1] reads it gave up, [2] next of those for the wave kernel */
+	const int max_row = budget_row(max_ext);
+	const bool budget = max_ext < 0x7fffffffu;
+	dbuf<int32_t> d_heavy(budget ? (size_t)n_reads : 1);
+	if (!scratch.ok() || !d_next.ok() || !d_heavy.ok()) { ssg_err_msg = "device allocation failed: seeding work lists"; return SSG_ENOMEM; }
 	CHK(d_next.zero());
+	int32_t *const hv = budget ? d_heavy.p : (int32_t*)0;
 	if (env_int("SSG_S2_TUNE", 0)) {
 		unsigned long long st[64]; memset(st, 0, sizeof(st)); st[0] = st[1] = ~0ull;
 #ifdef SSG_EMU
@@ -32,19 +38,24 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
 #else
 		CHK(rt_sync()); CHK(rt_check(hipMemcpyToSymbol(HIP_SYMBOL(ssg_s2_stat), st, sizeof(st)), "hipMemcpyToSymbol"));
 #endif
-		SSG_LAUNCH(ssg_k_smem2<true>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_next.p, max_ext, d_n_ext_read);
+		SSG_LAUNCH(ssg_k_smem2<true>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_next.p, max_ext, max_row, d_n_ext_read, hv, d_next.p + 1);
 		CHK(rt_sync());
 #ifdef SSG_EMU
 		memcpy(st, ssg_s2_stat, sizeof(st));
 #else
 		CHK(rt_check(hipMemcpyFromSymbol(st, HIP_SYMBOL(ssg_s2_stat), sizeof(st)), "hipMemcpyFromSymbol"));
 #endif
-		fprintf(stderr, "[ssgpu] smem2 timeline (ms): pool of reads empty at %.2f, last lane done at %.2f; %llu reads given up at %u extensions; rounds %llu, lanes ready %.1f, with a read %.1f of 64\n",
-		        (double)(st[1] - st[0]) / 1e5, (double)(st[2] - st[0]) / 1e5, st[3], max_ext, st[48], st[48] ? (double)st[49] / st[48] : 0., st[48] ? (double)st[50] / st[48] : 0.);
+		fprintf(stderr, "[ssgpu] smem2 timeline (ms): pool of reads empty at %.2f, last lane done at %.2f; %llu reads given up at %u extensions / rows of %d; rounds %llu, lanes ready %.1f, with a read %.1f of 64\n",
+		        (double)(st[1] - st[0]) / 1e5, (double)(st[2] - st[0]) / 1e5, st[3], max_ext, max_row, st[48], st[48] ? (double)st[49] / st[48] : 0., st[48] ? (double)st[50] / st[48] : 0.);
 		fprintf(stderr, "[ssgpu] smem2 reads by extensions (< 2^b):");
 		for (int b = 1; b <= 24; ++b) if (st[8 + b]) fprintf(stderr, " b%d=%llu", b, st[8 + b]);
 		fprintf(stderr, "\n");
 	} else
-		SSG_LAUNCH(ssg_k_smem2<false>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_next.p, max_ext, d_n_ext_read);
+		SSG_LAUNCH(ssg_k_smem2<false>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_next.p, max_ext, max_row, d_n_ext_read, hv, d_next.p + 1);
+	if (budget) {   /* the given-up reads, a wave each (their number stays on the device: the launch is sized for the chip) */
+		const long n_wg = std::min<long>(n_reads, 256L * env_int("SSG_SMEM_HEAVY_WAVES_PER_CU", 28));
+		if (scap <= 160) SSG_LAUNCH(ssg_k_smem_heavy<160>, n_wg, block, 0, idx->v, *opt, (const int32_t*)d_heavy.p, (const unsigned int*)(d_next.p + 1), (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, n_extend, d_next.p + 2);
+		else SSG_LAUNCH(ssg_k_smem_heavy<264>, n_wg, block, 0, idx->v, *opt, (const int32_t*)d_heavy.p, (const unsigned int*)(d_next.p + 1), (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, n_extend, d_next.p + 2);
+	}
 	return rt_sync();
 }

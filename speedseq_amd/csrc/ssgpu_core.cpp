@@ -440,7 +440,7 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	CHKA(scratch);
 	dbuf<unsigned int> d_nextread(1);
 	CHKA(d_nextread); CHK(d_nextread.zero());
-	if (smem2) CHK(ssg_seed_smem2(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv, d_n, n_extend, (unsigned int)env_int("SSG_SMEM_MAX_EXT", 0x7fffffff), (uint32_t*)0));
+	if (smem2) CHK(ssg_seed_smem2(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv, d_n, n_extend, (unsigned int)env_int("SSG_SMEM_MAX_EXT", 13 * max_len + 50), (uint32_t*)0));   /* 2000 at 150 bases: 1.8 % of the bench's reads go to the wave-per-read kernel (k_smem2.h) */
 	else if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0 SSG_SMQ_EXTRA_ARG);
 	else if (quad && idx->ktab_k > 0) CHK(ssg_ktab_launch_smem(idx, opt, nthreads / block, block, n_reads, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p));   /* opt-in table instance, ssg_ktab.cpp */
 	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p SSG_SMQ_EXTRA_ARG);

@@ -138,11 +138,16 @@ def check_global(lib, oracle, n, seed):
         assert osc == sc[i] and on == nc[i] and np.array_equal(ocg[:on], cg[i, :on]), (i, jobs[i])
 
 
-def check_smem(lib, oracle, n_pairs, seed, read_len=150):
-    prefix = EXAMPLE_FA
+def check_smem(lib, oracle, n_pairs, seed, read_len=150, prefix=EXAMPLE_FA, n_frac=0.0, cap=96):
+    """seeding intervals (upstream mem_collect_intv) of every read against the oracle; n_frac: share of the bases turned into N"""
     oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
-    _, seqs, seq, off = sim_reads(n_pairs, seed, read_len)
-    intv, cnt = lib.smem_batch(gidx, lib.opt_init(), seq, off, cap=96)
+    _, seqs, seq, off = sim_reads(n_pairs, seed, read_len, fasta=prefix)
+    if n_frac > 0:
+        rng = np.random.RandomState(seed)
+        seq = seq.copy()
+        seq[rng.random_sample(seq.size) < n_frac] = 4
+        seqs = [seq[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    intv, cnt = lib.smem_batch(gidx, lib.opt_init(), seq, off, cap=cap)
     for r, s in enumerate(seqs):
         o = oracle.collect_intv(oidx, s)
         assert len(o) == cnt[r] and np.array_equal(o, intv[r, :cnt[r]]), r

@@ -111,7 +111,26 @@ def test_gpu_pair_wave_kernel_forced(gpu_lib, oracle, repeat_pe_prefix, monkeypa
     common.check_pe_sam(gpu_lib, oracle, 600, seed=8, prefix=repeat_pe_prefix)
 
 
+def test_gpu_smem_budget_and_wave_kernel(gpu_lib, oracle, repeat_prefix, monkeypatch):
+    # extension budget of the lane kernel: given-up reads are redone by the wave-per-read kernel (k_smem2.h)
+    monkeypatch.setenv("SSG_SMEM_MAX_EXT", "1")        # every read given up at once: the wave kernel does them all, both list classes
+    common.check_smem(gpu_lib, oracle, 1500, seed=41)
+    common.check_smem(gpu_lib, oracle, 500, seed=42, read_len=250)
+    common.check_smem(gpu_lib, oracle, 500, seed=44, n_frac=0.02)
+    common.check_smem(gpu_lib, oracle, 40, seed=43, prefix=repeat_prefix, cap=512)
+    monkeypatch.setenv("SSG_SMEM_MAX_EXT", "700")      # some of each
+    monkeypatch.setenv("SSG_SMEM_MAX_ROW", "18")       # ... and reads whose first row is longer than this
+    common.check_smem(gpu_lib, oracle, 1500, seed=41)
+    common.check_smem(gpu_lib, oracle, 40, seed=43, prefix=repeat_prefix, cap=512)
+    monkeypatch.setenv("SSG_SMEM_MAX_EXT", "2147483647")   # no budget: the lane kernel alone, also on ambiguous bases and repeats
+    common.check_smem(gpu_lib, oracle, 500, seed=44, n_frac=0.02)
+    common.check_smem(gpu_lib, oracle, 40, seed=43, prefix=repeat_prefix, cap=512)
+
+
 def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
+    monkeypatch.setenv("SSG_SMEM_KERNEL", "quad")     # the round 1-3 form
+    common.check_smem(gpu_lib, oracle, 1500, seed=31)
+    monkeypatch.delenv("SSG_SMEM_KERNEL")
     # the quad-cooperative form and the nested-loop form, on the same reads (default: lane per read, lean per-lane fetch)
     monkeypatch.setenv("SSG_SMEM_LPR", "4")
     common.check_smem(gpu_lib, oracle, 1500, seed=31)

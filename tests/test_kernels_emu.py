@@ -101,7 +101,25 @@ def test_emu_pair_wave_kernel_forced(emu_lib, oracle, repeat_pe_prefix, monkeypa
     common.check_pe_sam(emu_lib, oracle, 120, seed=8, prefix=repeat_pe_prefix)
 
 
+def test_emu_smem_budget_and_wave_kernel(emu_lib, oracle, repeat_prefix, monkeypatch):
+    # extension budget of the lane kernel: given-up reads are redone by the wave-per-read kernel (k_smem2.h)
+    monkeypatch.setenv("SSG_SMEM_MAX_EXT", "1")        # every read given up at once: the wave kernel does them all, both list classes
+    common.check_smem(emu_lib, oracle, 60, seed=41)
+    common.check_smem(emu_lib, oracle, 30, seed=42, read_len=250)
+    common.check_smem(emu_lib, oracle, 40, seed=44, n_frac=0.02)
+    common.check_smem(emu_lib, oracle, 8, seed=43, prefix=repeat_prefix, cap=512)
+    monkeypatch.setenv("SSG_SMEM_MAX_EXT", "700")      # some of each
+    monkeypatch.setenv("SSG_SMEM_MAX_ROW", "18")       # ... and reads whose first row is longer than this
+    common.check_smem(emu_lib, oracle, 60, seed=41)
+    common.check_smem(emu_lib, oracle, 8, seed=43, prefix=repeat_prefix, cap=512)
+    monkeypatch.setenv("SSG_SMEM_MAX_EXT", "2147483647")   # no budget: the lane kernel alone, also on ambiguous bases and repeats
+    common.check_smem(emu_lib, oracle, 40, seed=44, n_frac=0.02)
+    common.check_smem(emu_lib, oracle, 8, seed=43, prefix=repeat_prefix, cap=512)
+
+
 def test_emu_smem_kernel_variants(emu_lib, oracle, monkeypatch):
+    monkeypatch.setenv("SSG_SMEM_KERNEL", "quad")     # the round 1-3 form
+    common.check_smem(emu_lib, oracle, 150, seed=31)
     monkeypatch.setenv("SSG_SMEM_LPR", "4")
     common.check_smem(emu_lib, oracle, 150, seed=31)
     monkeypatch.delenv("SSG_SMEM_LPR")
