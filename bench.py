@@ -616,24 +616,37 @@ def main():
                 # per chain: both read sides + their 2-bit windows + 40-byte job + 2 x 32-byte results
                 "ssg_k_ext_lane<136>": float(summary[7]) * (rl + (rl + 140) / 4.0 + 104) if len(summary) > 7 and summary[7] else 0.0,
             }
-            smk = next((k for k in kern if k.startswith("ssg_k_smem") and not k.startswith("ssg_k_smem_sort")), None)   # ssg_k_smem_quad<4> / <1> / ssg_k_smem_lane
+            # the seeding stage (rows a1-a2) is the HBM-bound part of the step -- random 64-byte rank blocks -- and the one the roofline line is about:
+            # since round 4 it is two launches, the lane-per-read kernel and the wave-per-read kernel for the reads it gives up (k_smem2.h); the
+            # algorithmic bytes are upstream's own count of bwt_extend calls x 2 rank blocks, whoever ran them.  The largest SINGLE kernel by
+            # time is named in `largest_kernel`: when that is the mate-rescue Smith-Waterman, an on-chip integer DP, neither an HBM nor an MFMA
+            # roofline applies to it and its figure of merit is the VALU issue fraction in `sw`.
+            seed_k = sorted(k for k in kern if k.startswith(("ssg_k_smem2", "ssg_k_smem_heavy", "ssg_k_smem_quad", "ssg_k_smem_lane")))
+            smk = " + ".join(seed_k) if seed_k else None
+            seed_ms = sum(kern[k][0] for k in seed_k) / a.steps if seed_k else 0.0
+            alg_seed = alg_bytes.pop("ssg_k_smem_quad")
             if smk:
-                alg_bytes[smk] = alg_bytes.pop("ssg_k_smem_quad")
+                alg_bytes[smk] = alg_seed
+                kern[smk] = (seed_ms * a.steps, a.steps)
+            largest = name
+            name, per_launch_ms = (smk, seed_ms) if smk else (name, per_launch_ms)
             alg = alg_bytes.get(name, 0.0)
             ach = alg / (per_launch_ms * 1e-3) / 1e9
             # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
             # tools/profile_round.sh; units calibrated on the random-gather probe): read from the committed summary when it was
-            # taken on this workload, otherwise null -- never a constant in this file
+            # taken on this workload with these kernels, otherwise null -- never a constant in this file
             traffic = None
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                if pm.get("pairs") == a.pairs and pm.get("read_len") == rl and abs(pm.get("ref_mbp", 0) - a.ref_mbp) < 1e-6:
-                    traffic = pm.get("bytes_per_launch", {}).get(name)
-            except Exception:
-                pass
+            for tag in ("r04", "r02"):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
+                    if pm.get("pairs") == a.pairs and pm.get("read_len") == rl and abs(pm.get("ref_mbp", 0) - a.ref_mbp) < 1e-6 and seed_k and all(k in pm.get("bytes_per_launch", {}) for k in seed_k):
+                        traffic = sum(pm["bytes_per_launch"][k] for k in seed_k)
+                        break
+                except Exception:
+                    pass
             valu = {}; sw_lane_ops = None
             try:   # fraction of the measured int32 VALU issue peak (tools/dbg/valu_probe) from the committed SQ counter pass of this workload
-                pq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+                pq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_sq.json")) else "r02_pmc_sq.json")))
                 valu = {k: round(v["valu_frac_of_probe_peak"], 3) for k, v in pq["kernels"].items() if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_smem")) and "valu_frac_of_probe_peak" in v and not k.endswith("_need")}
                 # vector instructions of the SW kernels per step (committed counters of the same kernels' code: the ISA is pinned) x 64 lanes
                 pmc_steps = max(1, pq["kernels"].get("ssg_k_matesw", {}).get("launches", 1))   # one mate-rescue launch per step of the counter run
@@ -643,9 +656,9 @@ def main():
                 pass
             sw_names = [k for k in kern if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need")]
             sw_ms = sum(kern[k][0] for k in sw_names) / a.steps
-            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+            out["roofline"] = {"bound": "hbm", "kernel": name, "largest_kernel": {"name": largest, "ms_per_launch": kern[largest][0] / kern[largest][1]}, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                                "ms_per_launch": per_launch_ms,
-                               "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
+                               "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0]) if k != smk or len(seed_k) == 1},
                                "hbm_gbps_by_kernel": {k: round(alg_bytes[k] / (kern[k][0] / kern[k][1] * 1e-3) / 1e9, 1) for k in alg_bytes if k in kern},
                                # FM-index kernels read random 64-byte lines: measured MI355X gather peak (tools/dbg/gather_probe.cpp)
                                "random64B": {"kernel": smk, "peak_glines_per_s": 55.0, "peak_gbps": 3520.0,
@@ -654,7 +667,7 @@ def main():
                                "sw": {"cells_per_step": int(summary[3]) + int(summary[4]), "kernels": sorted(sw_names),
                                       "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None,
                                       "lane_ops_per_cell": (sw_lane_ops / (int(summary[3]) + int(summary[4]))) if sw_lane_ops and (int(summary[3]) + int(summary[4])) else None,   # SQ_INSTS_VALU x 64 of the SW kernels (committed counters, pinned ISA) over this run's DP cells
-                                      "valu_frac": valu or None, "valu_frac_source": "profiles/r02_pmc_sq.json (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
+                                      "valu_frac": valu or None, "valu_frac_source": "profiles/r04_pmc_sq.json if present, else r02 (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
         # ---- parity gate ON THE TIMED CALL + CPU baseline: the step is run once more on the same device-resident inputs with its records
         # kept in HBM (identical inputs -> identical records; the summaries are compared), the records and samblaster's per-line decisions
         # are downloaded, and the oracle (scalar C restatement of bwa mem + samblaster) aligns the same pairs in the same upstream batches ----

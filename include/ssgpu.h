@@ -94,6 +94,19 @@ int ssg_global_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_glb_job_t *
 int ssg_smem_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
                    int cap, ssg_intv_t *out_intv, int32_t *out_n);
 
+/* Seeds of a batch of reads in upstream's visiting order (mem_chain(): for every interval of mem_collect_intv, every sampled occurrence:
+ * bwt_sa() + bns_intv2rid(); rows a1-a3), before chaining.  seed_off[n_reads + 1]; *seeds and *rids (bns_intv2rid per seed, < 0 = a seed
+ * upstream drops) are malloc'd by the library (ssg_free). */
+int ssg_seeds_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
+                    int64_t *seed_off, ssg_seed_t **seeds, int32_t **rids);
+
+/* upstream ksw_extend2() through the LANE-per-extension kernel code the product's mem_chain2aln path runs (k_extlane.h; ssg_extend_batch
+ * above goes through the wave-per-extension code): job i's target is jobs[i].tlen bases from doubled coordinate tpos[i] of the index's
+ * 2-bit reference in direction dir (+1 / -1; jobs[i].toff is ignored), its query qbuf[qoff .. qoff + qlen).  qcap selects the kernel
+ * instance (72 / 136 / 256 columns of LDS per lane; every qlen must fit).  Limits of the packed DP cells: h0 + qlen * a < 8191. */
+int ssg_extend_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_jobs, const ssg_ext_job_t *jobs, const int64_t *tpos, int dir,
+                          const uint8_t *qbuf, size_t qbytes, int qcap, ssg_ext_res_t *res, uint64_t *cells);
+
 /* upstream mem_align1_core() (bwamem.c; rows a1-a8) for a batch of reads: SMEM -> SAL -> chain ->
  * filter -> extend -> sort/dedup/patch.  reg_off[n_reads+1] and regs (malloc'd by the library,
  * release with ssg_free) receive each read's mem_alnreg_t list in upstream order. */

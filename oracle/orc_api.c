@@ -35,6 +35,30 @@ int orc_api_collect_intv(const orc_opt_t *opt, const orc_idx_t *idx, int len, co
 	return n;
 }
 
+/* the seeds mem_chain() visits for one read, in its order, before chaining (upstream bwamem.c mem_chain: for every interval of mem_collect_intv,
+ * step = x[2] > max_occ ? x[2] / max_occ : 1, occurrences k = 0, step, ... while count < max_occ; rbeg = bwt_sa(x[0] + k); rid = bns_intv2rid,
+ * seeds with rid < 0 are dropped by upstream and reported here with their rid).  out: 4 values per seed (rbeg, qbeg, len, rid).  Returns the count. */
+int64_t orc_api_seeds(const orc_opt_t *opt, const orc_idx_t *idx, int len, const uint8_t *seq, int64_t *out, int64_t cap)
+{
+	orc_intv_v mem = {0,0,0};
+	int64_t n = 0;
+	if (len < opt->min_seed_len) return 0;
+	orc_collect_intv(opt, idx->bwt, len, seq, &mem);
+	for (size_t i = 0; i < mem.n; ++i) {
+		const orc_intv_t *p = &mem.a[i];
+		const int slen = (int)((uint32_t)p->info - (uint32_t)(p->info >> 32));
+		const int64_t step = p->x[2] > (uint64_t)opt->max_occ ? (int64_t)(p->x[2] / opt->max_occ) : 1;
+		int count = 0;
+		for (int64_t k = 0; k < (int64_t)p->x[2] && count < opt->max_occ; k += step, ++count, ++n) {
+			if (n >= cap) continue;
+			const int64_t rbeg = (int64_t)orc_bwt_sa(idx->bwt, p->x[0] + k);
+			out[4 * n] = rbeg; out[4 * n + 1] = (int64_t)(p->info >> 32); out[4 * n + 2] = slen; out[4 * n + 3] = orc_bns_intv2rid(idx->bns, rbeg, rbeg + slen);
+		}
+	}
+	free(mem.a);
+	return n;
+}
+
 /* mem_align1_core for a batch of reads; regs are appended to out (cap entries); reg_off[n+1] */
 int64_t orc_api_align1_batch(const orc_opt_t *opt, const orc_idx_t *idx, int n_reads, const uint8_t *seq, const int64_t *off,
                              int64_t *reg_off, orc_flatreg_t *out, int64_t cap)

@@ -26,6 +26,7 @@ OPT_DT = np.dtype([
     ("mat", "i1", (25,)), ("_pad", "i1", (7,)),
 ], align=False)
 INTV_DT = np.dtype([("x0", "u8"), ("x1", "u8"), ("x2", "u8"), ("info", "u8")])
+SEED_DT = np.dtype([("rbeg", "i8"), ("qbeg", "i4"), ("len", "i4"), ("score", "i4"), ("next", "i4")])
 EXT_JOB_DT = np.dtype([("qoff", "i4"), ("qlen", "i4"), ("toff", "i4"), ("tlen", "i4"), ("w", "i4"), ("end_bonus", "i4"), ("zdrop", "i4"), ("h0", "i4")])
 EXT_RES_DT = np.dtype([("score", "i4"), ("qle", "i4"), ("tle", "i4"), ("gtle", "i4"), ("gscore", "i4"), ("max_off", "i4")])
 SW_JOB_DT = np.dtype([("qoff", "i4"), ("qlen", "i4"), ("toff", "i4"), ("tlen", "i4"), ("xtra", "i4"), ("_pad", "i4")])
@@ -140,6 +141,25 @@ class Lib:
         cnt = np.zeros(n, dtype=np.int32)
         self._chk(self.l.ssg_smem_batch(idx, _ptr(opt), C.c_int(n), _ptr(seq), _ptr(off), C.c_int(cap), _ptr(intv), _ptr(cnt)))
         return intv, cnt
+
+    def seeds_batch(self, idx, opt, seq, off):
+        """seeds of every read before chaining: (seed_off, seeds[rbeg qbeg len score next], rids)"""
+        n = len(off) - 1
+        seed_off = np.zeros(n + 1, dtype=np.int64)
+        sp, rp = C.c_void_p(), C.c_void_p()
+        self._chk(self.l.ssg_seeds_batch(idx, _ptr(opt), C.c_int(n), _ptr(seq), _ptr(off), _ptr(seed_off), C.byref(sp), C.byref(rp)))
+        tot = int(seed_off[n])
+        seeds = np.frombuffer((C.c_char * (tot * SEED_DT.itemsize)).from_address(sp.value), dtype=SEED_DT, count=tot).copy() if tot else np.zeros(0, SEED_DT)
+        rids = np.frombuffer((C.c_char * (tot * 4)).from_address(rp.value), dtype=np.int32, count=tot).copy() if tot else np.zeros(0, np.int32)
+        self.l.ssg_free(sp); self.l.ssg_free(rp)
+        return seed_off, seeds, rids
+
+    def extend_lane_batch(self, idx, opt, jobs, tpos, direction, qbuf, qcap):
+        res = np.zeros(len(jobs), dtype=EXT_RES_DT)
+        cells = C.c_uint64(0)
+        tpos = np.ascontiguousarray(tpos, dtype=np.int64)
+        self._chk(self.l.ssg_extend_lane_batch(idx, _ptr(opt), C.c_int(len(jobs)), _ptr(jobs), _ptr(tpos), C.c_int(direction), _ptr(qbuf), C.c_size_t(qbuf.size), C.c_int(qcap), _ptr(res), C.byref(cells)))
+        return res, cells.value
 
     def align1_batch(self, idx, opt, seq, off):
         n = len(off) - 1

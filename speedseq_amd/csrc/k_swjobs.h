@@ -5,6 +5,7 @@
 #ifndef SSG_K_SWJOBS_H
 #define SSG_K_SWJOBS_H
 #include "k_sw.h"
+#include "k_extlane.h"
 
 __global__ void __launch_bounds__(256) ssg_k_align2_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_sw_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,
                                   ssg_kswr_t *res, unsigned long long *bscratch, int bstride)
@@ -15,6 +16,28 @@ __global__ void __launch_bounds__(256) ssg_k_align2_jobs(ssg_mem_opt_t opt, int 
 	ssg_seqv_t q = { qbuf + jb.qoff, 1 }, t = { tbuf + jb.toff, 1 };
 	ssg_kswr_t r = wv_align2(opt, jb.qlen, q, jb.tlen, t, jb.xtra, bscratch + wid * (long)bstride, 0);
 	if (wv_lane() == 0) res[wid] = r;
+}
+
+/* Stage-level twin of ssg_k_ext_lane (row a7, the kernel that runs mem_chain2aln's ksw_extend2 calls in the product path): one LANE per
+ * job through the same ln_extend2 -- DP row in LDS words (13-bit h / e, 6-bit score table), target bases from a 2-bit pac.  A job's
+ * target is `tlen' bases of the doubled coordinate system of the pac in `ix' from position toff in direction `dir' (+1 / -1), as the
+ * product's left / right extensions read them; the query is qbuf[qoff .. qoff + qlen). */
+template <int QCAP>
+__global__ void __launch_bounds__(64) ssg_k_ext_lane_jobs(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_jobs, const ssg_ext_job_t *jobs, const int64_t *tpos, int dir,
+                                  const uint8_t *qbuf, ssg_ext_res_t *res, unsigned long long *cells)
+{
+	constexpr int U = QCAP > 72 ? 4 : 2;
+	__shared__ uint32_t L[(QCAP + 2 * U) * 64];
+	const long g = (long)blockIdx.x * 64 + threadIdx.x;
+	if (g >= n_jobs) return;
+	const ssg_ext_job_t jb = jobs[g];
+	uint32_t *Lc = L + (threadIdx.x & 63);
+	if (jb.qlen > QCAP) return;
+	for (int j = 0; j < jb.qlen; ++j) Lc[j * 64] = SSG_XL_QWORD(qbuf[jb.qoff + j]);
+	Lc[jb.qlen * 64] = 0;
+	unsigned long long nc = 0;
+	res[g] = ln_extend2<U>(opt, ix, Lc, jb.qlen, jb.tlen, tpos[g], dir, jb.w, jb.end_bonus, jb.zdrop, jb.h0, &nc);
+	if (cells && nc) atomicAdd(cells, nc);
 }
 
 __global__ void __launch_bounds__(256) ssg_k_global_jobs(ssg_mem_opt_t opt, int n_jobs, const ssg_glb_job_t *jobs, const uint8_t *qbuf, const uint8_t *tbuf,

@@ -173,7 +173,8 @@ void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, con
 	if (m && m->rid < 0 && rid >= 0) { m->rid = rid; m->pos = pos; m->is_rev = is_rev; m->n_cigar = 0; }
 	flag |= is_rev ? 0x10 : 0;
 	flag |= m && m->is_rev ? 0x20 : 0;
-	flag = (flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0);
+	/* flag 0x10000 (upstream -M: a supplementary line shown as secondary) becomes 0x100 only in the stored FLAG; the SEQ / QUAL / SA decisions below
+	 * test the raw flag, as mem_aln2sam and the text path (aln2sam above) do */
 	const size_t base = out.b.size();
 	out.b.resize(base + 36);
 	const size_t l_qname = strlen(name) + 1;
@@ -245,7 +246,7 @@ void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, con
 	uint32_t x[9];
 	x[0] = (uint32_t)(out.b.size() - base - 4);
 	x[1] = (uint32_t)tid; x[2] = (uint32_t)bpos; x[3] = (uint32_t)bin << 16 | (uint32_t)(mapq & 0xff) << 8 | (uint32_t)l_qname;
-	x[4] = (uint32_t)flag << 16 | (uint32_t)n_cigar; x[5] = (uint32_t)l_qseq; x[6] = (uint32_t)mtid; x[7] = (uint32_t)mpos; x[8] = (uint32_t)isize;
+	x[4] = (uint32_t)((flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)) << 16 | (uint32_t)n_cigar; x[5] = (uint32_t)l_qseq; x[6] = (uint32_t)mtid; x[7] = (uint32_t)mpos; x[8] = (uint32_t)isize;
 	memcpy(out.b.data() + base, x, 36);
 }
 } // namespace

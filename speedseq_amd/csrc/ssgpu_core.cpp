@@ -378,6 +378,33 @@ int ssg_extend_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_ext_job_t *
 	return 0;
 }
 
+int ssg_extend_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_jobs, const ssg_ext_job_t *jobs, const int64_t *tpos, int dir,
+                          const uint8_t *qbuf, size_t qbytes, int qcap, ssg_ext_res_t *res, uint64_t *cells)
+{
+	CHK(need_device());
+	if (n_jobs <= 0) return 0;
+	if (qcap != 72 && qcap != 136 && qcap != 256) { ssg_err_msg = "ssg_extend_lane_batch: qcap is 72, 136 or 256"; return SSG_EINVAL; }
+	if (dir != 1 && dir != -1) { ssg_err_msg = "ssg_extend_lane_batch: dir is +1 or -1"; return SSG_EINVAL; }
+	for (int i = 0; i < n_jobs; ++i) {
+		if (jobs[i].qlen > std::min(qcap, 254) || jobs[i].qlen < 0 || jobs[i].h0 <= 0 || jobs[i].tlen < 0) { ssg_err_msg = "ssg_extend_lane_batch: 0 <= qlen <= min(qcap, 254), h0 > 0, tlen >= 0"; return SSG_EINVAL; }
+		if ((long)jobs[i].h0 + (long)jobs[i].qlen * opt->a + std::max(jobs[i].end_bonus, 0) >= 8191) { ssg_err_msg = "ssg_extend_lane_batch: h0 + qlen * a exceeds the 13-bit DP cells"; return SSG_EINVAL; }
+		const int64_t last = tpos[i] + (int64_t)dir * (jobs[i].tlen - 1);
+		if (jobs[i].tlen > 0 && (tpos[i] < 0 || tpos[i] >= 2 * idx->v.l_pac || last < 0 || last >= 2 * idx->v.l_pac || (tpos[i] < idx->v.l_pac) != (last < idx->v.l_pac))) {
+			ssg_err_msg = "ssg_extend_lane_batch: a target leaves its strand of the doubled reference"; return SSG_EINVAL; }
+	}
+	dbuf<ssg_ext_job_t> dj(n_jobs); dbuf<int64_t> dp(n_jobs); dbuf<uint8_t> dq(qbytes + 1); dbuf<ssg_ext_res_t> dr(n_jobs); dbuf<unsigned long long> dc(1);
+	CHKA(dj); CHKA(dp); CHKA(dq); CHKA(dr); CHKA(dc);
+	CHK(dj.up(jobs, n_jobs)); CHK(dp.up(tpos, n_jobs)); CHK(dq.up(qbuf, qbytes)); CHK(dc.zero()); CHK(dr.zero());
+	const long nb = (n_jobs + 63) / 64;
+	if (qcap == 72) SSG_LAUNCH(ssg_k_ext_lane_jobs<72>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
+	else if (qcap == 136) SSG_LAUNCH(ssg_k_ext_lane_jobs<136>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
+	else SSG_LAUNCH(ssg_k_ext_lane_jobs<256>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
+	CHK(rt_sync());
+	CHK(dr.down(res, n_jobs));
+	if (cells) { unsigned long long c; CHK(dc.down(&c, 1)); *cells = c; }
+	return 0;
+}
+
 int ssg_align2_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *jobs, const uint8_t *qbuf, size_t qbytes,
                      const uint8_t *tbuf, size_t tbytes, ssg_kswr_t *res)
 {
@@ -748,6 +775,38 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_err.p, n_reads, 0, 0, 0, cc)); if (cc[4]) { ssg_err_msg = "reference window of a chain exceeds SSG_TWIN_GLB"; return SSG_EOVERFLOW; } }
 	if (stats) { unsigned long long c; CHK(d_cells.down(&c, 1)); stats[0] = (uint64_t)tot; stats[1] = c; stats[6] = (uint64_t)n_jobs; }
 	return 0;
+}
+
+int ssg_seeds_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,
+                    int64_t *seed_off, ssg_seed_t **seeds, int32_t **rids)
+{
+	CHK(need_device());
+	*seeds = 0; *rids = 0;
+	if (n_reads <= 0) { if (seed_off) seed_off[0] = 0; return 0; }
+	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
+	if (max_len > SSG_MAX_READ_LEN) { ssg_err_msg = "reads longer than " SSG_STR(SSG_MAX_READ_LEN) " bases are outside this build's scope"; return SSG_EINVAL; }
+	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1), d_soff(n_reads + 1); dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
+	CHKA(d_seq); CHKA(d_off); CHKA(d_soff); CHKA(d_nintv); CHKA(d_nseed);
+	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1));
+	dbuf<ssg_intv_t> d_intv;
+	for (int cap = std::max(64, max_len / 2); ; ) {   /* the dense interval layout widens itself, as in run_align1 */
+		int need = 0;
+		if (!d_intv.alloc((size_t)n_reads * cap)) { ssg_err_msg = "device allocation failed: d_intv"; return SSG_ENOMEM; }
+		CHK(run_smem(idx, opt, n_reads, d_seq.p, d_off.p, max_len, cap, d_intv.p, d_nintv.p, 0, &need));
+		if (need > cap) { cap = (need + 31) / 32 * 32; continue; }
+		SSG_LAUNCH(ssg_k_sal_count, (n_reads + 255) / 256, 256, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);
+		int64_t tot = 0;
+		CHK(dev_exclusive_scan(d_nseed.p, d_soff.p, n_reads, &tot));
+		dbuf<ssg_seed_t> d_seeds((size_t)tot + 1); dbuf<int32_t> d_srid((size_t)tot + 1);
+		CHKA(d_seeds); CHKA(d_srid);
+		if (tot > 0) SSG_LAUNCH(ssg_k_sal, (tot + 255) / 256, 256, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_soff.p, d_seeds.p, d_srid.p);
+		CHK(rt_sync());
+		CHK(d_soff.down(seed_off, (size_t)n_reads + 1));
+		*seeds = (ssg_seed_t*)malloc(sizeof(ssg_seed_t) * (size_t)(tot + 1)); *rids = (int32_t*)malloc(4 * (size_t)(tot + 1));
+		if (!*seeds || !*rids) { free(*seeds); free(*rids); *seeds = 0; *rids = 0; ssg_err_msg = "host allocation failed"; return SSG_ENOMEM; }
+		CHK(d_seeds.down(*seeds, (size_t)tot)); CHK(d_srid.down(*rids, (size_t)tot));
+		return 0;
+	}
 }
 
 int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off,

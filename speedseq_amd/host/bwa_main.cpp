@@ -199,8 +199,17 @@ static int main_mem(int argc, char **argv)
 	/* aligned batches wait here for their turn: the formatter takes them in input order whichever device finished first */
 	struct reorder_t {
 		std::mutex mu; std::condition_variable cv; std::map<int64_t, std::unique_ptr<batch_t> > ready; int64_t next; int open_workers; size_t cap;
-		reorder_t(int w, size_t c) : next(0), open_workers(w), cap(c) {}
-		void put(std::unique_ptr<batch_t> B) { std::unique_lock<std::mutex> l(mu); const int64_t s = B->seqno; cv.wait(l, [&] { return s == next || ready.size() < cap; }); ready[s] = std::move(B); cv.notify_all(); }
+		const std::atomic<int> *failed;
+		reorder_t(int w, size_t c, const std::atomic<int> *f) : next(0), open_workers(w), cap(c), failed(f) {}
+		/* once the run has failed the batch the buffer is waiting for may never come (its worker gave up): a worker must not wait for room then,
+		 * or it never reports itself done and the formatters wait for it for ever.  `fail' is raised in many places without this lock, hence the timed wait. */
+		void put(std::unique_ptr<batch_t> B)
+		{
+			std::unique_lock<std::mutex> l(mu); const int64_t s = B->seqno;
+			while (!(s == next || ready.size() < cap || failed->load())) cv.wait_for(l, std::chrono::milliseconds(50));
+			if (failed->load() && !(s == next || ready.size() < cap)) { if (B->res) ssg_pe_result_free(B->res); return; }
+			ready[s] = std::move(B); cv.notify_all();
+		}
 		void worker_done() { std::lock_guard<std::mutex> l(mu); --open_workers; cv.notify_all(); }
 		bool take(std::unique_ptr<batch_t> &B)
 		{
@@ -212,7 +221,7 @@ static int main_mem(int argc, char **argv)
 			}
 			B = std::move(ready.begin()->second); ready.erase(ready.begin()); ++next; cv.notify_all(); return true;
 		}
-	} to_fmt(n_work, (size_t)n_work + 1);
+	} to_fmt(n_work, (size_t)n_work + 1, &fail);
 	double tm_asm = 0; std::vector<double> tm_gpu((size_t)n_dev, 0.0); std::vector<long> calls((size_t)n_dev, 0);
 	std::thread t_asm([&]() {
 		fq_cursor_t c1(feed1); std::unique_ptr<fq_cursor_t> c2(feed2 ? new fq_cursor_t(*feed2) : 0);

@@ -40,10 +40,10 @@ struct fast_gz_t {
 	std::vector<uint32_t> tl, td;                          /* litlen / dist tables (primary + sub-tables) */
 	uint32_t crc_expect, isize_expect; uint64_t member_out; bool member_done;   /* set when a member's trailer has been read */
 	const char *err;
-	bool strict; int last_left;                            /* strict: a dynamic block header must describe complete codes (the block-boundary search of fast_inflate_mt.h) */
+	bool strict; int last_left, last_maxl;                            /* strict: a dynamic block header must describe complete codes (the block-boundary search of fast_inflate_mt.h) */
 
 	explicit fast_gz_t(int fd_) : fd(fd_), eof_in(false), ib(0), ip(0), iend(0), ireal(0), bitbuf(0), bitcnt(0), op(WIN), obase(WIN), st(S_HEADER), last_block(false),
-		stored_left(0), crc_expect(0), isize_expect(0), member_out(0), member_done(false), err(0), strict(false), last_left(0)
+		stored_left(0), crc_expect(0), isize_expect(0), member_out(0), member_done(false), err(0), strict(false), last_left(0), last_maxl(0)
 	{ if (fd >= 0) ibuf.resize((size_t)4 << 20); ib = ibuf.data(); tl.resize(((size_t)1 << PB_LIT) + 2048); td.resize(((size_t)1 << PB_DIST) + 2048); }
 
 	/* ---- input ---- */
@@ -51,6 +51,7 @@ struct fast_gz_t {
 	{	/* keep at least 4 KB ahead (a dynamic block header is < 1 KB); after the file's end the buffer is padded with zeros so that the
 		 * decoder's unconditional 8-byte loads stay inside it -- consumption past `ireal` is reported as truncation */
 		if (iend - ip >= 8192) return true;
+		if (fd < 0 || ib != ibuf.data()) return true;   /* a caller's buffer (fast_inflate_mt.h parses member headers that way): nothing to fill or move; what is missing shows as ip >= ireal */
 		{ const int held = bitcnt >> 3; ip -= (size_t)held; bitcnt &= 7; bitbuf &= ((uint64_t)1 << bitcnt) - 1; }   /* whole bytes waiting in the bit buffer go back: the move below must not lose them */
 		if (ip) { memmove(ibuf.data(), ibuf.data() + ip, iend - ip); iend -= ip; if (ireal >= ip) ireal -= ip; else ireal = 0; ip = 0; }
 		while (!eof_in && iend < ibuf.size() - 4096) {
@@ -76,7 +77,7 @@ struct fast_gz_t {
 		cnt[0] = 0;
 		int left = 1, maxl = 0;
 		for (int l = 1; l <= 15; ++l) { left = (left << 1) - cnt[l]; if (left < 0) return false; if (cnt[l]) maxl = l; }   /* over-subscribed */
-		last_left = left;                                                   /* 0: the code is complete */
+		last_left = left; last_maxl = maxl;                                 /* left 0: the code is complete */
 		if (maxl == 0) { for (size_t i = 0; i < ((size_t)1 << pb); ++i) t[i] = BAD; return true; }                       /* no codes: any use is an error */
 		uint32_t next[16]; { uint32_t c = 0; for (int l = 1; l <= 15; ++l) { c = (c + (uint32_t)cnt[l - 1]) << 1; next[l] = c; } }
 		for (size_t i = 0; i < ((size_t)1 << pb); ++i) t[i] = BAD;
@@ -141,7 +142,7 @@ struct fast_gz_t {
 		uint8_t cl[19]; memset(cl, 0, 19);
 		for (int i = 0; i < hclen; ++i) { if (bitcnt < 3) refill(); cl[order[i]] = (uint8_t)bits(3); }
 		std::vector<uint32_t> tc(((size_t)1 << 7) + 64);
-		if (!build(cl, 19, 7, tc, [](int s, uint32_t nb) { return mk(K_LIT, (uint32_t)s, 0, nb); })) return false;
+		if (!build(cl, 19, 7, tc, [](int s, uint32_t nb) { return mk(K_LIT, (uint32_t)s, 0, nb); }) || last_left != 0) return false;   /* zlib (inftrees.c): the code-length code must be complete */
 		uint8_t lens[320]; int i = 0;
 		while (i < hlit + hdist) {
 			refill();
@@ -158,9 +159,10 @@ struct fast_gz_t {
 			while (rep--) lens[i++] = v;
 		}
 		if (lens[256] == 0) return false;                                  /* no end-of-block code */
-		if (!build(lens, hlit, PB_LIT, tl, ent_lit) || (strict && last_left != 0)) return false;
-		if (!build(lens + hlit, hdist, PB_DIST, td, ent_dist)) return false;
-		if (strict && last_left != 0) { int used = 0; for (int k = 0; k < hdist; ++k) used += lens[hlit + k] != 0; if (used > 1) return false; }   /* one distance code (or none) may stand alone */
+		/* zlib's rule (inftrees.c: `left > 0 && (type == CODES || max != 1)' is an error): a literal / length or distance code may be incomplete
+		 * only when it consists of a single one-bit code; the boundary search of fast_inflate_mt.h (strict) takes no incomplete literal code at all */
+		if (!build(lens, hlit, PB_LIT, tl, ent_lit) || (last_left != 0 && (strict || last_maxl != 1))) return false;
+		if (!build(lens + hlit, hdist, PB_DIST, td, ent_dist) || (last_left != 0 && last_maxl > 1)) return false;
 		return true;
 	}
 

@@ -215,13 +215,19 @@ struct fast_gz_mt_t {
 			/* ---- member header (one thread, through the ordinary decoder's parser) ---- */
 			uint64_t pos;                                                  /* bit position in the FILE of the next block */
 			{
-				const size_t n = (size_t)std::min<uint64_t>(file_size - member_byte, 70000);
-				std::vector<uint8_t> hb(n + 16, 0);
-				if (!pread_all(fd, hb.data(), n, member_byte)) return finish(false, "read error");
-				fast_gz_t g(-1); g.ib = hb.data(); g.ireal = n; g.iend = n + 16; g.eof_in = true; g.ip = 0; g.member_done = !first_member;
-				if (!g.header()) return finish(false, g.err ? g.err : "damaged gzip header");
-				if (g.st == fast_gz_t::S_DONE) return finish(true, 0);        /* bytes that are no member after a complete one */
-				pos = (member_byte + g.ip) * 8;
+				/* the header's fields have no length limit (FNAME / FCOMMENT run to their NUL): a header that does not end inside the bytes
+				 * read so far is read again with more of the file, and is truncated only when the file itself ends inside it */
+				size_t hdr_len = 0; bool hdr_done = false, no_member = false;
+				for (size_t want = 70000; !hdr_done; want <<= 3) {
+					const size_t n = (size_t)std::min<uint64_t>(file_size - member_byte, want);
+					std::vector<uint8_t> hb(n + 16, 0);
+					if (!pread_all(fd, hb.data(), n, member_byte)) return finish(false, "read error");
+					fast_gz_t g(-1); g.ib = hb.data(); g.ireal = n; g.iend = n + 16; g.eof_in = true; g.ip = 0; g.member_done = !first_member;
+					if (g.header()) { hdr_done = true; no_member = g.st == fast_gz_t::S_DONE; hdr_len = g.ip; }
+					else if (n == file_size - member_byte || !g.err || strcmp(g.err, "truncated gzip header")) return finish(false, g.err ? g.err : "damaged gzip header");
+				}
+				if (no_member) return finish(true, 0);                        /* bytes that are no member after a complete one */
+				pos = (member_byte + hdr_len) * 8;
 			}
 			first_member = false;
 			bool member_end = false, new_member = true;

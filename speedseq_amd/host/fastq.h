@@ -122,7 +122,7 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 			while (!eof && raw.size() - pos < ((size_t)24 << 20)) {
 				const size_t old = raw.size(); raw.resize(old + ((size_t)8 << 20));
 				ssize_t r = read(fd, raw.data() + old, (size_t)8 << 20);
-				if (r < 0) { if (errno == EINTR) { raw.resize(old); continue; } r = 0; }
+				if (r < 0) { if (errno == EINTR) { raw.resize(old); continue; } io_err = 1; r = 0; }   /* a read error is not the end of the file */
 				raw.resize(old + (size_t)r);
 				if (r == 0) eof = true;
 			}
@@ -134,7 +134,14 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 				span_t x; x.off = q; x.len = m; x.isz = raw[q + m - 4] | (size_t)raw[q + m - 3] << 8 | (size_t)raw[q + m - 2] << 16 | (size_t)raw[q + m - 1] << 24; x.out = total;
 				total += x.isz; q += m; sp.push_back(x);
 			}
-			if (sp.empty()) break;                               /* end of file (or a trailing fragment that is not a member) */
+			if (sp.empty()) {
+				/* end of file -- unless bytes are left that are (the beginning of) a gzip member: a BGZF member cut short, or a member
+				 * without the BGZF field, which this loop cannot hand on.  Either way the input is not what was read so far: the run fails
+				 * (zlib reports both; bytes that are no gzip member at all are ignored, as gzread ignores them) */
+				if (raw.size() - pos >= 2 && raw[pos] == 0x1f && raw[pos + 1] == 0x8b) io_err = 1;
+				else if (raw.size() - pos == 1 && raw[pos] == 0x1f) io_err = 1;
+				break;
+			}
 			pos = q;
 			std::unique_ptr<chunk_t> c(new chunk_t(total));
 			std::atomic<size_t> next(0); std::atomic<int> bad(0);
@@ -142,12 +149,16 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 				for (;;) {
 					const size_t k = next.fetch_add(1);
 					if (k >= sp.size()) break;
-					if (!sp[k].isz) continue;
 					const unsigned char *h = raw.data() + sp[k].off; const size_t xlen = h[10] | (size_t)h[11] << 8;
+					if (sp[k].len < 12 + xlen + 8) { bad = 1; continue; }
 					z_stream zs; memset(&zs, 0, sizeof(zs));
 					zs.next_in = (Bytef*)(h + 12 + xlen); zs.avail_in = (uInt)(sp[k].len - 12 - xlen - 8); zs.next_out = c->data() + sp[k].out; zs.avail_out = (uInt)sp[k].isz;
-					if (inflateInit2(&zs, -15) != Z_OK || inflate(&zs, Z_FINISH) != Z_STREAM_END) bad = 1;
+					unsigned char none = 0; if (!sp[k].isz) zs.next_out = &none;   /* an empty member (the end-of-file block) still has a deflate stream and a CRC */
+					if (inflateInit2(&zs, -15) != Z_OK || inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.total_out != sp[k].isz) bad = 1;
 					inflateEnd(&zs);
+					const unsigned char *tr = h + sp[k].len - 8;   /* the member's own CRC-32 of its output */
+					const uint32_t want = tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
+					if (!bad && (uint32_t)crc32(crc32(0L, Z_NULL, 0), c->data() + sp[k].out, (uInt)sp[k].isz) != want) bad = 1;
 				}
 			};
 			std::vector<std::thread> w;

@@ -122,6 +122,60 @@ def check_extend(lib, oracle, n, seed):
     assert cells > 0
 
 
+def check_extend_lane(lib, oracle, n, seed, workdir, qcaps=(72, 136, 256)):
+    """ksw_extend2 through the lane-per-extension kernel code of the product's mem_chain2aln path (ssg_k_ext_lane's ln_extend2: packed 13-bit
+    cells in LDS, 6-bit score table, targets read from the 2-bit reference) against the oracle: the jobs of make_extend_jobs (w 5 / 20 / 100 /
+    200, zdrop 0 / 20 / 100, N in the query, h0 1..160) plus h0 up to the 13-bit ceiling, their targets laid out as a reference of their
+    own, read forward, backward and from the reverse strand (the four ways the product's left / right extensions walk the reference)."""
+    rng = np.random.default_rng(seed)
+    fa = os.path.join(str(workdir), "extlane_%d.fa" % seed)
+    done = 0
+    for qcap in qcaps:
+        jobs, qs, ts = make_extend_jobs(n, seed + qcap, max_qlen=min(qcap, 254) + 1)
+        for i in range(n):   # a share of the jobs with start scores near the ceiling of the packed cells (h0 + qlen * a + end_bonus < 8191)
+            if rng.random() < 0.15:
+                jobs[i]["h0"] = 8190 - int(jobs[i]["qlen"]) - 5 - int(rng.integers(0, 60))
+        tcat = np.concatenate(ts)
+        with open(fa, "w") as f:
+            f.write(">t\n")
+            txt = "".join("ACGT"[c] for c in tcat)
+            for k in range(0, len(txt), 80):
+                f.write(txt[k:k + 80] + "\n")
+        idx = lib.index_build_fasta(fa)
+        L = int(tcat.size)
+        starts = jobs["toff"].astype(np.int64)
+        tl = jobs["tlen"].astype(np.int64)
+        comp = lambda a: (3 - a).astype(np.uint8)
+        modes = [("fwd +1", starts, 1, lambda t: t), ("fwd -1", starts + tl - 1, -1, lambda t: t[::-1]),
+                 ("rev +1", 2 * L - starts - tl, 1, lambda t: comp(t[::-1])), ("rev -1", 2 * L - 1 - starts, -1, lambda t: comp(t))]
+        for name, tpos, d, view in modes:
+            res, cells = lib.extend_lane_batch(idx, lib.opt_init(), jobs, tpos, d, np.concatenate(qs), qcap)
+            assert cells > 0
+            for i in range(n):
+                o = oracle.extend2(qs[i], np.ascontiguousarray(view(ts[i])), int(jobs[i]["w"]), 5, int(jobs[i]["zdrop"]), int(jobs[i]["h0"]))
+                assert o == tuple(int(x) for x in res[i]), (qcap, name, i, jobs[i], o, res[i])
+            done += n
+        lib.index_destroy(idx)
+    return done
+
+
+def check_seeds(lib, oracle, n_pairs, seed, prefix=EXAMPLE_FA, read_len=150):
+    """the seeds mem_chain visits (interval -> sampled occurrences -> bwt_sa + bns_intv2rid, upstream's order) straight from ssg_k_sal against the oracle"""
+    oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
+    _, seqs, seq, off = sim_reads(n_pairs, seed, read_len, fasta=prefix)
+    seed_off, seeds, rids = lib.seeds_batch(gidx, lib.opt_init(), seq, off)
+    tot = 0
+    for r, s in enumerate(seqs):
+        o = oracle.seeds(oidx, s)
+        g = seeds[seed_off[r]:seed_off[r + 1]]
+        assert len(o) == len(g), (r, len(o), len(g))
+        assert np.array_equal(o[:, 0], g["rbeg"]) and np.array_equal(o[:, 1], g["qbeg"]) and np.array_equal(o[:, 2], g["len"]), r
+        assert np.array_equal(o[:, 3], rids[seed_off[r]:seed_off[r + 1]]), r
+        tot += len(o)
+    lib.index_destroy(gidx)
+    return tot
+
+
 def check_local(lib, oracle, n, seed):
     jobs, qs, ts = make_local_jobs(n, seed)
     res = lib.align2_batch(lib.opt_init(), jobs, np.concatenate(qs), np.concatenate(ts))

@@ -62,6 +62,14 @@ class Oracle:
         n = self.l.orc_api_collect_intv(self.opt, idx, C.c_int(len(seq)), _ptr(seq), _ptr(out), C.c_int(cap))
         return out[:n]
 
+    def seeds(self, idx, seq, cap=1 << 16):
+        """(rbeg, qbeg, len, rid) of every seed mem_chain visits for the read, in its order"""
+        out = np.zeros((cap, 4), dtype=np.int64)
+        self.l.orc_api_seeds.restype = C.c_int64
+        n = self.l.orc_api_seeds(self.opt, idx, C.c_int(len(seq)), _ptr(seq), _ptr(out), C.c_int64(cap))
+        assert n <= cap
+        return out[:n]
+
     def align1_batch(self, idx, seq, off):
         n = len(off) - 1
         reg_off = np.zeros(n + 1, dtype=np.int64)

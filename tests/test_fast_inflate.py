@@ -94,6 +94,40 @@ def test_members_headers_and_trailing_bytes(tmp_path):
     check(tmp_path, b"".join(gz(x, rng.choice([1, 6, 9])) for x in parts), b"".join(parts), members=60)
 
 
+def test_small_members_with_header_fields(tmp_path):
+    """header fields on members of a few hundred bytes (the several-thread decoder parses member headers from a buffer of its own: with fewer
+    than 8 KB left in the file it used to hand that buffer to the one-thread decoder's refill and crash), alone and behind a large member,
+    and a header longer than the first 70 000 bytes read for it"""
+    rng = random.Random(21)
+    small, big = fastq(rng, 12), fastq(rng, 30000)
+
+    def member(data, flg, extra=b"XY\x03\x00abc", name=b"reads_1.fq\0", comment=b"lane 3\0"):
+        hdr = b"\x1f\x8b\x08" + bytes([flg]) + bytes(6)
+        if flg & 4:
+            hdr += struct.pack("<H", len(extra)) + extra
+        if flg & 8:
+            hdr += name
+        if flg & 16:
+            hdr += comment
+        if flg & 2:
+            hdr += struct.pack("<H", zlib.crc32(hdr) & 0xffff)
+        return hdr + gz(data, 6)[10:]
+    for flg in (4, 8, 16, 2, 4 | 8, 4 | 8 | 16 | 2):
+        check(tmp_path, member(small, flg), small, members=1)
+        check(tmp_path, gz(big, 6) + member(small, flg), big + small, members=2)
+        check(tmp_path, member(small, flg) + member(small, flg) + gz(small, 1), small * 3, members=3)
+    long_name = bytes(rng.choice(b"abcdefghij") for _ in range(200000)) + b"\0"
+    check(tmp_path, member(big, 8, name=long_name), big, members=1)
+    check(tmp_path, member(small, 4 | 8, extra=bytes(65535), name=long_name), small, members=1)
+    p = tmp_path / "cut.gz"                          # the file ends inside a header field: an error, not a crash
+    blob = member(small, 4 | 8)
+    for cut in (11, 13, 16, 20, 24):
+        p.write_bytes(blob[:cut])
+        for mode in MODES:
+            rc, out, err = run(str(p), mode)
+            assert rc == 1 and "error" in err, (mode, cut, out, err)
+
+
 def test_large_stream_many_chunks(tmp_path):
     rng = random.Random(11)
     data = fastq(rng, 200000)                        # ~50 MB of text: a dozen output chunks, input refills

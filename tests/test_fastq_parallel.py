@@ -189,3 +189,52 @@ def test_compressed_input_parsed_by_several_threads(tmp_path, case, slab, piece)
     assert r.stdout == ref
     env["SSG_GZ_FAST"] = "0"                            # ... and behind zlib's decoder
     assert subprocess.run([FQ_DUMP, str(g)], env=env, capture_output=True, check=True, timeout=60).stdout == ref
+
+
+def bgzf_blocks(data, block=60000, eof=True):
+    """the byte stream bgzip writes (htslib bgzf.c:298-342): independent members of <= 64 KB with their size in a 'BC' extra field"""
+    import struct
+    import zlib
+    out = []
+    parts = [data[k:k + block] for k in range(0, len(data), block)] + ([b""] if eof else [])
+    for p in parts:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(p) + c.flush()
+        size = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04" + bytes(4) + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, size - 1) + body + struct.pack("<II", zlib.crc32(p), len(p)))
+    return out
+
+
+def test_bgzf_input_damage_is_an_error_not_a_short_read(tmp_path):
+    """a blocked-gzip FASTQ that is cut inside a member, carries a wrong CRC or length, or goes on with a gzip member that is not BGZF must
+    fail the read (end state other than a clean end of file): zlib reports all of them, and aligning the first part of the input as if
+    it were all of it is the one outcome that must not happen"""
+    import gzip
+    import struct
+    rng = random.Random(77)
+    text = four_line(rng, 6000, qual_chars="ABCDEFGHIJ").encode()
+    blocks = bgzf_blocks(text)
+    assert len(blocks) > 8
+    n_all = text.count(b"\n@r")  + 1
+    p = tmp_path / "r.fq.gz"
+
+    def end_state(blob, threads):
+        p.write_bytes(blob)
+        env = dict(os.environ, SSG_BGZF_THREADS=str(threads))
+        r = subprocess.run([FQ_DUMP, str(p)], env=env, capture_output=True, check=True, timeout=120)
+        last = r.stdout.decode().strip().split("\n")[-1].split("\t")
+        return int(last[1]), int(last[2])
+    for threads in (1, 3):
+        rc, n = end_state(b"".join(blocks), threads)
+        assert rc == -1 and n == 6000, (rc, n)                                  # intact: clean end, every record
+        assert end_state(b"".join(bgzf_blocks(text, eof=False)), threads) == (-1, 6000)   # no end-of-file block: htslib warns, reads on
+        assert end_state(b"".join(blocks) + bytes(100), threads) == (-1, 6000)  # bytes that are no gzip member: ignored, as gzread does
+        cut = b"".join(blocks[:5]) + blocks[5][:len(blocks[5]) // 2]
+        assert end_state(cut, threads)[0] != -1                                 # cut inside the 6th member
+        assert end_state(b"".join(blocks[:5]) + blocks[5][:10], threads)[0] != -1
+        bad_crc = bytearray(blocks[3]); bad_crc[-8] ^= 0x40
+        assert end_state(b"".join(blocks[:3]) + bytes(bad_crc) + b"".join(blocks[4:]), threads)[0] != -1
+        bad_len = bytearray(blocks[3]); bad_len[-4:] = struct.pack("<I", struct.unpack("<I", bytes(bad_len[-4:]))[0] - 1)
+        assert end_state(b"".join(blocks[:3]) + bytes(bad_len) + b"".join(blocks[4:]), threads)[0] != -1
+        more = four_line(rng, 500, qual_chars="ABCDEFGHIJ").encode()
+        assert end_state(b"".join(blocks[:-1]) + gzip.compress(more), threads)[0] != -1   # a plain gzip member behind the BGZF ones

@@ -14,6 +14,17 @@ def test_gpu_extend(gpu_lib, oracle):
     common.check_extend(gpu_lib, oracle, 3000, seed=11)
 
 
+def test_gpu_extend_lane_kernel(gpu_lib, oracle, tmp_path):
+    # row a7 as the product path runs it: ssg_k_ext_lane's ln_extend2 (the kernel behind mem_chain2aln), all three LDS classes
+    assert common.check_extend_lane(gpu_lib, oracle, 1000, seed=61, workdir=tmp_path) == 12000
+
+
+def test_gpu_seeds_sal(gpu_lib, oracle, repeat_prefix):
+    # row a3: ssg_k_sal's seed lists (bwt_sa + bns_intv2rid) directly, also on a repeat-rich reference and at the file's SA density
+    assert common.check_seeds(gpu_lib, oracle, 1500, seed=62) > 1000
+    assert common.check_seeds(gpu_lib, oracle, 10, seed=63, prefix=repeat_prefix) > 1000
+
+
 def test_gpu_local(gpu_lib, oracle):
     common.check_local(gpu_lib, oracle, 400, seed=12)
 

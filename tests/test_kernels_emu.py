@@ -9,6 +9,17 @@ def test_emu_extend(emu_lib, oracle):
     common.check_extend(emu_lib, oracle, 400, seed=1)
 
 
+def test_emu_extend_lane_kernel(emu_lib, oracle, tmp_path):
+    # row a7 as the product path runs it: ssg_k_ext_lane's ln_extend2 (the kernel behind mem_chain2aln), all three LDS classes
+    assert common.check_extend_lane(emu_lib, oracle, 60, seed=61, workdir=tmp_path) == 720
+
+
+def test_emu_seeds_sal(emu_lib, oracle, repeat_prefix):
+    # row a3: ssg_k_sal's seed lists (bwt_sa + bns_intv2rid) directly, also on a repeat-rich reference and at the file's SA density
+    assert common.check_seeds(emu_lib, oracle, 40, seed=62) > 1000
+    assert common.check_seeds(emu_lib, oracle, 10, seed=63, prefix=repeat_prefix) > 1000
+
+
 def test_emu_local(emu_lib, oracle):
     common.check_local(emu_lib, oracle, 60, seed=2)
 
