@@ -391,4 +391,13 @@ __global__ void __launch_bounds__(64) ssg_k_smem_heavy(ssg_index_view_t ix, ssg_
 	}
 	if (n_extend && nx && wv_lane() == 0) atomicAdd(n_extend, nx);
 }
+/* self-check of the denser table (SSG_SA_VERIFY=1): every `stride`-th entry against upstream's own bwt_sa walk on the file's samples */
+__global__ void ssg_k_sa_verify(ssg_index_view_t ix, int new_intv, const uint64_t *sa_new, long n_new, long stride, unsigned long long *bad)
+{
+	const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+	if (j >= n_new) return;
+	const uint64_t r = (uint64_t)j * (uint64_t)new_intv;
+	const uint64_t want = (r % (uint64_t)ix.sa_intv) == 0 ? ix.sa[r / (uint64_t)ix.sa_intv] : ssg_bwt_sa(ix, r);
+	if (sa_new[j] != want) atomicAdd(bad, 1ull);
+}
 #endif

@@ -115,21 +115,6 @@ SSG_DEVFN int wv_scan_add(int v)
 	return v;
 }
 #endif
-/* quad (4 adjacent lanes) exchange: DPP quad_perm on the GPU */
-#ifdef SSG_EMU
-SSG_DEVFN int wv_qx1(int v) { return wv_shfl(v, wv_lane() ^ 1); }
-SSG_DEVFN int wv_qx2(int v) { return wv_shfl(v, wv_lane() ^ 2); }
-#else
-SSG_DEVFN int wv_qx1(int v) { return SSG_DPP(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf); }
-SSG_DEVFN int wv_qx2(int v) { return SSG_DPP(0, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf); }
-#endif
-SSG_DEVFN unsigned long long wv_quad_sum64(unsigned long long v)
-{	/* sum over the 4 lanes of a quad, in every lane */
-	unsigned long long o;
-	o = (unsigned long long)(unsigned)wv_qx1((int)(unsigned)v) | (unsigned long long)(unsigned)wv_qx1((int)(unsigned)(v >> 32)) << 32; v += o;
-	o = (unsigned long long)(unsigned)wv_qx2((int)(unsigned)v) | (unsigned long long)(unsigned)wv_qx2((int)(unsigned)(v >> 32)) << 32; v += o;
-	return v;
-}
 SSG_DEVFN int wv_last(int v) { return wv_get(v, 63); }
 /* dynamic work distribution: lane 0 takes the next index of a global queue, the wave shares it */
 SSG_DEVFN long wv_queue_pop(unsigned int *queue)
@@ -247,61 +232,6 @@ SSG_DEVFN ssg_intv_t ssg_bwt_extend1(const ssg_index_view_t &ix, const ssg_intv_
 	if (is_back) { o.x0 = nk; o.x1 = no; } else { o.x1 = nk; o.x0 = no; }
 	return o;
 }
-/* ssg_bwt_extend1 by the 4 lanes of a quad: lane ql loads quarter ql (16 bytes) of each of the two rank
- * blocks -- quarters 0,1 = the four 64-bit running counts, quarters 2,3 = the 128 packed symbols -- adds
- * up its share of occ(l) - occ(k-1) per base, and three 64-bit quad sums give every lane the result.
- * One load instruction per block touches 16 lines per wave instead of 4 x 64 (TA / TLB work per line / 16). */
-SSG_DEVFN ssg_intv_t ssg_bwt_extend1_quad(const ssg_index_view_t &ix, const ssg_intv_t &ik, int c, int is_back, int ql)
-{
-	struct alignas(16) q16 { uint32_t v[4]; };
-	const uint64_t kx = is_back ? ik.x0 : ik.x1, ox = is_back ? ik.x1 : ik.x0;
-	uint64_t k1 = kx - 1, k2 = kx - 1 + ik.x2;
-	const bool z1 = k1 == (uint64_t)-1, z2 = k2 == (uint64_t)-1;   /* occ(-1) = 0 */
-	k1 = z1 ? 0 : k1 - (k1 >= ix.primary);
-	k2 = z2 ? 0 : k2 - (k2 >= ix.primary);
-	const q16 a = ((const q16*)(ix.bwt + ((k1 >> 7) << 4)))[ql];
-	const q16 b = ((const q16*)(ix.bwt + ((k2 >> 7) << 4)))[ql];
-	uint64_t dgt = 0, dc = 0, tkc = 0;
-	if (ql < 2) {
-		SSG_UNROLL for (int t = 0; t < 2; ++t) {
-			const int bi = 2 * ql + t;
-			const uint64_t pk = z1 ? 0 : ((uint64_t)a.v[2*t] | (uint64_t)a.v[2*t+1] << 32);
-			const uint64_t pl = z2 ? 0 : ((uint64_t)b.v[2*t] | (uint64_t)b.v[2*t+1] << 32);
-			const uint64_t d = pl - pk;
-			if (bi > c) dgt += d;
-			if (bi == c) { dc = d; tkc = pk; }
-		}
-	} else {
-		const int r1 = z1 ? 0 : (int)(k1 & 127) + 1, r2 = z2 ? 0 : (int)(k2 & 127) + 1, w0 = (ql - 2) * 4;
-		uint32_t m1[4], m2[4];
-		SSG_UNROLL for (int i = 0; i < 4; ++i) {
-			int ns = r1 - (w0 + i) * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns;
-			m1[i] = ns == 16 ? 0x55555555u : ns ? (~((1u << ((16 - ns) << 1)) - 1)) & 0x55555555u : 0u;
-			ns = r2 - (w0 + i) * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns;
-			m2[i] = ns == 16 ? 0x55555555u : ns ? (~((1u << ((16 - ns) << 1)) - 1)) & 0x55555555u : 0u;
-		}
-		SSG_UNROLL for (int bi = 0; bi < 4; ++bi) {
-			int nk = 0, nl = 0;
-			SSG_UNROLL for (int i = 0; i < 4; ++i) {
-				const uint32_t x = ~(a.v[i] ^ ((uint32_t)bi * 0x55555555u)), y = ~(b.v[i] ^ ((uint32_t)bi * 0x55555555u));
-				nk += __popc(x & (x >> 1) & m1[i]); nl += __popc(y & (y >> 1) & m2[i]);
-			}
-			const uint64_t d = (uint64_t)(int64_t)(nl - nk);
-			if (bi > c) dgt += d;
-			if (bi == c) { dc = d; tkc = (uint64_t)nk; }
-		}
-	}
-	dgt = wv_quad_sum64(dgt); dc = wv_quad_sum64(dc); tkc = wv_quad_sum64(tkc);
-	const uint64_t no = ox + (kx <= ix.primary && kx + ik.x2 - 1 >= ix.primary) + dgt;
-	uint64_t l2c = ix.L2[0];
-	SSG_UNROLL for (int bi = 1; bi < 4; ++bi) if (bi == c) l2c = ix.L2[bi];
-	ssg_intv_t o;
-	const uint64_t nk = l2c + 1 + tkc;
-	o.x2 = dc; o.info = 0;
-	if (is_back) { o.x0 = nk; o.x1 = no; } else { o.x1 = nk; o.x0 = no; }
-	return o;
-}
-
 /* ssg_bwt_extend1 that fetches only the quarters of each rank block the followed base needs.  With T = k + 1 symbols up to and
  * including stored position k, sum over b > c of occ_b equals T - occ_0 (c = 0), T - occ_0 - occ_1 (c = 1), occ_3 (c = 2), 0 (c = 3):
  * at most two of the four running counts -- one 16-byte quarter -- and two popcount passes instead of four; of the symbol words

@@ -59,3 +59,16 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
 	}
 	return rt_sync();
 }
+
+/* SSG_SA_VERIFY: every `stride`-th entry of the denser SA table against upstream's bwt_sa on the file's samples (view = the index before the swap) */
+extern "C" int ssg_sa_verify(const ssg_index *ix, int new_intv, const uint64_t *d_sa_new, long n_new)
+{
+	const long stride = n_new > (1L << 24) ? n_new >> 24 : 1, nt = (n_new + stride - 1) / stride;
+	dbuf<unsigned long long> d_bad(1); unsigned long long bad = 0;
+	if (!d_bad.ok()) { ssg_err_msg = "device allocation failed"; return SSG_ENOMEM; }
+	CHK(d_bad.zero());
+	SSG_LAUNCH(ssg_k_sa_verify, (nt + 255) / 256, 256, 0, ix->v, new_intv, d_sa_new, n_new, stride, d_bad.p);
+	CHK(rt_sync()); CHK(d_bad.down(&bad, 1));
+	fprintf(stderr, "[ssgpu] SA samples every %d rows: %llu of %ld checked entries differ from bwt_sa on the file's samples\n", new_intv, bad, nt);
+	return 0;
+}

@@ -3,7 +3,7 @@
  * Compiled by hipcc for gfx950 (product) or by g++ with -DSSG_EMU against tests/emu (CPU tests).
  *
  * Stage order for a batch of reads (all intermediates stay in HBM):
- *   ssg_k_smem_quad -> ssg_k_smem_sort -> ssg_k_sal_count -> [prefix sum] -> ssg_k_sal -> ssg_k_chain -> ssg_k_chain2aln
+ *   ssg_k_smem2 (+ ssg_k_smem_heavy; ssg_seed.cpp) -> ssg_k_smem_sort -> ssg_k_sal_count -> [prefix sum] -> ssg_k_sal -> ssg_k_chain -> ssg_k_chain2aln
  * Per-read variable-length outputs are placed by prefix sums over per-read counts; fixed-capacity
  * stages report overflow and the affected reads are re-run with a larger capacity -- nothing is
  * dropped silently and nothing falls back to the CPU.
@@ -61,13 +61,13 @@ static double ssg_stage_ms() { static thread_local std::chrono::steady_clock::ti
 #define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d  +%.1f ms\n", name, rc_, ssg_stage_ms()); fflush(stderr); if (rc_) return rc_; } } while (0)
 
 SSG_ABI_FP_DEFINE(core)
-extern "C" void ssg_abi_fp_index_build(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_ktab(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_seed(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_sam_format(ssg_abi_fp_t*);
+extern "C" void ssg_abi_fp_index_build(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_seed(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_sam_format(ssg_abi_fp_t*);
 extern "C" int ssg_abi_selfcheck(void)
 {	/* every translation unit of the library was compiled against the same shared declarations (ssg_index_int.h) */
 	static const char *const field[20] = { "sizeof(ssg_index_view_t)", "sizeof(ssg_mem_opt_t)", "sizeof(ssg_index)", "sizeof(ssg_intv_t)", "ssg_index_view_t.primary", "ssg_index_view_t.L2",
 		"ssg_index_view_t.l_pac", "ssg_index_view_t.sa_intv", "ssg_mem_opt_t.min_seed_len", "ssg_mem_opt_t.split_width", "ssg_mem_opt_t.max_mem_intv", "ssg_mem_opt_t.split_factor", "ssg_mem_opt_t.mat",
-		"ssg_index.bwt", "ssg_index.ktab", "ssg_index.bwt_words", "ssg_index.names", "sizeof(ssg_seed_t)", "sizeof(ssg_alnreg_t)", "sizeof(ssg_aln_t)" };
-	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_ktab", ssg_abi_fp_ktab }, { "ssg_seed", ssg_abi_fp_seed }, { "sam_format", ssg_abi_fp_sam_format } };
+		"ssg_index.bwt", "ssg_index.ctg_len", "ssg_index.bwt_words", "ssg_index.names", "sizeof(ssg_seed_t)", "sizeof(ssg_alnreg_t)", "sizeof(ssg_aln_t)" };
+	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_seed", ssg_abi_fp_seed }, { "sam_format", ssg_abi_fp_sam_format } };
 	ssg_abi_fp_t mine; ssg_abi_fp_core(&mine);
 	for (const auto &u : units) {
 		ssg_abi_fp_t o; u.fn(&o);
@@ -150,7 +150,7 @@ int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t prim
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
-	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }
@@ -269,7 +269,7 @@ int ssg_index_load2(const char *prefix, int defer_dense_sa, ssg_index_t **out)
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_seqs; ix->v.sa_intv = sa_intv;
 	ix->h_off = off; ix->h_len = len; ix->names = names;
-	{ int rc2 = defer_dense_sa ? 0 : densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = defer_dense_sa ? 0 : densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	if (ssg_debug() || getenv("SSG_LOAD_LOG")) {
 		const auto t_end = std::chrono::steady_clock::now();
 		fprintf(stderr, "[ssgpu] index load: files -> HBM %.3f s (%.2f GB), SA samples to every %d rows %.3f s\n", std::chrono::duration<double>(t_up - t_begin).count(),
@@ -284,7 +284,7 @@ void ssg_index_destroy(ssg_index_t *ix)
 	if (!ix) return;
 	if (ix->raw_alloc) { rt_free_raw(ix->bwt); rt_free_raw(ix->sa); rt_free_raw(ix->pac); }
 	else { rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); }
-	rt_free(ix->ctg_off); rt_free(ix->ctg_len); rt_free(ix->ktab);
+	rt_free(ix->ctg_off); rt_free(ix->ctg_len);
 	delete ix;
 }
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,
@@ -300,7 +300,7 @@ int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
-	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }
@@ -454,32 +454,24 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
                     int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0, int *need_cap = 0)
 {
 	const int block = 64;
-	const char *const kern = getenv("SSG_SMEM_KERNEL") ? getenv("SSG_SMEM_KERNEL") : "smem2";   /* smem2 (product, ssg_seed.cpp) | quad (round 1-3 form) | lane (nested loops as upstream writes them) */
-	const bool quad = strcmp(kern, "lane") != 0;
-	const bool smem2 = quad && strcmp(kern, "quad") != 0 && env_int("SSG_SMEM_LPR", 1) == 1 && idx->ktab_k == 0;
-	/* lanes per read: 1 (each lane fetches whole rank blocks; 64 reads per wave keep the state machine's instruction count per
-	 * extension low) or 4 (quad-cooperative fetch: a quarter of the translation work per line, but 16 reads per wave make the kernel
-	 * VALU-bound).  Measured at the 3.1 Gbp headline size: 154 ms (LPR 1, at the per-lane gather rate of 21 G lines/s) vs 178 ms (LPR 4). */
-	const int lpr = quad ? env_int("SSG_SMEM_LPR", 1) : 1, per_read = lpr;
-	long nthreads = std::min<long>(((long)n_reads * per_read + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64);
+	/* SSG_SMEM_KERNEL=lane: the nested-loop form (k_seed.h) instead of the product's kernels (ssg_seed.cpp: ssg_k_smem2 + ssg_k_smem_heavy) */
+	const bool smem2 = !(getenv("SSG_SMEM_KERNEL") && !strcmp(getenv("SSG_SMEM_KERNEL"), "lane"));
 	int scap = max_len + 2;
-	dbuf<ssg_intv_t> scratch(smem2 ? 64 : (size_t)nthreads * 3 * scap / per_read + 64);
-	CHKA(scratch);
-	dbuf<unsigned int> d_nextread(1);
-	CHKA(d_nextread); CHK(d_nextread.zero());
 	if (smem2) CHK(ssg_seed_smem2(idx, opt, n_reads, d_seq, d_off, max_len, cap, d_intv, d_n, n_extend, (unsigned int)env_int("SSG_SMEM_MAX_EXT", 13 * max_len + 50), (uint32_t*)0));   /* 2000 at 150 bases: 1.8 % of the bench's reads go to the wave-per-read kernel (k_smem2.h) */
-	else if (quad && lpr == 4) SSG_LAUNCH(ssg_k_smem_quad<4>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, (unsigned int*)0 SSG_SMQ_EXTRA_ARG);
-	else if (quad && idx->ktab_k > 0) CHK(ssg_ktab_launch_smem(idx, opt, nthreads / block, block, n_reads, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p));   /* opt-in table instance, ssg_ktab.cpp */
-	else if (quad) SSG_LAUNCH(ssg_k_smem_quad<1>, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend, d_nextread.p SSG_SMQ_EXTRA_ARG);
-	else SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
+	else {
+		const long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64);
+		dbuf<ssg_intv_t> scratch((size_t)nthreads * 3 * scap + 64);
+		CHKA(scratch);
+		SSG_LAUNCH(ssg_k_smem_lane, nthreads / block, block, 0, idx->v, *opt, n_reads, (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, scratch.p, scap, n_extend);
+	}
 	CHK(rt_sync());
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));
-	  if (!cc[3]) { if (quad) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; } }
+	  if (!cc[3]) { if (smem2) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; } }
 	std::vector<int32_t> hn(n_reads);
 	CHK(rt_d2h(hn.data(), d_n, (size_t)n_reads * 4));
 	std::vector<int32_t> ovf;
 	for (int r = 0; r < n_reads; ++r) if (hn[r] < 0) ovf.push_back(r);
-	if (ovf.empty()) { if (quad) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; }
+	if (ovf.empty()) { if (smem2) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; }
 	/* slow path: worst case is O(len^2) intervals in theory; len*8 has never been observed to overflow */
 	int bigcap = max_len * 8 + 64, no = (int)ovf.size();
 	dbuf<int32_t> d_ids(no), d_n2(no); dbuf<ssg_intv_t> d_big((size_t)no * bigcap);
@@ -504,7 +496,7 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 		CHK(rt_h2d(d_intv + (size_t)ovf[i] * cap, tmp.data(), (size_t)hn2[i] * sizeof(ssg_intv_t)));
 		CHK(rt_h2d(d_n + ovf[i], &hn2[i], 4));
 	}
-	if (quad) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap);
+	if (smem2) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap);
 	return 0;
 }
 

@@ -49,7 +49,24 @@ static inline void io_write_all(int fd, const void *p, size_t n)
 	while (n) { ssize_t w = write(fd, c, n); if (w < 0) { if (errno == EINTR) continue; perror("write"); exit(1); } c += w; n -= (size_t)w; }
 }
 
-/* one BGZF block from <= 0xff00 payload bytes; level 0 = stored; returns the block size */
+/* one BGZF block from <= 0xff00 payload bytes; level 0 = stored; returns the block size.
+ * The deflate state is the calling thread's own and lives as long as the thread: deflateInit2 allocates and clears ~256 KB, and a
+ * sort writes tens of thousands of blocks from hundreds of threads -- that many allocations and releases per second meet in the
+ * allocator and in the kernel's memory-map lock (round 3's sort wrote 0.8 GB/s of records on 256 threads); deflateReset keeps the
+ * memory and only clears the hash heads. */
+struct bgzf_deflater_t {
+	z_stream zs; int level; bool live;
+	bgzf_deflater_t() : level(-2), live(false) { memset(&zs, 0, sizeof(zs)); }
+	~bgzf_deflater_t() { if (live) deflateEnd(&zs); }
+	bool ready(int lvl)
+	{
+		if (live && lvl == level) return deflateReset(&zs) == Z_OK;
+		if (live) { deflateEnd(&zs); live = false; }
+		memset(&zs, 0, sizeof(zs));
+		if (deflateInit2(&zs, lvl, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+		live = true; level = lvl; return true;
+	}
+};
 static inline size_t bgzf_make_block(const uint8_t *src, size_t slen, int level, uint8_t *dst /* >= 65536 */)
 {
 	static const uint8_t hdr[16] = { 0x1f,0x8b,0x08,0x04,0,0,0,0,0,0xff,0x06,0,0x42,0x43,0x02,0 };
@@ -60,14 +77,12 @@ static inline size_t bgzf_make_block(const uint8_t *src, size_t slen, int level,
 		d[0] = 1; d[1] = (uint8_t)(slen & 0xff); d[2] = (uint8_t)(slen >> 8); d[3] = (uint8_t)~d[1]; d[4] = (uint8_t)~d[2];
 		memcpy(d + 5, src, slen); clen = slen + 5;
 	} else {
-		z_stream zs; memset(&zs, 0, sizeof(zs));
+		static thread_local bgzf_deflater_t df;
+		if (!df.ready(level)) { fprintf(stderr, "[sambamba] deflateInit2 failed\n"); exit(1); }
+		z_stream &zs = df.zs;
 		zs.next_in = (Bytef*)src; zs.avail_in = (uInt)slen; zs.next_out = dst + 18; zs.avail_out = 65536 - 18 - 8;
-		if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { fprintf(stderr, "[sambamba] deflateInit2 failed\n"); exit(1); }
-		if (deflate(&zs, Z_FINISH) != Z_STREAM_END) {   /* incompressible payload: store it instead */
-			deflateEnd(&zs);
-			return bgzf_make_block(src, slen, 0, dst);
-		}
-		clen = zs.total_out; deflateEnd(&zs);
+		if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return bgzf_make_block(src, slen, 0, dst);   /* incompressible payload: store it instead */
+		clen = zs.total_out;
 	}
 	const size_t bsize = 18 + clen + 8;
 	dst[16] = (uint8_t)((bsize - 1) & 0xff); dst[17] = (uint8_t)((bsize - 1) >> 8);

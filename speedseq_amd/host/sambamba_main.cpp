@@ -231,30 +231,37 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		if (cum[n] > cut.back()) cut.push_back(cum[n]);
 	}
 	const double tw1 = wall();
-	const size_t nb = cut.size() - 1, GRP = 128, ng = (nb + GRP - 1) / GRP;
+	const size_t nb = cut.size() - 1, GRP = 16, ng = (nb + GRP - 1) / GRP;   /* 1 MB of records per work item: a sort of a few hundred blocks still spreads over the pool, and the last items of a large one end together */
 	struct grp_t { std::vector<uint8_t> bytes; std::vector<uint32_t> bsz; bool done; grp_t() : done(false) {} };
 	std::vector<uint64_t> blk_coff(want_off ? nb + 1 : 0);      /* file offset of every block */
 	std::vector<grp_t> grp(ng);
 	std::mutex mu; std::condition_variable cv; size_t next_write = 0; std::atomic<size_t> next_grp(0);
 	const size_t window = (size_t)std::max(4, threads * 3);   /* groups compressed ahead of the writer */
+	std::atomic<long> us_gather(0), us_deflate(0), us_window(0), n_workers_used(0);   /* summed over the workers (SSG_DEBUG) */
 	auto worker = [&]() {
 		std::vector<uint8_t> payload(BGZF_MAX_PAYLOAD), blk(65536);
+		long my_g = 0, my_d = 0, my_w = 0; bool used = false;
 		for (;;) {
 			const size_t g = next_grp.fetch_add(1);
 			if (g >= ng) break;
-			{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return g < next_write + window; }); }
+			used = true;
+			{ const double t0 = wall(); std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return g < next_write + window; }); my_w += (long)((wall() - t0) * 1e6); }
 			std::vector<uint8_t> ob; ob.reserve(GRP * (lvl ? 24576 : 65536));
 			std::vector<uint32_t> bsz;
 			for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
 				const uint64_t v0 = cut[bk], v1 = cut[bk + 1];
 				size_t i = (size_t)(std::upper_bound(cum.begin(), cum.end(), v0) - cum.begin()) - 1; size_t w = 0;
+				const double t0 = wall();
 				for (uint64_t v = v0; v < v1; ++i) { const uint8_t *r = S.rec(perm[i]); const uint64_t a = v - cum[i], e = std::min(cum[i + 1], v1) - cum[i]; memcpy(payload.data() + w, r + a, (size_t)(e - a)); w += (size_t)(e - a); v = cum[i] + e; }
+				const double t1 = wall();
 				const size_t k = bgzf_make_block(payload.data(), w, lvl, blk.data());
 				ob.insert(ob.end(), blk.data(), blk.data() + k); bsz.push_back((uint32_t)k);
+				my_g += (long)((t1 - t0) * 1e6); my_d += (long)((wall() - t1) * 1e6);
 			}
 			{ std::lock_guard<std::mutex> l(mu); grp[g].bytes.swap(ob); grp[g].bsz.swap(bsz); grp[g].done = true; }
 			cv.notify_all();
 		}
+		us_gather += my_g; us_deflate += my_d; us_window += my_w; if (used) ++n_workers_used;
 	};
 	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets), built by a thread of
 	 * its own that follows the writer: a record's virtual offset is known as soon as the group holding its block has its file offset */
@@ -283,10 +290,11 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	std::vector<std::thread> th;
 	for (int t = 0; t < std::max(1, threads); ++t) th.emplace_back(worker);
 	uint64_t coff = (uint64_t)(hdr_end > 0 ? hdr_end : 0);
+	double t_wr_wait = 0, t_wr_io = 0; const double tw_spawn = wall();
 	for (size_t g = 0; g < ng; ++g) {
 		std::vector<uint8_t> ob; std::vector<uint32_t> bsz;
-		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz); }
-		io_write_all(fd, ob.data(), ob.size());
+		{ const double t0 = wall(); std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz); t_wr_wait += wall() - t0; }
+		{ const double t0 = wall(); io_write_all(fd, ob.data(), ob.size()); t_wr_io += wall() - t0; }
 		if (want_off) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }
 		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; if (bai_path) blocks_placed.store(std::min(nb, (g + 1) * GRP), std::memory_order_release); }
 		cv.notify_all();
@@ -300,7 +308,9 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	}
 	io_write_all(fd, BGZF_EOF, 28);
 	const double tw2 = wall();
-	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s\n", tw1 - tw0, nb, tw2 - tw1);
+	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index + thread start %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
+	                   "%ld workers with work, per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn - tw1, t_wr_wait, t_wr_io,
+	                   n_workers_used.load(), us_gather / 1e6 / std::max(1L, n_workers_used.load()), us_deflate / 1e6 / std::max(1L, n_workers_used.load()), us_window / 1e6 / std::max(1L, n_workers_used.load()));
 	if (!bai_path) return;
 	blk_coff[nb] = coff;
 	{ std::lock_guard<std::mutex> l(mu); file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release); }

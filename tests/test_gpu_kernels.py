@@ -139,15 +139,7 @@ def test_gpu_smem_budget_and_wave_kernel(gpu_lib, oracle, repeat_prefix, monkeyp
 
 
 def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
-    monkeypatch.setenv("SSG_SMEM_KERNEL", "quad")     # the round 1-3 form
-    common.check_smem(gpu_lib, oracle, 1500, seed=31)
-    monkeypatch.delenv("SSG_SMEM_KERNEL")
-    # the quad-cooperative form and the nested-loop form, on the same reads (default: lane per read, lean per-lane fetch)
-    monkeypatch.setenv("SSG_SMEM_LPR", "4")
-    common.check_smem(gpu_lib, oracle, 1500, seed=31)
-    assert common.check_align1(gpu_lib, oracle, 1500, seed=32) > 1500
-    monkeypatch.delenv("SSG_SMEM_LPR")
-    monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")
+    monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")     # the nested-loop form (the product kernels' fall-back), on the same reads
     common.check_smem(gpu_lib, oracle, 1500, seed=31)
     monkeypatch.delenv("SSG_SMEM_KERNEL")
     monkeypatch.setenv("SSG_SA_INTV", "32")   # the file's own suffix-array density

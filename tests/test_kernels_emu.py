@@ -129,12 +129,7 @@ def test_emu_smem_budget_and_wave_kernel(emu_lib, oracle, repeat_prefix, monkeyp
 
 
 def test_emu_smem_kernel_variants(emu_lib, oracle, monkeypatch):
-    monkeypatch.setenv("SSG_SMEM_KERNEL", "quad")     # the round 1-3 form
-    common.check_smem(emu_lib, oracle, 150, seed=31)
-    monkeypatch.setenv("SSG_SMEM_LPR", "4")
-    common.check_smem(emu_lib, oracle, 150, seed=31)
-    monkeypatch.delenv("SSG_SMEM_LPR")
-    monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")
+    monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")     # the nested-loop form (the product kernels' fall-back), on the same reads
     common.check_smem(emu_lib, oracle, 150, seed=31)
     monkeypatch.delenv("SSG_SMEM_KERNEL")
     monkeypatch.setenv("SSG_SA_INTV", "32")

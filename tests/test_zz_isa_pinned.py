@@ -1,9 +1,5 @@
-"""The product kernels' gfx950 machine code is the code whose results were checked on the MI355X (tools/isa_pin.py).
-
-Why a CPU-side test looks at machine code: in round 3 builds of the seeding kernel that execute the same statements as the checked one
-(different kernarg layout and register allocation) gave wrong results on the GPU while the emulation of the same source still agreed
-with the oracle; the cause is open (profiles/r03f_gpu_bisect.log).  Until it is understood, a change of any pinned kernel's code must go through `pytest -m gpu`
-and the bench's parity gate, then `python tools/isa_pin.py --write`."""
+"""The product kernels' gfx950 machine code is the code whose results were checked on the MI355X (tools/isa_pin.py): an alarm for kernels that
+changed -- in source, or only in the code the compiler made of them -- since the last GPU run, which the CPU-side suite cannot judge."""
 import os
 import subprocess
 import sys
@@ -18,4 +14,4 @@ def test_product_kernels_machine_code_is_the_gpu_checked_build():
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or not os.path.exists(lib):
         pytest.skip("llvm-objdump or libssgpu.so not available")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_pin.py")], capture_output=True, text=True)
-    assert r.returncode == 0, "kernel machine code differs from the GPU-checked build:\n" + r.stdout[-3000:]
+    assert r.returncode == 0, "kernels whose machine code has not been through `pytest -m gpu` + the parity gate yet (run a GPU script; it writes the new pin):\n" + r.stdout[-3000:]

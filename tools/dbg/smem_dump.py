@@ -2,7 +2,7 @@
 """Seeding intervals of the library named by SSGPU_LIB (default: the product build) against the oracle's mem_collect_intv on simulated reads
 of the bundled reference: how many reads differ, and for the first few the two lists side by side (start, end, occurrences) -- which pass
 the extra or missing intervals come from is visible from their shape (pass 1: SMEMs; pass 2: inside a long SMEM, more occurrences than
-it; pass 3: min_seed_len-ish seeds with fewer than max_mem_intv occurrences).  Used by tools/dbg/smem_variants.sh on the GPU box.
+it; pass 3: min_seed_len-ish seeds with fewer than max_mem_intv occurrences).  Used on the GPU box with SSGPU_LIB naming a variant library (`make variant`).
 usage: smem_dump.py [n_pairs] [--emu]"""
 import os
 import sys
@@ -23,20 +23,6 @@ def main():
     oidx, gidx = orc.idx_load(common.EXAMPLE_FA), lib.index_load(common.EXAMPLE_FA)
     _, seqs, seq, off = common.sim_reads(n_pairs, 14, 150)
     intv, cnt = lib.smem_batch(gidx, lib.opt_init(), seq, off, cap=96)
-    try:   # diagnostic builds (tools/dbg/kt_variants.sh): counters and the kernel's view of its by-value arguments
-        import ctypes as C
-        f = lib.l.ssg_ktab_dbg_read
-        d = (C.c_ulonglong * 64)()
-        f(d)
-        names = ["site_lanes", "site_pend_none", "site_state_fin", "site_pend_range", "tab_lookups", "tab_differs", "tab_differs_bwd", "tab_differs_fwd", "tab_differs_p3"]
-        print("counters:", " ".join("%s=%d" % (n, d[i]) for i, n in enumerate(names)))
-        opt = lib.opt_init()
-        echo = ["min_seed_len", "split_width", "max_mem_intv", "split_factor_bits", "split_len", "kt_k", "primary", "L2_0", "L2_1", "L2_2", "L2_3", "L2_4", "seq_len", "scap", "cap", "n_reads", "kt_tab", "bwt", "grid", "block", "max_occ", "sa_intv"]
-        print("kernel sees:", " ".join("%s=%d" % (n, d[16 + i]) for i, n in enumerate(echo)))
-        import struct
-        print("host has:    min_seed_len=%d split_width=%d max_mem_intv=%d split_factor_bits=%d max_occ=%d n_reads=%d cap=96" % (int(opt["min_seed_len"][0]), int(opt["split_width"][0]), int(opt["max_mem_intv"][0]), struct.unpack("<I", struct.pack("<f", float(opt["split_factor"][0])))[0], int(opt["max_occ"][0]), len(seqs)))
-    except AttributeError:
-        pass
     bad, tot_g, tot_o, shown = 0, 0, 0, 0
     for r, s in enumerate(seqs):
         o = orc.collect_intv(oidx, s)

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Pins the machine code of the product kernels (gfx950) to the build whose results were checked on the MI355X.
+"""An alarm, not a freeze: the machine code of every ssg_k_* kernel of libssgpu.so (gfx950, all translation units) against the build that
+last passed `pytest -m gpu` and the bench's parity gate on an MI355X (tests/golden/kernel_isa.sha256).
 
-Round 3 had builds whose seeding kernel gave wrong intervals on the GPU while the host emulation of the same source kept agreeing with
-the oracle; they differed from the good build in kernarg layout and register allocation, not in the statements executed, and the cause
-is still open (profiles/r03f_gpu_bisect.log).  The CPU-side suite cannot see such a thing, so it checks the next
-best thing: every ssg_k_* kernel of ssgpu_core.cpp's code object still is, instruction for instruction, the code of the build that last
-passed `pytest -m gpu` and the bench's parity gate (tests/golden/kernel_isa.sha256).  After an intended kernel change: run the GPU suite,
-then `python tools/isa_pin.py --write`.
-usage: isa_pin.py [--write] [--lib speedseq_amd/libssgpu.so]"""
+There is no GPU where the CPU-side suite runs, and this toolchain has compiled source that is right under the host emulation into code
+that is wrong on the GPU (a `continue` out of the middle of the seeding kernel's extension site; round 4 found the
+statement on the MI355X).  A kernel whose code differs from the pin -- because its source changed, or because something else in its
+translation unit did: adding a kernel re-schedules its neighbours -- has not been on a GPU yet; the test says so.  The GPU scripts
+(tools/gpu_r*.sh) write the new pin themselves after the suite and the parity gate are green (`--write --golden gpurun_out/...`), and the file is
+copied into tests/golden/ with the commit that ships those kernels.
+usage: isa_pin.py [--write] [--golden FILE] [--lib speedseq_amd/libssgpu.so]"""
 import hashlib
 import os
 import re
@@ -67,8 +68,10 @@ def current(lib):
     cos = code_objects(lib)
     if not cos:
         raise SystemExit("no gfx950 code object in %s" % lib)
-    best = max((kernel_hashes(c) for c in cos), key=len)                 # ssgpu_core.cpp's unit holds nearly all kernels
-    return best
+    res = {}
+    for c in cos:                                                        # one code object per translation unit (core, index build, seeding, table)
+        res.update(kernel_hashes(c))
+    return res
 
 
 def main():
@@ -76,13 +79,14 @@ def main():
     if "--lib" in sys.argv:
         lib = sys.argv[sys.argv.index("--lib") + 1]
     h = current(lib)
+    golden = sys.argv[sys.argv.index("--golden") + 1] if "--golden" in sys.argv else GOLDEN   # the GPU scripts write the pin themselves once the suite and the parity gate are green
     if "--write" in sys.argv:
-        with open(GOLDEN, "w") as f:
+        with open(golden, "w") as f:
             for k in sorted(h):
                 f.write("%s  %s\n" % (h[k], k))
         print("pinned %d kernels" % len(h))
         return 0
-    want = dict((l.split("  ", 1)[1].strip(), l.split("  ", 1)[0]) for l in open(GOLDEN) if l.strip())
+    want = dict((l.split("  ", 1)[1].strip(), l.split("  ", 1)[0]) for l in open(golden) if l.strip())
     bad = [k for k in want if h.get(k) != want[k]]
     new = [k for k in h if k not in want]
     for k in bad:
@@ -90,7 +94,7 @@ def main():
     for k in new:
         print("NEW (not pinned)", k[:150])
     print("%d pinned kernels, %d changed or missing, %d new" % (len(want), len(bad), len(new)))
-    return 1 if bad else 0
+    return 1 if bad or new else 0
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", ""), r.get("Stream_Id", "")))
 rows.sort()
 short = lambda n: re.sub(r"\(.*", "", n)[:60]
-big = [i for i, r in enumerate(rows) if "ssg_k_smem_quad" in r[2] and r[1] - r[0] > 20e6]
+big = [i for i, r in enumerate(rows) if "ssg_k_smem2" in r[2] and r[1] - r[0] > 20e6]
 i0 = big[-1]
 # the step starts a few small kernels before the SMEM launch (pestat reset etc.): walk back while gaps are < 50 us
 while i0 > 0 and rows[i0][0] - rows[i0 - 1][1] < 50e3 and "ssg_k" in rows[i0 - 1][2]:
