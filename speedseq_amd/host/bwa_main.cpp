@@ -192,8 +192,9 @@ static int main_mem(int argc, char **argv)
 		}
 	};
 	/* SSG_BWA_INFLIGHT = k > 1: k worker threads per device, each on a lane of its own (ssg_set_lane: own stream, own arena), so that the
-	 * upload and download of one call run under the kernels of another; default 1 = the default stream */
-	int inflight = 1; { const char *e = getenv("SSG_BWA_INFLIGHT"); if (e && atoi(e) > 0) inflight = std::min(3, atoi(e)); }
+	 * upload and download of one call run under the kernels of another; default 2 since round 4 (MI355X, 8 M pairs: reads -> records 4.72 -> 4.11 s,
+	 * the three BAMs unchanged; profiles/r04h); 1 = one call at a time on the default stream */
+	int inflight = 2; { const char *e = getenv("SSG_BWA_INFLIGHT"); if (e && atoi(e) > 0) inflight = std::min(3, atoi(e)); }
 	const int n_work = n_dev * inflight;
 	chan_t<std::unique_ptr<batch_t> > to_gpu((size_t)n_work);
 	/* aligned batches wait here for their turn: the formatter takes them in input order whichever device finished first */

@@ -213,7 +213,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	const double tw0 = wall();
 	/* virtual byte offsets of the sorted stream and the block cuts */
 	std::vector<uint64_t> cum(n + 1); cum[0] = 0;
-	parallel_for(threads, n, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) { uint32_t bs; memcpy(&bs, S.rec(perm[i]), 4); cum[i + 1] = 4 + (uint64_t)bs; } });
+	parallel_for((int)std::min<size_t>((size_t)std::max(1, threads), n / 65536 + 1), n, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) { uint32_t bs; memcpy(&bs, S.rec(perm[i]), 4); cum[i + 1] = 4 + (uint64_t)bs; } });
 	for (size_t i = 0; i < n; ++i) cum[i + 1] += cum[i];
 	std::vector<uint64_t> cut; cut.push_back(0);
 	std::vector<size_t> force_blk(force_at ? force_at->size() : 0, 0);   /* block that starts at each forced index */
@@ -232,20 +232,26 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	}
 	const double tw1 = wall();
 	const size_t nb = cut.size() - 1, GRP = 16, ng = (nb + GRP - 1) / GRP;   /* 1 MB of records per work item: a sort of a few hundred blocks still spreads over the pool, and the last items of a large one end together */
-	struct grp_t { std::vector<uint8_t> bytes; std::vector<uint32_t> bsz; bool done; grp_t() : done(false) {} };
+	/* Hand-over between the pool, the writer and the index thread is by atomics and short sleeps, not by one mutex + condition variable: with
+	 * 256 workers waiting on one condition every notify_all of the writer woke them all to fight for the mutex (round 4's first timers:
+	 * 1.98 s of deflate per worker inside 14.5 s of wall, 11.5 s of it `held back'); nobody here waits for long, so polling costs nothing. */
+	struct grp_t { std::vector<uint8_t> bytes; std::vector<uint32_t> bsz; };
 	std::vector<uint64_t> blk_coff(want_off ? nb + 1 : 0);      /* file offset of every block */
 	std::vector<grp_t> grp(ng);
-	std::mutex mu; std::condition_variable cv; size_t next_write = 0; std::atomic<size_t> next_grp(0);
-	const size_t window = (size_t)std::max(4, threads * 3);   /* groups compressed ahead of the writer */
-	std::atomic<long> us_gather(0), us_deflate(0), us_window(0), n_workers_used(0);   /* summed over the workers (SSG_DEBUG) */
+	std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[ng ? ng : 1]);
+	for (size_t g = 0; g < ng; ++g) done[g].store(0, std::memory_order_relaxed);
+	std::atomic<size_t> next_write(0), next_grp(0);
+	const int n_workers = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
+	const size_t window = std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
+	auto nap = [](int us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); };
+	std::atomic<long> us_gather(0), us_deflate(0), us_window(0);   /* summed over the workers (SSG_DEBUG) */
 	auto worker = [&]() {
 		std::vector<uint8_t> payload(BGZF_MAX_PAYLOAD), blk(65536);
-		long my_g = 0, my_d = 0, my_w = 0; bool used = false;
+		long my_g = 0, my_d = 0, my_w = 0;
 		for (;;) {
 			const size_t g = next_grp.fetch_add(1);
 			if (g >= ng) break;
-			used = true;
-			{ const double t0 = wall(); std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return g < next_write + window; }); my_w += (long)((wall() - t0) * 1e6); }
+			if (g >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g >= next_write.load(std::memory_order_acquire) + window) nap(200); my_w += (long)((wall() - t0) * 1e6); }
 			std::vector<uint8_t> ob; ob.reserve(GRP * (lvl ? 24576 : 65536));
 			std::vector<uint32_t> bsz;
 			for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
@@ -258,16 +264,16 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 				ob.insert(ob.end(), blk.data(), blk.data() + k); bsz.push_back((uint32_t)k);
 				my_g += (long)((t1 - t0) * 1e6); my_d += (long)((wall() - t1) * 1e6);
 			}
-			{ std::lock_guard<std::mutex> l(mu); grp[g].bytes.swap(ob); grp[g].bsz.swap(bsz); grp[g].done = true; }
-			cv.notify_all();
+			grp[g].bytes.swap(ob); grp[g].bsz.swap(bsz);
+			done[g].store(1, std::memory_order_release);
 		}
-		us_gather += my_g; us_deflate += my_d; us_window += my_w; if (used) ++n_workers_used;
+		us_gather += my_g; us_deflate += my_d; us_window += my_w;
 	};
 	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets), built by a thread of
 	 * its own that follows the writer: a record's virtual offset is known as soon as the group holding its block has its file offset */
 	struct ent_t { int32_t tid, pos, end; uint8_t mapped; };
 	std::vector<ent_t> ent(bai_path ? n : 0);
-	if (bai_path) parallel_for(threads, n, [&](size_t a, size_t b, int) {
+	if (bai_path) parallel_for((int)std::min<size_t>((size_t)threads, n / 65536 + 1), n, [&](size_t a, size_t b, int) {
 		for (size_t i = a; i < b; ++i) { const uint8_t *r = S.rec(perm[i]) + 4; bam_core_t c; memcpy(&c, r, 32); ent[i].tid = c.tid; ent[i].pos = c.pos; ent[i].end = bam_endpos(r); ent[i].mapped = !((c.flag_nc >> 16) & 4); }
 	});
 	std::atomic<size_t> blocks_placed(0);                       /* blk_coff[0 .. blocks_placed) are final */
@@ -276,7 +282,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	std::thread t_idx;
 	if (bai_path) t_idx = std::thread([&]() {
 		size_t bk = 0;
-		auto wait_blocks = [&](size_t need) { if (blocks_placed.load(std::memory_order_acquire) >= need) return; const double t0 = wall(); std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return blocks_placed.load(std::memory_order_acquire) >= need; }); t_idx_wait += wall() - t0; };
+		auto wait_blocks = [&](size_t need) { if (blocks_placed.load(std::memory_order_acquire) >= need) return; const double t0 = wall(); while (blocks_placed.load(std::memory_order_acquire) < need) nap(100); t_idx_wait += wall() - t0; };
 		auto voff = [&](size_t i) -> uint64_t { while (cut[bk + 1] <= cum[i]) ++bk; wait_blocks(bk + 1); return blk_coff[bk] << 16 | (cum[i] - cut[bk]); };
 		auto end_of_file = [&]() -> uint64_t { wait_blocks(nb + 1); return file_end_v.load(); };
 		const uint64_t first = n ? voff(0) : end_of_file();
@@ -288,16 +294,17 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		if (idx_ok) idx.finish(end_of_file());
 	});
 	std::vector<std::thread> th;
-	for (int t = 0; t < std::max(1, threads); ++t) th.emplace_back(worker);
+	const double tw_spawn0 = wall();
+	for (int t = 0; t < n_workers; ++t) th.emplace_back(worker);
 	uint64_t coff = (uint64_t)(hdr_end > 0 ? hdr_end : 0);
 	double t_wr_wait = 0, t_wr_io = 0; const double tw_spawn = wall();
 	for (size_t g = 0; g < ng; ++g) {
-		std::vector<uint8_t> ob; std::vector<uint32_t> bsz;
-		{ const double t0 = wall(); std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return grp[g].done; }); ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz); t_wr_wait += wall() - t0; }
+		if (!done[g].load(std::memory_order_acquire)) { const double t0 = wall(); while (!done[g].load(std::memory_order_acquire)) nap(50); t_wr_wait += wall() - t0; }
+		std::vector<uint8_t> ob; std::vector<uint32_t> bsz; ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz);
 		{ const double t0 = wall(); io_write_all(fd, ob.data(), ob.size()); t_wr_io += wall() - t0; }
 		if (want_off) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }
-		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; if (bai_path) blocks_placed.store(std::min(nb, (g + 1) * GRP), std::memory_order_release); }
-		cv.notify_all();
+		next_write.store(g + 1, std::memory_order_release);
+		if (bai_path) blocks_placed.store(std::min(nb, (g + 1) * GRP), std::memory_order_release);
 	}
 	for (auto &x : th) x.join();
 	if (force_at) {   /* a run: no end-of-file block; the offsets of its segments (indices at n = the end of the data) */
@@ -308,13 +315,12 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	}
 	io_write_all(fd, BGZF_EOF, 28);
 	const double tw2 = wall();
-	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index + thread start %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
-	                   "%ld workers with work, per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn - tw1, t_wr_wait, t_wr_io,
-	                   n_workers_used.load(), us_gather / 1e6 / std::max(1L, n_workers_used.load()), us_deflate / 1e6 / std::max(1L, n_workers_used.load()), us_window / 1e6 / std::max(1L, n_workers_used.load()));
+	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index %.2f s, %d workers started in %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
+	                   "per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn0 - tw1, n_workers, tw_spawn - tw_spawn0, t_wr_wait, t_wr_io,
+	                   us_gather / 1e6 / n_workers, us_deflate / 1e6 / n_workers, us_window / 1e6 / n_workers);
 	if (!bai_path) return;
 	blk_coff[nb] = coff;
-	{ std::lock_guard<std::mutex> l(mu); file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release); }
-	cv.notify_all();
+	file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release);
 	t_idx.join();
 	if (!idx_ok) return;
 	idx.save(bai_path);

@@ -90,17 +90,21 @@ def main():
         rep = dict(zip(("pairs", "dups", "discordant_pairs", "splitter_lines"), map(int, m.groups()))) if m else {}
         out["samblaster_reported"] = rep
         if os.path.exists(samtools):
+            from concurrent.futures import ThreadPoolExecutor   # the five passes over the BAMs side by side: each is one samtools thread
             def count(bam, *flt):
                 return int(subprocess.check_output([samtools, "view", "-c"] + list(flt) + [bam]))
             main_bam = r["out"] + ".bam"
-            chk = {"primary_records": count(main_bam, "-F", "0x900"), "dup_flagged_primaries": count(main_bam, "-f", "0x400", "-F", "0x900"),
-                   "discordant_records": count(r["out"] + ".discordants.bam"), "splitter_records": count(r["out"] + ".splitters.bam")}
+            with ThreadPoolExecutor(5) as ex:
+                f = {"primary_records": ex.submit(count, main_bam, "-F", "0x900"), "dup_flagged_primaries": ex.submit(count, main_bam, "-f", "0x400", "-F", "0x900"),
+                     "discordant_records": ex.submit(count, r["out"] + ".discordants.bam"), "splitter_records": ex.submit(count, r["out"] + ".splitters.bam")}
+                srt_f = ex.submit(subprocess.run, "%s view %s | cut -f3,4 | awk 'BEGIN{ok=1} { if ($1==c && $2<p) ok=0; c=$1; p=$2 } END{print ok}'" % (samtools, main_bam), shell=True, capture_output=True, text=True)
+                chk = {k: v.result() for k, v in f.items()}
+                srt = srt_f.result()
             out["bam_counts"] = chk
             ok = chk["primary_records"] == 2 * a.pairs
             if rep:
                 ok = ok and chk["dup_flagged_primaries"] == 2 * rep["dups"] and chk["discordant_records"] == 2 * rep["discordant_pairs"] and chk["splitter_records"] == rep["splitter_lines"]
             out["invariants_ok"] = bool(ok)
-            srt = subprocess.run("%s view %s | cut -f3,4 | awk 'BEGIN{ok=1} { if ($1==c && $2<p) ok=0; c=$1; p=$2 } END{print ok}'" % (samtools, main_bam), shell=True, capture_output=True, text=True)
             out["positions_nondecreasing_within_contig"] = srt.stdout.strip() == "1"
     print(json.dumps(out))
     td_obj.cleanup()
