@@ -232,6 +232,15 @@ int ssg_prof_get(int cap, const char **name, double *ms, long *launches);
 
 void ssg_free(void *p);
 
+/* ---- BGZF deflate on the device (row f1; htslib bgzf.c:298-342 is the format's writer in the reference) ----
+ * Block b's payload is payload[cut[b] .. cut[b+1]) (<= 0xff00 bytes, as bgzf_write cuts them); its raw deflate stream (RFC 1951, one final
+ * block; stored when it would not shrink) lands at out[out_off[b] .. out_off[b+1]).  The caller frames it: 18-byte BGZF header with the
+ * block size, CRC-32 and ISIZE of the payload.  out_cap: bytes available at out (the sum of the payloads + 5 per block always suffices).
+ * Host buffers; page-locked ones (ssg_host_alloc) travel at bus speed. */
+int ssg_bgzf_deflate(const uint8_t *payload, const uint64_t *cut, long n_blocks, uint8_t *out, uint64_t out_cap, uint64_t *out_off);
+void *ssg_host_alloc(size_t n);
+void ssg_host_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

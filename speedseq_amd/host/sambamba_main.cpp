@@ -241,10 +241,21 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[ng ? ng : 1]);
 	for (size_t g = 0; g < ng; ++g) done[g].store(0, std::memory_order_relaxed);
 	std::atomic<size_t> next_write(0), next_grp(0);
-	const int n_workers = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
-	const size_t window = std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
+	/* blocks deflated on the device: the final file of a sort at a compressing level, when there is a device (SSG_BGZF_DEVICE=0 keeps zlib on the
+	 * host's threads; the host emulation of the kernels only does it on request, it is slow) */
+	const char *const bd = getenv("SSG_BGZF_DEVICE");
+	const bool use_dev = !force_at && lvl != 0 && nb > 0 && !(bd && !strcmp(bd, "0")) && (bd || strcmp(ssg_backend(), "emu") != 0) && ssg_device_count() > 0 && GRP * 2 <= 2048 && 2048 % GRP == 0;
+	const int n_workers = use_dev ? 0 : (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
+	const size_t window = use_dev ? (size_t)8 * 2048 / GRP : std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
 	auto nap = [](int us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); };
 	std::atomic<long> us_gather(0), us_deflate(0), us_window(0);   /* summed over the workers (SSG_DEBUG) */
+	/* payload of block bk (records cut[bk] .. cut[bk+1] of the sorted stream, a record larger than a block split over several) into dst */
+	auto gather_block = [&](size_t bk, uint8_t *dst) -> size_t {
+		const uint64_t v0 = cut[bk], v1 = cut[bk + 1];
+		size_t i = (size_t)(std::upper_bound(cum.begin(), cum.end(), v0) - cum.begin()) - 1; size_t w = 0;
+		for (uint64_t v = v0; v < v1; ++i) { const uint8_t *r = S.rec(perm[i]); const uint64_t a = v - cum[i], e = std::min(cum[i + 1], v1) - cum[i]; memcpy(dst + w, r + a, (size_t)(e - a)); w += (size_t)(e - a); v = cum[i] + e; }
+		return w;
+	};
 	auto worker = [&]() {
 		std::vector<uint8_t> payload(BGZF_MAX_PAYLOAD), blk(65536);
 		long my_g = 0, my_d = 0, my_w = 0;
@@ -255,10 +266,8 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 			std::vector<uint8_t> ob; ob.reserve(GRP * (lvl ? 24576 : 65536));
 			std::vector<uint32_t> bsz;
 			for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
-				const uint64_t v0 = cut[bk], v1 = cut[bk + 1];
-				size_t i = (size_t)(std::upper_bound(cum.begin(), cum.end(), v0) - cum.begin()) - 1; size_t w = 0;
 				const double t0 = wall();
-				for (uint64_t v = v0; v < v1; ++i) { const uint8_t *r = S.rec(perm[i]); const uint64_t a = v - cum[i], e = std::min(cum[i + 1], v1) - cum[i]; memcpy(payload.data() + w, r + a, (size_t)(e - a)); w += (size_t)(e - a); v = cum[i] + e; }
+				const size_t w = gather_block(bk, payload.data());
 				const double t1 = wall();
 				const size_t k = bgzf_make_block(payload.data(), w, lvl, blk.data());
 				ob.insert(ob.end(), blk.data(), blk.data() + k); bsz.push_back((uint32_t)k);
@@ -267,6 +276,54 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 			grp[g].bytes.swap(ob); grp[g].bsz.swap(bsz);
 			done[g].store(1, std::memory_order_release);
 		}
+		us_gather += my_g; us_deflate += my_d; us_window += my_w;
+	};
+	/* ... or the blocks are deflated on the device (ssg_bgzf_deflate, k_bgzf.h): a few producer threads, each with a stream of its own, take
+	 * batches of 2048 blocks in turn -- gather into page-locked memory + CRC-32 by host threads, deflate on the GPU, framing (BGZF header,
+	 * CRC, ISIZE) -- and hand the groups to the same in-order writer.  The host's cores, which the deflate of a whole genome's records kept busy
+	 * for longer than the alignment took, only copy and checksum. */
+	const size_t DEV_BATCH = 2048;
+	const int n_prod = use_dev ? (int)std::max<size_t>(1, std::min<size_t>(3, (nb + DEV_BATCH - 1) / DEV_BATCH)) : 0;
+	std::atomic<int> dev_failed(0);
+	auto producer = [&](int t) {
+		if (ssg_set_lane(1 + t)) { dev_failed = 1; return; }
+		const int gth = std::max(1, threads / std::max(1, n_prod));
+		uint8_t *P = (uint8_t*)ssg_host_alloc(DEV_BATCH * BGZF_MAX_PAYLOAD + 64), *O = (uint8_t*)ssg_host_alloc(DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64);
+		std::vector<uint64_t> rel(DEV_BATCH + 1), off(DEV_BATCH + 1); std::vector<uint32_t> crc(DEV_BATCH);
+		long my_g = 0, my_d = 0, my_w = 0;
+		for (size_t b0 = (size_t)t * DEV_BATCH; b0 < nb && P && O && !dev_failed.load(); b0 += (size_t)n_prod * DEV_BATCH) {
+			const size_t b1 = std::min(nb, b0 + DEV_BATCH), n_b = b1 - b0, g0 = b0 / GRP, g1 = (b1 + GRP - 1) / GRP;
+			if (g0 >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g0 >= next_write.load(std::memory_order_acquire) + window) nap(200); my_w += (long)((wall() - t0) * 1e6); }
+			const double t0 = wall();
+			for (size_t k = 0; k <= n_b; ++k) rel[k] = cut[b0 + k] - cut[b0];
+			parallel_for((int)std::min<size_t>((size_t)gth, n_b / 8 + 1), n_b, [&](size_t a, size_t e, int) {
+				for (size_t k = a; k < e; ++k) { const size_t w = gather_block(b0 + k, P + rel[k]); crc[k] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), P + rel[k], (uInt)w); }
+			});
+			const double t1 = wall();
+			if (ssg_bgzf_deflate(P, rel.data(), (long)n_b, O, (uint64_t)DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64, off.data())) { fprintf(stderr, "[sambamba] sort: BGZF deflate on the device failed: %s\n", ssg_last_error()); dev_failed = 1; break; }
+			const double t2 = wall();
+			parallel_for((int)std::min<size_t>((size_t)std::min(gth, 8), g1 - g0), g1 - g0, [&](size_t a, size_t e, int) {
+				static const uint8_t hdr[16] = { 0x1f,0x8b,0x08,0x04,0,0,0,0,0,0xff,0x06,0,0x42,0x43,0x02,0 };
+				for (size_t g = g0 + a; g < g0 + e; ++g) {
+					std::vector<uint8_t> ob; std::vector<uint32_t> bsz;
+					for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
+						const size_t k = bk - b0, clen = (size_t)(off[k + 1] - off[k]), bsize = 18 + clen + 8, at = ob.size();
+						ob.resize(at + bsize);
+						uint8_t *d = ob.data() + at;
+						memcpy(d, hdr, 16); d[16] = (uint8_t)((bsize - 1) & 0xff); d[17] = (uint8_t)((bsize - 1) >> 8);
+						memcpy(d + 18, O + off[k], clen);
+						const uint32_t isz = (uint32_t)(rel[k + 1] - rel[k]);
+						memcpy(d + 18 + clen, &crc[k], 4); memcpy(d + 18 + clen + 4, &isz, 4);
+						bsz.push_back((uint32_t)bsize);
+					}
+					grp[g].bytes.swap(ob); grp[g].bsz.swap(bsz);
+					done[g].store(1, std::memory_order_release);
+				}
+			});
+			my_g += (long)((t1 - t0) * 1e6); my_d += (long)((t2 - t1) * 1e6); (void)my_w;
+		}
+		if (!P || !O) dev_failed = 1;
+		ssg_host_free(P); ssg_host_free(O);
 		us_gather += my_g; us_deflate += my_d; us_window += my_w;
 	};
 	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets), built by a thread of
@@ -296,10 +353,11 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	std::vector<std::thread> th;
 	const double tw_spawn0 = wall();
 	for (int t = 0; t < n_workers; ++t) th.emplace_back(worker);
+	for (int t = 0; t < n_prod; ++t) th.emplace_back(producer, t);
 	uint64_t coff = (uint64_t)(hdr_end > 0 ? hdr_end : 0);
 	double t_wr_wait = 0, t_wr_io = 0; const double tw_spawn = wall();
 	for (size_t g = 0; g < ng; ++g) {
-		if (!done[g].load(std::memory_order_acquire)) { const double t0 = wall(); while (!done[g].load(std::memory_order_acquire)) nap(50); t_wr_wait += wall() - t0; }
+		if (!done[g].load(std::memory_order_acquire)) { const double t0 = wall(); while (!done[g].load(std::memory_order_acquire)) { if (dev_failed.load()) die("sort: cannot compress the output on the device (SSG_BGZF_DEVICE=0 uses the host)"); nap(50); } t_wr_wait += wall() - t0; }
 		std::vector<uint8_t> ob; std::vector<uint32_t> bsz; ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz);
 		{ const double t0 = wall(); io_write_all(fd, ob.data(), ob.size()); t_wr_io += wall() - t0; }
 		if (want_off) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }
@@ -317,7 +375,8 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	const double tw2 = wall();
 	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index %.2f s, %d workers started in %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
 	                   "per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn0 - tw1, n_workers, tw_spawn - tw_spawn0, t_wr_wait, t_wr_io,
-	                   us_gather / 1e6 / n_workers, us_deflate / 1e6 / n_workers, us_window / 1e6 / n_workers);
+	                   us_gather / 1e6 / std::max(1, n_workers + n_prod), us_deflate / 1e6 / std::max(1, n_workers + n_prod), us_window / 1e6 / std::max(1, n_workers + n_prod));
+	if (dbg() && use_dev) fprintf(stderr, "[sambamba] sort: write: blocks deflated on the device (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_prod);
 	if (!bai_path) return;
 	blk_coff[nb] = coff;
 	file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release);

@@ -114,8 +114,17 @@ def test_sambamba_emu_matches_samtools(tmp_path, emu_lib, monkeypatch):
     _check([os.path.join(ROOT, "tests", "emu", "sambamba_emu")], tmp_path, monkeypatch)
 
 
+def test_sambamba_emu_device_deflate_matches_samtools(tmp_path, emu_lib, monkeypatch):
+    """the sorted file's BGZF blocks deflated by the device kernel (k_bgzf.h; the emulation only does so on request): the reference's
+    samtools must read the file -- records, order, index, region queries -- exactly as it reads the zlib-written one"""
+    monkeypatch.setenv("SSG_BGZF_DEVICE", "1")
+    _check([os.path.join(ROOT, "tests", "emu", "sambamba_emu")], tmp_path, monkeypatch)
+
+
 @pytest.mark.gpu
-def test_sambamba_gpu_matches_samtools(tmp_path, gpu_lib, monkeypatch):
+@pytest.mark.parametrize("device_deflate", ["1", "0"])
+def test_sambamba_gpu_matches_samtools(tmp_path, gpu_lib, monkeypatch, device_deflate):
+    monkeypatch.setenv("SSG_BGZF_DEVICE", device_deflate)   # 1: the default on a GPU (k_bgzf.h); 0: zlib on the host's threads
     _check([os.path.join(ROOT, "bin", "sambamba")], tmp_path, monkeypatch)
 
 
