@@ -16,6 +16,11 @@
  * touch on purpose (the translation unit the kernel sat in, two unused arguments).  The uniform form of the same statements is right in
  * every build that was tried.
  *
+ * Order of the passes: upstream runs bwt_seed_strategy1 (pass 3) last; here it runs FIRST.  The passes only append to the read's list, pass 2
+ * reads pass 1's entries alone, and the list is sorted by (start, end) afterwards, so the order of appending is free -- and pass 3 is a plain
+ * chain of ~150 extensions that never makes a read heavy: done first, its seeds survive when the read is given up in pass 1 or 2, and the
+ * wave-per-read kernel, whose time is dependent round trips, does not walk that chain again.
+ *
  * Per-read budget: a read whose extensions exceed `max_ext', or whose forward pass leaves a row of more than `max_row' intervals, is given up (out_n = -2, nothing of it is kept) and the caller hands it to the
  * wave-per-read kernel: a repeat-heavy read costs 10-50x the average, every one of its extensions is a dependent round trip, and a lane
  * that picked one up late used to hold the whole launch open long after the pool of reads had run dry.
@@ -95,7 +100,11 @@ SSG_DEVFN unsigned long long s2_wave_read(const ssg_index_view_t &ix, const ssg_
 	for (int b = lane; b < len; b += 64) qb[b] = q[b];
 	ssg_wave_ldssync();
 	ssg_intv_t *const mem = out_intv + (long)it * cap;
-	int mem_n = 0, ovf = 0;
+	/* what the lane kernel left: out_n = -2: nothing; -3 - k: the third pass is done, its k seeds are the list's first entries (k <= cap: it would have reported an overflow otherwise) */
+	const int left = -2 - out_n[it];
+	const bool skip_p3 = left >= 1;
+	const int n_p3 = skip_p3 ? left - 1 : 0;
+	int mem_n = n_p3, ovf = 0;
 	/* one call of upstream bwt_smem1a (max_intv = 0): start sx, smallest occurrence count min_intv; returns where the next call starts */
 	auto smem1 = [&](const int sx, uint64_t min_intv) -> int {
 		if (min_intv < 1) min_intv = 1;
@@ -160,7 +169,7 @@ SSG_DEVFN unsigned long long s2_wave_read(const ssg_index_view_t &ix, const ssg_
 		while (x < len) { if (wv_uni((int)qb[x]) < 4) x = smem1(x, 1); else ++x; }   /* pass 1 */
 		const int old_n = mem_n < cap ? mem_n : cap;
 		ssg_wave_memsync();
-		for (int k = 0; k < old_n; ++k) {   /* pass 2: re-seed from the middle of long SMEMs with few occurrences */
+		for (int k = n_p3; k < old_n; ++k) {   /* pass 2: re-seed from the middle of long SMEMs with few occurrences */
 			const ssg_intv_t m = wv_uni_intv(mem[k]);
 			const int start = (int)(m.info >> 32), end = (int)(uint32_t)m.info;
 			if (end - start >= split_len && m.x2 <= (uint64_t)opt.split_width) {
@@ -168,7 +177,7 @@ SSG_DEVFN unsigned long long s2_wave_read(const ssg_index_view_t &ix, const ssg_
 				if (wv_uni((int)qb[sx]) < 4) (void)smem1(sx, m.x2 + 1);
 			}
 		}
-		if (opt.max_mem_intv > 0) {   /* pass 3: upstream bwt_seed_strategy1 from every position it returns */
+		if (opt.max_mem_intv > 0 && !skip_p3) {   /* pass 3: upstream bwt_seed_strategy1 from every position it returns */
 			x = 0;
 			while (x < len) {
 				if (wv_uni((int)qb[x]) > 3) ++x;
@@ -197,17 +206,67 @@ SSG_DEVFN unsigned long long s2_wave_read(const ssg_index_view_t &ix, const ssg_
 	return nx;
 }
 
+/* ---- table of the intervals of all short patterns (ssg_index.ktab) ----
+ * The bidirectional interval of a pattern does not depend on the order in which the pattern was extended to, so the intervals of ALL patterns
+ * of 1..K bases can be tabulated once per index: 16 bytes each (x0, x1, x2 in 40 bits), level j (4^j entries, little-endian base-4 pattern
+ * code: first base least significant) after the levels below it -- 1.4 GB for K = 13 on a human-size index, built in ~20 ms.  A bwt_extend
+ * whose RESULT pattern has at most K bases then is one 16-byte load at an address that depends only on the read, instead of two rank blocks
+ * (2.5 loads each) and the popcounts; roughly four extensions in ten of a 150-base read are that short. */
+SSG_DEVFN long s2_ktab_off(int j) { return (long)(((1ull << (2 * j)) - 4ull) / 3ull); }   /* entries of the levels below j */
+/* level j from level j - 1: the four one-base left extensions of every pattern by upstream's own bwt_extend (is_back = 1): an entry is bit for
+ * bit what the extension it stands in for returns.  Children of pattern code p are 4p .. 4p + 3. */
+__global__ void ssg_k_ktab_level(ssg_index_view_t ix, int j, ssg_pk2_t *tab)
+{
+	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= (1L << (2 * (j - 1)))) return;
+	ssg_pk2_t *const out = tab + s2_ktab_off(j) + 4 * p;
+	ssg_intv_t ok[4];
+	if (j == 1) { for (int c = 0; c < 4; ++c) s2_set_intv(ix, c, ok[c]); }
+	else ssg_bwt_extend(ix, s2_unpk(tab[s2_ktab_off(j - 1) + p]), ok, 1);
+	for (int c = 0; c < 4; ++c) { ok[c].info = 0; out[c] = s2_pk(ok[c]); }
+}
+/* self-check (SSG_KTAB_VERIFY=1): every `stride'-th pattern of level j once more, the way the seeding kernel reaches it without the table --
+ * from its first base by forward extensions with the kernel's own ssg_bwt_extend1_lean -- and compared */
+__global__ void ssg_k_ktab_verify(ssg_index_view_t ix, int j, long stride, const ssg_pk2_t *tab, unsigned long long *bad)
+{
+	const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, code = t * stride;
+	if (code >= (1L << (2 * j))) return;
+	ssg_intv_t ik;
+	s2_set_intv(ix, (int)(code & 3), ik);
+	for (int k = 1; k < j; ++k) ik = ssg_bwt_extend1_lean(ix, ik, 3 - (int)((code >> (2 * k)) & 3), 0);
+	const ssg_intv_t e = s2_unpk(tab[s2_ktab_off(j) + code]);
+	if (ik.x2 != e.x2 || (ik.x2 && (ik.x0 != e.x0 || ik.x1 != e.x1))) atomicAdd(&bad[j], 1ull);
+}
+/* the 16 codes from position b of a read held as 4-bit codes, 8 per LDS word (word w of the read at qw[w * stride]), first base lowest */
+SSG_DEVFN uint64_t s2_window(const uint32_t *qw, int stride, int b)
+{
+	const int w0 = b >> 3, sh = (b & 7) << 2;
+	const int w1 = w0 + 1 < SSG_S2_QWORDS ? w0 + 1 : SSG_S2_QWORDS - 1, w2 = w0 + 2 < SSG_S2_QWORDS ? w0 + 2 : SSG_S2_QWORDS - 1;
+	uint64_t v = ((uint64_t)qw[w0 * stride] | (uint64_t)qw[w1 * stride] << 32) >> sh;
+	if (sh) v |= (uint64_t)qw[w2 * stride] << (64 - sh);
+	return v;
+}
+/* table code of the n <= 15 unambiguous bases from position b */
+SSG_DEVFN uint32_t s2_code(const uint32_t *qw, int stride, int b, int n)
+{
+	uint64_t v = s2_window(qw, stride, b);
+	v &= 0x3333333333333333ull; v = (v | v >> 2) & 0x0f0f0f0f0f0f0f0full; v = (v | v >> 4) & 0x00ff00ff00ff00ffull;
+	v = (v | v >> 8) & 0x0000ffff0000ffffull; v = (v | v >> 16) & 0xffffffffull;
+	return (uint32_t)v & ((1u << (2 * n)) - 1u);
+}
+
 /*
  * seq: concatenated nt4 codes, off[r]..off[r+1] delimit read r.  out_intv: [n_reads x cap]; out_n: per-read interval count (-1: the
- * per-read capacity or a work list overflowed, -2: given up at max_ext extensions).  scratch: per launched wave 2 lists x scap entries x
+ * per-read capacity or a work list overflowed; -2: given up; -3 - k: given up with the k seeds of the finished third pass in place).  scratch: per launched wave 2 lists x scap entries x
  * 64 lanes of 16 bytes, entry e of lane l at [e * 64 + l] (lanes pushing their e-th entries together write one 1-KB span).
  * next_read: shared counter the lanes take their reads from (evens out the per-read cost).  n_ext_read (optional): extensions per read.
  * heavy_ids / n_heavy (optional): the given-up reads, appended in no particular order, for ssg_k_smem_heavy (launched behind this kernel).
  */
-template <bool TUNE>
+template <bool TUNE, bool KT>
 __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap,
-                           ssg_pk2_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, unsigned int max_ext, int max_row, uint32_t *n_ext_read, int32_t *heavy_ids, unsigned int *n_heavy)
+                           ssg_pk2_t *scratch, int scap, unsigned long long *n_extend, unsigned int *next_read, unsigned int max_ext, int max_row, uint32_t *n_ext_read, int32_t *heavy_ids, unsigned int *n_heavy,
+                           const ssg_pk2_t *kt_tab, int kt_k /* KT: the table of short-pattern intervals, kt_k < min_seed_len */)
 {
 	__shared__ uint32_t qlds[SSG_S2_QWORDS * 64];
 	const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,7 +280,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 	unsigned int rd_nx = 0;          /* extensions of the current read */
 	long it = 0;
 	int state = S2_READ, pend = S2_PEND_NONE;
-	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0, heavy = 0;
+	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0, heavy = 0, n_p3 = -1;   /* n_p3 < 0: the third pass is not finished */
 	ssg_intv_t *mem = 0;
 	int sx = 0, i = 0, j = 0, curr_n = 0, prev_n = 0, prev_rev = 0, flip = 0, m1_n = 0, m1_last_beg = 0, ret = 0, e_c = 0;
 	uint64_t min_intv = 1, last_x2 = 0;
@@ -233,7 +292,22 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
 #define S2_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = s2_pk(ik); state = S2_BWD; if (prev_n > max_row) { heavy = 1; state = S2_OUT; } } while (0)
 	/* next start of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
-#define S2_P3START() do { while (x < len && S2Q(x) > 3) ++x; if (x >= len) state = S2_OUT; else { s2_set_intv(ix, S2Q(x), ik); i = x + 1; state = S2_P3F; } } while (0)
+#define S2_P3END() do { n_p3 = mem_n; x = 0; state = S2_P1; } while (0)   /* the third pass runs FIRST here (see the kernel's comment): on to pass 1 */
+/* With the table the first kt_k - 1 extensions of a start collapse into one look-up: upstream records nothing before the pattern has min_seed_len
+ * (> kt_k) bases, so only an ambiguous base or the read's end inside the window matters -- the start then moves past it exactly as upstream's
+ * loop returns, one window per trip (state S2_P3 comes back here); the skipped bwt_extend calls still count as the algorithm's. */
+#define S2_P3START() do { \
+		while (x < len && S2Q(x) > 3) ++x; \
+		if (x >= len) S2_P3END(); \
+		else if (!KT || kt_k < 2) { s2_set_intv(ix, S2Q(x), ik); i = x + 1; state = S2_P3F; } \
+		else { \
+			const unsigned long long nm_ = s2_window(ql_, 64, x) & 0x4444444444444444ull; \
+			int run_ = nm_ ? (int)((__ffsll(nm_) - 1) >> 2) : 16; \
+			run_ = run_ > len - x ? len - x : run_; \
+			if (run_ >= kt_k) { ik = s2_unpk(kt_tab[s2_ktab_off(kt_k) + (long)s2_code(ql_, 64, x, kt_k)]); i = x + kt_k; my_nx += (unsigned long long)(kt_k - 1); rd_nx += (unsigned int)(kt_k - 1); state = S2_P3F; } \
+			else { my_nx += (unsigned long long)(run_ - 1); rd_nx += (unsigned int)(run_ - 1); if (x + run_ >= len) S2_P3END(); else { x += run_ + 1; state = S2_P3; } } \
+		} \
+	} while (0)
 #define S2_RET() do { if (caller == 1) { x = ret; state = S2_P1; } else { ++k; state = S2_P2; } } while (0)
 	/* an SMEM leaves the backward pass: upstream keeps it when it starts left of the previous one of the call; the caller's length filter applied here */
 #define S2_EMIT(pp, beg) do { if (m1_n == 0 || (beg) < m1_last_beg) { ++m1_n; m1_last_beg = (beg); \
@@ -261,7 +335,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 					}
 				}
 			} else if (state == S2_P3F) {
-				if (i >= len) { x = len; state = S2_OUT; }
+				if (i >= len) S2_P3END();
 				else if (S2Q(i) < 4) { pend = S2_PEND_P3; e_c = 3 - S2Q(i); }
 				else { x = i + 1; S2_P3START(); }
 			} else if (state == S2_READ) {
@@ -294,14 +368,15 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 						}
 					}
 					x = 0;
-					state = len >= opt.min_seed_len ? S2_P1 : S2_OUT;
+					n_p3 = opt.max_mem_intv > 0 ? -1 : 0;
+					state = len < opt.min_seed_len ? S2_OUT : opt.max_mem_intv > 0 ? S2_P3 : S2_P1;
 				}
 			} else if (state == S2_P1) {
-				if (x >= len) { old_n = mem_n < cap ? mem_n : cap; k = 0; state = S2_P2; }
+				if (x >= len) { old_n = mem_n < cap ? mem_n : cap; k = n_p3 > 0 ? n_p3 : 0; state = S2_P2; }
 				else if (S2Q(x) > 3) ++x;
 				else { sx = x; min_intv = 1; caller = 1; state = S2_FWD; m1_n = 0; curr_n = 0; i = sx + 1; s2_set_intv(ix, S2Q(sx), ik); ik.info = (uint64_t)(sx + 1); }
 			} else if (state == S2_P2) { /* re-seed from the middle of long SMEMs with few occurrences */
-				if (k >= old_n) { x = 0; state = opt.max_mem_intv > 0 ? S2_P3 : S2_OUT; }
+				if (k >= old_n) state = S2_OUT;
 				else {
 					const ssg_intv_t m = mem[k];
 					const int start = (int)(m.info >> 32), end = (int)(uint32_t)m.info;
@@ -316,8 +391,8 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 				S2_P3START();
 			} else { /* S2_OUT */
 				const bool given_up = heavy != 0;
-				out_n[it] = given_up ? -2 : ovf ? -1 : mem_n;
-				if (given_up && heavy_ids) heavy_ids[atomicAdd(n_heavy, 1u)] = (int32_t)it;
+				out_n[it] = ovf ? -1 : given_up ? (n_p3 < 0 ? -2 : -3 - n_p3) : mem_n;   /* given up: the seeds of a finished third pass (the list's first n_p3 entries) stay */
+				if (given_up && !ovf && heavy_ids) heavy_ids[atomicAdd(n_heavy, 1u)] = (int32_t)it;
 				if (given_up) my_nx -= rd_nx;   /* n_extend counts the algorithm's extensions (upstream's own count): the wave kernel counts this read's */
 				if (n_ext_read) n_ext_read[it] = rd_nx;
 				if (TUNE) { S2_STAT_ADD(8 + (64 - __clzll((unsigned long long)(rd_nx | 1u))), 1); if (given_up) S2_STAT_ADD(3, 1); }
@@ -326,6 +401,11 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 		}
 		if (TUNE) { const unsigned long long rdy = wv_ballot(pend != S2_PEND_NONE), alv = wv_ballot(state != S2_FIN); if (lane == 0) { S2_STAT_ADD(48, 1); S2_STAT_ADD(49, __popcll(rdy)); S2_STAT_ADD(50, __popcll(alv)); } }
 		if (!wv_ballot(state != S2_FIN)) break;   /* the only exit: no lane of the wave has work */
+		/* the pattern an extension ends with: [i, end of p) going left, [start, i] going right; up to kt_k bases its interval is in the table.  The two
+		 * ways are separate passes for the wave and each is skipped when no lane wants it (the ballots stand where every lane passes) */
+		const int pat_b = pend == S2_PEND_BWD ? i : pend == S2_PEND_FWD ? sx : x, pat_n = (pend == S2_PEND_BWD ? (int)p.info : i + 1) - pat_b;
+		const bool by_table = KT && pend != S2_PEND_NONE && pat_n <= kt_k;
+		const bool any_tab = KT && wv_ballot(by_table) != 0, any_ext = !KT || wv_ballot(pend != S2_PEND_NONE && !by_table) != 0;
 		if (pend != S2_PEND_NONE) {
 			/* ---- the one extension site: the rank-block quarters of both queries + the next list entry, one memory round trip ---- */
 			const ssg_pk2_t *const prev = flip ? vec0 : vec1;
@@ -334,7 +414,9 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 			const int jn = back && j + 1 < prev_n ? j + 1 : 0;
 			ssg_pk2_t pf; pf.w0 = pf.w1 = 0;
 			if (jn) pf = S2V(prev, prev_rev ? prev_n - 1 - jn : jn);   /* issued together with the rank-block loads below */
-			const ssg_intv_t okc = ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back);
+			ssg_intv_t okc; okc.x0 = okc.x1 = okc.x2 = okc.info = 0;
+			if (any_tab) { if (by_table) okc = s2_unpk(kt_tab[s2_ktab_off(pat_n) + (long)s2_code(ql_, 64, pat_b, pat_n)]); }
+			if (any_ext) { if (!by_table) okc = ssg_bwt_extend1_lean(ix, back ? p : ik, e_c, back); }
 			++my_nx; ++rd_nx;
 			if (pend == S2_PEND_FWD) {
 				bool fwd_end = false;
@@ -370,13 +452,19 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 #undef S2V
 #undef S2_FWDEND
 #undef S2_P3START
+#undef S2_P3END
 #undef S2_RET
 #undef S2_EMIT
 	if (n_extend && my_nx) atomicAdd(n_extend, my_nx);
 }
 
+#ifdef SSG_HEAVY_MIN_WAVES   /* variant builds: tools/dbg/seed_variants.sh */
+#define SSG_HEAVY_BOUNDS __launch_bounds__(64, SSG_HEAVY_MIN_WAVES)
+#else
+#define SSG_HEAVY_BOUNDS __launch_bounds__(64)
+#endif
 template <int SC>
-__global__ void __launch_bounds__(64) ssg_k_smem_heavy(ssg_index_view_t ix, ssg_mem_opt_t opt, const int32_t *ids, const unsigned int *n_ids, const int32_t *read_ids,
+__global__ void SSG_HEAVY_BOUNDS ssg_k_smem_heavy(ssg_index_view_t ix, ssg_mem_opt_t opt, const int32_t *ids, const unsigned int *n_ids, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap, unsigned long long *n_extend, unsigned int *next)
 {
 	__shared__ uint8_t qb[264];

@@ -244,6 +244,7 @@ int ssg_index_build_dev(const uint8_t *d_fwd, int64_t l_pac, int n_ctg, const in
 	ssg_index *ix = new ssg_index();
 	int rc = build_from_fwd(d_fwd, l_pac, ix);
 	if (!rc) rc = set_contigs(ix, n_ctg, ctg_off, ctg_len);
+	if (!rc) rc = ssg_index_build_ktab(ix);
 	if (rc) { ssg_index_destroy(ix); return rc; }
 	ix->names.resize(n_ctg); ix->annos.assign(n_ctg, ""); ix->n_ambs.assign(n_ctg, 0);
 	for (int i = 0; i < n_ctg; ++i) ix->names[i] = std::to_string(i + 1);
@@ -310,6 +311,7 @@ int ssg_index_build_fasta(const char *fasta, ssg_index_t **out)
 	{ std::vector<uint8_t>().swap(codes); }
 	if (!rc) rc = build_from_fwd(d_fwd.p, l_pac, ix);
 	if (!rc) rc = set_contigs(ix, (int)off.size(), off.data(), len.data());
+	if (!rc) rc = ssg_index_build_ktab(ix);
 	if (rc) { ssg_index_destroy(ix); return rc; }
 	*out = ix;
 	return 0;

@@ -14,15 +14,20 @@ struct ssg_index {
 	ssg_index_view_t v;
 	/* owned device arrays (NULL when borrowed from the caller, ssg_index_from_device) */
 	uint32_t *bwt; uint64_t *sa; uint8_t *pac; int64_t *ctg_off; int32_t *ctg_len;
+	/* intervals of every pattern of 1..ktab_k bases (k_smem2.h), handed to the seeding kernel as arguments of its own -- the by-value view every
+	 * kernel takes stays as small as it is */
+	uint64_t *ktab; int ktab_k;
 	uint64_t bwt_words;                     /* u32 words of the .bwt body (0 when borrowed) */
 	bool raw_alloc;                         /* bwt/sa/pac came from rt_malloc_raw (index builder) */
 	std::vector<std::string> names, annos;  /* .ann: name and FASTA comment ("" = upstream's "(null)") */
 	std::vector<int32_t> n_ambs;            /* .ann: holes per contig */
 	std::vector<ssg_hole_t> holes;          /* .amb */
 	std::vector<int64_t> h_off; std::vector<int32_t> h_len;
-	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), bwt_words(0), raw_alloc(false) { memset(&v, 0, sizeof(v)); }
+	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), ktab(0), ktab_k(0), bwt_words(0), raw_alloc(false) { memset(&v, 0, sizeof(v)); }
 };
-/* ssg_seed.cpp: the product's seeding kernels (k_smem2.h) and the self-check of the denser suffix-array copy (SSG_SA_VERIFY) */
+/* ssg_seed.cpp: the product's seeding kernels (k_smem2.h), the table of short-pattern intervals (every constructor of an index ends with
+ * ssg_index_build_ktab) and the self-check of the denser suffix-array copy (SSG_SA_VERIFY) */
+extern "C" int ssg_index_build_ktab(ssg_index *ix);
 extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off, int max_len, int cap,
                               ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend, unsigned int max_ext, uint32_t *d_n_ext_read);
 extern "C" int ssg_sa_verify(const ssg_index *ix, int new_intv, const uint64_t *d_sa_new, long n_new);
@@ -45,7 +50,7 @@ static inline ssg_abi_fp_t ssg_abi_fp_make()
 	ssg_abi_fp_t f = {{ (uint32_t)sizeof(ssg_index_view_t), (uint32_t)sizeof(ssg_mem_opt_t), (uint32_t)sizeof(ssg_index), (uint32_t)sizeof(ssg_intv_t),
 		(uint32_t)offsetof(ssg_index_view_t, primary), (uint32_t)offsetof(ssg_index_view_t, L2), (uint32_t)offsetof(ssg_index_view_t, l_pac), (uint32_t)offsetof(ssg_index_view_t, sa_intv),
 		(uint32_t)offsetof(ssg_mem_opt_t, min_seed_len), (uint32_t)offsetof(ssg_mem_opt_t, split_width), (uint32_t)offsetof(ssg_mem_opt_t, max_mem_intv), (uint32_t)offsetof(ssg_mem_opt_t, split_factor),
-		(uint32_t)offsetof(ssg_mem_opt_t, mat), (uint32_t)offsetof(ssg_index, bwt), (uint32_t)offsetof(ssg_index, ctg_len), (uint32_t)offsetof(ssg_index, bwt_words),
+		(uint32_t)offsetof(ssg_mem_opt_t, mat), (uint32_t)offsetof(ssg_index, bwt), (uint32_t)offsetof(ssg_index, ktab), (uint32_t)offsetof(ssg_index, bwt_words),
 		(uint32_t)offsetof(ssg_index, names), (uint32_t)sizeof(ssg_seed_t), (uint32_t)sizeof(ssg_alnreg_t), (uint32_t)sizeof(ssg_aln_t) }};
 	return f;
 }

@@ -66,7 +66,7 @@ extern "C" int ssg_abi_selfcheck(void)
 {	/* every translation unit of the library was compiled against the same shared declarations (ssg_index_int.h) */
 	static const char *const field[20] = { "sizeof(ssg_index_view_t)", "sizeof(ssg_mem_opt_t)", "sizeof(ssg_index)", "sizeof(ssg_intv_t)", "ssg_index_view_t.primary", "ssg_index_view_t.L2",
 		"ssg_index_view_t.l_pac", "ssg_index_view_t.sa_intv", "ssg_mem_opt_t.min_seed_len", "ssg_mem_opt_t.split_width", "ssg_mem_opt_t.max_mem_intv", "ssg_mem_opt_t.split_factor", "ssg_mem_opt_t.mat",
-		"ssg_index.bwt", "ssg_index.ctg_len", "ssg_index.bwt_words", "ssg_index.names", "sizeof(ssg_seed_t)", "sizeof(ssg_alnreg_t)", "sizeof(ssg_aln_t)" };
+		"ssg_index.bwt", "ssg_index.ktab", "ssg_index.bwt_words", "ssg_index.names", "sizeof(ssg_seed_t)", "sizeof(ssg_alnreg_t)", "sizeof(ssg_aln_t)" };
 	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_seed", ssg_abi_fp_seed }, { "ssg_bgzf", ssg_abi_fp_bgzf }, { "sam_format", ssg_abi_fp_sam_format } };
 	ssg_abi_fp_t mine; ssg_abi_fp_core(&mine);
 	for (const auto &u : units) {
@@ -150,7 +150,7 @@ int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t prim
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
-	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }
@@ -269,7 +269,7 @@ int ssg_index_load2(const char *prefix, int defer_dense_sa, ssg_index_t **out)
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_seqs; ix->v.sa_intv = sa_intv;
 	ix->h_off = off; ix->h_len = len; ix->names = names;
-	{ int rc2 = defer_dense_sa ? 0 : densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = defer_dense_sa ? 0 : densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	if (ssg_debug() || getenv("SSG_LOAD_LOG")) {
 		const auto t_end = std::chrono::steady_clock::now();
 		fprintf(stderr, "[ssgpu] index load: files -> HBM %.3f s (%.2f GB), SA samples to every %d rows %.3f s\n", std::chrono::duration<double>(t_up - t_begin).count(),
@@ -284,7 +284,7 @@ void ssg_index_destroy(ssg_index_t *ix)
 	if (!ix) return;
 	if (ix->raw_alloc) { rt_free_raw(ix->bwt); rt_free_raw(ix->sa); rt_free_raw(ix->pac); }
 	else { rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); }
-	rt_free(ix->ctg_off); rt_free(ix->ctg_len);
+	rt_free(ix->ctg_off); rt_free(ix->ctg_len); rt_free(ix->ktab);
 	delete ix;
 }
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,
@@ -300,7 +300,7 @@ int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_
 	ix->v.primary = primary; for (int i = 0; i < 5; ++i) ix->v.L2[i] = L2[i];
 	ix->v.seq_len = L2[4]; ix->v.l_pac = l_pac; ix->v.n_ctg = n_ctg; ix->v.sa_intv = sa_intv;
 	ix->h_off.assign(ctg_off, ctg_off + n_ctg); ix->h_len.assign(ctg_len, ctg_len + n_ctg);
-	{ int rc2 = densify_sa(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
+	{ int rc2 = densify_sa(ix); if (!rc2) rc2 = ssg_index_build_ktab(ix); if (rc2) { ssg_index_destroy(ix); return rc2; } }
 	*out = ix;
 	return 0;
 }

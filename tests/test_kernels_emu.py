@@ -128,6 +128,23 @@ def test_emu_smem_budget_and_wave_kernel(emu_lib, oracle, repeat_prefix, monkeyp
     common.check_smem(emu_lib, oracle, 8, seed=43, prefix=repeat_prefix, cap=512)
 
 
+def test_emu_smem_table_of_short_pattern_intervals(emu_lib, oracle, repeat_prefix, monkeypatch):
+    # the table of the intervals of all patterns up to K bases (k_smem2.h): a bwt_extend whose result is that short is one load, the third pass
+    # starts K bases in; K is chosen at index load.  Same intervals for every K, with ambiguous bases, on repeats, with give-ups, and without a table
+    for k in ("2", "5", "11", "0", "25"):              # 25 >= min_seed_len: the kernel declines the table
+        monkeypatch.setenv("SSG_KTAB_K", k)
+        monkeypatch.setenv("SSG_KTAB_VERIFY", "1")
+        common.check_smem(emu_lib, oracle, 60, seed=51)
+        common.check_smem(emu_lib, oracle, 60, seed=52, n_frac=0.03)
+    monkeypatch.setenv("SSG_KTAB_K", "9")
+    common.check_smem(emu_lib, oracle, 8, seed=43, prefix=repeat_prefix, cap=512)
+    monkeypatch.setenv("SSG_SMEM_MAX_EXT", "300")
+    common.check_smem(emu_lib, oracle, 60, seed=53, n_frac=0.01)
+    monkeypatch.delenv("SSG_SMEM_MAX_EXT")
+    monkeypatch.setenv("SSG_SMEM_USE_KTAB", "0")       # a table in the index, not used
+    common.check_smem(emu_lib, oracle, 60, seed=51)
+
+
 def test_emu_smem_kernel_variants(emu_lib, oracle, monkeypatch):
     monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")     # the nested-loop form (the product kernels' fall-back), on the same reads
     common.check_smem(emu_lib, oracle, 150, seed=31)
