@@ -5,10 +5,9 @@
  * is independent of every other block, i.e. a wave's worth of work each.
  *
  * One wave per block:
- *   1. LZ77: the block goes by in regions of 8 KB, lane l parses the l-th 128 bytes of the region (greedy with one step of lazy matching) --
- *      hash of the next 4 bytes into a table SHARED by the wave (LDS, 4096 buckets of the two newest positions): everything before the
- *      region is in it, plus what the other lanes have passed of the region so far; a match lies before its position (<= 32768 back) and
- *      ends inside the lane's 128 bytes.  Symbols (literal / length + distance) go to a scratch list per
+ *   1. LZ77: the block goes by in regions of 4 KB, lane l parses the l-th 64 bytes of the region (greedy with one step of lazy matching) --
+ *      hash of the next 4 bytes into a table SHARED by the wave (LDS, 4096 buckets of two positions) that holds everything before the
+ *      region; a match lies <= 32768 back and ends inside the lane's 64 bytes.  Then the region's positions enter the table.  Symbols (literal / length + distance) go to a scratch list per
  *      lane, their frequencies to LDS counters.
  *   2. Huffman code lengths of the literal/length and distance alphabets and of the code-length alphabet (RFC 1951 3.2.7), by one lane:
  *      leaves sorted by frequency, two-queue merge; a tree deeper than the format allows (15 / 7 bits) is rebuilt on halved frequencies
@@ -24,8 +23,8 @@
 
 #define BZ_MAX_PAYLOAD 0xff00     /* htslib BGZF_BLOCK_SIZE */
 #define BZ_HBITS 13
-#define BZ_CHUNK 128              /* bytes a lane parses per region; a match ends inside its chunk */
-#define BZ_MAX_REGIONS 8          /* ceil(0xff00 / (64 * BZ_CHUNK)) */
+#define BZ_CHUNK 64               /* bytes a lane parses per region; a match ends inside its chunk */
+#define BZ_MAX_REGIONS 16         /* ceil(0xff00 / (64 * BZ_CHUNK)) */
 #define BZ_STRETCH_CAP 1024       /* symbols per lane: at most BZ_MAX_REGIONS * BZ_CHUNK */
 #define BZ_OUT_STRIDE 65536       /* bytes of temporary output per block: the stored form is payload + 5 */
 
@@ -131,26 +130,32 @@ __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload,
 	if (lane < 19) f_cl[lane] = 0;
 	for (int k = lane; k < BZ_OUT_STRIDE / 4; k += 64) out[k] = 0;
 	ssg_wave_ldssync();
-	/* ---- 1. LZ77: the block in regions of 64 x BZ_CHUNK bytes, lane l parses chunk l of the region; when the wave moves to the next region
-	 * everything before it is in the hash table (the lanes run in lock step, so with one long stretch per lane a lane would only ever see the
-	 * beginnings of the other stretches: 0.61 of the payload instead of 0.50 on BAM records, measured) ---- */
+	/* ---- 1. LZ77: the block goes by in regions of 64 x BZ_CHUNK bytes, lane l parses chunk l of the region against the hash table of everything
+	 * BEFORE the region (plus the byte just behind it, for runs); then the wave enters the region's positions.  The lanes run in lock step, so
+	 * a table filled while parsing shows a lane only the parts of the other chunks that lie at smaller offsets than its own -- half of the
+	 * previous record, in a BAM; measured: 0.61 (one stretch per lane) / 0.575 (regions, filled while parsing) of the payload against
+	 * 0.50 with the table complete.  What a region cannot see of itself it finds one region further back, for a few more distance bits. ---- */
 	const int n_regions = (n + 64 * BZ_CHUNK - 1) / (64 * BZ_CHUNK);
 	int ns = 0, s1 = 0;
 	uint16_t chunk_syms[BZ_MAX_REGIONS];
-	/* the longest match at position p among the two newest table entries of its hash (a bucket of two); p enters the table */
+	auto match_len = [&](const int cand, const int p, const int maxl) -> int {
+		int l = 0;
+		while (l + 4 <= maxl && bz_load32(src + cand + l) == bz_load32(src + p + l)) l += 4;
+		while (l < maxl && src[cand + l] == src[p + l]) ++l;
+		return l;
+	};
+	/* the longest match at position p among the two table entries of its hash and the position just before it */
 	auto find = [&](const int p, int &mlen, int &mdist) {
 		mlen = 0; mdist = 0;
+		const int maxl = s1 - p < 258 ? s1 - p : 258;
+		if (p > 0 && maxl >= 4) { const int l = match_len(p - 1, p, maxl); if (l >= 4) { mlen = l; mdist = 1; } }
 		if (p + 4 > n) return;
 		const uint32_t h = ((bz_load32(src + p) * 2654435761u) >> (32 - BZ_HBITS)) & ~1u;
 		const int c0 = (int)ht[h], c1 = (int)ht[h + 1];
-		ht[h + 1] = (uint16_t)c0; ht[h] = (uint16_t)p;
-		const int maxl = s1 - p < 258 ? s1 - p : 258;
 		SSG_UNROLL for (int t = 0; t < 2; ++t) {
 			const int cand = t ? c1 : c0;
-			if (cand != 0xffff && cand < p && p - cand <= 32768 && (t == 0 || cand != c0)) {
-				int l = 0;
-				while (l + 4 <= maxl && bz_load32(src + cand + l) == bz_load32(src + p + l)) l += 4;
-				while (l < maxl && src[cand + l] == src[p + l]) ++l;
+			if (cand != 0xffff && p - cand <= 32768 && (t == 0 || cand != c0)) {
+				const int l = match_len(cand, p, maxl);
 				if (l >= 4 && l > mlen) { mlen = l; mdist = p - cand; }
 			}
 		}
@@ -174,12 +179,15 @@ __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload,
 					bz_len_code(mlen, lc, le, lv); bz_dist_code(mdist, dc, de, dv);
 					atomicAdd(&f_ll[257 + lc], 1u); atomicAdd(&f_d[dc], 1u);
 					my_sym[(size_t)ns * 64] = 0x80000000u | (uint32_t)mlen << 16 | (uint32_t)(mdist - 1); ++ns;
-					/* the positions a match skips enter the table too (every second one: the next record's copy of this field may start at any of them) */
-					for (int q = pos + 2; q < pos + mlen && q + 4 <= n; q += 2) { const uint32_t hq = ((bz_load32(src + q) * 2654435761u) >> (32 - BZ_HBITS)) & ~1u; ht[hq + 1] = ht[hq]; ht[hq] = (uint16_t)q; }
 					pos += mlen;
 				} else { literal(pos); ++pos; }
 			}
-			ssg_wave_ldssync();   /* (the emulation's lanes are not in lock step: keep them region by region, as the hardware runs them) */
+			ssg_wave_ldssync();
+			for (int q = s0; q < s1 && q + 4 <= n; ++q) {   /* the region enters the table: every position, the two newest per hash */
+				const uint32_t hq = ((bz_load32(src + q) * 2654435761u) >> (32 - BZ_HBITS)) & ~1u;
+				ht[hq + 1] = ht[hq]; ht[hq] = (uint16_t)q;
+			}
+			ssg_wave_ldssync();
 		}
 		chunk_syms[j] = (uint16_t)(ns - ns0);
 	}

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 #define S2V(v, e) ((v)[(long)(e) * 64])
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	unsigned long long my_nx = 0;
-	unsigned int rd_nx = 0;          /* extensions of the current read */
+	unsigned int rd_nx = 0, nx_p3 = 0;   /* extensions of the current read; of its third pass */
 	long it = 0;
 	int state = S2_READ, pend = S2_PEND_NONE;
 	int len = 0, x = 0, k = 0, old_n = 0, caller = 0, mem_n = 0, ovf = 0, heavy = 0, n_p3 = -1;   /* n_p3 < 0: the third pass is not finished */
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 	 * the forward list becomes `prev', walked from its top (= ik), ret = end of the longest match; return of bwt_smem1a to its caller */
 #define S2_FWDEND() do { ret = (int)ik.info; flip ^= 1; prev_n = curr_n < scap ? curr_n : scap; prev_rev = 1; curr_n = 0; i = sx - 1; j = 0; first = s2_pk(ik); state = S2_BWD; if (prev_n > max_row) { heavy = 1; state = S2_OUT; } } while (0)
 	/* next start of the third pass (upstream bwt_seed_strategy1 from every position): skip ambiguous bases, open the interval */
-#define S2_P3END() do { n_p3 = mem_n; x = 0; state = S2_P1; } while (0)   /* the third pass runs FIRST here (see the kernel's comment): on to pass 1 */
+#define S2_P3END() do { n_p3 = mem_n; nx_p3 = rd_nx; x = 0; state = S2_P1; } while (0)   /* the third pass runs FIRST here (see the kernel's comment): on to pass 1 */
 /* With the table the first kt_k - 1 extensions of a start collapse into one look-up: upstream records nothing before the pattern has min_seed_len
  * (> kt_k) bases, so only an ambiguous base or the read's end inside the window matters -- the start then moves past it exactly as upstream's
  * loop returns, one window per trip (state S2_P3 comes back here); the skipped bwt_extend calls still count as the algorithm's. */
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 					const int r = read_ids ? read_ids[it] : (int)it;
 					const uint8_t *q = seq + off[r];
 					len = (int)(off[r+1] - off[r]);
-					mem = out_intv + (long)it * cap; mem_n = 0; ovf = 0; rd_nx = 0; heavy = 0;
+					mem = out_intv + (long)it * cap; mem_n = 0; ovf = 0; rd_nx = 0; nx_p3 = 0; heavy = 0;
 					/* the read as 4-bit codes, 8 per LDS word, fetched as aligned 8-byte words, four LDS words per round trip (this runs with few lanes active) */
 					const unsigned al = (unsigned)((uintptr_t)q & 7), sh8 = al << 3;
 					const uint64_t *const qa = (const uint64_t*)(q - al);
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(64, SSG_S2_WAVES) ssg_k_smem2(ssg_index_view_t
 				const bool given_up = heavy != 0;
 				out_n[it] = ovf ? -1 : given_up ? (n_p3 < 0 ? -2 : -3 - n_p3) : mem_n;   /* given up: the seeds of a finished third pass (the list's first n_p3 entries) stay */
 				if (given_up && !ovf && heavy_ids) heavy_ids[atomicAdd(n_heavy, 1u)] = (int32_t)it;
-				if (given_up) my_nx -= rd_nx;   /* n_extend counts the algorithm's extensions (upstream's own count): the wave kernel counts this read's */
+				if (given_up) my_nx -= n_p3 < 0 ? rd_nx : rd_nx - nx_p3;   /* n_extend counts the algorithm's extensions (upstream's own count): the wave kernel counts what it redoes of this read */
 				if (n_ext_read) n_ext_read[it] = rd_nx;
 				if (TUNE) { S2_STAT_ADD(8 + (64 - __clzll((unsigned long long)(rd_nx | 1u))), 1); if (given_up) S2_STAT_ADD(3, 1); }
 				state = S2_READ;

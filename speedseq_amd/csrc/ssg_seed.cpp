@@ -27,7 +27,7 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
                               ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend, unsigned int max_ext, uint32_t *d_n_ext_read)
 {
 	const int block = 64;
-	const long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 12) * 64)   /* 12 resident waves per CU measured better than the 16 that fit (round 4: 61.6 -> 58.0 ms) */;
+	const long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64)   /* resident waves per CU, measured (round 4, 1 M pairs): with the table 52.2 ms at 16, 57.4 at 12, 72.6 at 8; without it 12 was best (58.0 vs 61.6 at 16) */;
 	const int scap = max_len + 2;
 	/* the table of short-pattern intervals: used when the index has one and its patterns are shorter than a seed (the third pass jumps kt_k bases in) */
 	const int kt_k = idx->ktab && idx->ktab_k >= 2 && idx->ktab_k < opt->min_seed_len && env_int("SSG_SMEM_USE_KTAB", 1) ? idx->ktab_k : 0;
