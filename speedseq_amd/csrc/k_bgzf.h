@@ -6,8 +6,9 @@
  *
  * One wave per block:
  *   1. LZ77: the block goes by in regions of 4 KB, lane l parses the l-th 64 bytes of the region (greedy with one step of lazy matching) --
- *      hash of the next 4 bytes into a table SHARED by the wave (LDS, 4096 buckets of two positions) that holds everything before the
- *      region; a match lies <= 32768 back and ends inside the lane's 64 bytes.  Then the region's positions enter the table.  Symbols (literal / length + distance) go to a scratch list per
+ *      hash of the next 4 bytes into two tables SHARED by the wave (LDS): the region's own positions, entered before the parse (2048 buckets
+ *      of four; a lane takes what lies before its position), and everything before the region (4096 buckets of two); plus the byte just
+ *      behind (runs).  A match lies <= 32768 back and ends inside the lane's 64 bytes.  Symbols (literal / length + distance) go to a scratch list per
  *      lane, their frequencies to LDS counters.
  *   2. Huffman code lengths of the literal/length and distance alphabets and of the code-length alphabet (RFC 1951 3.2.7), by one lane:
  *      leaves sorted by frequency, two-queue merge; a tree deeper than the format allows (15 / 7 bits) is rebuilt on halved frequencies
@@ -23,6 +24,7 @@
 
 #define BZ_MAX_PAYLOAD 0xff00     /* htslib BGZF_BLOCK_SIZE */
 #define BZ_HBITS 13
+#define BZ_CBITS 13              /* the region's own table: 2048 buckets of the four newest positions */
 #define BZ_CHUNK 64               /* bytes a lane parses per region; a match ends inside its chunk */
 #define BZ_MAX_REGIONS 16         /* ceil(0xff00 / (64 * BZ_CHUNK)) */
 #define BZ_STRETCH_CAP 1024       /* symbols per lane: at most BZ_MAX_REGIONS * BZ_CHUNK */
@@ -112,6 +114,7 @@ SSG_DEVFN void bz_w_end(bz_writer_t &w) { if (w.nacc > 0) atomicOr(w.out + w.wor
 __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload, const uint64_t *cut, int n_blocks, uint8_t *tmp, uint32_t *sym, uint32_t *size)
 {
 	__shared__ uint16_t ht[1 << BZ_HBITS];
+	__shared__ uint16_t hc[1 << BZ_CBITS];
 	__shared__ uint32_t f_ll[288], f_d[32], f_cl[19];
 	__shared__ uint8_t l_ll[288], l_d[32], l_cl[19];
 	__shared__ uint16_t c_ll[288], c_d[32], c_cl[19];
@@ -125,16 +128,17 @@ __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload,
 	uint32_t *const out = (uint32_t*)(tmp + (size_t)b * BZ_OUT_STRIDE);
 	uint32_t *const my_sym = sym + (size_t)b * BZ_STRETCH_CAP * 64 + lane;
 	for (int k = lane; k < (1 << BZ_HBITS) / 2; k += 64) ((uint32_t*)ht)[k] = 0xffffffffu;
+	for (int k = lane; k < (1 << BZ_CBITS) / 2; k += 64) ((uint32_t*)hc)[k] = 0xffffffffu;
 	for (int k = lane; k < 288; k += 64) f_ll[k] = 0;
 	if (lane < 32) f_d[lane] = 0;
 	if (lane < 19) f_cl[lane] = 0;
 	for (int k = lane; k < BZ_OUT_STRIDE / 4; k += 64) out[k] = 0;
 	ssg_wave_ldssync();
-	/* ---- 1. LZ77: the block goes by in regions of 64 x BZ_CHUNK bytes, lane l parses chunk l of the region against the hash table of everything
-	 * BEFORE the region (plus the byte just behind it, for runs); then the wave enters the region's positions.  The lanes run in lock step, so
-	 * a table filled while parsing shows a lane only the parts of the other chunks that lie at smaller offsets than its own -- half of the
-	 * previous record, in a BAM; measured: 0.61 (one stretch per lane) / 0.575 (regions, filled while parsing) of the payload against
-	 * 0.50 with the table complete.  What a region cannot see of itself it finds one region further back, for a few more distance bits. ---- */
+	/* ---- 1. LZ77: the block goes by in regions of 64 x BZ_CHUNK bytes, lane l parses chunk l of the region.  The lanes run in lock step, so a table
+	 * filled while parsing shows a lane only the parts of the other chunks at smaller offsets than its own -- half of the previous record, in a
+	 * BAM.  Hence two tables: the region's positions all enter `hc' BEFORE the parse (a lane uses those before its position), and `ht' holds
+	 * what came before the region.  Sizes on a sorted BAM stream (zlib level 6 = 0.204, level 1 = 0.224 of the payload): one stretch per lane
+	 * and one table filled while parsing 0.29 (and 0.61 vs 0.47 on the synthetic records of the tests); this form 0.232. ---- */
 	const int n_regions = (n + 64 * BZ_CHUNK - 1) / (64 * BZ_CHUNK);
 	int ns = 0, s1 = 0;
 	uint16_t chunk_syms[BZ_MAX_REGIONS];
@@ -150,11 +154,10 @@ __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload,
 		const int maxl = s1 - p < 258 ? s1 - p : 258;
 		if (p > 0 && maxl >= 4) { const int l = match_len(p - 1, p, maxl); if (l >= 4) { mlen = l; mdist = 1; } }
 		if (p + 4 > n) return;
-		const uint32_t h = ((bz_load32(src + p) * 2654435761u) >> (32 - BZ_HBITS)) & ~1u;
-		const int c0 = (int)ht[h], c1 = (int)ht[h + 1];
-		SSG_UNROLL for (int t = 0; t < 2; ++t) {
-			const int cand = t ? c1 : c0;
-			if (cand != 0xffff && p - cand <= 32768 && (t == 0 || cand != c0)) {
+		const uint32_t w4 = bz_load32(src + p) * 2654435761u, h = (w4 >> (32 - BZ_HBITS)) & ~1u, g = (w4 >> (32 - BZ_CBITS)) & ~3u;
+		SSG_UNROLL for (int t = 0; t < 6; ++t) {   /* the region's own positions first (nearer: cheaper distances), then the two newest from before it */
+			const int cand = t < 4 ? (int)hc[g + t] : (int)ht[h + t - 4];
+			if (cand != 0xffff && cand < p && p - cand <= 32768) {
 				const int l = match_len(cand, p, maxl);
 				if (l >= 4 && l > mlen) { mlen = l; mdist = p - cand; }
 			}
@@ -166,6 +169,11 @@ __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload,
 		if (j < n_regions) {
 			const int c0 = (j * 64 + lane) * BZ_CHUNK, s0 = c0 < n ? c0 : n;
 			s1 = s0 + BZ_CHUNK < n ? s0 + BZ_CHUNK : n;
+			for (int q = s0; q < s1 && q + 4 <= n; ++q) {   /* the region's positions into its own table first: a lane takes from it what lies before its position */
+				const uint32_t gq = ((bz_load32(src + q) * 2654435761u) >> (32 - BZ_CBITS)) & ~3u;
+				hc[gq + 3] = hc[gq + 2]; hc[gq + 2] = hc[gq + 1]; hc[gq + 1] = hc[gq]; hc[gq] = (uint16_t)q;
+			}
+			ssg_wave_ldssync();
 			for (int pos = s0; pos < s1; ) {
 				int mlen, mdist;
 				find(pos, mlen, mdist);
