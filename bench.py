@@ -420,6 +420,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1000000, help="pairs per GPU per step (BASELINE.json configs[1]: 1M)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --pairs is the TOTAL over all ranks (each aligns pairs / N of one input); default is weak scaling, --pairs per GPU as the bench contract runs it")
     ap.add_argument("--ref-mbp", type=float, default=3100.0, help="synthetic GRCh37-shaped reference size (GRCh37 = 3100)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--ins-mean", type=int, default=0, help="fragment length mean (0: 400, or 800 for reads of 250 bases and more -- BASELINE.json configs[4]: wgsim -d 800 -s 150)")
@@ -463,6 +464,8 @@ def main():
             dist.init_process_group("gloo")                   # the flow check of the N > 1 step on the host emulation
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if a.strong and world > 1:
+        a.pairs = max(1, a.pairs // world)          # this rank's share; the ranks' reads are simulated with different seeds (12 + rank): one input of world * a.pairs pairs
     emu = a.emu_selftest
     if not emu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
@@ -579,7 +582,7 @@ def main():
     out = {
         "metric": "paired reads aligned+dup-marked/sec", "value": world * a.pairs * a.steps / dt, "unit": "pairs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": workload,
                    "pairs_per_gpu": a.pairs, "read_len": rl, "fragment_mean_std": [ins["ins_mean"], ins["ins_std"]], "ref_bp": int(sum(lens)), "index_build_s": round(t_index, 2), "ref_synth_s": round(t_ref, 2),
                    "records": int(summary[0]), "dup_pairs": n_dup_global[0] if multi else int(summary[1]), "dup_pairs_local_view": int(summary[1]), "seeds": int(summary[2]), "rescues": int(summary[5]),
@@ -639,11 +642,12 @@ def main():
             # tools/profile_round.sh; units calibrated on the random-gather probe): read from the committed summary when it was
             # taken on this workload with these kernels, otherwise null -- never a constant in this file
             traffic = None
+            real = {"ssg_k_smem2_kt": "ssg_k_smem2<false, true>", "ssg_k_smem2_plain": "ssg_k_smem2<false, false>"}   # the launcher's names of the template instances (ssg_seed.cpp) -> rocprofv3's
             for tag in ("r04", "r02"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
-                    if pm.get("pairs") == a.pairs and pm.get("read_len") == rl and abs(pm.get("ref_mbp", 0) - a.ref_mbp) < 1e-6 and seed_k and all(k in pm.get("bytes_per_launch", {}) for k in seed_k):
-                        traffic = sum(pm["bytes_per_launch"][k] for k in seed_k)
+                    if pm.get("pairs") == a.pairs and pm.get("read_len") == rl and abs(pm.get("ref_mbp", 0) - a.ref_mbp) < 1e-6 and seed_k and all(real.get(k, k) in pm.get("bytes_per_launch", {}) for k in seed_k):
+                        traffic = sum(pm["bytes_per_launch"][real.get(k, k)] for k in seed_k)
                         break
                 except Exception:
                     pass

@@ -6,8 +6,8 @@
  *
  * One wave per block:
  *   1. LZ77: the block goes by in regions of 4 KB, lane l parses the l-th 64 bytes of the region (greedy with one step of lazy matching) --
- *      hash of the next 4 bytes into two tables SHARED by the wave (LDS): the region's own positions, entered before the parse (2048 buckets
- *      of four; a lane takes what lies before its position), and everything before the region (4096 buckets of two); plus the byte just
+ *      hash of the next 4 bytes into two tables SHARED by the wave (LDS): the region's own positions, entered before the parse (1024 buckets
+ *      of four; a lane takes what lies before its position), and everything before the region (2048 buckets of two); plus the byte just
  *      behind (runs).  A match lies <= 32768 back and ends inside the lane's 64 bytes.  Symbols (literal / length + distance) go to a scratch list per
  *      lane, their frequencies to LDS counters.
  *   2. Huffman code lengths of the literal/length and distance alphabets and of the code-length alphabet (RFC 1951 3.2.7), by one lane:
@@ -23,8 +23,8 @@
 #include "ssg_dev.h"
 
 #define BZ_MAX_PAYLOAD 0xff00     /* htslib BGZF_BLOCK_SIZE */
-#define BZ_HBITS 13
-#define BZ_CBITS 13              /* the region's own table: 2048 buckets of the four newest positions */
+#define BZ_HBITS 12
+#define BZ_CBITS 12              /* the region's own table: 1024 buckets of the four newest positions */
 #define BZ_CHUNK 64               /* bytes a lane parses per region; a match ends inside its chunk */
 #define BZ_MAX_REGIONS 16         /* ceil(0xff00 / (64 * BZ_CHUNK)) */
 #define BZ_STRETCH_CAP 1024       /* symbols per lane: at most BZ_MAX_REGIONS * BZ_CHUNK */
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload,
 		const uint32_t w4 = bz_load32(src + p) * 2654435761u, h = (w4 >> (32 - BZ_HBITS)) & ~1u, g = (w4 >> (32 - BZ_CBITS)) & ~3u;
 		SSG_UNROLL for (int t = 0; t < 6; ++t) {   /* the region's own positions first (nearer: cheaper distances), then the two newest from before it */
 			const int cand = t < 4 ? (int)hc[g + t] : (int)ht[h + t - 4];
-			if (cand != 0xffff && cand < p && p - cand <= 32768) {
+			if (cand != 0xffff && cand < p && p - cand <= 32768 && !(t >= 4 && mlen >= 16)) {   /* a good match nearby: the older table is not asked */
 				const int l = match_len(cand, p, maxl);
 				if (l >= 4 && l > mlen) { mlen = l; mdist = p - cand; }
 			}

@@ -3,7 +3,7 @@
 # (HBM traffic: FETCH_SIZE / WRITE_SIZE; SQ issue counters), the two roofline probes with a FETCH_SIZE calibration pass.
 # Counters are collected with --kernel-trace only (no sys/hip/hsa trace domains).  Summaries: tools/pmc_summarize.py.
 tag=${1:-rXX}; out=$PWD/gpurun_out; mkdir -p $out
-B="python $PWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-profile"
+B="python $PWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-profile --config5-pairs 0 --no-dist-rehearsal"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $B > $out/${tag}_bench_under_rocprof.log 2>&1
 find /tmp/prof_$tag -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
