@@ -39,6 +39,19 @@ GRCH37_NAMES = [str(i) for i in range(1, 23)] + ["X", "Y", "MT"]
 _T0 = time.time()
 
 
+def host_cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cfs quota), None = no quota: the thread counts below are what was ASKED for"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return None if q <= 0 else round(q / per, 2)
+        except Exception:
+            return None
+
+
 def log(msg):
     """progress on stderr with the time since start: a run cut short still says where its time went"""
     sys.stderr.write("[bench %7.1f s] %s\n" % (time.time() - _T0, msg)); sys.stderr.flush()
@@ -405,7 +418,7 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
         log('script on the oracle executables, %d pairs: %s' % (nc, rc.get('wall_s', rc.get('error'))))
         if "wall_s" in rc:
             fixed = rw.get("wall_s")
-            res["cpu_script"] = {"value": nc / rc["wall_s"], "unit": "pairs/s", "cores": cores, "threads_given": cores, "hardware_threads": os.cpu_count(), "kind": "port", "pairs": nc, "wall_s": rc["wall_s"],
+            res["cpu_script"] = {"value": nc / rc["wall_s"], "unit": "pairs/s", "cores": cores, "threads_given": cores, "hardware_threads": os.cpu_count(), "host_cpu_quota": host_cpu_quota(), "kind": "port", "pairs": nc, "wall_s": rc["wall_s"],
                                  "warmup_run": {"pairs": min(nc, 50000), "wall_s": fixed},
                                  "marginal_pairs_per_s": (nc - min(nc, 50000)) / (rc["wall_s"] - fixed) if fixed and rc["wall_s"] > fixed and nc > 50000 else None,
                                  "what": "`speedseq align -t %d -p` (the reference's script, unmodified) with oracle/orc_bwa as bwa and samblaster and the reference's samtools 1.3.1 behind sambamba's command line, "
@@ -744,7 +757,7 @@ def main():
                                       "MC/MQ source lines reproduce the three streams of the oracle's samblaster line for line; index files written by ssg_index_save"
                                       % ("" if full else ", first %d pairs" % ns)),
                              "index_files_roundtrip_s": round(t_files, 1)}
-            out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
+            out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "host_cpu_quota": host_cpu_quota(), "hardware_threads": os.cpu_count(), "kind": "port",
                                    "sample": "%s of the timed batch (%d pairs) in its upstream batches, oracle/ (scalar C restatement of bwa mem PE) in process, %d threads, alignment only; after an untimed pass over %d pairs. "
                                              "The script-level baseline (`speedseq align -t <cores>` on the oracle's executables) is cpu_baseline.script" % ("all" if full else "the first pairs", ns, cores, nw)}
             try:   # oracle-independent validation of the same records (tests/validators.py): reference bases from the .pac just written
