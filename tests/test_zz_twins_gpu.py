@@ -76,16 +76,15 @@ def test_gpu_deferred_dense_suffix_array(tmp_path, gpu_lib):
     assert outs[0].count(b"\n") > 6000 and outs[1] == outs[0] and outs[2] == outs[0]
 
 
-@pytest.mark.skipif(not DRY and not os.environ.get("SSG_TEST_INFLIGHT"), reason="lanes have not run on an MI355X yet: first under tools/gpu_r04a.sh (SSG_TEST_INFLIGHT=1), not in the round-end tier")
 def test_gpu_zz_two_calls_in_flight(tmp_path, gpu_lib):
-    """SSG_BWA_INFLIGHT=2 (two lanes per device: own streams and arenas, ssg_set_lane) against one call at a time: same SAM.  Last of the
-    file: the lanes had not run on an MI355X when this was written; a run that does not finish is cut off after two minutes."""
+    """SSG_BWA_INFLIGHT=2 and 3 (lanes per device: own streams and arenas, ssg_set_lane; 2 is the default since round 4, when this ran on the
+    MI355X for the first time) against one call at a time: same SAM.  A run that does not finish is cut off after two minutes."""
     fq = str(tmp_path / "r.fq")
     simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 4000, seed=93))
     outs = []
-    for inflight in ("1", "2"):
+    for inflight in ("1", "2", "3"):
         env = dict(os.environ, SSG_BWA_INFLIGHT=inflight, SSG_BWA_CHUNK_BASES="60000", SSG_BWA_CALL_PAIRS="500", SSG_BWA_DENSIFY_AFTER="1500")
         r = subprocess.run([B("bwa"), "mem", "-t", "2", "-p", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=120)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(b"\n".join(l for l in r.stdout.split(b"\n") if not l.startswith(b"@PG")))
-    assert outs[0].count(b"\n") > 8000 and outs[1] == outs[0]
+    assert outs[0].count(b"\n") > 8000 and outs[1] == outs[0] and outs[2] == outs[0]
