@@ -56,6 +56,10 @@ static inline int orc_pac_get(const uint8_t *pac, int64_t l) { return pac[l>>2] 
 static inline int orc_ref_base(const uint8_t *pac, int64_t l_pac, int64_t p) { return p < l_pac ? orc_pac_get(pac, p) : 3 - orc_pac_get(pac, (l_pac<<1) - 1 - p); }
 
 /* ---------- options (upstream mem_opt_t, bwamem.h) ---------- */
+#define ORC_F_NO_MULTI 0x10    /* upstream MEM_F_NO_MULTI (bwa mem -M) */
+#define ORC_F_SOFTCLIP 0x200   /* upstream MEM_F_SOFTCLIP (bwa mem -Y) */
+#define ORC_F_NOPAIRING 0x4    /* upstream MEM_F_NOPAIRING (bwa mem -P): mate rescue only, no pairing of the hits */
+#define ORC_F_NO_RESCUE 0x20   /* upstream MEM_F_NO_RESCUE (bwa mem -S) */
 typedef struct {
 	int a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, pen_clip5, pen_clip3, w, zdrop;
 	uint64_t max_mem_intv;
@@ -67,6 +71,7 @@ typedef struct {
 	int8_t mat[25];
 } orc_opt_t;
 void orc_opt_init(orc_opt_t *o);
+void orc_fill_scmat(orc_opt_t *o);   /* after a change of a / b */
 
 /* ---------- Smith-Waterman (upstream ksw.c) ---------- */
 int orc_ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,

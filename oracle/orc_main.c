@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <math.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <sys/time.h>
 #include "orc.h"
@@ -122,19 +124,61 @@ static int main_index(int argc, char **argv)
 static int main_mem(int argc, char **argv)
 {
 	orc_opt_t opt; orc_opt_init(&opt);
-	int interleaved = 0, keep_comment = 0, i; char *rg = 0, rg_id[256] = ""; orc_pestat_t pes0[4], *pes = 0;
-	int ai = 1;
-	for (; ai < argc && argv[ai][0] == '-' && argv[ai][1]; ++ai) {
-		char *a = argv[ai];
-		if (!strcmp(a, "-p")) interleaved = 1;
-		else if (!strcmp(a, "-C")) keep_comment = 1;
-		else if (!strcmp(a, "-M")) ; /* not used by speedseq */
-		else if (!strcmp(a, "-t") && ai + 1 < argc) opt.n_threads = atoi(argv[++ai]);
-		else if (!strcmp(a, "-R") && ai + 1 < argc) rg = unescape_rg(argv[++ai]);
-		else if (!strcmp(a, "-I") && ai + 1 < argc) { /* upstream main_mem -I: FR only */
-			char *p; pes = pes0; memset(pes0, 0, sizeof(pes0));
+	int interleaved = 0, keep_comment = 0, fixed_chunk = 0, i; char *rg = 0, rg_id[256] = ""; orc_pestat_t pes0[4], *pes = 0;
+	int ai, c; char *p;
+	orc_opt_t opt0; memset(&opt0, 0, sizeof(opt0));   /* upstream main_mem: which scoring fields the command line set itself */
+	optind = 1;
+	/* upstream main_mem's option loop (fastmap.c, 0.7.12): same letters, same two-number forms, same order-independent scaling by -A below */
+	while ((c = getopt(argc, argv, "pMCSPYk:c:v:s:r:t:R:A:B:O:E:U:w:L:d:T:Q:D:m:I:N:W:G:h:y:K:X:")) >= 0) {
+		if (c == 'p') interleaved = 1;
+		else if (c == 'C') keep_comment = 1;
+		else if (c == 'M') opt.flag |= ORC_F_NO_MULTI;
+		else if (c == 'Y') opt.flag |= ORC_F_SOFTCLIP;
+		else if (c == 'S') opt.flag |= ORC_F_NO_RESCUE;
+		else if (c == 'P') opt.flag |= ORC_F_NOPAIRING;
+		else if (c == 'k') opt.min_seed_len = atoi(optarg), opt0.min_seed_len = 1;
+		else if (c == 'w') opt.w = atoi(optarg), opt0.w = 1;
+		else if (c == 'A') opt.a = atoi(optarg), opt0.a = 1;
+		else if (c == 'B') opt.b = atoi(optarg), opt0.b = 1;
+		else if (c == 'T') opt.T = atoi(optarg), opt0.T = 1;
+		else if (c == 'U') opt.pen_unpaired = atoi(optarg), opt0.pen_unpaired = 1;
+		else if (c == 't') opt.n_threads = atoi(optarg), opt.n_threads = opt.n_threads > 1 ? opt.n_threads : 1;
+		else if (c == 'c') opt.max_occ = atoi(optarg), opt0.max_occ = 1;
+		else if (c == 'd') opt.zdrop = atoi(optarg), opt0.zdrop = 1;
+		else if (c == 'v') ;   /* verbosity: nothing on stdout depends on it */
+		else if (c == 'r') opt.split_factor = atof(optarg), opt0.split_factor = 1.;
+		else if (c == 'D') opt.drop_ratio = atof(optarg), opt0.drop_ratio = 1.;
+		else if (c == 'm') opt.max_matesw = atoi(optarg), opt0.max_matesw = 1;
+		else if (c == 's') opt.split_width = atoi(optarg), opt0.split_width = 1;
+		else if (c == 'G') opt.max_chain_gap = atoi(optarg), opt0.max_chain_gap = 1;
+		else if (c == 'N') opt.max_chain_extend = atoi(optarg), opt0.max_chain_extend = 1;
+		else if (c == 'W') opt.min_chain_weight = atoi(optarg), opt0.min_chain_weight = 1;
+		else if (c == 'y') opt.max_mem_intv = atol(optarg), opt0.max_mem_intv = 1;
+		else if (c == 'K') fixed_chunk = atoi(optarg);
+		else if (c == 'X') opt.mask_level = atof(optarg);
+		else if (c == 'h') {
+			opt.max_XA_hits = opt.max_XA_hits_alt = strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.max_XA_hits_alt = strtol(p + 1, &p, 10);
+		} else if (c == 'Q') {
+			opt.mapQ_coef_len = atoi(optarg);
+			opt.mapQ_coef_fac = opt.mapQ_coef_len > 0 ? log(opt.mapQ_coef_len) : 0;
+		} else if (c == 'O') {
+			opt0.o_del = opt0.o_ins = 1;
+			opt.o_del = opt.o_ins = strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.o_ins = strtol(p + 1, &p, 10);
+		} else if (c == 'E') {
+			opt0.e_del = opt0.e_ins = 1;
+			opt.e_del = opt.e_ins = strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.e_ins = strtol(p + 1, &p, 10);
+		} else if (c == 'L') {
+			opt0.pen_clip5 = opt0.pen_clip3 = 1;
+			opt.pen_clip5 = opt.pen_clip3 = strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.pen_clip3 = strtol(p + 1, &p, 10);
+		} else if (c == 'R') rg = unescape_rg(optarg);
+		else if (c == 'I') { /* upstream main_mem -I: FR only */
+			pes = pes0; memset(pes0, 0, sizeof(pes0));
 			pes0[0].failed = pes0[2].failed = pes0[3].failed = 1;
-			pes0[1].avg = strtod(argv[++ai], &p);
+			pes0[1].avg = strtod(optarg, &p);
 			pes0[1].std = pes0[1].avg * .1;
 			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].std = strtod(p + 1, &p);
 			pes0[1].high = (int)(pes0[1].avg + 4. * pes0[1].std + .499);
@@ -142,8 +186,22 @@ static int main_mem(int argc, char **argv)
 			if (pes0[1].low < 1) pes0[1].low = 1;
 			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].high = (int)(strtod(p + 1, &p) + .499);
 			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].low  = (int)(strtod(p + 1, &p) + .499);
-		} else { fprintf(stderr, "[orc_bwa] unsupported option %s\n", a); return 1; }
+		} else { fprintf(stderr, "[orc_bwa] option outside the oracle's scope (upstream's -a -e -F -V -j -x -H are not restated)\n"); return 1; }
 	}
+	ai = optind;
+	if (opt0.a) { /* upstream update_a: a changed match score scales what the command line left alone */
+		if (!opt0.b) opt.b *= opt.a;
+		if (!opt0.T) opt.T *= opt.a;
+		if (!opt0.o_del) opt.o_del *= opt.a;
+		if (!opt0.e_del) opt.e_del *= opt.a;
+		if (!opt0.o_ins) opt.o_ins *= opt.a;
+		if (!opt0.e_ins) opt.e_ins *= opt.a;
+		if (!opt0.zdrop) opt.zdrop *= opt.a;
+		if (!opt0.pen_clip5) opt.pen_clip5 *= opt.a;
+		if (!opt0.pen_clip3) opt.pen_clip3 *= opt.a;
+		if (!opt0.pen_unpaired) opt.pen_unpaired *= opt.a;
+	}
+	orc_fill_scmat(&opt);
 	if (argc - ai < 2) { fprintf(stderr, "usage: orc_bwa mem [opts] <ref> <fq1> [fq2]\n"); return 1; }
 	if (rg) {
 		if (strncmp(rg, "@RG", 3) != 0) { fprintf(stderr, "[E::bwa_set_rg] the read group line is not started with @RG\n"); return 1; }
@@ -166,7 +224,7 @@ static int main_mem(int argc, char **argv)
 		char *h = orc_sam_header(idx, rg, cl); fputs(h, stdout); free(h);
 	}
 	{ const char *e = getenv("ORC_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: many batches from a small input */
-	int64_t n_processed = 0, chunk = (int64_t)opt.chunk_size * opt.n_threads;
+	int64_t n_processed = 0, chunk = fixed_chunk > 0 ? fixed_chunk : (int64_t)opt.chunk_size * opt.n_threads;   /* -K: batches that do not depend on -t */
 	for (;;) {
 		orc_read_t *s = 0; int n = 0, m = 0; int64_t size = 0; int rc = 0;
 		while (1) { /* upstream bseq_read */

@@ -53,7 +53,12 @@ void orc_opt_init(orc_opt_t *o)
 	o->min_chain_weight = 0;
 	o->max_chain_extend = 1<<30;
 	o->mapQ_coef_len = 50; o->mapQ_coef_fac = log(o->mapQ_coef_len);
-	for (int i = 0, k = 0; i < 4; ++i) { /* upstream bwa_fill_scmat */
+	orc_fill_scmat(o);
+}
+
+void orc_fill_scmat(orc_opt_t *o)
+{	/* upstream bwa_fill_scmat */
+	for (int i = 0, k = 0; i < 4; ++i) {
 		for (int j = 0; j < 4; ++j) o->mat[k++] = i == j ? o->a : -o->b;
 		o->mat[k++] = -1;
 	}

@@ -529,7 +529,7 @@ static void aln2sam(const orc_opt_t *opt, const orc_bns_t *bns, str_t *str, orc_
 		if (p->n_cigar) {
 			for (i = 0; i < p->n_cigar; ++i) {
 				int c = p->cigar[i] & 0xf;
-				if (!p->is_alt && (c == 3 || c == 4)) c = which ? 4 : 3; /* hard clip supplementary */
+				if (!(opt->flag & ORC_F_SOFTCLIP) && !p->is_alt && (c == 3 || c == 4)) c = which ? 4 : 3; /* hard clip supplementary */
 				s_putl(str, p->cigar[i] >> 4); s_putc(str, "MIDSH"[c]);
 			}
 		} else s_putc(str, '*');
@@ -551,7 +551,7 @@ static void aln2sam(const orc_opt_t *opt, const orc_bns_t *bns, str_t *str, orc_
 	if (p->flag & 0x100) s_putsn(str, "*\t*", 3);
 	else if (!p->is_rev) {
 		int qb = 0, qe = s->l_seq;
-		if (p->n_cigar && which && !p->is_alt) {
+		if (p->n_cigar && which && !(opt->flag & ORC_F_SOFTCLIP) && !p->is_alt) {
 			if ((p->cigar[0] & 0xf) == 4 || (p->cigar[0] & 0xf) == 3) qb += p->cigar[0] >> 4;
 			if ((p->cigar[p->n_cigar-1] & 0xf) == 4 || (p->cigar[p->n_cigar-1] & 0xf) == 3) qe -= p->cigar[p->n_cigar-1] >> 4;
 		}
@@ -561,7 +561,7 @@ static void aln2sam(const orc_opt_t *opt, const orc_bns_t *bns, str_t *str, orc_
 		else s_putc(str, '*');
 	} else {
 		int qb = 0, qe = s->l_seq;
-		if (p->n_cigar && which && !p->is_alt) {
+		if (p->n_cigar && which && !(opt->flag & ORC_F_SOFTCLIP) && !p->is_alt) {
 			if ((p->cigar[0] & 0xf) == 4 || (p->cigar[0] & 0xf) == 3) qe -= p->cigar[0] >> 4;
 			if ((p->cigar[p->n_cigar-1] & 0xf) == 4 || (p->cigar[p->n_cigar-1] & 0xf) == 3) qb += p->cigar[p->n_cigar-1] >> 4;
 		}
@@ -613,7 +613,7 @@ static void reg2sam(const orc_opt_t *opt, const orc_idx_t *idx, orc_read_t *s, o
 		q = orc_mem_reg2aln(opt, idx, s->l_seq, s->seq, p);
 		q.XA = XA ? XA[k] : 0;
 		q.flag |= extra_flag;
-		if (l && p->secondary < 0) q.flag |= 0x800;
+		if (l && p->secondary < 0) q.flag |= (opt->flag & ORC_F_NO_MULTI) ? 0x10000 : 0x800;
 		if (l && !p->is_alt && q.mapq > aa.a[0].mapq) q.mapq = aa.a[0].mapq;
 		PUSH(aa, orc_aln_t, q);
 		++l;
@@ -639,7 +639,7 @@ int orc_mem_sam_pe(const orc_opt_t *opt, const orc_idx_t *idx, const orc_pestat_
 	str_t str = {0,0,0};
 	orc_aln_t h[2];
 	memset(h, 0, sizeof(h));
-	{	/* mate rescue for the best hits */
+	if (!(opt->flag & ORC_F_NO_RESCUE)) {	/* mate rescue for the best hits */
 		orc_alnreg_v b[2] = {{0,0,0},{0,0,0}};
 		for (i = 0; i < 2; ++i)
 			for (j = 0; j < (int)a[i].n; ++j)
@@ -651,6 +651,7 @@ int orc_mem_sam_pe(const orc_opt_t *opt, const orc_idx_t *idx, const orc_pestat_
 	}
 	n_pri[0] = orc_mem_mark_primary_se(opt, (int)a[0].n, a[0].a, id << 1 | 0);
 	n_pri[1] = orc_mem_mark_primary_se(opt, (int)a[1].n, a[1].a, id << 1 | 1);
+	if (opt->flag & ORC_F_NOPAIRING) goto no_pairing;
 	if (n_pri[0] && n_pri[1] && (o = orc_mem_pair(opt, idx, pes, a, (int)id, &subo, &n_sub, z, n_pri)) > 0) {
 		int is_multi[2], q_pe, score_un, q_se[2];
 		char **XA[2];

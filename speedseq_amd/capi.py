@@ -23,7 +23,7 @@ OPT_DT = np.dtype([
     ("max_mem_intv", "u8"),
     ("split_factor", "f4"), ("mask_level", "f4"), ("drop_ratio", "f4"), ("XA_drop_ratio", "f4"),
     ("mask_level_redun", "f4"), ("mapQ_coef_len", "f4"),
-    ("mat", "i1", (25,)), ("_pad", "i1", (7,)),
+    ("mat", "i1", (25,)), ("_pad0", "i1"), ("flag", "u2"), ("_pad", "i1", (4,)),
 ], align=False)
 INTV_DT = np.dtype([("x0", "u8"), ("x1", "u8"), ("x2", "u8"), ("info", "u8")])
 SEED_DT = np.dtype([("rbeg", "i8"), ("qbeg", "i4"), ("len", "i4"), ("score", "i4"), ("next", "i4")])

@@ -510,7 +510,7 @@ SSG_DEVFN void ssg_pair_decide(const ssg_index_view_t &ix, const ssg_mem_opt_t &
 				ssg_alnreq_t q; q.read = (int32_t)(2*p + i); q.reg = (int32_t)(reg_off[2*p+i] + k); q.kind = SSG_REQ_MAIN; q.owner = k;
 				q.flag = (i ? 0x81 : 0x41) | extra_flag; q._pad0 = q._pad1 = 0;
 				q.mapq = pr.secondary < 0 ? ssg_approx_mapq_se(opt, pr) : 0;
-				if (l) q.flag |= 0x800;
+				if (l) q.flag |= (opt.flag & SSG_F_NO_MULTI) ? 0x10000 : 0x800;   /* upstream mem_reg2sam */
 				if (l && q.mapq > mapq0) q.mapq = mapq0;
 				if (!l) mapq0 = q.mapq;
 				rq[i][nrq[i]++] = q;
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_
 		ssg_alnreq_t *rq[2] = { req + req_off[2*p], req + req_off[2*p+1] };
 		n_pri[0] = ssg_mark_primary_se(opt, an[0], a[0], id << 1 | 0, z0, (int32_t*)v);
 		n_pri[1] = ssg_mark_primary_se(opt, an[1], a[1], id << 1 | 1, z0, (int32_t*)v);
-		if (n_pri[0] && n_pri[1]) o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, u, ucap, &myerr);
+		if (n_pri[0] && n_pri[1] && !(opt.flag & SSG_F_NOPAIRING)) o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, u, ucap, &myerr);
 		ssg_pair_decide(ix, opt, pes, p, a, an, n_pri, o, subo, n_sub, z, z0, reg_off, rq, n_req);
 		if (myerr) err[p] = myerr;
 	}

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) ssg_k_pair_final_wave(ssg_index_view_t ix
 			if (wv_lane() == 0) {
 				n_pri[0] = ssg_mark_primary_se(opt, an[0], a[0], id << 1 | 0, z0, (int32_t*)v);
 				n_pri[1] = ssg_mark_primary_se(opt, an[1], a[1], id << 1 | 1, z0, (int32_t*)v);
-				if (n_pri[0] && n_pri[1]) o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, S->u, 1024, &myerr);
+				if (n_pri[0] && n_pri[1] && !(opt.flag & SSG_F_NOPAIRING)) o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, S->u, 1024, &myerr);
 				ssg_pair_decide(ix, opt, pes, p, a, an, n_pri, o, subo, n_sub, z, z0, reg_off, rq, n_req);
 				if (myerr) err[p] = myerr;
 			}
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) ssg_k_pair_final_wave(ssg_index_view_t ix
 		}
 		n_pri[0] = wv_mark_primary_se(opt, an[0], a[0], id << 1 | 0, S, L, &myerr);
 		n_pri[1] = wv_mark_primary_se(opt, an[1], a[1], id << 1 | 1, S, L, &myerr);
-		if (n_pri[0] && n_pri[1] && !myerr) o = wv_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, S, L, &myerr);
+		if (n_pri[0] && n_pri[1] && !myerr && !(opt.flag & SSG_F_NOPAIRING)) o = wv_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, S, L, &myerr);
 		ssg_wave_memsync();
 		if (wv_lane() == 0) {
 			if (!myerr) ssg_pair_decide(ix, opt, pes, p, a, an, n_pri, o, subo, n_sub, z, z0, reg_off, rq, n_req);

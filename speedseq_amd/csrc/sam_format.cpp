@@ -41,7 +41,7 @@ inline int get_rlen(int n_cigar, const uint32_t *cigar)
 struct mate_t { int rid; long long pos; int is_rev, n_cigar; const uint32_t *cigar; };
 
 void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, const uint8_t *seq, const char *qual, const char *comment,
-             int n, const ssg_aln_t *const *list, int which, const mate_t *m_, const std::string *XA, const char *rg_id)
+             int n, const ssg_aln_t *const *list, int which, const mate_t *m_, const std::string *XA, const char *rg_id, bool softclip)
 {	/* upstream mem_aln2sam */
 	const ssg_aln_t &a = *list[which];
 	int flag = a.flag, rid = a.rid, is_rev = a.is_rev, n_cigar = a.n_cigar; long long pos = a.pos;
@@ -63,7 +63,7 @@ void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, con
 		if (n_cigar) {
 			for (int i = 0; i < n_cigar; ++i) {
 				int c = a.cigar[i] & 0xf;
-				if (c == 3 || c == 4) c = which ? 4 : 3;
+				if (!softclip && (c == 3 || c == 4)) c = which ? 4 : 3;
 				str.putl(a.cigar[i] >> 4); str.putc("MIDSH"[c]);
 			}
 		} else str.putc('*');
@@ -84,7 +84,7 @@ void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, con
 	if (flag & 0x100) str.puts("*\t*");
 	else if (!is_rev) {
 		int qb = 0, qe = l_seq;
-		if (n_cigar && which) {
+		if (n_cigar && which && !softclip) {
 			if ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3) qb += a.cigar[0] >> 4;
 			if ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3) qe -= a.cigar[n_cigar-1] >> 4;
 		}
@@ -93,7 +93,7 @@ void aln2sam(const ssg_index_t *idx, sbuf &str, const char *name, int l_seq, con
 		if (qual) str.s.append(qual + qb, qe - qb); else str.putc('*');
 	} else {
 		int qb = 0, qe = l_seq;
-		if (n_cigar && which) {
+		if (n_cigar && which && !softclip) {
 			if ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3) qe -= a.cigar[0] >> 4;
 			if ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3) qb += a.cigar[n_cigar-1] >> 4;
 		}
@@ -160,7 +160,7 @@ struct alignas(128) bbuf {
 };
 
 void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, const uint8_t *seq, const char *qual,
-             int n, const ssg_aln_t *const *list, int which, const mate_t *m_, const std::string *XA, const char *rg_id)
+             int n, const ssg_aln_t *const *list, int which, const mate_t *m_, const std::string *XA, const char *rg_id, bool softclip)
 {
 	const ssg_aln_t &a = *list[which];
 	int flag = a.flag, rid = a.rid, is_rev = a.is_rev, n_cigar = a.n_cigar; long long pos = a.pos;
@@ -184,7 +184,7 @@ void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, con
 		tid = rid; bpos = (int32_t)pos; mapq = a.mapq;
 		for (int i = 0; i < n_cigar; ++i) {
 			int c = a.cigar[i] & 0xf;
-			if (c == 3 || c == 4) c = which ? 4 : 3;
+			if (!softclip && (c == 3 || c == 4)) c = which ? 4 : 3;
 			const uint32_t len = a.cigar[i] >> 4, v = len << 4 | (uint32_t)(c <= 2 ? c : c + 1);   /* "MIDSH" -> BAM codes M0 I1 D2 S4 H5 */
 			out.put(&v, 4);
 			if (c == 0 || c == 2) rl += len;
@@ -205,7 +205,7 @@ void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, con
 	int32_t l_qseq = 0;
 	if (!(flag & 0x100)) {
 		int qb = 0, qe = l_seq;
-		const bool cl0 = n_cigar && which && ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3), cl1 = n_cigar && which && ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3);
+		const bool cl0 = n_cigar && which && !softclip && ((a.cigar[0] & 0xf) == 4 || (a.cigar[0] & 0xf) == 3), cl1 = n_cigar && which && !softclip && ((a.cigar[n_cigar-1] & 0xf) == 4 || (a.cigar[n_cigar-1] & 0xf) == 3);
 		if (!is_rev) { if (cl0) qb += a.cigar[0] >> 4; if (cl1) qe -= a.cigar[n_cigar-1] >> 4; }
 		else { if (cl0) qe -= a.cigar[0] >> 4; if (cl1) qb += a.cigar[n_cigar-1] >> 4; }
 		l_qseq = qe > qb ? qe - qb : 0;
@@ -253,7 +253,7 @@ void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, con
 
 /* pairs sel[p0..p1) (or p0..p1 themselves when sel == NULL) into `out` (text) or `bout` (BAM records); offs entries relative to the buffer's start */
 static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, const int32_t *sel, int p0, int p1, const char *const *names, const uint8_t *seq, const int64_t *off,
-                        const char *const *quals, const char *const *comments, const char *rg_id, sbuf *out, bbuf *bout, int64_t *offs)
+                        const char *const *quals, const char *const *comments, const char *rg_id, bool softclip, sbuf *out, bbuf *bout, int64_t *offs)
 {
 	const int64_t *req_off = ssg_pe_req_off(res);
 	const ssg_alnreq_t *req = ssg_pe_req(res);
@@ -292,9 +292,9 @@ static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, cons
 			const int l_seq = (int)(off[r+1] - off[r]);
 			for (size_t k = 0; k < mains[i].size(); ++k) {
 				if (out) aln2sam(idx, *out, names[r], l_seq, seq + off[r], quals ? quals[r] : 0, comments ? comments[r] : 0,
-				                 (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id);
+				                 (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id, softclip);
 				else aln2bam(idx, *bout, names[r], l_seq, seq + off[r], quals ? quals[r] : 0,
-				             (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id);
+				             (int)mains[i].size(), mains[i].data(), (int)k, &mate[!i], &xa[i][k], rg_id, softclip);
 			}
 		}
 	}
@@ -321,7 +321,7 @@ static int format_all(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ss
 			auto &B = bytes_of(outs[t]); B.clear(); B.reserve((size_t)(lo(t + 1) - lo(t)) * (text ? 1000 : 800));
 			sbuf *so = 0; bbuf *bo = 0;
 			if constexpr (std::is_same<BUF, sbuf>::value) so = &outs[t]; else bo = &outs[t];
-			rcs[t] = format_range(idx, res, sel, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, so, bo, offs); };
+			rcs[t] = format_range(idx, res, sel, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, opt && (opt->flag & SSG_F_SOFTCLIP), so, bo, offs); };   /* -Y: upstream MEM_F_SOFTCLIP */
 		if (T == 1) work(); else th.emplace_back(work);
 	}
 	for (auto &x : th) x.join();

@@ -20,8 +20,14 @@ typedef struct {
 	uint64_t max_mem_intv;
 	float split_factor, mask_level, drop_ratio, XA_drop_ratio, mask_level_redun, mapQ_coef_len;
 	int8_t mat[25];
-	int8_t _pad[7];
+	int8_t _pad0;
+	uint16_t flag;          /* upstream opt->flag, the bits this path reads: SSG_F_NO_MULTI (-M), SSG_F_SOFTCLIP (-Y) */
+	int8_t _pad[4];
 } ssg_mem_opt_t;
+#define SSG_F_NO_MULTI 0x10    /* upstream MEM_F_NO_MULTI: a supplementary line carries 0x10000 (printed as 0x100) instead of 0x800 */
+#define SSG_F_NOPAIRING 0x4    /* upstream MEM_F_NOPAIRING (-P): mate rescue, then every read on its own */
+#define SSG_F_NO_RESCUE 0x20   /* upstream MEM_F_NO_RESCUE (-S) */
+#define SSG_F_SOFTCLIP 0x200   /* upstream MEM_F_SOFTCLIP: supplementary lines keep soft clips and the whole SEQ / QUAL */
 
 /* FM-index resident in HBM (upstream bwt_t + bntseq_t + pac).  The .bwt body is kept in its
  * on-disk interleaved form: one 64-byte block = 4 x u64 running counts + 8 x u32 (128 symbols),

@@ -729,6 +729,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	CHKA(d_xjobs); CHKA(d_xl); CHKA(d_xr); CHKA(d_kl); CHKA(d_kr); CHKA(d_sl); CHKA(d_sr);
 	if (n_jobs > 0) {
 		if (opt->a * 2 * max_len + 64 >= 8191) { ssg_err_msg = "match score x read length beyond the 13-bit DP cells of the extension kernel"; return SSG_EINVAL; }
+		if (opt->min_chain_weight > 0 && 2.8f * (float)opt->min_chain_weight <= 0.05f * (float)max_len) {   /* upstream mem_flt_chained_seeds would run (MEM_HSP_COEF x W <= MEM_SEEDSW_COEF x l): its seed-level SW is not built */
+			ssg_err_msg = "-W this small against this read length turns on upstream's chained-seed filter (long-read path), which this build does not have"; return SSG_EINVAL; }
 		if (opt->a > 31 || opt->a < 0 || opt->b > 32 || opt->b < 0) { ssg_err_msg = "match score above 31 or mismatch penalty above 32: beyond the 6-bit score table of the extension kernel"; return SSG_EINVAL; }
 		const int short_cap = 72;   /* sides up to 72 bases run with half the LDS per wave (two waves per SIMD) */
 		dbuf<unsigned int> d_nlong(2);
@@ -925,7 +927,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	const int wpb = SSG_WAVES_PER_WG;
 	dbuf<unsigned int> d_q(1);
 	CHKA(d_q); CHK(d_q.zero());
-	{	/* ---- mate rescue ---- */
+	if (!(opt->flag & SSG_F_NO_RESCUE)) {	/* ---- mate rescue (upstream mem_sam_pe: unless -S) ---- */
 		long nwg = std::min<long>(((long)n_pairs + wpb - 1) / wpb, 256 * SSG_SW_WAVES_PER_SIMD);
 		long nw = nwg * wpb;
 		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB); dbuf<unsigned long long> d_bglb((size_t)nw * SSG_MS_BCAP); dbuf<ssg_alnreg_t> d_bcopy((size_t)nw * (128 + SSG_SDP_BIG)); dbuf<ssg_sdp_big_t> d_sdpbig((size_t)nw);

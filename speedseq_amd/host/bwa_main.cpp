@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <math.h>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -69,27 +70,71 @@ static int main_mem(int argc, char **argv)
 	ssg_mem_opt_t opt; ssg_mem_opt_init(&opt);
 	bool interleaved = false, keep_comment = false; std::string rg; char rg_id[256] = "";
 	ssg_pestat_t pes0[4], *pes = 0;
-	int ai = 1;
-	for (; ai < argc && argv[ai][0] == '-' && argv[ai][1]; ++ai) {
-		const char *a = argv[ai];
-		if (!strcmp(a, "-p")) interleaved = true;
-		else if (!strcmp(a, "-C")) keep_comment = true;
-		else if (!strcmp(a, "-M")) { fprintf(stderr, "[bwa] -M (mark shorter split hits as secondary) is not supported; speedseq align does not pass it\n"); return 1; }
-		else if (!strcmp(a, "-t") && ai + 1 < argc) opt.n_threads = atoi(argv[++ai]);
-		else if (!strcmp(a, "-R") && ai + 1 < argc) rg = unescape(argv[++ai]);
-		else if (!strcmp(a, "-I") && ai + 1 < argc) { /* upstream main_mem -I: FR orientation only */
-			char *p; pes = pes0; memset(pes0, 0, sizeof(pes0));
+	int ai, c, fixed_chunk = 0; char *p;
+	struct { bool a, b, T, o_del, e_del, o_ins, e_ins, zdrop, clip5, clip3, unpaired; } set = {};   /* upstream main_mem's opt0: the scoring fields the command line set itself */
+	auto second = [&p]() { return *p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1]); };   /* upstream's "INT[,INT]" forms */
+	optind = 1;
+	/* upstream main_mem's option letters (fastmap.c, 0.7.12).  Not taken: -a -e -F -V -j -x -H (INTEGRATION.md says what each would need) */
+	while ((c = getopt(argc, argv, "pMCSPYk:c:v:s:r:t:R:A:B:O:E:U:w:L:d:T:Q:D:m:I:N:W:G:h:y:K:X:")) >= 0) {
+		if (c == 'p') interleaved = true;
+		else if (c == 'C') keep_comment = true;
+		else if (c == 'M') opt.flag |= SSG_F_NO_MULTI;
+		else if (c == 'Y') opt.flag |= SSG_F_SOFTCLIP;
+		else if (c == 'S') opt.flag |= SSG_F_NO_RESCUE;
+		else if (c == 'P') opt.flag |= SSG_F_NOPAIRING;
+		else if (c == 'k') opt.min_seed_len = atoi(optarg);
+		else if (c == 'w') opt.w = atoi(optarg);
+		else if (c == 'A') opt.a = atoi(optarg), set.a = true;
+		else if (c == 'B') opt.b = atoi(optarg), set.b = true;
+		else if (c == 'T') opt.T = atoi(optarg), set.T = true;
+		else if (c == 'U') opt.pen_unpaired = atoi(optarg), set.unpaired = true;
+		else if (c == 't') opt.n_threads = atoi(optarg);
+		else if (c == 'c') opt.max_occ = atoi(optarg);
+		else if (c == 'd') opt.zdrop = atoi(optarg), set.zdrop = true;
+		else if (c == 'v') ;   /* verbosity: nothing on stdout depends on it */
+		else if (c == 'r') opt.split_factor = (float)atof(optarg);
+		else if (c == 'D') opt.drop_ratio = (float)atof(optarg);
+		else if (c == 'm') opt.max_matesw = atoi(optarg);
+		else if (c == 's') opt.split_width = atoi(optarg);
+		else if (c == 'G') opt.max_chain_gap = atoi(optarg);
+		else if (c == 'N') opt.max_chain_extend = atoi(optarg);
+		else if (c == 'W') opt.min_chain_weight = atoi(optarg);
+		else if (c == 'y') opt.max_mem_intv = (uint64_t)atol(optarg);
+		else if (c == 'K') fixed_chunk = atoi(optarg);
+		else if (c == 'X') opt.mask_level = (float)atof(optarg);
+		else if (c == 'h') { opt.max_XA_hits = opt.max_XA_hits_alt = (int)strtol(optarg, &p, 10); if (second()) opt.max_XA_hits_alt = (int)strtol(p + 1, &p, 10); }
+		else if (c == 'Q') { opt.mapQ_coef_len = (float)atoi(optarg); opt.mapQ_coef_fac = opt.mapQ_coef_len > 0 ? (int)log(opt.mapQ_coef_len) : 0; }
+		else if (c == 'O') { set.o_del = set.o_ins = true; opt.o_del = opt.o_ins = (int)strtol(optarg, &p, 10); if (second()) opt.o_ins = (int)strtol(p + 1, &p, 10); }
+		else if (c == 'E') { set.e_del = set.e_ins = true; opt.e_del = opt.e_ins = (int)strtol(optarg, &p, 10); if (second()) opt.e_ins = (int)strtol(p + 1, &p, 10); }
+		else if (c == 'L') { set.clip5 = set.clip3 = true; opt.pen_clip5 = opt.pen_clip3 = (int)strtol(optarg, &p, 10); if (second()) opt.pen_clip3 = (int)strtol(p + 1, &p, 10); }
+		else if (c == 'R') rg = unescape(optarg);
+		else if (c == 'I') { /* upstream main_mem -I: FR orientation only */
+			pes = pes0; memset(pes0, 0, sizeof(pes0));
 			pes0[0].failed = pes0[2].failed = pes0[3].failed = 1;
-			pes0[1].avg = strtod(argv[++ai], &p);
+			pes0[1].avg = strtod(optarg, &p);
 			pes0[1].std = pes0[1].avg * .1;
-			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].std = strtod(p + 1, &p);
+			if (second()) pes0[1].std = strtod(p + 1, &p);
 			pes0[1].high = (int)(pes0[1].avg + 4. * pes0[1].std + .499);
 			pes0[1].low  = (int)(pes0[1].avg - 4. * pes0[1].std + .499);
 			if (pes0[1].low < 1) pes0[1].low = 1;
-			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].high = (int)(strtod(p + 1, &p) + .499);
-			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0[1].low  = (int)(strtod(p + 1, &p) + .499);
-		} else { fprintf(stderr, "[bwa] unsupported option %s\n", a); return 1; }
+			if (second()) pes0[1].high = (int)(strtod(p + 1, &p) + .499);
+			if (second()) pes0[1].low  = (int)(strtod(p + 1, &p) + .499);
+		} else { fprintf(stderr, "[bwa] mem: option not supported here (of upstream's letters -a -e -F -V -j -x -H are not taken)\n"); return 1; }
 	}
+	ai = optind;
+	if (set.a) {   /* upstream update_a: a changed match score scales the penalties the command line left alone */
+		if (!set.b) opt.b *= opt.a;
+		if (!set.T) opt.T *= opt.a;
+		if (!set.o_del) opt.o_del *= opt.a;
+		if (!set.e_del) opt.e_del *= opt.a;
+		if (!set.o_ins) opt.o_ins *= opt.a;
+		if (!set.e_ins) opt.e_ins *= opt.a;
+		if (!set.zdrop) opt.zdrop *= opt.a;
+		if (!set.clip5) opt.pen_clip5 *= opt.a;
+		if (!set.clip3) opt.pen_clip3 *= opt.a;
+		if (!set.unpaired) opt.pen_unpaired *= opt.a;
+	}
+	for (int i = 0, k = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) opt.mat[k++] = (int8_t)(i == j ? opt.a : -opt.b); opt.mat[k++] = -1; }   /* upstream bwa_fill_scmat */
 	if (argc - ai < 2) { fprintf(stderr, "usage: bwa mem [-t INT] [-p] [-I ...] [-R STR] [-C] <ref> <fq1> [fq2]\n"); return 1; }
 	if (opt.n_threads < 1) opt.n_threads = 1;
 	if (!rg.empty()) {
@@ -110,7 +155,7 @@ static int main_mem(int argc, char **argv)
 	if (argc - ai >= 3) { fp2 = gzopen(argv[ai + 2], "r"); if (!fp2) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 2]); return 1; } }
 	if (!interleaved && !fp2) { fprintf(stderr, "[bwa] single-end input is not supported: speedseq align is paired-end\n"); return 1; }
 	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
-	const int64_t chunk = (int64_t)opt.chunk_size * opt.n_threads;
+	const int64_t chunk = fixed_chunk > 0 ? fixed_chunk : (int64_t)opt.chunk_size * opt.n_threads;   /* -K: batches that do not depend on -t */
 
 	/* One worker thread per visible device (SURVEY 8e coupling 1: whole upstream batches go to the GPUs, no collective): each loads its
 	 * own replica of the index and takes the next assembled batch when it is free; results are re-serialised in input order. */

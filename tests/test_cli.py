@@ -69,6 +69,13 @@ def test_cli_error_behaviour(tmp_path, emu_lib):
     for env in ({"SSG_FASTQ_THREADS": "4", "SSG_FASTQ_PIECE": "20000"}, {}):
         r = subprocess.run([emu, "mem", EXAMPLE_FA + ".missing", str(big), str(big)], capture_output=True, timeout=60, env=dict(os.environ, **env))
         assert r.returncode != 0 and b"fail to load the index" in r.stderr
+    # upstream letters this build does not take, and values that would need upstream's long-read path: an error that names the reason, never other output
+    fq = tmp_path / "few.fq"
+    simreads.write_fastq(str(fq), simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 50, seed=5))
+    for opts, msg in ((["-a"], b"not supported"), (["-x", "pacbio"], b"not supported"), (["-W", "2"], b"chained-seed filter"), (["-A", "40"], b"DP cells")):
+        r = subprocess.run([emu, "mem", "-p"] + opts + [EXAMPLE_FA, str(fq)], capture_output=True, timeout=120)
+        assert r.returncode != 0 and msg in r.stderr, (opts, r.stderr[-300:])
+        assert not any(l and l[0] != "@" for l in r.stdout.decode().split("\n")), opts
 
 
 @pytest.mark.gpu
@@ -226,3 +233,37 @@ def test_cli_emu_several_calls_in_flight(tmp_path, emu_lib):
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(_no_pg(r.stdout.decode()))
     assert outs[0].count("\n") > 1800 and outs[1] == outs[0] and outs[2] == outs[0]
+
+
+BWA_OPTION_SETS = [
+    ("-M",), ("-Y",), ("-M", "-Y"), ("-S",), ("-P",), ("-S", "-P"),
+    ("-k", "25"), ("-w", "40", "-d", "50"), ("-A", "2"), ("-A", "2", "-B", "5", "-O", "7,9", "-E", "2,1"), ("-L", "3,8", "-U", "9"),
+    ("-T", "45"), ("-c", "50", "-D", "0.3"), ("-r", "1.0", "-y", "10"), ("-m", "5", "-W", "6"), ("-h", "2", "-X", "0.3"), ("-K", "20000"),
+    ("-Q", "20", "-s", "5", "-G", "500", "-N", "3"),
+]
+
+
+@pytest.mark.parametrize("opts", BWA_OPTION_SETS, ids=lambda o: "".join(o))
+def test_cli_emu_bwa_mem_option_sets(tmp_path, emu_lib, opts):
+    """upstream main_mem's option letters (fastmap.c, 0.7.12): each set through the product's `bwa mem` and the oracle's, SAM byte for byte.
+    -M / -Y change how split hits are printed, -S / -P drop mate rescue / pairing, the rest are the scoring and heuristic knobs of mem_opt_t
+    (the `-A` forms also exercise upstream's update_a scaling of the penalties left alone)."""
+    _bwa_options(tmp_path, [os.path.join(ROOT, "tests", "emu", "bwa_emu")], opts, 400)
+
+
+def _bwa_options(tmp_path, bwa, opts, n_pairs):
+    d = str(tmp_path)
+    fq = os.path.join(d, "reads.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=77))
+    run = lambda exe: _no_pg(subprocess.run(exe + ["mem", "-t", "2", "-p", "-R", RG] + list(opts) + [EXAMPLE_FA, fq], capture_output=True, check=True).stdout.decode())
+    got, exp = run(bwa), run([ORC])
+    assert exp.count("\n") > 2 * n_pairs
+    if "-M" in opts:
+        assert any(int(l.split("\t")[1]) & 0x100 for l in exp.split("\n") if l and l[0] != "@"), "no split hit in the sample: -M untested"
+    assert got == exp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [("-M", "-Y"), ("-S", "-P"), ("-A", "2", "-B", "5", "-O", "7,9", "-E", "2,1"), ("-k", "25", "-c", "50", "-D", "0.3", "-r", "1.0")], ids=lambda o: "".join(o))
+def test_cli_gpu_bwa_mem_option_sets(tmp_path, gpu_lib, opts):
+    _bwa_options(tmp_path, [os.path.join(ROOT, "bin", "bwa")], opts, 20000)
