@@ -201,13 +201,23 @@ static void bai_note_write(const std::string &bam)
  * which the reference runs right after the sort (bin/speedseq:491-495), recognise the pair as current instead of inflating the BAM again */
 /* force_at != NULL (a sorted run on its way to the temporary directory, cmd_sort): no header; a block starts at each of these record
  * indices (ascending, <= n) and force_off receives the file offset of that block -- the run's segments, one per range of the genome */
+/* seg != NULL (the merge of sorted runs, merge_runs): the file is written by several calls, one per stretch of the genome; the first writes the
+ * header, the last the end-of-file block and the index, and the state that crosses calls lives in *seg */
+struct seg_out_t {
+	bool first, last;                                  /* set by the caller for each call */
+	uint64_t coff;                                     /* file offset of the next block */
+	std::unique_ptr<bai_t> idx; bool idx_ok;
+	bool pending; int32_t p_tid, p_pos, p_end; bool p_mapped;   /* the last record of the previous stretch: its entry closes at the first record of the next */
+	seg_out_t() : first(true), last(false), coff(0), idx_ok(true), pending(false), p_tid(0), p_pos(0), p_end(0), p_mapped(false) {}
+};
 static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads, const char *bai_path = 0,
-                         const std::vector<size_t> *force_at = 0, std::vector<uint64_t> *force_off = 0)
+                         const std::vector<size_t> *force_at = 0, std::vector<uint64_t> *force_off = 0, seg_out_t *seg = 0, std::vector<uint64_t> *force_uoff = 0)
 {
-	if (!force_at) { bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
-	const off_t hdr_end = force_at ? (off_t)0 : bai_path ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
-	if (hdr_end < 0) bai_path = 0;
-	const bool want_off = bai_path || force_at;
+	const bool opens = !seg || seg->first, closes = !seg || seg->last;
+	if (!force_at && opens) { bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
+	const off_t hdr_end = force_at ? (off_t)0 : !opens ? (off_t)seg->coff : (bai_path || seg) ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+	if (hdr_end < 0) { if (seg) die("sort: the output of a merge must be a regular file"); bai_path = 0; }
+	const bool want_off = bai_path || force_at || seg;
 	const size_t n = perm.size();
 	const int lvl = level < 0 ? 6 : level;
 	const double tw0 = wall();
@@ -244,7 +254,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	/* blocks deflated on the device: the final file of a sort at a compressing level, when there is a device (SSG_BGZF_DEVICE=0 keeps zlib on the
 	 * host's threads; the host emulation of the kernels only does it on request, it is slow) */
 	const char *const bd = getenv("SSG_BGZF_DEVICE");
-	const bool use_dev = !force_at && lvl != 0 && nb > 0 && !(bd && !strcmp(bd, "0")) && (bd || strcmp(ssg_backend(), "emu") != 0) && ssg_device_count() > 0 && GRP * 2 <= 2048 && 2048 % GRP == 0;
+	const bool use_dev = lvl != 0 && nb > 0 && !(bd && !strcmp(bd, "0")) && (bd || strcmp(ssg_backend(), "emu") != 0) && ssg_device_count() > 0 && GRP * 2 <= 2048 && 2048 % GRP == 0;
 	const int n_workers = use_dev ? 0 : (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
 	const size_t window = use_dev ? (size_t)8 * 2048 / GRP : std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
 	auto nap = [](int us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); };
@@ -335,20 +345,26 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	});
 	std::atomic<size_t> blocks_placed(0);                       /* blk_coff[0 .. blocks_placed) are final */
 	std::atomic<uint64_t> file_end_v(0);                        /* virtual offset of the end of the file, 0 until the last block is placed */
-	bai_t idx((int)h.names.size(), 0); bool idx_ok = true; double t_idx_wait = 0;
+	bai_t idx_own((int)h.names.size(), 0); bool idx_ok = seg ? seg->idx_ok : true; double t_idx_wait = 0;
 	std::thread t_idx;
 	if (bai_path) t_idx = std::thread([&]() {
 		size_t bk = 0;
 		auto wait_blocks = [&](size_t need) { if (blocks_placed.load(std::memory_order_acquire) >= need) return; const double t0 = wall(); while (blocks_placed.load(std::memory_order_acquire) < need) nap(100); t_idx_wait += wall() - t0; };
 		auto voff = [&](size_t i) -> uint64_t { while (cut[bk + 1] <= cum[i]) ++bk; wait_blocks(bk + 1); return blk_coff[bk] << 16 | (cum[i] - cut[bk]); };
 		auto end_of_file = [&]() -> uint64_t { wait_blocks(nb + 1); return file_end_v.load(); };
-		const uint64_t first = n ? voff(0) : end_of_file();
-		idx = bai_t((int)h.names.size(), first);
+		if (!idx_ok) return;
+		if (!n && !closes) return;                                     /* a stretch without records: nothing to say yet */
+		bai_t *ix = &idx_own;
+		if (!seg) idx_own = bai_t((int)h.names.size(), n ? voff(0) : end_of_file());
+		else { if (!seg->idx) seg->idx.reset(new bai_t((int)h.names.size(), n ? voff(0) : end_of_file())); ix = seg->idx.get(); }
+		if (seg && seg->pending && n) { if (ix->push(seg->p_tid, seg->p_pos, seg->p_end, voff(0), seg->p_mapped) < 0) { idx_ok = false; return; } seg->pending = false; }
 		for (size_t i = 0; i < n; ++i) {
+			if (i + 1 == n && !closes) { seg->pending = true; seg->p_tid = ent[i].tid; seg->p_pos = ent[i].pos; seg->p_end = ent[i].end; seg->p_mapped = ent[i].mapped != 0; break; }
 			const uint64_t after = i + 1 < n ? voff(i + 1) : end_of_file();
-			if (idx.push(ent[i].tid, ent[i].pos, ent[i].end, after, ent[i].mapped != 0) < 0) { idx_ok = false; break; }   /* cannot happen on a sorted stream; `sambamba index` will say so */
+			if (ix->push(ent[i].tid, ent[i].pos, ent[i].end, after, ent[i].mapped != 0) < 0) { idx_ok = false; break; }   /* cannot happen on a sorted stream; `sambamba index` will say so */
 		}
-		if (idx_ok) idx.finish(end_of_file());
+		if (idx_ok && closes && seg && seg->pending) { if (ix->push(seg->p_tid, seg->p_pos, seg->p_end, end_of_file(), seg->p_mapped) < 0) idx_ok = false; seg->pending = false; }
+		if (idx_ok && closes) ix->finish(end_of_file());
 	});
 	std::vector<std::thread> th;
 	const double tw_spawn0 = wall();
@@ -369,20 +385,23 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		blk_coff[nb] = coff;
 		force_off->resize(force_at->size());
 		for (size_t k = 0; k < force_at->size(); ++k) (*force_off)[k] = (*force_at)[k] >= n ? coff : blk_coff[force_blk[k]];
+		if (force_uoff) { force_uoff->resize(force_at->size()); for (size_t k = 0; k < force_at->size(); ++k) (*force_uoff)[k] = cum[std::min((*force_at)[k], n)]; }
 		return;
 	}
-	io_write_all(fd, BGZF_EOF, 28);
+	if (closes) io_write_all(fd, BGZF_EOF, 28);
 	const double tw2 = wall();
 	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index %.2f s, %d workers started in %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
 	                   "per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn0 - tw1, n_workers, tw_spawn - tw_spawn0, t_wr_wait, t_wr_io,
 	                   us_gather / 1e6 / std::max(1, n_workers + n_prod), us_deflate / 1e6 / std::max(1, n_workers + n_prod), us_window / 1e6 / std::max(1, n_workers + n_prod));
 	if (dbg() && use_dev) fprintf(stderr, "[sambamba] sort: write: blocks deflated on the device (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_prod);
+	if (seg) seg->coff = coff;
 	if (!bai_path) return;
 	blk_coff[nb] = coff;
-	file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release);
+	if (closes) { file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release); }
 	t_idx.join();
-	if (!idx_ok) return;
-	idx.save(bai_path);
+	if (seg) seg->idx_ok = idx_ok;
+	if (!idx_ok || !closes) return;
+	(seg ? *seg->idx : idx_own).save(bai_path);
 	if (dbg()) fprintf(stderr, "[sambamba] sort: write: index finished %.2f s after the last block (its thread waited %.2f s for block offsets)\n", wall() - tw2, t_idx_wait);
 }
 
@@ -408,7 +427,7 @@ static void kway_merge(std::vector<merge_src_t> &src, bgzf_out_t &out)
  * over whole runs -- a single thread moving every record -- but an independent small merge per range, run by the pool, each inflating
  * only its own byte range of every run and compressing its own stretch of the output; a writer puts the stretches out in order.  Ties
  * keep input order: equal keys share a range, and within a range the earlier run wins. */
-struct run_t { std::string path; int fd; std::vector<uint64_t> seg; };   /* seg[g] .. seg[g + 1]: the run's records of range g */
+struct run_t { std::string path; int fd; std::vector<uint64_t> seg, useg; };   /* seg[g] .. seg[g + 1]: the run's records of range g in the file; useg: the same in record bytes */
 
 static void make_ranges(const bam_hdr_t &h, size_t G, std::vector<uint64_t> &lo)
 {	/* lo[g] = smallest sort key of range g (equal shares of the genome's length); reads without a position sort last: the last range */
@@ -425,103 +444,102 @@ static void make_ranges(const bam_hdr_t &h, size_t G, std::vector<uint64_t> &lo)
 	}
 }
 
-struct run_reader_t {   /* the records of one byte range of a run file, in order */
-	int fd; uint64_t pos, end; std::vector<uint8_t> raw, buf; size_t bo; std::vector<uint8_t> rec; uint64_t key; bool ok;
-	run_reader_t(int fd_, uint64_t a, uint64_t b) : fd(fd_), pos(a), end(b), bo(0), key(0), ok(false) {}
-	bool fill()
-	{
-		buf.clear(); bo = 0;
-		if (pos >= end) return false;
-		const size_t want = (size_t)std::min<uint64_t>(end - pos, (uint64_t)1 << 20);
-		raw.resize(want);
-		for (size_t got = 0; got < want; ) { const ssize_t r = pread(fd, raw.data() + got, want - got, (off_t)(pos + got)); if (r < 0 && errno == EINTR) continue; if (r <= 0) die("sort: cannot read a sorted run back"); got += (size_t)r; }
-		size_t o = 0;
-		while (o + 18 <= want) {
-			const uint8_t *b = raw.data() + o;
-			if (b[0] != 0x1f || b[1] != 0x8b || !(b[3] & 4) || b[12] != 'B' || b[13] != 'C') die("sort: a sorted run is damaged");
-			const size_t bsize = (size_t)(b[16] | (size_t)b[17] << 8) + 1, xlen = b[10] | (size_t)b[11] << 8;
-			if (o + bsize > want) break;
-			uint32_t isz; memcpy(&isz, b + bsize - 4, 4);
-			const size_t at = buf.size(); buf.resize(at + isz);
-			if (isz) {
-				z_stream zs; memset(&zs, 0, sizeof(zs));
-				zs.next_in = (Bytef*)(b + 12 + xlen); zs.avail_in = (uInt)(bsize - 12 - xlen - 8); zs.next_out = buf.data() + at; zs.avail_out = isz;
-				if (inflateInit2(&zs, -15) != Z_OK || inflate(&zs, Z_FINISH) != Z_STREAM_END) die("sort: a sorted run does not inflate");
-				inflateEnd(&zs);
-			}
-			o += bsize;
-		}
-		if (!o) die("sort: a sorted run is damaged");
-		pos += o;
-		return true;
-	}
-	size_t get(void *dst, size_t n)
-	{
-		uint8_t *d = (uint8_t*)dst; size_t got = 0;
-		while (got < n) {
-			if (bo >= buf.size() && !fill()) break;
-			const size_t k = std::min(n - got, buf.size() - bo);
-			memcpy(d + got, buf.data() + bo, k); got += k; bo += k;
-		}
-		return got;
-	}
-	bool next()
-	{
-		uint32_t bs;
-		if (get(&bs, 4) != 4) { ok = false; return false; }
-		rec.resize(4 + (size_t)bs); memcpy(rec.data(), &bs, 4);
-		if (bs < 32 || get(rec.data() + 4, bs) != bs) die("sort: a sorted run is damaged");
-		key = bam_sort_key(rec.data() + 4); ok = true;
-		return true;
-	}
-};
-
-static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, int fd, int level, int threads)
+/* The merge of the runs is the in-memory sort again, a stretch of the genome at a time: consecutive ranges whose records -- of all runs -- fit
+ * a third of the budget are read back (every BGZF block of a run's byte range inflated by the pool), indexed per (run, range) piece in
+ * parallel, ordered by the device's stable radix sort of the keys (the pieces of one run are in order already, earlier runs come first:
+ * ties keep input order) and written through write_sorted's pipeline -- gather on the host, deflate on the device, one in-order writer, the
+ * .bai following it -- while the loader thread already inflates the next stretch. */
+static void load_stretch(std::vector<run_t> &runs, size_t g0, size_t g1, int threads, rec_store_t &S)
 {
-	{ bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
-	const int lvl = level < 0 ? 6 : level;
-	struct part_t { std::vector<uint8_t> bytes; bool done; part_t() : done(false) {} };
-	std::vector<part_t> part(G);
-	std::mutex mu; std::condition_variable cv; size_t next_write = 0; std::atomic<size_t> next_g(0);
-	const size_t window = (size_t)std::max(2, threads * 2);
-	auto worker = [&]() {
-		std::vector<uint8_t> payload, blk(65536); payload.reserve(BGZF_MAX_PAYLOAD);
-		for (;;) {
-			const size_t g = next_g.fetch_add(1);
-			if (g >= G) break;
-			{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return g < next_write + window; }); }
-			std::vector<uint8_t> ob;
-			auto flush = [&]() { if (payload.empty()) return; const size_t k = bgzf_make_block(payload.data(), payload.size(), lvl, blk.data()); ob.insert(ob.end(), blk.data(), blk.data() + k); payload.clear(); };
-			std::vector<std::unique_ptr<run_reader_t> > rd;
-			typedef std::pair<uint64_t, size_t> ent_t;
-			std::priority_queue<ent_t, std::vector<ent_t>, std::greater<ent_t> > pq;
-			for (size_t r = 0; r < runs.size(); ++r) {
-				rd.emplace_back(new run_reader_t(runs[r].fd, runs[r].seg[g], runs[r].seg[g + 1]));
-				if (runs[r].seg[g + 1] > runs[r].seg[g] && rd[r]->next()) pq.push(ent_t(rd[r]->key, r));
-			}
-			while (!pq.empty()) {
-				const size_t r = pq.top().second; pq.pop();
-				const uint8_t *p = rd[r]->rec.data(); size_t n = rd[r]->rec.size();
-				if (payload.size() + n > BGZF_MAX_PAYLOAD) flush();                       /* bgzf_flush_try */
-				while (n) { const size_t k = std::min(n, (size_t)BGZF_MAX_PAYLOAD - payload.size()); payload.insert(payload.end(), p, p + k); p += k; n -= k; if (payload.size() == BGZF_MAX_PAYLOAD) flush(); }
-				if (rd[r]->next()) pq.push(ent_t(rd[r]->key, r));
-			}
-			flush();
-			{ std::lock_guard<std::mutex> l(mu); part[g].bytes.swap(ob); part[g].done = true; }
-			cv.notify_all();
+	S.clear();
+	struct piece_t { size_t chunk; uint64_t a, b; std::vector<uint64_t> loc, key; };
+	std::vector<piece_t> pieces;
+	for (size_t r = 0; r < runs.size(); ++r) {
+		const run_t &R = runs[r];
+		const uint64_t c0 = R.seg[g0], c1 = R.seg[g1], u0 = R.useg[g0], u1 = R.useg[g1];
+		if (u1 == u0) continue;
+		std::vector<uint8_t> raw((size_t)(c1 - c0));
+		{	/* the byte range, read by several threads (page cache or disk) */
+			const size_t PIECE = (size_t)8 << 20, np = (raw.size() + PIECE - 1) / PIECE;
+			parallel_for((int)std::min<size_t>((size_t)std::max(1, threads), np), np, [&](size_t a, size_t b, int) {
+				for (size_t k = a; k < b; ++k) {
+					const size_t lo = k * PIECE, want = std::min(PIECE, raw.size() - lo);
+					for (size_t got = 0; got < want; ) { const ssize_t q = pread(R.fd, raw.data() + lo + got, want - got, (off_t)(c0 + lo + got)); if (q < 0 && errno == EINTR) continue; if (q <= 0) die("sort: cannot read a sorted run back"); got += (size_t)q; }
+				}
+			});
 		}
-	};
-	std::vector<std::thread> th;
-	for (int t = 0; t < std::max(1, std::min<int>(threads, (int)G)); ++t) th.emplace_back(worker);
-	for (size_t g = 0; g < G; ++g) {
-		std::vector<uint8_t> ob;
-		{ std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return part[g].done; }); ob.swap(part[g].bytes); }
-		io_write_all(fd, ob.data(), ob.size());
-		{ std::lock_guard<std::mutex> l(mu); next_write = g + 1; }
-		cv.notify_all();
+		struct blk_t { size_t at, bsize, xlen; uint64_t uo; uint32_t isz; };
+		std::vector<blk_t> blk; uint64_t uo = 0;
+		for (size_t o = 0; o < raw.size(); ) {
+			const uint8_t *b = raw.data() + o;
+			if (o + 18 > raw.size() || b[0] != 0x1f || b[1] != 0x8b || !(b[3] & 4) || b[12] != 'B' || b[13] != 'C') die("sort: a sorted run is damaged");
+			blk_t k; k.at = o; k.bsize = (size_t)(b[16] | (size_t)b[17] << 8) + 1; k.xlen = b[10] | (size_t)b[11] << 8;
+			if (o + k.bsize > raw.size() || k.bsize < 12 + k.xlen + 8) die("sort: a sorted run is damaged");
+			memcpy(&k.isz, b + k.bsize - 4, 4); k.uo = uo; uo += k.isz; o += k.bsize;
+			blk.push_back(k);
+		}
+		if (uo != u1 - u0) die("sort: a sorted run is damaged");
+		fu_buf_t buf; if (!buf.heap((size_t)uo)) die("sort: out of memory");
+		parallel_for((int)std::min<size_t>((size_t)std::max(1, threads), blk.size() / 4 + 1), blk.size(), [&](size_t a, size_t b, int) {
+			z_stream zs; memset(&zs, 0, sizeof(zs));
+			if (inflateInit2(&zs, -15) != Z_OK) die("sort: zlib");
+			for (size_t k = a; k < b; ++k) {
+				const blk_t &B = blk[k];
+				if (!B.isz) continue;
+				zs.next_in = (Bytef*)(raw.data() + B.at + 12 + B.xlen); zs.avail_in = (uInt)(B.bsize - 12 - B.xlen - 8); zs.next_out = buf.p + B.uo; zs.avail_out = B.isz;
+				if (inflateReset(&zs) != Z_OK || inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out) die("sort: a sorted run does not inflate");
+			}
+			inflateEnd(&zs);
+		});
+		const size_t id = S.chunk.size();
+		for (size_t g = g0; g < g1; ++g) if (R.useg[g + 1] > R.useg[g]) { piece_t P; P.chunk = id; P.a = R.useg[g] - u0; P.b = R.useg[g + 1] - u0; pieces.push_back(std::move(P)); }
+		S.chunk.push_back(std::move(buf)); S.chunk_len.push_back((size_t)uo); S.bytes += uo;
 	}
-	for (auto &x : th) x.join();
-	io_write_all(fd, BGZF_EOF, 28);
+	std::atomic<int> bad(0);
+	parallel_for((int)std::min<size_t>((size_t)std::max(1, threads), pieces.size()), pieces.size(), [&](size_t a, size_t b, int) {
+		for (size_t k = a; k < b; ++k) {
+			piece_t &P = pieces[k]; const uint8_t *p = S.chunk[P.chunk].p; uint64_t o = P.a;
+			while (o + 4 <= P.b) { uint32_t bs; memcpy(&bs, p + o, 4); if (o + 4 + (uint64_t)bs > P.b || bs < 32) { bad = 1; break; } P.loc.push_back((uint64_t)P.chunk << 40 | o); P.key.push_back(bam_sort_key(p + o + 4)); o += 4 + (uint64_t)bs; }
+			if (o != P.b) bad = 1;
+		}
+	});
+	if (bad) die("sort: a sorted run is damaged");
+	size_t n = 0; for (const piece_t &P : pieces) n += P.loc.size();
+	if (n >= 0xfffffff0u) die("sort: a stretch of the merge holds too many records (raise -m)");
+	S.loc.resize(n); S.key.resize(n);
+	{ std::vector<size_t> at(pieces.size() + 1, 0); for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].loc.size();
+	  parallel_for((int)std::min<size_t>((size_t)std::max(1, threads), pieces.size()), pieces.size(), [&](size_t a, size_t b, int) {
+		for (size_t k = a; k < b; ++k) { if (pieces[k].loc.empty()) continue; memcpy(&S.loc[at[k]], pieces[k].loc.data(), 8 * pieces[k].loc.size()); memcpy(&S.key[at[k]], pieces[k].key.data(), 8 * pieces[k].key.size()); } }); }
+}
+
+static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, int fd, int level, int threads, uint64_t budget, const char *bai_path)
+{
+	std::vector<size_t> cutg(1, 0);
+	{	const uint64_t target = std::max<uint64_t>(budget / 3, 1); uint64_t acc = 0;
+		for (size_t g = 0; g < G; ++g) {
+			uint64_t sz = 0; for (const run_t &R : runs) sz += R.useg[g + 1] - R.useg[g];
+			if (acc && acc + sz > target) { cutg.push_back(g); acc = 0; }
+			acc += sz;
+		}
+		cutg.push_back(G);
+	}
+	const size_t ns = cutg.size() - 1;
+	chan_t<std::unique_ptr<rec_store_t> > ch(1);
+	std::thread loader([&]() {
+		for (size_t k = 0; k < ns; ++k) { std::unique_ptr<rec_store_t> S(new rec_store_t()); load_stretch(runs, cutg[k], cutg[k + 1], threads, *S); ch.push(std::move(S)); }
+		ch.close();
+	});
+	seg_out_t seg; double t_wait = 0, t_perm = 0, t_write = 0;
+	for (size_t k = 0; k < ns; ++k) {
+		std::unique_ptr<rec_store_t> S;
+		{ const double t0 = wall(); if (!ch.pop(S)) die("sort: the merge lost a stretch"); t_wait += wall() - t0; }
+		seg.first = k == 0; seg.last = k + 1 == ns;
+		std::vector<uint32_t> perm;
+		{ const double t0 = wall(); gpu_perm(*S, perm); t_perm += wall() - t0; }
+		{ const double t0 = wall(); write_sorted(*S, perm, h, fd, level, threads, bai_path, 0, 0, &seg); t_write += wall() - t0; }
+	}
+	loader.join();
+	if (dbg()) fprintf(stderr, "[sambamba] sort: merge: %zu stretches of the genome; waited %.2f s for the loader (read + inflate + index of the runs), device sort of the keys %.2f s, gather + deflate + write %.2f s\n", ns, t_wait, t_perm, t_write);
 }
 
 static int cmd_sort(int argc, char **argv)
@@ -573,7 +591,7 @@ static int cmd_sort(int argc, char **argv)
 		char nm[64]; snprintf(nm, sizeof(nm), "/ssg_sort_%d_%04zu.run", (int)getpid(), runs.size());
 		run_t R; R.path = tmpdir + nm;
 		R.fd = open(R.path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644); if (R.fd < 0) die("sort: cannot write " + R.path);
-		write_sorted(S, perm, h, R.fd, 1, pool, 0, &at, &R.seg);
+		write_sorted(S, perm, h, R.fd, 1, pool, 0, &at, &R.seg, 0, &R.useg);
 		runs.push_back(R); spills.push_back(R.path); S.clear();
 	};
 	if (fused) {
@@ -612,7 +630,7 @@ static int cmd_sort(int argc, char **argv)
 		bi.raw.assign((const uint8_t*)first, (const uint8_t*)first + n_first);
 		if (!hdr_read(bi, h)) die("sort: not a BAM file");
 		change_so(h.text, "coordinate");
-		const size_t CH = (size_t)64 << 20;
+		const size_t CH = (size_t)std::min<uint64_t>((uint64_t)64 << 20, std::max<uint64_t>(budget / 4, 65536));   /* the budget is checked once per chunk */
 		fu_buf_t cur; size_t cap = CH, len = 0;
 		if (!cur.heap(CH)) die("sort: out of memory");
 		auto flush = [&]() { if (!len) return; if (!S.add_chunk(std::move(cur), len)) die("sort: malformed BAM record"); cap = CH; len = 0; if (!cur.heap(CH)) die("sort: out of memory"); if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill(); };
@@ -644,7 +662,9 @@ static int cmd_sort(int argc, char **argv)
 	else {
 		if (!S.key.empty()) spill();
 		const double t_m = wall();
-		merge_runs(runs, range_lo.size(), h, ofd, level, pool);
+		const std::string bai = outp + ".bai";
+		merge_runs(runs, range_lo.size(), h, ofd, level, pool, budget, getenv("SSG_SORT_NO_BAI") ? 0 : bai.c_str());
+		bai_note = !getenv("SSG_SORT_NO_BAI");
 		if (dbg()) fprintf(stderr, "[sambamba] sort: input %.2f s (from start), %zu sorted runs merged in %zu ranges of the genome by %d threads: %.2f s\n", t_in - t_start, runs.size(), range_lo.size(), pool, wall() - t_m);
 		for (run_t &R : runs) { close(R.fd); unlink(R.path.c_str()); }
 	}

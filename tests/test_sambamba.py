@@ -69,9 +69,10 @@ def _check(sambamba, tmp_path, monkeypatch):
     assert _view(d + "/mine_s.bam") == _view(d + "/ref_s.bam")
     # ... also through the spill-and-merge path and from a pipe
     monkeypatch.setenv("SSG_SORT_CHUNK_BYTES", "200000")
+    monkeypatch.setenv("SSG_SORT_RANGES", "23")              # the merge goes over the genome in several stretches (a third of the budget each)
     with open(d + "/mine_u.bam", "rb") as fi:
         subprocess.run(sambamba + ["sort", "-t", "2", "-m", "1G", "--tmpdir=" + d + "/tmp2", "-o", d + "/mine_s2.bam", "/dev/stdin"], stdin=fi, check=True)
-    monkeypatch.delenv("SSG_SORT_CHUNK_BYTES")
+    monkeypatch.delenv("SSG_SORT_CHUNK_BYTES"); monkeypatch.delenv("SSG_SORT_RANGES")
     assert _view(d + "/mine_s2.bam") == _view(d + "/ref_s.bam")
     assert os.listdir(d + "/tmp2") == []
     # the sort left the index of its output and a note next to it: `index` recognises the pair as current (and drops the note); the index
@@ -82,7 +83,14 @@ def _check(sambamba, tmp_path, monkeypatch):
     assert not os.path.exists(d + "/mine_s.bam.bai.ssg") and open(d + "/mine_s.bam.bai", "rb").read() == by_sort
     subprocess.run(sambamba + ["index", d + "/mine_s.bam"], check=True)                      # no note any more: computed from the file
     assert open(d + "/mine_s.bam.bai", "rb").read() == by_sort
-    assert os.path.exists(d + "/mine_s2.bam.bai.ssg") is False                                # spill-and-merge output: no index from the sort
+    # the spill-and-merge path writes its index too (stretch by stretch, behind the merge's writer): what samtools computes from that file
+    assert os.path.exists(d + "/mine_s2.bam.bai") and os.path.exists(d + "/mine_s2.bam.bai.ssg")
+    os.rename(d + "/mine_s2.bam.bai", d + "/mine2.bai")
+    subprocess.run([SAMTOOLS, "index", d + "/mine_s2.bam"], check=True)
+    assert _parse_bai(d + "/mine2.bai") == _parse_bai(d + "/mine_s2.bam.bai")
+    subprocess.run(sambamba + ["index", d + "/mine_s2.bam"], check=True)                     # note is stale now (the .bai was rewritten): computed from the file
+    assert open(d + "/mine_s2.bam.bai", "rb").read() == open(d + "/mine2.bai", "rb").read()
+    assert _view(d + "/mine_s2.bam", "20_slice:150000-151000") == _view(d + "/mine_s.bam", "20_slice:150000-151000")
     os.rename(d + "/mine_s.bam.bai", d + "/mine.bai")
     subprocess.run([SAMTOOLS, "index", d + "/mine_s.bam"], check=True)
     assert _parse_bai(d + "/mine.bai") == _parse_bai(d + "/mine_s.bam.bai")
