@@ -390,10 +390,10 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	}
 	if (closes) io_write_all(fd, BGZF_EOF, 28);
 	const double tw2 = wall();
-	if (dbg()) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index %.2f s, %d workers started in %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
+	if (dbg() && !seg) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index %.2f s, %d workers started in %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
 	                   "per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn0 - tw1, n_workers, tw_spawn - tw_spawn0, t_wr_wait, t_wr_io,
 	                   us_gather / 1e6 / std::max(1, n_workers + n_prod), us_deflate / 1e6 / std::max(1, n_workers + n_prod), us_window / 1e6 / std::max(1, n_workers + n_prod));
-	if (dbg() && use_dev) fprintf(stderr, "[sambamba] sort: write: blocks deflated on the device (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_prod);
+	if (dbg() && use_dev && !seg) fprintf(stderr, "[sambamba] sort: write: blocks deflated on the device (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_prod);
 	if (seg) seg->coff = coff;
 	if (!bai_path) return;
 	blk_coff[nb] = coff;
@@ -402,7 +402,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	if (seg) seg->idx_ok = idx_ok;
 	if (!idx_ok || !closes) return;
 	(seg ? *seg->idx : idx_own).save(bai_path);
-	if (dbg()) fprintf(stderr, "[sambamba] sort: write: index finished %.2f s after the last block (its thread waited %.2f s for block offsets)\n", wall() - tw2, t_idx_wait);
+	if (dbg() && !seg) fprintf(stderr, "[sambamba] sort: write: index finished %.2f s after the last block (its thread waited %.2f s for block offsets)\n", wall() - tw2, t_idx_wait);
 }
 
 struct merge_src_t {   /* one coordinate-sorted BAM being merged */
