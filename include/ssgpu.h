@@ -126,11 +126,16 @@ int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_rea
 typedef struct ssg_pe_result ssg_pe_result_t;
 int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
                           const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out);
+/* Single-end reads (upstream mem_process_seqs without MEM_F_PE, bwamem.c: worker1 = mem_align1_core, worker2 = mem_mark_primary_se with
+ * id = n_processed + i, then mem_reg2sam without a mate): n_reads reads, id0 = upstream's n_processed at the first of them.  The result
+ * is read through the same accessors (req_off has n_reads + 1 entries, there is no insert-size model) and printed by ssg_sam_format_se. */
+int ssg_mem_process_reads(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off, int64_t id0, ssg_pe_result_t **out);
 void ssg_pe_result_free(ssg_pe_result_t *r);
 /* optional warm-up: page-locks the host blocks the records of `n_calls` concurrent ssg_mem_process_pairs results of about `n_pairs`
  * pairs will land in (the first calls make them otherwise, ~0.2 s each); bin/bwa runs it next to the index load */
 int ssg_pe_reserve(int n_pairs, int n_calls);
 int64_t ssg_pe_n_req(const ssg_pe_result_t *r);
+int ssg_pe_is_se(const ssg_pe_result_t *r);                         /* 1: made by ssg_mem_process_reads */
 const int64_t *ssg_pe_req_off(const ssg_pe_result_t *r);          /* 2*n_pairs+1 offsets into req/alns */
 const ssg_alnreq_t *ssg_pe_req(const ssg_pe_result_t *r);     /* kind 0 = SAM record, 1 = XA entry (owner = region) */
 const ssg_aln_t *ssg_pe_alns(const ssg_pe_result_t *r);
@@ -143,6 +148,9 @@ const uint64_t *ssg_pe_stats(const ssg_pe_result_t *r);           /* [0] seeds [
 int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
                    const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
                    const char *rg_id, char **sam, int64_t *sam_off);
+int ssg_sam_format_se(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_reads,
+                      const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                      const char *rg_id, char **sam, int64_t *sam_off);   /* single-end results: sam_off[n_reads + 1] */
 /* the same for a selection of the batch's pairs: sel[0..n_sel) are pair indices, sam_off[2*n_sel+1] */
 int ssg_sam_format_sel(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, const int32_t *sel, int n_sel,
                        const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,

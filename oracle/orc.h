@@ -137,6 +137,7 @@ uint32_t *orc_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, 
 /* process one upstream "batch" (mem_process_seqs): n reads (n even, interleaved pairs); fills s[i].sam */
 void orc_mem_process_pairs(const orc_opt_t *opt, const orc_idx_t *idx, int64_t n_processed, int n, orc_read_t *s,
                            const orc_pestat_t *pes0, const char *rg_id, orc_pestat_t pes_out[4], int n_threads);
+void orc_mem_process_reads(const orc_opt_t *opt, const orc_idx_t *idx, int64_t n_processed, int n, orc_read_t *s, const char *rg_id, int n_threads);
 /* upstream bwa_print_sam_hdr: @SQ lines + optional @RG + @PG */
 char *orc_sam_header(const orc_idx_t *idx, const char *rg_line, const char *pg_cl);
 

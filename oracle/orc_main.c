@@ -217,7 +217,8 @@ static int main_mem(int argc, char **argv)
 	f1.fp = gzopen(argv[ai+1], "r");
 	if (!f1.fp) { fprintf(stderr, "[orc_bwa] fail to open %s\n", argv[ai+1]); return 1; }
 	if (argc - ai >= 3) { f2.fp = gzopen(argv[ai+2], "r"); if (!f2.fp) { fprintf(stderr, "[orc_bwa] fail to open %s\n", argv[ai+2]); return 1; } }
-	if (!interleaved && !f2.fp) { fprintf(stderr, "[orc_bwa] single-end input is outside the oracle's scope (speedseq align is paired-end)\n"); return 1; }
+	if (interleaved && f2.fp) { fprintf(stderr, "[W::main_mem] when '-p' is in use, the second query file is ignored.\n"); gzclose(f2.fp); f2.fp = 0; }
+	const int se = !interleaved && !f2.fp;   /* upstream main_mem: MEM_F_PE is set by -p or by a second file */
 	{
 		char cl[4096]; size_t l = 0; cl[0] = 0;
 		for (i = 0; i < argc && l < sizeof(cl) - 1; ++i) l += snprintf(cl + l, sizeof(cl) - l, "%s%s", i ? " " : "bwa ", argv[i]);
@@ -243,6 +244,18 @@ static int main_mem(int argc, char **argv)
 			if (size >= chunk && (n & 1) == 0) break;
 		}
 		if (rc == -2) { fprintf(stderr, "[orc_bwa] truncated / malformed FASTQ\n"); return 1; }
+		if (se) { /* upstream mem_process_seqs without MEM_F_PE */
+			if (n == 0) { free(s); break; }
+			orc_mem_process_reads(&opt, idx, n_processed, n, s, rg_id, opt.n_threads);
+			for (i = 0; i < n; ++i) {
+				fputs(s[i].sam, stdout);
+				free(s[i].sam); free(s[i].name); free(s[i].comment); free(s[i].seq); free(s[i].qual);
+			}
+			n_processed += n;
+			free(s);
+			if (rc < 0) break;
+			continue;
+		}
 		if (n & 1) { /* upstream main_mem, PE mode: the odd read at the end of the input is dropped */
 			fprintf(stderr, "[W::main_mem] odd number of reads in the PE mode; last read dropped\n");
 			--n; free(s[n].name); free(s[n].comment); free(s[n].seq); free(s[n].qual);

@@ -741,6 +741,12 @@ static void *worker(void *d)
 	if (w->stage == 1) {
 		for (int i = w->tid; i < w->n; i += w->nt)
 			w->regs[i] = orc_mem_align1_core(w->opt, w->idx, w->s[i].l_seq, w->s[i].seq);
+	} else if (w->stage == 3) {   /* upstream worker2 without MEM_F_PE */
+		for (int i = w->tid; i < w->n; i += w->nt) {
+			orc_mem_mark_primary_se(w->opt, (int)w->regs[i].n, w->regs[i].a, w->n_processed + i);
+			reg2sam(w->opt, w->idx, &w->s[i], &w->regs[i], 0, 0, w->rg_id);
+			free(w->regs[i].a);
+		}
 	} else {
 		for (int i = w->tid; i < w->n >> 1; i += w->nt) {
 			orc_mem_sam_pe(w->opt, w->idx, w->pes, (w->n_processed >> 1) + i, &w->s[i<<1], &w->regs[i<<1], w->rg_id);
@@ -779,6 +785,15 @@ void orc_mem_process_pairs(const orc_opt_t *opt, const orc_idx_t *idx, int64_t n
 	run_stage(&w, 2, n_threads);
 	clock_gettime(CLOCK_MONOTONIC, &t2_);
 	if (getenv("ORC_TIMING")) fprintf(stderr, "[orc] stage 1 %.3f s, stage 2 %.3f s (%d threads)\n", (t1_.tv_sec - t0_.tv_sec) + 1e-9 * (t1_.tv_nsec - t0_.tv_nsec), (t2_.tv_sec - t1_.tv_sec) + 1e-9 * (t2_.tv_nsec - t1_.tv_nsec), n_threads);
+	free(w.regs);
+}
+
+void orc_mem_process_reads(const orc_opt_t *opt, const orc_idx_t *idx, int64_t n_processed, int n, orc_read_t *s, const char *rg_id, int n_threads)
+{	/* upstream mem_process_seqs without MEM_F_PE: every read on its own (single-end input, and the unpaired reads of a `-p` stream) */
+	wk_t w = { opt, idx, n_processed, n, s, calloc(n, sizeof(orc_alnreg_v)), 0, rg_id, 0, 1, 0 };
+	if (n_threads < 1) n_threads = 1;
+	run_stage(&w, 1, n_threads);
+	run_stage(&w, 3, n_threads);
 	free(w.regs);
 }
 

@@ -547,6 +547,68 @@ SSG_DEVFN void ssg_pair_decide(const ssg_index_view_t &ix, const ssg_mem_opt_t &
 	}
 }
 
+/* Single-end reads (upstream mem_process_seqs without MEM_F_PE: worker2 = mem_mark_primary_se(id = n_processed + i) + mem_reg2sam with no
+ * mate).  One lane per read; the regions stay where stage 1 left them (reg_off = the read's seed offsets).  Requests as mem_reg2sam lists
+ * the records: every primary-chain hit with score >= T, the first as the main line, the others supplementary (0x800, or 0x10000 with -M);
+ * the XA candidates of the lines that will be printed. */
+__global__ void __launch_bounds__(64) ssg_k_se_final(ssg_mem_opt_t opt, int n_reads, int64_t id0, const int64_t *reg_off, ssg_alnreg_t *regs, const int32_t *n_reg,
+                               int32_t *zbuf, int32_t *ibuf, const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	ssg_alnreg_t *a = regs + reg_off[r]; const int an = n_reg[r];
+	int32_t *z0 = zbuf + reg_off[r];
+	ssg_alnreq_t *rq = req + req_off[r];
+	(void)ssg_mark_primary_se(opt, an, a, id0 + r, z0, ibuf + reg_off[r]);
+	int nrq = 0, l = 0, k, j, mapq0 = 0;
+	for (k = 0; k < an; ++k) {
+		const ssg_alnreg_t &pr = a[k];
+		if (pr.score < opt.T) continue;
+		if (pr.secondary >= 0) continue;
+		ssg_alnreq_t q; q.read = (int32_t)r; q.reg = (int32_t)(reg_off[r] + k); q.kind = SSG_REQ_MAIN; q.owner = k;
+		q.flag = 0; q._pad0 = q._pad1 = 0;
+		q.mapq = ssg_approx_mapq_se(opt, pr);
+		if (l) q.flag |= (opt.flag & SSG_F_NO_MULTI) ? 0x10000 : 0x800;
+		if (l && q.mapq > mapq0) q.mapq = mapq0;
+		if (!l) mapq0 = q.mapq;
+		rq[nrq++] = q;
+		++l;
+	}
+	if (l == 0) {
+		ssg_alnreq_t q; q.read = (int32_t)r; q.reg = -1; q.kind = SSG_REQ_MAIN; q.owner = -1;
+		q.flag = 0x4; q.mapq = 0; q._pad0 = q._pad1 = 0;
+		rq[nrq++] = q;
+	}
+	{	/* XA entries (upstream mem_gen_alt): count per primary, then emit for the main records */
+		int32_t *cnt = z0;
+		const int nmain = nrq; int tot = 0;
+		for (j = 0; j < an; ++j) cnt[j] = 0;
+		for (j = 0; j < an; ++j) {
+			const int kk = a[j].secondary_all;
+			if (kk >= 0 && a[j].score >= a[kk].score * (double)opt.XA_drop_ratio) { ++cnt[kk]; ++tot; }
+		}
+		if (tot) {
+			for (j = 0; j < an; ++j) {
+				const int kk = a[j].secondary_all;
+				if (!(kk >= 0 && a[j].score >= a[kk].score * (double)opt.XA_drop_ratio)) continue;
+				if (cnt[kk] > opt.max_XA_hits_alt || cnt[kk] > opt.max_XA_hits) continue;
+				bool wanted = false;
+				for (int m2 = 0; m2 < nmain; ++m2) if (rq[m2].owner == kk && rq[m2].reg >= 0) wanted = true;
+				if (!wanted) continue;
+				ssg_alnreq_t q; q.read = (int32_t)r; q.reg = (int32_t)(reg_off[r] + j); q.kind = SSG_REQ_XA; q.owner = kk; q.flag = 0; q.mapq = 0; q._pad0 = q._pad1 = 0;
+				rq[nrq++] = q;
+			}
+		}
+	}
+	n_req[r] = nrq;
+}
+
+__global__ void ssg_k_se_caps(int n_reads, const int32_t *n_reg, int32_t *capq)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < n_reads) capq[r] = 2 * n_reg[r] + 2;
+}
+
 __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, int64_t id0,
                                  const int64_t *reg_off, ssg_alnreg_t *regs, const int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                                  int32_t *zbuf, ssg_pair64_t *vbuf, ssg_pair64_t *ubuf, int ucap,

@@ -253,7 +253,7 @@ void aln2bam(const ssg_index_t *idx, bbuf &out, const char *name, int l_seq, con
 
 /* pairs sel[p0..p1) (or p0..p1 themselves when sel == NULL) into `out` (text) or `bout` (BAM records); offs entries relative to the buffer's start */
 static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, const int32_t *sel, int p0, int p1, const char *const *names, const uint8_t *seq, const int64_t *off,
-                        const char *const *quals, const char *const *comments, const char *rg_id, bool softclip, sbuf *out, bbuf *bout, int64_t *offs)
+                        const char *const *quals, const char *const *comments, const char *rg_id, bool softclip, bool se, sbuf *out, bbuf *bout, int64_t *offs)
 {
 	const int64_t *req_off = ssg_pe_req_off(res);
 	const ssg_alnreq_t *req = ssg_pe_req(res);
@@ -261,6 +261,34 @@ static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, cons
 	std::vector<const ssg_aln_t*> mains[2];
 	std::vector<std::string> xa[2];
 	std::vector<int> owner;
+	if (se) {   /* single-end reads (ssg_mem_process_reads): the units are reads; upstream mem_reg2sam with no mate */
+		for (int q = p0; q < p1; ++q) {
+			const int r = sel ? sel[q] : q;
+			mains[0].clear(); xa[0].clear(); owner.clear();
+			for (int64_t g = req_off[r]; g < req_off[r+1]; ++g)
+				if (req[g].kind == SSG_REQ_MAIN) { mains[0].push_back(&alns[g]); owner.push_back(req[g].owner); xa[0].emplace_back(); }
+			for (int64_t g = req_off[r]; g < req_off[r+1]; ++g) {
+				if (req[g].kind != SSG_REQ_XA) continue;
+				const ssg_aln_t &t = alns[g];
+				for (size_t k = 0; k < owner.size(); ++k) {
+					if (owner[k] != req[g].owner || mains[0][k]->rid < 0) continue;
+					sbuf x;
+					x.puts(ssg_index_name(idx, t.rid)); x.putc(','); x.putc("+-"[t.is_rev]); x.putl(t.pos + 1); x.putc(',');
+					for (int c = 0; c < t.n_cigar; ++c) { x.putl(t.cigar[c] >> 4); x.putc("MIDSHN"[t.cigar[c] & 0xf]); }
+					x.putc(','); x.putl(t.NM); x.putc(';');
+					xa[0][k] += x.s;
+				}
+			}
+			if (mains[0].empty()) return SSG_EINVAL;
+			offs[q] = (int64_t)(out ? out->s.size() : bout->b.size());
+			const int l_seq = (int)(off[r+1] - off[r]);
+			for (size_t k = 0; k < mains[0].size(); ++k) {
+				if (out) aln2sam(idx, *out, names[r], l_seq, seq + off[r], quals ? quals[r] : 0, comments ? comments[r] : 0, (int)mains[0].size(), mains[0].data(), (int)k, 0, &xa[0][k], rg_id, softclip);
+				else aln2bam(idx, *bout, names[r], l_seq, seq + off[r], quals ? quals[r] : 0, (int)mains[0].size(), mains[0].data(), (int)k, 0, &xa[0][k], rg_id, softclip);
+			}
+		}
+		return 0;
+	}
 	for (int q = p0; q < p1; ++q) {
 		const int p = sel ? sel[q] : q;
 		mate_t mate[2];
@@ -305,8 +333,10 @@ static int format_range(const ssg_index_t *idx, const ssg_pe_result_t *res, cons
 template <class BUF, class GET>
 static int format_all(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, const int32_t *sel, int n_pairs,
                       const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
-                      const char *rg_id, std::vector<BUF> &outs, GET bytes_of, bool text, char **outp, int64_t *offs)
+                      const char *rg_id, std::vector<BUF> &outs, GET bytes_of, bool text, char **outp, int64_t *offs, bool se = false)
 {
+	const int per = se ? 1 : 2;   /* reads per unit: n_pairs counts reads when the result is single-end */
+	if ((ssg_pe_is_se(res) != 0) != se) return SSG_EINVAL;   /* a single-end result is printed by ssg_sam_format_se, a paired one by the others */
 	int T = opt && opt->n_threads > 1 ? opt->n_threads : 1;
 	{ const int spare = (int)std::min(48u, std::thread::hardware_concurrency() / 4); if (T > 1 && spare > T) T = spare; }   /* -t sizes upstream's batches; printing has to keep up with an MI355X, not with -t CPU aligners */
 	{ const char *e = getenv("SSG_FMT_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
@@ -321,7 +351,7 @@ static int format_all(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ss
 			auto &B = bytes_of(outs[t]); B.clear(); B.reserve((size_t)(lo(t + 1) - lo(t)) * (text ? 1000 : 800));
 			sbuf *so = 0; bbuf *bo = 0;
 			if constexpr (std::is_same<BUF, sbuf>::value) so = &outs[t]; else bo = &outs[t];
-			rcs[t] = format_range(idx, res, sel, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, opt && (opt->flag & SSG_F_SOFTCLIP), so, bo, offs); };   /* -Y: upstream MEM_F_SOFTCLIP */
+			rcs[t] = format_range(idx, res, sel, lo(t), lo(t + 1), names, seq, off, quals, comments, rg_id, opt && (opt->flag & SSG_F_SOFTCLIP), se, so, bo, offs); };   /* -Y: upstream MEM_F_SOFTCLIP */
 		if (T == 1) work(); else th.emplace_back(work);
 	}
 	for (auto &x : th) x.join();
@@ -331,11 +361,11 @@ static int format_all(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ss
 	char *buf = (char*)malloc(tot + 1);
 	if (!buf) return SSG_ENOMEM;
 	for (int t = 0; t < T; ++t) {   /* joined in input order, each part copied by its own thread */
-		auto work = [&, t]() { memcpy(buf + base[t], bytes_of(outs[t]).data(), bytes_of(outs[t]).size()); for (int r = 2 * lo(t); r < 2 * lo(t + 1); ++r) offs[r] += (int64_t)base[t]; };
+		auto work = [&, t]() { memcpy(buf + base[t], bytes_of(outs[t]).data(), bytes_of(outs[t]).size()); for (int r = per * lo(t); r < per * lo(t + 1); ++r) offs[r] += (int64_t)base[t]; };
 		if (T == 1) work(); else th.emplace_back(work);
 	}
 	for (auto &x : th) x.join();
-	buf[tot] = 0; offs[2 * n_pairs] = (int64_t)tot;
+	buf[tot] = 0; offs[per * n_pairs] = (int64_t)tot;
 	*outp = buf;
 	return 0;
 }
@@ -354,6 +384,14 @@ extern "C" int ssg_sam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, 
                               const char *rg_id, char **sam, int64_t *sam_off)
 {
 	return ssg_sam_format_sel(idx, opt, res, 0, n_pairs, names, seq, off, quals, comments, rg_id, sam, sam_off);
+}
+/* single-end results (ssg_mem_process_reads): the lines of n_reads reads, sam_off[n_reads + 1] */
+extern "C" int ssg_sam_format_se(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_reads,
+                                 const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals, const char *const *comments,
+                                 const char *rg_id, char **sam, int64_t *sam_off)
+{
+	static thread_local std::vector<sbuf> keep;
+	return format_all(idx, opt, res, 0, n_reads, names, seq, off, quals, comments, rg_id, keep, [](sbuf &b) -> std::string& { return b.s; }, true, sam, sam_off, true);
 }
 extern "C" int ssg_bam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_pe_result_t *res, int n_pairs,
                               const char *const *names, const uint8_t *seq, const int64_t *off, const char *const *quals,

@@ -870,7 +870,7 @@ static void host_pestat(const ssg_mem_opt_t *opt, const uint32_t *hist /* [4][SS
 }
 
 struct ssg_pe_result {
-	int n_reads, n_batches;
+	int n_reads, n_batches, se = 0;      /* se: the reads are single-end (ssg_mem_process_reads): n_reads units, no pairs */
 	std::vector<int64_t> req_off;        /* n_reads + 1 */
 	hbuf<ssg_alnreq_t> req;              /* page-locked, recycled across calls */
 	hbuf<ssg_aln_t> alns;
@@ -1007,6 +1007,51 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	return 0;
 }
 
+/* single-end reads (upstream mem_process_seqs without MEM_F_PE): stage 1 as for pairs, then every read on its own -- primary marking with
+ * id = id0 + r (upstream's n_processed + i), the list of records (ssg_k_se_final), CIGAR / NM / MD.  No insert-size model, no mate rescue, no pairing. */
+static int se_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off, int max_len, int64_t id0, ssg_pe_result *res)
+{
+	res->n_reads = n_reads; res->n_batches = 0; res->se = 1; memset(res->stats, 0, sizeof(res->stats));
+	align1_dev_t a1;
+	CHK(run_align1(idx, opt, n_reads, d_seq, d_off, max_len, a1, res->stats));
+	const int block = 256, wpb = SSG_WAVES_PER_WG;
+	dbuf<int32_t> d_capq(n_reads), d_nreq(n_reads), d_zbuf((size_t)a1.tot_seeds + 1), d_ibuf((size_t)a1.tot_seeds + 1), d_gerr(1);
+	dbuf<int64_t> d_reqoff(n_reads + 1), d_coff(n_reads + 1); dbuf<unsigned long long> d_cnt(2);
+	CHKA(d_capq); CHKA(d_nreq); CHKA(d_zbuf); CHKA(d_ibuf); CHKA(d_gerr); CHKA(d_reqoff); CHKA(d_coff); CHKA(d_cnt);
+	CHK(d_gerr.zero()); CHK(d_cnt.zero());
+	SSG_LAUNCH(ssg_k_se_caps, (n_reads + block - 1) / block, block, 0, n_reads, a1.n_reg.p, d_capq.p);
+	int64_t tq = 0;
+	CHK(dev_exclusive_scan(d_capq.p, d_reqoff.p, n_reads, &tq));
+	dbuf<ssg_alnreq_t> d_req((size_t)tq + 1);
+	CHKA(d_req);
+	SSG_LAUNCH(ssg_k_se_final, (n_reads + 63) / 64, 64, 0, *opt, n_reads, id0, a1.seed_off.p, a1.regs.p, a1.n_reg.p, d_zbuf.p, d_ibuf.p, d_reqoff.p, d_req.p, d_nreq.p);
+	STAGE("se_final");
+	int64_t nreq = 0;
+	CHK(dev_exclusive_scan(d_nreq.p, d_coff.p, n_reads, &nreq));
+	res->req_off.resize((size_t)n_reads + 1); CHK(d_coff.down(res->req_off.data(), (size_t)n_reads + 1));
+	dbuf<ssg_alnreq_t> d_creq((size_t)nreq + 1); dbuf<ssg_aln_t> d_alns((size_t)nreq + 1);
+	CHKA(d_creq); CHKA(d_alns);
+	SSG_LAUNCH(ssg_k_compact_req, (n_reads + block - 1) / block, block, 0, n_reads, d_reqoff.p, d_req.p, d_nreq.p, d_coff.p, d_creq.p);
+	{
+		long nwg = std::min<long>(((long)nreq + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
+		long nw = nwg * wpb;
+		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB), d_z((size_t)nw * SSG_Z_CAP);
+		CHKA(d_tglb); CHKA(d_z);
+		dbuf<int32_t> d_rtodo((size_t)nreq + 1); dbuf<unsigned int> d_nrtodo(1);
+		CHKA(d_rtodo); CHKA(d_nrtodo); CHK(d_nrtodo.zero());
+		SSG_LAUNCH(ssg_k_reg2aln_lane, (nreq + 63) / 64, 64, 0, idx->v, *opt, (long)nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_gerr.p, d_rtodo.p, d_nrtodo.p);
+		SSG_LAUNCH(ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
+		CHK(rt_sync());
+	}
+	STAGE("reg2aln");
+	{ int32_t ge; CHK(d_gerr.down(&ge, 1)); if (ge) { char b[96]; snprintf(b, sizeof(b), "CIGAR generation exceeded an on-device capacity (code %d)", ge); ssg_err_msg = b; return SSG_EOVERFLOW; } }
+	{ unsigned long long c[2]; CHK(d_cnt.down(c, 2)); res->stats[2] = c[0]; res->stats[3] = c[1]; res->stats[4] = (uint64_t)nreq; }
+	if (!res->req.resize((size_t)nreq) || !res->alns.resize((size_t)nreq)) { ssg_err_msg = "host allocation failed: result records"; return SSG_ENOMEM; }
+	CHK(d_creq.down(res->req.data(), (size_t)nreq)); CHK(d_alns.down(res->alns.data(), (size_t)nreq));
+	STAGE("download");
+	return 0;
+}
+
 /* stable sort of (hash, ordinal) by hash: hipCUB radix sort on the GPU */
 static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, long n)
 {
@@ -1121,6 +1166,24 @@ int ssg_mem_process_pairs(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
                           const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result_t **out)
 {
 	return process_pairs_host(idx, opt, n_pairs, seq, off, pair_batch, n_batches, id0, pes0, out);
+}
+int ssg_mem_process_reads(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *seq, const int64_t *off, int64_t id0, ssg_pe_result_t **out)
+{
+	CHK(need_device());
+	*out = 0;
+	if (n_reads <= 0) { ssg_err_msg = "ssg_mem_process_reads: empty input"; return SSG_EINVAL; }
+	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
+	if (max_len > SSG_MAX_READ_LEN) { ssg_err_msg = "reads longer than " SSG_STR(SSG_MAX_READ_LEN) " bases are outside this build's scope"; return SSG_EINVAL; }
+	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1);
+	CHKA(d_seq); CHKA(d_off);
+	if (ssg_debug()) (void)ssg_stage_ms();
+	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1));
+	STAGE("upload");
+	std::unique_ptr<ssg_pe_result> res(new ssg_pe_result());
+	CHK(se_core(idx, opt, n_reads, d_seq.p, d_off.p, max_len, id0, res.get()));
+	ssg_prof_flush();
+	*out = res.release();
+	return 0;
 }
 /* upstream samblaster duplicate marking (row a14) on per-end records supplied by the caller
  * (2*n_pairs entries: read1, read2 primaries); dup[p] = 1 when an earlier pair has the same signature */
@@ -1370,6 +1433,7 @@ int ssg_pe_reserve(int n_pairs, int n_calls)
 }
 int64_t ssg_pe_n_req(const ssg_pe_result_t *r) { return (int64_t)r->req.size(); }
 const int64_t *ssg_pe_req_off(const ssg_pe_result_t *r) { return r->req_off.data(); }
+int ssg_pe_is_se(const ssg_pe_result_t *r) { return r->se; }
 const ssg_alnreq_t *ssg_pe_req(const ssg_pe_result_t *r) { return r->req.data(); }
 const ssg_aln_t *ssg_pe_alns(const ssg_pe_result_t *r) { return r->alns.data(); }
 const ssg_pestat_t *ssg_pe_pes(const ssg_pe_result_t *r) { return r->pes.data(); }

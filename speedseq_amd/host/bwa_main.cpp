@@ -149,11 +149,13 @@ static int main_mem(int argc, char **argv)
 	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
 	if (getenv("SSG_BWA_PROF")) { ssg_prof_reset(); ssg_prof_enable(1); }
 	/* fused mode (fused.h): BAM records in frames instead of SAM text when speedseq.config exported SSG_FUSED=1; never with -C */
-	const bool fused = fu_enabled() && !keep_comment;
+	bool fused = fu_enabled() && !keep_comment;
 	gzFile fp1 = gzopen(argv[ai + 1], "r"), fp2 = 0;
 	if (!fp1) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 1]); return 1; }
 	if (argc - ai >= 3) { fp2 = gzopen(argv[ai + 2], "r"); if (!fp2) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 2]); return 1; } }
-	if (!interleaved && !fp2) { fprintf(stderr, "[bwa] single-end input is not supported: speedseq align is paired-end\n"); return 1; }
+	if (interleaved && fp2) { fprintf(stderr, "[W::main_mem] when '-p' is in use, the second query file is ignored.\n"); gzclose(fp2); fp2 = 0; }
+	const bool se = !interleaved && !fp2;   /* upstream main_mem: MEM_F_PE is set by -p or by a second file; without it every read is aligned on its own */
+	if (se) fused = false;                  /* samblaster has nothing to do with unpaired reads: SAM text */
 	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
 	const int64_t chunk = fixed_chunk > 0 ? fixed_chunk : (int64_t)opt.chunk_size * opt.n_threads;   /* -K: batches that do not depend on -t */
 
@@ -275,7 +277,15 @@ static int main_mem(int argc, char **argv)
 		while (!eof && !fail) {
 			const double t0 = wall();
 			std::unique_ptr<batch_t> B(new batch_t()); B->id0 = id0; B->seqno = seqno;
-			while (!eof && (size_t)B->n() / 2 < max_pairs_per_call) {   /* upstream bseq_read: one batch */
+			while (se && !eof && (size_t)B->n() < 2 * max_pairs_per_call) {   /* single-end: a read's result depends on its ordinal only, batches need not be kept apart */
+				const fq_block_t *ba; int ia = 0;
+				(void)ba;
+				const int rc = c1.next(&ba, &ia);
+				if (rc == -1) { eof = true; break; }
+				if (rc < 0) { fprintf(stderr, "[bwa] truncated or malformed FASTQ\n"); fail = 1; eof = true; break; }
+				B->add(c1.cur, ia);
+			}
+			while (!se && !eof && (size_t)B->n() / 2 < max_pairs_per_call) {   /* upstream bseq_read: one batch */
 				int64_t size = 0; const int n0 = B->n();
 				for (;;) {
 					const fq_block_t *ba, *bb; int ia = 0, ib = 0;
@@ -302,7 +312,7 @@ static int main_mem(int argc, char **argv)
 			}
 			if (fail || B->n() == 0) break;
 			B->gather(std::min(8, std::max(1, opt.n_threads)));
-			id0 += B->n() / 2; ++seqno;
+			id0 += se ? B->n() : B->n() / 2; ++seqno;   /* pairs: the pair ordinal; single-end: upstream's n_processed */
 			tm_asm += wall() - t0;
 			to_gpu.push(std::move(B));
 		}
@@ -330,7 +340,8 @@ static int main_mem(int argc, char **argv)
 			}
 			D.pairs += B->n() / 2;
 			{	std::shared_lock<std::shared_mutex> l(D.mu);
-				if (!fail && ssg_mem_process_pairs(idxs[(size_t)g], &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res)) {
+				if (!fail && (se ? ssg_mem_process_reads(idxs[(size_t)g], &opt, B->n(), B->seq.get(), B->off.data(), B->id0, &B->res)
+				                 : ssg_mem_process_pairs(idxs[(size_t)g], &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res))) {
 					fprintf(stderr, "[bwa] alignment failed on device %d: %s\n", g, ssg_last_error()); fail = 1; }
 			}
 			{ std::lock_guard<std::mutex> l(D.tm); tm_gpu[(size_t)g] += wall() - t0; ++calls[(size_t)g]; }
@@ -374,7 +385,8 @@ static int main_mem(int argc, char **argv)
 			sam_off.resize((size_t)n + 1);
 			if (!fused) {
 				char *sam;
-				if (ssg_sam_format(idx, &opt, B->res, n / 2, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), B->comments.data(), rg_id, &sam, sam_off.data())) {
+				if (se ? ssg_sam_format_se(idx, &opt, B->res, n, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), B->comments.data(), rg_id, &sam, sam_off.data())
+				       : ssg_sam_format(idx, &opt, B->res, n / 2, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), B->comments.data(), rg_id, &sam, sam_off.data())) {
 					fprintf(stderr, "[bwa] SAM formatting failed: %s\n", ssg_last_error()); fail = 1; ssg_pe_result_free(B->res); continue; }
 				t.p = sam; t.len = (size_t)sam_off[(size_t)n];
 			} else {
@@ -413,7 +425,8 @@ static int main_mem(int argc, char **argv)
 			}
 			busy += wall() - t0;
 			const ssg_pestat_t *pp = ssg_pe_pes(B->res);
-			fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s device %d; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
+			if (se) fprintf(stderr, "[bwa] processed %d single-end reads on %s device %d\n", n, ssg_backend(), B->dev);
+			else fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s device %d; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
 			        n, B->n_batches, ssg_backend(), B->dev, pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
 			ssg_pe_result_free(B->res);
 			emit(B->seqno, t);

@@ -267,3 +267,33 @@ def _bwa_options(tmp_path, bwa, opts, n_pairs):
 @pytest.mark.parametrize("opts", [("-M", "-Y"), ("-S", "-P"), ("-A", "2", "-B", "5", "-O", "7,9", "-E", "2,1"), ("-k", "25", "-c", "50", "-D", "0.3", "-r", "1.0")], ids=lambda o: "".join(o))
 def test_cli_gpu_bwa_mem_option_sets(tmp_path, gpu_lib, opts):
     _bwa_options(tmp_path, [os.path.join(ROOT, "bin", "bwa")], opts, 20000)
+
+
+def _single_end(tmp_path, bwa, n_pairs, seed, opts=(), env=None, **kw):
+    """one FASTQ without -p: upstream aligns every read on its own (mem_process_seqs without MEM_F_PE: primary marking by read ordinal, no
+    insert-size model, no rescue, no mate fields)"""
+    d = str(tmp_path)
+    fq = os.path.join(d, "se_%d.fq" % seed)
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=seed, **kw)
+    with open(fq, "w") as f:   # both ends as independent reads with names of their own, and one more so that the count is odd
+        k = 0
+        for name, a, b in pairs:
+            for s in (a, b):
+                f.write("@%s_%d\n%s\n+\n%s\n" % (name, k, "".join("ACGTN"[c] for c in s), "I" * len(s)))
+                k += 1
+        f.write("@tail\n%s\n+\n%s\n" % ("".join("ACGTN"[c] for c in pairs[0][1]), "I" * len(pairs[0][1])))
+    run = lambda exe, e=None: _no_pg(subprocess.run(exe + ["mem", "-t", "2", "-R", RG] + list(opts) + [EXAMPLE_FA, fq], capture_output=True, check=True, env=e).stdout.decode())
+    exp = run([ORC])
+    assert exp.count("\n") > 2 * n_pairs and not any(int(l.split("\t")[1]) & 0xc1 for l in exp.split("\n") if l and l[0] != "@")
+    assert run(bwa, dict(os.environ, **(env or {}))) == exp
+
+
+@pytest.mark.parametrize("seed,opts,env,kw", [(61, (), {}, {}), (62, ("-M", "-Y"), {"SSG_BWA_CALL_PAIRS": "97"}, {}), (63, ("-k", "25", "-T", "40"), {}, {"read_len": 250, "ins_mean": 800, "ins_std": 150})],
+                         ids=["default", "MY_many_calls", "2x250_k25"])
+def test_cli_emu_single_end(tmp_path, emu_lib, seed, opts, env, kw):
+    _single_end(tmp_path, [os.path.join(ROOT, "tests", "emu", "bwa_emu")], 300, seed, opts, env, **kw)
+
+
+@pytest.mark.gpu
+def test_cli_gpu_single_end(tmp_path, gpu_lib):
+    _single_end(tmp_path, [os.path.join(ROOT, "bin", "bwa")], 20000, 64)
