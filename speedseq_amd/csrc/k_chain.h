@@ -66,29 +66,17 @@ struct ssg_chain_w_lt {
 };
 
 /*
- * One lane per read.  Per-read slices (all indexed from seed_off[r], capacity = #seeds of r):
- *   chains[]   chain records, order[] / kept[] int work arrays, chain_seeds[] seed ids per chain.
- * Output: n_chain[r] = #chains surviving the filter; order[0..n) = their ids in upstream's final
- * order; for each, chains[id].first_seed is rewritten to an offset into chain_seeds[] (absolute
- * index) holding its n seed ids (absolute) in insertion order.
+ * The chains of one read (upstream mem_chain + mem_chain_flt) on the slices the caller hands over -- global memory (ssg_k_chain) or the lane's
+ * part of LDS (ssg_k_chain_lds): sd[] / srid[] the read's ns seeds, iv[] its ni intervals, ch[] / ord[] / kp[] / cs[] work arrays of ns entries.
+ * Returns the number of chains that survive the filter; ord[0..n) = their ids in upstream's final order; for each, ch[id].first_seed is
+ * rewritten to s0 + (offset into cs[]) where its n seed ids (s0 + index, insertion order) lie.
  */
-__global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
-                            const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
-                            const int64_t *seed_off, ssg_seed_t *seeds, const int32_t *seed_rid,
-                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, int dbg_phase,
-                            const int32_t *work_order)
+SSG_DEVFN int ssg_chain_one(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const int len, const int ns, ssg_seed_t *sd, const int32_t *srid, const int ni, const ssg_intv_t *iv,
+                            ssg_chain_t *ch, int32_t *ord, int32_t *kp, int32_t *cs, const long s0, const int dbg_phase)
 {
-	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= n_reads) return;
-	if (work_order) r = work_order[r];   /* reads sorted by seed count: the lanes of a wave get similar work */
-	int len = (int)(read_off[r+1] - read_off[r]);
-	long s0 = seed_off[r]; int ns = (int)(seed_off[r+1] - s0);
-	ssg_chain_t *ch = chains + s0; int32_t *ord = order + s0, *kp = kept + s0, *cs = chain_seeds + s0;
-	ssg_seed_t *sd = seeds + s0; const int32_t *srid = seed_rid + s0;
 	int nc = 0, root = -1, ins_ctr = 0, i, k;
 	/* frac_rep (upstream mem_chain head) */
-	int b = 0, e = 0, l_rep = 0, ni = n_intv[r] > 0 ? n_intv[r] : 0;
-	const ssg_intv_t *iv = intv + r * cap;
+	int b = 0, e = 0, l_rep = 0;
 	for (i = 0; i < ni; ++i) {
 		int sb = (int)(iv[i].info >> 32), se = (int)(uint32_t)iv[i].info;
 		if (iv[i].x2 <= (uint64_t)opt.max_occ) continue;
@@ -126,10 +114,10 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 			++nc;
 		}
 	}
-	if (dbg_phase == 1) return;
+	if (dbg_phase == 1) return 0;
 	for (i = 0; i < nc; ++i) ord[i] = i;
 	{ ssg_chain_key_lt lt = { ch }; ssg_introsort(ord, (long)nc, lt); } /* == B-tree in-order traversal (keys are unique) */
-	if (dbg_phase == 2) return;
+	if (dbg_phase == 2) return 0;
 	float frac_rep = (float)l_rep / len;
 	/* upstream mem_chain_flt */
 	int n_chn = 0;
@@ -139,7 +127,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 		c.w = ssg_chain_weight(c, sd);
 		if (c.w >= opt.min_chain_weight) ord[n_chn++] = ord[i];
 	}
-	if (dbg_phase == 3) return;
+	if (dbg_phase == 3) return 0;
 	int n_out = 0;
 	if (n_chn > 0) {
 		{ ssg_chain_w_lt lt = { ch }; ssg_introsort(ord, (long)n_chn, lt); }
@@ -174,7 +162,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 		for (; i < n_chn; ++i) if (ch[ord[i]].kept < 3) ch[ord[i]].kept = 0;
 		for (i = 0; i < n_chn; ++i) if (ch[ord[i]].kept != 0) ord[n_out++] = ord[i];
 	}
-	if (dbg_phase == 4) return;
+	if (dbg_phase == 4) return 0;
 	/* flatten the seed lists of the surviving chains */
 	int pos = 0;
 	for (i = 0; i < n_out; ++i) {
@@ -183,6 +171,69 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 		for (k = 0; k < c.n; ++k, sid = sd[sid].next) cs[pos++] = (int)(s0 + sid);
 		c.first_seed = (int)(s0 + start);
 	}
+	return n_out;
+}
+
+/*
+ * One lane per read.  Per-read slices (all indexed from seed_off[r], capacity = #seeds of r):
+ *   chains[]   chain records, order[] / kept[] int work arrays, chain_seeds[] seed ids per chain.
+ * Output: n_chain[r] = #chains surviving the filter; order[0..n) = their ids in upstream's final
+ * order; for each, chains[id].first_seed is rewritten to an offset into chain_seeds[] (absolute
+ * index) holding its n seed ids (absolute) in insertion order.
+ */
+__global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
+                            const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
+                            const int64_t *seed_off, ssg_seed_t *seeds, const int32_t *seed_rid,
+                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, int dbg_phase,
+                            const int32_t *work_order)
+{
+	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	if (work_order) r = work_order[r];   /* reads sorted by seed count: the lanes of a wave get similar work */
+	const int len = (int)(read_off[r+1] - read_off[r]);
+	const long s0 = seed_off[r]; const int ns = (int)(seed_off[r+1] - s0);
+	n_chain[r] = ssg_chain_one(ix, opt, len, ns, seeds + s0, seed_rid + s0, n_intv[r] > 0 ? n_intv[r] : 0, intv + r * cap, chains + s0, order + s0, kept + s0, chain_seeds + s0, s0, dbg_phase);
+}
+
+/*
+ * The same for reads of up to CAP seeds with the read's state in LDS.  ssg_k_chain runs at 3.7 TB/s (PMC, round 4: 91 GB per launch for
+ * ~5 GB of seeds, chains and lists): every lane walks its own few KB of chain and seed records, the resident lanes' working sets together
+ * exceed L2 by far, and each touch becomes a line from HBM.  Here a lane copies its seeds in once (the algorithmic traffic), chains and
+ * filters on LDS pointers, and copies out what the next stage reads: the surviving chains, their order and their seed lists.
+ * Lane slices of PER bytes, PER / 8 odd (64-bit fields stay aligned, lanes at the same offset spread over the banks).
+ */
+template <int CAP> struct ssg_chain_lds_cfg {
+	static constexpr int RAW = CAP * (int)(sizeof(ssg_seed_t) + sizeof(ssg_chain_t) + 4 * sizeof(int32_t));
+	static constexpr int PER = ((RAW + 7) / 8 % 2 ? (RAW + 7) / 8 : (RAW + 7) / 8 + 1) * 8;
+};
+template <int CAP>
+__global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
+                            const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
+                            const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
+                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, const int32_t *work_order)
+{
+	constexpr int PER = ssg_chain_lds_cfg<CAP>::PER;
+	__shared__ __attribute__((aligned(16))) uint8_t lds[64 * PER];
+	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	if (work_order) r = work_order[r];
+	const int len = (int)(read_off[r+1] - read_off[r]);
+	const long s0 = seed_off[r]; const int ns = (int)(seed_off[r+1] - s0);
+	const int ni = n_intv[r] > 0 ? n_intv[r] : 0;
+	if (ns > CAP) {   /* not for this kernel (the host sends it reads of at most CAP seeds): the global form */
+		n_chain[r] = ssg_chain_one(ix, opt, len, ns, const_cast<ssg_seed_t*>(seeds) + s0, seed_rid + s0, ni, intv + r * cap, chains + s0, order + s0, kept + s0, chain_seeds + s0, s0, 0);
+		return;
+	}
+	uint8_t *base = lds + (size_t)threadIdx.x * PER;
+	ssg_seed_t *sd = (ssg_seed_t*)base;
+	ssg_chain_t *ch = (ssg_chain_t*)(base + CAP * sizeof(ssg_seed_t));
+	int32_t *srid = (int32_t*)(base + CAP * (sizeof(ssg_seed_t) + sizeof(ssg_chain_t)));
+	int32_t *ord = srid + CAP, *kp = ord + CAP, *cs = kp + CAP;
+	for (int i = 0; i < ns; ++i) { sd[i] = seeds[s0 + i]; srid[i] = seed_rid[s0 + i]; }
+	const int n_out = ssg_chain_one(ix, opt, len, ns, sd, srid, ni, intv + r * cap, ch, ord, kp, cs, s0, 0);
+	int n_cs = 0;
+	for (int i = 0; i < n_out; ++i) { const int id = ord[i]; chains[s0 + id] = ch[id]; order[s0 + i] = id; n_cs += ch[id].n; }
+	for (int i = 0; i < n_cs; ++i) chain_seeds[s0 + i] = cs[i];
 	n_chain[r] = n_out;
 }
 #endif
