@@ -66,8 +66,8 @@ struct ssg_chain_w_lt {
 };
 
 /*
- * The chains of one read (upstream mem_chain + mem_chain_flt) on the slices the caller hands over -- global memory (ssg_k_chain) or the lane's
- * part of LDS (ssg_k_chain_lds): sd[] / srid[] the read's ns seeds, iv[] its ni intervals, ch[] / ord[] / kp[] / cs[] work arrays of ns entries.
+ * The chains of one read (upstream mem_chain + mem_chain_flt) on the slices the caller hands over (global memory in ssg_k_chain; a form with the lane's
+ * part of LDS was built in round 4 and measured slower): sd[] / srid[] the read's ns seeds, iv[] its ni intervals, ch[] / ord[] / kp[] / cs[] work arrays of ns entries.
  * Returns the number of chains that survive the filter; ord[0..n) = their ids in upstream's final order; for each, ch[id].first_seed is
  * rewritten to s0 + (offset into cs[]) where its n seed ids (s0 + index, insertion order) lie.
  */
@@ -195,45 +195,4 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 	n_chain[r] = ssg_chain_one(ix, opt, len, ns, seeds + s0, seed_rid + s0, n_intv[r] > 0 ? n_intv[r] : 0, intv + r * cap, chains + s0, order + s0, kept + s0, chain_seeds + s0, s0, dbg_phase);
 }
 
-/*
- * The same for reads of up to CAP seeds with the read's state in LDS.  ssg_k_chain runs at 3.7 TB/s (PMC, round 4: 91 GB per launch for
- * ~5 GB of seeds, chains and lists): every lane walks its own few KB of chain and seed records, the resident lanes' working sets together
- * exceed L2 by far, and each touch becomes a line from HBM.  Here a lane copies its seeds in once (the algorithmic traffic), chains and
- * filters on LDS pointers, and copies out what the next stage reads: the surviving chains, their order and their seed lists.
- * Lane slices of PER bytes, PER / 8 odd (64-bit fields stay aligned, lanes at the same offset spread over the banks).
- */
-template <int CAP> struct ssg_chain_lds_cfg {
-	static constexpr int RAW = CAP * (int)(sizeof(ssg_seed_t) + sizeof(ssg_chain_t) + 4 * sizeof(int32_t));
-	static constexpr int PER = ((RAW + 7) / 8 % 2 ? (RAW + 7) / 8 : (RAW + 7) / 8 + 1) * 8;
-};
-template <int CAP>
-__global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int n_reads,
-                            const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
-                            const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
-                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, const int32_t *work_order)
-{
-	constexpr int PER = ssg_chain_lds_cfg<CAP>::PER;
-	__shared__ __attribute__((aligned(16))) uint8_t lds[64 * PER];
-	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= n_reads) return;
-	if (work_order) r = work_order[r];
-	const int len = (int)(read_off[r+1] - read_off[r]);
-	const long s0 = seed_off[r]; const int ns = (int)(seed_off[r+1] - s0);
-	const int ni = n_intv[r] > 0 ? n_intv[r] : 0;
-	if (ns > CAP) {   /* not for this kernel (the host sends it reads of at most CAP seeds): the global form */
-		n_chain[r] = ssg_chain_one(ix, opt, len, ns, const_cast<ssg_seed_t*>(seeds) + s0, seed_rid + s0, ni, intv + r * cap, chains + s0, order + s0, kept + s0, chain_seeds + s0, s0, 0);
-		return;
-	}
-	uint8_t *base = lds + (size_t)threadIdx.x * PER;
-	ssg_seed_t *sd = (ssg_seed_t*)base;
-	ssg_chain_t *ch = (ssg_chain_t*)(base + CAP * sizeof(ssg_seed_t));
-	int32_t *srid = (int32_t*)(base + CAP * (sizeof(ssg_seed_t) + sizeof(ssg_chain_t)));
-	int32_t *ord = srid + CAP, *kp = ord + CAP, *cs = kp + CAP;
-	for (int i = 0; i < ns; ++i) { sd[i] = seeds[s0 + i]; srid[i] = seed_rid[s0 + i]; }
-	const int n_out = ssg_chain_one(ix, opt, len, ns, sd, srid, ni, intv + r * cap, ch, ord, kp, cs, s0, 0);
-	int n_cs = 0;
-	for (int i = 0; i < n_out; ++i) { const int id = ord[i]; chains[s0 + id] = ch[id]; order[s0 + i] = id; n_cs += ch[id].n; }
-	for (int i = 0; i < n_cs; ++i) chain_seeds[s0 + i] = cs[i];
-	n_chain[r] = n_out;
-}
 #endif

@@ -49,10 +49,6 @@ thread_local std::vector<ssg_prof_rec> ssg_prof_pending;
 #define SSG_MAX_RESIDENT_WG 1024
 /* longest read the DP kernels are laid out for (LDS rows, 8-bit columns) */
 #define SSG_MAX_READ_LEN 254
-#define SSG_CHAIN_LDS_CAP 12       /* ssg_k_chain_lds: seeds (= chains at most) per lane in LDS: 1064 B a lane, 68 KB a wave, two waves per CU */
-#ifndef SSG_CHAIN_LDS_DEFAULT
-#define SSG_CHAIN_LDS_DEFAULT 1
-#endif
 #define SSG_STR_(x) #x
 #define SSG_STR(x) SSG_STR_(x)
 
@@ -716,21 +712,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 #undef SSG_CHW_LAUNCH
 		if (nC) SSG_LAUNCH_ON(0, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		/* the light reads, a lane each: those of up to 12 seeds (nearly all) with their state in LDS (k_chain.h: the global form is bound by its own
-		 * re-fetched traffic), the rest on global memory.  SSG_CHAIN_LDS=0: all of them on global memory (A/B, tests) */
-		int r1 = r0;
-		if (n_reads > r0 && env_int("SSG_CHAIN_LDS", SSG_CHAIN_LDS_DEFAULT) != 0 && dbgp == 0) {
-			ssg_thr6_t th = { { SSG_CHAIN_LDS_CAP, SSG_CHAIN_LDS_CAP, SSG_CHAIN_LDS_CAP, SSG_CHAIN_LDS_CAP, SSG_CHAIN_LDS_CAP, SSG_CHAIN_LDS_CAP, SSG_CHAIN_LDS_CAP } };
-			dbuf<unsigned int> d_c(8); unsigned int c[7];
-			CHKA(d_c); CHK(d_c.zero());
-			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
-			CHK(d_c.down(c, 7));
-			r1 = std::max(r0, (int)std::min<unsigned int>(c[0], (unsigned int)n_reads));   /* d_work is heaviest first: reads [r1, n_reads) have at most CAP seeds */
-			if (n_reads > r1) SSG_LAUNCH(ssg_k_chain_lds<SSG_CHAIN_LDS_CAP>, (n_reads - r1 + 63) / 64, 64, 0, idx->v, *opt, r1, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-			                             d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, d_work.p);
-		} else r1 = n_reads;
-		if (ssg_debug()) fprintf(stderr, "[ssgpu] chain: %d reads a wave each, %d a lane on global memory, %d a lane in LDS\n", r0 - nC, (r1 - r0) + nC, n_reads - r1);
-		if (r1 > r0) SSG_LAUNCH(ssg_k_chain, (r1 - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, r1, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
 		ssg_join(3);
 	}

@@ -94,14 +94,6 @@ def test_emu_repeats_align1(emu_lib, oracle, repeat_prefix, monkeypatch):
     assert common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix) > 500
 
 
-@pytest.mark.parametrize("lds", ["1", "0"])
-def test_emu_chain_lane_forms(emu_lib, oracle, monkeypatch, lds):
-    """the light reads' chaining, a lane per read: state in LDS (ssg_k_chain_lds, reads of up to 12 seeds) and on global memory (ssg_k_chain) give
-    the oracle's regions on the same reads; SSG_CHAIN_LDS=0 sends every light read to the global form"""
-    monkeypatch.setenv("SSG_CHAIN_LDS", lds)
-    assert common.check_align1(emu_lib, oracle, 200, seed=41) > 200
-
-
 def test_emu_repeats_pe_sam(emu_lib, oracle, repeat_prefix):
     text, stats = common.check_pe_sam(emu_lib, oracle, 10, seed=23, prefix=repeat_prefix)
     assert "XA:Z:" in text
