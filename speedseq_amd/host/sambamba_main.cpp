@@ -255,8 +255,13 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	 * host's threads; the host emulation of the kernels only does it on request, it is slow) */
 	const char *const bd = getenv("SSG_BGZF_DEVICE");
 	const bool use_dev = lvl != 0 && nb > 0 && !(bd && !strcmp(bd, "0")) && (bd || strcmp(ssg_backend(), "emu") != 0) && ssg_device_count() > 0 && GRP * 2 <= 2048 && 2048 % GRP == 0;
+	size_t DEV_BATCH = 2048; { const char *e = getenv("SSG_SORT_DEV_BATCH"); if (e && atol(e) >= (long)GRP && atol(e) <= 2048 && atol(e) % (long)GRP == 0) DEV_BATCH = (size_t)atol(e); }   /* tests: several producers on several devices for a small file */
+	/* every visible device deflates (SSG_SORT_DEVICES caps them): producer t works on device t mod n_dev, lane 1 + t / n_dev -- with one device three
+	 * producers on three lanes as before, with N devices at least two per device; the writer and the index thread do not care who made a block */
+	int n_devs = use_dev ? std::max(1, ssg_device_count()) : 1; { const char *e = getenv("SSG_SORT_DEVICES"); if (e && atoi(e) > 0) n_devs = std::min(n_devs, atoi(e)); }
+	const int n_prod = use_dev ? (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(3 * n_devs, std::max(3, 2 * n_devs)), (nb + DEV_BATCH - 1) / DEV_BATCH)) : 0;
 	const int n_workers = use_dev ? 0 : (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
-	const size_t window = use_dev ? (size_t)8 * 2048 / GRP : std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
+	const size_t window = use_dev ? (size_t)std::max(8, 2 * n_prod) * DEV_BATCH / GRP : std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
 	auto nap = [](int us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); };
 	std::atomic<long> us_gather(0), us_deflate(0), us_window(0);   /* summed over the workers (SSG_DEBUG) */
 	/* payload of block bk (records cut[bk] .. cut[bk+1] of the sorted stream, a record larger than a block split over several) into dst */
@@ -292,11 +297,9 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	 * batches of 2048 blocks in turn -- gather into page-locked memory + CRC-32 by host threads, deflate on the GPU, framing (BGZF header,
 	 * CRC, ISIZE) -- and hand the groups to the same in-order writer.  The host's cores, which the deflate of a whole genome's records kept busy
 	 * for longer than the alignment took, only copy and checksum. */
-	const size_t DEV_BATCH = 2048;
-	const int n_prod = use_dev ? (int)std::max<size_t>(1, std::min<size_t>(3, (nb + DEV_BATCH - 1) / DEV_BATCH)) : 0;
 	std::atomic<int> dev_failed(0);
 	auto producer = [&](int t) {
-		if (ssg_set_lane(1 + t)) { dev_failed = 1; return; }
+		if (ssg_set_device(t % n_devs) || ssg_set_lane(1 + (t / n_devs) % 3)) { dev_failed = 1; return; }
 		const int gth = std::max(1, threads / std::max(1, n_prod));
 		uint8_t *P = (uint8_t*)ssg_host_alloc(DEV_BATCH * BGZF_MAX_PAYLOAD + 64), *O = (uint8_t*)ssg_host_alloc(DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64);
 		std::vector<uint64_t> rel(DEV_BATCH + 1), off(DEV_BATCH + 1); std::vector<uint32_t> crc(DEV_BATCH);
@@ -393,7 +396,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	if (dbg() && !seg) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index %.2f s, %d workers started in %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
 	                   "per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn0 - tw1, n_workers, tw_spawn - tw_spawn0, t_wr_wait, t_wr_io,
 	                   us_gather / 1e6 / std::max(1, n_workers + n_prod), us_deflate / 1e6 / std::max(1, n_workers + n_prod), us_window / 1e6 / std::max(1, n_workers + n_prod));
-	if (dbg() && use_dev && !seg) fprintf(stderr, "[sambamba] sort: write: blocks deflated on the device (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_prod);
+	if (dbg() && use_dev && !seg) fprintf(stderr, "[sambamba] sort: write: blocks deflated on %d device(s) (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_devs, n_prod);
 	if (seg) seg->coff = coff;
 	if (!bai_path) return;
 	blk_coff[nb] = coff;

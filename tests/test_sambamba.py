@@ -129,6 +129,28 @@ def test_sambamba_emu_device_deflate_matches_samtools(tmp_path, emu_lib, monkeyp
     _check([os.path.join(ROOT, "tests", "emu", "sambamba_emu")], tmp_path, monkeypatch)
 
 
+def test_sambamba_emu_device_deflate_on_several_devices(tmp_path, emu_lib, monkeypatch):
+    """every visible device deflates blocks of the sorted file (producer t on device t mod N, the writer and the index thread follow whoever made a
+    block): three emulated devices, batches of 16 blocks so that a small file keeps several producers busy; same checks as above"""
+    monkeypatch.setenv("SSG_BGZF_DEVICE", "1")
+    monkeypatch.setenv("SSG_EMU_DEVICES", "3")
+    monkeypatch.setenv("SSG_SORT_DEV_BATCH", "16")
+    monkeypatch.setenv("SSG_DEBUG", "1")
+    d = str(tmp_path)
+    sam = _sam(tmp_path, 1500, seed=35)
+    sambamba = os.path.join(ROOT, "tests", "emu", "sambamba_emu")
+    with open(sam, "rb") as fi, open(d + "/u.bam", "wb") as fo:
+        subprocess.run([sambamba, "view", "-S", "-f", "bam", "-l", "0", "/dev/stdin"], stdin=fi, stdout=fo, check=True)
+    r = subprocess.run([sambamba, "sort", "-t", "4", "-m", "1G", "--tmpdir=" + d + "/tmp", "-o", d + "/s.bam", d + "/u.bam"], check=True, capture_output=True, text=True)
+    assert "blocks deflated on 3 device(s)" in r.stderr, r.stderr[-500:]
+    subprocess.run([SAMTOOLS, "view", "-b", "-u", "-o", d + "/ref_u.bam", sam], check=True)
+    subprocess.run([SAMTOOLS, "sort", "-o", d + "/ref_s.bam", d + "/ref_u.bam"], check=True)
+    assert _view(d + "/s.bam") == _view(d + "/ref_s.bam")
+    os.rename(d + "/s.bam.bai", d + "/mine.bai")
+    subprocess.run([SAMTOOLS, "index", d + "/s.bam"], check=True)
+    assert _parse_bai(d + "/mine.bai") == _parse_bai(d + "/s.bam.bai")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_deflate", ["1", "0"])
 def test_sambamba_gpu_matches_samtools(tmp_path, gpu_lib, monkeypatch, device_deflate):
