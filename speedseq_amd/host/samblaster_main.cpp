@@ -148,13 +148,152 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 		}
 		ch.close();
 	});
-	std::vector<uint64_t> rec_off; std::vector<ssg_sbl_line_t> lines; std::vector<uint8_t> newblk, bits; std::vector<int64_t> blk_off, mate;
+	/* Two stages, a batch each: this thread takes a frame, makes samblaster's numeric view of its lines and has the device decide (the duplicate
+	 * table makes that stage sequential by nature); a second thread rebuilds the records, writes the main frame and the side streams of the
+	 * batch before, in order.  (One thread doing both was 3.6 s of work per 8 M pairs on the MI355X box, as much as `bwa mem` needed for them.) */
+	struct work_t {
+		std::unique_ptr<frame_t> F; fu_batch_t bh; const fu_cand_t *cand; const char *text; const uint8_t *bam; size_t nr, n_blocks;
+		std::vector<uint64_t> rec_off; std::vector<ssg_sbl_line_t> lines; std::vector<uint8_t> newblk, bits; std::vector<int64_t> blk_off, mate;
+	};
 	std::vector<std::pair<const char*, uint32_t> > ltext;
 	std::vector<std::vector<uint8_t> > outb;                  /* per-thread output of a batch, kept across batches */
 	std::unique_ptr<frame_t> F;
-	int rc = 0;
+	std::atomic<int> rc(0);
+	chan_t<std::unique_ptr<work_t> > to_b(1);
+	std::mutex wpool_mu; std::vector<std::unique_ptr<work_t> > wpool;
 	double tm[6] = { 0, 0, 0, 0, 0, 0 };                     /* wait for a frame, numeric view, decisions, records rebuilt, main stream written, side streams */
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double tmb[4] = { 0, 0, 0, 0 };                          /* second stage: wait for a decided batch, records rebuilt, main stream written, side streams */
+	std::thread stage_b([&]() {
+		std::unique_ptr<work_t> W;
+		for (;;) {
+			{ const double t0 = now(); const bool got = to_b.pop(W); tmb[0] += now() - t0; if (!got) break; }
+			if (rc) continue;                                     /* a failed run: take the batches off the channel, do nothing with them */
+			std::unique_ptr<frame_t> &F = W->F; const fu_batch_t &bh = W->bh; const fu_cand_t *cand = W->cand; const char *text = W->text; const uint8_t *bam = W->bam;
+			const size_t nr = W->nr, n_blocks = W->n_blocks;
+			std::vector<uint64_t> &rec_off = W->rec_off; std::vector<ssg_sbl_line_t> &lines = W->lines; std::vector<uint8_t> &bits = W->bits; std::vector<int64_t> &blk_off = W->blk_off, &mate = W->mate;
+			auto view = [&](size_t i) { bam_view_t v; v.p = bam + rec_off[i] + 4; v.bs = (uint32_t)(rec_off[i + 1] - rec_off[i] - 4); return v; };
+			double t0 = now();
+			do {
+			const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 4096 + 1));
+			if (outb.size() < (size_t)T) outb.resize((size_t)T);
+			for (auto &v : outb) v.clear();
+			parallel_ranges(T, (size_t)T, [&](size_t ta, size_t tb) {
+				for (size_t t = ta; t < tb; ++t) {
+					const size_t b0 = n_blocks * t / (size_t)T, b1 = n_blocks * (t + 1) / (size_t)T;
+					std::vector<uint8_t> &ob = outb[t];
+					ob.reserve((size_t)((rec_off[(size_t)blk_off[b1]] - rec_off[(size_t)blk_off[b0]]) * 21 / 20) + 4096);
+					char cg[16];
+					for (size_t i = (size_t)blk_off[b0]; i < (size_t)blk_off[b1]; ++i) {
+						const bam_view_t v = view(i);
+						const size_t base = ob.size();
+						ob.insert(ob.end(), bam + rec_off[i], bam + rec_off[i + 1]);
+						if (bits[i] & SSG_SBL_DUP) { uint32_t fnc; memcpy(&fnc, ob.data() + base + 4 + 12, 4); fnc |= 0x400u << 16; memcpy(ob.data() + base + 4 + 12, &fnc, 4); }
+						if (o.add_mate_tags && mate[i] >= 0) {
+							const bam_view_t m = view((size_t)mate[i]);
+							if (!bam_has_tag(v, 'M', 'C')) {
+								ob.push_back('M'); ob.push_back('C'); ob.push_back('Z');
+								if (!m.n_cigar()) ob.push_back('*');
+								for (uint32_t k = 0; k < m.n_cigar(); ++k) {
+									uint32_t x; memcpy(&x, m.cigar() + 4 * k, 4); uint32_t len = x >> 4; int n = 0;
+									do { cg[n++] = (char)('0' + len % 10); len /= 10; } while (len);
+									while (n) ob.push_back((uint8_t)cg[--n]);
+									ob.push_back((uint8_t)"MIDNSHP=XB"[x & 0xf]);
+								}
+								ob.push_back(0);
+							}
+							if (!bam_has_tag(v, 'M', 'Q')) { ob.push_back('M'); ob.push_back('Q'); ob.push_back('C'); ob.push_back((uint8_t)m.mapq()); }   /* MAPQ <= 255: sam_parse1 types it 'C' */
+							const uint32_t nbs = (uint32_t)(ob.size() - base - 4); memcpy(ob.data() + base, &nbs, 4);
+						}
+					}
+				}
+			});
+			tmb[1] += now() - t0; t0 = now();
+			{	uint64_t tot = 0; std::vector<uint64_t> at(outb.size() + 1, 0);
+				for (size_t k = 0; k < outb.size(); ++k) { at[k] = tot; tot += outb[k].size(); }
+				fu_buf_t seg; std::string seg_path; bool ok;
+				if (fu_seg_create((size_t)tot, seg, seg_path)) {       /* the frame as a mapped segment: filled by the threads, only its name travels */
+					parallel_ranges((int)outb.size(), outb.size(), [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) if (!outb[k].empty()) memcpy(seg.p + at[k], outb[k].data(), outb[k].size()); });
+					ok = fu_seg_send(1, FU_MAIN, seg, seg_path);
+				} else {
+					fu_frame_t fh; fh.type = FU_MAIN; fh.zero = 0; fh.len = tot;
+					ok = fu_write_full(1, &fh, sizeof(fh));
+					for (auto &v : outb) ok = ok && fu_write_full(1, v.data(), v.size());
+				}
+				if (!ok) { perror("[samblaster] write"); rc = 1; } }
+			if (rc) break;
+			tmb[2] += now() - t0; t0 = now();
+			/* side streams, from the text bwa attached for the pairs that can qualify */
+			ltext.assign(nr, std::pair<const char*, uint32_t>((const char*)0, 0u));
+			for (uint64_t c = 0; c < bh.n_cand; ++c) {
+				const char *p = text + cand[c].text_off, *e = text + (c + 1 < bh.n_cand ? cand[c + 1].text_off : bh.text_bytes);
+				for (uint64_t k = 0; k < cand[c].n_rec && p < e; ++k) {
+					const char *nl = (const char*)memchr(p, '\n', (size_t)(e - p)); if (!nl) nl = e;
+					if (cand[c].first_rec + k < nr) ltext[(size_t)(cand[c].first_rec + k)] = std::make_pair(p, (uint32_t)(nl - p));
+					p = nl < e ? nl + 1 : e;
+				}
+			}
+			auto side = [&](out_t &w, size_t i, int flag, bool patch, const char *suffix) -> bool {
+				if (!ltext[i].first) return false;
+				lrec_t r, mr; const char *f[12]; const char *opt = 0;
+				if (!scan_fields(ltext[i].first, ltext[i].second, 0, r, f, &opt)) return false;
+				const lrec_t *m = 0; bool add_mc = false, add_mq = false; const char *mbase = 0;
+				if (o.add_mate_tags && mate[i] >= 0) {
+					const size_t mi = (size_t)mate[i]; const char *g[12];
+					if (!ltext[mi].first || !scan_fields(ltext[mi].first, ltext[mi].second, 0, mr, g, 0)) return false;
+					m = &mr; mbase = ltext[mi].first;
+					const char *oe = ltext[i].first + ltext[i].second;
+					add_mc = !(opt && has_tag(opt, oe, "MC:Z:")); add_mq = !(opt && has_tag(opt, oe, "MQ:i:"));
+				}
+				/* emit_line addresses the line and its mate through one base pointer: write the two parts separately */
+				const char *s0 = ltext[i].first;
+				if (!patch && !suffix) w.put(s0, r.len);
+				else { w.put(s0, r.qn_len); if (suffix) w.put(suffix, 2); w.putc('\t'); w.puti(flag); w.put(s0 + r.flag_end, r.len - r.flag_end); }
+				if (m) { if (add_mc) { w.put("\tMC:Z:", 6); w.put(mbase + m->cig_off, m->cig_len); } if (add_mq) { w.put("\tMQ:i:", 6); w.put(mbase + m->mq_off, m->mq_len); } }
+				w.putc('\n');
+				return true;
+			};
+			/* every block is looked at for the counters, few (a few per cent) put lines on a side stream: the look is done by the pool, the lines are
+			 * written in block order by this thread */
+			struct sideblk_t { int64_t b, d1, d2; bool dup, split; };
+			const int TS = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 16384 + 1));
+			std::vector<std::vector<sideblk_t> > found((size_t)TS); std::vector<unsigned long long> c_pairs((size_t)TS, 0), c_dups((size_t)TS, 0);
+			parallel_ranges(TS, (size_t)TS, [&](size_t ta, size_t tb) {
+				for (size_t t = ta; t < tb; ++t) {
+					for (size_t b = n_blocks * t / (size_t)TS, e = n_blocks * (t + 1) / (size_t)TS; b < e; ++b) {
+						bool paired = false, dup = false, split = false; int64_t d1 = -1, d2 = -1;
+						for (int64_t i = blk_off[b]; i < blk_off[b + 1]; ++i) {
+							const int bt = bits[(size_t)i];
+							if (mate[(size_t)i] >= 0) paired = true;
+							if (bt & SSG_SBL_DUP) dup = true;
+							if (bt & SSG_SBL_DISC) { if (lines[(size_t)i].flag & 0x40) d1 = i; else d2 = i; }
+							if (bt & SSG_SBL_SPLIT) split = true;
+						}
+						if (paired) { ++c_pairs[t]; if (dup) ++c_dups[t]; }
+						if ((disc && d1 >= 0 && d2 >= 0) || (spl && split)) { sideblk_t k; k.b = (int64_t)b; k.d1 = d1; k.d2 = d2; k.dup = dup; k.split = split; found[t].push_back(k); }
+					}
+				}
+			});
+			for (int t = 0; t < TS; ++t) { n_pairs += c_pairs[(size_t)t]; n_dups += c_dups[(size_t)t]; }
+			for (int t = 0; t < TS && !rc; ++t) for (const sideblk_t &k : found[(size_t)t]) {
+				const bool dup = k.dup; const int64_t d1 = k.d1, d2 = k.d2; const size_t b = (size_t)k.b;
+				if (disc && d1 >= 0 && d2 >= 0) {
+					for (int64_t i : { d1, d2 }) if (!side(*disc, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), dup, 0)) { fprintf(stderr, "[samblaster] fused stream: a discordant line came without its text\n"); rc = 1; }
+					++n_disc;
+				}
+				if (spl && k.split) for (int64_t i = blk_off[b]; i < blk_off[b + 1]; ++i) if (bits[(size_t)i] & SSG_SBL_SPLIT) {
+					if (!side(*spl, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), true, (lines[(size_t)i].flag & 0x40) ? "_1" : "_2")) { fprintf(stderr, "[samblaster] fused stream: a splitter line came without its text\n"); rc = 1; }
+					++n_spl;
+				}
+				if (rc) break;
+			}
+			if (F->b.mapped) F->b.reset();                           /* the segment's pages go back to the system now */
+			{ std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 3) pool.push_back(std::move(F)); }
+			tmb[3] += now() - t0;
+			} while (0);
+			{ std::lock_guard<std::mutex> l(wpool_mu); if (wpool.size() < 3) wpool.push_back(std::move(W)); }
+		}
+	});
 	for (;;) {
 		{ const double t0 = now(); const bool got = !rc && ch.pop(F); tm[0] += now() - t0; if (!got) break; }
 		if (F->h.type == FU_END) { ended = true; break; }
@@ -166,13 +305,17 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 			got_header = true; continue;
 		}
 		if (F->h.type != FU_BATCH || F->h.len < sizeof(fu_batch_t)) { fprintf(stderr, "[samblaster] unexpected frame in the fused stream\n"); rc = 1; break; }
-		fu_batch_t bh; memcpy(&bh, F->b.p, sizeof(bh));
+		std::unique_ptr<work_t> W;
+		{ std::lock_guard<std::mutex> l(wpool_mu); if (!wpool.empty()) { W = std::move(wpool.back()); wpool.pop_back(); } }
+		if (!W) W.reset(new work_t());
+		fu_batch_t &bh = W->bh; memcpy(&bh, F->b.p, sizeof(bh));
 		if (sizeof(bh) + bh.n_cand * sizeof(fu_cand_t) + bh.text_bytes + bh.bam_bytes != F->h.len) { fprintf(stderr, "[samblaster] malformed batch frame\n"); rc = 1; break; }
-		const fu_cand_t *cand = (const fu_cand_t*)(F->b.p + sizeof(bh));
-		const char *text = (const char*)(cand + bh.n_cand);
-		const uint8_t *bam = (const uint8_t*)text + bh.text_bytes;
-		const size_t nr = (size_t)bh.n_rec;
-		if (!nr) continue;
+		const fu_cand_t *cand = W->cand = (const fu_cand_t*)(F->b.p + sizeof(bh));
+		const char *text = W->text = (const char*)(cand + bh.n_cand);
+		const uint8_t *bam = W->bam = (const uint8_t*)text + bh.text_bytes;
+		const size_t nr = W->nr = (size_t)bh.n_rec;
+		if (!nr) { std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 4) pool.push_back(std::move(F)); continue; }
+		std::vector<uint64_t> &rec_off = W->rec_off; std::vector<ssg_sbl_line_t> &lines = W->lines; std::vector<uint8_t> &newblk = W->newblk, &bits = W->bits; std::vector<int64_t> &blk_off = W->blk_off, &mate = W->mate;
 		double t0 = now();
 		rec_off.resize(nr + 1);
 		{ uint64_t o2 = 0; size_t i = 0; for (; i < nr && o2 + 4 <= bh.bam_bytes; ++i) { rec_off[i] = o2; uint32_t bs; memcpy(&bs, bam + o2, 4); o2 += 4 + (uint64_t)bs; } rec_off[nr] = o2;
@@ -201,108 +344,14 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 		const size_t n_blocks = blk_off.size(); blk_off.push_back((int64_t)nr);
 		tm[1] += now() - t0; t0 = now();
 		if (ssg_sbl_process(st, &o, (long)n_blocks, blk_off.data(), lines.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); rc = 1; break; }
-		/* main stream: the records with 0x400 and MC / MQ, rebuilt by threads over ranges of blocks, written in order as one frame */
-		tm[2] += now() - t0; t0 = now();
-		const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 4096 + 1));
-		if (outb.size() < (size_t)T) outb.resize((size_t)T);
-		for (auto &v : outb) v.clear();
-		parallel_ranges(T, (size_t)T, [&](size_t ta, size_t tb) {
-			for (size_t t = ta; t < tb; ++t) {
-				const size_t b0 = n_blocks * t / (size_t)T, b1 = n_blocks * (t + 1) / (size_t)T;
-				std::vector<uint8_t> &ob = outb[t];
-				ob.reserve((size_t)((rec_off[(size_t)blk_off[b1]] - rec_off[(size_t)blk_off[b0]]) * 21 / 20) + 4096);
-				char cg[16];
-				for (size_t i = (size_t)blk_off[b0]; i < (size_t)blk_off[b1]; ++i) {
-					const bam_view_t v = view(i);
-					const size_t base = ob.size();
-					ob.insert(ob.end(), bam + rec_off[i], bam + rec_off[i + 1]);
-					if (bits[i] & SSG_SBL_DUP) { uint32_t fnc; memcpy(&fnc, ob.data() + base + 4 + 12, 4); fnc |= 0x400u << 16; memcpy(ob.data() + base + 4 + 12, &fnc, 4); }
-					if (o.add_mate_tags && mate[i] >= 0) {
-						const bam_view_t m = view((size_t)mate[i]);
-						if (!bam_has_tag(v, 'M', 'C')) {
-							ob.push_back('M'); ob.push_back('C'); ob.push_back('Z');
-							if (!m.n_cigar()) ob.push_back('*');
-							for (uint32_t k = 0; k < m.n_cigar(); ++k) {
-								uint32_t x; memcpy(&x, m.cigar() + 4 * k, 4); uint32_t len = x >> 4; int n = 0;
-								do { cg[n++] = (char)('0' + len % 10); len /= 10; } while (len);
-								while (n) ob.push_back((uint8_t)cg[--n]);
-								ob.push_back((uint8_t)"MIDNSHP=XB"[x & 0xf]);
-							}
-							ob.push_back(0);
-						}
-						if (!bam_has_tag(v, 'M', 'Q')) { ob.push_back('M'); ob.push_back('Q'); ob.push_back('C'); ob.push_back((uint8_t)m.mapq()); }   /* MAPQ <= 255: sam_parse1 types it 'C' */
-						const uint32_t nbs = (uint32_t)(ob.size() - base - 4); memcpy(ob.data() + base, &nbs, 4);
-					}
-				}
-			}
-		});
-		tm[3] += now() - t0; t0 = now();
-		{	uint64_t tot = 0; std::vector<uint64_t> at(outb.size() + 1, 0);
-			for (size_t k = 0; k < outb.size(); ++k) { at[k] = tot; tot += outb[k].size(); }
-			fu_buf_t seg; std::string seg_path; bool ok;
-			if (fu_seg_create((size_t)tot, seg, seg_path)) {       /* the frame as a mapped segment: filled by the threads, only its name travels */
-				parallel_ranges((int)outb.size(), outb.size(), [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) if (!outb[k].empty()) memcpy(seg.p + at[k], outb[k].data(), outb[k].size()); });
-				ok = fu_seg_send(1, FU_MAIN, seg, seg_path);
-			} else {
-				fu_frame_t fh; fh.type = FU_MAIN; fh.zero = 0; fh.len = tot;
-				ok = fu_write_full(1, &fh, sizeof(fh));
-				for (auto &v : outb) ok = ok && fu_write_full(1, v.data(), v.size());
-			}
-			if (!ok) { perror("[samblaster] write"); rc = 1; break; } }
-		tm[4] += now() - t0; t0 = now();
-		/* side streams, from the text bwa attached for the pairs that can qualify */
-		ltext.assign(nr, std::pair<const char*, uint32_t>((const char*)0, 0u));
-		for (uint64_t c = 0; c < bh.n_cand; ++c) {
-			const char *p = text + cand[c].text_off, *e = text + (c + 1 < bh.n_cand ? cand[c + 1].text_off : bh.text_bytes);
-			for (uint64_t k = 0; k < cand[c].n_rec && p < e; ++k) {
-				const char *nl = (const char*)memchr(p, '\n', (size_t)(e - p)); if (!nl) nl = e;
-				if (cand[c].first_rec + k < nr) ltext[(size_t)(cand[c].first_rec + k)] = std::make_pair(p, (uint32_t)(nl - p));
-				p = nl < e ? nl + 1 : e;
-			}
-		}
-		auto side = [&](out_t &w, size_t i, int flag, bool patch, const char *suffix) -> bool {
-			if (!ltext[i].first) return false;
-			lrec_t r, mr; const char *f[12]; const char *opt = 0;
-			if (!scan_fields(ltext[i].first, ltext[i].second, 0, r, f, &opt)) return false;
-			const lrec_t *m = 0; bool add_mc = false, add_mq = false; const char *mbase = 0;
-			if (o.add_mate_tags && mate[i] >= 0) {
-				const size_t mi = (size_t)mate[i]; const char *g[12];
-				if (!ltext[mi].first || !scan_fields(ltext[mi].first, ltext[mi].second, 0, mr, g, 0)) return false;
-				m = &mr; mbase = ltext[mi].first;
-				const char *oe = ltext[i].first + ltext[i].second;
-				add_mc = !(opt && has_tag(opt, oe, "MC:Z:")); add_mq = !(opt && has_tag(opt, oe, "MQ:i:"));
-			}
-			/* emit_line addresses the line and its mate through one base pointer: write the two parts separately */
-			const char *s0 = ltext[i].first;
-			if (!patch && !suffix) w.put(s0, r.len);
-			else { w.put(s0, r.qn_len); if (suffix) w.put(suffix, 2); w.putc('\t'); w.puti(flag); w.put(s0 + r.flag_end, r.len - r.flag_end); }
-			if (m) { if (add_mc) { w.put("\tMC:Z:", 6); w.put(mbase + m->cig_off, m->cig_len); } if (add_mq) { w.put("\tMQ:i:", 6); w.put(mbase + m->mq_off, m->mq_len); } }
-			w.putc('\n');
-			return true;
-		};
-		for (size_t b = 0; b < n_blocks && !rc; ++b) {
-			bool paired = false, dup = false; int64_t d1 = -1, d2 = -1;
-			for (int64_t i = blk_off[b]; i < blk_off[b + 1]; ++i) {
-				const int bt = bits[(size_t)i];
-				if (mate[(size_t)i] >= 0) paired = true;
-				if (bt & SSG_SBL_DUP) dup = true;
-				if (bt & SSG_SBL_DISC) { if (lines[(size_t)i].flag & 0x40) d1 = i; else d2 = i; }
-			}
-			if (paired) { ++n_pairs; if (dup) ++n_dups; }
-			if (disc && d1 >= 0 && d2 >= 0) {
-				for (int64_t i : { d1, d2 }) if (!side(*disc, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), dup, 0)) { fprintf(stderr, "[samblaster] fused stream: a discordant line came without its text\n"); rc = 1; }
-				++n_disc;
-			}
-			if (spl) for (int64_t i = blk_off[b]; i < blk_off[b + 1]; ++i) if (bits[(size_t)i] & SSG_SBL_SPLIT) {
-				if (!side(*spl, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), true, (lines[(size_t)i].flag & 0x40) ? "_1" : "_2")) { fprintf(stderr, "[samblaster] fused stream: a splitter line came without its text\n"); rc = 1; }
-				++n_spl;
-			}
-		}
-		if (F->b.mapped) F->b.reset();                           /* the segment's pages go back to the system now */
-		{ std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 3) pool.push_back(std::move(F)); }
-		tm[5] += now() - t0;
+		tm[2] += now() - t0;
+		W->n_blocks = n_blocks; W->F = std::move(F);
+		to_b.push(std::move(W));
 	}
-	if (getenv("SSG_SBL_LOG")) fprintf(stderr, "[samblaster] main thread: waiting for frames %.2f s, numeric view %.2f s, decisions %.2f s, records %.2f s, main stream written %.2f s, side streams %.2f s\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
+	to_b.close();
+	stage_b.join();
+	tm[3] = tmb[1]; tm[4] = tmb[2]; tm[5] = tmb[3];
+	if (getenv("SSG_SBL_LOG")) fprintf(stderr, "[samblaster] first stage: waiting for frames %.2f s, numeric view %.2f s, decisions %.2f s; second stage: waiting for decided batches %.2f s, records %.2f s, main stream written %.2f s, side streams %.2f s\n", tm[0], tm[1], tm[2], tmb[0], tm[3], tm[4], tm[5]);
 	{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
 	reader.join();
 	if (!rc && (rd_fail || !ended)) { fprintf(stderr, "[samblaster] the fused stream ended early\n"); rc = 1; }
