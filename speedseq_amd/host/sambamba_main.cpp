@@ -207,16 +207,18 @@ struct seg_out_t {
 	bool first, last;                                  /* set by the caller for each call */
 	uint64_t coff;                                     /* file offset of the next block */
 	std::unique_ptr<bai_t> idx; bool idx_ok;
+	bool no_index;                                     /* the output cannot be sought: no index */
 	bool pending; int32_t p_tid, p_pos, p_end; bool p_mapped;   /* the last record of the previous stretch: its entry closes at the first record of the next */
-	seg_out_t() : first(true), last(false), coff(0), idx_ok(true), pending(false), p_tid(0), p_pos(0), p_end(0), p_mapped(false) {}
+	seg_out_t() : first(true), last(false), coff(0), idx_ok(true), no_index(false), pending(false), p_tid(0), p_pos(0), p_end(0), p_mapped(false) {}
 };
 static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads, const char *bai_path = 0,
                          const std::vector<size_t> *force_at = 0, std::vector<uint64_t> *force_off = 0, seg_out_t *seg = 0, std::vector<uint64_t> *force_uoff = 0)
 {
 	const bool opens = !seg || seg->first, closes = !seg || seg->last;
 	if (!force_at && opens) { bgzf_out_t out(fd, level, threads); hdr_write(out, h); out.drain(true); }
-	const off_t hdr_end = force_at ? (off_t)0 : !opens ? (off_t)seg->coff : (bai_path || seg) ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
-	if (hdr_end < 0) { if (seg) die("sort: the output of a merge must be a regular file"); bai_path = 0; }
+	off_t hdr_end = force_at ? (off_t)0 : !opens ? (off_t)seg->coff : (bai_path || seg) ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+	if (hdr_end < 0) { bai_path = 0; if (seg) { seg->no_index = true; hdr_end = 0; } }   /* a pipe: no offsets, no index (the file offsets kept in *seg then only count from the first record) */
+	if (seg && seg->no_index) bai_path = 0;
 	const bool want_off = bai_path || force_at || seg;
 	const size_t n = perm.size();
 	const int lvl = level < 0 ? 6 : level;

@@ -129,6 +129,21 @@ def test_sambamba_emu_device_deflate_matches_samtools(tmp_path, emu_lib, monkeyp
     _check([os.path.join(ROOT, "tests", "emu", "sambamba_emu")], tmp_path, monkeypatch)
 
 
+def test_sambamba_emu_sort_to_a_pipe(tmp_path, emu_lib, monkeypatch):
+    """`-o /dev/stdout` into a pipe: no index can be written (no offsets), the records are the same, in memory and through the spill-and-merge path"""
+    d = str(tmp_path)
+    sam = _sam(tmp_path, 600, seed=36)
+    sambamba = os.path.join(ROOT, "tests", "emu", "sambamba_emu")
+    with open(sam, "rb") as fi, open(d + "/u.bam", "wb") as fo:
+        subprocess.run([sambamba, "view", "-S", "-f", "bam", "-l", "0", "/dev/stdin"], stdin=fi, stdout=fo, check=True)
+    subprocess.run([sambamba, "sort", "-t", "3", "-m", "1G", "--tmpdir=" + d + "/t0", "-o", d + "/file.bam", d + "/u.bam"], check=True)
+    for k, env in enumerate(({}, {"SSG_SORT_CHUNK_BYTES": "150000", "SSG_SORT_RANGES": "7"})):
+        out = "%s/piped%d.bam" % (d, k)
+        subprocess.run("%s sort -t 3 -m 1G --tmpdir=%s/t%d -o /dev/stdout %s/u.bam | cat > %s" % (sambamba, d, k + 1, d, out), shell=True, check=True, env=dict(os.environ, **env))
+        assert _view(out) == _view(d + "/file.bam")
+        assert os.listdir("%s/t%d" % (d, k + 1)) == []
+
+
 def test_sambamba_emu_device_deflate_on_several_devices(tmp_path, emu_lib, monkeypatch):
     """every visible device deflates blocks of the sorted file (producer t on device t mod N, the writer and the index thread follow whoever made a
     block): three emulated devices, batches of 16 blocks so that a small file keeps several producers busy; same checks as above"""
