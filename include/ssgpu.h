@@ -188,6 +188,13 @@ int ssg_sbl_markdup_stream(ssg_sbl_state_t *st, long n_pairs, const ssg_sbl_end_
 void ssg_sbl_opt_init(ssg_sbl_opt_t *o);
 int ssg_sbl_process(ssg_sbl_state_t *st, const ssg_sbl_opt_t *o, long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines,
                     uint8_t *line_bits, int64_t *mate_line);
+/* ssg_sbl_process in two halves, for several pipelines that share ONE duplicate set (rank mode: bin/speedseq-ranks).
+ * samblaster keeps the first pair of every signature in input order (GregoryFaust/samblaster samblaster.cpp, the duplicate hash set; SURVEY 8a
+ * a14): a pipeline extracts the two primary ends of every block (ends[2 * n_blocks]), the process that owns the set decides them with
+ * ssg_sbl_markdup_stream in input order, and the lines are classified with those verdicts (dup[n_blocks]). */
+int ssg_sbl_ends(long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines, ssg_sbl_end_t *ends);
+int ssg_sbl_classify(const ssg_sbl_opt_t *o, long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines, const uint8_t *dup,
+                     uint8_t *line_bits, int64_t *mate_line);
 
 /* stable device radix sort of 64-bit keys, returned as a permutation: the coordinate sort of BAM records (samtools bam_sort.c:1607-1614
  * key tid<<32 | (pos+1)<<1 | reverse; ties keep input order) for the `sambamba sort` the reference runs at bin/speedseq:427 (row f1) */

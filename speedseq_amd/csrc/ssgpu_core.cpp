@@ -1262,6 +1262,39 @@ int ssg_sbl_process(ssg_sbl_state_t *st, const ssg_sbl_opt_t *o, long n_blocks, 
 	return d_mate.down(mate_line, n_lines);
 }
 
+/* ssg_sbl_process in two halves, for pipelines that run side by side and share ONE duplicate set (rank mode): the ends of
+ * every block's primaries (what the signature is built from) go to the process that owns the set (ssg_sbl_markdup_stream there, batches in
+ * input order), its verdicts come back, and the lines are classified with them.  Same kernels as ssg_sbl_process, same results. */
+int ssg_sbl_ends(long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines, ssg_sbl_end_t *ends)
+{
+	CHK(need_device());
+	if (n_blocks <= 0) return 0;
+	if (n_blocks >= (1L << 31)) { ssg_err_msg = "ssg_sbl_ends: more than 2^31 blocks per call"; return SSG_EINVAL; }
+	const int64_t n_lines = blk_off[n_blocks]; const int block = 256;
+	dbuf<int64_t> d_off(n_blocks + 1), d_prim(2 * n_blocks); dbuf<ssg_sbl_line_t> d_lines(n_lines + 1); dbuf<ssg_sbl_end_t> d_ends(2 * n_blocks);
+	CHKA(d_off); CHKA(d_prim); CHKA(d_lines); CHKA(d_ends);
+	CHK(d_off.up(blk_off, n_blocks + 1)); CHK(d_lines.up(lines, n_lines));
+	SSG_LAUNCH(ssg_k_sbl_ends, (n_blocks + block - 1) / block, block, 0, n_blocks, d_off.p, d_lines.p, d_ends.p, d_prim.p);
+	return d_ends.down(ends, 2 * n_blocks);
+}
+int ssg_sbl_classify(const ssg_sbl_opt_t *o, long n_blocks, const int64_t *blk_off, const ssg_sbl_line_t *lines, const uint8_t *dup, uint8_t *line_bits, int64_t *mate_line)
+{
+	CHK(need_device());
+	if (n_blocks <= 0) return 0;
+	if (n_blocks >= (1L << 31)) { ssg_err_msg = "ssg_sbl_classify: more than 2^31 blocks per call"; return SSG_EINVAL; }
+	if (o->max_split_count > SSG_SBL_MAX_SPLIT) { ssg_err_msg = "samblaster: --maxSplitCount above 16 is not supported"; return SSG_EINVAL; }
+	const int64_t n_lines = blk_off[n_blocks]; const int block = 256;
+	dbuf<int64_t> d_off(n_blocks + 1), d_prim(2 * n_blocks), d_mate(n_lines + 1); dbuf<ssg_sbl_line_t> d_lines(n_lines + 1); dbuf<ssg_sbl_end_t> d_ends(2 * n_blocks);
+	dbuf<uint8_t> d_dup(n_blocks), d_out(n_lines + 1);
+	CHKA(d_off); CHKA(d_prim); CHKA(d_mate); CHKA(d_lines); CHKA(d_ends); CHKA(d_dup); CHKA(d_out);
+	CHK(d_off.up(blk_off, n_blocks + 1)); CHK(d_lines.up(lines, n_lines)); CHK(d_dup.up(dup, n_blocks));
+	SSG_LAUNCH(ssg_k_sbl_ends, (n_blocks + block - 1) / block, block, 0, n_blocks, d_off.p, d_lines.p, d_ends.p, d_prim.p);
+	SSG_LAUNCH(ssg_k_sbl_classify, (n_blocks + block - 1) / block, block, 0, *o, n_blocks, d_off.p, d_lines.p, d_prim.p, d_dup.p, d_out.p, d_mate.p);
+	CHK(rt_sync());
+	CHK(d_out.down(line_bits, n_lines));
+	return d_mate.down(mate_line, n_lines);
+}
+
 /* aligned records of one call kept in HBM with their samblaster view (lines, primaries), for the stages after alignment */
 struct ssg_dev_records {
 	pe_dev_t keep; long n_pairs; int64_t n_lines;

@@ -147,6 +147,12 @@ static int main_mem(int argc, char **argv)
 	const double t_start = wall();
 	size_t max_pairs_per_call = 1u << 19;   /* upstream batches are grouped up to this many pairs per device call (one batch alone may exceed it) */
 	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
+	/* Rank mode (bin/speedseq-ranks): SSG_WORLD pipelines of the reference's script run side by side, one per GPU; this
+	 * `bwa mem` reads the whole input, forms upstream's batches as ever -- their composition is the scope of the insert-size model -- and aligns
+	 * those whose index is SSG_RANK modulo SSG_WORLD, one batch per device call, pair ordinals counted over the whole input. */
+	int world = 1, rank = 0;
+	{ const char *w = getenv("SSG_WORLD"), *r = getenv("SSG_RANK"); if (w && atoi(w) > 1) { world = atoi(w); rank = r ? atoi(r) : -1; if (rank < 0 || rank >= world) { fprintf(stderr, "[bwa] SSG_RANK must be 0 .. SSG_WORLD - 1\n"); return 1; } } }
+	if (world > 1) max_pairs_per_call = 1;
 	if (getenv("SSG_BWA_PROF")) { ssg_prof_reset(); ssg_prof_enable(1); }
 	/* fused mode (fused.h): BAM records in frames instead of SAM text when speedseq.config exported SSG_FUSED=1; never with -C */
 	bool fused = fu_enabled() && !keep_comment;
@@ -155,6 +161,7 @@ static int main_mem(int argc, char **argv)
 	if (argc - ai >= 3) { fp2 = gzopen(argv[ai + 2], "r"); if (!fp2) { fprintf(stderr, "[bwa] fail to open %s\n", argv[ai + 2]); return 1; } }
 	if (interleaved && fp2) { fprintf(stderr, "[W::main_mem] when '-p' is in use, the second query file is ignored.\n"); gzclose(fp2); fp2 = 0; }
 	const bool se = !interleaved && !fp2;   /* upstream main_mem: MEM_F_PE is set by -p or by a second file; without it every read is aligned on its own */
+	if (se && world > 1) { fprintf(stderr, "[bwa] rank mode is for paired-end input\n"); return 1; }
 	if (se) fused = false;                  /* samblaster has nothing to do with unpaired reads: SAM text */
 	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
 	const int64_t chunk = fixed_chunk > 0 ? fixed_chunk : (int64_t)opt.chunk_size * opt.n_threads;   /* -K: batches that do not depend on -t */
@@ -273,7 +280,7 @@ static int main_mem(int argc, char **argv)
 	double tm_asm = 0; std::vector<double> tm_gpu((size_t)n_dev, 0.0); std::vector<long> calls((size_t)n_dev, 0);
 	std::thread t_asm([&]() {
 		fq_cursor_t c1(feed1); std::unique_ptr<fq_cursor_t> c2(feed2 ? new fq_cursor_t(*feed2) : 0);
-		int64_t id0 = 0, seqno = 0; bool eof = false;
+		int64_t id0 = 0, seqno = 0, bidx = 0; bool eof = false;
 		while (!eof && !fail) {
 			const double t0 = wall();
 			std::unique_ptr<batch_t> B(new batch_t()); B->id0 = id0; B->seqno = seqno;
@@ -311,6 +318,7 @@ static int main_mem(int argc, char **argv)
 				if (B->n() > n0) { for (int p = n0 / 2; p < B->n() / 2; ++p) B->pair_batch.push_back(B->n_batches); ++B->n_batches; }
 			}
 			if (fail || B->n() == 0) break;
+			if (world > 1 && (bidx++ % world) != rank) { id0 += B->n() / 2; continue; }   /* another rank's batch: only its pairs are counted */
 			B->gather(std::min(8, std::max(1, opt.n_threads)));
 			id0 += se ? B->n() : B->n() / 2; ++seqno;   /* pairs: the pair ordinal; single-end: upstream's n_processed */
 			tm_asm += wall() - t0;

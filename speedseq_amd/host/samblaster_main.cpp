@@ -29,6 +29,9 @@
 #include "../../include/ssgpu.h"
 #include "fastq.h"   /* chan_t */
 #include "fused.h"
+#include "ranks.h"
+#include <map>
+#include <condition_variable>
 
 static inline void parallel_ranges(int n_threads, size_t n, const std::function<void(size_t, size_t)> &fn)
 {
@@ -42,10 +45,11 @@ static inline void parallel_ranges(int n_threads, size_t n, const std::function<
 
 struct out_t {           /* buffered writer on a file descriptor */
 	int fd; std::vector<char> b; size_t n;
-	explicit out_t(int fd_) : fd(fd_), b(4u << 20), n(0) {}
+	explicit out_t(int fd_) : fd(fd_), b(fd_ < 0 ? (size_t)1 << 16 : (size_t)4 << 20), n(0) {}
 	void flush() { size_t o = 0; while (o < n) { ssize_t w = write(fd, b.data() + o, n - o); if (w < 0) { if (errno == EINTR) continue; perror("[samblaster] write"); exit(1); } o += (size_t)w; } n = 0; }
-	inline void put(const char *p, size_t l) { if (n + l > b.size()) { flush(); if (l > b.size()) b.resize(l * 2); } memcpy(b.data() + n, p, l); n += l; }
-	inline void putc(char c) { if (n == b.size()) flush(); b[n++] = c; }
+	/* fd < 0: everything stays in memory (rank mode: a batch's side-stream lines travel to rank 0) */
+	inline void put(const char *p, size_t l) { if (n + l > b.size()) { if (fd < 0) b.resize(std::max(2 * b.size(), n + l)); else { flush(); if (l > b.size()) b.resize(l * 2); } } memcpy(b.data() + n, p, l); n += l; }
+	inline void putc(char c) { if (n == b.size()) { if (fd < 0) b.resize(2 * b.size()); else flush(); } b[n++] = c; }
 	inline void puti(int v) { char t[16]; int k = 0; if (v == 0) t[k++] = '0'; unsigned u = (unsigned)v; char r[16]; int m = 0; while (u) { r[m++] = (char)('0' + u % 10); u /= 10; } while (m) t[k++] = r[--m]; put(t, (size_t)k); }
 };
 
@@ -123,12 +127,93 @@ static bool bam_has_tag(const bam_view_t &v, char a, char b)
 	return false;
 }
 
+/* Rank mode (ranks.h): rank 0's samblaster owns the duplicate set and both side streams.  Every rank -- rank 0 too -- is a client: per batch
+ * it sends the primary ends of its blocks and waits for the verdicts, later it sends the batch's side-stream lines.  The server decides the
+ * batches in input order b = 0, 1, 2, ... (batch b comes from rank b mod N), which is the order one samblaster would have seen them in, and
+ * writes the side-stream lines in that order too. */
+struct sbl_server_t {
+	int world, lfd; ssg_sbl_state_t *st; out_t *spl, *disc;
+	std::vector<int> cfd; std::vector<std::thread> readers; std::thread decider;
+	std::mutex mu; std::condition_variable cv;
+	struct ends_t { int rank; std::vector<uint8_t> p; };
+	std::map<uint64_t, ends_t> ends; std::map<uint64_t, std::vector<uint8_t> > side; std::vector<char> done; int failed;
+	sbl_server_t(int w, ssg_sbl_state_t *st_, out_t *s, out_t *d) : world(w), lfd(-1), st(st_), spl(s), disc(d), cfd((size_t)w, -1), done((size_t)w, 0), failed(0) {}
+	bool start(const std::string &path)
+	{
+		lfd = rk_listen(path, world);
+		if (lfd < 0) return false;
+		decider = std::thread([this]() {
+			for (int k = 0; k < world; ++k) {     /* every rank says hello with an empty DONE-typed header carrying its rank in `b` = ~0 */
+				const int fd = accept(lfd, 0, 0);
+				rk_hdr_t h; std::vector<uint8_t> pl;
+				if (fd < 0 || !rk_recv(fd, h, pl) || h.rank >= (uint32_t)world || cfd[h.rank] >= 0) { fprintf(stderr, "[samblaster] rank mode: a client did not introduce itself\n"); std::lock_guard<std::mutex> l(mu); failed = 1; cv.notify_all(); return; }
+				cfd[h.rank] = fd;
+			}
+			for (int r = 0; r < world; ++r) readers.emplace_back([this, r]() {
+				for (;;) {
+					rk_hdr_t h; std::vector<uint8_t> pl;
+					if (!rk_recv(cfd[(size_t)r], h, pl)) { std::lock_guard<std::mutex> l(mu); if (!done[(size_t)r]) failed = 1; cv.notify_all(); return; }
+					std::lock_guard<std::mutex> l(mu);
+					if (h.type == RK_ENDS) { ends_t e; e.rank = r; e.p.swap(pl); ends[h.b] = std::move(e); }
+					else if (h.type == RK_SIDE) side[h.b].swap(pl);
+					else if (h.type == RK_DONE) { done[(size_t)r] = 1; cv.notify_all(); return; }
+					cv.notify_all();
+				}
+			});
+			uint64_t next_dup = 0, next_side = 0; std::vector<uint8_t> dup;
+			for (;;) {
+				ends_t e; std::vector<uint8_t> sd; int what = 0;
+				{	std::unique_lock<std::mutex> l(mu);
+					cv.wait(l, [&] { bool all = true; for (char d : done) all = all && d; return failed || ends.count(next_dup) || side.count(next_side) || all; });
+					if (failed) break;
+					if (ends.count(next_dup)) { e = std::move(ends[next_dup]); ends.erase(next_dup); what = 1; }
+					else if (side.count(next_side)) { sd.swap(side[next_side]); side.erase(next_side); what = 2; }
+					else { if (!ends.empty() || !side.empty()) { fprintf(stderr, "[samblaster] rank mode: a batch is missing\n"); failed = 1; } break; }
+				}
+				if (what == 1) {
+					const long n = (long)(e.p.size() / (2 * sizeof(ssg_sbl_end_t)));
+					dup.assign((size_t)n, 0);
+					if (n && ssg_sbl_markdup_stream(st, n, (const ssg_sbl_end_t*)e.p.data(), dup.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); std::lock_guard<std::mutex> l(mu); failed = 1; break; }
+					if (!rk_send(cfd[(size_t)e.rank], RK_DUP, 0, next_dup, dup.data(), dup.size())) { std::lock_guard<std::mutex> l(mu); failed = 1; break; }
+					++next_dup;
+				} else {   /* payload: u64 bytes of splitter text, then the two texts */
+					uint64_t ns = 0; if (sd.size() >= 8) memcpy(&ns, sd.data(), 8);
+					if (sd.size() < 8 || ns > sd.size() - 8) { std::lock_guard<std::mutex> l(mu); failed = 1; break; }
+					if (spl && ns) spl->put((const char*)sd.data() + 8, (size_t)ns);
+					if (disc && sd.size() - 8 - ns) disc->put((const char*)sd.data() + 8 + ns, sd.size() - 8 - (size_t)ns);
+					++next_side;
+				}
+			}
+			if (failed) for (int fd : cfd) if (fd >= 0) shutdown(fd, SHUT_RDWR);   /* waiting clients get an error instead of silence */
+		});
+		return true;
+	}
+	int finish()
+	{
+		if (decider.joinable()) decider.join();
+		for (std::thread &t : readers) if (t.joinable()) t.join();
+		for (int fd : cfd) if (fd >= 0) close(fd);
+		if (lfd >= 0) close(lfd);
+		return failed;
+	}
+};
+
 static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *splf, FILE *discf, const char *pg)
 {
+	const int world = rk_world(), rank = rk_rank();
+	if (!rk_check("samblaster")) return 1;
 	ssg_sbl_state_t *st = ssg_sbl_state_new();
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
 	int threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
 	{ const char *e = getenv("SSG_SBL_THREADS"); if (e && atoi(e) > 0) threads = atoi(e); }
+	std::unique_ptr<sbl_server_t> srv; int cfd = -1; std::mutex c_mu;   /* rank mode: the server (rank 0) and this rank's connection to it */
+	if (world > 1) {
+		const std::string sock = rk_dir() + "/sbl.sock";
+		if (rank == 0) { srv.reset(new sbl_server_t(world, st, spl, disc)); if (!srv->start(sock)) return 1; }
+		cfd = rk_connect(sock);
+		if (cfd < 0 || !rk_send(cfd, 0, rank, 0, 0, 0)) { fprintf(stderr, "[samblaster] rank mode: cannot reach rank 0's samblaster\n"); return 1; }
+	}
+	uint64_t n_batch = 0;                                     /* BATCH frames seen: frame k of this rank is batch rank + k * world of the input */
 	if (!fu_write_full(1, FU_MAGIC, 8)) { perror("[samblaster] write"); return 1; }
 	bool got_header = false, ended = false;
 	/* frames are read by a thread of their own so that the next batch arrives while this one is decided and written */
@@ -152,7 +237,7 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	 * table makes that stage sequential by nature); a second thread rebuilds the records, writes the main frame and the side streams of the
 	 * batch before, in order.  (One thread doing both was 3.6 s of work per 8 M pairs on the MI355X box, as much as `bwa mem` needed for them.) */
 	struct work_t {
-		std::unique_ptr<frame_t> F; fu_batch_t bh; const fu_cand_t *cand; const char *text; const uint8_t *bam; size_t nr, n_blocks;
+		std::unique_ptr<frame_t> F; fu_batch_t bh; const fu_cand_t *cand; const char *text; const uint8_t *bam; size_t nr, n_blocks; uint64_t b;
 		std::vector<uint64_t> rec_off; std::vector<ssg_sbl_line_t> lines; std::vector<uint8_t> newblk, bits; std::vector<int64_t> blk_off, mate;
 	};
 	std::vector<std::pair<const char*, uint32_t> > ltext;
@@ -275,17 +360,24 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 				}
 			});
 			for (int t = 0; t < TS; ++t) { n_pairs += c_pairs[(size_t)t]; n_dups += c_dups[(size_t)t]; }
+			out_t mem_spl(-1), mem_disc(-1);                      /* rank mode: the batch's lines are collected and sent to rank 0, which writes every rank's in batch order */
+			out_t *const spl_w = world > 1 ? &mem_spl : spl, *const disc_w = world > 1 ? &mem_disc : disc;
 			for (int t = 0; t < TS && !rc; ++t) for (const sideblk_t &k : found[(size_t)t]) {
 				const bool dup = k.dup; const int64_t d1 = k.d1, d2 = k.d2; const size_t b = (size_t)k.b;
 				if (disc && d1 >= 0 && d2 >= 0) {
-					for (int64_t i : { d1, d2 }) if (!side(*disc, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), dup, 0)) { fprintf(stderr, "[samblaster] fused stream: a discordant line came without its text\n"); rc = 1; }
+					for (int64_t i : { d1, d2 }) if (!side(*disc_w, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), dup, 0)) { fprintf(stderr, "[samblaster] fused stream: a discordant line came without its text\n"); rc = 1; }
 					++n_disc;
 				}
 				if (spl && k.split) for (int64_t i = blk_off[b]; i < blk_off[b + 1]; ++i) if (bits[(size_t)i] & SSG_SBL_SPLIT) {
-					if (!side(*spl, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), true, (lines[(size_t)i].flag & 0x40) ? "_1" : "_2")) { fprintf(stderr, "[samblaster] fused stream: a splitter line came without its text\n"); rc = 1; }
+					if (!side(*spl_w, (size_t)i, lines[(size_t)i].flag | (dup ? 0x400 : 0), true, (lines[(size_t)i].flag & 0x40) ? "_1" : "_2")) { fprintf(stderr, "[samblaster] fused stream: a splitter line came without its text\n"); rc = 1; }
 					++n_spl;
 				}
 				if (rc) break;
+			}
+			if (world > 1 && !rc) {
+				const uint64_t ns = (uint64_t)mem_spl.n;
+				std::lock_guard<std::mutex> l(c_mu);
+				if (!rk_send(cfd, RK_SIDE, rank, W->b, &ns, 8, mem_spl.b.data(), mem_spl.n, mem_disc.b.data(), mem_disc.n)) { fprintf(stderr, "[samblaster] rank mode: rank 0's samblaster is gone\n"); rc = 1; }
 			}
 			if (F->b.mapped) F->b.reset();                           /* the segment's pages go back to the system now */
 			{ std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 3) pool.push_back(std::move(F)); }
@@ -314,6 +406,8 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 		const char *text = W->text = (const char*)(cand + bh.n_cand);
 		const uint8_t *bam = W->bam = (const uint8_t*)text + bh.text_bytes;
 		const size_t nr = W->nr = (size_t)bh.n_rec;
+		W->b = (uint64_t)rank + n_batch++ * (uint64_t)world;
+		if (!nr && world > 1) { fprintf(stderr, "[samblaster] rank mode: an empty batch\n"); rc = 1; break; }
 		if (!nr) { std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 4) pool.push_back(std::move(F)); continue; }
 		std::vector<uint64_t> &rec_off = W->rec_off; std::vector<ssg_sbl_line_t> &lines = W->lines; std::vector<uint8_t> &newblk = W->newblk, &bits = W->bits; std::vector<int64_t> &blk_off = W->blk_off, &mate = W->mate;
 		double t0 = now();
@@ -343,7 +437,15 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 		for (size_t i = 0; i < nr; ++i) if (newblk[i]) blk_off.push_back((int64_t)i);
 		const size_t n_blocks = blk_off.size(); blk_off.push_back((int64_t)nr);
 		tm[1] += now() - t0; t0 = now();
-		if (ssg_sbl_process(st, &o, (long)n_blocks, blk_off.data(), lines.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); rc = 1; break; }
+		if (world == 1) { if (ssg_sbl_process(st, &o, (long)n_blocks, blk_off.data(), lines.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); rc = 1; break; } }
+		else {   /* the ends of the blocks' primaries to the owner of the duplicate set, its verdicts back, then the lines' bits */
+			std::vector<ssg_sbl_end_t> ends(2 * n_blocks); rk_hdr_t rh; std::vector<uint8_t> dup;
+			bool ok = ssg_sbl_ends((long)n_blocks, blk_off.data(), lines.data(), ends.data()) == 0;
+			if (ok) { std::lock_guard<std::mutex> l(c_mu); ok = rk_send(cfd, RK_ENDS, rank, W->b, ends.data(), ends.size() * sizeof(ssg_sbl_end_t)); }
+			ok = ok && rk_recv(cfd, rh, dup) && rh.type == RK_DUP && rh.b == W->b && dup.size() == n_blocks;
+			if (!ok || ssg_sbl_classify(&o, (long)n_blocks, blk_off.data(), lines.data(), dup.data(), bits.data(), mate.data())) {
+				fprintf(stderr, "[samblaster] rank mode: batch %llu was not decided (%s)\n", (unsigned long long)W->b, ok ? ssg_last_error() : "rank 0's samblaster is gone"); rc = 1; break; }
+		}
 		tm[2] += now() - t0;
 		W->n_blocks = n_blocks; W->F = std::move(F);
 		to_b.push(std::move(W));
@@ -357,6 +459,11 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	if (!rc && (rd_fail || !ended)) { fprintf(stderr, "[samblaster] the fused stream ended early\n"); rc = 1; }
 	if (!rc && !got_header) { if (spl) spl->put(pg, strlen(pg)); if (disc) disc->put(pg, strlen(pg)); }
 	if (!rc && !fu_write_frame(1, FU_END, 0, 0)) rc = 1;
+	if (world > 1) {
+		{ std::lock_guard<std::mutex> l(c_mu); if (cfd >= 0) (void)rk_send(cfd, RK_DONE, rank, 0, 0, 0); }
+		if (srv && srv->finish()) { fprintf(stderr, "[samblaster] rank mode: the exchange between the ranks failed\n"); rc = 1; }
+		if (cfd >= 0) close(cfd);
+	}
 	if (spl) { spl->flush(); fclose(splf); }
 	if (disc) { disc->flush(); fclose(discf); }
 	ssg_sbl_state_free(st);
