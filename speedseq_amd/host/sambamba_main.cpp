@@ -18,6 +18,7 @@
 #include "bamio.h"
 #include "fastq.h"   /* chan_t */
 #include "fused.h"
+#include "ranks.h"
 #include <atomic>
 #include <mutex>
 #include <condition_variable>
@@ -153,15 +154,15 @@ static void change_so(std::string &text, const char *so)
  * copied or re-allocated while the input streams in; a record is (chunk << 40 | offset of its block_size word) */
 struct rec_store_t {
 	std::vector<fu_buf_t> chunk; std::vector<size_t> chunk_len;        /* heap memory, or the mapped segment a fused frame arrived in (fused.h) */
-	std::vector<uint64_t> loc, key; uint64_t bytes;
+	std::vector<uint64_t> loc, key, ord; uint64_t bytes;      /* ord (rank mode only): input ordinal of a record over all ranks, (batch << 28 | index in the batch) */
 	rec_store_t() : bytes(0) {}
 	const uint8_t *rec(size_t i) const { return chunk[(size_t)(loc[i] >> 40)].p + (loc[i] & (((uint64_t)1 << 40) - 1)); }
-	void clear() { chunk.clear(); chunk_len.clear(); loc.clear(); key.clear(); bytes = 0; }
+	void clear() { chunk.clear(); chunk_len.clear(); loc.clear(); key.clear(); ord.clear(); bytes = 0; }
 	/* index the whole records of chunk c[0..len) */
-	bool add_chunk(fu_buf_t c, size_t len)
+	bool add_chunk(fu_buf_t c, size_t len, uint64_t ord_base = ~(uint64_t)0)
 	{
-		const uint64_t id = chunk.size(); const uint8_t *p = c.p; size_t o = 0;
-		while (o + 4 <= len) { uint32_t bs; memcpy(&bs, p + o, 4); if (o + 4 + (size_t)bs > len || bs < 32) return false; loc.push_back(id << 40 | (uint64_t)o); key.push_back(bam_sort_key(p + o + 4)); o += 4 + (size_t)bs; }
+		const uint64_t id = chunk.size(); const uint8_t *p = c.p; size_t o = 0; uint64_t k = 0;
+		while (o + 4 <= len) { uint32_t bs; memcpy(&bs, p + o, 4); if (o + 4 + (size_t)bs > len || bs < 32) return false; loc.push_back(id << 40 | (uint64_t)o); key.push_back(bam_sort_key(p + o + 4)); if (ord_base != ~(uint64_t)0) ord.push_back(ord_base + k++); o += 4 + (size_t)bs; }
 		if (o != len) return false;
 		chunk.push_back(std::move(c)); chunk_len.push_back(len); bytes += len;
 		return true;
@@ -208,8 +209,9 @@ struct seg_out_t {
 	uint64_t coff;                                     /* file offset of the next block */
 	std::unique_ptr<bai_t> idx; bool idx_ok;
 	bool no_index;                                     /* the output cannot be sought: no index */
+	uint64_t hdr_end;                                  /* file offset of the first block after the header */
 	bool pending; int32_t p_tid, p_pos, p_end; bool p_mapped;   /* the last record of the previous stretch: its entry closes at the first record of the next */
-	seg_out_t() : first(true), last(false), coff(0), idx_ok(true), no_index(false), pending(false), p_tid(0), p_pos(0), p_end(0), p_mapped(false) {}
+	seg_out_t() : first(true), last(false), coff(0), idx_ok(true), no_index(false), hdr_end(0), pending(false), p_tid(0), p_pos(0), p_end(0), p_mapped(false) {}
 };
 static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads, const char *bai_path = 0,
                          const std::vector<size_t> *force_at = 0, std::vector<uint64_t> *force_off = 0, seg_out_t *seg = 0, std::vector<uint64_t> *force_uoff = 0)
@@ -219,6 +221,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	off_t hdr_end = force_at ? (off_t)0 : !opens ? (off_t)seg->coff : (bai_path || seg) ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
 	if (hdr_end < 0) { bai_path = 0; if (seg) { seg->no_index = true; hdr_end = 0; } }   /* a pipe: no offsets, no index (the file offsets kept in *seg then only count from the first record) */
 	if (seg && seg->no_index) bai_path = 0;
+	if (seg && opens) seg->hdr_end = (uint64_t)hdr_end;
 	const bool want_off = bai_path || force_at || seg;
 	const size_t n = perm.size();
 	const int lvl = level < 0 ? 6 : level;
@@ -432,7 +435,7 @@ static void kway_merge(std::vector<merge_src_t> &src, bgzf_out_t &out)
  * over whole runs -- a single thread moving every record -- but an independent small merge per range, run by the pool, each inflating
  * only its own byte range of every run and compressing its own stretch of the output; a writer puts the stretches out in order.  Ties
  * keep input order: equal keys share a range, and within a range the earlier run wins. */
-struct run_t { std::string path; int fd; std::vector<uint64_t> seg, useg; };   /* seg[g] .. seg[g + 1]: the run's records of range g in the file; useg: the same in record bytes */
+struct run_t { std::string path; int fd; std::vector<uint64_t> seg, useg, rcnt; int ord_fd; run_t() : fd(-1), ord_fd(-1) {} };   /* rcnt / ord_fd (rank mode): records before each range; the run's ordinals, 8 bytes a record */   /* seg[g] .. seg[g + 1]: the run's records of range g in the file; useg: the same in record bytes */
 
 static void make_ranges(const bam_hdr_t &h, size_t G, std::vector<uint64_t> &lo)
 {	/* lo[g] = smallest sort key of range g (equal shares of the genome's length); reads without a position sort last: the last range */
@@ -457,7 +460,7 @@ static void make_ranges(const bam_hdr_t &h, size_t G, std::vector<uint64_t> &lo)
 static void load_stretch(std::vector<run_t> &runs, size_t g0, size_t g1, int threads, rec_store_t &S)
 {
 	S.clear();
-	struct piece_t { size_t chunk; uint64_t a, b; std::vector<uint64_t> loc, key; };
+	struct piece_t { size_t chunk, run, g; uint64_t a, b; std::vector<uint64_t> loc, key; };
 	std::vector<piece_t> pieces;
 	for (size_t r = 0; r < runs.size(); ++r) {
 		const run_t &R = runs[r];
@@ -497,7 +500,7 @@ static void load_stretch(std::vector<run_t> &runs, size_t g0, size_t g1, int thr
 			inflateEnd(&zs);
 		});
 		const size_t id = S.chunk.size();
-		for (size_t g = g0; g < g1; ++g) if (R.useg[g + 1] > R.useg[g]) { piece_t P; P.chunk = id; P.a = R.useg[g] - u0; P.b = R.useg[g + 1] - u0; pieces.push_back(std::move(P)); }
+		for (size_t g = g0; g < g1; ++g) if (R.useg[g + 1] > R.useg[g]) { piece_t P; P.chunk = id; P.run = r; P.g = g; P.a = R.useg[g] - u0; P.b = R.useg[g + 1] - u0; pieces.push_back(std::move(P)); }
 		S.chunk.push_back(std::move(buf)); S.chunk_len.push_back((size_t)uo); S.bytes += uo;
 	}
 	std::atomic<int> bad(0);
@@ -513,20 +516,49 @@ static void load_stretch(std::vector<run_t> &runs, size_t g0, size_t g1, int thr
 	if (n >= 0xfffffff0u) die("sort: a stretch of the merge holds too many records (raise -m)");
 	S.loc.resize(n); S.key.resize(n);
 	{ std::vector<size_t> at(pieces.size() + 1, 0); for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].loc.size();
+	  const bool with_ord = !runs.empty() && runs[0].ord_fd >= 0;   /* rank mode: the records' input ordinals, from the runs' side files */
+	  if (with_ord) S.ord.resize(n);
 	  parallel_for((int)std::min<size_t>((size_t)std::max(1, threads), pieces.size()), pieces.size(), [&](size_t a, size_t b, int) {
-		for (size_t k = a; k < b; ++k) { if (pieces[k].loc.empty()) continue; memcpy(&S.loc[at[k]], pieces[k].loc.data(), 8 * pieces[k].loc.size()); memcpy(&S.key[at[k]], pieces[k].key.data(), 8 * pieces[k].key.size()); } }); }
+		for (size_t k = a; k < b; ++k) {
+			const piece_t &P = pieces[k];
+			if (P.loc.empty()) continue;
+			memcpy(&S.loc[at[k]], P.loc.data(), 8 * P.loc.size()); memcpy(&S.key[at[k]], P.key.data(), 8 * P.key.size());
+			if (with_ord) {
+				const run_t &R = runs[P.run];
+				if (R.rcnt[P.g + 1] - R.rcnt[P.g] != P.loc.size()) { bad = 1; continue; }
+				uint8_t *d = (uint8_t*)&S.ord[at[k]]; const size_t want = 8 * P.loc.size();
+				for (size_t got = 0; got < want; ) { const ssize_t q = pread(R.ord_fd, d + got, want - got, (off_t)(8 * R.rcnt[P.g] + got)); if (q < 0 && errno == EINTR) continue; if (q <= 0) { bad = 1; break; } got += (size_t)q; }
+			}
+		} }); }
+	if (bad) die("sort: a sorted run's ordinals are damaged");
 }
 
-static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, int fd, int level, int threads, uint64_t budget, const char *bai_path)
+/* order of a stretch's records: by key, equal keys by input ordinal when there are ordinals (rank mode: runs of several ranks hold records of
+ * interleaved batches), else by position in the store (stable sort: earlier run first) */
+static void stretch_perm(const rec_store_t &S, std::vector<uint32_t> &perm)
 {
-	std::vector<size_t> cutg(1, 0);
+	if (S.ord.empty()) { gpu_perm(S, perm); return; }
+	const size_t n = S.key.size();
+	std::vector<uint32_t> p1(n), p2(n); std::vector<uint64_t> k1(n);
+	if (ssg_sort_u64_perm(S.ord.data(), (int64_t)n, p1.data())) die(std::string("sort: ") + ssg_last_error());
+	for (size_t i = 0; i < n; ++i) k1[i] = S.key[p1[i]];
+	if (ssg_sort_u64_perm(k1.data(), (int64_t)n, p2.data())) die(std::string("sort: ") + ssg_last_error());
+	perm.resize(n);
+	for (size_t i = 0; i < n; ++i) perm[i] = p1[p2[i]];
+}
+
+/* g_lo .. g_hi: the ranges this call writes (all of them, or this rank's share in rank mode); seg_ret: where the header ended (rank mode's parts) */
+static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, int fd, int level, int threads, uint64_t budget, const char *bai_path, size_t g_lo = 0, size_t g_hi = (size_t)-1, uint64_t *hdr_end_ret = 0)
+{
+	if (g_hi == (size_t)-1) g_hi = G;
+	std::vector<size_t> cutg(1, g_lo);
 	{	const uint64_t target = std::max<uint64_t>(budget / 3, 1); uint64_t acc = 0;
-		for (size_t g = 0; g < G; ++g) {
+		for (size_t g = g_lo; g < g_hi; ++g) {
 			uint64_t sz = 0; for (const run_t &R : runs) sz += R.useg[g + 1] - R.useg[g];
 			if (acc && acc + sz > target) { cutg.push_back(g); acc = 0; }
 			acc += sz;
 		}
-		cutg.push_back(G);
+		cutg.push_back(g_hi);
 	}
 	const size_t ns = cutg.size() - 1;
 	chan_t<std::unique_ptr<rec_store_t> > ch(1);
@@ -540,10 +572,11 @@ static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, i
 		{ const double t0 = wall(); if (!ch.pop(S)) die("sort: the merge lost a stretch"); t_wait += wall() - t0; }
 		seg.first = k == 0; seg.last = k + 1 == ns;
 		std::vector<uint32_t> perm;
-		{ const double t0 = wall(); gpu_perm(*S, perm); t_perm += wall() - t0; }
+		{ const double t0 = wall(); stretch_perm(*S, perm); t_perm += wall() - t0; }
 		{ const double t0 = wall(); write_sorted(*S, perm, h, fd, level, threads, bai_path, 0, 0, &seg); t_write += wall() - t0; }
 	}
 	loader.join();
+	if (hdr_end_ret) *hdr_end_ret = seg.hdr_end;
 	if (dbg()) fprintf(stderr, "[sambamba] sort: merge: %zu stretches of the genome; waited %.2f s for the loader (read + inflate + index of the runs), device sort of the keys %.2f s, gather + deflate + write %.2f s\n", ns, t_wait, t_perm, t_write);
 }
 
@@ -571,6 +604,12 @@ static int cmd_sort(int argc, char **argv)
 	char first[8]; size_t n_first = 0;
 	while (n_first < 8) { ssize_t r = read(fd, first + n_first, 8 - n_first); if (r < 0) { if (errno == EINTR) continue; die("sort: read error"); } if (r == 0) break; n_first += (size_t)r; }
 	const bool fused = n_first == 8 && !memcmp(first, FU_MAGIC, 8);
+	/* Rank mode (ranks.h): this sort holds the records of its rank's batches; all ranks' sorts exchange sorted runs through SSG_RDV and each
+	 * writes the stretch of the genome it owns, as a BAM of its own that bin/speedseq-ranks joins to the others.  Only the main stream (frames)
+	 * is exchanged: the side streams were brought to rank 0 by the samblasters already. */
+	const int world = fused ? rk_world() : 1, rank = rk_rank();
+	if (world > 1 && !rk_check("sambamba")) return 1;
+	const std::string rdv = rk_dir();
 	uint64_t budget = (uint64_t)(std::max(mem_gb, 0.25) * 0.6 * 1073741824.0);   /* record bytes per in-memory run; the rest is keys, locations, output blocks */
 	{ const char *e = getenv("SSG_SORT_CHUNK_BYTES"); if (e && atoll(e) > 0) budget = (uint64_t)atoll(e); }   /* the tests force the spill-and-merge path */
 	rec_store_t S; std::vector<std::string> spills; bam_hdr_t h;
@@ -582,7 +621,7 @@ static int cmd_sort(int argc, char **argv)
 	auto spill = [&]() {
 		std::vector<uint32_t> perm; gpu_perm(S, perm);
 		if (runs.empty()) {   /* the ranges of the genome, fixed now: about 4 MB of a run each, so that one range of all runs is a small merge */
-			size_t G = (size_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, S.bytes >> 22));
+			size_t G = world > 1 ? 1024 : (size_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, S.bytes >> 22));   /* rank mode: the same ranges on every rank */
 			{ const char *e = getenv("SSG_SORT_RANGES"); if (e && atol(e) > 0) G = (size_t)atol(e); }
 			make_ranges(h, G, range_lo);
 		}
@@ -594,9 +633,24 @@ static int cmd_sort(int argc, char **argv)
 			at[g] = a;
 		}
 		char nm[64]; snprintf(nm, sizeof(nm), "/ssg_sort_%d_%04zu.run", (int)getpid(), runs.size());
-		run_t R; R.path = tmpdir + nm;
+		if (world > 1) snprintf(nm, sizeof(nm), "/run.%d.%zu.run", rank, runs.size());
+		run_t R; R.path = (world > 1 ? rdv : tmpdir) + nm;
 		R.fd = open(R.path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644); if (R.fd < 0) die("sort: cannot write " + R.path);
+		if (world > 1) {   /* equal keys keep their input order over all ranks: by ordinal within the run (the exchange sorts by it across runs) */
+			std::vector<uint32_t> p1(n), p2(n); std::vector<uint64_t> k1(n);
+			if (n && ssg_sort_u64_perm(S.ord.data(), (int64_t)n, p1.data())) die(std::string("sort: ") + ssg_last_error());
+			for (size_t i = 0; i < n; ++i) k1[i] = S.key[p1[i]];
+			if (n && ssg_sort_u64_perm(k1.data(), (int64_t)n, p2.data())) die(std::string("sort: ") + ssg_last_error());
+			for (size_t i = 0; i < n; ++i) perm[i] = p1[p2[i]];
+		}
 		write_sorted(S, perm, h, R.fd, 1, pool, 0, &at, &R.seg, 0, &R.useg);
+		if (world > 1) {   /* what the other ranks need of this run: segment offsets, record counts, ordinals in run order */
+			std::vector<uint64_t> idx; idx.push_back((uint64_t)G);
+			idx.insert(idx.end(), R.seg.begin(), R.seg.end()); idx.insert(idx.end(), R.useg.begin(), R.useg.end());
+			for (size_t g = 0; g <= G; ++g) idx.push_back((uint64_t)at[g]);
+			std::vector<uint64_t> od(n); for (size_t i = 0; i < n; ++i) od[i] = S.ord[perm[i]];
+			if (!rk_file_put(R.path + ".ord", od.data(), 8 * n) || !rk_file_put(R.path + ".idx", idx.data(), 8 * idx.size())) die("sort: cannot write into " + rdv);
+		}
 		runs.push_back(R); spills.push_back(R.path); S.clear();
 	};
 	if (fused) {
@@ -614,14 +668,15 @@ static int cmd_sort(int argc, char **argv)
 			}
 			ch.close();
 		});
-		std::unique_ptr<frame_t> F; bool ended = false; double t_wait = 0, t_index = 0; const char *bad = 0;
+		std::unique_ptr<frame_t> F; bool ended = false; double t_wait = 0, t_index = 0; const char *bad = 0; uint64_t n_main = 0;   /* MAIN frames so far: frame k of rank r holds batch r + k * world */
 		for (;;) {
 			{ const double t0 = wall(); const bool got = ch.pop(F); t_wait += wall() - t0; if (!got) break; }
 			if (F->fh.type == FU_END) { ended = true; break; }
 			if (F->fh.type == FU_HEADER) { h.text.assign((const char*)F->p.p, (size_t)F->fh.len); hdr_from_text(h); change_so(h.text, "coordinate"); continue; }
 			if (F->fh.type != FU_MAIN) { bad = "sort: unexpected frame in the fused stream"; break; }
-			if (!F->fh.len) continue;
-			{ const double t0 = wall(); if (!S.add_chunk(std::move(F->p), (size_t)F->fh.len)) { bad = "sort: malformed record frame"; break; } t_index += wall() - t0; }
+			if (!F->fh.len) { ++n_main; continue; }
+			{ const double t0 = wall(); if (!S.add_chunk(std::move(F->p), (size_t)F->fh.len, world > 1 ? ((uint64_t)rank + n_main * (uint64_t)world) << 28 : ~(uint64_t)0)) { bad = "sort: malformed record frame"; break; } t_index += wall() - t0; }
+			++n_main;
 			if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill();
 		}
 		if (dbg()) fprintf(stderr, "[sambamba] sort: input thread waited %.2f s for frames, indexed records for %.2f s\n", t_wait, t_index);
@@ -655,6 +710,42 @@ static int cmd_sort(int argc, char **argv)
 	const double t_in = wall();
 	bool bai_note = false;
 	int ofd = open(outp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + outp);
+	if (world > 1) {
+		/* every record of this rank goes into exchange runs (the last one now); then all ranks' runs are opened and this rank merges its share of the ranges */
+		if (!S.key.empty() || runs.empty()) spill();
+		const double t_x = wall();
+		{ const uint64_t nr = runs.size(); if (!rk_file_put(rdv + "/sorted." + std::to_string(rank), &nr, 8)) die("sort: cannot write into " + rdv); }
+		std::vector<run_t> all; size_t G = range_lo.size();
+		for (int r = 0; r < world; ++r) {
+			const std::string dn = rdv + "/sorted." + std::to_string(r); std::vector<uint8_t> b;
+			if (!rk_file_wait(dn) || !rk_file_get(dn, b) || b.size() != 8) die("sort: rank " + std::to_string(r) + " did not deliver its runs");
+			uint64_t nr; memcpy(&nr, b.data(), 8);
+			for (uint64_t k = 0; k < nr; ++k) {
+				run_t R; R.path = rdv + "/run." + std::to_string(r) + "." + std::to_string(k) + ".run";
+				std::vector<uint8_t> ib;
+				if (!rk_file_get(R.path + ".idx", ib) || ib.size() < 8) die("sort: cannot read " + R.path + ".idx");
+				uint64_t g; memcpy(&g, ib.data(), 8);
+				if (g != G || ib.size() != 8 * (1 + 3 * (g + 1))) die("sort: the ranks disagree about the ranges of the genome (different headers?)");
+				const uint64_t *q = (const uint64_t*)(ib.data() + 8);
+				R.seg.assign(q, q + g + 1); R.useg.assign(q + g + 1, q + 2 * (g + 1)); R.rcnt.assign(q + 2 * (g + 1), q + 3 * (g + 1));
+				R.fd = open(R.path.c_str(), O_RDONLY); R.ord_fd = open((R.path + ".ord").c_str(), O_RDONLY);
+				if (R.fd < 0 || R.ord_fd < 0) die("sort: cannot open " + R.path);
+				all.push_back(R);
+			}
+		}
+		const size_t g_lo = G * (size_t)rank / (size_t)world, g_hi = G * ((size_t)rank + 1) / (size_t)world;
+		uint64_t hdr_end = 0;
+		merge_runs(all, G, h, ofd, level, pool, budget, 0, g_lo, g_hi, &hdr_end);
+		close(ofd);
+		{ char t[64]; snprintf(t, sizeof(t), "%llu\n", (unsigned long long)hdr_end); if (!rk_file_put(outp + ".ssg_part", t, strlen(t))) die("sort: cannot write " + outp + ".ssg_part"); }
+		/* the runs may go when every rank has read what it needed of them */
+		if (!rk_file_put(rdv + "/merged." + std::to_string(rank), "", 0)) die("sort: cannot write into " + rdv);
+		for (int r = 0; r < world; ++r) if (!rk_file_wait(rdv + "/merged." + std::to_string(r))) die("sort: rank " + std::to_string(r) + " did not finish its merge");
+		for (run_t &R : all) { close(R.fd); close(R.ord_fd); }
+		for (run_t &R : runs) { close(R.fd); unlink(R.path.c_str()); unlink((R.path + ".ord").c_str()); unlink((R.path + ".idx").c_str()); }
+		if (dbg()) fprintf(stderr, "[sambamba] sort: rank %d of %d: input %.2f s (from start), %zu run(s) of its own, ranges %zu .. %zu of %zu from %zu runs of all ranks: %.2f s\n", rank, world, t_in - t_start, runs.size(), g_lo, g_hi, G, all.size(), wall() - t_x);
+		return 0;
+	}
 	if (spills.empty()) {
 		std::vector<uint32_t> perm; gpu_perm(S, perm);
 		const double t_perm = wall();

@@ -1,0 +1,76 @@
+"""Rank mode (bin/speedseq-ranks, speedseq_amd/host/ranks.h): N pipelines of the reference's unmodified script side by side -- one per GPU on a
+multi-GPU node, here N processes on the host emulation -- must end in the SAME three sorted BAMs as one pipeline: upstream's batches dealt
+round-robin (insert-size models unchanged), ONE duplicate set asked in batch order, side-stream lines leaving rank 0 in batch order, equal sort
+keys in input order across ranks, every rank writing one stretch of the genome."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import simreads
+from common import EXAMPLE_FA, ROOT
+from test_speedseq_script import REF_SCRIPT, SAMTOOLS, EMU, _need_tools, _view
+from test_sambamba import _parse_bai
+
+RG = "@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1"
+
+
+def _setup(d, config_extra):
+    os.makedirs(d)
+    bindir = os.path.join(d, "bin")
+    os.makedirs(bindir)
+    for name in ("bwa", "samblaster"):
+        with open(os.path.join(bindir, name), "w") as f:
+            f.write("#!/bin/sh\nexec %s \"$@\"\n" % os.path.join(EMU, name + "_emu"))
+        os.chmod(os.path.join(bindir, name), 0o755)
+    os.symlink(shutil.which("mawk"), os.path.join(bindir, "gawk"))
+    cfg = os.path.join(d, "speedseq.config")
+    with open(cfg, "w") as f:
+        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\nexport SSG_FUSED=1\n%s" % (bindir, bindir, os.path.join(EMU, "sambamba_emu"), ROOT, config_extra))
+    ref = os.path.join(d, "ref.fa")
+    shutil.copy(EXAMPLE_FA, ref)
+    for ext in ("amb", "ann", "bwt", "pac", "sa"):
+        shutil.copy(EXAMPLE_FA + "." + ext, ref + "." + ext)
+    return cfg, ref, dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]), SSG_BWA_CHUNK_BASES="40000", SSG_RANKS_KEEP_DEVICES="1", SSG_RDV_TIMEOUT="120")
+
+
+def _records(bam):
+    """the records' bytes in file order (the header aside): equal keys must be in the same order too"""
+    import gzip
+    import struct
+    raw = gzip.open(bam, "rb").read()
+    l_text, = struct.unpack_from("<i", raw, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, o)
+    o += 4
+    for _ in range(n_ref):
+        l, = struct.unpack_from("<i", raw, o)
+        o += 4 + l + 4
+    return raw[o:]
+
+
+@pytest.mark.parametrize("world,extra", [(2, ""), (3, "export SSG_SORT_CHUNK_BYTES=300000\n")], ids=["two_ranks", "three_ranks_spilling"])
+def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra):
+    _need_tools()
+    fq = str(tmp_path / "reads.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 2500, seed=13))
+    cfg, ref, env = _setup(str(tmp_path / "one"), "")
+    one = str(tmp_path / "one" / "out")
+    r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", one, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq], cwd=str(tmp_path / "one"), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cfg, ref, env = _setup(str(tmp_path / "many"), extra)
+    many = str(tmp_path / "many" / "out")
+    r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(world), "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", many, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq],
+                       cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
+        assert _view(many + suffix) == _view(one + suffix), suffix
+        assert _records(many + suffix) == _records(one + suffix), suffix
+        assert os.path.exists(many + suffix + ".bai")
+    os.rename(many + ".bam.bai", many + ".mine.bai")
+    subprocess.run([SAMTOOLS, "index", many + ".bam"], check=True)
+    assert _parse_bai(many + ".mine.bai") == _parse_bai(many + ".bam.bai")
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", "-f", "1024", many + ".bam"])) > 50
+    left = [f for f in os.listdir(str(tmp_path / "many")) if ".rank" in f]
+    assert left == [], left
