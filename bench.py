@@ -279,7 +279,7 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe, b=None):
     return res
 
 
-def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, sort_mem_gb=40, config_extra="", env_extra=None, limit_s=300):
+def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, sambamba, sort_mem_gb=40, config_extra="", env_extra=None, limit_s=300, ranks=0):
     """SURVEY.md 8d's own definition of the metric: the reference's `speedseq align` (the script itself, unmodified -- the fixture copy
     tests/golden/speedseq_ref_script.sh, or /root/reference/bin/speedseq where that exists) on the executables speedseq.config names,
     wall clock from FASTQ open to the three coordinate-sorted, indexed BAMs closed.  The index files are already next to `ref_prefix`.
@@ -312,7 +312,8 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
     env.update(env_extra or {})
     import signal
     t = time.perf_counter()
-    p = subprocess.Popen(["bash", script, "align", "-K", cfg, "-o", out, "-M", str(sort_mem_gb), "-t", str(threads), "-p",
+    launcher = [os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(ranks), "--script", script, "--"] if ranks > 1 else ["bash", script]   # rank mode: N pipelines side by side (speedseq_amd/host/ranks.h)
+    p = subprocess.Popen(launcher + ["align", "-K", cfg, "-o", out, "-M", str(sort_mem_gb), "-t", str(threads), "-p",
                           "-R", "@RG\\tID:bench\\tSM:bench\\tLB:lib1", ref_prefix, fq], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
         so, se = p.communicate(timeout=limit_s)
@@ -868,6 +869,15 @@ def main():
                     r["what"] = "`speedseq align -t %d -p` (reference script, unmodified; SSG_FUSED=1) with bin/bwa mem driving %d devices: whole upstream batches per device, no collective; FASTQ -> three sorted BAMs + BAI, index load on every device included" % (a.script_threads, world)
                     out["literal_multi"] = r
                     log('script on %d devices: %s pairs in %s s' % (world, r.get('pairs'), r.get('wall_s')))
+                    # ... and as `world` pipelines side by side, one per device (bin/speedseq-ranks): the same three BAMs, every stage N times
+                    cfg_r = "export SSG_FUSED=1\nexport SSG_BWA_DEVICES=1\nexport SSG_SORT_LOG=1\nexport SSG_SBL_LOG=1\n"
+                    r = script_leg(td, "ranks", prefix, fq, n_ml, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=max(8, 40 // world), config_extra=cfg_r, limit_s=180, ranks=world,
+                                   env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if emu else None)
+                    r.pop("out", None)
+                    r["devices"] = world
+                    r["what"] = "bin/speedseq-ranks -n %d: the reference's script (unmodified) once per device, `bwa mem` aligning the upstream batches of its rank, ONE duplicate set and both side streams in rank 0's samblaster, the sorts exchanging sorted runs and writing a stretch of the genome each; FASTQ -> the same three sorted BAMs + BAI" % world
+                    out["literal_ranks"] = r
+                    log('script as %d ranks: %s pairs in %s s' % (world, r.get('pairs'), r.get('wall_s')))
             except Exception as e:
                 out["literal_multi"] = {"error": repr(e)[:400]}
         if saved_stdout is not None:

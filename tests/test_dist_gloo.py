@@ -148,3 +148,6 @@ def test_bench_two_rank_flow_on_the_emulation(emu_lib, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "range exchange" in d["config"]["sorted_merge"]
     m = d["literal_multi"]                              # rank 0 also runs the reference's script with bin/bwa on both (emulated) devices
     assert m.get("devices") == 2 and m.get("pairs_per_s", 0) > 0 and m.get("bai_written") is True, m
+    k = d["literal_ranks"]                              # ... and as two pipelines side by side (bin/speedseq-ranks)
+    assert k.get("devices") == 2 and k.get("pairs_per_s", 0) > 0 and k.get("bai_written") is True, k
+    assert abs(k["bam_bytes"][".bam"] - m["bam_bytes"][".bam"]) < 0.02 * m["bam_bytes"][".bam"]   # the same records (tests/test_ranks.py compares them), BGZF blocks cut at the ranks' stretches
