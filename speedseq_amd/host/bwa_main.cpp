@@ -162,6 +162,7 @@ static int main_mem(int argc, char **argv)
 	if (interleaved && fp2) { fprintf(stderr, "[W::main_mem] when '-p' is in use, the second query file is ignored.\n"); gzclose(fp2); fp2 = 0; }
 	const bool se = !interleaved && !fp2;   /* upstream main_mem: MEM_F_PE is set by -p or by a second file; without it every read is aligned on its own */
 	if (se && world > 1) { fprintf(stderr, "[bwa] rank mode is for paired-end input\n"); return 1; }
+	if (world > 1 && !fused) { fprintf(stderr, "[bwa] rank mode needs the fused hand-off: `export SSG_FUSED=1` in speedseq.config (and no -C)\n"); return 1; }
 	if (se) fused = false;                  /* samblaster has nothing to do with unpaired reads: SAM text */
 	{ const char *e = getenv("SSG_BWA_CHUNK_BASES"); if (e && atoi(e) > 0) opt.chunk_size = atoi(e); }   /* tests: upstream's 10 M bases per thread make a batch of 33 k pairs */
 	const int64_t chunk = fixed_chunk > 0 ? fixed_chunk : (int64_t)opt.chunk_size * opt.n_threads;   /* -K: batches that do not depend on -t */

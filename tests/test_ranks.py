@@ -50,16 +50,18 @@ def _records(bam):
     return raw[o:]
 
 
-@pytest.mark.parametrize("world,extra", [(2, ""), (3, "export SSG_SORT_CHUNK_BYTES=300000\n")], ids=["two_ranks", "three_ranks_spilling"])
-def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra):
+@pytest.mark.parametrize("world,extra,chunk", [(2, "", "40000"), (3, "export SSG_SORT_CHUNK_BYTES=300000\n", "40000"), (4, "", "150000")], ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches"])
+def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chunk):
     _need_tools()
     fq = str(tmp_path / "reads.fq")
     simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 2500, seed=13))
     cfg, ref, env = _setup(str(tmp_path / "one"), "")
+    env["SSG_BWA_CHUNK_BASES"] = chunk                  # x -t 2: 267 or 1000 pairs per upstream batch (the last case: fewer batches than ranks)
     one = str(tmp_path / "one" / "out")
     r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", one, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq], cwd=str(tmp_path / "one"), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     cfg, ref, env = _setup(str(tmp_path / "many"), extra)
+    env["SSG_BWA_CHUNK_BASES"] = chunk
     many = str(tmp_path / "many" / "out")
     r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(world), "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", many, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq],
                        cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=900)
@@ -74,3 +76,16 @@ def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra):
     assert int(subprocess.check_output([SAMTOOLS, "view", "-c", "-f", "1024", many + ".bam"])) > 50
     left = [f for f in os.listdir(str(tmp_path / "many")) if ".rank" in f]
     assert left == [], left
+
+
+def test_ranks_need_the_fused_hand_off(tmp_path, emu_lib):
+    """without `export SSG_FUSED=1` the stages cannot carry batch ordinals: `bwa mem` says so and the launcher reports the failed rank"""
+    _need_tools()
+    fq = str(tmp_path / "reads.fq")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 200, seed=14))
+    cfg, ref, env = _setup(str(tmp_path / "many"), "")
+    text = open(cfg).read().replace("export SSG_FUSED=1\n", "")
+    open(cfg, "w").write(text)
+    r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", "2", "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", str(tmp_path / "many" / "out"), "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq],
+                       cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "rank mode needs the fused hand-off" in r.stderr and "failed" in r.stderr
