@@ -775,6 +775,10 @@ static int cmd_index(int argc, char **argv)
 	const char *in = 0; int threads = hw_threads();
 	for (int i = 0; i < argc; ++i) { if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]); else if (argv[i][0] != '-') { if (!in) in = argv[i]; } }
 	if (!in) die("usage: sambamba index <in.bam>");
+	if (rk_world() > 1) {   /* rank mode: a rank's stretch of the sorted file is not what gets indexed -- bin/speedseq-ranks indexes the joined file */
+		struct stat sb;
+		if (stat((std::string(in) + ".ssg_part").c_str(), &sb) == 0) { if (dbg()) fprintf(stderr, "[sambamba] index: %s is one rank's part of a sorted file: left to the join\n", in); return 0; }
+	}
 	{	/* the sort of this repository left the index of exactly this file next to it: nothing to do (the note goes, the pair stays) */
 		const std::string note_p = std::string(in) + ".bai.ssg";
 		FILE *f = fopen(note_p.c_str(), "r");
