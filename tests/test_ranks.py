@@ -16,18 +16,19 @@ from test_sambamba import _parse_bai
 RG = "@RG\\tID:NA12878\\tSM:NA12878\\tLB:lib1"
 
 
-def _setup(d, config_extra):
+def _setup(d, config_extra, exe=None):
+    exe = exe or (lambda name: os.path.join(EMU, name + "_emu"))
     os.makedirs(d)
     bindir = os.path.join(d, "bin")
     os.makedirs(bindir)
     for name in ("bwa", "samblaster"):
         with open(os.path.join(bindir, name), "w") as f:
-            f.write("#!/bin/sh\nexec %s \"$@\"\n" % os.path.join(EMU, name + "_emu"))
+            f.write("#!/bin/sh\nexec %s \"$@\"\n" % exe(name))
         os.chmod(os.path.join(bindir, name), 0o755)
     os.symlink(shutil.which("mawk"), os.path.join(bindir, "gawk"))
     cfg = os.path.join(d, "speedseq.config")
     with open(cfg, "w") as f:
-        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\nexport SSG_FUSED=1\n%s" % (bindir, bindir, os.path.join(EMU, "sambamba_emu"), ROOT, config_extra))
+        f.write("BWA=%s/bwa\nSAMBLASTER=%s/samblaster\nSAMBAMBA=%s\nPARALLEL=%s/bin/parallel\nexport SSG_FUSED=1\n%s" % (bindir, bindir, exe("sambamba"), ROOT, config_extra))
     ref = os.path.join(d, "ref.fa")
     shutil.copy(EXAMPLE_FA, ref)
     for ext in ("amb", "ann", "bwt", "pac", "sa"):
@@ -52,15 +53,25 @@ def _records(bam):
 
 @pytest.mark.parametrize("world,extra,chunk", [(2, "", "40000"), (3, "export SSG_SORT_CHUNK_BYTES=300000\n", "40000"), (4, "", "150000")], ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches"])
 def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chunk):
+    _ranks_equal_one(tmp_path, world, extra, chunk, None, 2500)
+
+
+@pytest.mark.gpu
+def test_ranks_gpu_two_pipelines_on_the_one_device(tmp_path, gpu_lib):
+    """the same on the MI355X: two pipelines side by side, both on the one GPU of the test box (SSG_RANKS_KEEP_DEVICES=1)"""
+    _ranks_equal_one(tmp_path, 2, "", "300000", lambda name: os.path.join(ROOT, "bin", name), 6000)
+
+
+def _ranks_equal_one(tmp_path, world, extra, chunk, exe, n_pairs):
     _need_tools()
     fq = str(tmp_path / "reads.fq")
-    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 2500, seed=13))
-    cfg, ref, env = _setup(str(tmp_path / "one"), "")
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=13))
+    cfg, ref, env = _setup(str(tmp_path / "one"), "", exe)
     env["SSG_BWA_CHUNK_BASES"] = chunk                  # x -t 2: 267 or 1000 pairs per upstream batch (the last case: fewer batches than ranks)
     one = str(tmp_path / "one" / "out")
     r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", one, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq], cwd=str(tmp_path / "one"), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    cfg, ref, env = _setup(str(tmp_path / "many"), extra)
+    cfg, ref, env = _setup(str(tmp_path / "many"), extra, exe)
     env["SSG_BWA_CHUNK_BASES"] = chunk
     many = str(tmp_path / "many" / "out")
     r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(world), "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", many, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq],
