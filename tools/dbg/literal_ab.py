@@ -2,7 +2,7 @@
 """A/B of the literal metric (FASTQ -> three sorted BAMs + BAI through the reference's unmodified script, fused hand-off, one GPU) under several
 host-side settings: one reference, one index, one FASTQ, then the script once per configuration.  No verification of the BAMs (tools/soak.py does
 that); the first configuration runs twice (the first run warms the page cache).
-usage: literal_ab.py [--pairs N] CONFIG...      CONFIG = name[:t=THREADS][:VAR=value...]   e.g.  quota:t=16:SSG_SORT_THREADS=24:SSG_FMT_THREADS=12"""
+usage: literal_ab.py [--pairs N] CONFIG...      CONFIG = name[:t=THREADS][:ranks=N][:VAR=value...]   e.g.  quota:t=16:SSG_SORT_THREADS=24:SSG_FMT_THREADS=12"""
 import argparse
 import json
 import os
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=8000000)
     ap.add_argument("--ref-mbp", type=float, default=3100.0)
     ap.add_argument("--mem", type=int, default=64)
+    ap.add_argument("--no-warmup", action="store_true")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "literal_ab.json"))
     ap.add_argument("configs", nargs="+")
     a = ap.parse_args()
@@ -51,17 +52,19 @@ def main():
     bench.log("index + FASTQ of %d pairs ready; host cpu quota: %s, os.cpu_count: %s" % (a.pairs, bench.host_cpu_quota(), os.cpu_count()))
     b = lambda n: os.path.join(ROOT, "bin", n)
     results = []
-    for k, cfg in enumerate([a.configs[0]] + a.configs):
+    for k, cfg in enumerate(([a.configs[0]] if not a.no_warmup else []) + a.configs):
         parts = cfg.split(":")
-        threads, env = 32, {}
+        threads, env, ranks = 32, {}, 0
         for p in parts[1:]:
             key, _, val = p.partition("=")
             if key == "t":
                 threads = int(val)
+            elif key == "ranks":
+                ranks = int(val)
             else:
                 env[key] = val
         extra = "export SSG_FUSED=1\nexport SSG_SORT_LOG=1\n" + "".join("export %s=%s\n" % kv for kv in env.items())
-        r = bench.script_leg(td, "ab%d" % k, prefix, fq, a.pairs, threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=extra, limit_s=400)
+        r = bench.script_leg(td, "ab%d" % k, prefix, fq, a.pairs, threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=extra, limit_s=400, ranks=ranks, env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if ranks > 1 else None)
         for x in (".bam", ".splitters.bam", ".discordants.bam"):
             for y in ("", ".bai"):
                 try:
@@ -69,7 +72,7 @@ def main():
                 except OSError:
                     pass
         keep = [l[:260] for l in r.get("stage_log", []) if "[bwa]" in l or "records" in l or "merge" in l]
-        res = {"config": cfg + (" (warm-up)" if k == 0 else ""), "wall_s": r.get("wall_s"), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "stage_log": keep}
+        res = {"config": cfg + (" (warm-up)" if k == 0 and not a.no_warmup else ""), "wall_s": r.get("wall_s"), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "stage_log": keep}
         results.append(res)
         bench.log(json.dumps({k2: v for k2, v in res.items() if k2 != "stage_log"}))
         for l in keep:
