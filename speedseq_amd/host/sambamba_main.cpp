@@ -210,8 +210,9 @@ struct seg_out_t {
 	std::unique_ptr<bai_t> idx; bool idx_ok;
 	bool no_index;                                     /* the output cannot be sought: no index */
 	uint64_t hdr_end;                                  /* file offset of the first block after the header */
+	int ent_fd;                                        /* >= 0 (rank mode): every record's index entry + virtual offset in this file goes here, 24 bytes each (cmd_index_parts) */
 	bool pending; int32_t p_tid, p_pos, p_end; bool p_mapped;   /* the last record of the previous stretch: its entry closes at the first record of the next */
-	seg_out_t() : first(true), last(false), coff(0), idx_ok(true), no_index(false), hdr_end(0), pending(false), p_tid(0), p_pos(0), p_end(0), p_mapped(false) {}
+	seg_out_t() : first(true), last(false), coff(0), idx_ok(true), no_index(false), hdr_end(0), ent_fd(-1), pending(false), p_tid(0), p_pos(0), p_end(0), p_mapped(false) {}
 };
 static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm, const bam_hdr_t &h, int fd, int level, int threads, const char *bai_path = 0,
                          const std::vector<size_t> *force_at = 0, std::vector<uint64_t> *force_off = 0, seg_out_t *seg = 0, std::vector<uint64_t> *force_uoff = 0)
@@ -347,8 +348,9 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets), built by a thread of
 	 * its own that follows the writer: a record's virtual offset is known as soon as the group holding its block has its file offset */
 	struct ent_t { int32_t tid, pos, end; uint8_t mapped; };
-	std::vector<ent_t> ent(bai_path ? n : 0);
-	if (bai_path) parallel_for((int)std::min<size_t>((size_t)threads, n / 65536 + 1), n, [&](size_t a, size_t b, int) {
+	const bool want_ent = bai_path || (seg && seg->ent_fd >= 0);
+	std::vector<ent_t> ent(want_ent ? n : 0);
+	if (want_ent) parallel_for((int)std::min<size_t>((size_t)threads, n / 65536 + 1), n, [&](size_t a, size_t b, int) {
 		for (size_t i = a; i < b; ++i) { const uint8_t *r = S.rec(perm[i]) + 4; bam_core_t c; memcpy(&c, r, 32); ent[i].tid = c.tid; ent[i].pos = c.pos; ent[i].end = bam_endpos(r); ent[i].mapped = !((c.flag_nc >> 16) & 4); }
 	});
 	std::atomic<size_t> blocks_placed(0);                       /* blk_coff[0 .. blocks_placed) are final */
@@ -403,6 +405,16 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	                   us_gather / 1e6 / std::max(1, n_workers + n_prod), us_deflate / 1e6 / std::max(1, n_workers + n_prod), us_window / 1e6 / std::max(1, n_workers + n_prod));
 	if (dbg() && use_dev && !seg) fprintf(stderr, "[sambamba] sort: write: blocks deflated on %d device(s) (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_devs, n_prod);
 	if (seg) seg->coff = coff;
+	if (seg && seg->ent_fd >= 0 && n) {   /* rank mode: what the index of the joined file needs of this stretch */
+		std::vector<uint8_t> eb(24 * n); size_t bk = 0;
+		for (size_t i = 0; i < n; ++i) {
+			while (cut[bk + 1] <= cum[i]) ++bk;
+			const uint64_t v = blk_coff[bk] << 16 | (cum[i] - cut[bk]);
+			uint8_t *d = eb.data() + 24 * i; const uint32_t m = ent[i].mapped;
+			memcpy(d, &ent[i].tid, 4); memcpy(d + 4, &ent[i].pos, 4); memcpy(d + 8, &ent[i].end, 4); memcpy(d + 12, &m, 4); memcpy(d + 16, &v, 8);
+		}
+		io_write_all(seg->ent_fd, eb.data(), eb.size());
+	}
 	if (!bai_path) return;
 	blk_coff[nb] = coff;
 	if (closes) { file_end_v.store((coff + 28) << 16); blocks_placed.store(nb + 1, std::memory_order_release); }
@@ -548,7 +560,7 @@ static void stretch_perm(const rec_store_t &S, std::vector<uint32_t> &perm)
 }
 
 /* g_lo .. g_hi: the ranges this call writes (all of them, or this rank's share in rank mode); seg_ret: where the header ended (rank mode's parts) */
-static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, int fd, int level, int threads, uint64_t budget, const char *bai_path, size_t g_lo = 0, size_t g_hi = (size_t)-1, uint64_t *hdr_end_ret = 0)
+static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, int fd, int level, int threads, uint64_t budget, const char *bai_path, size_t g_lo = 0, size_t g_hi = (size_t)-1, uint64_t *hdr_end_ret = 0, const char *ent_path = 0)
 {
 	if (g_hi == (size_t)-1) g_hi = G;
 	std::vector<size_t> cutg(1, g_lo);
@@ -567,6 +579,7 @@ static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, i
 		ch.close();
 	});
 	seg_out_t seg; double t_wait = 0, t_perm = 0, t_write = 0;
+	if (ent_path) { seg.ent_fd = open(ent_path, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (seg.ent_fd < 0) die(std::string("sort: cannot write ") + ent_path); }
 	for (size_t k = 0; k < ns; ++k) {
 		std::unique_ptr<rec_store_t> S;
 		{ const double t0 = wall(); if (!ch.pop(S)) die("sort: the merge lost a stretch"); t_wait += wall() - t0; }
@@ -576,6 +589,7 @@ static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, i
 		{ const double t0 = wall(); write_sorted(*S, perm, h, fd, level, threads, bai_path, 0, 0, &seg); t_write += wall() - t0; }
 	}
 	loader.join();
+	if (seg.ent_fd >= 0) close(seg.ent_fd);
 	if (hdr_end_ret) *hdr_end_ret = seg.hdr_end;
 	if (dbg()) fprintf(stderr, "[sambamba] sort: merge: %zu stretches of the genome; waited %.2f s for the loader (read + inflate + index of the runs), device sort of the keys %.2f s, gather + deflate + write %.2f s\n", ns, t_wait, t_perm, t_write);
 }
@@ -735,7 +749,7 @@ static int cmd_sort(int argc, char **argv)
 		}
 		const size_t g_lo = G * (size_t)rank / (size_t)world, g_hi = G * ((size_t)rank + 1) / (size_t)world;
 		uint64_t hdr_end = 0;
-		merge_runs(all, G, h, ofd, level, pool, budget, 0, g_lo, g_hi, &hdr_end);
+		merge_runs(all, G, h, ofd, level, pool, budget, 0, g_lo, g_hi, &hdr_end, (outp + ".ssg_ent").c_str());
 		close(ofd);
 		{ char t[64]; snprintf(t, sizeof(t), "%llu\n", (unsigned long long)hdr_end); if (!rk_file_put(outp + ".ssg_part", t, strlen(t))) die("sort: cannot write " + outp + ".ssg_part"); }
 		/* the runs may go when every rank has read what it needed of them */
@@ -812,6 +826,44 @@ static int cmd_index(int argc, char **argv)
 	return 0;
 }
 
+/* index of a file joined from the parts that the ranks of bin/speedseq-ranks wrote (ranks.h): every rank left, for each record of its part, the
+ * fields an index entry is made of and the record's virtual offset in the part; `shift` moves a part's offsets to where its blocks lie in the
+ * joined file.  The same bai_t calls in the same order as cmd_index makes from the file itself -- without inflating it again. */
+static int cmd_index_parts(int argc, char **argv)
+{
+	if (argc < 3 || (argc - 1) % 2) die("usage: sambamba index-parts <joined.bam> <part.ssg_ent> <shift> [...]");
+	const char *in = argv[0];
+	const int fd = open_in(in);
+	bgzf_in_t bi(fd, 2); bam_hdr_t h;
+	if (!hdr_read(bi, h)) die("index-parts: not a BAM file");
+	const uint64_t first = bi.tell();
+	struct stat sb; if (fstat(fd, &sb) != 0) die("index-parts: cannot stat the file");
+	const uint64_t eof_v = (uint64_t)sb.st_size << 16;
+	bai_t idx((int)h.names.size(), first);
+	bool have = false; int32_t e_tid = 0, e_pos = 0, e_end = 0; uint32_t e_m = 0;
+	std::vector<uint8_t> buf((size_t)24 << 16);
+	for (int a = 1; a + 1 < argc; a += 2) {
+		const long long shift = atoll(argv[a + 1]);
+		FILE *f = fopen(argv[a], "rb"); if (!f) die(std::string("index-parts: cannot read ") + argv[a]);
+		for (;;) {
+			const size_t k = fread(buf.data(), 24, buf.size() / 24, f);
+			if (!k) break;
+			for (size_t i = 0; i < k; ++i) {
+				const uint8_t *d = buf.data() + 24 * i; uint64_t v; memcpy(&v, d + 16, 8);
+				v = (uint64_t)((long long)(v >> 16) + shift) << 16 | (v & 0xffff);
+				if (have && idx.push(e_tid, e_pos, e_end, v, e_m != 0) < 0) die("index-parts: the parts are not in coordinate order");
+				memcpy(&e_tid, d, 4); memcpy(&e_pos, d + 4, 4); memcpy(&e_end, d + 8, 4); memcpy(&e_m, d + 12, 4); have = true;
+			}
+		}
+		fclose(f);
+	}
+	if (have && idx.push(e_tid, e_pos, e_end, eof_v, e_m != 0) < 0) die("index-parts: the parts are not in coordinate order");
+	idx.finish(eof_v);
+	idx.save((std::string(in) + ".bai").c_str());
+	close(fd);
+	return 0;
+}
+
 /* ---------------- merge ---------------- */
 static int cmd_merge(int argc, char **argv)
 {
@@ -853,6 +905,7 @@ int main(int argc, char **argv)
 	if (!strcmp(argv[1], "sort")) return cmd_sort(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "index")) return cmd_index(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "merge")) return cmd_merge(argc - 2, argv + 2);
+	if (!strcmp(argv[1], "index-parts")) return cmd_index_parts(argc - 2, argv + 2);
 	fprintf(stderr, "[sambamba] unsupported sub-command %s\n", argv[1]);
 	return 2;
 }
