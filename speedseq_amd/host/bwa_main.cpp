@@ -28,6 +28,7 @@
 #include <condition_variable>
 #include "fastq.h"
 #include "fused.h"
+#include "ranksplit.h"
 #include "../../include/ssgpu.h"
 
 #include <time.h>
@@ -176,13 +177,25 @@ static int main_mem(int argc, char **argv)
 	/* the readers (inflate + parse) start now: the first batches are parsed while the index travels to the device(s); several devices
 	 * take proportionally more parse threads on plain files (one thread parses about what one MI355X aligns) */
 	const int parse_hint = n_dev > 1 ? std::min(48, (fp2 ? 3 : 5) * n_dev) : 0;
-	fq_feed_t feed1(fp1, keep_comment, 16384, argv[ai + 1], parse_hint); std::unique_ptr<fq_feed_t> feed2(fp2 ? new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2], parse_hint) : 0);
+	/* rank mode on plain regular files (ranksplit.h): rank 0 scans the input for upstream's batches and publishes their byte ranges; every rank parses
+	 * the ranges of its batches only.  Compressed input, pipes, SSG_RANKS_SPLIT=0: every rank parses everything and keeps its batches. */
+	std::atomic<int> fail(0);
+	const bool split = world > 1 && !(getenv("SSG_RANKS_SPLIT") && !strcmp(getenv("SSG_RANKS_SPLIT"), "0")) && rs_plain_regular(argv[ai + 1]) && (!fp2 || rs_plain_regular(argv[ai + 2]));
+	std::shared_ptr<rs_table_t> rs_tab(split ? new rs_table_t(rk_dir()) : 0);
+	std::thread t_scan;
+	if (split && !rk_check("bwa")) return 1;
+	if (split && rank == 0) { const std::string f1 = argv[ai + 1], f2 = fp2 ? argv[ai + 2] : ""; const std::string rdv = rk_dir(); t_scan = std::thread([f1, f2, rdv, chunk, &fail]() { if (!rs_scan_and_publish(rdv, f1.c_str(), f2.empty() ? 0 : f2.c_str(), chunk)) fail = 1; }); }
+	struct scan_join_t { std::thread &t; ~scan_join_t() { if (t.joinable()) t.join(); } } scan_join = { t_scan };
+	std::unique_ptr<fq_feed_t> feed1_p(split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 1], false, rank, world, &fail), keep_comment, 16384, parse_hint)
+	                                         : new fq_feed_t(fp1, keep_comment, 16384, argv[ai + 1], parse_hint));
+	fq_feed_t &feed1 = *feed1_p;
+	std::unique_ptr<fq_feed_t> feed2(!fp2 ? 0 : split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 2], true, rank, world, &fail), keep_comment, 16384, parse_hint)
+	                                                  : new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2], parse_hint));
 	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
 	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms
 	 * per million pairs: a run does not know how long its input is, so each device makes the copy once it has aligned this many pairs
 	 * (the point where the walk has been paid for once over; 0 = at load time).  Results do not depend on it. */
 	long densify_after = 32000000; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
-	std::atomic<int> fail(0);
 	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
 	{
 		std::vector<std::thread> ld;
@@ -319,7 +332,12 @@ static int main_mem(int argc, char **argv)
 				if (B->n() > n0) { for (int p = n0 / 2; p < B->n() / 2; ++p) B->pair_batch.push_back(B->n_batches); ++B->n_batches; }
 			}
 			if (fail || B->n() == 0) break;
-			if (world > 1 && (bidx++ % world) != rank) { id0 += B->n() / 2; continue; }   /* another rank's batch: only its pairs are counted */
+			if (split) {   /* every batch of this stream is this rank's: its place in the input comes from the scanner's table */
+				rs_entry_t e; uint64_t first_pair = 0;
+				if (rs_tab->get((uint64_t)rank + (uint64_t)bidx * (uint64_t)world, &e, &first_pair) != 1 || e.pairs != (uint64_t)(B->n() / 2)) {
+					fprintf(stderr, "[bwa] rank mode: batch %lld of this rank is not what the scan of the input found (%d pairs parsed)\n", (long long)bidx, B->n() / 2); fail = 1; break; }
+				++bidx; B->id0 = (int64_t)first_pair;
+			} else if (world > 1 && (bidx++ % world) != rank) { id0 += B->n() / 2; continue; }   /* another rank's batch: only its pairs are counted */
 			B->gather(std::min(8, std::max(1, opt.n_threads)));
 			id0 += se ? B->n() : B->n() / 2; ++seqno;   /* pairs: the pair ordinal; single-end: upstream's n_processed */
 			tm_asm += wall() - t0;

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <thread>
+#include <functional>
 #include <memory>
 #include <string>
 #include <atomic>
@@ -207,6 +208,23 @@ struct fq_stream_t {                    /* kstream over gzread; for compressed i
 				if (n <= 0) break;
 				c->resize((size_t)n);
 				full.push(std::move(c));
+			}
+			full.close();
+		});
+	}
+	/* provider mode (rank mode, bwa_main.cpp): the bytes come from a function that fills a chunk at a time (false = the end) -- the byte ranges of
+	 * a plain file that hold this rank's batches; a thread of its own calls it, the parser takes the chunks as it takes a decoder's */
+	typedef std::function<bool(chunk_t&)> provider_t;
+	explicit fq_stream_t(provider_t prov) : fp(0), begin(0), end(0), is_eof(false), full(4), empty(8), threaded(true), bgzf(false), rfd(-1), roff(0), rend(0), mp(0), mn(0), mo(0), chain(0)
+	{
+		th = std::thread([this, prov]() {
+			while (!stop.load()) {
+				std::unique_ptr<chunk_t> c;
+				{ std::unique_lock<std::mutex> l(empty.mu); if (!empty.q.empty()) { c = std::move(empty.q.front()); empty.q.pop_front(); } }
+				if (!c) c.reset(new chunk_t());
+				c->clear();
+				if (!prov(*c)) break;
+				if (!c->empty()) full.push(std::move(c));
 			}
 			full.close();
 		});
@@ -544,6 +562,18 @@ struct fq_feed_t {
 				int T = threads_hint > 0 ? threads_hint : std::thread::hardware_concurrency() >= 32 ? 4 : 1;
 				{ const char *e = getenv("SSG_FASTQ_THREADS"); if (e) T = atoi(e); }
 				if (src.threaded && T > 1) parse_stream(src, keep_comment, per_block, T);
+				else { fq_reader_t rd((const unsigned char*)0, 0, &src, keep_comment); (void)drain(rd, per_block, [this](blk_t b) { ch.push(std::move(b)); }); }
+			}
+			ch.close();
+		});
+	}
+	fq_feed_t(fq_stream_t::provider_t prov, bool keep_comment, int per_block, int threads_hint = 0) : ch(4), pool(new fq_block_pool_t())
+	{
+		th = std::thread([this, prov, keep_comment, per_block, threads_hint]() {
+			{	fq_stream_t src(prov);
+				int T = threads_hint > 0 ? threads_hint : std::thread::hardware_concurrency() >= 32 ? 4 : 2;
+				{ const char *e = getenv("SSG_FASTQ_THREADS"); if (e) T = atoi(e); }
+				if (T > 1) parse_stream(src, keep_comment, per_block, T);
 				else { fq_reader_t rd((const unsigned char*)0, 0, &src, keep_comment); (void)drain(rd, per_block, [this](blk_t b) { ch.push(std::move(b)); }); }
 			}
 			ch.close();

@@ -100,3 +100,63 @@ def test_ranks_need_the_fused_hand_off(tmp_path, emu_lib):
     r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", "2", "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", str(tmp_path / "many" / "out"), "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq],
                        cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "rank mode needs the fused hand-off" in r.stderr and "failed" in r.stderr
+
+
+def _bwa_ranks(tmp_path, world, fqs, env_extra=None, expect_fail=False):
+    """`bwa mem` alone as `world` ranks (fused frames, as in rank mode): (return codes, stderr texts, the batches file of the run or None)"""
+    rdv = str(tmp_path / "rdv")
+    shutil.rmtree(rdv, ignore_errors=True)
+    os.makedirs(rdv)
+    env = dict(os.environ, SSG_FUSED="1", SSG_WORLD=str(world), SSG_RDV=rdv, SSG_RDV_TIMEOUT="60", SSG_BWA_CHUNK_BASES="40000", SSG_FUSED_SHM="0", **(env_extra or {}))
+    procs = [subprocess.Popen([os.path.join(EMU, "bwa_emu"), "mem", "-t", "2"] + ([] if len(fqs) == 2 else ["-p"]) + ["-R", RG, EXAMPLE_FA] + fqs, env=dict(env, SSG_RANK=str(r)),
+                              stdout=open(str(tmp_path / ("frames.%d" % r)), "wb"), stderr=subprocess.PIPE) for r in range(world)]
+    errs = [p.communicate()[1].decode() for p in procs]
+    b = os.path.join(rdv, "batches")
+    return [p.returncode for p in procs], errs, (open(b, "rb").read() if os.path.exists(b) else None)
+
+
+def test_ranks_read_only_their_share_of_plain_fastq(tmp_path, emu_lib):
+    """plain regular files: rank 0 scans the input for upstream's batches and publishes their byte ranges (SSG_RDV/batches), every rank parses the
+    ranges of its batches only; the frames are the same bytes as when every rank parses everything (SSG_RANKS_SPLIT=0, or compressed input)"""
+    import gzip
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 2000, seed=17)
+    one = str(tmp_path / "il.fq")
+    simreads.write_fastq(one, pairs)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    simreads.write_fastq(f1, pairs, interleaved=False, path2=f2)
+    gz = str(tmp_path / "il.fq.gz")
+    with open(one, "rb") as fi, gzip.open(gz, "wb", compresslevel=1) as fo:
+        fo.write(fi.read())
+    frames = {}
+    for tag, fqs, env in (("split", [one], {}), ("all", [one], {"SSG_RANKS_SPLIT": "0"}), ("gz", [gz], {}), ("two", [f1, f2], {}), ("two_all", [f1, f2], {"SSG_RANKS_SPLIT": "0"})):
+        rcs, errs, batches = _bwa_ranks(tmp_path, 3, fqs, env)
+        assert rcs == [0, 0, 0], errs
+        assert (batches is not None) == (tag in ("split", "two")), tag
+        if batches is not None:
+            assert len(batches) % 40 == 0 and len(batches) // 40 >= 6
+        frames[tag] = [open(str(tmp_path / ("frames.%d" % r)), "rb").read() for r in range(3)]
+    def body(fr):     # the frames without the header frame (its @PG line carries the command line)
+        out = []
+        for b in fr:
+            o = 8
+            import struct
+            t, z, l = struct.unpack_from("<IIQ", b, o)
+            assert t == 1
+            out.append(b[o + 16 + l:])
+        return out
+    assert body(frames["split"]) == body(frames["all"]) == body(frames["gz"])
+    assert body(frames["two"]) == body(frames["two_all"]) == body(frames["split"])
+
+
+def test_ranks_split_refuses_fastq_that_is_not_four_lines_a_record(tmp_path, emu_lib):
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 300, seed=18)
+    fq = str(tmp_path / "wrapped.fq")
+    with open(fq, "w") as f:
+        for name, a, b in pairs:
+            for s in (a, b):
+                t = "".join("ACGTN"[c] for c in s)
+                f.write("@%s\n%s\n%s\n+\n%s\n" % (name, t[:70], t[70:], "I" * len(t)))     # the sequence on two lines: kseq reads it, the scanner does not
+    rcs, errs, _ = _bwa_ranks(tmp_path, 2, [fq])
+    assert all(rc != 0 for rc in rcs) and "SSG_RANKS_SPLIT=0" in errs[0], errs
+    rcs, errs, _ = _bwa_ranks(tmp_path, 2, [fq], {"SSG_RANKS_SPLIT": "0"})
+    assert rcs == [0, 0], errs
