@@ -51,9 +51,11 @@ def _records(bam):
     return raw[o:]
 
 
-@pytest.mark.parametrize("world,extra,chunk", [(2, "", "40000"), (3, "export SSG_SORT_CHUNK_BYTES=300000\n", "40000"), (4, "", "150000")], ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches"])
-def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chunk):
-    _ranks_equal_one(tmp_path, world, extra, chunk, None, 2500)
+@pytest.mark.parametrize("world,extra,chunk,kw", [(2, "", "40000", {}), (3, "export SSG_SORT_CHUNK_BYTES=300000\n", "40000", {}), (4, "", "150000", {}),
+                                                  (2, "export SSG_RANKS_SPLIT=0\n", "60000", {"read_len": 250, "ins_mean": 800, "ins_std": 150})],
+                         ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches", "two_ranks_2x250_everyone_parses"])
+def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chunk, kw):
+    _ranks_equal_one(tmp_path, world, extra, chunk, None, 2500 if not kw else 1200, **kw)
 
 
 @pytest.mark.gpu
@@ -62,10 +64,10 @@ def test_ranks_gpu_two_pipelines_on_the_one_device(tmp_path, gpu_lib):
     _ranks_equal_one(tmp_path, 2, "", "300000", lambda name: os.path.join(ROOT, "bin", name), 6000)
 
 
-def _ranks_equal_one(tmp_path, world, extra, chunk, exe, n_pairs):
+def _ranks_equal_one(tmp_path, world, extra, chunk, exe, n_pairs, **kw):
     _need_tools()
     fq = str(tmp_path / "reads.fq")
-    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=13))
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=13, **kw))
     cfg, ref, env = _setup(str(tmp_path / "one"), "", exe)
     env["SSG_BWA_CHUNK_BASES"] = chunk                  # x -t 2: 267 or 1000 pairs per upstream batch (the last case: fewer batches than ranks)
     one = str(tmp_path / "one" / "out")
