@@ -204,7 +204,7 @@ static int main_mem(int argc, char **argv)
 		for (std::thread &x : ld) x.join();
 	}
 	t_warm.join();
-	if (fail) return 1;
+	if (fail) { rk_mark_failed("bwa"); return 1; }
 	ssg_index_t *idx = idxs[0];
 	const double t_loaded = wall();
 	/* header: upstream bwa_print_sam_hdr + @PG */
@@ -486,6 +486,7 @@ static int main_mem(int argc, char **argv)
 	feed1.th.join(); if (feed2) feed2->th.join();
 	gzclose(fp1); if (fp2) gzclose(fp2);
 	for (int g = 0; g < n_dev; ++g) { (void)ssg_set_device(g); ssg_index_destroy(idxs[(size_t)g]); }
+	if (fail) rk_mark_failed("bwa");
 	return fail ? 1 : 0;
 }
 

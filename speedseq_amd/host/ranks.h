@@ -21,6 +21,8 @@
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/un.h>
+#include <dirent.h>
+#include <fcntl.h>
 #include <string>
 #include <vector>
 
@@ -35,6 +37,22 @@ static inline bool rk_check(const char *who)
 }
 static inline double rk_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static inline double rk_timeout() { const char *e = getenv("SSG_RDV_TIMEOUT"); return e && atof(e) > 0 ? atof(e) : 86400.0; }   /* seconds a rank waits for another (tests set it low) */
+
+/* a stage that gives up in rank mode says so in the rendezvous directory: the reference's script does not stop when a stage of its pipeline
+ * fails, and the other ranks would wait for this one until their patience (SSG_RDV_TIMEOUT) ends */
+static inline void rk_mark_failed(const char *who)
+{
+	if (rk_world() == 1 || rk_dir().empty()) return;
+	const std::string p = rk_dir() + "/failed." + std::to_string(rk_rank()) + "." + who;
+	const int fd = open(p.c_str(), O_WRONLY | O_CREAT, 0644); if (fd >= 0) close(fd);
+}
+static inline bool rk_someone_failed()
+{
+	DIR *d = opendir(rk_dir().c_str()); if (!d) return false;
+	bool f = false;
+	while (struct dirent *e = readdir(d)) if (!strncmp(e->d_name, "failed.", 7)) { f = true; break; }
+	closedir(d); return f;
+}
 
 enum { RK_ENDS = 1, RK_DUP = 2, RK_SIDE = 3, RK_DONE = 4 };
 struct rk_hdr_t { uint32_t type, rank; uint64_t b, len; };
@@ -84,6 +102,7 @@ static inline int rk_connect(const std::string &path)
 		if (connect(fd, (sockaddr*)&a, sizeof(a)) == 0) return fd;
 		close(fd);
 		if (rk_now() - t0 > rk_timeout()) { fprintf(stderr, "[ranks] nobody listens at %s\n", path.c_str()); return -1; }
+		if (rk_someone_failed()) { fprintf(stderr, "[ranks] another rank's pipeline failed\n"); return -1; }
 		usleep(20000);
 	}
 }
@@ -91,7 +110,11 @@ static inline int rk_connect(const std::string &path)
 static inline bool rk_file_wait(const std::string &path)
 {
 	const double t0 = rk_now(); struct stat sb;
-	while (stat(path.c_str(), &sb) != 0) { if (rk_now() - t0 > rk_timeout()) { fprintf(stderr, "[ranks] %s did not appear\n", path.c_str()); return false; } usleep(20000); }
+	while (stat(path.c_str(), &sb) != 0) {
+		if (rk_now() - t0 > rk_timeout()) { fprintf(stderr, "[ranks] %s did not appear\n", path.c_str()); return false; }
+		if (rk_someone_failed()) { fprintf(stderr, "[ranks] another rank's pipeline failed\n"); return false; }
+		usleep(20000);
+	}
 	return true;
 }
 static inline bool rk_file_put(const std::string &path, const void *p, size_t n)

@@ -133,7 +133,7 @@ struct rs_table_t {
 			if (stat((rdv + "/batches.fail").c_str(), &sb) == 0) return -1;
 			std::vector<uint8_t> d;
 			if (stat((rdv + "/batches.done").c_str(), &sb) == 0 && rk_file_get(rdv + "/batches.done", d) && d.size() == 8) { memcpy(&total, d.data(), 8); done = true; continue; }   /* once more through the file: the last entries precede the marker */
-			if (rk_now() - t0 > rk_timeout()) return -1;
+			if (rk_now() - t0 > rk_timeout() || rk_someone_failed()) return -1;
 			usleep(5000);
 		}
 	}

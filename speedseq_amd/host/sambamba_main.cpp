@@ -28,7 +28,7 @@
 static double wall() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static bool dbg() { static int d = -1; if (d < 0) d = (getenv("SSG_DEBUG") || getenv("SSG_SORT_LOG")) ? 1 : 0; return d != 0; }
 static int hw_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)std::min(n, 32u) : 4; }
-static void die(const std::string &m) { fprintf(stderr, "[sambamba] %s\n", m.c_str()); exit(1); }
+static void die(const std::string &m) { fprintf(stderr, "[sambamba] %s\n", m.c_str()); rk_mark_failed("sambamba"); exit(1); }   /* rank mode: the other ranks must not wait for this one */
 static int open_in(const char *p) { if (!strcmp(p, "/dev/stdin") || !strcmp(p, "-")) return 0; int fd = open(p, O_RDONLY); if (fd < 0) die(std::string("cannot open ") + p); return fd; }
 
 /* ---------------- view ---------------- */

@@ -30,6 +30,7 @@
 #include "fastq.h"   /* chan_t */
 #include "fused.h"
 #include "ranks.h"
+#include <poll.h>
 #include <map>
 #include <condition_variable>
 
@@ -144,7 +145,12 @@ struct sbl_server_t {
 		if (lfd < 0) return false;
 		decider = std::thread([this]() {
 			for (int k = 0; k < world; ++k) {     /* every rank says hello with an empty DONE-typed header carrying its rank in `b` = ~0 */
-				const int fd = accept(lfd, 0, 0);
+				int fd = -1;
+				for (const double t0 = rk_now(); fd < 0; ) {   /* a rank whose pipeline died before its samblaster got here never connects */
+					struct pollfd pf; pf.fd = lfd; pf.events = POLLIN; pf.revents = 0;
+					if (poll(&pf, 1, 200) > 0) { fd = accept(lfd, 0, 0); break; }
+					if (rk_someone_failed() || rk_now() - t0 > rk_timeout()) break;
+				}
 				rk_hdr_t h; std::vector<uint8_t> pl;
 				if (fd < 0 || !rk_recv(fd, h, pl) || h.rank >= (uint32_t)world || cfd[h.rank] >= 0) { fprintf(stderr, "[samblaster] rank mode: a client did not introduce itself\n"); std::lock_guard<std::mutex> l(mu); failed = 1; cv.notify_all(); return; }
 				cfd[h.rank] = fd;
@@ -460,6 +466,7 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	if (!rc && !got_header) { if (spl) spl->put(pg, strlen(pg)); if (disc) disc->put(pg, strlen(pg)); }
 	if (!rc && !fu_write_frame(1, FU_END, 0, 0)) rc = 1;
 	if (world > 1) {
+		if (rc) rk_mark_failed("samblaster");
 		{ std::lock_guard<std::mutex> l(c_mu); if (cfd >= 0) (void)rk_send(cfd, RK_DONE, rank, 0, 0, 0); }
 		if (srv && srv->finish()) { fprintf(stderr, "[samblaster] rank mode: the exchange between the ranks failed\n"); rc = 1; }
 		if (cfd >= 0) close(cfd);

@@ -162,3 +162,23 @@ def test_ranks_split_refuses_fastq_that_is_not_four_lines_a_record(tmp_path, emu
     assert all(rc != 0 for rc in rcs) and "SSG_RANKS_SPLIT=0" in errs[0], errs
     rcs, errs, _ = _bwa_ranks(tmp_path, 2, [fq], {"SSG_RANKS_SPLIT": "0"})
     assert rcs == [0, 0], errs
+
+
+def test_ranks_stop_together_when_one_gives_up(tmp_path, emu_lib):
+    """the reference's script does not stop when a stage of its pipeline fails, and ranks wait for one another: a stage that gives up leaves a mark
+    in the rendezvous directory and every wait looks for one.  Here the scanner meets a wrapped record in the middle of the input, after all
+    ranks have started: the run ends at once, with the reason, instead of waiting for SSG_RDV_TIMEOUT"""
+    _need_tools()
+    pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 1500, seed=19)
+    fq = str(tmp_path / "half_wrapped.fq")
+    with open(fq, "w") as f:
+        for k, (name, a, b) in enumerate(pairs):
+            for s_ in (a, b):
+                t = "".join("ACGTN"[c] for c in s_)
+                f.write("@%s\n%s\n+\n%s\n" % (name, t if k < 750 else t[:70] + "\n" + t[70:], "I" * len(t)))
+    cfg, ref, env = _setup(str(tmp_path / "many"), "")
+    env["SSG_RDV_TIMEOUT"] = "600"
+    r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", "3", "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", str(tmp_path / "many" / "out"), "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq],
+                       cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "SSG_RANKS_SPLIT=0" in r.stderr
+    assert not os.path.exists(str(tmp_path / "many" / "out.bam"))
