@@ -170,8 +170,13 @@ struct sbl_server_t {
 			for (;;) {
 				ends_t e; std::vector<uint8_t> sd; int what = 0;
 				{	std::unique_lock<std::mutex> l(mu);
-					cv.wait(l, [&] { bool all = true; for (char d : done) all = all && d; return failed || ends.count(next_dup) || side.count(next_side) || all; });
+					/* also woken when the rank that owns the next batch has said it is done while later batches wait here (its pipeline lost one), and
+					 * twice a second to look for a rank that gave up elsewhere (ranks.h rk_mark_failed) */
+					auto ready = [&] { bool all = true; for (char d : done) all = all && d;
+						return failed || ends.count(next_dup) || side.count(next_side) || all || (done[(size_t)(next_dup % (uint64_t)world)] && !ends.empty()) || (done[(size_t)(next_side % (uint64_t)world)] && !side.empty()); };
+					while (!ready()) { cv.wait_for(l, std::chrono::milliseconds(500)); if (!ready() && rk_someone_failed()) { failed = 1; break; } }
 					if (failed) break;
+					if (!ends.count(next_dup) && !side.count(next_side)) { bool all = true; for (char d : done) all = all && d; if (!all || !ends.empty() || !side.empty()) { fprintf(stderr, "[samblaster] rank mode: a batch is missing\n"); failed = 1; break; } }
 					if (ends.count(next_dup)) { e = std::move(ends[next_dup]); ends.erase(next_dup); what = 1; }
 					else if (side.count(next_side)) { sd.swap(side[next_side]); side.erase(next_side); what = 2; }
 					else { if (!ends.empty() || !side.empty()) { fprintf(stderr, "[samblaster] rank mode: a batch is missing\n"); failed = 1; } break; }
