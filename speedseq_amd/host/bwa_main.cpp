@@ -178,18 +178,20 @@ static int main_mem(int argc, char **argv)
 	 * take proportionally more parse threads on plain files (one thread parses about what one MI355X aligns) */
 	const int parse_hint = n_dev > 1 ? std::min(48, (fp2 ? 3 : 5) * n_dev) : 0;
 	/* rank mode on plain regular files (ranksplit.h): rank 0 scans the input for upstream's batches and publishes their byte ranges; every rank parses
-	 * the ranges of its batches only.  Compressed input, pipes, SSG_RANKS_SPLIT=0: every rank parses everything and keeps its batches. */
+	 * the ranges of its batches only; compressed input is inflated and scanned by rank 0 alone and handed on batch by batch.  SSG_RANKS_SPLIT=0: every
+	 * rank reads and parses everything and keeps its batches. */
 	std::atomic<int> fail(0);
-	const bool split = world > 1 && !(getenv("SSG_RANKS_SPLIT") && !strcmp(getenv("SSG_RANKS_SPLIT"), "0")) && rs_plain_regular(argv[ai + 1]) && (!fp2 || rs_plain_regular(argv[ai + 2]));
+	const bool split = world > 1 && !(getenv("SSG_RANKS_SPLIT") && !strcmp(getenv("SSG_RANKS_SPLIT"), "0"));
+	const bool served = split && !(rs_plain_regular(argv[ai + 1]) && (!fp2 || rs_plain_regular(argv[ai + 2])));   /* compressed input: rank 0 inflates, scans and hands the batches on as files */
 	std::shared_ptr<rs_table_t> rs_tab(split ? new rs_table_t(rk_dir()) : 0);
 	std::thread t_scan;
 	if (split && !rk_check("bwa")) return 1;
-	if (split && rank == 0) { const std::string f1 = argv[ai + 1], f2 = fp2 ? argv[ai + 2] : ""; const std::string rdv = rk_dir(); t_scan = std::thread([f1, f2, rdv, chunk, &fail]() { if (!rs_scan_and_publish(rdv, f1.c_str(), f2.empty() ? 0 : f2.c_str(), chunk)) fail = 1; }); }
+	if (split && rank == 0) { const std::string f1 = argv[ai + 1], f2 = fp2 ? argv[ai + 2] : ""; const std::string rdv = rk_dir(); t_scan = std::thread([f1, f2, rdv, chunk, served, world, &fail]() { if (!rs_scan_and_publish(rdv, f1.c_str(), f2.empty() ? 0 : f2.c_str(), chunk, served, world)) fail = 1; }); }
 	struct scan_join_t { std::thread &t; ~scan_join_t() { if (t.joinable()) t.join(); } } scan_join = { t_scan };
-	std::unique_ptr<fq_feed_t> feed1_p(split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 1], false, rank, world, &fail), keep_comment, 16384, parse_hint)
+	std::unique_ptr<fq_feed_t> feed1_p(split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 1], false, rank, world, &fail, served), keep_comment, 16384, parse_hint)
 	                                         : new fq_feed_t(fp1, keep_comment, 16384, argv[ai + 1], parse_hint));
 	fq_feed_t &feed1 = *feed1_p;
-	std::unique_ptr<fq_feed_t> feed2(!fp2 ? 0 : split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 2], true, rank, world, &fail), keep_comment, 16384, parse_hint)
+	std::unique_ptr<fq_feed_t> feed2(!fp2 ? 0 : split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 2], true, rank, world, &fail, served), keep_comment, 16384, parse_hint)
 	                                                  : new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2], parse_hint));
 	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
 	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms

@@ -7,7 +7,8 @@
  * batches formed from the sequence lengths exactly as bseq_read forms them (bwa.c: a batch ends once its bases reach the chunk size, on an
  * even read count; interleaved or two files in step), one line of five numbers per batch appended to SSG_RDV/batches: pairs, and the byte range
  * of the batch in each file.  Every rank -- rank 0 too -- then parses only the ranges of its batches, handed to the parser as a stream
- * (fastq.h provider mode).  A batch cut out of the file is a batch to the rank's own bseq_read logic as well: each starts the base count
+ * (fastq.h provider mode).  Compressed input is inflated by rank 0 alone (one gzip stream has one reader however many want its bytes): the
+ * scanner runs behind fastq.h's decoder threads and hands every batch on as a file of its own in SSG_RDV.  A batch cut out of the file is a batch to the rank's own bseq_read logic as well: each starts the base count
  * afresh, so the boundaries it finds in its stream are the scanner's.
  */
 #ifndef SSG_RANKSPLIT_H
@@ -15,6 +16,7 @@
 #include "ranks.h"
 #include "fastq.h"
 #include <mutex>
+#include <functional>
 
 struct rs_entry_t { uint64_t pairs, a0, a1, b0, b1; };
 
@@ -27,34 +29,37 @@ static inline bool rs_plain_regular(const char *path)
 	close(fd); return plain;
 }
 
-/* one input file, read front to back in large pieces: the next four-line record's byte range and sequence length */
+/* one input, read front to back: the next four-line record's byte range (in bytes of the decoded input) and sequence length.  The bytes come from
+ * a sequential reader: pread over a plain file, or the decoder threads of fastq.h for compressed input */
 struct rs_scan_t {
-	int fd; size_t size, base, fill; std::vector<unsigned char> buf; size_t at;   /* buf[0 .. fill) = file bytes [base, base + fill); at = scan position in the file */
+	std::function<long(unsigned char*, size_t)> rd; bool eof_seen;
+	size_t base, fill; std::vector<unsigned char> buf; size_t at;   /* buf[0 .. fill) = input bytes [base, base + fill); at = scan position */
 	std::string why;
-	explicit rs_scan_t(const char *path) : fd(open(path, O_RDONLY)), size(0), base(0), fill(0), buf((size_t)16 << 20), at(0) { struct stat sb; if (fd >= 0 && fstat(fd, &sb) == 0) size = (size_t)sb.st_size; }
-	~rs_scan_t() { if (fd >= 0) close(fd); }
+	explicit rs_scan_t(std::function<long(unsigned char*, size_t)> r) : rd(r), eof_seen(false), base(0), fill(0), buf((size_t)16 << 20), at(0) {}
+	size_t lim() const { return eof_seen ? base + fill : (size_t)-1; }       /* the end of the input, once it has been seen */
+	const unsigned char *ptr(size_t off) const { return buf.data() + (off - base); }   /* valid for offsets >= the last record's start, until the next call */
 	bool more(size_t need_from)
 	{	/* keep [need_from, ...) and read on */
 		const size_t keep = base + fill - need_from;
 		if (keep == buf.size()) buf.resize(buf.size() * 2);
 		memmove(buf.data(), buf.data() + (need_from - base), keep); base = need_from; fill = keep;
-		while (base + fill < size) { const ssize_t r = pread(fd, buf.data() + fill, buf.size() - fill, (off_t)(base + fill)); if (r < 0 && errno == EINTR) continue; if (r <= 0) break; fill += (size_t)r; return true; }
-		return false;
+		if (eof_seen) return false;
+		const long r = rd(buf.data() + fill, buf.size() - fill);
+		if (r <= 0) { eof_seen = true; return false; }
+		fill += (size_t)r; return true;
 	}
-	/* end of the line that starts at file offset p (offset of its '\n', or of the end of the file); false: cannot tell yet (never: reads on) */
+	/* end of the line that starts at offset p: the offset of its '\n', or lim() when the input ends first */
 	size_t line_end(size_t p, size_t rec0)
 	{
 		for (;;) {
 			if (p < base + fill) { const unsigned char *e = (const unsigned char*)memchr(buf.data() + (p - base), '\n', base + fill - p); if (e) return base + (size_t)(e - buf.data()); }
-			if (base + fill >= size) return size;
-			if (!more(rec0)) return size;
+			if (!more(rec0)) return lim();
 		}
 	}
-	/* 1: record [*r0, *r1) with *len bases; 0: end of the file; -1: not four lines per record (why) */
+	/* 1: record [*r0, *r1) with *len bases; 0: end of the input; -1: not four lines per record (why) */
 	int next(size_t *r0, size_t *r1, size_t *len)
 	{
 		for (;;) {   /* blank space after the last record is what kseq skips too */
-			if (at >= size) return 0;
 			if (at >= base + fill && !more(at)) return 0;
 			const unsigned char c = buf[at - base];
 			if (c == '\n' || c == '\r' || c == ' ' || c == '\t') { ++at; continue; }
@@ -62,51 +67,95 @@ struct rs_scan_t {
 		}
 		const size_t rec0 = at;
 		if (buf[at - base] != '@') { why = "a record that does not start with '@'"; return -1; }
-		const size_t e1 = line_end(at, rec0); if (e1 >= size) { why = "a header line without a sequence"; return -1; }
-		const size_t s0 = e1 + 1, e2 = line_end(s0, rec0); if (e2 >= size) { why = "a sequence without a '+' line"; return -1; }
+		const size_t e1 = line_end(at, rec0); if (e1 >= lim()) { why = "a header line without a sequence"; return -1; }
+		const size_t s0 = e1 + 1, e2 = line_end(s0, rec0); if (e2 >= lim()) { why = "a sequence without a '+' line"; return -1; }
 		const size_t p0 = e2 + 1;
 		if (p0 >= base + fill && !more(rec0)) { why = "a sequence without a '+' line"; return -1; }
 		if (buf[p0 - base] != '+') { why = "a sequence of several lines (or no quality line)"; return -1; }
-		const size_t e3 = line_end(p0, rec0); if (e3 >= size) { why = "a '+' line without qualities"; return -1; }
+		const size_t e3 = line_end(p0, rec0); if (e3 >= lim()) { why = "a '+' line without qualities"; return -1; }
 		const size_t q0 = e3 + 1, e4 = line_end(q0, rec0);
 		if (e4 - q0 != e2 - s0) { why = "a quality string that is not as long as its sequence"; return -1; }
 		if (e2 > s0 && buf[e2 - 1 - base] == '\r') { why = "lines that end in CR LF"; return -1; }
 		if (e2 == s0) { why = "an empty sequence"; return -1; }
-		*r0 = rec0; *r1 = e4 < size ? e4 + 1 : size; *len = e2 - s0; at = *r1;
+		*r0 = rec0; *r1 = e4 < lim() ? e4 + 1 : lim(); *len = e2 - s0; at = *r1;
 		return 1;
 	}
 };
-
-/* rank 0: scan and publish.  Returns false (message printed, SSG_RDV/batches.fail written) when the input is not four lines per record. */
-static inline bool rs_scan_and_publish(const std::string &rdv, const char *f1, const char *f2, int64_t chunk)
+static inline std::function<long(unsigned char*, size_t)> rs_file_reader(const char *path)
 {
-	rs_scan_t A(f1); std::unique_ptr<rs_scan_t> B(f2 ? new rs_scan_t(f2) : 0);
+	struct st_t { int fd; size_t off; ~st_t() { if (fd >= 0) close(fd); } };
+	std::shared_ptr<st_t> st(new st_t()); st->fd = open(path, O_RDONLY); st->off = 0;
+	return [st](unsigned char *d, size_t cap) -> long {
+		for (;;) { const ssize_t r = st->fd < 0 ? -1 : pread(st->fd, d, cap, (off_t)st->off); if (r < 0 && errno == EINTR) continue; if (r > 0) st->off += (size_t)r; return (long)r; }
+	};
+}
+/* compressed input (or a pipe): fastq.h's stream with its decoder threads; *bad is set when the decoder met a damaged stream */
+static inline std::function<long(unsigned char*, size_t)> rs_stream_reader(const char *path, std::atomic<int> *bad)
+{
+	struct st_t { gzFile fp; std::unique_ptr<fq_stream_t> ks; ~st_t() { ks.reset(); if (fp) gzclose(fp); } };
+	std::shared_ptr<st_t> st(new st_t()); st->fp = gzopen(path, "r");
+	if (st->fp) st->ks.reset(new fq_stream_t(st->fp, path));
+	return [st, bad](unsigned char *d, size_t cap) -> long {
+		if (!st->ks) return -1;
+		fq_stream_t &ks = *st->ks;
+		if (ks.begin >= ks.end && !ks.fill()) { if (ks.had_io_err()) bad->store(1); return 0; }
+		const size_t k = std::min(cap, (size_t)(ks.end - ks.begin));
+		memcpy(d, ks.buf.data() + ks.begin, k); ks.begin += (int)k;
+		return (long)k;
+	};
+}
+
+/* rank 0: scan and publish.  Plain regular files: the batches' byte ranges in the files.  Anything else (`served`: compressed input, which only one
+ * process should inflate): the batches' bytes themselves, a file per batch and input in SSG_RDV (fq.<batch>.<1|2>, removed by the rank that reads
+ * it; rank 0 stays at most three rounds of batches ahead).  Returns false (message printed, SSG_RDV/batches.fail written) when the input is not
+ * four lines per record or cannot be read. */
+static inline bool rs_scan_and_publish(const std::string &rdv, const char *f1, const char *f2, int64_t chunk, bool served, int world)
+{
+	std::atomic<int> bad(0);
+	rs_scan_t A(served ? rs_stream_reader(f1, &bad) : rs_file_reader(f1));
+	std::unique_ptr<rs_scan_t> B(f2 ? new rs_scan_t(served ? rs_stream_reader(f2, &bad) : rs_file_reader(f2)) : 0);
 	const std::string path = rdv + "/batches";
 	const int out = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_APPEND, 0644);
 	auto fail = [&](const std::string &msg) { fprintf(stderr, "[bwa] rank mode: %s; SSG_RANKS_SPLIT=0 makes every rank parse the whole input instead\n", msg.c_str()); (void)rk_file_put(rdv + "/batches.fail", msg.data(), msg.size()); if (out >= 0) close(out); return false; };
-	if (A.fd < 0 || (B && B->fd < 0) || out < 0) return fail("cannot open the input or the rendezvous directory");
+	if (out < 0) return fail("cannot write into the rendezvous directory");
 	uint64_t n_batches = 0; bool eof = false;
+	std::vector<unsigned char> acc1, acc2;
 	while (!eof) {
 		rs_entry_t e; e.pairs = 0; e.a0 = A.at; e.b0 = B ? B->at : 0; e.a1 = e.a0; e.b1 = e.b0;
 		int64_t bases = 0; bool first = true;
+		acc1.clear(); acc2.clear();
 		for (;;) {
 			size_t r0, r1, l0, l1;
 			int rc = A.next(&r0, &r1, &l0);
 			if (rc < 0) return fail(std::string(f1) + " has " + A.why);
 			if (rc == 0) { eof = true; break; }
-			if (first) e.a0 = r0;
+			const size_t keep1 = acc1.size();
+			if (served) acc1.insert(acc1.end(), A.ptr(r0), A.ptr(r0) + (r1 - r0));   /* before the next call moves the buffer */
 			size_t m0 = 0, m1 = 0;
 			rs_scan_t &S2 = B ? *B : A;
-			const size_t a1_before = r1;
 			rc = S2.next(&m0, &m1, &l1);
 			if (rc < 0) return fail(std::string(B ? f2 : f1) + " has " + S2.why);
-			if (rc == 0) { fprintf(stderr, B ? "[W::bseq_read] the 2nd file has fewer sequences.\n" : "[W::main_mem] odd number of reads in the PE mode; last read dropped\n"); eof = true; break; }   /* upstream: the read without a mate is dropped */
-			if (B) { if (first) e.b0 = m0; e.a1 = a1_before; e.b1 = m1; } else e.a1 = m1;
+			if (rc == 0) { fprintf(stderr, B ? "[W::bseq_read] the 2nd file has fewer sequences.\n" : "[W::main_mem] odd number of reads in the PE mode; last read dropped\n"); acc1.resize(keep1); eof = true; break; }   /* upstream: the read without a mate is dropped */
+			if (served) { std::vector<unsigned char> &ac = B ? acc2 : acc1; ac.insert(ac.end(), S2.ptr(m0), S2.ptr(m0) + (m1 - m0)); }
+			if (first) { e.a0 = r0; if (B) e.b0 = m0; }
+			if (B) { e.a1 = r1; e.b1 = m1; } else e.a1 = m1;
 			first = false;
 			++e.pairs; bases += (int64_t)l0 + (int64_t)l1;
 			if (bases >= chunk) break;
 		}
-		if (e.pairs) { if (write(out, &e, sizeof(e)) != (ssize_t)sizeof(e)) return fail("cannot write into the rendezvous directory"); ++n_batches; }
+		if (bad.load()) return fail("the compressed input is damaged");
+		if (!e.pairs) continue;
+		if (served) {
+			const double t0 = rk_now(); struct stat sb;   /* not more than three rounds ahead of the slowest reader */
+			while (n_batches >= 3 * (uint64_t)world && stat((rdv + "/fq." + std::to_string(n_batches - 3 * (uint64_t)world) + ".1").c_str(), &sb) == 0) {
+				if (rk_someone_failed() || rk_now() - t0 > rk_timeout()) return fail("the other ranks do not take their batches");
+				usleep(2000);
+			}
+			e.a0 = 0; e.a1 = acc1.size(); e.b0 = 0; e.b1 = acc2.size();
+			if (!rk_file_put(rdv + "/fq." + std::to_string(n_batches) + ".1", acc1.data(), acc1.size()) || (B && !rk_file_put(rdv + "/fq." + std::to_string(n_batches) + ".2", acc2.data(), acc2.size()))) return fail("cannot write into the rendezvous directory");
+		}
+		if (write(out, &e, sizeof(e)) != (ssize_t)sizeof(e)) return fail("cannot write into the rendezvous directory");
+		++n_batches;
 	}
 	close(out);
 	return rk_file_put(rdv + "/batches.done", &n_batches, 8);
@@ -140,18 +189,21 @@ struct rs_table_t {
 };
 
 /* the bytes of this rank's batches in one of the files, as a stream for the parser */
-static inline fq_stream_t::provider_t rs_provider(std::shared_ptr<rs_table_t> tab, const char *path, bool second_file, int rank, int world, std::atomic<int> *failed)
+static inline fq_stream_t::provider_t rs_provider(std::shared_ptr<rs_table_t> tab, const char *path, bool second_file, int rank, int world, std::atomic<int> *failed, bool served)
 {
-	struct st_t { int fd; uint64_t k, off, end; bool open_range; };
-	std::shared_ptr<st_t> st(new st_t()); st->fd = open(path, O_RDONLY); st->k = 0; st->off = st->end = 0; st->open_range = false;
-	return [tab, st, second_file, rank, world, failed](fq_stream_t::chunk_t &c) -> bool {
-		if (st->fd < 0) { failed->store(1); return false; }
+	struct st_t { int fd; uint64_t k, off, end; bool open_range; std::string cur; };
+	std::shared_ptr<st_t> st(new st_t()); st->fd = served ? -1 : open(path, O_RDONLY); st->k = 0; st->off = st->end = 0; st->open_range = false;
+	return [tab, st, second_file, rank, world, failed, served](fq_stream_t::chunk_t &c) -> bool {
+		if (!served && st->fd < 0) { failed->store(1); return false; }
 		while (!st->open_range || st->off >= st->end) {
+			if (served && st->fd >= 0) { close(st->fd); st->fd = -1; unlink(st->cur.c_str()); }   /* the batch's file has been read: rank 0 may write on */
 			rs_entry_t e; uint64_t id0;
-			const int rc = tab->get((uint64_t)rank + st->k * (uint64_t)world, &e, &id0);
+			const uint64_t b = (uint64_t)rank + st->k * (uint64_t)world;
+			const int rc = tab->get(b, &e, &id0);
 			if (rc < 0) { failed->store(1); return false; }
 			if (rc == 0) return false;
 			++st->k; st->off = second_file ? e.b0 : e.a0; st->end = second_file ? e.b1 : e.a1; st->open_range = true;
+			if (served) { st->cur = tab->rdv + "/fq." + std::to_string(b) + (second_file ? ".2" : ".1"); st->fd = open(st->cur.c_str(), O_RDONLY); if (st->fd < 0) { failed->store(1); return false; } }
 		}
 		const size_t want = (size_t)std::min<uint64_t>(st->end - st->off, (uint64_t)4 << 20);
 		c.resize(want);

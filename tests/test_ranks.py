@@ -52,8 +52,9 @@ def _records(bam):
 
 
 @pytest.mark.parametrize("world,extra,chunk,kw", [(2, "", "40000", {}), (3, "export SSG_SORT_CHUNK_BYTES=300000\n", "40000", {}), (4, "", "150000", {}),
-                                                  (2, "export SSG_RANKS_SPLIT=0\n", "60000", {"read_len": 250, "ins_mean": 800, "ins_std": 150})],
-                         ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches", "two_ranks_2x250_everyone_parses"])
+                                                  (2, "export SSG_RANKS_SPLIT=0\n", "60000", {"read_len": 250, "ins_mean": 800, "ins_std": 150}),
+                                                  (3, "", "40000", {"gz_two_files": True})],
+                         ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches", "two_ranks_2x250_everyone_parses", "three_ranks_two_gz_files"])
 def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chunk, kw):
     _ranks_equal_one(tmp_path, world, extra, chunk, None, 2500 if not kw else 1200, **kw)
 
@@ -66,17 +67,20 @@ def test_ranks_gpu_two_pipelines_on_the_one_device(tmp_path, gpu_lib):
 
 def _ranks_equal_one(tmp_path, world, extra, chunk, exe, n_pairs, **kw):
     _need_tools()
-    fq = str(tmp_path / "reads.fq")
-    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=13, **kw))
+    two = kw.pop("gz_two_files", False)
+    fq = str(tmp_path / ("reads_1.fq.gz" if two else "reads.fq"))
+    fq2 = str(tmp_path / "reads_2.fq.gz") if two else None
+    simreads.write_fastq(fq, simreads.simulate(simreads.read_fasta(EXAMPLE_FA), n_pairs, seed=13, **kw), interleaved=not two, path2=fq2)
+    tail = (["-p"] if not two else []) + ["-R", RG]
     cfg, ref, env = _setup(str(tmp_path / "one"), "", exe)
     env["SSG_BWA_CHUNK_BASES"] = chunk                  # x -t 2: 267 or 1000 pairs per upstream batch (the last case: fewer batches than ranks)
     one = str(tmp_path / "one" / "out")
-    r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", one, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq], cwd=str(tmp_path / "one"), env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(["bash", REF_SCRIPT, "align", "-K", cfg, "-o", one, "-M", "3", "-t", "2"] + tail + [ref, fq] + ([fq2] if two else []), cwd=str(tmp_path / "one"), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     cfg, ref, env = _setup(str(tmp_path / "many"), extra, exe)
     env["SSG_BWA_CHUNK_BASES"] = chunk
     many = str(tmp_path / "many" / "out")
-    r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(world), "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", many, "-M", "3", "-t", "2", "-p", "-R", RG, ref, fq],
+    r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(world), "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", many, "-M", "3", "-t", "2"] + tail + [ref, fq] + ([fq2] if two else []),
                        cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
@@ -119,7 +123,8 @@ def _bwa_ranks(tmp_path, world, fqs, env_extra=None, expect_fail=False):
 
 def test_ranks_read_only_their_share_of_plain_fastq(tmp_path, emu_lib):
     """plain regular files: rank 0 scans the input for upstream's batches and publishes their byte ranges (SSG_RDV/batches), every rank parses the
-    ranges of its batches only; the frames are the same bytes as when every rank parses everything (SSG_RANKS_SPLIT=0, or compressed input)"""
+    ranges of its batches only; compressed input: rank 0 alone inflates it and hands every batch on as a file of its own; either way the frames
+    are the same bytes as when every rank reads and parses everything (SSG_RANKS_SPLIT=0)"""
     import gzip
     pairs = simreads.simulate(simreads.read_fasta(EXAMPLE_FA), 2000, seed=17)
     one = str(tmp_path / "il.fq")
@@ -130,10 +135,11 @@ def test_ranks_read_only_their_share_of_plain_fastq(tmp_path, emu_lib):
     with open(one, "rb") as fi, gzip.open(gz, "wb", compresslevel=1) as fo:
         fo.write(fi.read())
     frames = {}
-    for tag, fqs, env in (("split", [one], {}), ("all", [one], {"SSG_RANKS_SPLIT": "0"}), ("gz", [gz], {}), ("two", [f1, f2], {}), ("two_all", [f1, f2], {"SSG_RANKS_SPLIT": "0"})):
+    for tag, fqs, env in (("split", [one], {}), ("all", [one], {"SSG_RANKS_SPLIT": "0"}), ("gz", [gz], {}), ("gz_all", [gz], {"SSG_RANKS_SPLIT": "0"}), ("two", [f1, f2], {}), ("two_all", [f1, f2], {"SSG_RANKS_SPLIT": "0"})):
         rcs, errs, batches = _bwa_ranks(tmp_path, 3, fqs, env)
         assert rcs == [0, 0, 0], errs
-        assert (batches is not None) == (tag in ("split", "two")), tag
+        assert (batches is not None) == (tag in ("split", "two", "gz")), tag       # gz: rank 0 inflates and scans, the batches travel as files of their own
+        assert [f for f in os.listdir(str(tmp_path / "rdv")) if f.startswith("fq.")] == [], tag
         if batches is not None:
             assert len(batches) % 40 == 0 and len(batches) // 40 >= 6
         frames[tag] = [open(str(tmp_path / ("frames.%d" % r)), "rb").read() for r in range(3)]
@@ -146,7 +152,7 @@ def test_ranks_read_only_their_share_of_plain_fastq(tmp_path, emu_lib):
             assert t == 1
             out.append(b[o + 16 + l:])
         return out
-    assert body(frames["split"]) == body(frames["all"]) == body(frames["gz"])
+    assert body(frames["split"]) == body(frames["all"]) == body(frames["gz"]) == body(frames["gz_all"])
     assert body(frames["two"]) == body(frames["two_all"]) == body(frames["split"])
 
 
