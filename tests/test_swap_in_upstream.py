@@ -62,6 +62,23 @@ def test_upstream_bwa_mem_pins_the_oracle_and_the_emulated_product(tmp_path, emu
 
 
 @need_bwa
+@pytest.mark.parametrize("opts", [("-M",), ("-Y",), ("-S",), ("-P",), ("-A", "2"), ("-A", "2", "-B", "5", "-O", "7,9", "-E", "2,1"), ("-k", "25", "-c", "50", "-D", "0.3"), ("-L", "3,8", "-U", "9"), ("-T", "45", "-h", "2")],
+                         ids=lambda o: "".join(o))
+def test_upstream_bwa_mem_option_letters_pin_the_oracle(tmp_path, opts):
+    """the option letters restated late in round 4 (oracle/README.md row 10c): upstream's own reading of them"""
+    fq = _reads(tmp_path, 1500, 907)
+    assert _mem([ORC], fq, opts) == _mem([UP_BWA], fq, opts), "oracle/orc_bwa differs from upstream bwa mem under " + " ".join(opts)
+
+
+@need_bwa
+def test_upstream_bwa_mem_single_end_pins_the_oracle(tmp_path):
+    """one FASTQ without -p (oracle/README.md row 10d)"""
+    fq = _reads(tmp_path, 1500, 908)
+    run = lambda exe: _no_pg(subprocess.run(list(exe) + ["mem", "-t", "4", "-R", RG, EXAMPLE_FA, fq], capture_output=True, check=True).stdout.decode())
+    assert run([ORC]) == run([UP_BWA])
+
+
+@need_bwa
 @pytest.mark.gpu
 def test_upstream_bwa_mem_pins_the_product_on_the_gpu(tmp_path, gpu_lib):
     fq = _reads(tmp_path, 20000, 904)
