@@ -1,7 +1,7 @@
 /*
  * k_smem2.h -- the seeding kernel of the product path: upstream mem_collect_intv = bwt_smem1a from every
  * position the previous call returned (pass 1), bwt_smem1a with min_intv = occurrences + 1 from the middle of long SMEMs with few
- * occurrences (pass 2), bwt_seed_strategy1 (pass 3); oracle/orc_smem.c restates them from upstream bwt.c / bwamem.c.
+ * occurrences (pass 2), bwt_seed_strategy1 (pass 3); oracle/orc_mem.c restates them from upstream bwt.c / bwamem.c.
  *
  * One lane per read; the three passes are a per-lane state machine around ONE bwt_extend site per loop iteration, so that every lane of
  * the wave that has an extension pending issues its two rank-block fetches (and the fetch of its next interval-list entry) in the same
