@@ -107,6 +107,15 @@ int ssg_seeds_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 int ssg_extend_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_jobs, const ssg_ext_job_t *jobs, const int64_t *tpos, int dir,
                           const uint8_t *qbuf, size_t qbytes, int qcap, ssg_ext_res_t *res, uint64_t *cells);
 
+/* upstream ksw_align2() as mate rescue runs it in the product path (row a10; k_mswlane.h): the forward pass of every job by the LANE kernel
+ * (`lanes` = 1, 2 or 4 lanes per job, strips of 8 target rows in registers, strip boundaries in LDS), the reverse pass (KSW_XSTART) by the
+ * wave code; a job the lane kernel does not take (KSW_XSTOP, a window above 8192 rows, scores beyond the packed cells: a > 15, b > 16,
+ * qlen * a > 8190) goes through the wave code entirely.  Job i's target is jobs[i].tlen bases from doubled coordinate
+ * tpos[i] of the index's 2-bit reference (jobs[i].toff is ignored), its query qbuf[qoff .. qoff + qlen).  from_lane[i] (may be NULL) = 1 when
+ * the forward pass of job i came from the lane kernel. */
+int ssg_align2_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *jobs, const int64_t *tpos,
+                          const uint8_t *qbuf, size_t qbytes, int lanes, ssg_kswr_t *res, int32_t *from_lane);
+
 /* upstream mem_align1_core() (bwamem.c; rows a1-a8) for a batch of reads: SMEM -> SAL -> chain ->
  * filter -> extend -> sort/dedup/patch.  reg_off[n_reads+1] and regs (malloc'd by the library,
  * release with ssg_free) receive each read's mem_alnreg_t list in upstream order. */

@@ -22,6 +22,9 @@ static void flatten(const orc_alnreg_t *a, orc_flatreg_t *f)
 }
 
 orc_opt_t *orc_api_opt_new(void) { orc_opt_t *o = malloc(sizeof(orc_opt_t)); orc_opt_init(o); return o; }
+/* scoring of the stage-level checks (bwa mem -A -B -O -E): a, b, gap open / extend for deletions and insertions */
+void orc_api_opt_scores(orc_opt_t *o, int a, int b, int o_del, int e_del, int o_ins, int e_ins)
+{ o->a = a; o->b = b; o->o_del = o_del; o->e_del = e_del; o->o_ins = o_ins; o->e_ins = e_ins; orc_fill_scmat(o); }
 void orc_api_free(void *p) { free(p); }
 
 /* mem_collect_intv for one read; returns the number of intervals (out may be smaller than needed) */

@@ -161,6 +161,14 @@ class Lib:
         self._chk(self.l.ssg_extend_lane_batch(idx, _ptr(opt), C.c_int(len(jobs)), _ptr(jobs), _ptr(tpos), C.c_int(direction), _ptr(qbuf), C.c_size_t(qbuf.size), C.c_int(qcap), _ptr(res), C.byref(cells)))
         return res, cells.value
 
+    def align2_lane_batch(self, idx, opt, jobs, tpos, qbuf, lanes):
+        jobs = np.ascontiguousarray(jobs, dtype=SW_JOB_DT)
+        res = np.zeros(len(jobs), dtype=KSWR_DT)
+        from_lane = np.zeros(len(jobs), dtype=np.int32)
+        tpos = np.ascontiguousarray(tpos, dtype=np.int64)
+        self._chk(self.l.ssg_align2_lane_batch(idx, _ptr(opt), C.c_int(len(jobs)), _ptr(jobs), _ptr(tpos), _ptr(qbuf), C.c_size_t(qbuf.size), C.c_int(lanes), _ptr(res), _ptr(from_lane)))
+        return res, from_lane
+
     def align1_batch(self, idx, opt, seq, off):
         n = len(off) - 1
         reg_off = np.zeros(n + 1, dtype=np.int64)

@@ -203,7 +203,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
                                 uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells, unsigned long long *ph,
                                 ssg_sdp_small_t *sdp_lds, ssg_sdp_big_t *sdp_big, ssg_alnreg_t *sdp_tmp,
-                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r)
+                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, uint8_t *sdp_fixed)
 {
 	const uint8_t *query = seq + read_off[r];
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
@@ -362,6 +362,9 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 		if (av_n <= SSG_SDP_SMALL) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2, l_pac);
 		else if (av_n <= SSG_SDP_BIG) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2, l_pac);
 		av_n = m >= 0 ? m : wv_sort_dedup_patch(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
+		/* no pair of regions reached mem_patch_reg's alignment: the list is the output of the plain redundancy scan, a fixed point of it
+		 * (mate rescue's first re-sort of this list can be the incremental one, k_sdp.h wv_sort_dedup_incr) */
+		if (wv_lane() == 0 && sdp_fixed) sdp_fixed[r] = m >= 0;
 	}
 	SSG_PH(3);
 #undef SSG_PH
@@ -382,7 +385,8 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int64_t *read_off, const int64_t *seed_off,
                                 const ssg_seed_t *seeds, const int32_t *chain_seeds, const int32_t *n_chain, ssg_alnreg_t *regs, int32_t *n_reg,
                                 int32_t *err, const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r,
-                                const int32_t *work_order, int32_t *todo_list, unsigned int *n_todo /* out: reads the wave kernel has to do, roughly heaviest first */)
+                                const int32_t *work_order, int32_t *todo_list, unsigned int *n_todo /* out: reads the wave kernel has to do, roughly heaviest first */,
+                                uint8_t *sdp_fixed /* out: the list is a fixed point of the redundancy scan (always, here: a patch candidate sends the read to the wave kernel) */)
 {
 	const long g_ = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g_ >= n_reads) return;
@@ -493,6 +497,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, 
 		av_n = mm;
 	}   /* upstream returns n <= 1 untouched */
 	n_reg[r] = av_n; err[r] = 0;
+	if (sdp_fixed) sdp_fixed[r] = 1;
 #undef SSG_C2A_TODO
 }
 
@@ -502,7 +507,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
                                 uint8_t *tglb, int32_t *err, unsigned long long *cells, const int32_t *work_order, unsigned int *queue, int tune,
                                 ssg_sdp_big_t *sdpbig, ssg_alnreg_t *bcopy,
-                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, const int32_t *todo_list, const unsigned int *n_todo)
+                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, const int32_t *todo_list, const unsigned int *n_todo, uint8_t *sdp_fixed)
 {
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
 	__shared__ ssg_sdp_small_t sdp[SSG_WAVES_PER_WG];
@@ -514,7 +519,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 		const long k = wv_queue_pop(queue);
 		if (k >= (todo_list ? (long)*n_todo : (long)n_reads)) break;
 		wv_chain2aln_read(ix, opt, todo_list ? todo_list[k] : work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
-		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r);
+		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r, sdp_fixed);
 	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);
 	if (SSG_TUNING && tune && wv_lane() == 0) { /* tuning: window+seed sort, containment scan, extension, re-sort, wave total; #chains, #extended seeds, #regions */

@@ -19,13 +19,7 @@
 #include "k_extend.h"
 
 
-SSG_DEVFN int ssg_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)
-{	/* upstream mem_infer_dir */
-	int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
-	int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
-	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
-	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
-}
+#include "k_mswlane.h"
 
 SSG_DEVFN int ssg_cal_sub(const ssg_mem_opt_t &opt, const ssg_alnreg_t *a, int n)
 {	/* upstream cal_sub */
@@ -65,8 +59,8 @@ __global__ void ssg_k_pestat_hist(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_
 SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const ssg_pestat_t *pes, const ssg_alnreg_t a,
                         int l_ms, const uint8_t *ms, ssg_alnreg_t *ma, int *ma_n_, int ma_cap,
                         uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells, unsigned long long *ph,
-                        ssg_alnreg_t *sdp_tmp, ssg_sdp_lds_t *sdp_lds, ssg_sdp_big_t *sdp_big, int *ma_fixed)
-{	/* upstream mem_matesw; *ma_fixed: ma[] is the output of an earlier re-sort in this kernel (see wv_sort_dedup_incr); ph[]: cycle counters per phase (fetch, SW, re-sort, window rows) */
+                        ssg_alnreg_t *sdp_tmp, ssg_sdp_lds_t *sdp_lds, ssg_sdp_big_t *sdp_big, int *ma_fixed, const ssg_msres_t *jres /* this anchor's four slots, or null */, unsigned long long *npre)
+{	/* upstream mem_matesw; jres: forward passes computed ahead of the decision (k_mswlane.h); *ma_fixed: ma[] is the output of an earlier re-sort in this kernel (see wv_sort_dedup_incr); ph[]: cycle counters per phase (fetch, SW, re-sort, window rows) */
 	const int64_t l_pac = ix.l_pac;
 	int i, r, skip[4], n = 0, rid = -1, ma_n = *ma_n_;
 	for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
@@ -106,18 +100,27 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 		if (a.rid == rid && re - rb >= opt.min_seed_len) {
 			if (re - rb > tcap || re - rb > SSG_MS_BCAP) { *err = 1; continue; }
 			unsigned long long c0 = ssg_clock();
-			wv_fetch_ref(ix, rb, re, tbuf);
+			const int xtra = SSG_KSW_XSUBO | SSG_KSW_XSTART | (l_ms * opt.a < 250 ? SSG_KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
+			ssg_kswr_t aln;
+			int pre = 0;   /* the window's forward pass is in its slot (same window: start and length checked) */
+			if (jres) pre = wv_get((int)(jres[r].state == 1 && jres[r].rb == rb && jres[r].tlen == (int)(re - rb)), 0);
+			if (pre) { aln.score = wv_get(jres[r].score, 0); aln.te = wv_get(jres[r].te, 0); aln.qe = wv_get(jres[r].qe, 0); aln.score2 = wv_get(jres[r].score2, 0); aln.te2 = wv_get(jres[r].te2, 0); aln.tb = aln.qb = -1; ++*npre; if (cells) *cells += (unsigned long long)(re - rb) * l_ms; }
+			const bool want_rev = !pre || ssg_align2_has_rev(xtra, aln.score);   /* only a window that reached minsc has a reverse pass */
+			if (want_rev) wv_fetch_ref(ix, rb, pre ? rb + aln.te + 1 : re, tbuf);
 			ph[0] += ssg_clock() - c0; c0 = ssg_clock();
 			ssg_seqv_t q;
 			if (is_rev) {
-				ssg_wave_memsync();
-				for (i = wv_lane(); i < l_ms; i += 64) revbuf[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
-				ssg_wave_memsync();
+				if (want_rev) {
+					ssg_wave_memsync();
+					for (i = wv_lane(); i < l_ms; i += 64) revbuf[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
+					ssg_wave_memsync();
+				}
 				q.p = revbuf; q.dir = 1;
 			} else { q.p = ms; q.dir = 1; }
 			ssg_seqv_t t = { tbuf, 1 };
-			int xtra = SSG_KSW_XSUBO | SSG_KSW_XSTART | (l_ms * opt.a < 250 ? SSG_KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
-			ssg_kswr_t aln = wv_align2(opt, l_ms, q, (int)(re - rb), t, xtra, bscratch, cells);
+			if (!pre) aln = wv_align2(opt, l_ms, q, (int)(re - rb), t, xtra, bscratch, cells);
+			else if (want_rev) wv_align2_rev(opt, l_ms, q, t, xtra, aln, bscratch, cells);
+			if (SSG_TUNING && wv_lane() == 0) { if (pre && want_rev) { atomicAdd(&ssg_dbg_cyc[29], 1ull); atomicAdd(&ssg_dbg_cyc[30], (unsigned long long)(aln.te + 1)); } if (!pre) atomicAdd(&ssg_dbg_cyc[31], 1ull); }
 			ph[1] += ssg_clock() - c0; if (SSG_TUNING) ph[3] += (unsigned long long)(re - rb);
 			if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
 				ssg_alnreg_t b;
@@ -210,7 +213,9 @@ __global__ void __launch_bounds__(64) ssg_k_matesw_need(ssg_index_view_t ix, ssg
 __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const uint8_t *seq, const int64_t *read_off,
                              const int64_t *reg_off, ssg_alnreg_t *regs, int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                              ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue,
-                             const int32_t *work_order, unsigned int *queue, ssg_sdp_big_t *sdpbig, const unsigned int *n_todo /* work_order[] holds this many pairs */)
+                             const int32_t *work_order, unsigned int *queue, ssg_sdp_big_t *sdpbig, const unsigned int *n_todo /* work_order[] holds this many pairs */,
+                             const ssg_msres_t *jres, const int64_t *jbase /* forward passes of the windows of pair kq's sides: slots jbase[2 kq + i] + 4 j + r (k_mswlane.h); or null */,
+                             const uint8_t *sdp_fixed /* per read: the list is a fixed point of mem_sort_dedup_patch's scan already (k_extend.h); or null */)
 {
 	__shared__ uint8_t revlds[SSG_WAVES_PER_WG][256];
 	__shared__ ssg_sdp_lds_t sdplds[SSG_WAVES_PER_WG];
@@ -219,7 +224,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 	uint8_t *tg = tglb + wave0 * (long)SSG_TWIN_GLB;
 	unsigned long long *bs = bglb + wave0 * (long)SSG_MS_BCAP;
 	ssg_alnreg_t *bc = bcopy + wave0 * (128L + SSG_SDP_BIG);   /* upstream's b[2] (2 x 64) + the re-sort gather buffer */
-	unsigned long long nc = 0, nres = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long nc = 0, nres = 0, npre = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	const unsigned long long k0 = ssg_clock();
 	for (;;) { /* pairs come from a heaviest-first queue (many candidate hits => many rescues) */
 		const long kq = wv_queue_pop(queue);
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 			if (nb[i] > 64) { nb[i] = 64; myerr = 3; }
 		}
 		if (nb[0] + nb[1] > 0) {
-			int fixed[2] = { 0, 0 };   /* a[i] has been through a re-sort of this kernel: later ones are incremental */
+			int fixed[2] = { sdp_fixed ? (int)sdp_fixed[2*p] : 0, sdp_fixed ? (int)sdp_fixed[2*p + 1] : 0 };   /* a[i] is the output of a plain re-sort (stage 1's, or this kernel's): the next one is incremental */
 			ssg_wave_memsync();
 			for (int i2 = 0; i2 < 2; ++i2) { /* the first nb[i2] qualifying hits, in list order: 64 per step */
 				const int thr = an[i2] ? a[i2][0].score - opt.pen_unpaired : 0;
@@ -259,14 +264,14 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 				for (int j = 0; j < nb[i]; ++j) {
 					const int l_ms = (int)(read_off[2*p + !i + 1] - read_off[2*p + !i]);
 					const uint8_t *ms = seq + read_off[2*p + !i];
-					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot], sdpbig + wave0, &fixed[!i]);
+					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot], sdpbig + wave0, &fixed[!i], jres ? jres + jbase[2*kq + i] + 4 * j : 0, &npre);
 				}
 		}
 		if (wv_lane() == 0) { n_reg[2*p] = an[0]; n_reg[2*p+1] = an[1]; if (myerr) err[p] = myerr; }
 	}
 	if (wv_lane() == 0) {
 		if (cells) atomicAdd(cells, nc);
-		if (n_rescue) atomicAdd(n_rescue, nres);
+		if (n_rescue) { atomicAdd(n_rescue, nres); if (npre) atomicAdd(n_rescue + 1, npre); }   /* [1]: windows whose forward pass was there already */
 		if (SSG_TUNING) { ph[4] = ssg_clock() - k0; for (int t = 0; t < 8; ++t) atomicAdd(&ssg_dbg_cyc[t], ph[t]); }
 	}
 }

@@ -397,6 +397,19 @@ SSG_DEVFN ssg_sw1_t wv_local(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 #define SSG_KSW_XSUBO  0x40000
 #define SSG_KSW_XSTART 0x80000
 
+/* second half of upstream ksw_align2 (KSW_XSTART): the start of the alignment from the reversed prefixes, walked backwards from (qe, te).
+ * r holds the forward pass (score, te, qe); only target rows 0..te are read. */
+template <int NS>
+SSG_DEVFN void wv_align2_rev_t(const ssg_mem_opt_t &opt, ssg_seqv_t query, ssg_seqv_t target, int xtra, ssg_kswr_t &r,
+                               unsigned long long *bscratch, unsigned long long *cells)
+{
+	const int p = (xtra & SSG_KSW_XBYTE) ? 16 : 8;
+	r.tb = r.qb = -1;
+	if ((xtra & SSG_KSW_XSTART) == 0 || ((xtra & SSG_KSW_XSUBO) && r.score < (xtra & 0xffff))) return;
+	ssg_seqv_t rq = { query.p + query.dir * r.qe, -query.dir }, rt = { target.p + target.dir * r.te, -target.dir };
+	ssg_sw1_t rr = wv_local<NS>(opt, r.qe + 1, rq, r.te + 1, rt, p, 0x10000, r.score, bscratch, cells);
+	if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+}
 template <int NS>
 SSG_DEVFN ssg_kswr_t wv_align2_t(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int xtra,
                                  unsigned long long *bscratch, unsigned long long *cells)
@@ -407,20 +420,30 @@ SSG_DEVFN ssg_kswr_t wv_align2_t(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t 
 	const int endsc = (xtra & SSG_KSW_XSTOP) ? xtra & 0xffff : 0x10000;
 	ssg_sw1_t f = wv_local<NS>(opt, qlen, query, tlen, target, p, minsc, endsc, bscratch, cells);
 	r.score = f.score; r.te = f.te; r.qe = f.qe; r.score2 = f.score2; r.te2 = f.te2;
-	if ((xtra & SSG_KSW_XSTART) == 0 || ((xtra & SSG_KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
-	/* reverse both prefixes: walk them backwards from (qe, te) */
-	ssg_seqv_t rq = { query.p + query.dir * r.qe, -query.dir }, rt = { target.p + target.dir * r.te, -target.dir };
-	ssg_sw1_t rr = wv_local<NS>(opt, r.qe + 1, rq, r.te + 1, rt, p, 0x10000, r.score, bscratch, cells);
-	if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+	wv_align2_rev_t<NS>(opt, query, target, xtra, r, bscratch, cells);
 	return r;
 }
+/* does ksw_align2 run its reverse pass after a forward pass that ended with this score? */
+SSG_DEVFN bool ssg_align2_has_rev(int xtra, int score) { return (xtra & SSG_KSW_XSTART) != 0 && !((xtra & SSG_KSW_XSUBO) && score < (xtra & 0xffff)); }
+SSG_DEVFN int ssg_align2_qp(int qlen, int xtra) { return (xtra & SSG_KSW_XBYTE) ? ((qlen + 15) / 16) * 16 : ((qlen + 7) / 8) * 8; }
 SSG_DEVFN ssg_kswr_t wv_align2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int xtra,
                                unsigned long long *bscratch, unsigned long long *cells)
 {
-	int qp = ((qlen + 7) / 8) * 8; if (xtra & SSG_KSW_XBYTE) qp = ((qlen + 15) / 16) * 16;
+	const int qp = ssg_align2_qp(qlen, xtra);
 	if (qp <= 64)  return wv_align2_t<1>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 128) return wv_align2_t<2>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 192) return wv_align2_t<3>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	return wv_align2_t<4>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
+}
+/* ksw_align2 whose forward pass (r.score, te, qe, score2, te2) was computed elsewhere (k_mswlane.h): the reverse pass in the column layout
+ * the whole call would have used */
+SSG_DEVFN void wv_align2_rev(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, ssg_seqv_t target, int xtra, ssg_kswr_t &r,
+                             unsigned long long *bscratch, unsigned long long *cells)
+{
+	const int qp = ssg_align2_qp(qlen, xtra);
+	if (qp <= 64)  return wv_align2_rev_t<1>(opt, query, target, xtra, r, bscratch, cells);
+	if (qp <= 128) return wv_align2_rev_t<2>(opt, query, target, xtra, r, bscratch, cells);
+	if (qp <= 192) return wv_align2_rev_t<3>(opt, query, target, xtra, r, bscratch, cells);
+	return wv_align2_rev_t<4>(opt, query, target, xtra, r, bscratch, cells);
 }
 #endif

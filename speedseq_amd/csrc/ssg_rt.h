@@ -23,7 +23,9 @@ static inline int rt_set_device(int d) { if (d < 0 || d >= rt_device_count()) { 
 #define SSG_MAX_LANE 4
 extern thread_local int ssg_lane;
 static inline int rt_set_lane(int l) { if (l < 0 || l >= SSG_MAX_LANE) { ssg_err_msg = "ssg_set_lane: lane out of range"; return -22; } ssg_lane = l; return 0; }
-static inline void *rt_malloc(size_t n) { return calloc(n ? n : 1, 1); }
+/* SSG_EMU_POISON=1: device memory comes filled with 0xA5 instead of zeros (the device pool hands out whatever the last user left): reads of
+ * memory nobody wrote show in the CPU-side suite */
+static inline void *rt_malloc(size_t n) { static const int poison = getenv("SSG_EMU_POISON") ? atoi(getenv("SSG_EMU_POISON")) : 0; if (!poison) return calloc(n ? n : 1, 1); void *p = malloc(n ? n : 1); if (p) memset(p, 0xA5, n ? n : 1); return p; }
 static inline void rt_free(void *p) { free(p); }
 static inline int rt_h2d(void *d, const void *h, size_t n) { if (n) memcpy(d, h, n); return 0; }
 static inline int rt_d2h(void *h, const void *d, size_t n) { if (n) memcpy(h, d, n); return 0; }
@@ -80,14 +82,20 @@ static inline int rt_set_lane(int l) { if (l < 0 || l >= SSG_MAX_LANE) { ssg_err
 struct ssg_pool_t {
 	std::mutex mu; std::map<size_t, std::vector<void*> > free_; std::unordered_map<void*, size_t> size_;
 	static size_t cls(size_t n) { size_t c = 256; while (c < n) c <<= 1; if (c > (64u << 20)) { size_t g = 64u << 20; c = (n + g - 1) / g * g; } return c; }
+	std::unordered_map<void*, int> live_;   /* SSG_POOL_CHECK=1: a block handed out twice, or given back twice, is reported */
+	static bool check() { static const int c = getenv("SSG_POOL_CHECK") ? atoi(getenv("SSG_POOL_CHECK")) : 0; return c != 0; }
 	void *get(size_t n) {
 		size_t c = cls(n ? n : 1);
-		{ std::lock_guard<std::mutex> l(mu); auto it = free_.find(c); if (it != free_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; } }
+		{ std::lock_guard<std::mutex> l(mu); auto it = free_.find(c); if (it != free_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back();
+			if (check() && live_[p]++) fprintf(stderr, "[ssgpu] pool: block %p (class %zu) handed out while in use\n", p, c);
+			return p; } }
 		void *p = 0;
 		if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); release(); if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); return 0; } }
-		std::lock_guard<std::mutex> l(mu); size_[p] = c; return p;
+		std::lock_guard<std::mutex> l(mu); size_[p] = c; if (check()) live_[p] = 1; return p;
 	}
-	bool put(void *p) { std::lock_guard<std::mutex> l(mu); auto it = size_.find(p); if (it == size_.end()) return false; free_[it->second].push_back(p); return true; }
+	bool put(void *p) { std::lock_guard<std::mutex> l(mu); auto it = size_.find(p); if (it == size_.end()) return false;
+		if (check() && --live_[p] != 0) fprintf(stderr, "[ssgpu] pool: block %p (class %zu) given back twice\n", p, it->second);
+		free_[it->second].push_back(p); return true; }
 	void release() { std::lock_guard<std::mutex> l(mu); for (auto &kv : free_) for (void *p : kv.second) { size_.erase(p); (void)hipFree(p); } free_.clear(); }
 };
 extern ssg_pool_t ssg_pools[SSG_MAX_DEV][SSG_MAX_LANE];

@@ -421,6 +421,89 @@ int ssg_align2_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *j
 	return dr.down(res, n_jobs);
 }
 
+static int sort_keys_u64(uint64_t *k_in, uint64_t *k_out, long n, int begin_bit, int end_bit);
+/* The forward passes of nj mate-rescue windows (k_mswlane.h): d_keys[nj] = qp << 48 | tlen << 32 | slot (unsorted; sorted here so that a
+ * wavefront's jobs share the padded query length and have similar window lengths), results into d_res[slot].  lanes = 1, 2 or 4 per job;
+ * max_qp / max_tlen = the largest padded query length / window length among the jobs (LDS columns per lane = max_qp / lanes;
+ * b[] entries per job = max_tlen / 2 + 2). */
+static int run_msw_lane(const ssg_index_t *idx, const ssg_mem_opt_t *opt, long nj, uint64_t *d_keys, const ssg_msjob_t *d_jobs, const uint8_t *d_seq, ssg_msres_t *d_res,
+                        int max_qp, int max_tlen, int lanes, unsigned long long *d_cells, long n_slots, long seq_bytes)
+{
+	if (nj <= 0) return 0;
+	if (lanes != 1 && lanes != 2 && lanes != 4) { ssg_err_msg = "mate rescue lane kernel: 1, 2 or 4 lanes per job"; return SSG_EINVAL; }
+	dbuf<uint64_t> d_sorted((size_t)nj); dbuf<unsigned int> d_q(1);
+	CHKA(d_sorted); CHKA(d_q); CHK(d_q.zero());
+	/* bits [32, 58): padded query length (<= 256 at bit 48) over window length (< 2^16).  NOT [32, 64): hipcub / rocPRIM of ROCm 7.2 returns
+	 * a list that is not even a permutation of its input for that range of 64-bit keys (tools/dbg/sort_probe.cpp) */
+	CHK(sort_keys_u64(d_keys, d_sorted.p, nj, 32, 58));
+	STAGE("msw_sort");
+	if (ssg_debug() >= 2) {	/* diagnostic: the sorted list is a permutation of the keys, in order, and every key names a plausible job */
+		std::vector<uint64_t> hk((size_t)nj), hs((size_t)nj);
+		CHK(rt_d2h(hk.data(), d_keys, (size_t)nj * 8)); CHK(rt_d2h(hs.data(), d_sorted.p, (size_t)nj * 8));
+		long bad_slot = 0, bad_order = 0, bad_job = 0;
+		std::vector<ssg_msjob_t> hj((size_t)n_slots);
+		CHK(rt_d2h(hj.data(), d_jobs, (size_t)n_slots * sizeof(ssg_msjob_t)));
+		for (long i = 0; i < nj; ++i) {
+			const uint64_t sl = hk[(size_t)i] & 0xffffffffu;
+			if ((long)sl >= n_slots) { ++bad_slot; continue; }
+			const ssg_msjob_t &jb = hj[(size_t)sl];
+			if (!(jb.qlen >= 1 && jb.qlen <= 256 && jb.tlen >= 1 && jb.tlen <= SSG_ML_TMAX && (uint64_t)jb.qp == hk[(size_t)i] >> 48 && (uint64_t)jb.tlen == (hk[(size_t)i] >> 32 & 0xffff))) ++bad_job;
+		}
+		for (long i = 1; i < nj; ++i) if ((hs[(size_t)i] >> 32) < (hs[(size_t)i - 1] >> 32)) ++bad_order;
+		std::sort(hk.begin(), hk.end()); std::vector<uint64_t> hs2(hs); std::sort(hs2.begin(), hs2.end());
+		fprintf(stderr, "[ssgpu] msw keys: %ld keys, %ld with a slot out of range, %ld naming a job that does not match, %ld out of order after the sort, same multiset: %d\n", nj, bad_slot, bad_job, bad_order, (int)(hk == hs2));
+	}
+	const int J = 64 / lanes, ccap = (max_qp + lanes - 1) / lanes + 1;
+	const size_t lds = (size_t)(ccap + 2) * 64 * 4;
+	const long nchunk = (nj + J - 1) / J;
+	const long resident = 256L * std::min<long>(16, (long)(160 * 1024 / lds));
+	const long grid = std::min(nchunk, std::max(resident, 1L));
+	const int bcap = max_tlen / 2 + 2;
+	dbuf<unsigned long long> d_bl((size_t)grid * J * bcap);
+	CHKA(d_bl);
+	if (lanes == 4) SSG_LAUNCH(ssg_k_msw_lane<4>, grid, 64, lds, idx->v, *opt, nj, d_sorted.p, d_jobs, d_seq, d_res, d_bl.p, d_q.p, ccap, bcap, d_cells, n_slots, seq_bytes);
+	else if (lanes == 2) SSG_LAUNCH(ssg_k_msw_lane<2>, grid, 64, lds, idx->v, *opt, nj, d_sorted.p, d_jobs, d_seq, d_res, d_bl.p, d_q.p, ccap, bcap, d_cells, n_slots, seq_bytes);
+	else SSG_LAUNCH(ssg_k_msw_lane<1>, grid, 64, lds, idx->v, *opt, nj, d_sorted.p, d_jobs, d_seq, d_res, d_bl.p, d_q.p, ccap, bcap, d_cells, n_slots, seq_bytes);
+	int rc = rt_sync();   /* the temporaries are released on return */
+#if defined(SSG_ML_CHECK) && !defined(SSG_EMU)
+	{ unsigned long long dc[32]; if (hipMemcpyFromSymbol(dc, HIP_SYMBOL(ssg_dbg_cyc), 256) == hipSuccess) fprintf(stderr, "[ssgpu] lane kernel checks: slot %llu job %llu blist %llu (grid %ld J %d bcap %d ccap %d lds %zu nj %ld)\n", dc[24], dc[25], dc[26], grid, J, bcap, ccap, lds, nj); }
+#endif
+	return rc;
+}
+
+int ssg_align2_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *jobs, const int64_t *tpos,
+                          const uint8_t *qbuf, size_t qbytes, int lanes, ssg_kswr_t *res, int32_t *from_lane)
+{
+	CHK(need_device());
+	if (n_jobs <= 0) return 0;
+	int max_t = 1, max_qp = 16;
+	std::vector<ssg_msjob_t> hj((size_t)n_jobs); std::vector<uint64_t> hk;
+	for (int i = 0; i < n_jobs; ++i) {
+		const ssg_sw_job_t &jb = jobs[i];
+		if (jb.qlen > 256 || jb.qlen < 1 || jb.tlen < 0) { ssg_err_msg = "ssg_align2_lane_batch: 1 <= qlen <= 256, tlen >= 0"; return SSG_EINVAL; }
+		const int64_t last = tpos[i] + jb.tlen - 1;
+		if (jb.tlen > 0 && (tpos[i] < 0 || last >= 2 * idx->v.l_pac || (tpos[i] < idx->v.l_pac) != (last < idx->v.l_pac))) {
+			ssg_err_msg = "ssg_align2_lane_batch: a target leaves its strand of the doubled reference"; return SSG_EINVAL; }
+		max_t = std::max(max_t, jb.tlen);
+		ssg_msjob_t m; m.rb = tpos[i]; m.qoff = jb.qoff; m.tlen = jb.tlen; m.qlen = jb.qlen; m._pad = 0; m.is_rev = 0;
+		m.qp = (jb.xtra & SSG_KSW_XBYTE) ? (jb.qlen + 15) / 16 * 16 : (jb.qlen + 7) / 8 * 8;
+		m.minsc = (jb.xtra & SSG_KSW_XSUBO) ? jb.xtra & 0xffff : 0x10000;
+		hj[(size_t)i] = m;
+		const bool fits = opt->a >= 1 && opt->a <= 15 && opt->b >= 0 && opt->b <= 16 && jb.qlen * opt->a <= 8190;
+		if (fits && !(jb.xtra & SSG_KSW_XSTOP) && jb.tlen > 0 && jb.tlen <= SSG_ML_TMAX) { hk.push_back((uint64_t)m.qp << 48 | (uint64_t)m.tlen << 32 | (uint64_t)i); max_qp = std::max(max_qp, m.qp); }
+	}
+	dbuf<ssg_sw_job_t> dj(n_jobs); dbuf<ssg_msjob_t> dm(n_jobs); dbuf<ssg_msres_t> df(n_jobs); dbuf<int64_t> dp(n_jobs); dbuf<uint8_t> dq(qbytes + 1), dt((size_t)n_jobs * (max_t + 1));
+	dbuf<ssg_kswr_t> dr(n_jobs); dbuf<unsigned long long> db((size_t)n_jobs * (max_t + 1)); dbuf<uint64_t> dk(hk.size() + 1); dbuf<int32_t> du(n_jobs);
+	CHKA(dj); CHKA(dm); CHKA(df); CHKA(dp); CHKA(dq); CHKA(dt); CHKA(dr); CHKA(db); CHKA(dk); CHKA(du);
+	CHK(dj.up(jobs, n_jobs)); CHK(dm.up(hj.data(), n_jobs)); CHK(dp.up(tpos, n_jobs)); CHK(dq.up(qbuf, qbytes)); CHK(df.zero());
+	if (!hk.empty()) { CHK(dk.up(hk.data(), hk.size())); CHK(run_msw_lane(idx, opt, (long)hk.size(), dk.p, dm.p, dq.p, df.p, max_qp, max_t, lanes, 0, (long)n_jobs, (long)qbytes)); }
+	const int wpb = 4;
+	SSG_LAUNCH(ssg_k_align2_fin_jobs, (n_jobs + wpb - 1) / wpb, wpb * 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dq.p, df.p, dr.p, dt.p, max_t + 1, db.p, max_t + 1, du.p);
+	CHK(rt_sync());
+	if (from_lane) CHK(du.down(from_lane, n_jobs));
+	return dr.down(res, n_jobs);
+}
+
 int ssg_global_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_glb_job_t *jobs, const uint8_t *qbuf, size_t qbytes,
                      const uint8_t *tbuf, size_t tbytes, int32_t *score, int32_t *n_cigar, uint32_t *cigar, int cap)
 {
@@ -600,6 +683,7 @@ static int dev_class_counts(const int32_t *d_key, long n, int tA, int tB, int tC
 /* ------------------------------- mem_align1_core for a batch ------------------------------- */
 struct align1_dev_t {	/* device-resident result of stages 1-4 */
 	dbuf<int64_t> seed_off; dbuf<ssg_alnreg_t> regs; dbuf<int32_t> n_reg;
+	dbuf<uint8_t> sdp_fixed;   /* per read: its region list is a fixed point of the redundancy scan (no patch alignment was involved) */
 	std::vector<int64_t> h_seed_off; int64_t tot_seeds;
 };
 
@@ -759,11 +843,13 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		/* light reads one lane each; what is left (long lists, later-seed extensions, patches) one wave each */
 		dbuf<int32_t> d_todo((size_t)n_reads); dbuf<unsigned int> d_ntodo(1);
 		CHKA(d_todo); CHKA(d_ntodo); CHK(d_ntodo.zero());
+		if (!o.sdp_fixed.alloc((size_t)n_reads)) { ssg_err_msg = "device allocation failed: sdp_fixed"; return SSG_ENOMEM; }
+		CHK(o.sdp_fixed.zero());
 		SSG_LAUNCH(ssg_k_chain2aln_lane, (n_reads + 63) / 64, 64, 0, idx->v, *opt, n_reads, d_off, o.seed_off.p, d_seeds.p, d_cseeds.p, d_nchain.p, o.regs.p, o.n_reg.p, d_err.p,
-		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_work.p, d_todo.p, d_ntodo.p);
+		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_work.p, d_todo.p, d_ntodo.p, o.sdp_fixed.p);
 		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
 		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p, ssg_debug() >= 2, d_sdpbig.p, d_bcopy.p,
-		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_todo.p, d_ntodo.p);
+		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_todo.p, d_ntodo.p, o.sdp_fixed.p);
 		CHK(rt_sync());
 	}
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_err.p, n_reads, 0, 0, 0, cc)); if (cc[4]) { ssg_err_msg = "reference window of a chain exceeds SSG_TWIN_GLB"; return SSG_EOVERFLOW; } }
@@ -920,7 +1006,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	CHK(dev_exclusive_scan(d_cap2.p, d_r2off.p, n_reads, &t2)); CHK(dev_exclusive_scan(d_capq.p, d_reqoff.p, n_reads, &tq));
 	CHK(dev_order_desc(d_pkey.p, d_pw.p, n_pairs));   /* heaviest-first pair order for the pairing-stage kernels (key: candidate regions of both ends) */
 	dbuf<ssg_alnreg_t> d_regs2((size_t)t2 + 1); dbuf<int32_t> d_perr(n_pairs), d_zbuf((size_t)t2 + 1), d_nreq(n_reads), d_gerr(1);
-	dbuf<unsigned long long> d_cnt(2);
+	dbuf<unsigned long long> d_cnt(3);   /* SW cells, mate rescues, rescues whose forward pass was computed ahead of the decision */
 	CHKA(d_regs2); CHKA(d_perr); CHKA(d_zbuf); CHKA(d_nreq); CHKA(d_cnt); CHKA(d_gerr);
 	CHK(d_perr.zero()); CHK(d_cnt.zero()); CHK(d_gerr.zero());
 	SSG_LAUNCH(ssg_k_copy_regs, (n_reads + block - 1) / block, block, 0, n_reads, a1.seed_off.p, a1.regs.p, a1.n_reg.p, d_r2off.p, d_regs2.p);
@@ -935,9 +1021,46 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		dbuf<int32_t> d_mtodo((size_t)n_pairs); dbuf<unsigned int> d_nmtodo(1);
 		CHKA(d_mtodo); CHKA(d_nmtodo); CHK(d_nmtodo.zero());
 		SSG_LAUNCH(ssg_k_matesw_need, (n_pairs + 63) / 64, 64, 0, idx->v, *opt, n_pairs, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_pw.p, d_mtodo.p, d_nmtodo.p);
+		/* the windows' forward passes ahead of the decisions (k_mswlane.h): lanes per job; 0 = everything through the wave code */
+		dbuf<ssg_msres_t> d_jres; dbuf<int64_t> d_jbase;
+		const int ml_lanes = env_int("SSG_MSW_LANES", 4);
+		bool have_slots = false;
+		if (ml_lanes > 0) {
+			unsigned int n_todo = 0;
+			CHK(d_nmtodo.down(&n_todo, 1));
+			if (n_todo > 0 && n_todo < (1u << 30)) {
+				dbuf<int32_t> d_jcnt((size_t)2 * n_todo);
+				if (!d_jbase.alloc((size_t)2 * n_todo + 1)) { ssg_err_msg = "device allocation failed: mate rescue slots"; return SSG_ENOMEM; }
+				CHKA(d_jcnt);
+				SSG_LAUNCH(ssg_k_msw_count, (n_todo + 63) / 64, 64, 0, *opt, (int)n_todo, d_mtodo.p, d_r2off.p, d_regs2.p, a1.n_reg.p, d_jcnt.p);
+				int64_t nslot = 0;
+				STAGE("msw_count");
+				CHK(dev_exclusive_scan(d_jcnt.p, d_jbase.p, 2L * n_todo, &nslot));
+				STAGE("msw_scan");
+				if (nslot > 0 && nslot < (1LL << 31)) {
+					dbuf<ssg_msjob_t> d_jobs((size_t)nslot); dbuf<uint64_t> d_keys((size_t)nslot); dbuf<unsigned int> d_nj(2);   /* windows; the longest */
+					if (!d_jres.alloc((size_t)nslot)) { ssg_err_msg = "device allocation failed: mate rescue slots"; return SSG_ENOMEM; }
+					CHKA(d_jobs); CHKA(d_keys); CHKA(d_nj); CHK(d_nj.zero()); CHK(d_jres.zero());
+					SSG_LAUNCH(ssg_k_msw_emit, (nslot / 4 + 63) / 64, 64, 0, idx->v, *opt, (int)n_todo, (long)(nslot / 4), d_mtodo.p, d_jbase.p, d_off.p, d_r2off.p, d_regs2.p, a1.n_reg.p,
+					           d_pb.p, d_pes.p, d_jobs.p, d_keys.p, d_nj.p);
+					STAGE("msw_emit");
+					int64_t seq_bytes = 0;
+					CHK(rt_d2h(&seq_bytes, d_off.p + n_reads, 8));
+					unsigned int njt[2] = { 0, 0 };
+					CHK(d_nj.down(njt, 2));
+					const unsigned int nj = njt[0];
+					CHK(run_msw_lane(idx, opt, (long)nj, d_keys.p, d_jobs.p, d_seq.p, d_jres.p, (max_len + 15) / 16 * 16, (int)njt[1], ml_lanes, 0, (long)nslot, (long)seq_bytes));
+					have_slots = env_int("SSG_MSW_USE", 1) != 0;   /* 0: diagnostic -- the windows are computed and not used */
+					if (ssg_debug()) fprintf(stderr, "[ssgpu] mate rescue: %u listed pairs, %lld slots, %u windows ahead of the decision\n", n_todo, (long long)nslot, nj);
+				}
+			}
+		}
 		SSG_LAUNCH(ssg_k_matesw, nwg, wpb * 64, 0, idx->v, *opt, n_pairs, d_seq.p, d_off.p, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p,
-		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1, d_mtodo.p, d_q.p, d_sdpbig.p, d_nmtodo.p);
+		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1, d_mtodo.p, d_q.p, d_sdpbig.p, d_nmtodo.p,
+		           have_slots ? (const ssg_msres_t*)d_jres.p : (const ssg_msres_t*)0, have_slots ? (const int64_t*)d_jbase.p : (const int64_t*)0,
+		           env_int("SSG_MSW_FIXED", 1) ? (const uint8_t*)a1.sdp_fixed.p : (const uint8_t*)0);
 		CHK(rt_sync());
+		if (ssg_debug()) { unsigned long long c[3]; CHK(d_cnt.down(c, 3)); fprintf(stderr, "[ssgpu] mate rescue: %llu windows aligned, %llu of them ahead of the decision\n", c[1], c[2]); }
 	}
 	STAGE("matesw");
 	dbuf<ssg_alnreq_t> d_req((size_t)tq + 1);

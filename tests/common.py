@@ -159,6 +159,54 @@ def check_extend_lane(lib, oracle, n, seed, workdir, qcaps=(72, 136, 256)):
     return done
 
 
+def check_local_lane(lib, oracle, n, seed, workdir, lanes=(1, 2, 4), scores=None):
+    """ksw_align2 as mate rescue runs it in the product path (k_mswlane.h: forward pass by the lane kernel -- strips of 8 target rows in
+    registers, packed 13-bit strip boundaries in LDS, 5-bit score table, targets from the 2-bit reference --, reverse pass by the wave code)
+    against the oracle: make_local_jobs' queries (36 .. 250 bases, some with N) and targets (hits, half hits, second hits, none), the targets
+    laid out as a reference of their own and read from both strands, 1 / 2 / 4 lanes per job."""
+    rng = np.random.default_rng(seed)
+    jobs, qs, ts = make_local_jobs(n, seed)
+    for i in range(n):
+        if rng.random() < 0.2:   # N bases in the query
+            q = qs[i].copy(); q[rng.random(q.size) < 0.03] = 4; qs[i] = q
+        if ts[i].size == 0:
+            ts[i] = rng.integers(0, 4, size=40, dtype=np.uint8)
+    to = 0
+    for i in range(n):
+        jobs[i]["toff"] = to; jobs[i]["tlen"] = ts[i].size; to += ts[i].size
+    tcat = np.concatenate(ts)
+    fa = os.path.join(str(workdir), "locallane_%d.fa" % seed)
+    with open(fa, "w") as f:
+        f.write(">t\n")
+        txt = "".join("ACGT"[c] for c in tcat)
+        for k in range(0, len(txt), 80):
+            f.write(txt[k:k + 80] + "\n")
+    idx = lib.index_build_fasta(fa)
+    L = int(tcat.size)
+    starts = jobs["toff"].astype(np.int64)
+    tl = jobs["tlen"].astype(np.int64)
+    opt, oopt = lib.opt_init(), None
+    if scores:   # (a, b, o_del, e_del, o_ins, e_ins)
+        for k, v in zip(("a", "b", "o_del", "e_del", "o_ins", "e_ins"), scores):
+            opt[k] = v
+        m = opt["mat"][0]
+        for x in range(4):
+            for y in range(4):
+                m[x * 5 + y] = scores[0] if x == y else -scores[1]
+        oopt = oracle.opt_scores(*scores)
+    done = taken = 0
+    for name, tpos, view in (("fwd", starts, lambda t: t), ("rev", 2 * L - starts - tl, lambda t: (3 - t[::-1]).astype(np.uint8))):
+        want = [oracle.align2(qs[i], np.ascontiguousarray(view(ts[i])), int(jobs[i]["xtra"]), oopt) for i in range(n)]
+        for nl in lanes:
+            res, from_lane = lib.align2_lane_batch(idx, opt, jobs, tpos, np.concatenate(qs), nl)
+            for i in range(n):
+                assert want[i] == tuple(int(x) for x in res[i]), (nl, name, i, jobs[i], want[i], res[i], int(from_lane[i]))
+            done += n
+            taken += int(from_lane.sum())
+    lib.index_destroy(idx)
+    return done, taken
+
+
 def check_seeds(lib, oracle, n_pairs, seed, prefix=EXAMPLE_FA, read_len=150):
     """the seeds mem_chain visits (interval -> sampled occurrences -> bwt_sa + bns_intv2rid, upstream's order) straight from ssg_k_sal against the oracle"""
     oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)

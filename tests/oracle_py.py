@@ -46,9 +46,15 @@ class Oracle:
         self.l.orc_api_extend2(self.opt, C.c_int(len(q)), _ptr(q), C.c_int(len(t)), _ptr(t), C.c_int(w), C.c_int(end_bonus), C.c_int(zdrop), C.c_int(h0), out)
         return tuple(out)
 
-    def align2(self, q, t, xtra):
+    def opt_scores(self, a, b, o_del, e_del, o_ins, e_ins):
+        """an option block of its own with this scoring (release: let it go)"""
+        o = C.c_void_p(self.l.orc_api_opt_new())
+        self.l.orc_api_opt_scores(o, C.c_int(a), C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins))
+        return o
+
+    def align2(self, q, t, xtra, opt=None):
         out = (C.c_int * 7)()
-        self.l.orc_api_align2(self.opt, C.c_int(len(q)), _ptr(q), C.c_int(len(t)), _ptr(t), C.c_int(xtra), out)
+        self.l.orc_api_align2(opt or self.opt, C.c_int(len(q)), _ptr(q), C.c_int(len(t)), _ptr(t), C.c_int(xtra), out)
         return tuple(out)
 
     def global2(self, q, t, w, cap=64):

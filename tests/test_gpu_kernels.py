@@ -29,6 +29,17 @@ def test_gpu_local(gpu_lib, oracle):
     common.check_local(gpu_lib, oracle, 400, seed=12)
 
 
+def test_gpu_local_lane_kernel(gpu_lib, oracle, tmp_path):
+    # row a10 as the product path runs it (k_mswlane.h): the forward pass of ksw_align2 by ssg_k_msw_lane with 1 / 2 / 4 lanes per job, the
+    # reverse pass by the wave code; both strands of the 2-bit reference, N in queries, other scoring
+    done, taken = common.check_local_lane(gpu_lib, oracle, 1500, seed=71, workdir=tmp_path)
+    assert done == 9000 and taken > 8000
+    done, taken = common.check_local_lane(gpu_lib, oracle, 600, seed=72, workdir=tmp_path, scores=(2, 5, 7, 2, 9, 1))
+    assert done == 3600 and taken > 3000
+    done, taken = common.check_local_lane(gpu_lib, oracle, 300, seed=73, workdir=tmp_path, lanes=(4,), scores=(1, 4, 6, 1, 6, 1))
+    assert done == 600
+
+
 def test_gpu_global(gpu_lib, oracle):
     common.check_global(gpu_lib, oracle, 1000, seed=13)
 

@@ -24,6 +24,14 @@ def test_emu_local(emu_lib, oracle):
     common.check_local(emu_lib, oracle, 60, seed=2)
 
 
+def test_emu_local_lane_kernel(emu_lib, oracle, tmp_path):
+    # row a10 as the product path runs it: forward pass by ssg_k_msw_lane (1 / 2 / 4 lanes per job), reverse pass by the wave code
+    done, taken = common.check_local_lane(emu_lib, oracle, 40, seed=71, workdir=tmp_path)
+    assert done == 240 and taken > 200
+    done, taken = common.check_local_lane(emu_lib, oracle, 24, seed=72, workdir=tmp_path, lanes=(4,), scores=(2, 5, 7, 2, 9, 1))
+    assert done == 48 and taken > 40
+
+
 def test_emu_global(emu_lib, oracle):
     common.check_global(emu_lib, oracle, 150, seed=3)
 

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kernels", default="smem", help="comma-separated substrings of the kernel names whose times are listed per configuration")
+    ap.add_argument("--dbg-cycles", action="store_true", help="with an instrumented library (make tune): print the device phase counters after every configuration")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "smem_ab.json"))
     ap.add_argument("configs", nargs="+")
     a = ap.parse_args()
@@ -81,7 +82,12 @@ def main():
             kern = capi.prof_get(lib)
             lib.l.ssg_prof_enable(C.c_int(0))
             seed_ms = {k: round(v[0] / a.steps, 2) for k, v in kern.items() if any(x in k for x in a.kernels.split(","))}
-            r = {"config": cfg, "ms_per_step": round(1e3 * dt, 1), "seeding_kernels_ms": seed_ms, "records": int(summary[0]), "seeds": int(summary[2]), "bwt_extends": int(summary[6]),
+            dbg = None
+            if a.dbg_cycles:
+                out = (C.c_ulonglong * 32)()
+                lib.l.ssg_dbg_cycles(out)
+                dbg = [int(x) for x in out]
+            r = {"config": cfg, "dbg_cycles": dbg, "ms_per_step": round(1e3 * dt, 1), "seeding_kernels_ms": seed_ms, "records": int(summary[0]), "seeds": int(summary[2]), "bwt_extends": int(summary[6]),
                  "chains": int(summary[7]), "dup_pairs": int(summary[1]), "sam_lines": int(summary[10])}
         except Exception as e:   # a configuration that fails must not take the others with it
             r = {"config": cfg, "error": repr(e)}
