@@ -41,9 +41,9 @@ SSG_DEVFN int ssg_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist
 #define SSG_ML_R 8            /* target rows per strip */
 #define SSG_ML_TMAX 8192      /* longest window given to the lane kernel */
 
-/* 40 bytes each; slot = side base + 4 * anchor + orientation */
-struct ssg_msjob_t { int64_t rb, qoff; int32_t tlen, qlen, qp, minsc, is_rev, _pad; };
-struct ssg_msres_t { int64_t rb; int32_t tlen, state, score, te, qe, score2, te2, _pad; };   /* state: 0 = not computed, 1 = forward pass done */
+/* slot = side base + 4 * anchor + orientation.  p = 16 / 8: the padding unit of the query (KSW_XBYTE or not); xstart: KSW_XSTART */
+struct ssg_msjob_t { int64_t rb, qoff; int32_t tlen, qlen, qp, minsc, is_rev, p, xstart, _pad; };                 /* 48 bytes */
+struct ssg_msres_t { int64_t rb; int32_t tlen, state, score, te, qe, score2, te2, tb, qb, _pad; };   /* 48 bytes; state: 0 = not computed, 1 = forward pass, 2 = forward and reverse pass (tb, qb) */
 
 /* the lane kernel trusts no job record: a key that names no slot, or a record with impossible lengths, is skipped (the wave code does that
  * window then); -DSSG_ML_CHECK counts them in ssg_dbg_cyc[24 + code] */
@@ -70,7 +70,7 @@ SSG_DEVFN bool ssg_ml_fits(const ssg_mem_opt_t &opt, int qlen)
 
 /* target bases of 8 consecutive rows: doubled coordinates p .. p + 7 of the 2-bit pac, 4 bits per row (row 0 lowest).  Rows outside the
  * reference read as anything (the caller masks them); every byte index stays inside the pac array. */
-SSG_DEVFN uint32_t ssg_ml_rows8(const ssg_index_view_t &ix, int64_t p)
+SSG_DEVFN uint32_t ssg_ml_rows8_up(const ssg_index_view_t &ix, int64_t p)
 {
 	const int64_t l2 = ix.l_pac << 1, nb = (ix.l_pac >> 2) + 1;
 	const bool fw = p < ix.l_pac;
@@ -88,13 +88,25 @@ SSG_DEVFN uint32_t ssg_ml_rows8(const ssg_index_view_t &ix, int64_t p)
 	return out;
 }
 
+/* REV: rows walk the doubled coordinate downwards from p (the reverse pass: p, p - 1, ...): the ascending fetch of p - 7 .. p, nibbles reversed */
+template <bool REV> SSG_DEVFN uint32_t ssg_ml_rows8(const ssg_index_view_t &ix, int64_t p)
+{
+	if (!REV) return ssg_ml_rows8_up(ix, p);
+	int64_t p0 = p - 7;                                /* rows r > p - p0 lie before the strand's first base: never real rows of a window */
+	if (p0 < ix.l_pac && p >= ix.l_pac) p0 = ix.l_pac;
+	if (p0 < 0) p0 = 0;
+	uint32_t x = ssg_ml_rows8_up(ix, p0) << (4 * (7 - (int)(p - p0)));
+	x = (x >> 16) | (x << 16); x = ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu);   /* bytes reversed */
+	return ((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu);
+}
+
 /*
  * Forward pass of ksw_align2 for the jobs sorted[0 .. n_jobs), L lanes per job.  One wavefront per workgroup; workgroups take chunks of
  * 64 / L jobs from `queue`.  Dynamic LDS: (ccap + 2) * 64 words, ccap >= (largest qp) / L.  bglb: gridDim.x * (64 / L) * bcap entries; bcap >= (longest window) / 2 + 1 holds every b[] list
  * (upstream appends at most every other row).
  * A chunk's jobs must share qp (the sort key's leading field); a job whose qp differs from the chunk's first is left (state 0).
  */
-template <int L>
+template <int L, bool REV>
 __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_jobs, const uint64_t *sorted, const ssg_msjob_t *jobs,
                                const uint8_t *seq, ssg_msres_t *res, unsigned long long *bglb, unsigned int *queue, int ccap, int bcap, unsigned long long *cells, long n_slots, long seq_bytes)
 {
@@ -120,10 +132,16 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 		const long t = chunk * J + jslot;
 		bool pending = t < n_jobs;
 		const long slot = pending ? (long)(uint32_t)sorted[t] : 0;
-		ssg_msjob_t jb; jb.rb = 0; jb.qoff = 0; jb.tlen = 0; jb.qlen = 0; jb.qp = 0; jb.minsc = 0x10000; jb.is_rev = 0; jb._pad = 0;
+		ssg_msjob_t jb; jb.rb = 0; jb.qoff = 0; jb.tlen = 0; jb.qlen = 0; jb.qp = 0; jb.minsc = 0x10000; jb.is_rev = 0; jb.p = 16; jb.xstart = 0; jb._pad = 0;
 		if (pending && !SSG_ML_OK(0, slot < n_slots)) pending = false;
 		if (pending) jb = jobs[slot];
 		if (pending && !SSG_ML_OK(1, jb.qlen >= 1 && jb.qlen <= 256 && jb.tlen >= 1 && jb.tlen <= SSG_ML_TMAX && jb.qoff >= 0 && jb.qoff + jb.qlen <= seq_bytes && jb.rb >= 0 && jb.rb + jb.tlen <= (ix.l_pac << 1))) pending = false;
+		int f_te = 0, f_qe = 0, endsc = 0x10000, q_full = jb.qlen;   /* REV: the forward pass's end (the reverse pass starts there) and its score (where it stops) */
+		if (REV && pending) {	/* upstream ksw_align2: query[0..qe] and target[0..te] reversed, no b[], stop at the forward score */
+			const ssg_msres_t fw = res[slot];
+			if (!SSG_ML_OK(3, fw.state == 1 && fw.te >= 0 && fw.te < jb.tlen && fw.qe >= 0 && fw.qe < jb.qlen && (jb.p == 8 || jb.p == 16))) pending = false;
+			else { f_te = fw.te; f_qe = fw.qe; endsc = fw.score; jb.tlen = fw.te + 1; jb.qlen = fw.qe + 1; jb.qp = (jb.qlen + jb.p - 1) / jb.p * jb.p; jb.minsc = 0x10000; }
+		}
 		for (;;) {	/* one pass per padded query length in the chunk (the jobs are sorted by it: one pass, two where lengths meet) */
 		const unsigned long long pm = wv_ballot(pending);
 		if (pm == 0) break;
@@ -138,17 +156,19 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 			const int j = c * C + cc;
 			int code = 5;
 			if (have && cc < C && j < jb.qlen) {
-				if (jb.is_rev) { const int b0 = seq[jb.qoff + jb.qlen - 1 - j]; code = b0 < 4 ? 3 - b0 : 4; }
-				else code = seq[jb.qoff + j];
+				const int k = REV ? f_qe - j : j;      /* column j of the reverse pass is column qe - j of the forward one */
+				if (jb.is_rev) { const int b0 = seq[jb.qoff + q_full - 1 - k]; code = b0 < 4 ? 3 - b0 : 4; }
+				else code = seq[jb.qoff + k];
 			}
 			Lc[cc * 64] = (uint32_t)(code * 5);
 		}
 		int hA[R], hB[R], f[R], rm[R], dg = 0;
 		SSG_UNROLL for (int r = 0; r < R; ++r) { hA[r] = 0; hB[r] = 0; f[r] = 0; rm[r] = 0; }
-		int gmax = 0, te = -1, qe = 0, n_b = 0, last_sc = 0, last_row = -2;
+		int gmax = 0, te = -1, qe = 0, n_b = 0, last_sc = 0, last_row = -2, done = 0;
 		for (int s = 0; s < nstrip + L - 1; ++s) {
 			const int ks = s - c, i0 = ks * R;
 			const bool act = ks >= 0 && i0 < tlen;
+			if (REV && wv_ballot(have && c == L - 1 && !done && i0 < tlen) == 0) break;   /* every job of the wave has reached its score (or its last row) */
 			/* the left edge of this lane's strip: the right edge of the same strip in the lane to the left (a step ago); column -1 for the job's first lane */
 			if (L > 1) {
 				SSG_UNROLL for (int r = 0; r < R; ++r) { hA[r] = wv_prev(hA[r], 0); f[r] = wv_prev(f[r], 0); rm[r] = wv_prev(rm[r], 0); }
@@ -157,7 +177,7 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 			if (L == 1 || c == 0) { SSG_UNROLL for (int r = 0; r < R; ++r) { hA[r] = 0; f[r] = 0; rm[r] = 0; } dg = 0; }
 			if (wv_ballot(act) == 0) continue;
 			if (act) {
-				const uint32_t rows = ssg_ml_rows8(ix, jb.rb + i0);
+				const uint32_t rows = REV ? ssg_ml_rows8<true>(ix, jb.rb + f_te - i0) : ssg_ml_rows8<false>(ix, jb.rb + i0);
 				uint32_t T[R];
 				SSG_UNROLL for (int r = 0; r < R; ++r) { const uint32_t tb = rows >> (4 * r) & 3u; T[r] = t_mis ^ (t_x << (5 * tb)); }
 				int tag = 255 - c * C;
@@ -201,20 +221,28 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 				if (c == L - 1) {	/* the rows of this strip are complete: upstream's per-row bookkeeping, in row order */
 					SSG_UNROLL for (int r = 0; r < R; ++r) {
 						const int i = i0 + r, imax = rm[r] >> 8;
-						if (i < tlen) {
-							if (imax >= jb.minsc) {
+						if (i < tlen && !done) {
+							if (!REV && imax >= jb.minsc) {
 								const unsigned long long pk = (unsigned long long)imax << 32 | (unsigned)i;
 								if (n_b == 0 || last_row + 1 != i) { last_sc = imax; last_row = i; if (n_b < bcap && SSG_ML_OK(2, ((long)blockIdx.x * J + jslot) * bcap + n_b < (long)gridDim.x * J * bcap)) bl[n_b] = pk; ++n_b; }
 								else if (last_sc < imax) { last_sc = imax; last_row = i; if (n_b <= bcap) bl[n_b - 1] = pk; }
 							}
-							if (imax > gmax) { gmax = imax; te = i; qe = 255 - (rm[r] & 255); }
+							if (imax > gmax) { gmax = imax; te = i; qe = 255 - (rm[r] & 255); if (REV && gmax >= endsc) done = 1; }
 						}
 					}
 				}
 			}
 		}
+		if (REV) {
+			if (have && c == L - 1) {	/* upstream: the start is known when the reverse pass reaches the forward score */
+				ssg_msres_t o = res[slot];
+				o.state = 2; o.tb = o.qb = -1;
+				if (gmax == endsc) { o.tb = f_te - te; o.qb = f_qe - qe; }
+				res[slot] = o;
+			}
+		} else
 		if (have && c == L - 1) {
-			ssg_msres_t o; o.rb = jb.rb; o.tlen = jb.tlen; o.state = n_b <= bcap ? 1 : 0; o.score = gmax; o.te = te; o.qe = qe; o.score2 = -1; o.te2 = -1; o._pad = 0;
+			ssg_msres_t o; o.rb = jb.rb; o.tlen = jb.tlen; o.state = n_b <= bcap ? 1 : 0; o.score = gmax; o.te = te; o.qe = qe; o.score2 = -1; o.te2 = -1; o.tb = o.qb = -1; o._pad = 0;
 			if (n_b && n_b <= bcap) {
 				const int k = (gmax + maxsc - 1) / maxsc, low = te - k, high = te + k;
 				for (int x = 0; x < n_b; ++x) {
@@ -228,6 +256,21 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 		}
 	}
 	if (cells && ncell) atomicAdd(cells, ncell);
+}
+
+/* the jobs whose forward pass calls for the reverse pass (upstream ksw_align2: KSW_XSTART, and with KSW_XSUBO only a score that reached minsc):
+ * one lane per sorted job; keys[] = padded length of the reversed query prefix << 48 | rows (te + 1) << 32 | slot; n_out[1] = most rows */
+__global__ void __launch_bounds__(64) ssg_k_msw_revlist(long n_jobs, const uint64_t *sorted, const ssg_msjob_t *jobs, const ssg_msres_t *res, long n_slots, uint64_t *keys, unsigned int *n_out)
+{
+	const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_jobs) return;
+	const long slot = (long)(uint32_t)sorted[t];
+	if (slot >= n_slots) return;
+	const ssg_msjob_t jb = jobs[slot]; const ssg_msres_t r = res[slot];
+	if (r.state != 1 || !jb.xstart || (jb.minsc != 0x10000 && r.score < jb.minsc) || r.te < 0 || r.qe < 0 || (jb.p != 8 && jb.p != 16)) return;
+	const int qp = (r.qe + 1 + jb.p - 1) / jb.p * jb.p;
+	keys[atomicAdd(n_out, 1u)] = (uint64_t)qp << 48 | (uint64_t)(r.te + 1) << 32 | (uint64_t)slot;
+	atomicMax(n_out + 1, (unsigned int)(r.te + 1));
 }
 
 /* ---------------- which windows will mem_matesw align?  (the lists before any rescue) ---------------- */
@@ -301,7 +344,7 @@ __global__ void __launch_bounds__(64) ssg_k_msw_emit(ssg_index_view_t ix, ssg_me
 		if (re - rb > SSG_ML_TMAX) continue;
 		const int xtra = SSG_KSW_XSUBO | SSG_KSW_XSTART | (l_ms * opt.a < 250 ? SSG_KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
 		ssg_msjob_t jb; jb.rb = rb; jb.qoff = read_off[2*p + !i]; jb.tlen = (int)(re - rb); jb.qlen = l_ms; jb.qp = ssg_align2_qp(l_ms, xtra);
-		jb.minsc = xtra & 0xffff; jb.is_rev = is_rev; jb._pad = 0;
+		jb.minsc = xtra & 0xffff; jb.is_rev = is_rev; jb.p = (xtra & SSG_KSW_XBYTE) ? 16 : 8; jb.xstart = 1; jb._pad = 0;
 		const long slot = base[side] + 4 * j + r;
 		jobs[slot] = jb;
 		keys[atomicAdd(n_jobs, 1u)] = (uint64_t)jb.qp << 48 | (uint64_t)jb.tlen << 32 | (uint64_t)slot;

@@ -102,10 +102,11 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			unsigned long long c0 = ssg_clock();
 			const int xtra = SSG_KSW_XSUBO | SSG_KSW_XSTART | (l_ms * opt.a < 250 ? SSG_KSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
 			ssg_kswr_t aln;
-			int pre = 0;   /* the window's forward pass is in its slot (same window: start and length checked) */
-			if (jres) pre = wv_get((int)(jres[r].state == 1 && jres[r].rb == rb && jres[r].tlen == (int)(re - rb)), 0);
+			int pre = 0;   /* the window's forward pass (1), and its reverse pass too (2), are in its slot (same window: start and length checked) */
+			if (jres) pre = wv_get(jres[r].state >= 1 && jres[r].rb == rb && jres[r].tlen == (int)(re - rb) ? jres[r].state : 0, 0);
 			if (pre) { aln.score = wv_get(jres[r].score, 0); aln.te = wv_get(jres[r].te, 0); aln.qe = wv_get(jres[r].qe, 0); aln.score2 = wv_get(jres[r].score2, 0); aln.te2 = wv_get(jres[r].te2, 0); aln.tb = aln.qb = -1; ++*npre; if (cells) *cells += (unsigned long long)(re - rb) * l_ms; }
-			const bool want_rev = !pre || ssg_align2_has_rev(xtra, aln.score);   /* only a window that reached minsc has a reverse pass */
+			if (pre == 2) { aln.tb = wv_get(jres[r].tb, 0); aln.qb = wv_get(jres[r].qb, 0); }
+			const bool want_rev = !pre || (pre == 1 && ssg_align2_has_rev(xtra, aln.score));   /* only a window that reached minsc has a reverse pass */
 			if (want_rev) wv_fetch_ref(ix, rb, pre ? rb + aln.te + 1 : re, tbuf);
 			ph[0] += ssg_clock() - c0; c0 = ssg_clock();
 			ssg_seqv_t q;
@@ -120,7 +121,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			ssg_seqv_t t = { tbuf, 1 };
 			if (!pre) aln = wv_align2(opt, l_ms, q, (int)(re - rb), t, xtra, bscratch, cells);
 			else if (want_rev) wv_align2_rev(opt, l_ms, q, t, xtra, aln, bscratch, cells);
-			if (SSG_TUNING && wv_lane() == 0) { if (pre && want_rev) { atomicAdd(&ssg_dbg_cyc[29], 1ull); atomicAdd(&ssg_dbg_cyc[30], (unsigned long long)(aln.te + 1)); } if (!pre) atomicAdd(&ssg_dbg_cyc[31], 1ull); }
+			if (SSG_TUNING && wv_lane() == 0) { if (pre == 1 && want_rev) { atomicAdd(&ssg_dbg_cyc[29], 1ull); atomicAdd(&ssg_dbg_cyc[30], (unsigned long long)(aln.te + 1)); } if (!pre) atomicAdd(&ssg_dbg_cyc[31], 1ull); }
 			ph[1] += ssg_clock() - c0; if (SSG_TUNING) ph[3] += (unsigned long long)(re - rb);
 			if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
 				ssg_alnreg_t b;

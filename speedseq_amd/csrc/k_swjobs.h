@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane_jobs(ssg_index_view_t ix, s
 }
 
 /* Stage-level twin of mate rescue's alignment path (row a10; k_mswlane.h + k_pair.h wv_matesw): the forward pass of job i comes from the
- * lane kernel's slot fwd[i] when it is there (state 1, same window), the reverse pass -- or the whole call -- from the wave code, on the
+ * lane kernel's slot fwd[i] when it is there (state 1, same window), the reverse pass too when the lane kernel ran it (state 2), else that pass -- or the whole call -- from the wave code, on the
  * job's window decoded from the index's 2-bit reference: tlen bases from doubled coordinate tpos[i]. */
 __global__ void __launch_bounds__(256) ssg_k_align2_fin_jobs(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_jobs, const ssg_sw_job_t *jobs, const int64_t *tpos, const uint8_t *qbuf,
                                   const ssg_msres_t *fwd, ssg_kswr_t *res, uint8_t *tglb, int tstride, unsigned long long *bscratch, int bstride, int32_t *from_lane)
@@ -52,10 +52,11 @@ __global__ void __launch_bounds__(256) ssg_k_align2_fin_jobs(ssg_index_view_t ix
 	const ssg_sw_job_t jb = jobs[wid];
 	uint8_t *tb = tglb + wid * (long)tstride;
 	const int64_t rb = tpos[wid];
-	const int pre = wv_get((int)(fwd[wid].state == 1 && fwd[wid].rb == rb && fwd[wid].tlen == jb.tlen), 0);
+	const int pre = wv_get(fwd[wid].state >= 1 && fwd[wid].rb == rb && fwd[wid].tlen == jb.tlen ? fwd[wid].state : 0, 0);
 	ssg_kswr_t r;
 	if (pre) { r.score = wv_get(fwd[wid].score, 0); r.te = wv_get(fwd[wid].te, 0); r.qe = wv_get(fwd[wid].qe, 0); r.score2 = wv_get(fwd[wid].score2, 0); r.te2 = wv_get(fwd[wid].te2, 0); r.tb = r.qb = -1; }
-	const bool want_rev = !pre || ssg_align2_has_rev(jb.xtra, r.score);
+	if (pre == 2) { r.tb = wv_get(fwd[wid].tb, 0); r.qb = wv_get(fwd[wid].qb, 0); }
+	const bool want_rev = !pre || (pre == 1 && ssg_align2_has_rev(jb.xtra, r.score));
 	ssg_wave_memsync();
 	if (want_rev) for (int k = wv_lane(); k < (pre ? r.te + 1 : jb.tlen); k += 64) tb[k] = (uint8_t)ssg_ref_base(ix, rb + k);
 	ssg_wave_memsync();

@@ -427,7 +427,7 @@ static int sort_keys_u64(uint64_t *k_in, uint64_t *k_out, long n, int begin_bit,
  * max_qp / max_tlen = the largest padded query length / window length among the jobs (LDS columns per lane = max_qp / lanes;
  * b[] entries per job = max_tlen / 2 + 2). */
 static int run_msw_lane(const ssg_index_t *idx, const ssg_mem_opt_t *opt, long nj, uint64_t *d_keys, const ssg_msjob_t *d_jobs, const uint8_t *d_seq, ssg_msres_t *d_res,
-                        int max_qp, int max_tlen, int lanes, unsigned long long *d_cells, long n_slots, long seq_bytes)
+                        int max_qp, int max_tlen, int lanes, unsigned long long *d_cells, long n_slots, long seq_bytes, bool rev = false)
 {
 	if (nj <= 0) return 0;
 	if (lanes != 1 && lanes != 2 && lanes != 4) { ssg_err_msg = "mate rescue lane kernel: 1, 2 or 4 lanes per job"; return SSG_EINVAL; }
@@ -458,12 +458,21 @@ static int run_msw_lane(const ssg_index_t *idx, const ssg_mem_opt_t *opt, long n
 	const long nchunk = (nj + J - 1) / J;
 	const long resident = 256L * std::min<long>(16, (long)(160 * 1024 / lds));
 	const long grid = std::min(nchunk, std::max(resident, 1L));
-	const int bcap = max_tlen / 2 + 2;
+	const int bcap = rev ? 1 : max_tlen / 2 + 2;
 	dbuf<unsigned long long> d_bl((size_t)grid * J * bcap);
 	CHKA(d_bl);
-	if (lanes == 4) SSG_LAUNCH(ssg_k_msw_lane<4>, grid, 64, lds, idx->v, *opt, nj, d_sorted.p, d_jobs, d_seq, d_res, d_bl.p, d_q.p, ccap, bcap, d_cells, n_slots, seq_bytes);
-	else if (lanes == 2) SSG_LAUNCH(ssg_k_msw_lane<2>, grid, 64, lds, idx->v, *opt, nj, d_sorted.p, d_jobs, d_seq, d_res, d_bl.p, d_q.p, ccap, bcap, d_cells, n_slots, seq_bytes);
-	else SSG_LAUNCH(ssg_k_msw_lane<1>, grid, 64, lds, idx->v, *opt, nj, d_sorted.p, d_jobs, d_seq, d_res, d_bl.p, d_q.p, ccap, bcap, d_cells, n_slots, seq_bytes);
+#define SSG_ML_GO(LL, RR) SSG_LAUNCH((ssg_k_msw_lane<LL, RR>), grid, 64, lds, idx->v, *opt, nj, d_sorted.p, d_jobs, d_seq, d_res, d_bl.p, d_q.p, ccap, bcap, d_cells, n_slots, seq_bytes)
+	if (rev) { if (lanes == 4) SSG_ML_GO(4, true); else if (lanes == 2) SSG_ML_GO(2, true); else SSG_ML_GO(1, true); }
+	else { if (lanes == 4) SSG_ML_GO(4, false); else if (lanes == 2) SSG_ML_GO(2, false); else SSG_ML_GO(1, false); }
+#undef SSG_ML_GO
+	if (!rev && env_int("SSG_MSW_REV", 1)) {	/* the reverse passes (KSW_XSTART) of the windows that call for one, the same way */
+		dbuf<uint64_t> d_rkeys((size_t)nj); dbuf<unsigned int> d_nr(2);
+		CHKA(d_rkeys); CHKA(d_nr); CHK(d_nr.zero());
+		SSG_LAUNCH(ssg_k_msw_revlist, (nj + 63) / 64, 64, 0, nj, d_sorted.p, d_jobs, d_res, n_slots, d_rkeys.p, d_nr.p);
+		unsigned int nr[2] = { 0, 0 };
+		CHK(d_nr.down(nr, 2));
+		if (nr[0]) CHK(run_msw_lane(idx, opt, (long)nr[0], d_rkeys.p, d_jobs, d_seq, d_res, max_qp, (int)nr[1], lanes, 0, n_slots, seq_bytes, true));
+	}
 	int rc = rt_sync();   /* the temporaries are released on return */
 #if defined(SSG_ML_CHECK) && !defined(SSG_EMU)
 	{ unsigned long long dc[32]; if (hipMemcpyFromSymbol(dc, HIP_SYMBOL(ssg_dbg_cyc), 256) == hipSuccess) fprintf(stderr, "[ssgpu] lane kernel checks: slot %llu job %llu blist %llu (grid %ld J %d bcap %d ccap %d lds %zu nj %ld)\n", dc[24], dc[25], dc[26], grid, J, bcap, ccap, lds, nj); }
@@ -485,7 +494,7 @@ int ssg_align2_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
 		if (jb.tlen > 0 && (tpos[i] < 0 || last >= 2 * idx->v.l_pac || (tpos[i] < idx->v.l_pac) != (last < idx->v.l_pac))) {
 			ssg_err_msg = "ssg_align2_lane_batch: a target leaves its strand of the doubled reference"; return SSG_EINVAL; }
 		max_t = std::max(max_t, jb.tlen);
-		ssg_msjob_t m; m.rb = tpos[i]; m.qoff = jb.qoff; m.tlen = jb.tlen; m.qlen = jb.qlen; m._pad = 0; m.is_rev = 0;
+		ssg_msjob_t m; m.rb = tpos[i]; m.qoff = jb.qoff; m.tlen = jb.tlen; m.qlen = jb.qlen; m._pad = 0; m.is_rev = 0; m.p = (jb.xtra & SSG_KSW_XBYTE) ? 16 : 8; m.xstart = (jb.xtra & SSG_KSW_XSTART) ? 1 : 0;
 		m.qp = (jb.xtra & SSG_KSW_XBYTE) ? (jb.qlen + 15) / 16 * 16 : (jb.qlen + 7) / 8 * 8;
 		m.minsc = (jb.xtra & SSG_KSW_XSUBO) ? jb.xtra & 0xffff : 0x10000;
 		hj[(size_t)i] = m;

@@ -195,14 +195,17 @@ def check_local_lane(lib, oracle, n, seed, workdir, lanes=(1, 2, 4), scores=None
                 m[x * 5 + y] = scores[0] if x == y else -scores[1]
         oopt = oracle.opt_scores(*scores)
     done = taken = 0
-    for name, tpos, view in (("fwd", starts, lambda t: t), ("rev", 2 * L - starts - tl, lambda t: (3 - t[::-1]).astype(np.uint8))):
-        want = [oracle.align2(qs[i], np.ascontiguousarray(view(ts[i])), int(jobs[i]["xtra"]), oopt) for i in range(n)]
+    rc = lambda a: np.where(a[::-1] < 4, 3 - a[::-1], 4).astype(np.uint8)
+    for name, tpos, view, qview in (("fwd", starts, lambda t: t, lambda q: q), ("rev", 2 * L - starts - tl, rc, rc)):   # the reverse strand reads the windows reverse-complemented: so are the queries, or nothing would hit
+        qv = [np.ascontiguousarray(qview(q)) for q in qs]
+        want = [oracle.align2(qv[i], np.ascontiguousarray(view(ts[i])), int(jobs[i]["xtra"]), oopt) for i in range(n)]
         for nl in lanes:
-            res, from_lane = lib.align2_lane_batch(idx, opt, jobs, tpos, np.concatenate(qs), nl)
+            res, from_lane = lib.align2_lane_batch(idx, opt, jobs, tpos, np.concatenate(qv), nl)
             for i in range(n):
                 assert want[i] == tuple(int(x) for x in res[i]), (nl, name, i, jobs[i], want[i], res[i], int(from_lane[i]))
             done += n
-            taken += int(from_lane.sum())
+            taken += int((from_lane > 0).sum())
+            assert (from_lane == 2).sum() > n // 4, "the reverse passes did not go through the lane kernel"
     lib.index_destroy(idx)
     return done, taken
 
