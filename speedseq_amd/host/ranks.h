@@ -29,6 +29,10 @@
 static inline int rk_world() { const char *e = getenv("SSG_WORLD"); return e && atoi(e) > 1 ? atoi(e) : 1; }
 static inline int rk_rank() { const char *e = getenv("SSG_RANK"); return e ? atoi(e) : 0; }
 static inline std::string rk_dir() { const char *e = getenv("SSG_RDV"); return e ? e : ""; }
+/* where the ranks' BULK data goes -- the sorts' exchange runs with their ordinals, the batches of a served (compressed) input: SSG_RDV_DATA, a
+ * directory on disk that bin/speedseq-ranks makes next to the output (a whole genome's records do not belong in a memory file system);
+ * SSG_RDV itself keeps the socket and the small marker files */
+static inline std::string rk_data_dir() { const char *e = getenv("SSG_RDV_DATA"); return e && *e ? e : rk_dir(); }
 static inline bool rk_check(const char *who)
 {
 	if (rk_world() == 1) return true;

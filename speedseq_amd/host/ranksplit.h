@@ -147,12 +147,12 @@ static inline bool rs_scan_and_publish(const std::string &rdv, const char *f1, c
 		if (!e.pairs) continue;
 		if (served) {
 			const double t0 = rk_now(); struct stat sb;   /* not more than three rounds ahead of the slowest reader */
-			while (n_batches >= 3 * (uint64_t)world && stat((rdv + "/fq." + std::to_string(n_batches - 3 * (uint64_t)world) + ".1").c_str(), &sb) == 0) {
+			while (n_batches >= 3 * (uint64_t)world && stat((rk_data_dir() + "/fq." + std::to_string(n_batches - 3 * (uint64_t)world) + ".1").c_str(), &sb) == 0) {
 				if (rk_someone_failed() || rk_now() - t0 > rk_timeout()) return fail("the other ranks do not take their batches");
 				usleep(2000);
 			}
 			e.a0 = 0; e.a1 = acc1.size(); e.b0 = 0; e.b1 = acc2.size();
-			if (!rk_file_put(rdv + "/fq." + std::to_string(n_batches) + ".1", acc1.data(), acc1.size()) || (B && !rk_file_put(rdv + "/fq." + std::to_string(n_batches) + ".2", acc2.data(), acc2.size()))) return fail("cannot write into the rendezvous directory");
+			if (!rk_file_put(rk_data_dir() + "/fq." + std::to_string(n_batches) + ".1", acc1.data(), acc1.size()) || (B && !rk_file_put(rk_data_dir() + "/fq." + std::to_string(n_batches) + ".2", acc2.data(), acc2.size()))) return fail("cannot write into the rendezvous directory");
 		}
 		if (write(out, &e, sizeof(e)) != (ssize_t)sizeof(e)) return fail("cannot write into the rendezvous directory");
 		++n_batches;
@@ -168,20 +168,24 @@ struct rs_table_t {
 	~rs_table_t() { if (fd >= 0) close(fd); }
 	/* entry b: 1 = there, 0 = the input has fewer batches, -1 = the scan failed or nobody scans */
 	int get(uint64_t b, rs_entry_t *e, uint64_t *id0)
-	{
-		std::lock_guard<std::mutex> l(mu);
+	{	/* the lock is held for a look at the table and a read of what the file has new, never while waiting: a caller whose entry is there
+		 * already is not held up by one that polls for an entry yet to be published (with tiny batches the two providers of a rank can be
+		 * several batches apart, and rank 0's scanner waits for the slower one) */
 		const double t0 = rk_now(); struct stat sb;
 		for (;;) {
-			if (fd < 0) fd = open((rdv + "/batches").c_str(), O_RDONLY);
-			if (fd >= 0) {
-				rs_entry_t x;
-				while (pread(fd, &x, sizeof(x), (off_t)(ent.size() * sizeof(x))) == (ssize_t)sizeof(x)) { ent.push_back(x); pairs_before.push_back(pairs_before.back() + x.pairs); }
+			{
+				std::lock_guard<std::mutex> l(mu);
+				if (fd < 0) fd = open((rdv + "/batches").c_str(), O_RDONLY);
+				if (fd >= 0) {
+					rs_entry_t x;
+					while (pread(fd, &x, sizeof(x), (off_t)(ent.size() * sizeof(x))) == (ssize_t)sizeof(x)) { ent.push_back(x); pairs_before.push_back(pairs_before.back() + x.pairs); }
+				}
+				if (b < ent.size()) { *e = ent[(size_t)b]; *id0 = pairs_before[(size_t)b]; return 1; }
+				if (done) return b < total ? -1 : 0;
+				if (stat((rdv + "/batches.fail").c_str(), &sb) == 0) return -1;
+				std::vector<uint8_t> d;
+				if (stat((rdv + "/batches.done").c_str(), &sb) == 0 && rk_file_get(rdv + "/batches.done", d) && d.size() == 8) { memcpy(&total, d.data(), 8); done = true; continue; }   /* once more through the file: the last entries precede the marker */
 			}
-			if (b < ent.size()) { *e = ent[(size_t)b]; *id0 = pairs_before[(size_t)b]; return 1; }
-			if (done) return b < total ? -1 : 0;
-			if (stat((rdv + "/batches.fail").c_str(), &sb) == 0) return -1;
-			std::vector<uint8_t> d;
-			if (stat((rdv + "/batches.done").c_str(), &sb) == 0 && rk_file_get(rdv + "/batches.done", d) && d.size() == 8) { memcpy(&total, d.data(), 8); done = true; continue; }   /* once more through the file: the last entries precede the marker */
 			if (rk_now() - t0 > rk_timeout() || rk_someone_failed()) return -1;
 			usleep(5000);
 		}
@@ -203,7 +207,7 @@ static inline fq_stream_t::provider_t rs_provider(std::shared_ptr<rs_table_t> ta
 			if (rc < 0) { failed->store(1); return false; }
 			if (rc == 0) return false;
 			++st->k; st->off = second_file ? e.b0 : e.a0; st->end = second_file ? e.b1 : e.a1; st->open_range = true;
-			if (served) { st->cur = tab->rdv + "/fq." + std::to_string(b) + (second_file ? ".2" : ".1"); st->fd = open(st->cur.c_str(), O_RDONLY); if (st->fd < 0) { failed->store(1); return false; } }
+			if (served) { st->cur = rk_data_dir() + "/fq." + std::to_string(b) + (second_file ? ".2" : ".1"); st->fd = open(st->cur.c_str(), O_RDONLY); if (st->fd < 0) { failed->store(1); return false; } }
 		}
 		const size_t want = (size_t)std::min<uint64_t>(st->end - st->off, (uint64_t)4 << 20);
 		c.resize(want);

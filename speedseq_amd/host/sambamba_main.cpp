@@ -623,7 +623,7 @@ static int cmd_sort(int argc, char **argv)
 	 * is exchanged: the side streams were brought to rank 0 by the samblasters already. */
 	const int world = fused ? rk_world() : 1, rank = rk_rank();
 	if (world > 1 && !rk_check("sambamba")) return 1;
-	const std::string rdv = rk_dir();
+	const std::string rdv = rk_dir(), rdata = rk_data_dir();
 	uint64_t budget = (uint64_t)(std::max(mem_gb, 0.25) * 0.6 * 1073741824.0);   /* record bytes per in-memory run; the rest is keys, locations, output blocks */
 	{ const char *e = getenv("SSG_SORT_CHUNK_BYTES"); if (e && atoll(e) > 0) budget = (uint64_t)atoll(e); }   /* the tests force the spill-and-merge path */
 	rec_store_t S; std::vector<std::string> spills; bam_hdr_t h;
@@ -648,7 +648,7 @@ static int cmd_sort(int argc, char **argv)
 		}
 		char nm[64]; snprintf(nm, sizeof(nm), "/ssg_sort_%d_%04zu.run", (int)getpid(), runs.size());
 		if (world > 1) snprintf(nm, sizeof(nm), "/run.%d.%zu.run", rank, runs.size());
-		run_t R; R.path = (world > 1 ? rdv : tmpdir) + nm;
+		run_t R; R.path = (world > 1 ? rdata : tmpdir) + nm;
 		R.fd = open(R.path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644); if (R.fd < 0) die("sort: cannot write " + R.path);
 		if (world > 1) {   /* equal keys keep their input order over all ranks: by ordinal within the run (the exchange sorts by it across runs) */
 			std::vector<uint32_t> p1(n), p2(n); std::vector<uint64_t> k1(n);
@@ -663,7 +663,7 @@ static int cmd_sort(int argc, char **argv)
 			idx.insert(idx.end(), R.seg.begin(), R.seg.end()); idx.insert(idx.end(), R.useg.begin(), R.useg.end());
 			for (size_t g = 0; g <= G; ++g) idx.push_back((uint64_t)at[g]);
 			std::vector<uint64_t> od(n); for (size_t i = 0; i < n; ++i) od[i] = S.ord[perm[i]];
-			if (!rk_file_put(R.path + ".ord", od.data(), 8 * n) || !rk_file_put(R.path + ".idx", idx.data(), 8 * idx.size())) die("sort: cannot write into " + rdv);
+			if (!rk_file_put(R.path + ".ord", od.data(), 8 * n) || !rk_file_put(R.path + ".idx", idx.data(), 8 * idx.size())) die("sort: cannot write into " + rdata);
 		}
 		runs.push_back(R); spills.push_back(R.path); S.clear();
 	};
@@ -735,7 +735,7 @@ static int cmd_sort(int argc, char **argv)
 			if (!rk_file_wait(dn) || !rk_file_get(dn, b) || b.size() != 8) die("sort: rank " + std::to_string(r) + " did not deliver its runs");
 			uint64_t nr; memcpy(&nr, b.data(), 8);
 			for (uint64_t k = 0; k < nr; ++k) {
-				run_t R; R.path = rdv + "/run." + std::to_string(r) + "." + std::to_string(k) + ".run";
+				run_t R; R.path = rdata + "/run." + std::to_string(r) + "." + std::to_string(k) + ".run";
 				std::vector<uint8_t> ib;
 				if (!rk_file_get(R.path + ".idx", ib) || ib.size() < 8) die("sort: cannot read " + R.path + ".idx");
 				uint64_t g; memcpy(&g, ib.data(), 8);
@@ -784,6 +784,50 @@ static int cmd_sort(int argc, char **argv)
 }
 
 /* ---------------- index ---------------- */
+/* `sambamba flagstat <in.bam>` (upstream sambamba has the command; the reference does not call it): the counts of samtools flagstat that
+ * the soak's invariants need, in its line format, from the fixed fields only -- blocks inflated by the pool, one pass of a 100 GB file
+ * in the time the reference's samtools needs for a few GB -- plus one line samtools does not print: whether the file is in coordinate
+ * order (bam1_lt's key, unmapped reads last). */
+static int cmd_flagstat(int argc, char **argv)
+{
+	const char *in = 0; int threads = hw_threads();
+	for (int i = 0; i < argc; ++i) { if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]); else if (argv[i][0] != '-') { if (!in) in = argv[i]; } }
+	if (!in) die("usage: sambamba flagstat [-t N] <in.bam>");
+	const int fd = open_in(in);
+	bgzf_in_t bi(fd, threads); bam_hdr_t h;
+	if (!hdr_read(bi, h)) die("flagstat: not a BAM file");
+	uint64_t n = 0, sec = 0, sup = 0, dup = 0, mapped = 0, paired = 0, r1 = 0, r2 = 0, proper = 0, both = 0, single = 0, prim = 0, prim_dup = 0, descents = 0, prev = 0;
+	uint8_t rec[32];
+	for (;;) {
+		uint32_t bs;
+		if (bi.get(&bs, 4) != 4) break;
+		if (bs < 32 || bi.get(rec, 32) != 32) die("flagstat: malformed BAM record");
+		if (bi.skip(bs - 32) != bs - 32) die("flagstat: truncated BAM");
+		bam_core_t c; memcpy(&c, rec, 32);
+		const uint32_t f = c.flag_nc >> 16;
+		++n;
+		if (f & 0x100) ++sec; else if (f & 0x800) ++sup;
+		if (f & 0x400) ++dup;
+		if (!(f & 4)) ++mapped;
+		if (!(f & 0x900)) { ++prim; if (f & 0x400) ++prim_dup; }
+		if ((f & 1) && !(f & 0x900)) {
+			++paired; if (f & 0x40) ++r1; if (f & 0x80) ++r2;
+			if ((f & 2) && !(f & 4)) ++proper;
+			if (!(f & 4) && !(f & 8)) ++both;
+			if (!(f & 4) && (f & 8)) ++single;
+		}
+		const uint64_t key = (uint64_t)(uint32_t)c.tid << 32 | (uint32_t)((c.pos + 1) << 1) | ((f & 0x10) ? 1u : 0u);   /* tid -1 sorts last */
+		if (n > 1 && key < prev) ++descents;
+		prev = key;
+	}
+	close(fd);
+	printf("%llu + 0 in total (QC-passed reads + QC-failed reads)\n%llu + 0 secondary\n%llu + 0 supplementary\n%llu + 0 duplicates\n%llu + 0 mapped\n%llu + 0 paired in sequencing\n%llu + 0 read1\n%llu + 0 read2\n"
+	       "%llu + 0 properly paired\n%llu + 0 with itself and mate mapped\n%llu + 0 singletons\n%llu + 0 primary\n%llu + 0 primary duplicates\n%llu descents of the coordinate key (0 = sorted)\n",
+	       (unsigned long long)n, (unsigned long long)sec, (unsigned long long)sup, (unsigned long long)dup, (unsigned long long)mapped, (unsigned long long)paired, (unsigned long long)r1, (unsigned long long)r2,
+	       (unsigned long long)proper, (unsigned long long)both, (unsigned long long)single, (unsigned long long)prim, (unsigned long long)prim_dup, (unsigned long long)descents);
+	return 0;
+}
+
 static int cmd_index(int argc, char **argv)
 {
 	const char *in = 0; int threads = hw_threads();
@@ -904,6 +948,7 @@ int main(int argc, char **argv)
 	if (!strcmp(argv[1], "view")) return cmd_view(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "sort")) return cmd_sort(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "index")) return cmd_index(argc - 2, argv + 2);
+	if (!strcmp(argv[1], "flagstat")) return cmd_flagstat(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "merge")) return cmd_merge(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "index-parts")) return cmd_index_parts(argc - 2, argv + 2);
 	fprintf(stderr, "[sambamba] unsupported sub-command %s\n", argv[1]);

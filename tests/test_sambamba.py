@@ -99,6 +99,15 @@ def _check(sambamba, tmp_path, monkeypatch):
     for region in ("20_slice:1000-5000", "20_slice:150000-151000", "20_slice:300000"):
         assert _view(d + "/mine_s.bam", region) == _view(d + "/ref_s.bam", region)
         assert len(_view(d + "/mine_s.bam", region).split("\n")) > 10
+    # flagstat: the reference's samtools counts the same records; the sorted file is in order, the unsorted one is not
+    mine = subprocess.check_output(sambamba + ["flagstat", "-t", "2", d + "/mine_s.bam"], text=True).split("\n")
+    ref = subprocess.check_output([SAMTOOLS, "flagstat", d + "/ref_s.bam"], text=True)
+    for key in ("in total", "secondary", "supplementary", "duplicates", "paired in sequencing", "read1", "read2", "properly paired", "with itself and mate mapped", "singletons"):
+        a = [l for l in mine if key in l][0].split(" ")[0]; b = [l for l in ref.split("\n") if key in l][0].split(" ")[0]
+        assert a == b, (key, a, b)
+    assert [l for l in mine if "mapped" in l and "mate" not in l][0].split(" ")[0] == [l for l in ref.split("\n") if " mapped (" in l][0].split(" ")[0]
+    assert [l for l in mine if "descents" in l][0].startswith("0 ")
+    assert not [l for l in subprocess.check_output(sambamba + ["flagstat", d + "/mine_u.bam"], text=True).split("\n") if "descents" in l][0].startswith("0 ")
     # merge of two coordinate-sorted files
     (tmp_path / "second").mkdir()
     sam2 = _sam(tmp_path / "second", 300, seed=32, rg="h")      # another library: its own read group, as in `speedseq realign`

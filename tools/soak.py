@@ -29,6 +29,10 @@ def main():
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--mem", type=int, default=64, help="-M of speedseq align (GB): sambamba sort gets M-2")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--stream", action="store_true", help="the FASTQ never exists as a file: a thread simulates the pairs on the device chunk by chunk and writes them into a FIFO the "
+                    "pipeline reads (BASELINE.json configs[2] at its stated size: the FASTQ of 400 M pairs is 125 GB)")
+    ap.add_argument("--tmp", default="", help="directory for the script's outputs and the sort's runs (default: a memory file system when there is one)")
+    ap.add_argument("--limit", type=int, default=1500, help="seconds before the pipeline is given up")
     ap.add_argument("--emu-selftest", action="store_true")
     a = ap.parse_args()
     emu = a.emu_selftest
@@ -58,55 +62,91 @@ def main():
     lib.index_destroy(idx)
     bench.log("reference + index files ready (%.1f s)" % (time.time() - t0))
     fq = os.path.join(td, "reads.fq")
-    done = 0
-    with open(fq, "wb") as f:
-        while done < a.pairs:
-            n = min(a.chunk, a.pairs - done)
-            r = bench.simulate_pairs(ref, lens, n, a.read_len, 1000 + done // a.chunk, dev).cpu().numpy()
-            part = os.path.join(td, "part.fq")
-            bench.write_fastq(part, r, a.read_len, first_pair=done)
-            with open(part, "rb") as g:
-                while True:
-                    blk = g.read(64 << 20)
-                    if not blk:
-                        break
-                    f.write(blk)
-            os.remove(part)
-            done += n
-    del ref
-    if not emu:
-        torch.cuda.empty_cache()
-    bench.log("FASTQ of %d pairs written (%.1f GB)" % (a.pairs, os.path.getsize(fq) / 1e9))
+    producer = None
+    if a.stream:
+        import threading
+        os.mkfifo(fq)
+        gen_s = [0.0]
+
+        def produce():
+            try:
+                with open(fq, "wb", buffering=0) as f:      # blocks until `bwa mem` opens the other end
+                    done = 0
+                    while done < a.pairs:
+                        n = min(a.chunk, a.pairs - done)
+                        t1 = time.time()
+                        r = bench.simulate_pairs(ref, lens, n, a.read_len, 1000 + done // a.chunk, dev)
+                        rec = bench.fastq_records_dev(r, a.read_len, first_pair=done).cpu().numpy()
+                        gen_s[0] += time.time() - t1
+                        mv = memoryview(rec).cast("B")
+                        for o in range(0, len(mv), 64 << 20):
+                            f.write(mv[o:o + (64 << 20)])
+                        done += n
+            except BrokenPipeError:
+                bench.log("soak: the pipeline closed the FIFO early")
+        producer = threading.Thread(target=produce, daemon=True)
+        producer.start()
+        bench.log("FASTQ of %d pairs streamed through a FIFO in chunks of %d pairs" % (a.pairs, a.chunk))
+    else:
+        done = 0
+        with open(fq, "wb") as f:
+            while done < a.pairs:
+                n = min(a.chunk, a.pairs - done)
+                r = bench.simulate_pairs(ref, lens, n, a.read_len, 1000 + done // a.chunk, dev).cpu().numpy()
+                part = os.path.join(td, "part.fq")
+                bench.write_fastq(part, r, a.read_len, first_pair=done)
+                with open(part, "rb") as g:
+                    while True:
+                        blk = g.read(64 << 20)
+                        if not blk:
+                            break
+                        f.write(blk)
+                os.remove(part)
+                done += n
+        del ref
+        if not emu:
+            torch.cuda.empty_cache()
+        bench.log("FASTQ of %d pairs written (%.1f GB)" % (a.pairs, os.path.getsize(fq) / 1e9))
     cfg = "export SSG_FUSED=1\nexport SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128)
-    r = bench.script_leg(td, "soak", prefix, fq, a.pairs, a.threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=cfg, limit_s=1500)
+    wd = td
+    if a.tmp:
+        os.makedirs(a.tmp, exist_ok=True)
+        wd_obj = tempfile.TemporaryDirectory(dir=a.tmp); wd = wd_obj.name
+    r = bench.script_leg(wd, "soak", prefix, fq, a.pairs, a.threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=cfg, limit_s=a.limit)
+    if producer is not None:
+        producer.join(timeout=30)
+        r["fastq"] = "streamed through a FIFO, never a file; %.1f s of this process spent simulating and formatting the pairs on the device" % gen_s[0]
     rss_gb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0       # largest RSS of any child so far: the pipeline's heaviest process
     out = {"what": "`speedseq align -t %d -M %d -p` (reference script, unmodified; SSG_FUSED=1) on bin/bwa, bin/samblaster, bin/sambamba: %d synthetic 2x%d pairs vs the %.0f Mbp reference, one GPU"
                    % (a.threads, a.mem, a.pairs, a.read_len, sum(lens) / 1e6), "peak_child_rss_gb": round(rss_gb, 2)}
     out.update({k: v for k, v in r.items() if k != "out"})
     if "out" in r:
-        samtools = os.path.join(ROOT, "oracle", "_ref", "samtools")
         log = "\n".join(r.get("stage_log", []))
         m = re.search(r"pairs=(\d+) dups=(\d+) discordant_pairs=(\d+) splitter_lines=(\d+)", log)
         rep = dict(zip(("pairs", "dups", "discordant_pairs", "splitter_lines"), map(int, m.groups()))) if m else {}
         out["samblaster_reported"] = rep
-        if os.path.exists(samtools):
-            from concurrent.futures import ThreadPoolExecutor   # the five passes over the BAMs side by side: each is one samtools thread
-            def count(bam, *flt):
-                return int(subprocess.check_output([samtools, "view", "-c"] + list(flt) + [bam]))
-            main_bam = r["out"] + ".bam"
-            with ThreadPoolExecutor(5) as ex:
-                f = {"primary_records": ex.submit(count, main_bam, "-F", "0x900"), "dup_flagged_primaries": ex.submit(count, main_bam, "-f", "0x400", "-F", "0x900"),
-                     "discordant_records": ex.submit(count, r["out"] + ".discordants.bam"), "splitter_records": ex.submit(count, r["out"] + ".splitters.bam")}
-                srt_f = ex.submit(subprocess.run, "%s view %s | cut -f3,4 | awk 'BEGIN{ok=1} { if ($1==c && $2<p) ok=0; c=$1; p=$2 } END{print ok}'" % (samtools, main_bam), shell=True, capture_output=True, text=True)
-                chk = {k: v.result() for k, v in f.items()}
-                srt = srt_f.result()
-            out["bam_counts"] = chk
-            ok = chk["primary_records"] == 2 * a.pairs
-            if rep:
-                ok = ok and chk["dup_flagged_primaries"] == 2 * rep["dups"] and chk["discordant_records"] == 2 * rep["discordant_pairs"] and chk["splitter_records"] == rep["splitter_lines"]
-            out["invariants_ok"] = bool(ok)
-            out["positions_nondecreasing_within_contig"] = srt.stdout.strip() == "1"
+        # the three BAMs counted by `sambamba flagstat` of this repository (blocks inflated by a pool: one pass of a 100 GB file in a minute;
+        # tests/test_sambamba.py holds it against the reference's samtools flagstat), side by side
+        from concurrent.futures import ThreadPoolExecutor
+        def stat(bam, threads):
+            t1 = time.time()
+            o = subprocess.check_output([b("sambamba"), "flagstat", "-t", str(threads), bam], text=True)
+            d = {l.split(" + ")[1].split(" ", 1)[1].split(" (")[0] if " + " in l else "descents": int(l.split(" ")[0]) for l in o.split("\n") if l}
+            d["seconds"] = round(time.time() - t1, 1)
+            return d
+        with ThreadPoolExecutor(3) as ex:
+            fm = ex.submit(stat, r["out"] + ".bam", 12); fd = ex.submit(stat, r["out"] + ".discordants.bam", 2); fs = ex.submit(stat, r["out"] + ".splitters.bam", 2)
+            sm, sd, ss = fm.result(), fd.result(), fs.result()
+        chk = {"primary_records": sm["primary"], "dup_flagged_primaries": sm["primary duplicates"], "discordant_records": sd["in total"], "splitter_records": ss["in total"], "flagstat_seconds": sm["seconds"]}
+        out["bam_counts"] = chk
+        ok = chk["primary_records"] == 2 * a.pairs
+        if rep:
+            ok = ok and chk["dup_flagged_primaries"] == 2 * rep["dups"] and chk["discordant_records"] == 2 * rep["discordant_pairs"] and chk["splitter_records"] == rep["splitter_lines"]
+        out["invariants_ok"] = bool(ok)
+        out["positions_nondecreasing_within_contig"] = sm["descents"] == 0 and sd["descents"] == 0 and ss["descents"] == 0
     print(json.dumps(out))
+    if a.tmp:
+        wd_obj.cleanup()
     td_obj.cleanup()
 
 
