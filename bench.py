@@ -227,7 +227,7 @@ def fastq_records_dev(reads, rl, first_pair=0):
     return rec
 
 
-def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe, b=None):
+def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe, b=None, reads_long=None, n_wide=100000):
     """The plugin path as the reference wires it (bin/speedseq:438-439): FASTQ file -> `bwa mem -t T -p` | `samblaster --excludeDups
     --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile --discordantFile` -> three SAM streams on files, wall clock.
     The index is loaded from the files written by ssg_index_save; the rate excludes that one-off load (reported separately).
@@ -301,6 +301,46 @@ def e2e_leg(a, td, prefix, reads, reads2, rl, ns, orc_exe, b=None):
     for f in os.listdir(td):                              # the multi-GB SAM streams of the timed runs: free /dev/shm for what follows
         if f.startswith(("full.", "fullgz.", "dbg.")) or f.endswith(".fq.gz"):
             os.remove(os.path.join(td, f))
+    # ---- parity where it used to be thin: on THIS index, product executables against the oracle's, byte for byte:
+    # other option letters, single-end input, 2x250 -- n_wide pairs (reads) each
+    nw = min(n_wide, int(rn.shape[0] // 2))
+    wide = {}
+    if nw > 0:
+        wfq = os.path.join(td, "wide.fq")
+        write_fastq(wfq, rn[:2 * nw], rl)
+        legs = [("pe_default", "-p", wfq, True), ("pe_M_Y", "-p -M -Y", wfq, True), ("pe_scores_A2_B5_O7,9_E2,1", "-p -A 2 -B 5 -O 7,9 -E 2,1", wfq, True),
+                ("pe_k25_T40", "-p -k 25 -T 40", wfq, True), ("single_end", "", wfq, False)]
+        if reads_long is not None:
+            nl = min(nw, int(reads_long.shape[0] // 2))
+            lfq = os.path.join(td, "wide_long.fq")
+            write_fastq(lfq, reads_long[:2 * nl].cpu().numpy(), int(reads_long.shape[1]))
+            legs.append(("pe_2x%d" % int(reads_long.shape[1]), "-p", lfq, True))
+
+        def run_opts(bwa_cmd, sbl_cmd, fastq, tag, threads, opts, paired):
+            o, sp, di = (os.path.join(td, tag + x) for x in (".sam", ".spl.sam", ".disc.sam"))
+            if paired:
+                cmd = "%s mem -t %d %s %s %s 2> %s.bwa.err | %s --excludeDups --addMateTags --maxSplitCount 2 --minNonOverlap 20 --splitterFile %s --discordantFile %s > %s 2> %s.sbl.err" % (
+                    bwa_cmd, threads, opts, prefix, fastq, os.path.join(td, tag), sbl_cmd, sp, di, o, os.path.join(td, tag))
+            else:   # single-end reads: `bwa mem` alone (samblaster is a paired-end tool in the reference's pipeline)
+                cmd = "%s mem -t %d %s %s %s 2> %s.bwa.err > %s" % (bwa_cmd, threads, opts, prefix, fastq, os.path.join(td, tag), o)
+            rc = subprocess.call(["bash", "-c", "set -o pipefail; " + cmd], timeout=300)
+            if rc != 0:
+                raise RuntimeError("pipeline %s failed rc=%d: %s" % (tag, rc, open(os.path.join(td, tag + ".bwa.err")).read()[-400:]))
+            return (o, sp, di) if paired else (o,)
+        for name, opts, fastq, paired in legs:
+            try:
+                gfw = run_opts(bwa, sbl, fastq, "w_gpu", a.bwa_threads, opts, paired)
+                ofw = run_opts(orc_exe, orc_exe + " samblaster", fastq, "w_orc", min(os.cpu_count() or 1, 64), opts, paired)
+                gl, ol = [nopg(x) for x in gfw], [nopg(y) for y in ofw]
+                wide[name] = {"options": opts.strip(), "pairs" if paired else "reads": (nw if fastq == wfq else nl) * (1 if paired else 2), "sam_lines": len(gl[0]),
+                              "identical": bool(gl == ol), "lines_differing": sum(1 for x, y in zip(gl[0], ol[0]) if x != y) + abs(len(gl[0]) - len(ol[0]))}
+                for x in gfw + ofw:
+                    os.remove(x)
+            except Exception as e:
+                wide[name] = {"options": opts.strip(), "error": repr(e)[:300]}
+        res["parity_wide"] = {"what": "bin/bwa mem OPTIONS | bin/samblaster (the reference's switches) against oracle/orc_bwa mem OPTIONS | orc_bwa samblaster on the same FASTQ and the same "
+                                      "index files: the three SAM streams byte for byte (@PG aside); single-end: `bwa mem` alone", "legs": wide,
+                              "all_identical": bool(all(v.get("identical") for v in wide.values()))}
     return res
 
 
@@ -474,12 +514,13 @@ def main():
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip the plugin-path leg (bin/bwa mem | bin/samblaster on FASTQ files)")
     ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs in the FASTQ file of the plugin-path leg (the timed batch + freshly simulated ones): enough device calls for the pipeline's steady state to show")
     ap.add_argument("--config5-pairs", type=int, default=200000, help="pairs of the 2x250 leg (BASELINE.json configs[4]: long fragments, wider bands), 0 = skip")
+    ap.add_argument("--wide-pairs", type=int, default=100000, help="pairs (reads) of each leg of the wide parity check of the plugin-path leg: option letters, single-end, 2x250 against the oracle's executables on this index; 0 = skip")
     ap.add_argument("--no-dist-rehearsal", dest="dist_rehearsal", action="store_false", help="skip the one-rank rehearsal of the N > 1 code path (a second process)")
     ap.add_argument("--emu-selftest", action="store_true", help="TEST INFRASTRUCTURE, never a measurement: walk this script's whole flow on the CPU with the host-emulation build "
                     "(tests/emu) and the bundled chr20 slice as the reference, at toy sizes -- catches a broken leg before it costs GPU minutes")
     ap.add_argument("--partial", default=os.path.join(ROOT, "gpurun_out", "bench_partial.json"), help="the line so far is also written here after every leg (a run that is cut short leaves its numbers)")
     if "--emu-selftest" in sys.argv:                         # toy sizes unless given: the emulation runs the kernels lane by lane on the CPU
-        ap.set_defaults(pairs=600, steps=1, warmup=0, bwa_threads=1, e2e_pairs=1200, script_pairs=1200, script_threads=2, cpu_script_pairs=200, config5_pairs=300,
+        ap.set_defaults(pairs=600, steps=1, warmup=0, bwa_threads=1, e2e_pairs=1200, script_pairs=1200, script_threads=2, cpu_script_pairs=200, config5_pairs=300, wide_pairs=300,
                         no_profile=True, partial="/tmp/bench_emu_partial.json")
     a = ap.parse_args()
 
@@ -814,7 +855,7 @@ def main():
                         s5, _ = run5()
                     torch.cuda.synchronize()
                     t5 = (time.perf_counter() - t5) / 3
-                    ns5 = min(5000, n5)
+                    ns5 = min(a.wide_pairs if a.wide_pairs > 0 else 5000, n5)
                     h5 = reads5[:2 * ns5].cpu().numpy().reshape(-1); ho5 = np.arange(2 * ns5 + 1, dtype=np.int64) * r5
                     nm5 = ["q%d" % (i // 2) for i in range(2 * ns5)]
                     ot5, _, _ = orc.process_pairs(oidx, h5, ho5, nm5, None, 0, "", cores)
@@ -840,8 +881,8 @@ def main():
                 log('parity gate done: %s' % ok)
                 save_partial()
                 try:
-                    out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, nse, orc_exe=orc_exe, b=b)
-                    if not out["e2e"].get("sample_streams_identical", True):
+                    out["e2e"] = e2e_leg(a, td, prefix, reads, reads_e2e, rl, nse, orc_exe=orc_exe, b=b, reads_long=reads5, n_wide=a.wide_pairs)
+                    if not out["e2e"].get("sample_streams_identical", True) or out["e2e"].get("parity_wide", {}).get("all_identical") is False:
                         ok = False
                 except Exception as e:      # the plugin-path measurement must not take the headline down with it
                     out["e2e"] = {"error": repr(e)}

@@ -8,7 +8,7 @@
 #   ab250:KERNELS:CFG[;...]   the same at 2x250, 200 k pairs
 #   profile                   tools/profile_round.sh TAG (kernel stats + PMC passes + probes) and tools/pmc_summarize.py
 #   stats                     only the rocprofv3 --kernel-trace --stats pass of the device step
-#   soak:PAIRS[:MEM_GB]       tools/soak.py --pairs PAIRS [--mem MEM_GB]
+#   soak:PAIRS[:MEM_GB]       tools/soak.py --stream --pairs PAIRS [--mem MEM_GB]   (the FASTQ goes through a FIFO, never a file)
 #   pin                       write the kernel ISA pin if the suite log and the bench parity of this TAG are green
 #   sh:CMD                    any other command (with '+' for spaces)
 tag=$1; shift
@@ -52,7 +52,7 @@ PY
     grep ssg_k_ $out/${tag}_kernel_stats.csv | cut -c1-60,200- | head -30 ;;
   soak)
     pairs=${arg%%:*}; mem=""; [ "$arg" != "$pairs" ] && mem="--mem ${arg#*:}"
-    timeout 3000 python tools/soak.py --pairs $pairs $mem > $out/${tag}_soak_$pairs.json 2> $out/${tag}_soak_$pairs.err; tail -3 $out/${tag}_soak_$pairs.err | cut -c1-300
+    timeout 3000 python tools/soak.py --stream --limit 2400 --pairs $pairs $mem > $out/${tag}_soak_$pairs.json 2> $out/${tag}_soak_$pairs.err; tail -3 $out/${tag}_soak_$pairs.err | cut -c1-300
     python -c "import json,sys; d=json.load(open('$out/${tag}_soak_$pairs.json')); print({k:v for k,v in d.items() if k not in ('stage_log','what')})" ;;
   pin)
     python - $out/${tag}_bench.json $out/${tag}_pytest_gpu.log $out/${tag}_kernel_isa.sha256 <<'PY'
