@@ -27,8 +27,11 @@ speedseq_amd/libssgpu_tune.so: $(LIBOBJS)
 	$(MAKE) variant NAME=tune VFLAGS="-DSSG_TUNE -DSSG_C2A_WAVES_PER_SIMD=2"
 
 # bench utility: synthetic reference generator (one kernel launch)
-synth: tools/synth/libsynthref.so
+synth: tools/synth/libsynthref.so tools/synth/libsynthreads.so
 tools/synth/libsynthref.so: tools/synth/synth_ref.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -shared -fPIC $< -o $@
+# soak utility: interleaved FASTQ records of simulated pairs, one kernel launch per chunk (tools/soak.py --stream)
+tools/synth/libsynthreads.so: tools/synth/synth_reads.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 -shared -fPIC $< -o $@
 
 # random 64-byte-line gather probe (the roofline denominator of the FM-index kernels; tools/profile_round.sh runs it)

@@ -218,7 +218,7 @@ def fastq_records_dev(reads, rl, first_pair=0):
     c = 1 + name_w
     rec[:, c] = 10
     lut = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
-    rec[:, c + 1:c + 1 + rl] = lut[reads.long()]
+    rec[:, c + 1:c + 1 + rl] = lut.index_select(0, reads.reshape(-1).to(torch.int32)).reshape(n2, rl)   # int32 indices: a quarter of the int64 copy advanced indexing would make
     rec[:, c + 1 + rl] = 10
     rec[:, c + 2 + rl] = ord("+")
     rec[:, c + 3 + rl] = 10
@@ -398,10 +398,17 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
     shutil.rmtree(bindir, ignore_errors=True)
     r = type("R", (), {"returncode": p.returncode, "stdout": so, "stderr": se})
     if r.returncode != 0:
-        return {"error": (r.stdout[-400:] + r.stderr[-400:])}
+        keep = os.path.join(ROOT, "gpurun_out", "script_%s_failed.stderr" % tag)   # the whole of it: the tail is the script's own echo of its commands
+        try:
+            os.makedirs(os.path.dirname(keep), exist_ok=True)
+            open(keep, "w").write(r.stderr)
+        except OSError:
+            pass
+        msgs = [l for l in r.stderr.split("\n") if l.startswith(("[bwa]", "[samblaster]", "[sambamba]", "[ssgpu]", "[ranks]")) and not l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:"))]
+        return {"error": "rc %d after %.0f s; %s ... %s" % (r.returncode, t, " | ".join(msgs[-6:])[:1200], r.stderr[-300:]), "wall_s": round(t, 2)}
     sizes = {x: os.path.getsize(out + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
     ok = all(os.path.exists(out + x + ".bai") for x in sizes)
-    stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs", "[samblaster] main thread", "[samblaster] first stage", "[ssgpu] index load"))]
+    stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs", "[samblaster] main thread", "[samblaster] first stage", "[ssgpu] index load", "[ssgpu] device arena"))]
     return {"pairs": n_pairs, "threads": threads, "wall_s": round(t, 2), "pairs_per_s": n_pairs / t, "bam_bytes": sizes, "bai_written": ok, "out": out, "stage_log": stages}
 
 

@@ -131,27 +131,34 @@ SSG_DEVFN int ssg_chain_one(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 	int n_out = 0;
 	if (n_chn > 0) {
 		{ ssg_chain_w_lt lt = { ch }; ssg_introsort(ord, (long)n_chn, lt); }
+		/* The kept chains' query interval and weight travel in cs[] (free until the seed lists are flattened), one packed word per kept chain
+		 * next to kp[]: the quadratic loop below reads 4 contiguous bytes per kept chain instead of its 56-byte record and two seed
+		 * records (three to four cache lines apiece; that loop's re-reads were 17-40x the kernel's algorithmic bytes, profiles/r04_pmc_traffic.json). */
+		const bool compact = len < 512;   /* 9-bit query coordinates, weights below 2^14 (a weight never exceeds the read length) */
 		int nk = 0;
 		ch[ord[0]].kept = 3; kp[nk++] = 0;
+		if (compact) { const ssg_chain_t &c0 = ch[ord[0]]; cs[0] = sd[c0.first_seed].qbeg | (sd[c0.last_seed].qbeg + sd[c0.last_seed].len) << 9 | c0.w << 18; }
 		for (i = 1; i < n_chn; ++i) {
 			int large_ovlp = 0;
 			const ssg_chain_t &ci = ch[ord[i]];
 			int ib = sd[ci.first_seed].qbeg, ie = sd[ci.last_seed].qbeg + sd[ci.last_seed].len;
+			const int wi = ci.w;
 			for (k = 0; k < nk; ++k) {
-				int j = kp[k];
-				ssg_chain_t &cj = ch[ord[j]];
-				int jb = sd[cj.first_seed].qbeg, je = sd[cj.last_seed].qbeg + sd[cj.last_seed].len;
+				int jb, je, wj;
+				if (compact) { const int pk = cs[k]; jb = pk & 511; je = pk >> 9 & 511; wj = pk >> 18; }
+				else { const ssg_chain_t &cj = ch[ord[kp[k]]]; jb = sd[cj.first_seed].qbeg; je = sd[cj.last_seed].qbeg + sd[cj.last_seed].len; wj = cj.w; }
 				int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
 				if (e_min > b_max) {
 					int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj;
 					if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
 						large_ovlp = 1;
+						ssg_chain_t &cj = ch[ord[kp[k]]];
 						if (cj.first < 0) cj.first = i;
-						if (ci.w < cj.w * opt.drop_ratio && cj.w - ci.w >= opt.min_seed_len << 1) break;
+						if (wi < wj * opt.drop_ratio && wj - wi >= opt.min_seed_len << 1) break;
 					}
 				}
 			}
-			if (k == nk) { kp[nk++] = i; ch[ord[i]].kept = large_ovlp ? 2 : 3; }
+			if (k == nk) { if (compact) cs[nk] = ib | ie << 9 | wi << 18; kp[nk++] = i; ch[ord[i]].kept = large_ovlp ? 2 : 3; }
 		}
 		for (i = 0; i < nk; ++i) { const ssg_chain_t &c = ch[ord[kp[i]]]; if (c.first >= 0) ch[ord[c.first]].kept = 1; }
 		for (i = k = 0; i < n_chn; ++i) {

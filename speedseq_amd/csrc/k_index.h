@@ -30,14 +30,47 @@ __global__ void ssg_k_idx_text(const uint8_t *fwd, int64_t l_pac, uint8_t *T, in
 	}
 }
 
-/* flag[i] = suffix i belongs to bucket b (its first p symbols, 'A'-padded past the end, read as a base-4 number) */
-__global__ void ssg_k_idx_bucket_flag(const uint8_t *T, int64_t n, int p, uint32_t b, uint8_t *flag)
-{
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-		uint32_t v = 0;
-		for (int k = 0; k < p; ++k) v = v << 2 | T[i + k];   /* T is zero-padded past n */
-		flag[i] = (uint8_t)(v == b);
+/* The suffixes of bucket b listed in text order, without a flag array in between (until round 5: flag kernel + a library reduction + a library
+ * select per bucket, each over the whole text -- 128 passes of 74 ms at 6.2 G symbols, three quarters of the build).  A workgroup owns 4096
+ * consecutive positions, a lane 16 of them (the list keeps the order of the text): _count leaves the bucket's suffixes per workgroup,
+ * _scatter writes them behind the exclusive prefix sums of those counts. */
+#define SSG_IDX_BK_PER_LANE 16
+#define SSG_IDX_BK_PER_WG (256 * SSG_IDX_BK_PER_LANE)
+SSG_DEVFN uint32_t ssg_idx_bucket_mask(const uint8_t *T, int64_t n, int p, uint32_t b, int64_t i0)
+{	/* bit k: suffix i0 + k is in bucket b */
+	uint32_t m = 0, v = 0;
+	if (i0 >= n) return 0;
+	if (p == 0) { for (int k = 0; k < SSG_IDX_BK_PER_LANE; ++k) if (i0 + k < n) m |= 1u << k; return m; }   /* one bucket: every suffix */
+	for (int k = 0; k < p - 1; ++k) v = v << 2 | T[i0 + k];                /* T is zero-padded past n */
+	const uint32_t keep = p >= 16 ? ~0u : (1u << (2 * p)) - 1u;
+	for (int k = 0; k < SSG_IDX_BK_PER_LANE; ++k) {
+		v = (v << 2 | T[i0 + k + p - 1]) & keep;
+		if (i0 + k < n && v == b) m |= 1u << k;
 	}
+	return m;
+}
+__global__ void __launch_bounds__(256) ssg_k_idx_bucket_count(const uint8_t *T, int64_t n, int p, uint32_t b, uint32_t *wg_cnt)
+{
+	__shared__ uint32_t part[4];
+	const int64_t i0 = (int64_t)blockIdx.x * SSG_IDX_BK_PER_WG + (int64_t)threadIdx.x * SSG_IDX_BK_PER_LANE;
+	const int c = __popc(ssg_idx_bucket_mask(T, n, p, b, i0));
+	const int w = wv_sum(c);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (uint32_t)w;
+	__syncthreads();
+	if (threadIdx.x == 0) wg_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(256) ssg_k_idx_bucket_scatter(const uint8_t *T, int64_t n, int p, uint32_t b, const uint64_t *wg_off, uint64_t *pos)
+{
+	__shared__ uint32_t part[4];
+	const int64_t i0 = (int64_t)blockIdx.x * SSG_IDX_BK_PER_WG + (int64_t)threadIdx.x * SSG_IDX_BK_PER_LANE;
+	uint32_t m = ssg_idx_bucket_mask(T, n, p, b, i0);
+	const int c = __popc(m);
+	const int incl = wv_scan_add(c);
+	if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = (uint32_t)incl;
+	__syncthreads();
+	uint64_t at = wg_off[blockIdx.x] + (uint64_t)(incl - c);
+	for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) at += part[w];
+	while (m) { const int k = __ffsll((unsigned long long)m) - 1; m &= m - 1; pos[at++] = (uint64_t)(i0 + k); }
 }
 
 /* first-round key of the suffixes listed in pos[]: symbols p .. p+31, two bits each, first symbol most significant */

@@ -48,8 +48,11 @@ static int build_suffix_array(const uint8_t *d_T, int64_t n, uint64_t *d_SA)
 	else while (p < 8 && (n >> (2 * p)) > (1LL << 28)) ++p;
 	if (p < 0 || p > 8) { ssg_err_msg = "SSG_INDEX_BUCKET_P out of range"; return SSG_EINVAL; }
 	const uint32_t n_bucket = 1u << (2 * p);
-	rbuf<uint64_t> rank; rbuf<uint8_t> flag;
-	RALLOC(rank, (size_t)n); RALLOC(flag, (size_t)n);
+	rbuf<uint64_t> rank;
+	RALLOC(rank, (size_t)n);
+	const int64_t n_wg = (n + SSG_IDX_BK_PER_WG - 1) / SSG_IDX_BK_PER_WG;
+	rbuf<uint32_t> wg_cnt; rbuf<uint64_t> wg_off;
+	RALLOC(wg_cnt, (size_t)n_wg + 1); RALLOC(wg_off, (size_t)n_wg + 2);
 	struct chunk_t { uint64_t *pos, *grp; uint64_t m; };
 	std::vector<chunk_t> chunks;
 	auto free_chunks = [&]() { for (auto &c : chunks) { rt_free_raw(c.pos); rt_free_raw(c.grp); } chunks.clear(); };
@@ -58,18 +61,14 @@ static int build_suffix_array(const uint8_t *d_T, int64_t n, uint64_t *d_SA)
 	/* ---- round 1: per bucket of equal p-symbol prefix, sort by the next 32 symbols ---- */
 	for (uint32_t b = 0; b < n_bucket && !rc; ++b) {
 		uint64_t m = 0;
-		if (p == 0) m = (uint64_t)n;
-		else {
-			SSG_LAUNCH(ssg_k_idx_bucket_flag, nblk256(n), 256, 0, d_T, n, p, b, flag.p);
-			if ((rc = prim_count_flags(flag.p, n, &m))) break;
-		}
+		/* the bucket's suffixes in text order: per-workgroup counts straight from the text, their prefix sums, the scatter (k_index.h) */
+		SSG_LAUNCH(ssg_k_idx_bucket_count, n_wg, 256, 0, d_T, n, p, b, wg_cnt.p);
+		if ((rc = prim_exsum_u32_u64(wg_cnt.p, wg_off.p, n_wg))) break;
+		if ((rc = rt_d2h(&m, wg_off.p + n_wg, 8))) break;
 		if (m == 0) continue;
 		rbuf<uint64_t> pos, key, ps, ks, grp; rbuf<int64_t> head, gh; rbuf<uint8_t> pend;
 		if (!pos.alloc(m) || !key.alloc(m) || !ps.alloc(m) || !ks.alloc(m) || !head.alloc(m) || !gh.alloc(m) || !pend.alloc(m)) { ssg_err_msg = "index construction: device allocation failed (bucket)"; rc = SSG_ENOMEM; break; }
-		uint64_t got = 0;
-		if (p == 0 && (rc = rt_memset(flag.p, 1, (size_t)n))) break;
-		if ((rc = prim_select_u64(0, 0, flag.p, n, pos.p, &got))) break;
-		if (got != m) { ssg_err_msg = "index construction: bucket size mismatch"; rc = SSG_EHIP; break; }
+		SSG_LAUNCH(ssg_k_idx_bucket_scatter, n_wg, 256, 0, d_T, n, p, b, wg_off.p, pos.p);
 		SSG_LAUNCH(ssg_k_idx_key, nblk256((int64_t)m), 256, 0, d_T, pos.p, (int64_t)m, p, key.p);
 		if ((rc = prim_sort_pairs_u64(key.p, ks.p, pos.p, ps.p, (int64_t)m, 0, 64))) break;
 		SSG_LAUNCH(ssg_k_idx_heads, nblk256((int64_t)m), 256, 0, ks.p, (int64_t)m, head.p);
@@ -94,7 +93,7 @@ static int build_suffix_array(const uint8_t *d_T, int64_t n, uint64_t *d_SA)
 	}
 	if (!rc && base != (uint64_t)n) { ssg_err_msg = "index construction: buckets do not cover the text"; rc = SSG_EHIP; }
 	if (rc) { free_chunks(); return rc; }
-	flag.release();
+	wg_cnt.release(); wg_off.release();
 	/* ---- pending suffixes (SA order) ---- */
 	rbuf<uint64_t> P_pos, P_grp;
 	if (n_pend) {

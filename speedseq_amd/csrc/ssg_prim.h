@@ -1,13 +1,13 @@
 /*
- * ssg_prim.h -- device-wide primitives used by the host orchestration: hipCUB (rocPRIM back-end) on the
- * MI355X; plain loops in the host-emulation build (tests/emu, CPU-side tests only).  64-bit item counts.
+ * ssg_prim.h -- device-wide primitives used by the host orchestration: rocPRIM (AMD's own device library; no CUB-compatibility
+ * layer) on the MI355X; plain loops in the host-emulation build (tests/emu, CPU-side tests only).  64-bit item counts.
  */
 #ifndef SSG_PRIM_H
 #define SSG_PRIM_H
 #include "ssg_rt.h"
 #include "ssg_dev.h"
 #ifndef SSG_EMU
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #else
 #include <algorithm>
 #include <vector>
@@ -28,12 +28,12 @@ static inline int prim_sort_pairs_u64(const uint64_t *k_in, uint64_t *k_out, con
 	return 0;
 #else
 	size_t tb = 0;
-	PRIM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, n, b0, b1), "hipcub SortPairs (size query)");
+	PRIM_TRY(rocprim::radix_sort_pairs(nullptr, tb, k_in, k_out, v_in, v_out, (size_t)n, (unsigned)b0, (unsigned)b1), "rocprim radix_sort_pairs (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { ssg_err_msg = "device allocation failed: sort temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, k_in, k_out, v_in, v_out, n, b0, b1, ssg_stream);
+	hipError_t e = rocprim::radix_sort_pairs(tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, (unsigned)b0, (unsigned)b1, ssg_stream);
 	int rc = rt_sync(); rt_free(tmp);
-	if (e != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; (void)hipGetLastError(); return -1000; }
+	if (e != hipSuccess) { ssg_err_msg = "rocprim radix_sort_pairs failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
 #endif
 }
@@ -54,12 +54,12 @@ static inline int prim_scan_max_i64(const int64_t *in, int64_t *out, int64_t n)
 	return 0;
 #else
 	size_t tb = 0;
-	PRIM_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tb, in, out, prim_max_i64(), n), "hipcub InclusiveScan (size query)");
+	PRIM_TRY(rocprim::inclusive_scan(nullptr, tb, in, out, (size_t)n, prim_max_i64()), "rocprim inclusive_scan (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { ssg_err_msg = "device allocation failed: scan temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceScan::InclusiveScan(tmp, tb, in, out, prim_max_i64(), n, ssg_stream);
+	hipError_t e = rocprim::inclusive_scan(tmp, tb, in, out, (size_t)n, prim_max_i64(), ssg_stream);
 	int rc = rt_sync(); rt_free(tmp);
-	if (e != hipSuccess) { ssg_err_msg = "hipcub InclusiveScan failed"; (void)hipGetLastError(); return -1000; }
+	if (e != hipSuccess) { ssg_err_msg = "rocprim inclusive_scan failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
 #endif
 }
@@ -74,14 +74,14 @@ static inline int prim_exsum_u32_u64(const uint32_t *in, uint64_t *out, int64_t 
 	return 0;
 #else
 	/* scan n + 1 items of an input that is zero-extended by one element: the counts array is allocated with one spare slot */
-	hipcub::TransformInputIterator<uint64_t, prim_u32_to_u64, const uint32_t*> it(in, prim_u32_to_u64());
+	rocprim::transform_iterator<const uint32_t*, prim_u32_to_u64, uint64_t> it(in, prim_u32_to_u64());
 	size_t tb = 0;
-	PRIM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, out, n + 1), "hipcub ExclusiveSum (size query)");
+	PRIM_TRY(rocprim::exclusive_scan(nullptr, tb, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>()), "rocprim exclusive_scan (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { ssg_err_msg = "device allocation failed: scan temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, it, out, n + 1, ssg_stream);
+	hipError_t e = rocprim::exclusive_scan(tmp, tb, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ssg_stream);
 	int rc = rt_sync(); rt_free(tmp);
-	if (e != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum failed"; (void)hipGetLastError(); return -1000; }
+	if (e != hipSuccess) { ssg_err_msg = "rocprim exclusive_scan failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
 #endif
 }
@@ -95,17 +95,17 @@ static inline int prim_count_flags(const uint8_t *flag, int64_t n, uint64_t *cou
 	uint64_t c = 0; for (int64_t i = 0; i < n; ++i) c += flag[i] != 0;
 	*count = c; return 0;
 #else
-	hipcub::TransformInputIterator<uint64_t, prim_u8_to_u64, const uint8_t*> it(flag, prim_u8_to_u64());
+	rocprim::transform_iterator<const uint8_t*, prim_u8_to_u64, uint64_t> it(flag, prim_u8_to_u64());
 	uint64_t *d_out = (uint64_t*)rt_malloc(8);
 	size_t tb = 0;
-	PRIM_TRY(hipcub::DeviceReduce::Sum(nullptr, tb, it, d_out, n), "hipcub Reduce (size query)");
+	PRIM_TRY(rocprim::reduce(nullptr, tb, it, d_out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>()), "rocprim reduce (size query)");
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp || !d_out) { ssg_err_msg = "device allocation failed: reduce temporaries"; return -12; }
-	hipError_t e = hipcub::DeviceReduce::Sum(tmp, tb, it, d_out, n, ssg_stream);
+	hipError_t e = rocprim::reduce(tmp, tb, it, d_out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ssg_stream);
 	int rc = rt_sync();
 	if (!rc) rc = rt_d2h(count, d_out, 8);
 	rt_free(tmp); rt_free(d_out);
-	if (e != hipSuccess) { ssg_err_msg = "hipcub Reduce failed"; (void)hipGetLastError(); return -1000; }
+	if (e != hipSuccess) { ssg_err_msg = "rocprim reduce failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
 #endif
 }
@@ -123,17 +123,17 @@ static inline int prim_select_u64(const uint64_t *in, uint64_t base, const uint8
 	uint64_t *d_cnt = (uint64_t*)rt_malloc(8);
 	if (!d_cnt) { ssg_err_msg = "device allocation failed: select count"; return -12; }
 	size_t tb = 0; hipError_t e;
-	hipcub::CountingInputIterator<uint64_t> cit(base);
-	if (in) { PRIM_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb, in, flag, out, d_cnt, n), "hipcub Select (size query)"); }
-	else { PRIM_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb, cit, flag, out, d_cnt, n), "hipcub Select (size query)"); }
+	rocprim::counting_iterator<uint64_t> cit(base);
+	if (in) { PRIM_TRY(rocprim::select(nullptr, tb, in, flag, out, d_cnt, (size_t)n), "rocprim select (size query)"); }
+	else { PRIM_TRY(rocprim::select(nullptr, tb, cit, flag, out, d_cnt, (size_t)n), "rocprim select (size query)"); }
 	void *tmp = rt_malloc(tb + 16);
 	if (!tmp) { rt_free(d_cnt); ssg_err_msg = "device allocation failed: select temporaries"; return -12; }
-	if (in) e = hipcub::DeviceSelect::Flagged(tmp, tb, in, flag, out, d_cnt, n, ssg_stream);
-	else e = hipcub::DeviceSelect::Flagged(tmp, tb, cit, flag, out, d_cnt, n, ssg_stream);
+	if (in) e = rocprim::select(tmp, tb, in, flag, out, d_cnt, (size_t)n, ssg_stream);
+	else e = rocprim::select(tmp, tb, cit, flag, out, d_cnt, (size_t)n, ssg_stream);
 	int rc = rt_sync();
 	if (!rc) rc = rt_d2h(n_out, d_cnt, 8);
 	rt_free(tmp); rt_free(d_cnt);
-	if (e != hipSuccess) { ssg_err_msg = "hipcub Select failed"; (void)hipGetLastError(); return -1000; }
+	if (e != hipSuccess) { ssg_err_msg = "rocprim select failed"; (void)hipGetLastError(); return -1000; }
 	return rc;
 #endif
 }

@@ -81,22 +81,36 @@ static inline int rt_set_lane(int l) { if (l < 0 || l >= SSG_MAX_LANE) { ssg_err
 #include <mutex>
 struct ssg_pool_t {
 	std::mutex mu; std::map<size_t, std::vector<void*> > free_; std::unordered_map<void*, size_t> size_;
-	static size_t cls(size_t n) { size_t c = 256; while (c < n) c <<= 1; if (c > (64u << 20)) { size_t g = 64u << 20; c = (n + g - 1) / g * g; } return c; }
+	size_t held = 0, free_bytes = 0, held_max = 0;   /* bytes this arena got from the driver and has not given back; of them in the free lists */
+	/* size classes: powers of two up to 64 MB; above, eight steps per octave (a request is rounded up by at most an eighth).  The per-batch
+	 * arrays of a whole-genome run differ by a few per cent from call to call: with finer classes (64 MB steps until round 5) every array
+	 * left a block in several neighbouring classes and the free lists grew until another process of the pipeline could not allocate. */
+	static size_t cls(size_t n) { size_t c = 256; while (c < n) c <<= 1; if (c > (64u << 20)) { const size_t g = c >> 4; c = (n + g - 1) / g * g; } return c; }
+	/* what the free lists may hold (SSG_POOL_FREE_GB, default 48: about what the arrays of one device call of 1 M pairs add up to); beyond it a
+	 * returned block goes back to the driver, largest classes first */
+	static size_t free_cap() { static const size_t c = (size_t)(getenv("SSG_POOL_FREE_GB") && atof(getenv("SSG_POOL_FREE_GB")) > 0 ? atof(getenv("SSG_POOL_FREE_GB")) : 48.0) << 30; return c; }
 	std::unordered_map<void*, int> live_;   /* SSG_POOL_CHECK=1: a block handed out twice, or given back twice, is reported */
 	static bool check() { static const int c = getenv("SSG_POOL_CHECK") ? atoi(getenv("SSG_POOL_CHECK")) : 0; return c != 0; }
+	~ssg_pool_t() { if (held_max && getenv("SSG_POOL_LOG")) fprintf(stderr, "[ssgpu] device arena: at most %.2f GB held, %.2f GB of it in the free lists at exit\n", held_max / 1073741824.0, free_bytes / 1073741824.0); }
 	void *get(size_t n) {
 		size_t c = cls(n ? n : 1);
-		{ std::lock_guard<std::mutex> l(mu); auto it = free_.find(c); if (it != free_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back();
+		{ std::lock_guard<std::mutex> l(mu); auto it = free_.find(c); if (it != free_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); free_bytes -= c;
 			if (check() && live_[p]++) fprintf(stderr, "[ssgpu] pool: block %p (class %zu) handed out while in use\n", p, c);
 			return p; } }
 		void *p = 0;
 		if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); release(); if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); return 0; } }
-		std::lock_guard<std::mutex> l(mu); size_[p] = c; if (check()) live_[p] = 1; return p;
+		std::lock_guard<std::mutex> l(mu); size_[p] = c; held += c; held_max = held > held_max ? held : held_max; if (check()) live_[p] = 1; return p;
 	}
 	bool put(void *p) { std::lock_guard<std::mutex> l(mu); auto it = size_.find(p); if (it == size_.end()) return false;
 		if (check() && --live_[p] != 0) fprintf(stderr, "[ssgpu] pool: block %p (class %zu) given back twice\n", p, it->second);
-		free_[it->second].push_back(p); return true; }
-	void release() { std::lock_guard<std::mutex> l(mu); for (auto &kv : free_) for (void *p : kv.second) { size_.erase(p); (void)hipFree(p); } free_.clear(); }
+		free_[it->second].push_back(p); free_bytes += it->second;
+		while (free_bytes > free_cap() && !free_.empty()) {   /* trim: the largest free block first */
+			auto big = free_.end(); --big;
+			if (big->second.empty()) { free_.erase(big); continue; }
+			void *q = big->second.back(); big->second.pop_back(); free_bytes -= big->first; held -= big->first; size_.erase(q); (void)hipFree(q);
+		}
+		return true; }
+	void release() { std::lock_guard<std::mutex> l(mu); for (auto &kv : free_) for (void *p : kv.second) { size_.erase(p); held -= kv.first; (void)hipFree(p); } free_.clear(); free_bytes = 0; }
 };
 extern ssg_pool_t ssg_pools[SSG_MAX_DEV][SSG_MAX_LANE];
 #define ssg_pool (ssg_pools[ssg_cur_dev][ssg_lane])

@@ -30,7 +30,7 @@
 #include "../../include/ssgpu.h"
 #include "ssg_index_int.h"
 #ifndef SSG_EMU
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #endif
 
 thread_local std::string ssg_err_msg;
@@ -433,7 +433,7 @@ static int run_msw_lane(const ssg_index_t *idx, const ssg_mem_opt_t *opt, long n
 	if (lanes != 1 && lanes != 2 && lanes != 4) { ssg_err_msg = "mate rescue lane kernel: 1, 2 or 4 lanes per job"; return SSG_EINVAL; }
 	dbuf<uint64_t> d_sorted((size_t)nj); dbuf<unsigned int> d_q(1);
 	CHKA(d_sorted); CHKA(d_q); CHK(d_q.zero());
-	/* bits [32, 58): padded query length (<= 256 at bit 48) over window length (< 2^16).  NOT [32, 64): hipcub / rocPRIM of ROCm 7.2 returns
+	/* bits [32, 58): padded query length (<= 256 at bit 48) over window length (< 2^16).  NOT [32, 64): the radix sort of ROCm 7.2 (met through hipCUB, the same code underneath) returns
 	 * a list that is not even a permutation of its input for that range of 64-bit keys (tools/dbg/sort_probe.cpp) */
 	CHK(sort_keys_u64(d_keys, d_sorted.p, nj, 32, 58));
 	STAGE("msw_sort");
@@ -630,10 +630,10 @@ static int sort_keys_u64(uint64_t *k_in, uint64_t *k_out, long n, int begin_bit,
 	return 0;
 #else
 	size_t tmp_bytes = 0;
-	if (hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, k_in, k_out, (int)n, begin_bit, end_bit) != hipSuccess) { ssg_err_msg = "hipcub SortKeys (size query) failed"; return SSG_EHIP; }
+	if (rocprim::radix_sort_keys(nullptr, tmp_bytes, k_in, k_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit) != hipSuccess) { ssg_err_msg = "rocprim radix_sort_keys (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes);
 	CHKA(tmp);
-	if (hipcub::DeviceRadixSort::SortKeys(tmp.p, tmp_bytes, k_in, k_out, (int)n, begin_bit, end_bit, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub SortKeys failed"; return SSG_EHIP; }
+	if (rocprim::radix_sort_keys(tmp.p, tmp_bytes, k_in, k_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, ssg_stream) != hipSuccess) { ssg_err_msg = "rocprim radix_sort_keys failed"; return SSG_EHIP; }
 	return 0;
 #endif
 }
@@ -647,12 +647,12 @@ static int dev_exclusive_scan(const int32_t *d_in, int64_t *d_out, long n, int64
 	int64_t t = 0; for (long i = 0; i < n; ++i) { d_out[i] = t; t += d_in[i]; } d_out[n] = t; *total = t;
 	return 0;
 #else
-	hipcub::TransformInputIterator<int64_t, ssg_to_i64, const int32_t*> it(d_in, ssg_to_i64());
+	rocprim::transform_iterator<const int32_t*, ssg_to_i64, int64_t> it(d_in, ssg_to_i64());
 	size_t tmp_bytes = 0;
-	if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, it, d_out, (int)n) != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum (size query) failed"; return SSG_EHIP; }
+	if (rocprim::exclusive_scan(nullptr, tmp_bytes, it, d_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>()) != hipSuccess) { ssg_err_msg = "rocprim exclusive_scan (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes + 16);
 	CHKA(tmp);
-	if (hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, it, d_out, (int)n, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub ExclusiveSum failed"; return SSG_EHIP; }
+	if (rocprim::exclusive_scan(tmp.p, tmp_bytes, it, d_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), ssg_stream) != hipSuccess) { ssg_err_msg = "rocprim exclusive_scan failed"; return SSG_EHIP; }
 	SSG_LAUNCH(ssg_k_scan_tail, 1, 64, 0, d_in, d_out, n);
 	return rt_d2h(total, d_out + n, 8);
 #endif
@@ -672,10 +672,10 @@ static int dev_order_desc(const int32_t *d_key, int32_t *d_order, long n)
 	CHKA(iota); CHKA(kout);
 	SSG_LAUNCH(ssg_k_iota, (n + 255) / 256, 256, 0, iota.p, n);
 	size_t tmp_bytes = 0;
-	if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_key, kout.p, iota.p, d_order, (int)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairsDescending (size query) failed"; return SSG_EHIP; }
+	if (rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, d_key, kout.p, iota.p, d_order, (size_t)n, 0u, 32u) != hipSuccess) { ssg_err_msg = "rocprim radix_sort_pairs_desc (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes + 16);
 	CHKA(tmp);
-	if (hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tmp_bytes, d_key, kout.p, iota.p, d_order, (int)n, 0, 32, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub SortPairsDescending failed"; return SSG_EHIP; }
+	if (rocprim::radix_sort_pairs_desc(tmp.p, tmp_bytes, d_key, kout.p, iota.p, d_order, (size_t)n, 0u, 32u, ssg_stream) != hipSuccess) { ssg_err_msg = "rocprim radix_sort_pairs_desc failed"; return SSG_EHIP; }
 	return rt_sync();   /* the temporaries are released on return */
 #endif
 }
@@ -1194,10 +1194,10 @@ static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint3
 	return 0;
 #else
 	size_t tmp_bytes = 0;
-	if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int64_t)n) != hipSuccess) { ssg_err_msg = "hipcub SortPairs (size query) failed"; return SSG_EHIP; }
+	if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, 64u) != hipSuccess) { ssg_err_msg = "rocprim radix_sort_pairs (size query) failed"; return SSG_EHIP; }
 	dbuf<uint8_t> tmp(tmp_bytes);
 	CHKA(tmp);
-	if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int64_t)n, 0, 64, ssg_stream) != hipSuccess) { ssg_err_msg = "hipcub SortPairs failed"; return SSG_EHIP; }
+	if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, 64u, ssg_stream) != hipSuccess) { ssg_err_msg = "rocprim radix_sort_pairs failed"; return SSG_EHIP; }
 	return rt_sync();
 #endif
 }

@@ -4,6 +4,7 @@ the reference's `speedseq align` script (unmodified) on the product executables,
 the pipeline's processes, the duplicate-table size, sort spills, and checks samtools-flagstat-level invariants of the three BAMs against what
 bwa / samblaster reported on stderr.  Usage: python tools/soak.py --pairs 40000000 [--mem 64] [--emu-selftest]"""
 import argparse
+import ctypes as C
 import json
 import os
 import re
@@ -24,7 +25,7 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=40000000)
-    ap.add_argument("--chunk", type=int, default=4000000, help="pairs simulated and written per round")
+    ap.add_argument("--chunk", type=int, default=0, help="pairs simulated and written per round (default: 4 M to a file, 1 M into the FIFO: this process shares the device with the pipeline)")
     ap.add_argument("--ref-mbp", type=float, default=3100.0)
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--mem", type=int, default=64, help="-M of speedseq align (GB): sambamba sort gets M-2")
@@ -35,6 +36,8 @@ def main():
     ap.add_argument("--limit", type=int, default=1500, help="seconds before the pipeline is given up")
     ap.add_argument("--emu-selftest", action="store_true")
     a = ap.parse_args()
+    if a.chunk <= 0:
+        a.chunk = 1000000 if a.stream else 4000000
     emu = a.emu_selftest
     from speedseq_amd import capi
     import ctypes as C
@@ -67,21 +70,89 @@ def main():
         import threading
         os.mkfifo(fq)
         gen_s = [0.0]
+        vram = {"min_free_gb": None, "samples": []}
+
+        def sample_vram():    # the device's free memory as the driver reports it, every two seconds: every process of the pipeline shares the 288 GB
+            t00 = time.time()
+            while not vram.get("stop"):
+                try:
+                    fr, tot = torch.cuda.mem_get_info()
+                    g = fr / 2 ** 30
+                    vram["min_free_gb"] = g if vram["min_free_gb"] is None else min(vram["min_free_gb"], g)
+                    if len(vram["samples"]) < 400:
+                        vram["samples"].append((round(time.time() - t00), round(g, 1)))
+                except Exception:
+                    pass
+                time.sleep(2.0)
+        if not emu:
+            threading.Thread(target=sample_vram, daemon=True).start()
+
+        synlib = os.path.join(ROOT, "tools", "synth", "libsynthreads.so")
+        use_kernel = (not emu) and os.path.exists(synlib)
+
+        def write_all(fd, mv):
+            o = 0
+            while o < len(mv):
+                o += os.write(fd, mv[o:o + (8 << 20)])
 
         def produce():
+            import queue
             try:
-                with open(fq, "wb", buffering=0) as f:      # blocks until `bwa mem` opens the other end
+                fd = os.open(fq, os.O_WRONLY)                  # blocks until `bwa mem` opens the other end
+                try:
+                    import fcntl
+                    fcntl.fcntl(fd, 1031, 1 << 20)              # F_SETPIPE_SZ: a megabyte per hand-over instead of 64 KB
+                except Exception:
+                    pass
+                if use_kernel:
+                    # tools/synth/synth_reads.cpp: a chunk's records in one kernel launch (milliseconds of the device the pipeline is using), copied into
+                    # page-locked buffers by this thread while another writes the previous chunk into the FIFO
+                    syn = C.CDLL(synlib)
+                    offs_t = torch.tensor(ctg_off, dtype=torch.int64, device=dev); lens_t = torch.tensor(lens, dtype=torch.int64, device=dev)
+                    rec = 2 * a.read_len + 16
+                    dbuf = torch.empty(2 * a.chunk * rec, dtype=torch.uint8, device=dev)
+                    free_q, full_q = queue.Queue(), queue.Queue(maxsize=2)
+                    for _ in range(3):
+                        free_q.put(torch.empty(2 * a.chunk * rec, dtype=torch.uint8, pin_memory=True))
+                    ins_mean, ins_std = (800, 150) if a.read_len >= 250 else (400, 50)
+
+                    def gen():
+                        done = 0
+                        while done < a.pairs:
+                            n = min(a.chunk, a.pairs - done)
+                            t1 = time.time()
+                            rc = syn.synth_fastq_pairs(C.c_void_p(ref.data_ptr()), C.c_void_p(offs_t.data_ptr()), C.c_void_p(lens_t.data_ptr()), C.c_int(len(lens)), C.c_int64(int(sum(lens))),
+                                                       C.c_int64(done), C.c_int(n), C.c_int(a.read_len), C.c_uint64(20250927), C.c_int(ins_mean), C.c_int(ins_std), C.c_void_p(dbuf.data_ptr()))
+                            if rc:
+                                bench.log("soak: the read generator failed"); break
+                            hb = free_q.get()
+                            hb[:2 * n * rec].copy_(dbuf[:2 * n * rec]); torch.cuda.synchronize()
+                            gen_s[0] += time.time() - t1
+                            full_q.put((hb, 2 * n * rec))
+                            done += n
+                        full_q.put(None)
+                    threading.Thread(target=gen, daemon=True).start()
+                    while True:
+                        item = full_q.get()
+                        if item is None:
+                            break
+                        hb, nb = item
+                        write_all(fd, memoryview(hb.numpy())[:nb])
+                        free_q.put(hb)
+                else:
                     done = 0
                     while done < a.pairs:
                         n = min(a.chunk, a.pairs - done)
                         t1 = time.time()
                         r = bench.simulate_pairs(ref, lens, n, a.read_len, 1000 + done // a.chunk, dev)
                         rec = bench.fastq_records_dev(r, a.read_len, first_pair=done).cpu().numpy()
+                        del r
+                        if not emu:
+                            torch.cuda.empty_cache()            # this process is a guest on the device: nothing of a chunk stays cached
                         gen_s[0] += time.time() - t1
-                        mv = memoryview(rec).cast("B")
-                        for o in range(0, len(mv), 64 << 20):
-                            f.write(mv[o:o + (64 << 20)])
+                        write_all(fd, memoryview(rec).cast("B"))
                         done += n
+                os.close(fd)
             except BrokenPipeError:
                 bench.log("soak: the pipeline closed the FIFO early")
         producer = threading.Thread(target=produce, daemon=True)
@@ -107,7 +178,7 @@ def main():
         if not emu:
             torch.cuda.empty_cache()
         bench.log("FASTQ of %d pairs written (%.1f GB)" % (a.pairs, os.path.getsize(fq) / 1e9))
-    cfg = "export SSG_FUSED=1\nexport SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128)
+    cfg = "export SSG_FUSED=1\nexport SSG_POOL_LOG=1\nexport SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128)
     wd = td
     if a.tmp:
         os.makedirs(a.tmp, exist_ok=True)
@@ -115,7 +186,9 @@ def main():
     r = bench.script_leg(wd, "soak", prefix, fq, a.pairs, a.threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=cfg, limit_s=a.limit)
     if producer is not None:
         producer.join(timeout=30)
-        r["fastq"] = "streamed through a FIFO, never a file; %.1f s of this process spent simulating and formatting the pairs on the device" % gen_s[0]
+        r["fastq"] = "streamed through a FIFO, never a file; %.1f s of this process spent making the chunks (%s) and bringing them to the host" % (gen_s[0], "tools/synth/synth_reads.cpp: one kernel launch per chunk" if use_kernel else "bench.simulate_pairs + fastq_records_dev")
+        vram["stop"] = True
+        r["device_memory"] = {"min_free_gb": vram["min_free_gb"], "free_gb_every_20_s": vram["samples"][::10]}
     rss_gb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0       # largest RSS of any child so far: the pipeline's heaviest process
     out = {"what": "`speedseq align -t %d -M %d -p` (reference script, unmodified; SSG_FUSED=1) on bin/bwa, bin/samblaster, bin/sambamba: %d synthetic 2x%d pairs vs the %.0f Mbp reference, one GPU"
                    % (a.threads, a.mem, a.pairs, a.read_len, sum(lens) / 1e6), "peak_child_rss_gb": round(rss_gb, 2)}
