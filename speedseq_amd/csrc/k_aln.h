@@ -9,7 +9,7 @@
 #include "k_pair.h"
 
 #define SSG_Z_CAP (192 * 1024)   /* backtrack bytes per resident wave */
-#define SSG_ALN_QLDS 256          /* query bytes staged in LDS per wave */
+#define SSG_ALN_QLDS 320          /* query bytes staged in LDS per wave */
 
 SSG_DEVFN int ssg_infer_bw(int l1, int l2, int score, int a, int q, int r)
 {	/* upstream infer_bw */

@@ -29,8 +29,14 @@ template <int CAPC, int CAPS = CAPC> struct ssg_chw_lds_t {   /* CAPC chains, CA
 	int64_t b8[CAPC];   /* insertion: chain position [chain id] (shifting form: positions, sorted [slot]) | sort/filter: w<<32 | chain id, sorted by w */
 	int16_t rid[CAPC];  /* insertion: contig of the chain [chain id] (< 32768 contigs: host-checked) | filter: kept state [sorted idx] */
 	uint16_t ls[CAPC];  /* last seed [chain id]                                | filter: query end of kept chain */
-	uint16_t n[CAPC], fs[CAPC];            /* [chain id]: #seeds, first seed */
-	uint8_t fq[CAPC], lq[CAPC], ll[CAPC];  /* [chain id]: qbeg of first seed, qbeg/len of last seed (reads are < 255 bases) */
+	uint16_t n[CAPC], fs[CAPC];            /* [chain id]: #seeds (13 bits; bits 13 / 14 / 15 = bit 8 of fq / lq / ll), first seed */
+	SSG_DEVMEM int get_fq(int c) const { return fq[c] | (n[c] >> 13 & 1) << 8; }
+	SSG_DEVMEM int get_lq(int c) const { return lq[c] | (n[c] >> 14 & 1) << 8; }
+	SSG_DEVMEM int get_ll(int c) const { return ll[c] | (n[c] >> 15 & 1) << 8; }
+	SSG_DEVMEM int get_n(int c) const { return n[c] & 0x1fff; }
+	SSG_DEVMEM void new_chain(int c, int qbeg, int len) { fq[c] = lq[c] = (uint8_t)qbeg; ll[c] = (uint8_t)len; n[c] = (uint16_t)(1 | (qbeg >> 8 & 1) << 13 | (qbeg >> 8 & 1) << 14 | (len >> 8 & 1) << 15); }
+	SSG_DEVMEM void add_seed(int c, int qbeg, int len) { lq[c] = (uint8_t)qbeg; ll[c] = (uint8_t)len; n[c] = (uint16_t)((((n[c] & 0x1fff) + 1) & 0x1fff) | (n[c] & 0x2000) | (qbeg >> 8 & 1) << 14 | (len >> 8 & 1) << 15); }
+	uint8_t fq[CAPC], lq[CAPC], ll[CAPC];  /* [chain id]: qbeg of first seed, qbeg/len of last seed: the low 8 bits (the ninth of each, for reads of 256..511 bases, rides in n[]) */
 	uint16_t ids[CAPS]; /* insertion: chain id at position RANK (shifting form: of sorted slot) | filter: query begin of kept chain */
 	uint16_t nx[CAPS];  /* [seed]: next seed of the same chain */
 	uint64_t bm[CAPS / 64];                  /* ranks that hold a chain */
@@ -110,7 +116,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 				if (fl >= 0) { /* upstream test_and_merge against the floor chain */
 					const int c = L.ids[fl];
 					const int64_t f_rbeg = L.b8[c], l_rbeg = L.a8[c];
-					const int f_q = L.fq[c], l_q = L.lq[c], l_len = L.ll[c];
+					const int f_q = L.get_fq(c), l_q = L.get_lq(c), l_len = L.get_ll(c);
 					if (prid != L.rid[c]) res = 0;
 					else if (qbeg >= f_q && qbeg + len <= l_q + l_len && rbeg >= f_rbeg && rbeg + len <= l_rbeg + l_len) res = 1;
 					else if ((l_rbeg < l_pac || f_rbeg < l_pac) && rbeg >= l_pac) res = 0;
@@ -120,7 +126,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 					}
 					if (res == 2) {
 						ssg_wave_ldssync();
-						if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.lq[c] = (uint8_t)qbeg; L.ll[c] = (uint8_t)len; ++L.n[c]; }
+						if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.add_seed(c, qbeg, len); }
 						ssg_wave_ldssync();
 					}
 				}
@@ -131,8 +137,8 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 					ssg_wave_ldssync();
 					if (lane == 0) {
 						L.bm[rk >> 6] |= 1ull << (rk & 63); L.bms[rk >> 12] |= 1ull << ((rk >> 6) & 63);
-						L.ids[rk] = (uint16_t)nc; L.b8[nc] = rbeg; L.a8[nc] = rbeg; L.fq[nc] = L.lq[nc] = (uint8_t)qbeg; L.ll[nc] = (uint8_t)len;
-						L.n[nc] = 1; L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
+						L.ids[rk] = (uint16_t)nc; L.b8[nc] = rbeg; L.a8[nc] = rbeg; L.new_chain(nc, qbeg, len);
+						L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
 					}
 					ssg_wave_ldssync();
 					++nc;
@@ -168,7 +174,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			if (lower >= 0) { /* upstream test_and_merge against the floor chain */
 				const int c = L.ids[lower];
 				const int64_t f_rbeg = L.b8[lower], l_rbeg = L.a8[c];
-				const int f_q = L.fq[c], l_q = L.lq[c], l_len = L.ll[c];
+				const int f_q = L.get_fq(c), l_q = L.get_lq(c), l_len = L.get_ll(c);
 				if (prid != L.rid[c]) res = 0;
 				else if (qbeg >= f_q && qbeg + len <= l_q + l_len && rbeg >= f_rbeg && rbeg + len <= l_rbeg + l_len) res = 1;
 				else if ((l_rbeg < l_pac || f_rbeg < l_pac) && rbeg >= l_pac) res = 0;
@@ -178,7 +184,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 				}
 				if (res == 2) {
 					ssg_wave_ldssync();
-					if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.lq[c] = (uint8_t)qbeg; L.ll[c] = (uint8_t)len; ++L.n[c]; }
+					if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.add_seed(c, qbeg, len); }
 					ssg_wave_ldssync();
 				}
 			}
@@ -194,8 +200,8 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 					if (idx < hi) { L.b8[idx + 1] = v; L.ids[idx + 1] = w; }
 				}
 				if (lane == 0) {
-					L.b8[slot] = rbeg; L.ids[slot] = (uint16_t)nc; L.a8[nc] = rbeg; L.fq[nc] = L.lq[nc] = (uint8_t)qbeg; L.ll[nc] = (uint8_t)len;
-					L.n[nc] = 1; L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
+					L.b8[slot] = rbeg; L.ids[slot] = (uint16_t)nc; L.a8[nc] = rbeg; L.new_chain(nc, qbeg, len);
+					L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
 				}
 				ssg_wave_ldssync();
 				++nc;
@@ -209,7 +215,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 	ssg_wave_ldssync();
 	for (int c = lane; c < nc; c += 64) {
 		int w1 = 0, w2 = 0, sid = L.fs[c], end1 = 0; int64_t end2 = 0;
-		const int n = L.n[c];
+		const int n = L.get_n(c);
 		for (int j = 0; j < n; ++j, sid = L.nx[sid]) {
 			const ssg_seed_t s = sd[sid];
 			if (s.qbeg >= end1) w1 += s.len; else if (s.qbeg + s.len > end1) w1 += s.qbeg + s.len - end1;
@@ -259,7 +265,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		for (i = 0; i < n_chn; ++i) {
 			const int64_t me = L.b8[i];
 			const int id = (int)(uint32_t)me, wi = (int)(me >> 32);
-			const int ib = L.fq[id], ie = L.lq[id] + L.ll[id];
+			const int ib = L.get_fq(id), ie = L.get_lq(id) + L.get_ll(id);
 			int large_ovlp = 0, broke = 0;
 			for (int k0 = 0; k0 < nk && !broke; k0 += 64) {
 				const int kk = k0 + lane;
@@ -311,7 +317,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			const int kept = sl < n_chn ? L.rid[sl] : 0;
 			const int64_t me = sl < n_chn ? L.b8[sl] : 0;
 			const int id = (int)(uint32_t)me;
-			const int n = kept ? L.n[id] : 0;
+			const int n = kept ? L.get_n(id) : 0;
 			const unsigned long long bal = wv_ballot(kept != 0);
 			const int incl = wv_scan_add(n);
 			if (kept) {

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_m
 	ssg_xjob_t jb;
 	jb.read = r; jb.flag = 0; jb.l_query = (int16_t)l_query; jb.rbeg = 0; jb.rmax0 = jb.rmax1 = 0; jb.qbeg = jb.len = 0; jb.seed_t = 0;
 	jb.cn = c.n; jb.rid = c.rid; jb.first_seed = c.first_seed; jb.frac_rep = c.frac_rep;
-	if (c.n == 0) { jb.flag = 2; jobs[g] = jb; key_l[g] = (uint64_t)255 << 32 | (uint64_t)g; key_r[g] = (uint64_t)255 << 32 | (uint64_t)g; return; }
+	if (c.n == 0) { jb.flag = 2; jobs[g] = jb; key_l[g] = (uint64_t)511 << 32 | (uint64_t)g; key_r[g] = (uint64_t)511 << 32 | (uint64_t)g; return; }
 	int64_t rmax0 = l_pac << 1, rmax1 = 0;
 	uint64_t best = 0; int best_t = 0;
 	for (int i = 0; i < c.n; ++i) {
@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_m
 	if (rmax1 - rmax0 > twin_cap) jb.flag = 1;   /* window beyond the wave kernel's buffer: reported as an error there */
 	jobs[g] = jb;
 	const int ql = jb.flag ? 0 : s.qbeg, qr = jb.flag ? 0 : l_query - s.qbeg - s.len;
-	key_l[g] = (uint64_t)(255 - ql) << 32 | (uint64_t)g;   /* ascending sort = longest query side first; side 0 = nothing to do */
-	key_r[g] = (uint64_t)(255 - qr) << 32 | (uint64_t)g;
+	key_l[g] = (uint64_t)(511 - ql) << 32 | (uint64_t)g;   /* ascending sort = longest query side first; side 0 = nothing to do */
+	key_r[g] = (uint64_t)(511 - qr) << 32 | (uint64_t)g;
 	{	/* one atomic per wave and side */
 		const unsigned long long bl = wv_ballot(ql > short_cap), br = wv_ballot(qr > short_cap), act = wv_ballot(1);
 		if (wv_lane() == (int)__builtin_ctzll(act)) { if (bl) atomicAdd(&n_long[0], (unsigned)__popcll(bl)); if (br) atomicAdd(&n_long[1], (unsigned)__popcll(br)); }
@@ -186,14 +186,14 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 		else h1 = 0;
 		if (end > beg) {
 			ncell += (unsigned long long)(end - beg);
-			int mk = -1;                                 /* max over the row of (h << 8 | j): the largest h, at its last column */
+			int mk = -1;                                 /* max over the row of (h << 9 | j): the largest h, at its last column (columns up to 320) */
 			auto cell = [&](const uint32_t wd, const int jj) -> uint32_t {
 				int M = SSG_XL_H(wd), e = SSG_XL_E(wd), h, t;
 				const int sc = ssg_sbfe6(T, SSG_XL_QS(wd));
 				M = M ? M + sc : 0;
 				h = M > e ? M : e;
 				h = h > f ? h : f;
-				{ const int k = h << 8 | jj; mk = mk > k ? mk : k; }
+				{ const int k = h << 9 | jj; mk = mk > k ? mk : k; }
 				t = M - oe_del; t = t > 0 ? t : 0;
 				e -= e_del; e = e > t ? e : t;
 				const uint32_t out = (wd & SSG_XL_QMASK) | ((uint32_t)e << 13) | (uint32_t)h1;
@@ -212,7 +212,7 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 				SSG_UNROLL for (int u = 1; u < U; ++u) if (j + u < end) Lc[(j + u) * 64] = cell(wc[u], j + u);
 				SSG_UNROLL for (int u = 0; u < U; ++u) wc[u] = wn[u];
 			}
-			mm = mk >> 8; mj = mk & 255;                 /* end > beg: at least one column */
+			mm = mk >> 9; mj = mk & 511;                 /* end > beg: at least one column */
 			j = end;
 		} else j = beg;
 		Lc[end * 64] = (Lc[end * 64] & SSG_XL_QMASK) | (uint32_t)h1;
@@ -241,7 +241,7 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 #define SSG_XL_BAND_TRY 2   /* == SSG_MAX_BAND_TRY (upstream MAX_BAND_TRY) */
 
 /* side 0: left extensions (query and reference walked backwards from the seed); side 1: right extensions.
- * sorted[t] = (255 - side length) << 32 | job id; QCAP+1 columns of LDS per lane. */
+ * sorted[t] = (511 - side length) << 32 | job id; QCAP+1 columns of LDS per lane. */
 template <int QCAP>
 __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int side, long job_first, long n_jobs, const uint64_t *sorted,
                                const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 	const long t = job_first + (long)blockIdx.x * 64 + threadIdx.x;
 	if (t >= n_jobs) return;
 	const uint64_t key = sorted[t];
-	if ((key >> 32) >= 255) return;   /* nothing on this side */
+	if ((key >> 32) >= 511) return;   /* nothing on this side */
 	const long g = (long)(uint32_t)key;
 	const ssg_xjob_t jb = jobs[g];
 	if (jb.flag) return;

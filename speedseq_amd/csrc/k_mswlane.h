@@ -65,7 +65,7 @@ SSG_DEVFN int ssg_max3(int a, int b, int c) { a = a > b ? a : b; return a > c ? 
 /* may this scoring / read go through the 13-bit cells and the 5-bit score table? */
 SSG_DEVFN bool ssg_ml_fits(const ssg_mem_opt_t &opt, int qlen)
 {
-	return opt.a >= 1 && opt.a <= 15 && opt.b >= 0 && opt.b <= 16 && qlen >= 1 && qlen <= 256 && qlen * opt.a <= 8190;
+	return opt.a >= 1 && opt.a <= 15 && opt.b >= 0 && opt.b <= 16 && qlen >= 1 && qlen <= 320 && qlen * opt.a <= 8190;
 }
 
 /* target bases of 8 consecutive rows: doubled coordinates p .. p + 7 of the 2-bit pac, 4 bits per row (row 0 lowest).  Rows outside the
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 		ssg_msjob_t jb; jb.rb = 0; jb.qoff = 0; jb.tlen = 0; jb.qlen = 0; jb.qp = 0; jb.minsc = 0x10000; jb.is_rev = 0; jb.p = 16; jb.xstart = 0; jb._pad = 0;
 		if (pending && !SSG_ML_OK(0, slot < n_slots)) pending = false;
 		if (pending) jb = jobs[slot];
-		if (pending && !SSG_ML_OK(1, jb.qlen >= 1 && jb.qlen <= 256 && jb.tlen >= 1 && jb.tlen <= SSG_ML_TMAX && jb.qoff >= 0 && jb.qoff + jb.qlen <= seq_bytes && jb.rb >= 0 && jb.rb + jb.tlen <= (ix.l_pac << 1))) pending = false;
+		if (pending && !SSG_ML_OK(1, jb.qlen >= 1 && jb.qlen <= 320 && jb.tlen >= 1 && jb.tlen <= SSG_ML_TMAX && jb.qoff >= 0 && jb.qoff + jb.qlen <= seq_bytes && jb.rb >= 0 && jb.rb + jb.tlen <= (ix.l_pac << 1))) pending = false;
 		int f_te = 0, f_qe = 0, endsc = 0x10000, q_full = jb.qlen;   /* REV: the forward pass's end (the reverse pass starts there) and its score (where it stops) */
 		if (REV && pending) {	/* upstream ksw_align2: query[0..qe] and target[0..te] reversed, no b[], stop at the forward score */
 			const ssg_msres_t fw = res[slot];
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 				const uint32_t rows = REV ? ssg_ml_rows8<true>(ix, jb.rb + f_te - i0) : ssg_ml_rows8<false>(ix, jb.rb + i0);
 				uint32_t T[R];
 				SSG_UNROLL for (int r = 0; r < R; ++r) { const uint32_t tb = rows >> (4 * r) & 3u; T[r] = t_mis ^ (t_x << (5 * tb)); }
-				int tag = 255 - c * C;
+				int tag = 511 - c * C;   /* 511 - column: the larger key of two equal scores is the smaller column */
 				uint32_t w0 = Lc[0], w1 = Lc[64];
 				for (int cc = 0; cc < C; cc += 2) {
 					const uint32_t n0 = Lc[(cc + 2) * 64], n1 = Lc[(cc + 3) * 64];   /* next pair in flight (two spare columns behind the last) */
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 							d = hA[r];
 							h = ssg_max3(m, e, f[r]);
 							hB[r] = h;
-							{ const int k = h << 8 | tag; rm[r] = rm[r] > k ? rm[r] : k; }
+							{ const int k = h << 9 | tag; rm[r] = rm[r] > k ? rm[r] : k; }
 							e = ssg_max3(e - e_del, h - oe_del, 0);
 							f[r] = ssg_max3(f[r] - e_ins, h - oe_ins, 0);
 						}
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 							d = hB[r];
 							h = ssg_max3(m, e, f[r]);
 							hA[r] = h;
-							{ const int k = h << 8 | tag; rm[r] = rm[r] > k ? rm[r] : k; }
+							{ const int k = h << 9 | tag; rm[r] = rm[r] > k ? rm[r] : k; }
 							e = ssg_max3(e - e_del, h - oe_del, 0);
 							f[r] = ssg_max3(f[r] - e_ins, h - oe_ins, 0);
 						}
@@ -220,14 +220,14 @@ __global__ void __launch_bounds__(64) ssg_k_msw_lane(ssg_index_view_t ix, ssg_me
 				}
 				if (c == L - 1) {	/* the rows of this strip are complete: upstream's per-row bookkeeping, in row order */
 					SSG_UNROLL for (int r = 0; r < R; ++r) {
-						const int i = i0 + r, imax = rm[r] >> 8;
+						const int i = i0 + r, imax = rm[r] >> 9;
 						if (i < tlen && !done) {
 							if (!REV && imax >= jb.minsc) {
 								const unsigned long long pk = (unsigned long long)imax << 32 | (unsigned)i;
 								if (n_b == 0 || last_row + 1 != i) { last_sc = imax; last_row = i; if (n_b < bcap && SSG_ML_OK(2, ((long)blockIdx.x * J + jslot) * bcap + n_b < (long)gridDim.x * J * bcap)) bl[n_b] = pk; ++n_b; }
 								else if (last_sc < imax) { last_sc = imax; last_row = i; if (n_b <= bcap) bl[n_b - 1] = pk; }
 							}
-							if (imax > gmax) { gmax = imax; te = i; qe = 255 - (rm[r] & 255); if (REV && gmax >= endsc) done = 1; }
+							if (imax > gmax) { gmax = imax; te = i; qe = 511 - (rm[r] & 511); if (REV && gmax >= endsc) done = 1; }
 						}
 					}
 				}

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
                              const ssg_msres_t *jres, const int64_t *jbase /* forward passes of the windows of pair kq's sides: slots jbase[2 kq + i] + 4 j + r (k_mswlane.h); or null */,
                              const uint8_t *sdp_fixed /* per read: the list is a fixed point of mem_sort_dedup_patch's scan already (k_extend.h); or null */)
 {
-	__shared__ uint8_t revlds[SSG_WAVES_PER_WG][256];
+	__shared__ uint8_t revlds[SSG_WAVES_PER_WG][320];
 	__shared__ ssg_sdp_lds_t sdplds[SSG_WAVES_PER_WG];
 	const int wslot = (int)(threadIdx.x >> 6);
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;

@@ -29,16 +29,16 @@
 #define SSG_K_SMEM2_H
 #include "ssg_dev.h"
 
-#define SSG_S2_QWORDS 32   /* the read as 4-bit codes, 8 per LDS word: reads up to 256 bases */
+#define SSG_S2_QWORDS 40   /* the read as 4-bit codes, 8 per LDS word: reads up to 320 bases */
 enum { S2_FWD = 0, S2_BWD, S2_P3F, S2_READ, S2_P1, S2_P2, S2_P3, S2_OUT, S2_FIN };
 enum { S2_PEND_NONE = 0, S2_PEND_FWD, S2_PEND_BWD, S2_PEND_P3 };
 
-/* interval-list entry, 16 bytes: x0, x1, x2 < 2^40, info = end position < 256 */
+/* interval-list entry, 16 bytes: x0, x1 < 2^40, x2 < 2^39 (an occurrence count never exceeds the text length), info = end position < 512 */
 struct alignas(16) ssg_pk2_t { uint64_t w0, w1; };
 SSG_DEVFN ssg_pk2_t s2_pk(const ssg_intv_t &v)
-{ ssg_pk2_t p; p.w0 = v.x0 | (v.x1 & 0xffffffull) << 40; p.w1 = (v.x1 >> 24) | v.x2 << 16 | v.info << 56; return p; }
+{ ssg_pk2_t p; p.w0 = v.x0 | (v.x1 & 0xffffffull) << 40; p.w1 = (v.x1 >> 24) | v.x2 << 16 | v.info << 55; return p; }
 SSG_DEVFN ssg_intv_t s2_unpk(const ssg_pk2_t &p)
-{ ssg_intv_t v; v.x0 = p.w0 & 0xffffffffffull; v.x1 = (p.w0 >> 40) | (p.w1 & 0xffffull) << 24; v.x2 = (p.w1 >> 16) & 0xffffffffffull; v.info = p.w1 >> 56; return v; }
+{ ssg_intv_t v; v.x0 = p.w0 & 0xffffffffffull; v.x1 = (p.w0 >> 40) | (p.w1 & 0xffffull) << 24; v.x2 = (p.w1 >> 16) & 0x7fffffffffull; v.info = p.w1 >> 55; return v; }
 SSG_DEVFN void s2_set_intv(const ssg_index_view_t &ix, int c, ssg_intv_t &ik)
 {	/* upstream bwt_set_intv */
 	ik.x0 = ix.L2[c] + 1; ik.x2 = ix.L2[c+1] - ix.L2[c]; ik.x1 = ix.L2[3-c] + 1; ik.info = 0;
@@ -468,7 +468,7 @@ template <int SC>
 __global__ void SSG_HEAVY_BOUNDS ssg_k_smem_heavy(ssg_index_view_t ix, ssg_mem_opt_t opt, const int32_t *ids, const unsigned int *n_ids, const int32_t *read_ids,
                            const uint8_t *seq, const int64_t *off, ssg_intv_t *out_intv, int32_t *out_n, int cap, unsigned long long *n_extend, unsigned int *next)
 {
-	__shared__ uint8_t qb[264];
+	__shared__ uint8_t qb[328];
 	__shared__ ssg_pk2_t lst[2][SC];
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	const int n_todo = (int)*n_ids;

@@ -3,7 +3,7 @@
  * a10, a12): upstream ksw_extend2, ksw_global2 (+backtrace) and ksw_align2's contract.
  *
  * Layout (blocked): lane l of the wave owns the NS consecutive query columns j = l*NS + s
- * (NS <= 4, i.e. up to 256 columns: enough for 2x150 and 2x250).  H(i-1,j-1)/E(i,j) of upstream's
+ * (NS <= 5, i.e. up to 320 columns: 2x150, 2x250, 2x300).  H(i-1,j-1)/E(i,j) of upstream's
  * eh[] array live in VGPRs for the whole job, exactly one register pair per column, so even
  * upstream's reads of stale eh[] entries beyond a shrunken band are reproduced for free.
  * A DP row is processed by all lanes at once:
@@ -177,7 +177,8 @@ SSG_DEVFN ssg_ext_res_t wv_extend2_any(const ssg_mem_opt_t &opt, int qlen, ssg_s
 	if (qlen < 64)  return wv_extend2<1>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
 	if (qlen < 128) return wv_extend2<2>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
 	if (qlen < 192) return wv_extend2<3>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
-	return wv_extend2<4>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
+	if (qlen < 256) return wv_extend2<4>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
+	return wv_extend2<5>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -267,7 +268,8 @@ SSG_DEVFN int wv_global2_any(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 	if (qlen < 64)  return wv_global2<1>(opt, qlen, query, tlen, target, w, z, cells);
 	if (qlen < 128) return wv_global2<2>(opt, qlen, query, tlen, target, w, z, cells);
 	if (qlen < 192) return wv_global2<3>(opt, qlen, query, tlen, target, w, z, cells);
-	return wv_global2<4>(opt, qlen, query, tlen, target, w, z, cells);
+	if (qlen < 256) return wv_global2<4>(opt, qlen, query, tlen, target, w, z, cells);
+	return wv_global2<5>(opt, qlen, query, tlen, target, w, z, cells);
 }
 
 /* upstream ksw_global2 backtrace; single lane.  cigar[] gets ops in forward order; returns n_cigar
@@ -433,7 +435,8 @@ SSG_DEVFN ssg_kswr_t wv_align2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t qu
 	if (qp <= 64)  return wv_align2_t<1>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 128) return wv_align2_t<2>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 192) return wv_align2_t<3>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
-	return wv_align2_t<4>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
+	if (qp <= 256) return wv_align2_t<4>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
+	return wv_align2_t<5>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 }
 /* ksw_align2 whose forward pass (r.score, te, qe, score2, te2) was computed elsewhere (k_mswlane.h): the reverse pass in the column layout
  * the whole call would have used */
@@ -444,6 +447,7 @@ SSG_DEVFN void wv_align2_rev(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 	if (qp <= 64)  return wv_align2_rev_t<1>(opt, query, target, xtra, r, bscratch, cells);
 	if (qp <= 128) return wv_align2_rev_t<2>(opt, query, target, xtra, r, bscratch, cells);
 	if (qp <= 192) return wv_align2_rev_t<3>(opt, query, target, xtra, r, bscratch, cells);
-	return wv_align2_rev_t<4>(opt, query, target, xtra, r, bscratch, cells);
+	if (qp <= 256) return wv_align2_rev_t<4>(opt, query, target, xtra, r, bscratch, cells);
+	return wv_align2_rev_t<5>(opt, query, target, xtra, r, bscratch, cells);
 }
 #endif

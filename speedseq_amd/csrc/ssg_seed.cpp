@@ -65,7 +65,8 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
 	if (budget) {   /* the given-up reads, a wave each (their number stays on the device: the launch is sized for the chip) */
 		const long n_wg = std::min<long>(n_reads, 256L * env_int("SSG_SMEM_HEAVY_WAVES_PER_CU", 28));
 		if (scap <= 160) SSG_LAUNCH(ssg_k_smem_heavy<160>, n_wg, block, 0, idx->v, *opt, (const int32_t*)d_heavy.p, (const unsigned int*)(d_next.p + 1), (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, n_extend, d_next.p + 2);
-		else SSG_LAUNCH(ssg_k_smem_heavy<264>, n_wg, block, 0, idx->v, *opt, (const int32_t*)d_heavy.p, (const unsigned int*)(d_next.p + 1), (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, n_extend, d_next.p + 2);
+		else if (scap <= 264) SSG_LAUNCH(ssg_k_smem_heavy<264>, n_wg, block, 0, idx->v, *opt, (const int32_t*)d_heavy.p, (const unsigned int*)(d_next.p + 1), (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, n_extend, d_next.p + 2);
+		else SSG_LAUNCH(ssg_k_smem_heavy<328>, n_wg, block, 0, idx->v, *opt, (const int32_t*)d_heavy.p, (const unsigned int*)(d_next.p + 1), (const int32_t*)0, d_seq, d_off, d_intv, d_n, cap, n_extend, d_next.p + 2);
 	}
 	return rt_sync();
 }

@@ -48,7 +48,7 @@ thread_local std::vector<ssg_prof_rec> ssg_prof_pending;
  * so per-wave scratch slabs are sized by residency, not by batch size */
 #define SSG_MAX_RESIDENT_WG 1024
 /* longest read the DP kernels are laid out for (LDS rows, 8-bit columns) */
-#define SSG_MAX_READ_LEN 254
+#define SSG_MAX_READ_LEN 310   /* 2x300 with room; the kernels' column classes end at 320 (k_sw.h NS = 5, ssg_k_ext_lane<320>, SSG_S2_QWORDS) */
 #define SSG_STR_(x) #x
 #define SSG_STR(x) SSG_STR_(x)
 
@@ -366,7 +366,7 @@ int ssg_extend_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_ext_job_t *
 {
 	CHK(need_device());
 	if (n_jobs <= 0) return 0;
-	for (int i = 0; i < n_jobs; ++i) if (jobs[i].qlen > 254 || jobs[i].qlen < 0 || jobs[i].h0 <= 0) { ssg_err_msg = "ssg_extend_batch: qlen must be <= 254 and h0 > 0"; return SSG_EINVAL; }
+	for (int i = 0; i < n_jobs; ++i) if (jobs[i].qlen > 318 || jobs[i].qlen < 0 || jobs[i].h0 <= 0) { ssg_err_msg = "ssg_extend_batch: qlen must be <= 318 and h0 > 0"; return SSG_EINVAL; }
 	dbuf<ssg_ext_job_t> dj(n_jobs); dbuf<uint8_t> dq(qbytes + 1), dt(tbytes + 1); dbuf<ssg_ext_res_t> dr(n_jobs); dbuf<unsigned long long> dc(1);
 	CHKA(dj); CHKA(dq); CHKA(dt); CHKA(dr); CHKA(dc);
 	CHK(dj.up(jobs, n_jobs)); CHK(dq.up(qbuf, qbytes)); CHK(dt.up(tbuf, tbytes)); CHK(dc.zero());
@@ -383,10 +383,10 @@ int ssg_extend_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
 {
 	CHK(need_device());
 	if (n_jobs <= 0) return 0;
-	if (qcap != 72 && qcap != 136 && qcap != 256) { ssg_err_msg = "ssg_extend_lane_batch: qcap is 72, 136 or 256"; return SSG_EINVAL; }
+	if (qcap != 72 && qcap != 136 && qcap != 256 && qcap != 320) { ssg_err_msg = "ssg_extend_lane_batch: qcap is 72, 136, 256 or 320"; return SSG_EINVAL; }
 	if (dir != 1 && dir != -1) { ssg_err_msg = "ssg_extend_lane_batch: dir is +1 or -1"; return SSG_EINVAL; }
 	for (int i = 0; i < n_jobs; ++i) {
-		if (jobs[i].qlen > std::min(qcap, 254) || jobs[i].qlen < 0 || jobs[i].h0 <= 0 || jobs[i].tlen < 0) { ssg_err_msg = "ssg_extend_lane_batch: 0 <= qlen <= min(qcap, 254), h0 > 0, tlen >= 0"; return SSG_EINVAL; }
+		if (jobs[i].qlen > std::min(qcap, 318) || jobs[i].qlen < 0 || jobs[i].h0 <= 0 || jobs[i].tlen < 0) { ssg_err_msg = "ssg_extend_lane_batch: 0 <= qlen <= min(qcap, 318), h0 > 0, tlen >= 0"; return SSG_EINVAL; }
 		if ((long)jobs[i].h0 + (long)jobs[i].qlen * opt->a + std::max(jobs[i].end_bonus, 0) >= 8191) { ssg_err_msg = "ssg_extend_lane_batch: h0 + qlen * a exceeds the 13-bit DP cells"; return SSG_EINVAL; }
 		const int64_t last = tpos[i] + (int64_t)dir * (jobs[i].tlen - 1);
 		if (jobs[i].tlen > 0 && (tpos[i] < 0 || tpos[i] >= 2 * idx->v.l_pac || last < 0 || last >= 2 * idx->v.l_pac || (tpos[i] < idx->v.l_pac) != (last < idx->v.l_pac))) {
@@ -398,7 +398,8 @@ int ssg_extend_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
 	const long nb = (n_jobs + 63) / 64;
 	if (qcap == 72) SSG_LAUNCH(ssg_k_ext_lane_jobs<72>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
 	else if (qcap == 136) SSG_LAUNCH(ssg_k_ext_lane_jobs<136>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
-	else SSG_LAUNCH(ssg_k_ext_lane_jobs<256>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
+	else if (qcap == 256) SSG_LAUNCH(ssg_k_ext_lane_jobs<256>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
+	else SSG_LAUNCH(ssg_k_ext_lane_jobs<320>, nb, 64, 0, idx->v, *opt, n_jobs, dj.p, dp.p, dir, dq.p, dr.p, dc.p);
 	CHK(rt_sync());
 	CHK(dr.down(res, n_jobs));
 	if (cells) { unsigned long long c; CHK(dc.down(&c, 1)); *cells = c; }
@@ -411,7 +412,7 @@ int ssg_align2_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *j
 	CHK(need_device());
 	if (n_jobs <= 0) return 0;
 	int max_t = 1;
-	for (int i = 0; i < n_jobs; ++i) { if (jobs[i].qlen > 256 || jobs[i].qlen < 1) { ssg_err_msg = "ssg_align2_batch: 1 <= qlen <= 256"; return SSG_EINVAL; } max_t = std::max(max_t, jobs[i].tlen); }
+	for (int i = 0; i < n_jobs; ++i) { if (jobs[i].qlen > 320 || jobs[i].qlen < 1) { ssg_err_msg = "ssg_align2_batch: 1 <= qlen <= 320"; return SSG_EINVAL; } max_t = std::max(max_t, jobs[i].tlen); }
 	dbuf<ssg_sw_job_t> dj(n_jobs); dbuf<uint8_t> dq(qbytes + 1), dt(tbytes + 1); dbuf<ssg_kswr_t> dr(n_jobs); dbuf<unsigned long long> db((size_t)n_jobs * (max_t + 1));
 	CHKA(dj); CHKA(dq); CHKA(dt); CHKA(dr); CHKA(db);
 	CHK(dj.up(jobs, n_jobs)); CHK(dq.up(qbuf, qbytes)); CHK(dt.up(tbuf, tbytes));
@@ -447,7 +448,7 @@ static int run_msw_lane(const ssg_index_t *idx, const ssg_mem_opt_t *opt, long n
 			const uint64_t sl = hk[(size_t)i] & 0xffffffffu;
 			if ((long)sl >= n_slots) { ++bad_slot; continue; }
 			const ssg_msjob_t &jb = hj[(size_t)sl];
-			if (!(jb.qlen >= 1 && jb.qlen <= 256 && jb.tlen >= 1 && jb.tlen <= SSG_ML_TMAX && (uint64_t)jb.qp == hk[(size_t)i] >> 48 && (uint64_t)jb.tlen == (hk[(size_t)i] >> 32 & 0xffff))) ++bad_job;
+			if (!(jb.qlen >= 1 && jb.qlen <= 320 && jb.tlen >= 1 && jb.tlen <= SSG_ML_TMAX && (uint64_t)jb.qp == hk[(size_t)i] >> 48 && (uint64_t)jb.tlen == (hk[(size_t)i] >> 32 & 0xffff))) ++bad_job;
 		}
 		for (long i = 1; i < nj; ++i) if ((hs[(size_t)i] >> 32) < (hs[(size_t)i - 1] >> 32)) ++bad_order;
 		std::sort(hk.begin(), hk.end()); std::vector<uint64_t> hs2(hs); std::sort(hs2.begin(), hs2.end());
@@ -489,7 +490,7 @@ int ssg_align2_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
 	std::vector<ssg_msjob_t> hj((size_t)n_jobs); std::vector<uint64_t> hk;
 	for (int i = 0; i < n_jobs; ++i) {
 		const ssg_sw_job_t &jb = jobs[i];
-		if (jb.qlen > 256 || jb.qlen < 1 || jb.tlen < 0) { ssg_err_msg = "ssg_align2_lane_batch: 1 <= qlen <= 256, tlen >= 0"; return SSG_EINVAL; }
+		if (jb.qlen > 320 || jb.qlen < 1 || jb.tlen < 0) { ssg_err_msg = "ssg_align2_lane_batch: 1 <= qlen <= 320, tlen >= 0"; return SSG_EINVAL; }
 		const int64_t last = tpos[i] + jb.tlen - 1;
 		if (jb.tlen > 0 && (tpos[i] < 0 || last >= 2 * idx->v.l_pac || (tpos[i] < idx->v.l_pac) != (last < idx->v.l_pac))) {
 			ssg_err_msg = "ssg_align2_lane_batch: a target leaves its strand of the doubled reference"; return SSG_EINVAL; }
@@ -520,7 +521,7 @@ int ssg_global_batch(const ssg_mem_opt_t *opt, int n_jobs, const ssg_glb_job_t *
 	if (n_jobs <= 0) return 0;
 	long zmax = 1;
 	for (int i = 0; i < n_jobs; ++i) {
-		if (jobs[i].qlen > 254 || jobs[i].qlen < 1) { ssg_err_msg = "ssg_global_batch: 1 <= qlen <= 254"; return SSG_EINVAL; }
+		if (jobs[i].qlen > 318 || jobs[i].qlen < 1) { ssg_err_msg = "ssg_global_batch: 1 <= qlen <= 318"; return SSG_EINVAL; }
 		long ncol = std::min(jobs[i].qlen, 2 * jobs[i].w + 1); zmax = std::max(zmax, ncol * jobs[i].tlen);
 	}
 	dbuf<ssg_glb_job_t> dj(n_jobs); dbuf<uint8_t> dq(qbytes + 1), dt(tbytes + 1), dz((size_t)zmax * n_jobs); dbuf<int32_t> ds(n_jobs), dn(n_jobs); dbuf<uint32_t> dcg((size_t)n_jobs * cap);
@@ -830,7 +831,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		CHKA(d_nlong); CHK(d_nlong.zero());
 		SSG_LAUNCH(ssg_k_ext_prep, (n_jobs + 255) / 256, 256, 0, idx->v, *opt, n_reads, n_jobs, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
 		           d_choff.p, (int)SSG_TWIN_GLB, d_xjobs.p, d_kl.p, d_kr.p, short_cap, d_nlong.p);
-		CHK(sort_keys_u64(d_kl.p, d_sl.p, n_jobs, 32, 40)); CHK(sort_keys_u64(d_kr.p, d_sr.p, n_jobs, 32, 40));
+		CHK(sort_keys_u64(d_kl.p, d_sl.p, n_jobs, 32, 41)); CHK(sort_keys_u64(d_kr.p, d_sr.p, n_jobs, 32, 41));   /* 9 bits: 511 - side length */
 		unsigned int h_nlong[2];
 		CHK(d_nlong.down(h_nlong, 2));
 		if (ssg_debug()) fprintf(stderr, "[ssgpu] ext jobs %ld, long sides %u / %u\n", n_jobs, h_nlong[0], h_nlong[1]);
@@ -840,7 +841,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 			if (max_len <= 136 + opt->min_seed_len) {
 				if (nl) SSG_LAUNCH(ssg_k_ext_lane<136>, (nl + 63) / 64, 64, 0, idx->v, *opt, side, 0L, nl, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
 				if (n_jobs > nl) SSG_LAUNCH(ssg_k_ext_lane<72>, (n_jobs - nl + 63) / 64, 64, 0, idx->v, *opt, side, nl, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
-			} else SSG_LAUNCH(ssg_k_ext_lane<256>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, 0L, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
+			} else if (max_len <= 256) SSG_LAUNCH(ssg_k_ext_lane<256>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, 0L, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
+			else SSG_LAUNCH(ssg_k_ext_lane<320>, (n_jobs + 63) / 64, 64, 0, idx->v, *opt, side, 0L, n_jobs, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p);
 		}
 	}
 	STAGE("ext_lane");
@@ -905,7 +907,7 @@ int ssg_align1_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_rea
 	*regs = 0;
 	if (n_reads <= 0) { if (reg_off) reg_off[0] = 0; return 0; }
 	int max_len = 0; for (int r = 0; r < n_reads; ++r) max_len = std::max<int>(max_len, (int)(off[r+1] - off[r]));
-	if (max_len > 254) { ssg_err_msg = "reads longer than 254 bases are outside this build's scope"; return SSG_EINVAL; }
+	if (max_len > SSG_MAX_READ_LEN) { ssg_err_msg = "reads longer than " SSG_STR(SSG_MAX_READ_LEN) " bases are outside this build's scope"; return SSG_EINVAL; }
 	dbuf<uint8_t> d_seq((size_t)off[n_reads] + 1); dbuf<int64_t> d_off(n_reads + 1);
 	CHKA(d_seq); CHKA(d_off);
 	CHK(d_seq.up(seq, off[n_reads])); CHK(d_off.up(off, n_reads + 1));
@@ -1496,7 +1498,7 @@ int ssg_hotpath_dev_ex(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_p
 {
 	CHK(need_device());
 	if (keep_out) *keep_out = 0;
-	if (n_pairs <= 0 || max_len > 254) { ssg_err_msg = "ssg_hotpath_dev: bad arguments"; return SSG_EINVAL; }
+	if (n_pairs <= 0 || max_len > SSG_MAX_READ_LEN) { ssg_err_msg = "ssg_hotpath_dev: bad arguments"; return SSG_EINVAL; }
 	ssg_sbl_opt_t so; if (sbl) so = *sbl; else { ssg_sbl_opt_init(&so); so.exclude_dups = 1; so.add_mate_tags = 1; }   /* the reference's command line */
 	ssg_pe_result res; std::unique_ptr<ssg_dev_records> R(new ssg_dev_records());
 	R->n_pairs = n_pairs;

@@ -61,11 +61,11 @@ def make_extend_jobs(n, seed, max_qlen=200):
     return np.array(jobs, dtype=capi.EXT_JOB_DT), qs, ts
 
 
-def make_local_jobs(n, seed):
+def make_local_jobs(n, seed, qlens=(150, 150, 100, 76, 36, 250, 200)):
     rng = np.random.default_rng(seed)
     jobs, qs, ts, qo, to = [], [], [], 0, 0
     for _ in range(n):
-        qlen = int(rng.choice([150, 150, 100, 76, 36, 250, 200]))
+        qlen = int(rng.choice(list(qlens)))
         q = rng.integers(0, 4, size=qlen, dtype=np.uint8)
         mid = mutate(rng, q) if rng.random() < 0.8 else list(rng.integers(0, 4, size=50))
         if rng.random() < 0.3:
@@ -113,8 +113,8 @@ def sim_reads(n_pairs, seed, read_len=150, fasta=EXAMPLE_FA, **kw):
 REG_FIELDS = ["rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "csub", "w", "seedcov", "seedlen0", "n_comp", "frac_rep"]
 
 
-def check_extend(lib, oracle, n, seed):
-    jobs, qs, ts = make_extend_jobs(n, seed)
+def check_extend(lib, oracle, n, seed, max_qlen=200):
+    jobs, qs, ts = make_extend_jobs(n, seed, max_qlen=max_qlen)
     res, cells = lib.extend_batch(lib.opt_init(), jobs, np.concatenate(qs), np.concatenate(ts))
     for i in range(n):
         o = oracle.extend2(qs[i], ts[i], int(jobs[i]["w"]), 5, int(jobs[i]["zdrop"]), int(jobs[i]["h0"]))
@@ -131,7 +131,7 @@ def check_extend_lane(lib, oracle, n, seed, workdir, qcaps=(72, 136, 256)):
     fa = os.path.join(str(workdir), "extlane_%d.fa" % seed)
     done = 0
     for qcap in qcaps:
-        jobs, qs, ts = make_extend_jobs(n, seed + qcap, max_qlen=min(qcap, 254) + 1)
+        jobs, qs, ts = make_extend_jobs(n, seed + qcap, max_qlen=min(qcap, 318) + 1)
         for i in range(n):   # a share of the jobs with start scores near the ceiling of the packed cells (h0 + qlen * a + end_bonus < 8191)
             if rng.random() < 0.15:
                 jobs[i]["h0"] = 8190 - int(jobs[i]["qlen"]) - 5 - int(rng.integers(0, 60))
@@ -159,13 +159,13 @@ def check_extend_lane(lib, oracle, n, seed, workdir, qcaps=(72, 136, 256)):
     return done
 
 
-def check_local_lane(lib, oracle, n, seed, workdir, lanes=(1, 2, 4), scores=None):
+def check_local_lane(lib, oracle, n, seed, workdir, lanes=(1, 2, 4), scores=None, qlens=None):
     """ksw_align2 as mate rescue runs it in the product path (k_mswlane.h: forward pass by the lane kernel -- strips of 8 target rows in
     registers, packed 13-bit strip boundaries in LDS, 5-bit score table, targets from the 2-bit reference --, reverse pass by the wave code)
     against the oracle: make_local_jobs' queries (36 .. 250 bases, some with N) and targets (hits, half hits, second hits, none), the targets
     laid out as a reference of their own and read from both strands, 1 / 2 / 4 lanes per job."""
     rng = np.random.default_rng(seed)
-    jobs, qs, ts = make_local_jobs(n, seed)
+    jobs, qs, ts = make_local_jobs(n, seed, qlens) if qlens else make_local_jobs(n, seed)
     for i in range(n):
         if rng.random() < 0.2:   # N bases in the query
             q = qs[i].copy(); q[rng.random(q.size) < 0.03] = 4; qs[i] = q

@@ -25,11 +25,11 @@ def _run_pipeline(bwa, samblaster, ref, fq, d, tag, extra_bwa=()):
     return p1.stdout.decode(), p2.stdout.decode(), open(spl).read(), open(disc).read()
 
 
-def _check(bwa, samblaster, tmp_path, n_pairs, seed, extra_bwa=()):
+def _check(bwa, samblaster, tmp_path, n_pairs, seed, extra_bwa=(), **sim):
     d = str(tmp_path)
     contigs = simreads.read_fasta(EXAMPLE_FA)
     fq = os.path.join(d, "reads.fq.gz")
-    simreads.write_fastq(fq, simreads.simulate(contigs, n_pairs, seed=seed))
+    simreads.write_fastq(fq, simreads.simulate(contigs, n_pairs, seed=seed, **sim))
     got = _run_pipeline(bwa, samblaster, EXAMPLE_FA, fq, d, "got", extra_bwa)
     exp = _run_pipeline([ORC], [ORC, "samblaster"], EXAMPLE_FA, fq, d, "exp", extra_bwa)
     for g, e, what in zip(got, exp, ("bwa mem", "samblaster stdout", "splitters", "discordants")):
@@ -40,6 +40,12 @@ def _check(bwa, samblaster, tmp_path, n_pairs, seed, extra_bwa=()):
 def test_cli_emu_matches_oracle(tmp_path, emu_lib):
     emu = os.path.join(ROOT, "tests", "emu")
     _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 300, seed=21)
+
+
+def test_cli_emu_reads_of_300_bases(tmp_path, emu_lib):
+    # the reference's script takes reads of any length (bin/speedseq:196-200): 2x300 through the executables, text against the oracle's
+    emu = os.path.join(ROOT, "tests", "emu")
+    _check([os.path.join(emu, "bwa_emu")], [os.path.join(emu, "samblaster_emu")], tmp_path, 200, seed=23, read_len=300, ins_mean=900, ins_std=150)
 
 
 def test_cli_emu_samblaster_small_chunks(tmp_path, emu_lib, monkeypatch):
@@ -76,6 +82,11 @@ def test_cli_error_behaviour(tmp_path, emu_lib):
         r = subprocess.run([emu, "mem", "-p"] + opts + [EXAMPLE_FA, str(fq)], capture_output=True, timeout=120)
         assert r.returncode != 0 and msg in r.stderr, (opts, r.stderr[-300:])
         assert not any(l and l[0] != "@" for l in r.stdout.decode().split("\n")), opts
+
+
+@pytest.mark.gpu
+def test_cli_gpu_reads_of_300_bases(tmp_path, gpu_lib):
+    _check([os.path.join(ROOT, "bin", "bwa")], [os.path.join(ROOT, "bin", "samblaster")], tmp_path, 2000, seed=23, read_len=300, ins_mean=900, ins_std=150)
 
 
 @pytest.mark.gpu

@@ -63,6 +63,19 @@ def test_gpu_pe_sam_250_long_insert(gpu_lib, oracle):
     assert text.count("\n") >= 3000
 
 
+def test_gpu_pe_sam_300(gpu_lib, oracle, tmp_path, repeat_prefix):
+    # 2x300: every column class above 256 (see test_emu_pe_sam_300), end to end and stage by stage
+    text, stats = common.check_pe_sam(gpu_lib, oracle, 1200, seed=19, read_len=300, ins_mean=900, ins_std=150)
+    assert text.count("\n") >= 2400
+    assert common.check_align1(gpu_lib, oracle, 1500, seed=20, read_len=300) > 3000
+    assert common.check_extend_lane(gpu_lib, oracle, 500, seed=9, workdir=tmp_path, qcaps=(320,)) == 2000
+    common.check_extend(gpu_lib, oracle, 1500, seed=21, max_qlen=318)
+    done, taken = common.check_local_lane(gpu_lib, oracle, 400, seed=22, workdir=tmp_path, lanes=(4, 2, 1), qlens=(300, 300, 310, 280, 257, 264))
+    assert done == 2400 and taken > 2000
+    common.check_smem(gpu_lib, oracle, 600, seed=23, read_len=300, cap=192)
+    assert common.check_align1(gpu_lib, oracle, 200, seed=24, read_len=300, prefix=repeat_prefix) > 5000   # wave-per-read chaining: query coordinates beyond 255
+
+
 def test_gpu_pe_edge_cases(gpu_lib, oracle):
     common.check_pe_edge_cases(gpu_lib, oracle)
 

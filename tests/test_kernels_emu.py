@@ -107,6 +107,20 @@ def test_emu_repeats_pe_sam(emu_lib, oracle, repeat_prefix):
     assert "XA:Z:" in text
 
 
+def test_emu_pe_sam_300(emu_lib, oracle, tmp_path, repeat_prefix):
+    # 2x300 (the reference's script takes any read length, bin/speedseq:196-200): the column classes above 256 -- fifth register column of the
+    # wave SW (k_sw.h), ssg_k_ext_lane<320>, 9-bit column tags of the lane kernels, 16-bit query coordinates of the wave chaining, 40 LDS words of
+    # the seeding kernels -- end to end against the oracle, and the stage twins at those lengths
+    text, stats = common.check_pe_sam(emu_lib, oracle, 250, seed=19, read_len=300, ins_mean=900, ins_std=150)
+    assert text.count("\n") >= 500
+    assert common.check_align1(emu_lib, oracle, 200, seed=20, read_len=300) > 400
+    assert common.check_extend_lane(emu_lib, oracle, 60, seed=9, workdir=tmp_path, qcaps=(320,)) == 240
+    common.check_extend(emu_lib, oracle, 150, seed=21, max_qlen=318)
+    done, taken = common.check_local_lane(emu_lib, oracle, 24, seed=22, workdir=tmp_path, lanes=(4, 2), qlens=(300, 300, 310, 280, 257, 264))
+    assert done == 96 and taken > 80
+    assert common.check_align1(emu_lib, oracle, 40, seed=24, read_len=300, prefix=repeat_prefix) > 1000   # wave-per-read chaining: query coordinates beyond 255
+
+
 def test_emu_repeats_mate_rescue(emu_lib, oracle, repeat_pe_prefix):
     text, stats = common.check_pe_sam(emu_lib, oracle, 250, seed=5, prefix=repeat_pe_prefix)
     assert stats[3] > 1000   # rescues

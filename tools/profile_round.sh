@@ -18,7 +18,11 @@ $PWD/../repo/tools/dbg/gather_probe > $out/${tag}_gather_probe.txt 2>&1 || /root
 /root/repo/tools/dbg/libm_probe > $out/${tag}_libm_probe.txt 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_${tag}_probe -o pmc -- /root/repo/tools/dbg/gather_probe > $out/${tag}_probe_under_pmc.log 2>&1
 f=$(find /tmp/pmc_${tag}_probe -name "*counter_collection.csv" | head -1)
-if [ -n "$f" ]; then (head -1 $f; grep "probe" $f) > $out/${tag}_pmc_probe_calibration.csv; fi
+if [ -n "$f" ]; then (head -1 $f; grep "probe\|stream_" $f) > $out/${tag}_pmc_probe_calibration.csv; fi
+# ... and the write counter on the probe's streaming launches (a pass of its own: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_${tag}_probe_w -o pmc -- /root/repo/tools/dbg/gather_probe > $out/${tag}_probe_under_pmc_w.log 2>&1
+f=$(find /tmp/pmc_${tag}_probe_w -name "*counter_collection.csv" | head -1)
+if [ -n "$f" ]; then (head -1 $f; grep "stream_" $f) > $out/${tag}_pmc_probe_calibration_write.csv; fi
 rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|Counter).*(TCC_HIT|TCC_MISS|TCC_REQ|SQ_INSTS_VALU|FETCH_SIZE)" | head -20 > $out/${tag}_counter_names.txt
 ls -la $out | tail -20
 cat $out/${tag}_libm_probe.txt; grep -c ssg_k $out/${tag}_pmc_*.csv
