@@ -730,7 +730,7 @@ def main():
             # taken on this workload with these kernels, otherwise null -- never a constant in this file
             traffic = None
             real = {"ssg_k_smem2_kt": "ssg_k_smem2<false, true>", "ssg_k_smem2_plain": "ssg_k_smem2<false, false>"}   # the launcher's names of the template instances (ssg_seed.cpp) -> rocprofv3's
-            for tag in ("r04", "r02"):
+            for tag in ("r05", "r04", "r02"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
                     if pm.get("pairs") == a.pairs and pm.get("read_len") == rl and abs(pm.get("ref_mbp", 0) - a.ref_mbp) < 1e-6 and seed_k and all(real.get(k, k) in pm.get("bytes_per_launch", {}) for k in seed_k):
@@ -740,15 +740,15 @@ def main():
                     pass
             valu = {}; sw_lane_ops = None
             try:   # fraction of the measured int32 VALU issue peak (tools/dbg/valu_probe) from the committed SQ counter pass of this workload
-                pq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_sq.json")) else "r02_pmc_sq.json")))
-                valu = {k: round(v["valu_frac_of_probe_peak"], 3) for k, v in pq["kernels"].items() if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_smem")) and "valu_frac_of_probe_peak" in v and not k.endswith("_need")}
+                pq = json.load(open(next(f for f in (os.path.join(ROOT, "profiles", t + "_pmc_sq.json") for t in ("r05", "r04", "r02")) if os.path.exists(f))))
+                valu = {k: round(v["valu_frac_of_probe_peak"], 3) for k, v in pq["kernels"].items() if k.startswith(("ssg_k_matesw", "ssg_k_msw_lane", "ssg_k_ext_lane", "ssg_k_smem")) and "valu_frac_of_probe_peak" in v and not k.endswith("_need")}
                 # vector instructions of the SW kernels per step (committed counters of the same kernels' code: the ISA is pinned) x 64 lanes
-                pmc_steps = max(1, pq["kernels"].get("ssg_k_matesw", {}).get("launches", 1))   # one mate-rescue launch per step of the counter run
+                pmc_steps = max([1] + [v.get("launches", 1) for k, v in pq["kernels"].items() if k.startswith("ssg_k_matesw") and not k.startswith("ssg_k_matesw_need")])   # one mate-rescue launch per step of the counter run
                 sw_lane_ops = None if not (a.pairs == 1000000 and rl == 150 and abs(a.ref_mbp - 3100.0) < 1e-6) else 64.0 * sum(v["SQ_INSTS_VALU_per_launch"] * v["launches"] / pmc_steps for k, v in pq["kernels"].items()
-                                         if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need") and "SQ_INSTS_VALU_per_launch" in v)
+                                         if k.startswith(("ssg_k_matesw", "ssg_k_msw_lane", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need") and "SQ_INSTS_VALU_per_launch" in v)
             except Exception:
                 pass
-            sw_names = [k for k in kern if k.startswith(("ssg_k_matesw", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need")]
+            sw_names = [k for k in kern if k.startswith(("ssg_k_matesw", "ssg_k_msw_lane", "ssg_k_ext_lane", "ssg_k_chain2aln", "ssg_k_reg2aln")) and not k.endswith("_need")]
             sw_ms = sum(kern[k][0] for k in sw_names) / a.steps
             out["roofline"] = {"bound": "hbm", "kernel": name, "largest_kernel": {"name": largest, "ms_per_launch": kern[largest][0] / kern[largest][1]}, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                                "ms_per_launch": per_launch_ms,
@@ -761,7 +761,7 @@ def main():
                                "sw": {"cells_per_step": int(summary[3]) + int(summary[4]), "kernels": sorted(sw_names),
                                       "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None,
                                       "lane_ops_per_cell": (sw_lane_ops / (int(summary[3]) + int(summary[4]))) if sw_lane_ops and (int(summary[3]) + int(summary[4])) else None,   # SQ_INSTS_VALU x 64 of the SW kernels (committed counters, pinned ISA) over this run's DP cells
-                                      "valu_frac": valu or None, "valu_frac_source": "profiles/r04_pmc_sq.json if present, else r02 (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
+                                      "valu_frac": valu or None, "valu_frac_source": "profiles/r05_pmc_sq.json if present, else r04 / r02 (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
         # ---- parity gate ON THE TIMED CALL + CPU baseline: the step is run once more on the same device-resident inputs with its records
         # kept in HBM (identical inputs -> identical records; the summaries are compared), the records and samblaster's per-line decisions
         # are downloaded, and the oracle (scalar C restatement of bwa mem + samblaster) aligns the same pairs in the same upstream batches ----

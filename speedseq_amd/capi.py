@@ -328,7 +328,12 @@ def prof_get(lib, cap=64):
     ms = (C.c_double * cap)()
     cnt = (C.c_long * cap)()
     n = lib.l.ssg_prof_get(C.c_int(cap), names, ms, cnt)
-    return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}
+    out = {}
+    for i in range(min(n, cap)):   # the instance for reads up to 255 bases keeps the kernel's plain name; the other one says so
+        k = names[i].decode().replace("<false>", "").replace("<true>", "<wide>")
+        a, b = out.get(k, (0.0, 0))
+        out[k] = (a + ms[i], b + cnt[i])
+    return out
 
 
 def sam_format(lib, idx, opt, res, names, seq, off, quals=None, rg_id=""):

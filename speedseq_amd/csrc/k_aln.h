@@ -30,6 +30,7 @@ SSG_DEVFN int ssg_put_int(char *s, int l, int cap, int v, bool wr = true)
 }
 
 /* upstream bwa_gen_cigar2 for one region; fills out->cigar/n_cigar/NM/md; returns the score */
+template <bool WIDE>
 SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, int w_, int l_query, const uint8_t *query, int64_t rb, int64_t re,
                            uint8_t *tbuf, uint8_t *z, ssg_aln_t *out, int *err, unsigned long long *cells, uint8_t *tlds, uint8_t *qlds)
 {
@@ -61,7 +62,7 @@ SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 		w = w > min_w ? w : min_w;
 		const long ncol = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
 		if (ncol * rlen > SSG_Z_CAP) { *err = 5; return 0; }
-		score = wv_global2_any(opt, l_query, q, rlen, t, w, z, cells);
+		score = wv_global2_any<WIDE>(opt, l_query, q, rlen, t, w, z, cells);
 		int nc = 0;
 		SSG_LANE0(nc = ssg_global_backtrace(z, l_query, rlen, w, out->cigar, SSG_MAX_CIGAR));
 		n_cigar = wv_bcast(nc, 0);
@@ -174,6 +175,7 @@ __global__ void __launch_bounds__(64) ssg_k_reg2aln_lane(ssg_index_view_t ix, ss
 #ifndef SSG_R2A_WAVES
 #define SSG_R2A_WAVES 4   /* 128 VGPRs: 28 ms against 40 at 2 waves/SIMD (211 VGPRs) */
 #endif
+template <bool WIDE>
 __global__ void __launch_bounds__(256, SSG_R2A_WAVES) ssg_k_reg2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
                               const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, uint8_t *tglb, uint8_t *zglb, int32_t *err, unsigned long long *cells,
                               const int32_t *todo_list, const unsigned int *n_todo /* the records ssg_k_reg2aln_lane left (NULL: all n_req) */)
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256, SSG_R2A_WAVES) ssg_k_reg2aln(ssg_index_vi
 		i = 0;
 		do {
 			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
-			score = wv_gen_cigar(ix, opt, w2, qe - qb, query + qb, rb, re, tg, z, a, &myerr, &nc, tlds_[wslot], qlds_[wslot]);
+			score = wv_gen_cigar<WIDE>(ix, opt, w2, qe - qb, query + qb, rb, re, tg, z, a, &myerr, &nc, tlds_[wslot], qlds_[wslot]);
 			if (score == last_sc || w2 == opt.w << 2) break;
 			last_sc = score;
 			w2 <<= 1;

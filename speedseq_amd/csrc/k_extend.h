@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) ssg_k_extend_jobs(ssg_mem_opt_t opt, int 
 	ssg_ext_job_t jb = jobs[wid];
 	ssg_seqv_t q = { qbuf + jb.qoff, 1 }, t = { tbuf + jb.toff, 1 };
 	unsigned long long nc = 0;
-	ssg_ext_res_t r = wv_extend2_any(opt, jb.qlen, q, jb.tlen, t, jb.w, jb.end_bonus, jb.zdrop, jb.h0, &nc);
+	ssg_ext_res_t r = wv_extend2_any<true>(opt, jb.qlen, q, jb.tlen, t, jb.w, jb.end_bonus, jb.zdrop, jb.h0, &nc);
 	if (wv_lane() == 0) { res[wid] = r; if (cells) atomicAdd(cells, nc); }
 }
 
@@ -74,6 +74,7 @@ struct ssg_reg_sc_lt {
 
 /* score of the banded global alignment of query[qb,qe) vs reference [rb,re) as upstream
  * bwa_gen_cigar2 computes it with n_cigar == NULL (both reversed when on the reverse strand) */
+template <bool WIDE>
 SSG_DEVFN int wv_gen_score(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, int w_, int l_query, const uint8_t *query,
                            int64_t rb, int64_t re, uint8_t *tbuf, int *ok, unsigned long long *cells)
 {
@@ -99,9 +100,10 @@ SSG_DEVFN int wv_gen_score(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 	w = w < w_ ? w : w_;
 	int min_w = iabs(rlen - l_query) + 3;
 	w = w > min_w ? w : min_w;
-	return wv_global2_any(opt, l_query, q, rlen, t, w, 0, cells);
+	return wv_global2_any<WIDE>(opt, l_query, q, rlen, t, w, 0, cells);
 }
 
+template <bool WIDE>
 SSG_DEVFN int wv_patch_reg(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const uint8_t *query, const ssg_alnreg_t &a, const ssg_alnreg_t &b,
                            int *_w, uint8_t *tbuf, int tcap, int *err, unsigned long long *cells)
 {	/* upstream mem_patch_reg */
@@ -117,7 +119,7 @@ SSG_DEVFN int wv_patch_reg(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 	w += a.w + b.w;
 	w = w < opt.w << 2 ? w : opt.w << 2;
 	if (b.re - a.rb > tcap) { *err = 1; return 0; }
-	score = wv_gen_score(ix, opt, w, b.qe - a.qb, query + a.qb, a.rb, b.re, tbuf, &ok, cells);
+	score = wv_gen_score<WIDE>(ix, opt, w, b.qe - a.qb, query + a.qb, a.rb, b.re, tbuf, &ok, cells);
 	if (!ok) score = 0; /* upstream leaves score unset when bwa_gen_cigar2 bails out; unreachable for same-strand regs */
 	q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
 	r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
@@ -127,6 +129,7 @@ SSG_DEVFN int wv_patch_reg(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 }
 
 /* upstream mem_sort_dedup_patch (wave-uniform; `patch` enables mem_patch_reg as in mem_align1_core) */
+template <bool WIDE>
 SSG_DEVFN_COLD int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const uint8_t *query, int patch, int n, ssg_alnreg_t *a,
                                   uint8_t *tbuf, int tcap, int *err, unsigned long long *cells)
 {
@@ -147,7 +150,7 @@ SSG_DEVFN_COLD int wv_sort_dedup_patch(const ssg_index_view_t &ix, const ssg_mem
 			if (or_ > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq) {
 				if (p->score < q->score) { SSG_LANE0(p->qe = p->qb); break; }
 				else SSG_LANE0(q->qe = q->qb);
-			} else if (patch && q->rb < p->rb && (score = wv_patch_reg(ix, opt, query, *q, *p, &w, tbuf, tcap, err, cells)) > 0) {
+			} else if (patch && q->rb < p->rb && (score = wv_patch_reg<WIDE>(ix, opt, query, *q, *p, &w, tbuf, tcap, err, cells)) > 0) {
 				SSG_LANE0(
 				p->n_comp += q->n_comp + 1;
 				p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
@@ -198,6 +201,7 @@ SSG_DEVFN int ssg_seed_in_region(const ssg_mem_opt_t &opt, const ssg_seed_t &s, 
  * ids), srt[] (u64 work array), regs[] (capacity = #seeds of the read).  n_reg[r] receives the
  * number of regions left after mem_sort_dedup_patch; err[r] != 0 flags a window overflow.
  */
+template <bool WIDE>
 SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
@@ -315,7 +319,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				for (i = 0; i < SSG_MAX_BAND_TRY; ++i) {
 					int prev = a.score;
 					aw[0] = opt.w << i;
-					x = wv_extend2_any(opt, s.qbeg, qs, (int)tmp, rs, aw[0], opt.pen_clip5, opt.zdrop, s.len * opt.a, &nc);
+					x = wv_extend2_any<WIDE>(opt, s.qbeg, qs, (int)tmp, rs, aw[0], opt.pen_clip5, opt.zdrop, s.len * opt.a, &nc);
 					a.score = x.score; max_off[0] = x.max_off;
 					if (a.score == prev || max_off[0] < (aw[0] >> 1) + (aw[0] >> 2)) break;
 				}
@@ -335,7 +339,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				for (i = 0; i < SSG_MAX_BAND_TRY; ++i) {
 					int prev = a.score;
 					aw[1] = opt.w << i;
-					x = wv_extend2_any(opt, l_query - qe, qs, (int)(rmax[1] - rmax[0] - re), rs, aw[1], opt.pen_clip3, opt.zdrop, sc0, &nc);
+					x = wv_extend2_any<WIDE>(opt, l_query - qe, qs, (int)(rmax[1] - rmax[0] - re), rs, aw[1], opt.pen_clip3, opt.zdrop, sc0, &nc);
 					a.score = x.score; max_off[1] = x.max_off;
 					if (a.score == prev || max_off[1] < (aw[1] >> 1) + (aw[1] >> 2)) break;
 				}
@@ -361,7 +365,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 		int m = -1;
 		if (av_n <= SSG_SDP_SMALL) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2, l_pac);
 		else if (av_n <= SSG_SDP_BIG) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2, l_pac);
-		av_n = m >= 0 ? m : wv_sort_dedup_patch(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
+		av_n = m >= 0 ? m : wv_sort_dedup_patch<WIDE>(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
 		/* no pair of regions reached mem_patch_reg's alignment: the list is the output of the plain redundancy scan, a fixed point of it
 		 * (mate rescue's first re-sort of this list can be the incremental one, k_sdp.h wv_sort_dedup_incr) */
 		if (wv_lane() == 0 && sdp_fixed) sdp_fixed[r] = m >= 0;
@@ -380,8 +384,12 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
  * path has (an extension of a later seed, a patch alignment in mem_sort_dedup_patch, long lists) is left untouched
  * and flagged for the wave kernel.
  */
+#ifndef SSG_C2A_LANE_CHAINS
 #define SSG_C2A_LANE_CHAINS 6
+#endif
+#ifndef SSG_C2A_LANE_SEEDS
 #define SSG_C2A_LANE_SEEDS 8
+#endif
 __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const int64_t *read_off, const int64_t *seed_off,
                                 const ssg_seed_t *seeds, const int32_t *chain_seeds, const int32_t *n_chain, ssg_alnreg_t *regs, int32_t *n_reg,
                                 int32_t *err, const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r,
@@ -502,6 +510,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain2aln_lane(ssg_index_view_t ix, 
 }
 
 /* grid-strided: every resident wavefront owns one LDS window and one SSG_TWIN_GLB slab of tglb */
+template <bool WIDE>
 __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const uint8_t *seq, const int64_t *read_off,
                                 const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
@@ -518,7 +527,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 	for (;;) { /* waves pull reads from a heaviest-first list: the per-read work is heavy-tailed (repeats) */
 		const long k = wv_queue_pop(queue);
 		if (k >= (todo_list ? (long)*n_todo : (long)n_reads)) break;
-		wv_chain2aln_read(ix, opt, todo_list ? todo_list[k] : work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
+		wv_chain2aln_read<WIDE>(ix, opt, todo_list ? todo_list[k] : work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
 		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r, sdp_fixed);
 	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);

@@ -37,14 +37,18 @@ __global__ void ssg_k_idx_text(const uint8_t *fwd, int64_t l_pac, uint8_t *T, in
 #define SSG_IDX_BK_PER_LANE 16
 #define SSG_IDX_BK_PER_WG (256 * SSG_IDX_BK_PER_LANE)
 SSG_DEVFN uint32_t ssg_idx_bucket_mask(const uint8_t *T, int64_t n, int p, uint32_t b, int64_t i0)
-{	/* bit k: suffix i0 + k is in bucket b */
+{	/* bit k: suffix i0 + k is in bucket b.  The lane's 16 symbols and the p - 1 <= 15 behind them as two 16-byte loads (i0 is a multiple of 16,
+	 * T is zero-padded by >= 64 bytes past n: consecutive lanes read consecutive 16-byte words, the second load mostly hits the first of the next lane) */
 	uint32_t m = 0, v = 0;
 	if (i0 >= n) return 0;
 	if (p == 0) { for (int k = 0; k < SSG_IDX_BK_PER_LANE; ++k) if (i0 + k < n) m |= 1u << k; return m; }   /* one bucket: every suffix */
-	for (int k = 0; k < p - 1; ++k) v = v << 2 | T[i0 + k];                /* T is zero-padded past n */
+	uint32_t x[8];
+	memcpy(x, T + i0, 32);
+	uint64_t w = 0;   /* the 32 symbols two bits each, the first on top */
+	SSG_UNROLL for (int j = 0; j < 8; ++j) { const uint32_t t = x[j]; w = w << 8 | (uint64_t)((t & 3u) << 6 | (t >> 8 & 3u) << 4 | (t >> 16 & 3u) << 2 | (t >> 24 & 3u)); }
 	const uint32_t keep = p >= 16 ? ~0u : (1u << (2 * p)) - 1u;
-	for (int k = 0; k < SSG_IDX_BK_PER_LANE; ++k) {
-		v = (v << 2 | T[i0 + k + p - 1]) & keep;
+	SSG_UNROLL for (int k = 0; k < SSG_IDX_BK_PER_LANE; ++k) {   /* p + k <= 31: p <= 8 (SSG_INDEX_BUCKET_P), k <= 15 */
+		v = (uint32_t)(w >> (2 * (32 - p - k))) & keep;
 		if (i0 + k < n && v == b) m |= 1u << k;
 	}
 	return m;

@@ -56,6 +56,7 @@ __global__ void ssg_k_pestat_hist(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_
 /* ---------------- mate rescue ---------------- */
 #define SSG_MS_BCAP 32768   /* rows of a rescue window (b[] entries) per resident wave */
 
+template <bool WIDE>
 SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const ssg_pestat_t *pes, const ssg_alnreg_t a,
                         int l_ms, const uint8_t *ms, ssg_alnreg_t *ma, int *ma_n_, int ma_cap,
                         uint8_t *tbuf, int tcap, uint8_t *revbuf, unsigned long long *bscratch, int *err, unsigned long long *cells, unsigned long long *ph,
@@ -119,8 +120,8 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 				q.p = revbuf; q.dir = 1;
 			} else { q.p = ms; q.dir = 1; }
 			ssg_seqv_t t = { tbuf, 1 };
-			if (!pre) aln = wv_align2(opt, l_ms, q, (int)(re - rb), t, xtra, bscratch, cells);
-			else if (want_rev) wv_align2_rev(opt, l_ms, q, t, xtra, aln, bscratch, cells);
+			if (!pre) aln = wv_align2<WIDE>(opt, l_ms, q, (int)(re - rb), t, xtra, bscratch, cells);
+			else if (want_rev) wv_align2_rev<WIDE>(opt, l_ms, q, t, xtra, aln, bscratch, cells);
 			if (SSG_TUNING && wv_lane() == 0) { if (pre == 1 && want_rev) { atomicAdd(&ssg_dbg_cyc[29], 1ull); atomicAdd(&ssg_dbg_cyc[30], (unsigned long long)(aln.te + 1)); } if (!pre) atomicAdd(&ssg_dbg_cyc[31], 1ull); }
 			ph[1] += ssg_clock() - c0; if (SSG_TUNING) ph[3] += (unsigned long long)(re - rb);
 			if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
@@ -160,7 +161,7 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			if (*ma_fixed && ma_n - 1 <= SSG_SDP_BIG) m = xpos_last < 0 ? ma_n : wv_sort_dedup_incr(opt, ma_n, ma, sdp_tmp, xpos_last);
 			if (m < 0) m = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2)
 			           : ma_n <= SSG_SDP_BIG ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2)
-			           : wv_sort_dedup_patch(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells);
+			           : wv_sort_dedup_patch<WIDE>(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells);
 			ma_n = m; *ma_fixed = 1; xpos_last = -1;
 			c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1;
 		}
@@ -211,6 +212,7 @@ __global__ void __launch_bounds__(64) ssg_k_matesw_need(ssg_index_view_t ix, ssg
 	if (need) todo_list[atomicAdd(n_todo, 1u)] = (int32_t)p;
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, const uint8_t *seq, const int64_t *read_off,
                              const int64_t *reg_off, ssg_alnreg_t *regs, int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                              ssg_alnreg_t *bcopy, uint8_t *tglb, unsigned long long *bglb, int32_t *err, unsigned long long *cells, unsigned long long *n_rescue,
@@ -265,7 +267,7 @@ __global__ void __launch_bounds__(256, SSG_SW_WAVES_PER_SIMD) ssg_k_matesw(ssg_i
 				for (int j = 0; j < nb[i]; ++j) {
 					const int l_ms = (int)(read_off[2*p + !i + 1] - read_off[2*p + !i]);
 					const uint8_t *ms = seq + read_off[2*p + !i];
-					nres += (unsigned long long)wv_matesw(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot], sdpbig + wave0, &fixed[!i], jres ? jres + jbase[2*kq + i] + 4 * j : 0, &npre);
+					nres += (unsigned long long)wv_matesw<WIDE>(ix, opt, pes, bc[i * 64 + j], l_ms, ms, a[!i], &an[!i], cap[!i], tg, SSG_TWIN_GLB, revlds[wslot], bs, &myerr, &nc, ph, bc + 128, &sdplds[wslot], sdpbig + wave0, &fixed[!i], jres ? jres + jbase[2*kq + i] + 4 * j : 0, &npre);
 				}
 		}
 		if (wv_lane() == 0) { n_reg[2*p] = an[0]; n_reg[2*p+1] = an[1]; if (myerr) err[p] = myerr; }

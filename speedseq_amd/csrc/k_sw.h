@@ -171,14 +171,19 @@ SSG_DEVFN ssg_ext_res_t wv_extend2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_
 	return r;
 }
 
+/* WIDE: the kernel instance serves reads of 256..319 bases too (a fifth register column per lane).  A template parameter of every function on
+ * the way down from the kernel, because its mere presence costs the narrow reads: inlined it raised the register pressure of ssg_k_chain2aln
+ * (30.5 -> 38.8 ms on 2x150), out of line the call alone did (39.9 ms; profiles/r05n_ab.json).  The host launches the WIDE instance of a kernel
+ * only for a batch with a read above 255 bases. */
+template <bool WIDE>
 SSG_DEVFN ssg_ext_res_t wv_extend2_any(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target,
                                        int w, int end_bonus, int zdrop, int h0, unsigned long long *cells)
 {	/* qlen+1 columns are needed (eh[qlen]) */
 	if (qlen < 64)  return wv_extend2<1>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
 	if (qlen < 128) return wv_extend2<2>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
 	if (qlen < 192) return wv_extend2<3>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
-	if (qlen < 256) return wv_extend2<4>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
-	return wv_extend2<5>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
+	if (!WIDE || qlen < 256) return wv_extend2<4>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
+	return wv_extend2<WIDE ? 5 : 4>(opt, qlen, query, tlen, target, w, end_bonus, zdrop, h0, cells);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -263,13 +268,14 @@ SSG_DEVFN int wv_global2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, i
 	return wv_get(ssg_pick<NS>(H, qlen % NS), qlen / NS);
 }
 
+template <bool WIDE>
 SSG_DEVFN int wv_global2_any(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int w, uint8_t *z, unsigned long long *cells)
 {
 	if (qlen < 64)  return wv_global2<1>(opt, qlen, query, tlen, target, w, z, cells);
 	if (qlen < 128) return wv_global2<2>(opt, qlen, query, tlen, target, w, z, cells);
 	if (qlen < 192) return wv_global2<3>(opt, qlen, query, tlen, target, w, z, cells);
-	if (qlen < 256) return wv_global2<4>(opt, qlen, query, tlen, target, w, z, cells);
-	return wv_global2<5>(opt, qlen, query, tlen, target, w, z, cells);
+	if (!WIDE || qlen < 256) return wv_global2<4>(opt, qlen, query, tlen, target, w, z, cells);
+	return wv_global2<WIDE ? 5 : 4>(opt, qlen, query, tlen, target, w, z, cells);
 }
 
 /* upstream ksw_global2 backtrace; single lane.  cigar[] gets ops in forward order; returns n_cigar
@@ -428,6 +434,7 @@ SSG_DEVFN ssg_kswr_t wv_align2_t(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t 
 /* does ksw_align2 run its reverse pass after a forward pass that ended with this score? */
 SSG_DEVFN bool ssg_align2_has_rev(int xtra, int score) { return (xtra & SSG_KSW_XSTART) != 0 && !((xtra & SSG_KSW_XSUBO) && score < (xtra & 0xffff)); }
 SSG_DEVFN int ssg_align2_qp(int qlen, int xtra) { return (xtra & SSG_KSW_XBYTE) ? ((qlen + 15) / 16) * 16 : ((qlen + 7) / 8) * 8; }
+template <bool WIDE>
 SSG_DEVFN ssg_kswr_t wv_align2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target, int xtra,
                                unsigned long long *bscratch, unsigned long long *cells)
 {
@@ -435,11 +442,12 @@ SSG_DEVFN ssg_kswr_t wv_align2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t qu
 	if (qp <= 64)  return wv_align2_t<1>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 128) return wv_align2_t<2>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 	if (qp <= 192) return wv_align2_t<3>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
-	if (qp <= 256) return wv_align2_t<4>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
-	return wv_align2_t<5>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
+	if (!WIDE || qp <= 256) return wv_align2_t<4>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
+	return wv_align2_t<WIDE ? 5 : 4>(opt, qlen, query, tlen, target, xtra, bscratch, cells);
 }
 /* ksw_align2 whose forward pass (r.score, te, qe, score2, te2) was computed elsewhere (k_mswlane.h): the reverse pass in the column layout
  * the whole call would have used */
+template <bool WIDE>
 SSG_DEVFN void wv_align2_rev(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, ssg_seqv_t target, int xtra, ssg_kswr_t &r,
                              unsigned long long *bscratch, unsigned long long *cells)
 {
@@ -447,7 +455,7 @@ SSG_DEVFN void wv_align2_rev(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t quer
 	if (qp <= 64)  return wv_align2_rev_t<1>(opt, query, target, xtra, r, bscratch, cells);
 	if (qp <= 128) return wv_align2_rev_t<2>(opt, query, target, xtra, r, bscratch, cells);
 	if (qp <= 192) return wv_align2_rev_t<3>(opt, query, target, xtra, r, bscratch, cells);
-	if (qp <= 256) return wv_align2_rev_t<4>(opt, query, target, xtra, r, bscratch, cells);
-	return wv_align2_rev_t<5>(opt, query, target, xtra, r, bscratch, cells);
+	if (!WIDE || qp <= 256) return wv_align2_rev_t<4>(opt, query, target, xtra, r, bscratch, cells);
+	return wv_align2_rev_t<WIDE ? 5 : 4>(opt, query, target, xtra, r, bscratch, cells);
 }
 #endif

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) ssg_k_align2_jobs(ssg_mem_opt_t opt, int 
 	if (wid >= n_jobs) return;
 	ssg_sw_job_t jb = jobs[wid];
 	ssg_seqv_t q = { qbuf + jb.qoff, 1 }, t = { tbuf + jb.toff, 1 };
-	ssg_kswr_t r = wv_align2(opt, jb.qlen, q, jb.tlen, t, jb.xtra, bscratch + wid * (long)bstride, 0);
+	ssg_kswr_t r = wv_align2<true>(opt, jb.qlen, q, jb.tlen, t, jb.xtra, bscratch + wid * (long)bstride, 0);
 	if (wv_lane() == 0) res[wid] = r;
 }
 
@@ -61,8 +61,8 @@ __global__ void __launch_bounds__(256) ssg_k_align2_fin_jobs(ssg_index_view_t ix
 	if (want_rev) for (int k = wv_lane(); k < (pre ? r.te + 1 : jb.tlen); k += 64) tb[k] = (uint8_t)ssg_ref_base(ix, rb + k);
 	ssg_wave_memsync();
 	ssg_seqv_t q = { qbuf + jb.qoff, 1 }, t = { tb, 1 };
-	if (!pre) r = wv_align2(opt, jb.qlen, q, jb.tlen, t, jb.xtra, bscratch + wid * (long)bstride, 0);
-	else if (want_rev) wv_align2_rev(opt, jb.qlen, q, t, jb.xtra, r, bscratch + wid * (long)bstride, 0);
+	if (!pre) r = wv_align2<true>(opt, jb.qlen, q, jb.tlen, t, jb.xtra, bscratch + wid * (long)bstride, 0);
+	else if (want_rev) wv_align2_rev<true>(opt, jb.qlen, q, t, jb.xtra, r, bscratch + wid * (long)bstride, 0);
 	if (wv_lane() == 0) { res[wid] = r; from_lane[wid] = pre; }
 }
 
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) ssg_k_global_jobs(ssg_mem_opt_t opt, int 
 	ssg_glb_job_t jb = jobs[wid];
 	ssg_seqv_t q = { qbuf + jb.qoff, 1 }, t = { tbuf + jb.toff, 1 };
 	uint8_t *z = zscratch + wid * zstride;
-	int sc = wv_global2_any(opt, jb.qlen, q, jb.tlen, t, jb.w, z, 0);
+	int sc = wv_global2_any<true>(opt, jb.qlen, q, jb.tlen, t, jb.w, z, 0);
 	ssg_wave_memsync();
 	if (wv_lane() == 0) {
 		score[wid] = sc;

@@ -55,6 +55,8 @@ thread_local std::vector<ssg_prof_rec> ssg_prof_pending;
 #define CHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CHKA(b) do { if (!(b).ok()) { ssg_err_msg = "device allocation failed: " #b; return SSG_ENOMEM; } } while (0)
 
+/* the instance of a kernel templated on WIDE (k_sw.h): the one with the fifth register column only for a batch that has a read above 255 bases */
+#define SSG_LAUNCH_W(wide, kern, ...) do { if (wide) SSG_LAUNCH(kern<true>, __VA_ARGS__); else SSG_LAUNCH(kern<false>, __VA_ARGS__); } while (0)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 static int ssg_debug() { static int d = -1; if (d < 0) d = getenv("SSG_DEBUG") ? atoi(getenv("SSG_DEBUG")) : 0; return d; }
 static double ssg_stage_ms() { static thread_local std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); const auto t1 = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; return ms; }
@@ -858,7 +860,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		CHK(o.sdp_fixed.zero());
 		SSG_LAUNCH(ssg_k_chain2aln_lane, (n_reads + 63) / 64, 64, 0, idx->v, *opt, n_reads, d_off, o.seed_off.p, d_seeds.p, d_cseeds.p, d_nchain.p, o.regs.p, o.n_reg.p, d_err.p,
 		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_work.p, d_todo.p, d_ntodo.p, o.sdp_fixed.p);
-		SSG_LAUNCH(ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
+		SSG_LAUNCH_W(max_len > 255, ssg_k_chain2aln, nwg, wpb * 64, 0, idx->v, *opt, n_reads, d_seq, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
 		           d_nchain.p, d_srt.p, o.regs.p, o.n_reg.p, d_tglb.p, d_err.p, d_cells.p, d_work.p, d_queue.p, ssg_debug() >= 2, d_sdpbig.p, d_bcopy.p,
 		           d_choff.p, d_xjobs.p, d_xl.p, d_xr.p, d_todo.p, d_ntodo.p, o.sdp_fixed.p);
 		CHK(rt_sync());
@@ -1066,7 +1068,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 				}
 			}
 		}
-		SSG_LAUNCH(ssg_k_matesw, nwg, wpb * 64, 0, idx->v, *opt, n_pairs, d_seq.p, d_off.p, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p,
+		SSG_LAUNCH_W(max_len > 255, ssg_k_matesw, nwg, wpb * 64, 0, idx->v, *opt, n_pairs, d_seq.p, d_off.p, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p,
 		           d_bcopy.p, d_tglb.p, d_bglb.p, d_perr.p, d_cnt.p, d_cnt.p + 1, d_mtodo.p, d_q.p, d_sdpbig.p, d_nmtodo.p,
 		           have_slots ? (const ssg_msres_t*)d_jres.p : (const ssg_msres_t*)0, have_slots ? (const int64_t*)d_jbase.p : (const int64_t*)0,
 		           env_int("SSG_MSW_FIXED", 1) ? (const uint8_t*)a1.sdp_fixed.p : (const uint8_t*)0);
@@ -1126,7 +1128,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		dbuf<int32_t> d_rtodo((size_t)nreq + 1); dbuf<unsigned int> d_nrtodo(1);
 		CHKA(d_rtodo); CHKA(d_nrtodo); CHK(d_nrtodo.zero());
 		SSG_LAUNCH(ssg_k_reg2aln_lane, (nreq + 63) / 64, 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_gerr.p, d_rtodo.p, d_nrtodo.p);
-		SSG_LAUNCH(ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
+		SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
 		CHK(rt_sync());
 	}
 	STAGE("reg2aln");
@@ -1174,7 +1176,7 @@ static int se_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads
 		dbuf<int32_t> d_rtodo((size_t)nreq + 1); dbuf<unsigned int> d_nrtodo(1);
 		CHKA(d_rtodo); CHKA(d_nrtodo); CHK(d_nrtodo.zero());
 		SSG_LAUNCH(ssg_k_reg2aln_lane, (nreq + 63) / 64, 64, 0, idx->v, *opt, (long)nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_gerr.p, d_rtodo.p, d_nrtodo.p);
-		SSG_LAUNCH(ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
+		SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
 		CHK(rt_sync());
 	}
 	STAGE("reg2aln");

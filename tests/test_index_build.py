@@ -59,6 +59,11 @@ def test_index_build_emu_matches_golden(emu_lib, tmp_path, monkeypatch):
     _golden(emu_lib, tmp_path)
 
 
+def test_index_build_emu_bucketed_golden(emu_lib, tmp_path, monkeypatch):
+    monkeypatch.setenv("SSG_INDEX_BUCKET_P", "3")    # 64 buckets: a bucket's suffixes listed by ssg_k_idx_bucket_count / _scatter (k_index.h)
+    _golden(emu_lib, tmp_path)
+
+
 def test_index_build_emu_matches_oracle_on_holes_and_repeats(emu_lib, oracle, tmp_path, monkeypatch):
     _vs_oracle(emu_lib, oracle, tmp_path, monkeypatch)
 
