@@ -53,8 +53,8 @@ def _records(bam):
 
 @pytest.mark.parametrize("world,extra,chunk,kw", [(2, "", "40000", {}), (3, "export SSG_SORT_CHUNK_BYTES=300000\n", "40000", {}), (4, "", "150000", {}),
                                                   (2, "export SSG_RANKS_SPLIT=0\n", "60000", {"read_len": 250, "ins_mean": 800, "ins_std": 150}),
-                                                  (3, "", "40000", {"gz_two_files": True})],
-                         ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches", "two_ranks_2x250_everyone_parses", "three_ranks_two_gz_files"])
+                                                  (3, "", "40000", {"gz_two_files": True}), (8, "", "30000", {})],
+                         ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches", "two_ranks_2x250_everyone_parses", "three_ranks_two_gz_files", "eight_ranks"])
 def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chunk, kw):
     _ranks_equal_one(tmp_path, world, extra, chunk, None, 2500 if not kw else 1200, **kw)
 
