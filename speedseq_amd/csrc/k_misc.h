@@ -73,13 +73,13 @@ __global__ void ssg_k_class_counts(const int32_t *key, long n, int tA, int tB, i
 		if (b4) atomicAdd(&cnt[4], (unsigned)__popcll(b4));
 	}
 }
-/* cnt[i] = #(key > t[i]) for seven thresholds at once; one atomic per wave and threshold */
-struct ssg_thr6_t { int t[7]; };
+/* cnt[i] = #(key > t[i]) for ten thresholds at once; one atomic per wave and threshold */
+struct ssg_thr6_t { int t[10]; };
 __global__ void ssg_k_count_gt6(const int32_t *key, long n, ssg_thr6_t th, unsigned int *cnt)
 {
 	const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int k = i < n ? key[i] : (-2147483647 - 1);
-	SSG_UNROLL for (int j = 0; j < 7; ++j) {
+	SSG_UNROLL for (int j = 0; j < 10; ++j) {
 		const unsigned long long b = wv_ballot(k > th.t[j]);
 		if (b && wv_lane() == 0) atomicAdd(&cnt[j], (unsigned)__popcll(b));
 	}

@@ -415,4 +415,71 @@ SSG_DEVFN void ssg_introsort(T *a, long n, LT lt)
 		}
 	}
 }
+/* The same three sorts over an array VIEW (a.get(i) / a.set(i, x), int indices) instead of a pointer: for arrays that are not contiguous
+ * (lane-interleaved LDS words, k_chain.h).  Operation for operation the pointer forms above; the stack of pending ranges is four 16-bit
+ * entries in one register (a range is pushed only when it is the LARGER part of its parent and longer than 16: for n <= 256 there are
+ * never more than four), so nothing of it lives in scratch memory. */
+template <class A, class LT>
+SSG_DEVFN void ssg_insertsort_ix(A a, int s, int t, LT lt)
+{
+	for (int i = s + 1; i < t; ++i)
+		for (int j = i; j > s; --j) { const auto x = a.get(j), y = a.get(j - 1); if (!lt(x, y)) break; a.set(j, y); a.set(j - 1, x); }
+}
+template <class A, class LT>
+SSG_DEVFN void ssg_combsort_ix(A a, int s, int n, LT lt)
+{
+	const double shrink = 1.2473309501039786540366528676643;
+	int do_swap; int gap = n;
+	do {
+		if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+		do_swap = 0;
+		for (int i = s; i < s + n - gap; ++i) {
+			const auto x = a.get(i), y = a.get(i + gap);
+			if (lt(y, x)) { a.set(i, y); a.set(i + gap, x); do_swap = 1; }
+		}
+	} while (do_swap || gap > 2);
+	if (gap != 1) ssg_insertsort_ix(a, s, s + n, lt);
+}
+template <class A, class LT>
+SSG_DEVFN void ssg_introsort_ix(A a, int n, LT lt)   /* n <= 256 */
+{
+	unsigned long long stack = 0; int top = 0;   /* pending ranges, newest in the low 16 bits: first index | last index << 8 */
+	int d, s, t, i, j, k;
+	if (n < 1) return;
+	if (n == 2) { const auto x = a.get(0), y = a.get(1); if (lt(y, x)) { a.set(0, y); a.set(1, x); } return; }
+	for (d = 2; (1 << d) < n; ++d);
+	s = 0; t = n - 1; d <<= 1;
+	unsigned int dstack = 0;   /* the depth counters of the pushed ranges, 8 bits each */
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { ssg_combsort_ix(a, s, t - s + 1, lt); t = s; continue; }
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			{
+				const auto vk = a.get(k), vi = a.get(i), vj = a.get(j);
+				if (lt(vk, vi)) { if (lt(vk, vj)) k = j; }
+				else k = lt(vj, vi) ? i : j;
+			}
+			const auto rp = a.get(k);
+			if (k != t) { const auto x = a.get(t); a.set(k, x); a.set(t, rp); }
+			for (;;) {
+				auto vi = rp, vj = rp;
+				do { ++i; vi = a.get(i); } while (lt(vi, rp));
+				do { --j; if (i <= j) vj = a.get(j); } while (i <= j && lt(rp, vj));
+				if (j <= i) break;
+				a.set(i, vj); a.set(j, vi);
+			}
+			{ const auto x = a.get(i), y = a.get(t); a.set(i, y); a.set(t, x); }
+			if (i - s > t - i) {
+				if (i - s > 16) { stack = stack << 16 | (unsigned long long)(s | (i - 1) << 8); dstack = dstack << 8 | (unsigned)d; ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { stack = stack << 16 | (unsigned long long)((i + 1) | t << 8); dstack = dstack << 8 | (unsigned)d; ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) { ssg_insertsort_ix(a, 0, n, lt); return; }
+			--top; s = (int)(stack & 255); t = (int)(stack >> 8 & 255); d = (int)(dstack & 255); stack >>= 16; dstack >>= 8;
+		}
+	}
+}
 #endif

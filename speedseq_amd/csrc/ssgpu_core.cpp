@@ -761,15 +761,16 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int TB = env_int("SSG_CHAIN_WAVE_BIG", 0) > 0 ? env_int("SSG_CHAIN_WAVE_BIG", 0) : 1 << 30;
 		const bool ranked = env_int("SSG_CHAIN_RANKED", 1) != 0;
 		const int cap_lim = env_int("SSG_CHAIN_CAP_TEST", 1 << 30);   /* tests: pretend the ranked form holds fewer chains, to walk its fall-back (the shifting form) */
-		int g[7];
+		int g[7], gl[3];   /* gl: reads with more than 63 / 31 / 15 seeds (the classes of the light reads' LDS kernel) */
 		{	/* "greater than" counts of the seeds-per-read array in one pass (thresholds descending: the counts ascend) */
-			ssg_thr6_t th = { { 1 << 30, 5120, std::min(2048, TB), std::min(1024, TB), std::min(512, TB), std::min(256, TB), T - 1 } };
-			dbuf<unsigned int> d_c(8); unsigned int c[7];
+			ssg_thr6_t th = { { 1 << 30, 5120, std::min(2048, TB), std::min(1024, TB), std::min(512, TB), std::min(256, TB), T - 1, 63, 31, 15 } };
+			dbuf<unsigned int> d_c(16); unsigned int c[10];
 			CHKA(d_c); CHK(d_c.zero());
 			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
-			CHK(d_c.down(c, 7));
+			CHK(d_c.down(c, 10));
 			for (int i = 0; i < 7; ++i) g[i] = (int)std::min(c[i], c[6]);
 			for (int i = 1; i < 7; ++i) g[i] = std::max(g[i], g[i - 1]);
+			for (int i = 0; i < 3; ++i) gl[i] = (int)c[7 + i];
 		}
 		const int n_heavy = g[6];
 		const int nC = g[1], n5120 = g[2] - g[1], n2048 = g[3] - g[2], n1024 = g[4] - g[3], n512 = g[5] - g[4], n256 = g[6] - g[5];
@@ -808,8 +809,19 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 #undef SSG_CHW_LAUNCH
 		if (nC) SSG_LAUNCH_ON(0, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		if (n_reads > r0) SSG_LAUNCH(ssg_k_chain, (n_reads - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, n_reads, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+		{	/* the light reads, heaviest first: up to 15 / 31 / 63 seeds with the read's state in the lane's part of LDS (k_chain.h), the rest -- and everything when the
+			 * index has too many contigs for 14 bits, a read is too long for 9-bit query coordinates, or SSG_CHAIN_LDS = 0 (A/B, tests) -- on global memory */
+			const bool use_lds = env_int("SSG_CHAIN_LDS", 1) != 0 && idx->v.n_ctg < 0x3fff && max_len < 512;
+			const int b63 = use_lds ? std::min(n_reads, std::max(r0, gl[0])) : n_reads, b31 = std::min(n_reads, std::max(b63, gl[1])), b15 = std::min(n_reads, std::max(b31, gl[2]));
+			if (b63 > r0) SSG_LAUNCH(ssg_k_chain, (b63 - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, b63, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+			                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+#define SSG_CL_LAUNCH(CC, from, to) do { if ((to) > (from)) SSG_LAUNCH(ssg_k_chain_lds<CC>, ((to) - (from) + 63) / 64, 64, 0, idx->v, *opt, (from), (to), d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, \
+			d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p); } while (0)
+			SSG_CL_LAUNCH(64, b63, b31);
+			SSG_CL_LAUNCH(32, b31, b15);
+			SSG_CL_LAUNCH(16, b15, n_reads);
+#undef SSG_CL_LAUNCH
+		}
 		ssg_join(3);
 	}
 	STAGE("chain");

@@ -64,6 +64,14 @@ def repeat_prefix(oracle, tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def repeat_mid_prefix(oracle, tmp_path_factory):
+    """Small repeat families (a dozen copies, some of them identical: equal positions on the query, equal chain weights): reads with 10 to 63
+    seeds -- the classes of the light reads' LDS chaining kernel."""
+    import common
+    return common.repeat_reference(oracle, tmp_path_factory.mktemp("repeats_mid"), seed=11, n_copies=(14, 9, 5), fam_len=(500, 320, 260), unique=30000, max_div=0.02)
+
+
+@pytest.fixture(scope="session")
 def repeat_pe_prefix(oracle, tmp_path_factory):
     """Repeat families inside enough unique sequence for the insert-size model to succeed: mate rescue then
     runs against region lists of hundreds of entries (incremental re-sort path)."""

@@ -128,6 +128,16 @@ def test_gpu_repeats_align1(gpu_lib, oracle, repeat_prefix, monkeypatch):
     assert common.check_align1(gpu_lib, oracle, 150, seed=22, prefix=repeat_prefix) > 5000
 
 
+def test_gpu_light_reads_chain_lds(gpu_lib, oracle, repeat_mid_prefix, monkeypatch):
+    # reads with 10..63 seeds in small repeat families: the three classes of ssg_k_chain_lds (state in the lane's LDS), then the same reads through ssg_k_chain
+    monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "64")
+    n1 = common.check_align1(gpu_lib, oracle, 1500, seed=31, prefix=repeat_mid_prefix)
+    n2 = common.check_align1(gpu_lib, oracle, 1000, seed=32, read_len=250, prefix=repeat_mid_prefix)
+    assert n1 > 6000 and n2 > 4000
+    monkeypatch.setenv("SSG_CHAIN_LDS", "0")
+    assert common.check_align1(gpu_lib, oracle, 1500, seed=31, prefix=repeat_mid_prefix) == n1
+
+
 def test_gpu_repeats_pe_sam(gpu_lib, oracle, repeat_prefix):
     text, stats = common.check_pe_sam(gpu_lib, oracle, 300, seed=23, prefix=repeat_prefix)
     assert "XA:Z:" in text

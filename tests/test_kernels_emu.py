@@ -102,6 +102,16 @@ def test_emu_repeats_align1(emu_lib, oracle, repeat_prefix, monkeypatch):
     assert common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix) > 500
 
 
+def test_emu_light_reads_chain_lds(emu_lib, oracle, repeat_mid_prefix, monkeypatch):
+    # reads with 10..63 seeds in small repeat families: the three classes of ssg_k_chain_lds (state in the lane's LDS), then the same reads through ssg_k_chain
+    monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "64")
+    n1 = common.check_align1(emu_lib, oracle, 150, seed=31, prefix=repeat_mid_prefix)
+    n2 = common.check_align1(emu_lib, oracle, 100, seed=32, read_len=250, prefix=repeat_mid_prefix)
+    assert n1 > 600 and n2 > 400
+    monkeypatch.setenv("SSG_CHAIN_LDS", "0")
+    assert common.check_align1(emu_lib, oracle, 150, seed=31, prefix=repeat_mid_prefix) == n1
+
+
 def test_emu_repeats_pe_sam(emu_lib, oracle, repeat_prefix):
     text, stats = common.check_pe_sam(emu_lib, oracle, 10, seed=23, prefix=repeat_prefix)
     assert "XA:Z:" in text
