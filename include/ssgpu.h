@@ -116,6 +116,11 @@ int ssg_extend_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int 
 int ssg_align2_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *jobs, const int64_t *tpos,
                           const uint8_t *qbuf, size_t qbytes, int lanes, ssg_kswr_t *res, int32_t *from_lane);
 
+/* Test hook for the chaining kernels' weight sort (csrc/k_chainw.h wv_introsort_whi; upstream ks_introsort over chain weights, bwamem.c mem_chain_flt's
+ * ks_introsort(mem_flt, ...) with its unstable tie order): sorts n <= 5120 words (w << 32 | id) by w, descending, once by the whole wave (out_wave) and
+ * once by one lane running the textbook loops (out_lane); the two must be equal word for word. */
+int ssg_dbg_chain_sort(const int64_t *keys, int n, int64_t *out_lane, int64_t *out_wave);
+
 /* upstream mem_align1_core() (bwamem.c; rows a1-a8) for a batch of reads: SMEM -> SAL -> chain ->
  * filter -> extend -> sort/dedup/patch.  reg_off[n_reads+1] and regs (malloc'd by the library,
  * release with ssg_free) receive each read's mem_alnreg_t list in upstream order. */

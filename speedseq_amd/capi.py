@@ -169,6 +169,12 @@ class Lib:
         self._chk(self.l.ssg_align2_lane_batch(idx, _ptr(opt), C.c_int(len(jobs)), _ptr(jobs), _ptr(tpos), _ptr(qbuf), C.c_size_t(qbuf.size), C.c_int(lanes), _ptr(res), _ptr(from_lane)))
         return res, from_lane
 
+    def dbg_chain_sort(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        o0, o1 = np.zeros(len(keys), dtype=np.int64), np.zeros(len(keys), dtype=np.int64)
+        self._chk(self.l.ssg_dbg_chain_sort(_ptr(keys), C.c_int(len(keys)), _ptr(o0), _ptr(o1)))
+        return o0, o1
+
     def align1_batch(self, idx, opt, seq, off):
         n = len(off) - 1
         reg_off = np.zeros(n + 1, dtype=np.int64)

@@ -60,13 +60,102 @@ template <int CAPC, int CAPS> SSG_DEVFN int chw_prev_set(const ssg_chw_lds_t<CAP
 
 struct ssg_whi_gt { SSG_DEVMEM bool operator()(int64_t a, int64_t b) const { return (a >> 32) > (b >> 32); } };
 
+/*
+ * upstream's introsort of the (w << 32 | id) words in b8[0 .. n) by w, descending (ks_introsort with its unstable tie order: ties are the norm in a
+ * repeat family and the order among them decides what the filter keeps), replayed by the whole wave.  One lane running the textbook loops out of
+ * LDS pays an LDS round trip per element visit (~100 cycles; 44 % of a 1300-seed read's time).  What the sequential loops do is
+ * fixed by the array as it is when a partition starts (A0, after the pivot went to the end):
+ *   - the up-scan stops at the positions in (s, t] whose key is <= the pivot's, the down-scan at those in (s, t) whose key is >= it; neither
+ *     scan ever reads a position an earlier swap of the same partition wrote, except that the up-scan cannot pass the last swapped j;
+ *   - the k-th swap exchanges the k-th up-stop i_k with the k-th down-stop j_k while i_k < j_k; the pivot's place is min(i_(K+1), j_K).
+ * So the wave takes 64 positions from each end at a time, finds the stops with two ballots, pairs them by rank through a small table and writes
+ * all swaps of the block at once.  Ranges of 16 or fewer stay unsorted as upstream leaves them for its final insertion sort; that pass and depth
+ * exhaustion (upstream switches to combsort) stay on one lane.  Scratch: a8[] (dead between the weights and the filter).
+ * tests: against ssg_introsort on one lane, same input (ssg_dbg_chain_sort).
+ */
+template <int CAPC, int CAPS>
+SSG_DEVFN void wv_introsort_whi(ssg_chw_lds_t<CAPC, CAPS> &L, const int n)
+{
+	static_assert(CAPC >= 256, "a8[] holds the pairing tables and the range stack");
+	const int lane = wv_lane();
+	int64_t *a = L.b8, *tabI = L.a8, *tabJ = L.a8 + 64, *stk = L.a8 + 128;   /* stack entry: s | t << 16 | d << 32 */
+	if (n < 2) return;
+	if (n == 2) { ssg_wave_ldssync(); if (lane == 0 && (a[1] >> 32) > (a[0] >> 32)) { const int64_t x = a[0]; a[0] = a[1]; a[1] = x; } ssg_wave_ldssync(); return; }
+	int d, s = 0, t = n - 1, top = 0;
+	for (d = 2; (1 << d) < n; ++d);
+	d <<= 1;
+	ssg_wave_ldssync();
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { if (lane == 0) ssg_combsort(a + s, (long)(t - s + 1), ssg_whi_gt()); ssg_wave_ldssync(); t = s; continue; }
+			int k = s + ((t - s) >> 1) + 1;
+			const int64_t vk = a[k], vi0 = a[s], vj0 = a[t];
+			if ((vk >> 32) > (vi0 >> 32)) { if ((vk >> 32) > (vj0 >> 32)) k = t; }
+			else k = (vj0 >> 32) > (vi0 >> 32) ? s : t;
+			const int64_t rp = k == t ? vj0 : k == s ? vi0 : vk;
+			const int P = (int)(rp >> 32);
+			ssg_wave_ldssync();
+			if (k != t && lane == 0) { a[k] = vj0; a[t] = rp; }
+			ssg_wave_ldssync();
+			/* the partition */
+			int pi = s + 1, pj = t - 1, bi = 0, bj = 0, lastj = 1 << 30, fin;
+			unsigned long long MI = 0, MJ = 0; int64_t wi = 0, wj = 0; bool jdone = false;
+			for (;;) {
+				if (!MI) { bi = pi; pi += 64; const int q = bi + lane; const bool in = q <= t; wi = in ? a[q] : 0; MI = wv_ballot(in && (int)(wi >> 32) <= P); if (!MI) continue; }   /* ends: t is a stop */
+				if (!MJ && !jdone) {
+					if (pj < s + 1) jdone = true;
+					else { bj = pj; pj -= 64; const int q = bj - lane; const bool in = q >= s + 1; wj = in ? a[q] : 0; MJ = wv_ballot(in && (int)(wj >> 32) >= P); if (!MJ) continue; }
+				}
+				if (jdone) { const int i1 = bi + (int)__builtin_ctzll(MI); fin = i1 < lastj ? i1 : lastj; break; }
+				const int cI = __popcll(MI), cJ = __popcll(MJ), c = cI < cJ ? cI : cJ;
+				const int rI = wv_rank_of(MI), rJ = wv_rank_of(MJ);
+				const bool hasI = MI >> lane & 1, hasJ = MJ >> lane & 1;
+				ssg_wave_ldssync();
+				if (hasI && rI < c) tabI[rI] = bi + lane;
+				if (hasJ && rJ < c) tabJ[rJ] = bj - lane;
+				ssg_wave_ldssync();
+				const int ti = lane < c ? (int)tabI[lane] : 0, tj = lane < c ? (int)tabJ[lane] : 0;
+				const int v = __popcll(wv_ballot(lane < c && ti < tj));   /* the valid pairs are a prefix: i_k ascends, j_k descends */
+				if (hasI && rI < v) a[(int)tabJ[rI]] = wi;
+				if (hasJ && rJ < v) a[(int)tabI[rJ]] = wj;
+				if (v) lastj = wv_get(tj, v - 1);
+				if (v < c) { const int i1 = wv_get(ti, v); fin = i1 < lastj ? i1 : lastj; break; }
+				MI = wv_ballot(hasI && rI >= c); MJ = wv_ballot(hasJ && rJ >= c);
+			}
+			ssg_wave_ldssync();
+			const int i = fin;
+			if (lane == 0) { const int64_t x = a[i]; a[i] = a[t]; a[t] = x; }
+			ssg_wave_ldssync();
+			if (i - s > t - i) {
+				if (i - s > 16) { if (lane == 0) stk[top] = (int64_t)s | (int64_t)(i - 1) << 16 | (int64_t)d << 32; ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { if (lane == 0) stk[top] = (int64_t)(i + 1) | (int64_t)t << 16 | (int64_t)d << 32; ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) break;
+			--top;
+			ssg_wave_ldssync();
+			const int64_t e = stk[top];
+			s = (int)(e & 0xffff); t = (int)(e >> 16 & 0xffff); d = (int)(e >> 32);
+		}
+	}
+	/* upstream's closing insertion sort over the whole array, on one lane: ranges of 16 or fewer were left as they were, and the first element of a
+	 * range is never looked at by its partition (it may lie far from home), so no bound on the moves; on an array this close to sorted it costs
+	 * about one LDS round trip per element */
+	ssg_wave_ldssync();
+	if (lane == 0) ssg_insertsort(a, a + n, ssg_whi_gt());
+	ssg_wave_ldssync();
+}
+
 /* rank: this read's seeds ranked by (reference position, visiting order), or NULL for the shifting form (needs #seeds <= CAPC).
  * Returns 0, or -1 when the ranked form meets what it does not cover (more chains than CAPC, or a third chain at one position:
  * upstream's order among three equal positions is not rank order) -- the caller then chains the read another way. */
 template <int CAPC, int CAPS>
 SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const int64_t *read_off, const ssg_intv_t *intv,
                              const int32_t *n_intv, int cap, const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
-                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, ssg_chw_lds_t<CAPC, CAPS> &L, const uint16_t *rank, int capc_lim)
+                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, ssg_chw_lds_t<CAPC, CAPS> &L, const uint16_t *rank, int capc_lim, int wave_sort)
 {
 	const int lane = wv_lane();
 	const int len_read = (int)(read_off[r+1] - read_off[r]);
@@ -257,7 +346,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 	if (n_chn > 0) {
 		/* ---- upstream mem_chain_flt ---- */
 		const unsigned long long ph_t3 = ssg_clock();
-		if (lane == 0) ssg_introsort(L.b8, (long)n_chn, ssg_whi_gt());
+		if (wave_sort && n_chn > 24) wv_introsort_whi(L, n_chn); else if (lane == 0) ssg_introsort(L.b8, (long)n_chn, ssg_whi_gt());
 		ssg_wave_ldssync();
 		const unsigned long long ph_t4 = ssg_clock();
 		for (i = lane; i < n_chn; i += 64) L.rid[i] = 0;
@@ -348,16 +437,16 @@ __global__ void __launch_bounds__(64) ssg_k_chain_wave(ssg_index_view_t ix, ssg_
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain,
-                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */)
+                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */, int wave_sort /* the weight sort by the whole wave (0: one lane, A/B and tests) */)
 {
 	__shared__ ssg_chw_lds_t<CAP, CAP> L;
 	for (;;) {
 		const long k = r_first + wv_queue_pop(queue);
 		if (k >= r_end) break;
 		const long r = work_order ? work_order[k] : k;
-		int rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, hrank ? hrank + hoff[k] : (const uint16_t*)0, capc_lim);
+		int rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, hrank ? hrank + hoff[k] : (const uint16_t*)0, capc_lim, wave_sort);
 		rc = wv_get(rc, 0);
-		if (rc) rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, (const uint16_t*)0, CAP);
+		if (rc) rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, (const uint16_t*)0, CAP, wave_sort);
 	}
 }
 
@@ -380,5 +469,17 @@ __global__ void ssg_k_chw_ranks(long n, const uint64_t *key_sorted, const uint32
 {
 	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (p < n) hrank[val_sorted[p]] = (uint16_t)(p - hoff[key_sorted[p] >> 34]);
+}
+/* test hook (ssg_dbg_chain_sort): the weight sort of one array by the wave replay (mode 1) or by one lane (mode 0), in the LDS layout of the chaining kernel */
+template <int CAP>
+__global__ void __launch_bounds__(64) ssg_k_dbg_chain_sort(const int64_t *in, int n, int mode, int64_t *out)
+{
+	__shared__ ssg_chw_lds_t<CAP, CAP> L;
+	const int lane = wv_lane();
+	for (int q = lane; q < n; q += 64) L.b8[q] = in[q];
+	ssg_wave_ldssync();
+	if (mode) wv_introsort_whi(L, n); else if (lane == 0) ssg_introsort(L.b8, (long)n, ssg_whi_gt());
+	ssg_wave_ldssync();
+	for (int q = lane; q < n; q += 64) out[q] = L.b8[q];
 }
 #endif

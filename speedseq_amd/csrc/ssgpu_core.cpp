@@ -483,6 +483,22 @@ static int run_msw_lane(const ssg_index_t *idx, const ssg_mem_opt_t *opt, long n
 	return rc;
 }
 
+/* test hook: sorts n <= 5120 words (w << 32 | id) by w, descending, as the chaining kernels do -- by the whole wave (out_wave) and by one lane running
+ * upstream's introsort (out_lane); the two must be equal word for word */
+int ssg_dbg_chain_sort(const int64_t *keys, int n, int64_t *out_lane, int64_t *out_wave)
+{
+	CHK(need_device());
+	if (n < 0 || n > 5120) { ssg_err_msg = "ssg_dbg_chain_sort: 0 <= n <= 5120"; return SSG_EINVAL; }
+	dbuf<int64_t> d_in((size_t)n + 1), d_o0((size_t)n + 1), d_o1((size_t)n + 1);
+	CHKA(d_in); CHKA(d_o0); CHKA(d_o1);
+	CHK(d_in.up(keys, n));
+	if (n <= 1024) { SSG_LAUNCH(ssg_k_dbg_chain_sort<1024>, 1, 64, 0, d_in.p, n, 0, d_o0.p); SSG_LAUNCH(ssg_k_dbg_chain_sort<1024>, 1, 64, 0, d_in.p, n, 1, d_o1.p); }
+	else { SSG_LAUNCH(ssg_k_dbg_chain_sort<5120>, 1, 64, 0, d_in.p, n, 0, d_o0.p); SSG_LAUNCH(ssg_k_dbg_chain_sort<5120>, 1, 64, 0, d_in.p, n, 1, d_o1.p); }
+	CHK(rt_sync());
+	CHK(d_o0.down(out_lane, n)); CHK(d_o1.down(out_wave, n));
+	return SSG_OK;
+}
+
 int ssg_align2_lane_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_jobs, const ssg_sw_job_t *jobs, const int64_t *tpos,
                           const uint8_t *qbuf, size_t qbytes, int lanes, ssg_kswr_t *res, int32_t *from_lane)
 {
@@ -760,6 +776,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int T = idx->v.n_ctg > 32767 ? 1 << 30 : std::max(1, env_int("SSG_CHAIN_WAVE_MIN", 64));
 		const int TB = env_int("SSG_CHAIN_WAVE_BIG", 0) > 0 ? env_int("SSG_CHAIN_WAVE_BIG", 0) : 1 << 30;
 		const bool ranked = env_int("SSG_CHAIN_RANKED", 1) != 0;
+		const int wsort = env_int("SSG_CHAIN_WSORT", 1);   /* the weight sort of the wave kernels by the whole wave (k_chainw.h wv_introsort_whi); 0: by one lane (A/B, tests) */
 		const int cap_lim = env_int("SSG_CHAIN_CAP_TEST", 1 << 30);   /* tests: pretend the ranked form holds fewer chains, to walk its fall-back (the shifting form) */
 		int g[7], gl[3];   /* gl: reads with more than 63 / 31 / 15 seeds (the classes of the light reads' LDS kernel) */
 		{	/* "greater than" counts of the seeds-per-read array in one pass (thresholds descending: the counts ascend) */
@@ -800,7 +817,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		ssg_fork(3);
 		int r0 = nC;
 #define SSG_CHW_LAUNCH(si, CC, cnt, maxwg, qi) do { if ((cnt) > 0) SSG_LAUNCH_ON(si, ssg_k_chain_wave<CC>, std::min((int)(cnt), (int)(maxwg)), 64, 0, idx->v, *opt, r0, r0 + (cnt), d_off, d_intv.p, d_nintv.p, cap, \
-		o.seed_off.p, d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + (qi), hr, ho, std::min((int)(CC), cap_lim)); r0 += (cnt); } while (0)
+		o.seed_off.p, d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + (qi), hr, ho, std::min((int)(CC), cap_lim), wsort); r0 += (cnt); } while (0)
 		SSG_CHW_LAUNCH(0, 5120, n5120, 256, 1);
 		SSG_CHW_LAUNCH(1, 2048, n2048, 512, 3);
 		SSG_CHW_LAUNCH(2, 1024, n1024, 1280, 2);

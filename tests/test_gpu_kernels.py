@@ -118,14 +118,30 @@ def test_gpu_repeats_align1(gpu_lib, oracle, repeat_prefix, monkeypatch):
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "4")
     assert common.check_align1(gpu_lib, oracle, 150, seed=22, prefix=repeat_prefix) > 5000
     monkeypatch.setenv("SSG_CHAIN_RANKED", "0")         # the array-shifting insertion instead of the position-rank bitmap
+    monkeypatch.setenv("SSG_CHAIN_WSORT", "0")          # and the weight sort on one lane
     common.check_align1(gpu_lib, oracle, 300, seed=22, prefix=repeat_prefix)
     monkeypatch.delenv("SSG_CHAIN_RANKED")
+    monkeypatch.delenv("SSG_CHAIN_WSORT")
     monkeypatch.setenv("SSG_CHAIN_CAP_TEST", "40")      # the ranked form gives up at 40 chains: its fall-back, the shifting form, redoes those reads
     common.check_align1(gpu_lib, oracle, 300, seed=22, prefix=repeat_prefix)
     monkeypatch.delenv("SSG_CHAIN_CAP_TEST")
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "100000")  # and the lane-per-read kernel on the same reads
     monkeypatch.setenv("SSG_CHAIN_WAVE_BIG", "100000")
     assert common.check_align1(gpu_lib, oracle, 150, seed=22, prefix=repeat_prefix) > 5000
+
+
+def test_gpu_chain_weight_sort_by_the_wave(gpu_lib):
+    # upstream's unstable introsort of the chain weights (ties decide what the filter keeps): the wave replay against one lane running the textbook loops
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 70)) + [100, 127, 128, 129, 255, 256, 257, 500, 1000, 1023, 1024, 1025, 2000, 3000, 4000, 5120]:
+        for kind in range(6):
+            w = [rng.integers(0, 150, n), rng.integers(0, 4, n), np.full(n, 17), np.sort(rng.integers(0, 50, n)), np.sort(rng.integers(0, 50, n))[::-1].copy(),
+                 np.where(rng.random(n) < 0.9, 19, rng.integers(0, 40, n))][kind]
+            keys = (w.astype(np.int64) << 32) | np.arange(n, dtype=np.int64)
+            a, b = gpu_lib.dbg_chain_sort(keys)
+            assert np.array_equal(a, b), (n, kind)
+            assert np.all(np.diff(a >> 32) <= 0) and np.array_equal(np.sort(a), np.sort(keys))
 
 
 def test_gpu_light_reads_chain_lds(gpu_lib, oracle, repeat_mid_prefix, monkeypatch):
