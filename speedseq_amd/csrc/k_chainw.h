@@ -37,7 +37,7 @@ template <int CAPC, int CAPS = CAPC> struct ssg_chw_lds_t {   /* CAPC chains, CA
 	SSG_DEVMEM void new_chain(int c, int qbeg, int len) { fq[c] = lq[c] = (uint8_t)qbeg; ll[c] = (uint8_t)len; n[c] = (uint16_t)(1 | (qbeg >> 8 & 1) << 13 | (qbeg >> 8 & 1) << 14 | (len >> 8 & 1) << 15); }
 	SSG_DEVMEM void add_seed(int c, int qbeg, int len) { lq[c] = (uint8_t)qbeg; ll[c] = (uint8_t)len; n[c] = (uint16_t)((((n[c] & 0x1fff) + 1) & 0x1fff) | (n[c] & 0x2000) | (qbeg >> 8 & 1) << 14 | (len >> 8 & 1) << 15); }
 	uint8_t fq[CAPC], lq[CAPC], ll[CAPC];  /* [chain id]: qbeg of first seed, qbeg/len of last seed: the low 8 bits (the ninth of each, for reads of 256..511 bases, rides in n[]) */
-	uint16_t ids[CAPS]; /* insertion: chain id at position RANK (shifting form: of sorted slot) | filter: query begin of kept chain */
+	uint16_t ids[CAPS]; /* shifting form of the insertion: chain id of sorted slot (the ranked form needs none: a chain is named after the rank of its first seed) | filter: query begin of kept chain */
 	uint16_t nx[CAPS];  /* [seed]: next seed of the same chain */
 	uint64_t bm[CAPS / 64];                  /* ranks that hold a chain */
 	uint64_t bms[(CAPS / 64 + 63) / 64];     /* words of bm[] that are not empty */
@@ -191,22 +191,33 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			int64_t my_rbeg = 0; int my_q = 0, my_len = 0, my_rid = -1, my_rk = 0;
 			if (me < ns) { const ssg_seed_t sdd = sd[me]; my_rbeg = sdd.rbeg; my_q = sdd.qbeg; my_len = sdd.len; my_rid = srid[me]; my_rk = rank[me]; }
 			const int cn = ns - i0 < 64 ? ns - i0 : 64;
+			int pf_t = -1, pf_w = 0; uint64_t pf_m = 0;
 			for (int t = 0; t < cn; ++t) {
 				const int prid = wv_get(my_rid, t);
 				if (prid < 0) continue;
 				const int sid = i0 + t, rk = wv_get(my_rk, t);
 				const int64_t rbeg = wv_get64(my_rbeg, t);
 				const int qbeg = wv_get(my_q, t), len = wv_get(my_len, t);
-				int fl = chw_prev_set(L, rk), two_equal = 0, res = 0;
-				if (fl >= 0 && L.b8[L.ids[fl]] == rbeg) {   /* a chain at this very position: upstream tests the FIRST of them */
-					const int f2 = chw_prev_set(L, fl - 1);
-					if (f2 >= 0 && L.b8[L.ids[f2]] == rbeg) { fl = f2; two_equal = 1; }
-				}
+				/* A chain's id is the rank of its first seed: the floor lookup lands on the chain's state directly.  Two dependent LDS round trips
+				 * per seed: the bitmap word of the seed's rank (also the word a new chain sets its bit in), then the floor chain's state in one batch --
+				 * and the first of the two is read one seed ahead (a bit this seed sets in that word is patched into the copy). */
+				const int bw = rk >> 6, bit = rk & 63;
+				const uint64_t mw = pf_t == t ? pf_m : L.bm[bw];
+				if (t + 1 < cn) { pf_w = wv_get(my_rk, t + 1) >> 6; pf_m = L.bm[pf_w]; pf_t = t + 1; }   /* the next seed's word travels with this seed's state reads */
+				const uint64_t mlow = mw & (bit == 63 ? ~0ull : (1ull << (bit + 1)) - 1);
+				int fl = mlow ? (bw << 6) + 63 - __clzll(mlow) : chw_prev_set(L, (bw << 6) - 1), two_equal = 0, res = 0;
 				if (fl >= 0) { /* upstream test_and_merge against the floor chain */
-					const int c = L.ids[fl];
-					const int64_t f_rbeg = L.b8[c], l_rbeg = L.a8[c];
-					const int f_q = L.get_fq(c), l_q = L.get_lq(c), l_len = L.get_ll(c);
-					if (prid != L.rid[c]) res = 0;
+					int64_t f_rbeg = L.b8[fl], l_rbeg = L.a8[fl];
+					unsigned n16 = L.n[fl], ls = L.ls[fl]; int f_q = L.fq[fl], l_q = L.lq[fl], l_len = L.ll[fl], crid = L.rid[fl];
+					if (f_rbeg == rbeg) {   /* a chain at this very position: upstream tests the FIRST of them */
+						const int f2 = chw_prev_set(L, fl - 1);
+						if (f2 >= 0 && L.b8[f2] == rbeg) {
+							fl = f2; two_equal = 1;
+							f_rbeg = L.b8[fl]; l_rbeg = L.a8[fl]; n16 = L.n[fl]; ls = L.ls[fl]; f_q = L.fq[fl]; l_q = L.lq[fl]; l_len = L.ll[fl]; crid = L.rid[fl];
+						}
+					}
+					f_q |= (int)(n16 >> 13 & 1) << 8; l_q |= (int)(n16 >> 14 & 1) << 8; l_len |= (int)(n16 >> 15 & 1) << 8;
+					if (prid != crid) res = 0;
 					else if (qbeg >= f_q && qbeg + len <= l_q + l_len && rbeg >= f_rbeg && rbeg + len <= l_rbeg + l_len) res = 1;
 					else if ((l_rbeg < l_pac || f_rbeg < l_pac) && rbeg >= l_pac) res = 0;
 					else {
@@ -215,7 +226,10 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 					}
 					if (res == 2) {
 						ssg_wave_ldssync();
-						if (lane == 0) { L.nx[L.ls[c]] = (uint16_t)sid; L.ls[c] = (uint16_t)sid; L.a8[c] = rbeg; L.add_seed(c, qbeg, len); }
+						if (lane == 0) {
+							L.nx[ls] = (uint16_t)sid; L.ls[fl] = (uint16_t)sid; L.a8[fl] = rbeg; L.lq[fl] = (uint8_t)qbeg; L.ll[fl] = (uint8_t)len;
+							L.n[fl] = (uint16_t)((((n16 & 0x1fff) + 1) & 0x1fff) | (n16 & 0x2000) | (unsigned)(qbeg >> 8 & 1) << 14 | (unsigned)(len >> 8 & 1) << 15);
+						}
 						ssg_wave_ldssync();
 					}
 				}
@@ -225,11 +239,13 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 				if (res == 0) { /* new chain; its place in position order is its seed's rank */
 					ssg_wave_ldssync();
 					if (lane == 0) {
-						L.bm[rk >> 6] |= 1ull << (rk & 63); L.bms[rk >> 12] |= 1ull << ((rk >> 6) & 63);
-						L.ids[rk] = (uint16_t)nc; L.b8[nc] = rbeg; L.a8[nc] = rbeg; L.new_chain(nc, qbeg, len);
-						L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
+						L.bm[bw] = mw | 1ull << bit;
+						if (!mw) L.bms[bw >> 6] |= 1ull << (bw & 63);
+						L.b8[rk] = rbeg; L.a8[rk] = rbeg; L.new_chain(rk, qbeg, len);
+						L.fs[rk] = L.ls[rk] = (uint16_t)sid; L.rid[rk] = (int16_t)prid;
 					}
 					ssg_wave_ldssync();
+					if (pf_t == t + 1 && pf_w == bw) pf_m |= 1ull << bit;
 					++nc;
 				}
 			}
@@ -302,7 +318,8 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 	/* ---- upstream mem_chain_weight: one lane per chain ---- */
 	const unsigned long long ph_t1 = ssg_clock();
 	ssg_wave_ldssync();
-	for (int c = lane; c < nc; c += 64) {
+	for (int c = lane; c < (rank ? ns : nc); c += 64) {   /* (ranked form: chain ids are the ranks that hold a chain) */
+		if (rank && !((L.bm[c >> 6] >> (c & 63)) & 1)) continue;
 		int w1 = 0, w2 = 0, sid = L.fs[c], end1 = 0; int64_t end2 = 0;
 		const int n = L.get_n(c);
 		for (int j = 0; j < n; ++j, sid = L.nx[sid]) {
@@ -323,7 +340,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		for (int e0 = 0; e0 < ns; e0 += 64) {
 			const int rk = e0 + lane;
 			const int set = rk < ns && ((L.bm[rk >> 6] >> (rk & 63)) & 1);
-			const int id = set ? L.ids[rk] : 0;
+			const int id = rk;
 			const int w = set ? (int)L.a8[id] : 0;
 			const int keep = set && w >= opt.min_chain_weight;
 			const unsigned long long bal = wv_ballot(keep);
