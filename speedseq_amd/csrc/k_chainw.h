@@ -186,6 +186,83 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		for (i = lane; i < (ns + 63) / 64; i += 64) L.bm[i] = 0;
 		for (i = lane; i < ((ns + 63) / 64 + 63) / 64; i += 64) L.bms[i] = 0;
 		ssg_wave_ldssync();
+	}
+	if (rank && (wave_sort & 2)) {
+		/* 64 seeds at a time, every lane its own: the one-seed-at-a-time loop below is one wave alone on its SIMD running ~200 dependent instructions
+		 * per seed with 63 lanes idle (1 460 cycles per seed, profiles/r05n_chain_ab.json).  Here every lane looks up ITS seed's floor chain and decides
+		 * (contained / appended / new chain) against the state as it is when the round starts.  A lane's decision is what the sequential loop would
+		 * reach unless an EARLIER seed of the round changes what it read: a new chain whose rank falls between its floor and its own rank, or a seed
+		 * appended to its floor chain.  The lanes before the first such lane are right: they commit together (their writes touch different chains),
+		 * and the next round starts at that lane.  A seed that meets a chain at its own position (upstream's equal-position order) only commits as
+		 * the first of a round.  Rounds per 64 seeds: a few once the read's repeat copies have their chains, many while they are being created. */
+		for (int i0 = 0; i0 < ns && !fail; i0 += 64) {
+			const int me = i0 + lane;
+			int64_t my_rbeg = 0; int my_q = 0, my_len = 0, my_rid = -1, my_rk = 0;
+			if (me < ns) { const ssg_seed_t sdd = sd[me]; my_rbeg = sdd.rbeg; my_q = sdd.qbeg; my_len = sdd.len; my_rid = srid[me]; my_rk = rank[me]; }
+			const int cn = ns - i0 < 64 ? ns - i0 : 64;
+			int done = 0;
+			while (done < cn) {
+				const bool act = lane >= done && lane < cn && my_rid >= 0;
+				int fl = -1, res = 1, two_eq = 0, eqp = 0; unsigned ls = 0, n16 = 0;
+				if (act) {
+					fl = chw_prev_set(L, my_rk); res = 0;
+					if (fl >= 0) { /* upstream test_and_merge against the floor chain */
+						int64_t f_rbeg = L.b8[fl], l_rbeg = L.a8[fl];
+						int f_q = L.fq[fl], l_q = L.lq[fl], l_len = L.ll[fl], crid = L.rid[fl];
+						n16 = L.n[fl]; ls = L.ls[fl];
+						if (f_rbeg == my_rbeg) {   /* a chain at this very position: upstream tests the FIRST of them */
+							eqp = 1;
+							const int f2 = chw_prev_set(L, fl - 1);
+							if (f2 >= 0 && L.b8[f2] == my_rbeg) {
+								fl = f2; two_eq = 1;
+								f_rbeg = L.b8[fl]; l_rbeg = L.a8[fl]; n16 = L.n[fl]; ls = L.ls[fl]; f_q = L.fq[fl]; l_q = L.lq[fl]; l_len = L.ll[fl]; crid = L.rid[fl];
+							}
+						}
+						f_q |= (int)(n16 >> 13 & 1) << 8; l_q |= (int)(n16 >> 14 & 1) << 8; l_len |= (int)(n16 >> 15 & 1) << 8;
+						if (my_rid != crid) res = 0;
+						else if (my_q >= f_q && my_q + my_len <= l_q + l_len && my_rbeg >= f_rbeg && my_rbeg + my_len <= l_rbeg + l_len) res = 1;
+						else if ((l_rbeg < l_pac || f_rbeg < l_pac) && my_rbeg >= l_pac) res = 0;
+						else {
+							const int64_t x = my_q - l_q, y = my_rbeg - l_rbeg;
+							if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) res = 2;
+						}
+					}
+				}
+				/* the first lane an earlier lane of this round interferes with */
+				int inv = act && eqp && lane > done;
+				int p = cn;
+				{
+					const unsigned long long b0 = wv_ballot(inv);
+					if (b0) p = (int)__builtin_ctzll(b0);
+				}
+				for (int t = done; t + 1 < p; ++t) {
+					const int r1 = wv_get(res, t);
+					if (r1 == 1) continue;
+					const int rk1 = wv_get(my_rk, t), fl1 = wv_get(fl, t);
+					if (act && lane > t) inv |= r1 == 0 ? (fl < rk1 && rk1 <= my_rk) : (fl == fl1);
+					const unsigned long long b1 = wv_ballot(inv);
+					if (b1) { const int p1 = (int)__builtin_ctzll(b1); p = p1 < p ? p1 : p; }
+				}
+				const bool com = act && lane < p;
+				const unsigned long long cre = wv_ballot(com && res == 0);
+				if (wv_ballot(com && res == 0 && (two_eq || nc + wv_rank_of(cre) >= capc_lim))) { fail = 1; break; }   /* not covered here: the caller redoes the read */
+				ssg_wave_ldssync();
+				if (com && res == 2) {
+					L.nx[ls] = (uint16_t)me; L.ls[fl] = (uint16_t)me; L.a8[fl] = my_rbeg; L.lq[fl] = (uint8_t)my_q; L.ll[fl] = (uint8_t)my_len;
+					L.n[fl] = (uint16_t)((((n16 & 0x1fff) + 1) & 0x1fff) | (n16 & 0x2000) | (unsigned)(my_q >> 8 & 1) << 14 | (unsigned)(my_len >> 8 & 1) << 15);
+				}
+				if (com && res == 0) {
+					const int bw = my_rk >> 6;
+					atomicOr((unsigned long long*)&L.bm[bw], 1ull << (my_rk & 63)); atomicOr((unsigned long long*)&L.bms[bw >> 6], 1ull << (bw & 63));
+					L.b8[my_rk] = my_rbeg; L.a8[my_rk] = my_rbeg; L.new_chain(my_rk, my_q, my_len);
+					L.fs[my_rk] = L.ls[my_rk] = (uint16_t)me; L.rid[my_rk] = (int16_t)my_rid;
+				}
+				ssg_wave_ldssync();
+				nc += __popcll(cre);
+				done = p;
+			}
+		}
+	} else if (rank) {
 		for (int i0 = 0; i0 < ns && !fail; i0 += 64) {
 			const int me = i0 + lane;
 			int64_t my_rbeg = 0; int my_q = 0, my_len = 0, my_rid = -1, my_rk = 0;
@@ -363,7 +440,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 	if (n_chn > 0) {
 		/* ---- upstream mem_chain_flt ---- */
 		const unsigned long long ph_t3 = ssg_clock();
-		if (wave_sort && n_chn > 24) wv_introsort_whi(L, n_chn); else if (lane == 0) ssg_introsort(L.b8, (long)n_chn, ssg_whi_gt());
+		if ((wave_sort & 1) && n_chn > 24) wv_introsort_whi(L, n_chn); else if (lane == 0) ssg_introsort(L.b8, (long)n_chn, ssg_whi_gt());
 		ssg_wave_ldssync();
 		const unsigned long long ph_t4 = ssg_clock();
 		for (i = lane; i < n_chn; i += 64) L.rid[i] = 0;
@@ -454,7 +531,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_wave(ssg_index_view_t ix, ssg_
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain,
-                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */, int wave_sort /* the weight sort by the whole wave (0: one lane, A/B and tests) */)
+                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */, int wave_sort /* bit 0: the weight sort by the whole wave, bit 1: the insertion 64 seeds at a time (0: one lane / one seed, A/B and tests) */)
 {
 	__shared__ ssg_chw_lds_t<CAP, CAP> L;
 	for (;;) {

@@ -93,11 +93,14 @@ def test_emu_repeats_align1(emu_lib, oracle, repeat_prefix, monkeypatch):
     assert common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix) > 500
     monkeypatch.setenv("SSG_CHAIN_RANKED", "0")         # the array-shifting insertion instead of the position-rank bitmap
     monkeypatch.setenv("SSG_CHAIN_WSORT", "0")          # and the weight sort on one lane
+    monkeypatch.setenv("SSG_CHAIN_SPEC", "0")           # (and, below with the bitmap again, the insertion seed by seed instead of 64 seeds a round)
     common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix)
     monkeypatch.delenv("SSG_CHAIN_RANKED")
     monkeypatch.delenv("SSG_CHAIN_WSORT")
     monkeypatch.setenv("SSG_CHAIN_CAP_TEST", "40")      # the ranked form gives up at 40 chains: its fall-back, the shifting form, redoes those reads
     common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix)
+    monkeypatch.delenv("SSG_CHAIN_SPEC")
+    common.check_align1(emu_lib, oracle, 12, seed=22, prefix=repeat_prefix)   # the same give-up out of a round of 64 seeds
     monkeypatch.delenv("SSG_CHAIN_CAP_TEST")
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "100000")  # and the lane-per-read kernel on the same reads
     monkeypatch.setenv("SSG_CHAIN_WAVE_BIG", "100000")
