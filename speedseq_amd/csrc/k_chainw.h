@@ -445,6 +445,70 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		const unsigned long long ph_t4 = ssg_clock();
 		for (i = lane; i < n_chn; i += 64) L.rid[i] = 0;
 		int nk = 0;
+		if (wave_sort & 4) {
+			/* 64 chains of the sorted list at a time, a lane each, against the kept chains in order.  (One chain at a time against 64 kept chains, below, spends most
+			 * of its ~2 200 cycles per chain on the round trips around the few tests it makes.)  A kept chain is one word: query begin | end << 9 | w << 18 in the
+			 * high half of a8[k], the first chain it shadows in the low 16 bits.  The sequential loop's order is kept: a lane stops caring at its first `break'
+			 * (the tests before it have their side effect, the ones after it none); `first' of a kept chain goes to the smallest i that reaches it with an overlap;
+			 * within the block the lanes become kept chains in order, each tested by the later lanes still running. */
+			for (int i0 = 0; i0 < n_chn; i0 += 64) {
+				const int ci = i0 + lane; const bool act = ci < n_chn;
+				const int64_t me = act ? L.b8[ci] : 0;
+				const int id = (int)(uint32_t)me, wi = (int)(me >> 32);
+				const int ib = act ? L.get_fq(id) : 0, ie = act ? L.get_lq(id) + L.get_ll(id) : 0;
+				int lo = 0, broke = !act, myfirst = 0xffff;
+				const int nk0 = nk;
+				for (int k0 = 0; k0 < nk0; k0 += 64) {
+					if (!wv_ballot(!broke)) break;
+					const int kk = k0 + lane;
+					const int64_t kw = kk < nk0 ? L.a8[kk] : 0;
+					const int kwh = (int)(kw >> 32), kwl = (int)(uint32_t)kw;
+					const int cnt = nk0 - k0 < 64 ? nk0 - k0 : 64;
+					for (int j = 0; j < cnt; ++j) {
+						const int hw = wv_get(kwh, j);
+						const int jb = hw & 511, je = hw >> 9 & 511, wj = (int)((unsigned)hw >> 18);
+						int ov = 0, brk = 0;
+						const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
+						if (!broke && e_min > b_max) {
+							const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj;
+							if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+								ov = 1;
+								brk = (wi < wj * opt.drop_ratio) & (wj - wi >= opt.min_seed_len << 1);
+							}
+						}
+						const unsigned long long ovm = wv_ballot(ov);
+						if (ovm) {
+							lo |= ov; broke |= brk;
+							if ((wv_get(kwl, j) & 0xffff) == 0xffff && lane == 0) L.a8[k0 + j] = (int64_t)(((uint64_t)(uint32_t)hw << 32) | (uint32_t)(i0 + (int)__builtin_ctzll(ovm)));
+						}
+					}
+				}
+				const int cnt_b = n_chn - i0 < 64 ? n_chn - i0 : 64;
+				for (int t = 0; t < cnt_b; ++t) {
+					if (wv_get(broke, t)) continue;
+					const int jb = wv_get(ib, t), je = wv_get(ie, t), wj = wv_get(wi, t);
+					int ov = 0, brk = 0;
+					const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
+					if (!broke && lane > t && e_min > b_max) {
+						const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj;
+						if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+							ov = 1;
+							brk = (wi < wj * opt.drop_ratio) & (wj - wi >= opt.min_seed_len << 1);
+						}
+					}
+					const unsigned long long ovm = wv_ballot(ov);
+					if (ovm) { lo |= ov; broke |= brk; if (lane == t) myfirst = i0 + (int)__builtin_ctzll(ovm); }
+				}
+				const unsigned long long keptm = wv_ballot(!broke);
+				ssg_wave_ldssync();
+				if (!broke) {
+					L.a8[nk + wv_rank_of(keptm)] = (int64_t)(((uint64_t)(uint32_t)(ib | ie << 9 | wi << 18)) << 32 | (uint32_t)myfirst);
+					L.rid[ci] = lo ? 2 : 3;
+				}
+				nk += __popcll(keptm);
+				ssg_wave_ldssync();
+			}
+		} else
 		for (i = 0; i < n_chn; ++i) {
 			const int64_t me = L.b8[i];
 			const int id = (int)(uint32_t)me, wi = (int)(me >> 32);
@@ -531,7 +595,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_wave(ssg_index_view_t ix, ssg_
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain,
-                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */, int wave_sort /* bit 0: the weight sort by the whole wave, bit 1: the insertion 64 seeds at a time (0: one lane / one seed, A/B and tests) */)
+                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */, int wave_sort /* bit 0: the weight sort by the whole wave, bit 1: the insertion 64 seeds a round, bit 2: the filter 64 chains a round (0: one lane / one seed / one chain, A/B and tests) */)
 {
 	__shared__ ssg_chw_lds_t<CAP, CAP> L;
 	for (;;) {

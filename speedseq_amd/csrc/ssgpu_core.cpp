@@ -776,7 +776,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int T = idx->v.n_ctg > 32767 ? 1 << 30 : std::max(1, env_int("SSG_CHAIN_WAVE_MIN", 64));
 		const int TB = env_int("SSG_CHAIN_WAVE_BIG", 0) > 0 ? env_int("SSG_CHAIN_WAVE_BIG", 0) : 1 << 30;
 		const bool ranked = env_int("SSG_CHAIN_RANKED", 1) != 0;
-		const int wsort = (env_int("SSG_CHAIN_WSORT", 1) ? 1 : 0) | (env_int("SSG_CHAIN_SPEC", 1) ? 2 : 0);   /* the wave kernels' weight sort by the whole wave (k_chainw.h wv_introsort_whi) and insertion 64 seeds at a time; 0: by one lane / seed by seed (A/B, tests) */
+		const int wsort = (env_int("SSG_CHAIN_WSORT", 1) ? 1 : 0) | (env_int("SSG_CHAIN_SPEC", 1) ? 2 : 0) | (env_int("SSG_CHAIN_BFLT", 1) ? 4 : 0);   /* the wave kernels' weight sort by the whole wave (k_chainw.h wv_introsort_whi) insertion 64 seeds a round and filter 64 chains a round; 0: by one lane / seed by seed / chain by chain (A/B, tests) */
 		const int cap_lim = env_int("SSG_CHAIN_CAP_TEST", 1 << 30);   /* tests: pretend the ranked form holds fewer chains, to walk its fall-back (the shifting form) */
 		int g[7], gl[3];   /* gl: reads with more than 63 / 31 / 15 seeds (the classes of the light reads' LDS kernel) */
 		{	/* "greater than" counts of the seeds-per-read array in one pass (thresholds descending: the counts ascend) */

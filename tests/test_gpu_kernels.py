@@ -118,11 +118,13 @@ def test_gpu_repeats_align1(gpu_lib, oracle, repeat_prefix, monkeypatch):
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "4")
     assert common.check_align1(gpu_lib, oracle, 150, seed=22, prefix=repeat_prefix) > 5000
     monkeypatch.setenv("SSG_CHAIN_RANKED", "0")         # the array-shifting insertion instead of the position-rank bitmap
-    monkeypatch.setenv("SSG_CHAIN_WSORT", "0")          # and the weight sort on one lane
+    monkeypatch.setenv("SSG_CHAIN_WSORT", "0")          # and the weight sort on one lane,
+    monkeypatch.setenv("SSG_CHAIN_BFLT", "0")           # the filter one chain at a time
     monkeypatch.setenv("SSG_CHAIN_SPEC", "0")           # (and, below with the bitmap again, the insertion seed by seed instead of 64 seeds a round)
     common.check_align1(gpu_lib, oracle, 300, seed=22, prefix=repeat_prefix)
     monkeypatch.delenv("SSG_CHAIN_RANKED")
     monkeypatch.delenv("SSG_CHAIN_WSORT")
+    monkeypatch.delenv("SSG_CHAIN_BFLT")
     monkeypatch.setenv("SSG_CHAIN_CAP_TEST", "40")      # the ranked form gives up at 40 chains: its fall-back, the shifting form, redoes those reads
     common.check_align1(gpu_lib, oracle, 300, seed=22, prefix=repeat_prefix)
     monkeypatch.delenv("SSG_CHAIN_SPEC")
