@@ -130,7 +130,10 @@ static inline int rt_lane_copy(void *d, const void *s, size_t n, hipMemcpyKind k
 static inline int rt_h2d(void *d, const void *h, size_t n) { return !n ? 0 : ssg_stream ? rt_lane_copy(d, h, n, hipMemcpyHostToDevice, "hipMemcpyAsync H2D") : rt_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
 static inline int rt_d2h(void *h, const void *d, size_t n) { return !n ? 0 : ssg_stream ? rt_lane_copy(h, d, n, hipMemcpyDeviceToHost, "hipMemcpyAsync D2H") : rt_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
 static inline int rt_memset(void *d, int v, size_t n) { return !n ? 0 : ssg_stream ? rt_check(hipMemsetAsync(d, v, n, ssg_stream), "hipMemsetAsync") : rt_check(hipMemset(d, v, n), "hipMemset"); }
-static inline int rt_sync() { int rc = ssg_stream ? rt_check(hipStreamSynchronize(ssg_stream), "hipStreamSynchronize") : rt_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
+/* waits for THIS thread's stream (lane 0: the null stream), not for the device: kernels forked onto the side streams (which are joined by events before their results are
+ * used) keep running across the host round trips of the stream that forked them -- a device-wide wait here made the chaining stage's rank preparation wait for the light
+ * reads' kernels (6 ms of a 20 ms stage, profiles/r05q_timeline.txt) */
+static inline int rt_sync() { int rc = rt_check(hipStreamSynchronize(ssg_stream), "hipStreamSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
 /* multi-gigabyte, build-time-only arrays (index construction) bypass the arena: they must return to the driver when freed */
 static inline void *rt_malloc_raw(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); ssg_pool.release(); if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return 0; } } return p; }
 static inline void rt_free_raw(void *p) { if (p) (void)hipFree(p); }

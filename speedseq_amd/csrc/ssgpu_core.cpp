@@ -779,11 +779,11 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int wsort = (env_int("SSG_CHAIN_WSORT", 1) ? 1 : 0) | (env_int("SSG_CHAIN_SPEC", 1) ? 2 : 0) | (env_int("SSG_CHAIN_BFLT", 1) ? 4 : 0);   /* the wave kernels' weight sort by the whole wave (k_chainw.h wv_introsort_whi) insertion 64 seeds a round and filter 64 chains a round; 0: by one lane / seed by seed / chain by chain (A/B, tests) */
 		const int cap_lim = env_int("SSG_CHAIN_CAP_TEST", 1 << 30);   /* tests: pretend the ranked form holds fewer chains, to walk its fall-back (the shifting form) */
 		int g[7], gl[3];   /* gl: reads with more than 63 / 31 / 15 seeds (the classes of the light reads' LDS kernel) */
-		{	/* "greater than" counts of the seeds-per-read array in one pass (thresholds descending: the counts ascend) */
+		{	/* "greater than" counts of the seeds-per-read array (d_work sorts it descending: a binary search per threshold; thresholds descending: the counts ascend) */
 			ssg_thr6_t th = { { 1 << 30, 5120, std::min(2048, TB), std::min(1024, TB), std::min(512, TB), std::min(256, TB), T - 1, 63, 31, 15 } };
 			dbuf<unsigned int> d_c(16); unsigned int c[10];
 			CHKA(d_c); CHK(d_c.zero());
-			SSG_LAUNCH(ssg_k_count_gt6, (n_reads + 255) / 256, 256, 0, d_nseed.p, (long)n_reads, th, d_c.p);
+			SSG_LAUNCH(ssg_k_count_gt6, 1, 64, 0, d_nseed.p, d_work.p, (long)n_reads, th, d_c.p);
 			CHK(d_c.down(c, 10));
 			for (int i = 0; i < 7; ++i) g[i] = (int)std::min(c[i], c[6]);
 			for (int i = 1; i < 7; ++i) g[i] = std::max(g[i], g[i - 1]);
