@@ -25,6 +25,9 @@ orc_opt_t *orc_api_opt_new(void) { orc_opt_t *o = malloc(sizeof(orc_opt_t)); orc
 /* scoring of the stage-level checks (bwa mem -A -B -O -E): a, b, gap open / extend for deletions and insertions */
 void orc_api_opt_scores(orc_opt_t *o, int a, int b, int o_del, int e_del, int o_ins, int e_ins)
 { o->a = a; o->b = b; o->o_del = o_del; o->e_del = e_del; o->o_ins = o_ins; o->e_ins = e_ins; orc_fill_scmat(o); }
+/* the chain filter's knobs (bwa mem -D, -W, -N and the compiled-in mask_level / max_chain_gap), for the chaining kernels' tests */
+void orc_api_opt_chain(orc_opt_t *o, float drop_ratio, float mask_level, int min_chain_weight, int max_chain_extend, int max_chain_gap)
+{ o->drop_ratio = drop_ratio; o->mask_level = mask_level; o->min_chain_weight = min_chain_weight; o->max_chain_extend = max_chain_extend; o->max_chain_gap = max_chain_gap; }
 void orc_api_free(void *p) { free(p); }
 
 /* mem_collect_intv for one read; returns the number of intervals (out may be smaller than needed) */

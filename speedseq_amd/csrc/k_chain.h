@@ -352,7 +352,41 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 		/* byte arrays in the words of CB (its weights live in S now): state of sorted chain i; the first chain kept chain k shadows */
 		constexpr int W_ST = C::W_CB, W_KF = C::W_CB + CAP / 4;
 		int nk = 0;
-		for (i = 0; i < n_chn; ++i) {
+		{	/* The chains that cannot `break' against the heaviest one by the weights alone break against none (w descends; both tests are monotone in w): a prefix [0, m) of
+			 * the list, all kept.  For these the quadratic loop below leaves behind: `first' of kept chain e = the first later chain that overlaps it; large_ovlp of chain e =
+			 * some earlier chain overlaps it -- two scans that stop at their first hit (in a repeat family everything overlaps everything). */
+			const int w0 = (int)(lw[(C::W_RLO + 0) * 64] >> 8);
+			int m = 0;
+			for (; m < n_chn; ++m) {
+				const uint32_t me = lw[(C::W_RLO + m) * 64];
+				const int wc = (int)(me >> 8);
+				if ((wc < w0 * opt.drop_ratio) & (w0 - wc >= opt.min_seed_len << 1)) break;
+				const unsigned id = me & 255;
+				const unsigned ls = lw[(C::W_CA + id) * 64] & 255;
+				const uint32_t ml = lw[(C::W_META + ls) * 64];
+				lw[(C::W_RHI + m) * 64] = (lw[(C::W_META + id) * 64] & 511) | ((ml & 511) + (ml >> 9 & 511)) << 9 | (uint32_t)wc << 18;
+			}
+			for (int e = 0; e < m; ++e) {
+				const uint32_t pe = lw[(C::W_RHI + e) * 64];
+				const int ib = (int)(pe & 511), ie = (int)(pe >> 9 & 511);
+				int f = 0x7f, lo = 0;
+				for (int q = e + 1; q < m; ++q) {
+					const uint32_t pk = lw[(C::W_RHI + q) * 64];
+					const int jb = (int)(pk & 511), je = (int)(pk >> 9 & 511);
+					const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
+					if (e_min > b_max) { const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj; if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) { f = q; break; } }
+				}
+				for (int q = e - 1; q >= 0; --q) {
+					const uint32_t pk = lw[(C::W_RHI + q) * 64];
+					const int jb = (int)(pk & 511), je = (int)(pk >> 9 & 511);
+					const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
+					if (e_min > b_max) { const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj; if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) { lo = 1; break; } }
+				}
+				SSG_CL_B(W_KF, e) = (uint8_t)f; SSG_CL_B(W_ST, e) = (uint8_t)(lo ? 2 : 3);
+			}
+			nk = m;
+		}
+		for (i = nk; i < n_chn; ++i) {
 			const uint32_t me = lw[(C::W_RLO + i) * 64];
 			const unsigned id = me & 255; const int wi = (int)(me >> 8);
 			const unsigned ls = lw[(C::W_CA + id) * 64] & 255;

@@ -451,7 +451,53 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			 * high half of a8[k], the first chain it shadows in the low 16 bits.  The sequential loop's order is kept: a lane stops caring at its first `break'
 			 * (the tests before it have their side effect, the ones after it none); `first' of a kept chain goes to the smallest i that reaches it with an overlap;
 			 * within the block the lanes become kept chains in order, each tested by the later lanes still running. */
-			for (int i0 = 0; i0 < n_chn; i0 += 64) {
+			/* The heaviest chains first, all at once: w descends, so a chain that cannot `break' against chain 0 by the weights alone (w < w0 x drop_ratio and w0 - w >=
+			 * 2 min_seed_len are both monotone in w) breaks against no chain: these form a prefix [0, m) of the list and are all kept.  What the sequential loop leaves
+			 * behind for them: `first' of kept chain e = the first later chain that overlaps it, and large_ovlp of chain e = some earlier chain overlaps it -- two scans
+			 * per lane that stop at their first hit (in a repeat family everything overlaps everything: the quadratic loop becomes linear). */
+			int m = n_chn;
+			{
+				const int w0 = (int)(L.b8[0] >> 32);
+				for (int i0 = 0; i0 < n_chn; i0 += 64) {
+					const int ci = i0 + lane;
+					const int wc = ci < n_chn ? (int)(L.b8[ci] >> 32) : 0;
+					const unsigned long long um = wv_ballot(ci < n_chn && ((wc < w0 * opt.drop_ratio) & (w0 - wc >= opt.min_seed_len << 1)));
+					if (um) { m = i0 + (int)__builtin_ctzll(um); break; }
+				}
+			}
+			ssg_wave_ldssync();
+			for (int e = lane; e < m; e += 64) {
+				const int64_t me = L.b8[e];
+				const int id = (int)(uint32_t)me, wi = (int)(me >> 32);
+				L.a8[e] = (int64_t)(((uint64_t)(uint32_t)(L.get_fq(id) | (L.get_lq(id) + L.get_ll(id)) << 9 | wi << 18)) << 32 | 0xffffu);
+			}
+			ssg_wave_ldssync();
+			for (int e0 = 0; e0 < m; e0 += 64) {
+				const int e = e0 + lane; const bool act = e < m;
+				const int hwe = act ? (int)(L.a8[e] >> 32) : 0;
+				const int ib = hwe & 511, ie = hwe >> 9 & 511;
+				int f = 0xffff, lo = 0;
+				for (int dir = 0; dir < 2; ++dir) {   /* forward: the first later chain of the prefix that overlaps; backward: any earlier one */
+					int q = dir ? e - 1 : e + 1;
+					bool run = act && (dir ? q >= 0 : q < m);
+					while (wv_ballot(run)) {
+						if (run) {
+							const int hw = (int)(L.a8[q] >> 32);
+							const int jb = hw & 511, je = hw >> 9 & 511;
+							const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
+							bool ov = false;
+							if (e_min > b_max) { const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj; ov = e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap; }
+							if (ov) { if (dir) lo = 1; else f = q; run = false; }
+							else { q += dir ? -1 : 1; run = dir ? q >= 0 : q < m; }
+						}
+					}
+				}
+				ssg_wave_ldssync();
+				if (act) { L.a8[e] = (int64_t)(((uint64_t)(uint32_t)hwe) << 32 | (uint32_t)f); L.rid[e] = lo ? 2 : 3; }
+			}
+			nk = m;
+			ssg_wave_ldssync();
+			for (int i0 = m; i0 < n_chn; i0 += 64) {
 				const int ci = i0 + lane; const bool act = ci < n_chn;
 				const int64_t me = act ? L.b8[ci] : 0;
 				const int id = (int)(uint32_t)me, wi = (int)(me >> 32);

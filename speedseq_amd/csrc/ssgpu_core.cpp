@@ -792,16 +792,16 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int n_heavy = g[6];
 		const int nC = g[1], n5120 = g[2] - g[1], n2048 = g[3] - g[2], n1024 = g[4] - g[3], n512 = g[5] - g[4], n256 = g[6] - g[5];
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
-		ssg_fork(4);
+		ssg_fork(3);
 		{	/* The light reads go first, on a stream of their own, while this one ranks the heavy reads' seeds (small latency-bound launches that leave the chip idle); behind the wave
 			 * kernels they would wait for LDS (the 63-seed class asks for 94 KB a workgroup) and run as a tail.  Heaviest first: up to 15 / 31 / 63 seeds with the read's state in the lane's part of LDS (k_chain.h), the rest -- and everything when the
 			 * index has too many contigs for 14 bits, a read is too long for 9-bit query coordinates, or SSG_CHAIN_LDS = 0 (A/B, tests) -- on global memory */
 			const bool use_lds = env_int("SSG_CHAIN_LDS", 1) != 0 && idx->v.n_ctg < 0x3fff && max_len < 512;
 			const int r0 = n_heavy;
 			const int b63 = use_lds ? std::min(n_reads, std::max(r0, gl[0])) : n_reads, b31 = std::min(n_reads, std::max(b63, gl[1])), b15 = std::min(n_reads, std::max(b31, gl[2]));
-			if (b63 > r0) SSG_LAUNCH_ON(3, ssg_k_chain, (b63 - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, b63, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+			if (b63 > r0) SSG_LAUNCH_ON(2, ssg_k_chain, (b63 - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, b63, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 			                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-#define SSG_CL_LAUNCH(CC, from, to) do { if ((to) > (from)) SSG_LAUNCH_ON(3, ssg_k_chain_lds<CC>, ((to) - (from) + 63) / 64, 64, 0, idx->v, *opt, (from), (to), d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, \
+#define SSG_CL_LAUNCH(CC, from, to) do { if ((to) > (from)) SSG_LAUNCH_ON(2, ssg_k_chain_lds<CC>, ((to) - (from) + 63) / 64, 64, 0, idx->v, *opt, (from), (to), d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, \
 			d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p); } while (0)
 			SSG_CL_LAUNCH(64, b63, b31);
 			SSG_CL_LAUNCH(32, b31, b15);
@@ -830,19 +830,19 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		/* the classes are independent and each of the heavy ones fills a fraction of the chip: overlap them */
 		/* four queues: the two big classes one each, the short jobs (top class, small classes, then the one-lane monsters) in a row on the third,
 		 * the light reads' lane kernel on the default stream (more streams than hardware queues serialize behind one another anyway) */
-		ssg_fork(3);   /* (again: the wave kernels read the ranks) */
+		ssg_fork(2);   /* (again, the wave kernels' two streams: they read the ranks) */
 		int r0 = nC;
 #define SSG_CHW_LAUNCH(si, CC, cnt, maxwg, qi) do { if ((cnt) > 0) SSG_LAUNCH_ON(si, ssg_k_chain_wave<CC>, std::min((int)(cnt), (int)(maxwg)), 64, 0, idx->v, *opt, r0, r0 + (cnt), d_off, d_intv.p, d_nintv.p, cap, \
 		o.seed_off.p, d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + (qi), hr, ho, std::min((int)(CC), cap_lim), wsort); r0 += (cnt); } while (0)
 		SSG_CHW_LAUNCH(0, 5120, n5120, 256, 1);
 		SSG_CHW_LAUNCH(1, 2048, n2048, 512, 3);
-		SSG_CHW_LAUNCH(2, 1024, n1024, 1280, 2);
+		SSG_CHW_LAUNCH(1, 1024, n1024, 1280, 2);   /* (behind the 2048 class: this stream + two side streams + the light reads' stream are the four hardware queues; a fifth stream shares one) */
 		SSG_CHW_LAUNCH(0, 512, n512, 2560, 5);
 		SSG_CHW_LAUNCH(0, 256, n256, 5120, 4);
 #undef SSG_CHW_LAUNCH
 		if (nC) SSG_LAUNCH_ON(0, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-		ssg_join(4);
+		ssg_join(3);
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */

@@ -416,11 +416,17 @@ def check_dedup(lib, oracle, n_pairs, seed, dup_frac=0.2):
     return int(dup.sum())
 
 
-def check_align1(lib, oracle, n_pairs, seed, read_len=150, prefix=EXAMPLE_FA):
+def check_align1(lib, oracle, n_pairs, seed, read_len=150, prefix=EXAMPLE_FA, chain_opt=None):
+    """chain_opt: (drop_ratio, mask_level, min_chain_weight, max_chain_extend, max_chain_gap) for the chain filter, both sides"""
     oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
     _, seqs, seq, off = sim_reads(n_pairs, seed, read_len, fasta=prefix)
-    ro, regs, st = lib.align1_batch(gidx, lib.opt_init(), seq, off)
-    oro, oregs = oracle.align1_batch(oidx, seq, off)
+    opt, oopt = lib.opt_init(), None
+    if chain_opt is not None:
+        for f, v in zip(("drop_ratio", "mask_level", "min_chain_weight", "max_chain_extend", "max_chain_gap"), chain_opt):
+            opt[f] = v
+        oopt = oracle.opt_chain(*chain_opt)
+    ro, regs, st = lib.align1_batch(gidx, opt, seq, off)
+    oro, oregs = oracle.align1_batch(oidx, seq, off, oopt)
     assert np.array_equal(ro, oro)
     for f in REG_FIELDS:
         assert np.array_equal(regs[f], oregs[f]), f

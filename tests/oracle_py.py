@@ -52,6 +52,12 @@ class Oracle:
         self.l.orc_api_opt_scores(o, C.c_int(a), C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins))
         return o
 
+    def opt_chain(self, drop_ratio, mask_level, min_chain_weight, max_chain_extend, max_chain_gap):
+        """an option block of its own with these chain-filter settings"""
+        o = C.c_void_p(self.l.orc_api_opt_new())
+        self.l.orc_api_opt_chain(o, C.c_float(drop_ratio), C.c_float(mask_level), C.c_int(min_chain_weight), C.c_int(max_chain_extend), C.c_int(max_chain_gap))
+        return o
+
     def align2(self, q, t, xtra, opt=None):
         out = (C.c_int * 7)()
         self.l.orc_api_align2(opt or self.opt, C.c_int(len(q)), _ptr(q), C.c_int(len(t)), _ptr(t), C.c_int(xtra), out)
@@ -76,13 +82,13 @@ class Oracle:
         assert n <= cap
         return out[:n]
 
-    def align1_batch(self, idx, seq, off):
+    def align1_batch(self, idx, seq, off, opt=None):
         n = len(off) - 1
         reg_off = np.zeros(n + 1, dtype=np.int64)
         cap = 64 * n + 1024
         while True:
             out = np.zeros(cap, dtype=ALNREG_DT)
-            tot = self.l.orc_api_align1_batch(self.opt, idx, C.c_int(n), _ptr(seq), _ptr(off), _ptr(reg_off), _ptr(out), C.c_int64(cap))
+            tot = self.l.orc_api_align1_batch(opt or self.opt, idx, C.c_int(n), _ptr(seq), _ptr(off), _ptr(reg_off), _ptr(out), C.c_int64(cap))
             if tot <= cap:
                 return reg_off, out[:tot]
             cap = tot

@@ -149,6 +149,16 @@ def test_gpu_chain_weight_sort_by_the_wave(gpu_lib):
             assert np.all(np.diff(a >> 32) <= 0) and np.array_equal(np.sort(a), np.sort(keys))
 
 
+def test_gpu_chain_filter_options(gpu_lib, oracle, repeat_mid_prefix, monkeypatch):
+    # mem_chain_flt's knobs away from their defaults (drop ratio, mask level, minimum weight, the cap on extended chains, the gap that makes an overlap count):
+    # the light reads' lane kernel, then the same reads through the wave kernels
+    sets = [(0.3, 0.2, 60, 10, 40), (0.8, 0.5, 0, 1 << 30, 100), (0.95, 0.9, 30, 3, 10000), (0.5, 0.5, 0, 50, 40)]
+    for wmin in ("64", "4"):
+        monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", wmin)
+        for k, co in enumerate(sets):
+            assert common.check_align1(gpu_lib, oracle, 600, seed=40 + k, read_len=(150, 250)[k & 1], prefix=repeat_mid_prefix, chain_opt=co) > 0
+
+
 def test_gpu_light_reads_chain_lds(gpu_lib, oracle, repeat_mid_prefix, monkeypatch):
     # reads with 10..63 seeds in small repeat families: the three classes of ssg_k_chain_lds (state in the lane's LDS), then the same reads through ssg_k_chain
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "64")
