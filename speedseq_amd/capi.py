@@ -336,7 +336,7 @@ def prof_get(lib, cap=64):
     n = lib.l.ssg_prof_get(C.c_int(cap), names, ms, cnt)
     out = {}
     for i in range(min(n, cap)):   # the instance for reads up to 255 bases keeps the kernel's plain name; the other one says so
-        k = names[i].decode().replace("<false>", "").replace("<true>", "<wide>")
+        k = names[i].decode().replace("<false>", "").replace("<true>", "<wide>").strip("()")
         a, b = out.get(k, (0.0, 0))
         out[k] = (a + ms[i], b + cnt[i])
     return out

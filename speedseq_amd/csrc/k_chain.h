@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
  * sets together exceed L2 many times over, and each touch becomes a line from HBM.  Here a lane reads its seeds ONCE (the algorithmic
  * traffic), chains and filters on LDS, and writes out what the next stage reads: the surviving chains, their order and their seed lists.
  *
- * Layout: 32-bit words, word W of lane l at lds[W * 64 + l] (lanes at the same W hit 64 different banks); 5.75 words per seed slot:
+ * Layout: 32-bit words, word W of lane l at lds[W * LN + l] (LN lanes a workgroup; lanes at the same W hit different banks); 5.75 words per seed slot:
  *   RLO / RHI [seed]   rbeg of the seed        | after the weights: S[i] = w << 8 | chain (position order, then sorted by weight) / K[k] = kept chain's query begin | end << 9 | w << 18
  *   META [seed]        qbeg | len << 9 | contig << 18 (0x3fff: no contig, the seed is skipped; the host sends indexes with more contigs to ssg_k_chain)
  *   CA [chain]         last seed | left << 8 | right << 16 | #seeds << 24     (a chain's id IS its first seed's index: its position and contig are that seed's)
@@ -225,15 +225,15 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
 template <int CAP> struct ssg_cl_cfg {
 	static constexpr int W_RLO = 0, W_RHI = CAP, W_META = 2 * CAP, W_CA = 3 * CAP, W_CB = 4 * CAP, W_NEXT = 5 * CAP, W_SUCC = W_NEXT + CAP / 4, W_ORD = W_SUCC + CAP / 4, WORDS = W_ORD + CAP / 4;
 };
-struct ssg_cl_words_t {   /* a[i] = word (base + i) of this lane */
+template <int LN> struct ssg_cl_words_t {   /* a[i] = word (base + i) of this lane; LN lanes share the block */
 	uint32_t *w;
-	SSG_DEVMEM uint32_t get(int i) const { return w[i * 64]; }
-	SSG_DEVMEM void set(int i, uint32_t x) const { w[i * 64] = x; }
+	SSG_DEVMEM uint32_t get(int i) const { return w[i * LN]; }
+	SSG_DEVMEM void set(int i, uint32_t x) const { w[i * LN] = x; }
 };
 struct ssg_cl_w_gt { SSG_DEVMEM bool operator()(uint32_t a, uint32_t b) const { return (a >> 8) > (b >> 8); } };
-#define SSG_CL_B(word0, e) (((uint8_t*)(lw + ((word0) + ((e) >> 2)) * 64))[(e) & 3])
+#define SSG_CL_B(word0, e) (((uint8_t*)(lw + ((word0) + ((e) >> 2)) * LN))[(e) & 3])
 
-template <int CAP>
+template <int CAP, int LN /* reads (lanes) per workgroup: 64, or 32 where a whole wave's state would leave a CU's LDS to one workgroup */>
 __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int r_end,
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 {
 	typedef ssg_cl_cfg<CAP> C;
 	static_assert(CAP <= 64 && CAP % 4 == 0, "chain ids are 6 bits, byte arrays fill whole words");
-	__shared__ uint32_t lds[C::WORDS * 64];
+	__shared__ uint32_t lds[C::WORDS * LN];
 	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= r_end) return;
 	if (work_order) r = work_order[r];
@@ -271,33 +271,33 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 		int64_t rb[4]; int q[4], l[4], rd[4];
 		SSG_UNROLL for (k = 0; k < 4; ++k) { const int e = i + k < ns ? i + k : ns - 1; const ssg_seed_t *p = seeds + s0 + e; rb[k] = p->rbeg; q[k] = p->qbeg; l[k] = p->len; rd[k] = seed_rid[s0 + e]; }
 		SSG_UNROLL for (k = 0; k < 4; ++k) if (i + k < ns) {
-			lw[(C::W_RLO + i + k) * 64] = (uint32_t)rb[k]; lw[(C::W_RHI + i + k) * 64] = (uint32_t)((uint64_t)rb[k] >> 32);
-			lw[(C::W_META + i + k) * 64] = (uint32_t)q[k] | (uint32_t)l[k] << 9 | (rd[k] < 0 ? 0x3fffu : (uint32_t)rd[k]) << 18;
+			lw[(C::W_RLO + i + k) * LN] = (uint32_t)rb[k]; lw[(C::W_RHI + i + k) * LN] = (uint32_t)((uint64_t)rb[k] >> 32);
+			lw[(C::W_META + i + k) * LN] = (uint32_t)q[k] | (uint32_t)l[k] << 9 | (rd[k] < 0 ? 0x3fffu : (uint32_t)rd[k]) << 18;
 		}
 	}
 	/* greedy chaining in seed-visiting order */
 	unsigned root = SSG_CL_NONE, head = SSG_CL_NONE; int ins_ctr = 0;
 	for (i = 0; i < ns; ++i) {
-		const uint32_t mi = lw[(C::W_META + i) * 64];
+		const uint32_t mi = lw[(C::W_META + i) * LN];
 		const uint32_t rid_i = mi >> 18;
 		if (rid_i == 0x3fffu) continue;
-		const int64_t rbeg = (int64_t)((uint64_t)lw[(C::W_RHI + i) * 64] << 32 | lw[(C::W_RLO + i) * 64]);
+		const int64_t rbeg = (int64_t)((uint64_t)lw[(C::W_RHI + i) * LN] << 32 | lw[(C::W_RLO + i) * LN]);
 		const int qbeg = (int)(mi & 511), slen = (int)(mi >> 9 & 511);
 		unsigned cur = root, lower = SSG_CL_NONE, par = SSG_CL_NONE; int par_right = 0;
 		int64_t lower_pos = 0; uint32_t lower_ca = 0;
 		while (cur != SSG_CL_NONE) { /* floor of (rbeg, first) */
-			const int64_t pos = (int64_t)((uint64_t)lw[(C::W_RHI + cur) * 64] << 32 | lw[(C::W_RLO + cur) * 64]);
-			const uint32_t ca = lw[(C::W_CA + cur) * 64], cb = lw[(C::W_CB + cur) * 64];
+			const int64_t pos = (int64_t)((uint64_t)lw[(C::W_RHI + cur) * LN] << 32 | lw[(C::W_RLO + cur) * LN]);
+			const uint32_t ca = lw[(C::W_CA + cur) * LN], cb = lw[(C::W_CB + cur) * LN];
 			const bool go_right = pos < rbeg || (pos == rbeg && (cb >> 16) == 0);
 			par = cur; par_right = go_right;
 			if (go_right) { lower = cur; lower_pos = pos; lower_ca = ca; cur = ca >> 16 & 255; } else cur = ca >> 8 & 255;
 		}
 		bool merged = false;
 		if (lower != SSG_CL_NONE) { /* upstream test_and_merge against the floor chain */
-			const uint32_t mf = lw[(C::W_META + lower) * 64];
+			const uint32_t mf = lw[(C::W_META + lower) * LN];
 			const unsigned ls = lower_ca & 255;
-			const uint32_t ml = lw[(C::W_META + ls) * 64];
-			const int64_t l_rbeg = (int64_t)((uint64_t)lw[(C::W_RHI + ls) * 64] << 32 | lw[(C::W_RLO + ls) * 64]);
+			const uint32_t ml = lw[(C::W_META + ls) * LN];
+			const int64_t l_rbeg = (int64_t)((uint64_t)lw[(C::W_RHI + ls) * LN] << 32 | lw[(C::W_RLO + ls) * LN]);
 			const int f_q = (int)(mf & 511), l_q = (int)(ml & 511), l_len = (int)(ml >> 9 & 511);
 			if (rid_i != mf >> 18) merged = false;
 			else if (qbeg >= f_q && qbeg + slen <= l_q + l_len && rbeg >= lower_pos && rbeg + slen <= l_rbeg + l_len) merged = true;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 				const int64_t x = qbeg - l_q, y = rbeg - l_rbeg;
 				if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
 					SSG_CL_B(C::W_NEXT, ls) = (uint8_t)i;
-					lw[(C::W_CA + lower) * 64] = ((lower_ca & ~255u) | (uint32_t)i) + (1u << 24);
+					lw[(C::W_CA + lower) * LN] = ((lower_ca & ~255u) | (uint32_t)i) + (1u << 24);
 					merged = true;
 				}
 			}
@@ -314,21 +314,21 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 		if (!merged) { /* a new chain, named after its seed */
 			uint32_t sec = 0;
 			if (lower != SSG_CL_NONE && lower_pos == rbeg) { ++ins_ctr; sec = (uint32_t)(64 - ins_ctr); }
-			lw[(C::W_CA + i) * 64] = (uint32_t)i | SSG_CL_NONE << 8 | SSG_CL_NONE << 16 | 1u << 24;
-			lw[(C::W_CB + i) * 64] = sec << 16;
+			lw[(C::W_CA + i) * LN] = (uint32_t)i | SSG_CL_NONE << 8 | SSG_CL_NONE << 16 | 1u << 24;
+			lw[(C::W_CB + i) * LN] = sec << 16;
 			if (par == SSG_CL_NONE) root = (unsigned)i;
-			else ((uint8_t*)(lw + (C::W_CA + par) * 64))[par_right ? 2 : 1] = (uint8_t)i;
+			else ((uint8_t*)(lw + (C::W_CA + par) * LN))[par_right ? 2 : 1] = (uint8_t)i;
 			if (lower == SSG_CL_NONE) { SSG_CL_B(C::W_SUCC, i) = (uint8_t)head; head = (unsigned)i; }
 			else { SSG_CL_B(C::W_SUCC, i) = SSG_CL_B(C::W_SUCC, lower); SSG_CL_B(C::W_SUCC, lower) = (uint8_t)i; }
 		}
 	}
 	/* upstream mem_chain_weight, both passes in one walk */
 	for (unsigned c = head; c != SSG_CL_NONE; c = SSG_CL_B(C::W_SUCC, c)) {
-		const int n = (int)(lw[(C::W_CA + c) * 64] >> 24);
+		const int n = (int)(lw[(C::W_CA + c) * LN] >> 24);
 		int w1 = 0, w2 = 0, end1 = 0; int64_t end2 = 0; unsigned sid = c;
 		for (int j = 0; j < n; ++j) {
-			const uint32_t m = lw[(C::W_META + sid) * 64];
-			const int64_t srb = (int64_t)((uint64_t)lw[(C::W_RHI + sid) * 64] << 32 | lw[(C::W_RLO + sid) * 64]);
+			const uint32_t m = lw[(C::W_META + sid) * LN];
+			const int64_t srb = (int64_t)((uint64_t)lw[(C::W_RHI + sid) * LN] << 32 | lw[(C::W_RLO + sid) * LN]);
 			const int sq = (int)(m & 511), sl = (int)(m >> 9 & 511);
 			sid = SSG_CL_B(C::W_NEXT, sid);
 			if (sq >= end1) w1 += sl; else if (sq + sl > end1) w1 += sq + sl - end1;
@@ -337,17 +337,17 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 			end2 = end2 > srb + sl ? end2 : srb + sl;
 		}
 		const int w = w2 < w1 ? w2 : w1;
-		lw[(C::W_CB + c) * 64] |= (uint32_t)w;   /* a weight never exceeds the read length */
+		lw[(C::W_CB + c) * LN] |= (uint32_t)w;   /* a weight never exceeds the read length */
 	}
 	/* chains in position order with w >= min_chain_weight -> S[] */
 	int n_chn = 0;
 	for (unsigned c = head; c != SSG_CL_NONE; c = SSG_CL_B(C::W_SUCC, c)) {
-		const int w = (int)(lw[(C::W_CB + c) * 64] & 0xffff);
-		if (w >= opt.min_chain_weight) { lw[(C::W_RLO + n_chn) * 64] = (uint32_t)w << 8 | c; ++n_chn; }
+		const int w = (int)(lw[(C::W_CB + c) * LN] & 0xffff);
+		if (w >= opt.min_chain_weight) { lw[(C::W_RLO + n_chn) * LN] = (uint32_t)w << 8 | c; ++n_chn; }
 	}
 	int n_out = 0;
 	if (n_chn > 0) { /* upstream mem_chain_flt */
-		const ssg_cl_words_t S = { lw + C::W_RLO * 64 };
+		const ssg_cl_words_t<LN> S = { lw + C::W_RLO * LN };
 		ssg_introsort_ix(S, n_chn, ssg_cl_w_gt());
 		/* byte arrays in the words of CB (its weights live in S now): state of sorted chain i; the first chain kept chain k shadows */
 		constexpr int W_ST = C::W_CB, W_KF = C::W_CB + CAP / 4;
@@ -355,29 +355,29 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 		{	/* The chains that cannot `break' against the heaviest one by the weights alone break against none (w descends; both tests are monotone in w): a prefix [0, m) of
 			 * the list, all kept.  For these the quadratic loop below leaves behind: `first' of kept chain e = the first later chain that overlaps it; large_ovlp of chain e =
 			 * some earlier chain overlaps it -- two scans that stop at their first hit (in a repeat family everything overlaps everything). */
-			const int w0 = (int)(lw[(C::W_RLO + 0) * 64] >> 8);
+			const int w0 = (int)(lw[(C::W_RLO + 0) * LN] >> 8);
 			int m = 0;
 			for (; m < n_chn; ++m) {
-				const uint32_t me = lw[(C::W_RLO + m) * 64];
+				const uint32_t me = lw[(C::W_RLO + m) * LN];
 				const int wc = (int)(me >> 8);
 				if ((wc < w0 * opt.drop_ratio) & (w0 - wc >= opt.min_seed_len << 1)) break;
 				const unsigned id = me & 255;
-				const unsigned ls = lw[(C::W_CA + id) * 64] & 255;
-				const uint32_t ml = lw[(C::W_META + ls) * 64];
-				lw[(C::W_RHI + m) * 64] = (lw[(C::W_META + id) * 64] & 511) | ((ml & 511) + (ml >> 9 & 511)) << 9 | (uint32_t)wc << 18;
+				const unsigned ls = lw[(C::W_CA + id) * LN] & 255;
+				const uint32_t ml = lw[(C::W_META + ls) * LN];
+				lw[(C::W_RHI + m) * LN] = (lw[(C::W_META + id) * LN] & 511) | ((ml & 511) + (ml >> 9 & 511)) << 9 | (uint32_t)wc << 18;
 			}
 			for (int e = 0; e < m; ++e) {
-				const uint32_t pe = lw[(C::W_RHI + e) * 64];
+				const uint32_t pe = lw[(C::W_RHI + e) * LN];
 				const int ib = (int)(pe & 511), ie = (int)(pe >> 9 & 511);
 				int f = 0x7f, lo = 0;
 				for (int q = e + 1; q < m; ++q) {
-					const uint32_t pk = lw[(C::W_RHI + q) * 64];
+					const uint32_t pk = lw[(C::W_RHI + q) * LN];
 					const int jb = (int)(pk & 511), je = (int)(pk >> 9 & 511);
 					const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
 					if (e_min > b_max) { const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj; if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) { f = q; break; } }
 				}
 				for (int q = e - 1; q >= 0; --q) {
-					const uint32_t pk = lw[(C::W_RHI + q) * 64];
+					const uint32_t pk = lw[(C::W_RHI + q) * LN];
 					const int jb = (int)(pk & 511), je = (int)(pk >> 9 & 511);
 					const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
 					if (e_min > b_max) { const int li = ie - ib, lj = je - jb, min_l = li < lj ? li : lj; if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) { lo = 1; break; } }
@@ -387,14 +387,14 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 			nk = m;
 		}
 		for (i = nk; i < n_chn; ++i) {
-			const uint32_t me = lw[(C::W_RLO + i) * 64];
+			const uint32_t me = lw[(C::W_RLO + i) * LN];
 			const unsigned id = me & 255; const int wi = (int)(me >> 8);
-			const unsigned ls = lw[(C::W_CA + id) * 64] & 255;
-			const uint32_t ml = lw[(C::W_META + ls) * 64];
-			const int ib = (int)(lw[(C::W_META + id) * 64] & 511), ie = (int)(ml & 511) + (int)(ml >> 9 & 511);
+			const unsigned ls = lw[(C::W_CA + id) * LN] & 255;
+			const uint32_t ml = lw[(C::W_META + ls) * LN];
+			const int ib = (int)(lw[(C::W_META + id) * LN] & 511), ie = (int)(ml & 511) + (int)(ml >> 9 & 511);
 			int large_ovlp = 0;
 			for (k = 0; k < nk; ++k) {
-				const uint32_t pk = lw[(C::W_RHI + k) * 64];
+				const uint32_t pk = lw[(C::W_RHI + k) * LN];
 				const int jb = (int)(pk & 511), je = (int)(pk >> 9 & 511), wj = (int)(pk >> 18);
 				const int b_max = jb > ib ? jb : ib, e_min = je < ie ? je : ie;
 				if (e_min > b_max) {
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 				}
 			}
 			if (k == nk) {
-				lw[(C::W_RHI + nk) * 64] = (uint32_t)ib | (uint32_t)ie << 9 | (uint32_t)wi << 18;
+				lw[(C::W_RHI + nk) * LN] = (uint32_t)ib | (uint32_t)ie << 9 | (uint32_t)wi << 18;
 				SSG_CL_B(W_KF, nk) = 0x7f; ++nk;
 				SSG_CL_B(W_ST, i) = (uint8_t)(i == 0 ? 3 : large_ovlp ? 2 : 3);
 			} else SSG_CL_B(W_ST, i) = 0;
@@ -424,11 +424,11 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 		for (i = 0; i < n_chn; ++i) {
 			const int kk = SSG_CL_B(W_ST, i);
 			if (kk == 0) continue;
-			const uint32_t me = lw[(C::W_RLO + i) * 64];
+			const uint32_t me = lw[(C::W_RLO + i) * LN];
 			const unsigned id = me & 255;
-			const int n = (int)(lw[(C::W_CA + id) * 64] >> 24);
+			const int n = (int)(lw[(C::W_CA + id) * LN] >> 24);
 			ssg_chain_t c;
-			c.pos = seeds[s0 + id].rbeg; c.first_seed = (int)(s0 + pos); c.last_seed = -1; c.n = n; c.rid = (int)(lw[(C::W_META + id) * 64] >> 18);
+			c.pos = seeds[s0 + id].rbeg; c.first_seed = (int)(s0 + pos); c.last_seed = -1; c.n = n; c.rid = (int)(lw[(C::W_META + id) * LN] >> 18);
 			c.w = (int)(me >> 8); c.kept = kk; c.first = -1; c.left = c.right = -1; c.frac_rep = frac_rep; c._pad = 0; c.sec = 0;
 			chains[s0 + id] = c;
 			order[s0 + n_out++] = (int)id;

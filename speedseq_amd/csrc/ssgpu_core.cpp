@@ -801,11 +801,11 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 			const int b63 = use_lds ? std::min(n_reads, std::max(r0, gl[0])) : n_reads, b31 = std::min(n_reads, std::max(b63, gl[1])), b15 = std::min(n_reads, std::max(b31, gl[2]));
 			if (b63 > r0) SSG_LAUNCH_ON(2, ssg_k_chain, (b63 - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, b63, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 			                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
-#define SSG_CL_LAUNCH(CC, from, to) do { if ((to) > (from)) SSG_LAUNCH_ON(2, ssg_k_chain_lds<CC>, ((to) - (from) + 63) / 64, 64, 0, idx->v, *opt, (from), (to), d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, \
+#define SSG_CL_LAUNCH(CC, LN, from, to) do { if ((to) > (from)) SSG_LAUNCH_ON(2, (ssg_k_chain_lds<CC, LN>), ((to) - (from) + (LN) - 1) / (LN), (LN), 0, idx->v, *opt, (from), (to), d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, \
 			d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p); } while (0)
-			SSG_CL_LAUNCH(64, b63, b31);
-			SSG_CL_LAUNCH(32, b31, b15);
-			SSG_CL_LAUNCH(16, b15, n_reads);
+			if (env_int("SSG_CHAIN_LDS64_LANES", 32) == 32) SSG_CL_LAUNCH(64, 32, b63, b31); else SSG_CL_LAUNCH(64, 64, b63, b31);   /* 47 KB a workgroup instead of 94: fits beside the wave kernels' blocks */
+			SSG_CL_LAUNCH(32, 64, b31, b15);
+			SSG_CL_LAUNCH(16, 64, b15, n_reads);
 #undef SSG_CL_LAUNCH
 		}
 		/* position ranks of the heavy reads' seeds: one stable radix sort of (read, reference position) over all of them */
