@@ -773,7 +773,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		 * few) reads beyond 5120 seeds one lane each on their own stream.  The LDS kernels keep contig ids in 16 bits: an index with
 		 * more contigs chains every read in the lane kernel.  SSG_CHAIN_WAVE_BIG = n sends every wave-class read with more than n seeds
 		 * to the top class (tests); SSG_CHAIN_RANKED = 0 selects the array-shifting form of the insertion (A/B, tests). */
-		const int T = idx->v.n_ctg > 32767 ? 1 << 30 : std::max(1, env_int("SSG_CHAIN_WAVE_MIN", 64));
+		const int T = idx->v.n_ctg > 32767 ? 1 << 30 : std::max(1, env_int("SSG_CHAIN_WAVE_MIN", 48));
 		const int TB = env_int("SSG_CHAIN_WAVE_BIG", 0) > 0 ? env_int("SSG_CHAIN_WAVE_BIG", 0) : 1 << 30;
 		const bool ranked = env_int("SSG_CHAIN_RANKED", 1) != 0;
 		const int wsort = (env_int("SSG_CHAIN_WSORT", 1) ? 1 : 0) | (env_int("SSG_CHAIN_SPEC", 1) ? 2 : 0) | (env_int("SSG_CHAIN_BFLT", 1) ? 4 : 0);   /* the wave kernels' weight sort by the whole wave (k_chainw.h wv_introsort_whi) insertion 64 seeds a round and filter 64 chains a round; 0: by one lane / seed by seed / chain by chain (A/B, tests) */
