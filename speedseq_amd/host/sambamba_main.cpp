@@ -283,6 +283,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		for (;;) {
 			const size_t g = next_grp.fetch_add(1);
 			if (g >= ng) break;
+			if (done[g].load(std::memory_order_acquire)) continue;   /* (made on the device before it failed: see the writer's fall-back) */
 			if (g >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g >= next_write.load(std::memory_order_acquire) + window) nap(200); my_w += (long)((wall() - t0) * 1e6); }
 			std::vector<uint8_t> ob; ob.reserve(GRP * (lvl ? 24576 : 65536));
 			std::vector<uint32_t> bsz;
@@ -304,6 +305,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	 * CRC, ISIZE) -- and hand the groups to the same in-order writer.  The host's cores, which the deflate of a whole genome's records kept busy
 	 * for longer than the alignment took, only copy and checksum. */
 	std::atomic<int> dev_failed(0);
+	std::atomic<long> dev_batches(0); const long fail_after = getenv("SSG_BGZF_FAIL_AFTER") ? atol(getenv("SSG_BGZF_FAIL_AFTER")) : -1;   /* tests: the device "fails" from its n-th batch on */
 	auto producer = [&](int t) {
 		if (ssg_set_device(t % n_devs) || ssg_set_lane(1 + (t / n_devs) % 3)) { dev_failed = 1; return; }
 		const int gth = std::max(1, threads / std::max(1, n_prod));
@@ -312,14 +314,16 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		long my_g = 0, my_d = 0, my_w = 0;
 		for (size_t b0 = (size_t)t * DEV_BATCH; b0 < nb && P && O && !dev_failed.load(); b0 += (size_t)n_prod * DEV_BATCH) {
 			const size_t b1 = std::min(nb, b0 + DEV_BATCH), n_b = b1 - b0, g0 = b0 / GRP, g1 = (b1 + GRP - 1) / GRP;
-			if (g0 >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g0 >= next_write.load(std::memory_order_acquire) + window) nap(200); my_w += (long)((wall() - t0) * 1e6); }
+			if (g0 >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g0 >= next_write.load(std::memory_order_acquire) + window && !dev_failed.load()) nap(200); my_w += (long)((wall() - t0) * 1e6); }
+			if (dev_failed.load()) break;   /* (the writer is waiting for the producers to stop before it hands the rest to the host's pool) */
 			const double t0 = wall();
 			for (size_t k = 0; k <= n_b; ++k) rel[k] = cut[b0 + k] - cut[b0];
 			parallel_for((int)std::min<size_t>((size_t)gth, n_b / 8 + 1), n_b, [&](size_t a, size_t e, int) {
 				for (size_t k = a; k < e; ++k) { const size_t w = gather_block(b0 + k, P + rel[k]); crc[k] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), P + rel[k], (uInt)w); }
 			});
 			const double t1 = wall();
-			if (ssg_bgzf_deflate(P, rel.data(), (long)n_b, O, (uint64_t)DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64, off.data())) { fprintf(stderr, "[sambamba] sort: BGZF deflate on the device failed: %s\n", ssg_last_error()); dev_failed = 1; break; }
+			if ((fail_after >= 0 && dev_batches.fetch_add(1) >= fail_after) || ssg_bgzf_deflate(P, rel.data(), (long)n_b, O, (uint64_t)DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64, off.data())) {
+				fprintf(stderr, "[sambamba] sort: BGZF deflate on the device failed: %s\n", fail_after >= 0 ? "(SSG_BGZF_FAIL_AFTER: test)" : ssg_last_error()); dev_failed = 1; break; }
 			const double t2 = wall();
 			parallel_for((int)std::min<size_t>((size_t)std::min(gth, 8), g1 - g0), g1 - g0, [&](size_t a, size_t e, int) {
 				static const uint8_t hdr[16] = { 0x1f,0x8b,0x08,0x04,0,0,0,0,0,0xff,0x06,0,0x42,0x43,0x02,0 };
@@ -381,9 +385,23 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	for (int t = 0; t < n_workers; ++t) th.emplace_back(worker);
 	for (int t = 0; t < n_prod; ++t) th.emplace_back(producer, t);
 	uint64_t coff = (uint64_t)(hdr_end > 0 ? hdr_end : 0);
+	bool fell_back = false;
 	double t_wr_wait = 0, t_wr_io = 0; const double tw_spawn = wall();
 	for (size_t g = 0; g < ng; ++g) {
-		if (!done[g].load(std::memory_order_acquire)) { const double t0 = wall(); while (!done[g].load(std::memory_order_acquire)) { if (dev_failed.load()) die("sort: cannot compress the output on the device (SSG_BGZF_DEVICE=0 uses the host)"); nap(50); } t_wr_wait += wall() - t0; }
+		if (!done[g].load(std::memory_order_acquire)) {
+			const double t0 = wall();
+			while (!done[g].load(std::memory_order_acquire)) {
+				if (dev_failed.load() && !fell_back) {   /* a device that cannot be set up, runs out of memory or loses a kernel does not end the sort: the producers stop, the host's pool (zlib, as SSG_BGZF_DEVICE=0) makes the groups that are not there yet */
+					for (auto &x : th) x.join();
+					th.clear(); fell_back = true;
+					fprintf(stderr, "[sambamba] sort: compressing the rest of the output on the host (zlib level %d)\n", lvl);
+					const int nw = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));
+					for (int t = 0; t < nw; ++t) th.emplace_back(worker);
+				}
+				nap(50);
+			}
+			t_wr_wait += wall() - t0;
+		}
 		std::vector<uint8_t> ob; std::vector<uint32_t> bsz; ob.swap(grp[g].bytes); bsz.swap(grp[g].bsz);
 		{ const double t0 = wall(); io_write_all(fd, ob.data(), ob.size()); t_wr_io += wall() - t0; }
 		if (want_off) for (size_t k = 0; k < bsz.size(); ++k) { blk_coff[g * GRP + k] = coff; coff += bsz[k]; }

@@ -175,6 +175,29 @@ def test_sambamba_emu_device_deflate_on_several_devices(tmp_path, emu_lib, monke
     assert _parse_bai(d + "/mine.bai") == _parse_bai(d + "/s.bam.bai")
 
 
+@pytest.mark.parametrize("fail_after", ["0", "3"])
+def test_sambamba_emu_device_deflate_failure_falls_back_to_the_host(tmp_path, emu_lib, monkeypatch, fail_after):
+    """a device that fails while the sorted file is being written (before its first batch, or after two) does not end the sort: the producers stop and the
+    host's pool compresses the groups that are not there yet; samtools reads the same records in the same order, and the index the sort wrote is the file's"""
+    monkeypatch.setenv("SSG_BGZF_DEVICE", "1")
+    monkeypatch.setenv("SSG_EMU_DEVICES", "2")
+    monkeypatch.setenv("SSG_SORT_DEV_BATCH", "16")
+    monkeypatch.setenv("SSG_BGZF_FAIL_AFTER", fail_after)
+    d = str(tmp_path)
+    sam = _sam(tmp_path, 20000, seed=37)   # ~100 blocks: seven batches of 16
+    sambamba = os.path.join(ROOT, "tests", "emu", "sambamba_emu")
+    with open(sam, "rb") as fi, open(d + "/u.bam", "wb") as fo:
+        subprocess.run([sambamba, "view", "-S", "-f", "bam", "-l", "0", "/dev/stdin"], stdin=fi, stdout=fo, check=True)
+    r = subprocess.run([sambamba, "sort", "-t", "4", "-m", "1G", "--tmpdir=" + d + "/tmp", "-o", d + "/s.bam", d + "/u.bam"], check=True, capture_output=True, text=True, timeout=300)
+    assert "compressing the rest of the output on the host" in r.stderr, r.stderr[-500:]
+    subprocess.run([SAMTOOLS, "view", "-b", "-u", "-o", d + "/ref_u.bam", sam], check=True)
+    subprocess.run([SAMTOOLS, "sort", "-o", d + "/ref_s.bam", d + "/ref_u.bam"], check=True)
+    assert _view(d + "/s.bam") == _view(d + "/ref_s.bam")
+    os.rename(d + "/s.bam.bai", d + "/mine.bai")
+    subprocess.run([SAMTOOLS, "index", d + "/s.bam"], check=True)
+    assert _parse_bai(d + "/mine.bai") == _parse_bai(d + "/s.bam.bai")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_deflate", ["1", "0"])
 def test_sambamba_gpu_matches_samtools(tmp_path, gpu_lib, monkeypatch, device_deflate):
