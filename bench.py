@@ -714,6 +714,8 @@ def main():
             # algorithmic bytes are upstream's own count of bwt_extend calls x 2 rank blocks, whoever ran them.  The largest SINGLE kernel by
             # time is named in `largest_kernel`: when that is the mate-rescue Smith-Waterman, an on-chip integer DP, neither an HBM nor an MFMA
             # roofline applies to it and its figure of merit is the VALU issue fraction in `sw`.
+            if "ssg_k_ext_lane_dyn<4>" in kern:   # the extension kernel with per-class LDS (all classes above 72 columns in one name)
+                alg_bytes["ssg_k_ext_lane_dyn<4>"] = alg_bytes.pop("ssg_k_ext_lane<136>")
             seed_k = sorted(k for k in kern if k.startswith(("ssg_k_smem2", "ssg_k_smem_heavy", "ssg_k_smem_quad", "ssg_k_smem_lane")))
             smk = " + ".join(seed_k) if seed_k else None
             seed_ms = sum(kern[k][0] for k in seed_k) / a.steps if seed_k else 0.0

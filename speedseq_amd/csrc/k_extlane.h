@@ -242,13 +242,12 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 
 /* side 0: left extensions (query and reference walked backwards from the seed); side 1: right extensions.
  * sorted[t] = (511 - side length) << 32 | job id; QCAP+1 columns of LDS per lane. */
-template <int QCAP>
-__global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int side, long job_first, long n_jobs, const uint64_t *sorted,
-                               const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
-                               unsigned long long *cells)
+/* one job of one side; L: the workgroup's (qcap + 2 U) x 64 words of LDS */
+template <int U>
+SSG_DEVFN void ssg_ext_lane_job(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const int side, const long job_first, const long n_jobs, const uint64_t *sorted,
+                                const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
+                                unsigned long long *cells, uint32_t *L, const int qcap)
 {
-	constexpr int U = QCAP > 72 ? 4 : 2;
-	__shared__ uint32_t L[(QCAP + 2 * U) * 64];   /* columns 0..qlen, and the 2U - 1 the cell loop may read ahead */
 	const long t = job_first + (long)blockIdx.x * 64 + threadIdx.x;
 	if (t >= n_jobs) return;
 	const uint64_t key = sorted[t];
@@ -263,7 +262,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 	int aw = opt.w, score = -1;
 	if (side == 0) {
 		const int qlen = jb.qbeg;
-		if (qlen <= 0 || qlen > QCAP) return;
+		if (qlen <= 0 || qlen > qcap) return;
 		for (int j = 0; j < qlen; ++j) Lc[j * 64] = SSG_XL_QWORD(query[jb.qbeg - 1 - j]);
 		Lc[qlen * 64] = 0;
 		const int tlen = (int)(jb.rbeg - jb.rmax0);
@@ -278,7 +277,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 		res_l[g] = o;
 	} else {
 		const int qe = jb.qbeg + jb.len, qlen = jb.l_query - qe;
-		if (qlen <= 0 || qlen > QCAP) return;
+		if (qlen <= 0 || qlen > qcap) return;
 		const int sc0 = jb.qbeg ? res_l[g].score : jb.len * opt.a;
 		for (int j = 0; j < qlen; ++j) Lc[j * 64] = SSG_XL_QWORD(query[qe + j]);
 		Lc[qlen * 64] = 0;
@@ -295,5 +294,44 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_me
 		res_r[g] = o;
 	}
 	if (cells && nc) atomicAdd(cells, nc);
+}
+
+template <int QCAP>
+__global__ void __launch_bounds__(64) ssg_k_ext_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, int side, long job_first, long n_jobs, const uint64_t *sorted,
+                               const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
+                               unsigned long long *cells)
+{
+	constexpr int U = QCAP > 72 ? 4 : 2;
+	__shared__ uint32_t L[(QCAP + 2 * U) * 64];   /* columns 0..qlen, and the 2U - 1 the cell loop may read ahead */
+	ssg_ext_lane_job<U>(ix, opt, side, job_first, n_jobs, sorted, jobs, seq, read_off, res_l, res_r, cells, L, QCAP);
+}
+
+/* The same with as much LDS as the launch asks for ((qcap + 2 U) x 256 bytes): the host cuts the sorted job list into classes of 8 more columns each, so that a wave
+ * holds what its longest side needs -- 73..80 columns: 22 KB, seven waves a CU; 129..136: 37 KB, four (what the fixed class above gives every side beyond 72); a side
+ * of 100 of a 250-base read: 28 KB instead of the 68 KB of the 256-column class (two waves a CU). */
+template <int U>
+__global__ void __launch_bounds__(64) ssg_k_ext_lane_dyn(ssg_index_view_t ix, ssg_mem_opt_t opt, int side, long job_first, long n_jobs, const uint64_t *sorted,
+                               const ssg_xjob_t *jobs, const uint8_t *seq, const int64_t *read_off, ssg_xres_t *res_l, ssg_xres_t *res_r,
+                               unsigned long long *cells, int qcap)
+{
+#ifdef SSG_EMU
+	uint32_t *L = (uint32_t*)emu::dyn_lds;
+#else
+	extern __shared__ uint32_t ssg_xl_lds[];
+	uint32_t *L = ssg_xl_lds;
+#endif
+	ssg_ext_lane_job<U>(ix, opt, side, job_first, n_jobs, sorted, jobs, seq, read_off, res_l, res_r, cells, L, qcap);
+}
+
+/* out[j] = number of keys whose high word is below t[j], in a list sorted ascending by it (= sides longer than 511 - t[j]): a binary search per threshold */
+struct ssg_thr64_t { int n; int t[63]; };
+__global__ void ssg_k_sorted_hi_below(const uint64_t *sorted, long n, ssg_thr64_t th, unsigned int *out)
+{
+	const int j = (int)threadIdx.x;
+	if (j >= th.n) return;
+	const uint64_t t = (uint64_t)th.t[j];
+	long lo = 0, hi = n;
+	while (lo < hi) { const long mid = (lo + hi) >> 1; if ((sorted[mid] >> 32) < t) lo = mid + 1; else hi = mid; }
+	out[j] = (unsigned int)lo;
 }
 #endif

@@ -869,6 +869,44 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		unsigned int h_nlong[2];
 		CHK(d_nlong.down(h_nlong, 2));
 		if (ssg_debug()) fprintf(stderr, "[ssgpu] ext jobs %ld, long sides %u / %u\n", n_jobs, h_nlong[0], h_nlong[1]);
+		/* Classes of 8 more columns each, a launch per class with the LDS its longest side needs (k_extlane.h ssg_k_ext_lane_dyn): the list is sorted longest side first, the
+		 * class boundaries are binary searches; a side's classes go round three queues (no tail of one launch before the next starts, and a CU holds a mix of block sizes),
+		 * the right sides after all left ones (they start from the left side's score).  SSG_EXT_DYN=0: the fixed classes below. */
+		const bool ext_dyn = env_int("SSG_EXT_DYN", 1) != 0;
+		if (ext_dyn) {
+			ssg_thr64_t th; int caps[64], ncap = 0;
+			caps[ncap++] = 40; caps[ncap++] = 72;
+			for (int c = 80; c < max_len + 8 && c <= 320; c += 8) caps[ncap++] = c;
+			th.n = ncap + 1;
+			for (int k = 0; k < ncap; ++k) th.t[k] = 511 - caps[k];   /* #sides longer than caps[k] */
+			th.t[ncap] = 511;                                        /* #sides longer than 0 */
+			dbuf<unsigned int> d_b(128); unsigned int hb[2][64];
+			CHKA(d_b);
+			SSG_LAUNCH(ssg_k_sorted_hi_below, 1, 64, 0, d_sl.p, n_jobs, th, d_b.p);
+			SSG_LAUNCH(ssg_k_sorted_hi_below, 1, 64, 0, d_sr.p, n_jobs, th, d_b.p + 64);
+			CHK(d_b.down(&hb[0][0], 128));
+#ifndef SSG_EMU
+			if (max_len > 240) {   /* blocks above 64 KB */
+				static bool attr_set[SSG_MAX_DEV] = { false };
+				if (!attr_set[ssg_cur_dev]) { (void)hipFuncSetAttribute((const void*)ssg_k_ext_lane_dyn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (320 + 8) * 256); attr_set[ssg_cur_dev] = true; }
+			}
+#endif
+			for (int side = 0; side < 2; ++side) {
+				const uint64_t *srt = side ? d_sr.p : d_sl.p;
+				ssg_fork(2);
+				for (int k = ncap - 1, q = 0; k >= 0; --k) {   /* longest class first */
+					const long from = (long)hb[side][k], to = (long)hb[side][k == 0 ? ncap : k - 1];
+					if (to <= from) continue;
+					const int c = caps[k], U = c > 72 ? 4 : 2; const size_t lds = (size_t)(c + 2 * U) * 256;
+#define SSG_XL_GO(LAUNCH, ...) do { if (U == 4) LAUNCH(__VA_ARGS__ ssg_k_ext_lane_dyn<4>, (to - from + 63) / 64, 64, lds, idx->v, *opt, side, from, to, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p, c); \
+                                    else LAUNCH(__VA_ARGS__ ssg_k_ext_lane_dyn<2>, (to - from + 63) / 64, 64, lds, idx->v, *opt, side, from, to, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p, c); } while (0)
+					if (q % 3 == 0) SSG_XL_GO(SSG_LAUNCH); else if (q % 3 == 1) SSG_XL_GO(SSG_LAUNCH_ON, 0,); else SSG_XL_GO(SSG_LAUNCH_ON, 1,);
+#undef SSG_XL_GO
+					++q;
+				}
+				ssg_join(2);
+			}
+		} else
 		for (int side = 0; side < 2; ++side) {
 			const uint64_t *srt = side ? d_sr.p : d_sl.p;
 			const long nl = (long)h_nlong[side];   /* jobs are sorted longest side first */

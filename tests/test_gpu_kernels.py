@@ -159,6 +159,14 @@ def test_gpu_chain_filter_options(gpu_lib, oracle, repeat_mid_prefix, monkeypatc
             assert common.check_align1(gpu_lib, oracle, 600, seed=40 + k, read_len=(150, 250)[k & 1], prefix=repeat_mid_prefix, chain_opt=co) > 0
 
 
+def test_gpu_extension_column_classes(gpu_lib, oracle, monkeypatch):
+    # the lane-per-extension kernel with the LDS its class's longest side needs (classes of 8 columns, three queues), then the fixed classes (72 / 136 / 256 / 320 columns)
+    for dyn in ("1", "0"):
+        monkeypatch.setenv("SSG_EXT_DYN", dyn)
+        for k, rl in enumerate((150, 250, 300, 101)):
+            assert common.check_align1(gpu_lib, oracle, 1500, seed=50 + k, read_len=rl) > 1500
+
+
 def test_gpu_light_reads_chain_lds(gpu_lib, oracle, repeat_mid_prefix, monkeypatch):
     # reads with 10..63 seeds in small repeat families: the three classes of ssg_k_chain_lds (state in the lane's LDS), then the same reads through ssg_k_chain
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "64")

@@ -133,6 +133,14 @@ def test_emu_chain_filter_options(emu_lib, oracle, repeat_mid_prefix, monkeypatc
             assert common.check_align1(emu_lib, oracle, 60, seed=40 + k, read_len=(150, 250)[k & 1], prefix=repeat_mid_prefix, chain_opt=co) > 0
 
 
+def test_emu_extension_column_classes(emu_lib, oracle, monkeypatch):
+    # the lane-per-extension kernel with the LDS its class's longest side needs (classes of 8 columns, three queues), then the fixed classes (72 / 136 / 256 / 320 columns)
+    for dyn in ("1", "0"):
+        monkeypatch.setenv("SSG_EXT_DYN", dyn)
+        for k, rl in enumerate((150, 250, 300, 101)):
+            assert common.check_align1(emu_lib, oracle, 40, seed=50 + k, read_len=rl) > 40
+
+
 def test_emu_light_reads_chain_lds(emu_lib, oracle, repeat_mid_prefix, monkeypatch):
     # reads with 10..63 seeds in small repeat families: the three classes of ssg_k_chain_lds (state in the lane's LDS), then the same reads through ssg_k_chain
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "64")
