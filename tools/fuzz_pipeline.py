@@ -3,7 +3,7 @@
 text hand-off against the fused one, every switch of the host side drawn at random per run (emulated devices, calls in flight, formatter
 threads, frame segments on / off, gzip decoding threads, parse threads and their slab / piece sizes, the moment of the suffix-array
 densification, sort spills and their genome ranges, samblaster's options).  The sorted BAM's record bytes and both side streams must be
-equal.  usage: tools/fuzz_pipeline.py [runs]"""
+equal.  usage: tools/fuzz_pipeline.py [runs [BINDIR]]   (BINDIR: the product's executables bwa / samblaster / sambamba, e.g. bin/ on a GPU box; default the emulation build)"""
 import gzip
 import os
 import random
@@ -32,10 +32,11 @@ def recs(bam):
     return raw[o:]
 
 
-def main():
-    runs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+def main(runs=None, bindir=None, first_seed=0):
+    runs = 8 if runs is None else runs
+    exe = (lambda n: os.path.join(bindir, n)) if bindir else (lambda n: os.path.join(EMU, n + "_emu"))
     bad = 0
-    for seed in range(runs):
+    for seed in range(first_seed, first_seed + runs):
         rng = random.Random(seed)
         with tempfile.TemporaryDirectory() as d:
             fq = os.path.join(d, "r.fq.gz")
@@ -52,11 +53,11 @@ def main():
                 if mode == "fused":
                     env["SSG_FUSED"] = "1"
                 spl, disc = os.path.join(d, mode + ".spl"), os.path.join(d, mode + ".disc")
-                p1 = subprocess.run([EMU + "/bwa_emu", "mem", "-t", "2", "-p", "-R", "@RG\\tID:g\\tSM:s\\tLB:l", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=300)
-                p2 = subprocess.run([EMU + "/samblaster_emu"] + opts + ["--splitterFile", spl, "--discordantFile", disc], input=p1.stdout, capture_output=True, env=env, timeout=300)
-                p3 = subprocess.run([EMU + "/sambamba_emu", "view", "-S", "-f", "bam", "-l", "0", "/dev/stdin"], input=p2.stdout, capture_output=True, env=env, timeout=300)
+                p1 = subprocess.run([exe("bwa"), "mem", "-t", "2", "-p", "-R", "@RG\\tID:g\\tSM:s\\tLB:l", EXAMPLE_FA, fq], capture_output=True, env=env, timeout=300)
+                p2 = subprocess.run([exe("samblaster")] + opts + ["--splitterFile", spl, "--discordantFile", disc], input=p1.stdout, capture_output=True, env=env, timeout=300)
+                p3 = subprocess.run([exe("sambamba"), "view", "-S", "-f", "bam", "-l", "0", "/dev/stdin"], input=p2.stdout, capture_output=True, env=env, timeout=300)
                 env2 = dict(env, SSG_SORT_CHUNK_BYTES=str(rng.choice([100000, 10 ** 9])), SSG_SORT_RANGES=str(rng.choice([1, 5, 40])))
-                p4 = subprocess.run([EMU + "/sambamba_emu", "sort", "-t", "3", "-m", "1G", "--tmpdir", os.path.join(d, mode + "tmp"), "-o", os.path.join(d, mode + ".bam"), "/dev/stdin"],
+                p4 = subprocess.run([exe("sambamba"), "sort", "-t", "3", "-m", "1G", "--tmpdir", os.path.join(d, mode + "tmp"), "-o", os.path.join(d, mode + ".bam"), "/dev/stdin"],
                                     input=p3.stdout, capture_output=True, env=env2, timeout=300)
                 if any(p.returncode for p in (p1, p2, p3, p4)):
                     bad += 1
@@ -75,4 +76,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else None, sys.argv[2] if len(sys.argv) > 2 else None))
