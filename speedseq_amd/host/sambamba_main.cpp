@@ -770,9 +770,51 @@ static int cmd_sort(int argc, char **argv)
 		merge_runs(all, G, h, ofd, level, pool, budget, 0, g_lo, g_hi, &hdr_end, (outp + ".ssg_ent").c_str());
 		close(ofd);
 		{ char t[64]; snprintf(t, sizeof(t), "%llu\n", (unsigned long long)hdr_end); if (!rk_file_put(outp + ".ssg_part", t, strlen(t))) die("sort: cannot write " + outp + ".ssg_part"); }
-		/* the runs may go when every rank has read what it needed of them */
-		if (!rk_file_put(rdv + "/merged." + std::to_string(rank), "", 0)) die("sort: cannot write into " + rdv);
+		/* the runs may go when every rank has read what it needed of them; the marker says how long this rank's part is and where its header blocks end */
+		struct stat psb; if (stat(outp.c_str(), &psb) != 0) die("sort: cannot stat " + outp);
+		{ char t[96]; snprintf(t, sizeof(t), "%llu %llu\n", (unsigned long long)psb.st_size, (unsigned long long)hdr_end); if (!rk_file_put(rdv + "/merged." + std::to_string(rank), t, strlen(t))) die("sort: cannot write into " + rdv); }
 		for (int r = 0; r < world; ++r) if (!rk_file_wait(rdv + "/merged." + std::to_string(r))) die("sort: rank " + std::to_string(r) + " did not finish its merge");
+		/* Every rank places its own stretch in the joined file (PREFIX.bam for a part named PREFIX.rank<r>.bam) at the offset the parts before it leave -- the
+		 * stretches' lengths are only known now, so this is a copy, but N of them side by side instead of one by the launcher after the last rank has ended
+		 * (the one term of the ranks' wall time that grew with the input and did not divide by N).  Part 0 goes with its header blocks, the others without; the
+		 * last rank adds the end-of-file block; bin/speedseq-ranks finds joined.<r> of every rank and only indexes.  SSG_RANKS_JOIN=0 leaves the copy to it. */
+		const std::string tail = ".rank" + std::to_string(rank) + ".bam";
+		if (!(getenv("SSG_RANKS_JOIN") && !strcmp(getenv("SSG_RANKS_JOIN"), "0")) && outp.size() > tail.size() && outp.compare(outp.size() - tail.size(), tail.size(), tail) == 0) {
+			const double tj = wall();
+			uint64_t at = 0, my_from = 0, my_len = 0; bool ok = true;
+			for (int r = 0; r < world && ok; ++r) {
+				std::vector<uint8_t> b; unsigned long long sz = 0, he = 0;
+				if (!rk_file_get(rdv + "/merged." + std::to_string(r), b)) { ok = false; break; }
+				b.push_back(0);
+				if (sscanf((const char*)b.data(), "%llu %llu", &sz, &he) != 2 || sz < 28 + he) { ok = false; break; }
+				const uint64_t from = r ? he : 0, len = sz - 28 - from;
+				if (r == rank) { my_from = from; my_len = len; break; }
+				at += len;
+			}
+			const std::string joined = outp.substr(0, outp.size() - tail.size()) + ".bam";
+			int jfd = ok ? open(joined.c_str(), O_WRONLY | O_CREAT, 0644) : -1, pfd = ok ? open(outp.c_str(), O_RDONLY) : -1;
+			if (jfd >= 0 && pfd >= 0) {
+				std::vector<uint8_t> buf;
+				uint64_t done_b = 0;
+				while (done_b < my_len && ok) {
+					off64_t oi = (off64_t)(my_from + done_b), oo = (off64_t)(at + done_b);
+					ssize_t k = copy_file_range(pfd, &oi, jfd, &oo, (size_t)std::min<uint64_t>(my_len - done_b, (uint64_t)1 << 30), 0);
+					if (k <= 0) {   /* a file system that cannot: through a buffer */
+						if (buf.empty()) buf.resize((size_t)8 << 20);
+						k = pread(pfd, buf.data(), (size_t)std::min<uint64_t>(my_len - done_b, buf.size()), (off_t)(my_from + done_b));
+						if (k <= 0) { ok = false; break; }
+						for (ssize_t w = 0; w < k; ) { const ssize_t x = pwrite(jfd, buf.data() + w, (size_t)(k - w), (off_t)(at + done_b + (uint64_t)w)); if (x <= 0) { ok = false; break; } w += x; }
+					}
+					done_b += (uint64_t)k;
+				}
+				if (ok && rank == world - 1 && pwrite(jfd, BGZF_EOF, 28, (off_t)(at + my_len)) != 28) ok = false;
+			} else ok = false;
+			if (jfd >= 0 && close(jfd) != 0) ok = false;
+			if (pfd >= 0) close(pfd);
+			if (!ok) die("sort: cannot place this rank's stretch in " + joined);
+			if (!rk_file_put(rdv + "/joined." + std::to_string(rank), "", 0)) die("sort: cannot write into " + rdv);
+			if (dbg()) fprintf(stderr, "[sambamba] sort: rank %d placed its stretch (%.2f GB) at byte %llu of %s in %.2f s\n", rank, (double)my_len / 1e9, (unsigned long long)at, joined.c_str(), wall() - tj);
+		}
 		for (run_t &R : all) { close(R.fd); close(R.ord_fd); }
 		for (run_t &R : runs) { close(R.fd); unlink(R.path.c_str()); unlink((R.path + ".ord").c_str()); unlink((R.path + ".idx").c_str()); }
 		if (dbg()) fprintf(stderr, "[sambamba] sort: rank %d of %d: input %.2f s (from start), %zu run(s) of its own, ranges %zu .. %zu of %zu from %zu runs of all ranks: %.2f s\n", rank, world, t_in - t_start, runs.size(), g_lo, g_hi, G, all.size(), wall() - t_x);

@@ -83,6 +83,7 @@ def _ranks_equal_one(tmp_path, world, extra, chunk, exe, n_pairs, **kw):
     r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(world), "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", many, "-M", "3", "-t", "2"] + tail + [ref, fq] + ([fq2] if two else []),
                        cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "stretches placed by the ranks" in r.stderr, r.stderr[-500:]   # every sort put its stretch into the one file itself (sambamba_main.cpp), the launcher only indexed
     for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
         assert _view(many + suffix) == _view(one + suffix), suffix
         assert _records(many + suffix) == _records(one + suffix), suffix
