@@ -950,7 +950,7 @@ def main():
                                    env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if emu else None)
                     r.pop("out", None)
                     r["devices"] = world
-                    r["what"] = "bin/speedseq-ranks -n %d: the reference's script (unmodified) once per device, `bwa mem` aligning the upstream batches of its rank, ONE duplicate set and both side streams in rank 0's samblaster, the sorts exchanging sorted runs and writing a stretch of the genome each; FASTQ -> the same three sorted BAMs + BAI" % world
+                    r["what"] = "bin/speedseq-ranks -n %d: the reference's script (unmodified) once per device, `bwa mem` aligning the upstream batches of its rank, the duplicate set sharded over the ranks' samblasters by signature (first seen wins in input order), both side streams in rank 0's, the sorts exchanging sorted runs and each placing its stretch of the genome in the one file; FASTQ -> the same three sorted BAMs + BAI" % world
                     out["literal_ranks"] = r
                     log('script as %d ranks: %s pairs in %s s' % (world, r.get('pairs'), r.get('wall_s')))
             except Exception as e:

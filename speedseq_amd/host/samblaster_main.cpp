@@ -128,10 +128,33 @@ static bool bam_has_tag(const bam_view_t &v, char a, char b)
 	return false;
 }
 
-/* Rank mode (ranks.h): rank 0's samblaster owns the duplicate set and both side streams.  Every rank -- rank 0 too -- is a client: per batch
- * it sends the primary ends of its blocks and waits for the verdicts, later it sends the batch's side-stream lines.  The server decides the
- * batches in input order b = 0, 1, 2, ... (batch b comes from rank b mod N), which is the order one samblaster would have seen them in, and
- * writes the side-stream lines in that order too. */
+/* Rank mode (ranks.h): the duplicate set is SHARDED over the ranks by signature -- every rank's samblaster serves the slice of the table whose signatures
+ * hash to it (its own table in its own GPU's HBM), and every rank is a client of all of them: per batch it sends each server the primary ends of the
+ * pairs that server owns (an empty slice too: the servers advance batch by batch) and puts the verdicts that come back into pair order; later it sends
+ * the batch's side-stream lines to rank 0's server, which owns both side streams.  Every server decides the batches in input order b = 0, 1, 2, ...
+ * (batch b comes from rank b mod N): equal signatures always meet in the same server, in the order one samblaster would have seen them in -- first seen
+ * wins over all ranks exactly as in one pipeline, with N tables deciding side by side instead of rank 0's alone (SSG_RANKS_SHARD=0: everything to rank 0). */
+static inline uint64_t sbl_mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+/* which server owns a pair: a function of its 5'-unclipped signature (the fields csrc/k_misc.h ssg_k_sig keys the table on: upstream samblaster's) and nothing else */
+static inline uint64_t sbl_route(const ssg_sbl_end_t *e, uint64_t p)
+{
+	uint64_t k[2][3]; int m[2];
+	for (int i = 0; i < 2; ++i) {
+		const ssg_sbl_end_t &x = e[i];
+		m[i] = !(x.flag & 0x4) && x.seq >= 0;
+		const uint64_t strand = (x.flag & 0x10) ? 1 : 0;
+		const int64_t q = strand ? (int64_t)x.pos + x.ralen - 1 + x.rclip : (int64_t)x.pos - x.lclip;
+		k[i][0] = (uint64_t)(uint32_t)x.seq; k[i][1] = (uint64_t)(q + (1LL << 31)); k[i][2] = strand;
+	}
+	uint64_t k0, k1, k2;
+	if (m[0] && m[1]) {
+		const bool swap = k[0][0] > k[1][0] || (k[0][0] == k[1][0] && (k[0][1] > k[1][1] || (k[0][1] == k[1][1] && k[0][2] > k[1][2])));
+		const uint64_t *lo = swap ? k[1] : k[0], *hi = swap ? k[0] : k[1];
+		k0 = lo[0] << 32 | hi[0]; k1 = lo[1] << 1 | lo[2]; k2 = hi[1] << 1 | hi[2];
+	} else if (m[0] || m[1]) { const uint64_t *a = m[0] ? k[0] : k[1]; k0 = a[0]; k1 = a[1] << 1 | a[2]; k2 = 0; }
+	else return p;   /* never a duplicate: anywhere */
+	return sbl_mix64(k0 ^ sbl_mix64(k1 ^ sbl_mix64(k2))) >> 7;
+}
 struct sbl_server_t {
 	int world, lfd; ssg_sbl_state_t *st; out_t *spl, *disc;
 	std::vector<int> cfd; std::vector<std::thread> readers; std::thread decider;
@@ -217,13 +240,18 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
 	int threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
 	{ const char *e = getenv("SSG_SBL_THREADS"); if (e && atoi(e) > 0) threads = atoi(e); }
-	std::unique_ptr<sbl_server_t> srv; int cfd = -1; std::mutex c_mu;   /* rank mode: the server (rank 0) and this rank's connection to it */
+	std::unique_ptr<sbl_server_t> srv; std::vector<int> cfds; std::mutex c_mu;   /* rank mode: this rank's slice of the duplicate set (rank 0's: the side streams too) and its connections to every rank's */
+	const bool shard = !(getenv("SSG_RANKS_SHARD") && !strcmp(getenv("SSG_RANKS_SHARD"), "0"));
 	if (world > 1) {
-		const std::string sock = rk_dir() + "/sbl.sock";
-		if (rank == 0) { srv.reset(new sbl_server_t(world, st, spl, disc)); if (!srv->start(sock)) return 1; }
-		cfd = rk_connect(sock);
-		if (cfd < 0 || !rk_send(cfd, 0, rank, 0, 0, 0)) { fprintf(stderr, "[samblaster] rank mode: cannot reach rank 0's samblaster\n"); return 1; }
+		srv.reset(new sbl_server_t(world, st, rank == 0 ? spl : 0, rank == 0 ? disc : 0));
+		if (!srv->start(rk_dir() + "/sbl." + std::to_string(rank) + ".sock")) return 1;
+		cfds.assign((size_t)world, -1);
+		for (int q = 0; q < world; ++q) {
+			cfds[(size_t)q] = rk_connect(rk_dir() + "/sbl." + std::to_string(q) + ".sock");
+			if (cfds[(size_t)q] < 0 || !rk_send(cfds[(size_t)q], 0, rank, 0, 0, 0)) { fprintf(stderr, "[samblaster] rank mode: cannot reach rank %d's samblaster\n", q); return 1; }
+		}
 	}
+	const int cfd = world > 1 ? cfds[0] : -1;   /* the side streams' owner */
 	uint64_t n_batch = 0;                                     /* BATCH frames seen: frame k of this rank is batch rank + k * world of the input */
 	if (!fu_write_full(1, FU_MAGIC, 8)) { perror("[samblaster] write"); return 1; }
 	bool got_header = false, ended = false;
@@ -450,12 +478,20 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 		tm[1] += now() - t0; t0 = now();
 		if (world == 1) { if (ssg_sbl_process(st, &o, (long)n_blocks, blk_off.data(), lines.data(), bits.data(), mate.data())) { fprintf(stderr, "[samblaster] %s\n", ssg_last_error()); rc = 1; break; } }
 		else {   /* the ends of the blocks' primaries to the owner of the duplicate set, its verdicts back, then the lines' bits */
-			std::vector<ssg_sbl_end_t> ends(2 * n_blocks); rk_hdr_t rh; std::vector<uint8_t> dup;
+			std::vector<ssg_sbl_end_t> ends(2 * n_blocks); rk_hdr_t rh; std::vector<uint8_t> dup(n_blocks), part;
 			bool ok = ssg_sbl_ends((long)n_blocks, blk_off.data(), lines.data(), ends.data()) == 0;
-			if (ok) { std::lock_guard<std::mutex> l(c_mu); ok = rk_send(cfd, RK_ENDS, rank, W->b, ends.data(), ends.size() * sizeof(ssg_sbl_end_t)); }
-			ok = ok && rk_recv(cfd, rh, dup) && rh.type == RK_DUP && rh.b == W->b && dup.size() == n_blocks;
+			std::vector<std::vector<ssg_sbl_end_t> > slice((size_t)world); std::vector<std::vector<uint32_t> > who((size_t)world);
+			for (size_t p = 0; ok && p < n_blocks; ++p) {   /* pair order within a slice = pair order within the batch */
+				const size_t q = shard ? (size_t)(sbl_route(&ends[2 * p], (uint64_t)p) % (uint64_t)world) : 0;
+				slice[q].push_back(ends[2 * p]); slice[q].push_back(ends[2 * p + 1]); who[q].push_back((uint32_t)p);
+			}
+			if (ok) { std::lock_guard<std::mutex> l(c_mu); for (int q = 0; ok && q < world; ++q) ok = rk_send(cfds[(size_t)q], RK_ENDS, rank, W->b, slice[(size_t)q].data(), slice[(size_t)q].size() * sizeof(ssg_sbl_end_t)); }
+			for (int q = 0; ok && q < world; ++q) {
+				ok = rk_recv(cfds[(size_t)q], rh, part) && rh.type == RK_DUP && rh.b == W->b && part.size() == who[(size_t)q].size();
+				for (size_t k = 0; ok && k < part.size(); ++k) dup[who[(size_t)q][k]] = part[k];
+			}
 			if (!ok || ssg_sbl_classify(&o, (long)n_blocks, blk_off.data(), lines.data(), dup.data(), bits.data(), mate.data())) {
-				fprintf(stderr, "[samblaster] rank mode: batch %llu was not decided (%s)\n", (unsigned long long)W->b, ok ? ssg_last_error() : "rank 0's samblaster is gone"); rc = 1; break; }
+				fprintf(stderr, "[samblaster] rank mode: batch %llu was not decided (%s)\n", (unsigned long long)W->b, ok ? ssg_last_error() : "another rank's samblaster is gone"); rc = 1; break; }
 		}
 		tm[2] += now() - t0;
 		W->n_blocks = n_blocks; W->F = std::move(F);
@@ -472,9 +508,9 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	if (!rc && !fu_write_frame(1, FU_END, 0, 0)) rc = 1;
 	if (world > 1) {
 		if (rc) rk_mark_failed("samblaster");
-		{ std::lock_guard<std::mutex> l(c_mu); if (cfd >= 0) (void)rk_send(cfd, RK_DONE, rank, 0, 0, 0); }
+		{ std::lock_guard<std::mutex> l(c_mu); for (int fd : cfds) if (fd >= 0) (void)rk_send(fd, RK_DONE, rank, 0, 0, 0); }
 		if (srv && srv->finish()) { fprintf(stderr, "[samblaster] rank mode: the exchange between the ranks failed\n"); rc = 1; }
-		if (cfd >= 0) close(cfd);
+		for (int fd : cfds) if (fd >= 0) close(fd);
 	}
 	if (spl) { spl->flush(); fclose(splf); }
 	if (disc) { disc->flush(); fclose(discf); }
