@@ -60,9 +60,11 @@ oracle:
 	$(MAKE) -C oracle
 
 # host emulation of the HIP execution model: same kernel + host sources, CPU-side tests only
-emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu tests/emu/fq_dump tests/emu/fi_test tests/emu/fi_mt_test
+emu: tests/emu/libssgpu_emu.so tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu tests/emu/fq_dump tests/emu/fi_test tests/emu/fi_mt_test tests/emu/scan_test
 tests/emu/fi_mt_test: tools/dbg/fi_mt_test.cpp $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fi_mt_test.cpp -o $@ -lz -lpthread
+tests/emu/scan_test: tools/dbg/scan_test.cpp $(HOST)/ranksplit.h $(HOST)/ranks.h $(HOST)/fastq.h
+	$(CXX) -O2 -std=c++17 -I$(HOST) tools/dbg/scan_test.cpp -o $@ -lz -lpthread
 tests/emu/fi_test: tools/dbg/fi_test.cpp $(HOST)/fast_inflate.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fi_test.cpp -o $@ -lz
 tests/emu/fq_dump: tools/dbg/fq_dump.cpp $(HOST)/fastq.h $(HOST)/fast_inflate.h
@@ -79,7 +81,7 @@ tests/emu/sambamba_emu: $(HOST)/sambamba_main.cpp $(HOST)/bamio.h $(HOST)/fastq.
 	$(CXX) -O2 -std=c++17 $(HOST)/sambamba_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 
 clean:
-	rm -rf build; rm -f speedseq_amd/libssgpu.so speedseq_amd/libssgpu_*.so $(CSRC)/*.d tests/emu/libssgpu_emu.so bin/bwa bin/samblaster bin/sambamba tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu tests/emu/fq_dump tests/emu/fi_test tests/emu/fi_mt_test $(CSRC)/*.o
+	rm -rf build; rm -f speedseq_amd/libssgpu.so speedseq_amd/libssgpu_*.so $(CSRC)/*.d tests/emu/libssgpu_emu.so bin/bwa bin/samblaster bin/sambamba tests/emu/bwa_emu tests/emu/samblaster_emu tests/emu/sambamba_emu tests/emu/fq_dump tests/emu/fi_test tests/emu/fi_mt_test tests/emu/scan_test $(CSRC)/*.o
 	$(MAKE) -C oracle clean
 .PHONY: all lib tools oracle emu clean variant tune
 
