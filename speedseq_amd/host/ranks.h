@@ -3,11 +3,12 @@
  *
  * The reference has one pipeline `bwa mem | samblaster | sambamba view | sambamba sort` (/root/reference/bin/speedseq:438-441); its results
  * depend on the input order in three places: upstream's batches (the scope of the insert-size model), samblaster's first-seen-wins duplicate
- * set, and the order of equal sort keys.  Rank r of SSG_WORLD pipelines aligns the batches r, r + N, ... (bwa_main.cpp); the samblasters share
- * ONE duplicate set, owned by rank 0's process and asked in batch order (the server below); side-stream lines travel to rank 0 as well and
- * leave it in batch order, so that its two small sorts see what a single pipeline's would; the main stream's records carry (batch, index)
- * ordinals into the sorts, which exchange sorted runs through the rendezvous directory and each write one stretch of the genome
- * (sambamba_main.cpp).  Everything between the processes goes through SSG_RDV: a UNIX socket for samblaster, files for the sorts.
+ * set, and the order of equal sort keys.  Rank r of SSG_WORLD pipelines aligns the batches r, r + N, ... (bwa_main.cpp; ranksplit.h: who reads
+ * which bytes); the samblasters share ONE duplicate set, sharded over them by signature -- every rank serves a slice of the table and asks all
+ * of them, each slice decided in batch order (samblaster_main.cpp); side-stream lines travel to rank 0 and leave it in batch order, so that its
+ * two small sorts see what a single pipeline's would; the main stream's records carry (batch, index) ordinals into the sorts, which exchange
+ * sorted runs through files, merge one stretch of the genome each and place it in the one output file (sambamba_main.cpp).  Everything between
+ * the processes goes through SSG_RDV (and SSG_RDV_DATA for the bulk): UNIX sockets for the samblasters, files for the sorts.
  */
 #ifndef SSG_RANKS_H
 #define SSG_RANKS_H

@@ -1,6 +1,6 @@
 """Rank mode (bin/speedseq-ranks, speedseq_amd/host/ranks.h): N pipelines of the reference's unmodified script side by side -- one per GPU on a
 multi-GPU node, here N processes on the host emulation -- must end in the SAME three sorted BAMs as one pipeline: upstream's batches dealt
-round-robin (insert-size models unchanged), ONE duplicate set asked in batch order, side-stream lines leaving rank 0 in batch order, equal sort
+round-robin (insert-size models unchanged), ONE duplicate set (sharded over the ranks by signature) asked in batch order, side-stream lines leaving rank 0 in batch order, equal sort
 keys in input order across ranks, every rank writing one stretch of the genome."""
 import os
 import shutil
