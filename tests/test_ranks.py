@@ -53,8 +53,10 @@ def _records(bam):
 
 @pytest.mark.parametrize("world,extra,chunk,kw", [(2, "", "40000", {}), (3, "export SSG_SORT_CHUNK_BYTES=300000\n", "40000", {}), (4, "", "150000", {}),
                                                   (2, "export SSG_RANKS_SPLIT=0\n", "60000", {"read_len": 250, "ins_mean": 800, "ins_std": 150}),
-                                                  (3, "", "40000", {"gz_two_files": True}), (8, "", "30000", {})],
-                         ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches", "two_ranks_2x250_everyone_parses", "three_ranks_two_gz_files", "eight_ranks"])
+                                                  (3, "", "40000", {"gz_two_files": True}), (8, "", "30000", {}),
+                                                  (3, "export SSG_RANKS_SCAN_SLICE=3000\nexport SSG_RANKS_SCAN_THREADS=3\nexport SSG_RANKS_SHARD=0\nexport SSG_RANKS_JOIN=0\n", "40000", {})],
+                         ids=["two_ranks", "three_ranks_spilling", "four_ranks_three_batches", "two_ranks_2x250_everyone_parses", "three_ranks_two_gz_files", "eight_ranks",
+                              "three_ranks_tiny_scan_slices_one_table_launcher_join"])
 def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chunk, kw):
     _ranks_equal_one(tmp_path, world, extra, chunk, None, 2500 if not kw else 1200, **kw)
 
@@ -83,7 +85,7 @@ def _ranks_equal_one(tmp_path, world, extra, chunk, exe, n_pairs, **kw):
     r = subprocess.run([os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(world), "--script", REF_SCRIPT, "--", "align", "-K", cfg, "-o", many, "-M", "3", "-t", "2"] + tail + [ref, fq] + ([fq2] if two else []),
                        cwd=str(tmp_path / "many"), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    assert "stretches placed by the ranks" in r.stderr, r.stderr[-500:]   # every sort put its stretch into the one file itself (sambamba_main.cpp), the launcher only indexed
+    assert ("stretches copied by the launcher" if "SSG_RANKS_JOIN=0" in extra else "stretches placed by the ranks") in r.stderr, r.stderr[-500:]   # every sort put its stretch into the one file itself (sambamba_main.cpp), the launcher only indexed
     for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
         assert _view(many + suffix) == _view(one + suffix), suffix
         assert _records(many + suffix) == _records(one + suffix), suffix
