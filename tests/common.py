@@ -434,6 +434,48 @@ def check_align1(lib, oracle, n_pairs, seed, read_len=150, prefix=EXAMPLE_FA, ch
     return len(regs)
 
 
+
+def reads_with_inner_repeats(fasta, n, seed, rl=250):
+    """reads that carry the same reference segment two or three times, further apart than the band: seeds at EQUAL reference positions that do not merge
+    (a second, then a third chain at one position: upstream's order among equal positions, the give-up of the wave kernels' ranked form)"""
+    rng = np.random.default_rng(seed)
+    ctg = simreads.read_fasta(fasta)
+    ref = np.asarray(ctg[0][1] if isinstance(ctg[0], tuple) else ctg[0], dtype=np.uint8)
+    out = []
+    for _ in range(n):
+        copies = int(rng.choice([2, 3, 3]))
+        xl = int(rng.integers(25, 45))
+        p = int(rng.integers(1000, len(ref) - 1000))
+        x = ref[p:p + xl]
+        gap = int(rng.integers(105, 125)) if copies == 2 else max(5, (rl - copies * xl) // (copies - 1) - 1)
+        parts = []
+        for c in range(copies):
+            parts.append(x)
+            if c + 1 < copies:
+                parts.append(rng.integers(0, 4, size=gap).astype(np.uint8))
+        s = np.concatenate(parts)[:rl]
+        if len(s) < rl:
+            s = np.concatenate([s, rng.integers(0, 4, size=rl - len(s)).astype(np.uint8)])
+        if rng.random() < 0.5:
+            s = (3 - s[::-1]).astype(np.uint8)
+        out.append(s)
+    return out
+
+
+def check_align1_reads(lib, oracle, seqs, prefix=EXAMPLE_FA):
+    """mem_align1_core on given reads: every region field against the oracle"""
+    oidx, gidx = oracle.idx_load(prefix), lib.index_load(prefix)
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    seq = np.concatenate(seqs)
+    ro, regs, st = lib.align1_batch(gidx, lib.opt_init(), seq, off)
+    oro, oregs = oracle.align1_batch(oidx, seq, off)
+    assert np.array_equal(ro, oro)
+    for f in REG_FIELDS:
+        assert np.array_equal(regs[f], oregs[f]), f
+    lib.index_destroy(gidx)
+    return len(regs)
+
 def repeat_reference(oracle, dirname, seed=5, n_copies=(300, 70), fam_len=(600, 350), unique=40000, max_div=0.03):
     """Writes a small repeat-rich reference (two planted families at 0-3 % divergence, both strands)
     and its index (built by the oracle) into dirname; returns the prefix.  Reads drawn from it carry

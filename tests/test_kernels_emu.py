@@ -141,6 +141,21 @@ def test_emu_extension_column_classes(emu_lib, oracle, monkeypatch):
             assert common.check_align1(emu_lib, oracle, 40, seed=50 + k, read_len=rl) > 40
 
 
+def test_emu_chains_at_equal_positions(emu_lib, oracle, monkeypatch):
+    # reads with the same reference segment two or three times, too far apart to merge: a second chain at one position (upstream's order among equal positions), a third
+    # (the ranked wave form gives the read up and redoes it) -- through the lane kernels (LDS, global) and every form of the wave kernels
+    seqs = common.reads_with_inner_repeats(common.EXAMPLE_FA, 120, 5) + common.reads_with_inner_repeats(common.EXAMPLE_FA, 80, 6, rl=150)
+    counts = set()
+    for env in ({}, {"SSG_CHAIN_LDS": "0"}, {"SSG_CHAIN_WAVE_MIN": "1"}, {"SSG_CHAIN_WAVE_MIN": "1", "SSG_CHAIN_SPEC": "0"}, {"SSG_CHAIN_WAVE_MIN": "1", "SSG_CHAIN_RANKED": "0"},
+                {"SSG_CHAIN_WAVE_MIN": "1", "SSG_CHAIN_BFLT": "0", "SSG_CHAIN_WSORT": "0"}):
+        for k in ("SSG_CHAIN_LDS", "SSG_CHAIN_WAVE_MIN", "SSG_CHAIN_SPEC", "SSG_CHAIN_RANKED", "SSG_CHAIN_BFLT", "SSG_CHAIN_WSORT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        counts.add(common.check_align1_reads(emu_lib, oracle, seqs))
+    assert len(counts) == 1 and min(counts) > 120
+
+
 def test_emu_light_reads_chain_lds(emu_lib, oracle, repeat_mid_prefix, monkeypatch):
     # reads with 10..63 seeds in small repeat families: the three classes of ssg_k_chain_lds (state in the lane's LDS), then the same reads through ssg_k_chain
     monkeypatch.setenv("SSG_CHAIN_WAVE_MIN", "64")
