@@ -121,6 +121,13 @@ def test_emu_chain_weight_sort_by_the_wave(emu_lib):
             a, b = emu_lib.dbg_chain_sort(keys)
             assert np.array_equal(a, b), (n, kind)
             assert np.all(np.diff(a >> 32) <= 0) and np.array_equal(np.sort(a), np.sort(keys))
+    for n in (17, 100, 600, 1200, 5120):   # distinct keys in order, organ pipes, interleavings: upstream's pivot rule runs out of depth on these and switches to combsort
+        for w in (np.arange(n), np.arange(n)[::-1].copy(), np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]), np.concatenate([np.arange(n // 2) * 2, np.arange(n - n // 2) * 2 + 1]),
+                  np.ravel(np.column_stack([np.arange(n // 2), np.arange(n // 2)[::-1]])), np.arange(n) // 3):
+            keys = (w.astype(np.int64) << 32) | np.arange(len(w), dtype=np.int64)
+            a, b = emu_lib.dbg_chain_sort(keys)
+            assert np.array_equal(a, b), n
+            assert np.all(np.diff(a >> 32) <= 0)
 
 
 def test_emu_chain_filter_options(emu_lib, oracle, repeat_mid_prefix, monkeypatch):
