@@ -64,6 +64,8 @@ def main():
             else:
                 env[key] = val
         extra = "export SSG_FUSED=1\nexport SSG_SORT_LOG=1\n" + "".join("export %s=%s\n" % kv for kv in env.items())
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
         r = bench.script_leg(td, "ab%d" % k, prefix, fq, a.pairs, threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=extra, limit_s=400, ranks=ranks, env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if ranks > 1 else None)
         for x in (".bam", ".splitters.bam", ".discordants.bam"):
             for y in ("", ".bai"):
@@ -71,8 +73,10 @@ def main():
                     os.remove(r.get("out", "") + x + y)
                 except OSError:
                     pass
-        keep = [l[:260] for l in r.get("stage_log", []) if "[bwa]" in l or "records" in l or "merge" in l]
-        res = {"config": cfg + (" (warm-up)" if k == 0 and not a.no_warmup else ""), "wall_s": r.get("wall_s"), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "stage_log": keep}
+        keep = [l[:260] for l in r.get("stage_log", []) if "[bwa]" in l or "records" in l or "merge" in l or "[samblaster]" in l or "[sambamba] sort: write" in l]
+        ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+        cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)   # CPU seconds of every process of the pipeline: against wall x the host's CPU quota
+        res = {"config": cfg + (" (warm-up)" if k == 0 and not a.no_warmup else ""), "wall_s": r.get("wall_s"), "children_cpu_s": round(cpu_s, 2), "children_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "stage_log": keep}
         results.append(res)
         bench.log(json.dumps({k2: v for k2, v in res.items() if k2 != "stage_log"}))
         for l in keep:

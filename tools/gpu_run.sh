@@ -7,6 +7,7 @@
 #   ab:KERNELS:CFG[;CFG...]   tools/smem_ab.py --kernels KERNELS CFG...   (A/B of variants inside the device step)
 #   ab250:KERNELS:CFG[;...]   the same at 2x250, 200 k pairs
 #   profile                   tools/profile_round.sh TAG (kernel stats + PMC passes + probes) and tools/pmc_summarize.py
+#   profile250                the same on the 2x250 workload (BASELINE.json configs[4], 200 k pairs), no probes: TAG_cfg5_*
 #   stats                     only the rocprofv3 --kernel-trace --stats pass of the device step
 #   soak:PAIRS[:MEM_GB]       tools/soak.py --stream --pairs PAIRS [--mem MEM_GB]   (the FASTQ goes through a FIFO, never a file)
 #   pin                       write the kernel ISA pin if the suite log and the bench parity of this TAG are green
@@ -45,6 +46,9 @@ PY
   profile)
     bash tools/profile_round.sh $tag > $out/${tag}_profile_round.log 2>&1; tail -5 $out/${tag}_profile_round.log
     python tools/pmc_summarize.py $tag $out $out 2>&1 | tail -20 ;;
+  profile250)
+    BENCH_EXTRA="--read-len 250 --pairs 200000" PROFILE_PROBES=0 bash tools/profile_round.sh ${tag}_cfg5 > $out/${tag}_cfg5_profile_round.log 2>&1; tail -3 $out/${tag}_cfg5_profile_round.log
+    python tools/pmc_summarize.py ${tag}_cfg5 $out $out 2>&1 | tail -20 ;;
   stats)
     B="python $PWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-profile --config5-pairs 0 --no-dist-rehearsal --script-pairs 0 --cpu-script-pairs 0"
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $B > $out/${tag}_bench_under_rocprof.log 2>&1)

@@ -23,8 +23,22 @@ def load(path):
 
 def main():
     tag, outdir, src = sys.argv[1], sys.argv[2], sys.argv[3]
+    # a workload tag (r06_cfg5) takes the probes and their calibration passes from its round's own profile (r06), here or under profiles/
+    import os
+    base = tag.split("_")[0]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def aux(name):
+        for t, d in ((tag, src), (base, src), (base, os.path.join(root, "profiles"))):
+            q = "%s/%s_%s" % (d, t, name)
+            if os.path.exists(q):
+                return q
+        import glob
+        older = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_" + name)))   # the newest earlier round's (same part, same probes)
+        return older[-1] if older else "%s/%s_%s" % (src, tag, name)
+    workload = {"pairs": 200000, "read_len": 250} if "cfg5" in tag else {"pairs": 1000000, "read_len": 150}
     # ---- calibration: the probe reads lanes * iters * lines_per_step random 64-byte lines per launch ----
-    cal, _ = load("%s/%s_pmc_probe_calibration.csv" % (src, tag))
+    cal, _ = load(aux("pmc_probe_calibration.csv"))
     lines = {"probe<0>": 1, "probe<1>": 1, "probe<2>": 2, "probe<3>": 0.25, "probe<4>": 0.5}
     ratios = []
     for k, c in cal.items():
@@ -43,7 +57,7 @@ def main():
     if sr:
         unit_stream_read = STREAM_BYTES / (sum(sr) / len(sr))
     try:
-        calw, _ = load("%s/%s_pmc_probe_calibration_write.csv" % (src, tag))
+        calw, _ = load(aux("pmc_probe_calibration_write.csv"))
         sw = calw.get("stream_write", {}).get("WRITE_SIZE", [])
         if sw:
             unit_stream_write = STREAM_BYTES / (sum(sw) / len(sw))
@@ -57,7 +71,7 @@ def main():
         traffic[k] = {"launches": len(f), "fetch_bytes_per_launch": sum(f) / len(f) * unit, "write_bytes_per_launch": sum(w) / max(1, len(w)) * (unit_stream_write or unit),
                       # the same counts priced as coalesced streaming reads: an upper bound for kernels that read arrays in order
                       "fetch_bytes_per_launch_if_streaming": sum(f) / len(f) * unit_stream_read if unit_stream_read else None}
-    json.dump({"tag": tag, "pairs": 1000000, "read_len": 150, "ref_mbp": 3100.0,
+    json.dump({"tag": tag, "pairs": workload["pairs"], "read_len": workload["read_len"], "ref_mbp": 3100.0,
                "calibration": {"bytes_per_counter_unit": unit, "bytes_per_counter_unit_streaming_read": unit_stream_read, "bytes_per_counter_unit_streaming_write": unit_stream_write, "probe_launches_used": len(ratios), "spread": [min(ratios) * unit, max(ratios) * unit],
                                "how": "tools/dbg/gather_probe under --pmc FETCH_SIZE: launches with a known count of random 64-byte line reads; WRITE_SIZE priced with the streaming-write unit when the probe's write pass is there; fetch also priced as coalesced streaming reads (an upper bound for in-order readers)"},
                "bytes_per_launch": {k: v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in traffic.items()},
@@ -67,7 +81,7 @@ def main():
     sq2, _ = load("%s/%s_pmc_SQ_INSTS_SALU.csv" % (src, tag))
     valu_peak = None
     try:
-        for line in open("%s/%s_valu_probe.txt" % (src, tag)):
+        for line in open(aux("valu_probe.txt")):
             m = re.search(r"v_add_u32 \+ v_max_i32\s+waves/CU\s+16.0\s+\S+ ms\s+(\S+) T lane-ops/s", line)
             if m:
                 valu_peak = float(m.group(1)) * 1e12
@@ -89,7 +103,7 @@ def main():
         if valu_peak:
             row["valu_frac_of_probe_peak"] = row["valu_lane_ops_per_s"] / valu_peak
         out[k] = row
-    json.dump({"tag": tag, "valu_probe_peak_lane_ops_per_s": valu_peak,
+    json.dump({"tag": tag, "workload": workload, "valu_probe_peak_lane_ops_per_s": valu_peak,
                "note": "SQ_INSTS_VALU counts wave64 instructions; lane-ops = x 64 (inactive lanes included); peak = tools/dbg/valu_probe, add + max mix at 16 waves/CU",
                "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches"]))},
               open("%s/%s_pmc_sq.json" % (outdir, tag), "w"), indent=1)
