@@ -11,7 +11,7 @@ all: lib tools oracle emu synth
 lib: speedseq_amd/libssgpu.so
 # Every object's prerequisites come from the compiler (-MMD): no hand-kept header lists, so no object can be stale against a shared
 # declaration (round 3 shipped variant libraries linked from objects of different ages).
-HIPOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_seed.o $(CSRC)/ssg_bgzf.o
+HIPOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_seed.o $(CSRC)/ssg_bgzf.o $(CSRC)/ssg_bam.o
 $(HIPOBJS): $(CSRC)/%.o: $(CSRC)/%.cpp
 	$(HIPCC) $(HIPFLAGS) -MMD -MP -x hip -c $< -o $@
 $(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp
@@ -69,9 +69,9 @@ tests/emu/fi_test: tools/dbg/fi_test.cpp $(HOST)/fast_inflate.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fi_test.cpp -o $@ -lz
 tests/emu/fq_dump: tools/dbg/fq_dump.cpp $(HOST)/fastq.h $(HOST)/fast_inflate.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fq_dump.cpp -o $@ -lz -lpthread
-tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
+tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
-		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
+		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
 tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h tests/emu/libssgpu_emu.so
@@ -90,10 +90,10 @@ clean:
 # objects, which `lib` has just brought up to date against every header they include (-MMD), so no stale object can be linked.
 #   make variant NAME=x VFLAGS="-D..."                   all translation units
 #   make variant NAME=x VFLAGS="-D..." VUNITS=ssg_seed   only that unit (seconds)
-VUNITS ?= ssgpu_core ssg_index_build ssg_seed ssg_bgzf
+VUNITS ?= ssgpu_core ssg_index_build ssg_seed ssg_bgzf ssg_bam
 variant: lib
 	mkdir -p build/$(NAME) && rm -f build/$(NAME)/*.o
-	for u in ssgpu_core ssg_index_build ssg_seed ssg_bgzf; do \
+	for u in ssgpu_core ssg_index_build ssg_seed ssg_bgzf ssg_bam; do \
 	  case " $(VUNITS) " in *" $$u "*) $(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/$$u.cpp -o build/$(NAME)/$$u.o || exit 1;; \
 	  *) cp $(CSRC)/$$u.o build/$(NAME)/$$u.o;; esac; done
 	cp $(CSRC)/sam_format.o build/$(NAME)/sam_format.o

@@ -352,3 +352,64 @@ def sam_format(lib, idx, opt, res, names, seq, off, quals=None, rg_id=""):
     text = C.string_at(sam, int(sam_off[n])).decode()
     lib.l.ssg_free(sam)
     return text, sam_off
+
+
+def bam_format(lib, idx, opt, res, names, seq, off, quals=None, rg_id=""):
+    """ssg_bam_format: the host formatter's BAM records of a PeResult (what `sambamba view -S -f bam` makes of ssg_sam_format's lines)."""
+    n = 2 * res.n_pairs
+    NA = (C.c_char_p * n)(*[s.encode() for s in names])
+    QA = (C.c_char_p * n)(*[(s.encode() if s is not None else None) for s in quals]) if quals is not None else None
+    bam = C.c_void_p()
+    bam_off = np.zeros(n + 1, dtype=np.int64)
+    lib._chk(lib.l.ssg_bam_format(idx, _ptr(opt), res.h, C.c_int(res.n_pairs), NA, _ptr(seq), _ptr(off), QA, rg_id.encode(), C.byref(bam), _ptr(bam_off)))
+    data = C.string_at(bam, int(bam_off[n]))
+    lib.l.ssg_free(bam)
+    return data, bam_off
+
+
+BAM_CAND_DT = np.dtype([("pair", "i8"), ("first_rec", "i8"), ("n_rec", "i8"), ("byte_off", "i8"), ("n_bytes", "i8")])
+
+
+def _take_pe_bam(lib, h, n_batches):
+    l = lib.l
+    for f in ("ssg_pe_bam_data", "ssg_pe_bam_cands", "ssg_pe_bam_pes", "ssg_pe_bam_stats"):
+        getattr(l, f).restype = C.c_void_p
+        getattr(l, f).argtypes = [C.c_void_p]
+    for f in ("ssg_pe_bam_bytes", "ssg_pe_bam_n_rec", "ssg_pe_bam_n_cand"):
+        getattr(l, f).restype = C.c_int64
+        getattr(l, f).argtypes = [C.c_void_p]
+    l.ssg_pe_bam_free.argtypes = [C.c_void_p]
+    nb, nc = l.ssg_pe_bam_bytes(h), l.ssg_pe_bam_n_cand(h)
+    out = {"bam": C.string_at(l.ssg_pe_bam_data(h), nb) if nb else b"", "n_rec": l.ssg_pe_bam_n_rec(h),
+           "cands": np.frombuffer((C.c_char * (nc * BAM_CAND_DT.itemsize)).from_address(l.ssg_pe_bam_cands(h)), dtype=BAM_CAND_DT, count=nc).copy() if nc else np.zeros(0, BAM_CAND_DT),
+           "pes": np.frombuffer((C.c_char * (n_batches * 4 * PESTAT_DT.itemsize)).from_address(l.ssg_pe_bam_pes(h)), dtype=PESTAT_DT, count=n_batches * 4).copy(),
+           "stats": np.ctypeslib.as_array(C.cast(l.ssg_pe_bam_stats(h), C.POINTER(C.c_uint64)), shape=(8,)).copy()}
+    l.ssg_pe_bam_free(h)
+    return out
+
+
+def mem_process_pairs_bam(lib, idx, opt, seq, off, names, quals=None, pair_batch=None, n_batches=1, id0=0, pes0=None, rg_id=""):
+    """ssg_mem_process_pairs_bam: parsed reads in, BAM record bytes (made on the device) out."""
+    n_pairs = (len(off) - 1) // 2
+    n = 2 * n_pairs
+    pair_batch = np.ascontiguousarray(pair_batch if pair_batch is not None else np.zeros(n_pairs, dtype=np.int32), dtype=np.int32)
+    NA = (C.c_char_p * n)(*[s.encode() for s in names])
+    QA = (C.c_char_p * n)(*[(s.encode() if s is not None else None) for s in quals]) if quals is not None else None
+    h = C.c_void_p()
+    p0 = _ptr(pes0) if pes0 is not None else None
+    lib._chk(lib.l.ssg_mem_process_pairs_bam(idx, _ptr(opt), C.c_int(n_pairs), _ptr(seq), _ptr(off), NA, QA, _ptr(pair_batch), C.c_int(n_batches), C.c_int64(id0), p0,
+                                             rg_id.encode() if rg_id else None, C.byref(h)))
+    return _take_pe_bam(lib, h, n_batches)
+
+
+def mem_process_fastq_bam(lib, idx, opt, text, rec_off, pair_batch=None, n_batches=1, id0=0, pes0=None, rg_id=""):
+    """ssg_mem_process_fastq_bam: FASTQ text (bytes) of plain four-line records + the offset of every record's '@' in read order."""
+    rec_off = np.ascontiguousarray(rec_off, dtype=np.int64)
+    n_pairs = len(rec_off) // 2
+    pair_batch = np.ascontiguousarray(pair_batch if pair_batch is not None else np.zeros(n_pairs, dtype=np.int32), dtype=np.int32)
+    buf = np.frombuffer(text, dtype=np.uint8)
+    h = C.c_void_p()
+    p0 = _ptr(pes0) if pes0 is not None else None
+    lib._chk(lib.l.ssg_mem_process_fastq_bam(idx, _ptr(opt), C.c_int(n_pairs), _ptr(buf), C.c_int64(len(text)), _ptr(rec_off), _ptr(pair_batch), C.c_int(n_batches),
+                                             C.c_int64(id0), p0, rg_id.encode() if rg_id else None, C.byref(h)))
+    return _take_pe_bam(lib, h, n_batches)

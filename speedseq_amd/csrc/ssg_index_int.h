@@ -6,6 +6,8 @@
 #define SSG_INDEX_INT_H
 #include <vector>
 #include <string>
+#include <mutex>
+#include <string.h>
 #include "ssg_types.h"
 
 struct ssg_hole_t { int64_t offset; int32_t len; char amb; };   /* upstream bntamb1_t (.amb) */
@@ -23,7 +25,9 @@ struct ssg_index {
 	std::vector<int32_t> n_ambs;            /* .ann: holes per contig */
 	std::vector<ssg_hole_t> holes;          /* .amb */
 	std::vector<int64_t> h_off; std::vector<int32_t> h_len;
-	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), ktab(0), ktab_k(0), bwt_words(0), raw_alloc(false) { memset(&v, 0, sizeof(v)); }
+	/* the contig names in HBM, for the kernel that writes SA / XA strings (k_bam.h); made by the first call that needs them (ssg_bam.cpp), dropped by ssg_index_set_names */
+	std::mutex names_mu; char *d_names; int32_t *d_name_off;
+	ssg_index() : bwt(0), sa(0), pac(0), ctg_off(0), ctg_len(0), ktab(0), ktab_k(0), bwt_words(0), raw_alloc(false), d_names(0), d_name_off(0) { memset(&v, 0, sizeof(v)); }
 };
 /* ssg_seed.cpp: the product's seeding kernels (k_smem2.h), the table of short-pattern intervals (every constructor of an index ends with
  * ssg_index_build_ktab) and the self-check of the denser suffix-array copy (SSG_SA_VERIFY) */

@@ -103,4 +103,9 @@ typedef struct {
 	char md[SSG_MAX_MD];
 } ssg_aln_t;
 
+
+/* a pair of a batch whose lines can reach one of samblaster's side streams (a read with several main lines, or both ends mapped without the
+ * proper-pair flag): where its records lie among the batch's BAM records (ssg_mem_process_fastq_bam) */
+typedef struct { int64_t pair, first_rec, n_rec, byte_off, n_bytes; } ssg_bam_cand_t;
+
 #endif

@@ -29,6 +29,7 @@
 #include "k_sbl.h"
 #include "../../include/ssgpu.h"
 #include "ssg_index_int.h"
+#include "ssg_pe_int.h"
 #ifndef SSG_EMU
 #include <rocprim/rocprim.hpp>
 #endif
@@ -47,8 +48,7 @@ thread_local std::vector<ssg_prof_rec> ssg_prof_pending;
 /* wave-per-item kernels are grid-strided over at most this many 4-wave workgroups (256 CUs x 4),
  * so per-wave scratch slabs are sized by residency, not by batch size */
 #define SSG_MAX_RESIDENT_WG 1024
-/* longest read the DP kernels are laid out for (LDS rows, 8-bit columns) */
-#define SSG_MAX_READ_LEN 310   /* 2x300 with room; the kernels' column classes end at 320 (k_sw.h NS = 5, ssg_k_ext_lane<320>, SSG_S2_QWORDS) */
+/* longest read the DP kernels are laid out for (LDS rows, 8-bit columns): SSG_MAX_READ_LEN, ssg_pe_int.h */
 #define SSG_STR_(x) #x
 #define SSG_STR(x) SSG_STR_(x)
 
@@ -63,13 +63,13 @@ static double ssg_stage_ms() { static thread_local std::chrono::steady_clock::ti
 #define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d  +%.1f ms\n", name, rc_, ssg_stage_ms()); fflush(stderr); if (rc_) return rc_; } } while (0)
 
 SSG_ABI_FP_DEFINE(core)
-extern "C" void ssg_abi_fp_index_build(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_seed(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_bgzf(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_sam_format(ssg_abi_fp_t*);
+extern "C" void ssg_abi_fp_index_build(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_seed(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_bgzf(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_sam_format(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_bam(ssg_abi_fp_t*);
 extern "C" int ssg_abi_selfcheck(void)
 {	/* every translation unit of the library was compiled against the same shared declarations (ssg_index_int.h) */
 	static const char *const field[20] = { "sizeof(ssg_index_view_t)", "sizeof(ssg_mem_opt_t)", "sizeof(ssg_index)", "sizeof(ssg_intv_t)", "ssg_index_view_t.primary", "ssg_index_view_t.L2",
 		"ssg_index_view_t.l_pac", "ssg_index_view_t.sa_intv", "ssg_mem_opt_t.min_seed_len", "ssg_mem_opt_t.split_width", "ssg_mem_opt_t.max_mem_intv", "ssg_mem_opt_t.split_factor", "ssg_mem_opt_t.mat",
 		"ssg_index.bwt", "ssg_index.ktab", "ssg_index.bwt_words", "ssg_index.names", "sizeof(ssg_seed_t)", "sizeof(ssg_alnreg_t)", "sizeof(ssg_aln_t)" };
-	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_seed", ssg_abi_fp_seed }, { "ssg_bgzf", ssg_abi_fp_bgzf }, { "sam_format", ssg_abi_fp_sam_format } };
+	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_seed", ssg_abi_fp_seed }, { "ssg_bgzf", ssg_abi_fp_bgzf }, { "sam_format", ssg_abi_fp_sam_format }, { "ssg_bam", ssg_abi_fp_bam } };
 	ssg_abi_fp_t mine; ssg_abi_fp_core(&mine);
 	for (const auto &u : units) {
 		ssg_abi_fp_t o; u.fn(&o);
@@ -85,6 +85,7 @@ static int need_device()
 	if (rt_device_count() < 1) { ssg_err_msg = "no HIP device visible: libssgpu has no CPU path"; return SSG_ENODEV; }
 	return ssg_abi_selfcheck();
 }
+int ssg_need_device() { return need_device(); }
 
 extern "C" {
 
@@ -286,7 +287,7 @@ void ssg_index_destroy(ssg_index_t *ix)
 	if (!ix) return;
 	if (ix->raw_alloc) { rt_free_raw(ix->bwt); rt_free_raw(ix->sa); rt_free_raw(ix->pac); }
 	else { rt_free(ix->bwt); rt_free(ix->sa); rt_free(ix->pac); }
-	rt_free(ix->ctg_off); rt_free(ix->ctg_len); rt_free(ix->ktab);
+	rt_free(ix->ctg_off); rt_free(ix->ctg_len); rt_free(ix->ktab); rt_free(ix->d_names); rt_free(ix->d_name_off);
 	delete ix;
 }
 int ssg_index_from_device(const uint32_t *d_bwt, uint64_t primary, const uint64_t L2[5], const uint64_t *d_sa, int sa_intv,
@@ -1038,20 +1039,6 @@ static void host_pestat(const ssg_mem_opt_t *opt, const uint32_t *hist /* [4][SS
 	for (d = 0; d < 4; ++d) if (pes[d].failed == 0 && n[d] < max * 0.05) pes[d].failed = 1;
 }
 
-struct ssg_pe_result {
-	int n_reads, n_batches, se = 0;      /* se: the reads are single-end (ssg_mem_process_reads): n_reads units, no pairs */
-	std::vector<int64_t> req_off;        /* n_reads + 1 */
-	hbuf<ssg_alnreq_t> req;              /* page-locked, recycled across calls */
-	hbuf<ssg_aln_t> alns;
-	std::vector<ssg_pestat_t> pes;        /* n_batches * 4 */
-	uint64_t stats[8];
-};
-
-/* device-resident output of the PE stage (kept in HBM for the duplicate-marking stage / the bench) */
-struct pe_dev_t {
-	dbuf<ssg_alnreq_t> req; dbuf<ssg_aln_t> alns; dbuf<int64_t> req_off; int64_t n_req;
-};
-
 /* the whole PE hot path on device-resident inputs; `keep` != NULL leaves the records in HBM
  * instead of downloading them into `res` */
 static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *d_seq_p, const int64_t *d_off_p, int max_len,
@@ -1212,6 +1199,13 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	}
 	return 0;
 }
+
+int ssg_pe_core(const ssg_index *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *d_seq, const int64_t *d_off, int max_len,
+                const int32_t *d_pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result *res, pe_dev_t *keep)
+{
+	return pe_core(idx, opt, n_pairs, d_seq, d_off, max_len, d_pair_batch, n_batches, id0, pes0, res, keep);
+}
+int ssg_dev_exclusive_scan(const int32_t *d_in, int64_t *d_out, long n, int64_t *total) { return dev_exclusive_scan(d_in, d_out, n, total); }
 
 /* single-end reads (upstream mem_process_seqs without MEM_F_PE): stage 1 as for pairs, then every read on its own -- primary marking with
  * id = id0 + r (upstream's n_processed + i), the list of records (ssg_k_se_final), CIGAR / NM / MD.  No insert-size model, no mate rescue, no pairing. */
@@ -1651,6 +1645,7 @@ int ssg_index_set_names(ssg_index_t *ix, int n, const char *const *names)
 {
 	if (n != ix->v.n_ctg) { ssg_err_msg = "ssg_index_set_names: contig count mismatch"; return SSG_EINVAL; }
 	ix->names.assign(names, names + n);
+	{ std::lock_guard<std::mutex> l(ix->names_mu); rt_free(ix->d_names); rt_free(ix->d_name_off); ix->d_names = 0; ix->d_name_off = 0; }
 	return 0;
 }
 const char *ssg_index_name(const ssg_index_t *ix, int i) { return i >= 0 && i < (int)ix->names.size() ? ix->names[i].c_str() : "*"; }
