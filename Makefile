@@ -4,6 +4,7 @@ CXX     ?= g++
 CSRC    = speedseq_amd/csrc
 HOST    = speedseq_amd/host
 KHDRS   = $(wildcard $(CSRC)/*.h) include/ssgpu.h
+HOSTHDRS = $(wildcard $(HOST)/*.h) include/ssgpu.h $(CSRC)/ssg_types.h
 HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable
 
 all: lib tools oracle emu synth
@@ -49,11 +50,11 @@ tools: bin/bwa bin/samblaster bin/sambamba bin/bamkit
 bin/bamkit: $(HOST)/bamkit_main.cpp $(HOST)/bamio.h
 	$(CXX) -O2 -std=c++17 $(HOST)/bamkit_main.cpp -o $@ -lz -lpthread
 	for t in bamtofastq bamheadrg bamcleanheader bamlibs; do ln -sf bamkit bin/$$t.py; done
-bin/sambamba: $(HOST)/sambamba_main.cpp $(HOST)/bamio.h $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h speedseq_amd/libssgpu.so
+bin/sambamba: $(HOST)/sambamba_main.cpp $(HOSTHDRS) speedseq_amd/libssgpu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/sambamba_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
-bin/bwa: $(HOST)/bwa_main.cpp $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h speedseq_amd/libssgpu.so
+bin/bwa: $(HOST)/bwa_main.cpp $(HOSTHDRS) speedseq_amd/libssgpu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
-bin/samblaster: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h speedseq_amd/libssgpu.so
+bin/samblaster: $(HOST)/samblaster_main.cpp $(HOSTHDRS) speedseq_amd/libssgpu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Lspeedseq_amd -lssgpu -lz -lpthread -Wl,-rpath,'$$ORIGIN/../speedseq_amd'
 
 oracle:
@@ -72,12 +73,12 @@ tests/emu/fq_dump: tools/dbg/fq_dump.cpp $(HOST)/fastq.h $(HOST)/fast_inflate.h
 tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
 		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
-tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h tests/emu/libssgpu_emu.so
+tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOSTHDRS) tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
-tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h tests/emu/libssgpu_emu.so
+tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOSTHDRS) tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/samblaster_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 
-tests/emu/sambamba_emu: $(HOST)/sambamba_main.cpp $(HOST)/bamio.h $(HOST)/fastq.h $(HOST)/fused.h $(HOST)/ranks.h $(HOST)/ranksplit.h $(HOST)/fast_inflate.h $(HOST)/fast_inflate_mt.h include/ssgpu.h tests/emu/libssgpu_emu.so
+tests/emu/sambamba_emu: $(HOST)/sambamba_main.cpp $(HOSTHDRS) tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/sambamba_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 
 clean:

@@ -179,14 +179,15 @@ int ssg_bam_format(const ssg_index_t *idx, const ssg_mem_opt_t *opt, const ssg_p
 /* ---- the same path with both text ends on the device (SURVEY 2.1 K1 + K11; rows a13, f2) ----
  * upstream bseq_read / kseq_read (htslib kseq.h:189-229) + mem_process_seqs + what `sambamba view -S -f bam` makes of mem_aln2sam's lines
  * (sam.c:835-1028 sam_parse1, sam.c:443-473 bam_write1) in ONE call: the FASTQ text of 2 * n_pairs plain four-line records goes to the device as it
- * is -- text[rec_off[r]] is the '@' of read r (read1, read2 interleaved; the caller's line scanner found them and checked the four-line form; the
- * device checks again) -- names, nt4 codes and qualities are taken from it there, and the block_size-prefixed BAM records of all reads come back
+ * is, in n_parts pieces (the two input files, say; page-locked pieces from ssg_host_alloc travel at bus speed) -- byte rec_off[r] of their
+ * concatenation is the '@' of read r (read1, read2 interleaved; the caller's line scanner found them and checked the four-line form; the
+ * device checks again; a record does not straddle two pieces) -- names, nt4 codes and qualities are taken from it there, and the block_size-prefixed BAM records of all reads come back
  * in input order, with the list of the pairs whose lines can reach one of samblaster's side streams under any options.  No comments (-C) on this
  * path.  pair_batch / n_batches / id0 / pes0 as for ssg_mem_process_pairs; rg_id: RG:Z value or NULL.  SSG_EINVAL with upstream's words when the
  * two reads of a pair carry different names. */
 typedef struct ssg_pe_bam ssg_pe_bam_t;
-int ssg_mem_process_fastq_bam(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *text, int64_t text_bytes, const int64_t *rec_off,
-                              const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, const char *rg_id, ssg_pe_bam_t **out);
+int ssg_mem_process_fastq_bam(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *const *parts, const int64_t *part_bytes, int n_parts,
+                              const int64_t *rec_off, const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, const char *rg_id, ssg_pe_bam_t **out);
 /* the same from parsed reads (codes, names, qualities as C strings; quals or quals[r] may be NULL): any FASTQ / FASTA the reader accepts */
 int ssg_mem_process_pairs_bam(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *seq, const int64_t *off,
                               const char *const *names, const char *const *quals, const int32_t *pair_batch, int n_batches, int64_t id0,

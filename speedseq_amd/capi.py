@@ -407,9 +407,12 @@ def mem_process_fastq_bam(lib, idx, opt, text, rec_off, pair_batch=None, n_batch
     rec_off = np.ascontiguousarray(rec_off, dtype=np.int64)
     n_pairs = len(rec_off) // 2
     pair_batch = np.ascontiguousarray(pair_batch if pair_batch is not None else np.zeros(n_pairs, dtype=np.int32), dtype=np.int32)
-    buf = np.frombuffer(text, dtype=np.uint8)
+    texts = [text] if isinstance(text, (bytes, bytearray)) else list(text)          # one piece, or several (the input files of a batch)
+    bufs = [np.frombuffer(t, dtype=np.uint8) for t in texts]
+    PA = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    nbytes = np.array([len(t) for t in texts], dtype=np.int64)
     h = C.c_void_p()
     p0 = _ptr(pes0) if pes0 is not None else None
-    lib._chk(lib.l.ssg_mem_process_fastq_bam(idx, _ptr(opt), C.c_int(n_pairs), _ptr(buf), C.c_int64(len(text)), _ptr(rec_off), _ptr(pair_batch), C.c_int(n_batches),
+    lib._chk(lib.l.ssg_mem_process_fastq_bam(idx, _ptr(opt), C.c_int(n_pairs), PA, _ptr(nbytes), C.c_int(len(bufs)), _ptr(rec_off), _ptr(pair_batch), C.c_int(n_batches),
                                              C.c_int64(id0), p0, rg_id.encode() if rg_id else None, C.byref(h)))
     return _take_pe_bam(lib, h, n_batches)

@@ -85,17 +85,20 @@ static int check_args(int n_pairs, const int32_t *pair_batch, int n_batches, ssg
 
 extern "C" {
 
-int ssg_mem_process_fastq_bam(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *text, int64_t text_bytes, const int64_t *rec_off,
-                              const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, const char *rg_id, ssg_pe_bam_t **out)
+int ssg_mem_process_fastq_bam(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *const *parts, const int64_t *part_bytes, int n_parts,
+                              const int64_t *rec_off, const int32_t *pair_batch, int n_batches, int64_t id0, const ssg_pestat_t *pes0, const char *rg_id, ssg_pe_bam_t **out)
 {
 	CHK(ssg_need_device());
 	CHK(check_args(n_pairs, pair_batch, n_batches, out));
-	if (text_bytes <= 0) { ssg_err_msg = "ssg_mem_process_fastq_bam: no text"; return SSG_EINVAL; }
+	int64_t text_bytes = 0;
+	for (int k = 0; k < n_parts; ++k) { if (part_bytes[k] < 0) { ssg_err_msg = "ssg_mem_process_fastq_bam: a part of negative length"; return SSG_EINVAL; } text_bytes += part_bytes[k]; }
+	if (n_parts <= 0 || text_bytes <= 0) { ssg_err_msg = "ssg_mem_process_fastq_bam: no text"; return SSG_EINVAL; }
 	const long n_reads = 2L * n_pairs;
 	dbuf<uint8_t> d_text((size_t)text_bytes + 8); dbuf<int64_t> d_rec((size_t)n_reads), d_seq_at((size_t)n_reads), d_off((size_t)n_reads + 1);
 	dbuf<ssg_rdtext_t> d_rd((size_t)n_reads); dbuf<int32_t> d_len((size_t)n_reads), d_err(4), d_pb(n_pairs);
 	CHKA(d_text); CHKA(d_rec); CHKA(d_seq_at); CHKA(d_off); CHKA(d_rd); CHKA(d_len); CHKA(d_err); CHKA(d_pb);
-	CHK(d_text.up(text, (size_t)text_bytes)); CHK(d_rec.up(rec_off, (size_t)n_reads)); CHK(d_pb.up(pair_batch, n_pairs));
+	{ int64_t at = 0; for (int k = 0; k < n_parts; ++k) { CHK(rt_h2d(d_text.p + at, parts[k], (size_t)part_bytes[k])); at += part_bytes[k]; } }   /* the parts back to back: rec_off counts over their concatenation */
+	CHK(d_rec.up(rec_off, (size_t)n_reads)); CHK(d_pb.up(pair_batch, n_pairs));
 	{ const int32_t e0[4] = { 0, 0, 0x7fffffff, 0 }; CHK(d_err.up(e0, 4)); }
 	SSG_LAUNCH(ssg_k_fq_unpack, (n_reads + 255) / 256, 256, 0, n_reads, (const uint8_t*)d_text.p, text_bytes, (const int64_t*)d_rec.p, d_rd.p, d_seq_at.p, d_len.p, d_err.p);
 	SSG_LAUNCH(ssg_k_fq_pair_names, (n_pairs + 255) / 256, 256, 0, (long)n_pairs, (const uint8_t*)d_text.p, (const ssg_rdtext_t*)d_rd.p, d_err.p + 2);
@@ -107,10 +110,13 @@ int ssg_mem_process_fastq_bam(const ssg_index_t *idx, const ssg_mem_opt_t *opt, 
 	if (err[2] != 0x7fffffff) {   /* upstream mem_sam_pe's words, with the two names from the caller's text */
 		const long p = err[2] - 1;
 		auto name = [&](long r) {
-			const uint8_t *s = text + rec_off[r] + 1; size_t k = 0;
-			while (rec_off[r] + 1 + (int64_t)k < text_bytes && !(s[k] == ' ' || (s[k] >= 9 && s[k] <= 13))) ++k;
-			if (k > 2 && s[k - 2] == '/' && s[k - 1] >= '0' && s[k - 1] <= '9') k -= 2;
-			return std::string((const char*)s, k);
+			int64_t o = rec_off[r] + 1; int k = 0;
+			while (k < n_parts && o >= part_bytes[k]) o -= part_bytes[k++];   /* a record lies within one part (the device found it plain) */
+			if (k >= n_parts) return std::string("?");
+			const uint8_t *s = parts[k] + o; size_t n = 0;
+			while (o + (int64_t)n < part_bytes[k] && !(s[n] == ' ' || (s[n] >= 9 && s[n] <= 13))) ++n;
+			if (n > 2 && s[n - 2] == '/' && s[n - 1] >= '0' && s[n - 1] <= '9') n -= 2;
+			return std::string((const char*)s, n);
 		};
 		ssg_err_msg = "[mem_sam_pe] paired reads have different names: \"" + name(2 * p) + "\", \"" + name(2 * p + 1) + "\""; return SSG_EINVAL;
 	}

@@ -29,6 +29,8 @@
 #include "fastq.h"
 #include "fused.h"
 #include "ranksplit.h"
+#include "rawfeed.h"
+#include "bam2sam.h"
 #include "../../include/ssgpu.h"
 
 #include <time.h>
@@ -188,10 +190,15 @@ static int main_mem(int argc, char **argv)
 	if (split && !rk_check("bwa")) return 1;
 	if (split && rank == 0) { const std::string f1 = argv[ai + 1], f2 = fp2 ? argv[ai + 2] : ""; const std::string rdv = rk_dir(); t_scan = std::thread([f1, f2, rdv, chunk, served, world, &fail]() { if (!rs_scan_and_publish(rdv, f1.c_str(), f2.empty() ? 0 : f2.c_str(), chunk, served, world)) fail = 1; }); }
 	struct scan_join_t { std::thread &t; ~scan_join_t() { if (t.joinable()) t.join(); } } scan_join = { t_scan };
-	std::unique_ptr<fq_feed_t> feed1_p(split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 1], false, rank, world, &fail, served), keep_comment, 16384, parse_hint)
+	/* The device-text path (rawfeed.h, csrc/k_bam.h; SURVEY 2.1 K1 + K11): with the fused hand-off the reads travel to the MI355X as the FASTQ text they
+	 * are -- the host only finds the records by their newlines and forms upstream's batches from the sequence lengths -- and come back as the BAM
+	 * records of their alignments; no parser, no formatter on the host.  Input that is not plain four-line records goes through the parser from the
+	 * batch where the scanner meets it.  SSG_BWA_DEVTEXT=0: parser and host formatter as before (the three BAMs are the same either way: tests/test_fused.py). */
+	const bool devtext = fused && world == 1 && !(getenv("SSG_BWA_DEVTEXT") && !strcmp(getenv("SSG_BWA_DEVTEXT"), "0"));
+	std::unique_ptr<raw_feed_t> rawf(devtext ? new raw_feed_t(argv[ai + 1], fp1, fp2 ? argv[ai + 2] : 0, fp2, chunk, max_pairs_per_call) : 0);
+	std::unique_ptr<fq_feed_t> feed1(devtext ? 0 : split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 1], false, rank, world, &fail, served), keep_comment, 16384, parse_hint)
 	                                         : new fq_feed_t(fp1, keep_comment, 16384, argv[ai + 1], parse_hint));
-	fq_feed_t &feed1 = *feed1_p;
-	std::unique_ptr<fq_feed_t> feed2(!fp2 ? 0 : split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 2], true, rank, world, &fail, served), keep_comment, 16384, parse_hint)
+	std::unique_ptr<fq_feed_t> feed2(!fp2 || devtext ? 0 : split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 2], true, rank, world, &fail, served), keep_comment, 16384, parse_hint)
 	                                                  : new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2], parse_hint));
 	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
 	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms
@@ -232,8 +239,9 @@ static int main_mem(int argc, char **argv)
 		std::unique_ptr<uint8_t[]> seq; std::vector<int64_t> off;
 		std::vector<int32_t> pair_batch; int n_batches; int64_t id0, seqno;
 		ssg_pe_result_t *res; int dev;
-		batch_t() : n_batches(0), id0(0), seqno(0), res(0), dev(0) { off.push_back(0); }
-		int n() const { return (int)names.size(); }
+		std::unique_ptr<raw_call_t> raw; ssg_pe_bam_t *bres;   /* the device-text path: the batch is FASTQ text, its result BAM record bytes */
+		batch_t() : n_batches(0), id0(0), seqno(0), res(0), dev(0), bres(0) { off.push_back(0); }
+		int n() const { return raw ? 2 * raw->n_pairs() : (int)names.size(); }
 		void add(const std::shared_ptr<fq_block_t> &h, int i)
 		{
 			const fq_block_t &b = *h;
@@ -278,7 +286,7 @@ static int main_mem(int argc, char **argv)
 		{
 			std::unique_lock<std::mutex> l(mu); const int64_t s = B->seqno;
 			while (!(s == next || ready.size() < cap || failed->load())) cv.wait_for(l, std::chrono::milliseconds(50));
-			if (failed->load() && !(s == next || ready.size() < cap)) { if (B->res) ssg_pe_result_free(B->res); return; }
+			if (failed->load() && !(s == next || ready.size() < cap)) { if (B->res) ssg_pe_result_free(B->res); if (B->bres) ssg_pe_bam_free(B->bres); return; }
 			ready[s] = std::move(B); cv.notify_all();
 		}
 		void worker_done() { std::lock_guard<std::mutex> l(mu); --open_workers; cv.notify_all(); }
@@ -294,9 +302,10 @@ static int main_mem(int argc, char **argv)
 		}
 	} to_fmt(n_work, (size_t)n_work + 1, &fail);
 	double tm_asm = 0; std::vector<double> tm_gpu((size_t)n_dev, 0.0); std::vector<long> calls((size_t)n_dev, 0);
-	std::thread t_asm([&]() {
+	/* the parser's side of the assembler: upstream's batches from the reader threads' blocks, from pair ordinal id0 / device call seqno on */
+	auto parsed_asm = [&](fq_feed_t &feed1, fq_feed_t *feed2, int64_t id0, int64_t seqno) {
 		fq_cursor_t c1(feed1); std::unique_ptr<fq_cursor_t> c2(feed2 ? new fq_cursor_t(*feed2) : 0);
-		int64_t id0 = 0, seqno = 0, bidx = 0; bool eof = false;
+		int64_t bidx = 0; bool eof = false;
 		while (!eof && !fail) {
 			const double t0 = wall();
 			std::unique_ptr<batch_t> B(new batch_t()); B->id0 = id0; B->seqno = seqno;
@@ -345,6 +354,36 @@ static int main_mem(int argc, char **argv)
 			tm_asm += wall() - t0;
 			to_gpu.push(std::move(B));
 		}
+	};
+	std::unique_ptr<fq_feed_t> fb1, fb2;   /* the parser taking over from the device-text path (an input that is not plain four-line records) */
+	std::thread t_asm([&]() {
+		if (rawf) {
+			int64_t id0 = 0, seqno = 0;
+			while (!fail) {
+				const double t0 = wall();
+				std::unique_ptr<batch_t> B(new batch_t()); B->raw.reset(new raw_call_t());
+				const int rc = rawf->next_call(B->raw.get());
+				if (rc < 0) { fprintf(stderr, "[bwa] %s\n", rawf->msg.c_str()); fail = 1; break; }
+				tm_asm += wall() - t0;
+				if (rc == 0) break;
+				B->id0 = id0; B->seqno = seqno++; B->n_batches = B->raw->n_batches; id0 += B->raw->n_pairs();
+				to_gpu.push(std::move(B));
+			}
+			if (!fail && rawf->fell_back) {
+				fprintf(stderr, "[bwa] %s after %llu plain pairs: the parser takes the rest of the input\n", rawf->why.c_str(), (unsigned long long)rawf->pairs_done);
+				raw_feed_t *rf = rawf.get();
+				auto mk = [rf, keep_comment](int i) -> std::function<fq_reader_t*()> {
+					return [rf, i, keep_comment]() -> fq_reader_t* {
+						raw_src_t &S = i ? *rf->B : *rf->A;
+						if (S.p) { struct stat sb; if (S.fd < 0 || fstat(S.fd, &sb) != 0) return 0; return new fq_reader_t(S.fd, rf->resume_off[i], (size_t)sb.st_size, keep_comment); }
+						return new fq_reader_t(rf->resume_mem[i].data(), rf->resume_mem[i].size(), S.ks.get(), keep_comment);
+					};
+				};
+				fb1.reset(new fq_feed_t(mk(0), 16384));
+				if (rf->B) fb2.reset(new fq_feed_t(mk(1), 16384));
+				parsed_asm(*fb1, fb2.get(), id0, seqno);
+			}
+		} else parsed_asm(*feed1, feed2.get(), 0, 0);
 		to_gpu.close();
 	});
 	std::vector<std::thread> t_gpu;
@@ -368,6 +407,16 @@ static int main_mem(int argc, char **argv)
 				}
 			}
 			D.pairs += B->n() / 2;
+			if (B->raw) {	/* FASTQ text in, BAM record bytes out (csrc/ssg_bam.cpp) */
+				std::shared_lock<std::shared_mutex> l(D.mu);
+				raw_call_t &R = *B->raw;
+				const uint8_t *parts[2] = { R.txt[0].p, R.txt[1].p }; const int64_t nb[2] = { (int64_t)R.txt[0].n, (int64_t)R.txt[1].n };
+				if (!fail && ssg_mem_process_fastq_bam(idxs[(size_t)g], &opt, R.n_pairs(), parts, nb, R.txt[1].n ? 2 : 1, R.rec_off.data(), R.pair_batch.data(), R.n_batches, B->id0, pes, rg_id, &B->bres)) {
+					const char *m = ssg_last_error();
+					if (!strncmp(m, "[mem_sam_pe]", 12)) fprintf(stderr, "%s\n", m); else fprintf(stderr, "[bwa] alignment failed on device %d: %s\n", g, m);
+					fail = 1; }
+				R.txt[0].release(); R.txt[1].release();   /* the text has been read: its page-locked blocks go back to the pool for the next call */
+			} else
 			{	std::shared_lock<std::shared_mutex> l(D.mu);
 				if (!fail && (se ? ssg_mem_process_reads(idxs[(size_t)g], &opt, B->n(), B->seq.get(), B->off.data(), B->id0, &B->res)
 				                 : ssg_mem_process_pairs(idxs[(size_t)g], &opt, B->n() / 2, B->seq.get(), B->off.data(), B->pair_batch.data(), B->n_batches, B->id0, pes, &B->res))) {
@@ -407,11 +456,48 @@ static int main_mem(int argc, char **argv)
 		std::unique_ptr<batch_t> B;
 		std::vector<int32_t> cand; std::vector<int64_t> sam_off; double busy = 0;
 		while (to_fmt.take(B)) {
-			if (fail) { if (B->res) ssg_pe_result_free(B->res); continue; }
+			if (fail) { if (B->res) ssg_pe_result_free(B->res); if (B->bres) ssg_pe_bam_free(B->bres); continue; }
 			const double t0 = wall();
 			const int n = B->n();
 			text_t t; t.p = 0; t.len = 0; t.frame = 0; t.seg = 0; t.seg_path = 0;
 			sam_off.resize((size_t)n + 1);
+			if (B->raw) {
+				/* the records came from the device as BAM bytes; the SAM text of the pairs samblaster may copy to a side stream is printed from their records
+				 * (bam2sam.h: sam_format1's rules -- the line a record came from, since the record is what sam_parse1 makes of that line) */
+				const ssg_pe_bam_t *R = B->bres;
+				const uint8_t *bam = ssg_pe_bam_data(R); const ssg_bam_cand_t *cd = ssg_pe_bam_cands(R); const size_t nc = (size_t)ssg_pe_bam_n_cand(R);
+				std::string ctext; std::vector<uint64_t> c_off(nc + 1, 0); bool ok = true;
+				auto cname = [&](int i) { return ssg_index_name(idx, i); };
+				ctext.reserve(nc * 1200);
+				for (size_t k = 0; k < nc && ok; ++k) {
+					c_off[k] = ctext.size();
+					const uint8_t *q = bam + cd[k].byte_off;
+					for (int64_t j = 0; j < cd[k].n_rec && ok; ++j) { uint32_t bs; memcpy(&bs, q, 4); ok = bam_record_to_sam(q, cname, ctext); q += 4 + (size_t)bs; }
+				}
+				if (!ok) { fprintf(stderr, "[bwa] a record the device made cannot be printed as SAM\n"); fail = 1; ssg_pe_bam_free(B->bres); continue; }
+				fu_batch_t bh; bh.n_rec = (uint64_t)ssg_pe_bam_n_rec(R); bh.bam_bytes = (uint64_t)ssg_pe_bam_bytes(R); bh.n_cand = nc; bh.text_bytes = ctext.size();
+				t.len = sizeof(bh) + nc * sizeof(fu_cand_t) + (size_t)bh.text_bytes + (size_t)bh.bam_bytes; t.frame = FU_BATCH;
+				{	std::unique_ptr<fu_buf_t> sg(new fu_buf_t()); std::unique_ptr<std::string> sp(new std::string());
+					if (fu_seg_create(t.len, *sg, *sp)) { t.seg = sg.release(); t.seg_path = sp.release(); t.p = (char*)t.seg->p; }
+					else t.p = (char*)malloc(t.len ? t.len : 1); }
+				if (!t.p) { fprintf(stderr, "[bwa] out of memory\n"); fail = 1; ssg_pe_bam_free(B->bres); continue; }
+				char *w = t.p; memcpy(w, &bh, sizeof(bh)); w += sizeof(bh);
+				for (size_t k = 0; k < nc; ++k) { fu_cand_t c; c.first_rec = (uint64_t)cd[k].first_rec; c.n_rec = (uint64_t)cd[k].n_rec; c.text_off = c_off[k]; memcpy(w, &c, sizeof(c)); w += sizeof(c); }
+				if (bh.text_bytes) memcpy(w, ctext.data(), (size_t)bh.text_bytes);
+				w += bh.text_bytes;
+				{	const size_t nb = (size_t)bh.bam_bytes; const int T = (int)std::max<size_t>(1, std::min<size_t>(8, nb >> 24));
+					std::vector<std::thread> th;
+					for (int k = 0; k < T; ++k) th.emplace_back([=]() { const size_t a = nb * (size_t)k / (size_t)T, e = nb * (size_t)(k + 1) / (size_t)T; memcpy(w + a, bam + a, e - a); });
+					for (std::thread &x : th) x.join();
+				}
+				busy += wall() - t0;
+				const ssg_pestat_t *pp = ssg_pe_bam_pes(R);
+				fprintf(stderr, "[bwa] processed %d reads in %d upstream batch(es) on %s device %d; FR insert (first batch): failed=%d low=%d high=%d avg=%.2f std=%.2f\n",
+				        n, B->n_batches, ssg_backend(), B->dev, pp[1].failed, pp[1].low, pp[1].high, pp[1].avg, pp[1].std);
+				ssg_pe_bam_free(B->bres);
+				emit(B->seqno, t);
+				continue;
+			}
 			if (!fused) {
 				char *sam;
 				if (se ? ssg_sam_format_se(idx, &opt, B->res, n, B->names.data(), B->seq.get(), B->off.data(), B->quals.data(), B->comments.data(), rg_id, &sam, sam_off.data())
@@ -484,8 +570,8 @@ static int main_mem(int argc, char **argv)
 		std::sort(o.begin(), o.end(), [&](int a, int b) { return ms[a] > ms[b]; });
 		for (int i = 0; i < n && i < 24; ++i) fprintf(stderr, "[bwa] kernel %-28s %9.1f ms in %ld launches\n", nm[o[i]], ms[o[i]], cnt[o[i]]);
 	}
-	{ std::shared_ptr<fq_block_t> drop; while (feed1.ch.pop(drop)) {} if (feed2) while (feed2->ch.pop(drop)) {} }   /* let the readers finish after an error */
-	feed1.th.join(); if (feed2) feed2->th.join();
+	for (fq_feed_t *f : { feed1.get(), feed2.get(), fb1.get(), fb2.get() }) if (f) { std::shared_ptr<fq_block_t> drop; while (f->ch.pop(drop)) {} f->th.join(); }   /* let the readers finish after an error */
+	fb1.reset(); fb2.reset(); rawf.reset();   /* (the fall-back parsers read from the device-text path's decoders) */
 	gzclose(fp1); if (fp2) gzclose(fp2);
 	for (int g = 0; g < n_dev; ++g) { (void)ssg_set_device(g); ssg_index_destroy(idxs[(size_t)g]); }
 	if (fail) rk_mark_failed("bwa");

@@ -579,6 +579,14 @@ struct fq_feed_t {
 			ch.close();
 		});
 	}
+	/* one serial reader made by the caller (bwa_main.cpp: the parser taking over from the device-text path in the middle of an input) */
+	fq_feed_t(std::function<fq_reader_t*()> mk, int per_block) : ch(4), pool(new fq_block_pool_t())
+	{
+		th = std::thread([this, mk, per_block]() {
+			{ std::unique_ptr<fq_reader_t> rd(mk()); if (rd) (void)drain(*rd, per_block, [this](blk_t b) { ch.push(std::move(b)); }); }
+			ch.close();
+		});
+	}
 	~fq_feed_t() { ch.abandon(); if (th.joinable()) th.join(); }
 };
 

@@ -36,11 +36,13 @@ struct rs_scan_t {
 	std::function<long(unsigned char*, size_t)> rd; bool eof_seen;
 	size_t base, fill; std::vector<unsigned char> buf; size_t at;   /* buf[0 .. fill) = input bytes [base, base + fill); at = scan position */
 	std::string why;
+	std::function<void()> before_move;   /* called before bytes already handed out through ptr() move or go away (a caller that still points at them copies them now) */
 	explicit rs_scan_t(std::function<long(unsigned char*, size_t)> r, size_t from = 0) : rd(r), eof_seen(false), base(from), fill(0), buf((size_t)16 << 20), at(from) {}   /* from: the reader starts at this offset of the input */
 	size_t lim() const { return eof_seen ? base + fill : (size_t)-1; }       /* the end of the input, once it has been seen */
 	const unsigned char *ptr(size_t off) const { return buf.data() + (off - base); }   /* valid for offsets >= the last record's start, until the next call */
 	bool more(size_t need_from)
 	{	/* keep [need_from, ...) and read on */
+		if (before_move) before_move();
 		const size_t keep = base + fill - need_from;
 		if (keep == buf.size()) buf.resize(buf.size() * 2);
 		memmove(buf.data(), buf.data() + (need_from - base), keep); base = need_from; fill = keep;
@@ -121,6 +123,10 @@ struct rs_pscan_t {
 	std::vector<sl_t> win; size_t w0;          /* slices of the current window, which starts at file offset w0 */
 	size_t cur_sl, cur_rec;
 	std::unique_ptr<rs_scan_t> slow;
+	std::function<void()> before_move;   /* as rs_scan_t's: called before a window's buffers are loaded anew or handed back */
+	void to_slow(size_t from) { if (before_move) before_move(); slow.reset(new rs_scan_t(rs_file_reader(path.c_str(), from), from)); slow->before_move = before_move; win.clear(); cur_sl = 0; }
+	/* the bytes of the record next() has just returned (valid until the next call, or until before_move is called) */
+	const unsigned char *ptr(size_t off) const { if (slow) return slow->ptr(off); const sl_t &S = win[cur_sl]; return S.buf.data() + (off - S.base); }
 	explicit rs_pscan_t(const char *p) : size(0), fd(-1), path(p), at(0), n_thr(1), slice((size_t)32 << 20), w0(0), cur_sl(0), cur_rec(0)
 	{
 		struct stat sb;
@@ -130,7 +136,7 @@ struct rs_pscan_t {
 		n_thr = (int)std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
 		{ const char *e = getenv("SSG_RANKS_SCAN_THREADS"); if (e && atoi(e) > 0) n_thr = std::min(64, atoi(e)); }
 		{ const char *e = getenv("SSG_RANKS_SCAN_SLICE"); if (e && atol(e) > 0) slice = (size_t)atol(e); }   /* tests: many slices in a small file */
-		if (!size) slow.reset(new rs_scan_t(rs_file_reader(p)));   /* cannot be opened (or empty): the one-thread scanner says what there is to say */
+		if (!size) slow.reset(new rs_scan_t(rs_file_reader(p)));   /* cannot be opened (or empty): the one-thread scanner says what there is to say (a caller sets before_move after construction: nothing has been handed out yet) */
 	}
 	~rs_pscan_t() { if (fd >= 0) close(fd); }
 	/* bytes [from, from + want) of the file (less at its end) into the slice's buffer */
@@ -194,6 +200,7 @@ struct rs_pscan_t {
 	}
 	bool next_window()
 	{	/* slices from `at` (a record starts there: slice 0 needs no guess), a thread each: read, guess, scan */
+		if (before_move) before_move();
 		w0 = at; int k = 0;
 		while (k < n_thr && w0 + (size_t)k * slice < size) ++k;
 		win.resize((size_t)k);
@@ -213,16 +220,16 @@ struct rs_pscan_t {
 	int next(size_t *r0, size_t *r1, size_t *len)
 	{
 		for (;;) {
-			if (slow) { const int rc = slow->next(r0, r1, len); at = slow->at; if (rc < 0) why = slow->why; return rc; }
+			if (slow) { if (!slow->before_move && before_move) slow->before_move = before_move; const int rc = slow->next(r0, r1, len); at = slow->at; if (rc < 0) why = slow->why; return rc; }
 			if (cur_sl >= win.size()) {
-				if (at >= size || !next_window()) { slow.reset(new rs_scan_t(rs_file_reader(path.c_str(), at), at)); win.clear(); continue; }   /* the end of the input (or a read error): in the one-thread scanner's words */
+				if (at >= size || !next_window()) { to_slow(at); continue; }   /* the end of the input (or a read error): in the one-thread scanner's words */
 			}
 			sl_t &S = win[cur_sl];
 			if (!S.checked) {
 				const size_t lim = std::min(size, w0 + slice * (cur_sl + 1));
 				if (at >= lim) { ++cur_sl; cur_rec = 0; continue; }   /* the records before ran over this whole slice */
 				if (S.guess != at) {                                 /* the guess was not where the records before end: this slice again, from there */
-					if (at < S.base && !load(S, at, lim - at + MARGIN)) { slow.reset(new rs_scan_t(rs_file_reader(path.c_str(), at), at)); win.clear(); cur_sl = 0; continue; }
+					if (at < S.base && !load(S, at, lim - at + MARGIN)) { to_slow(at); continue; }
 					scan_slice(S, at, lim);
 				}
 				S.checked = true; cur_rec = 0;
@@ -231,7 +238,7 @@ struct rs_pscan_t {
 				*r0 = at; *r1 = at + S.rec[cur_rec]; *len = S.rec[cur_rec + 1]; cur_rec += 2; at = *r1;
 				return 1;
 			}
-			if (!S.plain_end) { slow.reset(new rs_scan_t(rs_file_reader(path.c_str(), at), at)); win.clear(); cur_sl = 0; continue; }   /* something that is not a plain record: from here on one thread, and its words */
+			if (!S.plain_end) { to_slow(at); continue; }   /* something that is not a plain record: from here on one thread, and its words */
 			++cur_sl; cur_rec = 0;
 		}
 	}

@@ -66,7 +66,12 @@ def check_device_bam(lib, n_pairs, seed, flag=0, read_len=150, rg="grp1", n_batc
     got = capi.mem_process_pairs_bam(lib, gidx, opt, seq, off, names, quals, pair_batch=pb, n_batches=n_batches, id0=1000, rg_id=rg)
     text, rec_off = _fastq(seqs, names, quals, suffix, comment)
     got2 = capi.mem_process_fastq_bam(lib, gidx, opt, text, rec_off, pair_batch=pb, n_batches=n_batches, id0=1000, rg_id=rg)
-    for g, what in ((got, "parsed reads"), (got2, "FASTQ text")):
+    # ... and as two files would arrive: the first reads in one piece, the second reads in another
+    t1, r1 = _fastq(seqs[0::2], names[0::2], quals[0::2], suffix, comment)
+    t2, r2 = _fastq(seqs[1::2], names[1::2], quals[1::2], suffix, comment)
+    rec2 = np.empty(2 * n_pairs, dtype=np.int64); rec2[0::2] = r1; rec2[1::2] = r2 + len(t1)
+    got3 = capi.mem_process_fastq_bam(lib, gidx, opt, [t1, t2], rec2, pair_batch=pb, n_batches=n_batches, id0=1000, rg_id=rg)
+    for g, what in ((got, "parsed reads"), (got2, "FASTQ text"), (got3, "FASTQ text of two files")):
         if g["bam"] != want:
             a, b = _records(g["bam"]), _records(want)
             assert len(a) == len(b), (what, len(a), len(b))
