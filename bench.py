@@ -376,7 +376,7 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
     env = dict(os.environ, PATH="%s:%s" % (bindir, os.environ["PATH"]))
     env.update(env_extra or {})
     import signal
-    t = time.perf_counter()
+    t = time.perf_counter(); t_epoch = time.time()
     launcher = [os.path.join(ROOT, "bin", "speedseq-ranks"), "-n", str(ranks), "--script", script, "--"] if ranks > 1 else ["bash", script]   # rank mode: N pipelines side by side (speedseq_amd/host/ranks.h)
     p = subprocess.Popen(launcher + ["align", "-K", cfg, "-o", out, "-M", str(sort_mem_gb), "-t", str(threads), "-p",
                           "-R", "@RG\\tID:bench\\tSM:bench\\tLB:lib1", ref_prefix, fq], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
@@ -409,7 +409,16 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
     sizes = {x: os.path.getsize(out + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
     ok = all(os.path.exists(out + x + ".bai") for x in sizes)
     stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs", "[samblaster] main thread", "[samblaster] first stage", "[ssgpu] index load", "[ssgpu] device arena"))]
-    return {"pairs": n_pairs, "threads": threads, "wall_s": round(t, 2), "pairs_per_s": n_pairs / t, "bam_bytes": sizes, "bai_written": ok, "out": out, "stage_log": stages}
+    # SSG_STAMP=1 (config_extra): when each stage started and ended, in seconds after the script was launched
+    stamps = []
+    for l in r.stderr.split("\n"):
+        if l.startswith("[stamp] "):
+            w = l.split()
+            stamps.append((round(float(w[3]) - t_epoch, 3), w[1], w[2]))
+    res = {"pairs": n_pairs, "threads": threads, "wall_s": round(t, 2), "pairs_per_s": n_pairs / t, "bam_bytes": sizes, "bai_written": ok, "out": out, "stage_log": stages}
+    if stamps:
+        res["timeline_s"] = ["%.3f %s %s" % x for x in sorted(stamps)]
+    return res
 
 
 def bam_view(samtools, bam):

@@ -148,6 +148,7 @@ static int main_mem(int argc, char **argv)
 		rg_id[i] = 0;
 	}
 	const double t_start = wall();
+	ssg_stamp("bwa", "start");
 	size_t max_pairs_per_call = 1u << 19;   /* upstream batches are grouped up to this many pairs per device call (one batch alone may exceed it) */
 	{ const char *e = getenv("SSG_BWA_CALL_PAIRS"); if (e && atol(e) > 0) max_pairs_per_call = (size_t)atol(e); }
 	/* Rank mode (bin/speedseq-ranks): SSG_WORLD pipelines of the reference's script run side by side, one per GPU; this
@@ -216,6 +217,7 @@ static int main_mem(int argc, char **argv)
 	if (fail) { rk_mark_failed("bwa"); return 1; }
 	ssg_index_t *idx = idxs[0];
 	const double t_loaded = wall();
+	ssg_stamp("bwa", "index_loaded");
 	/* header: upstream bwa_print_sam_hdr + @PG */
 	std::string hdr;
 	for (int i = 0; i < ssg_index_n_ctg(idx); ++i) { char b[64]; snprintf(b, sizeof(b), "\tLN:%d\n", ssg_index_len(idx, i)); hdr += "@SQ\tSN:"; hdr += ssg_index_name(idx, i); hdr += b; }
@@ -560,6 +562,7 @@ static int main_mem(int argc, char **argv)
 	if (fused && !fail) { text_t t; t.len = 0; t.frame = FU_END; t.seg = 0; t.seg_path = 0; t.p = (char*)malloc(1); to_write.push(t); }
 	to_write.close(); t_write.join();
 	t_asm.join(); for (std::thread &x : t_gpu) x.join();
+	ssg_stamp("bwa", "output_closed");
 	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> %s %.2f s\n", t_loaded - t_start, fused ? "BAM records (fused)" : "SAM", wall() - t_loaded);
 	{ double g = 0; for (double x : tm_gpu) g += x; fprintf(stderr, "[bwa] stage busy time: assemble %.2f s, device call %.2f s, format %.2f s\n", tm_asm, g, tm_fmt); }
 	if (n_dev > 1) for (int g = 0; g < n_dev; ++g) fprintf(stderr, "[bwa] device %d: %ld calls, %.2f s busy\n", g, calls[(size_t)g], tm_gpu[(size_t)g]);
@@ -575,6 +578,7 @@ static int main_mem(int argc, char **argv)
 	gzclose(fp1); if (fp2) gzclose(fp2);
 	for (int g = 0; g < n_dev; ++g) { (void)ssg_set_device(g); ssg_index_destroy(idxs[(size_t)g]); }
 	if (fail) rk_mark_failed("bwa");
+	ssg_stamp("bwa", "end");
 	return fail ? 1 : 0;
 }
 

@@ -42,6 +42,15 @@
 #include <string>
 #include <atomic>
 
+/* SSG_STAMP=1: every stage of the pipeline says when it started and ended, in seconds of the realtime clock (bench.py / tools/dbg/literal_ab.py lay them on one axis) */
+#include <time.h>
+static inline void ssg_stamp(const char *who, const char *what)
+{
+	static const bool on = getenv("SSG_STAMP") != 0;
+	if (!on) return;
+	struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+	fprintf(stderr, "[stamp] %s %s %.3f\n", who, what, (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+}
 #define FU_MAGIC "SSGFUSE1"
 enum { FU_HEADER = 1, FU_BATCH = 2, FU_MAIN = 3, FU_END = 4, FU_REF = 5 };
 struct fu_frame_t { uint32_t type, zero; uint64_t len; };

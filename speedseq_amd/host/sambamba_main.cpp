@@ -740,6 +740,7 @@ static int cmd_sort(int argc, char **argv)
 		flush();
 	}
 	const double t_in = wall();
+	ssg_stamp("sambamba_sort", "input_done");
 	bool bai_note = false;
 	int ofd = open(outp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + outp);
 	if (world > 1) {
@@ -1006,8 +1007,8 @@ int main(int argc, char **argv)
 	(void)fcntl(0, F_SETPIPE_SZ, 1 << 20); (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);   /* the reference's pipelines: fewer wake-ups per megabyte (fails harmlessly on files) */
 #endif
 	if (!strcmp(argv[1], "view")) return cmd_view(argc - 2, argv + 2);
-	if (!strcmp(argv[1], "sort")) return cmd_sort(argc - 2, argv + 2);
-	if (!strcmp(argv[1], "index")) return cmd_index(argc - 2, argv + 2);
+	if (!strcmp(argv[1], "sort")) { ssg_stamp("sambamba_sort", "start"); const int rc = cmd_sort(argc - 2, argv + 2); ssg_stamp("sambamba_sort", "end"); return rc; }
+	if (!strcmp(argv[1], "index")) { ssg_stamp("sambamba_index", "start"); const int rc = cmd_index(argc - 2, argv + 2); ssg_stamp("sambamba_index", "end"); return rc; }
 	if (!strcmp(argv[1], "flagstat")) return cmd_flagstat(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "merge")) return cmd_merge(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "index-parts")) return cmd_index_parts(argc - 2, argv + 2);

@@ -519,7 +519,9 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	return rc;
 }
 
-int main(int argc, char **argv)
+static int main_(int argc, char **argv);
+int main(int argc, char **argv) { ssg_stamp("samblaster", "start"); const int rc = main_(argc, argv); ssg_stamp("samblaster", "end"); return rc; }
+static int main_(int argc, char **argv)
 {
 	ssg_sbl_opt_t o; ssg_sbl_opt_init(&o);
 	const char *spl_path = 0, *disc_path = 0;

@@ -54,33 +54,45 @@ def main():
     results = []
     for k, cfg in enumerate(([a.configs[0]] if not a.no_warmup else []) + a.configs):
         parts = cfg.split(":")
-        threads, env, ranks = 32, {}, 0
+        threads, env, ranks, trace = 32, {}, 0, False
         for p in parts[1:]:
             key, _, val = p.partition("=")
             if key == "t":
                 threads = int(val)
+            elif key == "trace":          # the kernels of `bwa mem` alone, as rocprofv3 sees them inside the pipeline (tools/dbg/trace_util.py prints who waits for whom)
+                trace = True
             elif key == "ranks":
                 ranks = int(val)
             else:
                 env[key] = val
-        extra = "export SSG_FUSED=1\nexport SSG_SORT_LOG=1\n" + "".join("export %s=%s\n" % kv for kv in env.items())
+        extra = "export SSG_FUSED=1\nexport SSG_SORT_LOG=1\nexport SSG_STAMP=1\nexport SSG_SBL_LOG=1\n" + "".join("export %s=%s\n" % kv for kv in env.items())
         import resource
         ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
-        r = bench.script_leg(td, "ab%d" % k, prefix, fq, a.pairs, threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=extra, limit_s=400, ranks=ranks, env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if ranks > 1 else None)
+        bwa_cmd = b("bwa")
+        if trace:
+            tdir = "/tmp/prof_bwa_%d" % k
+            bwa_cmd = "env TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d %s -o bwa -- %s" % (tdir, b("bwa"))
+        r = bench.script_leg(td, "ab%d" % k, prefix, fq, a.pairs, threads, bwa_cmd, b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=extra, limit_s=400, ranks=ranks, env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if ranks > 1 else None)
         for x in (".bam", ".splitters.bam", ".discordants.bam"):
             for y in ("", ".bai"):
                 try:
                     os.remove(r.get("out", "") + x + y)
                 except OSError:
                     pass
+        if trace:
+            import subprocess
+            tr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "trace_util.py"), tdir], capture_output=True, text=True)
+            open(os.path.join(ROOT, "gpurun_out", "literal_ab_trace_%d.txt" % k), "w").write(tr.stdout + tr.stderr)
+            bench.log(tr.stdout[-3000:])
         keep = [l[:260] for l in r.get("stage_log", []) if "[bwa]" in l or "records" in l or "merge" in l or "[samblaster]" in l or "[sambamba] sort: write" in l]
         ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
         cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)   # CPU seconds of every process of the pipeline: against wall x the host's CPU quota
-        res = {"config": cfg + (" (warm-up)" if k == 0 and not a.no_warmup else ""), "wall_s": r.get("wall_s"), "children_cpu_s": round(cpu_s, 2), "children_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "stage_log": keep}
+        res = {"config": cfg + (" (warm-up)" if k == 0 and not a.no_warmup else ""), "wall_s": r.get("wall_s"), "children_cpu_s": round(cpu_s, 2), "children_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "timeline_s": r.get("timeline_s"), "stage_log": keep}
         results.append(res)
         bench.log(json.dumps({k2: v for k2, v in res.items() if k2 != "stage_log"}))
         for l in keep:
             bench.log("      " + l)
+        bench.log("      timeline: " + " | ".join(r.get("timeline_s") or []))
     json.dump(results, open(a.out, "w"), indent=1)
     td_obj.cleanup()
 
