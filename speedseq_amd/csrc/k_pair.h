@@ -620,12 +620,14 @@ __global__ void ssg_k_se_caps(int n_reads, const int32_t *n_reg, int32_t *capq)
 __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, int64_t id0,
                                  const int64_t *reg_off, ssg_alnreg_t *regs, const int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
                                  int32_t *zbuf, ssg_pair64_t *vbuf, ssg_pair64_t *ubuf, int ucap,
-                                 const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err, const int32_t *work_order, int pq_first)
+                                 const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err, const int32_t *work_order, int pq_first,
+                                 const int32_t *todo_list, const unsigned int *n_todo /* the pairs ssg_k_pair_final_lds left (NULL: pq_first .. n_pairs of work_order) */)
 {
 	long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
 	ssg_pair64_t *u = ubuf + gt * (long)ucap;
-	for (long pq = pq_first + gt; pq < n_pairs; pq += nt) {
-		const long p = work_order ? work_order[pq] : pq;   /* similar-cost pairs share a wave */
+	const long n_work = todo_list ? (long)*n_todo : (long)n_pairs;
+	for (long pq = (todo_list ? 0 : pq_first) + gt; pq < n_work; pq += nt) {
+		const long p = todo_list ? todo_list[pq] : work_order ? work_order[pq] : pq;   /* similar-cost pairs share a wave */
 		const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
 		const int64_t id = id0 + p;
 		ssg_alnreg_t *a[2] = { regs + reg_off[2*p], regs + reg_off[2*p+1] };
@@ -640,5 +642,45 @@ __global__ void __launch_bounds__(64) ssg_k_pair_final(ssg_index_view_t ix, ssg_
 		ssg_pair_decide(ix, opt, pes, p, a, an, n_pri, o, subo, n_sub, z, z0, reg_off, rq, n_req);
 		if (myerr) err[p] = myerr;
 	}
+}
+
+/* The same for the pairs with few candidate regions (nearly all of a batch), with the pair's state in the lane's slice of LDS: mem_mark_primary_se, mem_pair
+ * and mem_sam_pe's decisions touch every field of every region record several times -- sorts included -- and on global memory each touch was a round trip
+ * (round 5: 18 ms per million pairs at 0.6 % of the VALU rate, profiles/r05_pmc_sq.json).  Here a lane copies the regions of its two reads in (88 bytes each),
+ * the same device functions run on the copies (sort scratch, pairing candidates and the z list lie in the slice too), and the records go back once.  Pairs with
+ * more than SSG_PF_CAP regions in all are listed for ssg_k_pair_final. */
+#ifndef SSG_PF_CAP
+#define SSG_PF_CAP 6   /* 52 KB of LDS a wave: three waves a CU; 8 would pass the 64 KB of a static block */
+#endif
+#define SSG_PF_UCAP ((SSG_PF_CAP / 2) * (SSG_PF_CAP - SSG_PF_CAP / 2))     /* mem_pair lists a (hit of read 1, hit of read 2) combination at most once */
+#define SSG_PF_SLICE ((SSG_PF_CAP * (int)sizeof(ssg_alnreg_t) + SSG_PF_CAP * 4 + SSG_PF_CAP * 16 + SSG_PF_UCAP * 16 + 8 + 15) / 16 * 16 + 8)   /* bytes per lane; an odd number of 8-byte words: the lanes' slices start in different banks */
+__global__ void __launch_bounds__(64) ssg_k_pair_final_lds(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_pairs, int64_t id0,
+                                 const int64_t *reg_off, ssg_alnreg_t *regs, const int32_t *n_reg, const int32_t *pair_batch, const ssg_pestat_t *pes_all,
+                                 const int64_t *req_off, ssg_alnreq_t *req, int32_t *n_req, int32_t *err, const int32_t *work_order, int pq_first,
+                                 int32_t *todo_list, unsigned int *n_todo)
+{
+	__shared__ uint64_t lds_[64 * SSG_PF_SLICE / 8];
+	const long pq = pq_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (pq >= n_pairs) return;
+	const long p = work_order ? work_order[pq] : pq;
+	const int an[2] = { n_reg[2*p], n_reg[2*p+1] };
+	if (an[0] + an[1] > SSG_PF_CAP) { todo_list[atomicAdd(n_todo, 1u)] = (int32_t)p; return; }
+	uint8_t *sl = (uint8_t*)lds_ + (size_t)threadIdx.x * SSG_PF_SLICE;
+	ssg_alnreg_t *L = (ssg_alnreg_t*)sl;
+	ssg_pair64_t *v = (ssg_pair64_t*)(sl + SSG_PF_CAP * sizeof(ssg_alnreg_t)), *u = v + SSG_PF_CAP;
+	int32_t *z0 = (int32_t*)(u + SSG_PF_UCAP);
+	ssg_alnreg_t *g[2] = { regs + reg_off[2*p], regs + reg_off[2*p+1] };
+	ssg_alnreg_t *a[2] = { L, L + an[0] };
+	for (int i = 0; i < 2; ++i) for (int k = 0; k < an[i]; ++k) a[i][k] = g[i][k];
+	const ssg_pestat_t *pes = pes_all + (long)pair_batch[p] * 4;
+	const int64_t id = id0 + p;
+	int n_pri[2], z[2] = {0, 0}, o = 0, subo = 0, n_sub = 0, myerr = 0;
+	ssg_alnreq_t *rq[2] = { req + req_off[2*p], req + req_off[2*p+1] };
+	n_pri[0] = ssg_mark_primary_se(opt, an[0], a[0], id << 1 | 0, z0, (int32_t*)v);
+	n_pri[1] = ssg_mark_primary_se(opt, an[1], a[1], id << 1 | 1, z0, (int32_t*)v);
+	if (n_pri[0] && n_pri[1] && !(opt.flag & SSG_F_NOPAIRING)) o = ssg_mem_pair(ix, opt, pes, a, (int)id, &subo, &n_sub, z, n_pri, v, u, SSG_PF_UCAP, &myerr);
+	ssg_pair_decide(ix, opt, pes, p, a, an, n_pri, o, subo, n_sub, z, z0, reg_off, rq, n_req);
+	for (int i = 0; i < 2; ++i) for (int k = 0; k < an[i]; ++k) g[i][k] = a[i][k];
+	if (myerr) err[p] = myerr;
 }
 #endif

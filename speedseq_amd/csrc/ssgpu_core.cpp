@@ -720,9 +720,13 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
                       align1_dev_t &o, uint64_t stats[8])
 {
 	/* intervals per read in the dense layout: upstream's list is unbounded; a batch that needs more widens the layout for itself
-	 * and for the calls after it (low-complexity reads collect > len / 2 intervals from the re-seeding passes) */
+	 * and for the calls after it (low-complexity reads collect > len / 2 intervals from the re-seeding passes).  The layout starts at 5/4 of the
+	 * read length: at len / 2 (until round 6) one batch in three or four of the 1 M-pair bench met a read beyond it and paid the one-lane kernel of
+	 * the slow path (24-36 ms with the chip idle) plus a second run of the whole seeding stage (44-52 ms) -- profiles/r05_kernel_stats.csv shows the
+	 * fourth ssg_k_smem2 launch in three steps; only the entries a read has are ever touched, so the width costs HBM (12 GB per million pairs), not time */
 	static std::atomic<int> learned_cap(0);
-	int cap = std::max(64 > max_len / 2 ? 64 : max_len / 2, learned_cap.load());
+	int cap = std::max(std::max(96, (max_len * 5 / 4 + 31) / 32 * 32), learned_cap.load());
+	{ const int e = env_int("SSG_SMEM_CAP", 0); if (e > 0) cap = e; }   /* tests: a narrow layout walks the widening path */
 	dbuf<ssg_intv_t> d_intv; dbuf<int32_t> d_nintv(n_reads), d_nseed(n_reads);
 	CHKA(d_nintv); CHKA(d_nseed);
 	dbuf<unsigned long long> d_next(1);
@@ -1151,11 +1155,21 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		if (n_heavy > 0)
 			SSG_LAUNCH_ON(0, ssg_k_pair_final_wave, nwg_h, wpb * 64, 0, idx->v, *opt, n_heavy, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_slab.p,
 			              d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, d_q.p);
-		if (n_pairs > n_heavy)
+		if (n_pairs > n_heavy) {
+			/* the pairs with a handful of regions (nearly all) with their state in LDS (k_pair.h ssg_k_pair_final_lds); what it lists, on global memory.  SSG_PAIR_LDS=0: all on global memory (A/B, tests) */
+			dbuf<int32_t> d_ptodo((size_t)n_pairs); dbuf<unsigned int> d_nptodo(1);
+			CHKA(d_ptodo); CHKA(d_nptodo); CHK(d_nptodo.zero());
+			const bool pf_lds = env_int("SSG_PAIR_LDS", 1) != 0;
+			if (pf_lds) SSG_LAUNCH(ssg_k_pair_final_lds, (n_pairs - n_heavy + 63) / 64, 64, 0, idx->v, *opt, n_pairs, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p,
+			                       d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, n_heavy, d_ptodo.p, d_nptodo.p);
 			SSG_LAUNCH(ssg_k_pair_final, nthr / 64, 64, 0, idx->v, *opt, n_pairs, id0, d_r2off.p, d_regs2.p, a1.n_reg.p, d_pb.p, d_pes.p, d_zbuf.p, d_v.p, d_u.p, ucap,
-			           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, n_heavy);
-		ssg_join(1);
-		CHK(rt_sync());
+			           d_reqoff.p, d_req.p, d_nreq.p, d_perr.p, d_pw.p, n_heavy, pf_lds ? (const int32_t*)d_ptodo.p : (const int32_t*)0, pf_lds ? (const unsigned int*)d_nptodo.p : (const unsigned int*)0);
+			ssg_join(1);
+			CHK(rt_sync());   /* (before the work lists of this scope go back to the arena) */
+		} else {
+			ssg_join(1);
+			CHK(rt_sync());
+		}
 	}
 	STAGE("pair_final");
 	{

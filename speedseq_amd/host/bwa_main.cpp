@@ -586,7 +586,7 @@ int main(int argc, char **argv)
 {
 	if (argc < 2) { fprintf(stderr, "usage: bwa <index|mem> ...  (libssgpu %s, %s)\n", ssg_version(), ssg_backend()); return 1; }
 	if (!strcmp(argv[1], "index")) return main_index(argc - 1, argv + 1);
-	if (!strcmp(argv[1], "mem")) return main_mem(argc - 1, argv + 1);
+	if (!strcmp(argv[1], "mem")) return ssg_fast_exit(main_mem(argc - 1, argv + 1));
 	fprintf(stderr, "[bwa] unknown command %s\n", argv[1]);
 	return 1;
 }

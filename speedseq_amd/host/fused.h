@@ -51,6 +51,16 @@ static inline void ssg_stamp(const char *who, const char *what)
 	struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
 	fprintf(stderr, "[stamp] %s %s %.3f\n", who, what, (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
 }
+/* the end of a stage's main(): everything it owed is written and closed; what is left is giving gigabytes of page-locked blocks, HBM arenas and mapped
+ * frames back one by one (destructors, the HIP runtime's exit handlers) -- the kernel does that wholesale when the process is gone.  SSG_FAST_EXIT=0: the long way. */
+#include <unistd.h>
+static inline int ssg_fast_exit(int rc)
+{
+	const char *e = getenv("SSG_FAST_EXIT");
+	if (e && !strcmp(e, "0")) return rc;
+	fflush(stdout); fflush(stderr);
+	_exit(rc);
+}
 #define FU_MAGIC "SSGFUSE1"
 enum { FU_HEADER = 1, FU_BATCH = 2, FU_MAIN = 3, FU_END = 4, FU_REF = 5 };
 struct fu_frame_t { uint32_t type, zero; uint64_t len; };

@@ -520,7 +520,7 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 }
 
 static int main_(int argc, char **argv);
-int main(int argc, char **argv) { ssg_stamp("samblaster", "start"); const int rc = main_(argc, argv); ssg_stamp("samblaster", "end"); return rc; }
+int main(int argc, char **argv) { ssg_stamp("samblaster", "start"); const int rc = main_(argc, argv); ssg_stamp("samblaster", "end"); return ssg_fast_exit(rc); }
 static int main_(int argc, char **argv)
 {
 	ssg_sbl_opt_t o; ssg_sbl_opt_init(&o);
