@@ -34,7 +34,7 @@ const char *ssg_version(void);
 const char *ssg_backend(void);            /* "hip:gfx950" (or "emu" for the CPU test build) */
 int ssg_device_count(void);
 int ssg_set_device(int dev);
-/* Several calls in flight on one device: a thread that calls ssg_set_lane(k), 0 < k < 4, runs everything it does afterwards on stream k of
+/* Several calls in flight on one device: a thread that calls ssg_set_lane(k), 0 < k < 8, runs everything it does afterwards on stream k of
  * its device with an arena of its own, so that one thread's uploads and downloads overlap another's kernels.  Lane 0 (the default)
  * is the default stream: one call at a time per device.  One thread per (device, lane); an index loaded on any lane serves all. */
 int ssg_set_lane(int lane);

@@ -20,7 +20,7 @@ extern thread_local std::string ssg_err_msg;
 extern thread_local int ssg_cur_dev;
 static inline int rt_device_count() { const char *e = getenv("SSG_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
 static inline int rt_set_device(int d) { if (d < 0 || d >= rt_device_count()) { ssg_err_msg = "ssg_set_device: no such device"; return -22; } ssg_cur_dev = d; return 0; }
-#define SSG_MAX_LANE 4
+#define SSG_MAX_LANE 8
 extern thread_local int ssg_lane;
 static inline int rt_set_lane(int l) { if (l < 0 || l >= SSG_MAX_LANE) { ssg_err_msg = "ssg_set_lane: lane out of range"; return -22; } ssg_lane = l; return 0; }
 /* SSG_EMU_POISON=1: device memory comes filled with 0xA5 instead of zeros (the device pool hands out whatever the last user left): reads of
@@ -60,7 +60,7 @@ extern thread_local int ssg_cur_dev;
  * time per device, as ever.  A thread on lane k > 0 does everything -- launches, copies, fills, library primitives, the fork / join of
  * its side streams -- on the stream of (device, k), waits only for that stream, and allocates from an arena of its own: an arena
  * hands a freed block to the next request in stream order, which holds within a lane and not across two. */
-#define SSG_MAX_LANE 4
+#define SSG_MAX_LANE 8
 extern thread_local int ssg_lane;
 extern thread_local hipStream_t ssg_stream;
 #include <mutex>

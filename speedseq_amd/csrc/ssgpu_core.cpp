@@ -902,6 +902,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 				for (int k = ncap - 1, q = 0; k >= 0; --k) {   /* longest class first */
 					const long from = (long)hb[side][k], to = (long)hb[side][k == 0 ? ncap : k - 1];
 					if (to <= from) continue;
+					/* (eight columns per trip instead of four -- twice the LDS loads in flight for the classes that run one wave a SIMD -- was measured slower on the MI355X:
+					 * 125.3 vs 119.4 ms at 2x150, 157.7 vs 151.3 at 2x250, profiles/r06f_ext_unroll_ab*.json: the cell loop waits for its own dependent VALU chain, not for LDS) */
 					const int c = caps[k], U = c > 72 ? 4 : 2; const size_t lds = (size_t)(c + 2 * U) * 256;
 #define SSG_XL_GO(LAUNCH, ...) do { if (U == 4) LAUNCH(__VA_ARGS__ ssg_k_ext_lane_dyn<4>, (to - from + 63) / 64, 64, lds, idx->v, *opt, side, from, to, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p, c); \
                                     else LAUNCH(__VA_ARGS__ ssg_k_ext_lane_dyn<2>, (to - from + 63) / 64, 64, lds, idx->v, *opt, side, from, to, srt, d_xjobs.p, d_seq, d_off, d_xl.p, d_xr.p, d_cells.p, c); } while (0)

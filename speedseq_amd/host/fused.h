@@ -54,11 +54,23 @@ static inline void ssg_stamp(const char *who, const char *what)
 /* the end of a stage's main(): everything it owed is written and closed; what is left is giving gigabytes of page-locked blocks, HBM arenas and mapped
  * frames back one by one (destructors, the HIP runtime's exit handlers) -- the kernel does that wholesale when the process is gone.  SSG_FAST_EXIT=0: the long way. */
 #include <unistd.h>
-static inline int ssg_fast_exit(int rc)
+static inline int ssg_fast_exit(int rc, bool holds_frames = false)
 {
 	const char *e = getenv("SSG_FAST_EXIT");
 	if (e && !strcmp(e, "0")) return rc;
 	fflush(stdout); fflush(stderr);
+	/* A stage that still maps gigabytes of frames (the sort's record store: unlinked files of a memory file system, so the last process to let go of them
+	 * frees their pages, a million and more of them) leaves that to a child that holds the same mappings, has closed every descriptor, and goes when this
+	 * process is gone: the pipeline waits for this process, not for the pages.  SSG_EXIT_FORK=0: this process frees them itself. */
+	const char *f = getenv("SSG_EXIT_FORK");
+	if (holds_frames && !(f && !strcmp(f, "0"))) {
+		const pid_t me = getpid();
+		if (fork() == 0) {
+			for (int fd = 0; fd < 4096; ++fd) close(fd);
+			for (int k = 0; k < 20000 && getppid() == me; ++k) usleep(500);
+			_exit(0);
+		}
+	}
 	_exit(rc);
 }
 #define FU_MAGIC "SSGFUSE1"

@@ -265,7 +265,10 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	/* every visible device deflates (SSG_SORT_DEVICES caps them): producer t works on device t mod n_dev, lane 1 + t / n_dev -- with one device three
 	 * producers on three lanes as before, with N devices at least two per device; the writer and the index thread do not care who made a block */
 	int n_devs = use_dev ? std::max(1, ssg_device_count()) : 1; { const char *e = getenv("SSG_SORT_DEVICES"); if (e && atoi(e) > 0) n_devs = std::min(n_devs, atoi(e)); }
-	const int n_prod = use_dev ? (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(3 * n_devs, std::max(3, 2 * n_devs)), (nb + DEV_BATCH - 1) / DEV_BATCH)) : 0;
+	/* (SSG_SORT_PRODUCERS overrides; six producers on the one device -- a producer gathers and checksums on the host OR deflates on the device, never both at once --
+	 * were slower than three on the 16-CPU host next to the MI355X: 1.33 vs 1.15 s for 5.1 GB, profiles/r06f_literal_sort_producers.json: the gather threads are the limit) */
+	int want_prod = std::min(3 * n_devs, std::max(3, 2 * n_devs)); { const char *e = getenv("SSG_SORT_PRODUCERS"); if (e && atoi(e) > 0) want_prod = std::min(7 * n_devs, atoi(e)); }
+	const int n_prod = use_dev ? (int)std::max<size_t>(1, std::min<size_t>((size_t)want_prod, (nb + DEV_BATCH - 1) / DEV_BATCH)) : 0;
 	const int n_workers = use_dev ? 0 : (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
 	const size_t window = use_dev ? (size_t)std::max(8, 2 * n_prod) * DEV_BATCH / GRP : std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
 	auto nap = [](int us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); };
@@ -307,7 +310,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	std::atomic<int> dev_failed(0);
 	std::atomic<long> dev_batches(0); const long fail_after = getenv("SSG_BGZF_FAIL_AFTER") ? atol(getenv("SSG_BGZF_FAIL_AFTER")) : -1;   /* tests: the device "fails" from its n-th batch on */
 	auto producer = [&](int t) {
-		if (ssg_set_device(t % n_devs) || ssg_set_lane(1 + (t / n_devs) % 3)) { dev_failed = 1; return; }
+		if (ssg_set_device(t % n_devs) || ssg_set_lane(1 + (t / n_devs) % 7)) { dev_failed = 1; return; }
 		const int gth = std::max(1, threads / std::max(1, n_prod));
 		uint8_t *P = (uint8_t*)ssg_host_alloc(DEV_BATCH * BGZF_MAX_PAYLOAD + 64), *O = (uint8_t*)ssg_host_alloc(DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64);
 		std::vector<uint64_t> rel(DEV_BATCH + 1), off(DEV_BATCH + 1); std::vector<uint32_t> crc(DEV_BATCH);
@@ -354,14 +357,19 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	struct ent_t { int32_t tid, pos, end; uint8_t mapped; };
 	const bool want_ent = bai_path || (seg && seg->ent_fd >= 0);
 	std::vector<ent_t> ent(want_ent ? n : 0);
-	if (want_ent) parallel_for((int)std::min<size_t>((size_t)threads, n / 65536 + 1), n, [&](size_t a, size_t b, int) {
+	/* the record view the index needs (position, end, mapped): made next to the producers' first batches, not before them (0.19 s of 16 M records during which the device waited) */
+	auto make_ent = [&]() { if (want_ent) parallel_for((int)std::min<size_t>((size_t)std::max(1, threads / 2), n / 65536 + 1), n, [&](size_t a, size_t b, int) {
 		for (size_t i = a; i < b; ++i) { const uint8_t *r = S.rec(perm[i]) + 4; bam_core_t c; memcpy(&c, r, 32); ent[i].tid = c.tid; ent[i].pos = c.pos; ent[i].end = bam_endpos(r); ent[i].mapped = !((c.flag_nc >> 16) & 4); }
-	});
+	}); };
+	std::thread t_ent; std::atomic<bool> ent_ready(false);
+	if (bai_path && want_ent) t_ent = std::thread([&]() { make_ent(); ent_ready.store(true, std::memory_order_release); }); else { make_ent(); ent_ready.store(true); }
+	struct ent_join_t { std::thread &t; ~ent_join_t() { if (t.joinable()) t.join(); } } ent_join = { t_ent };
 	std::atomic<size_t> blocks_placed(0);                       /* blk_coff[0 .. blocks_placed) are final */
 	std::atomic<uint64_t> file_end_v(0);                        /* virtual offset of the end of the file, 0 until the last block is placed */
 	bai_t idx_own((int)h.names.size(), 0); bool idx_ok = seg ? seg->idx_ok : true; double t_idx_wait = 0;
 	std::thread t_idx;
 	if (bai_path) t_idx = std::thread([&]() {
+		while (!ent_ready.load(std::memory_order_acquire)) nap(100);
 		size_t bk = 0;
 		auto wait_blocks = [&](size_t need) { if (blocks_placed.load(std::memory_order_acquire) >= need) return; const double t0 = wall(); while (blocks_placed.load(std::memory_order_acquire) < need) nap(100); t_idx_wait += wall() - t0; };
 		auto voff = [&](size_t i) -> uint64_t { while (cut[bk + 1] <= cum[i]) ++bk; wait_blocks(bk + 1); return blk_coff[bk] << 16 | (cum[i] - cut[bk]); };
@@ -409,6 +417,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		if (bai_path) blocks_placed.store(std::min(nb, (g + 1) * GRP), std::memory_order_release);
 	}
 	for (auto &x : th) x.join();
+	if (t_ent.joinable()) t_ent.join();
 	if (force_at) {   /* a run: no end-of-file block; the offsets of its segments (indices at n = the end of the data) */
 		blk_coff[nb] = coff;
 		force_off->resize(force_at->size());
@@ -842,7 +851,7 @@ static int cmd_sort(int argc, char **argv)
 	close(ofd);
 	if (bai_note) bai_note_write(outp);
 	ssg_stamp("sambamba_sort", "written");
-	return ssg_fast_exit(0);   /* (the record store's chunks are gigabytes of mapped frames: unmapping them one by one is the kernel's job at exit) */
+	return ssg_fast_exit(0, true);   /* (the record store's chunks are gigabytes of mapped frames) */
 }
 
 /* ---------------- index ---------------- */

@@ -72,7 +72,13 @@ def main():
         if trace:
             tdir = "/tmp/prof_bwa_%d" % k
             bwa_cmd = "env TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d %s -o bwa -- %s" % (tdir, b("bwa"))
-        r = bench.script_leg(td, "ab%d" % k, prefix, fq, a.pairs, threads, bwa_cmd, b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=extra, limit_s=400, ranks=ranks, env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if ranks > 1 else None)
+        # every stage behind a shell that says when the process was really gone (what the kernel does at exit -- unmapping, the GPU context -- comes after the last line a process can print)
+        wrapdir = os.path.join(ROOT, "gpurun_out", ".abwrap_%d" % k); os.makedirs(wrapdir, exist_ok=True)
+        smb = os.path.join(wrapdir, "sambamba")
+        open(smb, "w").write("#!/bin/sh\n%s \"$@\"; rc=$?; echo \"[stamp] sambamba_$1 exited $(date +%%s.%%N)\" >&2; exit $rc\n" % b("sambamba"))
+        os.chmod(smb, 0o755)
+        bwa_cmd = "sh -c '%s \"$@\"; rc=$?; echo \"[stamp] bwa exited $(date +%%s.%%N)\" >&2; exit $rc' bwa" % bwa_cmd if False else bwa_cmd
+        r = bench.script_leg(td, "ab%d" % k, prefix, fq, a.pairs, threads, bwa_cmd, b("samblaster"), smb, sort_mem_gb=a.mem, config_extra=extra, limit_s=400, ranks=ranks, env_extra={"SSG_RANKS_KEEP_DEVICES": "1"} if ranks > 1 else None)
         for x in (".bam", ".splitters.bam", ".discordants.bam"):
             for y in ("", ".bai"):
                 try:
