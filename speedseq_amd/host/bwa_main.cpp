@@ -201,35 +201,6 @@ static int main_mem(int argc, char **argv)
 	                                         : new fq_feed_t(fp1, keep_comment, 16384, argv[ai + 1], parse_hint));
 	std::unique_ptr<fq_feed_t> feed2(!fp2 || devtext ? 0 : split ? new fq_feed_t(rs_provider(rs_tab, argv[ai + 2], true, rank, world, &fail, served), keep_comment, 16384, parse_hint)
 	                                                  : new fq_feed_t(fp2, keep_comment, 16384, argv[ai + 2], parse_hint));
-	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
-	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms
-	 * per million pairs: a run does not know how long its input is, so each device makes the copy once it has aligned this many pairs
-	 * (the point where the walk has been paid for once over; 0 = at load time).  Results do not depend on it. */
-	long densify_after = 32000000; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
-	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
-	{
-		std::vector<std::thread> ld;
-		for (int g = 0; g < n_dev; ++g) ld.emplace_back([&, g]() {
-			if (ssg_set_device(g) || ssg_index_load2(argv[ai], densify_after > 0, &idxs[(size_t)g])) { fprintf(stderr, "[bwa] fail to load the index on device %d: %s\n", g, ssg_last_error()); fail = 1; } });
-		for (std::thread &x : ld) x.join();
-	}
-	t_warm.join();
-	if (fail) { rk_mark_failed("bwa"); return 1; }
-	ssg_index_t *idx = idxs[0];
-	const double t_loaded = wall();
-	ssg_stamp("bwa", "index_loaded");
-	/* header: upstream bwa_print_sam_hdr + @PG */
-	std::string hdr;
-	for (int i = 0; i < ssg_index_n_ctg(idx); ++i) { char b[64]; snprintf(b, sizeof(b), "\tLN:%d\n", ssg_index_len(idx, i)); hdr += "@SQ\tSN:"; hdr += ssg_index_name(idx, i); hdr += b; }
-	if (!rg.empty()) { hdr += rg; hdr += '\n'; }
-	{ hdr += "@PG\tID:bwa\tPN:bwa\tVN:0.7.12-ssgpu\tCL:bwa"; for (int i = 0; i < argc; ++i) { hdr += ' '; hdr += argv[i]; } hdr += '\n'; }
-#ifdef F_SETPIPE_SZ
-	(void)fcntl(1, F_SETPIPE_SZ, 1 << 20);   /* fewer wake-ups on the pipe to samblaster */
-#endif
-	if (fused) fu_seg_sweep();
-	if (fused) { if (!fu_write_full(1, FU_MAGIC, 8) || !fu_write_frame(1, FU_HEADER, hdr.data(), hdr.size())) { perror("[bwa] write"); return 1; } }
-	else if (!fu_write_full(1, hdr.data(), hdr.size())) { perror("[bwa] write"); return 1; }
-
 	/* Overlapped stages, one batch each: (1) assemble upstream's batches from the reader threads' blocks, (2) align on an MI355X,
 	 * (3) format (SAM text, or BAM records in fused mode; threads inside libssgpu) and (4) write.  Several upstream batches
 	 * (bseq_read's chunk_size * n_threads bases, even read count: the scope of the insert-size model) travel to the GPU in one call. */
@@ -388,6 +359,38 @@ static int main_mem(int argc, char **argv)
 		} else parsed_asm(*feed1, feed2.get(), 0, 0);
 		to_gpu.close();
 	});
+	/* the index travels to the device(s) while the assembler is already at work: by the time it is there the first device calls are waiting (until round 6 the
+	 * assembler started afterwards and the first call, alone on the device, began a scan of half a million pairs later) */
+	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
+	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms
+	 * per million pairs: a run does not know how long its input is, so each device makes the copy once it has aligned this many pairs
+	 * (the point where the walk has been paid for once over; 0 = at load time).  Results do not depend on it. */
+	long densify_after = 32000000; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
+	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
+	{
+		std::vector<std::thread> ld;
+		for (int g = 0; g < n_dev; ++g) ld.emplace_back([&, g]() {
+			if (ssg_set_device(g) || ssg_index_load2(argv[ai], densify_after > 0, &idxs[(size_t)g])) { fprintf(stderr, "[bwa] fail to load the index on device %d: %s\n", g, ssg_last_error()); fail = 1; } });
+		for (std::thread &x : ld) x.join();
+	}
+	t_warm.join();
+	ssg_index_t *idx = idxs[0];
+	const double t_loaded = wall();
+	ssg_stamp("bwa", "index_loaded");
+	/* header: upstream bwa_print_sam_hdr + @PG */
+	std::string hdr;
+	if (!fail) for (int i = 0; i < ssg_index_n_ctg(idx); ++i) { char b[64]; snprintf(b, sizeof(b), "\tLN:%d\n", ssg_index_len(idx, i)); hdr += "@SQ\tSN:"; hdr += ssg_index_name(idx, i); hdr += b; }
+	if (!rg.empty()) { hdr += rg; hdr += '\n'; }
+	{ hdr += "@PG\tID:bwa\tPN:bwa\tVN:0.7.12-ssgpu\tCL:bwa"; for (int i = 0; i < argc; ++i) { hdr += ' '; hdr += argv[i]; } hdr += '\n'; }
+#ifdef F_SETPIPE_SZ
+	(void)fcntl(1, F_SETPIPE_SZ, 1 << 20);   /* fewer wake-ups on the pipe to samblaster */
+#endif
+	if (fused) fu_seg_sweep();
+	/* (the assembler is running: a failure from here on is flagged and runs through the common way out, which stops and joins every stage) */
+	if (fail) {}
+	else if (fused) { if (!fu_write_full(1, FU_MAGIC, 8) || !fu_write_frame(1, FU_HEADER, hdr.data(), hdr.size())) { perror("[bwa] write"); fail = 1; } }
+	else if (!fu_write_full(1, hdr.data(), hdr.size())) { perror("[bwa] write"); fail = 1; }
+
 	std::vector<std::thread> t_gpu;
 	/* per device: calls hold the index shared, the one-off densification holds it alone */
 	struct dev_state_t { std::shared_mutex mu; std::atomic<long> pairs{0}; std::atomic<bool> dense{false}; std::mutex tm; };

@@ -54,24 +54,47 @@ static inline void ssg_stamp(const char *who, const char *what)
 /* the end of a stage's main(): everything it owed is written and closed; what is left is giving gigabytes of page-locked blocks, HBM arenas and mapped
  * frames back one by one (destructors, the HIP runtime's exit handlers) -- the kernel does that wholesale when the process is gone.  SSG_FAST_EXIT=0: the long way. */
 #include <unistd.h>
-static inline int ssg_fast_exit(int rc, bool holds_frames = false)
+static inline int ssg_fast_exit(int rc)
 {
 	const char *e = getenv("SSG_FAST_EXIT");
 	if (e && !strcmp(e, "0")) return rc;
 	fflush(stdout); fflush(stderr);
-	/* A stage that still maps gigabytes of frames (the sort's record store: unlinked files of a memory file system, so the last process to let go of them
-	 * frees their pages, a million and more of them) leaves that to a child that holds the same mappings, has closed every descriptor, and goes when this
-	 * process is gone: the pipeline waits for this process, not for the pages.  SSG_EXIT_FORK=0: this process frees them itself. */
-	const char *f = getenv("SSG_EXIT_FORK");
-	if (holds_frames && !(f && !strcmp(f, "0"))) {
-		const pid_t me = getpid();
-		if (fork() == 0) {
-			for (int fd = 0; fd < 4096; ++fd) close(fd);
-			for (int k = 0; k < 20000 && getppid() == me; ++k) usleep(500);
-			_exit(0);
-		}
-	}
 	_exit(rc);
+}
+/* A stage whose LAST act is long -- `sambamba sort` ends holding gigabytes of mapped frames, page-locked blocks and a GPU context, and the kernel needs
+ * 0.4 - 0.9 s to take all that back when the process goes (profiles/r06g_literal_exit_times.json: `written' to `exited') -- runs as a worker behind a
+ * waiter: the process the pipeline started forks before it has a thread or a device, the child does the stage's work and says so through a pipe when the
+ * output is complete and closed, the waiter exits with that status at once and the script goes on while the worker is taken apart.  A worker that dies
+ * without saying anything is waited for and its status passed on.  SSG_DETACH=0: one process, as ever. */
+#include <sys/wait.h>
+static int ssg_worker_fd = -1;
+static inline void ssg_worker_begin()
+{
+	const char *e = getenv("SSG_DETACH");
+	if (e && !strcmp(e, "0")) return;
+	int pfd[2];
+	if (pipe(pfd) != 0) return;
+	const pid_t c = fork();
+	if (c < 0) { close(pfd[0]); close(pfd[1]); return; }
+	if (c == 0) { close(pfd[0]); ssg_worker_fd = pfd[1]; return; }   /* the worker: goes on as the stage */
+	close(pfd[1]);
+	unsigned char st = 0; ssize_t n;
+	do n = read(pfd[0], &st, 1); while (n < 0 && errno == EINTR);
+	if (n == 1) _exit(st);
+	int ws = 0; pid_t w;
+	do w = waitpid(c, &ws, 0); while (w < 0 && errno == EINTR);
+	_exit(w == c && WIFEXITED(ws) ? WEXITSTATUS(ws) : 1);
+}
+/* the worker's output is complete: the waiter may go.  The worker's own descriptors are closed first -- whoever reads the pipeline's stderr must not wait for the teardown */
+static inline void ssg_worker_done(int rc)
+{
+	if (ssg_worker_fd < 0) return;
+	fflush(stdout); fflush(stderr);
+	const int fd = ssg_worker_fd; ssg_worker_fd = -1;
+	for (int k = 0; k < 3; ++k) close(k);
+	const unsigned char st = (unsigned char)rc;
+	ssize_t n; do n = write(fd, &st, 1); while (n < 0 && errno == EINTR);
+	close(fd);
 }
 #define FU_MAGIC "SSGFUSE1"
 enum { FU_HEADER = 1, FU_BATCH = 2, FU_MAIN = 3, FU_END = 4, FU_REF = 5 };

@@ -851,7 +851,8 @@ static int cmd_sort(int argc, char **argv)
 	close(ofd);
 	if (bai_note) bai_note_write(outp);
 	ssg_stamp("sambamba_sort", "written");
-	return ssg_fast_exit(0, true);   /* (the record store's chunks are gigabytes of mapped frames) */
+	ssg_worker_done(0);         /* (the record store's chunks are gigabytes of mapped frames: the script does not wait for them to be unmapped) */
+	return ssg_fast_exit(0);
 }
 
 /* ---------------- index ---------------- */
@@ -1017,7 +1018,7 @@ int main(int argc, char **argv)
 	(void)fcntl(0, F_SETPIPE_SZ, 1 << 20); (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);   /* the reference's pipelines: fewer wake-ups per megabyte (fails harmlessly on files) */
 #endif
 	if (!strcmp(argv[1], "view")) return cmd_view(argc - 2, argv + 2);
-	if (!strcmp(argv[1], "sort")) { ssg_stamp("sambamba_sort", "start"); const int rc = cmd_sort(argc - 2, argv + 2); ssg_stamp("sambamba_sort", "end"); return ssg_fast_exit(rc); }
+	if (!strcmp(argv[1], "sort")) { ssg_worker_begin(); ssg_stamp("sambamba_sort", "start"); const int rc = cmd_sort(argc - 2, argv + 2); ssg_stamp("sambamba_sort", "end"); ssg_worker_done(rc); return ssg_fast_exit(rc); }
 	if (!strcmp(argv[1], "index")) { ssg_stamp("sambamba_index", "start"); const int rc = cmd_index(argc - 2, argv + 2); ssg_stamp("sambamba_index", "end"); return rc; }
 	if (!strcmp(argv[1], "flagstat")) return cmd_flagstat(argc - 2, argv + 2);
 	if (!strcmp(argv[1], "merge")) return cmd_merge(argc - 2, argv + 2);
