@@ -312,20 +312,47 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	auto producer = [&](int t) {
 		if (ssg_set_device(t % n_devs) || ssg_set_lane(1 + (t / n_devs) % 7)) { dev_failed = 1; return; }
 		const int gth = std::max(1, threads / std::max(1, n_prod));
-		uint8_t *P = (uint8_t*)ssg_host_alloc(DEV_BATCH * BGZF_MAX_PAYLOAD + 64), *O = (uint8_t*)ssg_host_alloc(DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64);
-		std::vector<uint64_t> rel(DEV_BATCH + 1), off(DEV_BATCH + 1); std::vector<uint32_t> crc(DEV_BATCH);
-		long my_g = 0, my_d = 0, my_w = 0;
-		for (size_t b0 = (size_t)t * DEV_BATCH; b0 < nb && P && O && !dev_failed.load(); b0 += (size_t)n_prod * DEV_BATCH) {
-			const size_t b1 = std::min(nb, b0 + DEV_BATCH), n_b = b1 - b0, g0 = b0 / GRP, g1 = (b1 + GRP - 1) / GRP;
-			if (g0 >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g0 >= next_write.load(std::memory_order_acquire) + window && !dev_failed.load()) nap(200); my_w += (long)((wall() - t0) * 1e6); }
-			if (dev_failed.load()) break;   /* (the writer is waiting for the producers to stop before it hands the rest to the host's pool) */
-			const double t0 = wall();
-			for (size_t k = 0; k <= n_b; ++k) rel[k] = cut[b0 + k] - cut[b0];
-			parallel_for((int)std::min<size_t>((size_t)gth, n_b / 8 + 1), n_b, [&](size_t a, size_t e, int) {
-				for (size_t k = a; k < e; ++k) { const size_t w = gather_block(b0 + k, P + rel[k]); crc[k] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), P + rel[k], (uInt)w); }
-			});
+		/* two slots: a helper thread gathers and checksums batch k + 1 on the host while this one has batch k deflated on the device (until round 6 a producer did one
+		 * after the other, and the device waited whenever all producers were gathering: 0.74 s of 1.15 s for 5.1 GB, profiles/r06f_literal_sort_producers.json) */
+		struct slot_t { uint8_t *P; std::vector<uint64_t> rel; std::vector<uint32_t> crc; size_t b0, n_b; std::atomic<int> state; slot_t() : P(0), b0(0), n_b(0), state(0) {} };   /* state: 0 free, 1 gathered, 2 no more batches */
+		slot_t slot[2];
+		for (slot_t &sl : slot) { sl.P = (uint8_t*)ssg_host_alloc(DEV_BATCH * BGZF_MAX_PAYLOAD + 64); sl.rel.resize(DEV_BATCH + 1); sl.crc.resize(DEV_BATCH); }
+		uint8_t *O = (uint8_t*)ssg_host_alloc(DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64);
+		std::vector<uint64_t> off(DEV_BATCH + 1);
+		std::atomic<long> my_g(0); long my_d = 0; std::atomic<long> my_w(0);
+		const bool mem_ok = slot[0].P && slot[1].P && O;
+		std::thread gatherer([&]() {
+			int k = 0;
+			for (size_t b0 = (size_t)t * DEV_BATCH; b0 < nb && mem_ok && !dev_failed.load(); b0 += (size_t)n_prod * DEV_BATCH, k ^= 1) {
+				slot_t &sl = slot[k];
+				while (sl.state.load(std::memory_order_acquire) != 0 && !dev_failed.load()) nap(100);
+				const size_t b1 = std::min(nb, b0 + DEV_BATCH), n_b = b1 - b0, g0 = b0 / GRP;
+				if (g0 >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g0 >= next_write.load(std::memory_order_acquire) + window && !dev_failed.load()) nap(200); my_w += (long)((wall() - t0) * 1e6); }
+				if (dev_failed.load()) break;   /* (the writer is waiting for the producers to stop before it hands the rest to the host's pool) */
+				const double t0 = wall();
+				for (size_t i = 0; i <= n_b; ++i) sl.rel[i] = cut[b0 + i] - cut[b0];
+				parallel_for((int)std::min<size_t>((size_t)gth, n_b / 8 + 1), n_b, [&](size_t a, size_t e, int) {
+					for (size_t i = a; i < e; ++i) { const size_t w = gather_block(b0 + i, sl.P + sl.rel[i]); sl.crc[i] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), sl.P + sl.rel[i], (uInt)w); }
+				});
+				my_g += (long)((wall() - t0) * 1e6);
+				sl.b0 = b0; sl.n_b = n_b;
+				sl.state.store(1, std::memory_order_release);
+			}
+			for (int j = 0; j < 2; ++j, k ^= 1) {   /* the end: in the slot order the consumer follows */
+				slot_t &sl = slot[k];
+				while (sl.state.load(std::memory_order_acquire) != 0 && !dev_failed.load()) nap(100);
+				if (dev_failed.load()) break;
+				sl.state.store(2, std::memory_order_release);
+			}
+		});
+		for (int k = 0; mem_ok; k ^= 1) {
+			slot_t &sl = slot[k];
+			int st;
+			while ((st = sl.state.load(std::memory_order_acquire)) == 0 && !dev_failed.load()) nap(50);
+			if (st != 1) break;
+			const size_t b0 = sl.b0, n_b = sl.n_b, b1 = b0 + n_b, g0 = b0 / GRP, g1 = (b1 + GRP - 1) / GRP;
 			const double t1 = wall();
-			if ((fail_after >= 0 && dev_batches.fetch_add(1) >= fail_after) || ssg_bgzf_deflate(P, rel.data(), (long)n_b, O, (uint64_t)DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64, off.data())) {
+			if ((fail_after >= 0 && dev_batches.fetch_add(1) >= fail_after) || ssg_bgzf_deflate(sl.P, sl.rel.data(), (long)n_b, O, (uint64_t)DEV_BATCH * (BGZF_MAX_PAYLOAD + 5) + 64, off.data())) {
 				fprintf(stderr, "[sambamba] sort: BGZF deflate on the device failed: %s\n", fail_after >= 0 ? "(SSG_BGZF_FAIL_AFTER: test)" : ssg_last_error()); dev_failed = 1; break; }
 			const double t2 = wall();
 			parallel_for((int)std::min<size_t>((size_t)std::min(gth, 8), g1 - g0), g1 - g0, [&](size_t a, size_t e, int) {
@@ -333,24 +360,27 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 				for (size_t g = g0 + a; g < g0 + e; ++g) {
 					std::vector<uint8_t> ob; std::vector<uint32_t> bsz;
 					for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
-						const size_t k = bk - b0, clen = (size_t)(off[k + 1] - off[k]), bsize = 18 + clen + 8, at = ob.size();
+						const size_t i = bk - b0, clen = (size_t)(off[i + 1] - off[i]), bsize = 18 + clen + 8, at = ob.size();
 						ob.resize(at + bsize);
 						uint8_t *d = ob.data() + at;
 						memcpy(d, hdr, 16); d[16] = (uint8_t)((bsize - 1) & 0xff); d[17] = (uint8_t)((bsize - 1) >> 8);
-						memcpy(d + 18, O + off[k], clen);
-						const uint32_t isz = (uint32_t)(rel[k + 1] - rel[k]);
-						memcpy(d + 18 + clen, &crc[k], 4); memcpy(d + 18 + clen + 4, &isz, 4);
+						memcpy(d + 18, O + off[i], clen);
+						const uint32_t isz = (uint32_t)(sl.rel[i + 1] - sl.rel[i]);
+						memcpy(d + 18 + clen, &sl.crc[i], 4); memcpy(d + 18 + clen + 4, &isz, 4);
 						bsz.push_back((uint32_t)bsize);
 					}
 					grp[g].bytes.swap(ob); grp[g].bsz.swap(bsz);
 					done[g].store(1, std::memory_order_release);
 				}
 			});
-			my_g += (long)((t1 - t0) * 1e6); my_d += (long)((t2 - t1) * 1e6); (void)my_w;
+			my_d += (long)((t2 - t1) * 1e6);
+			sl.state.store(0, std::memory_order_release);
 		}
-		if (!P || !O) dev_failed = 1;
-		ssg_host_free(P); ssg_host_free(O);
-		us_gather += my_g; us_deflate += my_d; us_window += my_w;
+		if (!mem_ok) dev_failed = 1;
+		gatherer.join();
+		for (slot_t &sl : slot) ssg_host_free(sl.P);
+		ssg_host_free(O);
+		us_gather += my_g.load(); us_deflate += my_d; us_window += my_w.load();
 	};
 	/* the index `sambamba index` would make of this file (cmd_index below: same bai_t calls, same virtual offsets), built by a thread of
 	 * its own that follows the writer: a record's virtual offset is known as soon as the group holding its block has its file offset */
