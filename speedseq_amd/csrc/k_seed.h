@@ -252,7 +252,7 @@ __global__ void ssg_k_sa_densify_walk(ssg_index_view_t ix, int new_intv, uint64_
 		if (!wv_ballot(have)) break;
 		if (have) {
 			if (r == ix.primary) r = 0;
-			else { const int c = ssg_bwt_sym(ix, r - (r > ix.primary)); r = ix.L2[c] + ssg_occ1(ix, r, c); }
+			else r = ssg_lf_step(ix, r);
 			--v;
 			if ((r & omask) == 0) have = false;
 			else if ((r & nmask) == 0) sa_new[r >> nshift] = v;

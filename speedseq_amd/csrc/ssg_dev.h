@@ -196,6 +196,28 @@ SSG_DEVFN int ssg_bwt_sym(const ssg_index_view_t &ix, uint64_t k)
 	const uint32_t *p = ix.bwt + ((k >> 7) << 4) + 8;
 	return p[(k & 127) >> 4] >> ((~k & 15) << 1) & 3;
 }
+/* One LF step of upstream bwt_sa / bwt_invPsi: for a row k other than the primary, the row of the suffix one position to the left -- L2[c] + occ(k, c) with
+ * c the row's BWT symbol.  Symbol and rank lie in the same 64-byte block (stored index k - (k > primary) for both), fetched here as four independent 16-byte
+ * loads: one round trip and four requests a step, where ssg_bwt_sym + ssg_occ1 made up to ten 4-byte requests in two dependent trips -- and the request rate
+ * of random lines, not their bytes, is what the locate stage and the denser-table walk run at. */
+SSG_DEVFN uint64_t ssg_lf_step(const ssg_index_view_t &ix, uint64_t k)
+{
+	const uint64_t x = k - (k > ix.primary);
+	struct alignas(16) q16 { uint32_t v[4]; };
+	const q16 *pb = (const q16*)(ix.bwt + ((x >> 7) << 4));
+	const q16 c01 = pb[0], c23 = pb[1], w0 = pb[2], w1 = pb[3];
+	const uint32_t w[8] = { w0.v[0], w0.v[1], w0.v[2], w0.v[3], w1.v[0], w1.v[1], w1.v[2], w1.v[3] };
+	const int r = (int)(x & 127), wi = r >> 4;
+	uint32_t ww = 0;
+	SSG_UNROLL for (int i = 0; i < 8; ++i) if (i == wi) ww = w[i];
+	const int c = (int)(ww >> ((~r & 15) << 1)) & 3;
+	const uint64_t cnt[4] = { (uint64_t)c01.v[0] | (uint64_t)c01.v[1] << 32, (uint64_t)c01.v[2] | (uint64_t)c01.v[3] << 32, (uint64_t)c23.v[0] | (uint64_t)c23.v[1] << 32, (uint64_t)c23.v[2] | (uint64_t)c23.v[3] << 32 };
+	uint64_t n = 0;
+	SSG_UNROLL for (int i = 0; i < 4; ++i) if (i == c) n = cnt[i];
+	const int upto = r + 1;
+	SSG_UNROLL for (int i = 0; i < 8; ++i) { int ns = upto - i * 16; ns = ns < 0 ? 0 : ns > 16 ? 16 : ns; n += (uint64_t)ssg_cnt16(w[i], c, ns); }
+	return ix.L2[c] + n;
+}
 /* upstream bwt_extend */
 SSG_DEVFN void ssg_bwt_extend(const ssg_index_view_t &ix, const ssg_intv_t &ik, ssg_intv_t ok[4], int is_back)
 {
@@ -312,9 +334,7 @@ SSG_DEVFN uint64_t ssg_bwt_sa(const ssg_index_view_t &ix, uint64_t k)
 	while (k & mask) {
 		++sa;
 		if (k == ix.primary) { k = 0; continue; }
-		uint64_t x = k - (k > ix.primary);
-		int c = ssg_bwt_sym(ix, x);
-		k = ix.L2[c] + ssg_occ1(ix, k, c);
+		k = ssg_lf_step(ix, k);
 	}
 	return sa + ix.sa[k / (uint64_t)ix.sa_intv];
 }
