@@ -137,3 +137,59 @@ def _check_outputs_min(out):
     for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
         assert os.path.getsize(out + suffix) > 0 and os.path.exists(out + suffix + ".bai")
     assert int(subprocess.check_output([SAMTOOLS, "view", "-c", out + ".bam"])) >= 1400
+
+
+# ---- BASELINE.json configs[0] with the reference's own read simulator ----
+WGSIM = os.path.join(ROOT, "oracle", "_ref", "wgsim")
+
+
+def _wgsim_fastq(tmp_path, n_pairs, seed=11):
+    """example/run_speedseq.sh:4-10 aligns data/NA12878.20slice.30X.fastq.gz, which the reference tree lists as a missing blob; SURVEY.md 8d prescribes its
+    stand-in: 30x of the example FASTA from the reference's wgsim (src/samtools-1.3.1/misc/wgsim.c:438-463), interleaved and gzipped"""
+    import gzip
+    if not os.path.exists(WGSIM) and os.path.exists("/root/reference"):
+        subprocess.check_call(["sh", os.path.join(ROOT, "oracle", "build_ref_tools.sh")])
+    if not os.path.exists(WGSIM):
+        pytest.skip("the reference's wgsim (oracle/_ref) is not built")
+    r1, r2 = str(tmp_path / "w1.fq"), str(tmp_path / "w2.fq")
+    subprocess.check_call([WGSIM, "-S", str(seed), "-N", str(n_pairs), "-1", "150", "-2", "150", "-d", "400", "-s", "50", "-e", "0.005", "-r", "0.001", "-R", "0.15", "-X", "0.3",
+                           EXAMPLE_FA, r1, r2], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    fq = str(tmp_path / "wgsim.fq.gz")
+    with open(r1) as a, open(r2) as b, gzip.open(fq, "wt", compresslevel=1) as out:
+        while True:
+            x = [a.readline() for _ in range(4)]
+            y = [b.readline() for _ in range(4)]
+            if not x[0] or not y[0]:
+                break
+            out.write("".join(x)); out.write("".join(y))
+    return fq
+
+
+def _check_wgsim_outputs(out, n_pairs):
+    for suffix in (".bam", ".splitters.bam", ".discordants.bam"):
+        assert os.path.getsize(out + suffix) > 0 and os.path.exists(out + suffix + ".bai")
+    assert int(subprocess.check_output([SAMTOOLS, "view", "-c", "-F", "2304", out + ".bam"])) == 2 * n_pairs      # every read once as a primary line
+    assert "SO:coordinate" in subprocess.check_output([SAMTOOLS, "view", "-H", out + ".bam"], text=True)
+
+
+def test_reference_align_script_on_wgsim_reads_emulated(tmp_path, emu_lib):
+    """config 1 at a size the host emulation finishes in a minute: reads of the reference's wgsim, the unmodified script, product sources vs the oracle's executables, three BAMs"""
+    _need_tools()
+    fq = _wgsim_fastq(tmp_path, 1500)
+    exp = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", fq)
+    out = _run_align(str(tmp_path / "emu"), os.path.join(EMU, "bwa_emu"), os.path.join(EMU, "samblaster_emu"), fq, sambamba=os.path.join(EMU, "sambamba_emu"))
+    _check_wgsim_outputs(out, 1500)
+    _compare(out, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_reference_align_script_on_wgsim_reads_config1(tmp_path, gpu_lib, fused):
+    """config 1 as SURVEY.md 8d states it -- wgsim -S 11 -N 32164 (30x of the 321 635-base example) -- on the MI355X, text and fused hand-off, against the oracle's run"""
+    _need_tools()
+    fq = _wgsim_fastq(tmp_path, 32164)
+    exp = _run_align(str(tmp_path / "orc"), ORC, ORC + " samblaster", fq, n_threads=8)
+    out = _run_align(str(tmp_path / "gpu"), os.path.join(ROOT, "bin", "bwa"), os.path.join(ROOT, "bin", "samblaster"), fq, sambamba=os.path.join(ROOT, "bin", "sambamba"),
+                     config_extra="export SSG_FUSED=1\n" if fused else "")
+    _check_wgsim_outputs(out, 32164)
+    _compare(out, exp)
