@@ -842,6 +842,17 @@ def main():
                                       "MC/MQ source lines reproduce the three streams of the oracle's samblaster line for line; index files written by ssg_index_save"
                                       % ("" if full else ", first %d pairs" % ns)),
                              "index_files_roundtrip_s": round(t_files, 1)}
+            try:   # the one container of the hot path that was a shared deviation of oracle and kernels until round 6 (upstream mem_chain keeps the chains in klib's B-tree)
+                ne = min(2 * ns, 400000)
+                ex = orc.chain_exposure(oidx, hs[:int(hoff[ne])], hoff[:ne + 1], n_threads=cores)
+                out["parity"]["chain_container"] = {"reads_checked": ex["reads"], "reads_with_more_than_9_chains": ex["gt9"], "reads_with_two_chains_at_one_position": ex["dup"],
+                                                    "reads_with_both (can differ)": ex["gt9_and_dup"], "reads_whose_chains_differ_between_btree_and_array": ex["differ"],
+                                                    "device_reads_rechained_on_the_btree (whole timed batch)": int(summary[11]) if len(summary) > 11 else None,
+                                                    "what": "oracle/orc_mem.c runs every read of the sample through klib's B-tree (upstream's container, restated) and through the position-sorted array the kernels use for "
+                                                            "unflagged reads; the kernels flag reads with more than 9 chains and two at one position and chain them again on the tree (csrc/k_chain.h ssg_k_chain_kb); "
+                                                            "the oracle the records are compared with uses the tree"}
+            except Exception as e:
+                out["parity"]["chain_container"] = {"error": repr(e)}
             out["cpu_baseline"] = {"value": ns / tc, "unit": "pairs/s", "cores": cores, "host_cpu_quota": host_cpu_quota(), "hardware_threads": os.cpu_count(), "kind": "port",
                                    "sample": "%s of the timed batch (%d pairs) in its upstream batches, oracle/ (scalar C restatement of bwa mem PE) in process, %d threads, alignment only; after an untimed pass over %d pairs. "
                                              "The script-level baseline (`speedseq align -t <cores>` on the oracle's executables) is cpu_baseline.script" % ("all" if full else "the first pairs", ns, cores, nw)}

@@ -110,6 +110,10 @@ int  orc_smem1(const orc_bwt_t *bwt, int len, const uint8_t *q, int x, int min_i
 int  orc_seed_strategy1(const orc_bwt_t *bwt, int len, const uint8_t *q, int x, int min_len, int max_intv, orc_intv_t *mem);
 void orc_collect_intv(const orc_opt_t *opt, const orc_bwt_t *bwt, int len, const uint8_t *seq, orc_intv_v *mem);
 orc_chain_v orc_mem_chain(const orc_opt_t *opt, const orc_idx_t *idx, int len, const uint8_t *seq);
+/* the container of mem_chain: 0 = the position-sorted array with the single-leaf semantics of klib's B-tree (what the HIP kernels restate), 1 = the B-tree itself
+ * (orc_mem.c; per thread).  orc_chain_exposure: one read through both; 1 when the chain lists differ */
+void orc_set_chain_container(int kbtree);
+int  orc_chain_exposure(const orc_opt_t *opt, const orc_idx_t *idx, int len, const uint8_t *seq, int *n_chains, int *dup);
 int  orc_mem_chain_flt(const orc_opt_t *opt, int n_chn, orc_chain_t *a);
 void orc_mem_chain2aln(const orc_opt_t *opt, const orc_idx_t *idx, int l_query, const uint8_t *query, const orc_chain_t *c, orc_alnreg_v *av);
 int  orc_mem_sort_dedup_patch(const orc_opt_t *opt, const orc_idx_t *idx, uint8_t *query, int n, orc_alnreg_t *a);

@@ -130,3 +130,36 @@ char *orc_api_process_pairs(const orc_opt_t *opt, const orc_idx_t *idx, int n_pa
 	free(s);
 	return buf;
 }
+
+/* Exposure of the one container that is not upstream's (orc_mem.c: the chains of a read in a position-sorted array instead of klib's B-tree): every read through
+ * both, on n_threads threads.  out[0] = reads whose chain lists differ, [1] = reads with more than 9 chains AND two chains at one position (the only reads that can
+ * differ), [2] = reads with more than 9 chains, [3] = reads with two chains at one position, [4] = reads looked at. */
+#include <pthread.h>
+typedef struct { const orc_opt_t *opt; const orc_idx_t *idx; const uint8_t *seq; const int64_t *off; int r0, r1; int64_t c[4]; int32_t *which; } expo_t;
+static void *expo_worker(void *p)
+{
+	expo_t *w = (expo_t*)p;
+	for (int r = w->r0; r < w->r1; ++r) {
+		int nc = 0, dup = 0;
+		const int d = orc_chain_exposure(w->opt, w->idx, (int)(w->off[r + 1] - w->off[r]), w->seq + w->off[r], &nc, &dup);
+		w->c[0] += d; w->c[1] += nc > 9 && dup; w->c[2] += nc > 9; w->c[3] += dup;
+		if (w->which) w->which[r] = (d ? 1 : 0) | (nc > 9 && dup ? 2 : 0);
+	}
+	return 0;
+}
+void orc_api_chain_exposure(const orc_opt_t *opt, const orc_idx_t *idx, int n_reads, const uint8_t *seq, const int64_t *off, int n_threads, int64_t out[5], int32_t *which /* may be NULL: per read, bit 0 differs, bit 1 > 9 chains and a shared position */)
+{
+	if (n_threads < 1) n_threads = 1;
+	if (n_threads > n_reads) n_threads = n_reads > 0 ? n_reads : 1;
+	pthread_t *th = malloc(n_threads * sizeof(pthread_t)); expo_t *w = calloc(n_threads, sizeof(expo_t));
+	for (int t = 0; t < n_threads; ++t) {
+		w[t].opt = opt; w[t].idx = idx; w[t].seq = seq; w[t].off = off; w[t].which = which;
+		w[t].r0 = (int)((int64_t)n_reads * t / n_threads); w[t].r1 = (int)((int64_t)n_reads * (t + 1) / n_threads);
+		pthread_create(&th[t], 0, expo_worker, &w[t]);
+	}
+	out[0] = out[1] = out[2] = out[3] = 0; out[4] = n_reads;
+	for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], 0); for (int k = 0; k < 4; ++k) out[k] += w[t].c[k]; }
+	free(th); free(w);
+}
+/* the container of mem_chain for the calls this thread makes (orc_align1 and the batch entry points run their workers on threads of their own: see ORC_CHAIN_KBTREE) */
+void orc_api_set_chain_container(int kbtree) { orc_set_chain_container(kbtree); }

@@ -212,6 +212,89 @@ static int test_and_merge(const orc_opt_t *opt, int64_t l_pac, orc_chain_t *c, c
 	return 0;
 }
 
+/* ---- klib's B-tree as upstream mem_chain uses it (kbtree.h, KBTREE_INIT(chn, mem_chain_t, chain_cmp) with kb_init(chn, KB_DEFAULT_SIZE = 512)) ----
+ * [RECALL: kbtree.h is not in the reference tree.]  Keys are compared by `pos` alone, equal keys are allowed.  For sizeof(mem_chain_t) = 40 the minimum
+ * degree is t = ((512 - 4 - 8) / (8 + 40) + 1) >> 1 = 5: a node holds up to 2t - 1 = 9 keys, so a read's chains live in ONE leaf until the tenth is put, and the
+ * position-sorted array below is that leaf.  From the tenth chain on kb_putp splits full nodes on its way down (__kb_split: the median key moves up) and both
+ * kb_intervalp and kb_putp search node by node (__kb_getp_aux: the FIRST key >= k of the node at hand, one back when that key is greater) -- with several chains at
+ * one position, which of them a lookup meets and where a new one lands then depends on the node boundaries.  orc_chain_container selects the container:
+ * 1 (default) = this tree, 0 = the array (ORC_CHAIN_ARRAY in the environment; what the HIP kernels keep for every read that is not flagged: csrc/k_chain.h ssg_kbflag).  orc_chain_exposure() runs a read through both and says whether they differ. */
+#define KB_T 5
+typedef struct kbn { int is_internal, n; int key[2 * KB_T - 1]; struct kbn *ptr[2 * KB_T]; } kbn_t;   /* keys = indices into the pool of chains */
+typedef struct { kbn_t *root; const orc_chain_t *pool; } kbt_t;
+static int kb_getp_aux(const kbt_t *b, const kbn_t *x, int64_t pos, int *r)
+{
+	int tr, *rr = r ? r : &tr, begin = 0, end = x->n;
+	if (x->n == 0) return -1;
+	while (begin < end) { const int mid = (begin + end) >> 1; if (b->pool[x->key[mid]].pos < pos) begin = mid + 1; else end = mid; }
+	if (begin == x->n) { *rr = 1; return x->n - 1; }
+	*rr = (pos > b->pool[x->key[begin]].pos) - (pos < b->pool[x->key[begin]].pos);
+	if (*rr < 0) --begin;
+	return begin;
+}
+static int kb_interval_lower(const kbt_t *b, int64_t pos)
+{	/* kb_intervalp's `lower`: index of a chain with the largest position <= pos, or -1 */
+	const kbn_t *x = b->root; int lower = -1;
+	while (x) {
+		int r = 0; const int i = kb_getp_aux(b, x, pos, &r);
+		if (i >= 0 && r == 0) return x->key[i];
+		if (i >= 0) lower = x->key[i];
+		if (!x->is_internal) return lower;
+		x = x->ptr[i + 1];
+	}
+	return lower;
+}
+static void kb_split(kbn_t *x, int i, kbn_t *y)
+{
+	kbn_t *z = calloc(1, sizeof(kbn_t));
+	z->is_internal = y->is_internal; z->n = KB_T - 1;
+	memcpy(z->key, y->key + KB_T, sizeof(int) * (KB_T - 1));
+	if (y->is_internal) memcpy(z->ptr, y->ptr + KB_T, sizeof(kbn_t*) * KB_T);
+	y->n = KB_T - 1;
+	memmove(x->ptr + i + 2, x->ptr + i + 1, sizeof(kbn_t*) * (x->n - i));
+	x->ptr[i + 1] = z;
+	memmove(x->key + i + 1, x->key + i, sizeof(int) * (x->n - i));
+	x->key[i] = y->key[KB_T - 1];
+	++x->n;
+}
+static void kb_putp_aux(const kbt_t *b, kbn_t *x, int k)
+{
+	const int64_t pos = b->pool[k].pos;
+	if (!x->is_internal) {
+		const int i = kb_getp_aux(b, x, pos, 0);
+		if (i != x->n - 1) memmove(x->key + i + 2, x->key + i + 1, (x->n - i - 1) * sizeof(int));
+		x->key[i + 1] = k; ++x->n;
+	} else {
+		int i = kb_getp_aux(b, x, pos, 0) + 1;
+		if (x->ptr[i]->n == 2 * KB_T - 1) {
+			kb_split(x, i, x->ptr[i]);
+			if (pos > b->pool[x->key[i]].pos) ++i;
+		}
+		kb_putp_aux(b, x->ptr[i], k);
+	}
+}
+static void kb_putp(kbt_t *b, int k)
+{
+	kbn_t *r = b->root;
+	if (r->n == 2 * KB_T - 1) {
+		kbn_t *s = calloc(1, sizeof(kbn_t));
+		b->root = s; s->is_internal = 1; s->n = 0; s->ptr[0] = r;
+		kb_split(s, 0, r);
+		r = s;
+	}
+	kb_putp_aux(b, r, k);
+}
+static void kb_traverse(const kbn_t *x, int *out, int *n)
+{	/* __kb_traverse: in order */
+	if (!x) return;
+	for (int i = 0; i < x->n; ++i) { if (x->is_internal) kb_traverse(x->ptr[i], out, n); out[(*n)++] = x->key[i]; }
+	if (x->is_internal) kb_traverse(x->ptr[x->n], out, n);
+}
+static void kb_free(kbn_t *x) { if (!x) return; if (x->is_internal) for (int i = 0; i <= x->n; ++i) kb_free(x->ptr[i]); free(x); }
+static __thread int orc_chain_container = -1;   /* -1: not chosen yet on this thread -> upstream's tree, unless ORC_CHAIN_ARRAY is set in the environment */
+void orc_set_chain_container(int kbtree) { orc_chain_container = kbtree; }
+static int chain_container(void) { if (orc_chain_container < 0) orc_chain_container = getenv("ORC_CHAIN_ARRAY") ? 0 : 1; return orc_chain_container; }
+
 orc_chain_v orc_mem_chain(const orc_opt_t *opt, const orc_idx_t *idx, int len, const uint8_t *seq)
 {	/* upstream mem_chain */
 	int i, b, e, l_rep;
@@ -219,7 +302,10 @@ orc_chain_v orc_mem_chain(const orc_opt_t *opt, const orc_idx_t *idx, int len, c
 	int64_t l_pac = bns->l_pac;
 	orc_chain_v chain = {0,0,0};
 	orc_intv_v mem = {0,0,0};
+	kbt_t tree = { 0, 0 };
 	if (len < opt->min_seed_len) return chain;
+	const int use_tree = chain_container();
+	if (use_tree) tree.root = calloc(1, sizeof(kbn_t));
 	orc_collect_intv(opt, bwt, len, seq, &mem);
 	for (i = 0, b = e = l_rep = 0; i < (int)mem.n; ++i) { /* frac_rep */
 		orc_intv_t *p = &mem.a[i];
@@ -242,6 +328,21 @@ orc_chain_v orc_mem_chain(const orc_opt_t *opt, const orc_idx_t *idx, int len, c
 			s.score = s.len = slen;
 			rid = orc_bns_intv2rid(bns, s.rbeg, s.rbeg + s.len);
 			if (rid < 0) continue;
+			if (use_tree) {   /* klib's B-tree; chain.a is the pool, in order of creation */
+				tree.pool = chain.a;
+				const int lw = chain.n ? kb_interval_lower(&tree, s.rbeg) : -1;
+				if (lw < 0 || !test_and_merge(opt, l_pac, &chain.a[lw], &s, rid)) {
+					orc_chain_t tmp; memset(&tmp, 0, sizeof(tmp));
+					tmp.pos = s.rbeg; tmp.n = 1; tmp.m = 4;
+					tmp.seeds = calloc(tmp.m, sizeof(orc_seed_t));
+					tmp.seeds[0] = s; tmp.rid = rid; tmp.is_alt = 0;
+					if (chain.n == chain.m) { chain.m = chain.m ? chain.m << 1 : 8; chain.a = realloc(chain.a, chain.m * sizeof(orc_chain_t)); }
+					chain.a[chain.n++] = tmp;
+					tree.pool = chain.a;
+					kb_putp(&tree, (int)chain.n - 1);
+				}
+				continue;
+			}
 			/* sorted-array stand-in for kb_intervalp/kb_putp (see file header) */
 			size_t lo = 0, hi = chain.n;
 			while (lo < hi) { size_t mid = (lo + hi) >> 1; if (chain.a[mid].pos < s.rbeg) lo = mid + 1; else hi = mid; }
@@ -261,9 +362,38 @@ orc_chain_v orc_mem_chain(const orc_opt_t *opt, const orc_idx_t *idx, int len, c
 			}
 		}
 	}
+	if (use_tree) {   /* the chains in the tree's order (mem_chain: __kb_traverse into the vector) */
+		int *ord = malloc((chain.n + 1) * sizeof(int)), no = 0;
+		orc_chain_t *srt = malloc((chain.n + 1) * sizeof(orc_chain_t));
+		kb_traverse(tree.root, ord, &no);
+		for (i = 0; i < no; ++i) srt[i] = chain.a[ord[i]];
+		memcpy(chain.a, srt, no * sizeof(orc_chain_t));
+		free(ord); free(srt); kb_free(tree.root);
+	}
 	for (i = 0; i < (int)chain.n; ++i) chain.a[i].frac_rep = (float)l_rep / len;
 	free(mem.a);
 	return chain;
+}
+
+/* One read through both containers.  Returns 1 when the chain lists differ (positions, seed lists or order): the read is one on which the array -- and so the
+ * HIP kernels -- may part from upstream's tree.  *n_chains = chains before filtering, *dup = some two of them share a position. */
+int orc_chain_exposure(const orc_opt_t *opt, const orc_idx_t *idx, int len, const uint8_t *seq, int *n_chains, int *dup)
+{
+	const int saved = orc_chain_container;
+	orc_chain_container = 0; orc_chain_v a = orc_mem_chain(opt, idx, len, seq);
+	orc_chain_container = 1; orc_chain_v b = orc_mem_chain(opt, idx, len, seq);
+	orc_chain_container = saved;
+	int differ = a.n != b.n;
+	for (size_t i = 0; !differ && i < a.n; ++i) {
+		differ = a.a[i].pos != b.a[i].pos || a.a[i].n != b.a[i].n || a.a[i].rid != b.a[i].rid;
+		for (int j = 0; !differ && j < a.a[i].n; ++j) differ = memcmp(&a.a[i].seeds[j], &b.a[i].seeds[j], sizeof(orc_seed_t)) != 0;
+	}
+	*n_chains = (int)a.n; *dup = 0;
+	for (size_t i = 1; i < a.n; ++i) if (a.a[i].pos == a.a[i-1].pos) *dup = 1;
+	for (size_t i = 0; i < a.n; ++i) free(a.a[i].seeds);
+	for (size_t i = 0; i < b.n; ++i) free(b.a[i].seeds);
+	free(a.a); free(b.a);
+	return differ;
 }
 
 static int chain_weight(const orc_chain_t *c)

@@ -65,6 +65,97 @@ struct ssg_chain_w_lt {
 	SSG_DEVMEM bool operator()(int a, int b) const { return c[a].w > c[b].w; }
 };
 
+/* ---- klib's B-tree as upstream mem_chain uses it (kbtree.h: KBTREE_INIT(chn, mem_chain_t, chain_cmp), kb_init(chn, 512): minimum degree t = 5 for the 40-byte
+ * mem_chain_t, up to 9 chains a node; [RECALL: kbtree.h is not in the reference tree], restated in oracle/orc_mem.c, which says where it parts from the (pos, sec)
+ * order: only for a read with more than 9 chains AND two chains at one position).  Every chaining kernel flags such reads (ssg_kbflag); ssg_k_chain_kb then redoes
+ * them on this tree: nodes of 21 words in a slab of the caller -- [0] internal? [1] #keys [2..10] keys (chain ids) [11..20] children (node numbers). ---- */
+#define SSG_KB_T 5
+#define SSG_KB_NODE 21
+struct ssg_kb_t { int32_t *nd; int n_nodes, cap_nodes, root; const ssg_chain_t *ch; int ovf; };
+SSG_DEVFN int ssg_kb_new(ssg_kb_t &b, int internal) { if (b.n_nodes >= b.cap_nodes) { b.ovf = 1; return 0; } const int x = b.n_nodes++; int32_t *p = b.nd + (long)x * SSG_KB_NODE; p[0] = internal; p[1] = 0; return x; }
+SSG_DEVFN int ssg_kb_getp(const ssg_kb_t &b, int x, int64_t pos, int *r)
+{	/* __kb_getp_aux: the first key >= pos of node x, one back when that key is greater; -1 for an empty node */
+	const int32_t *p = b.nd + (long)x * SSG_KB_NODE;
+	int begin = 0, end = p[1];
+	if (p[1] == 0) return -1;
+	while (begin < end) { const int mid = (begin + end) >> 1; if (b.ch[p[2 + mid]].pos < pos) begin = mid + 1; else end = mid; }
+	if (begin == p[1]) { *r = 1; return p[1] - 1; }
+	const int64_t kp = b.ch[p[2 + begin]].pos;
+	*r = (pos > kp) - (pos < kp);
+	if (*r < 0) --begin;
+	return begin;
+}
+SSG_DEVFN int ssg_kb_lower(const ssg_kb_t &b, int64_t pos)
+{	/* kb_intervalp's lower bound: a chain with the largest position <= pos, or -1 */
+	int x = b.root, lower = -1;
+	for (;;) {
+		const int32_t *p = b.nd + (long)x * SSG_KB_NODE;
+		int r = 0; const int i = ssg_kb_getp(b, x, pos, &r);
+		if (i >= 0 && r == 0) return p[2 + i];
+		if (i >= 0) lower = p[2 + i];
+		if (!p[0]) return lower;
+		x = p[11 + i + 1];
+	}
+}
+SSG_DEVFN void ssg_kb_split(ssg_kb_t &b, int x, int i, int y)
+{	/* __kb_split: child y of x (the i-th) is full; its upper t - 1 keys go to a new node, its median into x */
+	int32_t *py = b.nd + (long)y * SSG_KB_NODE;
+	const int z = ssg_kb_new(b, py[0]);
+	int32_t *px = b.nd + (long)x * SSG_KB_NODE, *pz = b.nd + (long)z * SSG_KB_NODE;
+	pz[1] = SSG_KB_T - 1;
+	for (int k = 0; k < SSG_KB_T - 1; ++k) pz[2 + k] = py[2 + SSG_KB_T + k];
+	if (py[0]) for (int k = 0; k < SSG_KB_T; ++k) pz[11 + k] = py[11 + SSG_KB_T + k];
+	py[1] = SSG_KB_T - 1;
+	for (int k = px[1]; k > i; --k) px[11 + k + 1] = px[11 + k];
+	px[11 + i + 1] = z;
+	for (int k = px[1] - 1; k >= i; --k) px[2 + k + 1] = px[2 + k];
+	px[2 + i] = py[2 + SSG_KB_T - 1];
+	++px[1];
+}
+SSG_DEVFN void ssg_kb_put(ssg_kb_t &b, int k)
+{	/* kb_putp */
+	const int64_t pos = b.ch[k].pos;
+	if (b.nd[(long)b.root * SSG_KB_NODE + 1] == 2 * SSG_KB_T - 1) {
+		const int r = b.root, s = ssg_kb_new(b, 1);
+		b.nd[(long)s * SSG_KB_NODE + 11] = r; b.root = s;
+		ssg_kb_split(b, s, 0, r);
+	}
+	int x = b.root;
+	while (!b.ovf) {
+		int32_t *p = b.nd + (long)x * SSG_KB_NODE;
+		int r = 0;
+		if (!p[0]) {
+			const int i = ssg_kb_getp(b, x, pos, &r);
+			for (int t = p[1] - 1; t > i; --t) p[2 + t + 1] = p[2 + t];
+			p[2 + i + 1] = k; ++p[1];
+			return;
+		}
+		int i = ssg_kb_getp(b, x, pos, &r) + 1;
+		if (b.nd[(long)p[11 + i] * SSG_KB_NODE + 1] == 2 * SSG_KB_T - 1) {
+			ssg_kb_split(b, x, i, p[11 + i]);
+			if (pos > b.ch[p[2 + i]].pos) ++i;
+		}
+		x = p[11 + i];
+	}
+}
+SSG_DEVFN int ssg_kb_inorder(const ssg_kb_t &b, int32_t *out)
+{	/* __kb_traverse */
+	int stk_x[16], stk_i[16], top = 0, n = 0;
+	stk_x[0] = b.root; stk_i[0] = 0;
+	while (top >= 0) {
+		const int32_t *p = b.nd + (long)stk_x[top] * SSG_KB_NODE;
+		const int i = stk_i[top];
+		if (!p[0]) { for (int k = 0; k < p[1]; ++k) out[n++] = p[2 + k]; --top; continue; }
+		if (i > p[1]) { --top; continue; }
+		if (i > 0) out[n++] = p[2 + i - 1];
+		stk_i[top] = i + 1;
+		if (top + 1 < 16) { ++top; stk_x[top] = p[11 + i]; stk_i[top] = 0; }
+	}
+	return n;
+}
+/* a read whose chains may lie differently in upstream's tree: more than 9 of them and two at one position */
+SSG_DEVFN void ssg_kbflag(int32_t *kbflag, long r, int n_chains, int n_dup) { if (kbflag && n_chains > 9 && n_dup > 0) kbflag[r] = 1; }
+
 /*
  * The chains of one read (upstream mem_chain + mem_chain_flt) on the slices the caller hands over (global memory in ssg_k_chain; a form with the lane's
  * part of LDS was built in round 4 and measured slower): sd[] / srid[] the read's ns seeds, iv[] its ni intervals, ch[] / ord[] / kp[] / cs[] work arrays of ns entries.
@@ -72,9 +163,12 @@ struct ssg_chain_w_lt {
  * rewritten to s0 + (offset into cs[]) where its n seed ids (s0 + index, insertion order) lie.
  */
 SSG_DEVFN int ssg_chain_one(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const int len, const int ns, ssg_seed_t *sd, const int32_t *srid, const int ni, const ssg_intv_t *iv,
-                            ssg_chain_t *ch, int32_t *ord, int32_t *kp, int32_t *cs, const long s0, const int dbg_phase)
+                            ssg_chain_t *ch, int32_t *ord, int32_t *kp, int32_t *cs, const long s0, const int dbg_phase,
+                            int32_t *kb_slab = 0, int kb_nodes = 0 /* != 0: the chains in klib's B-tree (nodes in kb_slab) instead of the (pos, sec) tree */, int *flag_out = 0, int *err_out = 0)
 {
 	int nc = 0, root = -1, ins_ctr = 0, i, k;
+	ssg_kb_t kb; kb.nd = kb_slab; kb.n_nodes = 0; kb.cap_nodes = kb_nodes; kb.root = 0; kb.ch = ch; kb.ovf = 0;
+	if (kb_slab) kb.root = ssg_kb_new(kb, 0);
 	/* frac_rep (upstream mem_chain head) */
 	int b = 0, e = 0, l_rep = 0;
 	for (i = 0; i < ni; ++i) {
@@ -89,7 +183,8 @@ SSG_DEVFN int ssg_chain_one(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 		if (srid[i] < 0) continue;
 		int64_t rbeg = sd[i].rbeg;
 		int cur = root, lower = -1, to_add = 0;
-		while (cur >= 0) { /* floor of (rbeg, SEC_FIRST) */
+		if (kb_slab) lower = nc ? ssg_kb_lower(kb, rbeg) : -1;
+		else while (cur >= 0) { /* floor of (rbeg, SEC_FIRST) */
 			if (ch[cur].pos < rbeg || (ch[cur].pos == rbeg && ch[cur].sec == SSG_SEC_FIRST)) { lower = cur; cur = ch[cur].right; }
 			else cur = ch[cur].left;
 		}
@@ -101,7 +196,8 @@ SSG_DEVFN int ssg_chain_one(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			c.w = 0; c.kept = 0; c.first = -1; c.left = c.right = -1; c.frac_rep = 0; c._pad = 0;
 			c.sec = (lower >= 0 && ch[lower].pos == rbeg) ? -(++ins_ctr) : SSG_SEC_FIRST;
 			ch[nc] = c;
-			if (root < 0) root = nc;
+			if (kb_slab) ssg_kb_put(kb, nc);
+			else if (root < 0) root = nc;
 			else {
 				cur = root;
 				for (;;) {
@@ -114,9 +210,14 @@ SSG_DEVFN int ssg_chain_one(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			++nc;
 		}
 	}
+	if (flag_out) *flag_out = nc > 9 && ins_ctr > 0;
+	if (err_out && kb.ovf) *err_out = 1;
 	if (dbg_phase == 1) return 0;
-	for (i = 0; i < nc; ++i) ord[i] = i;
-	{ ssg_chain_key_lt lt = { ch }; ssg_introsort(ord, (long)nc, lt); } /* == B-tree in-order traversal (keys are unique) */
+	if (kb_slab && !kb.ovf) { const int m = ssg_kb_inorder(kb, ord); if (m != nc && err_out) *err_out = 1; }
+	else {
+		for (i = 0; i < nc; ++i) ord[i] = i;
+		ssg_chain_key_lt lt = { ch }; ssg_introsort(ord, (long)nc, lt);   /* == B-tree in-order traversal while the tree is one leaf, or the positions are distinct */
+	}
 	if (dbg_phase == 2) return 0;
 	float frac_rep = (float)l_rep / len;
 	/* upstream mem_chain_flt */
@@ -192,14 +293,45 @@ __global__ void __launch_bounds__(64) ssg_k_chain(ssg_index_view_t ix, ssg_mem_o
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain, int dbg_phase,
-                            const int32_t *work_order)
+                            const int32_t *work_order, int32_t *kbflag)
 {
 	long r = r_first + (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
 	if (work_order) r = work_order[r];   /* reads sorted by seed count: the lanes of a wave get similar work */
 	const int len = (int)(read_off[r+1] - read_off[r]);
 	const long s0 = seed_off[r]; const int ns = (int)(seed_off[r+1] - s0);
-	n_chain[r] = ssg_chain_one(ix, opt, len, ns, seeds + s0, seed_rid + s0, n_intv[r] > 0 ? n_intv[r] : 0, intv + r * cap, chains + s0, order + s0, kept + s0, chain_seeds + s0, s0, dbg_phase);
+	int flag = 0;
+	n_chain[r] = ssg_chain_one(ix, opt, len, ns, seeds + s0, seed_rid + s0, n_intv[r] > 0 ? n_intv[r] : 0, intv + r * cap, chains + s0, order + s0, kept + s0, chain_seeds + s0, s0, dbg_phase, 0, 0, &flag);
+	if (kbflag && flag) kbflag[r] = 1;
+}
+
+/* The flagged reads again, their chains in klib's B-tree: one lane per listed read (they are few: none in a million simulated human pairs, every one of a
+ * test's constructed reads); the seeds' chain links are reset first (the first pass left its own).  slab_off[k] .. slab_off[k + 1]: the words of read list[k]'s nodes. */
+__global__ void __launch_bounds__(64) ssg_k_chain_kb(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_list, const int32_t *list,
+                            const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
+                            const int64_t *seed_off, ssg_seed_t *seeds, const int32_t *seed_rid,
+                            ssg_chain_t *chains, int32_t *order, int32_t *kept, int32_t *chain_seeds, int32_t *n_chain,
+                            int32_t *slab, const int64_t *slab_off, int32_t *err)
+{
+	const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_list) return;
+	const long r = list[k];
+	const int len = (int)(read_off[r+1] - read_off[r]);
+	const long s0 = seed_off[r]; const int ns = (int)(seed_off[r+1] - s0);
+	for (int i = 0; i < ns; ++i) seeds[s0 + i].next = -1;
+	int e = 0;
+	n_chain[r] = ssg_chain_one(ix, opt, len, ns, seeds + s0, seed_rid + s0, n_intv[r] > 0 ? n_intv[r] : 0, intv + r * cap, chains + s0, order + s0, kept + s0, chain_seeds + s0, s0, 0,
+	                           slab + slab_off[k], (int)((slab_off[k + 1] - slab_off[k]) / SSG_KB_NODE), 0, &e);
+	if (e) atomicMax(err, 1);
+}
+/* the flagged reads as a list, and the node words each needs (a tree of nc <= ns chains has at most nc / 4 leaves and a third as many inner nodes) */
+__global__ void ssg_k_chain_kb_list(int n_reads, const int32_t *kbflag, const int64_t *seed_off, int32_t *list, int32_t *need, unsigned int *n_list)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads || !kbflag[r]) return;
+	const unsigned int k = atomicAdd(n_list, 1u);
+	list[k] = (int32_t)r;
+	need[k] = (int32_t)(((seed_off[r + 1] - seed_off[r]) / 3 + 12) * SSG_KB_NODE);
 }
 
 /*
@@ -237,7 +369,7 @@ template <int CAP, int LN /* reads (lanes) per workgroup: 64, or 32 where a whol
 __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_mem_opt_t opt, int r_first, int r_end,
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
-                            ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, const int32_t *work_order)
+                            ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, const int32_t *work_order, int32_t *kbflag)
 {
 	typedef ssg_cl_cfg<CAP> C;
 	static_assert(CAP <= 64 && CAP % 4 == 0, "chain ids are 6 bits, byte arrays fill whole words");
@@ -276,7 +408,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 		}
 	}
 	/* greedy chaining in seed-visiting order */
-	unsigned root = SSG_CL_NONE, head = SSG_CL_NONE; int ins_ctr = 0;
+	unsigned root = SSG_CL_NONE, head = SSG_CL_NONE; int ins_ctr = 0, n_made = 0;
 	for (i = 0; i < ns; ++i) {
 		const uint32_t mi = lw[(C::W_META + i) * LN];
 		const uint32_t rid_i = mi >> 18;
@@ -313,6 +445,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 		}
 		if (!merged) { /* a new chain, named after its seed */
 			uint32_t sec = 0;
+			++n_made;
 			if (lower != SSG_CL_NONE && lower_pos == rbeg) { ++ins_ctr; sec = (uint32_t)(64 - ins_ctr); }
 			lw[(C::W_CA + i) * LN] = (uint32_t)i | SSG_CL_NONE << 8 | SSG_CL_NONE << 16 | 1u << 24;
 			lw[(C::W_CB + i) * LN] = sec << 16;
@@ -322,6 +455,7 @@ __global__ void __launch_bounds__(64) ssg_k_chain_lds(ssg_index_view_t ix, ssg_m
 			else { SSG_CL_B(C::W_SUCC, i) = SSG_CL_B(C::W_SUCC, lower); SSG_CL_B(C::W_SUCC, lower) = (uint8_t)i; }
 		}
 	}
+	ssg_kbflag(kbflag, r, n_made, ins_ctr);
 	/* upstream mem_chain_weight, both passes in one walk */
 	for (unsigned c = head; c != SSG_CL_NONE; c = SSG_CL_B(C::W_SUCC, c)) {
 		const int n = (int)(lw[(C::W_CA + c) * LN] >> 24);

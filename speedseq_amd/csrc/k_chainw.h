@@ -155,7 +155,7 @@ SSG_DEVFN void wv_introsort_whi(ssg_chw_lds_t<CAPC, CAPS> &L, const int n)
 template <int CAPC, int CAPS>
 SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const long r, const int64_t *read_off, const ssg_intv_t *intv,
                              const int32_t *n_intv, int cap, const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
-                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, ssg_chw_lds_t<CAPC, CAPS> &L, const uint16_t *rank, int capc_lim, int wave_sort)
+                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain, ssg_chw_lds_t<CAPC, CAPS> &L, const uint16_t *rank, int capc_lim, int wave_sort, int32_t *kbflag)
 {
 	const int lane = wv_lane();
 	const int len_read = (int)(read_off[r+1] - read_off[r]);
@@ -164,6 +164,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 	const ssg_seed_t *sd = seeds + s0; const int32_t *srid = seed_rid + s0;
 	const int64_t l_pac = ix.l_pac;
 	int nc = 0, i, k;
+	int n_dup = 0;   /* chains made at a position that had one (wave-uniform): with more than 9 chains the read is flagged for klib's B-tree (k_chain.h ssg_kbflag) */
 	/* frac_rep (upstream mem_chain head); wave-uniform */
 	int b = 0, e = 0, l_rep = 0, ni = n_intv[r] > 0 ? n_intv[r] : 0;
 	const ssg_intv_t *iv = intv + r * cap;
@@ -246,6 +247,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 				const bool com = act && lane < p;
 				const unsigned long long cre = wv_ballot(com && res == 0);
 				if (wv_ballot(com && res == 0 && (two_eq || nc + wv_rank_of(cre) >= capc_lim))) { fail = 1; break; }   /* not covered here: the caller redoes the read */
+				n_dup += __popcll(wv_ballot(com && res == 0 && eqp));
 				ssg_wave_ldssync();
 				if (com && res == 2) {
 					L.nx[ls] = (uint16_t)me; L.ls[fl] = (uint16_t)me; L.a8[fl] = my_rbeg; L.lq[fl] = (uint8_t)my_q; L.ll[fl] = (uint8_t)my_len;
@@ -282,11 +284,12 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 				const uint64_t mw = pf_t == t ? pf_m : L.bm[bw];
 				if (t + 1 < cn) { pf_w = wv_get(my_rk, t + 1) >> 6; pf_m = L.bm[pf_w]; pf_t = t + 1; }   /* the next seed's word travels with this seed's state reads */
 				const uint64_t mlow = mw & (bit == 63 ? ~0ull : (1ull << (bit + 1)) - 1);
-				int fl = mlow ? (bw << 6) + 63 - __clzll(mlow) : chw_prev_set(L, (bw << 6) - 1), two_equal = 0, res = 0;
+				int fl = mlow ? (bw << 6) + 63 - __clzll(mlow) : chw_prev_set(L, (bw << 6) - 1), two_equal = 0, res = 0, eqp2 = 0;
 				if (fl >= 0) { /* upstream test_and_merge against the floor chain */
 					int64_t f_rbeg = L.b8[fl], l_rbeg = L.a8[fl];
 					unsigned n16 = L.n[fl], ls = L.ls[fl]; int f_q = L.fq[fl], l_q = L.lq[fl], l_len = L.ll[fl], crid = L.rid[fl];
 					if (f_rbeg == rbeg) {   /* a chain at this very position: upstream tests the FIRST of them */
+						eqp2 = 1;
 						const int f2 = chw_prev_set(L, fl - 1);
 						if (f2 >= 0 && L.b8[f2] == rbeg) {
 							fl = f2; two_equal = 1;
@@ -323,7 +326,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 					}
 					ssg_wave_ldssync();
 					if (pf_t == t + 1 && pf_w == bw) pf_m |= 1ull << bit;
-					++nc;
+					++nc; n_dup += wv_get(eqp2, 0);
 				}
 			}
 		}
@@ -386,7 +389,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 					L.fs[nc] = L.ls[nc] = (uint16_t)sid; L.rid[nc] = (int16_t)prid;
 				}
 				ssg_wave_ldssync();
-				++nc;
+				++nc; n_dup += wv_get(eq, 0);
 			}
 		}
 	}
@@ -627,7 +630,7 @@ SSG_DEVFN int wv_chain_read(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt
 			n_out += __popcll(bal);
 		}
 	}
-	if (lane == 0) n_chain[r] = n_out;
+	if (lane == 0) { n_chain[r] = n_out; ssg_kbflag(kbflag, r, nc, n_dup); }
 	}
 	ssg_wave_ldssync();
 	return -fail;
@@ -641,16 +644,16 @@ __global__ void __launch_bounds__(64) ssg_k_chain_wave(ssg_index_view_t ix, ssg_
                             const int64_t *read_off, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
                             const int64_t *seed_off, const ssg_seed_t *seeds, const int32_t *seed_rid,
                             ssg_chain_t *chains, int32_t *order, int32_t *chain_seeds, int32_t *n_chain,
-                            const int32_t *work_order, unsigned int *queue, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */, int wave_sort /* bit 0: the weight sort by the whole wave, bit 1: the insertion 64 seeds a round, bit 2: the filter 64 chains a round (0: one lane / one seed / one chain, A/B and tests) */)
+                            const int32_t *work_order, unsigned int *queue, int32_t *kbflag, const uint16_t *hrank, const int64_t *hoff, int capc_lim /* CAP; smaller only in tests */, int wave_sort /* bit 0: the weight sort by the whole wave, bit 1: the insertion 64 seeds a round, bit 2: the filter 64 chains a round (0: one lane / one seed / one chain, A/B and tests) */)
 {
 	__shared__ ssg_chw_lds_t<CAP, CAP> L;
 	for (;;) {
 		const long k = r_first + wv_queue_pop(queue);
 		if (k >= r_end) break;
 		const long r = work_order ? work_order[k] : k;
-		int rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, hrank ? hrank + hoff[k] : (const uint16_t*)0, capc_lim, wave_sort);
+		int rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, hrank ? hrank + hoff[k] : (const uint16_t*)0, capc_lim, wave_sort, kbflag);
 		rc = wv_get(rc, 0);
-		if (rc) rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, (const uint16_t*)0, CAP, wave_sort);
+		if (rc) rc = wv_chain_read<CAP, CAP>(ix, opt, r, read_off, intv, n_intv, cap, seed_off, seeds, seed_rid, chains, order, chain_seeds, n_chain, L, (const uint16_t*)0, CAP, wave_sort, kbflag);
 	}
 }
 

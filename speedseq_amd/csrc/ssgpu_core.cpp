@@ -797,6 +797,11 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		const int n_heavy = g[6];
 		const int nC = g[1], n5120 = g[2] - g[1], n2048 = g[3] - g[2], n1024 = g[4] - g[3], n512 = g[5] - g[4], n256 = g[6] - g[5];
 		const int dbgp = ssg_debug() >= 2 ? -1 : 0;
+		/* reads whose chains may lie differently in upstream's B-tree than in the kernels' (pos, sec) order -- more than 9 chains AND two at one position -- are flagged by
+		 * every chaining kernel and chained again on the tree itself afterwards (k_chain.h ssg_k_chain_kb); SSG_CHAIN_KBTREE=0 leaves them as they are (the array order: tests) */
+		dbuf<int32_t> d_kbflag((size_t)n_reads);
+		CHKA(d_kbflag); CHK(d_kbflag.zero());
+		int32_t *const kbf = env_int("SSG_CHAIN_KBTREE", 1) ? d_kbflag.p : (int32_t*)0;
 		ssg_fork(3);
 		{	/* The light reads go first, on a stream of their own, while this one ranks the heavy reads' seeds (small latency-bound launches that leave the chip idle); behind the wave
 			 * kernels they would wait for LDS (the 63-seed class asks for 94 KB a workgroup) and run as a tail.  Heaviest first: up to 15 / 31 / 63 seeds with the read's state in the lane's part of LDS (k_chain.h), the rest -- and everything when the
@@ -805,9 +810,9 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 			const int r0 = n_heavy;
 			const int b63 = use_lds ? std::min(n_reads, std::max(r0, gl[0])) : n_reads, b31 = std::min(n_reads, std::max(b63, gl[1])), b15 = std::min(n_reads, std::max(b31, gl[2]));
 			if (b63 > r0) SSG_LAUNCH_ON(2, ssg_k_chain, (b63 - r0 + 63) / 64, 64, 0, idx->v, *opt, r0, b63, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-			                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+			                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p, kbf);
 #define SSG_CL_LAUNCH(CC, LN, from, to) do { if ((to) > (from)) SSG_LAUNCH_ON(2, (ssg_k_chain_lds<CC, LN>), ((to) - (from) + (LN) - 1) / (LN), (LN), 0, idx->v, *opt, (from), (to), d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, \
-			d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p); } while (0)
+			d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, kbf); } while (0)
 			if (env_int("SSG_CHAIN_LDS64_LANES", 32) == 32) SSG_CL_LAUNCH(64, 32, b63, b31); else SSG_CL_LAUNCH(64, 64, b63, b31);   /* 47 KB a workgroup instead of 94: fits beside the wave kernels' blocks */
 			SSG_CL_LAUNCH(32, 64, b31, b15);
 			SSG_CL_LAUNCH(16, 64, b15, n_reads);
@@ -838,7 +843,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		ssg_fork(2);   /* (again, the wave kernels' two streams: they read the ranks) */
 		int r0 = nC;
 #define SSG_CHW_LAUNCH(si, CC, cnt, maxwg, qi) do { if ((cnt) > 0) SSG_LAUNCH_ON(si, ssg_k_chain_wave<CC>, std::min((int)(cnt), (int)(maxwg)), 64, 0, idx->v, *opt, r0, r0 + (cnt), d_off, d_intv.p, d_nintv.p, cap, \
-		o.seed_off.p, d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + (qi), hr, ho, std::min((int)(CC), cap_lim), wsort); r0 += (cnt); } while (0)
+		o.seed_off.p, d_seeds.p, d_srid.p, d_chains.p, d_order.p, d_cseeds.p, d_nchain.p, d_work.p, d_queue.p + (qi), kbf, hr, ho, std::min((int)(CC), cap_lim), wsort); r0 += (cnt); } while (0)
 		SSG_CHW_LAUNCH(0, 5120, n5120, 256, 1);
 		SSG_CHW_LAUNCH(1, 2048, n2048, 512, 3);
 		SSG_CHW_LAUNCH(1, 1024, n1024, 1280, 2);   /* (behind the 2048 class: this stream + two side streams + the light reads' stream are the four hardware queues; a fifth stream shares one) */
@@ -846,8 +851,33 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		SSG_CHW_LAUNCH(0, 256, n256, 5120, 4);
 #undef SSG_CHW_LAUNCH
 		if (nC) SSG_LAUNCH_ON(0, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
-		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p);
+		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p, kbf);
 		ssg_join(3);
+		if (kbf) {   /* the flagged reads (none in a million simulated human pairs; the constructed reads of tests/test_chain_btree.py) on klib's B-tree */
+			dbuf<int32_t> d_klist((size_t)n_reads), d_kneed((size_t)n_reads); dbuf<unsigned int> d_nk(1);
+			CHKA(d_klist); CHKA(d_kneed); CHKA(d_nk); CHK(d_nk.zero());
+			SSG_LAUNCH(ssg_k_chain_kb_list, (n_reads + 255) / 256, 256, 0, n_reads, (const int32_t*)d_kbflag.p, o.seed_off.p, d_klist.p, d_kneed.p, d_nk.p);
+			unsigned int nk = 0;
+			CHK(d_nk.down(&nk, 1));
+			if (stats) stats[7] = nk;
+			if (nk) {
+				std::vector<int32_t> kl(nk), kn(nk);   /* (the list in read order: the kernel's atomics hand out places as they come) */
+				CHK(d_klist.down(kl.data(), nk)); CHK(d_kneed.down(kn.data(), nk));
+				std::vector<size_t> by(nk); for (size_t i = 0; i < nk; ++i) by[i] = i;
+				std::sort(by.begin(), by.end(), [&](size_t a, size_t b) { return kl[a] < kl[b]; });
+				std::vector<int32_t> kl2(nk); std::vector<int64_t> ko((size_t)nk + 1, 0);
+				for (size_t i = 0; i < nk; ++i) { kl2[i] = kl[by[i]]; ko[i + 1] = ko[i] + kn[by[i]]; }
+				dbuf<int32_t> d_slab((size_t)ko[nk] + 1), d_kerr(1); dbuf<int64_t> d_ko((size_t)nk + 1);
+				CHKA(d_slab); CHKA(d_kerr); CHKA(d_ko); CHK(d_kerr.zero());
+				CHK(d_klist.up(kl2.data(), nk)); CHK(d_ko.up(ko.data(), (size_t)nk + 1));
+				SSG_LAUNCH(ssg_k_chain_kb, (nk + 63) / 64, 64, 0, idx->v, *opt, (int)nk, (const int32_t*)d_klist.p, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
+				           d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, d_slab.p, (const int64_t*)d_ko.p, d_kerr.p);
+				int32_t ke = 0;
+				CHK(d_kerr.down(&ke, 1));
+				if (ke) { ssg_err_msg = "chaining on the B-tree exceeded its node slab"; return SSG_EOVERFLOW; }
+				if (ssg_debug()) fprintf(stderr, "[ssgpu] %u reads chained again on klib's B-tree (more than 9 chains and two at one position)\n", nk);
+			}
+		}
 	}
 	STAGE("chain");
 	/* ---- extensions of every chain's first seed, one lane each (k_extlane.h) ---- */
@@ -1599,6 +1629,7 @@ int ssg_hotpath_dev_ex(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_p
 	}
 	summary[0] = res.stats[4]; summary[2] = res.stats[0]; summary[3] = res.stats[1]; summary[4] = res.stats[2]; summary[5] = res.stats[3];
 	summary[7] = res.stats[6]; /* chains = first-seed extensions */
+	summary[11] = res.stats[7]; /* reads chained again on klib's B-tree (more than 9 chains and two at one position) */
 	summary[6] = res.stats[5]; /* bwt_extend calls in the SMEM kernel (2 rank queries = 2 x 64-byte lines each) */
 	if (keep_out) *keep_out = R.release();
 	return 0;

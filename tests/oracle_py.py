@@ -93,6 +93,16 @@ class Oracle:
                 return reg_off, out[:tot]
             cap = tot
 
+    def chain_exposure(self, idx, seq, off, n_threads=8, opt=None, per_read=False):
+        """every read through both containers of mem_chain (orc_mem.c: the position-sorted array the kernels restate, and klib's B-tree as upstream uses it):
+        dict(differ, gt9_and_dup, gt9, dup, reads) [+ per-read flags]"""
+        n = len(off) - 1
+        out = np.zeros(5, dtype=np.int64)
+        which = np.zeros(n, dtype=np.int32) if per_read else None
+        self.l.orc_api_chain_exposure(opt or self.opt, idx, C.c_int(n), _ptr(seq), _ptr(off), C.c_int(n_threads), _ptr(out), _ptr(which) if per_read else None)
+        d = dict(differ=int(out[0]), gt9_and_dup=int(out[1]), gt9=int(out[2]), dup=int(out[3]), reads=int(out[4]))
+        return (d, which) if per_read else d
+
     def samblaster(self, sam_text, exclude_dups=True, add_mate_tags=True, max_split=2, min_non_overlap=20):
         """Oracle samblaster over SAM text (via temp files); returns the marked SAM text."""
         import os
