@@ -798,8 +798,22 @@ def main():
             names = ["r%d" % (i // 2) for i in range(2 * ns)]
             cores = min(os.cpu_count() or 1, 128)   # the oracle's worker threads: every hardware thread the host shows (cgroup quotas may give less: tools/dbg/host_probe.py)
             hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(ctg_names, lens))
+            lf0 = (0, 0)
+            try:
+                lf0 = orc.lazyf(1)                     # count, on the first pairs, the mate-rescue alignments on which upstream's lazy-F pass could part from the textbook recurrence (oracle/orc_ksw.c)
+            except Exception:
+                pass
             nw = min(ns, 2000)                         # untimed: the worker threads' allocator heaps and the index pages they touch first
             orc.process_pairs(oidx, hs[:2 * nw * rl], hoff[:2 * nw + 1], names[:2 * nw], None, 0, "", cores)
+            try:
+                nlf = min(ns, 50000)
+                orc.process_pairs(oidx, hs[:2 * nlf * rl], hoff[:2 * nlf + 1], names[:2 * nlf], None, 0, "", cores)
+                lf1 = orc.lazyf(0)
+                lazyf = {"pairs": nlf, "ksw_align2_calls": lf1[0] - lf0[0], "calls_whose_result_changes_without_E_from_F_raised_H": lf1[1] - lf0[1],
+                         "what": "every mate-rescue alignment of these pairs a second time with E never opened from an H that F alone raised -- more than upstream's lazy-F pass leaves out -- "
+                                 "0 differing calls = the textbook recurrence the kernels compute and upstream's agree on all of them"}
+            except Exception as e:
+                lazyf = {"error": repr(e)}
             tc = time.perf_counter()
             otext = ""
             nb_s = int(pb[ns - 1]) + 1
@@ -842,6 +856,7 @@ def main():
                                       "MC/MQ source lines reproduce the three streams of the oracle's samblaster line for line; index files written by ssg_index_save"
                                       % ("" if full else ", first %d pairs" % ns)),
                              "index_files_roundtrip_s": round(t_files, 1)}
+            out["parity"]["ksw_align2_lazy_f"] = lazyf
             try:   # the one container of the hot path that was a shared deviation of oracle and kernels until round 6 (upstream mem_chain keeps the chains in klib's B-tree)
                 ne = min(2 * ns, 400000)
                 ex = orc.chain_exposure(oidx, hs[:int(hoff[ne])], hoff[:ne + 1], n_threads=cores)

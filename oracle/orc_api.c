@@ -163,3 +163,8 @@ void orc_api_chain_exposure(const orc_opt_t *opt, const orc_idx_t *idx, int n_re
 }
 /* the container of mem_chain for the calls this thread makes (orc_align1 and the batch entry points run their workers on threads of their own: see ORC_CHAIN_KBTREE) */
 void orc_api_set_chain_container(int kbtree) { orc_set_chain_container(kbtree); }
+
+/* exposure of the other shared deviation (orc_ksw.c local_sw): on = 1 makes every orc_ksw_align2 call run a second time with E never opened from an F-raised H
+ * and counts the calls whose result changes; out[0] = calls, out[1] = calls that differ (both since the process began) */
+extern int orc_lazyf_count; extern uint64_t orc_lazyf_calls, orc_lazyf_differ;
+void orc_api_lazyf(int on, uint64_t out[2]) { if (on >= 0) orc_lazyf_count = on; out[0] = orc_lazyf_calls; out[1] = orc_lazyf_differ; }

@@ -196,8 +196,11 @@ int orc_ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
  */
 typedef struct { int score, te, qe, score2, te2; } sw1_t;
 
+/* no_e_from_f: E is never opened from an H that F alone raised -- MORE than upstream leaves out (its lazy-F pass skips the re-opening only for an F that crosses a
+ * stripe boundary), so a call whose result is the same with and without this switch is a call on which the textbook recurrence and upstream's agree (orc_ksw_align2
+ * counts the calls that differ when ORC_LAZYF_COUNT is set: bench.py's parity object, tests/test_kernels_emu.py) */
 static sw1_t local_sw(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
-                      int o_del, int e_del, int o_ins, int e_ins, int p, int minsc, int endsc)
+                      int o_del, int e_del, int o_ins, int e_ins, int p, int minsc, int endsc, int no_e_from_f)
 {
 	sw1_t r = { 0, -1, -1, -1, -1 };
 	int slen = (qlen + p - 1) / p, qp = slen * p, i, j, gmax = 0, te = -1, n_b = 0, m_b = 0, maxsc = 0;
@@ -213,11 +216,12 @@ static sw1_t local_sw(int qlen, const uint8_t *query, int tlen, const uint8_t *t
 			int32_t h = diag + s, e = E[j];
 			diag = H[j];
 			h = h > e ? h : e;
+			const int32_t h_before_f = h;
 			h = h > f ? h : f;
 			h = h > 0 ? h : 0;
 			H[j] = h;
 			imax = imax > h ? imax : h;
-			e -= e_del; { int32_t t = h - oe_del; e = e > t ? e : t; } E[j] = e > 0 ? e : 0;
+			e -= e_del; { int32_t t = (no_e_from_f ? (h_before_f > 0 ? h_before_f : 0) : h) - oe_del; e = e > t ? e : t; } E[j] = e > 0 ? e : 0;
 			f -= e_ins; { int32_t t = h - oe_ins; f = f > t ? f : t; } f = f > 0 ? f : 0;
 		}
 		orc_cnt_cells += qlen;
@@ -252,18 +256,34 @@ static sw1_t local_sw(int qlen, const uint8_t *query, int tlen, const uint8_t *t
 
 static void revseq(int l, uint8_t *s) { for (int i = 0; i < l >> 1; ++i) { uint8_t t = s[i]; s[i] = s[l-1-i]; s[l-1-i] = t; } }
 
+int orc_lazyf_count = -1;   /* -1: ask the environment (ORC_LAZYF_COUNT) at the first call */
+uint64_t orc_lazyf_calls = 0, orc_lazyf_differ = 0;   /* ORC_LAZYF_COUNT: ksw_align2 calls looked at / whose result changes when E is never opened from an F-raised H */
+static orc_kswr_t align2_mode(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra, int no_e_from_f);
 orc_kswr_t orc_ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
                           int o_del, int e_del, int o_ins, int e_ins, int xtra)
+{
+	if (orc_lazyf_count < 0) orc_lazyf_count = getenv("ORC_LAZYF_COUNT") != 0;
+	const int count = orc_lazyf_count;
+	const orc_kswr_t r = align2_mode(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, xtra, 0);
+	if (count) {
+		const orc_kswr_t s = align2_mode(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, xtra, 1);
+		__atomic_fetch_add(&orc_lazyf_calls, 1, __ATOMIC_RELAXED);
+		if (memcmp(&r, &s, sizeof(r)) != 0) __atomic_fetch_add(&orc_lazyf_differ, 1, __ATOMIC_RELAXED);
+	}
+	return r;
+}
+static orc_kswr_t align2_mode(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
+                          int o_del, int e_del, int o_ins, int e_ins, int xtra, int no_e_from_f)
 {	/* upstream ksw_align2 */
 	orc_kswr_t r = { 0, -1, -1, -1, -1, -1, -1 };
 	int p = (xtra & ORC_KSW_XBYTE) ? 16 : 8;
 	int minsc = (xtra & ORC_KSW_XSUBO) ? xtra & 0xffff : 0x10000;
 	int endsc = (xtra & ORC_KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-	sw1_t f = local_sw(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, p, minsc, endsc), rr;
+	sw1_t f = local_sw(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, p, minsc, endsc, no_e_from_f), rr;
 	r.score = f.score; r.te = f.te; r.qe = f.qe; r.score2 = f.score2; r.te2 = f.te2;
 	if ((xtra & ORC_KSW_XSTART) == 0 || ((xtra & ORC_KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
 	revseq(r.qe + 1, query); revseq(r.te + 1, target);
-	rr = local_sw(r.qe + 1, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, p, 0x10000, r.score);
+	rr = local_sw(r.qe + 1, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, p, 0x10000, r.score, no_e_from_f);
 	revseq(r.qe + 1, query); revseq(r.te + 1, target);
 	if (r.score == rr.score) r.tb = r.te - rr.te, r.qb = r.qe - rr.qe;
 	return r;

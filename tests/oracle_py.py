@@ -103,6 +103,12 @@ class Oracle:
         d = dict(differ=int(out[0]), gt9_and_dup=int(out[1]), gt9=int(out[2]), dup=int(out[3]), reads=int(out[4]))
         return (d, which) if per_read else d
 
+    def lazyf(self, on=-1):
+        """(calls, calls that differ) of orc_ksw_align2 under the lazy-F exposure count; on = 1 / 0 switches the counting on / off, -1 only reads"""
+        out = np.zeros(2, dtype=np.uint64)
+        self.l.orc_api_lazyf(C.c_int(on), _ptr(out))
+        return int(out[0]), int(out[1])
+
     def samblaster(self, sam_text, exclude_dups=True, add_mate_tags=True, max_split=2, min_non_overlap=20):
         """Oracle samblaster over SAM text (via temp files); returns the marked SAM text."""
         import os
