@@ -12,7 +12,7 @@ all: lib tools oracle emu synth
 lib: speedseq_amd/libssgpu.so
 # Every object's prerequisites come from the compiler (-MMD): no hand-kept header lists, so no object can be stale against a shared
 # declaration (round 3 shipped variant libraries linked from objects of different ages).
-HIPOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_seed.o $(CSRC)/ssg_bgzf.o $(CSRC)/ssg_bam.o
+HIPOBJS = $(CSRC)/ssgpu_core.o $(CSRC)/ssg_index_build.o $(CSRC)/ssg_seed.o $(CSRC)/ssg_bgzf.o $(CSRC)/ssg_bam.o $(CSRC)/ssg_coll.o
 $(HIPOBJS): $(CSRC)/%.o: $(CSRC)/%.cpp
 	$(HIPCC) $(HIPFLAGS) -MMD -MP -x hip -c $< -o $@
 $(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp
@@ -20,7 +20,7 @@ $(CSRC)/sam_format.o: $(CSRC)/sam_format.cpp
 -include $(wildcard $(CSRC)/*.d)
 LIBOBJS = $(HIPOBJS) $(CSRC)/sam_format.o
 speedseq_amd/libssgpu.so: $(LIBOBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(LIBOBJS) -o $@ -lz
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(LIBOBJS) -o $@ -lz -ldl
 
 # instrumented build (device phase counters, tools/dbg/phase.py); never the default library
 tune: speedseq_amd/libssgpu_tune.so
@@ -70,9 +70,9 @@ tests/emu/fi_test: tools/dbg/fi_test.cpp $(HOST)/fast_inflate.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fi_test.cpp -o $@ -lz
 tests/emu/fq_dump: tools/dbg/fq_dump.cpp $(HOST)/fastq.h $(HOST)/fast_inflate.h
 	$(CXX) -O2 -std=c++17 tools/dbg/fq_dump.cpp -o $@ -lz -lpthread
-tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
+tests/emu/libssgpu_emu.so: $(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/ssg_coll.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp tests/emu/emu.h $(KHDRS)
 	$(CXX) -O2 -g -std=c++17 -fPIC -ffp-contract=off -DSSG_EMU -Itests/emu -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-variable \
-		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
+		$(CSRC)/ssgpu_core.cpp $(CSRC)/ssg_index_build.cpp $(CSRC)/ssg_seed.cpp $(CSRC)/ssg_bgzf.cpp $(CSRC)/ssg_bam.cpp $(CSRC)/ssg_coll.cpp $(CSRC)/sam_format.cpp tests/emu/emu.cpp -shared -o $@ -lpthread -lz
 tests/emu/bwa_emu: $(HOST)/bwa_main.cpp $(HOSTHDRS) tests/emu/libssgpu_emu.so
 	$(CXX) -O2 -std=c++17 $(HOST)/bwa_main.cpp -o $@ -Ltests/emu -lssgpu_emu -lz -lpthread -Wl,-rpath,'$$ORIGIN'
 tests/emu/samblaster_emu: $(HOST)/samblaster_main.cpp $(HOSTHDRS) tests/emu/libssgpu_emu.so
@@ -91,12 +91,12 @@ clean:
 # objects, which `lib` has just brought up to date against every header they include (-MMD), so no stale object can be linked.
 #   make variant NAME=x VFLAGS="-D..."                   all translation units
 #   make variant NAME=x VFLAGS="-D..." VUNITS=ssg_seed   only that unit (seconds)
-VUNITS ?= ssgpu_core ssg_index_build ssg_seed ssg_bgzf ssg_bam
+VUNITS ?= ssgpu_core ssg_index_build ssg_seed ssg_bgzf ssg_bam ssg_coll
 variant: lib
 	mkdir -p build/$(NAME) && rm -f build/$(NAME)/*.o
-	for u in ssgpu_core ssg_index_build ssg_seed ssg_bgzf ssg_bam; do \
+	for u in ssgpu_core ssg_index_build ssg_seed ssg_bgzf ssg_bam ssg_coll; do \
 	  case " $(VUNITS) " in *" $$u "*) $(HIPCC) $(HIPFLAGS) $(VFLAGS) -x hip -c $(CSRC)/$$u.cpp -o build/$(NAME)/$$u.o || exit 1;; \
 	  *) cp $(CSRC)/$$u.o build/$(NAME)/$$u.o;; esac; done
 	cp $(CSRC)/sam_format.o build/$(NAME)/sam_format.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC build/$(NAME)/*.o -o speedseq_amd/libssgpu_$(NAME).so -lz
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC build/$(NAME)/*.o -o speedseq_amd/libssgpu_$(NAME).so -lz -ldl
 	rm -rf build/$(NAME)

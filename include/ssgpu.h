@@ -285,6 +285,19 @@ int ssg_prof_get(int cap, const char **name, double *ms, long *launches);
 
 void ssg_free(void *p);
 
+/* ---- the exchange step of the path over several GPUs (SURVEY 8e coupling 3: the coordinate-sorted merge; the reference ends in ONE OUT.bam,
+ * /root/reference/bin/speedseq:441,491-495) ----
+ * One process per GPU (bin/speedseq-ranks); every rank's `sambamba sort` owns a stretch of the genome and receives the records of that stretch from all ranks:
+ * an all-to-all of variable-size blocks, here as grouped ncclSend / ncclRecv over RCCL (every xGMI link of a device at once; no ring).  ssg_coll_init: the
+ * communicator over the calling process's device; rank 0 leaves the unique id in rendezvous_dir (a directory all ranks share).  Blocks are host buffers
+ * (the records are made by host stages) staged through HBM.  SSG_ENODEV when there is no device or no RCCL: the caller's other transports take over. */
+typedef struct ssg_coll ssg_coll_t;
+int ssg_coll_available(void);   /* 1: a device is visible and RCCL loads (the ranks tell one another before any of them enters ssg_coll_init, which is collective) */
+int ssg_coll_init(int rank, int world, const char *rendezvous_dir, ssg_coll_t **out);
+int ssg_coll_alltoallv(ssg_coll_t *c, const void *const *send, const uint64_t *send_bytes, void *const *recv, const uint64_t *recv_bytes);   /* block q to / from rank q */
+int ssg_coll_alltoall_u64(ssg_coll_t *c, const uint64_t *send, uint64_t *recv, int k);   /* k values to / from every rank */
+void ssg_coll_destroy(ssg_coll_t *c);
+
 /* ---- BGZF deflate on the device (row f1; htslib bgzf.c:298-342 is the format's writer in the reference) ----
  * Block b's payload is payload[cut[b] .. cut[b+1]) (<= 0xff00 bytes, as bgzf_write cuts them); its raw deflate stream (RFC 1951, one final
  * block; stored when it would not shrink) lands at out[out_off[b] .. out_off[b+1]).  The caller frames it: 18-byte BGZF header with the

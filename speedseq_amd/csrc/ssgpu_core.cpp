@@ -63,13 +63,13 @@ static double ssg_stage_ms() { static thread_local std::chrono::steady_clock::ti
 #define STAGE(name) do { if (ssg_debug()) { int rc_ = rt_sync(); fprintf(stderr, "[ssgpu] stage %s done rc=%d  +%.1f ms\n", name, rc_, ssg_stage_ms()); fflush(stderr); if (rc_) return rc_; } } while (0)
 
 SSG_ABI_FP_DEFINE(core)
-extern "C" void ssg_abi_fp_index_build(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_seed(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_bgzf(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_sam_format(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_bam(ssg_abi_fp_t*);
+extern "C" void ssg_abi_fp_index_build(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_seed(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_bgzf(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_sam_format(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_bam(ssg_abi_fp_t*); extern "C" void ssg_abi_fp_coll(ssg_abi_fp_t*);
 extern "C" int ssg_abi_selfcheck(void)
 {	/* every translation unit of the library was compiled against the same shared declarations (ssg_index_int.h) */
 	static const char *const field[20] = { "sizeof(ssg_index_view_t)", "sizeof(ssg_mem_opt_t)", "sizeof(ssg_index)", "sizeof(ssg_intv_t)", "ssg_index_view_t.primary", "ssg_index_view_t.L2",
 		"ssg_index_view_t.l_pac", "ssg_index_view_t.sa_intv", "ssg_mem_opt_t.min_seed_len", "ssg_mem_opt_t.split_width", "ssg_mem_opt_t.max_mem_intv", "ssg_mem_opt_t.split_factor", "ssg_mem_opt_t.mat",
 		"ssg_index.bwt", "ssg_index.ktab", "ssg_index.bwt_words", "ssg_index.names", "sizeof(ssg_seed_t)", "sizeof(ssg_alnreg_t)", "sizeof(ssg_aln_t)" };
-	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_seed", ssg_abi_fp_seed }, { "ssg_bgzf", ssg_abi_fp_bgzf }, { "sam_format", ssg_abi_fp_sam_format }, { "ssg_bam", ssg_abi_fp_bam } };
+	struct { const char *unit; void (*fn)(ssg_abi_fp_t*); } const units[] = { { "ssg_index_build", ssg_abi_fp_index_build }, { "ssg_seed", ssg_abi_fp_seed }, { "ssg_bgzf", ssg_abi_fp_bgzf }, { "sam_format", ssg_abi_fp_sam_format }, { "ssg_bam", ssg_abi_fp_bam }, { "ssg_coll", ssg_abi_fp_coll } };
 	ssg_abi_fp_t mine; ssg_abi_fp_core(&mine);
 	for (const auto &u : units) {
 		ssg_abi_fp_t o; u.fn(&o);

@@ -18,6 +18,7 @@
 #include "bamio.h"
 #include "fastq.h"   /* chan_t */
 #include "fused.h"
+#include "xchg.h"
 #include "ranks.h"
 #include <atomic>
 #include <mutex>
@@ -168,6 +169,17 @@ struct rec_store_t {
 		return true;
 	}
 };
+
+/* the whole records of a received block with the ordinals that came with them (rank mode's exchange) */
+static bool add_chunk_ords(rec_store_t &S, fu_buf_t c, size_t len, const uint64_t *ords, size_t n)
+{
+	const size_t n0 = S.key.size();
+	if (!S.add_chunk(std::move(c), len)) return false;
+	if (S.key.size() - n0 != n) return false;
+	S.ord.resize(n0);
+	S.ord.insert(S.ord.end(), ords, ords + n);
+	return true;
+}
 
 static void gpu_perm(const rec_store_t &S, std::vector<uint32_t> &perm)
 {
@@ -651,6 +663,59 @@ static void merge_runs(std::vector<run_t> &runs, size_t G, const bam_hdr_t &h, i
 	if (dbg()) fprintf(stderr, "[sambamba] sort: merge: %zu stretches of the genome; waited %.2f s for the loader (read + inflate + index of the runs), device sort of the keys %.2f s, gather + deflate + write %.2f s\n", ns, t_wait, t_perm, t_write);
 }
 
+/* rank mode, after a rank's part is written (by the merge of all ranks' runs, or from the blocks of the collective exchange): the markers the other ranks and
+ * bin/speedseq-ranks wait for, and this rank's stretch placed in the joined file */
+static bool place_part(const std::string &outp, const std::string &rdv, int rank, int world, uint64_t hdr_end)
+{
+		{ char t[64]; snprintf(t, sizeof(t), "%llu\n", (unsigned long long)hdr_end); if (!rk_file_put(outp + ".ssg_part", t, strlen(t))) die("sort: cannot write " + outp + ".ssg_part"); }
+		/* the runs may go when every rank has read what it needed of them; the marker says how long this rank's part is and where its header blocks end */
+		struct stat psb; if (stat(outp.c_str(), &psb) != 0) die("sort: cannot stat " + outp);
+		{ char t[96]; snprintf(t, sizeof(t), "%llu %llu\n", (unsigned long long)psb.st_size, (unsigned long long)hdr_end); if (!rk_file_put(rdv + "/merged." + std::to_string(rank), t, strlen(t))) die("sort: cannot write into " + rdv); }
+		for (int r = 0; r < world; ++r) if (!rk_file_wait(rdv + "/merged." + std::to_string(r))) die("sort: rank " + std::to_string(r) + " did not finish its merge");
+		/* Every rank places its own stretch in the joined file (PREFIX.bam for a part named PREFIX.rank<r>.bam) at the offset the parts before it leave -- the
+		 * stretches' lengths are only known now, so this is a copy, but N of them side by side instead of one by the launcher after the last rank has ended
+		 * (the one term of the ranks' wall time that grew with the input and did not divide by N).  Part 0 goes with its header blocks, the others without; the
+		 * last rank adds the end-of-file block; bin/speedseq-ranks finds joined.<r> of every rank and only indexes.  SSG_RANKS_JOIN=0 leaves the copy to it. */
+		const std::string tail = ".rank" + std::to_string(rank) + ".bam";
+		if (!(getenv("SSG_RANKS_JOIN") && !strcmp(getenv("SSG_RANKS_JOIN"), "0")) && outp.size() > tail.size() && outp.compare(outp.size() - tail.size(), tail.size(), tail) == 0) {
+			const double tj = wall();
+			uint64_t at = 0, my_from = 0, my_len = 0; bool ok = true;
+			for (int r = 0; r < world && ok; ++r) {
+				std::vector<uint8_t> b; unsigned long long sz = 0, he = 0;
+				if (!rk_file_get(rdv + "/merged." + std::to_string(r), b)) { ok = false; break; }
+				b.push_back(0);
+				if (sscanf((const char*)b.data(), "%llu %llu", &sz, &he) != 2 || sz < 28 + he) { ok = false; break; }
+				const uint64_t from = r ? he : 0, len = sz - 28 - from;
+				if (r == rank) { my_from = from; my_len = len; break; }
+				at += len;
+			}
+			const std::string joined = outp.substr(0, outp.size() - tail.size()) + ".bam";
+			int jfd = ok ? open(joined.c_str(), O_WRONLY | O_CREAT, 0644) : -1, pfd = ok ? open(outp.c_str(), O_RDONLY) : -1;
+			if (jfd >= 0 && pfd >= 0) {
+				std::vector<uint8_t> buf;
+				uint64_t done_b = 0;
+				while (done_b < my_len && ok) {
+					off64_t oi = (off64_t)(my_from + done_b), oo = (off64_t)(at + done_b);
+					ssize_t k = copy_file_range(pfd, &oi, jfd, &oo, (size_t)std::min<uint64_t>(my_len - done_b, (uint64_t)1 << 30), 0);
+					if (k <= 0) {   /* a file system that cannot: through a buffer */
+						if (buf.empty()) buf.resize((size_t)8 << 20);
+						k = pread(pfd, buf.data(), (size_t)std::min<uint64_t>(my_len - done_b, buf.size()), (off_t)(my_from + done_b));
+						if (k <= 0) { ok = false; break; }
+						for (ssize_t w = 0; w < k; ) { const ssize_t x = pwrite(jfd, buf.data() + w, (size_t)(k - w), (off_t)(at + done_b + (uint64_t)w)); if (x <= 0) { ok = false; break; } w += x; }
+					}
+					done_b += (uint64_t)k;
+				}
+				if (ok && rank == world - 1 && pwrite(jfd, BGZF_EOF, 28, (off_t)(at + my_len)) != 28) ok = false;
+			} else ok = false;
+			if (jfd >= 0 && close(jfd) != 0) ok = false;
+			if (pfd >= 0) close(pfd);
+			if (!ok) die("sort: cannot place this rank's stretch in " + joined);
+			if (!rk_file_put(rdv + "/joined." + std::to_string(rank), "", 0)) die("sort: cannot write into " + rdv);
+			if (dbg()) fprintf(stderr, "[sambamba] sort: rank %d placed its stretch (%.2f GB) at byte %llu of %s in %.2f s\n", rank, (double)my_len / 1e9, (unsigned long long)at, joined.c_str(), wall() - tj);
+		}
+	return true;
+}
+
 static int cmd_sort(int argc, char **argv)
 {
 	int threads = hw_threads(), level = -1; double mem_gb = 2; std::string tmpdir = ".", outp; const char *in = 0;
@@ -681,6 +746,9 @@ static int cmd_sort(int argc, char **argv)
 	const int world = fused ? rk_world() : 1, rank = rk_rank();
 	if (world > 1 && !rk_check("sambamba")) return 1;
 	const std::string rdv = rk_dir(), rdata = rk_data_dir();
+	/* the transport of the sorts' exchange (xchg.h: RCCL, sockets, or none = the files of rounds 4-5) comes up while the input streams in */
+	xchg_t *X = 0; std::thread t_xchg;
+	if (world > 1) t_xchg = std::thread([&]() { X = xchg_open(rank, world, rdv); });
 	uint64_t budget = (uint64_t)(std::max(mem_gb, 0.25) * 0.6 * 1073741824.0);   /* record bytes per in-memory run; the rest is keys, locations, output blocks */
 	{ const char *e = getenv("SSG_SORT_CHUNK_BYTES"); if (e && atoll(e) > 0) budget = (uint64_t)atoll(e); }   /* the tests force the spill-and-merge path */
 	rec_store_t S; std::vector<std::string> spills; bam_hdr_t h;
@@ -783,6 +851,78 @@ static int cmd_sort(int argc, char **argv)
 	bool bai_note = false;
 	int ofd = open(outp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (ofd < 0) die("sort: cannot write " + outp);
 	if (world > 1) {
+		t_xchg.join();
+		if (X == (xchg_t*)-1) die("sort: the ranks' exchange transport failed to come up");
+		if (X) {
+			/* The collective form of the exchange (SURVEY.md 8e coupling 3): the records of this rank in (key, ordinal) order, cut at the stretches of the genome the ranks own (the
+			 * same 1024 ranges as the file form, so the same records land on the same rank); sizes first, then one all-to-all of the blocks (ordinals + record bytes); the
+			 * receiver orders what it got by (key, ordinal) on its device and writes its part.  Whether everybody can -- no rank has spilled, every rank's stretch fits its
+			 * budget -- is itself agreed by an exchange; otherwise all ranks go on through the files. */
+			const double t_x = wall();
+			const size_t G = 1024; make_ranges(h, G, range_lo);
+			std::vector<uint32_t> perm; stretch_perm(S, perm);
+			const size_t n = perm.size();
+			std::vector<size_t> cutp((size_t)world + 1, n);
+			for (int d = 0; d < world; ++d) {
+				const uint64_t lo_key = range_lo[G * (size_t)d / (size_t)world];
+				size_t a = 0, b = n;
+				while (a < b) { const size_t m = (a + b) >> 1; if (S.key[perm[m]] < lo_key) a = m + 1; else b = m; }
+				cutp[(size_t)d] = a;
+			}
+			cutp[0] = 0;
+			std::vector<uint64_t> cs((size_t)world * 3), cr((size_t)world * 3);
+			for (int d = 0; d < world; ++d) {
+				uint64_t bytes = 0;
+				for (size_t i = cutp[(size_t)d]; i < cutp[(size_t)d + 1]; ++i) { uint32_t bs; memcpy(&bs, S.rec(perm[i]), 4); bytes += 4 + (uint64_t)bs; }
+				cs[(size_t)d * 3] = cutp[(size_t)d + 1] - cutp[(size_t)d]; cs[(size_t)d * 3 + 1] = bytes; cs[(size_t)d * 3 + 2] = runs.empty() ? 1 : 0;
+			}
+			if (!X->alltoall_u64(cs.data(), cr.data(), 3)) die("sort: the ranks' exchange failed");
+			uint64_t in_bytes = 0; bool all_ok = true;
+			for (int q = 0; q < world; ++q) { in_bytes += cr[(size_t)q * 3 + 1]; if (!cr[(size_t)q * 3 + 2]) all_ok = false; }
+			std::vector<uint64_t> f1((size_t)world, (all_ok && in_bytes <= budget * 2) ? 1 : 0), f2((size_t)world, 0);
+			if (!X->alltoall_u64(f1.data(), f2.data(), 1)) die("sort: the ranks' exchange failed");
+			for (int q = 0; q < world; ++q) if (!f2[(size_t)q]) all_ok = false;
+			if (!all_ok) { if (rank == 0 && dbg()) fprintf(stderr, "[sambamba] sort: a rank's share does not fit its memory (or its input did not): the ranks exchange through files\n"); delete X; X = 0; }
+			else {
+				std::vector<std::vector<uint8_t> > sb((size_t)world), rb((size_t)world);
+				std::vector<const void*> sp((size_t)world); std::vector<void*> rp((size_t)world); std::vector<uint64_t> sn((size_t)world), rn((size_t)world);
+				parallel_for(std::min(pool, world), (size_t)world, [&](size_t a, size_t b, int) {
+					for (size_t d = a; d < b; ++d) {
+						const size_t nd = cutp[d + 1] - cutp[d];
+						sb[d].resize(8 * nd + (size_t)cs[d * 3 + 1]);
+						uint8_t *w = sb[d].data() + 8 * nd;
+						for (size_t i = 0; i < nd; ++i) {
+							const uint32_t id = perm[cutp[d] + i]; memcpy(sb[d].data() + 8 * i, &S.ord[id], 8);
+							const uint8_t *r = S.rec(id); uint32_t bs; memcpy(&bs, r, 4); memcpy(w, r, 4 + (size_t)bs); w += 4 + (size_t)bs;
+						}
+					}
+				});
+				for (int q = 0; q < world; ++q) { rb[(size_t)q].resize(8 * (size_t)cr[(size_t)q * 3] + (size_t)cr[(size_t)q * 3 + 1]); sp[(size_t)q] = sb[(size_t)q].data(); rp[(size_t)q] = rb[(size_t)q].data(); sn[(size_t)q] = sb[(size_t)q].size(); rn[(size_t)q] = rb[(size_t)q].size(); }
+				S.clear();
+				if (!X->alltoallv(sp.data(), sn.data(), rp.data(), rn.data())) die("sort: the ranks' exchange failed");
+				for (auto &v : sb) { std::vector<uint8_t>().swap(v); }
+				rec_store_t R;
+				for (int q = 0; q < world; ++q) {
+					const size_t nq = (size_t)cr[(size_t)q * 3], len = (size_t)cr[(size_t)q * 3 + 1];
+					if (!nq) continue;
+					fu_buf_t c; if (!c.heap(len)) die("sort: out of memory");
+					memcpy(c.p, rb[(size_t)q].data() + 8 * nq, len);
+					std::vector<uint64_t> od(nq); memcpy(od.data(), rb[(size_t)q].data(), 8 * nq);
+					std::vector<uint8_t>().swap(rb[(size_t)q]);
+					if (!add_chunk_ords(R, std::move(c), len, od.data(), nq)) die("sort: a block of the ranks' exchange is not whole records");
+				}
+				std::vector<uint32_t> pr; stretch_perm(R, pr);
+				seg_out_t seg; seg.first = true; seg.last = true;
+				seg.ent_fd = open((outp + ".ssg_ent").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (seg.ent_fd < 0) die("sort: cannot write " + outp + ".ssg_ent");
+				write_sorted(R, pr, h, ofd, level, pool, 0, 0, 0, &seg);
+				close(seg.ent_fd); close(ofd);
+				const uint64_t hdr_end = seg.hdr_end;
+				if (dbg()) fprintf(stderr, "[sambamba] sort: rank %d of %d: %zu records of its own in, %zu records of its stretch out, exchanged over %s: %.2f s\n", rank, world, n, pr.size(), X->name(), wall() - t_x);
+				delete X; X = 0;
+				if (!place_part(outp, rdv, rank, world, hdr_end)) die("sort: cannot place this rank's stretch");
+				return 0;
+			}
+		}
 		/* every record of this rank goes into exchange runs (the last one now); then all ranks' runs are opened and this rank merges its share of the ranges */
 		if (!S.key.empty() || runs.empty()) spill();
 		const double t_x = wall();
@@ -809,52 +949,7 @@ static int cmd_sort(int argc, char **argv)
 		uint64_t hdr_end = 0;
 		merge_runs(all, G, h, ofd, level, pool, budget, 0, g_lo, g_hi, &hdr_end, (outp + ".ssg_ent").c_str());
 		close(ofd);
-		{ char t[64]; snprintf(t, sizeof(t), "%llu\n", (unsigned long long)hdr_end); if (!rk_file_put(outp + ".ssg_part", t, strlen(t))) die("sort: cannot write " + outp + ".ssg_part"); }
-		/* the runs may go when every rank has read what it needed of them; the marker says how long this rank's part is and where its header blocks end */
-		struct stat psb; if (stat(outp.c_str(), &psb) != 0) die("sort: cannot stat " + outp);
-		{ char t[96]; snprintf(t, sizeof(t), "%llu %llu\n", (unsigned long long)psb.st_size, (unsigned long long)hdr_end); if (!rk_file_put(rdv + "/merged." + std::to_string(rank), t, strlen(t))) die("sort: cannot write into " + rdv); }
-		for (int r = 0; r < world; ++r) if (!rk_file_wait(rdv + "/merged." + std::to_string(r))) die("sort: rank " + std::to_string(r) + " did not finish its merge");
-		/* Every rank places its own stretch in the joined file (PREFIX.bam for a part named PREFIX.rank<r>.bam) at the offset the parts before it leave -- the
-		 * stretches' lengths are only known now, so this is a copy, but N of them side by side instead of one by the launcher after the last rank has ended
-		 * (the one term of the ranks' wall time that grew with the input and did not divide by N).  Part 0 goes with its header blocks, the others without; the
-		 * last rank adds the end-of-file block; bin/speedseq-ranks finds joined.<r> of every rank and only indexes.  SSG_RANKS_JOIN=0 leaves the copy to it. */
-		const std::string tail = ".rank" + std::to_string(rank) + ".bam";
-		if (!(getenv("SSG_RANKS_JOIN") && !strcmp(getenv("SSG_RANKS_JOIN"), "0")) && outp.size() > tail.size() && outp.compare(outp.size() - tail.size(), tail.size(), tail) == 0) {
-			const double tj = wall();
-			uint64_t at = 0, my_from = 0, my_len = 0; bool ok = true;
-			for (int r = 0; r < world && ok; ++r) {
-				std::vector<uint8_t> b; unsigned long long sz = 0, he = 0;
-				if (!rk_file_get(rdv + "/merged." + std::to_string(r), b)) { ok = false; break; }
-				b.push_back(0);
-				if (sscanf((const char*)b.data(), "%llu %llu", &sz, &he) != 2 || sz < 28 + he) { ok = false; break; }
-				const uint64_t from = r ? he : 0, len = sz - 28 - from;
-				if (r == rank) { my_from = from; my_len = len; break; }
-				at += len;
-			}
-			const std::string joined = outp.substr(0, outp.size() - tail.size()) + ".bam";
-			int jfd = ok ? open(joined.c_str(), O_WRONLY | O_CREAT, 0644) : -1, pfd = ok ? open(outp.c_str(), O_RDONLY) : -1;
-			if (jfd >= 0 && pfd >= 0) {
-				std::vector<uint8_t> buf;
-				uint64_t done_b = 0;
-				while (done_b < my_len && ok) {
-					off64_t oi = (off64_t)(my_from + done_b), oo = (off64_t)(at + done_b);
-					ssize_t k = copy_file_range(pfd, &oi, jfd, &oo, (size_t)std::min<uint64_t>(my_len - done_b, (uint64_t)1 << 30), 0);
-					if (k <= 0) {   /* a file system that cannot: through a buffer */
-						if (buf.empty()) buf.resize((size_t)8 << 20);
-						k = pread(pfd, buf.data(), (size_t)std::min<uint64_t>(my_len - done_b, buf.size()), (off_t)(my_from + done_b));
-						if (k <= 0) { ok = false; break; }
-						for (ssize_t w = 0; w < k; ) { const ssize_t x = pwrite(jfd, buf.data() + w, (size_t)(k - w), (off_t)(at + done_b + (uint64_t)w)); if (x <= 0) { ok = false; break; } w += x; }
-					}
-					done_b += (uint64_t)k;
-				}
-				if (ok && rank == world - 1 && pwrite(jfd, BGZF_EOF, 28, (off_t)(at + my_len)) != 28) ok = false;
-			} else ok = false;
-			if (jfd >= 0 && close(jfd) != 0) ok = false;
-			if (pfd >= 0) close(pfd);
-			if (!ok) die("sort: cannot place this rank's stretch in " + joined);
-			if (!rk_file_put(rdv + "/joined." + std::to_string(rank), "", 0)) die("sort: cannot write into " + rdv);
-			if (dbg()) fprintf(stderr, "[sambamba] sort: rank %d placed its stretch (%.2f GB) at byte %llu of %s in %.2f s\n", rank, (double)my_len / 1e9, (unsigned long long)at, joined.c_str(), wall() - tj);
-		}
+		if (!place_part(outp, rdv, rank, world, hdr_end)) die("sort: cannot place this rank's stretch");
 		for (run_t &R : all) { close(R.fd); close(R.ord_fd); }
 		for (run_t &R : runs) { close(R.fd); unlink(R.path.c_str()); unlink((R.path + ".ord").c_str()); unlink((R.path + ".idx").c_str()); }
 		if (dbg()) fprintf(stderr, "[sambamba] sort: rank %d of %d: input %.2f s (from start), %zu run(s) of its own, ranges %zu .. %zu of %zu from %zu runs of all ranks: %.2f s\n", rank, world, t_in - t_start, runs.size(), g_lo, g_hi, G, all.size(), wall() - t_x);

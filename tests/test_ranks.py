@@ -61,6 +61,39 @@ def test_ranks_emulated_equal_one_pipeline(tmp_path, emu_lib, world, extra, chun
     _ranks_equal_one(tmp_path, world, extra, chunk, None, 2500 if not kw else 1200, **kw)
 
 
+@pytest.mark.parametrize("world,extra,chunk,expect", [(2, "export SSG_RANKS_XCHG=sock\n", "40000", "exchanged over UNIX sockets"), (4, "export SSG_RANKS_XCHG=sock\n", "40000", "exchanged over UNIX sockets"),
+                                                      (3, "export SSG_RANKS_XCHG=sock\nexport SSG_SORT_CHUNK_BYTES=300000\n", "40000", "the ranks exchange through files")],
+                         ids=["two_ranks_collective", "four_ranks_collective", "three_ranks_collective_a_rank_spills"])
+def test_ranks_emulated_collective_exchange_equals_one_pipeline(tmp_path, emu_lib, world, extra, chunk, expect):
+    """the sorts' exchange as ONE all-to-all of (ordinal, record) blocks (speedseq_amd/host/xchg.h; on a node of MI355X: grouped ncclSend / ncclRecv, csrc/ssg_coll.cpp;
+    here the same code over the socket transport, the stand-in where there is no RCCL) instead of sorted runs in files -- the same three BAMs, byte for byte; and when a rank
+    has spilled its input, every rank agrees -- by the same exchange -- to go through the files"""
+    err = _ranks_equal_one(tmp_path, world, extra + "export SSG_DEBUG=1\n", chunk, None, 2500)
+    assert expect in err, err[-1500:]
+
+
+@pytest.mark.gpu
+def test_ranks_gpu_rccl_exchange_one_rank_loopback(tmp_path, gpu_lib):
+    """the RCCL transport itself on the one MI355X of the test box: a communicator of ONE rank, the all-to-all to itself through HBM (ncclSend / ncclRecv to the own rank),
+    blocks and sizes back unchanged -- what a node with a GPU per rank runs between N of them (N > 1 ranks cannot share a device under RCCL: the N-rank run of this transport
+    is the driver's multi-GPU bench)"""
+    import ctypes as C
+    import numpy as np
+    lib = gpu_lib.l
+    assert lib.ssg_coll_available() == 1
+    h = C.c_void_p()
+    rc = lib.ssg_coll_init(0, 1, str(tmp_path).encode(), C.byref(h))
+    assert rc == 0, lib.ssg_last_error()
+    for n in (0, 1, 1000, 50_000_000):
+        src = np.random.default_rng(n).integers(0, 256, n, dtype=np.uint8); dst = np.zeros(n, dtype=np.uint8)
+        sp = (C.c_void_p * 1)(src.ctypes.data); rp = (C.c_void_p * 1)(dst.ctypes.data); nb = (C.c_uint64 * 1)(n)
+        assert lib.ssg_coll_alltoallv(h, sp, nb, rp, nb) == 0, lib.ssg_last_error()
+        assert np.array_equal(src, dst)
+    a = np.arange(3, dtype=np.uint64) + 7; b = np.zeros(3, dtype=np.uint64)
+    assert lib.ssg_coll_alltoall_u64(h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 3) == 0 and np.array_equal(a, b)
+    lib.ssg_coll_destroy(h)
+
+
 @pytest.mark.gpu
 def test_ranks_gpu_two_pipelines_on_the_one_device(tmp_path, gpu_lib):
     """the same on the MI355X: two pipelines side by side, both on the one GPU of the test box (SSG_RANKS_KEEP_DEVICES=1)"""
@@ -96,6 +129,7 @@ def _ranks_equal_one(tmp_path, world, extra, chunk, exe, n_pairs, **kw):
     assert int(subprocess.check_output([SAMTOOLS, "view", "-c", "-f", "1024", many + ".bam"])) > 50
     left = [f for f in os.listdir(str(tmp_path / "many")) if ".rank" in f]
     assert left == [], left
+    return r.stderr
 
 
 def test_ranks_need_the_fused_hand_off(tmp_path, emu_lib):
