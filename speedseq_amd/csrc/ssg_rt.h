@@ -76,6 +76,7 @@ static inline int rt_set_device(int d) { if (d < 0 || d >= SSG_MAX_DEV) { ssg_er
 static inline int rt_set_lane(int l) { if (l < 0 || l >= SSG_MAX_LANE) { ssg_err_msg = "ssg_set_lane: lane out of range"; return -22; } ssg_lane = l; ssg_stream = ssg_lane_stream(ssg_cur_dev, l); if (l && !ssg_stream) { ssg_err_msg = "ssg_set_lane: cannot create a stream"; return -1000; } return 0; }
 /* HBM arena: freed blocks are kept in size-class free lists and reused by later calls, so the
  * steady-state hot path performs no hipMalloc/hipFree (288 GB of HBM3E make the slack irrelevant) */
+#include <algorithm>
 #include <map>
 #include <unordered_map>
 #include <mutex>
@@ -88,7 +89,7 @@ struct ssg_pool_t {
 	static size_t cls(size_t n) { size_t c = 256; while (c < n) c <<= 1; if (c > (64u << 20)) { const size_t g = c >> 4; c = (n + g - 1) / g * g; } return c; }
 	/* what the free lists may hold (SSG_POOL_FREE_GB, default 48: about what the arrays of one device call of 1 M pairs add up to); beyond it a
 	 * returned block goes back to the driver, largest classes first */
-	static size_t free_cap() { static const size_t c = (size_t)(getenv("SSG_POOL_FREE_GB") && atof(getenv("SSG_POOL_FREE_GB")) > 0 ? atof(getenv("SSG_POOL_FREE_GB")) : 48.0) << 30; return c; }
+	static size_t free_cap() { static const size_t c = (size_t)(std::max(getenv("SSG_POOL_FREE_GB") && atof(getenv("SSG_POOL_FREE_GB")) > 0 ? atof(getenv("SSG_POOL_FREE_GB")) : 48.0, 0.25) * 1073741824.0); return c; }   /* (fractions of a GB count; never below 256 MB: a cap of 0 would send every free to hipFree, which waits for the device) */
 	std::unordered_map<void*, int> live_;   /* SSG_POOL_CHECK=1: a block handed out twice, or given back twice, is reported */
 	static bool check() { static const int c = getenv("SSG_POOL_CHECK") ? atoi(getenv("SSG_POOL_CHECK")) : 0; return c != 0; }
 	~ssg_pool_t() { if (held_max && getenv("SSG_POOL_LOG")) fprintf(stderr, "[ssgpu] device arena: at most %.2f GB held, %.2f GB of it in the free lists at exit\n", held_max / 1073741824.0, free_bytes / 1073741824.0); }

@@ -802,6 +802,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		dbuf<int32_t> d_kbflag((size_t)n_reads);
 		CHKA(d_kbflag); CHK(d_kbflag.zero());
 		int32_t *const kbf = env_int("SSG_CHAIN_KBTREE", 1) ? d_kbflag.p : (int32_t*)0;
+		/* an error return between the fork and the join below hands this scope's buffers back to the arena: not before the side streams' kernels, which write them, are done */
+		struct fork_guard_t { int n; bool armed; ~fork_guard_t() { if (armed) { ssg_join(n); (void)rt_sync(); } } } fork_guard = { 3, true };
 		ssg_fork(3);
 		{	/* The light reads go first, on a stream of their own, while this one ranks the heavy reads' seeds (small latency-bound launches that leave the chip idle); behind the wave
 			 * kernels they would wait for LDS (the 63-seed class asks for 94 KB a workgroup) and run as a tail.  Heaviest first: up to 15 / 31 / 63 seeds with the read's state in the lane's part of LDS (k_chain.h), the rest -- and everything when the
@@ -853,6 +855,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		if (nC) SSG_LAUNCH_ON(0, ssg_k_chain, (nC + 63) / 64, 64, 0, idx->v, *opt, 0, nC, d_off, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p,
 		                   d_chains.p, d_order.p, d_kept.p, d_cseeds.p, d_nchain.p, dbgp, d_work.p, kbf);
 		ssg_join(3);
+		fork_guard.armed = false;
 		if (kbf) {   /* the flagged reads (none in a million simulated human pairs; the constructed reads of tests/test_chain_btree.py) on klib's B-tree */
 			dbuf<int32_t> d_klist((size_t)n_reads), d_kneed((size_t)n_reads); dbuf<unsigned int> d_nk(1);
 			CHKA(d_klist); CHKA(d_kneed); CHKA(d_nk); CHK(d_nk.zero());
