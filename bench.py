@@ -701,7 +701,7 @@ def main():
             name, (ms, cnt) = max(kern.items(), key=lambda kv: kv[1][0])
             per_launch_ms = ms / cnt
             n_ext, seeds, recs, nreads = float(summary[6]), float(summary[2]), float(summary[0]), 2.0 * a.pairs
-            # ALGORITHMIC bytes per launch of each hot kernel (DESIGN.md section 3 states the per-unit figures):
+            # ALGORITHMIC bytes per launch of each hot kernel (DESIGN.md section 4 states the per-unit figures):
             alg_bytes = {
                 # every bwt_extend = 2 rank queries = 2 x 64-byte Occ blocks (SURVEY 8d B_fm) + the read itself
                 "ssg_k_smem_quad": 128.0 * n_ext + nreads * rl,
