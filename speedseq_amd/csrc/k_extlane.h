@@ -141,7 +141,7 @@ SSG_DEVFN int ssg_sbfe6(uint32_t t, unsigned off) { return __builtin_amdgcn_sbfe
 /* upstream ksw_extend2, one lane; Lc[j*64] is this lane's column j (query field already set); U = columns per trip of the cell loop */
 template <int U>
 SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_view_t &ix, uint32_t *Lc, int qlen, int tlen, int64_t p0, int dir,
-                                   int w, int end_bonus, int zdrop, int h0, unsigned long long *cells)
+                                   int w, int end_bonus, int zdrop, int h0, unsigned long long *cells, unsigned int *tune_rowmax = 0, unsigned long long *tune_lane = 0)
 {
 	const int sa = opt.a, sb = opt.b;
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -249,6 +249,15 @@ SSG_DEVFN void ssg_ext_lane_job(const ssg_index_view_t &ix, const ssg_mem_opt_t 
                                 unsigned long long *cells, uint32_t *L, const int qcap)
 {
 	const long t = job_first + (long)blockIdx.x * 64 + threadIdx.x;
+#ifdef SSG_TUNE   /* lane utilisation of this wave: per row index the widest lane's trips (rows run in step), against the lanes' own sums; slots 32.. (U = 2) / 40.. (U = 4) */
+	__shared__ unsigned int tune_rowmax[SSG_XL_BAND_TRY][512];
+	for (int k = (int)threadIdx.x; k < SSG_XL_BAND_TRY * 512; k += 64) (&tune_rowmax[0][0])[k] = 0;
+	unsigned long long tune_lane[2] = { 0, 0 };
+	__syncthreads();
+#define SSG_XL_TUNE_ARGS(i) , tune_rowmax[i], tune_lane
+#else
+#define SSG_XL_TUNE_ARGS(i)
+#endif
 	if (t >= n_jobs) return;
 	const uint64_t key = sorted[t];
 	if ((key >> 32) >= 511) return;   /* nothing on this side */
@@ -269,7 +278,7 @@ SSG_DEVFN void ssg_ext_lane_job(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 		for (int i = 0; i < SSG_XL_BAND_TRY; ++i) {
 			const int prev = score;
 			aw = opt.w << i;
-			x = ln_extend2<U>(opt, ix, Lc, qlen, tlen, jb.rbeg - 1, -1, aw, opt.pen_clip5, opt.zdrop, jb.len * opt.a, &nc);
+			x = ln_extend2<U>(opt, ix, Lc, qlen, tlen, jb.rbeg - 1, -1, aw, opt.pen_clip5, opt.zdrop, jb.len * opt.a, &nc SSG_XL_TUNE_ARGS(i));
 			score = x.score;
 			if (score == prev || x.max_off < (aw >> 1) + (aw >> 2)) break;
 		}
@@ -286,7 +295,7 @@ SSG_DEVFN void ssg_ext_lane_job(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 		for (int i = 0; i < SSG_XL_BAND_TRY; ++i) {
 			const int prev = score;
 			aw = opt.w << i;
-			x = ln_extend2<U>(opt, ix, Lc, qlen, tlen, jb.rbeg + jb.len, 1, aw, opt.pen_clip3, opt.zdrop, sc0, &nc);
+			x = ln_extend2<U>(opt, ix, Lc, qlen, tlen, jb.rbeg + jb.len, 1, aw, opt.pen_clip3, opt.zdrop, sc0, &nc SSG_XL_TUNE_ARGS(i));
 			score = x.score;
 			if (score == prev || x.max_off < (aw >> 1) + (aw >> 2)) break;
 		}
@@ -294,6 +303,17 @@ SSG_DEVFN void ssg_ext_lane_job(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 		res_r[g] = o;
 	}
 	if (cells && nc) atomicAdd(cells, nc);
+#ifdef SSG_TUNE
+	{
+		const int sl = U == 2 ? 32 : 40;
+		atomicAdd(&ssg_dbg_cyc[sl], tune_lane[0]); atomicAdd(&ssg_dbg_cyc[sl + 1], tune_lane[1]); atomicAdd(&ssg_dbg_cyc[sl + 2], 1ull);   /* lanes' trips, lanes' rows, lanes that had a side */
+		if (wv_lane() == (int)__builtin_ctzll(wv_ballot(1))) {   /* the wave's: sum over rows of the widest lane's trips, and its rows */
+			unsigned long long wt = 0, wr = 0;
+			for (int k = 0; k < SSG_XL_BAND_TRY * 512; ++k) { const unsigned v = (&tune_rowmax[0][0])[k]; if (v) { wt += v - 1; ++wr; } }
+			atomicAdd(&ssg_dbg_cyc[sl + 3], wt); atomicAdd(&ssg_dbg_cyc[sl + 4], wr); atomicAdd(&ssg_dbg_cyc[sl + 5], 1ull);
+		}
+	}
+#endif
 }
 
 template <int QCAP>

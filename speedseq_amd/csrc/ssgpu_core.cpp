@@ -359,6 +359,19 @@ int ssg_dbg_cycles(unsigned long long out[32])
 	return 0;
 #endif
 }
+/* slots 32..47 (the lane-per-extension kernel's lane utilisation: k_extlane.h) */
+int ssg_dbg_cycles_hi(unsigned long long out[16])
+{
+#ifdef SSG_EMU
+	memcpy(out, ssg_dbg_cyc + 32, 128); memset(ssg_dbg_cyc + 32, 0, 128);
+	return 0;
+#else
+	unsigned long long z[16]; memset(z, 0, sizeof z);
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 128, 256) != hipSuccess) return SSG_EHIP;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 128, 256) != hipSuccess) return SSG_EHIP;
+	return 0;
+#endif
+}
 
 int64_t ssg_index_l_pac(const ssg_index_t *ix) { return ix->v.l_pac; }
 int ssg_index_n_ctg(const ssg_index_t *ix) { return ix->v.n_ctg; }

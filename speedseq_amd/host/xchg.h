@@ -8,6 +8,8 @@
 #ifndef SSG_XCHG_H
 #define SSG_XCHG_H
 #include <thread>
+#include <atomic>
+#include <memory>
 #include <vector>
 #include <string>
 #include "ranks.h"
@@ -83,8 +85,8 @@ struct xchg_sock_t : xchg_t {
 };
 
 /* SSG_RANKS_XCHG: rccl | sock | file (bin/speedseq-ranks sets rccl when every rank has a device of its own; unset = file).  NULL = the files of rounds 4-5.
- * Which transport is used is agreed through the rendezvous directory before any collective call is made: a rank that cannot bring RCCL up must not leave the
- * others waiting inside ncclCommInitRank. */
+ * Which transport is used is agreed through the rendezvous directory before any collective call is made (and again after the first one): a rank that cannot
+ * bring RCCL up must not leave the others waiting inside a collective call. */
 static inline xchg_t *xchg_open(int rank, int world, const std::string &rdv)
 {
 	const char *e = getenv("SSG_RANKS_XCHG");
@@ -102,10 +104,30 @@ static inline xchg_t *xchg_open(int rank, int world, const std::string &rdv)
 	bool all = can == 'y';
 	for (int q = 0; q < world; ++q) { std::vector<uint8_t> b; if (!rk_file_wait(rdv + "/xchg." + std::to_string(q)) || !rk_file_get(rdv + "/xchg." + std::to_string(q), b) || b.size() != 1 || b[0] != 'y') all = false; }
 	if (!all) { if (rank == 0) fprintf(stderr, "[sambamba] sort: RCCL is not available on every rank; exchanging through files\n"); return 0; }
-	xchg_rccl_t *r = new xchg_rccl_t(rank, world);
-	if (r->up(rdv)) return r;
-	fprintf(stderr, "[sambamba] sort: no RCCL communicator: %s\n", ssg_last_error());
-	delete r;
-	return (xchg_t*)-1;
+	/* The communicator and a first exchange of one word with every peer (RCCL sets its peer connections up on first use) are made by a thread that is given
+	 * SSG_RANKS_RCCL_TIMEOUT seconds (90); what came of it is agreed through the directory once more, so that one rank's failure sends ALL ranks to the files
+	 * instead of leaving the others inside a collective call.  A communicator that is not used is left alone (destroying it can block on the rank that failed). */
+	struct att_t { std::atomic<int> st{0}; xchg_rccl_t *r = 0; std::string why; };
+	std::shared_ptr<att_t> att = std::make_shared<att_t>();
+	att->r = new xchg_rccl_t(rank, world);
+	std::thread([att, rdv, world]() {
+		bool ok = att->r->up(rdv);
+		if (ok) { std::vector<uint64_t> a((size_t)world, 1), b((size_t)world, 0); ok = att->r->alltoall_u64(a.data(), b.data(), 1); for (uint64_t v : b) if (v != 1) ok = false; }
+		if (!ok) att->why = ssg_last_error();
+		att->st.store(ok ? 1 : 2, std::memory_order_release);
+	}).detach();
+	const char *te = getenv("SSG_RANKS_RCCL_TIMEOUT");
+	const double limit = te && atof(te) > 0 ? atof(te) : 90.0;
+	double waited = 0;
+	while (att->st.load(std::memory_order_acquire) == 0 && waited < limit) { usleep(5000); waited += 0.005; }
+	const int st = att->st.load(std::memory_order_acquire);
+	const char up = st == 1 ? 'y' : 'n';
+	if (st != 1) fprintf(stderr, "[sambamba] sort: rank %d has no RCCL exchange (%s)\n", rank, st == 0 ? "no answer within the time limit" : att->why.c_str());
+	if (!rk_file_put(rdv + "/xchgup." + std::to_string(rank), &up, 1)) return (xchg_t*)-1;
+	all = up == 'y';
+	for (int q = 0; q < world; ++q) { std::vector<uint8_t> b; if (!rk_file_wait(rdv + "/xchgup." + std::to_string(q)) || !rk_file_get(rdv + "/xchgup." + std::to_string(q), b) || b.size() != 1 || b[0] != 'y') all = false; }
+	if (all) return att->r;
+	if (rank == 0) fprintf(stderr, "[sambamba] sort: RCCL did not come up on every rank; exchanging through files\n");
+	return 0;
 }
 #endif
