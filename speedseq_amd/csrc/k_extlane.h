@@ -38,61 +38,6 @@ SSG_DEVFN int ssg_cal_max_gap2(const ssg_mem_opt_t &opt, int qlen)
 	return l < opt.w << 1 ? l : opt.w << 1;
 }
 
-/* one lane per surviving chain g (global numbering: chain_off[r] + position in the read's order[]) */
-__global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, long n_jobs, const int64_t *read_off,
-                               const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
-                               const int32_t *chain_seeds, const int64_t *chain_off, int twin_cap,
-                               ssg_xjob_t *jobs, uint64_t *key_l, uint64_t *key_r, int short_cap, unsigned int *n_long /* [2]: sides longer than short_cap */)
-{
-	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= n_jobs) return;
-	int lo = 0, hi = n_reads - 1;   /* last read with chain_off[r] <= g */
-	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chain_off[mid] <= g) lo = mid; else hi = mid - 1; }
-	const int r = lo, ci = (int)(g - chain_off[r]);
-	const long s0 = seed_off[r];
-	const int l_query = (int)(read_off[r+1] - read_off[r]);
-	const ssg_chain_t c = chains[s0 + order[s0 + ci]];
-	const int32_t *cs = chain_seeds + c.first_seed;
-	const int64_t l_pac = ix.l_pac;
-	ssg_xjob_t jb;
-	jb.read = r; jb.flag = 0; jb.l_query = (int16_t)l_query; jb.rbeg = 0; jb.rmax0 = jb.rmax1 = 0; jb.qbeg = jb.len = 0; jb.seed_t = 0;
-	jb.cn = c.n; jb.rid = c.rid; jb.first_seed = c.first_seed; jb.frac_rep = c.frac_rep;
-	if (c.n == 0) { jb.flag = 2; jobs[g] = jb; key_l[g] = (uint64_t)511 << 32 | (uint64_t)g; key_r[g] = (uint64_t)511 << 32 | (uint64_t)g; return; }
-	int64_t rmax0 = l_pac << 1, rmax1 = 0;
-	uint64_t best = 0; int best_t = 0;
-	for (int i = 0; i < c.n; ++i) {
-		const ssg_seed_t t = seeds[cs[i]];
-		const int64_t b = t.rbeg - (t.qbeg + ssg_cal_max_gap2(opt, t.qbeg));
-		const int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + ssg_cal_max_gap2(opt, l_query - t.qbeg - t.len));
-		rmax0 = rmax0 < b ? rmax0 : b;
-		rmax1 = rmax1 > e ? rmax1 : e;
-		const uint64_t k = (uint64_t)t.score << 32 | (uint64_t)i;   /* upstream sorts (score<<32 | i) and starts from the largest */
-		if (i == 0 || k > best) { best = k; best_t = i; }
-	}
-	rmax0 = rmax0 > 0 ? rmax0 : 0;
-	rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
-	const int64_t rbeg0 = seeds[cs[0]].rbeg;
-	if (rmax0 < l_pac && l_pac < rmax1) { if (rbeg0 < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
-	{	/* upstream bns_fetch_seq: clip to the contig holding the first seed */
-		int is_rev; const int rid = ssg_pos2rid(ix, ssg_depos(ix, rbeg0, &is_rev));
-		int64_t far_beg = ix.ctg_off[rid], far_end = far_beg + ix.ctg_len[rid];
-		if (is_rev) { const int64_t t2 = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t2; }
-		rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
-		rmax1 = rmax1 < far_end ? rmax1 : far_end;
-	}
-	const ssg_seed_t s = seeds[cs[best_t]];
-	jb.rbeg = s.rbeg; jb.rmax0 = rmax0; jb.rmax1 = rmax1; jb.qbeg = (int16_t)s.qbeg; jb.len = (int16_t)s.len; jb.seed_t = (int16_t)best_t;
-	if (rmax1 - rmax0 > twin_cap) jb.flag = 1;   /* window beyond the wave kernel's buffer: reported as an error there */
-	jobs[g] = jb;
-	const int ql = jb.flag ? 0 : s.qbeg, qr = jb.flag ? 0 : l_query - s.qbeg - s.len;
-	key_l[g] = (uint64_t)(511 - ql) << 32 | (uint64_t)g;   /* ascending sort = longest query side first; side 0 = nothing to do */
-	key_r[g] = (uint64_t)(511 - qr) << 32 | (uint64_t)g;
-	{	/* one atomic per wave and side */
-		const unsigned long long bl = wv_ballot(ql > short_cap), br = wv_ballot(qr > short_cap), act = wv_ballot(1);
-		if (wv_lane() == (int)__builtin_ctzll(act)) { if (bl) atomicAdd(&n_long[0], (unsigned)__popcll(bl)); if (br) atomicAdd(&n_long[1], (unsigned)__popcll(br)); }
-	}
-}
-
 /* reference bases along an extension: doubled coordinate p0 + i*dir, read from the forward-strand pac */
 struct ssg_tgt_t {
 	const uint8_t *pac; int64_t f, nbytes, cur_i; int fs, comp; uint32_t cur, nxt;
@@ -123,6 +68,90 @@ SSG_DEVFN int ssg_tgt_next(ssg_tgt_t &t)
 	const int base = (int)(t.cur >> (((k >> 2) << 3) + ((~k & 3) << 1))) & 3;
 	t.f += t.fs;
 	return t.comp ? 3 - base : base;
+}
+
+/* How many rows an extension is likely to run, from its ungapped diagonal alone: ksw_extend2 leaves its row loop when the row maximum falls zdrop below the
+ * best one (or to zero); without that it runs all tlen rows.  The lanes of a wave run their rows in step, so a wave lasts as long as its longest lane: jobs are
+ * ordered by side length AND by this figure (measured on the bench batch before: the lanes of the long classes ran 78 rows on average in waves of 163).  A sort
+ * key only -- no result depends on it. */
+SSG_DEVFN int ssg_xl_pred_rows(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const uint8_t *q, int qstep, int qlen, int tlen, int64_t p0, int dir, int h0)
+{
+	if (qlen <= 0 || tlen <= 0) return 0;
+	ssg_tgt_t tg;
+	ssg_tgt_init(tg, ix, p0, dir);
+	const int n = qlen < tlen ? qlen : tlen;
+	int sc = h0, mx = h0;
+	for (int i = 0; i < n; ++i, q += qstep) {
+		const int tb = ssg_tgt_next(tg), qb = (int)*q;
+		sc += qb > 3 ? -1 : qb == tb ? opt.a : -opt.b;
+		if (sc > mx) mx = sc;
+		else if (sc <= 0 || (opt.zdrop > 0 && mx - sc > opt.zdrop)) return i + 1;
+	}
+	return tlen;
+}
+
+/* one lane per surviving chain g (global numbering: chain_off[r] + position in the read's order[]) */
+__global__ void __launch_bounds__(256) ssg_k_ext_prep(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, long n_jobs, const int64_t *read_off,
+                               const int64_t *seed_off, const ssg_seed_t *seeds, const ssg_chain_t *chains, const int32_t *order,
+                               const int32_t *chain_seeds, const int64_t *chain_off, int twin_cap,
+                               ssg_xjob_t *jobs, uint64_t *key_l, uint64_t *key_r, int short_cap, unsigned int *n_long /* [2]: sides longer than short_cap */,
+                               const uint8_t *seq, int rows_key /* 0: order by side length alone */)
+{
+	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_jobs) return;
+	int lo = 0, hi = n_reads - 1;   /* last read with chain_off[r] <= g */
+	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chain_off[mid] <= g) lo = mid; else hi = mid - 1; }
+	const int r = lo, ci = (int)(g - chain_off[r]);
+	const long s0 = seed_off[r];
+	const int l_query = (int)(read_off[r+1] - read_off[r]);
+	const ssg_chain_t c = chains[s0 + order[s0 + ci]];
+	const int32_t *cs = chain_seeds + c.first_seed;
+	const int64_t l_pac = ix.l_pac;
+	ssg_xjob_t jb;
+	jb.read = r; jb.flag = 0; jb.l_query = (int16_t)l_query; jb.rbeg = 0; jb.rmax0 = jb.rmax1 = 0; jb.qbeg = jb.len = 0; jb.seed_t = 0;
+	jb.cn = c.n; jb.rid = c.rid; jb.first_seed = c.first_seed; jb.frac_rep = c.frac_rep;
+	if (c.n == 0) { jb.flag = 2; jobs[g] = jb; key_l[g] = (uint64_t)511 << 41 | (uint64_t)g; key_r[g] = (uint64_t)511 << 41 | (uint64_t)g; return; }
+	int64_t rmax0 = l_pac << 1, rmax1 = 0;
+	uint64_t best = 0; int best_t = 0;
+	for (int i = 0; i < c.n; ++i) {
+		const ssg_seed_t t = seeds[cs[i]];
+		const int64_t b = t.rbeg - (t.qbeg + ssg_cal_max_gap2(opt, t.qbeg));
+		const int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + ssg_cal_max_gap2(opt, l_query - t.qbeg - t.len));
+		rmax0 = rmax0 < b ? rmax0 : b;
+		rmax1 = rmax1 > e ? rmax1 : e;
+		const uint64_t k = (uint64_t)t.score << 32 | (uint64_t)i;   /* upstream sorts (score<<32 | i) and starts from the largest */
+		if (i == 0 || k > best) { best = k; best_t = i; }
+	}
+	rmax0 = rmax0 > 0 ? rmax0 : 0;
+	rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+	const int64_t rbeg0 = seeds[cs[0]].rbeg;
+	if (rmax0 < l_pac && l_pac < rmax1) { if (rbeg0 < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
+	{	/* upstream bns_fetch_seq: clip to the contig holding the first seed */
+		int is_rev; const int rid = ssg_pos2rid(ix, ssg_depos(ix, rbeg0, &is_rev));
+		int64_t far_beg = ix.ctg_off[rid], far_end = far_beg + ix.ctg_len[rid];
+		if (is_rev) { const int64_t t2 = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t2; }
+		rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+		rmax1 = rmax1 < far_end ? rmax1 : far_end;
+	}
+	const ssg_seed_t s = seeds[cs[best_t]];
+	jb.rbeg = s.rbeg; jb.rmax0 = rmax0; jb.rmax1 = rmax1; jb.qbeg = (int16_t)s.qbeg; jb.len = (int16_t)s.len; jb.seed_t = (int16_t)best_t;
+	if (rmax1 - rmax0 > twin_cap) jb.flag = 1;   /* window beyond the wave kernel's buffer: reported as an error there */
+	jobs[g] = jb;
+	const int ql = jb.flag ? 0 : s.qbeg, qr = jb.flag ? 0 : l_query - s.qbeg - s.len;
+	int pl = 0, pr = 0;
+	if (rows_key && !jb.flag) {
+		const uint8_t *query = seq + read_off[r];
+		pl = ssg_xl_pred_rows(ix, opt, query + s.qbeg - 1, -1, ql, (int)(s.rbeg - rmax0), s.rbeg - 1, -1, s.len * opt.a);
+		pr = ssg_xl_pred_rows(ix, opt, query + s.qbeg + s.len, 1, qr, (int)(rmax1 - (s.rbeg + s.len)), s.rbeg + s.len, 1, s.len * opt.a);
+		pl = pl < 511 ? pl : 511; pr = pr < 511 ? pr : 511;
+	}
+	/* ascending sort = longest query side first (511 = nothing to do on this side), and among sides of one length the one expected to run most rows first */
+	key_l[g] = (uint64_t)(511 - ql) << 41 | (uint64_t)(511 - pl) << 32 | (uint64_t)g;
+	key_r[g] = (uint64_t)(511 - qr) << 41 | (uint64_t)(511 - pr) << 32 | (uint64_t)g;
+	{	/* one atomic per wave and side */
+		const unsigned long long bl = wv_ballot(ql > short_cap), br = wv_ballot(qr > short_cap), act = wv_ballot(1);
+		if (wv_lane() == (int)__builtin_ctzll(act)) { if (bl) atomicAdd(&n_long[0], (unsigned)__popcll(bl)); if (br) atomicAdd(&n_long[1], (unsigned)__popcll(br)); }
+	}
 }
 
 /* LDS word of a column: h:13 | e:13 | 6 x query code:6 (DP values stay below 8191: checked on the host).  The query field is the
@@ -184,6 +213,11 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 		if (end > qlen) end = qlen;
 		if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
 		else h1 = 0;
+		if (SSG_TUNING && tune_rowmax) {   /* rows of a wave's lanes run in step: the wave pays the widest lane's trips in every row */
+			const unsigned trips = end > beg ? (unsigned)((end - beg + U - 1) / U) : 0u;
+			atomicMax(&tune_rowmax[i < 511 ? i : 511], trips + 1u);
+			tune_lane[0] += trips; tune_lane[1] += 1;
+		}
 		if (end > beg) {
 			ncell += (unsigned long long)(end - beg);
 			int mk = -1;                                 /* max over the row of (h << 9 | j): the largest h, at its last column (columns up to 320) */
@@ -241,7 +275,7 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 #define SSG_XL_BAND_TRY 2   /* == SSG_MAX_BAND_TRY (upstream MAX_BAND_TRY) */
 
 /* side 0: left extensions (query and reference walked backwards from the seed); side 1: right extensions.
- * sorted[t] = (511 - side length) << 32 | job id; QCAP+1 columns of LDS per lane. */
+ * sorted[t] = (511 - side length) << 41 | (511 - expected rows) << 32 | job id; QCAP+1 columns of LDS per lane. */
 /* one job of one side; L: the workgroup's (qcap + 2 U) x 64 words of LDS */
 template <int U>
 SSG_DEVFN void ssg_ext_lane_job(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, const int side, const long job_first, const long n_jobs, const uint64_t *sorted,
@@ -260,7 +294,7 @@ SSG_DEVFN void ssg_ext_lane_job(const ssg_index_view_t &ix, const ssg_mem_opt_t 
 #endif
 	if (t >= n_jobs) return;
 	const uint64_t key = sorted[t];
-	if ((key >> 32) >= 511) return;   /* nothing on this side */
+	if ((key >> 41) >= 511) return;   /* nothing on this side */
 	const long g = (long)(uint32_t)key;
 	const ssg_xjob_t jb = jobs[g];
 	if (jb.flag) return;
@@ -343,7 +377,7 @@ __global__ void __launch_bounds__(64) ssg_k_ext_lane_dyn(ssg_index_view_t ix, ss
 	ssg_ext_lane_job<U>(ix, opt, side, job_first, n_jobs, sorted, jobs, seq, read_off, res_l, res_r, cells, L, qcap);
 }
 
-/* out[j] = number of keys whose high word is below t[j], in a list sorted ascending by it (= sides longer than 511 - t[j]): a binary search per threshold */
+/* out[j] = number of keys whose side-length field (bits 41..49) is below t[j], in a list sorted ascending by it (= sides longer than 511 - t[j]): a binary search per threshold */
 struct ssg_thr64_t { int n; int t[63]; };
 __global__ void ssg_k_sorted_hi_below(const uint64_t *sorted, long n, ssg_thr64_t th, unsigned int *out)
 {
@@ -351,7 +385,7 @@ __global__ void ssg_k_sorted_hi_below(const uint64_t *sorted, long n, ssg_thr64_
 	if (j >= th.n) return;
 	const uint64_t t = (uint64_t)th.t[j];
 	long lo = 0, hi = n;
-	while (lo < hi) { const long mid = (lo + hi) >> 1; if ((sorted[mid] >> 32) < t) lo = mid + 1; else hi = mid; }
+	while (lo < hi) { const long mid = (lo + hi) >> 1; if ((sorted[mid] >> 41) < t) lo = mid + 1; else hi = mid; }
 	out[j] = (unsigned int)lo;
 }
 #endif

@@ -915,8 +915,8 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		dbuf<unsigned int> d_nlong(2);
 		CHKA(d_nlong); CHK(d_nlong.zero());
 		SSG_LAUNCH(ssg_k_ext_prep, (n_jobs + 255) / 256, 256, 0, idx->v, *opt, n_reads, n_jobs, d_off, o.seed_off.p, d_seeds.p, d_chains.p, d_order.p, d_cseeds.p,
-		           d_choff.p, (int)SSG_TWIN_GLB, d_xjobs.p, d_kl.p, d_kr.p, short_cap, d_nlong.p);
-		CHK(sort_keys_u64(d_kl.p, d_sl.p, n_jobs, 32, 41)); CHK(sort_keys_u64(d_kr.p, d_sr.p, n_jobs, 32, 41));   /* 9 bits: 511 - side length */
+		           d_choff.p, (int)SSG_TWIN_GLB, d_xjobs.p, d_kl.p, d_kr.p, short_cap, d_nlong.p, d_seq, env_int("SSG_EXT_ROWS_KEY", 1));
+		CHK(sort_keys_u64(d_kl.p, d_sl.p, n_jobs, 32, 50)); CHK(sort_keys_u64(d_kr.p, d_sr.p, n_jobs, 32, 50));   /* 9 + 9 bits: 511 - side length, 511 - expected rows */
 		unsigned int h_nlong[2];
 		CHK(d_nlong.down(h_nlong, 2));
 		if (ssg_debug()) fprintf(stderr, "[ssgpu] ext jobs %ld, long sides %u / %u\n", n_jobs, h_nlong[0], h_nlong[1]);
