@@ -112,11 +112,220 @@ SSG_DEVFN int wv_gen_cigar(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt,
 	return score;
 }
 
+/* ---- the banded global alignment with ONE LANE PER REQUEST ----
+ * Nine records in ten that need ksw_global2 need it with a narrow band (three or four mismatches: w = 11 or 16; a short indel: w = 4..8).  A wavefront per record
+ * runs such a band on a third of its lanes, row after dependent row, then backtracks and walks NM / MD on lane 0: 18 ms of the step for 280 k records.  Here a lane
+ * owns a record: the row {H, E} of the band in LDS (a ring of 2w + 2 columns, h:16 | e:16 -- "minus infinity" is -16384, every value of the recurrence is an
+ * offset from it or a real score far above it, so all comparisons come out as upstream's), the query as 4-bit codes in LDS, the direction bits four to a cell and
+ * eight cells to a word in a per-wave HBM slab ([row][word][lane]: coalesced), then the lane backtracks its own matrix and walks NM / MD from the 2-bit pac.
+ * Classes by band width (LDS per wave); a record whose first alignment does not end upstream's loop (score < truesc - a: the band is doubled) is handed to the
+ * wave kernel, which starts over. */
+#define SSG_R2D_CLASSES 3
+#define SSG_R2D_NEG (-16384)
+SSG_DEVFN int ssg_r2d_wmax(int cls) { return cls == 0 ? 8 : cls == 1 ? 16 : 32; }
+/* the band bwa_gen_cigar2 runs for (w_, l_query, rlen) */
+SSG_DEVFN int ssg_gen_cigar_band(const ssg_mem_opt_t &opt, int w_, int l_query, int rlen)
+{
+	int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+	int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+	int max_gap = max_ins > max_del ? max_ins : max_del;
+	max_gap = max_gap > 1 ? max_gap : 1;
+	int w = (max_gap + iabs(rlen - l_query) + 1) >> 1;
+	w = w < w_ ? w : w_;
+	const int min_w = iabs(rlen - l_query) + 3;
+	return w > min_w ? w : min_w;
+}
+SSG_DEVFN int ssg_r2d_class(const ssg_mem_opt_t &opt, int w_, int l_query, int rlen)
+{
+	if (l_query == rlen && w_ == 0) return -1;   /* (the gap-free branch: never listed) */
+	if (l_query < 1 || rlen < 1 || l_query > SSG_ALN_QLDS) return -1;
+	const int w = ssg_gen_cigar_band(opt, w_, l_query, rlen);
+	return w <= 8 ? 0 : w <= 16 ? 1 : w <= 32 ? 2 : -1;
+}
+
+/* grid-strided over list[0 .. *n_list); LDS: (2 wmax + 2 + qwords) x 64 words; zslab: per wave zrows x zw x 64 words */
+__global__ void __launch_bounds__(64) ssg_k_reg2aln_dplane(ssg_index_view_t ix, ssg_mem_opt_t opt, const int32_t *list, const unsigned int *n_list, const ssg_alnreq_t *req,
+                              const ssg_alnreg_t *regs, const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, uint32_t *zslab, int wmax, int qwords, int zw, int zrows,
+                              int32_t *err, unsigned long long *cells, int32_t *todo_list, unsigned int *n_todo)
+{
+#ifdef SSG_EMU
+	uint32_t *L = (uint32_t*)emu::dyn_lds;
+#else
+	extern __shared__ uint32_t ssg_r2d_lds[];
+	uint32_t *L = ssg_r2d_lds;
+#endif
+	const int lane = (int)threadIdx.x;
+	const int S = 2 * wmax + 2;
+	uint32_t *EH = L + lane, *Q = L + (long)S * 64 + lane;
+	uint32_t *Z = zslab + (long)blockIdx.x * zrows * zw * 64 + lane;
+	const long n = (long)*n_list;
+	const int sa = opt.a, sb = opt.b;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	unsigned long long ncell = 0;
+	int myerr = 0;
+	for (long t = (long)blockIdx.x * 64 + lane; t < n; t += (long)gridDim.x * 64) {
+		const long g = list[t];
+		const ssg_alnreq_t rq = req[g];
+		const ssg_alnreg_t ar = regs[rq.reg];
+		ssg_aln_t *a = alns + g;
+		const int l_query = (int)(read_off[rq.read + 1] - read_off[rq.read]);
+		const int qb = ar.qb, qe = ar.qe, qlen = qe - qb;
+		const int64_t rb = ar.rb, re = ar.re;
+		const int tlen = (int)(re - rb);
+		int w2;
+		{
+			const int tmp = ssg_infer_bw(qlen, tlen, ar.truesc, opt.a, opt.o_del, opt.e_del);
+			w2 = ssg_infer_bw(qlen, tlen, ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+			w2 = w2 > tmp ? w2 : tmp;
+			if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+		}
+		const int w = ssg_gen_cigar_band(opt, w2, qlen, tlen);
+		const bool rev = rb >= ix.l_pac;
+		const uint8_t *query = seq + read_off[rq.read] + qb;
+		if (w > wmax || tlen > zrows || (qlen + 7) / 8 > qwords) { todo_list[atomicAdd(n_todo, 1u)] = (int32_t)g; continue; }   /* (not listed for this class by ssg_k_reg2aln_lane) */
+		/* query codes in alignment order, eight to a word */
+		for (int k = 0; k * 8 < qlen; ++k) {
+			uint32_t wd = 0;
+			for (int u = 0; u < 8 && k * 8 + u < qlen; ++u) { const int j = k * 8 + u; wd |= (uint32_t)(rev ? query[qlen - 1 - j] : query[j]) << (4 * u); }
+			Q[k * 64] = wd;
+		}
+		/* row -1 */
+#define SSG_R2D_PACK(h, e) (((uint32_t)(e) << 16) | ((uint32_t)(h) & 0xffffu))
+		EH[0] = SSG_R2D_PACK(0, SSG_R2D_NEG);
+		for (int j = 1; j <= qlen && j <= w; ++j) EH[(j % S) * 64] = SSG_R2D_PACK(-(o_ins + e_ins * j), SSG_R2D_NEG);
+		if (w + 1 <= qlen) EH[((w + 1) % S) * 64] = SSG_R2D_PACK(SSG_R2D_NEG, SSG_R2D_NEG);   /* (row 0 reads columns 0 .. w only; set for tidiness) */
+		const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+		ssg_tgt_t tg;
+		ssg_tgt_init(tg, ix, rev ? re - 1 : rb, rev ? -1 : 1);
+		int sbeg = 0;   /* ring slot of column beg */
+		for (int i = 0; i < tlen; ++i) {
+			const int tb = ssg_tgt_next(tg);
+			const int beg = i > w ? i - w : 0;
+			const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+			if (i > w) { ++sbeg; if (sbeg == S) sbeg = 0; }
+			int h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : SSG_R2D_NEG, f = SSG_R2D_NEG;
+			int slot = sbeg, zi = 0;
+			uint32_t zacc = 0, qw = Q[(beg >> 3) * 64];
+			ncell += (unsigned long long)(end - beg);
+			for (int j = beg; j < end; ++j) {
+				if ((j & 7) == 0) qw = Q[(j >> 3) * 64];
+				const uint32_t wd = EH[slot * 64];
+				int m = (int)(wd << 16) >> 16, e = (int)wd >> 16, h, tt;
+				m += ssg_sc(sa, sb, tb, (int)(qw >> ((j & 7) * 4)) & 15);
+				uint32_t d = m >= e ? 0u : 1u;
+				h = m >= e ? m : e;
+				d = h >= f ? d : 2u;
+				h = h >= f ? h : f;
+				tt = m - oe_del;
+				e -= e_del;
+				d |= e > tt ? 4u : 0u;
+				e = e > tt ? e : tt;
+				EH[slot * 64] = SSG_R2D_PACK(h1, e);
+				h1 = h;
+				tt = m - oe_ins;
+				f -= e_ins;
+				d |= f > tt ? 8u : 0u;
+				f = f > tt ? f : tt;
+				const int c = j - beg;
+				zacc |= d << ((c & 7) * 4);
+				if ((c & 7) == 7) { Z[((long)i * zw + zi) * 64] = zacc; zacc = 0; ++zi; }
+				++slot; if (slot == S) slot = 0;
+			}
+			if ((end - beg) & 7) Z[((long)i * zw + zi) * 64] = zacc;
+			EH[slot * 64] = SSG_R2D_PACK(h1, SSG_R2D_NEG);   /* eh[end] */
+		}
+		int score;
+		{ const uint32_t wd = EH[(qlen % S) * 64]; score = (int)(wd << 16) >> 16; }
+		/* upstream's loop ends after this alignment when the score is within one match of the local one, or the band cannot grow */
+		if (!(w2 == opt.w << 2 || !(score < ar.truesc - opt.a))) { todo_list[atomicAdd(n_todo, 1u)] = (int32_t)g; continue; }
+		/* backtrace (upstream ksw_global2): ops from the end, merged, then reversed */
+		int n_cigar = 0;
+		{
+			int which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+			int cur_op = -1, cur_len = 0, nst = 0;
+#define SSG_R2D_PUSH(op, len) do { if ((op) == cur_op) cur_len += (len); else { if (cur_op >= 0) { if (nst < SSG_MAX_CIGAR) a->cigar[nst] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++nst; } cur_op = (op); cur_len = (len); } } while (0)
+			while (i >= 0 && k >= 0) {
+				const int c = k - (i > w ? i - w : 0);
+				const uint32_t nib = Z[((long)i * zw + (c >> 3)) * 64] >> ((c & 7) * 4) & 15u;
+				which = which == 0 ? (int)(nib & 3u) : which == 1 ? (int)(nib >> 2 & 1u) : (int)(nib >> 3 & 1u) * 2;
+				if (which == 0) { SSG_R2D_PUSH(0, 1); --i; --k; }
+				else if (which == 1) { SSG_R2D_PUSH(2, 1); --i; }
+				else { SSG_R2D_PUSH(1, 1); --k; }
+			}
+			if (i >= 0) SSG_R2D_PUSH(2, i + 1);
+			if (k >= 0) SSG_R2D_PUSH(1, k + 1);
+			if (cur_op >= 0) { if (nst < SSG_MAX_CIGAR) a->cigar[nst] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++nst; }
+#undef SSG_R2D_PUSH
+			const int mst = nst < SSG_MAX_CIGAR ? nst : SSG_MAX_CIGAR;
+			for (int x = 0; x < mst >> 1; ++x) { const uint32_t t2 = a->cigar[x]; a->cigar[x] = a->cigar[mst - 1 - x]; a->cigar[mst - 1 - x] = t2; }
+			n_cigar = nst;
+			if (n_cigar > SSG_MAX_CIGAR - 2) { myerr = 6; n_cigar = SSG_MAX_CIGAR - 2; }
+			(void)n_col;
+		}
+		/* NM and MD (upstream bwa_gen_cigar2's walk) */
+		int nm, lmd;
+		{
+			const char *int2base = rev ? "TGCAN" : "ACGTN";
+			int x = 0, u = 0, n_mm = 0, n_gap = 0, l = 0;
+			ssg_tgt_init(tg, ix, rev ? re - 1 : rb, rev ? -1 : 1);
+			for (int k = 0; k < n_cigar; ++k) {
+				const uint32_t cg = a->cigar[k];
+				const int op = (int)(cg & 0xf), len = (int)(cg >> 4);
+				if (op == 0) {
+					for (int i = 0; i < len; ++i) {
+						const int tb = ssg_tgt_next(tg), qc = (int)(Q[((x + i) >> 3) * 64] >> (((x + i) & 7) * 4)) & 15;
+						if (qc != tb) { l = ssg_put_int(a->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) a->md[l] = int2base[tb]; ++l; ++n_mm; u = 0; }
+						else ++u;
+					}
+					x += len;
+				} else if (op == 2) {
+					const bool mid = k > 0 && k < n_cigar - 1;
+					if (mid) { l = ssg_put_int(a->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) a->md[l] = '^'; ++l; }
+					for (int i = 0; i < len; ++i) { const int tb = ssg_tgt_next(tg); if (mid) { if (l < SSG_MAX_MD - 1) a->md[l] = int2base[tb]; ++l; } }
+					if (mid) { u = 0; n_gap += len; }
+				} else if (op == 1) { x += len; n_gap += len; }
+			}
+			l = ssg_put_int(a->md, l, SSG_MAX_MD - 1, u);
+			a->md[l < SSG_MAX_MD - 1 ? l : SSG_MAX_MD - 1] = 0;
+			nm = n_mm + n_gap; lmd = l;
+			if (lmd >= SSG_MAX_MD - 1) myerr = myerr > 7 ? myerr : 7;
+		}
+		/* the record (upstream mem_reg2aln after the loop) */
+		{
+			int is_rev;
+			int64_t pos = ssg_depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+			if (n_cigar > 0) { /* squeeze out a leading or trailing deletion */
+				if ((a->cigar[0] & 0xf) == 2) { pos += a->cigar[0] >> 4; --n_cigar; for (int k = 0; k < n_cigar; ++k) a->cigar[k] = a->cigar[k+1]; }
+				else if ((a->cigar[n_cigar-1] & 0xf) == 2) --n_cigar;
+			}
+			if (qb != 0 || qe != l_query) {
+				const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+				if (clip5) { for (int k = n_cigar; k > 0; --k) a->cigar[k] = a->cigar[k-1]; a->cigar[0] = (uint32_t)clip5 << 4 | 3; ++n_cigar; }
+				if (clip3) a->cigar[n_cigar++] = (uint32_t)clip3 << 4 | 3;
+			}
+			a->n_cigar = n_cigar; a->NM = nm; a->l_md = lmd;
+			a->rid = ssg_pos2rid(ix, pos);
+			a->pos = pos - ix.ctg_off[a->rid];
+			a->is_rev = is_rev;
+			a->flag = rq.flag | (ar.secondary >= 0 ? 0x100 : 0);
+			a->mapq = rq.mapq;
+			a->score = ar.score; a->sub = ar.sub > ar.csub ? ar.sub : ar.csub;
+			a->reg_idx = rq.owner; a->xa_cnt = 0; a->_pad = rq.kind;
+		}
+	}
+#undef SSG_R2D_PACK
+	if (cells && ncell) atomicAdd(cells, ncell);
+	if (myerr) atomicMax(err, myerr);
+}
+
 /* Records whose region aligns without gaps (upstream bwa_gen_cigar2's first branch: equal lengths and a zero band from
  * infer_bw -- the bulk of a batch) need no DP: one LANE per record walks the bases once for NM / MD.  The rest (and any
  * malformed request) goes to the wave-per-record kernel through todo_list. */
 __global__ void __launch_bounds__(64) ssg_k_reg2aln_lane(ssg_index_view_t ix, ssg_mem_opt_t opt, long n_req, const ssg_alnreq_t *req, const ssg_alnreg_t *regs,
-                              const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, int32_t *err, int32_t *todo_list, unsigned int *n_todo)
+                              const uint8_t *seq, const int64_t *read_off, ssg_aln_t *alns, int32_t *err, int32_t *todo_list, unsigned int *n_todo,
+                              int32_t *dp_list /* [SSG_R2D_CLASSES][n_req] or NULL: requests whose band fits the lane-per-request DP kernel, by class */, unsigned int *n_dp)
 {
 	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_req) return;
@@ -138,7 +347,14 @@ __global__ void __launch_bounds__(64) ssg_k_reg2aln_lane(ssg_index_view_t ix, ss
 		w2 = w2 > tmp ? w2 : tmp;
 		if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
 	}
-	if (w2 != 0 || (int64_t)lq != re - rb) { todo_list[atomicAdd(n_todo, 1u)] = (int32_t)g; return; }
+	if (w2 != 0 || (int64_t)lq != re - rb) {
+		if (SSG_TUNING) { const int wb = w2 < 0 ? 15 : w2 == 0 ? 0 : w2 <= 4 ? 1 : w2 <= 8 ? 2 : w2 <= 12 ? 3 : w2 <= 16 ? 4 : w2 <= 24 ? 5 : w2 <= 32 ? 6 : w2 <= 48 ? 7 : w2 <= 64 ? 8 : w2 < 100 ? 9 : 10; atomicAdd(&ssg_dbg_cyc[48 + wb], 1ull); }
+		if (dp_list && w2 >= 0) {
+			const int cls = ssg_r2d_class(opt, w2 < opt.w << 2 ? w2 : opt.w << 2, lq, (int)(re - rb));
+			if (cls >= 0) { dp_list[(long)cls * n_req + atomicAdd(&n_dp[cls], 1u)] = (int32_t)g; return; }
+		}
+		todo_list[atomicAdd(n_todo, 1u)] = (int32_t)g; return;
+	}
 	const uint8_t *query = seq + read_off[rq.read] + qb;
 	const bool rev = rb >= ix.l_pac;
 	const char *int2base = rev ? "TGCAN" : "ACGTN";

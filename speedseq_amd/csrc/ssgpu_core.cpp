@@ -359,16 +359,16 @@ int ssg_dbg_cycles(unsigned long long out[32])
 	return 0;
 #endif
 }
-/* slots 32..47 (the lane-per-extension kernel's lane utilisation: k_extlane.h) */
-int ssg_dbg_cycles_hi(unsigned long long out[16])
+/* slots 32..63 (32..47: the lane-per-extension kernel's lane utilisation, k_extlane.h; 48..63: band widths of the requests that need a DP, k_aln.h) */
+int ssg_dbg_cycles_hi(unsigned long long out[32])
 {
 #ifdef SSG_EMU
-	memcpy(out, ssg_dbg_cyc + 32, 128); memset(ssg_dbg_cyc + 32, 0, 128);
+	memcpy(out, ssg_dbg_cyc + 32, 256); memset(ssg_dbg_cyc + 32, 0, 256);
 	return 0;
 #else
-	unsigned long long z[16]; memset(z, 0, sizeof z);
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 128, 256) != hipSuccess) return SSG_EHIP;
-	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 128, 256) != hipSuccess) return SSG_EHIP;
+	unsigned long long z[32]; memset(z, 0, sizeof z);
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), 256, 256) != hipSuccess) return SSG_EHIP;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, 256, 256) != hipSuccess) return SSG_EHIP;
 	return 0;
 #endif
 }
@@ -1093,6 +1093,51 @@ static void host_pestat(const ssg_mem_opt_t *opt, const uint32_t *hist /* [4][SS
 
 /* the whole PE hot path on device-resident inputs; `keep` != NULL leaves the records in HBM
  * instead of downloading them into `res` */
+/* CIGAR / NM / MD of the compacted requests (k_aln.h): gap-free records one lane each; records whose band is narrow one lane each through the DP (three classes of
+ * band width, a launch each with the LDS that class needs, side by side); the rest -- wide bands, and records whose first alignment does not end upstream's
+ * loop -- one wave each.  SSG_R2A_DPLANE=0: no lane DP (A/B, tests). */
+static int run_reg2aln(const ssg_index *idx, const ssg_mem_opt_t *opt, int64_t nreq, const ssg_alnreq_t *d_creq, const ssg_alnreg_t *d_regs, const uint8_t *d_seq, const int64_t *d_off,
+                       ssg_aln_t *d_alns, int32_t *d_gerr, unsigned long long *d_cnt, int max_len)
+{
+	const int wpb = SSG_WAVES_PER_WG;
+	long nwg = std::min<long>(((long)nreq + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
+	long nw = nwg * wpb;
+	dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB), d_z((size_t)nw * SSG_Z_CAP);
+	CHKA(d_tglb); CHKA(d_z);
+	dbuf<int32_t> d_rtodo((size_t)nreq + 1); dbuf<unsigned int> d_nrtodo(1 + SSG_R2D_CLASSES);
+	CHKA(d_rtodo); CHKA(d_nrtodo); CHK(d_nrtodo.zero());
+	const bool dplane = env_int("SSG_R2A_DPLANE", 1) != 0 && max_len <= SSG_ALN_QLDS;
+	dbuf<int32_t> d_dpl(dplane ? (size_t)nreq * SSG_R2D_CLASSES + 1 : 1);
+	CHKA(d_dpl);
+	SSG_LAUNCH(ssg_k_reg2aln_lane, (nreq + 63) / 64, 64, 0, idx->v, *opt, (long)nreq, d_creq, d_regs, d_seq, d_off, d_alns, d_gerr, d_rtodo.p, d_nrtodo.p,
+	           dplane ? d_dpl.p : (int32_t*)0, d_nrtodo.p + 1);
+	if (dplane) {
+		const int qwords = (max_len + 7) / 8, zrows = max_len + 32;
+		const long G = std::min<long>((nreq + 63) / 64, (long)env_int("SSG_R2D_WAVES", 2048));
+		size_t zoff[SSG_R2D_CLASSES + 1]; zoff[0] = 0;
+		for (int c = 0; c < SSG_R2D_CLASSES; ++c) { const int wm = c == 0 ? 8 : c == 1 ? 16 : 32; zoff[c + 1] = zoff[c] + (size_t)G * zrows * ((2 * wm + 1 + 7) / 8) * 64; }
+		dbuf<uint32_t> d_zs(zoff[SSG_R2D_CLASSES] + 1);
+		CHKA(d_zs);
+		ssg_fork(2);
+		for (int c = SSG_R2D_CLASSES - 1; c >= 0; --c) {   /* widest class first */
+			const int wm = c == 0 ? 8 : c == 1 ? 16 : 32, zw = (2 * wm + 1 + 7) / 8;
+			const size_t lds = (size_t)(2 * wm + 2 + qwords) * 256;
+#define SSG_R2D_GO(LAUNCH, ...) LAUNCH(__VA_ARGS__ ssg_k_reg2aln_dplane, G, 64, lds, idx->v, *opt, d_dpl.p + (size_t)c * nreq, d_nrtodo.p + 1 + c, d_creq, d_regs, d_seq, d_off, d_alns, \
+                                       d_zs.p + zoff[c], wm, qwords, zw, zrows, d_gerr, d_cnt, d_rtodo.p, d_nrtodo.p)
+			if (c == 2) SSG_R2D_GO(SSG_LAUNCH); else if (c == 1) SSG_R2D_GO(SSG_LAUNCH_ON, 0,); else SSG_R2D_GO(SSG_LAUNCH_ON, 1,);
+#undef SSG_R2D_GO
+		}
+		ssg_join(2);
+		SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq, d_regs, d_seq, d_off, d_alns, d_tglb.p, d_z.p, d_gerr, d_cnt, d_rtodo.p, d_nrtodo.p);
+		CHK(rt_sync());   /* (before the slabs go back to the arena) */
+		if (ssg_debug()) { unsigned int c[1 + SSG_R2D_CLASSES]; CHK(d_nrtodo.down(c, 1 + SSG_R2D_CLASSES)); fprintf(stderr, "[ssgpu] reg2aln: %lld requests; lane DP by band class %u / %u / %u, wave kernel %u\n", (long long)nreq, c[1], c[2], c[3], c[0]); }
+		return 0;
+	}
+	SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq, d_regs, d_seq, d_off, d_alns, d_tglb.p, d_z.p, d_gerr, d_cnt, d_rtodo.p, d_nrtodo.p);
+	CHK(rt_sync());
+	return 0;
+}
+
 static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *d_seq_p, const int64_t *d_off_p, int max_len,
                    const int32_t *d_pb_p, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result *res, pe_dev_t *keep)
 {
@@ -1189,14 +1234,14 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	CHKA(d_req);
 	{	/* ---- primary marking, pairing, MAPQ, record selection ---- */
 		const int ucap = 1024;
-		long nthr = std::min<long>(((long)n_pairs + 63) / 64 * 64, 131072);   /* 8 waves/CU at 2 waves/SIMD (249 VGPRs); 16 KB of candidate scratch per lane */
+		long nthr = std::min<long>(((long)n_pairs + 63) / 64 * 64, (long)env_int("SSG_PF_THREADS", 131072));   /* 8 waves/CU at 2 waves/SIMD (249 VGPRs); 16 KB of candidate scratch per lane */
 		dbuf<ssg_pair64_t> d_v((size_t)t2 + 1), d_u((size_t)nthr * ucap);
 		CHKA(d_v); CHKA(d_u);
 		/* d_pw is heaviest first: pairs with long region lists get a wavefront each (k_pairw.h), the rest a lane each */
 		unsigned int cc[5];
 		CHK(dev_class_counts(d_pkey.p, n_pairs, 0, 0, env_int("SSG_PAIR_WAVE_MIN", 64), cc));
 		const int n_heavy = (int)cc[0];
-		const long nwg_h = n_heavy > 0 ? std::min<long>(((long)n_heavy + wpb - 1) / wpb, 512) : 0;
+		const long nwg_h = n_heavy > 0 ? std::min<long>(((long)n_heavy + wpb - 1) / wpb, (long)env_int("SSG_PFW_WGS", 512)) : 0;
 		dbuf<ssg_pw_slab_t> d_slab((size_t)nwg_h * wpb + 1);
 		CHKA(d_slab); CHK(d_q.zero());
 		ssg_fork(1);
@@ -1238,18 +1283,7 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 	dbuf<ssg_alnreq_t> d_creq((size_t)nreq + 1); dbuf<ssg_aln_t> d_alns((size_t)nreq + 1);
 	CHKA(d_creq); CHKA(d_alns);
 	SSG_LAUNCH(ssg_k_compact_req, (n_reads + block - 1) / block, block, 0, n_reads, d_reqoff.p, d_req.p, d_nreq.p, d_coff.p, d_creq.p);
-	{
-		long nwg = std::min<long>(((long)nreq + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
-		long nw = nwg * wpb;
-		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB), d_z((size_t)nw * SSG_Z_CAP);
-		CHKA(d_tglb); CHKA(d_z);
-		/* gap-free records one lane each; the records that need the banded global alignment one wave each */
-		dbuf<int32_t> d_rtodo((size_t)nreq + 1); dbuf<unsigned int> d_nrtodo(1);
-		CHKA(d_rtodo); CHKA(d_nrtodo); CHK(d_nrtodo.zero());
-		SSG_LAUNCH(ssg_k_reg2aln_lane, (nreq + 63) / 64, 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_gerr.p, d_rtodo.p, d_nrtodo.p);
-		SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
-		CHK(rt_sync());
-	}
+	CHK(run_reg2aln(idx, opt, nreq, d_creq.p, d_regs2.p, d_seq.p, d_off.p, d_alns.p, d_gerr.p, d_cnt.p, max_len));
 	STAGE("reg2aln");
 	{ int32_t ge; CHK(d_gerr.down(&ge, 1)); if (ge) { char b[96]; snprintf(b, sizeof(b), "CIGAR generation exceeded an on-device capacity (code %d)", ge); ssg_err_msg = b; return SSG_EOVERFLOW; } }
 	{ unsigned long long c[2]; CHK(d_cnt.down(c, 2)); res->stats[2] = c[0]; res->stats[3] = c[1]; res->stats[4] = (uint64_t)nreq; }
@@ -1294,17 +1328,7 @@ static int se_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads
 	dbuf<ssg_alnreq_t> d_creq((size_t)nreq + 1); dbuf<ssg_aln_t> d_alns((size_t)nreq + 1);
 	CHKA(d_creq); CHKA(d_alns);
 	SSG_LAUNCH(ssg_k_compact_req, (n_reads + block - 1) / block, block, 0, n_reads, d_reqoff.p, d_req.p, d_nreq.p, d_coff.p, d_creq.p);
-	{
-		long nwg = std::min<long>(((long)nreq + wpb - 1) / wpb, SSG_MAX_RESIDENT_WG);
-		long nw = nwg * wpb;
-		dbuf<uint8_t> d_tglb((size_t)nw * SSG_TWIN_GLB), d_z((size_t)nw * SSG_Z_CAP);
-		CHKA(d_tglb); CHKA(d_z);
-		dbuf<int32_t> d_rtodo((size_t)nreq + 1); dbuf<unsigned int> d_nrtodo(1);
-		CHKA(d_rtodo); CHKA(d_nrtodo); CHK(d_nrtodo.zero());
-		SSG_LAUNCH(ssg_k_reg2aln_lane, (nreq + 63) / 64, 64, 0, idx->v, *opt, (long)nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_gerr.p, d_rtodo.p, d_nrtodo.p);
-		SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_tglb.p, d_z.p, d_gerr.p, d_cnt.p, d_rtodo.p, d_nrtodo.p);
-		CHK(rt_sync());
-	}
+	CHK(run_reg2aln(idx, opt, nreq, d_creq.p, a1.regs.p, d_seq, d_off, d_alns.p, d_gerr.p, d_cnt.p, max_len));
 	STAGE("reg2aln");
 	{ int32_t ge; CHK(d_gerr.down(&ge, 1)); if (ge) { char b[96]; snprintf(b, sizeof(b), "CIGAR generation exceeded an on-device capacity (code %d)", ge); ssg_err_msg = b; return SSG_EOVERFLOW; } }
 	{ unsigned long long c[2]; CHK(d_cnt.down(c, 2)); res->stats[2] = c[0]; res->stats[3] = c[1]; res->stats[4] = (uint64_t)nreq; }

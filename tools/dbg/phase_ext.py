@@ -10,7 +10,7 @@ with contextlib.redirect_stdout(buf):
 sys.path.insert(0, '.')
 from speedseq_amd import capi
 lib = capi.Lib()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 lib.l.ssg_dbg_cycles_hi(out)
 t = list(out)
 for name, b in (("U=2 (sides <= 72)", 0), ("U=4 (longer sides)", 8)):
@@ -19,3 +19,4 @@ for name, b in (("U=2 (sides <= 72)", 0), ("U=4 (longer sides)", 8)):
         continue
     print("%s: %d lanes in %d waves (%.1f per wave); trips: lanes %d, waves x 64 %d -> lane utilisation %.3f; rows: per lane %.1f, per wave %.1f (row utilisation %.3f); trips per row: lane %.2f, wave (widest) %.2f"
           % (name, ln, wn, ln / wn, lt, 64 * wt, lt / max(1, 64 * wt), lr / max(1, ln), wr / wn, lr / max(1, 64 * wr), lt / max(1, lr), wt / max(1, wr)))
+print("requests listed for the DP kernel by band width w2 (0: lengths differ only; <=4, <=8, <=12, <=16, <=24, <=32, <=48, <=64, <100, >=100; last: not computable):", t[16:27], t[31])

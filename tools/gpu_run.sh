@@ -9,6 +9,7 @@
 #   profile                   tools/profile_round.sh TAG (kernel stats + PMC passes + probes) and tools/pmc_summarize.py
 #   profile250                the same on the 2x250 workload (BASELINE.json configs[4], 200 k pairs), no probes: TAG_cfg5_*
 #   stats                     only the rocprofv3 --kernel-trace --stats pass of the device step
+#   timeline[:ARGS]           kernel trace of the device step -> which kernels run alone, in what order (TAG_timeline.txt)
 #   soak:PAIRS[:MEM_GB]       tools/soak.py --stream --pairs PAIRS [--mem MEM_GB]   (the FASTQ goes through a FIFO, never a file)
 #   pin                       write the kernel ISA pin if the suite log and the bench parity of this TAG are green
 #   sh:CMD                    any other command (with '+' for spaces)
@@ -54,6 +55,11 @@ PY
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $B > $out/${tag}_bench_under_rocprof.log 2>&1)
     find /tmp/prof_$tag -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
     grep ssg_k_ $out/${tag}_kernel_stats.csv | cut -c1-60,200- | head -30 ;;
+  timeline)   # the last device step of a traced run: which kernels run alone (tools/dbg/kernel_timeline.py)
+    B="python $PWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-profile --config5-pairs 0 --no-dist-rehearsal --script-pairs 0 --cpu-script-pairs 0 ${arg//+/ }"
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$tag -o $tag -- $B > $out/${tag}_bench_under_trace.log 2>&1)
+    f=$(find /tmp/tl_$tag -name "*kernel_trace.csv" | head -1)
+    python tools/dbg/kernel_timeline.py $f --json $out/${tag}_timeline.json > $out/${tag}_timeline.txt 2>&1; head -60 $out/${tag}_timeline.txt | cut -c1-200 ;;
   soak)
     pairs=${arg%%:*}; mem=""; [ "$arg" != "$pairs" ] && mem="--mem ${arg#*:}"
     timeout 3000 python tools/soak.py --stream --limit 2400 --pairs $pairs $mem > $out/${tag}_soak_$pairs.json 2> $out/${tag}_soak_$pairs.err; tail -3 $out/${tag}_soak_$pairs.err | cut -c1-300
