@@ -363,8 +363,8 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	}
 	{	/* mem_sort_dedup_patch: on compact keys unless a pair of regions has to be globally aligned (patched) */
 		int m = -1;
-		if (av_n <= SSG_SDP_SMALL) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2, l_pac);
-		else if (av_n <= SSG_SDP_BIG) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2, l_pac);
+		if (av_n <= SSG_SDP_SMALL) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_lds->key, sdp_lds->skey, sdp_lds->idx, sdp_lds->idx2, l_pac);
+		else if (av_n <= SSG_SDP_BIG) m = wv_sort_dedup_fast(opt, av_n, av, sdp_tmp, sdp_big->key, sdp_big->skey, sdp_big->idx, sdp_big->idx2, l_pac);
 		av_n = m >= 0 ? m : wv_sort_dedup_patch<WIDE>(ix, opt, query, 1, av_n, av, tg, SSG_TWIN_GLB, &myerr, &nc);
 		/* no pair of regions reached mem_patch_reg's alignment: the list is the output of the plain redundancy scan, a fixed point of it
 		 * (mate rescue's first re-sort of this list can be the incremental one, k_sdp.h wv_sort_dedup_incr) */

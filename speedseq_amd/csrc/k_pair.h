@@ -159,8 +159,8 @@ SSG_DEVFN int wv_matesw(const ssg_index_view_t &ix, const ssg_mem_opt_t &opt, co
 			unsigned long long c1 = ssg_clock(); const int n_in = ma_n;
 			int m = -1;
 			if (*ma_fixed && ma_n - 1 <= SSG_SDP_BIG) m = xpos_last < 0 ? ma_n : wv_sort_dedup_incr(opt, ma_n, ma, sdp_tmp, xpos_last);
-			if (m < 0) m = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds->key, sdp_lds->idx, sdp_lds->idx2)
-			           : ma_n <= SSG_SDP_BIG ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_big->key, sdp_big->idx, sdp_big->idx2)
+			if (m < 0) m = ma_n <= SSG_SDP_CAP ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_lds->key, sdp_lds->skey, sdp_lds->idx, sdp_lds->idx2)
+			           : ma_n <= SSG_SDP_BIG ? wv_sort_dedup_fast(opt, ma_n, ma, sdp_tmp, sdp_big->key, sdp_big->skey, sdp_big->idx, sdp_big->idx2)
 			           : wv_sort_dedup_patch<WIDE>(ix, opt, 0, 0, ma_n, ma, tbuf, tcap, err, cells);
 			ma_n = m; *ma_fixed = 1; xpos_last = -1;
 			c1 = ssg_clock() - c1; ph[2] += c1; ph[n_in <= 8 ? 5 : n_in <= 64 ? 6 : 7] += c1;

@@ -16,10 +16,10 @@
 #define SSG_SDP_CAP 256
 #define SSG_SDP_BIG 2048
 struct ssg_sdp_key_t { int64_t re, rb; int32_t qb, qe, score, rid; };
-struct ssg_sdp_lds_t { ssg_sdp_key_t key[SSG_SDP_CAP]; uint16_t idx[SSG_SDP_CAP], idx2[SSG_SDP_CAP]; };
+struct ssg_sdp_lds_t { ssg_sdp_key_t key[SSG_SDP_CAP]; uint64_t skey[SSG_SDP_CAP]; uint16_t idx[SSG_SDP_CAP], idx2[SSG_SDP_CAP]; };
 #define SSG_SDP_SMALL 96   /* chain extension: most reads end with a handful of regions; bigger sets use the HBM slab */
-struct ssg_sdp_small_t { ssg_sdp_key_t key[SSG_SDP_SMALL]; uint16_t idx[SSG_SDP_SMALL], idx2[SSG_SDP_SMALL]; };
-struct ssg_sdp_big_t { ssg_sdp_key_t key[SSG_SDP_BIG]; uint16_t idx[SSG_SDP_BIG], idx2[SSG_SDP_BIG]; };
+struct ssg_sdp_small_t { ssg_sdp_key_t key[SSG_SDP_SMALL]; uint64_t skey[SSG_SDP_SMALL]; uint16_t idx[SSG_SDP_SMALL], idx2[SSG_SDP_SMALL]; };
+struct ssg_sdp_big_t { ssg_sdp_key_t key[SSG_SDP_BIG]; uint64_t skey[SSG_SDP_BIG]; uint16_t idx[SSG_SDP_BIG], idx2[SSG_SDP_BIG]; };
 struct ssg_key_re_lt { const ssg_sdp_key_t *k; SSG_DEVMEM bool operator()(uint16_t a, uint16_t b) const { return k[a].re < k[b].re; } };
 SSG_DEVFN bool ssg_key_sc_less(const ssg_sdp_key_t &x, const ssg_sdp_key_t &y)
 { return (x.score > y.score) | ((x.score == y.score) & ((x.rb < y.rb) | ((x.rb == y.rb) & (x.qb < y.qb)))); }
@@ -37,6 +37,26 @@ SSG_DEVFN bool wv_rank_sort(const ssg_sdp_key_t *key, const uint16_t *in, uint16
 		for (int j = 0; j < n; ++j) { const ssg_sdp_key_t kj = key[in[j]]; const bool lt = less(kj, km), gt = less(km, kj); r += lt; eq += !(lt | gt); }
 		tie |= eq > 1;
 		if (eq == 1) out[r] = me;
+	}
+	return wv_ballot(tie) != 0;
+}
+/* The same on 64-bit sort keys laid out in input order (skey[t] = key of in[t], every key below 2^64 - 1): a block of 64 keys is loaded once, one per lane, and
+ * handed round by v_readlane, so the inner loop touches no memory -- the loop above waits for two dependent loads per key (840 cycles an iteration on the
+ * MI355X, measured: three quarters of the re-sort, which is half of ssg_k_chain2aln).  f(t, rank, ties) for every t < n; returns whether any key ties. */
+template <class F>
+SSG_DEVFN bool wv_rank_u64(const uint64_t *skey, int n, F f)
+{
+	const int lane = wv_lane();
+	int tie = 0;
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		const int me = i0 + lane;
+		const unsigned long long km = me < n ? skey[me] : ~0ull;
+		int r = 0, eq = 0;
+		for (int j0 = 0; j0 < n; j0 += 64) {
+			const unsigned long long kl = j0 + lane < n ? skey[j0 + lane] : ~0ull;
+			SSG_UNROLL for (int t = 0; t < 64; ++t) { const unsigned long long k = (unsigned long long)wv_get64((long long)kl, t); r += k < km; eq += k == km; }
+		}
+		if (me < n) { f(me, r, eq); tie |= eq > 1; }
 	}
 	return wv_ballot(tie) != 0;
 }
@@ -63,20 +83,27 @@ SSG_DEVFN int ssg_patch_candidate(const ssg_mem_opt_t &opt, int64_t l_pac, const
 /* patch_l_pac < 0: no patching (mem_matesw's call).  Otherwise (mem_align1_core's call) the scan returns -1, with
  * a[] untouched, as soon as a pair of regions would reach mem_patch_reg's global alignment; the caller then runs
  * the general routine.  (Everything mem_patch_reg rejects before aligning leaves no trace, so skipping it is exact.) */
-SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, ssg_alnreg_t *tmp, ssg_sdp_key_t *key, uint16_t *idx, uint16_t *idx2, int64_t patch_l_pac = -1)
+SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *a, ssg_alnreg_t *tmp, ssg_sdp_key_t *key, uint64_t *skey, uint16_t *idx, uint16_t *idx2, int64_t patch_l_pac = -1)
 {
 	if (n <= 1) return n;
 	const int lane = wv_lane();
+	unsigned long long tq0 = ssg_clock(), tq1;
+#define SSG_SDP_PH(x) do { if (SSG_TUNING) { tq1 = ssg_clock(); if (lane == 0) atomicAdd(&ssg_dbg_cyc[64 + (x)], tq1 - tq0); tq0 = tq1; } } while (0)
 	ssg_wave_memsync();
 	for (int i = lane; i < n; i += 64) {
 		const ssg_alnreg_t r = a[i];
 		ssg_sdp_key_t k; k.re = r.re; k.rb = r.rb; k.qb = r.qb; k.qe = r.qe; k.score = r.score; k.rid = r.rid;
-		key[i] = k; idx2[i] = (uint16_t)i;
+		key[i] = k; idx2[i] = (uint16_t)i; skey[i] = (uint64_t)r.re;
 	}
 	ssg_wave_memsync();
-	if (wv_rank_sort(key, idx2, idx, n, ssg_re_less())) { /* ties in `re`: upstream's unstable sort decides */
+	SSG_SDP_PH(0);
+	if (wv_rank_u64(skey, n, [&](int t, int rank, int ties) { if (ties == 1) idx[rank] = (uint16_t)t; })) { /* ties in `re`: upstream's unstable sort decides */
+		SSG_SDP_PH(1);
 		SSG_LANE0(for (int t = 0; t < n; ++t) idx[t] = (uint16_t)t; ssg_key_re_lt lt = { key }; ssg_introsort(idx, (long)n, lt));
-	}
+		SSG_SDP_PH(2);
+		if (SSG_TUNING && lane == 0) { atomicAdd(&ssg_dbg_cyc[72], 1ull); atomicAdd(&ssg_dbg_cyc[73], (unsigned long long)n); }
+	} else SSG_SDP_PH(1);
+	if (SSG_TUNING && lane == 0) { atomicAdd(&ssg_dbg_cyc[74], 1ull); atomicAdd(&ssg_dbg_cyc[75], (unsigned long long)n); atomicAdd(&ssg_dbg_cyc[76], (unsigned long long)n * n); }
 	ssg_wave_memsync();
 	int n2 = 0;
 	if (lane == 0) {
@@ -105,11 +132,24 @@ SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *
 		}
 	}
 	n2 = wv_bcast(n2, 0);
+	SSG_SDP_PH(3);
 	if (n2 < 0) return -1;
 	ssg_wave_memsync();
-	if (wv_rank_sort(key, idx2, idx, n2, ssg_sc_less())) { /* identical (score, rb, qb): tie order selects the survivor */
-		SSG_LANE0(for (int t = 0; t < n2; ++t) idx[t] = idx2[t]; ssg_key_sc_lt lt = { key }; ssg_introsort(idx, (long)n2, lt));
+	/* (score descending, rb, qb) as one 64-bit key when the fields fit (they do: scores below 2^16, positions below 2^38, query offsets below 2^10) */
+	int wide = 0;
+	for (int t = lane; t < n2; t += 64) {
+		const ssg_sdp_key_t &k = key[idx2[t]];
+		wide |= k.score < 0 || k.score > 0xfffe || k.rb < 0 || k.rb >= (int64_t)1 << 38 || k.qb < 0 || k.qb > 1023;
+		skey[t] = (uint64_t)(0xffff - k.score) << 48 | (uint64_t)k.rb << 10 | (uint64_t)k.qb;
 	}
+	const bool packed = wv_ballot(wide) == 0;
+	ssg_wave_memsync();
+	if (packed ? wv_rank_u64(skey, n2, [&](int t, int rank, int ties) { if (ties == 1) idx[rank] = idx2[t]; })
+	           : wv_rank_sort(key, idx2, idx, n2, ssg_sc_less())) { /* identical (score, rb, qb): tie order selects the survivor */
+		SSG_SDP_PH(4);
+		SSG_LANE0(for (int t = 0; t < n2; ++t) idx[t] = idx2[t]; ssg_key_sc_lt lt = { key }; ssg_introsort(idx, (long)n2, lt));
+		SSG_SDP_PH(5);
+	} else SSG_SDP_PH(4);
 	ssg_wave_memsync();
 	int m = 0;
 	if (lane == 0) {
@@ -127,6 +167,8 @@ SSG_DEVFN int wv_sort_dedup_fast(const ssg_mem_opt_t &opt, int n, ssg_alnreg_t *
 	ssg_wave_memsync();
 	for (int k = lane; k < m; k += 64) a[k] = tmp[k];
 	ssg_wave_memsync();
+	SSG_SDP_PH(6);
+#undef SSG_SDP_PH
 	return m;
 }
 

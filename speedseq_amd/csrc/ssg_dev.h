@@ -31,11 +31,11 @@ SSG_DEVFN unsigned long long wv_ballot(int p) { return __ballot(p); }
 #define SSG_WAVE 64
 /* phase cycle counters for kernel tuning (read back with ssg_dbg_cycles) */
 #ifdef SSG_EMU
-static unsigned long long ssg_dbg_cyc[64];
+static unsigned long long ssg_dbg_cyc[96];
 #define SSG_TUNING 0
 SSG_DEVFN unsigned long long ssg_clock() { return 0; }
 #else
-__device__ unsigned long long ssg_dbg_cyc[64];
+__device__ unsigned long long ssg_dbg_cyc[96];
 #ifdef SSG_TUNE   /* `make lib TUNE=1`: instrumented build for tools/dbg/phase.py; the counters cost ~16 VGPRs in the SW kernels */
 #define SSG_TUNING 1
 SSG_DEVFN unsigned long long ssg_clock() { return (unsigned long long)clock64(); }

@@ -359,6 +359,22 @@ int ssg_dbg_cycles(unsigned long long out[32])
 	return 0;
 #endif
 }
+/* any stretch of the counters (tuning builds) */
+int ssg_dbg_cycles_at(int first, int n, unsigned long long *out)
+{
+	if (first < 0 || n < 0 || first + n > 96) return SSG_EINVAL;
+#ifdef SSG_EMU
+	memcpy(out, ssg_dbg_cyc + first, (size_t)n * 8); memset(ssg_dbg_cyc + first, 0, (size_t)n * 8);
+	return 0;
+#else
+	unsigned long long z[96]; memset(z, 0, sizeof z);
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssg_dbg_cyc), (size_t)n * 8, (size_t)first * 8) != hipSuccess) return SSG_EHIP;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(ssg_dbg_cyc), z, (size_t)n * 8, (size_t)first * 8) != hipSuccess) return SSG_EHIP;
+	return 0;
+#endif
+}
+/* test hook: how the last call of this thread split its CIGAR requests (wave kernel, lane DP classes 0..2) */
+void ssg_dbg_reg2aln_counts(unsigned int out[4]);
 /* slots 32..63 (32..47: the lane-per-extension kernel's lane utilisation, k_extlane.h; 48..63: band widths of the requests that need a DP, k_aln.h) */
 int ssg_dbg_cycles_hi(unsigned long long out[32])
 {
@@ -1093,6 +1109,7 @@ static void host_pestat(const ssg_mem_opt_t *opt, const uint32_t *hist /* [4][SS
 
 /* the whole PE hot path on device-resident inputs; `keep` != NULL leaves the records in HBM
  * instead of downloading them into `res` */
+static thread_local unsigned int ssg_r2a_last[1 + SSG_R2D_CLASSES];   /* of this thread's last call: records left to the wave kernel, records per class of the lane DP */
 /* CIGAR / NM / MD of the compacted requests (k_aln.h): gap-free records one lane each; records whose band is narrow one lane each through the DP (three classes of
  * band width, a launch each with the LDS that class needs, side by side); the rest -- wide bands, and records whose first alignment does not end upstream's
  * loop -- one wave each.  SSG_R2A_DPLANE=0: no lane DP (A/B, tests). */
@@ -1130,13 +1147,16 @@ static int run_reg2aln(const ssg_index *idx, const ssg_mem_opt_t *opt, int64_t n
 		ssg_join(2);
 		SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq, d_regs, d_seq, d_off, d_alns, d_tglb.p, d_z.p, d_gerr, d_cnt, d_rtodo.p, d_nrtodo.p);
 		CHK(rt_sync());   /* (before the slabs go back to the arena) */
-		if (ssg_debug()) { unsigned int c[1 + SSG_R2D_CLASSES]; CHK(d_nrtodo.down(c, 1 + SSG_R2D_CLASSES)); fprintf(stderr, "[ssgpu] reg2aln: %lld requests; lane DP by band class %u / %u / %u, wave kernel %u\n", (long long)nreq, c[1], c[2], c[3], c[0]); }
+		CHK(d_nrtodo.down(ssg_r2a_last, 1 + SSG_R2D_CLASSES));
+		if (ssg_debug()) fprintf(stderr, "[ssgpu] reg2aln: %lld requests; lane DP by band class %u / %u / %u, wave kernel %u\n", (long long)nreq, ssg_r2a_last[1], ssg_r2a_last[2], ssg_r2a_last[3], ssg_r2a_last[0]);
 		return 0;
 	}
 	SSG_LAUNCH_W(max_len > 255, ssg_k_reg2aln, nwg, wpb * 64, 0, idx->v, *opt, (long)nreq, d_creq, d_regs, d_seq, d_off, d_alns, d_tglb.p, d_z.p, d_gerr, d_cnt, d_rtodo.p, d_nrtodo.p);
 	CHK(rt_sync());
 	return 0;
 }
+
+extern "C" void ssg_dbg_reg2aln_counts(unsigned int out[4]) { for (int k = 0; k < 1 + SSG_R2D_CLASSES; ++k) out[k] = ssg_r2a_last[k]; }
 
 static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs, const uint8_t *d_seq_p, const int64_t *d_off_p, int max_len,
                    const int32_t *d_pb_p, int n_batches, int64_t id0, const ssg_pestat_t *pes0, ssg_pe_result *res, pe_dev_t *keep)

@@ -269,3 +269,24 @@ def test_gpu_hotpath_batches_and_dups(gpu_lib, read_len):
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "hotpath_check.py"), str(read_len)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "hotpath ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+@pytest.mark.gpu
+def test_gpu_reg2aln_lane_dp_classes(gpu_lib, oracle, monkeypatch):
+    # MI355X twin of test_emu_reg2aln_lane_dp_classes: the lane-per-record banded global alignment (three band classes) and the wave kernel's share,
+    # against the oracle's SAM text; more pairs than the emulation takes
+    import ctypes as C
+    import numpy as np
+    seen = []
+    for k, (err, indel, rl) in enumerate(((0.02, 0.01, 150), (0.05, 0.004, 150), (0.03, 0.01, 250), (0.01, 0.02, 101))):
+        texts = []
+        for dp in ("1", "0"):
+            monkeypatch.setenv("SSG_R2A_DPLANE", dp)
+            text, _ = common.check_pe_sam(gpu_lib, oracle, 400, seed=300 + k, read_len=rl, err=err, indel_frac=indel, ins_mean=500 if rl < 250 else 800, ins_std=60)
+            texts.append(text)
+            if dp == "1":
+                c = (C.c_uint * 4)()
+                gpu_lib.l.ssg_dbg_reg2aln_counts(c)
+                seen.append([c[1], c[2], c[3], c[0]])
+        assert texts[0] == texts[1]
+    tot = np.array(seen).sum(axis=0)
+    assert all(tot[:3] > 0) and tot[3] > 0, seen

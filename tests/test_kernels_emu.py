@@ -275,25 +275,22 @@ def test_emu_owner_side_dedup_matches_min_ordinal_rule(emu_lib):
     assert np.array_equal(dup, exp) and exp.sum() > n // 2
 
 
-def test_emu_reg2aln_lane_dp_classes(emu_lib, oracle, monkeypatch, capfd):
+def test_emu_reg2aln_lane_dp_classes(emu_lib, oracle, monkeypatch):
     # ksw_global2 + backtrace + NM / MD with one lane per record (k_aln.h ssg_k_reg2aln_dplane: ring of 2w + 2 columns in LDS, 4-bit direction cells in
     # an HBM slab) against the oracle, at error and indel rates that fill all three band classes and leave records to the wave kernel; then with the
     # lane DP switched off: the same text both ways (check_pe_sam compares with the oracle's SAM line by line)
-    monkeypatch.setenv("SSG_DEBUG", "1")
+    import ctypes as C
     seen = []
     for k, (err, indel, rl) in enumerate(((0.02, 0.01, 150), (0.05, 0.004, 150), (0.03, 0.01, 250), (0.01, 0.02, 101))):
         texts = []
         for dp in ("1", "0"):
             monkeypatch.setenv("SSG_R2A_DPLANE", dp)
-            capfd.readouterr()
             text, _ = common.check_pe_sam(emu_lib, oracle, 120, seed=300 + k, read_len=rl, err=err, indel_frac=indel, ins_mean=500 if rl < 250 else 800, ins_std=60)
             texts.append(text)
             if dp == "1":
-                log = capfd.readouterr().err
-                line = [l for l in log.split("\n") if "reg2aln:" in l and "lane DP" in l]
-                assert line, log[-2000:]
-                nums = line[-1].split("band class")[1].replace(", wave kernel", " /").split("/")
-                seen.append([int(x) for x in nums])
+                c = (C.c_uint * 4)()
+                emu_lib.l.ssg_dbg_reg2aln_counts(c)
+                seen.append([c[1], c[2], c[3], c[0]])
         assert texts[0] == texts[1]
     tot = np.array(seen).sum(axis=0)
     assert all(tot[:3] > 0) and tot[3] > 0, seen   # every class of the lane DP and the wave kernel had records

@@ -26,3 +26,10 @@ s = max(1, t[20])
 print("chain2aln fractions of wave time: record %.3f scan %.3f resort %.3f append %.3f results+build %.3f; cycles per scan chunk %.0f" % (t[16]/s, t[17]/s, t[19]/s, t[22]/s, t[23]/s, t[17]/max(1,t[21])))
 r = max(1, t[26])
 print("smem (wave cycles): state machine=%d extension site=%d | rounds=%d, ready lanes per round %.1f of %.1f alive" % (t[24], t[25], t[26], 64.0 * t[27] / r, 64.0 * t[28] / r))
+o2 = (C.c_ulonglong * 16)()
+lib.l.ssg_dbg_cycles_at(64, 16, o2)
+u = list(o2)
+tot = max(1, sum(u[:7]))
+print("sort_dedup_fast (lane-0 cycles, chain2aln + matesw): keys %.3f rank sort(re) %.3f introsort(re ties) %.3f scan %.3f rank sort(score) %.3f introsort(score ties) %.3f gather %.3f of %d"
+      % tuple([x / tot for x in u[:7]] + [tot]))
+print("  calls %d (regions %d, sum n^2 %d); with ties in re: %d calls, %d regions" % (u[10], u[11], u[12], u[8], u[9]))
