@@ -30,15 +30,25 @@ struct ssg_pw_lds_t { int32_t zqb[SSG_PW_ZCAP], zqe[SSG_PW_ZCAP], zsc[SSG_PW_ZCA
 
 SSG_DEVFN bool ssg_p128_less(const ssg_pair64_t &a, const ssg_pair64_t &b) { return (a.x < b.x) | ((a.x == b.x) & (a.y < b.y)); }
 
-/* out[rank of key[i]] = i for distinct keys */
+/* out[rank of key[i]] = i for distinct keys (below the all-ones key).  A block of 64 keys is loaded once, one per lane, and handed round by v_readlane: no
+ * memory in the inner loop (k_sdp.h wv_rank_u64 has the measurement that led here). */
 SSG_DEVFN void wv_rank_sort128(const ssg_pair64_t *key, int n, int32_t *out_idx, ssg_pair64_t *out_key)
 {
-	for (int i = wv_lane(); i < n; i += 64) {
-		const ssg_pair64_t me = key[i];
+	const int lane = wv_lane();
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		const int i = i0 + lane;
+		ssg_pair64_t me; me.x = me.y = ~0ull;
+		if (i < n) me = key[i];
 		int r = 0;
-		for (int j = 0; j < n; ++j) r += ssg_p128_less(key[j], me);
-		if (out_idx) out_idx[r] = i;
-		if (out_key) out_key[r] = me;
+		for (int j0 = 0; j0 < n; j0 += 64) {
+			ssg_pair64_t kl; kl.x = kl.y = ~0ull;
+			if (j0 + lane < n) kl = key[j0 + lane];
+			SSG_UNROLL for (int t = 0; t < 64; ++t) {
+				const uint64_t kx = (uint64_t)wv_get64((long long)kl.x, t), ky = (uint64_t)wv_get64((long long)kl.y, t);
+				r += (kx < me.x) | ((kx == me.x) & (ky < me.y));
+			}
+		}
+		if (i < n) { if (out_idx) out_idx[r] = i; if (out_key) out_key[r] = me; }
 	}
 }
 
