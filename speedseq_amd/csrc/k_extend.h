@@ -207,7 +207,8 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
                                 const int32_t *chain_seeds, const int32_t *n_chain, uint64_t *srt_all, ssg_alnreg_t *regs, int32_t *n_reg,
                                 uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells, unsigned long long *ph,
                                 ssg_sdp_small_t *sdp_lds, ssg_sdp_big_t *sdp_big, ssg_alnreg_t *sdp_tmp,
-                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, uint8_t *sdp_fixed)
+                                const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, uint8_t *sdp_fixed,
+                                uint16_t *hq /* LDS, SSG_SDP_BIG entries: (rb >> 10) of the read's regions so far */)
 {
 	const uint8_t *query = seq + read_off[r];
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
@@ -216,6 +217,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	ssg_alnreg_t *av = regs + s0;
 	const int64_t l_pac = ix.l_pac;
 	int av_n = 0, myerr = 0;
+	int hq_ok = 1;   /* every region so far spans at most 1024 reference bases: one containing a seed starts in the seed's 1024-base bin or the one before */
 	unsigned long long nc = 0;
 	const int nch = n_chain[r];
 	ssg_sdp_key_t *const ck = sdp_big->key;   /* (rb, re, qb, qe, w -> .score, seedlen0 -> .rid) of av[]: what the containment test reads */
@@ -260,7 +262,27 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 			{	/* is the seed contained in an earlier region?  Compact keys of the regions (ck[]), SSG_C2A_SCAN x 64 regions per round
 				 * trip; the scalar loop's first hit decides */
 				int hit = av_n;
-				if (av_n <= SSG_SDP_BIG) {
+				if (av_n <= SSG_SDP_BIG && hq_ok) {
+					/* The scan is quadratic in a read's regions and nearly always finds nothing (repeat copies lie elsewhere): 64 regions' bins from LDS per
+					 * step, the keys themselves (HBM slab: 1900 cycles a step, a quarter of this kernel) only for a region in the seed's bin */
+					const uint16_t hs = (uint16_t)(s.rbeg >> 10), hs1 = (uint16_t)(hs - 1);
+					for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64) {
+						if (SSG_TUNING && ph) ++ph[5];
+						const int ii = i0 + wv_lane();
+						const uint16_t hv = ii < av_n ? hq[ii] : (uint16_t)(hs + 2);
+						const bool cand = hv == hs || hv == hs1;
+						if (!wv_ballot(cand)) continue;
+						int h = 0;
+						if (cand) {
+							ssg_sdp_key_t kk;
+							if (ii < SSG_C2A_LKEYS) { const uint64_t m = lk_m[ii]; kk.rb = lk_rb[ii]; kk.re = lk_re[ii]; kk.qb = (int)(m & 0xffff); kk.qe = (int)(m >> 16 & 0xffff); kk.score = (int)(m >> 32 & 0xffff); kk.rid = (int)(m >> 48); }
+							else kk = ck[ii];
+							h = ssg_seed_in_region(opt, s, l_query, kk.rb, kk.re, kk.qb, kk.qe, kk.score, kk.rid);
+						}
+						const unsigned long long bal = wv_ballot(h);
+						if (bal) hit = i0 + (int)__builtin_ctzll(bal);
+					}
+				} else if (av_n <= SSG_SDP_BIG) {
 					for (int i0 = 0; i0 < av_n && hit == av_n; i0 += 64 * SSG_C2A_SCAN) {
 						if (SSG_TUNING && ph) ++ph[5];
 						ssg_sdp_key_t kk[SSG_C2A_SCAN];
@@ -356,7 +378,9 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 			SSG_PH(7);
 			SSG_LANE0(av[av_n] = a;
 			          if (av_n < SSG_C2A_LKEYS) { lk_rb[av_n] = a.rb; lk_re[av_n] = a.re; lk_m[av_n] = (uint64_t)(uint16_t)a.qb | (uint64_t)(uint16_t)a.qe << 16 | (uint64_t)(uint16_t)a.w << 32 | (uint64_t)(uint16_t)a.seedlen0 << 48; }
-			          else if (av_n < SSG_SDP_BIG) { ssg_sdp_key_t ka; ka.re = a.re; ka.rb = a.rb; ka.qb = a.qb; ka.qe = a.qe; ka.score = a.w; ka.rid = a.seedlen0; ck[av_n] = ka; });
+			          else if (av_n < SSG_SDP_BIG) { ssg_sdp_key_t ka; ka.re = a.re; ka.rb = a.rb; ka.qb = a.qb; ka.qe = a.qe; ka.score = a.w; ka.rid = a.seedlen0; ck[av_n] = ka; }
+			          if (av_n < SSG_SDP_BIG) hq[av_n] = (uint16_t)(a.rb >> 10););
+			if (a.re - a.rb > 1024 || a.rb < 0) hq_ok = 0;
 			++av_n;
 			SSG_PH(6);
 		}
@@ -520,6 +544,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 {
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
 	__shared__ ssg_sdp_small_t sdp[SSG_WAVES_PER_WG];
+	__shared__ uint16_t hq_[SSG_WAVES_PER_WG][SSG_SDP_BIG];
 	const int wslot = (int)(threadIdx.x >> 6);
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
 	unsigned long long nc = 0, ph[8] = {0,0,0,0,0,0,0,0};
@@ -528,7 +553,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 		const long k = wv_queue_pop(queue);
 		if (k >= (todo_list ? (long)*n_todo : (long)n_reads)) break;
 		wv_chain2aln_read<WIDE>(ix, opt, todo_list ? todo_list[k] : work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
-		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r, sdp_fixed);
+		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r, sdp_fixed, hq_[wslot]);
 	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);
 	if (SSG_TUNING && tune && wv_lane() == 0) { /* tuning: window+seed sort, containment scan, extension, re-sort, wave total; #chains, #extended seeds, #regions */
