@@ -62,7 +62,7 @@ PY
     python tools/dbg/kernel_timeline.py $f --json $out/${tag}_timeline.json > $out/${tag}_timeline.txt 2>&1; head -60 $out/${tag}_timeline.txt | cut -c1-200 ;;
   soak)
     pairs=${arg%%:*}; mem=""; [ "$arg" != "$pairs" ] && mem="--mem ${arg#*:}"
-    timeout 3000 python tools/soak.py --stream --limit 2400 --pairs $pairs $mem > $out/${tag}_soak_$pairs.json 2> $out/${tag}_soak_$pairs.err; tail -3 $out/${tag}_soak_$pairs.err | cut -c1-300
+    timeout 3000 python tools/soak.py ${SOAK_MODE:---stream} --limit 2400 --pairs $pairs $mem > $out/${tag}_soak_$pairs.json 2> $out/${tag}_soak_$pairs.err; tail -3 $out/${tag}_soak_$pairs.err | cut -c1-300
     python -c "import json,sys; d=json.load(open('$out/${tag}_soak_$pairs.json')); print({k:v for k,v in d.items() if k not in ('stage_log','what')})" ;;
   pin)
     python - $out/${tag}_bench.json $out/${tag}_pytest_gpu.log $out/${tag}_kernel_isa.sha256 <<'PY'
