@@ -28,6 +28,13 @@
 #include <time.h>
 static double wall() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static bool dbg() { static int d = -1; if (d < 0) d = (getenv("SSG_DEBUG") || getenv("SSG_SORT_LOG")) ? 1 : 0; return d != 0; }
+/* cores this process may really use: the cgroup's CPU quota when there is one (a container next to the GPU: 256 hardware threads visible, 16 cores granted), else the hardware threads */
+static double usable_cores()
+{
+	double c = (double)std::max(1u, std::thread::hardware_concurrency());
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[64]; double per = 0; if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) c = std::min(c, atof(q) / per); fclose(f); }
+	return c;
+}
 static int hw_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)std::min(n, 32u) : 4; }
 static void die(const std::string &m) { fprintf(stderr, "[sambamba] %s\n", m.c_str()); rk_mark_failed("sambamba"); exit(1); }   /* rank mode: the other ranks must not wait for this one */
 static int open_in(const char *p) { if (!strcmp(p, "/dev/stdin") || !strcmp(p, "-")) return 0; int fd = open(p, O_RDONLY); if (fd < 0) die(std::string("cannot open ") + p); return fd; }
@@ -281,7 +288,16 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	 * were slower than three on the 16-CPU host next to the MI355X: 1.33 vs 1.15 s for 5.1 GB, profiles/r06f_literal_sort_producers.json: the gather threads are the limit) */
 	int want_prod = std::min(3 * n_devs, std::max(3, 2 * n_devs)); { const char *e = getenv("SSG_SORT_PRODUCERS"); if (e && atoi(e) > 0) want_prod = std::min(7 * n_devs, atoi(e)); }
 	const int n_prod = use_dev ? (int)std::max<size_t>(1, std::min<size_t>((size_t)want_prod, (nb + DEV_BATCH - 1) / DEV_BATCH)) : 0;
-	const int n_workers = use_dev ? 0 : (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
+	/* ... and on a host with many cores next to the device, some batches stay with the host's pool (zlib): batch k of the file belongs to slot k mod (producers + host
+	 * slots), a fixed rule -- the file's bytes do not depend on who was faster.  SSG_SORT_HOST_BATCHES: host slots per round (2 from 96 usable cores, 1 from 48, else 0: zlib at level 6 makes 35 MB/s a core). */
+	int host_slots = 0;
+	if (use_dev) { const char *e = getenv("SSG_SORT_HOST_BATCHES"); const double cores = std::min((double)threads, usable_cores()); host_slots = e && *e ? std::max(0, std::min(16, atoi(e))) : cores >= 96 ? 2 : cores >= 48 ? 1 : 0; if ((nb + DEV_BATCH - 1) / DEV_BATCH <= (size_t)n_prod) host_slots = 0; }
+	const int slot_round = n_prod + host_slots;
+	std::atomic<bool> host_takes_all(!use_dev);
+	std::atomic<int> dev_failed(0);
+	auto host_group = [&](size_t g) -> bool { return host_takes_all.load(std::memory_order_relaxed) || (int)((g * GRP / DEV_BATCH) % (size_t)slot_round) >= n_prod; };
+	const int n_workers = use_dev ? (host_slots ? (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng)) : 0)
+	                              : (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));   /* no more threads than work items */
 	const size_t window = use_dev ? (size_t)std::max(8, 2 * n_prod) * DEV_BATCH / GRP : std::max<size_t>(64, (size_t)n_workers * 8);   /* work items compressed ahead of the writer (memory bound: ~0.3 MB each) */
 	auto nap = [](int us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); };
 	std::atomic<long> us_gather(0), us_deflate(0), us_window(0);   /* summed over the workers (SSG_DEBUG) */
@@ -299,7 +315,14 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 			const size_t g = next_grp.fetch_add(1);
 			if (g >= ng) break;
 			if (done[g].load(std::memory_order_acquire)) continue;   /* (made on the device before it failed: see the writer's fall-back) */
-			if (g >= next_write.load(std::memory_order_acquire) + window) { const double t0 = wall(); while (g >= next_write.load(std::memory_order_acquire) + window) nap(200); my_w += (long)((wall() - t0) * 1e6); }
+			if (!host_group(g)) continue;                            /* (a batch of the device's producers) */
+			bool give_up = false;   /* (the device failed while this thread waited: the writer wants every thread joined before it starts the host-only pool, which makes this group then) */
+			if (g >= next_write.load(std::memory_order_acquire) + window) {
+				const double t0 = wall();
+				while (g >= next_write.load(std::memory_order_acquire) + window && !(give_up = dev_failed.load() && !host_takes_all.load())) nap(200);
+				my_w += (long)((wall() - t0) * 1e6);
+			}
+			if (give_up) break;
 			std::vector<uint8_t> ob; ob.reserve(GRP * (lvl ? 24576 : 65536));
 			std::vector<uint32_t> bsz;
 			for (size_t bk = g * GRP; bk < std::min(nb, (g + 1) * GRP); ++bk) {
@@ -319,7 +342,6 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	 * batches of 2048 blocks in turn -- gather into page-locked memory + CRC-32 by host threads, deflate on the GPU, framing (BGZF header,
 	 * CRC, ISIZE) -- and hand the groups to the same in-order writer.  The host's cores, which the deflate of a whole genome's records kept busy
 	 * for longer than the alignment took, only copy and checksum. */
-	std::atomic<int> dev_failed(0);
 	std::atomic<long> dev_batches(0); const long fail_after = getenv("SSG_BGZF_FAIL_AFTER") ? atol(getenv("SSG_BGZF_FAIL_AFTER")) : -1;   /* tests: the device "fails" from its n-th batch on */
 	auto producer = [&](int t) {
 		if (ssg_set_device(t % n_devs) || ssg_set_lane(1 + (t / n_devs) % 7)) { dev_failed = 1; return; }
@@ -335,7 +357,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 		const bool mem_ok = slot[0].P && slot[1].P && O;
 		std::thread gatherer([&]() {
 			int k = 0;
-			for (size_t b0 = (size_t)t * DEV_BATCH; b0 < nb && mem_ok && !dev_failed.load(); b0 += (size_t)n_prod * DEV_BATCH, k ^= 1) {
+			for (size_t b0 = (size_t)t * DEV_BATCH; b0 < nb && mem_ok && !dev_failed.load(); b0 += (size_t)slot_round * DEV_BATCH, k ^= 1) {
 				slot_t &sl = slot[k];
 				while (sl.state.load(std::memory_order_acquire) != 0 && !dev_failed.load()) nap(100);
 				const size_t b1 = std::min(nb, b0 + DEV_BATCH), n_b = b1 - b0, g0 = b0 / GRP;
@@ -443,7 +465,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 			while (!done[g].load(std::memory_order_acquire)) {
 				if (dev_failed.load() && !fell_back) {   /* a device that cannot be set up, runs out of memory or loses a kernel does not end the sort: the producers stop, the host's pool (zlib, as SSG_BGZF_DEVICE=0) makes the groups that are not there yet */
 					for (auto &x : th) x.join();
-					th.clear(); fell_back = true;
+					th.clear(); fell_back = true; host_takes_all = true; next_grp = 0;
 					fprintf(stderr, "[sambamba] sort: compressing the rest of the output on the host (zlib level %d)\n", lvl);
 					const int nw = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), ng));
 					for (int t = 0; t < nw; ++t) th.emplace_back(worker);
@@ -472,7 +494,8 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	if (dbg() && !seg) fprintf(stderr, "[sambamba] sort: write: offsets and block cuts %.2f s, gather + deflate + write of %zu blocks %.2f s (record view for the index %.2f s, %d workers started in %.2f s; writer: waited %.2f s for blocks, wrote for %.2f s; "
 	                   "per worker: gather %.2f s, deflate %.2f s, held back by the writer's window %.2f s)\n", tw1 - tw0, nb, tw2 - tw1, tw_spawn0 - tw1, n_workers, tw_spawn - tw_spawn0, t_wr_wait, t_wr_io,
 	                   us_gather / 1e6 / std::max(1, n_workers + n_prod), us_deflate / 1e6 / std::max(1, n_workers + n_prod), us_window / 1e6 / std::max(1, n_workers + n_prod));
-	if (dbg() && use_dev && !seg) fprintf(stderr, "[sambamba] sort: write: blocks deflated on %d device(s) (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)\n", n_devs, n_prod);
+	if (dbg() && use_dev && !seg) fprintf(stderr, "[sambamba] sort: write: blocks deflated on %d device(s) (%d producer threads; `gather' = gather + CRC-32 on the host, `deflate' = upload + kernels + download)%s\n", n_devs, n_prod,
+	                                    host_slots ? (std::string("; ") + std::to_string(host_slots) + " of every " + std::to_string(slot_round) + " batches by the host's pool (zlib)").c_str() : "");
 	if (seg) seg->coff = coff;
 	if (seg && seg->ent_fd >= 0 && n) {   /* rank mode: what the index of the joined file needs of this stretch */
 		std::vector<uint8_t> eb(24 * n); size_t bk = 0;

@@ -228,3 +228,36 @@ def test_sambamba_emu_stream_of_many_blocks(tmp_path, emu_lib):
     subprocess.check_call("%s view -b -u %s | %s sort -o %s -" % (SAMTOOLS, big, SAMTOOLS, ref), shell=True, stderr=subprocess.DEVNULL)
     assert _view(out).split("\n")[len(hdr):] == _view(ref).split("\n")[len(hdr):] or \
         [l for l in _view(out).split("\n") if not l.startswith("@")] == [l for l in _view(ref).split("\n") if not l.startswith("@")]
+
+
+@pytest.mark.parametrize("host_batches,fail_after", [("1", ""), ("2", ""), ("1", "2")])
+def test_sambamba_emu_device_and_host_share_the_blocks(tmp_path, emu_lib, monkeypatch, host_batches, fail_after):
+    """batch k of the sorted file belongs to slot k mod (device producers + host slots): the device's producers and the host's zlib pool write one file, the
+    same bytes on every run (the rule is fixed, not first come first served); with a device that fails on the way the host finishes alone"""
+    monkeypatch.setenv("SSG_BGZF_DEVICE", "1")
+    monkeypatch.setenv("SSG_EMU_DEVICES", "2")
+    monkeypatch.setenv("SSG_SORT_DEV_BATCH", "16")
+    monkeypatch.setenv("SSG_SORT_HOST_BATCHES", host_batches)
+    monkeypatch.setenv("SSG_DEBUG", "1")
+    if fail_after:
+        monkeypatch.setenv("SSG_BGZF_FAIL_AFTER", fail_after)
+    d = str(tmp_path)
+    sam = _sam(tmp_path, 20000, seed=39)   # ~100 blocks: seven batches of 16
+    sambamba = os.path.join(ROOT, "tests", "emu", "sambamba_emu")
+    with open(sam, "rb") as fi, open(d + "/u.bam", "wb") as fo:
+        subprocess.run([sambamba, "view", "-S", "-f", "bam", "-l", "0", "/dev/stdin"], stdin=fi, stdout=fo, check=True)
+    outs = []
+    for k in range(1 if fail_after else 2):
+        r = subprocess.run([sambamba, "sort", "-t", "4", "-m", "1G", "--tmpdir=" + d + "/tmp", "-o", "%s/s%d.bam" % (d, k), d + "/u.bam"], check=True, capture_output=True, text=True, timeout=300)
+        if fail_after:
+            assert "compressing the rest of the output on the host" in r.stderr, r.stderr[-500:]
+        else:
+            assert "batches by the host's pool" in r.stderr, r.stderr[-800:]
+        outs.append(open("%s/s%d.bam" % (d, k), "rb").read())
+    assert len(set(outs)) == 1
+    subprocess.run([SAMTOOLS, "view", "-b", "-u", "-o", d + "/ref_u.bam", sam], check=True)
+    subprocess.run([SAMTOOLS, "sort", "-o", d + "/ref_s.bam", d + "/ref_u.bam"], check=True)
+    assert _view(d + "/s0.bam") == _view(d + "/ref_s.bam")
+    os.rename(d + "/s0.bam.bai", d + "/mine.bai")
+    subprocess.run([SAMTOOLS, "index", d + "/s0.bam"], check=True)
+    assert _parse_bai(d + "/mine.bai") == _parse_bai(d + "/s0.bam.bai")

@@ -68,6 +68,27 @@ def main():
     bench.log("reference + index files ready (%.1f s)" % (time.time() - t0))
     fq = os.path.join(td, "reads.fq")
     producer = None
+    guard = {"tripped": False, "peak_gb": 0.0}
+    if a.pregen and not a.emu_selftest:
+        import threading
+
+        def mem_guard():   # the box's memory is a cgroup limit (300 GiB where this was written) and the FASTQ, the sort's runs and the output all live in it: give the input up rather than lose the box
+            try:
+                lim = int(open("/sys/fs/cgroup/memory.max").read())
+            except Exception:
+                return
+            while not guard.get("stop"):
+                try:
+                    cur = int(open("/sys/fs/cgroup/memory.current").read())
+                    guard["peak_gb"] = max(guard["peak_gb"], cur / 2 ** 30)
+                    if cur > 0.88 * lim and not guard["tripped"]:
+                        guard["tripped"] = True
+                        bench.log("soak: %.0f GB of the cgroup's %.0f GB in use: the FASTQ is given up (truncated)" % (cur / 2 ** 30, lim / 2 ** 30))
+                        os.truncate(fq, 0)
+                except Exception:
+                    pass
+                time.sleep(1.0)
+        threading.Thread(target=mem_guard, daemon=True).start()
     if a.stream or a.pregen:
         import threading
         if not a.pregen:
@@ -197,6 +218,8 @@ def main():
         wd_obj = tempfile.TemporaryDirectory(dir=a.tmp); wd = wd_obj.name
     r = bench.script_leg(wd, "soak", prefix, fq, a.pairs, a.threads, b("bwa"), b("samblaster"), b("sambamba"), sort_mem_gb=a.mem, config_extra=cfg, limit_s=a.limit)
     if a.pregen:
+        guard["stop"] = True
+        r["memory_guard"] = {"tripped": guard["tripped"], "peak_cgroup_gb": round(guard["peak_gb"], 1)}
         r["fastq"] = "a plain file of %.1f GB on a memory file system, written before the run (%.0f s, not in wall_s) by tools/synth/synth_reads.cpp" % (os.path.getsize(fq) / 1e9, pregen_s)
         vram["stop"] = True
         r["device_memory"] = {"min_free_gb": vram["min_free_gb"], "free_gb_every_20_s": vram["samples"][::10]}
