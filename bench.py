@@ -408,7 +408,7 @@ def script_leg(td, tag, ref_prefix, fq, n_pairs, threads, bwa, samblaster, samba
         return {"error": "rc %d after %.0f s; %s ... %s" % (r.returncode, t, " | ".join(msgs[-6:])[:1200], r.stderr[-300:]), "wall_s": round(t, 2)}
     sizes = {x: os.path.getsize(out + x) for x in (".bam", ".splitters.bam", ".discordants.bam")}
     ok = all(os.path.exists(out + x + ".bai") for x in sizes)
-    stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs", "[samblaster] main thread", "[samblaster] first stage", "[ssgpu] index load", "[ssgpu] device arena"))]
+    stages = [l for l in r.stderr.split("\n") if l.startswith(("[bwa] wall", "[bwa] stage busy", "[sambamba] sort:", "[samblaster] pairs", "[samblaster] main thread", "[samblaster] first stage", "[ssgpu] index load", "[ssgpu] device arena", "[bwa] kernel", "[bwa] device"))]
     # SSG_STAMP=1 (config_extra): when each stage started and ended, in seconds after the script was launched
     stamps = []
     for l in r.stderr.split("\n"):

@@ -236,16 +236,17 @@ SSG_DEVFN ssg_ext_res_t ln_extend2(const ssg_mem_opt_t &opt, const ssg_index_vie
 				f -= e_ins; f = f > t ? f : t;
 				return out;
 			};
-			/* U columns per trip, the next U in flight meanwhile (the long class runs one wave per SIMD: nothing else hides LDS latency) */
+			/* U columns per trip, the next U in flight meanwhile (the long class runs one wave per SIMD: nothing else hides LDS latency).  Whole trips carry no
+			 * per-column test (five instructions of twenty-six a cell went into `is this column still in the band'); the last columns of the row follow once */
 			uint32_t wc[U];
 			SSG_UNROLL for (int u = 0; u < U; ++u) wc[u] = Lc[(beg + u) * 64];
-			for (j = beg; j < end; j += U) {
+			for (j = beg; j + U <= end; j += U) {
 				uint32_t wn[U];
 				SSG_UNROLL for (int u = 0; u < U; ++u) wn[u] = Lc[(j + U + u) * 64];
-				Lc[j * 64] = cell(wc[0], j);
-				SSG_UNROLL for (int u = 1; u < U; ++u) if (j + u < end) Lc[(j + u) * 64] = cell(wc[u], j + u);
+				SSG_UNROLL for (int u = 0; u < U; ++u) Lc[(j + u) * 64] = cell(wc[u], j + u);
 				SSG_UNROLL for (int u = 0; u < U; ++u) wc[u] = wn[u];
 			}
+			SSG_UNROLL for (int u = 0; u < U - 1; ++u) if (j + u < end) Lc[(j + u) * 64] = cell(wc[u], j + u);
 			mm = mk >> 9; mj = mk & 511;                 /* end > beg: at least one column */
 			j = end;
 		} else j = beg;

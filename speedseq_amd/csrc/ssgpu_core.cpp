@@ -114,9 +114,9 @@ void ssg_mem_opt_init(ssg_mem_opt_t *o)
 
 /* ------------------------------- index ------------------------------- */
 /* HBM-resident SA sampled more densely than the file (see ssg_k_sa_densify); SSG_SA_INTV overrides the interval (power of two) */
-static int densify_sa(ssg_index *ix)
+static int densify_sa(ssg_index *ix, int to = 0)
 {
-	const int want = env_int("SSG_SA_INTV", 4);   /* 5.0 ms of SAL per step at 4, 9.2 at 8, 32 at the file's 32; 2 bytes of HBM per reference base at 4 */
+	const int want = to > 0 ? to : env_int("SSG_SA_INTV", 4);   /* SAL per million pairs: 8 ms at 4, 67 ms at the file's 32 (MI355X, 60 M seeds); 2 bytes of HBM per reference base at 4 */
 	if (want <= 0 || want >= ix->v.sa_intv || (want & (want - 1)) || ix->v.sa_intv % want) return 0;
 	const long n_new = (long)((ix->v.seq_len + (uint64_t)want) / (uint64_t)want);
 	uint64_t *d = (uint64_t*)rt_malloc((size_t)n_new * 8);
@@ -214,6 +214,14 @@ int ssg_index_densify(ssg_index_t *ix)
 	CHK(need_device());
 	if (!ix) { ssg_err_msg = "ssg_index_densify: no index"; return SSG_EINVAL; }
 	return densify_sa(ix);
+}
+/* ... to every intv-th row (a power of two below the current interval; anything else is a no-op): the walk costs in proportion to the rows it adds, so a
+ * caller that does not know yet how long its input is can take a cheap first step (32 -> 16: an eighth of the work of 32 -> 4, half of the seed-location walks gone) */
+int ssg_index_densify_to(ssg_index_t *ix, int intv)
+{
+	CHK(need_device());
+	if (!ix || intv <= 0) { ssg_err_msg = "ssg_index_densify_to: bad arguments"; return SSG_EINVAL; }
+	return densify_sa(ix, intv);
 }
 int ssg_index_load2(const char *prefix, int defer_dense_sa, ssg_index_t **out)
 {	/* on-disk layout: SURVEY.md Appendix A (verified against the bundled example index) */

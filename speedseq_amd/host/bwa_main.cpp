@@ -366,11 +366,27 @@ static int main_mem(int argc, char **argv)
 	 * per million pairs: a run does not know how long its input is, so each device makes the copy once it has aligned this many pairs
 	 * (the point where the walk has been paid for once over; 0 = at load time).  Results do not depend on it. */
 	long densify_after = 32000000; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
+	/* Measured on the MI355X (round 6, 3.1 Gbp): locating the seeds of a million pairs takes 67 ms on the file's samples (every 32nd row) and 8 ms on every 4th;
+	 * the copy to every 4th row costs 1.05 s -- paid back after 18 M pairs -- and a copy to every 16th an eighth of that.  So: plain regular input files that hold
+	 * more than that get the full copy at once; everything else a first step to every SSG_BWA_SA_FIRST-th row (16; 32 = none) right after the load, and the full
+	 * copy once the input has proved long. */
+	int sa_first = 16; { const char *e = getenv("SSG_BWA_SA_FIRST"); if (e && atoi(e) > 0) sa_first = atoi(e); }
+	if (!getenv("SSG_BWA_DENSIFY_AFTER")) {
+		uint64_t bytes = 0; bool known = true;
+		for (int k = ai + 1; k < argc && k < ai + 3; ++k) {
+			struct stat sb; const size_t l = strlen(argv[k]);
+			if (stat(argv[k], &sb) != 0 || !S_ISREG(sb.st_mode) || (l > 3 && !strcmp(argv[k] + l - 3, ".gz"))) { known = false; break; }
+			bytes += (uint64_t)sb.st_size;
+		}
+		if (known && bytes / 640 >= 18000000) densify_after = 0;   /* (about 640 bytes of FASTQ a pair at 2x150; longer reads: fewer pairs, more seeds each) */
+		else densify_after = 16000000;
+	}
 	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
 	{
 		std::vector<std::thread> ld;
 		for (int g = 0; g < n_dev; ++g) ld.emplace_back([&, g]() {
-			if (ssg_set_device(g) || ssg_index_load2(argv[ai], densify_after > 0, &idxs[(size_t)g])) { fprintf(stderr, "[bwa] fail to load the index on device %d: %s\n", g, ssg_last_error()); fail = 1; } });
+			if (ssg_set_device(g) || ssg_index_load2(argv[ai], densify_after > 0, &idxs[(size_t)g])) { fprintf(stderr, "[bwa] fail to load the index on device %d: %s\n", g, ssg_last_error()); fail = 1; }
+			else if (densify_after > 0 && sa_first < 32 && ssg_index_densify_to(idxs[(size_t)g], sa_first)) { fprintf(stderr, "[bwa] %s\n", ssg_last_error()); fail = 1; } });
 		for (std::thread &x : ld) x.join();
 	}
 	t_warm.join();
