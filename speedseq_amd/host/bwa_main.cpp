@@ -367,10 +367,10 @@ static int main_mem(int argc, char **argv)
 	 * (the point where the walk has been paid for once over; 0 = at load time).  Results do not depend on it. */
 	long densify_after = 32000000; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
 	/* Measured on the MI355X (round 6, 3.1 Gbp): locating the seeds of a million pairs takes 67 ms on the file's samples (every 32nd row) and 8 ms on every 4th;
-	 * the copy to every 4th row costs 1.05 s -- paid back after 18 M pairs -- and a copy to every 16th an eighth of that.  So: plain regular input files that hold
-	 * more than that get the full copy at once; everything else a first step to every SSG_BWA_SA_FIRST-th row (16; 32 = none) right after the load, and the full
-	 * copy once the input has proved long. */
-	int sa_first = 16; { const char *e = getenv("SSG_BWA_SA_FIRST"); if (e && atoi(e) > 0) sa_first = atoi(e); }
+	 * the denser copy costs 1.05 s whatever its density (the walk visits every row once: a first step to every 16th row costs the same, tried and dropped --
+	 * SSG_BWA_SA_FIRST is that experiment's switch), i.e. it is paid back after 18 M pairs.  So: plain regular input files that hold more than that get the
+	 * copy at load time; every other input once it has proved that long. */
+	int sa_first = 32; { const char *e = getenv("SSG_BWA_SA_FIRST"); if (e && atoi(e) > 0) sa_first = atoi(e); }
 	if (!getenv("SSG_BWA_DENSIFY_AFTER")) {
 		uint64_t bytes = 0; bool known = true;
 		for (int k = ai + 1; k < argc && k < ai + 3; ++k) {
@@ -379,7 +379,7 @@ static int main_mem(int argc, char **argv)
 			bytes += (uint64_t)sb.st_size;
 		}
 		if (known && bytes / 640 >= 18000000) densify_after = 0;   /* (about 640 bytes of FASTQ a pair at 2x150; longer reads: fewer pairs, more seeds each) */
-		else densify_after = 16000000;
+		else densify_after = 18000000;
 	}
 	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
 	{
