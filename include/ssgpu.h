@@ -52,7 +52,7 @@ int ssg_index_load(const char *prefix, ssg_index_t **out);      /* reads prefix.
  * and calls ssg_index_densify() once the input has proved long -- between device calls, never while one runs on this index. */
 int ssg_index_load2(const char *prefix, int defer_dense_sa, ssg_index_t **out);
 int ssg_index_densify(ssg_index_t *idx);                         /* no-op when the index already is as dense as SSG_SA_INTV asks */
-int ssg_index_densify_to(ssg_index_t *idx, int intv);             /* the same to every intv-th row (power of two below the current interval, else a no-op): a cheaper first step */
+int ssg_index_densify_to(ssg_index_t *idx, int intv);             /* the same to every intv-th row (power of two below the current interval, else a no-op); the walk costs the same at any density */
 /* (All index constructors fill the HBM copy of the suffix-array samples to every 4th row -- SSG_SA_INTV overrides -- with
  *  upstream's bwt_sa walk: 2 bytes of HBM per reference base, same locations, ~6x less work per located seed.) */
 int ssg_index_from_arrays(const uint32_t *bwt, uint64_t bwt_words, uint64_t primary, const uint64_t L2[5],

@@ -215,8 +215,8 @@ int ssg_index_densify(ssg_index_t *ix)
 	if (!ix) { ssg_err_msg = "ssg_index_densify: no index"; return SSG_EINVAL; }
 	return densify_sa(ix);
 }
-/* ... to every intv-th row (a power of two below the current interval; anything else is a no-op): the walk costs in proportion to the rows it adds, so a
- * caller that does not know yet how long its input is can take a cheap first step (32 -> 16: an eighth of the work of 32 -> 4, half of the seed-location walks gone) */
+/* ... to every intv-th row (a power of two below the current interval; anything else is a no-op).  The walk visits every row once whatever the target density:
+ * a sparser copy is not cheaper to make (measured: 1.0 s to every 16th row as to every 4th), only smaller. */
 int ssg_index_densify_to(ssg_index_t *ix, int intv)
 {
 	CHK(need_device());

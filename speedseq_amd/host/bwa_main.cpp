@@ -329,7 +329,12 @@ static int main_mem(int argc, char **argv)
 		}
 	};
 	std::unique_ptr<fq_feed_t> fb1, fb2;   /* the parser taking over from the device-text path (an input that is not plain four-line records) */
+	/* The assembler waits for the index: page-locking its text buffers (and the result blocks of ssg_pe_reserve) while the index files stream into HBM made that load
+	 * three times as long -- 0.89 s against 0.34 s alone, the driver serialises page-locked allocations and the loader's staging blocks queued behind gigabytes of
+	 * them -- and nothing the assembler prepares can be used before the index is there (profiles/r06y_literal_load_contention.json).  SSG_BWA_LATE_PARSE=0: as before. */
+	std::atomic<bool> go_parse(getenv("SSG_BWA_LATE_PARSE") && atoi(getenv("SSG_BWA_LATE_PARSE")) == 0);
 	std::thread t_asm([&]() {
+		while (!go_parse.load() && !fail) std::this_thread::sleep_for(std::chrono::microseconds(200));
 		if (rawf) {
 			int64_t id0 = 0, seqno = 0;
 			while (!fail) {
@@ -381,7 +386,8 @@ static int main_mem(int argc, char **argv)
 		if (known && bytes / 640 >= 18000000) densify_after = 0;   /* (about 640 bytes of FASTQ a pair at 2x150; longer reads: fewer pairs, more seeds each) */
 		else densify_after = 18000000;
 	}
-	std::thread t_warm([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
+	const int warm = getenv("SSG_BWA_WARM") ? atoi(getenv("SSG_BWA_WARM")) : 0;   /* page-locked result blocks ahead of the first calls: 1 = while the index loads (until round 6), 2 = right after; 0 = the calls make them as they go */
+	std::thread t_warm([max_pairs_per_call, warm]() { if (warm == 1) (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */
 	{
 		std::vector<std::thread> ld;
 		for (int g = 0; g < n_dev; ++g) ld.emplace_back([&, g]() {
@@ -390,6 +396,8 @@ static int main_mem(int argc, char **argv)
 		for (std::thread &x : ld) x.join();
 	}
 	t_warm.join();
+	go_parse = true;
+	if (warm == 2) t_warm = std::thread([max_pairs_per_call]() { (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });
 	ssg_index_t *idx = idxs[0];
 	const double t_loaded = wall();
 	ssg_stamp("bwa", "index_loaded");
@@ -581,6 +589,7 @@ static int main_mem(int argc, char **argv)
 	if (fused && !fail) { text_t t; t.len = 0; t.frame = FU_END; t.seg = 0; t.seg_path = 0; t.p = (char*)malloc(1); to_write.push(t); }
 	to_write.close(); t_write.join();
 	t_asm.join(); for (std::thread &x : t_gpu) x.join();
+	if (t_warm.joinable()) t_warm.join();
 	ssg_stamp("bwa", "output_closed");
 	fprintf(stderr, "[bwa] wall: index load %.2f s, reads -> %s %.2f s\n", t_loaded - t_start, fused ? "BAM records (fused)" : "SAM", wall() - t_loaded);
 	{ double g = 0; for (double x : tm_gpu) g += x; fprintf(stderr, "[bwa] stage busy time: assemble %.2f s, device call %.2f s, format %.2f s\n", tm_asm, g, tm_fmt); }
