@@ -831,12 +831,26 @@ static int cmd_sort(int argc, char **argv)
 			ch.close();
 		});
 		std::unique_ptr<frame_t> F; bool ended = false; double t_wait = 0, t_index = 0; const char *bad = 0; uint64_t n_main = 0;   /* MAIN frames so far: frame k of rank r holds batch r + k * world */
+		/* the page-locked staging blocks of the writer's producers (write_sorted: three producers, two slots and an output block each, 134 MB apiece) are made now, next
+		 * to the input, and wait in the library's pool: page-locking 1.2 GB when the last record has arrived was a fifth of a second of the sort's tail.  Started with
+		 * the first record frame -- by then `bwa mem' has its index on the device (the driver serialises page-locked allocations: see bwa_main.cpp). */
+		std::thread prewarm; bool prewarmed = level == 0 || (getenv("SSG_SORT_PREWARM") && atoi(getenv("SSG_SORT_PREWARM")) == 0);
+		struct prewarm_join_t { std::thread &t; ~prewarm_join_t() { if (t.joinable()) t.join(); } } prewarm_join = { prewarm };
 		for (;;) {
 			{ const double t0 = wall(); const bool got = ch.pop(F); t_wait += wall() - t0; if (!got) break; }
 			if (F->fh.type == FU_END) { ended = true; break; }
 			if (F->fh.type == FU_HEADER) { h.text.assign((const char*)F->p.p, (size_t)F->fh.len); hdr_from_text(h); change_so(h.text, "coordinate"); continue; }
 			if (F->fh.type != FU_MAIN) { bad = "sort: unexpected frame in the fused stream"; break; }
 			if (!F->fh.len) { ++n_main; continue; }
+			if (!prewarmed) {
+				prewarmed = true;
+				prewarm = std::thread([]() {
+					if (ssg_device_count() < 1 || !strcmp(ssg_backend(), "emu")) return;
+					std::vector<void*> b;
+					for (int k = 0; k < 9; ++k) b.push_back(ssg_host_alloc((size_t)2048 * (BGZF_MAX_PAYLOAD + 5) + 64));
+					for (void *p : b) ssg_host_free(p);
+				});
+			}
 			{ const double t0 = wall(); if (!S.add_chunk(std::move(F->p), (size_t)F->fh.len, world > 1 ? ((uint64_t)rank + n_main * (uint64_t)world) << 28 : ~(uint64_t)0)) { bad = "sort: malformed record frame"; break; } t_index += wall() - t0; }
 			++n_main;
 			if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill();
