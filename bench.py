@@ -741,7 +741,7 @@ def main():
             # taken on this workload with these kernels, otherwise null -- never a constant in this file
             traffic = None
             real = {"ssg_k_smem2_kt": "ssg_k_smem2<false, true>", "ssg_k_smem2_plain": "ssg_k_smem2<false, false>"}   # the launcher's names of the template instances (ssg_seed.cpp) -> rocprofv3's
-            for tag in ("r05", "r04", "r02"):
+            for tag in ("r06", "r05", "r04", "r02"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
                     if pm.get("pairs") == a.pairs and pm.get("read_len") == rl and abs(pm.get("ref_mbp", 0) - a.ref_mbp) < 1e-6 and seed_k and all(real.get(k, k) in pm.get("bytes_per_launch", {}) for k in seed_k):
@@ -751,7 +751,7 @@ def main():
                     pass
             valu = {}; sw_lane_ops = None
             try:   # fraction of the measured int32 VALU issue peak (tools/dbg/valu_probe) from the committed SQ counter pass of this workload
-                pq = json.load(open(next(f for f in (os.path.join(ROOT, "profiles", t + "_pmc_sq.json") for t in ("r05", "r04", "r02")) if os.path.exists(f))))
+                pq = json.load(open(next(f for f in (os.path.join(ROOT, "profiles", t + "_pmc_sq.json") for t in ("r06", "r05", "r04", "r02")) if os.path.exists(f))))
                 valu = {k: round(v["valu_frac_of_probe_peak"], 3) for k, v in pq["kernels"].items() if k.startswith(("ssg_k_matesw", "ssg_k_msw_lane", "ssg_k_ext_lane", "ssg_k_smem")) and "valu_frac_of_probe_peak" in v and not k.endswith("_need")}
                 # vector instructions of the SW kernels per step (committed counters of the same kernels' code: the ISA is pinned) x 64 lanes
                 pmc_steps = max([1] + [v.get("launches", 1) for k, v in pq["kernels"].items() if k.startswith("ssg_k_matesw") and not k.startswith("ssg_k_matesw_need")])   # one mate-rescue launch per step of the counter run
@@ -772,7 +772,7 @@ def main():
                                "sw": {"cells_per_step": int(summary[3]) + int(summary[4]), "kernels": sorted(sw_names),
                                       "gcups": (int(summary[3]) + int(summary[4])) / (sw_ms * 1e-3) / 1e9 if sw_ms else None,
                                       "lane_ops_per_cell": (sw_lane_ops / (int(summary[3]) + int(summary[4]))) if sw_lane_ops and (int(summary[3]) + int(summary[4])) else None,   # SQ_INSTS_VALU x 64 of the SW kernels (committed counters, pinned ISA) over this run's DP cells
-                                      "valu_frac": valu or None, "valu_frac_source": "profiles/r05_pmc_sq.json if present, else r04 / r02 (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
+                                      "valu_frac": valu or None, "valu_frac_source": "profiles/r06_pmc_sq.json if present, else r05 / r04 / r02 (SQ_INSTS_VALU x 64 lanes / kernel time, over tools/dbg/valu_probe's add+max rate at 16 waves/CU)"}}
         # ---- parity gate ON THE TIMED CALL + CPU baseline: the step is run once more on the same device-resident inputs with its records
         # kept in HBM (identical inputs -> identical records; the summaries are compared), the records and samblaster's per-line decisions
         # are downloaded, and the oracle (scalar C restatement of bwa mem + samblaster) aligns the same pairs in the same upstream batches ----
