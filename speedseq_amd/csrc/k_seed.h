@@ -230,15 +230,17 @@ __global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, c
  * sampled row -- the walks partition the LF cycle, every row is visited once (seq_len line fetches in all; asking bwt_sa for each new
  * sample instead walks ~sa_intv steps per sample: 7 x the fetches at 32 -> 4).  Walk lengths are geometric, so lanes take new
  * walks from a counter as they finish (one atomic per wave and refill). */
-__global__ void ssg_k_sa_densify_walk(ssg_index_view_t ix, int new_intv, uint64_t *sa_new, unsigned long long n_old, unsigned long long *next)
+__global__ void ssg_k_sa_densify_walk(ssg_index_view_t ix, int new_intv, uint64_t *sa_new, unsigned long long n_old, unsigned long long *next, int refill_min)
 {
 	const uint64_t omask = (uint64_t)ix.sa_intv - 1, nmask = (uint64_t)new_intv - 1;
 	int nshift = 0; while ((1 << nshift) < new_intv) ++nshift;
 	const int lane = wv_lane();
 	bool have = false, done = false; uint64_t r = 0, v = 0;
 	for (;;) {
+		/* idle lanes take new walks when refill_min of them wait (or nobody works): a refill is an atomic and two dependent loads that every working lane of the wave
+		 * sits out -- taken every round (as until round 6) the walk made 5.9 G LF steps a second, a tenth of what this memory serves */
 		const unsigned long long need = wv_ballot(!have && !done);
-		if (need) {
+		if (need && (__popcll(need) >= refill_min || !wv_ballot(have))) {
 			const int leader = __ffsll(need) - 1;
 			unsigned long long base = 0;
 			if (lane == leader) base = atomicAdd(next, (unsigned long long)__popcll(need));

@@ -126,7 +126,7 @@ static int densify_sa(ssg_index *ix, int to = 0)
 	if (!d_next.ok()) { rt_free(d); ssg_err_msg = "index allocation failed: dense SA"; return SSG_ENOMEM; }
 	CHK(d_next.zero());
 	const long n_wg = std::min<long>((long)((n_old + 255) / 256), 256L * env_int("SSG_DENSIFY_WG_PER_CU", 8));   /* persistent: lanes refill from the counter */
-	SSG_LAUNCH(ssg_k_sa_densify_walk, n_wg, 256, 0, ix->v, want, d, n_old, d_next.p);
+	SSG_LAUNCH(ssg_k_sa_densify_walk, n_wg, 256, 0, ix->v, want, d, n_old, d_next.p, std::max(1, std::min(64, env_int("SSG_DENSIFY_REFILL", 32))));
 	CHK(rt_sync());
 	if (env_int("SSG_SA_VERIFY", 0)) CHK(ssg_sa_verify(ix, want, d, n_new));
 	rt_free(ix->sa);   /* the lower-density copy, when this index owns it */

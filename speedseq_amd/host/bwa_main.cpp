@@ -367,15 +367,12 @@ static int main_mem(int argc, char **argv)
 	/* the index travels to the device(s) while the assembler is already at work: by the time it is there the first device calls are waiting (until round 6 the
 	 * assembler started afterwards and the first call, alone on the device, began a scan of half a million pairs later) */
 	std::vector<ssg_index_t*> idxs((size_t)n_dev, (ssg_index_t*)0);
-	/* the denser suffix-array copy costs one LF walk over the text (about a second of the device for a human-size index) and saves ~27 ms
-	 * per million pairs: a run does not know how long its input is, so each device makes the copy once it has aligned this many pairs
-	 * (the point where the walk has been paid for once over; 0 = at load time).  Results do not depend on it. */
-	long densify_after = 32000000; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
-	/* Measured on the MI355X (round 6, 3.1 Gbp): locating the seeds of a million pairs takes 67 ms on the file's samples (every 32nd row) and 8 ms on every 4th;
-	 * the denser copy costs 1.05 s whatever its density (the walk visits every row once: a first step to every 16th row costs the same, tried and dropped --
-	 * SSG_BWA_SA_FIRST is that experiment's switch), i.e. it is paid back after 18 M pairs.  So: plain regular input files that hold more than that get the
-	 * copy at load time; every other input once it has proved that long. */
-	int sa_first = 32; { const char *e = getenv("SSG_BWA_SA_FIRST"); if (e && atoi(e) > 0) sa_first = atoi(e); }
+	/* The denser suffix-array copy (every 4th row instead of the file's every 32nd) takes locating the seeds of a million pairs from 67 ms to 8 ms and costs one LF
+	 * walk over the text: 0.21 s on the MI355X at 3.1 Gbp since the walk's lanes refill in batches (1.05 s before, when it was put off until an input had proved
+	 * long) -- paid back after 4 M pairs.  So it is made at load time, unless the input is a plain regular file that is known to be shorter than that.
+	 * SSG_BWA_DENSIFY_AFTER=n: after n pairs instead (0 = at load time).  Results do not depend on it. */
+	long densify_after = 0; { const char *e = getenv("SSG_BWA_DENSIFY_AFTER"); if (e) densify_after = atol(e); }
+	int sa_first = 32; { const char *e = getenv("SSG_BWA_SA_FIRST"); if (e && atoi(e) > 0) sa_first = atoi(e); }   /* (experiment: a first step to a sparser copy; costs the same walk) */
 	if (!getenv("SSG_BWA_DENSIFY_AFTER")) {
 		uint64_t bytes = 0; bool known = true;
 		for (int k = ai + 1; k < argc && k < ai + 3; ++k) {
@@ -383,8 +380,7 @@ static int main_mem(int argc, char **argv)
 			if (stat(argv[k], &sb) != 0 || !S_ISREG(sb.st_mode) || (l > 3 && !strcmp(argv[k] + l - 3, ".gz"))) { known = false; break; }
 			bytes += (uint64_t)sb.st_size;
 		}
-		if (known && bytes / 640 >= 18000000) densify_after = 0;   /* (about 640 bytes of FASTQ a pair at 2x150; longer reads: fewer pairs, more seeds each) */
-		else densify_after = 18000000;
+		if (known && bytes / 640 < 4000000) densify_after = 4000000;   /* (about 640 bytes of FASTQ a pair at 2x150: never reached) */
 	}
 	const int warm = getenv("SSG_BWA_WARM") ? atoi(getenv("SSG_BWA_WARM")) : 0;   /* page-locked result blocks ahead of the first calls: 1 = while the index loads (until round 6), 2 = right after; 0 = the calls make them as they go */
 	std::thread t_warm([max_pairs_per_call, warm]() { if (warm == 1) (void)ssg_pe_reserve((int)std::min<size_t>(max_pairs_per_call, (size_t)1 << 22), 2); });   /* page-locked result blocks, while the index loads */

@@ -294,3 +294,14 @@ def test_emu_reg2aln_lane_dp_classes(emu_lib, oracle, monkeypatch):
         assert texts[0] == texts[1]
     tot = np.array(seen).sum(axis=0)
     assert all(tot[:3] > 0) and tot[3] > 0, seen   # every class of the lane DP and the wave kernel had records
+
+
+@pytest.mark.parametrize("refill", ["1", "32", "64"])
+def test_emu_sa_densify_walks_refilled_in_batches(emu_lib, monkeypatch, refill):
+    # the denser suffix-array copy (k_seed.h ssg_k_sa_densify_walk): idle lanes take new walks when `refill` of them wait; every new sample checked against bwt_sa (SSG_SA_VERIFY)
+    monkeypatch.setenv("SSG_SA_VERIFY", "1")
+    monkeypatch.setenv("SSG_DENSIFY_REFILL", refill)
+    for intv in ("4", "8", "1"):
+        monkeypatch.setenv("SSG_SA_INTV", intv)
+        idx = emu_lib.index_load(common.EXAMPLE_FA)
+        emu_lib.index_destroy(idx)
