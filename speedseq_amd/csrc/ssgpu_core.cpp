@@ -768,6 +768,13 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	CHKA(d_nintv); CHKA(d_nseed);
 	dbuf<unsigned long long> d_next(1);
 	CHKA(d_next);
+	/* One call at a time in the seeding stage of a device.  Two calls in flight (bin/bwa: a lane each) gain only where their stages differ -- seeding is bound by
+	 * the memory, extension by the vector units, the wave kernels by latency -- and lose nothing but the overlap when they run the same stage side by side; runs
+	 * of the 8 M-pair script leg fell into two groups, 2.7 s and 3.7 s of alignment, by whether the two lanes happened to stay out of step.  A call that finds the
+	 * other one seeding waits here once, and from then on they alternate.  Off unless SSG_SEED_TOKEN=1: on a second box every run was of the fast kind with and without it (profiles/r06y_literal_seed_token.json). */
+	static std::mutex seed_token[16];
+	std::unique_lock<std::mutex> seed_lock(seed_token[ssg_cur_dev & 15], std::defer_lock);
+	if (env_int("SSG_SEED_TOKEN", 0) != 0) seed_lock.lock();
 	for (;;) {
 		int need = 0;
 		if (!d_intv.alloc((size_t)n_reads * cap)) { ssg_err_msg = "device allocation failed: d_intv"; return SSG_ENOMEM; }
@@ -779,6 +786,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 		if (ssg_debug()) fprintf(stderr, "[ssgpu] SMEM interval capacity widened to %d per read\n", cap);
 	}
 	if (stats) { unsigned long long c; CHK(d_next.down(&c, 1)); stats[5] = c; }
+	if (seed_lock.owns_lock()) { CHK(rt_sync()); seed_lock.unlock(); }
 	STAGE("smem");
 	const int block = 256;
 	SSG_LAUNCH(ssg_k_sal_count, (n_reads + block - 1) / block, block, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);

@@ -67,6 +67,12 @@ def main():
                 env[key] = val
         extra = "export SSG_FUSED=1\nexport SSG_SORT_LOG=1\nexport SSG_STAMP=1\nexport SSG_SBL_LOG=1\n" + "".join("export %s=%s\n" % kv for kv in env.items())
         import resource
+        def cpu_stat():
+            try:
+                return {l.split()[0]: int(l.split()[1]) for l in open("/sys/fs/cgroup/cpu.stat").read().split("\n") if l}
+            except Exception:
+                return {}
+        cs0 = cpu_stat()
         ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
         bwa_cmd = b("bwa")
         if trace:
@@ -93,7 +99,7 @@ def main():
         keep = [l[:260] for l in r.get("stage_log", []) if "[bwa]" in l or "records" in l or "merge" in l or "[samblaster]" in l or "[sambamba] sort: write" in l]
         ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
         cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)   # CPU seconds of every process of the pipeline: against wall x the host's CPU quota
-        res = {"config": cfg + (" (warm-up)" if k == 0 and not a.no_warmup else ""), "wall_s": r.get("wall_s"), "children_cpu_s": round(cpu_s, 2), "children_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "timeline_s": r.get("timeline_s"), "stage_log": keep}
+        res = {"config": cfg + (" (warm-up)" if k == 0 and not a.no_warmup else ""), "wall_s": r.get("wall_s"), "children_cpu_s": round(cpu_s, 2), "children_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "pairs_per_s": round(r.get("pairs_per_s", 0)), "error": r.get("error"), "timeline_s": r.get("timeline_s"), "stage_log": keep, "cgroup_throttled": {k: cpu_stat().get(k, 0) - cs0.get(k, 0) for k in ("nr_periods", "nr_throttled", "throttled_usec")}}
         results.append(res)
         bench.log(json.dumps({k2: v for k2, v in res.items() if k2 != "stage_log"}))
         for l in keep:
