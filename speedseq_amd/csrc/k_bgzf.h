@@ -154,12 +154,19 @@ __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload,
 		const int maxl = s1 - p < 258 ? s1 - p : 258;
 		if (p > 0 && maxl >= 4) { const int l = match_len(p - 1, p, maxl); if (l >= 4) { mlen = l; mdist = 1; } }
 		if (p + 4 > n) return;
-		const uint32_t w4 = bz_load32(src + p) * 2654435761u, h = (w4 >> (32 - BZ_HBITS)) & ~1u, g = (w4 >> (32 - BZ_CBITS)) & ~3u;
+		const uint32_t wp = bz_load32(src + p), w4 = wp * 2654435761u, h = (w4 >> (32 - BZ_HBITS)) & ~1u, g = (w4 >> (32 - BZ_CBITS)) & ~3u;
+		/* the six candidates' first four bytes are fetched together (one round trip instead of six one after the other: the parse is a chain of dependent loads, and a
+		 * candidate that differs there -- most do: the tables keep positions by hash -- could not give the four bytes a match needs); the choice is as before */
+		int cnd[6]; uint32_t wc[6];
+		SSG_UNROLL for (int t = 0; t < 6; ++t) {
+			cnd[t] = t < 4 ? (int)hc[g + t] : (int)ht[h + t - 4];
+			const bool ok = cnd[t] != 0xffff && cnd[t] < p && p - cnd[t] <= 32768;
+			wc[t] = ok ? bz_load32(src + cnd[t]) : ~wp;
+		}
 		SSG_UNROLL for (int t = 0; t < 6; ++t) {   /* the region's own positions first (nearer: cheaper distances), then the two newest from before it */
-			const int cand = t < 4 ? (int)hc[g + t] : (int)ht[h + t - 4];
-			if (cand != 0xffff && cand < p && p - cand <= 32768 && !(t >= 4 && mlen >= 16)) {   /* a good match nearby: the older table is not asked */
-				const int l = match_len(cand, p, maxl);
-				if (l >= 4 && l > mlen) { mlen = l; mdist = p - cand; }
+			if (wc[t] == wp && maxl >= 4 && !(t >= 4 && mlen >= 16)) {   /* a good match nearby: the older table is not asked */
+				const int l = match_len(cnd[t], p, maxl);
+				if (l >= 4 && l > mlen) { mlen = l; mdist = p - cnd[t]; }
 			}
 		}
 	};
