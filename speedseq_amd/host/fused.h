@@ -38,6 +38,24 @@
 #include <dirent.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
+#include <algorithm>
+/* cores this process may really use: the cgroup's CPU quota when there is one (a container next to the GPU: 256 hardware threads visible, 16 cores granted), else the
+ * hardware threads.  A host pool larger than this only takes the quota away from the threads that feed the device: at 200 M pairs the sort's 128 gather threads held
+ * `bwa mem`'s device calls to half their rate (profiles/r06_soak_200M.json) */
+static inline double ssg_usable_cores()
+{
+	double c = (double)std::max(1u, std::thread::hardware_concurrency());
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[64]; double per = 0; if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) c = std::min(c, atof(q) / per); fclose(f); }
+	return c;
+}
+/* a pool of `asked` threads on this host: no more than the usable cores (rounded up, at least 4); SSG_POOL_CAP=0: as asked */
+static inline int ssg_pool_threads(int asked)
+{
+	const char *e = getenv("SSG_POOL_CAP");
+	if (e && atoi(e) == 0) return std::max(1, asked);
+	return std::max(1, std::min(asked, std::max(4, (int)(ssg_usable_cores() + 0.999))));
+}
 #include <sys/statvfs.h>
 #include <string>
 #include <atomic>

@@ -28,13 +28,6 @@
 #include <time.h>
 static double wall() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static bool dbg() { static int d = -1; if (d < 0) d = (getenv("SSG_DEBUG") || getenv("SSG_SORT_LOG")) ? 1 : 0; return d != 0; }
-/* cores this process may really use: the cgroup's CPU quota when there is one (a container next to the GPU: 256 hardware threads visible, 16 cores granted), else the hardware threads */
-static double usable_cores()
-{
-	double c = (double)std::max(1u, std::thread::hardware_concurrency());
-	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[64]; double per = 0; if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) c = std::min(c, atof(q) / per); fclose(f); }
-	return c;
-}
 static int hw_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)std::min(n, 32u) : 4; }
 static void die(const std::string &m) { fprintf(stderr, "[sambamba] %s\n", m.c_str()); rk_mark_failed("sambamba"); exit(1); }   /* rank mode: the other ranks must not wait for this one */
 static int open_in(const char *p) { if (!strcmp(p, "/dev/stdin") || !strcmp(p, "-")) return 0; int fd = open(p, O_RDONLY); if (fd < 0) die(std::string("cannot open ") + p); return fd; }
@@ -291,7 +284,7 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	/* ... and on a host with many cores next to the device, some batches stay with the host's pool (zlib): batch k of the file belongs to slot k mod (producers + host
 	 * slots), a fixed rule -- the file's bytes do not depend on who was faster.  SSG_SORT_HOST_BATCHES: host slots per round (2 from 96 usable cores, 1 from 48, else 0: zlib at level 6 makes 35 MB/s a core). */
 	int host_slots = 0;
-	if (use_dev) { const char *e = getenv("SSG_SORT_HOST_BATCHES"); const double cores = std::min((double)threads, usable_cores()); host_slots = e && *e ? std::max(0, std::min(16, atoi(e))) : cores >= 96 ? 2 : cores >= 48 ? 1 : 0; if ((nb + DEV_BATCH - 1) / DEV_BATCH <= (size_t)n_prod) host_slots = 0; }
+	if (use_dev) { const char *e = getenv("SSG_SORT_HOST_BATCHES"); const double cores = std::min((double)threads, ssg_usable_cores()); host_slots = e && *e ? std::max(0, std::min(16, atoi(e))) : cores >= 96 ? 2 : cores >= 48 ? 1 : 0; if ((nb + DEV_BATCH - 1) / DEV_BATCH <= (size_t)n_prod) host_slots = 0; }
 	const int slot_round = n_prod + host_slots;
 	std::atomic<bool> host_takes_all(!use_dev);
 	std::atomic<int> dev_failed(0);
@@ -759,6 +752,7 @@ static int cmd_sort(int argc, char **argv)
 	{ const char *e = getenv("SSG_BAM_LEVEL"); if (level < 0 && e && *e) level = atoi(e); }   /* deflate level of the sorted file when -l is not given (default: zlib's 6, as sambamba's) */
 	/* compression is CPU work the reference's `-t` undersizes on a host with hundreds of cores next to an MI355X: the pool may use more (SSG_SORT_THREADS) */
 	int pool = threads; { const char *e = getenv("SSG_SORT_THREADS"); if (e && atoi(e) > 0) pool = atoi(e); }
+	pool = ssg_pool_threads(pool);
 	const int fd = open_in(in);
 	char first[8]; size_t n_first = 0;
 	while (n_first < 8) { ssize_t r = read(fd, first + n_first, 8 - n_first); if (r < 0) { if (errno == EINTR) continue; die("sort: read error"); } if (r == 0) break; n_first += (size_t)r; }

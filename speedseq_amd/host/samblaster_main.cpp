@@ -240,6 +240,7 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
 	int threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
 	{ const char *e = getenv("SSG_SBL_THREADS"); if (e && atoi(e) > 0) threads = atoi(e); }
+	threads = ssg_pool_threads(threads);
 	std::unique_ptr<sbl_server_t> srv; std::vector<int> cfds; std::mutex c_mu;   /* rank mode: this rank's slice of the duplicate set (rank 0's: the side streams too) and its connections to every rank's */
 	const bool shard = !(getenv("SSG_RANKS_SHARD") && !strcmp(getenv("SSG_RANKS_SHARD"), "0"));
 	if (world > 1) {
