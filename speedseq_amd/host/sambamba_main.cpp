@@ -280,6 +280,10 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	/* (SSG_SORT_PRODUCERS overrides; six producers on the one device -- a producer gathers and checksums on the host OR deflates on the device, never both at once --
 	 * were slower than three on the 16-CPU host next to the MI355X: 1.33 vs 1.15 s for 5.1 GB, profiles/r06f_literal_sort_producers.json: the gather threads are the limit) */
 	int want_prod = std::min(3 * n_devs, std::max(3, 2 * n_devs)); { const char *e = getenv("SSG_SORT_PRODUCERS"); if (e && atoi(e) > 0) want_prod = std::min(7 * n_devs, atoi(e)); }
+	/* a run (force_at: written while the input still arrives and `bwa mem' works on the same device) takes little of it: one producer, batches of 512 blocks -- a
+	 * wave of the deflate kernel holds 22 KB of LDS, seven of them fill a CU, and three producers' batches held the extension kernels of `bwa mem' to a third of
+	 * their rate for as long as a run was written (profiles/r06_soak_200M.json) */
+	if (force_at && use_dev && !getenv("SSG_SORT_DEV_BATCH")) { DEV_BATCH = 512; want_prod = 1; }
 	const int n_prod = use_dev ? (int)std::max<size_t>(1, std::min<size_t>((size_t)want_prod, (nb + DEV_BATCH - 1) / DEV_BATCH)) : 0;
 	/* ... and on a host with many cores next to the device, some batches stay with the host's pool (zlib): batch k of the file belongs to slot k mod (producers + host
 	 * slots), a fixed rule -- the file's bytes do not depend on who was faster.  SSG_SORT_HOST_BATCHES: host slots per round (2 from 96 usable cores, 1 from 48, else 0: zlib at level 6 makes 35 MB/s a core). */
@@ -774,7 +778,11 @@ static int cmd_sort(int argc, char **argv)
 	struct joiner_t { std::thread &t; ~joiner_t() { if (t.joinable()) t.join(); } } warm_join = { warm };
 	if (mkdir(tmpdir.c_str(), 0777) != 0 && errno != EEXIST) die("sort: cannot create " + tmpdir + ": " + strerror(errno));
 	std::vector<run_t> runs; std::vector<uint64_t> range_lo;
-	auto spill = [&]() {
+	/* One run at a time; in the fused single-pipeline sort a run is written by a thread of its own while the input goes on into a second store (each of half the
+	 * budget): until round 6 the input -- and with it samblaster and `bwa mem` -- stood still for as long as a run took to write. */
+	rec_store_t S_bg; std::thread t_spill;
+	auto spill_wait = [&]() { if (t_spill.joinable()) t_spill.join(); };
+	auto spill_store = [&](rec_store_t &S) {
 		std::vector<uint32_t> perm; gpu_perm(S, perm);
 		if (runs.empty()) {   /* the ranges of the genome, fixed now: about 4 MB of a run each, so that one range of all runs is a small merge */
 			size_t G = world > 1 ? 1024 : (size_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, S.bytes >> 22));   /* rank mode: the same ranges on every rank */
@@ -809,6 +817,11 @@ static int cmd_sort(int argc, char **argv)
 		}
 		runs.push_back(R); spills.push_back(R.path); S.clear();
 	};
+	auto spill = [&]() { spill_wait(); spill_store(S); };
+	const bool spill_bg = fused && world == 1 && !(getenv("SSG_SORT_SPILL_BG") && atoi(getenv("SSG_SORT_SPILL_BG")) == 0);
+	auto spill_async = [&]() { spill_wait(); std::swap(S, S_bg); t_spill = std::thread([&]() { spill_store(S_bg); }); };
+	struct spill_join_t { std::thread &t; ~spill_join_t() { if (t.joinable()) t.join(); } } spill_join = { t_spill };
+	const uint64_t budget_in = spill_bg ? std::max<uint64_t>(budget / 2, 1) : budget;
 	if (fused) {
 		/* frames straight from samblaster (fused.h): a reader thread takes them off the pipe, this thread indexes the records (keys +
 		 * locations) of each while the next arrives -- the sort's input work overlaps the alignment upstream */
@@ -847,8 +860,9 @@ static int cmd_sort(int argc, char **argv)
 			}
 			{ const double t0 = wall(); if (!S.add_chunk(std::move(F->p), (size_t)F->fh.len, world > 1 ? ((uint64_t)rank + n_main * (uint64_t)world) << 28 : ~(uint64_t)0)) { bad = "sort: malformed record frame"; break; } t_index += wall() - t0; }
 			++n_main;
-			if (S.bytes >= budget || S.key.size() >= 0xfffffff0u) spill();
+			if (S.bytes >= budget_in || S.key.size() >= 0xfffffff0u) { if (spill_bg) spill_async(); else spill(); }
 		}
+		spill_wait();
 		if (dbg()) fprintf(stderr, "[sambamba] sort: input thread waited %.2f s for frames, indexed records for %.2f s\n", t_wait, t_index);
 		{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
 		reader.join();                                           /* the rest of the stream was taken in (and its segments released) even after an error */
