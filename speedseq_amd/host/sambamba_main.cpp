@@ -272,7 +272,11 @@ static void write_sorted(const rec_store_t &S, const std::vector<uint32_t> &perm
 	/* blocks deflated on the device: the final file of a sort at a compressing level, when there is a device (SSG_BGZF_DEVICE=0 keeps zlib on the
 	 * host's threads; the host emulation of the kernels only does it on request, it is slow) */
 	const char *const bd = getenv("SSG_BGZF_DEVICE");
-	const bool use_dev = lvl != 0 && nb > 0 && !(bd && !strcmp(bd, "0")) && (bd || strcmp(ssg_backend(), "emu") != 0) && ssg_device_count() > 0 && GRP * 2 <= 2048 && 2048 % GRP == 0;
+	/* a run's blocks by the host's zlib pool (level 1), the device left to `bwa mem', where the host has the cores for it (32 usable ones): at 200 M pairs behind a 16-core
+	 * quota both ways end at 0.95-0.97 M pairs/s -- the device way slows bwa's kernels, the host way starves its threads (profiles/r06_soak_200M*.json).  SSG_SORT_RUN_DEVICE=0 / 1 decides. */
+	const char *const rde = getenv("SSG_SORT_RUN_DEVICE");
+	const bool run_on_host = force_at && (rde && *rde ? atoi(rde) == 0 : ssg_usable_cores() >= 32);
+	const bool use_dev = lvl != 0 && nb > 0 && !run_on_host && !(bd && !strcmp(bd, "0")) && (bd || strcmp(ssg_backend(), "emu") != 0) && ssg_device_count() > 0 && GRP * 2 <= 2048 && 2048 % GRP == 0;
 	size_t DEV_BATCH = 2048; { const char *e = getenv("SSG_SORT_DEV_BATCH"); if (e && atol(e) >= (long)GRP && atol(e) <= 2048 && atol(e) % (long)GRP == 0) DEV_BATCH = (size_t)atol(e); }   /* tests: several producers on several devices for a small file */
 	/* every visible device deflates (SSG_SORT_DEVICES caps them): producer t works on device t mod n_dev, lane 1 + t / n_dev -- with one device three
 	 * producers on three lanes as before, with N devices at least two per device; the writer and the index thread do not care who made a block */

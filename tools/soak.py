@@ -211,7 +211,7 @@ def main():
         if not emu:
             torch.cuda.empty_cache()
         bench.log("FASTQ of %d pairs written (%.1f GB)" % (a.pairs, os.path.getsize(fq) / 1e9))
-    cfg = "export SSG_FUSED=1\nexport SSG_BWA_PROF=1\nexport SSG_POOL_LOG=1\nexport SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128)
+    cfg = os.environ.get("SSG_SOAK_CONFIG_EXTRA", "").replace(";", "\n") + "\nexport SSG_FUSED=1\nexport SSG_BWA_PROF=1\nexport SSG_POOL_LOG=1\nexport SSG_SORT_THREADS=%d\nexport SSG_SORT_LOG=1\n" % min(os.cpu_count() or 8, 128)
     wd = td
     if a.tmp:
         os.makedirs(a.tmp, exist_ok=True)
