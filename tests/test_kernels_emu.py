@@ -305,3 +305,15 @@ def test_emu_sa_densify_walks_refilled_in_batches(emu_lib, monkeypatch, refill):
         monkeypatch.setenv("SSG_SA_INTV", intv)
         idx = emu_lib.index_load(common.EXAMPLE_FA)
         emu_lib.index_destroy(idx)
+
+
+def test_emu_index_densify_to_steps(emu_lib, oracle):
+    # ssg_index_load2 with the file's samples, then ssg_index_densify_to in two steps (16, then 4; a step that is not denser is a no-op): the same alignments as the oracle's
+    import ctypes as C
+    h = C.c_void_p()
+    assert emu_lib.l.ssg_index_load2(common.EXAMPLE_FA.encode(), 1, C.byref(h)) == 0
+    for intv in (16, 32, 4, 8):
+        assert emu_lib.l.ssg_index_densify_to(h, C.c_int(intv)) == 0
+    assert emu_lib.l.ssg_index_densify_to(h, C.c_int(0)) != 0
+    emu_lib.index_destroy(h)
+    assert common.check_align1(emu_lib, oracle, 60, seed=77) > 60
