@@ -74,7 +74,7 @@ __global__ void ssg_k_class_counts(const int32_t *key, long n, int tA, int tB, i
 	}
 }
 /* cnt[j] = #(key > t[j]) for ten thresholds at once, given the order that sorts the keys descending: a binary search per threshold (a lane each) instead of a pass
- * over the keys with an atomic per wave and threshold (1.6 ms per step for 2 M reads, profiles/r05q_timeline.txt) */
+ * over the keys with an atomic per wave and threshold (1.6 ms per step for 2 M reads, profiles/r05q_chain_stage_timeline_before.txt) */
 struct ssg_thr6_t { int t[10]; };
 __global__ void ssg_k_count_gt6(const int32_t *key, const int32_t *order, long n, ssg_thr6_t th, unsigned int *cnt)
 {

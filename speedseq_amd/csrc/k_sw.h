@@ -173,7 +173,7 @@ SSG_DEVFN ssg_ext_res_t wv_extend2(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_
 
 /* WIDE: the kernel instance serves reads of 256..319 bases too (a fifth register column per lane).  A template parameter of every function on
  * the way down from the kernel, because its mere presence costs the narrow reads: inlined it raised the register pressure of ssg_k_chain2aln
- * (30.5 -> 38.8 ms on 2x150), out of line the call alone did (39.9 ms; profiles/r05n_ab.json).  The host launches the WIDE instance of a kernel
+ * (30.5 -> 38.8 ms on 2x150), out of line the call alone did (39.9 ms; measured in round 5).  The host launches the WIDE instance of a kernel
  * only for a batch with a read above 255 bases. */
 template <bool WIDE>
 SSG_DEVFN ssg_ext_res_t wv_extend2_any(const ssg_mem_opt_t &opt, int qlen, ssg_seqv_t query, int tlen, ssg_seqv_t target,

@@ -133,7 +133,7 @@ static inline int rt_d2h(void *h, const void *d, size_t n) { return !n ? 0 : ssg
 static inline int rt_memset(void *d, int v, size_t n) { return !n ? 0 : ssg_stream ? rt_check(hipMemsetAsync(d, v, n, ssg_stream), "hipMemsetAsync") : rt_check(hipMemset(d, v, n), "hipMemset"); }
 /* waits for THIS thread's stream (lane 0: the null stream), not for the device: kernels forked onto the side streams (which are joined by events before their results are
  * used) keep running across the host round trips of the stream that forked them -- a device-wide wait here made the chaining stage's rank preparation wait for the light
- * reads' kernels (6 ms of a 20 ms stage, profiles/r05q_timeline.txt) */
+ * reads' kernels (6 ms of a 20 ms stage, profiles/r05q_chain_stage_timeline_before.txt) */
 static inline int rt_sync() { int rc = rt_check(hipStreamSynchronize(ssg_stream), "hipStreamSynchronize"); return rc ? rc : rt_check(hipGetLastError(), "kernel launch"); }
 /* multi-gigabyte, build-time-only arrays (index construction) bypass the arena: they must return to the driver when freed */
 static inline void *rt_malloc_raw(size_t n) { void *p = 0; if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); ssg_pool.release(); if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return 0; } } return p; }

@@ -80,7 +80,7 @@ static inline int ssg_fast_exit(int rc)
 	_exit(rc);
 }
 /* A stage whose LAST act is long -- `sambamba sort` ends holding gigabytes of mapped frames, page-locked blocks and a GPU context, and the kernel needs
- * 0.4 - 0.9 s to take all that back when the process goes (profiles/r06g_literal_exit_times.json: `written' to `exited') -- runs as a worker behind a
+ * 0.4 - 0.9 s to take all that back when the process goes (measured in round 6 with SSG_STAMP: `written' to `exited') -- runs as a worker behind a
  * waiter: the process the pipeline started forks before it has a thread or a device, the child does the stage's work and says so through a pipe when the
  * output is complete and closed, the waiter exits with that status at once and the script goes on while the worker is taken apart.  A worker that dies
  * without saying anything is waited for and its status passed on.  SSG_DETACH=0: one process, as ever. */
