@@ -29,7 +29,7 @@
 #define SSG_C2A_SCAN 1   /* chunks of 64 region keys fetched per round trip of the containment scan (2 trips the backend's odd-aligned 64-bit reload bug at 168 VGPRs) */
 #endif
 #ifndef SSG_C2A_WAVES_PER_SIMD
-#define SSG_C2A_WAVES_PER_SIMD 3   /* chain2aln: 168 VGPRs; measured 266 vs 282 ms against 4 waves (128 VGPRs) */
+#define SSG_C2A_WAVES_PER_SIMD 2   /* chain2aln: no spills at 2 (256 VGPRs); 18.0 ms against 18.9 at 3 (168 VGPRs, where the backend's odd-aligned 64-bit scratch reload error comes and goes with small changes) and 282 vs 266 ms a step at 4 (round 5) */
 #endif
 #ifndef SSG_SW_WAVES_PER_SIMD
 #define SSG_SW_WAVES_PER_SIMD 3   /* mate rescue: 168 VGPRs; 91 ms against 106 at 4 waves (128 VGPRs) */
