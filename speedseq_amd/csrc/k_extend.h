@@ -226,10 +226,16 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	unsigned long long t0 = 0, t1;
 #define SSG_PH(x) do { if (SSG_TUNING && ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
 	if (SSG_TUNING && ph) { t0 = ssg_clock(); }
+	/* the next chain's record and the results of its first seed's extensions are fetched while this chain is worked on: a chain is a string of dependent round trips
+	 * (record -> seed -> results), a read of the wave kernel has hundreds of chains, and the three loads here were a third of them */
+	const long gid0 = (long)chain_off[r];
+	ssg_xjob_t xj_n; ssg_xres_t xl_n, xr_n;
+	if (nch > 0) { xj_n = xjobs[gid0]; xl_n = xres_l[gid0]; xr_n = xres_r[gid0]; }
 	for (int ci = 0; ci < nch; ++ci) {
 		/* the chain's record (ssg_k_ext_prep): window, best seed, seed count, contig, frac_rep -- no walk through chains[] / order[] */
-		const long gid = (long)chain_off[r] + ci;
-		const ssg_xjob_t xj = xjobs[gid];
+		const long gid = gid0 + ci;
+		const ssg_xjob_t xj = xj_n; const ssg_xres_t xl_c = xl_n, xr_c = xr_n;
+		if (ci + 1 < nch) { xj_n = xjobs[gid + 1]; xl_n = xres_l[gid + 1]; xr_n = xres_r[gid + 1]; }
 		struct { int n, rid; float frac_rep; } c = { xj.cn, xj.rid, xj.frac_rep };
 		const int32_t *cs = chain_seeds + xj.first_seed;
 		int i, k, max_off[2], aw[2];
@@ -334,7 +340,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				tmp = s.rbeg - rmax[0];
 				ssg_seqv_t qs = { query + s.qbeg - 1, -1 }, rs = { rseq + tmp - 1, -1 };
 				if (ahead) {
-					const ssg_xres_t o = xres_l[gid];
+					const ssg_xres_t o = xl_c;
 					x.score = o.score; x.qle = o.qle; x.tle = o.tle; x.gtle = o.gtle; x.gscore = o.gscore; x.max_off = o.max_off;
 					aw[0] = o.aw; a.score = o.score; max_off[0] = o.max_off;
 				} else
@@ -354,7 +360,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				int re = (int)(s.rbeg + s.len - rmax[0]);
 				ssg_seqv_t qs = { query + qe, 1 }, rs = { rseq + re, 1 };
 				if (ahead) {
-					const ssg_xres_t o = xres_r[gid];
+					const ssg_xres_t o = xr_c;
 					x.score = o.score; x.qle = o.qle; x.tle = o.tle; x.gtle = o.gtle; x.gscore = o.gscore; x.max_off = o.max_off;
 					aw[1] = o.aw; a.score = o.score; max_off[1] = o.max_off;
 				} else
