@@ -361,9 +361,14 @@ __global__ void __launch_bounds__(64) ssg_k_reg2aln_lane(ssg_index_view_t ix, ss
 	int u = 0, n_mm = 0, l = 0;
 	ssg_tgt_t tg;   /* reference bases from the 2-bit pac, 16 per aligned word (k_extlane.h) */
 	ssg_tgt_init(tg, ix, rev ? re - 1 : rb, rev ? -1 : 1);
+	uint64_t q8 = 0;   /* eight bases of the read at a time: a byte per trip of this loop fetched the read's line again and again (the wave's other lanes' lines push it out of the cache in between: 6 KB fetched per record, PMC round 5) */
 	for (int i = 0; i < lq; ++i) {
+		if ((i & 7) == 0) {
+			q8 = 0;
+			SSG_UNROLL for (int b = 0; b < 8; ++b) if (i + b < lq) q8 |= (uint64_t)(rev ? query[lq - 1 - i - b] : query[i + b]) << (8 * b);
+		}
 		const int tb = ssg_tgt_next(tg);
-		const int qc = rev ? query[lq - 1 - i] : query[i];
+		const int qc = (int)(q8 >> ((i & 7) << 3)) & 0xff;
 		if (qc != tb) { l = ssg_put_int(a->md, l, SSG_MAX_MD - 1, u); if (l < SSG_MAX_MD - 1) a->md[l] = int2base[tb]; ++l; ++n_mm; u = 0; }
 		else ++u;
 	}
