@@ -239,8 +239,7 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	ssg_sbl_state_t *st = ssg_sbl_state_new();
 	unsigned long long n_pairs = 0, n_dups = 0, n_disc = 0, n_spl = 0;
 	int threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-	{ const char *e = getenv("SSG_SBL_THREADS"); if (e && atoi(e) > 0) threads = atoi(e); }
-	threads = ssg_pool_threads(threads);
+	{ const char *e = getenv("SSG_SBL_THREADS"); if (e && atoi(e) > 0) threads = atoi(e); }   /* (not cut to the cgroup's cores as the sort's pool is: its bursts are short, and 16 threads instead of 32 lengthened the end of an 8 M-pair run by 0.3 s) */
 	std::unique_ptr<sbl_server_t> srv; std::vector<int> cfds; std::mutex c_mu;   /* rank mode: this rank's slice of the duplicate set (rank 0's: the side streams too) and its connections to every rank's */
 	const bool shard = !(getenv("SSG_RANKS_SHARD") && !strcmp(getenv("SSG_RANKS_SHARD"), "0"));
 	if (world > 1) {
@@ -289,65 +288,18 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	double tm[6] = { 0, 0, 0, 0, 0, 0 };                     /* wait for a frame, numeric view, decisions, records rebuilt, main stream written, side streams */
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double tmb[4] = { 0, 0, 0, 0 };                          /* second stage: wait for a decided batch, records rebuilt, main stream written, side streams */
-	std::thread stage_b([&]() {
+	/* ... and a third thread writes the batch's side streams (the FIFOs' readers -- gawk, `sambamba view -S` -- take their time: 1.3 s of an 8 M-pair run were spent in
+	 * those writes by the thread that also had the next batch's records to rebuild, at the pace `bwa mem' now delivers them) */
+	chan_t<std::unique_ptr<work_t> > to_c(1);
+	std::thread stage_c([&]() {
 		std::unique_ptr<work_t> W;
 		for (;;) {
-			{ const double t0 = now(); const bool got = to_b.pop(W); tmb[0] += now() - t0; if (!got) break; }
-			if (rc) continue;                                     /* a failed run: take the batches off the channel, do nothing with them */
-			std::unique_ptr<frame_t> &F = W->F; const fu_batch_t &bh = W->bh; const fu_cand_t *cand = W->cand; const char *text = W->text; const uint8_t *bam = W->bam;
+			if (!to_c.pop(W)) break;
+			if (!rc) {
+			std::unique_ptr<frame_t> &F = W->F; const fu_batch_t &bh = W->bh; const fu_cand_t *cand = W->cand; const char *text = W->text;
 			const size_t nr = W->nr, n_blocks = W->n_blocks;
-			std::vector<uint64_t> &rec_off = W->rec_off; std::vector<ssg_sbl_line_t> &lines = W->lines; std::vector<uint8_t> &bits = W->bits; std::vector<int64_t> &blk_off = W->blk_off, &mate = W->mate;
-			auto view = [&](size_t i) { bam_view_t v; v.p = bam + rec_off[i] + 4; v.bs = (uint32_t)(rec_off[i + 1] - rec_off[i] - 4); return v; };
+			std::vector<ssg_sbl_line_t> &lines = W->lines; std::vector<uint8_t> &bits = W->bits; std::vector<int64_t> &blk_off = W->blk_off, &mate = W->mate;
 			double t0 = now();
-			do {
-			const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 4096 + 1));
-			if (outb.size() < (size_t)T) outb.resize((size_t)T);
-			for (auto &v : outb) v.clear();
-			parallel_ranges(T, (size_t)T, [&](size_t ta, size_t tb) {
-				for (size_t t = ta; t < tb; ++t) {
-					const size_t b0 = n_blocks * t / (size_t)T, b1 = n_blocks * (t + 1) / (size_t)T;
-					std::vector<uint8_t> &ob = outb[t];
-					ob.reserve((size_t)((rec_off[(size_t)blk_off[b1]] - rec_off[(size_t)blk_off[b0]]) * 21 / 20) + 4096);
-					char cg[16];
-					for (size_t i = (size_t)blk_off[b0]; i < (size_t)blk_off[b1]; ++i) {
-						const bam_view_t v = view(i);
-						const size_t base = ob.size();
-						ob.insert(ob.end(), bam + rec_off[i], bam + rec_off[i + 1]);
-						if (bits[i] & SSG_SBL_DUP) { uint32_t fnc; memcpy(&fnc, ob.data() + base + 4 + 12, 4); fnc |= 0x400u << 16; memcpy(ob.data() + base + 4 + 12, &fnc, 4); }
-						if (o.add_mate_tags && mate[i] >= 0) {
-							const bam_view_t m = view((size_t)mate[i]);
-							if (!bam_has_tag(v, 'M', 'C')) {
-								ob.push_back('M'); ob.push_back('C'); ob.push_back('Z');
-								if (!m.n_cigar()) ob.push_back('*');
-								for (uint32_t k = 0; k < m.n_cigar(); ++k) {
-									uint32_t x; memcpy(&x, m.cigar() + 4 * k, 4); uint32_t len = x >> 4; int n = 0;
-									do { cg[n++] = (char)('0' + len % 10); len /= 10; } while (len);
-									while (n) ob.push_back((uint8_t)cg[--n]);
-									ob.push_back((uint8_t)"MIDNSHP=XB"[x & 0xf]);
-								}
-								ob.push_back(0);
-							}
-							if (!bam_has_tag(v, 'M', 'Q')) { ob.push_back('M'); ob.push_back('Q'); ob.push_back('C'); ob.push_back((uint8_t)m.mapq()); }   /* MAPQ <= 255: sam_parse1 types it 'C' */
-							const uint32_t nbs = (uint32_t)(ob.size() - base - 4); memcpy(ob.data() + base, &nbs, 4);
-						}
-					}
-				}
-			});
-			tmb[1] += now() - t0; t0 = now();
-			{	uint64_t tot = 0; std::vector<uint64_t> at(outb.size() + 1, 0);
-				for (size_t k = 0; k < outb.size(); ++k) { at[k] = tot; tot += outb[k].size(); }
-				fu_buf_t seg; std::string seg_path; bool ok;
-				if (fu_seg_create((size_t)tot, seg, seg_path)) {       /* the frame as a mapped segment: filled by the threads, only its name travels */
-					parallel_ranges((int)outb.size(), outb.size(), [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) if (!outb[k].empty()) memcpy(seg.p + at[k], outb[k].data(), outb[k].size()); });
-					ok = fu_seg_send(1, FU_MAIN, seg, seg_path);
-				} else {
-					fu_frame_t fh; fh.type = FU_MAIN; fh.zero = 0; fh.len = tot;
-					ok = fu_write_full(1, &fh, sizeof(fh));
-					for (auto &v : outb) ok = ok && fu_write_full(1, v.data(), v.size());
-				}
-				if (!ok) { perror("[samblaster] write"); rc = 1; } }
-			if (rc) break;
-			tmb[2] += now() - t0; t0 = now();
 			/* side streams, from the text bwa attached for the pairs that can qualify */
 			ltext.assign(nr, std::pair<const char*, uint32_t>((const char*)0, 0u));
 			for (uint64_t c = 0; c < bh.n_cand; ++c) {
@@ -422,7 +374,71 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 			if (F->b.mapped) F->b.reset();                           /* the segment's pages go back to the system now */
 			{ std::lock_guard<std::mutex> l(pool_mu); if (pool.size() < 3) pool.push_back(std::move(F)); }
 			tmb[3] += now() - t0;
+			}
+			{ std::lock_guard<std::mutex> l(wpool_mu); if (wpool.size() < 3) wpool.push_back(std::move(W)); }
+		}
+	});
+	std::thread stage_b([&]() {
+		std::unique_ptr<work_t> W;
+		for (;;) {
+			{ const double t0 = now(); const bool got = to_b.pop(W); tmb[0] += now() - t0; if (!got) break; }
+			if (rc) continue;                                     /* a failed run: take the batches off the channel, do nothing with them */
+			std::unique_ptr<frame_t> &F = W->F; const fu_batch_t &bh = W->bh; const fu_cand_t *cand = W->cand; const char *text = W->text; const uint8_t *bam = W->bam;
+			const size_t nr = W->nr, n_blocks = W->n_blocks;
+			std::vector<uint64_t> &rec_off = W->rec_off; std::vector<ssg_sbl_line_t> &lines = W->lines; std::vector<uint8_t> &bits = W->bits; std::vector<int64_t> &blk_off = W->blk_off, &mate = W->mate;
+			auto view = [&](size_t i) { bam_view_t v; v.p = bam + rec_off[i] + 4; v.bs = (uint32_t)(rec_off[i + 1] - rec_off[i] - 4); return v; };
+			double t0 = now();
+			do {
+			const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n_blocks / 4096 + 1));
+			if (outb.size() < (size_t)T) outb.resize((size_t)T);
+			for (auto &v : outb) v.clear();
+			parallel_ranges(T, (size_t)T, [&](size_t ta, size_t tb) {
+				for (size_t t = ta; t < tb; ++t) {
+					const size_t b0 = n_blocks * t / (size_t)T, b1 = n_blocks * (t + 1) / (size_t)T;
+					std::vector<uint8_t> &ob = outb[t];
+					ob.reserve((size_t)((rec_off[(size_t)blk_off[b1]] - rec_off[(size_t)blk_off[b0]]) * 21 / 20) + 4096);
+					char cg[16];
+					for (size_t i = (size_t)blk_off[b0]; i < (size_t)blk_off[b1]; ++i) {
+						const bam_view_t v = view(i);
+						const size_t base = ob.size();
+						ob.insert(ob.end(), bam + rec_off[i], bam + rec_off[i + 1]);
+						if (bits[i] & SSG_SBL_DUP) { uint32_t fnc; memcpy(&fnc, ob.data() + base + 4 + 12, 4); fnc |= 0x400u << 16; memcpy(ob.data() + base + 4 + 12, &fnc, 4); }
+						if (o.add_mate_tags && mate[i] >= 0) {
+							const bam_view_t m = view((size_t)mate[i]);
+							if (!bam_has_tag(v, 'M', 'C')) {
+								ob.push_back('M'); ob.push_back('C'); ob.push_back('Z');
+								if (!m.n_cigar()) ob.push_back('*');
+								for (uint32_t k = 0; k < m.n_cigar(); ++k) {
+									uint32_t x; memcpy(&x, m.cigar() + 4 * k, 4); uint32_t len = x >> 4; int n = 0;
+									do { cg[n++] = (char)('0' + len % 10); len /= 10; } while (len);
+									while (n) ob.push_back((uint8_t)cg[--n]);
+									ob.push_back((uint8_t)"MIDNSHP=XB"[x & 0xf]);
+								}
+								ob.push_back(0);
+							}
+							if (!bam_has_tag(v, 'M', 'Q')) { ob.push_back('M'); ob.push_back('Q'); ob.push_back('C'); ob.push_back((uint8_t)m.mapq()); }   /* MAPQ <= 255: sam_parse1 types it 'C' */
+							const uint32_t nbs = (uint32_t)(ob.size() - base - 4); memcpy(ob.data() + base, &nbs, 4);
+						}
+					}
+				}
+			});
+			tmb[1] += now() - t0; t0 = now();
+			{	uint64_t tot = 0; std::vector<uint64_t> at(outb.size() + 1, 0);
+				for (size_t k = 0; k < outb.size(); ++k) { at[k] = tot; tot += outb[k].size(); }
+				fu_buf_t seg; std::string seg_path; bool ok;
+				if (fu_seg_create((size_t)tot, seg, seg_path)) {       /* the frame as a mapped segment: filled by the threads, only its name travels */
+					parallel_ranges((int)outb.size(), outb.size(), [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) if (!outb[k].empty()) memcpy(seg.p + at[k], outb[k].data(), outb[k].size()); });
+					ok = fu_seg_send(1, FU_MAIN, seg, seg_path);
+				} else {
+					fu_frame_t fh; fh.type = FU_MAIN; fh.zero = 0; fh.len = tot;
+					ok = fu_write_full(1, &fh, sizeof(fh));
+					for (auto &v : outb) ok = ok && fu_write_full(1, v.data(), v.size());
+				}
+				if (!ok) { perror("[samblaster] write"); rc = 1; } }
+			if (rc) break;
+			tmb[2] += now() - t0; t0 = now();
 			} while (0);
+			if (!rc) { to_c.push(std::move(W)); continue; }   /* the side streams of this batch: the third stage */
 			{ std::lock_guard<std::mutex> l(wpool_mu); if (wpool.size() < 3) wpool.push_back(std::move(W)); }
 		}
 	});
@@ -500,6 +516,8 @@ static int fused_main(const ssg_sbl_opt_t &o, out_t *spl, out_t *disc, FILE *spl
 	}
 	to_b.close();
 	stage_b.join();
+	to_c.close();
+	stage_c.join();
 	tm[3] = tmb[1]; tm[4] = tmb[2]; tm[5] = tmb[3];
 	if (getenv("SSG_SBL_LOG")) fprintf(stderr, "[samblaster] first stage: waiting for frames %.2f s, numeric view %.2f s, decisions %.2f s; second stage: waiting for decided batches %.2f s, records %.2f s, main stream written %.2f s, side streams %.2f s\n", tm[0], tm[1], tm[2], tmb[0], tm[3], tm[4], tm[5]);
 	{ std::unique_ptr<frame_t> drop; while (ch.pop(drop)) {} }
