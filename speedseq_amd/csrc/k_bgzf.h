@@ -113,12 +113,14 @@ SSG_DEVFN void bz_w_end(bz_writer_t &w) { if (w.nacc > 0) atomicOr(w.out + w.wor
  */
 __global__ void __launch_bounds__(64) ssg_k_bgzf_deflate(const uint8_t *payload, const uint64_t *cut, int n_blocks, uint8_t *tmp, uint32_t *sym, uint32_t *size)
 {
-	__shared__ uint16_t ht[1 << BZ_HBITS];
-	__shared__ uint16_t hc[1 << BZ_CBITS];
+	/* the two hash tables are dead when the codes are built: the work arrays of the code builder (5.8 KB) lie over them, and a CU holds ten waves of this kernel instead of seven */
+	__shared__ uint32_t lz_pool[((1 << BZ_HBITS) + (1 << BZ_CBITS)) / 2];
+	uint16_t *const ht = (uint16_t*)lz_pool, *const hc = ht + (1 << BZ_HBITS);
+	static_assert(sizeof(lz_pool) >= (288 + 576 + 576) * 4, "the code builder's work arrays fit the hash tables' space");
+	int32_t *const w_idx = (int32_t*)lz_pool; uint32_t *const w_wt = lz_pool + 288; int32_t *const w_par = (int32_t*)lz_pool + 288 + 576;
 	__shared__ uint32_t f_ll[288], f_d[32], f_cl[19];
 	__shared__ uint8_t l_ll[288], l_d[32], l_cl[19];
 	__shared__ uint16_t c_ll[288], c_d[32], c_cl[19];
-	__shared__ int32_t w_idx[288]; __shared__ uint32_t w_wt[576]; __shared__ int32_t w_par[576];
 	__shared__ uint16_t rle[320];            /* the code-length sequence: symbol | extra value << 5 */
 	__shared__ uint32_t sh_misc[8];          /* 0: n_rle, 1: hlit, 2: hdist, 3: hclen, 4: header bits */
 	const int b = (int)blockIdx.x, lane = wv_lane();
