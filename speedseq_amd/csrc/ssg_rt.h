@@ -155,6 +155,7 @@ struct ssg_hostpool_t {
 		}
 		void *p = 0; const size_t c = n + n / 4;
 		if (hipHostMalloc(&p, c, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return 0; }
+		if (getenv("SSG_HOSTPOOL_LOG")) fprintf(stderr, "[ssgpu] page-locked block of %.0f MB made (pool holds %.0f MB free)\n", (double)c / 1048576.0, (double)free_bytes / 1048576.0);
 		std::lock_guard<std::mutex> l(mu); cap_[p] = c;
 		return p;
 	}
@@ -164,7 +165,8 @@ struct ssg_hostpool_t {
 		std::vector<void*> drop;
 		{	std::lock_guard<std::mutex> l(mu);
 			free_.push_back(p); free_bytes += cap_[p];
-			while (free_bytes > ((size_t)4 << 30) && !free_.empty()) { void *q = free_.front(); free_.erase(free_.begin()); free_bytes -= cap_[q]; cap_.erase(q); drop.push_back(q); }
+			static const size_t cap_bytes = []() { const char *e = getenv("SSG_HOSTPOOL_GB"); const double g = e && atof(e) > 0 ? atof(e) : 4.0; return (size_t)(g * 1073741824.0); }();
+			while (free_bytes > cap_bytes && !free_.empty()) { void *q = free_.front(); free_.erase(free_.begin()); free_bytes -= cap_[q]; cap_.erase(q); drop.push_back(q); }
 		}
 		for (void *q : drop) (void)hipHostFree(q);
 	}
