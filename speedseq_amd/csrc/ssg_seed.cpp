@@ -30,7 +30,8 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
 	const long nthreads = std::min<long>(((long)n_reads + block - 1) / block * block, 256L * env_int("SSG_SMEM_WAVES_PER_CU", 16) * 64)   /* resident waves per CU, measured (round 4, 1 M pairs): with the table 52.2 ms at 16, 57.4 at 12, 72.6 at 8; without it 12 was best (58.0 vs 61.6 at 16) */;
 	const int scap = max_len + 2;
 	/* the table of short-pattern intervals: used when the index has one and its patterns are shorter than a seed (the third pass jumps kt_k bases in) */
-	const int kt_k = idx->ktab && idx->ktab_k >= 2 && idx->ktab_k < opt->min_seed_len && env_int("SSG_SMEM_USE_KTAB", 1) ? idx->ktab_k : 0;
+	const int kt_want = idx->ktab && env_int("SSG_SMEM_USE_KTAB", 1) ? std::min(idx->ktab_k, opt->min_seed_len - 1) : 0;   /* (every level below the table's K is there too: `-k' at or below K uses the levels under it) */
+	const int kt_k = kt_want >= 2 ? kt_want : 0;
 	const ssg_pk2_t *const kt = kt_k ? (const ssg_pk2_t*)idx->ktab : (const ssg_pk2_t*)0;
 	dbuf<ssg_pk2_t> scratch((size_t)nthreads * 2 * scap + 64);
 	dbuf<unsigned int> d_next(4);   /* [0] next read of the lane kernel, [1] reads it gave up, [2] next of those for the wave kernel */
@@ -71,13 +72,15 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
 	return rt_sync();
 }
 
-/* table of the intervals of all patterns up to K bases (k_smem2.h): K = SSG_KTAB_K, default 13 capped at log4(text length) - 2 (1.4 GB for a
- * human-size index: 89 M bwt_extend calls, ~20 ms); 0 = none.  Every constructor of an index ends with this. */
+/* table of the intervals of all patterns up to K bases (k_smem2.h): K = SSG_KTAB_K; default 15 on a human-size index (text of 4^16 symbols or more: 22.9 GB of the
+ * 288, 358 M bwt_extend calls, < 50 ms; measured at 1 M pairs / 3.1 Gbp, profiles/r06T_ktab_pairwave_sa_ab.json: the lane kernel 57.4 ms at 12, 56.0 at 13, 55.2 at 14,
+ * 52.6 at 15), else 13 capped at log4(text length) - 2; never more than 15 (s2_code packs 15 bases) nor than log4(text length) + 2 (a table of 16 times more patterns
+ * than the text has positions is empty space); 0 = none.  Every constructor of an index ends with this. */
 extern "C" int ssg_index_build_ktab(ssg_index *ix)
 {
 	int lg = 0; while ((ix->v.seq_len >> (2 * (lg + 1))) != 0) ++lg;    /* floor(log4(seq_len)) */
-	int K = env_int("SSG_KTAB_K", std::min(13, lg - 2));
-	if (K > 14) K = 14;
+	int K = env_int("SSG_KTAB_K", lg >= 16 ? 15 : std::min(13, lg - 2));
+	K = std::min(K, std::min(15, lg + 2));
 	rt_free(ix->ktab); ix->ktab = 0; ix->ktab_k = 0;
 	if (K < 2 || ix->v.seq_len >= (1ull << 40)) return 0;
 	const size_t n_ent = (size_t)((((1ull << (2 * (K + 1))) - 4ull) / 3ull));

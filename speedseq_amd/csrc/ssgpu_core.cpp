@@ -1273,9 +1273,10 @@ static int pe_core(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_pairs
 		long nthr = std::min<long>(((long)n_pairs + 63) / 64 * 64, (long)env_int("SSG_PF_THREADS", 131072));   /* 8 waves/CU at 2 waves/SIMD (249 VGPRs); 16 KB of candidate scratch per lane */
 		dbuf<ssg_pair64_t> d_v((size_t)t2 + 1), d_u((size_t)nthr * ucap);
 		CHKA(d_v); CHKA(d_u);
-		/* d_pw is heaviest first: pairs with long region lists get a wavefront each (k_pairw.h), the rest a lane each */
+		/* d_pw is heaviest first: pairs with long region lists get a wavefront each (k_pairw.h), the rest a lane each.  From 16 regions (64 until r06T: the lane kernel on
+		 * global memory took 3.9 ms for the pairs of 7..63 regions, it takes 0.5 ms for those of 7..15, and the wave kernel 0.1 ms more: profiles/r06T_ktab_pairwave_sa_ab.json) */
 		unsigned int cc[5];
-		CHK(dev_class_counts(d_pkey.p, n_pairs, 0, 0, env_int("SSG_PAIR_WAVE_MIN", 64), cc));
+		CHK(dev_class_counts(d_pkey.p, n_pairs, 0, 0, env_int("SSG_PAIR_WAVE_MIN", 16), cc));
 		const int n_heavy = (int)cc[0];
 		const long nwg_h = n_heavy > 0 ? std::min<long>(((long)n_heavy + wpb - 1) / wpb, (long)env_int("SSG_PFW_WGS", 512)) : 0;
 		dbuf<ssg_pw_slab_t> d_slab((size_t)nwg_h * wpb + 1);

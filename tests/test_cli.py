@@ -251,6 +251,7 @@ BWA_OPTION_SETS = [
     ("-k", "25"), ("-w", "40", "-d", "50"), ("-A", "2"), ("-A", "2", "-B", "5", "-O", "7,9", "-E", "2,1"), ("-L", "3,8", "-U", "9"),
     ("-T", "45"), ("-c", "50", "-D", "0.3"), ("-r", "1.0", "-y", "10"), ("-m", "5", "-W", "6"), ("-h", "2", "-X", "0.3"), ("-K", "20000"),
     ("-Q", "20", "-s", "5", "-G", "500", "-N", "3"),
+    ("-k", "8"),   # seeds shorter than the patterns of the index's table of short-pattern intervals: the seeding kernel uses the table's levels below 8 (ssg_seed.cpp kt_k)
 ]
 
 
@@ -275,7 +276,7 @@ def _bwa_options(tmp_path, bwa, opts, n_pairs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opts", [("-M", "-Y"), ("-S", "-P"), ("-A", "2", "-B", "5", "-O", "7,9", "-E", "2,1"), ("-k", "25", "-c", "50", "-D", "0.3", "-r", "1.0")], ids=lambda o: "".join(o))
+@pytest.mark.parametrize("opts", [("-M", "-Y"), ("-S", "-P"), ("-A", "2", "-B", "5", "-O", "7,9", "-E", "2,1"), ("-k", "25", "-c", "50", "-D", "0.3", "-r", "1.0"), ("-k", "8")], ids=lambda o: "".join(o))
 def test_cli_gpu_bwa_mem_option_sets(tmp_path, gpu_lib, opts):
     _bwa_options(tmp_path, [os.path.join(ROOT, "bin", "bwa")], opts, 20000)
 

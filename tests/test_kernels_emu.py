@@ -225,7 +225,7 @@ def test_emu_smem_budget_and_wave_kernel(emu_lib, oracle, repeat_prefix, monkeyp
 def test_emu_smem_table_of_short_pattern_intervals(emu_lib, oracle, repeat_prefix, monkeypatch):
     # the table of the intervals of all patterns up to K bases (k_smem2.h): a bwt_extend whose result is that short is one load, the third pass
     # starts K bases in; K is chosen at index load.  Same intervals for every K, with ambiguous bases, on repeats, with give-ups, and without a table
-    for k in ("2", "5", "11", "0", "25"):              # 25 >= min_seed_len: the kernel declines the table
+    for k in ("2", "5", "11", "0", "25"):              # 25: capped by what the index is worth (log4 of the text + 2) and by min_seed_len - 1 in the kernel
         monkeypatch.setenv("SSG_KTAB_K", k)
         monkeypatch.setenv("SSG_KTAB_VERIFY", "1")
         common.check_smem(emu_lib, oracle, 60, seed=51)

@@ -71,6 +71,12 @@ def main():
         saved = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
+            # two switches are read when an index is made, not per step: the table of short-pattern intervals is rebuilt for this configuration (and
+            # again, at its default, after it); the suffix-array samples only ever get denser, so such configurations go last, in falling order
+            if "SSG_KTAB_K" in env:
+                lib._chk(lib.l.ssg_index_build_ktab(idx))
+            if "SSG_SA_INTV" in env:
+                lib._chk(lib.l.ssg_index_densify_to(idx, C.c_int(int(env["SSG_SA_INTV"]))))
             capi.hotpath_dev_ex(lib, idx, opt, a.pairs, rl, d_seq.data_ptr(), d_off.data_ptr(), d_pb.data_ptr(), n_batches, 0)   # warm-up
             torch.cuda.synchronize()
             lib.l.ssg_prof_reset(); lib.l.ssg_prof_enable(C.c_int(1))
@@ -97,6 +103,8 @@ def main():
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+            if "SSG_KTAB_K" in env:
+                lib.l.ssg_index_build_ktab(idx)
         results.append(r)
         bench.log(json.dumps(r))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
