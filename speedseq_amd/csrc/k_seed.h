@@ -177,6 +177,74 @@ __global__ void __launch_bounds__(64) ssg_k_smem_sort(int n_reads, ssg_intv_t *i
 	if (n > 1 && n <= cap) ssg_introsort(intv + r * cap, (long)n, ssg_intv_lt());
 }
 
+/* The same for the lists of up to LC intervals (nearly all) without introsort's per-lane control flow: the lanes of a wave sort lists of different lengths and
+ * contents, so the wave walks the union of 64 different introsort paths, every compare a dependent load on the lane's own lines (3.7 ms per million pairs at
+ * 1 % of the VALU rate, profiles/r06_pmc_sq.json).  Here a lane copies its records into LDS (four at a time, independent loads), holds the keys in registers,
+ * ranks every key against the others in fully unrolled, predicated loops (no memory in the rank phase: a first form that read the keys from LDS in an n x n loop
+ * took 4.5 ms, r06U), and writes record i to place rank(i).  LDS word (8 bytes) w of lane l at [w * 64 + l]: bank = lane whatever w.
+ * The key is (start, end) = `info`; two intervals of a read with equal keys are intervals of the same pattern, hence the same 32 bytes (the order in which a
+ * pattern was extended to does not change its interval: the premise of the table of short-pattern intervals as well), so every order of equal keys --
+ * introsort's, or the stable one of the ranks here -- leaves the same list. */
+template <int LC>
+__global__ void __launch_bounds__(64) ssg_k_smem_sort_rank(int n_reads, ssg_intv_t *intv, const int32_t *n_intv, int cap, int32_t *todo, unsigned int *n_todo /* the reads with longer lists: ssg_k_smem_sort_wave */)
+{
+	__shared__ uint64_t L[LC * 3 * 64];   /* x0, x1, x2 of every record; the keys stay in registers */
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const int n = n_intv[r];
+	if (n <= 1 || n > cap) return;
+	ssg_intv_t *const p = intv + r * cap;
+	if (n > LC) { todo[atomicAdd(n_todo, 1u)] = (int32_t)r; return; }   /* (one long list sorted by its lane held the whole wave: one read in twenty has one, nearly every wave had one) */
+	uint64_t *const Ll = L + (threadIdx.x & 63);
+	uint64_t key[LC];
+	SSG_UNROLL for (int i0 = 0; i0 < LC; i0 += 4) {
+		ssg_intv_t v[4];
+		SSG_UNROLL for (int u = 0; u < 4; ++u) if (i0 + u < n) v[u] = p[i0 + u]; else { v[u].x0 = v[u].x1 = v[u].x2 = 0; v[u].info = ~0ull; }
+		SSG_UNROLL for (int u = 0; u < 4; ++u) {
+			key[i0 + u] = v[u].info;
+			if (i0 + u < n) { Ll[((i0 + u) * 3 + 0) * 64] = v[u].x0; Ll[((i0 + u) * 3 + 1) * 64] = v[u].x1; Ll[((i0 + u) * 3 + 2) * 64] = v[u].x2; }
+		}
+	}
+	SSG_UNROLL for (int i = 0; i < LC; ++i) {
+		if (i < n) {
+			int rank = 0;
+			SSG_UNROLL for (int j = 0; j < LC; ++j) rank += (int)((j < n) & ((key[j] < key[i]) | ((key[j] == key[i]) & (j < i))));
+			if (rank != i) { ssg_intv_t v; v.x0 = Ll[(i * 3 + 0) * 64]; v.x1 = Ll[(i * 3 + 1) * 64]; v.x2 = Ll[(i * 3 + 2) * 64]; v.info = key[i]; p[rank] = v; }
+		}
+	}
+}
+
+/* the longer lists, one WAVE per read: lane l holds records l, l + 64, ... (up to four: 256 intervals; beyond that lane 0 sorts), the keys lie in LDS and are
+ * handed round by v_readlane as in k_sdp.h wv_rank_u64; rank = keys below + equal keys before (equal keys: identical records, see above). */
+__global__ void __launch_bounds__(64) ssg_k_smem_sort_wave(ssg_intv_t *intv, const int32_t *n_intv, int cap, const int32_t *todo, const unsigned int *n_todo)
+{
+	__shared__ uint64_t sk[256];
+	const int lane = wv_lane();
+	const unsigned int nt = *n_todo;
+	for (unsigned int t = blockIdx.x; t < nt; t += gridDim.x) {
+		const long r = todo[t];
+		const int n = n_intv[r];
+		ssg_intv_t *const p = intv + r * cap;
+		if (n > 256) { SSG_LANE0(ssg_introsort(p, (long)n, ssg_intv_lt())); continue; }
+		ssg_intv_t rec[4];
+		ssg_wave_ldssync();
+		SSG_UNROLL for (int c = 0; c < 4; ++c) {
+			const int me = c * 64 + lane;
+			if (me < n) { rec[c] = p[me]; sk[me] = rec[c].info; } else { rec[c].x0 = rec[c].x1 = rec[c].x2 = 0; rec[c].info = ~0ull; }
+		}
+		ssg_wave_ldssync();
+		int rk[4] = { 0, 0, 0, 0 };
+		for (int j0 = 0; j0 < n; j0 += 64) {
+			const unsigned long long kl = j0 + lane < n ? sk[j0 + lane] : ~0ull;
+			SSG_UNROLL for (int u = 0; u < 64; ++u) {
+				const unsigned long long k = (unsigned long long)wv_get64((long long)kl, u);
+				SSG_UNROLL for (int c = 0; c < 4; ++c) rk[c] += (int)((k < rec[c].info) | ((k == rec[c].info) & (j0 + u < c * 64 + lane)));
+			}
+		}
+		SSG_UNROLL for (int c = 0; c < 4; ++c) if (c * 64 + lane < n && rk[c] != c * 64 + lane) p[rk[c]] = rec[c];
+	}
+}
+
 /* number of sampled occurrences of one interval (upstream mem_chain: step/count rule) */
 SSG_DEVFN int ssg_intv_nocc(const ssg_mem_opt_t &opt, uint64_t x2)
 {

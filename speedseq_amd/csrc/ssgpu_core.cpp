@@ -599,6 +599,19 @@ struct seed_stage_t {
  * private large capacity and copies their lists back; on return every n_intv[r] >= 0. */
 static int dev_class_counts(const int32_t *d_key, long n, int tA, int tB, int tC, unsigned int out[5]);
 static int sort_pairs_u64(uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, long n);
+/* upstream's ks_introsort(mem_intv) of every read's list (k_seed.h): a lane per read ranks the lists of up to 24 intervals, a wave per read the longer ones;
+ * SSG_SMEM_SORT_RANK=0: introsort by a lane per read for all (until r06V) */
+static int launch_smem_sort(int n_reads, ssg_intv_t *d_intv, const int32_t *d_n, int cap)
+{
+	if (env_int("SSG_SMEM_SORT_RANK", 1) == 0) { SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; }
+	dbuf<int32_t> d_todo((size_t)n_reads); dbuf<unsigned int> d_nt(1);
+	if (!d_todo.ok() || !d_nt.ok()) { ssg_err_msg = "device allocation failed: interval sort work list"; return SSG_ENOMEM; }
+	CHK(d_nt.zero());
+	SSG_LAUNCH(ssg_k_smem_sort_rank<24>, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap, d_todo.p, d_nt.p);
+	SSG_LAUNCH(ssg_k_smem_sort_wave, std::min(n_reads, 256 * 32), 64, 0, d_intv, d_n, cap, (const int32_t*)d_todo.p, (const unsigned int*)d_nt.p);
+	return rt_sync();   /* (before the work list goes back to the arena) */
+}
+
 static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_reads, const uint8_t *d_seq, const int64_t *d_off,
                     int max_len, int cap, ssg_intv_t *d_intv, int32_t *d_n, unsigned long long *n_extend = 0, int *need_cap = 0)
 {
@@ -615,12 +628,12 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 	}
 	CHK(rt_sync());
 	{ unsigned int cc[5]; CHK(dev_class_counts(d_n, n_reads, 0, 0, 0, cc));
-	  if (!cc[3]) { if (smem2) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; } }
+	  if (!cc[3]) { if (smem2) CHK(launch_smem_sort(n_reads, d_intv, d_n, cap)); return 0; } }
 	std::vector<int32_t> hn(n_reads);
 	CHK(rt_d2h(hn.data(), d_n, (size_t)n_reads * 4));
 	std::vector<int32_t> ovf;
 	for (int r = 0; r < n_reads; ++r) if (hn[r] < 0) ovf.push_back(r);
-	if (ovf.empty()) { if (smem2) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap); return 0; }
+	if (ovf.empty()) { if (smem2) CHK(launch_smem_sort(n_reads, d_intv, d_n, cap)); return 0; }
 	/* slow path: worst case is O(len^2) intervals in theory; len*8 has never been observed to overflow */
 	int bigcap = max_len * 8 + 64, no = (int)ovf.size();
 	dbuf<int32_t> d_ids(no), d_n2(no); dbuf<ssg_intv_t> d_big((size_t)no * bigcap);
@@ -645,7 +658,7 @@ static int run_smem(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 		CHK(rt_h2d(d_intv + (size_t)ovf[i] * cap, tmp.data(), (size_t)hn2[i] * sizeof(ssg_intv_t)));
 		CHK(rt_h2d(d_n + ovf[i], &hn2[i], 4));
 	}
-	if (smem2) SSG_LAUNCH(ssg_k_smem_sort, (n_reads + 63) / 64, 64, 0, n_reads, d_intv, d_n, cap);
+	if (smem2) CHK(launch_smem_sort(n_reads, d_intv, d_n, cap));
 	return 0;
 }
 
