@@ -254,14 +254,21 @@ SSG_DEVFN int ssg_intv_nocc(const ssg_mem_opt_t &opt, uint64_t x2)
 }
 
 /* per read: total #occurrences over its intervals (for the prefix sum that places seeds) */
-__global__ void ssg_k_sal_count(ssg_mem_opt_t opt, int n_reads, const ssg_intv_t *intv, const int32_t *n_intv, int cap, int32_t *n_seed)
+__global__ void ssg_k_sal_count(ssg_mem_opt_t opt, int n_reads, const ssg_intv_t *intv, const int32_t *n_intv, int cap, int32_t *n_seed, int32_t *pre /* optional [n_reads x cap]: occurrences of the read's earlier intervals */)
 {
 	long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
 	int n = n_intv[r], tot = 0;
 	const ssg_intv_t *p = intv + r * cap;
-	for (int i = 0; i < n; ++i) tot += ssg_intv_nocc(opt, p[i].x2);
+	for (int i = 0; i < n; ++i) { if (pre) pre[r * cap + i] = tot; tot += ssg_intv_nocc(opt, p[i].x2); }
 	n_seed[r] = tot;
+}
+
+/* read_of[first seed of read r] = r for the reads that have seeds (the array zeroed before): its running maximum is every seed's read */
+__global__ void ssg_k_sal_mark(int n_reads, const int64_t *seed_off, int32_t *read_of)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < n_reads && seed_off[r + 1] > seed_off[r]) read_of[seed_off[r]] = (int32_t)r;
 }
 
 /*
@@ -270,17 +277,26 @@ __global__ void ssg_k_sal_count(ssg_mem_opt_t opt, int n_reads, const ssg_intv_t
  * Invalid seeds (bns_intv2rid < 0) get len = -1 and are skipped by the chaining kernel.
  */
 __global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, const ssg_intv_t *intv, const int32_t *n_intv, int cap,
-                          const int64_t *seed_off, ssg_seed_t *seeds, int32_t *seed_rid)
+                          const int64_t *seed_off, ssg_seed_t *seeds, int32_t *seed_rid, const int32_t *pre /* from ssg_k_sal_count, or null */,
+                          const int32_t *read_of /* per seed: its read (ssg_k_sal_mark + a running maximum), or null: bisection of seed_off */)
 {	/* one lane per SEED (sampled occurrence): every lane does one independent <=31-step LF walk, so the
 	 * random 64-byte fetches of a wave are 64 independent chains and long intervals cost no tail */
 	const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= seed_off[n_reads]) return;
 	long lo = 0, hi = n_reads;                       /* last r with seed_off[r] <= g */
-	while (lo < hi) { long mid = (lo + hi + 1) >> 1; if (seed_off[mid] <= g) lo = mid; else hi = mid - 1; }
+	if (read_of) lo = read_of[g];                    /* (21 dependent loads for two million reads, by every lane) */
+	else while (lo < hi) { long mid = (lo + hi + 1) >> 1; if (seed_off[mid] <= g) lo = mid; else hi = mid - 1; }
 	const long r = lo;
 	const ssg_intv_t *p = intv + r * cap;
 	long k = g - seed_off[r];
 	int ii = 0, c;
+	if (pre) {   /* the seed's interval by bisection of the read's running counts: the walk along the list below is a dependent load per interval, and the 64 seeds
+	              * of a wave that lies inside a repeat-heavy read (lists of a hundred intervals, hundreds of occurrences each) all walk most of it */
+		const int32_t *pr = pre + r * cap;
+		int lo2 = 0, hi2 = n_intv[r] - 1;
+		while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if ((long)pr[mid] <= k) lo2 = mid; else hi2 = mid - 1; }
+		ii = lo2; k -= pr[ii];
+	} else
 	while ((c = ssg_intv_nocc(opt, p[ii].x2)) <= k) { k -= c; ++ii; }
 	const ssg_intv_t v = p[ii];
 	const uint64_t step = v.x2 > (uint64_t)opt.max_occ ? v.x2 / (uint64_t)opt.max_occ : 1;
@@ -290,7 +306,7 @@ __global__ void ssg_k_sal(ssg_index_view_t ix, ssg_mem_opt_t opt, int n_reads, c
 	s.len = s.score = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
 	s.next = -1;
 	seeds[g] = s;
-	seed_rid[g] = ssg_intv2rid(ix, s.rbeg, s.rbeg + s.len);
+	seed_rid[g] = ssg_intv2rid_1(ix, s.rbeg, s.rbeg + s.len);
 }
 /* HBM copy of the suffix array sampled every `new_intv` rows instead of the file's sa_intv (upstream's .sa keeps every 32nd row; a seed
  * located through a denser table walks ~new_intv LF steps instead of ~32).  Each sampled row of the file starts a walk: LF(row with

@@ -372,6 +372,18 @@ SSG_DEVFN int ssg_intv2rid(const ssg_index_view_t &ix, int64_t rb, int64_t re)
 	int rid_e = rb < re ? ssg_pos2rid(ix, ssg_depos(ix, re - 1, &is_rev)) : rid_b;
 	return rid_b == rid_e ? rid_b : -1;
 }
+/* the same with one bisection: the contig of the first base, then whether the last base lies in it too (bns_pos2rid of a position below l_pac is the contig that
+ * holds it, so rid_e == rid_b exactly when it does) */
+SSG_DEVFN int ssg_intv2rid_1(const ssg_index_view_t &ix, int64_t rb, int64_t re)
+{
+	int is_rev;
+	if (rb < ix.l_pac && re > ix.l_pac) return -2;
+	const int rid_b = ssg_pos2rid(ix, ssg_depos(ix, rb, &is_rev));
+	if (rb >= re || rid_b < 0) return rid_b;
+	const int64_t pe = ssg_depos(ix, re - 1, &is_rev);
+	const int64_t lo = ix.ctg_off[rid_b], hi = rid_b == ix.n_ctg - 1 ? ix.l_pac : ix.ctg_off[rid_b + 1];
+	return pe >= lo && pe < hi ? rid_b : -1;
+}
 SSG_DEVFN int ssg_score(const ssg_mem_opt_t &o, int t, int q) { return o.mat[t * 5 + q]; }
 
 /* ---------------- klib-compatible introsort over an index permutation ----------------

@@ -728,6 +728,26 @@ static int dev_exclusive_scan(const int32_t *d_in, int64_t *d_out, long n, int64
 #endif
 }
 
+/* out[i] = max(in[0..i]) */
+#ifndef SSG_EMU
+struct ssg_max_i32 { __device__ int32_t operator()(const int32_t &a, const int32_t &b) const { return a > b ? a : b; } };
+#endif
+static int dev_scan_max_i32(const int32_t *d_in, int32_t *d_out, long n)
+{
+	if (n <= 0) return 0;
+#ifdef SSG_EMU
+	int32_t m = d_in[0]; for (long i = 0; i < n; ++i) { m = d_in[i] > m ? d_in[i] : m; d_out[i] = m; }
+	return 0;
+#else
+	size_t tmp_bytes = 0;
+	if (rocprim::inclusive_scan(nullptr, tmp_bytes, d_in, d_out, (size_t)n, ssg_max_i32()) != hipSuccess) { ssg_err_msg = "rocprim inclusive_scan (size query) failed"; return SSG_EHIP; }
+	dbuf<uint8_t> tmp(tmp_bytes + 16);
+	CHKA(tmp);
+	if (rocprim::inclusive_scan(tmp.p, tmp_bytes, d_in, d_out, (size_t)n, ssg_max_i32(), ssg_stream) != hipSuccess) { ssg_err_msg = "rocprim inclusive_scan failed"; return SSG_EHIP; }
+	return 0;
+#endif
+}
+
 /* order[] = indices 0..n-1 by descending key (heaviest-first work lists), on the device */
 static int dev_order_desc(const int32_t *d_key, int32_t *d_order, long n)
 {
@@ -802,7 +822,9 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	if (seed_lock.owns_lock()) { CHK(rt_sync()); seed_lock.unlock(); }
 	STAGE("smem");
 	const int block = 256;
-	SSG_LAUNCH(ssg_k_sal_count, (n_reads + block - 1) / block, block, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);
+	dbuf<int32_t> d_pre;   /* per interval: occurrences of the read's earlier ones (ssg_k_sal finds a seed's interval by bisection); SSG_SAL_PREFIX=0: the walk along the list */
+	if (env_int("SSG_SAL_PREFIX", 1) && !d_pre.alloc((size_t)n_reads * cap)) { ssg_err_msg = "device allocation failed: d_pre"; return SSG_ENOMEM; }
+	SSG_LAUNCH(ssg_k_sal_count, (n_reads + block - 1) / block, block, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p, d_pre.p);
 	CHK(rt_sync());
 	STAGE("sal_count");
 	int64_t tot = 0;
@@ -817,7 +839,14 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 	CHK(d_cells.zero());
 	{
 		long g = (long)tot;
-		SSG_LAUNCH(ssg_k_sal, (g + block - 1) / block, block, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p);
+		/* every seed's read by a running maximum over marks at the reads' first seeds (d_order / d_kept are free until the chaining stage); SSG_SAL_READ_OF=0: bisection of seed_off by every lane */
+		const bool rof = g > 0 && env_int("SSG_SAL_READ_OF", 1) != 0;
+		if (rof) {
+			CHK(rt_memset(d_order.p, 0, (size_t)g * 4));
+			SSG_LAUNCH(ssg_k_sal_mark, (n_reads + block - 1) / block, block, 0, n_reads, o.seed_off.p, d_order.p);
+			CHK(dev_scan_max_i32(d_order.p, d_kept.p, g));
+		}
+		SSG_LAUNCH(ssg_k_sal, (g + block - 1) / block, block, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, (const int32_t*)d_pre.p, rof ? (const int32_t*)d_kept.p : (const int32_t*)0);
 	}
 	STAGE("sal");
 	/* heaviest-first work order (seed count): the per-read cost of chaining / extension is heavy-tailed */
@@ -1055,12 +1084,12 @@ int ssg_seeds_batch(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_read
 		if (!d_intv.alloc((size_t)n_reads * cap)) { ssg_err_msg = "device allocation failed: d_intv"; return SSG_ENOMEM; }
 		CHK(run_smem(idx, opt, n_reads, d_seq.p, d_off.p, max_len, cap, d_intv.p, d_nintv.p, 0, &need));
 		if (need > cap) { cap = (need + 31) / 32 * 32; continue; }
-		SSG_LAUNCH(ssg_k_sal_count, (n_reads + 255) / 256, 256, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p);
+		SSG_LAUNCH(ssg_k_sal_count, (n_reads + 255) / 256, 256, 0, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_nseed.p, (int32_t*)0);
 		int64_t tot = 0;
 		CHK(dev_exclusive_scan(d_nseed.p, d_soff.p, n_reads, &tot));
 		dbuf<ssg_seed_t> d_seeds((size_t)tot + 1); dbuf<int32_t> d_srid((size_t)tot + 1);
 		CHKA(d_seeds); CHKA(d_srid);
-		if (tot > 0) SSG_LAUNCH(ssg_k_sal, (tot + 255) / 256, 256, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_soff.p, d_seeds.p, d_srid.p);
+		if (tot > 0) SSG_LAUNCH(ssg_k_sal, (tot + 255) / 256, 256, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, d_soff.p, d_seeds.p, d_srid.p, (const int32_t*)0, (const int32_t*)0);
 		CHK(rt_sync());
 		CHK(d_soff.down(seed_off, (size_t)n_reads + 1));
 		*seeds = (ssg_seed_t*)malloc(sizeof(ssg_seed_t) * (size_t)(tot + 1)); *rids = (int32_t*)malloc(4 * (size_t)(tot + 1));
