@@ -247,15 +247,20 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 		uint8_t *rseq = span <= SSG_TWIN_LDS ? tlds_w : tg;
 		if (xj.flag) { myerr = 1; continue; }
 		int fetched = 0;   /* the 1-byte-per-base window is only needed when a later seed of the chain is extended here */
+		/* chains of 2..64 seeds (a read of this kernel has hundreds): lane t keeps seed t, its rank in upstream's order (score, index) and its `srt[] = 0' mark in
+		 * registers; the seed of a rank comes over by v_readlane and the walk along the later seeds is one test by their lanes -- through srt[] -> chain_seeds[] ->
+		 * seeds[] in global memory every seed after the first cost three dependent round trips, and every step of that walk three more */
+		const bool in_regs = c.n >= 2 && c.n <= 64;
+		ssg_seed_t ms; ms.rbeg = 0; ms.qbeg = ms.len = ms.score = 0; ms.next = -1;
+		int my_rnk = -1; bool my_alive = false;
 		if (c.n == 1) { /* nothing to order; the only seed is in the record */ }
-		else if (c.n <= 64) { /* seeds by (score, index): distinct keys, rank = number of smaller keys, one lane per seed */
+		else if (in_regs) { /* seeds by (score, index): distinct keys, rank = number of smaller keys, one lane per seed */
 			const int t = wv_lane();
-			const uint64_t key = t < c.n ? ((uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t) : ~0ull;
+			if (t < c.n) ms = seeds[cs[t]];
+			const uint64_t key = t < c.n ? ((uint64_t)ms.score << 32 | (uint64_t)t) : ~0ull;
 			int rnk = 0;
 			for (int j = 0; j < c.n; ++j) rnk += (uint64_t)wv_get64((long long)key, j) < key;
-			ssg_wave_memsync();
-			if (t < c.n) srt[rnk] = key;
-			ssg_wave_memsync();
+			if (t < c.n) { my_rnk = rnk; my_alive = true; }
 		} else {
 			SSG_LANE0(for (int t = 0; t < c.n; ++t) srt[t] = (uint64_t)seeds[cs[t]].score << 32 | (uint64_t)t;
 			          ssg_introsort(srt, (long)c.n, ssg_u64_lt()));
@@ -263,7 +268,10 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 		SSG_PH(0);
 		for (k = c.n - 1; k >= 0; --k) {
 			ssg_seed_t s;
+			int own = 0;   /* the lane that holds the seed of rank k */
+			if (in_regs) own = (int)__builtin_ctzll(wv_ballot(my_rnk == k) | 1ull << 63);
 			if (k == c.n - 1) { s.rbeg = xj.rbeg; s.qbeg = xj.qbeg; s.len = s.score = xj.len; s.next = -1; }   /* the best seed travels in the record */
+			else if (in_regs) { s.rbeg = (int64_t)wv_get64((long long)ms.rbeg, own); s.qbeg = wv_get(ms.qbeg, own); s.len = wv_get(ms.len, own); s.score = wv_get(ms.score, own); s.next = -1; }
 			else s = seeds[cs[(uint32_t)srt[k]]];
 			{	/* is the seed contained in an earlier region?  Compact keys of the regions (ck[]), SSG_C2A_SCAN x 64 regions per round
 				 * trip; the scalar loop's first hit decides */
@@ -317,7 +325,13 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				}
 				i = hit;
 			}
-			if (i < av_n) {
+			if (i < av_n && in_regs) {   /* upstream's walk over the seeds of higher rank leaves early at the first one that overlaps s off its diagonal: only whether one does matters */
+				bool brk = false;
+				if (my_rnk > k && my_alive && !(ms.len < s.len * .95))
+					brk = (s.qbeg <= ms.qbeg && s.qbeg + s.len - ms.qbeg >= s.len >> 2 && ms.qbeg - s.qbeg != ms.rbeg - s.rbeg)
+					   || (ms.qbeg <= s.qbeg && ms.qbeg + ms.len - s.qbeg >= s.len >> 2 && s.qbeg - ms.qbeg != s.rbeg - ms.rbeg);
+				if (!wv_ballot(brk)) { if (wv_lane() == own) my_alive = false; SSG_PH(1); continue; }
+			} else if (i < av_n) {
 				for (i = k + 1; i < c.n; ++i) {
 					if (srt[i] == 0) continue;
 					const ssg_seed_t t = seeds[cs[(uint32_t)srt[i]]];
@@ -374,9 +388,15 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 				if (x.gscore <= 0 || x.gscore <= a.score - opt.pen_clip3) { a.qe = qe + x.qle; a.re = rmax[0] + re + x.tle; a.truesc += a.score - sc0; }
 				else { a.qe = l_query; a.re = rmax[0] + re + x.gtle; a.truesc += x.gscore - sc0; }
 			} else { a.qe = l_query; a.re = s.rbeg + s.len; }
-			for (i = 0, a.seedcov = 0; i < c.n; ++i) {
-				const ssg_seed_t t = c.n == 1 ? s : seeds[cs[i]];
-				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) a.seedcov += t.len;
+			if (c.n == 1) a.seedcov = s.qbeg >= a.qb && s.qbeg + s.len <= a.qe && s.rbeg >= a.rb && s.rbeg + s.len <= a.re ? s.len : 0;
+			else if (in_regs) { const int cov = my_rnk >= 0 && ms.qbeg >= a.qb && ms.qbeg + ms.len <= a.qe && ms.rbeg >= a.rb && ms.rbeg + ms.len <= a.re ? ms.len : 0; a.seedcov = wv_sum(cov); }
+			else {   /* a lane per seed (the wave walking the chain's seeds together paid two dependent round trips a seed: index, then seed) */
+				int cov = 0;
+				for (int i0 = 0; i0 < c.n; i0 += 64) {
+					const int i2 = i0 + wv_lane();
+					if (i2 < c.n) { const ssg_seed_t t = seeds[cs[i2]]; if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len; }
+				}
+				a.seedcov = wv_sum(cov);
 			}
 			a.w = aw[0] > aw[1] ? aw[0] : aw[1];
 			a.seedlen0 = s.len;
