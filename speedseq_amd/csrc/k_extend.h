@@ -24,7 +24,10 @@
 #define SSG_TWIN_GLB 32768
 #define SSG_WAVES_PER_WG 4
 /* register budgets of the wave-per-item kernels are set by measurement (launch bounds below) */
-#define SSG_C2A_LKEYS 144   /* 144 x 24 bytes = sizeof(ssg_sdp_small_t) */
+#ifndef SSG_C2A_LKEYS
+#define SSG_C2A_LKEYS 448   /* containment keys of a read's first regions in LDS, 24 bytes each: 10.5 KB a wave, 79 KB a workgroup with the rest -- two workgroups a CU, what 256 VGPRs allow anyway
+                             * (144 until r06c2, laid over the re-sort's key area; repeat-heavy reads have hundreds of regions near one another and fetched the keys beyond from the HBM slab: a round trip per 64 regions and seed) */
+#endif
 #ifndef SSG_C2A_SCAN
 #define SSG_C2A_SCAN 1   /* chunks of 64 region keys fetched per round trip of the containment scan (2 trips the backend's odd-aligned 64-bit reload bug at 168 VGPRs) */
 #endif
@@ -208,7 +211,7 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
                                 uint8_t *tlds_w, uint8_t *tg, int32_t *err, unsigned long long *cells, unsigned long long *ph,
                                 ssg_sdp_small_t *sdp_lds, ssg_sdp_big_t *sdp_big, ssg_alnreg_t *sdp_tmp,
                                 const int64_t *chain_off, const ssg_xjob_t *xjobs, const ssg_xres_t *xres_l, const ssg_xres_t *xres_r, uint8_t *sdp_fixed,
-                                uint16_t *hq /* LDS, SSG_SDP_BIG entries: (rb >> 10) of the read's regions so far */)
+                                uint16_t *hq /* LDS, SSG_SDP_BIG entries: (rb >> 10) of the read's regions so far */, uint64_t *lk /* LDS, 3 x SSG_C2A_LKEYS words */)
 {
 	const uint8_t *query = seq + read_off[r];
 	const int l_query = (int)(read_off[r+1] - read_off[r]);
@@ -221,8 +224,8 @@ SSG_DEVFN void wv_chain2aln_read(const ssg_index_view_t &ix, const ssg_mem_opt_t
 	unsigned long long nc = 0;
 	const int nch = n_chain[r];
 	ssg_sdp_key_t *const ck = sdp_big->key;   /* (rb, re, qb, qe, w -> .score, seedlen0 -> .rid) of av[]: what the containment test reads */
-	/* the first SSG_C2A_LKEYS of them also in LDS (the re-sort's key area is idle until the read's last chain): 8 + 8 + 8 bytes */
-	int64_t *const lk_rb = (int64_t*)sdp_lds, *const lk_re = lk_rb + SSG_C2A_LKEYS; uint64_t *const lk_m = (uint64_t*)(lk_re + SSG_C2A_LKEYS);
+	/* the first SSG_C2A_LKEYS of them also in LDS: 8 + 8 + 8 bytes */
+	int64_t *const lk_rb = (int64_t*)lk, *const lk_re = lk_rb + SSG_C2A_LKEYS; uint64_t *const lk_m = (uint64_t*)(lk_re + SSG_C2A_LKEYS);
 	unsigned long long t0 = 0, t1;
 #define SSG_PH(x) do { if (SSG_TUNING && ph) { t1 = ssg_clock(); ph[x] += t1 - t0; t0 = t1; } } while (0)
 	if (SSG_TUNING && ph) { t0 = ssg_clock(); }
@@ -571,6 +574,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 	__shared__ uint8_t tlds[SSG_WAVES_PER_WG][SSG_TWIN_LDS];
 	__shared__ ssg_sdp_small_t sdp[SSG_WAVES_PER_WG];
 	__shared__ uint16_t hq_[SSG_WAVES_PER_WG][SSG_SDP_BIG];
+	__shared__ uint64_t lk_[SSG_WAVES_PER_WG][3 * SSG_C2A_LKEYS];
 	const int wslot = (int)(threadIdx.x >> 6);
 	const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + wslot;
 	unsigned long long nc = 0, ph[8] = {0,0,0,0,0,0,0,0};
@@ -579,7 +583,7 @@ __global__ void __launch_bounds__(256, SSG_C2A_WAVES_PER_SIMD) ssg_k_chain2aln(s
 		const long k = wv_queue_pop(queue);
 		if (k >= (todo_list ? (long)*n_todo : (long)n_reads)) break;
 		wv_chain2aln_read<WIDE>(ix, opt, todo_list ? todo_list[k] : work_order ? work_order[k] : k, seq, read_off, seed_off, seeds, chains, order, chain_seeds, n_chain, srt_all, regs, n_reg,
-		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r, sdp_fixed, hq_[wslot]);
+		                  tlds[wslot], tglb + wave0 * (long)SSG_TWIN_GLB, err, &nc, SSG_TUNING && tune ? ph : 0, &sdp[wslot], sdpbig + wave0, bcopy + wave0 * (long)SSG_SDP_BIG, chain_off, xjobs, xres_l, xres_r, sdp_fixed, hq_[wslot], lk_[wslot]);
 	}
 	if (wv_lane() == 0 && cells) atomicAdd(cells, nc);
 	if (SSG_TUNING && tune && wv_lane() == 0) { /* tuning: window+seed sort, containment scan, extension, re-sort, wave total; #chains, #extended seeds, #regions */
