@@ -256,6 +256,14 @@ def test_gpu_smem_kernel_variants(gpu_lib, oracle, monkeypatch):
     monkeypatch.delenv("SSG_SMEM_KERNEL")
     monkeypatch.setenv("SSG_SA_INTV", "32")   # the file's own suffix-array density
     assert common.check_align1(gpu_lib, oracle, 1500, seed=33) > 1500
+    monkeypatch.delenv("SSG_SA_INTV")
+    # the forms the round's last kernels replaced stay behind switches: introsort by a lane per read; the locate stage's walks instead of running counts / running maximum
+    monkeypatch.setenv("SSG_SMEM_SORT_RANK", "0")
+    common.check_smem(gpu_lib, oracle, 1500, seed=35)
+    monkeypatch.delenv("SSG_SMEM_SORT_RANK")
+    monkeypatch.setenv("SSG_SAL_PREFIX", "0")
+    monkeypatch.setenv("SSG_SAL_READ_OF", "0")
+    assert common.check_align1(gpu_lib, oracle, 1500, seed=36) > 1500
 
 
 @pytest.mark.parametrize("read_len", [150, 250])

@@ -239,12 +239,22 @@ def test_emu_smem_table_of_short_pattern_intervals(emu_lib, oracle, repeat_prefi
     common.check_smem(emu_lib, oracle, 60, seed=51)
 
 
-def test_emu_smem_kernel_variants(emu_lib, oracle, monkeypatch):
+def test_emu_smem_kernel_variants(emu_lib, oracle, repeat_prefix, monkeypatch):
     monkeypatch.setenv("SSG_SMEM_KERNEL", "lane")     # the nested-loop form (the product kernels' fall-back), on the same reads
     common.check_smem(emu_lib, oracle, 150, seed=31)
     monkeypatch.delenv("SSG_SMEM_KERNEL")
     monkeypatch.setenv("SSG_SA_INTV", "32")
     assert common.check_align1(emu_lib, oracle, 150, seed=33) > 150
+    monkeypatch.delenv("SSG_SA_INTV")
+    # the forms the round's last kernels replaced stay behind switches: introsort by a lane per read; the locate stage's walks instead of running counts / running maximum
+    monkeypatch.setenv("SSG_SMEM_SORT_RANK", "0")
+    common.check_smem(emu_lib, oracle, 60, seed=35)
+    common.check_smem(emu_lib, oracle, 8, seed=43, prefix=repeat_prefix, cap=512)
+    monkeypatch.delenv("SSG_SMEM_SORT_RANK")
+    common.check_smem(emu_lib, oracle, 8, seed=43, prefix=repeat_prefix, cap=512)   # lists beyond 24 intervals: the wave form of the sort
+    monkeypatch.setenv("SSG_SAL_PREFIX", "0")
+    monkeypatch.setenv("SSG_SAL_READ_OF", "0")
+    assert common.check_align1(emu_lib, oracle, 150, seed=36) > 150
 
 
 @pytest.mark.parametrize("read_len", [150, 250])
