@@ -209,7 +209,7 @@ SSG_DEVFN unsigned long long s2_wave_read(const ssg_index_view_t &ix, const ssg_
 /* ---- table of the intervals of all short patterns (ssg_index.ktab) ----
  * The bidirectional interval of a pattern does not depend on the order in which the pattern was extended to, so the intervals of ALL patterns
  * of 1..K bases can be tabulated once per index: 16 bytes each (x0, x1, x2 in 40 bits), level j (4^j entries, little-endian base-4 pattern
- * code: first base least significant) after the levels below it -- 1.4 GB for K = 13 on a human-size index, built in ~20 ms.  A bwt_extend
+ * code: first base least significant) after the levels below it -- 1.4 GB for K = 13 on a human-size index (built in ~20 ms), 22.9 GB for the K = 15 of ssg_seed.cpp.  A bwt_extend
  * whose RESULT pattern has at most K bases then is one 16-byte load at an address that depends only on the read, instead of two rank blocks
  * (2.5 loads each) and the popcounts; roughly four extensions in ten of a 150-base read are that short. */
 SSG_DEVFN long s2_ktab_off(int j) { return (long)(((1ull << (2 * j)) - 4ull) / 3ull); }   /* entries of the levels below j */

@@ -72,14 +72,16 @@ extern "C" int ssg_seed_smem2(const ssg_index *idx, const ssg_mem_opt_t *opt, in
 	return rt_sync();
 }
 
-/* table of the intervals of all patterns up to K bases (k_smem2.h): K = SSG_KTAB_K; default 15 on a human-size index (text of 4^16 symbols or more: 22.9 GB of the
- * 288, 358 M bwt_extend calls, < 50 ms; measured at 1 M pairs / 3.1 Gbp, profiles/r06T_ktab_pairwave_sa_ab.json: the lane kernel 57.4 ms at 12, 56.0 at 13, 55.2 at 14,
- * 52.6 at 15), else 13 capped at log4(text length) - 2; never more than 15 (s2_code packs 15 bases) nor than log4(text length) + 2 (a table of 16 times more patterns
- * than the text has positions is empty space); 0 = none.  Every constructor of an index ends with this. */
+/* table of the intervals of all patterns up to K bases (k_smem2.h): K = SSG_KTAB_K, default 13 capped at log4(text length) - 2 (1.4 GB for a human-size index: 89 M
+ * bwt_extend calls, ~20 ms); never more than 15 (s2_code packs 15 bases; 22.9 GB, < 50 ms) nor than log4(text length) + 2; 0 = none.  Every constructor of an index
+ * ends with this.  Why not 15: with the device to itself the lane kernel takes 57.4 ms at 12, 56.0 at 13, 55.2 at 14, 52.6 at 15 (1 M pairs / 3.1 Gbp,
+ * profiles/r06T_ktab_pairwave_sa_ab.json) -- but inside the script's pipeline, where two calls of `bwa mem' and two more processes share the memory system, the same
+ * kernel takes 62 ms a launch at 13 and 100 at 15, and 40 M pairs go through at 1.57 against 1.42 M pairs/s (profiles/r06j2_soak_40M_ktab13.json, r06i2_..._ktab15.json,
+ * one box): the small table's upper levels stay in the 256-MB cache, the large one's entries never do. */
 extern "C" int ssg_index_build_ktab(ssg_index *ix)
 {
 	int lg = 0; while ((ix->v.seq_len >> (2 * (lg + 1))) != 0) ++lg;    /* floor(log4(seq_len)) */
-	int K = env_int("SSG_KTAB_K", lg >= 16 ? 15 : std::min(13, lg - 2));
+	int K = env_int("SSG_KTAB_K", std::min(13, lg - 2));
 	K = std::min(K, std::min(15, lg + 2));
 	rt_free(ix->ktab); ix->ktab = 0; ix->ktab_k = 0;
 	if (K < 2 || ix->v.seq_len >= (1ull << 40)) return 0;
