@@ -847,6 +847,7 @@ static int run_align1(const ssg_index_t *idx, const ssg_mem_opt_t *opt, int n_re
 			CHK(dev_scan_max_i32(d_order.p, d_kept.p, g));
 		}
 		SSG_LAUNCH(ssg_k_sal, (g + block - 1) / block, block, 0, idx->v, *opt, n_reads, d_intv.p, d_nintv.p, cap, o.seed_off.p, d_seeds.p, d_srid.p, (const int32_t*)d_pre.p, rof ? (const int32_t*)d_kept.p : (const int32_t*)0);
+		{ dbuf<int32_t> done; done.swap(d_pre); }   /* 1.5 GB per million pairs back to the lane's arena (whatever takes it next is queued behind the kernel above) */
 	}
 	STAGE("sal");
 	/* heaviest-first work order (seed count): the per-read cost of chaining / extension is heavy-tailed */
